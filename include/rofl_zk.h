@@ -1,0 +1,140 @@
+/*
+ * librofl_zk.so -- MI355X (gfx950) drop-in C ABI for rofl_crypto's ZK norm-bound hot path.
+ *
+ * Each entry point names the reference interface it replaces (paths relative to the reference repo,
+ * rofl_crypto/src/...).  Data formats at the boundary:
+ *   scalars     : 32 bytes little-endian, canonical (curve25519_dalek_ng::scalar::Scalar::to_bytes)
+ *   points      : 32 bytes compressed Ristretto (CompressedRistretto)
+ *   range proofs: bulletproofs 4.0.0 RangeProof::to_bytes layout, 32*(9 + 2*lg(n*m)) bytes per chunk
+ *   values      : IEEE f32
+ * (fp_bits, fp_frac) are the reference's compile-time cargo features fp{8,16,32,64} / frac{0..12}
+ * (fp.rs:8-139), taken at run time here (mirrors ModelConfig.fp_bits/fp_frac, flservice.proto:54-55).
+ *
+ * All buffers are caller-owned host memory unless the name ends in _dev (HIP device pointers on the
+ * library's current device).  The library never retains caller pointers after return.
+ * No C++ exceptions cross this boundary.  Calls are serialised per device context (thread-safe).
+ *
+ * Return codes: 0 ok; 1 WrongNumBlindingFactors; 2 ValueOutOfRangeError; 3 InvalidBitsize;
+ * 4 InvalidAggregation; 5 FormatError; 6 InvalidGeneratorsLength; 7 NormOutOfRangeError;
+ * 8 OverflowError; 9 SumError; 10 non-finite input (reference panics); 11 bad parameter
+ * (reference panics); 12 nonce stream too short; >= 100 HIP runtime error (100 + hipError_t).
+ * A failed verification is NOT an error: it is reported through *ok_out = 0 with return code 0
+ * (range_proof_vec/mod.rs:210-215 maps VerificationError to Ok(false)).
+ */
+#ifndef ROFL_ZK_H
+#define ROFL_ZK_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    ROFL_OK = 0, ROFL_WRONG_NUM_BLINDING = 1, ROFL_VALUE_OUT_OF_RANGE = 2, ROFL_INVALID_BITSIZE = 3,
+    ROFL_INVALID_AGGREGATION = 4, ROFL_FORMAT_ERROR = 5, ROFL_INVALID_GENS_LENGTH = 6,
+    ROFL_NORM_OUT_OF_RANGE = 7, ROFL_OVERFLOW = 8, ROFL_SUM_ERROR = 9, ROFL_NON_FINITE = 10,
+    ROFL_BAD_PARAM = 11, ROFL_NONCE_SHORT = 12, ROFL_HIP_ERROR = 100
+};
+
+/* Prover randomness.  The reference draws every nonce from rand::thread_rng() inside
+ * bulletproofs::RangeProof::prove_multiple; for reproducible (bit-exact) proofs the stream is an
+ * explicit input here.
+ *   mode 0: `stream` holds 64-byte wide scalars in the reference draw order
+ *           (per chunk c, offset c*m*(2n+4): per party a_blinding, s_blinding, s_L[0..n), s_R[0..n);
+ *            then per party t_1_blinding, t_2_blinding), each reduced like Scalar::from_bytes_mod_order_wide.
+ *   mode 1: scalar k = wide-reduce(SHAKE256("rofl-zk/nonce/v1" || seed[32] || u64le(k))[0..64]). */
+typedef struct {
+    int mode;
+    const uint8_t *stream;
+    size_t stream_scalars;
+    uint8_t seed[32];
+} rofl_nonce_t;
+
+/* ---- context / device ---- */
+int rofl_set_device(int device);                       /* select the HIP device used by later calls */
+int rofl_last_error(char *buf, size_t len);            /* human-readable text of the last failure */
+/* BulletproofGens::new(n_bits, m) (generators.rs; re-run by the reference on every helper call,
+ * range_proof_vec/mod.rs:126,201) -- built once on the device and cached per (n_bits, m). */
+int rofl_bp_gens_prepare(size_t n_bits, size_t m);
+/* copy the cached generators back, compressed, party-major: G_out/H_out n_bits*m*32 bytes each */
+int rofl_bp_gens_export(size_t n_bits, size_t m, uint8_t *G_out, uint8_t *H_out);
+
+/* ---- sizes ---- */
+size_t rofl_next_pow2(size_t v);                       /* range_proof_vec/mod.rs:225-235 */
+size_t rofl_rangeproof_chunks(size_t d, size_t n_partition);       /* number of proofs produced */
+size_t rofl_rangeproof_size(size_t n_bits, size_t d, size_t n_partition); /* bytes per proof */
+size_t rofl_nonces_per_chunk(size_t n_bits, size_t m);
+
+/* ---- range_proof_vec (range_proof_vec/mod.rs) ---- */
+/* create_rangeproof(&Vec<f32>, &Vec<Scalar>, prove_range, n_partition) :16-102 */
+int rofl_create_rangeproof(const float *values, size_t d, const uint8_t *blindings32, size_t d_blindings,
+                           size_t prove_range, size_t n_partition, unsigned fp_bits, unsigned fp_frac,
+                           const rofl_nonce_t *nonce, uint8_t *proofs_out, size_t *proof_len_out,
+                           size_t *n_proofs_out, uint8_t *commits_out /* d*32 */);
+/* verify_rangeproof(&Vec<RangeProof>, &Vec<RistrettoPoint>, prove_range) :149-191.
+ * verifier_seed[32] derives the batching scalar c that upstream draws from thread_rng. */
+int rofl_verify_rangeproof(const uint8_t *proofs, size_t proof_len, size_t n_proofs,
+                           const uint8_t *commits32, size_t d, size_t prove_range, unsigned fp_bits,
+                           unsigned fp_frac, const uint8_t verifier_seed[32], int *ok_out);
+/* server-side batch (server.rs:656-687 hands one client per pool thread): n_clients independent
+ * (proofs, commits) sets with identical (d, prove_range, n_proofs); ok_out[n_clients] */
+int rofl_verify_rangeproof_batch(size_t n_clients, const uint8_t *const *proofs, size_t proof_len,
+                                 size_t n_proofs, const uint8_t *const *commits32, size_t d,
+                                 size_t prove_range, unsigned fp_bits, unsigned fp_frac,
+                                 const uint8_t verifier_seed[32], int *ok_out);
+/* clip_f32_to_range_vec :104-111 */
+int rofl_clip_f32(const float *in, size_t d, size_t prove_range, unsigned fp_bits, unsigned fp_frac, float *out);
+
+/* ---- l2_range_proof_vec (l2_range_proof_vec/mod.rs) ---- */
+/* create_rangeproof_l2 :15-140 */
+int rofl_create_rangeproof_l2(const float *values, size_t d, const uint8_t *blindings32, size_t d_blindings,
+                              size_t prove_range, size_t n_partition, unsigned fp_bits, unsigned fp_frac,
+                              const rofl_nonce_t *nonce, uint8_t *proof_out, size_t *proof_len_out,
+                              uint8_t commit_out[32]);
+/* verify_rangeproof_l2 :185-253 */
+int rofl_verify_rangeproof_l2(const uint8_t *proof, size_t proof_len, const uint8_t commit[32],
+                              size_t prove_range, unsigned fp_bits, unsigned fp_frac,
+                              const uint8_t verifier_seed[32], int *ok_out);
+
+/* ---- pedersen_ops (pedersen_ops.rs) ---- */
+int rofl_commit_vec(const uint8_t *values32, const uint8_t *blindings32 /* NULL: commit_no_blinding_vec */,
+                    size_t d, uint8_t *out32);                                   /* :9-25 */
+int rofl_add_points_vec(const uint8_t *a32, const uint8_t *b32, size_t d, uint8_t *out32);   /* :56-59 */
+int rofl_shift_points(const uint8_t *a32, size_t d, const uint8_t offset32[32], uint8_t *out32); /* :103-108 */
+int rofl_f32_to_scalar_vec(const float *in, size_t d, unsigned fp_bits, unsigned fp_frac, uint8_t *out32); /* conversion32.rs:11-22 */
+int rofl_scalar_to_f32_vec(const uint8_t *in32, size_t d, unsigned fp_bits, unsigned fp_frac, float *out); /* conversion32.rs:24-39 */
+int rofl_get_clip_bounds(size_t range, unsigned fp_bits, unsigned fp_frac, float *min_out, float *max_out); /* conversion32.rs:56-60 */
+int rofl_get_l2_clip_bounds(size_t range, unsigned fp_bits, unsigned fp_frac, float *out);  /* conversion32.rs:62-64 */
+
+/* ---- measurement hooks (bench.py) ---- */
+/* Time of the kernels of the last create / verify call, from HIP events on the library's stream. */
+typedef struct {
+    double total_ms;          /* first launch -> last completion, device clock */
+    double msm_accumulate_ms; /* sum over launches of k_msm_accumulate */
+    uint64_t msm_accumulate_launches;
+    uint64_t msm_terms;       /* non-trivial (scalar, point) terms fed to Pippenger */
+    double fold_ms;           /* sum over launches of k_fold_gens */
+    uint64_t fold_launches;
+    uint64_t fold_point_reads;   /* niels points read by k_fold_gens (96 B each) */
+    double host_ms;           /* host-side (transcript, Horner, fixed-base) time */
+} rofl_timing_t;
+int rofl_last_timing(rofl_timing_t *out);
+int rofl_set_timing(int enabled);
+/* field-multiply micro-benchmark: returns GF(2^255-19) multiplications per second on the device */
+int rofl_bench_femul(unsigned iters, double *fe_mul_per_sec_out);
+
+/* ---- host-side self-test hooks (same source as the device math, compiled for the CPU) ---- */
+int rofl_dbg_host_fe_mul(const uint8_t a[32], const uint8_t b[32], uint8_t out[32]);
+int rofl_dbg_host_fe_ops(const uint8_t a[32], const uint8_t b[32], uint8_t out_add[32], uint8_t out_sub[32], uint8_t out_sq[32], uint8_t out_inv[32]);
+int rofl_dbg_host_sc_mul(const uint8_t a[32], const uint8_t b[32], uint8_t out[32]);
+int rofl_dbg_host_sc_wide(const uint8_t in[64], uint8_t out[32]);
+int rofl_dbg_host_from_uniform(const uint8_t in[64], uint8_t out[32]);
+int rofl_dbg_host_scalarmult_base(const uint8_t k[32], int use_blinding_base, uint8_t out[32]);
+int rofl_dbg_host_decode_encode(const uint8_t in[32], uint8_t out[32]);   /* returns 5 if invalid */
+int rofl_dbg_host_merlin(const uint8_t *label, size_t label_len, const uint8_t *msg, size_t msg_len, uint8_t out[64]);
+int rofl_dbg_host_nonce(const uint8_t seed[32], uint64_t idx, uint8_t out[32]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

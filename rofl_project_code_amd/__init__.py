@@ -1,0 +1,12 @@
+"""MI355X-native drop-in for rofl_crypto's ZK norm-bound hot path.
+
+Host-side mirror of the reference interface (same module names, argument meaning and error
+behaviour as rofl_crypto::{range_proof_vec, l2_range_proof_vec, pedersen_ops, conversion32}),
+bound to the C ABI in include/rofl_zk.h via ctypes.  There is NO CPU fallback: if librofl_zk.so is
+missing or no HIP device is present the calls fail loudly.
+"""
+from . import api  # noqa: F401
+from .api import (  # noqa: F401
+    RoflError, Nonce, lib, range_proof_vec, l2_range_proof_vec, pedersen_ops, conversion32,
+    set_device, last_timing, set_timing, bench_femul,
+)

@@ -1,0 +1,302 @@
+"""ctypes binding of librofl_zk.so, shaped like the reference's Rust modules.
+
+Reference signatures mirrored here (rofl_crypto/src/...):
+  range_proof_vec/mod.rs:16-21   create_rangeproof(values, blindings, prove_range, n_partition)
+  range_proof_vec/mod.rs:149-153 verify_rangeproof(proofs, commits, prove_range)
+  l2_range_proof_vec/mod.rs:15-20, :185-189
+  pedersen_ops.rs:9-127, conversion32.rs:11-66
+Scalars / points are numpy uint8 arrays of shape (d, 32); proofs are (n_proofs, proof_len).
+Errors that the reference reports as Err(..) (or panics) raise RoflError(code).
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "librofl_zk.so")
+
+ERROR_NAMES = {
+    1: "WrongNumBlindingFactors", 2: "ValueOutOfRangeError", 3: "InvalidBitsize", 4: "InvalidAggregation",
+    5: "FormatError", 6: "InvalidGeneratorsLength", 7: "NormOutOfRangeError", 8: "OverflowError", 9: "SumError",
+    10: "NonFiniteValue", 11: "BadParameter", 12: "NonceStreamTooShort",
+}
+
+
+class RoflError(Exception):
+    def __init__(self, code, msg=""):
+        self.code = code
+        self.name = ERROR_NAMES.get(code, "HipError" if code >= 100 else "Unknown")
+        super().__init__(f"{self.name} ({code}): {msg}")
+
+
+class _NonceStruct(ctypes.Structure):
+    _fields_ = [("mode", ctypes.c_int), ("stream", ctypes.c_void_p), ("stream_scalars", ctypes.c_size_t),
+                ("seed", ctypes.c_ubyte * 32)]
+
+
+class _Timing(ctypes.Structure):
+    _fields_ = [("total_ms", ctypes.c_double), ("msm_accumulate_ms", ctypes.c_double),
+                ("msm_accumulate_launches", ctypes.c_uint64), ("msm_terms", ctypes.c_uint64),
+                ("fold_ms", ctypes.c_double), ("fold_launches", ctypes.c_uint64),
+                ("fold_point_reads", ctypes.c_uint64), ("host_ms", ctypes.c_double)]
+
+
+class Nonce:
+    """Prover randomness (the reference uses rand::thread_rng inside bulletproofs).
+
+    Nonce.seeded(seed32): deterministic SHAKE256 stream; Nonce.stream(bytes): explicit 64-byte wide scalars
+    in the reference draw order; Nonce.random(): fresh OS randomness (what a deployment uses)."""
+
+    def __init__(self, mode, seed=None, stream=None):
+        self.mode, self.seed, self._stream = mode, seed, stream
+
+    @staticmethod
+    def seeded(seed32):
+        seed32 = bytes(seed32)
+        assert len(seed32) == 32
+        return Nonce(1, seed=seed32)
+
+    @staticmethod
+    def random():
+        return Nonce(1, seed=os.urandom(32))
+
+    @staticmethod
+    def stream(data):
+        arr = np.ascontiguousarray(np.frombuffer(bytes(data), dtype=np.uint8))
+        assert arr.size % 64 == 0
+        return Nonce(0, stream=arr)
+
+    def _struct(self):
+        s = _NonceStruct()
+        s.mode = self.mode
+        if self.mode == 1:
+            s.seed = (ctypes.c_ubyte * 32)(*self.seed)
+        else:
+            s.stream = self._stream.ctypes.data
+            s.stream_scalars = self._stream.size // 64
+        return s
+
+
+_lib = None
+
+
+def lib():
+    """Load librofl_zk.so (no fallback: a missing library is a hard error)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError(f"{_LIB_PATH} not found: build it with `python -m rofl_project_code_amd.build` "
+                               "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        _lib = ctypes.CDLL(_LIB_PATH)
+        for name in ("rofl_next_pow2", "rofl_rangeproof_chunks", "rofl_rangeproof_size", "rofl_nonces_per_chunk"):
+            getattr(_lib, name).restype = ctypes.c_size_t
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        buf = ctypes.create_string_buffer(512)
+        lib().rofl_last_error(buf, ctypes.c_size_t(512))
+        raise RoflError(rc, buf.value.decode(errors="replace"))
+
+
+_sz = ctypes.c_size_t
+
+
+def _u8(a, last=32):
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.uint8))
+    if a.ndim == 1 and last and a.size % last == 0:
+        a = a.reshape(-1, last)
+    return a
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def set_device(dev):
+    _check(lib().rofl_set_device(int(dev)))
+
+
+def set_timing(on):
+    _check(lib().rofl_set_timing(int(bool(on))))
+
+
+def last_timing():
+    t = _Timing()
+    _check(lib().rofl_last_timing(ctypes.byref(t)))
+    return {f[0]: getattr(t, f[0]) for f in _Timing._fields_}
+
+
+def bench_femul(iters=2000):
+    out = ctypes.c_double()
+    _check(lib().rofl_bench_femul(ctypes.c_uint(iters), ctypes.byref(out)))
+    return out.value
+
+
+class _FpConfig:
+    """The reference selects (N_BITS, frac) with cargo features (fp.rs); here it is module state."""
+    fp_bits = 16
+    fp_frac = 7
+
+
+def set_fp(fp_bits, fp_frac):
+    _FpConfig.fp_bits, _FpConfig.fp_frac = int(fp_bits), int(fp_frac)
+
+
+class range_proof_vec:
+    @staticmethod
+    def next_pow2(v):
+        return lib().rofl_next_pow2(_sz(v))
+
+    @staticmethod
+    def clip_f32_to_range_vec(values, prove_range):
+        v = np.ascontiguousarray(values, dtype=np.float32)
+        out = np.empty_like(v)
+        _check(lib().rofl_clip_f32(_ptr(v), _sz(v.size), _sz(prove_range), _FpConfig.fp_bits, _FpConfig.fp_frac, _ptr(out)))
+        return out
+
+    @staticmethod
+    def create_rangeproof(values, blindings, prove_range, n_partition, nonce=None):
+        """-> (proofs uint8[n_proofs, proof_len], commitments uint8[d, 32])"""
+        v = np.ascontiguousarray(values, dtype=np.float32)
+        b = _u8(blindings)
+        nonce = nonce or Nonce.random()
+        ns = nonce._struct()
+        d = v.size
+        npr = lib().rofl_rangeproof_chunks(_sz(max(d, 1)), _sz(max(n_partition, 1)))
+        plen = lib().rofl_rangeproof_size(_sz(max(prove_range, 1)), _sz(max(d, 1)), _sz(max(n_partition, 1)))
+        proofs = np.zeros((max(npr, 1), max(plen, 32)), dtype=np.uint8)
+        commits = np.zeros((max(d, 1), 32), dtype=np.uint8)
+        plen_o, npr_o = _sz(), _sz()
+        _check(lib().rofl_create_rangeproof(_ptr(v), _sz(d), _ptr(b), _sz(b.shape[0] if b.size else 0), _sz(prove_range),
+                                            _sz(n_partition), _FpConfig.fp_bits, _FpConfig.fp_frac, ctypes.byref(ns),
+                                            _ptr(proofs), ctypes.byref(plen_o), ctypes.byref(npr_o), _ptr(commits)))
+        assert plen_o.value == plen and npr_o.value == npr
+        return proofs, commits[:d]
+
+    @staticmethod
+    def verify_rangeproof(proofs, commits, prove_range, verifier_seed=None):
+        p = np.ascontiguousarray(proofs, dtype=np.uint8)
+        c = _u8(commits)
+        seed = bytes(verifier_seed) if verifier_seed is not None else os.urandom(32)
+        ok = ctypes.c_int()
+        _check(lib().rofl_verify_rangeproof(_ptr(p), _sz(p.shape[1]), _sz(p.shape[0]), _ptr(c), _sz(c.shape[0]),
+                                            _sz(prove_range), _FpConfig.fp_bits, _FpConfig.fp_frac, seed, ctypes.byref(ok)))
+        return bool(ok.value)
+
+    @staticmethod
+    def verify_rangeproof_batch(proofs_list, commits_list, prove_range, verifier_seed=None):
+        ps = [np.ascontiguousarray(p, dtype=np.uint8) for p in proofs_list]
+        cs = [_u8(c) for c in commits_list]
+        n = len(ps)
+        seed = bytes(verifier_seed) if verifier_seed is not None else os.urandom(32)
+        pp = (ctypes.c_void_p * n)(*[p.ctypes.data for p in ps])
+        cp = (ctypes.c_void_p * n)(*[c.ctypes.data for c in cs])
+        ok = (ctypes.c_int * n)()
+        _check(lib().rofl_verify_rangeproof_batch(_sz(n), pp, _sz(ps[0].shape[1]), _sz(ps[0].shape[0]), cp, _sz(cs[0].shape[0]),
+                                                  _sz(prove_range), _FpConfig.fp_bits, _FpConfig.fp_frac, seed, ok))
+        return [bool(x) for x in ok]
+
+
+class l2_range_proof_vec:
+    @staticmethod
+    def create_rangeproof_l2(values, blindings, prove_range, n_partition, nonce=None):
+        v = np.ascontiguousarray(values, dtype=np.float32)
+        b = _u8(blindings)
+        nonce = nonce or Nonce.random()
+        ns = nonce._struct()
+        proof = np.zeros(32 * (9 + 2 * 6), dtype=np.uint8)
+        commit = np.zeros(32, dtype=np.uint8)
+        plen = _sz()
+        _check(lib().rofl_create_rangeproof_l2(_ptr(v), _sz(v.size), _ptr(b), _sz(b.shape[0] if b.size else 0), _sz(prove_range),
+                                               _sz(n_partition), _FpConfig.fp_bits, _FpConfig.fp_frac, ctypes.byref(ns),
+                                               _ptr(proof), ctypes.byref(plen), _ptr(commit)))
+        return proof[:plen.value].copy(), commit
+
+    @staticmethod
+    def verify_rangeproof_l2(proof, commit, prove_range, verifier_seed=None):
+        p = np.ascontiguousarray(proof, dtype=np.uint8)
+        c = np.ascontiguousarray(commit, dtype=np.uint8)
+        seed = bytes(verifier_seed) if verifier_seed is not None else os.urandom(32)
+        ok = ctypes.c_int()
+        _check(lib().rofl_verify_rangeproof_l2(_ptr(p), _sz(p.size), _ptr(c), _sz(prove_range), _FpConfig.fp_bits,
+                                               _FpConfig.fp_frac, seed, ctypes.byref(ok)))
+        return bool(ok.value)
+
+
+class pedersen_ops:
+    @staticmethod
+    def commit_vec(scalars, blindings):
+        s, b = _u8(scalars), _u8(blindings)
+        assert s.shape == b.shape
+        out = np.zeros_like(s)
+        _check(lib().rofl_commit_vec(_ptr(s), _ptr(b), _sz(s.shape[0]), _ptr(out)))
+        return out
+
+    @staticmethod
+    def commit_no_blinding_vec(scalars):
+        s = _u8(scalars)
+        out = np.zeros_like(s)
+        _check(lib().rofl_commit_vec(_ptr(s), None, _sz(s.shape[0]), _ptr(out)))
+        return out
+
+    @staticmethod
+    def add_rp_vec(a, b):
+        a, b = _u8(a), _u8(b)
+        assert a.shape == b.shape
+        out = np.zeros_like(a)
+        _check(lib().rofl_add_points_vec(_ptr(a), _ptr(b), _sz(a.shape[0]), _ptr(out)))
+        return out
+
+    @staticmethod
+    def add_rp_vec_vec(vecs):
+        acc = pedersen_ops.zero_rp_vec(_u8(vecs[0]).shape[0])
+        for v in vecs:
+            acc = pedersen_ops.add_rp_vec(acc, v)
+        return acc
+
+    @staticmethod
+    def zero_rp_vec(length):
+        return np.zeros((length, 32), dtype=np.uint8)   # identity compresses to 32 zero bytes
+
+    @staticmethod
+    def zero_scalar_vec(length):
+        return np.zeros((length, 32), dtype=np.uint8)
+
+    @staticmethod
+    def compute_shifted_values_rp(points, offset):
+        p = _u8(points)
+        o = np.ascontiguousarray(offset, dtype=np.uint8)
+        out = np.zeros_like(p)
+        _check(lib().rofl_shift_points(_ptr(p), _sz(p.shape[0]), _ptr(o), _ptr(out)))
+        return out
+
+
+class conversion32:
+    @staticmethod
+    def f32_to_scalar_vec(values):
+        v = np.ascontiguousarray(values, dtype=np.float32)
+        out = np.zeros((v.size, 32), dtype=np.uint8)
+        _check(lib().rofl_f32_to_scalar_vec(_ptr(v), _sz(v.size), _FpConfig.fp_bits, _FpConfig.fp_frac, _ptr(out)))
+        return out
+
+    @staticmethod
+    def scalar_to_f32_vec(scalars):
+        s = _u8(scalars)
+        out = np.zeros(s.shape[0], dtype=np.float32)
+        _check(lib().rofl_scalar_to_f32_vec(_ptr(s), _sz(s.shape[0]), _FpConfig.fp_bits, _FpConfig.fp_frac, _ptr(out)))
+        return out
+
+    @staticmethod
+    def get_clip_bounds(prove_range):
+        mn, mx = ctypes.c_float(), ctypes.c_float()
+        _check(lib().rofl_get_clip_bounds(_sz(prove_range), _FpConfig.fp_bits, _FpConfig.fp_frac, ctypes.byref(mn), ctypes.byref(mx)))
+        return mn.value, mx.value
+
+    @staticmethod
+    def get_l2_clip_bounds(prove_range):
+        out = ctypes.c_float()
+        _check(lib().rofl_get_l2_clip_bounds(_sz(prove_range), _FpConfig.fp_bits, _FpConfig.fp_frac, ctypes.byref(out)))
+        return out.value

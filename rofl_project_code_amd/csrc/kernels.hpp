@@ -1,0 +1,618 @@
+// HIP kernels for the range-proof hot path (gfx950 only).  See DESIGN.md for the kernel table.
+//
+// Conventions: blockIdx.y = "problem" (one Bulletproof chunk, or one MSM problem).
+// Scalars in device arrays are in Montgomery form unless a name ends with _canon.
+#pragma once
+#include "fe32.hpp"
+#include "keccak.hpp"
+
+namespace rofl {
+
+#define TPB 256
+
+// ---------------------------------------------------------------- small helpers
+__device__ __forceinline__ niels load_niels(const niels *p) {
+    niels r;
+    const uint4 *s = reinterpret_cast<const uint4 *>(p);
+    uint4 *d = reinterpret_cast<uint4 *>(&r);
+#pragma unroll
+    for (int i = 0; i < 6; i++) d[i] = s[i];
+    return r;
+}
+__device__ __forceinline__ void store_niels(niels *p, const niels &v) {
+    uint4 *d = reinterpret_cast<uint4 *>(p);
+    const uint4 *s = reinterpret_cast<const uint4 *>(&v);
+#pragma unroll
+    for (int i = 0; i < 6; i++) d[i] = s[i];
+}
+__device__ __forceinline__ ge load_ge(const ge *p) {
+    ge r;
+    const uint4 *s = reinterpret_cast<const uint4 *>(p);
+    uint4 *d = reinterpret_cast<uint4 *>(&r);
+#pragma unroll
+    for (int i = 0; i < 8; i++) d[i] = s[i];
+    return r;
+}
+__device__ __forceinline__ void store_ge(ge *p, const ge &v) {
+    uint4 *d = reinterpret_cast<uint4 *>(p);
+    const uint4 *s = reinterpret_cast<const uint4 *>(&v);
+#pragma unroll
+    for (int i = 0; i < 8; i++) d[i] = s[i];
+}
+__device__ __forceinline__ sc load_sc(const sc *p) {
+    sc r;
+    const uint4 *s = reinterpret_cast<const uint4 *>(p);
+    uint4 *d = reinterpret_cast<uint4 *>(&r);
+    d[0] = s[0]; d[1] = s[1];
+    return r;
+}
+__device__ __forceinline__ void store_sc(sc *p, const sc &v) {
+    uint4 *d = reinterpret_cast<uint4 *>(p);
+    const uint4 *s = reinterpret_cast<const uint4 *>(&v);
+    d[0] = s[0]; d[1] = s[1];
+}
+
+// x^e (Montgomery) from the table sq[b] = x^(2^b)
+__device__ __forceinline__ sc sc_pow_tab(const sc *sq, u32 e) {
+    sc acc = sc_one_mont();
+    for (int b = 0; e; b++, e >>= 1)
+        if (e & 1) acc = sc_montmul(acc, sq[b]);
+    return acc;
+}
+
+// block-wide sum of NS scalars per thread; result valid in thread 0
+template <int NS>
+__device__ __forceinline__ void block_sum_sc(sc (&v)[NS], sc *lds /* TPB*NS */) {
+    int t = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < NS; k++) lds[k * TPB + t] = v[k];
+    __syncthreads();
+    for (int s = TPB / 2; s > 0; s >>= 1) {
+        if (t < s) {
+#pragma unroll
+            for (int k = 0; k < NS; k++) lds[k * TPB + t] = sc_add(lds[k * TPB + t], lds[k * TPB + t + s]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < NS; k++) v[k] = lds[k * TPB];
+}
+
+// ---------------------------------------------------------------- per-chunk parameter block
+#define MAX_LG 32
+struct ChunkParams {
+    sc y, z, zz, x, yinv;            // Montgomery
+    sc ypow2[MAX_LG];                // y^(2^b)
+    sc yinvpow2[MAX_LG];             // y^-(2^b)
+    sc zpow2[MAX_LG];                // z^(2^b)
+    sc u[MAX_LG], uinv[MAX_LG];      // IPP challenges (verify: all rounds; prove: current round)
+    sc stabG[64], stabH[64];         // pending-challenge products for lazily folded generators
+    sc a_fin, b_fin;                 // verify: ipp a, b
+    sc c_zz;                         // verify: c * z^2
+    u64 nonce_base;                  // index of this chunk's first nonce
+};
+
+// ================================================================ K1: generators
+// bulletproofs GeneratorsChain: SHAKE256("GeneratorsChain" || label5), 64 B per generator.
+// One thread per (which, party): sequential XOF squeeze, n <= 64 generators.
+__global__ void __launch_bounds__(TPB) k_gens_xof(u32 n, u32 m, uint8_t *uni /* [2][m][n][64] */) {
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 2 * m) return;
+    u32 which = t / m, j = t % m;
+    u64 st[25];
+#pragma unroll
+    for (int i = 0; i < 25; i++) st[i] = 0;
+    // message: "GeneratorsChain" (15) || 'G'/'H' || u32le(j)   = 20 bytes, then 0x1F pad
+    const char lab[16] = {'G', 'e', 'n', 'e', 'r', 'a', 't', 'o', 'r', 's', 'C', 'h', 'a', 'i', 'n', 0};
+    u64 w0 = 0, w1 = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) w0 |= (u64)(uint8_t)lab[i] << (8 * i);
+#pragma unroll
+    for (int i = 0; i < 7; i++) w1 |= (u64)(uint8_t)lab[8 + i] << (8 * i);
+    w1 |= (u64)(which ? 'H' : 'G') << 56;
+    st[0] = w0; st[1] = w1;
+    st[2] = (u64)j | (0x1FULL << 32);
+    st[16] ^= 0x8000000000000000ULL;
+    keccak_f1600(st);
+    u64 *out = reinterpret_cast<u64 *>(uni + ((size_t)which * m + j) * n * 64);
+    u32 pos = 0;   // word position in the 17-word rate
+    for (u32 i = 0; i < n * 8; i++) {
+        if (pos == 17) { keccak_f1600(st); pos = 0; }
+        out[i] = st[pos++];
+    }
+}
+// uniform bytes -> affine niels table [G(N) | H(N)]
+__global__ void __launch_bounds__(TPB) k_gens_map(u32 total, const uint8_t *uni, niels *tbl) {
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    ge p = ristretto_from_uniform(uni + (size_t)t * 64);
+    store_niels(&tbl[t], ge_to_niels(p));
+}
+
+// ================================================================ nonces
+// mode 1: SHAKE256("rofl-zk/nonce/v1" || seed || u64le(idx)) ; mode 0: explicit 64-byte stream.
+// Reference draw order (bulletproofs party.rs): per party j: a_bl, s_bl, s_L[0..n), s_R[0..n);
+// then per party: t1_bl, t2_bl.
+struct NonceSeed { u64 w[4]; };
+__global__ void __launch_bounds__(TPB) k_nonce_expand(u32 n, u32 m, int mode, NonceSeed seed, const uint8_t *stream, u64 stream_scalars,
+                               const ChunkParams *cp, sc *sL, sc *sR, sc *party /* [chunk][4][m] */, sc *S_canon /* [chunk][2N] */) {
+    u32 c = blockIdx.y;
+    u64 per = (u64)m * (2 * n + 4);
+    u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= per) return;
+    u64 idx = cp[c].nonce_base + k;
+    sc lo, hi;
+    if (mode == 1) {
+        const u64 dom[2] = {0x2f6b7a2d6c666f72ULL, 0x31762f65636e6f6eULL};  // "rofl-zk/" "nonce/v1"
+        u64 st[25];
+        shake256_seeded_block(st, dom, seed.w, idx);
+#pragma unroll
+        for (int i = 0; i < 4; i++) { lo.v[2 * i] = (u32)st[i]; lo.v[2 * i + 1] = (u32)(st[i] >> 32); hi.v[2 * i] = (u32)st[4 + i]; hi.v[2 * i + 1] = (u32)(st[4 + i] >> 32); }
+    } else {
+        if (idx < stream_scalars) {
+            const u32 *s = reinterpret_cast<const u32 *>(stream + idx * 64);
+#pragma unroll
+            for (int i = 0; i < 8; i++) { lo.v[i] = s[i]; hi.v[i] = s[8 + i]; }
+        } else { lo = sc_zero(); hi = sc_zero(); }
+    }
+    sc vc = sc_from_wide(lo, hi);
+    sc v = sc_to_mont(vc);
+    u64 first = (u64)m * (2 * n + 2);
+    size_t N = (size_t)n * m;
+    if (k < first) {
+        u32 j = (u32)(k / (2 * n + 2)), r = (u32)(k % (2 * n + 2));
+        if (r == 0) store_sc(&party[((size_t)c * 4 + 0) * m + j], v);
+        else if (r == 1) store_sc(&party[((size_t)c * 4 + 1) * m + j], v);
+        else if (r < 2 + n) { store_sc(&sL[c * N + (size_t)j * n + (r - 2)], v); store_sc(&S_canon[c * 2 * N + (size_t)j * n + (r - 2)], vc); }
+        else { store_sc(&sR[c * N + (size_t)j * n + (r - 2 - n)], v); store_sc(&S_canon[c * 2 * N + N + (size_t)j * n + (r - 2 - n)], vc); }
+    } else {
+        u64 q = k - first; u32 j = (u32)(q / 2);
+        store_sc(&party[((size_t)c * 4 + 2 + (q & 1)) * m + j], v);
+    }
+}
+
+// ================================================================ K2: quantize + shift
+// conversion32.rs:11-18 f32_to_scalar, range_proof_vec/mod.rs:27-43.  status bits: 1 out-of-range, 2 NaN.
+__global__ void __launch_bounds__(TPB) k_quantize_shift(const float *vals, u32 d, u32 dpad, u32 prove_range, u32 fp_bits, u32 fp_frac,
+                                 float clip_min, float clip_max, u64 *vshift, u32 *status) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= dpad) return;
+    if (i >= d) { vshift[i] = 0; return; }
+    float v = vals[i];
+    u32 st = 0;
+    if (clip_min > v || v > clip_max) st |= 1;
+    if (v != v) st |= 2;
+    if (st) { atomicOr(status, st); vshift[i] = 0; return; }
+    double x = fabs((double)v) * (double)(1ULL << fp_frac);
+    double lim = ldexp(1.0, (int)fp_bits);
+    u64 maxbits = fp_bits >= 64 ? ~0ULL : ((1ULL << fp_bits) - 1);
+    u64 k;
+    if (x >= lim) k = maxbits;
+    else { double r = rint(x); k = (r >= lim) ? maxbits : (u64)r; }
+    // (+-k + 2^(range-1)) mod l, then read_from_bytes keeps the low fp_bits bits (fp.rs)
+    u64 off = 1ULL << (prove_range - 1);
+    u64 lowbits;
+    if (v < 0.0f) {
+        if (off >= k) lowbits = off - k;
+        else {   // l - (k - off): low 64 bits of l minus (k-off)
+            u64 l_lo = ((u64)SC_L1 << 32) | SC_L0;
+            lowbits = l_lo - (k - off);
+        }
+    } else lowbits = k + off;   // k, off < 2^63 for fp_bits <= 63; fp64 wraps like the u64 cast chain
+    vshift[i] = lowbits & maxbits;
+}
+
+// ================================================================ K3: Pedersen commit (fixed-base)
+// tables: radix-16 signed digits, tab[w][e] = (e+1) * 16^w * P, w < 64, e < 8  (affine niels)
+__device__ __forceinline__ ge fixed_base_mul_acc(ge acc, const niels *tab, const sc &k, int nwin) {
+    // k canonical (< 2^253 when nwin == 64 so the carry digit is zero)
+    int carry = 0;
+    for (int i = 0; i < nwin; i++) {
+        int v = (int)((k.v[i >> 3] >> ((i & 7) * 4)) & 15) + carry;
+        carry = (v + 8) >> 4;
+        int dgt = v - (carry << 4);
+        int ad = dgt < 0 ? -dgt : dgt;
+        if (ad) {
+            niels q = load_niels(&tab[i * 8 + ad - 1]);
+            acc = ge_madd(acc, q, dgt < 0);
+        }
+    }
+    if (carry && nwin < 64) {
+        niels q = load_niels(&tab[nwin * 8 + 0]);
+        acc = ge_madd(acc, q, false);
+    }
+    return acc;
+}
+// V_j = v_j*B + r_j*Bb (compressed), and optionally C_j = V_j + shift (compressed)
+__global__ void __launch_bounds__(TPB) k_commit(u32 count, const u64 *v64, const sc *v256_canon, const sc *blind_canon /* may be null */,
+                         const niels *tabB, const niels *tabBb, const niels *shift /* may be null */,
+                         uint8_t *V_out /* may be null */, uint8_t *C_out /* may be null */, u32 c_count) {
+    u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    ge acc = ge_identity();
+    if (v64) { sc v = sc_from_u64(v64[j]); acc = fixed_base_mul_acc(acc, tabB, v, 16); }
+    else { sc v = load_sc(&v256_canon[j]); acc = fixed_base_mul_acc(acc, tabB, v, 64); }
+    if (blind_canon) { sc r = load_sc(&blind_canon[j]); acc = fixed_base_mul_acc(acc, tabBb, r, 64); }
+    if (V_out) ristretto_encode(V_out + (size_t)j * 32, acc);
+    if (C_out && j < c_count) {
+        ge cpt = shift ? ge_madd(acc, load_niels(shift), false) : acc;
+        ristretto_encode(C_out + (size_t)j * 32, cpt);
+    }
+}
+
+// ================================================================ K4: A = sum (bit ? G : -H)
+__global__ void __launch_bounds__(TPB) k_bitcommit(u32 n, u32 m, const u64 *vshift /* [chunk][m] */, const niels *tbl, ge *partial /* [chunk][m] */) {
+    u32 c = blockIdx.y;
+    u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    size_t N = (size_t)n * m;
+    u64 v = vshift[(size_t)c * m + j];
+    ge acc = ge_identity();
+    for (u32 i = 0; i < n; i++) {
+        bool bit = (v >> i) & 1;
+        const niels *p = bit ? &tbl[(size_t)j * n + i] : &tbl[N + (size_t)j * n + i];
+        acc = ge_madd(acc, load_niels(p), !bit);
+    }
+    store_ge(&partial[(size_t)c * m + j], acc);
+}
+
+// generic point reduction: in [prob][n] -> out [prob][gridDim.x]
+__global__ void __launch_bounds__(TPB) k_point_sum(const ge *in, u32 n, ge *out) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    ge *lds = reinterpret_cast<ge *>(smem);
+    u32 p = blockIdx.y, t = threadIdx.x;
+    const ge *src = in + (size_t)p * n;
+    ge acc = ge_identity();
+    for (u32 i = blockIdx.x * blockDim.x + t; i < n; i += gridDim.x * blockDim.x) acc = ge_add(acc, load_ge(&src[i]));
+    lds[t] = acc;
+    __syncthreads();
+    for (u32 s = blockDim.x / 2; s > 0; s >>= 1) {
+        if (t < s) lds[t] = ge_add(lds[t], lds[t + s]);
+        __syncthreads();
+    }
+    if (t == 0) store_ge(&out[(size_t)p * gridDim.x + blockIdx.x], lds[0]);
+}
+
+// ================================================================ party-level scalar sums
+// phase 0: sum a_bl, s_bl              -> out[chunk][blk][0..1]
+// phase 1: sum t1_bl, t2_bl, zz*z^j*vbl -> out[chunk][blk][0..2]
+__global__ void __launch_bounds__(TPB) k_party_sums(u32 m, int phase, const ChunkParams *cp, const sc *party, const sc *blind_canon /* [chunk][m] */, sc *out) {
+    __shared__ sc lds[TPB * 3];
+    u32 c = blockIdx.y;
+    sc v[3] = {sc_zero(), sc_zero(), sc_zero()};
+    for (u32 j = blockIdx.x * blockDim.x + threadIdx.x; j < m; j += gridDim.x * blockDim.x) {
+        if (phase == 0) {
+            v[0] = sc_add(v[0], load_sc(&party[((size_t)c * 4 + 0) * m + j]));
+            v[1] = sc_add(v[1], load_sc(&party[((size_t)c * 4 + 1) * m + j]));
+        } else {
+            v[0] = sc_add(v[0], load_sc(&party[((size_t)c * 4 + 2) * m + j]));
+            v[1] = sc_add(v[1], load_sc(&party[((size_t)c * 4 + 3) * m + j]));
+            sc zj = sc_montmul(cp[c].zz, sc_pow_tab(cp[c].zpow2, j));
+            sc bl = sc_to_mont(load_sc(&blind_canon[(size_t)c * m + j]));
+            v[2] = sc_add(v[2], sc_montmul(zj, bl));
+        }
+    }
+    block_sum_sc<3>(v, lds);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) store_sc(&out[((size_t)c * gridDim.x + blockIdx.x) * 3 + k], v[k]);
+    }
+}
+
+// ================================================================ K6: polynomial vectors
+// bulletproofs party.rs apply_challenge: l0 = aL - z, l1 = sL, r0 = y^k (aR + z) + z^(2+j) 2^i, r1 = y^k sR
+__device__ __forceinline__ void slot_vectors(const ChunkParams &P, u32 n, u32 k, u64 v, const sc &sR,
+                                             sc &l0, sc &r0, sc &r1, const sc *two_pow) {
+    u32 j = k / n, i = k % n;
+    bool bit = (v >> i) & 1;
+    sc one = sc_one_mont();
+    sc aL = bit ? one : sc_zero();
+    sc aR = bit ? sc_zero() : sc_neg(one);
+    sc yk = sc_pow_tab(P.ypow2, k);
+    l0 = sc_sub(aL, P.z);
+    sc zj2 = sc_montmul(sc_montmul(P.zz, sc_pow_tab(P.zpow2, j)), two_pow[i]);
+    r0 = sc_add(sc_montmul(yk, sc_add(aR, P.z)), zj2);
+    r1 = sc_montmul(yk, sR);
+}
+// t0,t1,t2 partial sums -> out[chunk][blk][3]
+__global__ void __launch_bounds__(TPB) k_poly_t(u32 n, u32 m, const ChunkParams *cp, const u64 *vshift, const sc *sL, const sc *sR,
+                         const sc *two_pow, sc *out) {
+    __shared__ sc lds[TPB * 3];
+    u32 c = blockIdx.y;
+    size_t N = (size_t)n * m;
+    sc v[3] = {sc_zero(), sc_zero(), sc_zero()};
+    for (u32 k = blockIdx.x * blockDim.x + threadIdx.x; k < N; k += gridDim.x * blockDim.x) {
+        sc l0, r0, r1;
+        sc l1 = load_sc(&sL[c * N + k]);
+        slot_vectors(cp[c], n, k, vshift[(size_t)c * m + k / n], load_sc(&sR[c * N + k]), l0, r0, r1, two_pow);
+        v[0] = sc_add(v[0], sc_montmul(l0, r0));
+        v[1] = sc_add(v[1], sc_add(sc_montmul(l0, r1), sc_montmul(l1, r0)));
+        v[2] = sc_add(v[2], sc_montmul(l1, r1));
+    }
+    block_sum_sc<3>(v, lds);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) store_sc(&out[((size_t)c * gridDim.x + blockIdx.x) * 3 + k], v[k]);
+    }
+}
+// a = l(x), b = r(x); also yinv^k table
+__global__ void __launch_bounds__(TPB) k_lr_vec(u32 n, u32 m, const ChunkParams *cp, const u64 *vshift, const sc *sL, const sc *sR,
+                         const sc *two_pow, sc *a, sc *b, sc *yinvpow) {
+    u32 c = blockIdx.y;
+    size_t N = (size_t)n * m;
+    u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= N) return;
+    sc l0, r0, r1;
+    sc l1 = load_sc(&sL[c * N + k]);
+    slot_vectors(cp[c], n, k, vshift[(size_t)c * m + k / n], load_sc(&sR[c * N + k]), l0, r0, r1, two_pow);
+    store_sc(&a[c * N + k], sc_add(l0, sc_montmul(l1, cp[c].x)));
+    store_sc(&b[c * N + k], sc_add(r0, sc_montmul(r1, cp[c].x)));
+    store_sc(&yinvpow[c * N + k], sc_pow_tab(cp[c].yinvpow2, k));
+}
+
+// ================================================================ K7: inner-product argument
+// Lazily folded generators: the materialised arrays Gc/Hc have n_g entries; the logical vectors have
+// n_k = n_g >> r entries; true G[i] = sum_h stabG[h] Gc[h*n_k+i], true H[i] = sum_h stabH[h] y^-j Hc[j].
+// Writes canonical MSM scalars for L (SL) and R (SR) over [Gc | Hc].
+__global__ void __launch_bounds__(TPB) k_ipp_scalars(u32 n_g, u32 n_k, const ChunkParams *cp, const sc *a, const sc *b, size_t ab_stride,
+                              const sc *yinvpow, size_t y_stride, sc *SL, sc *SR) {
+    u32 c = blockIdx.y;
+    u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_g) return;
+    u32 h = j / n_k, i = j % n_k, nh = n_k / 2;
+    const sc *ac = a + c * ab_stride, *bc = b + c * ab_stride;
+    sc sG = cp[c].stabG[h];
+    sc sH = sc_montmul(cp[c].stabH[h], load_sc(&yinvpow[c * y_stride + j]));
+    sc *sl = SL + (size_t)c * 2 * n_g, *sr = SR + (size_t)c * 2 * n_g;
+    sc zero = sc_zero();
+    if (i < nh) {
+        // G_L / H_L halves: R gets a_R * G_L ; L gets b_R * H_L
+        store_sc(&sr[j], sc_from_mont(sc_montmul(load_sc(&ac[nh + i]), sG)));
+        store_sc(&sl[j], zero);
+        store_sc(&sl[n_g + j], sc_from_mont(sc_montmul(load_sc(&bc[nh + i]), sH)));
+        store_sc(&sr[n_g + j], zero);
+    } else {
+        u32 ii = i - nh;
+        store_sc(&sl[j], sc_from_mont(sc_montmul(load_sc(&ac[ii]), sG)));
+        store_sc(&sr[j], zero);
+        store_sc(&sr[n_g + j], sc_from_mont(sc_montmul(load_sc(&bc[ii]), sH)));
+        store_sc(&sl[n_g + j], zero);
+    }
+}
+// c_L = <a_L, b_R>, c_R = <a_R, b_L>  -> out[chunk][blk][2]
+__global__ void __launch_bounds__(TPB) k_ipp_inner(u32 nh, const sc *a, const sc *b, size_t ab_stride, sc *out) {
+    __shared__ sc lds[TPB * 2];
+    u32 c = blockIdx.y;
+    const sc *ac = a + c * ab_stride, *bc = b + c * ab_stride;
+    sc v[2] = {sc_zero(), sc_zero()};
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < nh; i += gridDim.x * blockDim.x) {
+        v[0] = sc_add(v[0], sc_montmul(load_sc(&ac[i]), load_sc(&bc[nh + i])));
+        v[1] = sc_add(v[1], sc_montmul(load_sc(&ac[nh + i]), load_sc(&bc[i])));
+    }
+    block_sum_sc<2>(v, lds);
+    if (threadIdx.x == 0) {
+        store_sc(&out[((size_t)c * gridDim.x + blockIdx.x) * 2 + 0], v[0]);
+        store_sc(&out[((size_t)c * gridDim.x + blockIdx.x) * 2 + 1], v[1]);
+    }
+}
+// a_L = a_L u + u^-1 a_R ; b_L = b_L u^-1 + u b_R   (cp.u[0], cp.uinv[0] = this round's challenge)
+__global__ void __launch_bounds__(TPB) k_ipp_fold_ab(u32 nh, const ChunkParams *cp, sc *a, sc *b, size_t ab_stride) {
+    u32 c = blockIdx.y;
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nh) return;
+    sc *ac = a + c * ab_stride, *bc = b + c * ab_stride;
+    sc u = cp[c].u[0], ui = cp[c].uinv[0];
+    store_sc(&ac[i], sc_add(sc_montmul(load_sc(&ac[i]), u), sc_montmul(load_sc(&ac[nh + i]), ui)));
+    store_sc(&bc[i], sc_add(sc_montmul(load_sc(&bc[i]), ui), sc_montmul(load_sc(&bc[nh + i]), u)));
+}
+
+// Materialise folded generators: dst[i] = sum_{h < nsrc} s_h * src[h*n_new + i], all outputs of a problem
+// share the scalars s_h (given as NAF digits, wave-uniform control flow => no divergence).
+struct FoldProb { const niels *src; niels *dst; };
+#define FOLD_MAXSRC 64
+__global__ void __launch_bounds__(64) k_fold_gens(u32 n_new, u32 nsrc, int top_bit, const FoldProb *probs, const int8_t *naf /* [prob][nsrc][256] */) {
+    u32 q = blockIdx.y;
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_new) return;
+    const niels *src = probs[q].src;
+    const int8_t *dg = naf + (size_t)q * nsrc * 256;
+    ge acc = ge_identity();
+    for (int bit = top_bit; bit >= 0; bit--) {
+        acc = ge_double(acc);
+        for (u32 h = 0; h < nsrc; h++) {
+            int d = dg[h * 256 + bit];
+            if (d != 0) acc = ge_madd(acc, load_niels(&src[(size_t)h * n_new + i]), d < 0);
+        }
+    }
+    store_niels(&probs[q].dst[i], ge_to_niels(acc));
+}
+
+// ================================================================ K5: Pippenger MSM
+// Booth-recoded signed c-bit digit of window w: in [-2^(c-1), 2^(c-1)]
+__device__ __forceinline__ int msm_digit(const sc &k, u32 w, u32 c) {
+    int pos = (int)(w * c) - 1;           // lowest bit needed (b_{cw-1}), -1 for w = 0
+    u32 need = c + 1;
+    u64 bits;
+    if (pos < 0) {
+        bits = ((u64)k.v[0] | ((u64)k.v[1] << 32)) << 1;
+    } else {
+        u32 limb = (u32)pos >> 5, off = (u32)pos & 31;
+        u64 lo = limb < 8 ? k.v[limb] : 0, mid = limb + 1 < 8 ? k.v[limb + 1] : 0, hi = limb + 2 < 8 ? k.v[limb + 2] : 0;
+        bits = (lo >> off) | (mid << (32 - off));
+        if (off) bits |= hi << (64 - off);
+    }
+    u32 x = (u32)(bits & ((1ULL << need) - 1));
+    // x = b_{cw-1} + 2*V, V = the c window bits; digit = V_low(c-1 bits) + b_{cw-1} - top * 2^(c-1)
+    u32 V = x >> 1, bm1 = x & 1, top = (V >> (c - 1)) & 1;
+    return (int)(V & ((1u << (c - 1)) - 1)) + (int)bm1 - (int)(top << (c - 1));
+}
+struct MsmProb { const niels *pts; const sc *scal; };   // per problem: points and canonical scalars
+__global__ void __launch_bounds__(TPB) k_msm_count(u32 n, u32 c, u32 W, const MsmProb *probs, u32 *cnt /* [prob][W][B] */) {
+    u32 p = blockIdx.y, B = 1u << (c - 1);
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    sc k = load_sc(&probs[p].scal[i]);
+    if (sc_iszero(k)) return;
+    for (u32 w = 0; w < W; w++) {
+        int d = msm_digit(k, w, c);
+        if (d) atomicAdd(&cnt[((size_t)p * W + w) * B + (u32)(d < 0 ? -d : d) - 1], 1u);
+    }
+}
+// exclusive scan of each (prob, window) histogram; one block per (prob, window)
+__global__ void __launch_bounds__(TPB) k_msm_scan(u32 B, const u32 *cnt, u32 *off, u32 *cursor) {
+    __shared__ u32 part[TPB];
+    size_t base = (size_t)blockIdx.x * B;
+    u32 t = threadIdx.x, per = (B + TPB - 1) / TPB;
+    u32 lo = t * per, hi = lo + per < B ? lo + per : B;
+    u32 s = 0;
+    for (u32 i = lo; i < hi && i < B; i++) s += cnt[base + i];
+    part[t] = s;
+    __syncthreads();
+    // simple Hillis-Steele inclusive scan over 256 partials
+    for (u32 d = 1; d < TPB; d <<= 1) {
+        u32 v = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    u32 run = t ? part[t - 1] : 0;
+    for (u32 i = lo; i < hi && i < B; i++) { off[base + i] = run; cursor[base + i] = run; run += cnt[base + i]; }
+}
+__global__ void __launch_bounds__(TPB) k_msm_scatter(u32 n, u32 c, u32 W, const MsmProb *probs, u32 *cursor, u32 *sorted /* [prob][W][n] */) {
+    u32 p = blockIdx.y, B = 1u << (c - 1);
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    sc k = load_sc(&probs[p].scal[i]);
+    if (sc_iszero(k)) return;
+    for (u32 w = 0; w < W; w++) {
+        int d = msm_digit(k, w, c);
+        if (d) {
+            u32 ad = (u32)(d < 0 ? -d : d) - 1;
+            u32 pos = atomicAdd(&cursor[((size_t)p * W + w) * B + ad], 1u);
+            sorted[((size_t)p * W + w) * n + pos] = i | (d < 0 ? 0x80000000u : 0u);
+        }
+    }
+}
+// one thread per bucket: sum its points.  buckets [prob][W][B] extended.
+__global__ void __launch_bounds__(TPB) k_msm_accumulate(u32 n, u32 c, u32 W, const MsmProb *probs, const u32 *cnt, const u32 *off,
+                                 const u32 *sorted, ge *buckets) {
+    u32 p = blockIdx.y, B = 1u << (c - 1);
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= W * B) return;
+    u32 w = t / B;
+    size_t bi = (size_t)p * W * B + t;
+    u32 start = off[bi], num = cnt[bi];
+    const u32 *lst = sorted + ((size_t)p * W + w) * n + start;
+    const niels *pts = probs[p].pts;
+    ge acc = ge_identity();
+    for (u32 e = 0; e < num; e++) {
+        u32 v = lst[e];
+        acc = ge_madd(acc, load_niels(&pts[v & 0x7fffffffu]), (v >> 31) != 0);
+    }
+    store_ge(&buckets[bi], acc);
+}
+// Bucket reduction without doublings: sum_b (b+1) B_b = S + sum_l 2^l D_l, D_l = sum of buckets whose
+// index has bit l set.  One 8-ary tree level per launch:
+//   role 0 threads: 8 children of S_in -> S_out, and the three new bit-sums (11 adds)
+//   role r>=1     : carried bit-sum r-1: 8 children -> 1 (7 adds)
+// in: S_in [PW][E], C_in [PW][nb][E];  out: S_out [PW][E/8], C_out [PW][nb+3][E/8]
+__global__ void __launch_bounds__(TPB) k_msm_reduce_level(u32 E, u32 nb, const ge *S_in, const ge *C_in, ge *S_out, ge *C_out) {
+    u32 pw = blockIdx.y, E8 = E / 8;
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= E8 * (1 + nb)) return;
+    u32 role = t / E8, g = t % E8;
+    if (role == 0) {
+        const ge *s = S_in + (size_t)pw * E + (size_t)g * 8;
+        ge p0 = load_ge(&s[0]), p1 = load_ge(&s[1]);
+        ge q0 = ge_add(p0, p1); ge D0 = p1;
+        p0 = load_ge(&s[2]); p1 = load_ge(&s[3]);
+        ge q1 = ge_add(p0, p1); D0 = ge_add(D0, p1);
+        p0 = load_ge(&s[4]); p1 = load_ge(&s[5]);
+        ge q2 = ge_add(p0, p1); D0 = ge_add(D0, p1);
+        p0 = load_ge(&s[6]); p1 = load_ge(&s[7]);
+        ge q3 = ge_add(p0, p1); D0 = ge_add(D0, p1);
+        ge r0 = ge_add(q0, q1), r1 = ge_add(q2, q3);
+        ge D1 = ge_add(q1, q3);
+        ge S = ge_add(r0, r1);
+        store_ge(&S_out[(size_t)pw * E8 + g], S);
+        ge *co = C_out + (size_t)pw * (nb + 3) * E8;
+        store_ge(&co[(size_t)(nb + 0) * E8 + g], D0);
+        store_ge(&co[(size_t)(nb + 1) * E8 + g], D1);
+        store_ge(&co[(size_t)(nb + 2) * E8 + g], r1);
+    } else {
+        const ge *s = C_in + ((size_t)pw * nb + (role - 1)) * E + (size_t)g * 8;
+        ge acc = ge_add(load_ge(&s[0]), load_ge(&s[1]));
+#pragma unroll 1
+        for (int k = 2; k < 8; k++) acc = ge_add(acc, load_ge(&s[k]));
+        store_ge(&C_out[((size_t)pw * (nb + 3) + (role - 1)) * E8 + g], acc);
+    }
+}
+
+// ================================================================ K8/K9: verification
+// decode compressed points into affine niels (+ validity); optional shift (adds `shift` before use)
+// and optional re-encode of the shifted point (verify_rangeproof: range_proof_vec/mod.rs:155-167).
+__global__ void __launch_bounds__(TPB) k_decode(u32 count, u32 valid_count, const uint8_t *in, const niels *shift, niels *out_niels,
+                         uint8_t *out_enc, u32 *status) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    if (i >= valid_count) {   // padding: identity
+        if (out_niels) store_niels(&out_niels[i], niels_identity());
+        if (out_enc) { uint4 z = make_uint4(0, 0, 0, 0); reinterpret_cast<uint4 *>(out_enc + (size_t)i * 32)[0] = z; reinterpret_cast<uint4 *>(out_enc + (size_t)i * 32)[1] = z; }
+        return;
+    }
+    __align__(16) uint8_t b[32];
+    const uint4 *s = reinterpret_cast<const uint4 *>(in + (size_t)i * 32);
+    reinterpret_cast<uint4 *>(b)[0] = s[0]; reinterpret_cast<uint4 *>(b)[1] = s[1];
+    ge p;
+    if (!ristretto_decode(p, b)) { atomicOr(status, 4u); p = ge_identity(); }
+    if (shift) p = ge_madd(p, load_niels(shift), false);
+    if (out_enc) ristretto_encode(out_enc + (size_t)i * 32, p);
+    if (out_niels) store_niels(&out_niels[i], ge_to_niels(p));
+}
+// out = a + b (compressed in/out): pedersen_ops.rs:56-59 add_rp_vec
+__global__ void __launch_bounds__(TPB) k_add_points(u32 count, const uint8_t *a, const uint8_t *b, uint8_t *out, u32 *status) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    ge p, q;
+    if (!ristretto_decode(p, a + (size_t)i * 32)) { atomicOr(status, 4u); p = ge_identity(); }
+    if (!ristretto_decode(q, b + (size_t)i * 32)) { atomicOr(status, 4u); q = ge_identity(); }
+    ristretto_encode(out + (size_t)i * 32, ge_add(p, q));
+}
+// bulletproofs verify_multiple: g_k = -z - a s_k ; h_k = z + y^-k (zz z^j 2^i - b s_k^-1)  -> canonical [g | h]
+__global__ void __launch_bounds__(TPB) k_verify_scalars(u32 n, u32 m, u32 lgN, const ChunkParams *cp, const sc *two_pow, sc *out) {
+    u32 c = blockIdx.y;
+    size_t N = (size_t)n * m;
+    u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= N) return;
+    const ChunkParams &P = cp[c];
+    sc s = sc_one_mont(), sinv = sc_one_mont();
+    for (u32 q = 0; q < lgN; q++) {
+        bool bit = (k >> (lgN - 1 - q)) & 1;    // challenge q (creation order) <-> bit lgN-1-q
+        s = sc_montmul(s, bit ? P.u[q] : P.uinv[q]);
+        sinv = sc_montmul(sinv, bit ? P.uinv[q] : P.u[q]);
+    }
+    u32 j = k / n, i = k % n;
+    sc g = sc_neg(sc_add(P.z, sc_montmul(P.a_fin, s)));
+    sc zj2 = sc_montmul(sc_montmul(P.zz, sc_pow_tab(P.zpow2, j)), two_pow[i]);
+    sc h = sc_add(P.z, sc_montmul(sc_pow_tab(P.yinvpow2, k), sc_sub(zj2, sc_montmul(P.b_fin, sinv))));
+    sc *o = out + (size_t)c * 2 * N;
+    store_sc(&o[k], sc_from_mont(g));
+    store_sc(&o[N + k], sc_from_mont(h));
+}
+// value-commitment scalars c * zz * z^j  -> canonical, written at out[chunk*stride + j]
+__global__ void __launch_bounds__(TPB) k_vscalars(u32 m, const ChunkParams *cp, sc *out, size_t stride) {
+    u32 c = blockIdx.y;
+    u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    store_sc(&out[c * stride + j], sc_from_mont(sc_montmul(cp[c].c_zz, sc_pow_tab(cp[c].zpow2, j))));
+}
+
+// ================================================================ micro-benchmark: field multiply rate
+__global__ void __launch_bounds__(TPB) k_bench_femul(u32 iters, const fe *in, fe *out) {
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    fe a = in[t & 255], b = in[(t + 1) & 255];
+    for (u32 i = 0; i < iters; i++) { a = fe_mul(a, b); b = fe_sq(b); a = fe_mul(a, b); b = fe_mul(b, a); }
+    out[t] = fe_add(a, b);
+}
+
+}  // namespace rofl

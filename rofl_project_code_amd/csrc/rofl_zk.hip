@@ -1,0 +1,1041 @@
+// librofl_zk.so: C ABI (include/rofl_zk.h) + host orchestration of the HIP kernels.
+//
+// Host responsibilities: Merlin transcripts (sequential), final window/bit combination of MSM partial
+// sums (a 256-step Horner chain that would serialise a single GPU lane), fixed-base multiples of B and
+// B_blinding, proof (de)serialisation.  Everything proportional to d * n_bits runs in kernels.hpp.
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/rofl_zk.h"
+#include "kernels.hpp"
+
+using namespace rofl;
+
+namespace {
+
+// ---------------------------------------------------------------- error plumbing
+thread_local std::string g_err;
+int fail(int code, const std::string &msg) { g_err = msg; return code; }
+struct HipErr { hipError_t e; const char *what; };
+#define HIPCHK(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) throw HipErr{e__, #x}; } while (0)
+
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// ---------------------------------------------------------------- host scalar helpers (canonical <-> Montgomery)
+sc h_mont(const sc &canon) { return sc_to_mont(canon); }
+sc h_canon(const sc &mont) { return sc_from_mont(mont); }
+sc h_mul(const sc &a, const sc &b) { return sc_mul_plain(a, b); }          // canonical * canonical
+sc h_inv(const sc &canon) { return h_canon(sc_invert_mont(h_mont(canon))); }
+bool sc_is_canonical_bytes(const uint8_t *b) { sc s = sc_frombytes(b); return !sc_geq_l(s.v); }
+
+// width-2 NAF (digits -1,0,1) of a canonical scalar; returns index of the highest non-zero digit (-1 if zero)
+int sc_naf(int8_t out[256], const sc &k) {
+    u32 x[9]; for (int i = 0; i < 8; i++) x[i] = k.v[i]; x[8] = 0;
+    int top = -1;
+    for (int pos = 0; pos < 256; pos++) {
+        int d = 0;
+        if (x[0] & 1) {
+            d = 2 - (int)(x[0] & 3);          // 1 -> +1, 3 -> -1
+            if (d > 0) { x[0] -= 1; }
+            else { u64 c = 1; for (int i = 0; i < 9 && c; i++) { c += x[i]; x[i] = (u32)c; c >>= 32; } }
+            top = pos;
+        }
+        out[pos] = (int8_t)d;
+        for (int i = 0; i < 8; i++) x[i] = (x[i] >> 1) | (x[i + 1] << 31);
+        x[8] >>= 1;
+    }
+    return top;
+}
+
+// ---------------------------------------------------------------- host point helpers
+struct HostTables { std::vector<niels> B, Bb; ge base, bblind; };
+
+void build_fixed_table(std::vector<niels> &tab, ge P) {
+    tab.resize(64 * 8);
+    for (int w = 0; w < 64; w++) {
+        ge acc = P;
+        for (int e = 0; e < 8; e++) {
+            tab[w * 8 + e] = ge_to_niels(acc);
+            acc = ge_add(acc, P);
+        }
+        for (int k = 0; k < 4; k++) P = ge_double(P);
+    }
+}
+ge h_fixed_mul(const std::vector<niels> &tab, const sc &k_canon) {
+    ge acc = ge_identity();
+    int carry = 0;
+    for (int i = 0; i < 64; i++) {
+        int v = (int)((k_canon.v[i >> 3] >> ((i & 7) * 4)) & 15) + carry;
+        carry = (v + 8) >> 4;
+        int d = v - (carry << 4);
+        if (d > 0) acc = ge_madd(acc, tab[i * 8 + d - 1], false);
+        else if (d < 0) acc = ge_madd(acc, tab[i * 8 - d - 1], true);
+    }
+    return acc;
+}
+
+// ---------------------------------------------------------------- device buffers
+struct DevBuf {
+    void *p = nullptr; size_t cap = 0;
+    void *ensure(size_t bytes) {
+        if (bytes > cap) {
+            if (p) HIPCHK(hipFree(p));
+            p = nullptr; cap = 0;
+            size_t want = bytes + bytes / 8 + 256;
+            HIPCHK(hipMalloc(&p, want)); cap = want;
+        }
+        return p;
+    }
+    template <class T> T *as(size_t count) { return reinterpret_cast<T *>(ensure(count * sizeof(T))); }
+};
+struct PinBuf {
+    void *p = nullptr; size_t cap = 0;
+    void *ensure(size_t bytes) {
+        if (bytes > cap) {
+            if (p) HIPCHK(hipHostFree(p));
+            p = nullptr; cap = 0;
+            HIPCHK(hipHostMalloc(&p, bytes + 256, hipHostMallocDefault)); cap = bytes + 256;
+        }
+        return p;
+    }
+    template <class T> T *as(size_t count) { return reinterpret_cast<T *>(ensure(count * sizeof(T))); }
+};
+
+struct Timing {
+    bool enabled = false;
+    rofl_timing_t t{};
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> acc_ev, fold_ev;
+    hipEvent_t first = nullptr, last = nullptr;
+    std::vector<hipEvent_t> pool; size_t used = 0;
+    hipEvent_t get() {
+        if (used == pool.size()) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); pool.push_back(e); }
+        return pool[used++];
+    }
+    void reset() { t = rofl_timing_t{}; acc_ev.clear(); fold_ev.clear(); used = 0; first = last = nullptr; }
+};
+
+struct Ctx {
+    int device = 0;
+    bool inited = false;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    HostTables ht;
+    niels *d_tabB = nullptr, *d_tabBb = nullptr;
+    sc *d_two_pow = nullptr;
+    std::map<std::pair<size_t, size_t>, niels *> gens;   // (n, m) -> [G(N) | H(N)]
+    int fold_t = 4;
+    Timing tm;
+    // workspace
+    DevBuf cp, sL, sR, party, Scanon, vshift, blind, Vbytes, Cbytes, status, partial, partial2, scpart, a, b, yinv,
+        SL, SR, msm_cnt, msm_off, msm_cur, msm_sorted, msm_buckets, msm_S[2], msm_C[2], msm_probs, foldprobs, naf,
+        gbuf[2], aux_pts, aux_scal, vscal, tmp_in, tmp_in2, tmp_out, vals, uni, stream_buf;
+    PinBuf h_cp, h_res, h_part, h_misc, h_misc2;
+
+    void init() {
+        if (inited) return;
+        HIPCHK(hipSetDevice(device));
+        HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        // PedersenGens::default(): B = Ristretto basepoint, B_blinding = hash_from_bytes::<Sha3_512>(B)
+        static const uint8_t Bc[32] = {0xe2, 0xf2, 0xae, 0x0a, 0x6a, 0xbc, 0x4e, 0x71, 0xa8, 0x84, 0xa9, 0x61, 0xc5, 0x00, 0x51, 0x5f,
+                                       0x58, 0xe3, 0x0b, 0x6a, 0xa5, 0x82, 0xdd, 0x8d, 0xb6, 0xa6, 0x59, 0x45, 0xe0, 0x8d, 0x2d, 0x76};
+        ristretto_decode(ht.base, Bc);
+        uint8_t h[64]; sha3_512(h, Bc, 32);
+        ht.bblind = ristretto_from_uniform(h);
+        build_fixed_table(ht.B, ht.base);
+        build_fixed_table(ht.Bb, ht.bblind);
+        HIPCHK(hipMalloc(&d_tabB, sizeof(niels) * 512));
+        HIPCHK(hipMalloc(&d_tabBb, sizeof(niels) * 512));
+        HIPCHK(hipMemcpy(d_tabB, ht.B.data(), sizeof(niels) * 512, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d_tabBb, ht.Bb.data(), sizeof(niels) * 512, hipMemcpyHostToDevice));
+        sc tp[64]; sc two = h_mont(sc_from_u64(2)); tp[0] = sc_one_mont();
+        for (int i = 1; i < 64; i++) tp[i] = sc_montmul(tp[i - 1], two);
+        HIPCHK(hipMalloc(&d_two_pow, sizeof(tp)));
+        HIPCHK(hipMemcpy(d_two_pow, tp, sizeof(tp), hipMemcpyHostToDevice));
+        if (const char *e = getenv("ROFL_FOLD_T")) { int v = atoi(e); if (v >= 1 && v <= 6) fold_t = v; }
+        inited = true;
+    }
+};
+
+std::mutex g_ctx_mu;
+std::map<int, Ctx *> g_ctxs;
+int g_device = 0;
+Ctx &ctx() {
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    auto it = g_ctxs.find(g_device);
+    if (it == g_ctxs.end()) { Ctx *c = new Ctx(); c->device = g_device; it = g_ctxs.emplace(g_device, c).first; }
+    return *it->second;
+}
+
+inline dim3 grid1(size_t n, u32 y = 1) { return dim3((unsigned)((n + TPB - 1) / TPB), y, 1); }
+unsigned lg2u(size_t x) { unsigned r = 0; while (((size_t)1 << r) < x) r++; return r; }
+bool is_pow2(size_t x) { return x && !(x & (x - 1)); }
+size_t next_pow2(size_t val) { if (val == 1) return 1; size_t n = val - 1; while ((n & (n - 1)) != 0) n &= n - 1; return n << 1; }
+
+// ---------------------------------------------------------------- generators
+niels *get_gens(Ctx &C, size_t n, size_t m) {
+    auto key = std::make_pair(n, m);
+    auto it = C.gens.find(key);
+    if (it != C.gens.end()) return it->second;
+    size_t N = n * m;
+    niels *tbl; HIPCHK(hipMalloc(&tbl, sizeof(niels) * 2 * N));
+    uint8_t *uni = C.uni.as<uint8_t>(2 * N * 64);
+    hipLaunchKernelGGL(k_gens_xof, grid1(2 * m), dim3(TPB), 0, C.stream, (u32)n, (u32)m, uni);
+    hipLaunchKernelGGL(k_gens_map, grid1(2 * N), dim3(TPB), 0, C.stream, (u32)(2 * N), uni, tbl);
+    HIPCHK(hipStreamSynchronize(C.stream));
+    C.gens[key] = tbl;
+    return tbl;
+}
+
+// ---------------------------------------------------------------- MSM driver
+struct MsmPlan { u32 c, W, B, levels; };
+MsmPlan msm_plan(size_t n) {
+    MsmPlan p;
+    if (n >= (1u << 17)) p.c = 16; else if (n >= (1u << 13)) p.c = 13; else if (n >= (1u << 9)) p.c = 10; else if (n >= 64) p.c = 7; else p.c = 4;
+    if (const char *e = getenv("ROFL_MSM_C")) { int v = atoi(e); if (v == 4 || v == 7 || v == 10 || v == 13 || v == 16) p.c = (u32)v; }
+    p.W = (254 + p.c - 1) / p.c;
+    p.B = 1u << (p.c - 1);
+    p.levels = (p.c - 1) / 3;
+    return p;
+}
+// results[p] = sum_i scal[p][i] * pts[p][i]   (all problems have n terms).  Synchronises the stream.
+void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge> &results) {
+    size_t np = probs.size();
+    MsmPlan P = msm_plan(n);
+    size_t PW = np * P.W;
+    MsmProb *d_probs = C.msm_probs.as<MsmProb>(np);
+    MsmProb *h_probs = C.h_misc.as<MsmProb>(np);
+    for (size_t i = 0; i < np; i++) h_probs[i] = probs[i];
+    HIPCHK(hipMemcpyAsync(d_probs, h_probs, sizeof(MsmProb) * np, hipMemcpyHostToDevice, C.stream));
+    u32 *cnt = C.msm_cnt.as<u32>(PW * P.B), *off = C.msm_off.as<u32>(PW * P.B), *cur = C.msm_cur.as<u32>(PW * P.B);
+    u32 *sorted = C.msm_sorted.as<u32>(PW * n);
+    ge *buckets = C.msm_buckets.as<ge>(PW * P.B);
+    HIPCHK(hipMemsetAsync(cnt, 0, sizeof(u32) * PW * P.B, C.stream));
+    hipLaunchKernelGGL(k_msm_count, grid1(n, (u32)np), dim3(TPB), 0, C.stream, (u32)n, P.c, P.W, d_probs, cnt);
+    hipLaunchKernelGGL(k_msm_scan, dim3((unsigned)PW), dim3(TPB), 0, C.stream, P.B, cnt, off, cur);
+    hipLaunchKernelGGL(k_msm_scatter, grid1(n, (u32)np), dim3(TPB), 0, C.stream, (u32)n, P.c, P.W, d_probs, cur, sorted);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (C.tm.enabled) { e0 = C.tm.get(); e1 = C.tm.get(); HIPCHK(hipEventRecord(e0, C.stream)); }
+    hipLaunchKernelGGL(k_msm_accumulate, grid1((size_t)P.W * P.B, (u32)np), dim3(TPB), 0, C.stream, (u32)n, P.c, P.W, d_probs, cnt, off, sorted, buckets);
+    if (C.tm.enabled) { HIPCHK(hipEventRecord(e1, C.stream)); C.tm.acc_ev.push_back({e0, e1}); C.tm.t.msm_accumulate_launches++; }
+    // reduction tree
+    const ge *S_in = buckets; const ge *C_in = nullptr;
+    u32 E = P.B, nb = 0;
+    for (u32 lv = 0; lv < P.levels; lv++) {
+        u32 E8 = E / 8;
+        ge *S_out = C.msm_S[lv & 1].as<ge>(PW * E8);
+        ge *C_out = C.msm_C[lv & 1].as<ge>(PW * (size_t)(nb + 3) * E8);
+        hipLaunchKernelGGL(k_msm_reduce_level, grid1((size_t)E8 * (1 + nb), (u32)PW), dim3(TPB), 0, C.stream, E, nb, S_in, C_in, S_out, C_out);
+        S_in = S_out; C_in = C_out; E = E8; nb += 3;
+    }
+    // E == 1: S_in [PW], C_in [PW][c-1]
+    size_t per = 1 + nb;
+    ge *h = C.h_res.as<ge>(PW * per);
+    HIPCHK(hipMemcpyAsync(h, S_in, sizeof(ge) * PW, hipMemcpyDeviceToHost, C.stream));
+    HIPCHK(hipMemcpyAsync(h + PW, C_in, sizeof(ge) * PW * nb, hipMemcpyDeviceToHost, C.stream));
+    HIPCHK(hipStreamSynchronize(C.stream));
+    double t0 = now_ms();
+    results.resize(np);
+    for (size_t p = 0; p < np; p++) {
+        ge acc = ge_identity(); bool started = false;
+        for (int w = (int)P.W - 1; w >= 0; w--) {
+            size_t pw = p * P.W + w;
+            for (int l = (int)P.c - 1; l >= 0; l--) {
+                if (started) acc = ge_double(acc);
+                if (l <= (int)P.c - 2) { acc = ge_add(acc, h[PW + pw * nb + l]); started = true; }
+                if (l == 0) { acc = ge_add(acc, h[pw]); started = true; }
+            }
+        }
+        results[p] = acc;
+    }
+    C.tm.t.host_ms += now_ms() - t0;
+}
+
+// ---------------------------------------------------------------- transcript helpers
+void tr_append_point(Merlin &t, const char *label, const ge &p, uint8_t *enc_out) {
+    uint8_t e[32]; ristretto_encode(e, p); t.append(label, e, 32); if (enc_out) memcpy(enc_out, e, 32);
+}
+void fill_pow2(sc *tab, sc base_mont, int count) { tab[0] = base_mont; for (int i = 1; i < count; i++) tab[i] = sc_montmul(tab[i - 1], tab[i - 1]); }
+
+sc sum_partials(const sc *p, size_t count, size_t stride, size_t which) {
+    sc acc = sc_zero();
+    for (size_t i = 0; i < count; i++) acc = sc_add(acc, p[i * stride + which]);
+    return acc;
+}
+
+// ================================================================ prover (bulletproofs RangeProof::prove_multiple)
+// P chunks of m values each; vshift [P][m] (device), blind_canon [P][m] (device).
+// Outputs: proofs (host, P*plen), V bytes (host, P*m*32).
+void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const u64 *d_vshift, const sc *d_blind,
+                  const rofl_nonce_t *nonce, u64 nonce_base0, const uint8_t *h_V /* [P][m][32] host */, uint8_t *proofs_out) {
+    size_t N = n * m; unsigned lgN = lg2u(N);
+    size_t plen = 32 * (9 + 2 * (size_t)lgN);
+    niels *tbl = get_gens(C, n, m);
+    ChunkParams *h_cp = C.h_cp.as<ChunkParams>(P);
+    ChunkParams *d_cp = C.cp.as<ChunkParams>(P);
+    memset(h_cp, 0, sizeof(ChunkParams) * P);
+    u64 per = (u64)m * (2 * n + 4);
+    for (size_t c = 0; c < P; c++) h_cp[c].nonce_base = nonce_base0 + c * per;
+    HIPCHK(hipMemcpyAsync(d_cp, h_cp, sizeof(ChunkParams) * P, hipMemcpyHostToDevice, C.stream));
+    // nonces
+    NonceSeed seed{}; const uint8_t *d_stream = nullptr; u64 stream_scalars = 0;
+    if (nonce->mode == 1) memcpy(seed.w, nonce->seed, 32);
+    else {
+        stream_scalars = nonce->stream_scalars;
+        uint8_t *sb = C.stream_buf.as<uint8_t>(stream_scalars * 64 + 64);
+        HIPCHK(hipMemcpyAsync(sb, nonce->stream, stream_scalars * 64, hipMemcpyHostToDevice, C.stream));
+        d_stream = sb;
+    }
+    sc *sL = C.sL.as<sc>(P * N), *sR = C.sR.as<sc>(P * N), *party = C.party.as<sc>(P * 4 * m), *Scanon = C.Scanon.as<sc>(P * 2 * N);
+    hipLaunchKernelGGL(k_nonce_expand, grid1(per, (u32)P), dim3(TPB), 0, C.stream, (u32)n, (u32)m, nonce->mode, seed, d_stream, stream_scalars, d_cp, sL, sR, party, Scanon);
+    // A partials
+    ge *partial = C.partial.as<ge>(P * m);
+    hipLaunchKernelGGL(k_bitcommit, grid1(m, (u32)P), dim3(TPB), 0, C.stream, (u32)n, (u32)m, d_vshift, tbl, partial);
+    u32 nblkA = (u32)std::min<size_t>(16, (m + TPB - 1) / TPB);
+    ge *partial2 = C.partial2.as<ge>(P * nblkA);
+    hipLaunchKernelGGL(k_point_sum, dim3(nblkA, (u32)P), dim3(TPB), TPB * sizeof(ge), C.stream, partial, (u32)m, partial2);
+    u32 nblkS = (u32)std::min<size_t>(16, (m + TPB - 1) / TPB);
+    sc *scpart = C.scpart.as<sc>(P * 64 * 3);
+    hipLaunchKernelGGL(k_party_sums, dim3(nblkS, (u32)P), dim3(TPB), 0, C.stream, (u32)m, 0, d_cp, party, d_blind, scpart);
+    ge *h_A = C.h_part.as<ge>(P * nblkA);
+    sc *h_sc = C.h_misc2.as<sc>(P * 64 * 3);
+    HIPCHK(hipMemcpyAsync(h_A, partial2, sizeof(ge) * P * nblkA, hipMemcpyDeviceToHost, C.stream));
+    HIPCHK(hipMemcpyAsync(h_sc, scpart, sizeof(sc) * P * nblkS * 3, hipMemcpyDeviceToHost, C.stream));
+    // S = <sL,G> + <sR,H> + s_bl * Bb
+    std::vector<MsmProb> probs(P); std::vector<ge> res;
+    for (size_t c = 0; c < P; c++) probs[c] = MsmProb{tbl, Scanon + c * 2 * N};
+    C.tm.t.msm_terms += P * 2 * N;
+    msm_run(C, probs, 2 * N, res);
+
+    double th = now_ms();
+    std::vector<Merlin> tr; tr.reserve(P);
+    std::vector<sc> a_bl(P), s_bl(P), y(P), z(P), zz(P), x(P), w(P);
+    for (size_t c = 0; c < P; c++) {
+        uint8_t *o = proofs_out + c * plen;
+        tr.emplace_back(label, strlen(label));
+        Merlin &t = tr[c];
+        t.append("dom-sep", (const uint8_t *)"rangeproof v1", 13);
+        t.append_u64("n", n); t.append_u64("m", m);
+        for (size_t j = 0; j < m; j++) t.append("V", h_V + (c * m + j) * 32, 32);
+        a_bl[c] = h_canon(sum_partials(h_sc + c * nblkS * 3, nblkS, 3, 0));
+        s_bl[c] = h_canon(sum_partials(h_sc + c * nblkS * 3, nblkS, 3, 1));
+        ge A = h_fixed_mul(C.ht.Bb, a_bl[c]);
+        for (u32 k = 0; k < nblkA; k++) A = ge_add(A, h_A[c * nblkA + k]);
+        ge S = ge_add(res[c], h_fixed_mul(C.ht.Bb, s_bl[c]));
+        tr_append_point(t, "A", A, o); tr_append_point(t, "S", S, o + 32);
+        y[c] = t.challenge_scalar("y"); z[c] = t.challenge_scalar("z");
+        zz[c] = h_mul(z[c], z[c]);
+        ChunkParams &cp = h_cp[c];
+        cp.y = h_mont(y[c]); cp.z = h_mont(z[c]); cp.zz = h_mont(zz[c]);
+        cp.yinv = h_mont(h_inv(y[c]));
+        fill_pow2(cp.ypow2, cp.y, MAX_LG); fill_pow2(cp.yinvpow2, cp.yinv, MAX_LG); fill_pow2(cp.zpow2, cp.z, MAX_LG);
+    }
+    C.tm.t.host_ms += now_ms() - th;
+    HIPCHK(hipMemcpyAsync(d_cp, h_cp, sizeof(ChunkParams) * P, hipMemcpyHostToDevice, C.stream));
+    u32 nblkT = (u32)std::min<size_t>(64, (N + TPB - 1) / TPB);
+    sc *tpart = C.tmp_out.as<sc>(P * 64 * 3);
+    hipLaunchKernelGGL(k_poly_t, dim3(nblkT, (u32)P), dim3(TPB), 0, C.stream, (u32)n, (u32)m, d_cp, d_vshift, sL, sR, C.d_two_pow, tpart);
+    hipLaunchKernelGGL(k_party_sums, dim3(nblkS, (u32)P), dim3(TPB), 0, C.stream, (u32)m, 1, d_cp, party, d_blind, scpart);
+    sc *h_t = C.h_part.as<sc>(P * 64 * 3);
+    HIPCHK(hipMemcpyAsync(h_t, tpart, sizeof(sc) * P * nblkT * 3, hipMemcpyDeviceToHost, C.stream));
+    HIPCHK(hipMemcpyAsync(h_sc, scpart, sizeof(sc) * P * nblkS * 3, hipMemcpyDeviceToHost, C.stream));
+    HIPCHK(hipStreamSynchronize(C.stream));
+    th = now_ms();
+    for (size_t c = 0; c < P; c++) {
+        uint8_t *o = proofs_out + c * plen;
+        Merlin &t = tr[c];
+        sc t0 = h_canon(sum_partials(h_t + c * nblkT * 3, nblkT, 3, 0));
+        sc t1 = h_canon(sum_partials(h_t + c * nblkT * 3, nblkT, 3, 1));
+        sc t2 = h_canon(sum_partials(h_t + c * nblkT * 3, nblkT, 3, 2));
+        sc t1_bl = h_canon(sum_partials(h_sc + c * nblkS * 3, nblkS, 3, 0));
+        sc t2_bl = h_canon(sum_partials(h_sc + c * nblkS * 3, nblkS, 3, 1));
+        sc zvbl = h_canon(sum_partials(h_sc + c * nblkS * 3, nblkS, 3, 2));
+        ge T1 = ge_add(h_fixed_mul(C.ht.B, t1), h_fixed_mul(C.ht.Bb, t1_bl));
+        ge T2 = ge_add(h_fixed_mul(C.ht.B, t2), h_fixed_mul(C.ht.Bb, t2_bl));
+        tr_append_point(t, "T_1", T1, o + 64); tr_append_point(t, "T_2", T2, o + 96);
+        x[c] = t.challenge_scalar("x");
+        sc xx = h_mul(x[c], x[c]);
+        sc t_x = sc_add(sc_add(t0, h_mul(t1, x[c])), h_mul(t2, xx));
+        sc t_x_bl = sc_add(sc_add(zvbl, h_mul(t1_bl, x[c])), h_mul(t2_bl, xx));
+        sc e_bl = sc_add(a_bl[c], h_mul(s_bl[c], x[c]));
+        t.append_scalar("t_x", t_x); t.append_scalar("t_x_blinding", t_x_bl); t.append_scalar("e_blinding", e_bl);
+        sc_tobytes(o + 128, t_x); sc_tobytes(o + 160, t_x_bl); sc_tobytes(o + 192, e_bl);
+        w[c] = t.challenge_scalar("w");
+        h_cp[c].x = h_mont(x[c]);
+        // InnerProductProof::create
+        t.append("dom-sep", (const uint8_t *)"ipp v1", 6);
+        t.append_u64("n", N);
+    }
+    C.tm.t.host_ms += now_ms() - th;
+    HIPCHK(hipMemcpyAsync(d_cp, h_cp, sizeof(ChunkParams) * P, hipMemcpyHostToDevice, C.stream));
+    sc *a = C.a.as<sc>(P * N), *b = C.b.as<sc>(P * N), *yinvpow = C.yinv.as<sc>(P * N);
+    hipLaunchKernelGGL(k_lr_vec, grid1(N, (u32)P), dim3(TPB), 0, C.stream, (u32)n, (u32)m, d_cp, d_vshift, sL, sR, C.d_two_pow, a, b, yinvpow);
+
+    // ---- IPP rounds with lazily folded generators
+    size_t n_g = N; unsigned r = 0;
+    std::vector<const niels *> cur(P, tbl);
+    std::vector<std::vector<sc>> pu(P), pui(P);    // pending challenges (Montgomery)
+    int gsel = 0;
+    for (unsigned round = 0; round < lgN; round++) {
+        size_t n_k = n_g >> r, nh = n_k / 2;
+        for (size_t c = 0; c < P; c++) {
+            ChunkParams &cp = h_cp[c];
+            for (u32 h = 0; h < (1u << r); h++) {
+                sc g = sc_one_mont(), hh = sc_one_mont();
+                for (unsigned q = 0; q < r; q++) {
+                    bool bit = (h >> (r - 1 - q)) & 1;
+                    g = sc_montmul(g, bit ? pu[c][q] : pui[c][q]);
+                    hh = sc_montmul(hh, bit ? pui[c][q] : pu[c][q]);
+                }
+                cp.stabG[h] = g; cp.stabH[h] = hh;
+            }
+        }
+        HIPCHK(hipMemcpyAsync(d_cp, h_cp, sizeof(ChunkParams) * P, hipMemcpyHostToDevice, C.stream));
+        sc *SL = C.SL.as<sc>(P * 2 * n_g), *SR = C.SR.as<sc>(P * 2 * n_g);
+        hipLaunchKernelGGL(k_ipp_scalars, grid1(n_g, (u32)P), dim3(TPB), 0, C.stream, (u32)n_g, (u32)n_k, d_cp, a, b, N, yinvpow, N, SL, SR);
+        u32 nblkI = (u32)std::min<size_t>(32, (nh + TPB - 1) / TPB);
+        sc *ipart = C.tmp_out.as<sc>(P * 64 * 3);
+        hipLaunchKernelGGL(k_ipp_inner, dim3(nblkI, (u32)P), dim3(TPB), 0, C.stream, (u32)nh, a, b, N, ipart);
+        sc *h_ip = C.h_part.as<sc>(P * 64 * 3);
+        HIPCHK(hipMemcpyAsync(h_ip, ipart, sizeof(sc) * P * nblkI * 2, hipMemcpyDeviceToHost, C.stream));
+        std::vector<MsmProb> pr(2 * P);
+        for (size_t c = 0; c < P; c++) { pr[2 * c] = MsmProb{cur[c], SL + c * 2 * n_g}; pr[2 * c + 1] = MsmProb{cur[c], SR + c * 2 * n_g}; }
+        C.tm.t.msm_terms += P * 2 * n_g;
+        msm_run(C, pr, 2 * n_g, res);
+        th = now_ms();
+        for (size_t c = 0; c < P; c++) {
+            uint8_t *o = proofs_out + c * plen + 7 * 32 + 64 * round;
+            sc cL = h_canon(sum_partials(h_ip + c * nblkI * 2, nblkI, 2, 0));
+            sc cR = h_canon(sum_partials(h_ip + c * nblkI * 2, nblkI, 2, 1));
+            ge L = ge_add(res[2 * c], h_fixed_mul(C.ht.B, h_mul(cL, w[c])));
+            ge R = ge_add(res[2 * c + 1], h_fixed_mul(C.ht.B, h_mul(cR, w[c])));
+            tr_append_point(tr[c], "L", L, o); tr_append_point(tr[c], "R", R, o + 32);
+            sc u = tr[c].challenge_scalar("u");
+            sc um = h_mont(u), uim = sc_invert_mont(um);
+            h_cp[c].u[0] = um; h_cp[c].uinv[0] = uim;
+            pu[c].push_back(um); pui[c].push_back(uim);
+        }
+        C.tm.t.host_ms += now_ms() - th;
+        HIPCHK(hipMemcpyAsync(d_cp, h_cp, sizeof(ChunkParams) * P, hipMemcpyHostToDevice, C.stream));
+        hipLaunchKernelGGL(k_ipp_fold_ab, grid1(nh, (u32)P), dim3(TPB), 0, C.stream, (u32)nh, d_cp, a, b, N);
+        r++;
+        bool last = (round + 1 == lgN);
+        if (!last && (r == (unsigned)C.fold_t)) {
+            // materialise: new[i] = sum_h s_h * cur[h*n_new + i]
+            size_t n_new = n_g >> r; u32 nsrc = 1u << r;
+            th = now_ms();
+            int8_t *h_naf = C.h_misc.as<int8_t>(2 * P * nsrc * 256);
+            FoldProb *h_fp = C.h_misc2.as<FoldProb>(2 * P);
+            niels *gnew = C.gbuf[gsel].as<niels>(P * 2 * n_new);
+            int top = 0;
+            for (size_t c = 0; c < P; c++) {
+                sc yn = sc_one_mont();                       // y^-(h*n_new), stepping by y^-n_new
+                sc ystep = sc_one_mont();
+                { size_t e = n_new; int bidx = 0; while (e) { if (e & 1) ystep = sc_montmul(ystep, h_cp[c].yinvpow2[bidx]); e >>= 1; bidx++; } }
+                for (u32 h = 0; h < nsrc; h++) {
+                    sc g = sc_one_mont(), hh = sc_one_mont();
+                    for (unsigned q = 0; q < r; q++) {
+                        bool bit = (h >> (r - 1 - q)) & 1;
+                        g = sc_montmul(g, bit ? pu[c][q] : pui[c][q]);
+                        hh = sc_montmul(hh, bit ? pui[c][q] : pu[c][q]);
+                    }
+                    hh = sc_montmul(hh, yn);
+                    yn = sc_montmul(yn, ystep);
+                    int t1 = sc_naf(h_naf + ((2 * c) * nsrc + h) * 256, h_canon(g));
+                    int t2 = sc_naf(h_naf + ((2 * c + 1) * nsrc + h) * 256, h_canon(hh));
+                    top = std::max(top, std::max(t1, t2));
+                }
+                h_fp[2 * c] = FoldProb{cur[c], gnew + c * 2 * n_new};
+                h_fp[2 * c + 1] = FoldProb{cur[c] + n_g, gnew + c * 2 * n_new + n_new};
+            }
+            C.tm.t.host_ms += now_ms() - th;
+            int8_t *d_naf = C.naf.as<int8_t>(2 * P * nsrc * 256);
+            FoldProb *d_fp = C.foldprobs.as<FoldProb>(2 * P);
+            HIPCHK(hipMemcpyAsync(d_naf, h_naf, 2 * P * nsrc * 256, hipMemcpyHostToDevice, C.stream));
+            HIPCHK(hipMemcpyAsync(d_fp, h_fp, sizeof(FoldProb) * 2 * P, hipMemcpyHostToDevice, C.stream));
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (C.tm.enabled) { e0 = C.tm.get(); e1 = C.tm.get(); HIPCHK(hipEventRecord(e0, C.stream)); }
+            hipLaunchKernelGGL(k_fold_gens, dim3((unsigned)((n_new + 63) / 64), (u32)(2 * P)), dim3(64), 0, C.stream, (u32)n_new, nsrc, top, d_fp, d_naf);
+            if (C.tm.enabled) { HIPCHK(hipEventRecord(e1, C.stream)); C.tm.fold_ev.push_back({e0, e1}); C.tm.t.fold_launches++; C.tm.t.fold_point_reads += (uint64_t)2 * P * n_g; }
+            HIPCHK(hipStreamSynchronize(C.stream));   // h_naf / h_fp staging reused next round
+            for (size_t c = 0; c < P; c++) { cur[c] = gnew + c * 2 * n_new; pu[c].clear(); pui[c].clear(); }
+            // the y^-j weighting of H persists: true H[j] = y^-j * Hc[j] for the new array as well
+            n_g = n_new; r = 0; gsel ^= 1;
+        }
+    }
+    // a[0], b[0]
+    sc *h_ab = C.h_part.as<sc>(2 * P);
+    for (size_t c = 0; c < P; c++) {
+        HIPCHK(hipMemcpyAsync(h_ab + 2 * c, a + c * N, sizeof(sc), hipMemcpyDeviceToHost, C.stream));
+        HIPCHK(hipMemcpyAsync(h_ab + 2 * c + 1, b + c * N, sizeof(sc), hipMemcpyDeviceToHost, C.stream));
+    }
+    HIPCHK(hipStreamSynchronize(C.stream));
+    for (size_t c = 0; c < P; c++) {
+        uint8_t *o = proofs_out + c * plen + 7 * 32 + 64 * lgN;
+        sc_tobytes(o, h_canon(h_ab[2 * c])); sc_tobytes(o + 32, h_canon(h_ab[2 * c + 1]));
+    }
+}
+
+// ================================================================ verifier (RangeProof::verify_multiple)
+// P chunks; proofs host [P][plen]; V bytes host [P][m][32]; V niels device [P][m].
+// results: ok[P] (0/1); returns error code (format etc.)
+sc verifier_c(const uint8_t seed[32], u64 idx) {
+    const u64 dom[2] = {0x2f6b7a2d6c666f72ULL, 0x31762f6379667276ULL};  // "rofl-zk/" "vrfyc/v1"
+    u64 sd[4]; memcpy(sd, seed, 32);
+    u64 st[25]; shake256_seeded_block(st, dom, sd, idx);
+    sc lo, hi;
+    for (int i = 0; i < 4; i++) { lo.v[2 * i] = (u32)st[i]; lo.v[2 * i + 1] = (u32)(st[i] >> 32); hi.v[2 * i] = (u32)st[4 + i]; hi.v[2 * i + 1] = (u32)(st[4 + i] >> 32); }
+    return sc_from_wide(lo, hi);
+}
+
+int verify_chunks(Ctx &C, const char *label, size_t gens_capacity, size_t P, size_t n, size_t m, const uint8_t *proofs, size_t plen,
+                  const uint8_t *h_V, const niels *d_Vniels, const uint8_t seed[32], const u64 *c_index, int *ok) {
+    for (size_t c = 0; c < P; c++) ok[c] = 0;
+    // RangeProof::from_bytes / InnerProductProof::from_bytes
+    if (plen % 32 != 0 || plen < 7 * 32) return ROFL_FORMAT_ERROR;
+    size_t ne = (plen - 7 * 32) / 32;
+    if (ne < 2 || (ne - 2) % 2 != 0) return ROFL_FORMAT_ERROR;
+    size_t lg = (ne - 2) / 2;
+    if (lg >= 32) return ROFL_FORMAT_ERROR;
+    for (size_t c = 0; c < P; c++) {
+        const uint8_t *p = proofs + c * plen;
+        if (!sc_is_canonical_bytes(p + 128) || !sc_is_canonical_bytes(p + 160) || !sc_is_canonical_bytes(p + 192) ||
+            !sc_is_canonical_bytes(p + 7 * 32 + 64 * lg) || !sc_is_canonical_bytes(p + 7 * 32 + 64 * lg + 32))
+            return ROFL_FORMAT_ERROR;
+    }
+    if (!(n == 8 || n == 16 || n == 32 || n == 64)) return ROFL_INVALID_BITSIZE;
+    if (gens_capacity < n) return ROFL_INVALID_GENS_LENGTH;
+    size_t N = n * m;
+    std::vector<char> dead(P, 0);
+    if (N != ((size_t)1 << lg)) return ROFL_OK;    // VerificationError for every chunk
+    niels *tbl = get_gens(C, n, m);
+    ChunkParams *h_cp = C.h_cp.as<ChunkParams>(P);
+    ChunkParams *d_cp = C.cp.as<ChunkParams>(P);
+    memset(h_cp, 0, sizeof(ChunkParams) * P);
+    size_t naux = m + 4 + 2 * lg;
+    uint8_t *h_auxc = C.h_misc.as<uint8_t>(P * (4 + 2 * lg) * 32);
+    sc *h_auxs = C.h_misc2.as<sc>(P * (4 + 2 * lg));
+    std::vector<sc> sB(P), sBb(P);
+    static const uint8_t zero32[32] = {0};
+    double th = now_ms();
+    for (size_t c = 0; c < P; c++) {
+        const uint8_t *p = proofs + c * plen; const uint8_t *ipp = p + 7 * 32;
+        Merlin t(label, strlen(label));
+        t.append("dom-sep", (const uint8_t *)"rangeproof v1", 13);
+        t.append_u64("n", n); t.append_u64("m", m);
+        for (size_t j = 0; j < m; j++) t.append("V", h_V + (c * m + j) * 32, 32);
+        // validate_and_append_point rejects the identity encoding
+        bool bad = false;
+        for (int i = 0; i < 4; i++) if (!memcmp(p + 32 * i, zero32, 32)) bad = true;
+        for (size_t k = 0; k < 2 * lg; k++) if (!memcmp(ipp + 32 * k, zero32, 32)) bad = true;
+        if (bad) { dead[c] = 1; }
+        t.append("A", p, 32); t.append("S", p + 32, 32);
+        sc y = t.challenge_scalar("y"), z = t.challenge_scalar("z");
+        t.append("T_1", p + 64, 32); t.append("T_2", p + 96, 32);
+        sc x = t.challenge_scalar("x");
+        sc t_x = sc_frombytes(p + 128), t_x_bl = sc_frombytes(p + 160), e_bl = sc_frombytes(p + 192);
+        t.append("t_x", p + 128, 32); t.append("t_x_blinding", p + 160, 32); t.append("e_blinding", p + 192, 32);
+        sc w = t.challenge_scalar("w");
+        sc cc = verifier_c(seed, c_index[c]);
+        t.append("dom-sep", (const uint8_t *)"ipp v1", 6);
+        t.append_u64("n", N);
+        ChunkParams &cp = h_cp[c];
+        sc a = sc_frombytes(ipp + 64 * lg), b = sc_frombytes(ipp + 64 * lg + 32);
+        std::vector<sc> u(lg), ui(lg);
+        for (size_t k = 0; k < lg; k++) {
+            t.append("L", ipp + 64 * k, 32); t.append("R", ipp + 64 * k + 32, 32);
+            u[k] = t.challenge_scalar("u");
+            cp.u[k] = h_mont(u[k]); cp.uinv[k] = sc_invert_mont(cp.u[k]);
+            ui[k] = h_canon(cp.uinv[k]);
+        }
+        sc zz = h_mul(z, z);
+        cp.y = h_mont(y); cp.z = h_mont(z); cp.zz = h_mont(zz); cp.x = h_mont(x);
+        cp.yinv = sc_invert_mont(cp.y);
+        fill_pow2(cp.ypow2, cp.y, MAX_LG); fill_pow2(cp.yinvpow2, cp.yinv, MAX_LG); fill_pow2(cp.zpow2, cp.z, MAX_LG);
+        cp.a_fin = h_mont(a); cp.b_fin = h_mont(b);
+        cp.c_zz = h_mont(h_mul(cc, zz));
+        // aux points and scalars: A S T1 T2 L* R*
+        uint8_t *ac = h_auxc + c * (4 + 2 * lg) * 32; sc *as = h_auxs + c * (4 + 2 * lg);
+        memcpy(ac, p, 128);
+        as[0] = sc_one_plain(); as[1] = x; as[2] = h_mul(cc, x); as[3] = h_mul(as[2], x);
+        for (size_t k = 0; k < lg; k++) {
+            memcpy(ac + 128 + 32 * k, ipp + 64 * k, 32); memcpy(ac + 128 + 32 * (lg + k), ipp + 64 * k + 32, 32);
+            as[4 + k] = h_mul(u[k], u[k]); as[4 + lg + k] = h_mul(ui[k], ui[k]);
+        }
+        // B_blinding: -e_bl - c t_x_bl ; B: w (t_x - a b) + c (delta - t_x)
+        sBb[c] = sc_neg(sc_add(e_bl, h_mul(cc, t_x_bl)));
+        // sum_{i<N} y^i = prod_b (1 + y^(2^b)) for N = 2^lg ; likewise for 2^n and z^m
+        auto geo = [&](const sc *pow2tab, unsigned bits) { sc acc = sc_one_mont(); for (unsigned q = 0; q < bits; q++) acc = sc_montmul(acc, sc_add(sc_one_mont(), pow2tab[q])); return h_canon(acc); };
+        sc sum_y = geo(cp.ypow2, (unsigned)lg);
+        sc sum_z = geo(cp.zpow2, lg2u(m));
+        sc twom[MAX_LG]; fill_pow2(twom, h_mont(sc_from_u64(2)), 8);
+        sc sum_2 = geo(twom, lg2u(n));
+        sc delta = sc_sub(h_mul(sc_sub(z, zz), sum_y), h_mul(h_mul(h_mul(zz, z), sum_2), sum_z));
+        sB[c] = sc_add(h_mul(w, sc_sub(t_x, h_mul(a, b))), h_mul(cc, sc_sub(delta, t_x)));
+    }
+    C.tm.t.host_ms += now_ms() - th;
+    HIPCHK(hipMemcpyAsync(d_cp, h_cp, sizeof(ChunkParams) * P, hipMemcpyHostToDevice, C.stream));
+    sc *gh = C.SL.as<sc>(P * 2 * N);
+    hipLaunchKernelGGL(k_verify_scalars, grid1(N, (u32)P), dim3(TPB), 0, C.stream, (u32)n, (u32)m, (u32)lg, d_cp, C.d_two_pow, gh);
+    // aux arrays
+    niels *aux_pts = C.aux_pts.as<niels>(P * naux);
+    sc *aux_scal = C.aux_scal.as<sc>(P * naux);
+    uint8_t *d_auxc = C.tmp_in.as<uint8_t>(P * (4 + 2 * lg) * 32);
+    niels *d_auxn = C.tmp_in2.as<niels>(P * (4 + 2 * lg));
+    u32 *status = C.status.as<u32>(4);
+    HIPCHK(hipMemsetAsync(status, 0, 16, C.stream));
+    HIPCHK(hipMemcpyAsync(d_auxc, h_auxc, P * (4 + 2 * lg) * 32, hipMemcpyHostToDevice, C.stream));
+    hipLaunchKernelGGL(k_decode, grid1(P * (4 + 2 * lg)), dim3(TPB), 0, C.stream, (u32)(P * (4 + 2 * lg)), (u32)(P * (4 + 2 * lg)), d_auxc, (const niels *)nullptr, d_auxn, (uint8_t *)nullptr, status);
+    hipLaunchKernelGGL(k_vscalars, grid1(m, (u32)P), dim3(TPB), 0, C.stream, (u32)m, d_cp, aux_scal, naux);
+    for (size_t c = 0; c < P; c++) {
+        HIPCHK(hipMemcpyAsync(aux_pts + c * naux, d_Vniels + c * m, sizeof(niels) * m, hipMemcpyDeviceToDevice, C.stream));
+        HIPCHK(hipMemcpyAsync(aux_pts + c * naux + m, d_auxn + c * (4 + 2 * lg), sizeof(niels) * (4 + 2 * lg), hipMemcpyDeviceToDevice, C.stream));
+        HIPCHK(hipMemcpyAsync(aux_scal + c * naux + m, h_auxs + c * (4 + 2 * lg), sizeof(sc) * (4 + 2 * lg), hipMemcpyHostToDevice, C.stream));
+    }
+    u32 h_status = 0;
+    std::vector<MsmProb> pr(P); std::vector<ge> resA, resB;
+    for (size_t c = 0; c < P; c++) pr[c] = MsmProb{tbl, gh + c * 2 * N};
+    C.tm.t.msm_terms += P * 2 * N;
+    msm_run(C, pr, 2 * N, resA);
+    for (size_t c = 0; c < P; c++) pr[c] = MsmProb{aux_pts + c * naux, aux_scal + c * naux};
+    C.tm.t.msm_terms += P * naux;
+    msm_run(C, pr, naux, resB);
+    HIPCHK(hipMemcpy(&h_status, status, 4, hipMemcpyDeviceToHost));
+    th = now_ms();
+    for (size_t c = 0; c < P; c++) {
+        ge tot = ge_add(resA[c], resB[c]);
+        tot = ge_add(tot, h_fixed_mul(C.ht.B, sB[c]));
+        tot = ge_add(tot, h_fixed_mul(C.ht.Bb, sBb[c]));
+        ok[c] = (!dead[c] && ge_is_identity_ristretto(tot)) ? 1 : 0;
+    }
+    C.tm.t.host_ms += now_ms() - th;
+    if (h_status & 4u) {
+        // some proof point failed to decompress: upstream returns VerificationError for that proof.
+        // Re-check per chunk on the host to attribute the failure.
+        for (size_t c = 0; c < P; c++) {
+            const uint8_t *ac = h_auxc + c * (4 + 2 * lg) * 32;
+            for (size_t k = 0; k < 4 + 2 * lg; k++) { ge tmp; if (!ristretto_decode(tmp, ac + 32 * k)) ok[c] = 0; }
+        }
+    }
+    return ROFL_OK;
+}
+
+// ---------------------------------------------------------------- conversion32.rs helpers (host)
+u64 fix_max_bits(unsigned fp_bits) { return fp_bits >= 64 ? ~0ULL : ((1ULL << fp_bits) - 1); }
+int fix_from_abs_f32(float v, unsigned fp_bits, unsigned fp_frac, u64 *out) {
+    if (std::isnan(v)) return ROFL_NON_FINITE;
+    double x = std::fabs((double)v) * (double)(1ULL << fp_frac);
+    double lim = std::ldexp(1.0, (int)fp_bits);
+    if (std::isinf(x) || x >= lim) { *out = fix_max_bits(fp_bits); return 0; }
+    double k = std::nearbyint(x);
+    *out = (k >= lim) ? fix_max_bits(fp_bits) : (u64)k;
+    return 0;
+}
+float fix_to_f32(u64 k, unsigned fp_frac) { volatile float f = (float)k; return f / (float)(1ULL << fp_frac); }
+u64 read_from_bytes(const sc &s, unsigned fp_bits) { u64 r = (u64)s.v[0] | ((u64)s.v[1] << 32); return r & fix_max_bits(fp_bits); }
+int f32_to_sc(float v, unsigned fp_bits, unsigned fp_frac, sc *out) {
+    u64 k; int rc = fix_from_abs_f32(v, fp_bits, fp_frac, &k); if (rc) return rc;
+    sc s = sc_from_u64(k); *out = (v < 0.0f) ? sc_neg(s) : s; return 0;
+}
+float sc_to_f32(const sc &s, unsigned fp_bits, unsigned fp_frac) {
+    if ((s.v[7] >> 24) != 0) return -fix_to_f32(read_from_bytes(sc_neg(s), fp_bits), fp_frac);
+    return fix_to_f32(read_from_bytes(s, fp_bits), fp_frac);
+}
+void clip_bounds(size_t range, unsigned fp_bits, unsigned fp_frac, float *mn, float *mx) {
+    unsigned __int128 v = ((unsigned __int128)1 << (range - 1)) - 1;
+    *mx = fix_to_f32((u64)v & fix_max_bits(fp_bits), fp_frac); *mn = -*mx;
+}
+float l2_clip_bound(size_t range, unsigned fp_bits, unsigned fp_frac) {
+    unsigned __int128 v = ((unsigned __int128)1 << range) - 1;
+    return fix_to_f32((u64)v & fix_max_bits(fp_bits), fp_frac);
+}
+bool valid_fp(unsigned fp_bits, unsigned fp_frac) { return (fp_bits == 8 || fp_bits == 16 || fp_bits == 32 || fp_bits == 64) && fp_frac <= 12 && fp_frac < fp_bits; }
+
+void timing_begin(Ctx &C) {
+    C.tm.reset();
+    if (C.tm.enabled) { C.tm.first = C.tm.get(); C.tm.last = C.tm.get(); HIPCHK(hipEventRecord(C.tm.first, C.stream)); }
+}
+void timing_end(Ctx &C) {
+    if (!C.tm.enabled) return;
+    HIPCHK(hipEventRecord(C.tm.last, C.stream));
+    HIPCHK(hipEventSynchronize(C.tm.last));
+    float ms = 0; HIPCHK(hipEventElapsedTime(&ms, C.tm.first, C.tm.last)); C.tm.t.total_ms = ms;
+    for (auto &e : C.tm.acc_ev) { HIPCHK(hipEventElapsedTime(&ms, e.first, e.second)); C.tm.t.msm_accumulate_ms += ms; }
+    for (auto &e : C.tm.fold_ev) { HIPCHK(hipEventElapsedTime(&ms, e.first, e.second)); C.tm.t.fold_ms += ms; }
+}
+
+template <class F> int guarded(F f) {
+    try { return f(); }
+    catch (const HipErr &e) {
+        char buf[256]; snprintf(buf, sizeof buf, "HIP error %d (%s) in %s", (int)e.e, hipGetErrorString(e.e), e.what);
+        return fail(ROFL_HIP_ERROR + (int)e.e, buf);
+    }
+    catch (const std::exception &e) { return fail(ROFL_HIP_ERROR, std::string("exception: ") + e.what()); }
+}
+
+int create_impl(Ctx &C, const float *values, size_t d, const uint8_t *blind, size_t d_blind, size_t prove_range, size_t n_partition,
+                unsigned fp_bits, unsigned fp_frac, const rofl_nonce_t *nonce, uint8_t *proofs_out, size_t *plen_out, size_t *np_out, uint8_t *commits_out) {
+    if (d != d_blind) return fail(ROFL_WRONG_NUM_BLINDING, "WrongNumBlindingFactors");
+    if (!valid_fp(fp_bits, fp_frac) || d == 0 || n_partition == 0 || prove_range == 0 || prove_range > fp_bits || !nonce)
+        return fail(ROFL_BAD_PARAM, "bad parameter (the reference panics here)");
+    size_t dp = next_pow2(d);
+    size_t n_chunks = std::min(dp, n_partition), chunk = dp / n_chunks;
+    size_t P = (dp + chunk - 1) / chunk;
+    float mn, mx; clip_bounds(prove_range, fp_bits, fp_frac, &mn, &mx);
+    C.init();
+    timing_begin(C);
+    float *d_vals = C.vals.as<float>(d);
+    HIPCHK(hipMemcpyAsync(d_vals, values, sizeof(float) * d, hipMemcpyHostToDevice, C.stream));
+    u64 *vshift = C.vshift.as<u64>(dp);
+    sc *d_blind_buf = C.blind.as<sc>(dp);
+    HIPCHK(hipMemsetAsync(d_blind_buf, 0, sizeof(sc) * dp, C.stream));
+    HIPCHK(hipMemcpyAsync(d_blind_buf, blind, 32 * d, hipMemcpyHostToDevice, C.stream));
+    u32 *status = C.status.as<u32>(4);
+    HIPCHK(hipMemsetAsync(status, 0, 16, C.stream));
+    hipLaunchKernelGGL(k_quantize_shift, grid1(dp), dim3(TPB), 0, C.stream, d_vals, (u32)d, (u32)dp, (u32)prove_range, fp_bits, fp_frac, mn, mx, vshift, status);
+    u32 h_status = 0;
+    HIPCHK(hipMemcpyAsync(C.h_misc.as<u32>(4), status, 4, hipMemcpyDeviceToHost, C.stream));
+    HIPCHK(hipStreamSynchronize(C.stream));
+    h_status = *C.h_misc.as<u32>(4);
+    if (h_status & 1) return fail(ROFL_VALUE_OUT_OF_RANGE, "ValueOutOfRangeError");
+    if (h_status & 2) return fail(ROFL_NON_FINITE, "non-finite value (the reference panics in fixed::saturating_from_float)");
+    if (!is_pow2(chunk) || dp % chunk) return fail(ROFL_INVALID_AGGREGATION, "InvalidAggregation (the reference panics)");
+    if (!(prove_range == 8 || prove_range == 16 || prove_range == 32 || prove_range == 64)) return fail(ROFL_INVALID_BITSIZE, "InvalidBitsize");
+    if (nonce->mode == 0 && nonce->stream_scalars < P * chunk * (2 * prove_range + 4)) return fail(ROFL_NONCE_SHORT, "nonce stream too short");
+    // V_j and un-shifted commitments C_j = V_j - 2^(range-1) B   (range_proof_vec/mod.rs:96-99)
+    sc negoff = sc_neg(sc_from_u64(1ULL << (prove_range - 1)));
+    niels h_shift = ge_to_niels(h_fixed_mul(C.ht.B, negoff));
+    niels *d_shift = C.tmp_in.as<niels>(1);
+    HIPCHK(hipMemcpyAsync(d_shift, &h_shift, sizeof(niels), hipMemcpyHostToDevice, C.stream));
+    uint8_t *Vb = C.Vbytes.as<uint8_t>(dp * 32), *Cb = C.Cbytes.as<uint8_t>(dp * 32);
+    hipLaunchKernelGGL(k_commit, grid1(dp), dim3(TPB), 0, C.stream, (u32)dp, vshift, (const sc *)nullptr, d_blind_buf, C.d_tabB, C.d_tabBb, d_shift, Vb, Cb, (u32)d);
+    std::vector<uint8_t> hV(dp * 32);
+    HIPCHK(hipMemcpyAsync(hV.data(), Vb, dp * 32, hipMemcpyDeviceToHost, C.stream));
+    HIPCHK(hipMemcpyAsync(commits_out, Cb, d * 32, hipMemcpyDeviceToHost, C.stream));
+    prove_chunks(C, "RangeProof", P, prove_range, chunk, vshift, d_blind_buf, nonce, 0, hV.data(), proofs_out);
+    timing_end(C);
+    *plen_out = 32 * (9 + 2 * (size_t)lg2u(prove_range * chunk)); *np_out = P;
+    return ROFL_OK;
+}
+
+int verify_impl(Ctx &C, size_t n_clients, const uint8_t *const *proofs, size_t proof_len, size_t n_proofs, const uint8_t *const *commits,
+                size_t d, size_t prove_range, unsigned fp_bits, unsigned fp_frac, const uint8_t seed[32], int *ok_out) {
+    for (size_t i = 0; i < n_clients; i++) ok_out[i] = 0;
+    if (!valid_fp(fp_bits, fp_frac) || d == 0 || n_proofs == 0 || prove_range == 0 || prove_range > fp_bits || n_clients == 0)
+        return fail(ROFL_BAD_PARAM, "bad parameter (the reference panics here)");
+    size_t dp = next_pow2(d);
+    size_t chunk = dp / n_proofs;
+    if (chunk == 0) return fail(ROFL_BAD_PARAM, "more proofs than padded commitments (the reference panics in chunks(0))");
+    size_t n_chunks = (dp + chunk - 1) / chunk;
+    size_t nv = std::min(n_proofs, n_chunks);            // zip truncates (range_proof_vec/mod.rs:173-176)
+    if (dp % chunk) return fail(ROFL_BAD_PARAM, "ragged chunks are not supported");
+    C.init();
+    timing_begin(C);
+    // shift up by 2^(range-1) B, pad with identity, compress (:155-167)
+    niels h_shift = ge_to_niels(h_fixed_mul(C.ht.B, sc_from_u64(1ULL << (prove_range - 1))));
+    niels *d_shift = C.tmp_out.as<niels>(1);
+    HIPCHK(hipMemcpyAsync(d_shift, &h_shift, sizeof(niels), hipMemcpyHostToDevice, C.stream));
+    size_t tot = n_clients * dp;
+    uint8_t *d_in = C.Cbytes.as<uint8_t>(tot * 32);
+    uint8_t *d_enc = C.Vbytes.as<uint8_t>(tot * 32);
+    niels *d_vn = C.gbuf[0].as<niels>(tot);
+    u32 *status = C.status.as<u32>(4);
+    HIPCHK(hipMemsetAsync(status, 0, 16, C.stream));
+    std::vector<uint8_t> hV(tot * 32);
+    for (size_t i = 0; i < n_clients; i++) {
+        HIPCHK(hipMemcpyAsync(d_in + i * dp * 32, commits[i], d * 32, hipMemcpyHostToDevice, C.stream));
+        hipLaunchKernelGGL(k_decode, grid1(dp), dim3(TPB), 0, C.stream, (u32)dp, (u32)d, d_in + i * dp * 32, d_shift, d_vn + i * dp, d_enc + i * dp * 32, status);
+    }
+    HIPCHK(hipMemcpyAsync(hV.data(), d_enc, tot * 32, hipMemcpyDeviceToHost, C.stream));
+    u32 *h_st = C.h_misc.as<u32>(4);
+    HIPCHK(hipMemcpyAsync(h_st, status, 4, hipMemcpyDeviceToHost, C.stream));
+    HIPCHK(hipStreamSynchronize(C.stream));
+    if (*h_st & 4u) return fail(ROFL_FORMAT_ERROR, "commitment is not a valid Ristretto encoding");
+    // flatten (client, chunk) -> problem list
+    size_t P = n_clients * nv;
+    std::vector<uint8_t> pf(P * proof_len), Vh(P * chunk * 32);
+    std::vector<u64> cidx(P);
+    niels *d_vn2 = C.gbuf[1].as<niels>(P * chunk);
+    for (size_t i = 0; i < n_clients; i++)
+        for (size_t c = 0; c < nv; c++) {
+            size_t q = i * nv + c;
+            memcpy(&pf[q * proof_len], proofs[i] + c * proof_len, proof_len);
+            memcpy(&Vh[q * chunk * 32], &hV[(i * dp + c * chunk) * 32], chunk * 32);
+            HIPCHK(hipMemcpyAsync(d_vn2 + q * chunk, d_vn + i * dp + c * chunk, sizeof(niels) * chunk, hipMemcpyDeviceToDevice, C.stream));
+            cidx[q] = c;
+        }
+    std::vector<int> okc(P);
+    int rc = verify_chunks(C, "RangeProof", prove_range, P, prove_range, chunk, pf.data(), proof_len, Vh.data(), d_vn2, seed, cidx.data(), okc.data());
+    timing_end(C);
+    if (rc) return fail(rc, "proof rejected before verification (format / bitsize)");
+    for (size_t i = 0; i < n_clients; i++) { int r = 1; for (size_t c = 0; c < nv; c++) r &= okc[i * nv + c]; ok_out[i] = r; }
+    return ROFL_OK;
+}
+
+}  // namespace
+
+// ================================================================ C ABI
+extern "C" {
+
+int rofl_set_device(int device) { g_device = device; return guarded([&]() -> int { Ctx &C = ctx(); std::lock_guard<std::mutex> lk(C.mu); C.init(); return ROFL_OK; }); }
+int rofl_last_error(char *buf, size_t len) { if (!buf || !len) return ROFL_BAD_PARAM; snprintf(buf, len, "%s", g_err.c_str()); return ROFL_OK; }
+size_t rofl_next_pow2(size_t v) { return v ? next_pow2(v) : 0; }
+size_t rofl_rangeproof_chunks(size_t d, size_t n_partition) {
+    if (!d || !n_partition) return 0;
+    size_t dp = next_pow2(d), nc = std::min(dp, n_partition), chunk = dp / nc; return (dp + chunk - 1) / chunk;
+}
+size_t rofl_rangeproof_size(size_t n_bits, size_t d, size_t n_partition) {
+    if (!d || !n_partition) return 0;
+    size_t dp = next_pow2(d), nc = std::min(dp, n_partition), chunk = dp / nc; return 32 * (9 + 2 * (size_t)lg2u(n_bits * chunk));
+}
+size_t rofl_nonces_per_chunk(size_t n_bits, size_t m) { return m * (2 * n_bits + 4); }
+
+int rofl_bp_gens_prepare(size_t n_bits, size_t m) {
+    return guarded([&]() -> int { Ctx &C = ctx(); std::lock_guard<std::mutex> lk(C.mu); C.init(); if (!n_bits || !m) return fail(ROFL_BAD_PARAM, "bad parameter"); get_gens(C, n_bits, m); return ROFL_OK; });
+}
+int rofl_bp_gens_export(size_t n_bits, size_t m, uint8_t *G_out, uint8_t *H_out) {
+    return guarded([&]() -> int {
+        Ctx &C = ctx(); std::lock_guard<std::mutex> lk(C.mu); C.init();
+        if (!n_bits || !m) return fail(ROFL_BAD_PARAM, "bad parameter");
+        niels *tbl = get_gens(C, n_bits, m); size_t N = n_bits * m;
+        // encode through the commit path: decode-free -- use k_msm-free helper: copy niels back and encode on host
+        std::vector<niels> h(2 * N);
+        HIPCHK(hipMemcpy(h.data(), tbl, sizeof(niels) * 2 * N, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < 2 * N; i++) { ge p = ge_from_niels(h[i]); ristretto_encode((i < N ? G_out + 32 * i : H_out + 32 * (i - N)), p); }
+        return ROFL_OK;
+    });
+}
+
+int rofl_create_rangeproof(const float *values, size_t d, const uint8_t *blindings32, size_t d_blindings, size_t prove_range, size_t n_partition,
+                           unsigned fp_bits, unsigned fp_frac, const rofl_nonce_t *nonce, uint8_t *proofs_out, size_t *proof_len_out,
+                           size_t *n_proofs_out, uint8_t *commits_out) {
+    return guarded([&]() -> int { Ctx &C = ctx(); std::lock_guard<std::mutex> lk(C.mu);
+        return create_impl(C, values, d, blindings32, d_blindings, prove_range, n_partition, fp_bits, fp_frac, nonce, proofs_out, proof_len_out, n_proofs_out, commits_out); });
+}
+int rofl_verify_rangeproof(const uint8_t *proofs, size_t proof_len, size_t n_proofs, const uint8_t *commits32, size_t d, size_t prove_range,
+                           unsigned fp_bits, unsigned fp_frac, const uint8_t verifier_seed[32], int *ok_out) {
+    return guarded([&]() -> int { Ctx &C = ctx(); std::lock_guard<std::mutex> lk(C.mu);
+        return verify_impl(C, 1, &proofs, proof_len, n_proofs, &commits32, d, prove_range, fp_bits, fp_frac, verifier_seed, ok_out); });
+}
+int rofl_verify_rangeproof_batch(size_t n_clients, const uint8_t *const *proofs, size_t proof_len, size_t n_proofs, const uint8_t *const *commits32,
+                                 size_t d, size_t prove_range, unsigned fp_bits, unsigned fp_frac, const uint8_t verifier_seed[32], int *ok_out) {
+    return guarded([&]() -> int { Ctx &C = ctx(); std::lock_guard<std::mutex> lk(C.mu);
+        return verify_impl(C, n_clients, proofs, proof_len, n_proofs, commits32, d, prove_range, fp_bits, fp_frac, verifier_seed, ok_out); });
+}
+int rofl_clip_f32(const float *in, size_t d, size_t prove_range, unsigned fp_bits, unsigned fp_frac, float *out) {
+    if (!valid_fp(fp_bits, fp_frac) || prove_range == 0) return fail(ROFL_BAD_PARAM, "bad parameter");
+    float mn, mx; clip_bounds(prove_range, fp_bits, fp_frac, &mn, &mx);
+    for (size_t i = 0; i < d; i++) { float t = fmaxf(mn, in[i]); out[i] = fminf(mx, t); }
+    return ROFL_OK;
+}
+
+int rofl_create_rangeproof_l2(const float *values, size_t d, const uint8_t *blindings32, size_t d_blindings, size_t prove_range, size_t n_partition,
+                              unsigned fp_bits, unsigned fp_frac, const rofl_nonce_t *nonce, uint8_t *proof_out, size_t *proof_len_out, uint8_t commit_out[32]) {
+    return guarded([&]() -> int {
+        Ctx &C = ctx(); std::lock_guard<std::mutex> lk(C.mu);
+        if (d != d_blindings) return fail(ROFL_WRONG_NUM_BLINDING, "WrongNumBlindingFactors");
+        if (!valid_fp(fp_bits, fp_frac) || d == 0 || n_partition == 0 || prove_range == 0 || !nonce) return fail(ROFL_BAD_PARAM, "bad parameter (the reference panics here)");
+        float mn, mx; clip_bounds(prove_range, fp_bits, fp_frac, &mn, &mx);
+        for (size_t i = 0; i < d; i++) if (mn > values[i] || values[i] > mx) return fail(ROFL_VALUE_OUT_OF_RANGE, "ValueOutOfRangeError");
+        // l2_range_proof_vec/mod.rs:37-79: scalar sum of squares, the f32 shadow sum in the reference's
+        // serial left-to-right order (its result decides the OverflowError branch), and the blinding sum.
+        sc val = sc_zero(), bsum = sc_zero();
+        volatile float val_float = 0.0f; float shift = (float)(1u << fp_frac);
+        for (size_t i = 0; i < d; i++) {
+            sc s; int rc = f32_to_sc(values[i], fp_bits, fp_frac, &s); if (rc) return fail(rc, "non-finite value");
+            val = sc_add(val, h_mul(s, s));
+            volatile float q = sc_to_f32(s, fp_bits, fp_frac); volatile float qq = q * q; volatile float term = qq * shift;
+            val_float = (i == 0) ? term : val_float + term;
+            sc bl = sc_frombytes(blindings32 + 32 * i); if (sc_geq_l(bl.v)) bl = sc_from_mont(sc_to_mont(bl));
+            bsum = sc_add(bsum, bl);
+        }
+        float val_f = sc_to_f32(val, fp_bits, fp_frac);
+        volatile float diff = val_f - val_float;
+        if (std::fabs(diff) > 1.1920929e-07f) return fail(ROFL_OVERFLOW, "OverflowError");
+        if (val_f > l2_clip_bound(prove_range, fp_bits, fp_frac)) return fail(ROFL_NORM_OUT_OF_RANGE, "NormOutOfRangeError");
+        if (!(prove_range == 8 || prove_range == 16 || prove_range == 32 || prove_range == 64)) return fail(ROFL_INVALID_BITSIZE, "InvalidBitsize");
+        if (nonce->mode == 0 && nonce->stream_scalars < 2 * prove_range + 4) return fail(ROFL_NONCE_SHORT, "nonce stream too short");
+        C.init();
+        timing_begin(C);
+        u64 v = read_from_bytes(val, fp_bits);
+        u64 *vshift = C.vshift.as<u64>(1); sc *d_bl = C.blind.as<sc>(1);
+        HIPCHK(hipMemcpyAsync(vshift, &v, 8, hipMemcpyHostToDevice, C.stream));
+        HIPCHK(hipMemcpyAsync(d_bl, &bsum, 32, hipMemcpyHostToDevice, C.stream));
+        uint8_t *Vb = C.Vbytes.as<uint8_t>(32);
+        hipLaunchKernelGGL(k_commit, grid1(1), dim3(TPB), 0, C.stream, 1u, vshift, (const sc *)nullptr, d_bl, C.d_tabB, C.d_tabBb, (const niels *)nullptr, Vb, (uint8_t *)nullptr, 0u);
+        uint8_t hV[32];
+        HIPCHK(hipMemcpyAsync(hV, Vb, 32, hipMemcpyDeviceToHost, C.stream));
+        HIPCHK(hipStreamSynchronize(C.stream));
+        // BulletproofGens::new(64, 1), label "L2RangeProof" (l2_range_proof_vec/mod.rs:156-171): the first
+        // prove_range generators of party 0 are the same chain prefix.
+        prove_chunks(C, "L2RangeProof", 1, prove_range, 1, vshift, d_bl, nonce, 0, hV, proof_out);
+        timing_end(C);
+        memcpy(commit_out, hV, 32);
+        *proof_len_out = 32 * (9 + 2 * (size_t)lg2u(prove_range));
+        return ROFL_OK;
+    });
+}
+int rofl_verify_rangeproof_l2(const uint8_t *proof, size_t proof_len, const uint8_t commit[32], size_t prove_range, unsigned fp_bits, unsigned fp_frac,
+                              const uint8_t verifier_seed[32], int *ok_out) {
+    return guarded([&]() -> int {
+        Ctx &C = ctx(); std::lock_guard<std::mutex> lk(C.mu);
+        *ok_out = 0;
+        if (!valid_fp(fp_bits, fp_frac) || prove_range == 0) return fail(ROFL_BAD_PARAM, "bad parameter");
+        C.init();
+        timing_begin(C);
+        uint8_t *d_in = C.Cbytes.as<uint8_t>(32), *d_enc = C.Vbytes.as<uint8_t>(32);
+        niels *d_vn = C.gbuf[0].as<niels>(1);
+        u32 *status = C.status.as<u32>(4);
+        HIPCHK(hipMemsetAsync(status, 0, 16, C.stream));
+        HIPCHK(hipMemcpyAsync(d_in, commit, 32, hipMemcpyHostToDevice, C.stream));
+        hipLaunchKernelGGL(k_decode, grid1(1), dim3(TPB), 0, C.stream, 1u, 1u, d_in, (const niels *)nullptr, d_vn, d_enc, status);
+        uint8_t hV[32]; u32 st = 0;
+        HIPCHK(hipMemcpyAsync(hV, d_enc, 32, hipMemcpyDeviceToHost, C.stream));
+        HIPCHK(hipMemcpyAsync(&st, status, 4, hipMemcpyDeviceToHost, C.stream));
+        HIPCHK(hipStreamSynchronize(C.stream));
+        if (st & 4u) return fail(ROFL_FORMAT_ERROR, "commitment is not a valid Ristretto encoding");
+        u64 cidx = 0; int ok = 0;
+        int rc = verify_chunks(C, "L2RangeProof", 64, 1, prove_range, 1, proof, proof_len, hV, d_vn, verifier_seed, &cidx, &ok);
+        timing_end(C);
+        if (rc) return fail(rc, "proof rejected before verification (format / bitsize)");
+        *ok_out = ok;
+        return ROFL_OK;
+    });
+}
+
+int rofl_commit_vec(const uint8_t *values32, const uint8_t *blindings32, size_t d, uint8_t *out32) {
+    return guarded([&]() -> int {
+        Ctx &C = ctx(); std::lock_guard<std::mutex> lk(C.mu);
+        if (d == 0) return ROFL_OK;
+        C.init();
+        sc *dv = C.tmp_in.as<sc>(d); sc *db = blindings32 ? C.tmp_in2.as<sc>(d) : nullptr;
+        uint8_t *o = C.Cbytes.as<uint8_t>(d * 32);
+        HIPCHK(hipMemcpyAsync(dv, values32, 32 * d, hipMemcpyHostToDevice, C.stream));
+        if (db) HIPCHK(hipMemcpyAsync(db, blindings32, 32 * d, hipMemcpyHostToDevice, C.stream));
+        hipLaunchKernelGGL(k_commit, grid1(d), dim3(TPB), 0, C.stream, (u32)d, (const u64 *)nullptr, dv, db, C.d_tabB, C.d_tabBb, (const niels *)nullptr, (uint8_t *)nullptr, o, (u32)d);
+        HIPCHK(hipMemcpyAsync(out32, o, 32 * d, hipMemcpyDeviceToHost, C.stream));
+        HIPCHK(hipStreamSynchronize(C.stream));
+        return ROFL_OK;
+    });
+}
+int rofl_add_points_vec(const uint8_t *a32, const uint8_t *b32, size_t d, uint8_t *out32) {
+    return guarded([&]() -> int {
+        Ctx &C = ctx(); std::lock_guard<std::mutex> lk(C.mu);
+        if (d == 0) return ROFL_OK;
+        C.init();
+        uint8_t *da = C.tmp_in.as<uint8_t>(d * 32), *db = C.tmp_in2.as<uint8_t>(d * 32), *o = C.Cbytes.as<uint8_t>(d * 32);
+        u32 *status = C.status.as<u32>(4);
+        HIPCHK(hipMemsetAsync(status, 0, 16, C.stream));
+        HIPCHK(hipMemcpyAsync(da, a32, 32 * d, hipMemcpyHostToDevice, C.stream));
+        HIPCHK(hipMemcpyAsync(db, b32, 32 * d, hipMemcpyHostToDevice, C.stream));
+        hipLaunchKernelGGL(k_add_points, grid1(d), dim3(TPB), 0, C.stream, (u32)d, da, db, o, status);
+        u32 st = 0;
+        HIPCHK(hipMemcpyAsync(out32, o, 32 * d, hipMemcpyDeviceToHost, C.stream));
+        HIPCHK(hipMemcpyAsync(&st, status, 4, hipMemcpyDeviceToHost, C.stream));
+        HIPCHK(hipStreamSynchronize(C.stream));
+        if (st & 4u) return fail(ROFL_FORMAT_ERROR, "invalid Ristretto encoding");
+        return ROFL_OK;
+    });
+}
+int rofl_shift_points(const uint8_t *a32, size_t d, const uint8_t offset32[32], uint8_t *out32) {
+    return guarded([&]() -> int {
+        Ctx &C = ctx(); std::lock_guard<std::mutex> lk(C.mu);
+        if (d == 0) return ROFL_OK;
+        C.init();
+        ge off; if (!ristretto_decode(off, offset32)) return fail(ROFL_FORMAT_ERROR, "invalid Ristretto encoding");
+        niels hs = ge_to_niels(off);
+        niels *ds = C.tmp_in2.as<niels>(1);
+        uint8_t *da = C.tmp_in.as<uint8_t>(d * 32), *o = C.Cbytes.as<uint8_t>(d * 32);
+        u32 *status = C.status.as<u32>(4);
+        HIPCHK(hipMemsetAsync(status, 0, 16, C.stream));
+        HIPCHK(hipMemcpyAsync(ds, &hs, sizeof hs, hipMemcpyHostToDevice, C.stream));
+        HIPCHK(hipMemcpyAsync(da, a32, 32 * d, hipMemcpyHostToDevice, C.stream));
+        hipLaunchKernelGGL(k_decode, grid1(d), dim3(TPB), 0, C.stream, (u32)d, (u32)d, da, ds, (niels *)nullptr, o, status);
+        u32 st = 0;
+        HIPCHK(hipMemcpyAsync(out32, o, 32 * d, hipMemcpyDeviceToHost, C.stream));
+        HIPCHK(hipMemcpyAsync(&st, status, 4, hipMemcpyDeviceToHost, C.stream));
+        HIPCHK(hipStreamSynchronize(C.stream));
+        if (st & 4u) return fail(ROFL_FORMAT_ERROR, "invalid Ristretto encoding");
+        return ROFL_OK;
+    });
+}
+int rofl_f32_to_scalar_vec(const float *in, size_t d, unsigned fp_bits, unsigned fp_frac, uint8_t *out32) {
+    if (!valid_fp(fp_bits, fp_frac)) return fail(ROFL_BAD_PARAM, "bad parameter");
+    for (size_t i = 0; i < d; i++) { sc s; int rc = f32_to_sc(in[i], fp_bits, fp_frac, &s); if (rc) return fail(rc, "non-finite value"); sc_tobytes(out32 + 32 * i, s); }
+    return ROFL_OK;
+}
+int rofl_scalar_to_f32_vec(const uint8_t *in32, size_t d, unsigned fp_bits, unsigned fp_frac, float *out) {
+    if (!valid_fp(fp_bits, fp_frac)) return fail(ROFL_BAD_PARAM, "bad parameter");
+    for (size_t i = 0; i < d; i++) out[i] = sc_to_f32(sc_frombytes(in32 + 32 * i), fp_bits, fp_frac);
+    return ROFL_OK;
+}
+int rofl_get_clip_bounds(size_t range, unsigned fp_bits, unsigned fp_frac, float *mn, float *mx) {
+    if (!valid_fp(fp_bits, fp_frac) || range == 0 || range > 128) return fail(ROFL_BAD_PARAM, "bad parameter");
+    clip_bounds(range, fp_bits, fp_frac, mn, mx); return ROFL_OK;
+}
+int rofl_get_l2_clip_bounds(size_t range, unsigned fp_bits, unsigned fp_frac, float *out) {
+    if (!valid_fp(fp_bits, fp_frac) || range == 0 || range > 127) return fail(ROFL_BAD_PARAM, "bad parameter");
+    *out = l2_clip_bound(range, fp_bits, fp_frac); return ROFL_OK;
+}
+
+int rofl_set_timing(int enabled) { return guarded([&]() -> int { Ctx &C = ctx(); std::lock_guard<std::mutex> lk(C.mu); C.tm.enabled = enabled != 0; return ROFL_OK; }); }
+int rofl_last_timing(rofl_timing_t *out) { return guarded([&]() -> int { Ctx &C = ctx(); std::lock_guard<std::mutex> lk(C.mu); *out = C.tm.t; return ROFL_OK; }); }
+int rofl_bench_femul(unsigned iters, double *out) {
+    return guarded([&]() -> int {
+        Ctx &C = ctx(); std::lock_guard<std::mutex> lk(C.mu); C.init();
+        const u32 blocks = 256 * 8, threads = blocks * TPB;
+        fe *din, *dout; HIPCHK(hipMalloc(&din, sizeof(fe) * 256)); HIPCHK(hipMalloc(&dout, sizeof(fe) * threads));
+        std::vector<fe> h(256); for (int i = 0; i < 256; i++) for (int k = 0; k < 8; k++) h[i].v[k] = 0x9e3779b9u * (i * 8 + k + 1);
+        HIPCHK(hipMemcpy(din, h.data(), sizeof(fe) * 256, hipMemcpyHostToDevice));
+        hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+        hipLaunchKernelGGL(k_bench_femul, dim3(blocks), dim3(TPB), 0, C.stream, 8u, din, dout);
+        HIPCHK(hipEventRecord(e0, C.stream));
+        hipLaunchKernelGGL(k_bench_femul, dim3(blocks), dim3(TPB), 0, C.stream, iters, din, dout);
+        HIPCHK(hipEventRecord(e1, C.stream));
+        HIPCHK(hipEventSynchronize(e1));
+        float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        *out = (double)threads * iters * 4.0 / (ms * 1e-3);
+        HIPCHK(hipFree(din)); HIPCHK(hipFree(dout)); HIPCHK(hipEventDestroy(e0)); HIPCHK(hipEventDestroy(e1));
+        return ROFL_OK;
+    });
+}
+
+// ---- host-side self-tests of the shared host/device math (no GPU needed)
+int rofl_dbg_host_fe_mul(const uint8_t a[32], const uint8_t b[32], uint8_t out[32]) { fe_tobytes(out, fe_mul(fe_frombytes(a), fe_frombytes(b))); return 0; }
+int rofl_dbg_host_fe_ops(const uint8_t a[32], const uint8_t b[32], uint8_t oa[32], uint8_t os[32], uint8_t oq[32], uint8_t oi[32]) {
+    fe x = fe_frombytes(a), y = fe_frombytes(b);
+    // exercise the non-canonical range as well: add 2p-ish slack by doubling through fe_add
+    fe_tobytes(oa, fe_add(x, y)); fe_tobytes(os, fe_sub(x, y)); fe_tobytes(oq, fe_sq(x)); fe_tobytes(oi, fe_invert(x)); return 0;
+}
+int rofl_dbg_host_sc_mul(const uint8_t a[32], const uint8_t b[32], uint8_t out[32]) { sc_tobytes(out, h_mul(sc_frombytes(a), sc_frombytes(b))); return 0; }
+int rofl_dbg_host_sc_wide(const uint8_t in[64], uint8_t out[32]) { sc_tobytes(out, sc_from_wide(sc_frombytes(in), sc_frombytes(in + 32))); return 0; }
+int rofl_dbg_host_from_uniform(const uint8_t in[64], uint8_t out[32]) { ristretto_encode(out, ristretto_from_uniform(in)); return 0; }
+int rofl_dbg_host_scalarmult_base(const uint8_t k[32], int use_bb, uint8_t out[32]) {
+    static HostTables ht; static bool init = false; static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!init) {
+        static const uint8_t Bc[32] = {0xe2, 0xf2, 0xae, 0x0a, 0x6a, 0xbc, 0x4e, 0x71, 0xa8, 0x84, 0xa9, 0x61, 0xc5, 0x00, 0x51, 0x5f,
+                                       0x58, 0xe3, 0x0b, 0x6a, 0xa5, 0x82, 0xdd, 0x8d, 0xb6, 0xa6, 0x59, 0x45, 0xe0, 0x8d, 0x2d, 0x76};
+        ristretto_decode(ht.base, Bc); uint8_t h[64]; sha3_512(h, Bc, 32); ht.bblind = ristretto_from_uniform(h);
+        build_fixed_table(ht.B, ht.base); build_fixed_table(ht.Bb, ht.bblind); init = true;
+    }
+    ristretto_encode(out, h_fixed_mul(use_bb ? ht.Bb : ht.B, sc_frombytes(k))); return 0;
+}
+int rofl_dbg_host_decode_encode(const uint8_t in[32], uint8_t out[32]) { ge p; if (!ristretto_decode(p, in)) return ROFL_FORMAT_ERROR; ristretto_encode(out, ge_add(p, ge_identity())); return 0; }
+int rofl_dbg_host_merlin(const uint8_t *label, size_t label_len, const uint8_t *msg, size_t msg_len, uint8_t out[64]) {
+    Merlin t((const char *)label, label_len); t.append("msg", msg, msg_len); t.challenge_bytes("chal", out, 64); return 0;
+}
+int rofl_dbg_host_nonce(const uint8_t seed[32], uint64_t idx, uint8_t out[32]) {
+    const u64 dom[2] = {0x2f6b7a2d6c666f72ULL, 0x31762f65636e6f6eULL};
+    u64 sd[4]; memcpy(sd, seed, 32); u64 st[25]; shake256_seeded_block(st, dom, sd, idx);
+    sc lo, hi; for (int i = 0; i < 4; i++) { lo.v[2 * i] = (u32)st[i]; lo.v[2 * i + 1] = (u32)(st[i] >> 32); hi.v[2 * i] = (u32)st[4 + i]; hi.v[2 * i + 1] = (u32)(st[4 + i] >> 32); }
+    sc_tobytes(out, sc_from_wide(lo, hi)); return 0;
+}
+
+}  // extern "C"

@@ -136,7 +136,7 @@ struct Ctx {
     DevBuf cp, sL, sR, party, Scanon, vshift, blind, Vbytes, Cbytes, status, partial, partial2, scpart, a, b, yinv,
         SL, SR, msm_cnt, msm_off, msm_cur, msm_sorted, msm_buckets, msm_S[2], msm_C[2], msm_probs, foldprobs, naf,
         gbuf[2], aux_pts, aux_scal, vscal, tmp_in, tmp_in2, tmp_out, vals, uni, stream_buf;
-    PinBuf h_cp, h_res, h_part, h_misc, h_misc2;
+    PinBuf h_cp, h_res, h_part, h_misc, h_misc2, h_probs, h_auxc, h_auxs;
 
     void init() {
         if (inited) return;
@@ -210,7 +210,7 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
     MsmPlan P = msm_plan(n);
     size_t PW = np * P.W;
     MsmProb *d_probs = C.msm_probs.as<MsmProb>(np);
-    MsmProb *h_probs = C.h_misc.as<MsmProb>(np);
+    MsmProb *h_probs = C.h_probs.as<MsmProb>(np);
     for (size_t i = 0; i < np; i++) h_probs[i] = probs[i];
     HIPCHK(hipMemcpyAsync(d_probs, h_probs, sizeof(MsmProb) * np, hipMemcpyHostToDevice, C.stream));
     u32 *cnt = C.msm_cnt.as<u32>(PW * P.B), *off = C.msm_off.as<u32>(PW * P.B), *cur = C.msm_cur.as<u32>(PW * P.B);
@@ -519,8 +519,8 @@ int verify_chunks(Ctx &C, const char *label, size_t gens_capacity, size_t P, siz
     ChunkParams *d_cp = C.cp.as<ChunkParams>(P);
     memset(h_cp, 0, sizeof(ChunkParams) * P);
     size_t naux = m + 4 + 2 * lg;
-    uint8_t *h_auxc = C.h_misc.as<uint8_t>(P * (4 + 2 * lg) * 32);
-    sc *h_auxs = C.h_misc2.as<sc>(P * (4 + 2 * lg));
+    uint8_t *h_auxc = C.h_auxc.as<uint8_t>(P * (4 + 2 * lg) * 32);
+    sc *h_auxs = C.h_auxs.as<sc>(P * (4 + 2 * lg));
     std::vector<sc> sB(P), sBb(P);
     static const uint8_t zero32[32] = {0};
     double th = now_ms();

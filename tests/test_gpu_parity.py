@@ -1,0 +1,256 @@
+"""GPU parity tests: the HIP path (through the C ABI) vs the oracle on identical seeded inputs, vs the committed
+golden fixtures, plus size-independent properties at BASELINE.json's full sizes.  Integer work: bit-exact."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+import orc
+
+pytestmark = pytest.mark.gpu
+H = bytes.fromhex
+
+
+@pytest.fixture(scope="module")
+def R():
+    import rofl_project_code_amd as R
+    from rofl_project_code_amd import build
+    build.build()
+    R.set_device(0)     # fails loudly when there is no HIP device / library
+    return R
+
+
+def _inputs(R, rng, d, nb, fb, ff):
+    R.api.set_fp(fb, ff)
+    mn, mx = R.conversion32.get_clip_bounds(nb)
+    vals = rng.uniform(mn, mx, size=d).astype(np.float32)
+    vals = np.clip(vals, mn, np.nextafter(np.float32(mx), np.float32(0)))   # half-open, SURVEY 8(d)
+    return vals, orc.rand_scalars(rng, d)
+
+
+def test_generators_match_oracle(R):
+    for n, m in ((8, 4), (32, 2), (64, 1)):
+        G = np.zeros((n * m, 32), np.uint8); Hh = np.zeros((n * m, 32), np.uint8)
+        rc = R.lib().rofl_bp_gens_export(ctypes.c_size_t(n), ctypes.c_size_t(m), G.ctypes.data_as(ctypes.c_void_p), Hh.ctypes.data_as(ctypes.c_void_p))
+        assert rc == 0
+        oG, oH = orc.bp_gens(n, m)
+        assert (G == oG).all() and (Hh == oH).all()
+
+
+def test_generators_match_golden(R, prim):
+    G = np.zeros((9 * 6, 32), np.uint8); Hh = np.zeros((9 * 6, 32), np.uint8)
+    # gens_capacity 9 is not a proof size, but the chain prefix property makes it a valid table
+    assert R.lib().rofl_bp_gens_export(ctypes.c_size_t(9), ctypes.c_size_t(6), G.ctypes.data_as(ctypes.c_void_p), Hh.ctypes.data_as(ctypes.c_void_p)) == 0
+    for name, lst in prim["generators"].items():
+        arr = G if name[0] == "G" else Hh
+        for i, enc in enumerate(lst):
+            assert arr[int(name[1:]) * 9 + i].tobytes().hex() == enc
+
+
+@pytest.mark.parametrize("d,nb,P,fb,ff", [(1, 8, 1, 16, 7), (3, 16, 4, 16, 7), (100, 8, 4, 16, 7), (16, 32, 4, 32, 7),
+                                           (37, 16, 8, 16, 7), (300, 8, 4, 16, 7), (5, 64, 2, 64, 7), (200, 32, 1, 32, 12),
+                                           (1000, 32, 4, 32, 7), (5, 8, 3, 16, 7)])
+def test_create_bit_exact_vs_oracle(R, d, nb, P, fb, ff):
+    rng = np.random.default_rng(d * 1000 + nb)
+    vals, bl = _inputs(R, rng, d, nb, fb, ff)
+    seed = bytes(rng.integers(0, 256, 32, dtype=np.uint8))
+    pr, cm = R.range_proof_vec.create_rangeproof(vals, bl, nb, P, nonce=R.Nonce.seeded(seed))
+    rc, opr, ocm = orc.create_rangeproof(vals, bl, nb, P, fb, ff, seed=seed)
+    assert rc == 0
+    assert (cm == ocm).all(), "commitments differ"
+    assert pr.shape == opr.shape and (pr == opr).all(), "proof bytes differ"
+    # cross verification both ways, and tamper tests (Ok(false), not Err)
+    assert R.range_proof_vec.verify_rangeproof(pr, cm, nb, verifier_seed=b"\x01" * 32)
+    assert R.range_proof_vec.verify_rangeproof(opr, ocm, nb, verifier_seed=b"\x02" * 32)
+    assert orc.verify_rangeproof(pr, cm, nb, fb, ff) == (0, True)
+    bad = pr.copy(); bad[0, 5 * 32 + 3] ^= 1
+    assert not R.range_proof_vec.verify_rangeproof(bad, cm, nb, verifier_seed=b"\x03" * 32)
+    bad = pr.copy(); bad[-1, 7 * 32 + 40] ^= 4
+    assert not R.range_proof_vec.verify_rangeproof(bad, cm, nb, verifier_seed=b"\x03" * 32)
+    if d > 1:
+        badc = cm.copy(); badc[0] = cm[1]
+        if not (cm[0] == cm[1]).all():
+            assert not R.range_proof_vec.verify_rangeproof(pr, badc, nb, verifier_seed=b"\x04" * 32)
+
+
+def test_explicit_nonce_stream_mode(R):
+    rng = np.random.default_rng(5)
+    d, nb, P, fb, ff = 6, 8, 2, 16, 7
+    vals, bl = _inputs(R, rng, d, nb, fb, ff)
+    n_sc = 2 * 4 * (2 * nb + 4)
+    stream = rng.integers(0, 256, n_sc * 64, dtype=np.uint8).tobytes()
+    pr, cm = R.range_proof_vec.create_rangeproof(vals, bl, nb, P, nonce=R.Nonce.stream(stream))
+    rc, opr, ocm = orc.create_rangeproof(vals, bl, nb, P, fb, ff, stream=stream)
+    assert rc == 0 and (pr == opr).all() and (cm == ocm).all()
+    with pytest.raises(R.RoflError) as e:
+        R.range_proof_vec.create_rangeproof(vals, bl, nb, P, nonce=R.Nonce.stream(stream[:64 * 10]))
+    assert e.value.code == 12
+
+
+def test_golden_fixtures(R, golden_proofs):
+    for g in golden_proofs:
+        R.api.set_fp(g["fp_bits"], g["fp_frac"])
+        bl = np.frombuffer(H(g["blindings"]), np.uint8).reshape(-1, 32)
+        if g["kind"] == "linf":
+            pr, cm = R.range_proof_vec.create_rangeproof(g["values"], bl, g["prove_range"], g["n_partition"], nonce=R.Nonce.seeded(H(g["seed"])))
+            assert pr.tobytes().hex() == g["proofs"] and cm.tobytes().hex() == g["commits"]
+            assert R.range_proof_vec.verify_rangeproof(pr, cm, g["prove_range"], verifier_seed=b"\x07" * 32)
+        else:
+            pr, cm = R.l2_range_proof_vec.create_rangeproof_l2(g["values"], bl, g["prove_range"], g["n_partition"], nonce=R.Nonce.seeded(H(g["seed"])))
+            assert pr.tobytes().hex() == g["proofs"] and cm.tobytes().hex() == g["commits"]
+            assert R.l2_range_proof_vec.verify_rangeproof_l2(pr, cm, g["prove_range"], verifier_seed=b"\x07" * 32)
+
+
+def test_reference_semantic_tests_on_gpu(R, prim):
+    # range_proof_vec/mod.rs:318-332 and :369-399 through the C ABI
+    R.api.set_fp(16, 7)
+    ref = prim["reference_values_fp16_frac7"]
+    cms = []
+    rng = np.random.default_rng(9)
+    vecs = {"x": [0.25, 1.25, -1.5], "y": [-0.75, 1.25, -2.0], "z": [0.5, 1.25, -3.0]}
+    for name, vec in vecs.items():
+        pr, cm = R.range_proof_vec.create_rangeproof(vec, np.zeros((3, 32), np.uint8), 16, 4, nonce=R.Nonce.seeded(b"\x01" * 32))
+        assert [c.tobytes().hex() for c in cm] == ref[name]
+        assert R.range_proof_vec.verify_rangeproof(pr, cm, 16)
+        cms.append(cm)
+    tot = R.pedersen_ops.add_rp_vec_vec(cms)
+    assert [c.tobytes().hex() for c in tot] == ref["sum"]
+    # clipping + errors
+    with pytest.raises(R.RoflError) as e:
+        R.range_proof_vec.create_rangeproof([5.0], orc.rand_scalars(rng, 1), 8, 1)
+    assert e.value.code == 2
+    with pytest.raises(R.RoflError) as e:
+        R.range_proof_vec.create_rangeproof([0.5], orc.rand_scalars(rng, 2), 8, 1)
+    assert e.value.code == 1
+    with pytest.raises(R.RoflError) as e:
+        R.range_proof_vec.create_rangeproof([0.5] * 9, orc.rand_scalars(rng, 9), 8, 3)
+    assert e.value.code == 4
+    with pytest.raises(R.RoflError) as e:
+        R.range_proof_vec.create_rangeproof([float("nan")], orc.rand_scalars(rng, 1), 8, 1)
+    assert e.value.code == 10
+    with pytest.raises(R.RoflError) as e:
+        R.range_proof_vec.create_rangeproof([], np.zeros((0, 32), np.uint8), 8, 1)
+    assert e.value.code == 11
+    # wrap-around quirk at x == +fp_max with prove_range == N_BITS: same wrong commitment as the oracle
+    R.api.set_fp(32, 7)
+    v = [16777216.0]
+    bl = orc.rand_scalars(rng, 1)
+    pr, cm = R.range_proof_vec.create_rangeproof(v, bl, 32, 1, nonce=R.Nonce.seeded(b"\x02" * 32))
+    rc, opr, ocm = orc.create_rangeproof(v, bl, 32, 1, 32, 7, seed=b"\x02" * 32)
+    assert (pr == opr).all() and (cm == ocm).all()
+    R.api.set_fp(16, 7)
+
+
+def test_format_and_identity_rejections(R):
+    R.api.set_fp(16, 7)
+    rng = np.random.default_rng(2)
+    pr, cm = R.range_proof_vec.create_rangeproof([0.5, 0.25], orc.rand_scalars(rng, 2), 8, 2, nonce=R.Nonce.seeded(b"\x03" * 32))
+    bad = pr.copy(); bad[0, 4 * 32:5 * 32] = 0xFF
+    with pytest.raises(R.RoflError) as e:
+        R.range_proof_vec.verify_rangeproof(bad, cm, 8)
+    assert e.value.code == 5
+    with pytest.raises(R.RoflError) as e:
+        R.range_proof_vec.verify_rangeproof(pr[:, :-32], cm, 8)
+    assert e.value.code == 5
+    bad = pr.copy(); bad[1, 0:32] = 0
+    assert R.range_proof_vec.verify_rangeproof(bad, cm, 8) is False
+    bad = pr.copy(); bad[0, 32:64] = bytes([1] + [0] * 31)      # S does not decompress -> VerificationError -> false
+    assert R.range_proof_vec.verify_rangeproof(bad, cm, 8) is False
+    badc = cm.copy(); badc[0] = np.frombuffer(bytes([1] + [0] * 31), np.uint8)
+    with pytest.raises(R.RoflError) as e:
+        R.range_proof_vec.verify_rangeproof(pr, badc, 8)
+    assert e.value.code == 5
+
+
+def test_l2_path(R):
+    R.api.set_fp(16, 7)
+    rng = np.random.default_rng(4)
+    bl = orc.rand_scalars(rng, 3)
+    pr, cm = R.l2_range_proof_vec.create_rangeproof_l2([1.25, 0.5, 0.25], bl, 16, 4, nonce=R.Nonce.seeded(b"\x05" * 32))
+    rc, opr, ocm = orc.create_rangeproof_l2([1.25, 0.5, 0.25], bl, 16, 4, 16, 7, seed=b"\x05" * 32)
+    assert rc == 0 and (pr == opr).all() and (cm == ocm).all()
+    assert R.l2_range_proof_vec.verify_rangeproof_l2(pr, cm, 16)
+    assert orc.verify_rangeproof_l2(pr, cm, 16, 16, 7) == (0, True)
+    for vals, code in (([8.0], 8), ([6.0, 6.0], 8)):
+        with pytest.raises(R.RoflError) as e:
+            R.l2_range_proof_vec.create_rangeproof_l2(vals, orc.rand_scalars(rng, len(vals)), 16, 16)
+        assert e.value.code == orc.create_rangeproof_l2(vals, orc.rand_scalars(rng, len(vals)), 16, 16, 16, 7, seed=b"\x00" * 32)[0] == code
+    fake = orc.commit_vec(np.frombuffer((1 << 17).to_bytes(32, "little"), np.uint8).reshape(1, 32), orc.rand_scalars(rng, 1))[0]
+    assert R.l2_range_proof_vec.verify_rangeproof_l2(pr, fake, 16) is False
+    # BASELINE config 3 shape: d = 25 000 on the quantisation grid (bench l2rangeproof inputs), fp32
+    R.api.set_fp(32, 7)
+    d = 25000
+    vals = (rng.integers(-3, 4, size=d) / 128.0).astype(np.float32)
+    bl = orc.rand_scalars(rng, 64)
+    bl = np.tile(bl, (d // 64 + 1, 1))[:d]
+    pr, cm = R.l2_range_proof_vec.create_rangeproof_l2(vals, bl, 32, 4, nonce=R.Nonce.seeded(b"\x06" * 32))
+    rc, opr, ocm = orc.create_rangeproof_l2(vals, bl, 32, 4, 32, 7, seed=b"\x06" * 32)
+    assert rc == 0 and (pr == opr).all() and (cm == ocm).all()
+    assert R.l2_range_proof_vec.verify_rangeproof_l2(pr, cm, 32)
+    R.api.set_fp(16, 7)
+
+
+def test_pedersen_ops(R):
+    rng = np.random.default_rng(6)
+    s, b = orc.rand_scalars(rng, 70), orc.rand_scalars(rng, 70)
+    c1 = R.pedersen_ops.commit_vec(s, b)
+    assert (c1 == orc.commit_vec(s, b)).all()
+    c0 = R.pedersen_ops.commit_no_blinding_vec(s)
+    assert (c0 == orc.commit_vec(s, None)).all()
+    rc, osum = orc.add_points_vec(c1, c0)
+    assert (R.pedersen_ops.add_rp_vec(c1, c0) == osum).all()
+    sh = R.pedersen_ops.compute_shifted_values_rp(c1, c0[0])
+    rc, osh = orc.add_points_vec(c1, np.tile(c0[0], (70, 1)))
+    assert (sh == osh).all()
+    # homomorphism: commit(a, r) + commit(b, s) == commit(a + b, r + s)
+    def addsc(x, y):
+        return np.stack([np.frombuffer(((int.from_bytes(x[i].tobytes(), "little") + int.from_bytes(y[i].tobytes(), "little")) % orc.L_ORDER).to_bytes(32, "little"), np.uint8) for i in range(len(x))])
+    s2, b2 = orc.rand_scalars(rng, 70), orc.rand_scalars(rng, 70)
+    assert (R.pedersen_ops.add_rp_vec(c1, R.pedersen_ops.commit_vec(s2, b2)) == R.pedersen_ops.commit_vec(addsc(s, s2), addsc(b, b2))).all()
+    assert (R.pedersen_ops.commit_no_blinding_vec(np.zeros((4, 32), np.uint8)) == 0).all()     # zero_rp_vec
+
+
+def test_batch_verify(R):
+    R.api.set_fp(16, 7)
+    rng = np.random.default_rng(8)
+    prs, cms = [], []
+    for c in range(5):
+        vals, bl = _inputs(R, rng, 50, 8, 16, 7)
+        pr, cm = R.range_proof_vec.create_rangeproof(vals, bl, 8, 4, nonce=R.Nonce.seeded(bytes([c]) * 32))
+        prs.append(pr); cms.append(cm)
+    assert R.range_proof_vec.verify_rangeproof_batch(prs, cms, 8, verifier_seed=b"\x01" * 32) == [True] * 5
+    prs[3] = prs[3].copy(); prs[3][2, 100] ^= 1
+    cms[1] = cms[1].copy(); cms[1][7] = cms[1][8]
+    assert R.range_proof_vec.verify_rangeproof_batch(prs, cms, 8, verifier_seed=b"\x01" * 32) == [True, False, True, False, True]
+
+
+def test_full_size_properties_cfg2(R):
+    """BASELINE config 2 (d = 25 000, 32-bit, P = 4): the oracle would need minutes, so check the
+    size-independent properties: determinism, create -> verify round trip, tamper rejection, commitment
+    homomorphism against an independent small-kernel path, and oracle parity of a transcript prefix."""
+    R.api.set_fp(32, 7)
+    rng = np.random.default_rng(25000)
+    d, nb, P = 25000, 32, 4
+    vals, _ = _inputs(R, rng, d, nb, 32, 7)
+    raw = rng.integers(0, 256, size=(d, 32), dtype=np.uint8); raw[:, 31] &= 0x0F
+    bl = raw
+    pr, cm = R.range_proof_vec.create_rangeproof(vals, bl, nb, P, nonce=R.Nonce.seeded(b"\x11" * 32))
+    pr2, cm2 = R.range_proof_vec.create_rangeproof(vals, bl, nb, P, nonce=R.Nonce.seeded(b"\x11" * 32))
+    assert pr.shape == (4, 1440) and (pr == pr2).all() and (cm == cm2).all()
+    assert R.range_proof_vec.verify_rangeproof(pr, cm, nb, verifier_seed=b"\x01" * 32)
+    assert R.range_proof_vec.verify_rangeproof(pr, cm, nb, verifier_seed=b"\x02" * 32)
+    bad = pr.copy(); bad[2, 9 * 32 + 1] ^= 1
+    assert not R.range_proof_vec.verify_rangeproof(bad, cm, nb, verifier_seed=b"\x01" * 32)
+    badc = cm.copy(); badc[24999] = cm[0]
+    assert not R.range_proof_vec.verify_rangeproof(pr, badc, nb, verifier_seed=b"\x01" * 32)
+    # commitments == commit_vec(f32_to_scalar(values), blindings) (independent kernel path), and vs the oracle on a sample
+    sc = R.conversion32.f32_to_scalar_vec(vals)
+    assert (R.pedersen_ops.commit_vec(sc, bl) == cm).all()
+    idx = rng.choice(d, 64, replace=False)
+    assert (orc.commit_vec(sc[idx], bl[idx]) == cm[idx]).all()
+    # a different nonce seed changes the proof but not the commitments
+    pr3, cm3 = R.range_proof_vec.create_rangeproof(vals, bl, nb, P, nonce=R.Nonce.seeded(b"\x12" * 32))
+    assert (cm3 == cm).all() and not (pr3 == pr).all()
+    assert R.range_proof_vec.verify_rangeproof(pr3, cm3, nb, verifier_seed=b"\x01" * 32)
+    R.api.set_fp(16, 7)

@@ -1,0 +1,111 @@
+"""Pin the ORACLE against golden vectors from independent implementations (libsodium, hashlib, the
+published Merlin vector) -- tests/golden/gen_fixtures.py says where each section comes from."""
+import ctypes
+
+import numpy as np
+
+import orc
+
+H = bytes.fromhex
+sz = ctypes.c_size_t
+
+
+def buf(n=32):
+    return ctypes.create_string_buffer(n)
+
+
+def test_basepoint_multiples_and_scalarmult(prim):
+    o = orc.lib()
+    for k, enc in enumerate(prim["base_multiples"], start=1):
+        out = buf(); o.orc_ristretto_scalarmult_base(k.to_bytes(32, "little"), out)
+        assert out.raw == H(enc)
+    for v in prim["scalarmult"]:
+        out = buf(); assert o.orc_ristretto_scalarmult(H(v["k"]), H(v["p"]), out) == 0
+        assert out.raw == H(v["kp"])
+        o.orc_ristretto_scalarmult_base(H(v["k"]), out); assert out.raw == H(v["kB"])
+
+
+def test_from_uniform_add_and_encodings(prim):
+    o = orc.lib()
+    for v in prim["from_uniform"]:
+        out = buf(); o.orc_ristretto_from_uniform(H(v["in"]), out); assert out.raw == H(v["out"])
+    for v in prim["add"]:
+        out = buf(); assert o.orc_ristretto_add(H(v["p"]), H(v["q"]), out) == 0; assert out.raw == H(v["sum"])
+    assert any(not e["valid"] for e in prim["encodings"]) and any(e["valid"] for e in prim["encodings"])
+    for e in prim["encodings"]:
+        assert bool(o.orc_ristretto_is_valid(H(e["enc"]))) == e["valid"]
+
+
+def test_scalar_field(prim):
+    o = orc.lib()
+    for v in prim["scalars"]:
+        out = buf()
+        o.orc_sc_reduce_wide(H(v["wide"]), out); assert out.raw == H(v["reduced"])
+        o.orc_sc_mul(H(v["a"]), H(v["b"]), out); assert out.raw == H(v["mul"])
+        o.orc_sc_add(H(v["a"]), H(v["b"]), out); assert out.raw == H(v["add"])
+        o.orc_sc_invert(H(v["a"]), out); assert out.raw == H(v["inv"])
+
+
+def test_hashes(prim):
+    o = orc.lib()
+    for v in prim["hashes"]:
+        m = H(v["in"])
+        out = buf(64); o.orc_sha3_512(m, sz(len(m)), out); assert out.raw.hex() == v["sha3_512"]
+        out = buf(200); o.orc_shake256(m, sz(len(m)), out, sz(200)); assert out.raw.hex() == v["shake256_200"]
+
+
+def test_merlin(prim):
+    o = orc.lib()
+    t = buf(256)
+    o.orc_merlin_init(t, b"test protocol", sz(13))
+    o.orc_merlin_append(t, b"some label", b"some data", sz(9))
+    out = buf(32); o.orc_merlin_challenge(t, b"challenge", out, sz(32))
+    assert out.raw.hex() == prim["merlin_published"] == "d5a21972d0d5fe320c0d263fac7fffb8145aa640af6e9bca177c03c7efcf0615"
+    t = buf(256); o.orc_merlin_init(t, b"RangeProof", sz(10))
+    for step in prim["merlin_script"]:
+        m = H(step["append"]); o.orc_merlin_append(t, b"V", m, sz(len(m)))
+        if "challenge64" in step:
+            out = buf(64); o.orc_merlin_challenge(t, b"y", out, sz(64)); assert out.raw.hex() == step["challenge64"]
+
+
+def test_generators_and_pedersen(prim):
+    o = orc.lib()
+    B, Bb = buf(), buf(); o.orc_pedersen_gens(B, Bb)
+    assert B.raw.hex() == prim["pedersen"]["B"] and Bb.raw.hex() == prim["pedersen"]["B_blinding"]
+    G, Hh = orc.bp_gens(9, 6)
+    for name, lst in prim["generators"].items():
+        which, j = name[0], int(name[1:])
+        arr = G if which == "G" else Hh
+        for i, enc in enumerate(lst):
+            assert arr[j * 9 + i].tobytes().hex() == enc
+    # capacity independence: the first 8 generators of a capacity-64 chain equal those of capacity 8
+    G64, H64 = orc.bp_gens(64, 1); G8, H8 = orc.bp_gens(8, 1)
+    assert (G64[:8] == G8).all() and (H64[:8] == H8).all()
+
+
+def test_conversion_table(prim):
+    for v in prim["conversion"]:
+        rc, s = orc.f32_to_scalar(v["v"], v["fp_bits"], v["fp_frac"])
+        assert rc == 0 and s.tobytes().hex() == v["scalar"], v
+
+
+def test_reference_values_commit(prim):
+    # range_proof_vec/mod.rs:318-332: blinding 0 => commitment == f32_to_scalar(x) * B
+    ref = prim["reference_values_fp16_frac7"]
+    for name, vec in (("x", [0.25, 1.25, -1.5]), ("y", [-0.75, 1.25, -2.0]), ("z", [0.5, 1.25, -3.0])):
+        rc, pr, cm = orc.create_rangeproof(vec, np.zeros((3, 32), np.uint8), 16, 4, 16, 7, seed=b"\x01" * 32)
+        assert rc == 0
+        assert [c.tobytes().hex() for c in cm] == ref[name]
+
+
+def test_golden_proofs_reproduce(golden_proofs):
+    for g in golden_proofs:
+        bl = np.frombuffer(H(g["blindings"]), np.uint8).reshape(-1, 32)
+        if g["kind"] == "linf":
+            rc, pr, cm = orc.create_rangeproof(g["values"], bl, g["prove_range"], g["n_partition"], g["fp_bits"], g["fp_frac"], seed=H(g["seed"]))
+            assert rc == 0 and pr.tobytes().hex() == g["proofs"] and cm.tobytes().hex() == g["commits"]
+            assert orc.verify_rangeproof(pr, cm, g["prove_range"], g["fp_bits"], g["fp_frac"]) == (0, True)
+        else:
+            rc, pr, cm = orc.create_rangeproof_l2(g["values"], bl, g["prove_range"], g["n_partition"], g["fp_bits"], g["fp_frac"], seed=H(g["seed"]))
+            assert rc == 0 and pr.tobytes().hex() == g["proofs"] and cm.tobytes().hex() == g["commits"]
+            assert orc.verify_rangeproof_l2(pr, cm, g["prove_range"], g["fp_bits"], g["fp_frac"]) == (0, True)

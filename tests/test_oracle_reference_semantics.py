@@ -1,0 +1,108 @@
+"""The reference's own property tests, restated against the oracle.
+Citations: rofl_crypto/src/range_proof_vec/mod.rs, l2_range_proof_vec/mod.rs, conversion32.rs."""
+import numpy as np
+import pytest
+
+import orc
+
+FB, FF = 16, 7     # the reference's default build (fp.rs:125-139)
+rng = np.random.default_rng(11)
+
+
+def test_next_pow2():   # range_proof_vec/mod.rs:260-264
+    import ctypes
+    f = lambda v: orc.lib().orc_next_pow2(ctypes.c_size_t(v))
+    assert f(1) == 1 and f(127) == 128 and f(1 << 31) == 1 << 31 and f(2) == 2 and f(3) == 4 and f(25000) == 32768
+
+
+def test_rangeproof_roundtrip_and_fake():   # :267-293
+    mn, mx = orc.clip_bounds(16, FB, FF)
+    vals = np.clip(np.array([-1.25, 0.5, -mx], np.float32), mn, mx)
+    rc, pr, cm = orc.create_rangeproof(vals, orc.rand_scalars(rng, 3), 16, 4, FB, FF, seed=b"\x02" * 32)
+    assert rc == 0 and orc.verify_rangeproof(pr, cm, 16, FB, FF) == (0, True)
+    fake = orc.commit_vec(np.frombuffer((1 << 17).to_bytes(32, "little"), np.uint8).reshape(1, 32), orc.rand_scalars(rng, 1))
+    cm2 = cm.copy(); cm2[0] = fake[0]
+    assert orc.verify_rangeproof(pr, cm2, 16, FB, FF) == (0, False)       # Ok(false), not Err
+
+
+def test_rangeproof_par_roundtrip():   # :296-315  (100 values, P = 4)
+    mn, mx = orc.clip_bounds(8, FB, FF)
+    vals = rng.uniform(mn, mx, 100).astype(np.float32)
+    rc, pr, cm = orc.create_rangeproof(vals, orc.rand_scalars(rng, 100), 8, 4, FB, FF, seed=b"\x03" * 32)
+    assert rc == 0 and pr.shape[0] == 4 and orc.verify_rangeproof(pr, cm, 8, FB, FF) == (0, True)
+
+
+def test_cancelling_blindings_homomorphism():   # :369-399
+    vecs = [[0.25, 1.25, -1.5], [-0.75, 1.25, -2.0], [0.5, 1.25, -3.0]]
+    b0, b1 = orc.rand_scalars(rng, 3), orc.rand_scalars(rng, 3)
+    b2 = np.zeros_like(b0)
+    for i in range(3):
+        s = (-(int.from_bytes(b0[i].tobytes(), "little") + int.from_bytes(b1[i].tobytes(), "little"))) % orc.L_ORDER
+        b2[i] = np.frombuffer(s.to_bytes(32, "little"), np.uint8)
+    cms = []
+    for v, b in zip(vecs, (b0, b1, b2)):
+        rc, pr, cm = orc.create_rangeproof(v, b, 16, 4, FB, FF, seed=b"\x04" * 32)
+        assert rc == 0 and orc.verify_rangeproof(pr, cm, 16, FB, FF) == (0, True)
+        cms.append(cm)
+    rc, s01 = orc.add_points_vec(cms[0], cms[1]); rc, tot = orc.add_points_vec(s01, cms[2])
+    target = [0.0, 3.75, -6.5]
+    expect = orc.commit_vec(np.stack([orc.f32_to_scalar(t, FB, FF)[1] for t in target]), None)
+    assert (tot == expect).all()
+
+
+def test_clipped():   # :402-417
+    mn, mx = orc.clip_bounds(16, FB, FF)
+    out = np.zeros(2, np.float32)
+    x = np.array([mn - 2, mx + 3], np.float32)
+    orc.lib().orc_clip_f32(x.ctypes.data_as(__import__("ctypes").c_void_p), __import__("ctypes").c_size_t(2), 16, FB, FF,
+                           out.ctypes.data_as(__import__("ctypes").c_void_p))
+    assert out[0] == mn and out[1] == mx
+    rc, pr, cm = orc.create_rangeproof(out, np.zeros((2, 32), np.uint8), 16, 2, FB, FF, seed=b"\x05" * 32)
+    assert rc == 0
+    expect = orc.commit_vec(np.stack([orc.f32_to_scalar(float(t), FB, FF)[1] for t in (mn, mx)]), None)
+    assert (cm == expect).all()
+
+
+def test_errors():
+    assert orc.create_rangeproof([0.5], orc.rand_scalars(rng, 2), 8, 1, FB, FF, seed=b"\x01" * 32)[0] == 1     # WrongNumBlindingFactors
+    assert orc.create_rangeproof([5.0], orc.rand_scalars(rng, 1), 8, 1, FB, FF, seed=b"\x01" * 32)[0] == 2     # ValueOutOfRange
+    assert orc.create_rangeproof([0.5] * 5, orc.rand_scalars(rng, 5), 8, 3, FB, FF, seed=b"\x01" * 32)[0] == 0  # chunk = 8/3 = 2
+    assert orc.create_rangeproof([0.5] * 9, orc.rand_scalars(rng, 9), 8, 3, FB, FF, seed=b"\x01" * 32)[0] == 4  # 16/3 = 5 -> InvalidAggregation
+
+
+def test_conversion_semantics():   # conversion32.rs:182-230
+    for v in (0.5, -1.25):
+        rc, s = orc.f32_to_scalar(v, FB, FF); assert orc.scalar_to_f32(s, FB, FF) == v
+    mx = (2 ** 16 - 1) / 128.0
+    rc, s = orc.f32_to_scalar(mx + 5.0, FB, FF); assert orc.scalar_to_f32(s, FB, FF) == np.float32(mx)
+    rc, s = orc.f32_to_scalar(-mx - 100.0, FB, FF); assert orc.scalar_to_f32(s, FB, FF) == -np.float32(mx)
+    a = np.float32(mx - 0.1); rc, s = orc.f32_to_scalar(float(a), FB, FF)
+    assert abs(float(a) - orc.scalar_to_f32(s, FB, FF)) <= 2.0 ** (-FF - 1)
+    assert orc.clip_bounds(32, 32, 7) == (-16777216.0, 16777216.0)           # rounds to 2^24 in f32
+    assert orc.f32_to_scalar(float("nan"), FB, FF)[0] == 10
+
+
+def test_l2_semantics():   # l2_range_proof_vec/mod.rs:305-431
+    rc, pr, cm = orc.create_rangeproof_l2([1.25, 0.5, 0.25], orc.rand_scalars(rng, 3), 16, 4, FB, FF, seed=b"\x06" * 32)
+    assert rc == 0 and len(pr) == 32 * (9 + 2 * 4) and orc.verify_rangeproof_l2(pr, cm, 16, FB, FF) == (0, True)
+    assert orc.create_rangeproof_l2([8.0], orc.rand_scalars(rng, 1), 16, 16, FB, FF, seed=b"\x06" * 32)[0] != 0        # :358-364
+    assert orc.create_rangeproof_l2([6.0, 6.0], orc.rand_scalars(rng, 2), 16, 16, FB, FF, seed=b"\x06" * 32)[0] != 0   # :367-373
+    for v in (7.9, -7.9):   # :333-355 at fp32
+        rc, pr, cm = orc.create_rangeproof_l2([v], orc.rand_scalars(rng, 1), 32, 32, 32, 7, seed=b"\x06" * 32)
+        assert rc == 0 and orc.verify_rangeproof_l2(pr, cm, 32, 32, 7) == (0, True)
+    # :414-431: zero blindings => commitment == (3.875 * 2^frac * 2^frac) * B
+    rc, pr, cm = orc.create_rangeproof_l2([0.25, 1.25, -1.5], np.zeros((3, 32), np.uint8), 16, 4, FB, FF, seed=b"\x06" * 32)
+    k = int(3.875 * 128 * 128)
+    assert (cm == orc.commit_vec(np.frombuffer(k.to_bytes(32, "little"), np.uint8).reshape(1, 32), None)[0]).all()
+    # fake commitment
+    fake = orc.commit_vec(np.frombuffer((1 << 17).to_bytes(32, "little"), np.uint8).reshape(1, 32), orc.rand_scalars(rng, 1))[0]
+    assert orc.verify_rangeproof_l2(pr, fake, 16, FB, FF) == (0, False)
+
+
+def test_format_errors():
+    rc, pr, cm = orc.create_rangeproof([0.5], orc.rand_scalars(rng, 1), 8, 1, FB, FF, seed=b"\x01" * 32)
+    bad = pr.copy(); bad[0, 4 * 32:5 * 32] = 0xFF       # non-canonical t_x
+    assert orc.verify_rangeproof(bad, cm, 8, FB, FF)[0] == 5
+    assert orc.verify_rangeproof(pr[:, :-32], cm, 8, FB, FF)[0] == 5
+    bad = pr.copy(); bad[0, 0:32] = 0                    # identity A -> VerificationError -> Ok(false)
+    assert orc.verify_rangeproof(bad, cm, 8, FB, FF) == (0, False)

@@ -155,7 +155,7 @@ def test_format_and_identity_rejections(R):
     assert e.value.code == 5
     bad = pr.copy(); bad[1, 0:32] = 0
     assert R.range_proof_vec.verify_rangeproof(bad, cm, 8) is False
-    bad = pr.copy(); bad[0, 32:64] = bytes([1] + [0] * 31)      # S does not decompress -> VerificationError -> false
+    bad = pr.copy(); bad[0, 32:64] = np.frombuffer(bytes([1] + [0] * 31), np.uint8)      # S does not decompress -> VerificationError -> false
     assert R.range_proof_vec.verify_rangeproof(bad, cm, 8) is False
     badc = cm.copy(); badc[0] = np.frombuffer(bytes([1] + [0] * 31), np.uint8)
     with pytest.raises(R.RoflError) as e:

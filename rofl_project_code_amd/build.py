@@ -5,7 +5,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "rofl_zk.hip")
-DEPS = [os.path.join(HERE, "csrc", f) for f in ("rofl_zk.hip", "kernels.hpp", "fe32.hpp", "keccak.hpp")] + [
+DEPS = [os.path.join(HERE, "csrc", f) for f in ("rofl_zk.hip", "kernels.hpp", "fe32.hpp", "keccak.hpp", "host51.hpp")] + [
     os.path.join(HERE, "..", "include", "rofl_zk.h")]
 OUT = os.path.join(HERE, "librofl_zk.so")
 

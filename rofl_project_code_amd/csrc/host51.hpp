@@ -1,0 +1,164 @@
+// Host-only fast curve arithmetic (5 x 51-bit limbs, unsigned __int128) for the strictly sequential tails the
+// GPU hands back: the ~256-step Horner chain that combines Pippenger window/bit partial sums, fixed-base
+// multiples of B / B_blinding, and the (de)compression of the handful of proof points per round.
+// A single GPU lane would need ~0.5 ms for such a chain; a host core needs ~50 us.
+#pragma once
+#include "fe32.hpp"
+
+namespace rofl {
+namespace h51 {
+
+typedef unsigned __int128 u128;
+struct fe5 { u64 v[5]; };
+struct ge5 { fe5 X, Y, Z, T; };
+struct niels5 { fe5 ypx, ymx, t2d; };
+static const u64 M51 = 0x7ffffffffffffULL;
+
+inline fe5 from_fe(const fe &a) {   // any representative -> canonical -> 51-bit limbs
+    fe c = fe_canon(a);
+    u64 t0 = (u64)c.v[0] | ((u64)c.v[1] << 32), t1 = (u64)c.v[2] | ((u64)c.v[3] << 32);
+    u64 t2 = (u64)c.v[4] | ((u64)c.v[5] << 32), t3 = (u64)c.v[6] | ((u64)c.v[7] << 32);
+    fe5 r;
+    r.v[0] = t0 & M51; r.v[1] = ((t0 >> 51) | (t1 << 13)) & M51; r.v[2] = ((t1 >> 38) | (t2 << 26)) & M51;
+    r.v[3] = ((t2 >> 25) | (t3 << 39)) & M51; r.v[4] = (t3 >> 12) & M51;
+    return r;
+}
+inline void carry(fe5 &h) {
+    u64 c;
+    c = h.v[0] >> 51; h.v[0] &= M51; h.v[1] += c;
+    c = h.v[1] >> 51; h.v[1] &= M51; h.v[2] += c;
+    c = h.v[2] >> 51; h.v[2] &= M51; h.v[3] += c;
+    c = h.v[3] >> 51; h.v[3] &= M51; h.v[4] += c;
+    c = h.v[4] >> 51; h.v[4] &= M51; h.v[0] += c * 19;
+}
+inline fe to_fe(const fe5 &a) {     // -> canonical 8 x 32
+    fe5 t = a; carry(t); carry(t);
+    t.v[0] += 19; carry(t);
+    t.v[0] += (1ULL << 51) - 19; t.v[1] += (1ULL << 51) - 1; t.v[2] += (1ULL << 51) - 1; t.v[3] += (1ULL << 51) - 1; t.v[4] += (1ULL << 51) - 1;
+    u64 c;
+    c = t.v[0] >> 51; t.v[0] &= M51; t.v[1] += c;
+    c = t.v[1] >> 51; t.v[1] &= M51; t.v[2] += c;
+    c = t.v[2] >> 51; t.v[2] &= M51; t.v[3] += c;
+    c = t.v[3] >> 51; t.v[3] &= M51; t.v[4] += c;
+    t.v[4] &= M51;
+    u64 w0 = t.v[0] | (t.v[1] << 51), w1 = (t.v[1] >> 13) | (t.v[2] << 38), w2 = (t.v[2] >> 26) | (t.v[3] << 25), w3 = (t.v[3] >> 39) | (t.v[4] << 12);
+    fe r = {{(u32)w0, (u32)(w0 >> 32), (u32)w1, (u32)(w1 >> 32), (u32)w2, (u32)(w2 >> 32), (u32)w3, (u32)(w3 >> 32)}};
+    return r;
+}
+inline fe5 add(const fe5 &f, const fe5 &g) { fe5 h; for (int i = 0; i < 5; i++) h.v[i] = f.v[i] + g.v[i]; carry(h); return h; }
+inline fe5 sub(const fe5 &f, const fe5 &g) {
+    fe5 h;
+    h.v[0] = f.v[0] + 0x1fffffffffffb4ULL - g.v[0];
+    for (int i = 1; i < 5; i++) h.v[i] = f.v[i] + 0x1ffffffffffffcULL - g.v[i];
+    carry(h); return h;
+}
+inline fe5 mul(const fe5 &f, const fe5 &g) {
+    u128 f0 = f.v[0], f1 = f.v[1], f2 = f.v[2], f3 = f.v[3], f4 = f.v[4];
+    u64 g0 = g.v[0], g1 = g.v[1], g2 = g.v[2], g3 = g.v[3], g4 = g.v[4];
+    u64 g1_19 = 19 * g1, g2_19 = 19 * g2, g3_19 = 19 * g3, g4_19 = 19 * g4;
+    u128 r0 = f0 * g0 + f1 * g4_19 + f2 * g3_19 + f3 * g2_19 + f4 * g1_19;
+    u128 r1 = f0 * g1 + f1 * g0 + f2 * g4_19 + f3 * g3_19 + f4 * g2_19;
+    u128 r2 = f0 * g2 + f1 * g1 + f2 * g0 + f3 * g4_19 + f4 * g3_19;
+    u128 r3 = f0 * g3 + f1 * g2 + f2 * g1 + f3 * g0 + f4 * g4_19;
+    u128 r4 = f0 * g4 + f1 * g3 + f2 * g2 + f3 * g1 + f4 * g0;
+    fe5 h;
+    r1 += (u64)(r0 >> 51); h.v[0] = (u64)r0 & M51;
+    r2 += (u64)(r1 >> 51); h.v[1] = (u64)r1 & M51;
+    r3 += (u64)(r2 >> 51); h.v[2] = (u64)r2 & M51;
+    r4 += (u64)(r3 >> 51); h.v[3] = (u64)r3 & M51;
+    u64 c = (u64)(r4 >> 51); h.v[4] = (u64)r4 & M51;
+    h.v[0] += c * 19; c = h.v[0] >> 51; h.v[0] &= M51; h.v[1] += c;
+    return h;
+}
+inline fe5 sq(const fe5 &f) {
+    u128 f0 = f.v[0], f1 = f.v[1], f2 = f.v[2], f3 = f.v[3], f4 = f.v[4];
+    u64 f0_2 = 2 * f.v[0], f1_2 = 2 * f.v[1], f3_19 = 19 * f.v[3], f4_19 = 19 * f.v[4];
+    u128 r0 = f0 * f.v[0] + (u128)(2 * f.v[1]) * f4_19 + (u128)(2 * f.v[2]) * f3_19;
+    u128 r1 = (u128)f0_2 * f.v[1] + (u128)(2 * f.v[2]) * f4_19 + f3 * f3_19;
+    u128 r2 = (u128)f0_2 * f.v[2] + f1 * f.v[1] + (u128)(2 * f.v[3]) * f4_19;
+    u128 r3 = (u128)f0_2 * f.v[3] + (u128)f1_2 * f.v[2] + f4 * f4_19;
+    u128 r4 = (u128)f0_2 * f.v[4] + (u128)f1_2 * f.v[3] + f2 * f.v[2];
+    fe5 h;
+    r1 += (u64)(r0 >> 51); h.v[0] = (u64)r0 & M51;
+    r2 += (u64)(r1 >> 51); h.v[1] = (u64)r1 & M51;
+    r3 += (u64)(r2 >> 51); h.v[2] = (u64)r2 & M51;
+    r4 += (u64)(r3 >> 51); h.v[3] = (u64)r3 & M51;
+    u64 c = (u64)(r4 >> 51); h.v[4] = (u64)r4 & M51;
+    h.v[0] += c * 19; c = h.v[0] >> 51; h.v[0] &= M51; h.v[1] += c;
+    return h;
+}
+inline fe5 zero() { fe5 r = {{0, 0, 0, 0, 0}}; return r; }
+inline fe5 one() { fe5 r = {{1, 0, 0, 0, 0}}; return r; }
+inline fe5 neg(const fe5 &f) { return sub(zero(), f); }
+inline fe5 sqn(fe5 a, int n) { for (int i = 0; i < n; i++) a = sq(a); return a; }
+inline fe5 pow_2_250_1(const fe5 &z, fe5 &z11) {
+    fe5 z2 = sq(z), z9 = mul(sqn(z2, 2), z); z11 = mul(z9, z2);
+    fe5 z_5_0 = mul(sq(z11), z9), z_10_0 = mul(sqn(z_5_0, 5), z_5_0), z_20_0 = mul(sqn(z_10_0, 10), z_10_0);
+    fe5 z_40_0 = mul(sqn(z_20_0, 20), z_20_0), z_50_0 = mul(sqn(z_40_0, 10), z_10_0), z_100_0 = mul(sqn(z_50_0, 50), z_50_0);
+    fe5 z_200_0 = mul(sqn(z_100_0, 100), z_100_0);
+    return mul(sqn(z_200_0, 50), z_50_0);
+}
+inline fe5 invert(const fe5 &z) { fe5 z11; fe5 t = pow_2_250_1(z, z11); return mul(sqn(t, 5), z11); }
+inline fe5 pow22523(const fe5 &z) { fe5 z11; fe5 t = pow_2_250_1(z, z11); return mul(sqn(t, 2), z); }
+inline bool isneg(const fe5 &a) { return to_fe(a).v[0] & 1; }
+inline bool iszero(const fe5 &a) { fe c = to_fe(a); u32 o = 0; for (int i = 0; i < 8; i++) o |= c.v[i]; return o == 0; }
+inline bool eq(const fe5 &a, const fe5 &b) { return iszero(sub(a, b)); }
+inline fe5 fabs5(const fe5 &a) { return isneg(a) ? neg(a) : a; }
+
+struct Consts { fe5 d2, sqrtm1, invsqrt_a_minus_d; };
+inline const Consts &K() { static Consts k = {from_fe(fe_d2()), from_fe(fe_sqrtm1()), from_fe(fe_invsqrt_a_minus_d())}; return k; }
+
+inline bool sqrt_ratio_i(fe5 &out, const fe5 &u, const fe5 &v) {
+    fe5 v3 = mul(sq(v), v), v7 = mul(sq(v3), v);
+    fe5 r = mul(mul(u, v3), pow22523(mul(u, v7)));
+    fe5 check = mul(v, sq(r)), neg_u = neg(u);
+    bool correct = eq(check, u), flipped = eq(check, neg_u), flipped_i = eq(check, mul(neg_u, K().sqrtm1));
+    if (flipped || flipped_i) r = mul(r, K().sqrtm1);
+    out = fabs5(r);
+    return correct || flipped;
+}
+
+inline ge5 identity() { ge5 r = {zero(), one(), one(), zero()}; return r; }
+inline ge5 from_ge(const ge &p) { ge5 r = {from_fe(p.X), from_fe(p.Y), from_fe(p.Z), from_fe(p.T)}; return r; }
+inline ge to_ge(const ge5 &p) { ge r; r.X = to_fe(p.X); r.Y = to_fe(p.Y); r.Z = to_fe(p.Z); r.T = to_fe(p.T); return r; }
+inline niels5 from_niels(const niels &q) { niels5 r = {from_fe(q.ypx), from_fe(q.ymx), from_fe(q.t2d)}; return r; }
+inline ge5 gadd(const ge5 &p, const ge5 &q) {
+    fe5 A = mul(sub(p.Y, p.X), sub(q.Y, q.X)), B = mul(add(p.Y, p.X), add(q.Y, q.X));
+    fe5 C = mul(mul(p.T, q.T), K().d2), D = mul(p.Z, q.Z); D = add(D, D);
+    fe5 E = sub(B, A), F = sub(D, C), G = add(D, C), H = add(B, A);
+    ge5 r = {mul(E, F), mul(G, H), mul(F, G), mul(E, H)};
+    return r;
+}
+inline ge5 gmadd(const ge5 &p, const niels5 &q, bool negq) {
+    fe5 A = mul(sub(p.Y, p.X), negq ? q.ypx : q.ymx), B = mul(add(p.Y, p.X), negq ? q.ymx : q.ypx);
+    fe5 C = mul(p.T, q.t2d), D = add(p.Z, p.Z);
+    fe5 E = sub(B, A), H = add(B, A), F = negq ? add(D, C) : sub(D, C), G = negq ? sub(D, C) : add(D, C);
+    ge5 r = {mul(E, F), mul(G, H), mul(F, G), mul(E, H)};
+    return r;
+}
+inline ge5 gdouble(const ge5 &p) {
+    fe5 A = sq(p.X), B = sq(p.Y), C = sq(p.Z); C = add(C, C);
+    fe5 E = sub(sub(sq(add(p.X, p.Y)), A), B), G = sub(B, A), F = sub(G, C), H = neg(add(A, B));
+    ge5 r = {mul(E, F), mul(G, H), mul(F, G), mul(E, H)};
+    return r;
+}
+inline bool is_identity_ristretto(const ge5 &p) { return iszero(p.X) || iszero(p.Y); }
+inline void encode(uint8_t *s, const ge5 &p) {
+    fe5 u1 = mul(add(p.Z, p.Y), sub(p.Z, p.Y)), u2 = mul(p.X, p.Y);
+    fe5 invsqrt; sqrt_ratio_i(invsqrt, one(), mul(u1, sq(u2)));
+    fe5 den1 = mul(invsqrt, u1), den2 = mul(invsqrt, u2), z_inv = mul(mul(den1, den2), p.T);
+    fe5 ix0 = mul(p.X, K().sqrtm1), iy0 = mul(p.Y, K().sqrtm1), ench = mul(den1, K().invsqrt_a_minus_d);
+    bool rotate = isneg(mul(p.T, z_inv));
+    fe5 x = rotate ? iy0 : p.X, y = rotate ? ix0 : p.Y, den_inv = rotate ? ench : den2;
+    if (isneg(mul(x, z_inv))) y = neg(y);
+    fe_tobytes(s, to_fe(fabs5(mul(den_inv, sub(p.Z, y)))));
+}
+inline niels5 to_niels5(const ge5 &p) {
+    fe5 zi = invert(p.Z), x = mul(p.X, zi), y = mul(p.Y, zi);
+    niels5 r = {add(y, x), sub(y, x), mul(mul(x, y), K().d2)};
+    return r;
+}
+inline niels to_niels32(const ge5 &p) { niels5 q = to_niels5(p); niels r; r.ypx = to_fe(q.ypx); r.ymx = to_fe(q.ymx); r.t2d = to_fe(q.t2d); return r; }
+
+}  // namespace h51
+}  // namespace rofl

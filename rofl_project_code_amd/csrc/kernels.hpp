@@ -410,21 +410,39 @@ __global__ void __launch_bounds__(TPB) k_ipp_fold_ab(u32 nh, const ChunkParams *
 // share the scalars s_h (given as NAF digits, wave-uniform control flow => no divergence).
 struct FoldProb { const niels *src; niels *dst; };
 #define FOLD_MAXSRC 64
-__global__ void __launch_bounds__(64) k_fold_gens(u32 n_new, u32 nsrc, int top_bit, const FoldProb *probs, const int8_t *naf /* [prob][nsrc][256] */) {
+#define FOLD_MAXSEG 4
+// The 254 NAF digit positions are split into K contiguous segments (threadIdx.y); segment k covers bits
+// [seg.lo[k], seg.lo[k+1]) and finishes with seg.lo[k] plain doublings, so K threads share one output and the
+// launch has K times as many waves in flight (the chain is latency-bound at 2 waves/SIMD otherwise).
+struct FoldSeg { int lo[FOLD_MAXSEG + 1]; };
+__global__ void __launch_bounds__(256) k_fold_gens(u32 n_new, u32 nsrc, FoldSeg seg, const FoldProb *probs, const int8_t *naf /* [prob][nsrc][256] */) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    ge *lds = reinterpret_cast<ge *>(smem);
     u32 q = blockIdx.y;
-    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_new) return;
+    u32 i = blockIdx.x * 64 + threadIdx.x;
+    u32 k = threadIdx.y, K = blockDim.y;
+    bool active = i < n_new;
     const niels *src = probs[q].src;
     const int8_t *dg = naf + (size_t)q * nsrc * 256;
     ge acc = ge_identity();
-    for (int bit = top_bit; bit >= 0; bit--) {
-        acc = ge_double(acc);
-        for (u32 h = 0; h < nsrc; h++) {
-            int d = dg[h * 256 + bit];
-            if (d != 0) acc = ge_madd(acc, load_niels(&src[(size_t)h * n_new + i]), d < 0);
+    if (active) {
+        int lo = seg.lo[k], hi = seg.lo[k + 1] - 1;
+        for (int bit = hi; bit >= lo; bit--) {
+            acc = ge_double(acc);
+            for (u32 h = 0; h < nsrc; h++) {
+                int d = dg[h * 256 + bit];
+                if (d != 0) acc = ge_madd(acc, load_niels(&src[(size_t)h * n_new + i]), d < 0);
+            }
         }
+        for (int t = 0; t < lo; t++) acc = ge_double(acc);
     }
-    store_niels(&probs[q].dst[i], ge_to_niels(acc));
+    if (K > 1) {
+        if (k > 0) lds[(k - 1) * 64 + threadIdx.x] = acc;
+        __syncthreads();
+        if (k == 0)
+            for (u32 s2 = 1; s2 < K; s2++) acc = ge_add(acc, lds[(s2 - 1) * 64 + threadIdx.x]);
+    }
+    if (active && k == 0) store_niels(&probs[q].dst[i], ge_to_niels(acc));
 }
 
 // ================================================================ K5: Pippenger MSM
@@ -447,28 +465,31 @@ __device__ __forceinline__ int msm_digit(const sc &k, u32 w, u32 c) {
     return (int)(V & ((1u << (c - 1)) - 1)) + (int)bm1 - (int)(top << (c - 1));
 }
 struct MsmProb { const niels *pts; const sc *scal; };   // per problem: points and canonical scalars
+// Counting sort of (term, window) pairs by bucket.  blockIdx.y = prob * W + window, so the blocks in flight at
+// any time hit one 4*B-byte histogram and one 4*n-byte output region: both stay resident in the XCD L2s
+// instead of spraying partial-line writes over the whole [prob][W][n] array.
 __global__ void __launch_bounds__(TPB) k_msm_count(u32 n, u32 c, u32 W, const MsmProb *probs, u32 *cnt /* [prob][W][B] */) {
-    u32 p = blockIdx.y, B = 1u << (c - 1);
+    u32 pw = blockIdx.y, p = pw / W, w = pw % W, B = 1u << (c - 1);
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     sc k = load_sc(&probs[p].scal[i]);
-    if (sc_iszero(k)) return;
-    for (u32 w = 0; w < W; w++) {
-        int d = msm_digit(k, w, c);
-        if (d) atomicAdd(&cnt[((size_t)p * W + w) * B + (u32)(d < 0 ? -d : d) - 1], 1u);
-    }
+    int d = msm_digit(k, w, c);
+    if (d) atomicAdd(&cnt[(size_t)pw * B + (u32)(d < 0 ? -d : d) - 1], 1u);
 }
-// exclusive scan of each (prob, window) histogram; one block per (prob, window)
-__global__ void __launch_bounds__(TPB) k_msm_scan(u32 B, const u32 *cnt, u32 *off, u32 *cursor) {
+// One block per (prob, window): exclusive scan of the histogram (off, cursor) and a bucket permutation sorted by
+// descending count (perm), so that the 64 lanes of an accumulate wave own buckets of (nearly) equal size.
+__global__ void __launch_bounds__(TPB) k_msm_scan(u32 B, const u32 *cnt, u32 *off, u32 *cursor, u32 *perm) {
     __shared__ u32 part[TPB];
+    __shared__ u32 hist[256];
     size_t base = (size_t)blockIdx.x * B;
     u32 t = threadIdx.x, per = (B + TPB - 1) / TPB;
     u32 lo = t * per, hi = lo + per < B ? lo + per : B;
     u32 s = 0;
-    for (u32 i = lo; i < hi && i < B; i++) s += cnt[base + i];
+    hist[t] = 0;
+    __syncthreads();
+    for (u32 i = lo; i < hi && i < B; i++) { u32 cv = cnt[base + i]; s += cv; atomicAdd(&hist[cv > 255 ? 255 : cv], 1u); }
     part[t] = s;
     __syncthreads();
-    // simple Hillis-Steele inclusive scan over 256 partials
     for (u32 d = 1; d < TPB; d <<= 1) {
         u32 v = t >= d ? part[t - d] : 0;
         __syncthreads();
@@ -477,30 +498,44 @@ __global__ void __launch_bounds__(TPB) k_msm_scan(u32 B, const u32 *cnt, u32 *of
     }
     u32 run = t ? part[t - 1] : 0;
     for (u32 i = lo; i < hi && i < B; i++) { off[base + i] = run; cursor[base + i] = run; run += cnt[base + i]; }
+    // descending-count start offsets: start[b] = #buckets with count bin > b
+    __syncthreads();
+    part[t] = hist[255 - t];          // reversed, then inclusive scan
+    __syncthreads();
+    for (u32 d = 1; d < TPB; d <<= 1) {
+        u32 v = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    hist[255 - t] = t ? part[t - 1] : 0;   // exclusive start of bin (255 - t)
+    __syncthreads();
+    for (u32 i = lo; i < hi && i < B; i++) {
+        u32 cv = cnt[base + i];
+        u32 pos = atomicAdd(&hist[cv > 255 ? 255 : cv], 1u);
+        perm[base + pos] = i;
+    }
 }
 __global__ void __launch_bounds__(TPB) k_msm_scatter(u32 n, u32 c, u32 W, const MsmProb *probs, u32 *cursor, u32 *sorted /* [prob][W][n] */) {
-    u32 p = blockIdx.y, B = 1u << (c - 1);
+    u32 pw = blockIdx.y, p = pw / W, w = pw % W, B = 1u << (c - 1);
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     sc k = load_sc(&probs[p].scal[i]);
-    if (sc_iszero(k)) return;
-    for (u32 w = 0; w < W; w++) {
-        int d = msm_digit(k, w, c);
-        if (d) {
-            u32 ad = (u32)(d < 0 ? -d : d) - 1;
-            u32 pos = atomicAdd(&cursor[((size_t)p * W + w) * B + ad], 1u);
-            sorted[((size_t)p * W + w) * n + pos] = i | (d < 0 ? 0x80000000u : 0u);
-        }
+    int d = msm_digit(k, w, c);
+    if (d) {
+        u32 ad = (u32)(d < 0 ? -d : d) - 1;
+        u32 pos = atomicAdd(&cursor[(size_t)pw * B + ad], 1u);
+        sorted[(size_t)pw * n + pos] = i | (d < 0 ? 0x80000000u : 0u);
     }
 }
 // one thread per bucket: sum its points.  buckets [prob][W][B] extended.
 __global__ void __launch_bounds__(TPB) k_msm_accumulate(u32 n, u32 c, u32 W, const MsmProb *probs, const u32 *cnt, const u32 *off,
-                                 const u32 *sorted, ge *buckets) {
+                                 const u32 *sorted, const u32 *perm, ge *buckets) {
     u32 p = blockIdx.y, B = 1u << (c - 1);
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= W * B) return;
     u32 w = t / B;
-    size_t bi = (size_t)p * W * B + t;
+    size_t bi = ((size_t)p * W + w) * B + perm[(size_t)p * W * B + t];
     u32 start = off[bi], num = cnt[bi];
     const u32 *lst = sorted + ((size_t)p * W + w) * n + start;
     const niels *pts = probs[p].pts;

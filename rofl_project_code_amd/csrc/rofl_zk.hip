@@ -15,6 +15,7 @@
 
 #include "../../include/rofl_zk.h"
 #include "kernels.hpp"
+#include "host51.hpp"
 
 using namespace rofl;
 
@@ -55,7 +56,8 @@ int sc_naf(int8_t out[256], const sc &k) {
 }
 
 // ---------------------------------------------------------------- host point helpers
-struct HostTables { std::vector<niels> B, Bb; ge base, bblind; };
+using h51::ge5; using h51::niels5;
+struct HostTables { std::vector<niels> B, Bb; std::vector<niels5> B5, Bb5; ge base, bblind; };
 
 void build_fixed_table(std::vector<niels> &tab, ge P) {
     tab.resize(64 * 8);
@@ -68,7 +70,20 @@ void build_fixed_table(std::vector<niels> &tab, ge P) {
         for (int k = 0; k < 4; k++) P = ge_double(P);
     }
 }
-ge h_fixed_mul(const std::vector<niels> &tab, const sc &k_canon) {
+ge5 h_fixed_mul(const std::vector<niels5> &tab, const sc &k_canon) {
+    ge5 acc = h51::identity();
+    int carry = 0;
+    for (int i = 0; i < 64; i++) {
+        int v = (int)((k_canon.v[i >> 3] >> ((i & 7) * 4)) & 15) + carry;
+        carry = (v + 8) >> 4;
+        int d = v - (carry << 4);
+        if (d > 0) acc = h51::gmadd(acc, tab[i * 8 + d - 1], false);
+        else if (d < 0) acc = h51::gmadd(acc, tab[i * 8 - d - 1], true);
+    }
+    return acc;
+}
+void to_tab5(std::vector<niels5> &o, const std::vector<niels> &t) { o.resize(t.size()); for (size_t i = 0; i < t.size(); i++) o[i] = h51::from_niels(t[i]); }
+ge h_fixed_mul32(const std::vector<niels> &tab, const sc &k_canon) {
     ge acc = ge_identity();
     int carry = 0;
     for (int i = 0; i < 64; i++) {
@@ -130,11 +145,11 @@ struct Ctx {
     niels *d_tabB = nullptr, *d_tabBb = nullptr;
     sc *d_two_pow = nullptr;
     std::map<std::pair<size_t, size_t>, niels *> gens;   // (n, m) -> [G(N) | H(N)]
-    int fold_t = 4;
+    int fold_t = 2, fold_k = 0; long fold_threads = 524288;
     Timing tm;
     // workspace
     DevBuf cp, sL, sR, party, Scanon, vshift, blind, Vbytes, Cbytes, status, partial, partial2, scpart, a, b, yinv,
-        SL, SR, msm_cnt, msm_off, msm_cur, msm_sorted, msm_buckets, msm_S[2], msm_C[2], msm_probs, foldprobs, naf,
+        SL, SR, msm_cnt, msm_off, msm_cur, msm_perm, msm_sorted, msm_buckets, msm_S[2], msm_C[2], msm_probs, foldprobs, naf,
         gbuf[2], aux_pts, aux_scal, vscal, tmp_in, tmp_in2, tmp_out, vals, uni, stream_buf;
     PinBuf h_cp, h_res, h_part, h_misc, h_misc2, h_probs, h_auxc, h_auxs;
 
@@ -150,6 +165,7 @@ struct Ctx {
         ht.bblind = ristretto_from_uniform(h);
         build_fixed_table(ht.B, ht.base);
         build_fixed_table(ht.Bb, ht.bblind);
+        to_tab5(ht.B5, ht.B); to_tab5(ht.Bb5, ht.Bb);
         HIPCHK(hipMalloc(&d_tabB, sizeof(niels) * 512));
         HIPCHK(hipMalloc(&d_tabBb, sizeof(niels) * 512));
         HIPCHK(hipMemcpy(d_tabB, ht.B.data(), sizeof(niels) * 512, hipMemcpyHostToDevice));
@@ -159,6 +175,8 @@ struct Ctx {
         HIPCHK(hipMalloc(&d_two_pow, sizeof(tp)));
         HIPCHK(hipMemcpy(d_two_pow, tp, sizeof(tp), hipMemcpyHostToDevice));
         if (const char *e = getenv("ROFL_FOLD_T")) { int v = atoi(e); if (v >= 1 && v <= 6) fold_t = v; }
+        if (const char *e = getenv("ROFL_FOLD_K")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) fold_k = v; }
+        if (const char *e = getenv("ROFL_FOLD_THREADS")) { long v = atol(e); if (v > 0) fold_threads = v; }
         inited = true;
     }
 };
@@ -205,7 +223,7 @@ MsmPlan msm_plan(size_t n) {
     return p;
 }
 // results[p] = sum_i scal[p][i] * pts[p][i]   (all problems have n terms).  Synchronises the stream.
-void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge> &results) {
+void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge5> &results) {
     size_t np = probs.size();
     MsmPlan P = msm_plan(n);
     size_t PW = np * P.W;
@@ -215,14 +233,15 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
     HIPCHK(hipMemcpyAsync(d_probs, h_probs, sizeof(MsmProb) * np, hipMemcpyHostToDevice, C.stream));
     u32 *cnt = C.msm_cnt.as<u32>(PW * P.B), *off = C.msm_off.as<u32>(PW * P.B), *cur = C.msm_cur.as<u32>(PW * P.B);
     u32 *sorted = C.msm_sorted.as<u32>(PW * n);
+    u32 *perm = C.msm_perm.as<u32>(PW * P.B);
     ge *buckets = C.msm_buckets.as<ge>(PW * P.B);
     HIPCHK(hipMemsetAsync(cnt, 0, sizeof(u32) * PW * P.B, C.stream));
-    hipLaunchKernelGGL(k_msm_count, grid1(n, (u32)np), dim3(TPB), 0, C.stream, (u32)n, P.c, P.W, d_probs, cnt);
-    hipLaunchKernelGGL(k_msm_scan, dim3((unsigned)PW), dim3(TPB), 0, C.stream, P.B, cnt, off, cur);
-    hipLaunchKernelGGL(k_msm_scatter, grid1(n, (u32)np), dim3(TPB), 0, C.stream, (u32)n, P.c, P.W, d_probs, cur, sorted);
+    hipLaunchKernelGGL(k_msm_count, grid1(n, (u32)PW), dim3(TPB), 0, C.stream, (u32)n, P.c, P.W, d_probs, cnt);
+    hipLaunchKernelGGL(k_msm_scan, dim3((unsigned)PW), dim3(TPB), 0, C.stream, P.B, cnt, off, cur, perm);
+    hipLaunchKernelGGL(k_msm_scatter, grid1(n, (u32)PW), dim3(TPB), 0, C.stream, (u32)n, P.c, P.W, d_probs, cur, sorted);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (C.tm.enabled) { e0 = C.tm.get(); e1 = C.tm.get(); HIPCHK(hipEventRecord(e0, C.stream)); }
-    hipLaunchKernelGGL(k_msm_accumulate, grid1((size_t)P.W * P.B, (u32)np), dim3(TPB), 0, C.stream, (u32)n, P.c, P.W, d_probs, cnt, off, sorted, buckets);
+    hipLaunchKernelGGL(k_msm_accumulate, grid1((size_t)P.W * P.B, (u32)np), dim3(TPB), 0, C.stream, (u32)n, P.c, P.W, d_probs, cnt, off, sorted, perm, buckets);
     if (C.tm.enabled) { HIPCHK(hipEventRecord(e1, C.stream)); C.tm.acc_ev.push_back({e0, e1}); C.tm.t.msm_accumulate_launches++; }
     // reduction tree
     const ge *S_in = buckets; const ge *C_in = nullptr;
@@ -242,14 +261,15 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
     HIPCHK(hipStreamSynchronize(C.stream));
     double t0 = now_ms();
     results.resize(np);
+#pragma omp parallel for schedule(dynamic, 1)
     for (size_t p = 0; p < np; p++) {
-        ge acc = ge_identity(); bool started = false;
+        ge5 acc = h51::identity(); bool started = false;
         for (int w = (int)P.W - 1; w >= 0; w--) {
             size_t pw = p * P.W + w;
             for (int l = (int)P.c - 1; l >= 0; l--) {
-                if (started) acc = ge_double(acc);
-                if (l <= (int)P.c - 2) { acc = ge_add(acc, h[PW + pw * nb + l]); started = true; }
-                if (l == 0) { acc = ge_add(acc, h[pw]); started = true; }
+                if (started) acc = h51::gdouble(acc);
+                if (l <= (int)P.c - 2) { acc = h51::gadd(acc, h51::from_ge(h[PW + pw * nb + l])); started = true; }
+                if (l == 0) { acc = h51::gadd(acc, h51::from_ge(h[pw])); started = true; }
             }
         }
         results[p] = acc;
@@ -258,8 +278,8 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
 }
 
 // ---------------------------------------------------------------- transcript helpers
-void tr_append_point(Merlin &t, const char *label, const ge &p, uint8_t *enc_out) {
-    uint8_t e[32]; ristretto_encode(e, p); t.append(label, e, 32); if (enc_out) memcpy(enc_out, e, 32);
+void tr_append_point(Merlin &t, const char *label, const ge5 &p, uint8_t *enc_out) {
+    uint8_t e[32]; h51::encode(e, p); t.append(label, e, 32); if (enc_out) memcpy(enc_out, e, 32);
 }
 void fill_pow2(sc *tab, sc base_mont, int count) { tab[0] = base_mont; for (int i = 1; i < count; i++) tab[i] = sc_montmul(tab[i - 1], tab[i - 1]); }
 
@@ -308,7 +328,7 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
     HIPCHK(hipMemcpyAsync(h_A, partial2, sizeof(ge) * P * nblkA, hipMemcpyDeviceToHost, C.stream));
     HIPCHK(hipMemcpyAsync(h_sc, scpart, sizeof(sc) * P * nblkS * 3, hipMemcpyDeviceToHost, C.stream));
     // S = <sL,G> + <sR,H> + s_bl * Bb
-    std::vector<MsmProb> probs(P); std::vector<ge> res;
+    std::vector<MsmProb> probs(P); std::vector<ge5> res;
     for (size_t c = 0; c < P; c++) probs[c] = MsmProb{tbl, Scanon + c * 2 * N};
     C.tm.t.msm_terms += P * 2 * N;
     msm_run(C, probs, 2 * N, res);
@@ -316,18 +336,19 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
     double th = now_ms();
     std::vector<Merlin> tr; tr.reserve(P);
     std::vector<sc> a_bl(P), s_bl(P), y(P), z(P), zz(P), x(P), w(P);
+    for (size_t c = 0; c < P; c++) tr.emplace_back(label, strlen(label));
+#pragma omp parallel for schedule(dynamic, 1)
     for (size_t c = 0; c < P; c++) {
         uint8_t *o = proofs_out + c * plen;
-        tr.emplace_back(label, strlen(label));
         Merlin &t = tr[c];
         t.append("dom-sep", (const uint8_t *)"rangeproof v1", 13);
         t.append_u64("n", n); t.append_u64("m", m);
         for (size_t j = 0; j < m; j++) t.append("V", h_V + (c * m + j) * 32, 32);
         a_bl[c] = h_canon(sum_partials(h_sc + c * nblkS * 3, nblkS, 3, 0));
         s_bl[c] = h_canon(sum_partials(h_sc + c * nblkS * 3, nblkS, 3, 1));
-        ge A = h_fixed_mul(C.ht.Bb, a_bl[c]);
-        for (u32 k = 0; k < nblkA; k++) A = ge_add(A, h_A[c * nblkA + k]);
-        ge S = ge_add(res[c], h_fixed_mul(C.ht.Bb, s_bl[c]));
+        ge5 A = h_fixed_mul(C.ht.Bb5, a_bl[c]);
+        for (u32 k = 0; k < nblkA; k++) A = h51::gadd(A, h51::from_ge(h_A[c * nblkA + k]));
+        ge5 S = h51::gadd(res[c], h_fixed_mul(C.ht.Bb5, s_bl[c]));
         tr_append_point(t, "A", A, o); tr_append_point(t, "S", S, o + 32);
         y[c] = t.challenge_scalar("y"); z[c] = t.challenge_scalar("z");
         zz[c] = h_mul(z[c], z[c]);
@@ -347,6 +368,7 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
     HIPCHK(hipMemcpyAsync(h_sc, scpart, sizeof(sc) * P * nblkS * 3, hipMemcpyDeviceToHost, C.stream));
     HIPCHK(hipStreamSynchronize(C.stream));
     th = now_ms();
+#pragma omp parallel for schedule(dynamic, 1)
     for (size_t c = 0; c < P; c++) {
         uint8_t *o = proofs_out + c * plen;
         Merlin &t = tr[c];
@@ -356,8 +378,8 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
         sc t1_bl = h_canon(sum_partials(h_sc + c * nblkS * 3, nblkS, 3, 0));
         sc t2_bl = h_canon(sum_partials(h_sc + c * nblkS * 3, nblkS, 3, 1));
         sc zvbl = h_canon(sum_partials(h_sc + c * nblkS * 3, nblkS, 3, 2));
-        ge T1 = ge_add(h_fixed_mul(C.ht.B, t1), h_fixed_mul(C.ht.Bb, t1_bl));
-        ge T2 = ge_add(h_fixed_mul(C.ht.B, t2), h_fixed_mul(C.ht.Bb, t2_bl));
+        ge5 T1 = h51::gadd(h_fixed_mul(C.ht.B5, t1), h_fixed_mul(C.ht.Bb5, t1_bl));
+        ge5 T2 = h51::gadd(h_fixed_mul(C.ht.B5, t2), h_fixed_mul(C.ht.Bb5, t2_bl));
         tr_append_point(t, "T_1", T1, o + 64); tr_append_point(t, "T_2", T2, o + 96);
         x[c] = t.challenge_scalar("x");
         sc xx = h_mul(x[c], x[c]);
@@ -409,12 +431,13 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
         C.tm.t.msm_terms += P * 2 * n_g;
         msm_run(C, pr, 2 * n_g, res);
         th = now_ms();
+#pragma omp parallel for schedule(dynamic, 1)
         for (size_t c = 0; c < P; c++) {
             uint8_t *o = proofs_out + c * plen + 7 * 32 + 64 * round;
             sc cL = h_canon(sum_partials(h_ip + c * nblkI * 2, nblkI, 2, 0));
             sc cR = h_canon(sum_partials(h_ip + c * nblkI * 2, nblkI, 2, 1));
-            ge L = ge_add(res[2 * c], h_fixed_mul(C.ht.B, h_mul(cL, w[c])));
-            ge R = ge_add(res[2 * c + 1], h_fixed_mul(C.ht.B, h_mul(cR, w[c])));
+            ge5 L = h51::gadd(res[2 * c], h_fixed_mul(C.ht.B5, h_mul(cL, w[c])));
+            ge5 R = h51::gadd(res[2 * c + 1], h_fixed_mul(C.ht.B5, h_mul(cR, w[c])));
             tr_append_point(tr[c], "L", L, o); tr_append_point(tr[c], "R", R, o + 32);
             sc u = tr[c].challenge_scalar("u");
             sc um = h_mont(u), uim = sc_invert_mont(um);
@@ -461,7 +484,26 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
             HIPCHK(hipMemcpyAsync(d_fp, h_fp, sizeof(FoldProb) * 2 * P, hipMemcpyHostToDevice, C.stream));
             hipEvent_t e0 = nullptr, e1 = nullptr;
             if (C.tm.enabled) { e0 = C.tm.get(); e1 = C.tm.get(); HIPCHK(hipEventRecord(e0, C.stream)); }
-            hipLaunchKernelGGL(k_fold_gens, dim3((unsigned)((n_new + 63) / 64), (u32)(2 * P)), dim3(64), 0, C.stream, (u32)n_new, nsrc, top, d_fp, d_naf);
+            {
+                // segment the digit positions so that K threads share one output with equal work
+                u32 K = 1;
+                size_t thr = (size_t)2 * P * n_new;
+                while (K < FOLD_MAXSEG && thr * K < (size_t)C.fold_threads) K *= 2;
+                if (C.fold_k > 0) K = (u32)C.fold_k;
+                FoldSeg seg{};
+                double cst = 1.0 + nsrc / 3.0, lo_t = 0, hi_t = (top + 1) * cst + top + 1;
+                int bounds[FOLD_MAXSEG + 1];
+                for (int it = 0; it < 60; it++) {
+                    double T = 0.5 * (lo_t + hi_t), pos = 0;
+                    for (u32 k = 0; k < K; k++) { double len = (T - pos) / cst; if (len < 0) len = 0; pos += len; }
+                    if (pos >= top + 1) hi_t = T; else lo_t = T;
+                }
+                { double pos = 0; bounds[0] = 0; for (u32 k = 0; k < K; k++) { double len = (hi_t - pos) / cst; if (len < 0) len = 0; pos += len; bounds[k + 1] = (int)(pos + 0.5); } }
+                bounds[K] = top + 1;
+                for (u32 k = 1; k <= K; k++) if (bounds[k] < bounds[k - 1]) bounds[k] = bounds[k - 1];
+                for (u32 k = 0; k <= FOLD_MAXSEG; k++) seg.lo[k] = bounds[k <= K ? k : K];
+                hipLaunchKernelGGL(k_fold_gens, dim3((unsigned)((n_new + 63) / 64), (u32)(2 * P)), dim3(64, K), (K - 1) * 64 * sizeof(ge), C.stream, (u32)n_new, nsrc, seg, d_fp, d_naf);
+            }
             if (C.tm.enabled) { HIPCHK(hipEventRecord(e1, C.stream)); C.tm.fold_ev.push_back({e0, e1}); C.tm.t.fold_launches++; C.tm.t.fold_point_reads += (uint64_t)2 * P * n_g; }
             HIPCHK(hipStreamSynchronize(C.stream));   // h_naf / h_fp staging reused next round
             for (size_t c = 0; c < P; c++) { cur[c] = gnew + c * 2 * n_new; pu[c].clear(); pui[c].clear(); }
@@ -524,6 +566,7 @@ int verify_chunks(Ctx &C, const char *label, size_t gens_capacity, size_t P, siz
     std::vector<sc> sB(P), sBb(P);
     static const uint8_t zero32[32] = {0};
     double th = now_ms();
+#pragma omp parallel for schedule(dynamic, 1)
     for (size_t c = 0; c < P; c++) {
         const uint8_t *p = proofs + c * plen; const uint8_t *ipp = p + 7 * 32;
         Merlin t(label, strlen(label));
@@ -599,7 +642,7 @@ int verify_chunks(Ctx &C, const char *label, size_t gens_capacity, size_t P, siz
         HIPCHK(hipMemcpyAsync(aux_scal + c * naux + m, h_auxs + c * (4 + 2 * lg), sizeof(sc) * (4 + 2 * lg), hipMemcpyHostToDevice, C.stream));
     }
     u32 h_status = 0;
-    std::vector<MsmProb> pr(P); std::vector<ge> resA, resB;
+    std::vector<MsmProb> pr(P); std::vector<ge5> resA, resB;
     for (size_t c = 0; c < P; c++) pr[c] = MsmProb{tbl, gh + c * 2 * N};
     C.tm.t.msm_terms += P * 2 * N;
     msm_run(C, pr, 2 * N, resA);
@@ -609,10 +652,10 @@ int verify_chunks(Ctx &C, const char *label, size_t gens_capacity, size_t P, siz
     HIPCHK(hipMemcpy(&h_status, status, 4, hipMemcpyDeviceToHost));
     th = now_ms();
     for (size_t c = 0; c < P; c++) {
-        ge tot = ge_add(resA[c], resB[c]);
-        tot = ge_add(tot, h_fixed_mul(C.ht.B, sB[c]));
-        tot = ge_add(tot, h_fixed_mul(C.ht.Bb, sBb[c]));
-        ok[c] = (!dead[c] && ge_is_identity_ristretto(tot)) ? 1 : 0;
+        ge5 tot = h51::gadd(resA[c], resB[c]);
+        tot = h51::gadd(tot, h_fixed_mul(C.ht.B5, sB[c]));
+        tot = h51::gadd(tot, h_fixed_mul(C.ht.Bb5, sBb[c]));
+        ok[c] = (!dead[c] && h51::is_identity_ristretto(tot)) ? 1 : 0;
     }
     C.tm.t.host_ms += now_ms() - th;
     if (h_status & 4u) {
@@ -710,7 +753,7 @@ int create_impl(Ctx &C, const float *values, size_t d, const uint8_t *blind, siz
     if (nonce->mode == 0 && nonce->stream_scalars < P * chunk * (2 * prove_range + 4)) return fail(ROFL_NONCE_SHORT, "nonce stream too short");
     // V_j and un-shifted commitments C_j = V_j - 2^(range-1) B   (range_proof_vec/mod.rs:96-99)
     sc negoff = sc_neg(sc_from_u64(1ULL << (prove_range - 1)));
-    niels h_shift = ge_to_niels(h_fixed_mul(C.ht.B, negoff));
+    niels h_shift = h51::to_niels32(h_fixed_mul(C.ht.B5, negoff));
     niels *d_shift = C.tmp_in.as<niels>(1);
     HIPCHK(hipMemcpyAsync(d_shift, &h_shift, sizeof(niels), hipMemcpyHostToDevice, C.stream));
     uint8_t *Vb = C.Vbytes.as<uint8_t>(dp * 32), *Cb = C.Cbytes.as<uint8_t>(dp * 32);
@@ -738,7 +781,7 @@ int verify_impl(Ctx &C, size_t n_clients, const uint8_t *const *proofs, size_t p
     C.init();
     timing_begin(C);
     // shift up by 2^(range-1) B, pad with identity, compress (:155-167)
-    niels h_shift = ge_to_niels(h_fixed_mul(C.ht.B, sc_from_u64(1ULL << (prove_range - 1))));
+    niels h_shift = h51::to_niels32(h_fixed_mul(C.ht.B5, sc_from_u64(1ULL << (prove_range - 1))));
     niels *d_shift = C.tmp_out.as<niels>(1);
     HIPCHK(hipMemcpyAsync(d_shift, &h_shift, sizeof(niels), hipMemcpyHostToDevice, C.stream));
     size_t tot = n_clients * dp;
@@ -1025,7 +1068,8 @@ int rofl_dbg_host_scalarmult_base(const uint8_t k[32], int use_bb, uint8_t out[3
         ristretto_decode(ht.base, Bc); uint8_t h[64]; sha3_512(h, Bc, 32); ht.bblind = ristretto_from_uniform(h);
         build_fixed_table(ht.B, ht.base); build_fixed_table(ht.Bb, ht.bblind); init = true;
     }
-    ristretto_encode(out, h_fixed_mul(use_bb ? ht.Bb : ht.B, sc_frombytes(k))); return 0;
+    if (use_bb & 2) { to_tab5(ht.B5, ht.B); to_tab5(ht.Bb5, ht.Bb); h51::encode(out, h_fixed_mul((use_bb & 1) ? ht.Bb5 : ht.B5, sc_frombytes(k))); return 0; }
+    ristretto_encode(out, h_fixed_mul32((use_bb & 1) ? ht.Bb : ht.B, sc_frombytes(k))); return 0;
 }
 int rofl_dbg_host_decode_encode(const uint8_t in[32], uint8_t out[32]) { ge p; if (!ristretto_decode(p, in)) return ROFL_FORMAT_ERROR; ristretto_encode(out, ge_add(p, ge_identity())); return 0; }
 int rofl_dbg_host_merlin(const uint8_t *label, size_t label_len, const uint8_t *msg, size_t msg_len, uint8_t out[64]) {

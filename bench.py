@@ -135,6 +135,18 @@ def main():
         else:
             kname, kms, kl, alg, layout = "k_msm_accumulate", agg["msm_accumulate_ms"], agg["msm_accumulate_launches"], acc_alg, agg["msm_terms"] * 96.0
         achieved = alg / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+        # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command (separate --pmc FETCH_SIZE and
+        # --pmc WRITE_SIZE runs, profiles/*_pmc_traffic.json).  gfx950: FETCH_SIZE counts 64 B per 128 B request for wide
+        # (16 B/lane) reads, so reads are doubled (MI355X_MICROARCH.md, HBM); gathers of 96 B points are 16 B/lane loads.
+        traffic = None
+        try:
+            import glob
+            pj = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))[-1]
+            ent = json.load(open(pj)).get("rofl::" + kname)
+            if ent:
+                traffic = (2.0 * ent["fetch_kb_per_launch"] + ent["write_kb_per_launch"]) * 1024.0
+        except Exception:      # noqa: BLE001
+            traffic = None
         out = {
             "metric": "range-proof elements/sec (create+verify), d=25k 32-bit", "value": value, "unit": "elements/s",
             "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": elapsed / K * 1e3,
@@ -145,7 +157,7 @@ def main():
             "breakdown_ms_per_step": {"create": agg["create_ms"] / K, "verify": agg["verify_ms"] / K, "device": agg["total_ms"] / K,
                                       "k_fold_gens": agg["fold_ms"] / K, "k_msm_accumulate": agg["msm_accumulate_ms"] / K, "host": agg["host_ms"] / K},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "avg_launch_ms": kms / max(kl, 1), "launches_per_step": kl / K,
                          "algorithmic_bytes_per_launch": alg / max(kl, 1), "layout_bytes_per_launch": layout / max(kl, 1),
                          "note": "255-bit modular integer path: VALU-issue bound, HBM fraction is tiny by construction (SURVEY 8(d))"},

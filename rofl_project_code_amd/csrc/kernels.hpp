@@ -86,7 +86,6 @@ struct ChunkParams {
     sc yinvpow2[MAX_LG];             // y^-(2^b)
     sc zpow2[MAX_LG];                // z^(2^b)
     sc u[MAX_LG], uinv[MAX_LG];      // IPP challenges (verify: all rounds; prove: current round)
-    sc stabG[64], stabH[64];         // pending-challenge products for lazily folded generators
     sc a_fin, b_fin;                 // verify: ipp a, b
     sc c_zz;                         // verify: c * z^2
     u64 nonce_base;                  // index of this chunk's first nonce
@@ -127,6 +126,24 @@ __global__ void __launch_bounds__(TPB) k_gens_map(u32 total, const uint8_t *uni,
     if (t >= total) return;
     ge p = ristretto_from_uniform(uni + (size_t)t * 64);
     store_niels(&tbl[t], ge_to_niels(p));
+}
+
+// odd multiples of the 2^(64q)-shifted generators (see k_fold_gens_tab); slice 0 is the plain table
+__global__ void __launch_bounds__(TPB) k_gens_tables(u32 total, niels *tbl16, size_t stride) {
+    u32 g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    ge cur = ge_from_niels(load_niels(&tbl16[g]));
+    for (u32 q = 0; q < 4; q++) {
+        if (q > 0) store_niels(&tbl16[(size_t)(q * 4) * stride + g], ge_to_niels(cur));
+        ge p2 = ge_double(cur);
+        ge pk = ge_add(cur, p2);
+        store_niels(&tbl16[(size_t)(q * 4 + 1) * stride + g], ge_to_niels(pk));
+        pk = ge_add(pk, p2);
+        store_niels(&tbl16[(size_t)(q * 4 + 2) * stride + g], ge_to_niels(pk));
+        pk = ge_add(pk, p2);
+        store_niels(&tbl16[(size_t)(q * 4 + 3) * stride + g], ge_to_niels(pk));
+        if (q < 3) for (int t = 0; t < 64; t++) cur = ge_double(cur);
+    }
 }
 
 // ================================================================ nonces
@@ -352,17 +369,17 @@ __global__ void __launch_bounds__(TPB) k_lr_vec(u32 n, u32 m, const ChunkParams 
 
 // ================================================================ K7: inner-product argument
 // Lazily folded generators: the materialised arrays Gc/Hc have n_g entries; the logical vectors have
-// n_k = n_g >> r entries; true G[i] = sum_h stabG[h] Gc[h*n_k+i], true H[i] = sum_h stabH[h] y^-j Hc[j].
+// n_k = n_g >> r entries; true G[i] = sum_h stab[0][h] Gc[h*n_k+i], true H[i] = sum_h stab[1][h] y^-j Hc[j].
 // Writes canonical MSM scalars for L (SL) and R (SR) over [Gc | Hc].
-__global__ void __launch_bounds__(TPB) k_ipp_scalars(u32 n_g, u32 n_k, const ChunkParams *cp, const sc *a, const sc *b, size_t ab_stride,
+__global__ void __launch_bounds__(TPB) k_ipp_scalars(u32 n_g, u32 n_k, const sc *stab /* [chunk][2][nstab] */, u32 nstab, const sc *a, const sc *b, size_t ab_stride,
                               const sc *yinvpow, size_t y_stride, sc *SL, sc *SR) {
     u32 c = blockIdx.y;
     u32 j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_g) return;
     u32 h = j / n_k, i = j % n_k, nh = n_k / 2;
     const sc *ac = a + c * ab_stride, *bc = b + c * ab_stride;
-    sc sG = cp[c].stabG[h];
-    sc sH = sc_montmul(cp[c].stabH[h], load_sc(&yinvpow[c * y_stride + j]));
+    sc sG = load_sc(&stab[((size_t)c * 2 + 0) * nstab + h]);
+    sc sH = sc_montmul(load_sc(&stab[((size_t)c * 2 + 1) * nstab + h]), load_sc(&yinvpow[c * y_stride + j]));
     sc *sl = SL + (size_t)c * 2 * n_g, *sr = SR + (size_t)c * 2 * n_g;
     sc zero = sc_zero();
     if (i < nh) {
@@ -415,7 +432,7 @@ struct FoldProb { const niels *src; niels *dst; };
 // [seg.lo[k], seg.lo[k+1]) and finishes with seg.lo[k] plain doublings, so K threads share one output and the
 // launch has K times as many waves in flight (the chain is latency-bound at 2 waves/SIMD otherwise).
 struct FoldSeg { int lo[FOLD_MAXSEG + 1]; };
-__global__ void __launch_bounds__(256) k_fold_gens(u32 n_new, u32 nsrc, FoldSeg seg, const FoldProb *probs, const int8_t *naf /* [prob][nsrc][256] */) {
+__global__ void __launch_bounds__(256) k_fold_gens(u32 n_new, u32 nsrc, FoldSeg seg, const FoldProb *probs, const int8_t *naf /* [prob][nsrc][256] */, int unit_first) {
     extern __shared__ __align__(16) unsigned char smem[];
     ge *lds = reinterpret_cast<ge *>(smem);
     u32 q = blockIdx.y;
@@ -429,7 +446,7 @@ __global__ void __launch_bounds__(256) k_fold_gens(u32 n_new, u32 nsrc, FoldSeg 
         int lo = seg.lo[k], hi = seg.lo[k + 1] - 1;
         for (int bit = hi; bit >= lo; bit--) {
             acc = ge_double(acc);
-            for (u32 h = 0; h < nsrc; h++) {
+            for (u32 h = unit_first ? 1 : 0; h < nsrc; h++) {
                 int d = dg[h * 256 + bit];
                 if (d != 0) acc = ge_madd(acc, load_niels(&src[(size_t)h * n_new + i]), d < 0);
             }
@@ -442,25 +459,81 @@ __global__ void __launch_bounds__(256) k_fold_gens(u32 n_new, u32 nsrc, FoldSeg 
         if (k == 0)
             for (u32 s2 = 1; s2 < K; s2++) acc = ge_add(acc, lds[(s2 - 1) * 64 + threadIdx.x]);
     }
-    if (active && k == 0) store_niels(&probs[q].dst[i], ge_to_niels(acc));
+    if (active && k == 0) {
+        if (unit_first) acc = ge_madd(acc, load_niels(&src[i]), false);   // source 0 has scalar 1 (scale kept aside)
+        store_niels(&probs[q].dst[i], ge_to_niels(acc));
+    }
+}
+
+// First materialisation: the sources are the FIXED generators, for which get_gens precomputed
+//   tbl16[(q*4+e)*stride + g] = (2e+1) * 2^(64q) * G_g      (q < 4, e < 4; affine niels)
+// so a 253-bit scalar becomes four 64-bit pieces in width-4 NAF: 64 doublings per output instead of 253 and
+// ~51 instead of ~84 mixed additions per source.  HBM capacity (16 x 50 MB at N = 262144) traded for VALU work.
+#define FOLD_TAB_DIGITS 72
+struct FoldTabProb { u32 src_off; niels *dst; };
+__global__ void __launch_bounds__(256) k_fold_gens_tab(u32 n_new, u32 nsrc, FoldSeg seg, const niels *tbl16, size_t stride,
+                                                       const FoldTabProb *probs, const int8_t *dig /* [prob][nsrc][4][72] */, int unit_first) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    ge *lds = reinterpret_cast<ge *>(smem);
+    u32 q = blockIdx.y;
+    u32 i = blockIdx.x * 64 + threadIdx.x;
+    u32 k = threadIdx.y, K = blockDim.y;
+    bool active = i < n_new;
+    const niels *src = tbl16 + probs[q].src_off;
+    const int8_t *dg = dig + (size_t)q * nsrc * 4 * FOLD_TAB_DIGITS;
+    ge acc = ge_identity();
+    if (active) {
+        int lo = seg.lo[k], hi = seg.lo[k + 1] - 1;
+        for (int bit = hi; bit >= lo; bit--) {
+            acc = ge_double(acc);
+            for (u32 h = unit_first ? 1 : 0; h < nsrc; h++) {
+#pragma unroll
+                for (u32 pc = 0; pc < 4; pc++) {
+                    int d = dg[(h * 4 + pc) * FOLD_TAB_DIGITS + bit];
+                    if (d != 0) {
+                        u32 e = (u32)((d < 0 ? -d : d) - 1) >> 1;
+                        acc = ge_madd(acc, load_niels(&src[(size_t)(pc * 4 + e) * stride + (size_t)h * n_new + i]), d < 0);
+                    }
+                }
+            }
+        }
+        for (int t = 0; t < lo; t++) acc = ge_double(acc);
+    }
+    if (K > 1) {
+        if (k > 0) lds[(k - 1) * 64 + threadIdx.x] = acc;
+        __syncthreads();
+        if (k == 0)
+            for (u32 s2 = 1; s2 < K; s2++) acc = ge_add(acc, lds[(s2 - 1) * 64 + threadIdx.x]);
+    }
+    if (active && k == 0) {
+        if (unit_first) acc = ge_madd(acc, load_niels(&src[i]), false);
+        store_niels(&probs[q].dst[i], ge_to_niels(acc));
+    }
 }
 
 // ================================================================ K5: Pippenger MSM
 // Booth-recoded signed c-bit digit of window w: in [-2^(c-1), 2^(c-1)]
-__device__ __forceinline__ int msm_digit(const sc &k, u32 w, u32 c) {
-    int pos = (int)(w * c) - 1;           // lowest bit needed (b_{cw-1}), -1 for w = 0
+// Window layout: W = ceil(254 / c) windows; the first `wide` windows are c bits, the rest c-1 bits, so that the top
+// window is as full as the others (a short top window would put all terms into a handful of buckets).
+struct MsmWin { u32 c, W, wide; };
+__device__ __forceinline__ void msm_window(const MsmWin &mw, u32 w, u32 &pos, u32 &width) {
+    if (w < mw.wide) { pos = w * mw.c; width = mw.c; }
+    else { pos = mw.wide * mw.c + (w - mw.wide) * (mw.c - 1); width = mw.c - 1; }
+}
+// Booth-recoded signed digit of the window [pos, pos + width): in [-2^(width-1), 2^(width-1)]
+__device__ __forceinline__ int msm_digit(const sc &k, u32 wpos, u32 c) {
+    int pos = (int)wpos - 1;              // lowest bit needed (b_{pos-1}), -1 for the first window
     u32 need = c + 1;
     u64 bits;
     if (pos < 0) {
         bits = ((u64)k.v[0] | ((u64)k.v[1] << 32)) << 1;
     } else {
         u32 limb = (u32)pos >> 5, off = (u32)pos & 31;
-        u64 lo = limb < 8 ? k.v[limb] : 0, mid = limb + 1 < 8 ? k.v[limb + 1] : 0, hi = limb + 2 < 8 ? k.v[limb + 2] : 0;
+        u64 lo = limb < 8 ? k.v[limb] : 0, mid = limb + 1 < 8 ? k.v[limb + 1] : 0;
         bits = (lo >> off) | (mid << (32 - off));
-        if (off) bits |= hi << (64 - off);
     }
     u32 x = (u32)(bits & ((1ULL << need) - 1));
-    // x = b_{cw-1} + 2*V, V = the c window bits; digit = V_low(c-1 bits) + b_{cw-1} - top * 2^(c-1)
+    // x = b_{pos-1} + 2*V, V = the c window bits; digit = V_low(c-1 bits) + b_{pos-1} - top * 2^(c-1)
     u32 V = x >> 1, bm1 = x & 1, top = (V >> (c - 1)) & 1;
     return (int)(V & ((1u << (c - 1)) - 1)) + (int)bm1 - (int)(top << (c - 1));
 }
@@ -468,12 +541,13 @@ struct MsmProb { const niels *pts; const sc *scal; };   // per problem: points a
 // Counting sort of (term, window) pairs by bucket.  blockIdx.y = prob * W + window, so the blocks in flight at
 // any time hit one 4*B-byte histogram and one 4*n-byte output region: both stay resident in the XCD L2s
 // instead of spraying partial-line writes over the whole [prob][W][n] array.
-__global__ void __launch_bounds__(TPB) k_msm_count(u32 n, u32 c, u32 W, const MsmProb *probs, u32 *cnt /* [prob][W][B] */) {
-    u32 pw = blockIdx.y, p = pw / W, w = pw % W, B = 1u << (c - 1);
+__global__ void __launch_bounds__(TPB) k_msm_count(u32 n, MsmWin mw, const MsmProb *probs, u32 *cnt /* [prob][W][B] */) {
+    u32 W = mw.W, pw = blockIdx.y, p = pw / W, w = pw % W, B = 1u << (mw.c - 1);
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     sc k = load_sc(&probs[p].scal[i]);
-    int d = msm_digit(k, w, c);
+    u32 wpos, wwid; msm_window(mw, w, wpos, wwid);
+    int d = msm_digit(k, wpos, wwid);
     if (d) atomicAdd(&cnt[(size_t)pw * B + (u32)(d < 0 ? -d : d) - 1], 1u);
 }
 // One block per (prob, window): exclusive scan of the histogram (off, cursor) and a bucket permutation sorted by
@@ -516,12 +590,13 @@ __global__ void __launch_bounds__(TPB) k_msm_scan(u32 B, const u32 *cnt, u32 *of
         perm[base + pos] = i;
     }
 }
-__global__ void __launch_bounds__(TPB) k_msm_scatter(u32 n, u32 c, u32 W, const MsmProb *probs, u32 *cursor, u32 *sorted /* [prob][W][n] */) {
-    u32 pw = blockIdx.y, p = pw / W, w = pw % W, B = 1u << (c - 1);
+__global__ void __launch_bounds__(TPB) k_msm_scatter(u32 n, MsmWin mw, const MsmProb *probs, u32 *cursor, u32 *sorted /* [prob][W][n] */) {
+    u32 W = mw.W, pw = blockIdx.y, p = pw / W, w = pw % W, B = 1u << (mw.c - 1);
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     sc k = load_sc(&probs[p].scal[i]);
-    int d = msm_digit(k, w, c);
+    u32 wpos, wwid; msm_window(mw, w, wpos, wwid);
+    int d = msm_digit(k, wpos, wwid);
     if (d) {
         u32 ad = (u32)(d < 0 ? -d : d) - 1;
         u32 pos = atomicAdd(&cursor[(size_t)pw * B + ad], 1u);

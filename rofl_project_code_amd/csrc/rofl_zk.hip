@@ -9,7 +9,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <map>
+#include <memory>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -55,6 +60,17 @@ int sc_naf(int8_t out[256], const sc &k) {
     return top;
 }
 
+// width-4 NAF (digits in +-{1,3,5,7}) of a 64-bit piece; returns the highest non-zero position (-1 if zero)
+int wnaf4_u64(int8_t out[FOLD_TAB_DIGITS], u64 piece) {
+    unsigned __int128 k = piece; int top = -1;
+    for (int pos = 0; pos < FOLD_TAB_DIGITS; pos++) {
+        int d = 0;
+        if (k & 1) { d = (int)(k & 15); if (d >= 8) d -= 16; if (d >= 0) k -= (unsigned)d; else k += (unsigned)(-d); top = pos; }
+        out[pos] = (int8_t)d; k >>= 1;
+    }
+    return top;
+}
+
 // ---------------------------------------------------------------- host point helpers
 using h51::ge5; using h51::niels5;
 struct HostTables { std::vector<niels> B, Bb; std::vector<niels5> B5, Bb5; ge base, bblind; };
@@ -96,6 +112,34 @@ ge h_fixed_mul32(const std::vector<niels> &tab, const sc &k_canon) {
     return acc;
 }
 
+// ---------------------------------------------------------------- small host thread pool
+// The per-round host tails (one Horner chain + transcript per chunk) are independent across chunks.
+class HostPool {
+    std::vector<std::thread> workers; std::mutex mu; std::condition_variable cv;
+    std::function<void(size_t)> fn; std::atomic<size_t> count{0}, next{0}, done{0}; std::atomic<int> active{0}; uint64_t gen = 0; bool stop = false;
+    void work() { active.fetch_add(1); for (;;) { size_t i = next.fetch_add(1); if (i >= count.load()) break; fn(i); done.fetch_add(1); } active.fetch_sub(1); }
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return stop || gen != seen; }); if (stop) return; seen = gen; }
+            work();
+        }
+    }
+public:
+    explicit HostPool(int nthreads) { for (int i = 1; i < nthreads; i++) workers.emplace_back([this] { loop(); }); }
+    ~HostPool() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); for (auto &t : workers) t.join(); }
+    void run(size_t n, std::function<void(size_t)> f) {
+        if (n <= 1 || workers.empty()) { for (size_t i = 0; i < n; i++) f(i); return; }
+        while (active.load() > 0) std::this_thread::yield();     // no straggler of the previous job may still look at fn
+        { std::lock_guard<std::mutex> lk(mu); count = 0; fn = std::move(f); done = 0; next = 0; count = n; gen++; }
+        cv.notify_all();
+        work();
+        while (done.load() < n) std::this_thread::yield();
+        // workers that woke late see next >= count and go back to sleep; make sure none is still inside work()
+        // with a stale fn before the next run() replaces it: done == n implies every claimed index finished.
+    }
+};
+
 // ---------------------------------------------------------------- device buffers
 struct DevBuf {
     void *p = nullptr; size_t cap = 0;
@@ -127,13 +171,14 @@ struct Timing {
     bool enabled = false;
     rofl_timing_t t{};
     std::vector<std::pair<hipEvent_t, hipEvent_t>> acc_ev, fold_ev;
+    std::vector<std::string> acc_tag, fold_tag;
     hipEvent_t first = nullptr, last = nullptr;
     std::vector<hipEvent_t> pool; size_t used = 0;
     hipEvent_t get() {
         if (used == pool.size()) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); pool.push_back(e); }
         return pool[used++];
     }
-    void reset() { t = rofl_timing_t{}; acc_ev.clear(); fold_ev.clear(); used = 0; first = last = nullptr; }
+    void reset() { t = rofl_timing_t{}; acc_ev.clear(); fold_ev.clear(); acc_tag.clear(); fold_tag.clear(); used = 0; first = last = nullptr; }
 };
 
 struct Ctx {
@@ -145,13 +190,15 @@ struct Ctx {
     niels *d_tabB = nullptr, *d_tabBb = nullptr;
     sc *d_two_pow = nullptr;
     std::map<std::pair<size_t, size_t>, niels *> gens;   // (n, m) -> [G(N) | H(N)]
-    int fold_t = 2, fold_k = 0; long fold_threads = 524288;
+    std::unique_ptr<HostPool> pool;
+    size_t fold_min = 1024;
+    int fold_t = 2, fold_t1 = 3, fold_k = 0, fold_tab = 1, fold_unit = 1; long fold_threads = 524288;
     Timing tm;
     // workspace
     DevBuf cp, sL, sR, party, Scanon, vshift, blind, Vbytes, Cbytes, status, partial, partial2, scpart, a, b, yinv,
-        SL, SR, msm_cnt, msm_off, msm_cur, msm_perm, msm_sorted, msm_buckets, msm_S[2], msm_C[2], msm_probs, foldprobs, naf,
+        SL, SR, msm_cnt, msm_off, msm_cur, msm_perm, msm_sorted, msm_buckets, msm_S[2], msm_C[2], stab, msm_probs, foldprobs, naf,
         gbuf[2], aux_pts, aux_scal, vscal, tmp_in, tmp_in2, tmp_out, vals, uni, stream_buf;
-    PinBuf h_cp, h_res, h_part, h_misc, h_misc2, h_probs, h_auxc, h_auxs;
+    PinBuf h_cp, h_res, h_part, h_misc, h_misc2, h_probs, h_auxc, h_auxs, h_stab;
 
     void init() {
         if (inited) return;
@@ -175,6 +222,11 @@ struct Ctx {
         HIPCHK(hipMalloc(&d_two_pow, sizeof(tp)));
         HIPCHK(hipMemcpy(d_two_pow, tp, sizeof(tp), hipMemcpyHostToDevice));
         if (const char *e = getenv("ROFL_FOLD_T")) { int v = atoi(e); if (v >= 1 && v <= 6) fold_t = v; }
+        if (const char *e = getenv("ROFL_FOLD_MIN")) { long v = atol(e); if (v >= 1) fold_min = (size_t)v; }
+        { int nt = 8; if (const char *e = getenv("ROFL_HOST_THREADS")) nt = atoi(e); unsigned hc = std::thread::hardware_concurrency(); if (hc && (unsigned)nt > hc) nt = (int)hc; if (nt < 1) nt = 1; pool.reset(new HostPool(nt)); }
+        if (const char *e = getenv("ROFL_FOLD_T1")) { int v = atoi(e); if (v >= 1 && v <= 6) fold_t1 = v; }
+        if (const char *e = getenv("ROFL_FOLD_TAB")) fold_tab = atoi(e) != 0;
+        if (const char *e = getenv("ROFL_FOLD_UNIT")) fold_unit = atoi(e) != 0;
         if (const char *e = getenv("ROFL_FOLD_K")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) fold_k = v; }
         if (const char *e = getenv("ROFL_FOLD_THREADS")) { long v = atol(e); if (v > 0) fold_threads = v; }
         inited = true;
@@ -202,22 +254,24 @@ niels *get_gens(Ctx &C, size_t n, size_t m) {
     auto it = C.gens.find(key);
     if (it != C.gens.end()) return it->second;
     size_t N = n * m;
-    niels *tbl; HIPCHK(hipMalloc(&tbl, sizeof(niels) * 2 * N));
+    niels *tbl; HIPCHK(hipMalloc(&tbl, sizeof(niels) * 2 * N * 16));      // slice 0 = generators, 1..15 = fold tables
     uint8_t *uni = C.uni.as<uint8_t>(2 * N * 64);
     hipLaunchKernelGGL(k_gens_xof, grid1(2 * m), dim3(TPB), 0, C.stream, (u32)n, (u32)m, uni);
     hipLaunchKernelGGL(k_gens_map, grid1(2 * N), dim3(TPB), 0, C.stream, (u32)(2 * N), uni, tbl);
+    hipLaunchKernelGGL(k_gens_tables, grid1(2 * N), dim3(TPB), 0, C.stream, (u32)(2 * N), tbl, (size_t)(2 * N));
     HIPCHK(hipStreamSynchronize(C.stream));
     C.gens[key] = tbl;
     return tbl;
 }
 
 // ---------------------------------------------------------------- MSM driver
-struct MsmPlan { u32 c, W, B, levels; };
+struct MsmPlan { u32 c, W, B, levels, wide; };
 MsmPlan msm_plan(size_t n) {
     MsmPlan p;
     if (n >= (1u << 17)) p.c = 16; else if (n >= (1u << 13)) p.c = 13; else if (n >= (1u << 9)) p.c = 10; else if (n >= 64) p.c = 7; else p.c = 4;
     if (const char *e = getenv("ROFL_MSM_C")) { int v = atoi(e); if (v == 4 || v == 7 || v == 10 || v == 13 || v == 16) p.c = (u32)v; }
     p.W = (254 + p.c - 1) / p.c;
+    p.wide = 254 - (p.c - 1) * p.W;      // `wide` windows of c bits, the rest c-1 bits: wide*c + (W-wide)*(c-1) = 254
     p.B = 1u << (p.c - 1);
     p.levels = (p.c - 1) / 3;
     return p;
@@ -236,13 +290,14 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
     u32 *perm = C.msm_perm.as<u32>(PW * P.B);
     ge *buckets = C.msm_buckets.as<ge>(PW * P.B);
     HIPCHK(hipMemsetAsync(cnt, 0, sizeof(u32) * PW * P.B, C.stream));
-    hipLaunchKernelGGL(k_msm_count, grid1(n, (u32)PW), dim3(TPB), 0, C.stream, (u32)n, P.c, P.W, d_probs, cnt);
+    MsmWin mw{P.c, P.W, P.wide};
+    hipLaunchKernelGGL(k_msm_count, grid1(n, (u32)PW), dim3(TPB), 0, C.stream, (u32)n, mw, d_probs, cnt);
     hipLaunchKernelGGL(k_msm_scan, dim3((unsigned)PW), dim3(TPB), 0, C.stream, P.B, cnt, off, cur, perm);
-    hipLaunchKernelGGL(k_msm_scatter, grid1(n, (u32)PW), dim3(TPB), 0, C.stream, (u32)n, P.c, P.W, d_probs, cur, sorted);
+    hipLaunchKernelGGL(k_msm_scatter, grid1(n, (u32)PW), dim3(TPB), 0, C.stream, (u32)n, mw, d_probs, cur, sorted);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (C.tm.enabled) { e0 = C.tm.get(); e1 = C.tm.get(); HIPCHK(hipEventRecord(e0, C.stream)); }
     hipLaunchKernelGGL(k_msm_accumulate, grid1((size_t)P.W * P.B, (u32)np), dim3(TPB), 0, C.stream, (u32)n, P.c, P.W, d_probs, cnt, off, sorted, perm, buckets);
-    if (C.tm.enabled) { HIPCHK(hipEventRecord(e1, C.stream)); C.tm.acc_ev.push_back({e0, e1}); C.tm.t.msm_accumulate_launches++; }
+    if (C.tm.enabled) { HIPCHK(hipEventRecord(e1, C.stream)); C.tm.acc_ev.push_back({e0, e1}); C.tm.t.msm_accumulate_launches++; char tg[96]; snprintf(tg, sizeof tg, "msm np=%zu n=%zu c=%u", np, n, P.c); C.tm.acc_tag.push_back(tg); }
     // reduction tree
     const ge *S_in = buckets; const ge *C_in = nullptr;
     u32 E = P.B, nb = 0;
@@ -261,19 +316,19 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
     HIPCHK(hipStreamSynchronize(C.stream));
     double t0 = now_ms();
     results.resize(np);
-#pragma omp parallel for schedule(dynamic, 1)
-    for (size_t p = 0; p < np; p++) {
+    C.pool->run(np, [&](size_t p) {
         ge5 acc = h51::identity(); bool started = false;
         for (int w = (int)P.W - 1; w >= 0; w--) {
             size_t pw = p * P.W + w;
-            for (int l = (int)P.c - 1; l >= 0; l--) {
+            int width = (u32)w < P.wide ? (int)P.c : (int)P.c - 1;
+            for (int l = width - 1; l >= 0; l--) {
                 if (started) acc = h51::gdouble(acc);
                 if (l <= (int)P.c - 2) { acc = h51::gadd(acc, h51::from_ge(h[PW + pw * nb + l])); started = true; }
                 if (l == 0) { acc = h51::gadd(acc, h51::from_ge(h[pw])); started = true; }
             }
         }
         results[p] = acc;
-    }
+    });
     C.tm.t.host_ms += now_ms() - t0;
 }
 
@@ -337,8 +392,7 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
     std::vector<Merlin> tr; tr.reserve(P);
     std::vector<sc> a_bl(P), s_bl(P), y(P), z(P), zz(P), x(P), w(P);
     for (size_t c = 0; c < P; c++) tr.emplace_back(label, strlen(label));
-#pragma omp parallel for schedule(dynamic, 1)
-    for (size_t c = 0; c < P; c++) {
+    C.pool->run(P, [&](size_t c) {
         uint8_t *o = proofs_out + c * plen;
         Merlin &t = tr[c];
         t.append("dom-sep", (const uint8_t *)"rangeproof v1", 13);
@@ -356,7 +410,7 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
         cp.y = h_mont(y[c]); cp.z = h_mont(z[c]); cp.zz = h_mont(zz[c]);
         cp.yinv = h_mont(h_inv(y[c]));
         fill_pow2(cp.ypow2, cp.y, MAX_LG); fill_pow2(cp.yinvpow2, cp.yinv, MAX_LG); fill_pow2(cp.zpow2, cp.z, MAX_LG);
-    }
+    });
     C.tm.t.host_ms += now_ms() - th;
     HIPCHK(hipMemcpyAsync(d_cp, h_cp, sizeof(ChunkParams) * P, hipMemcpyHostToDevice, C.stream));
     u32 nblkT = (u32)std::min<size_t>(64, (N + TPB - 1) / TPB);
@@ -368,8 +422,7 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
     HIPCHK(hipMemcpyAsync(h_sc, scpart, sizeof(sc) * P * nblkS * 3, hipMemcpyDeviceToHost, C.stream));
     HIPCHK(hipStreamSynchronize(C.stream));
     th = now_ms();
-#pragma omp parallel for schedule(dynamic, 1)
-    for (size_t c = 0; c < P; c++) {
+    C.pool->run(P, [&](size_t c) {
         uint8_t *o = proofs_out + c * plen;
         Merlin &t = tr[c];
         sc t0 = h_canon(sum_partials(h_t + c * nblkT * 3, nblkT, 3, 0));
@@ -393,34 +446,48 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
         // InnerProductProof::create
         t.append("dom-sep", (const uint8_t *)"ipp v1", 6);
         t.append_u64("n", N);
-    }
+    });
     C.tm.t.host_ms += now_ms() - th;
     HIPCHK(hipMemcpyAsync(d_cp, h_cp, sizeof(ChunkParams) * P, hipMemcpyHostToDevice, C.stream));
     sc *a = C.a.as<sc>(P * N), *b = C.b.as<sc>(P * N), *yinvpow = C.yinv.as<sc>(P * N);
     hipLaunchKernelGGL(k_lr_vec, grid1(N, (u32)P), dim3(TPB), 0, C.stream, (u32)n, (u32)m, d_cp, d_vshift, sL, sR, C.d_two_pow, a, b, yinvpow);
 
     // ---- IPP rounds with lazily folded generators
+    // Invariant: true G[j] = gscale * Gc[j], true H[j] = hscale * y^-j * Hc[j] for the materialised arrays Gc, Hc.
     size_t n_g = N; unsigned r = 0;
     std::vector<const niels *> cur(P, tbl);
     std::vector<std::vector<sc>> pu(P), pui(P);    // pending challenges (Montgomery)
-    int gsel = 0;
+    std::vector<sc> gscale(P, sc_one_mont()), hscale(P, sc_one_mont());
+    int gsel = 0; bool first_level = true;
+    auto stab = [&](size_t c, u32 h, sc &g, sc &hh) {
+        g = sc_one_mont(); hh = sc_one_mont();
+        for (unsigned q = 0; q < r; q++) {
+            bool bit = (h >> (r - 1 - q)) & 1;
+            g = sc_montmul(g, bit ? pu[c][q] : pui[c][q]);
+            hh = sc_montmul(hh, bit ? pui[c][q] : pu[c][q]);
+        }
+    };
     for (unsigned round = 0; round < lgN; round++) {
         size_t n_k = n_g >> r, nh = n_k / 2;
+        // products of the pending challenges: s[h] for h < 2^r, built by doubling (1 multiplication per entry)
+        u32 nstab = 1u << r;
+        sc *h_stab = C.h_stab.as<sc>(P * 2 * nstab);
+        sc *d_stab = C.stab.as<sc>(P * 2 * nstab);
         for (size_t c = 0; c < P; c++) {
-            ChunkParams &cp = h_cp[c];
-            for (u32 h = 0; h < (1u << r); h++) {
-                sc g = sc_one_mont(), hh = sc_one_mont();
-                for (unsigned q = 0; q < r; q++) {
-                    bool bit = (h >> (r - 1 - q)) & 1;
-                    g = sc_montmul(g, bit ? pu[c][q] : pui[c][q]);
-                    hh = sc_montmul(hh, bit ? pui[c][q] : pu[c][q]);
+            sc *sg = h_stab + (c * 2 + 0) * nstab, *sh = h_stab + (c * 2 + 1) * nstab;
+            sg[0] = gscale[c]; sh[0] = hscale[c];
+            for (unsigned q = 0; q < r; q++) {          // challenge q <-> bit (r-1-q) of h; process from the last challenge (bit 0) up
+                unsigned qq = r - 1 - q; u32 half = 1u << q;   // after this step entries [0, 2*half) are valid for bits 0..q
+                for (u32 hlow = 0; hlow < half; hlow++) {
+                    sc g0v = sg[hlow], h0v = sh[hlow];
+                    sg[hlow] = sc_montmul(g0v, pui[c][qq]); sg[hlow + half] = sc_montmul(g0v, pu[c][qq]);
+                    sh[hlow] = sc_montmul(h0v, pu[c][qq]); sh[hlow + half] = sc_montmul(h0v, pui[c][qq]);
                 }
-                cp.stabG[h] = g; cp.stabH[h] = hh;
             }
         }
-        HIPCHK(hipMemcpyAsync(d_cp, h_cp, sizeof(ChunkParams) * P, hipMemcpyHostToDevice, C.stream));
+        HIPCHK(hipMemcpyAsync(d_stab, h_stab, sizeof(sc) * P * 2 * nstab, hipMemcpyHostToDevice, C.stream));
         sc *SL = C.SL.as<sc>(P * 2 * n_g), *SR = C.SR.as<sc>(P * 2 * n_g);
-        hipLaunchKernelGGL(k_ipp_scalars, grid1(n_g, (u32)P), dim3(TPB), 0, C.stream, (u32)n_g, (u32)n_k, d_cp, a, b, N, yinvpow, N, SL, SR);
+        hipLaunchKernelGGL(k_ipp_scalars, grid1(n_g, (u32)P), dim3(TPB), 0, C.stream, (u32)n_g, (u32)n_k, d_stab, nstab, a, b, N, yinvpow, N, SL, SR);
         u32 nblkI = (u32)std::min<size_t>(32, (nh + TPB - 1) / TPB);
         sc *ipart = C.tmp_out.as<sc>(P * 64 * 3);
         hipLaunchKernelGGL(k_ipp_inner, dim3(nblkI, (u32)P), dim3(TPB), 0, C.stream, (u32)nh, a, b, N, ipart);
@@ -431,8 +498,7 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
         C.tm.t.msm_terms += P * 2 * n_g;
         msm_run(C, pr, 2 * n_g, res);
         th = now_ms();
-#pragma omp parallel for schedule(dynamic, 1)
-        for (size_t c = 0; c < P; c++) {
+        C.pool->run(P, [&](size_t c) {
             uint8_t *o = proofs_out + c * plen + 7 * 32 + 64 * round;
             sc cL = h_canon(sum_partials(h_ip + c * nblkI * 2, nblkI, 2, 0));
             sc cR = h_canon(sum_partials(h_ip + c * nblkI * 2, nblkI, 2, 1));
@@ -443,45 +509,68 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
             sc um = h_mont(u), uim = sc_invert_mont(um);
             h_cp[c].u[0] = um; h_cp[c].uinv[0] = uim;
             pu[c].push_back(um); pui[c].push_back(uim);
-        }
+        });
         C.tm.t.host_ms += now_ms() - th;
         HIPCHK(hipMemcpyAsync(d_cp, h_cp, sizeof(ChunkParams) * P, hipMemcpyHostToDevice, C.stream));
         hipLaunchKernelGGL(k_ipp_fold_ab, grid1(nh, (u32)P), dim3(TPB), 0, C.stream, (u32)nh, d_cp, a, b, N);
         r++;
         bool last = (round + 1 == lgN);
-        if (!last && (r == (unsigned)C.fold_t)) {
-            // materialise: new[i] = sum_h s_h * cur[h*n_new + i]
+        unsigned t_now = first_level ? (unsigned)C.fold_t1 : (unsigned)C.fold_t;
+        if (!last && r >= t_now && (n_g >> r) >= C.fold_min) {
+            // materialise: new[i] = sum_h s_h * cur[h*n_new + i]; with fold_unit the common factor s_0 moves into
+            // gscale / hscale so that source 0 needs a single addition
             size_t n_new = n_g >> r; u32 nsrc = 1u << r;
+            bool use_tab = first_level && C.fold_tab;
+            int unit = C.fold_unit;
+            size_t dstride = use_tab ? (size_t)4 * FOLD_TAB_DIGITS : 256;
             th = now_ms();
-            int8_t *h_naf = C.h_misc.as<int8_t>(2 * P * nsrc * 256);
+            int8_t *h_dig = C.h_misc.as<int8_t>(2 * P * nsrc * dstride);
+            memset(h_dig, 0, 2 * P * nsrc * dstride);
             FoldProb *h_fp = C.h_misc2.as<FoldProb>(2 * P);
+            FoldTabProb *h_ftp = C.h_probs.as<FoldTabProb>(2 * P);
             niels *gnew = C.gbuf[gsel].as<niels>(P * 2 * n_new);
             int top = 0;
             for (size_t c = 0; c < P; c++) {
                 sc yn = sc_one_mont();                       // y^-(h*n_new), stepping by y^-n_new
                 sc ystep = sc_one_mont();
                 { size_t e = n_new; int bidx = 0; while (e) { if (e & 1) ystep = sc_montmul(ystep, h_cp[c].yinvpow2[bidx]); e >>= 1; bidx++; } }
+                // s_G(0) = prod uinv and s_G(all ones) = prod u = 1 / s_G(0); for H the roles of u and uinv swap
+                sc g0, h0; stab(c, 0, g0, h0);
+                sc gall, hall; stab(c, nsrc - 1, gall, hall);
                 for (u32 h = 0; h < nsrc; h++) {
-                    sc g = sc_one_mont(), hh = sc_one_mont();
-                    for (unsigned q = 0; q < r; q++) {
-                        bool bit = (h >> (r - 1 - q)) & 1;
-                        g = sc_montmul(g, bit ? pu[c][q] : pui[c][q]);
-                        hh = sc_montmul(hh, bit ? pui[c][q] : pu[c][q]);
-                    }
+                    sc g, hh; stab(c, h, g, hh);
                     hh = sc_montmul(hh, yn);
                     yn = sc_montmul(yn, ystep);
-                    int t1 = sc_naf(h_naf + ((2 * c) * nsrc + h) * 256, h_canon(g));
-                    int t2 = sc_naf(h_naf + ((2 * c + 1) * nsrc + h) * 256, h_canon(hh));
-                    top = std::max(top, std::max(t1, t2));
+                    if (unit) {
+                        if (h == 0) continue;                 // scalar 1: handled by one addition in the kernel
+                        g = sc_montmul(g, gall); hh = sc_montmul(hh, hall);
+                    }
+                    sc gc = h_canon(g), hc = h_canon(hh);
+                    if (use_tab) {
+                        for (int pc = 0; pc < 4; pc++) {
+                            u64 pg = (u64)gc.v[2 * pc] | ((u64)gc.v[2 * pc + 1] << 32), ph = (u64)hc.v[2 * pc] | ((u64)hc.v[2 * pc + 1] << 32);
+                            int t1 = wnaf4_u64(h_dig + (((2 * c) * nsrc + h) * 4 + pc) * FOLD_TAB_DIGITS, pg);
+                            int t2 = wnaf4_u64(h_dig + (((2 * c + 1) * nsrc + h) * 4 + pc) * FOLD_TAB_DIGITS, ph);
+                            top = std::max(top, std::max(t1, t2));
+                        }
+                    } else {
+                        int t1 = sc_naf(h_dig + ((2 * c) * nsrc + h) * 256, gc);
+                        int t2 = sc_naf(h_dig + ((2 * c + 1) * nsrc + h) * 256, hc);
+                        top = std::max(top, std::max(t1, t2));
+                    }
                 }
+                if (unit) { gscale[c] = sc_montmul(gscale[c], g0); hscale[c] = sc_montmul(hscale[c], h0); }
                 h_fp[2 * c] = FoldProb{cur[c], gnew + c * 2 * n_new};
                 h_fp[2 * c + 1] = FoldProb{cur[c] + n_g, gnew + c * 2 * n_new + n_new};
+                h_ftp[2 * c] = FoldTabProb{0u, gnew + c * 2 * n_new};
+                h_ftp[2 * c + 1] = FoldTabProb{(u32)n_g, gnew + c * 2 * n_new + n_new};
             }
             C.tm.t.host_ms += now_ms() - th;
-            int8_t *d_naf = C.naf.as<int8_t>(2 * P * nsrc * 256);
-            FoldProb *d_fp = C.foldprobs.as<FoldProb>(2 * P);
-            HIPCHK(hipMemcpyAsync(d_naf, h_naf, 2 * P * nsrc * 256, hipMemcpyHostToDevice, C.stream));
-            HIPCHK(hipMemcpyAsync(d_fp, h_fp, sizeof(FoldProb) * 2 * P, hipMemcpyHostToDevice, C.stream));
+            int8_t *d_dig = C.naf.as<int8_t>(2 * P * nsrc * dstride);
+            HIPCHK(hipMemcpyAsync(d_dig, h_dig, 2 * P * nsrc * dstride, hipMemcpyHostToDevice, C.stream));
+            void *d_fpv = C.foldprobs.ensure(2 * P * 16);
+            if (use_tab) HIPCHK(hipMemcpyAsync(d_fpv, h_ftp, sizeof(FoldTabProb) * 2 * P, hipMemcpyHostToDevice, C.stream));
+            else HIPCHK(hipMemcpyAsync(d_fpv, h_fp, sizeof(FoldProb) * 2 * P, hipMemcpyHostToDevice, C.stream));
             hipEvent_t e0 = nullptr, e1 = nullptr;
             if (C.tm.enabled) { e0 = C.tm.get(); e1 = C.tm.get(); HIPCHK(hipEventRecord(e0, C.stream)); }
             {
@@ -491,7 +580,8 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
                 while (K < FOLD_MAXSEG && thr * K < (size_t)C.fold_threads) K *= 2;
                 if (C.fold_k > 0) K = (u32)C.fold_k;
                 FoldSeg seg{};
-                double cst = 1.0 + nsrc / 3.0, lo_t = 0, hi_t = (top + 1) * cst + top + 1;
+                double eff = (double)(nsrc - (unit ? 1 : 0));
+                double cst = 1.0 + (use_tab ? eff * 4.0 / 5.0 : eff / 3.0), lo_t = 0, hi_t = (top + 1) * cst + top + 1;
                 int bounds[FOLD_MAXSEG + 1];
                 for (int it = 0; it < 60; it++) {
                     double T = 0.5 * (lo_t + hi_t), pos = 0;
@@ -502,13 +592,17 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
                 bounds[K] = top + 1;
                 for (u32 k = 1; k <= K; k++) if (bounds[k] < bounds[k - 1]) bounds[k] = bounds[k - 1];
                 for (u32 k = 0; k <= FOLD_MAXSEG; k++) seg.lo[k] = bounds[k <= K ? k : K];
-                hipLaunchKernelGGL(k_fold_gens, dim3((unsigned)((n_new + 63) / 64), (u32)(2 * P)), dim3(64, K), (K - 1) * 64 * sizeof(ge), C.stream, (u32)n_new, nsrc, seg, d_fp, d_naf);
+                dim3 grid((unsigned)((n_new + 63) / 64), (u32)(2 * P)), block(64, K);
+                if (use_tab)
+                    hipLaunchKernelGGL(k_fold_gens_tab, grid, block, (K - 1) * 64 * sizeof(ge), C.stream, (u32)n_new, nsrc, seg, tbl, (size_t)(2 * N),
+                                       (const FoldTabProb *)d_fpv, d_dig, unit);
+                else
+                    hipLaunchKernelGGL(k_fold_gens, grid, block, (K - 1) * 64 * sizeof(ge), C.stream, (u32)n_new, nsrc, seg, (const FoldProb *)d_fpv, d_dig, unit);
             }
-            if (C.tm.enabled) { HIPCHK(hipEventRecord(e1, C.stream)); C.tm.fold_ev.push_back({e0, e1}); C.tm.t.fold_launches++; C.tm.t.fold_point_reads += (uint64_t)2 * P * n_g; }
-            HIPCHK(hipStreamSynchronize(C.stream));   // h_naf / h_fp staging reused next round
+            if (C.tm.enabled) { HIPCHK(hipEventRecord(e1, C.stream)); C.tm.fold_ev.push_back({e0, e1}); C.tm.t.fold_launches++; { char tg[96]; snprintf(tg, sizeof tg, "fold n_g=%zu nsrc=%u tab=%d", n_g, nsrc, (int)use_tab); C.tm.fold_tag.push_back(tg); } C.tm.t.fold_point_reads += (uint64_t)2 * P * n_g; }
+            HIPCHK(hipStreamSynchronize(C.stream));   // digit / problem staging buffers are reused next time
             for (size_t c = 0; c < P; c++) { cur[c] = gnew + c * 2 * n_new; pu[c].clear(); pui[c].clear(); }
-            // the y^-j weighting of H persists: true H[j] = y^-j * Hc[j] for the new array as well
-            n_g = n_new; r = 0; gsel ^= 1;
+            n_g = n_new; r = 0; gsel ^= 1; first_level = false;
         }
     }
     // a[0], b[0]
@@ -566,8 +660,7 @@ int verify_chunks(Ctx &C, const char *label, size_t gens_capacity, size_t P, siz
     std::vector<sc> sB(P), sBb(P);
     static const uint8_t zero32[32] = {0};
     double th = now_ms();
-#pragma omp parallel for schedule(dynamic, 1)
-    for (size_t c = 0; c < P; c++) {
+    C.pool->run(P, [&](size_t c) {
         const uint8_t *p = proofs + c * plen; const uint8_t *ipp = p + 7 * 32;
         Merlin t(label, strlen(label));
         t.append("dom-sep", (const uint8_t *)"rangeproof v1", 13);
@@ -621,7 +714,7 @@ int verify_chunks(Ctx &C, const char *label, size_t gens_capacity, size_t P, siz
         sc sum_2 = geo(twom, lg2u(n));
         sc delta = sc_sub(h_mul(sc_sub(z, zz), sum_y), h_mul(h_mul(h_mul(zz, z), sum_2), sum_z));
         sB[c] = sc_add(h_mul(w, sc_sub(t_x, h_mul(a, b))), h_mul(cc, sc_sub(delta, t_x)));
-    }
+    });
     C.tm.t.host_ms += now_ms() - th;
     HIPCHK(hipMemcpyAsync(d_cp, h_cp, sizeof(ChunkParams) * P, hipMemcpyHostToDevice, C.stream));
     sc *gh = C.SL.as<sc>(P * 2 * N);
@@ -709,8 +802,9 @@ void timing_end(Ctx &C) {
     HIPCHK(hipEventRecord(C.tm.last, C.stream));
     HIPCHK(hipEventSynchronize(C.tm.last));
     float ms = 0; HIPCHK(hipEventElapsedTime(&ms, C.tm.first, C.tm.last)); C.tm.t.total_ms = ms;
-    for (auto &e : C.tm.acc_ev) { HIPCHK(hipEventElapsedTime(&ms, e.first, e.second)); C.tm.t.msm_accumulate_ms += ms; }
-    for (auto &e : C.tm.fold_ev) { HIPCHK(hipEventElapsedTime(&ms, e.first, e.second)); C.tm.t.fold_ms += ms; }
+    bool trace = getenv("ROFL_TRACE") != nullptr;
+    for (size_t i = 0; i < C.tm.acc_ev.size(); i++) { auto &e = C.tm.acc_ev[i]; HIPCHK(hipEventElapsedTime(&ms, e.first, e.second)); C.tm.t.msm_accumulate_ms += ms; if (trace) fprintf(stderr, "[rofl] %-40s accumulate %.3f ms\n", C.tm.acc_tag[i].c_str(), ms); }
+    for (size_t i = 0; i < C.tm.fold_ev.size(); i++) { auto &e = C.tm.fold_ev[i]; HIPCHK(hipEventElapsedTime(&ms, e.first, e.second)); C.tm.t.fold_ms += ms; if (trace) fprintf(stderr, "[rofl] %-40s %.3f ms\n", C.tm.fold_tag[i].c_str(), ms); }
 }
 
 template <class F> int guarded(F f) {

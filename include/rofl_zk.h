@@ -120,6 +120,9 @@ typedef struct {
 } rofl_timing_t;
 int rofl_last_timing(rofl_timing_t *out);
 int rofl_set_timing(int enabled);
+/* GPU multi-scalar multiplication sum_i k_i * P_i through the production Pippenger pipeline (dalek
+ * vartime_multiscalar_mul as used by upstream verify_multiple); test hook for skewed / extreme scalars. */
+int rofl_dbg_msm(const uint8_t *scalars32, const uint8_t *points32, size_t n, uint8_t out32[32]);
 /* field-multiply micro-benchmark: returns GF(2^255-19) multiplications per second on the device */
 int rofl_bench_femul(unsigned iters, double *fe_mul_per_sec_out);
 

@@ -513,11 +513,15 @@ __global__ void __launch_bounds__(256) k_fold_gens_tab(u32 n_new, u32 nsrc, Fold
 
 // ================================================================ K5: Pippenger MSM
 // Booth-recoded signed c-bit digit of window w: in [-2^(c-1), 2^(c-1)]
-// Window layout: W = ceil(254 / c) windows; the first `wide` windows are c bits, the rest c-1 bits, so that the top
-// window is as full as the others (a short top window would put all terms into a handful of buckets).
+// Window layout over bits [0, 254): the top window is c+1 bits wide, [253-c, 254) -- scalars are < l ~ 2^252, so
+// its two top bits are (almost) always zero and its digits fill the same 2^(c-1) buckets as a signed c-bit window;
+// below it `wide` windows of c bits and the rest of c-1 bits.  (A short top window would put every term into a
+// handful of buckets and serialise the accumulation.)  Digits above 2^(c-1) can only occur for scalars >= 2^252
+// and are split into two bucket entries.
 struct MsmWin { u32 c, W, wide; };
 __device__ __forceinline__ void msm_window(const MsmWin &mw, u32 w, u32 &pos, u32 &width) {
-    if (w < mw.wide) { pos = w * mw.c; width = mw.c; }
+    if (w + 1 == mw.W) { pos = 253 - mw.c; width = mw.c + 1; }
+    else if (w < mw.wide) { pos = w * mw.c; width = mw.c; }
     else { pos = mw.wide * mw.c + (w - mw.wide) * (mw.c - 1); width = mw.c - 1; }
 }
 // Booth-recoded signed digit of the window [pos, pos + width): in [-2^(width-1), 2^(width-1)]
@@ -548,7 +552,9 @@ __global__ void __launch_bounds__(TPB) k_msm_count(u32 n, MsmWin mw, const MsmPr
     sc k = load_sc(&probs[p].scal[i]);
     u32 wpos, wwid; msm_window(mw, w, wpos, wwid);
     int d = msm_digit(k, wpos, wwid);
-    if (d) atomicAdd(&cnt[(size_t)pw * B + (u32)(d < 0 ? -d : d) - 1], 1u);
+    u32 ad = (u32)(d < 0 ? -d : d);
+    if (ad > B) { atomicAdd(&cnt[(size_t)pw * B + B - 1], 1u); ad -= B; }
+    if (ad) atomicAdd(&cnt[(size_t)pw * B + ad - 1], 1u);
 }
 // One block per (prob, window): exclusive scan of the histogram (off, cursor) and a bucket permutation sorted by
 // descending count (perm), so that the 64 lanes of an accumulate wave own buckets of (nearly) equal size.
@@ -571,7 +577,7 @@ __global__ void __launch_bounds__(TPB) k_msm_scan(u32 B, const u32 *cnt, u32 *of
         __syncthreads();
     }
     u32 run = t ? part[t - 1] : 0;
-    for (u32 i = lo; i < hi && i < B; i++) { off[base + i] = run; cursor[base + i] = run; run += cnt[base + i]; }
+    if (cursor) for (u32 i = lo; i < hi && i < B; i++) { off[base + i] = run; cursor[base + i] = run; run += cnt[base + i]; }
     // descending-count start offsets: start[b] = #buckets with count bin > b
     __syncthreads();
     part[t] = hist[255 - t];          // reversed, then inclusive scan
@@ -597,22 +603,56 @@ __global__ void __launch_bounds__(TPB) k_msm_scatter(u32 n, MsmWin mw, const Msm
     sc k = load_sc(&probs[p].scal[i]);
     u32 wpos, wwid; msm_window(mw, w, wpos, wwid);
     int d = msm_digit(k, wpos, wwid);
-    if (d) {
-        u32 ad = (u32)(d < 0 ? -d : d) - 1;
-        u32 pos = atomicAdd(&cursor[(size_t)pw * B + ad], 1u);
-        sorted[(size_t)pw * n + pos] = i | (d < 0 ? 0x80000000u : 0u);
+    u32 ad = (u32)(d < 0 ? -d : d), entry = i | (d < 0 ? 0x80000000u : 0u);
+    if (ad > B) { u32 pos = atomicAdd(&cursor[(size_t)pw * B + B - 1], 1u); sorted[(size_t)pw * n * 2 + pos] = entry; ad -= B; }
+    if (ad) { u32 pos = atomicAdd(&cursor[(size_t)pw * B + ad - 1], 1u); sorted[(size_t)pw * n * 2 + pos] = entry; }
+}
+// Single-pass variant: every bucket owns `cap` slots (HBM capacity instead of a counting pass); cursor doubles as the
+// per-bucket count.  The (astronomically rare for hash-derived scalars) entries beyond `cap` go to an overflow list
+// that k_msm_overflow adds afterwards; if even that list overflows the host falls back to the two-pass path.
+struct MsmOvf { u32 bucket; u32 entry; };
+__global__ void __launch_bounds__(TPB) k_msm_scatter_slots(u32 n, MsmWin mw, const MsmProb *probs, u32 *cursor, u32 *slots /* [prob][W][B][cap] */,
+                                                           u32 cap, u32 *ovf_count, MsmOvf *ovf, u32 ovf_max) {
+    u32 W = mw.W, pw = blockIdx.y, p = pw / W, w = pw % W, B = 1u << (mw.c - 1);
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    sc k = load_sc(&probs[p].scal[i]);
+    u32 wpos, wwid; msm_window(mw, w, wpos, wwid);
+    int d = msm_digit(k, wpos, wwid);
+    u32 ad = (u32)(d < 0 ? -d : d), entry = i | (d < 0 ? 0x80000000u : 0u);
+    for (int rep = 0; rep < 2; rep++) {
+        u32 a1 = rep == 0 ? (ad > B ? B : 0u) : (ad > B ? ad - B : ad);
+        if (!a1) continue;
+        u32 bi = pw * B + a1 - 1;
+        u32 pos = atomicAdd(&cursor[bi], 1u);
+        if (pos < cap) slots[(size_t)bi * cap + pos] = entry;
+        else { u32 o = atomicAdd(ovf_count, 1u); if (o < ovf_max) { ovf[o].bucket = bi; ovf[o].entry = entry; } }
+    }
+}
+// one 64-lane wave; lane l owns the overflow entries whose bucket index is l mod 64 (no two lanes share a bucket)
+__global__ void k_msm_overflow(u32 W, u32 B, const MsmProb *probs, const u32 *ovf_count, const MsmOvf *ovf, u32 ovf_max, ge *buckets) {
+    if (blockIdx.x) return;
+    u32 cnt = *ovf_count; if (cnt > ovf_max) cnt = ovf_max;
+    for (u32 o = 0; o < cnt; o++) {
+        u32 bi = ovf[o].bucket, v = ovf[o].entry, p = bi / (W * B);
+        if ((bi & 63u) != threadIdx.x) continue;
+        ge acc = load_ge(&buckets[bi]);
+        acc = ge_madd(acc, load_niels(&probs[p].pts[v & 0x7fffffffu]), (v >> 31) != 0);
+        store_ge(&buckets[bi], acc);
     }
 }
 // one thread per bucket: sum its points.  buckets [prob][W][B] extended.
 __global__ void __launch_bounds__(TPB) k_msm_accumulate(u32 n, u32 c, u32 W, const MsmProb *probs, const u32 *cnt, const u32 *off,
-                                 const u32 *sorted, const u32 *perm, ge *buckets) {
+                                 const u32 *sorted, const u32 *perm, ge *buckets, u32 cap) {
     u32 p = blockIdx.y, B = 1u << (c - 1);
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= W * B) return;
     u32 w = t / B;
     size_t bi = ((size_t)p * W + w) * B + perm[(size_t)p * W * B + t];
-    u32 start = off[bi], num = cnt[bi];
-    const u32 *lst = sorted + ((size_t)p * W + w) * n + start;
+    u32 num = cnt[bi];
+    const u32 *lst;
+    if (cap) { lst = sorted + bi * cap; if (num > cap) num = cap; }        // slot mode: `sorted` is the slot array
+    else lst = sorted + ((size_t)p * W + w) * n * 2 + off[bi];   // stride 2n: a top-window digit may emit two entries
     const niels *pts = probs[p].pts;
     ge acc = ge_identity();
     for (u32 e = 0; e < num; e++) {
@@ -626,13 +666,11 @@ __global__ void __launch_bounds__(TPB) k_msm_accumulate(u32 n, u32 c, u32 W, con
 //   role 0 threads: 8 children of S_in -> S_out, and the three new bit-sums (11 adds)
 //   role r>=1     : carried bit-sum r-1: 8 children -> 1 (7 adds)
 // in: S_in [PW][E], C_in [PW][nb][E];  out: S_out [PW][E/8], C_out [PW][nb+3][E/8]
-__global__ void __launch_bounds__(TPB) k_msm_reduce_level(u32 E, u32 nb, const ge *S_in, const ge *C_in, ge *S_out, ge *C_out) {
-    u32 pw = blockIdx.y, E8 = E / 8;
-    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= E8 * (1 + nb)) return;
-    u32 role = t / E8, g = t % E8;
+// one work item of a tree level; pointers are already offset to this (prob, window)
+__device__ __forceinline__ void msm_reduce_item(u32 E, u32 nb, const ge *S_in, const ge *C_in, ge *S_out, ge *C_out, u32 item) {
+    u32 E8 = E / 8, role = item / E8, g = item % E8;
     if (role == 0) {
-        const ge *s = S_in + (size_t)pw * E + (size_t)g * 8;
+        const ge *s = S_in + (size_t)g * 8;
         ge p0 = load_ge(&s[0]), p1 = load_ge(&s[1]);
         ge q0 = ge_add(p0, p1); ge D0 = p1;
         p0 = load_ge(&s[2]); p1 = load_ge(&s[3]);
@@ -644,17 +682,42 @@ __global__ void __launch_bounds__(TPB) k_msm_reduce_level(u32 E, u32 nb, const g
         ge r0 = ge_add(q0, q1), r1 = ge_add(q2, q3);
         ge D1 = ge_add(q1, q3);
         ge S = ge_add(r0, r1);
-        store_ge(&S_out[(size_t)pw * E8 + g], S);
-        ge *co = C_out + (size_t)pw * (nb + 3) * E8;
-        store_ge(&co[(size_t)(nb + 0) * E8 + g], D0);
-        store_ge(&co[(size_t)(nb + 1) * E8 + g], D1);
-        store_ge(&co[(size_t)(nb + 2) * E8 + g], r1);
+        store_ge(&S_out[g], S);
+        store_ge(&C_out[(size_t)(nb + 0) * E8 + g], D0);
+        store_ge(&C_out[(size_t)(nb + 1) * E8 + g], D1);
+        store_ge(&C_out[(size_t)(nb + 2) * E8 + g], r1);
     } else {
-        const ge *s = C_in + ((size_t)pw * nb + (role - 1)) * E + (size_t)g * 8;
+        const ge *s = C_in + (size_t)(role - 1) * E + (size_t)g * 8;
         ge acc = ge_add(load_ge(&s[0]), load_ge(&s[1]));
 #pragma unroll 1
         for (int k = 2; k < 8; k++) acc = ge_add(acc, load_ge(&s[k]));
-        store_ge(&C_out[((size_t)pw * (nb + 3) + (role - 1)) * E8 + g], acc);
+        store_ge(&C_out[(size_t)(role - 1) * E8 + g], acc);
+    }
+}
+__global__ void __launch_bounds__(TPB) k_msm_reduce_level(u32 E, u32 nb, const ge *S_in, const ge *C_in, ge *S_out, ge *C_out) {
+    u32 pw = blockIdx.y, E8 = E / 8;
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= E8 * (1 + nb)) return;
+    msm_reduce_item(E, nb, S_in + (size_t)pw * E, C_in + (size_t)pw * nb * E, S_out + (size_t)pw * E8, C_out + (size_t)pw * (nb + 3) * E8, t);
+}
+// All remaining levels (E <= 512) of one (prob, window) in a single block through LDS: one launch instead of
+// three or four latency-bound ones.  Output: S_fin [PW], C_fin [PW][nb_final].
+__global__ void __launch_bounds__(TPB) k_msm_reduce_fused(u32 E, u32 nb, const ge *S_in, const ge *C_in, ge *S_fin, ge *C_fin, u32 nb_final) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    ge *buf0 = reinterpret_cast<ge *>(smem);            // level outputs ping-pong; sized by the host for the largest level
+    u32 pw = blockIdx.x;
+    const ge *si = S_in + (size_t)pw * E, *ci = C_in + (size_t)pw * nb * E;
+    u32 half = (E / 8) * (1 + nb + 3);                  // elements of the first (largest) output level
+    ge *bufs[2] = {buf0, buf0 + half};
+    int sel = 0;
+    while (E > 1) {
+        u32 E8 = E / 8;
+        ge *so, *co;
+        if (E8 == 1) { so = S_fin + pw; co = C_fin + (size_t)pw * nb_final; }
+        else { so = bufs[sel]; co = bufs[sel] + E8; }
+        for (u32 item = threadIdx.x; item < E8 * (1 + nb); item += blockDim.x) msm_reduce_item(E, nb, si, ci, so, co, item);
+        __syncthreads();
+        si = so; ci = co; E = E8; nb += 3; sel ^= 1;
     }
 }
 

@@ -192,13 +192,14 @@ struct Ctx {
     std::map<std::pair<size_t, size_t>, niels *> gens;   // (n, m) -> [G(N) | H(N)]
     std::unique_ptr<HostPool> pool;
     size_t fold_min = 1024;
+    bool msm_slots = true;
     int fold_t = 2, fold_t1 = 3, fold_k = 0, fold_tab = 1, fold_unit = 1; long fold_threads = 524288;
     Timing tm;
     // workspace
     DevBuf cp, sL, sR, party, Scanon, vshift, blind, Vbytes, Cbytes, status, partial, partial2, scpart, a, b, yinv,
-        SL, SR, msm_cnt, msm_off, msm_cur, msm_perm, msm_sorted, msm_buckets, msm_S[2], msm_C[2], stab, msm_probs, foldprobs, naf,
+        SL, SR, msm_cnt, msm_off, msm_cur, msm_perm, msm_sorted, msm_ovf, msm_buckets, msm_S[2], msm_C[2], stab, msm_probs, foldprobs, naf,
         gbuf[2], aux_pts, aux_scal, vscal, tmp_in, tmp_in2, tmp_out, vals, uni, stream_buf;
-    PinBuf h_cp, h_res, h_part, h_misc, h_misc2, h_probs, h_auxc, h_auxs, h_stab;
+    PinBuf h_cp, h_res, h_part, h_misc, h_misc2, h_probs, h_auxc, h_auxs, h_stab, h_ovf;
 
     void init() {
         if (inited) return;
@@ -213,6 +214,7 @@ struct Ctx {
         build_fixed_table(ht.B, ht.base);
         build_fixed_table(ht.Bb, ht.bblind);
         to_tab5(ht.B5, ht.B); to_tab5(ht.Bb5, ht.Bb);
+        HIPCHK(hipFuncSetAttribute((const void *)k_msm_reduce_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipMalloc(&d_tabB, sizeof(niels) * 512));
         HIPCHK(hipMalloc(&d_tabBb, sizeof(niels) * 512));
         HIPCHK(hipMemcpy(d_tabB, ht.B.data(), sizeof(niels) * 512, hipMemcpyHostToDevice));
@@ -222,6 +224,7 @@ struct Ctx {
         HIPCHK(hipMalloc(&d_two_pow, sizeof(tp)));
         HIPCHK(hipMemcpy(d_two_pow, tp, sizeof(tp), hipMemcpyHostToDevice));
         if (const char *e = getenv("ROFL_FOLD_T")) { int v = atoi(e); if (v >= 1 && v <= 6) fold_t = v; }
+        if (const char *e = getenv("ROFL_MSM_SLOTS")) msm_slots = atoi(e) != 0;
         if (const char *e = getenv("ROFL_FOLD_MIN")) { long v = atol(e); if (v >= 1) fold_min = (size_t)v; }
         { int nt = 8; if (const char *e = getenv("ROFL_HOST_THREADS")) nt = atoi(e); unsigned hc = std::thread::hardware_concurrency(); if (hc && (unsigned)nt > hc) nt = (int)hc; if (nt < 1) nt = 1; pool.reset(new HostPool(nt)); }
         if (const char *e = getenv("ROFL_FOLD_T1")) { int v = atoi(e); if (v >= 1 && v <= 6) fold_t1 = v; }
@@ -271,7 +274,8 @@ MsmPlan msm_plan(size_t n) {
     if (n >= (1u << 17)) p.c = 16; else if (n >= (1u << 13)) p.c = 13; else if (n >= (1u << 9)) p.c = 10; else if (n >= 64) p.c = 7; else p.c = 4;
     if (const char *e = getenv("ROFL_MSM_C")) { int v = atoi(e); if (v == 4 || v == 7 || v == 10 || v == 13 || v == 16) p.c = (u32)v; }
     p.W = (254 + p.c - 1) / p.c;
-    p.wide = 254 - (p.c - 1) * p.W;      // `wide` windows of c bits, the rest c-1 bits: wide*c + (W-wide)*(c-1) = 254
+    p.W = (253 - p.c + p.c - 1) / p.c + 1;                // top window [253-c, 254) + ceil((253-c)/c) lower windows
+    p.wide = (253 - p.c) - (p.c - 1) * (p.W - 1);          // wide*c + (W-1-wide)*(c-1) = 253 - c
     p.B = 1u << (p.c - 1);
     p.levels = (p.c - 1) / 3;
     return p;
@@ -285,42 +289,71 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
     MsmProb *h_probs = C.h_probs.as<MsmProb>(np);
     for (size_t i = 0; i < np; i++) h_probs[i] = probs[i];
     HIPCHK(hipMemcpyAsync(d_probs, h_probs, sizeof(MsmProb) * np, hipMemcpyHostToDevice, C.stream));
-    u32 *cnt = C.msm_cnt.as<u32>(PW * P.B), *off = C.msm_off.as<u32>(PW * P.B), *cur = C.msm_cur.as<u32>(PW * P.B);
-    u32 *sorted = C.msm_sorted.as<u32>(PW * n);
+    u32 *cnt = C.msm_cnt.as<u32>(PW * P.B + 4), *off = C.msm_off.as<u32>(PW * P.B), *cur = C.msm_cur.as<u32>(PW * P.B);
     u32 *perm = C.msm_perm.as<u32>(PW * P.B);
     ge *buckets = C.msm_buckets.as<ge>(PW * P.B);
-    HIPCHK(hipMemsetAsync(cnt, 0, sizeof(u32) * PW * P.B, C.stream));
     MsmWin mw{P.c, P.W, P.wide};
-    hipLaunchKernelGGL(k_msm_count, grid1(n, (u32)PW), dim3(TPB), 0, C.stream, (u32)n, mw, d_probs, cnt);
-    hipLaunchKernelGGL(k_msm_scan, dim3((unsigned)PW), dim3(TPB), 0, C.stream, P.B, cnt, off, cur, perm);
-    hipLaunchKernelGGL(k_msm_scatter, grid1(n, (u32)PW), dim3(TPB), 0, C.stream, (u32)n, mw, d_probs, cur, sorted);
+    // slot mode: capacity 4x the worst-case mean bucket load (all scalars non-zero), clamped to [16, 256]
+    u32 cap = 16; while (cap < 256 && (size_t)cap * P.B < 4 * n) cap *= 2;
+    const u32 OVF_MAX = 4096;
+    bool slots_ok = C.msm_slots && (size_t)PW * P.B * cap * 4 <= ((size_t)8 << 30);
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (C.tm.enabled) { e0 = C.tm.get(); e1 = C.tm.get(); HIPCHK(hipEventRecord(e0, C.stream)); }
-    hipLaunchKernelGGL(k_msm_accumulate, grid1((size_t)P.W * P.B, (u32)np), dim3(TPB), 0, C.stream, (u32)n, P.c, P.W, d_probs, cnt, off, sorted, perm, buckets);
-    if (C.tm.enabled) { HIPCHK(hipEventRecord(e1, C.stream)); C.tm.acc_ev.push_back({e0, e1}); C.tm.t.msm_accumulate_launches++; char tg[96]; snprintf(tg, sizeof tg, "msm np=%zu n=%zu c=%u", np, n, P.c); C.tm.acc_tag.push_back(tg); }
-    // reduction tree
-    const ge *S_in = buckets; const ge *C_in = nullptr;
-    u32 E = P.B, nb = 0;
-    for (u32 lv = 0; lv < P.levels; lv++) {
-        u32 E8 = E / 8;
-        ge *S_out = C.msm_S[lv & 1].as<ge>(PW * E8);
-        ge *C_out = C.msm_C[lv & 1].as<ge>(PW * (size_t)(nb + 3) * E8);
-        hipLaunchKernelGGL(k_msm_reduce_level, grid1((size_t)E8 * (1 + nb), (u32)PW), dim3(TPB), 0, C.stream, E, nb, S_in, C_in, S_out, C_out);
-        S_in = S_out; C_in = C_out; E = E8; nb += 3;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        HIPCHK(hipMemsetAsync(cnt, 0, sizeof(u32) * (PW * P.B + 4), C.stream));
+        if (slots_ok) {
+            u32 *slots = C.msm_sorted.as<u32>(PW * P.B * cap);
+            MsmOvf *ovf = C.msm_ovf.as<MsmOvf>(OVF_MAX);
+            u32 *ovf_count = cnt + PW * P.B;
+            hipLaunchKernelGGL(k_msm_scatter_slots, grid1(n, (u32)PW), dim3(TPB), 0, C.stream, (u32)n, mw, d_probs, cnt, slots, cap, ovf_count, ovf, OVF_MAX);
+            hipLaunchKernelGGL(k_msm_scan, dim3((unsigned)PW), dim3(TPB), 0, C.stream, P.B, cnt, off, (u32 *)nullptr, perm);
+            if (C.tm.enabled) { e0 = C.tm.get(); e1 = C.tm.get(); HIPCHK(hipEventRecord(e0, C.stream)); }
+            hipLaunchKernelGGL(k_msm_accumulate, grid1((size_t)P.W * P.B, (u32)np), dim3(TPB), 0, C.stream, (u32)n, P.c, P.W, d_probs, cnt, off, slots, perm, buckets, cap);
+            if (C.tm.enabled) HIPCHK(hipEventRecord(e1, C.stream));
+            hipLaunchKernelGGL(k_msm_overflow, dim3(1), dim3(64), 0, C.stream, P.W, P.B, d_probs, ovf_count, ovf, OVF_MAX, buckets);
+            HIPCHK(hipMemcpyAsync(C.h_ovf.as<u32>(4), ovf_count, 4, hipMemcpyDeviceToHost, C.stream));
+        } else {
+            u32 *sorted = C.msm_sorted.as<u32>(PW * n * 2);
+            hipLaunchKernelGGL(k_msm_count, grid1(n, (u32)PW), dim3(TPB), 0, C.stream, (u32)n, mw, d_probs, cnt);
+            hipLaunchKernelGGL(k_msm_scan, dim3((unsigned)PW), dim3(TPB), 0, C.stream, P.B, cnt, off, cur, perm);
+            hipLaunchKernelGGL(k_msm_scatter, grid1(n, (u32)PW), dim3(TPB), 0, C.stream, (u32)n, mw, d_probs, cur, sorted);
+            if (C.tm.enabled) { e0 = C.tm.get(); e1 = C.tm.get(); HIPCHK(hipEventRecord(e0, C.stream)); }
+            hipLaunchKernelGGL(k_msm_accumulate, grid1((size_t)P.W * P.B, (u32)np), dim3(TPB), 0, C.stream, (u32)n, P.c, P.W, d_probs, cnt, off, sorted, perm, buckets, 0u);
+            if (C.tm.enabled) HIPCHK(hipEventRecord(e1, C.stream));
+        }
+        if (C.tm.enabled) { C.tm.acc_ev.push_back({e0, e1}); C.tm.t.msm_accumulate_launches++; char tg[96]; snprintf(tg, sizeof tg, "msm np=%zu n=%zu c=%u cap=%u", np, n, P.c, slots_ok ? cap : 0u); C.tm.acc_tag.push_back(tg); }
+        // reduction tree: global levels while more than 512 nodes remain, then one fused launch
+        const ge *S_in = buckets; const ge *C_in = nullptr;
+        u32 E = P.B, nb = 0, lv = 0;
+        while (E > 512) {
+            u32 E8 = E / 8;
+            ge *S_out = C.msm_S[lv & 1].as<ge>(PW * E8);
+            ge *C_out = C.msm_C[lv & 1].as<ge>(PW * (size_t)(nb + 3) * E8);
+            hipLaunchKernelGGL(k_msm_reduce_level, grid1((size_t)E8 * (1 + nb), (u32)PW), dim3(TPB), 0, C.stream, E, nb, S_in, C_in, S_out, C_out);
+            S_in = S_out; C_in = C_out; E = E8; nb += 3; lv++;
+        }
+        u32 nb_final = P.c - 1;
+        ge *S_fin = C.msm_S[lv & 1].as<ge>(PW);
+        ge *C_fin = C.msm_C[lv & 1].as<ge>(PW * (size_t)nb_final);
+        size_t lds = ((size_t)(E / 8) * (1 + nb + 3) + (size_t)(E / 64) * (1 + nb + 6) + 1) * sizeof(ge);
+        hipLaunchKernelGGL(k_msm_reduce_fused, dim3((unsigned)PW), dim3(TPB), lds, C.stream, E, nb, S_in, C_in, S_fin, C_fin, nb_final);
+        size_t per = 1 + nb_final;
+        ge *hres = C.h_res.as<ge>(PW * per);
+        HIPCHK(hipMemcpyAsync(hres, S_fin, sizeof(ge) * PW, hipMemcpyDeviceToHost, C.stream));
+        HIPCHK(hipMemcpyAsync(hres + PW, C_fin, sizeof(ge) * PW * nb_final, hipMemcpyDeviceToHost, C.stream));
+        HIPCHK(hipStreamSynchronize(C.stream));
+        if (slots_ok && getenv("ROFL_TRACE")) fprintf(stderr, "[rofl] msm np=%zu n=%zu c=%u cap=%u overflow=%u\n", np, n, P.c, cap, *C.h_ovf.as<u32>(4));
+        if (slots_ok && *C.h_ovf.as<u32>(4) > OVF_MAX) { slots_ok = false; continue; }    // pathological input: redo with the two-pass sort
+        break;
     }
-    // E == 1: S_in [PW], C_in [PW][c-1]
-    size_t per = 1 + nb;
-    ge *h = C.h_res.as<ge>(PW * per);
-    HIPCHK(hipMemcpyAsync(h, S_in, sizeof(ge) * PW, hipMemcpyDeviceToHost, C.stream));
-    HIPCHK(hipMemcpyAsync(h + PW, C_in, sizeof(ge) * PW * nb, hipMemcpyDeviceToHost, C.stream));
-    HIPCHK(hipStreamSynchronize(C.stream));
+    u32 nb = P.c - 1;
+    ge *h = C.h_res.as<ge>(PW * (1 + nb));
     double t0 = now_ms();
     results.resize(np);
     C.pool->run(np, [&](size_t p) {
         ge5 acc = h51::identity(); bool started = false;
         for (int w = (int)P.W - 1; w >= 0; w--) {
             size_t pw = p * P.W + w;
-            int width = (u32)w < P.wide ? (int)P.c : (int)P.c - 1;
+            int width = (u32)w + 1 == P.W ? (int)P.c + 1 : ((u32)w < P.wide ? (int)P.c : (int)P.c - 1);
             for (int l = width - 1; l >= 0; l--) {
                 if (started) acc = h51::gdouble(acc);
                 if (l <= (int)P.c - 2) { acc = h51::gadd(acc, h51::from_ge(h[PW + pw * nb + l])); started = true; }
@@ -1121,6 +1154,29 @@ int rofl_get_l2_clip_bounds(size_t range, unsigned fp_bits, unsigned fp_frac, fl
     *out = l2_clip_bound(range, fp_bits, fp_frac); return ROFL_OK;
 }
 
+int rofl_dbg_msm(const uint8_t *scalars32, const uint8_t *points32, size_t n, uint8_t out32[32]) {
+    return guarded([&]() -> int {
+        Ctx &C = ctx(); std::lock_guard<std::mutex> lk(C.mu);
+        if (n == 0) return fail(ROFL_BAD_PARAM, "bad parameter");
+        C.init();
+        std::vector<sc> hs(n);
+        for (size_t i = 0; i < n; i++) { hs[i] = sc_frombytes(scalars32 + 32 * i); if (sc_geq_l(hs[i].v)) hs[i] = sc_from_mont(sc_to_mont(hs[i])); }
+        uint8_t *dp = C.tmp_in.as<uint8_t>(n * 32); niels *dn = C.aux_pts.as<niels>(n); sc *ds = C.aux_scal.as<sc>(n);
+        u32 *status = C.status.as<u32>(4);
+        HIPCHK(hipMemsetAsync(status, 0, 16, C.stream));
+        HIPCHK(hipMemcpyAsync(dp, points32, n * 32, hipMemcpyHostToDevice, C.stream));
+        HIPCHK(hipMemcpyAsync(ds, hs.data(), n * 32, hipMemcpyHostToDevice, C.stream));
+        hipLaunchKernelGGL(k_decode, grid1(n), dim3(TPB), 0, C.stream, (u32)n, (u32)n, dp, (const niels *)nullptr, dn, (uint8_t *)nullptr, status);
+        u32 st = 0;
+        HIPCHK(hipMemcpyAsync(&st, status, 4, hipMemcpyDeviceToHost, C.stream));
+        HIPCHK(hipStreamSynchronize(C.stream));
+        if (st & 4u) return fail(ROFL_FORMAT_ERROR, "invalid Ristretto encoding");
+        std::vector<MsmProb> pr(1, MsmProb{dn, ds}); std::vector<ge5> res;
+        msm_run(C, pr, n, res);
+        h51::encode(out32, res[0]);
+        return ROFL_OK;
+    });
+}
 int rofl_set_timing(int enabled) { return guarded([&]() -> int { Ctx &C = ctx(); std::lock_guard<std::mutex> lk(C.mu); C.tm.enabled = enabled != 0; return ROFL_OK; }); }
 int rofl_last_timing(rofl_timing_t *out) { return guarded([&]() -> int { Ctx &C = ctx(); std::lock_guard<std::mutex> lk(C.mu); *out = C.tm.t; return ROFL_OK; }); }
 int rofl_bench_femul(unsigned iters, double *out) {

@@ -142,3 +142,11 @@ def rand_scalars(rng, d):
     for i in range(d):
         out[i] = np.frombuffer((int.from_bytes(raw[i].tobytes(), "little") % L_ORDER).to_bytes(32, "little"), dtype=np.uint8)
     return out
+
+
+def msm(scalars32, points32):
+    k = np.ascontiguousarray(scalars32, dtype=np.uint8).reshape(-1, 32)
+    p = np.ascontiguousarray(points32, dtype=np.uint8).reshape(-1, 32)
+    out = np.zeros(32, dtype=np.uint8)
+    lib().orc_msm(_p(k), _p(p), _sz(k.shape[0]), _p(out))
+    return out

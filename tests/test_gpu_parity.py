@@ -254,3 +254,32 @@ def test_full_size_properties_cfg2(R):
     assert (cm3 == cm).all() and not (pr3 == pr).all()
     assert R.range_proof_vec.verify_rangeproof(pr3, cm3, nb, verifier_seed=b"\x01" * 32)
     R.api.set_fp(16, 7)
+
+
+def _gpu_msm(R, k, p):
+    out = np.zeros(32, np.uint8)
+    rc = R.lib().rofl_dbg_msm(k.ctypes.data_as(ctypes.c_void_p), p.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(k.shape[0]), out.ctypes.data_as(ctypes.c_void_p))
+    assert rc == 0
+    return out
+
+
+@pytest.mark.parametrize("n", [1, 5, 63, 64, 300, 513, 2000, 9000])
+def test_msm_extreme_scalars(R, n):
+    """The Pippenger pipeline on inputs the proof path never produces: heavy bucket skew (slot overflow list /
+    two-pass fallback), scalars in [2^252, l) (split top-window digit), zeros, small and all-ones scalars."""
+    rng = np.random.default_rng(n)
+    pts = orc.commit_vec(orc.rand_scalars(rng, n), None)            # n random valid points
+    L = orc.L_ORDER
+    def sc(v):
+        return np.frombuffer((v % L).to_bytes(32, "little"), np.uint8)
+    cases = {
+        "random": orc.rand_scalars(rng, n),
+        "all_equal": np.tile(sc(int.from_bytes(rng.integers(0, 256, 32, dtype=np.uint8).tobytes(), "little")), (n, 1)),
+        "top_range": np.stack([sc(L - 1 - i) for i in range(n)]),                    # >= 2^252
+        "two_pow_252": np.stack([sc((1 << 252) + i * 12345) for i in range(n)]),
+        "small": np.stack([sc(i) for i in range(n)]),                                 # includes 0
+        "minus_one": np.tile(sc(L - 1), (n, 1)),
+    }
+    for name, k in cases.items():
+        k = np.ascontiguousarray(k)
+        assert (_gpu_msm(R, k, pts) == orc.msm(k, pts)).all(), name

@@ -700,24 +700,41 @@ __global__ void __launch_bounds__(TPB) k_msm_reduce_level(u32 E, u32 nb, const g
     if (t >= E8 * (1 + nb)) return;
     msm_reduce_item(E, nb, S_in + (size_t)pw * E, C_in + (size_t)pw * nb * E, S_out + (size_t)pw * E8, C_out + (size_t)pw * (nb + 3) * E8, t);
 }
-// All remaining levels (E <= 512) of one (prob, window) in a single block through LDS: one launch instead of
-// three or four latency-bound ones.  Output: S_fin [PW], C_fin [PW][nb_final].
-__global__ void __launch_bounds__(TPB) k_msm_reduce_fused(u32 E, u32 nb, const ge *S_in, const ge *C_in, ge *S_fin, ge *C_fin, u32 nb_final) {
+// All remaining levels (E <= 512) of one (prob, window) in a single block through LDS: one launch instead of three
+// or four latency-bound ones.  First level 8-ary (global -> LDS), the rest binary (one addition deep per level):
+// S'[g] = S[2g] + S[2g+1], new bit-sum = S[2g+1], carried bit-sums pairwise.  Output: S_fin [PW], C_fin [PW][nb_final].
+__global__ void __launch_bounds__(512) k_msm_reduce_fused(u32 E, u32 nb, const ge *S_in, const ge *C_in, ge *S_fin, ge *C_fin, u32 nb_final) {
     extern __shared__ __align__(16) unsigned char smem[];
-    ge *buf0 = reinterpret_cast<ge *>(smem);            // level outputs ping-pong; sized by the host for the largest level
+    ge *buf0 = reinterpret_cast<ge *>(smem);
     u32 pw = blockIdx.x;
     const ge *si = S_in + (size_t)pw * E, *ci = C_in + (size_t)pw * nb * E;
-    u32 half = (E / 8) * (1 + nb + 3);                  // elements of the first (largest) output level
+    ge *fin_s = S_fin + pw, *fin_c = C_fin + (size_t)pw * nb_final;
+    // level 1: 8-ary
+    u32 E8 = E / 8;
+    ge *so = E8 == 1 ? fin_s : buf0, *co = E8 == 1 ? fin_c : buf0 + E8;
+    for (u32 item = threadIdx.x; item < E8 * (1 + nb); item += blockDim.x) msm_reduce_item(E, nb, si, ci, so, co, item);
+    __syncthreads();
+    if (E8 == 1) return;
+    u32 half = E8 * (1 + nb + 3);
     ge *bufs[2] = {buf0, buf0 + half};
-    int sel = 0;
+    int sel = 1;
+    si = so; ci = co; E = E8; nb += 3;
     while (E > 1) {
-        u32 E8 = E / 8;
-        ge *so, *co;
-        if (E8 == 1) { so = S_fin + pw; co = C_fin + (size_t)pw * nb_final; }
-        else { so = bufs[sel]; co = bufs[sel] + E8; }
-        for (u32 item = threadIdx.x; item < E8 * (1 + nb); item += blockDim.x) msm_reduce_item(E, nb, si, ci, so, co, item);
+        u32 E2 = E / 2;
+        if (E2 == 1) { so = fin_s; co = fin_c; } else { so = bufs[sel]; co = bufs[sel] + E2; }
+        for (u32 item = threadIdx.x; item < E2 * (1 + nb); item += blockDim.x) {
+            u32 role = item / E2, g = item % E2;
+            if (role == 0) {
+                ge lo = si[2 * g], hi = si[2 * g + 1];
+                so[g] = ge_add(lo, hi);
+                co[(size_t)nb * E2 + g] = hi;
+            } else {
+                const ge *cc = ci + (size_t)(role - 1) * E;
+                co[(size_t)(role - 1) * E2 + g] = ge_add(cc[2 * g], cc[2 * g + 1]);
+            }
+        }
         __syncthreads();
-        si = so; ci = co; E = E8; nb += 3; sel ^= 1;
+        si = so; ci = co; E = E2; nb += 1; sel ^= 1;
     }
 }
 

@@ -334,8 +334,8 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
         u32 nb_final = P.c - 1;
         ge *S_fin = C.msm_S[lv & 1].as<ge>(PW);
         ge *C_fin = C.msm_C[lv & 1].as<ge>(PW * (size_t)nb_final);
-        size_t lds = ((size_t)(E / 8) * (1 + nb + 3) + (size_t)(E / 64) * (1 + nb + 6) + 1) * sizeof(ge);
-        hipLaunchKernelGGL(k_msm_reduce_fused, dim3((unsigned)PW), dim3(TPB), lds, C.stream, E, nb, S_in, C_in, S_fin, C_fin, nb_final);
+        size_t lds = ((size_t)(E / 8) * (1 + nb + 3) + (size_t)(E / 16) * (1 + nb + 4) + 1) * sizeof(ge);
+        hipLaunchKernelGGL(k_msm_reduce_fused, dim3((unsigned)PW), dim3((E / 8) * (1 + nb) > 256 ? 512 : 256), lds, C.stream, E, nb, S_in, C_in, S_fin, C_fin, nb_final);
         size_t per = 1 + nb_final;
         ge *hres = C.h_res.as<ge>(PW * per);
         HIPCHK(hipMemcpyAsync(hres, S_fin, sizeof(ge) * PW, hipMemcpyDeviceToHost, C.stream));

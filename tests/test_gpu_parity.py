@@ -283,3 +283,24 @@ def test_msm_extreme_scalars(R, n):
     for name, k in cases.items():
         k = np.ascontiguousarray(k)
         assert (_gpu_msm(R, k, pts) == orc.msm(k, pts)).all(), name
+
+
+def test_cfg4_shape_batch_verify(R):
+    """BASELINE config 4 shape on one rank: d = 55 000 (d_pad = 65 536, m = 16 384, N = 524 288), 32-bit, P = 4;
+    three clients verified in one batched call; tampered members are singled out."""
+    R.api.set_fp(32, 7)
+    d, nb, P = 55000, 32, 4
+    mx = np.float32(16777216.0)
+    prs, cms = [], []
+    for c in range(3):
+        rng = np.random.default_rng(7000 + c)
+        vals = np.clip(rng.uniform(-mx, mx, size=d).astype(np.float32), -mx, np.nextafter(mx, np.float32(0)))
+        bl = rng.integers(0, 256, size=(d, 32), dtype=np.uint8); bl[:, 31] &= 0x0F
+        pr, cm = R.range_proof_vec.create_rangeproof(vals, bl, nb, P, nonce=R.Nonce.seeded(bytes([c + 1]) * 32))
+        assert pr.shape == (4, 1504)
+        prs.append(pr); cms.append(cm)
+    assert R.range_proof_vec.verify_rangeproof_batch(prs, cms, nb, verifier_seed=b"\x01" * 32) == [True, True, True]
+    prs[1] = prs[1].copy(); prs[1][3, 77] ^= 1
+    cms[2] = cms[2].copy(); cms[2][54999] = cms[2][0]
+    assert R.range_proof_vec.verify_rangeproof_batch(prs, cms, nb, verifier_seed=b"\x02" * 32) == [True, False, False]
+    R.api.set_fp(16, 7)

@@ -4,6 +4,7 @@
 // Scalars in device arrays are in Montgomery form unless a name ends with _canon.
 #pragma once
 #include "fe32.hpp"
+#include "fe26.hpp"
 #include "keccak.hpp"
 
 namespace rofl {
@@ -39,6 +40,9 @@ __device__ __forceinline__ void store_ge(ge *p, const ge &v) {
 #pragma unroll
     for (int i = 0; i < 8; i++) d[i] = s[i];
 }
+__device__ __forceinline__ nd load_nd(const niels *p) { return nd_unpack(load_niels(p)); }
+__device__ __forceinline__ gd load_gd(const ge *p) { return gd_unpack(load_ge(p)); }
+__device__ __forceinline__ void store_gd(ge *p, const gd &v) { store_ge(p, gd_pack(v)); }
 __device__ __forceinline__ sc load_sc(const sc *p) {
     sc r;
     const uint4 *s = reinterpret_cast<const uint4 *>(p);
@@ -264,13 +268,13 @@ __global__ void __launch_bounds__(TPB) k_bitcommit(u32 n, u32 m, const u64 *vshi
     if (j >= m) return;
     size_t N = (size_t)n * m;
     u64 v = vshift[(size_t)c * m + j];
-    ge acc = ge_identity();
+    gd acc = gd_identity();
     for (u32 i = 0; i < n; i++) {
         bool bit = (v >> i) & 1;
         const niels *p = bit ? &tbl[(size_t)j * n + i] : &tbl[N + (size_t)j * n + i];
-        acc = ge_madd(acc, load_niels(p), !bit);
+        acc = gd_madd(acc, load_nd(p), !bit);
     }
-    store_ge(&partial[(size_t)c * m + j], acc);
+    store_gd(&partial[(size_t)c * m + j], acc);
 }
 
 // generic point reduction: in [prob][n] -> out [prob][gridDim.x]
@@ -441,27 +445,27 @@ __global__ void __launch_bounds__(256) k_fold_gens(u32 n_new, u32 nsrc, FoldSeg 
     bool active = i < n_new;
     const niels *src = probs[q].src;
     const int8_t *dg = naf + (size_t)q * nsrc * 256;
-    ge acc = ge_identity();
+    gd acc = gd_identity();
     if (active) {
         int lo = seg.lo[k], hi = seg.lo[k + 1] - 1;
         for (int bit = hi; bit >= lo; bit--) {
-            acc = ge_double(acc);
+            acc = gd_double(acc);
             for (u32 h = unit_first ? 1 : 0; h < nsrc; h++) {
                 int d = dg[h * 256 + bit];
-                if (d != 0) acc = ge_madd(acc, load_niels(&src[(size_t)h * n_new + i]), d < 0);
+                if (d != 0) acc = gd_madd(acc, load_nd(&src[(size_t)h * n_new + i]), d < 0);
             }
         }
-        for (int t = 0; t < lo; t++) acc = ge_double(acc);
+        for (int t = 0; t < lo; t++) acc = gd_double(acc);
     }
     if (K > 1) {
-        if (k > 0) lds[(k - 1) * 64 + threadIdx.x] = acc;
+        if (k > 0) lds[(k - 1) * 64 + threadIdx.x] = gd_pack(acc);
         __syncthreads();
         if (k == 0)
-            for (u32 s2 = 1; s2 < K; s2++) acc = ge_add(acc, lds[(s2 - 1) * 64 + threadIdx.x]);
+            for (u32 s2 = 1; s2 < K; s2++) acc = gd_add(acc, gd_unpack(lds[(s2 - 1) * 64 + threadIdx.x]));
     }
     if (active && k == 0) {
-        if (unit_first) acc = ge_madd(acc, load_niels(&src[i]), false);   // source 0 has scalar 1 (scale kept aside)
-        store_niels(&probs[q].dst[i], ge_to_niels(acc));
+        if (unit_first) acc = gd_madd(acc, load_nd(&src[i]), false);   // source 0 has scalar 1 (scale kept aside)
+        store_niels(&probs[q].dst[i], gd_to_niels(acc));
     }
 }
 
@@ -481,33 +485,33 @@ __global__ void __launch_bounds__(256) k_fold_gens_tab(u32 n_new, u32 nsrc, Fold
     bool active = i < n_new;
     const niels *src = tbl16 + probs[q].src_off;
     const int8_t *dg = dig + (size_t)q * nsrc * 4 * FOLD_TAB_DIGITS;
-    ge acc = ge_identity();
+    gd acc = gd_identity();
     if (active) {
         int lo = seg.lo[k], hi = seg.lo[k + 1] - 1;
         for (int bit = hi; bit >= lo; bit--) {
-            acc = ge_double(acc);
+            acc = gd_double(acc);
             for (u32 h = unit_first ? 1 : 0; h < nsrc; h++) {
 #pragma unroll
                 for (u32 pc = 0; pc < 4; pc++) {
                     int d = dg[(h * 4 + pc) * FOLD_TAB_DIGITS + bit];
                     if (d != 0) {
                         u32 e = (u32)((d < 0 ? -d : d) - 1) >> 1;
-                        acc = ge_madd(acc, load_niels(&src[(size_t)(pc * 4 + e) * stride + (size_t)h * n_new + i]), d < 0);
+                        acc = gd_madd(acc, load_nd(&src[(size_t)(pc * 4 + e) * stride + (size_t)h * n_new + i]), d < 0);
                     }
                 }
             }
         }
-        for (int t = 0; t < lo; t++) acc = ge_double(acc);
+        for (int t = 0; t < lo; t++) acc = gd_double(acc);
     }
     if (K > 1) {
-        if (k > 0) lds[(k - 1) * 64 + threadIdx.x] = acc;
+        if (k > 0) lds[(k - 1) * 64 + threadIdx.x] = gd_pack(acc);
         __syncthreads();
         if (k == 0)
-            for (u32 s2 = 1; s2 < K; s2++) acc = ge_add(acc, lds[(s2 - 1) * 64 + threadIdx.x]);
+            for (u32 s2 = 1; s2 < K; s2++) acc = gd_add(acc, gd_unpack(lds[(s2 - 1) * 64 + threadIdx.x]));
     }
     if (active && k == 0) {
-        if (unit_first) acc = ge_madd(acc, load_niels(&src[i]), false);
-        store_niels(&probs[q].dst[i], ge_to_niels(acc));
+        if (unit_first) acc = gd_madd(acc, load_nd(&src[i]), false);
+        store_niels(&probs[q].dst[i], gd_to_niels(acc));
     }
 }
 
@@ -636,9 +640,9 @@ __global__ void k_msm_overflow(u32 W, u32 B, const MsmProb *probs, const u32 *ov
     for (u32 o = 0; o < cnt; o++) {
         u32 bi = ovf[o].bucket, v = ovf[o].entry, p = bi / (W * B);
         if ((bi & 63u) != threadIdx.x) continue;
-        ge acc = load_ge(&buckets[bi]);
-        acc = ge_madd(acc, load_niels(&probs[p].pts[v & 0x7fffffffu]), (v >> 31) != 0);
-        store_ge(&buckets[bi], acc);
+        gd acc = load_gd(&buckets[bi]);
+        acc = gd_madd(acc, load_nd(&probs[p].pts[v & 0x7fffffffu]), (v >> 31) != 0);
+        store_gd(&buckets[bi], acc);
     }
 }
 // one thread per bucket: sum its points.  buckets [prob][W][B] extended.
@@ -654,12 +658,12 @@ __global__ void __launch_bounds__(TPB) k_msm_accumulate(u32 n, u32 c, u32 W, con
     if (cap) { lst = sorted + bi * cap; if (num > cap) num = cap; }        // slot mode: `sorted` is the slot array
     else lst = sorted + ((size_t)p * W + w) * n * 2 + off[bi];   // stride 2n: a top-window digit may emit two entries
     const niels *pts = probs[p].pts;
-    ge acc = ge_identity();
+    gd acc = gd_identity();
     for (u32 e = 0; e < num; e++) {
         u32 v = lst[e];
-        acc = ge_madd(acc, load_niels(&pts[v & 0x7fffffffu]), (v >> 31) != 0);
+        acc = gd_madd(acc, load_nd(&pts[v & 0x7fffffffu]), (v >> 31) != 0);
     }
-    store_ge(&buckets[bi], acc);
+    store_gd(&buckets[bi], acc);
 }
 // Bucket reduction without doublings: sum_b (b+1) B_b = S + sum_l 2^l D_l, D_l = sum of buckets whose
 // index has bit l set.  One 8-ary tree level per launch:
@@ -671,27 +675,27 @@ __device__ __forceinline__ void msm_reduce_item(u32 E, u32 nb, const ge *S_in, c
     u32 E8 = E / 8, role = item / E8, g = item % E8;
     if (role == 0) {
         const ge *s = S_in + (size_t)g * 8;
-        ge p0 = load_ge(&s[0]), p1 = load_ge(&s[1]);
-        ge q0 = ge_add(p0, p1); ge D0 = p1;
-        p0 = load_ge(&s[2]); p1 = load_ge(&s[3]);
-        ge q1 = ge_add(p0, p1); D0 = ge_add(D0, p1);
-        p0 = load_ge(&s[4]); p1 = load_ge(&s[5]);
-        ge q2 = ge_add(p0, p1); D0 = ge_add(D0, p1);
-        p0 = load_ge(&s[6]); p1 = load_ge(&s[7]);
-        ge q3 = ge_add(p0, p1); D0 = ge_add(D0, p1);
-        ge r0 = ge_add(q0, q1), r1 = ge_add(q2, q3);
-        ge D1 = ge_add(q1, q3);
-        ge S = ge_add(r0, r1);
-        store_ge(&S_out[g], S);
-        store_ge(&C_out[(size_t)(nb + 0) * E8 + g], D0);
-        store_ge(&C_out[(size_t)(nb + 1) * E8 + g], D1);
-        store_ge(&C_out[(size_t)(nb + 2) * E8 + g], r1);
+        gd p0 = load_gd(&s[0]), p1 = load_gd(&s[1]);
+        gd q0 = gd_add(p0, p1); gd D0 = p1;
+        p0 = load_gd(&s[2]); p1 = load_gd(&s[3]);
+        gd q1 = gd_add(p0, p1); D0 = gd_add(D0, p1);
+        p0 = load_gd(&s[4]); p1 = load_gd(&s[5]);
+        gd q2 = gd_add(p0, p1); D0 = gd_add(D0, p1);
+        p0 = load_gd(&s[6]); p1 = load_gd(&s[7]);
+        gd q3 = gd_add(p0, p1); D0 = gd_add(D0, p1);
+        store_gd(&C_out[(size_t)(nb + 0) * E8 + g], D0);
+        gd D1 = gd_add(q1, q3);
+        store_gd(&C_out[(size_t)(nb + 1) * E8 + g], D1);
+        gd r1 = gd_add(q2, q3);
+        store_gd(&C_out[(size_t)(nb + 2) * E8 + g], r1);
+        gd S = gd_add(gd_add(q0, q1), r1);
+        store_gd(&S_out[g], S);
     } else {
         const ge *s = C_in + (size_t)(role - 1) * E + (size_t)g * 8;
-        ge acc = ge_add(load_ge(&s[0]), load_ge(&s[1]));
+        gd acc = gd_add(load_gd(&s[0]), load_gd(&s[1]));
 #pragma unroll 1
-        for (int k = 2; k < 8; k++) acc = ge_add(acc, load_ge(&s[k]));
-        store_ge(&C_out[(size_t)(role - 1) * E8 + g], acc);
+        for (int k = 2; k < 8; k++) acc = gd_add(acc, load_gd(&s[k]));
+        store_gd(&C_out[(size_t)(role - 1) * E8 + g], acc);
     }
 }
 __global__ void __launch_bounds__(TPB) k_msm_reduce_level(u32 E, u32 nb, const ge *S_in, const ge *C_in, ge *S_out, ge *C_out) {
@@ -726,11 +730,11 @@ __global__ void __launch_bounds__(512) k_msm_reduce_fused(u32 E, u32 nb, const g
             u32 role = item / E2, g = item % E2;
             if (role == 0) {
                 ge lo = si[2 * g], hi = si[2 * g + 1];
-                so[g] = ge_add(lo, hi);
+                so[g] = gd_pack(gd_add(gd_unpack(lo), gd_unpack(hi)));
                 co[(size_t)nb * E2 + g] = hi;
             } else {
                 const ge *cc = ci + (size_t)(role - 1) * E;
-                co[(size_t)(role - 1) * E2 + g] = ge_add(cc[2 * g], cc[2 * g + 1]);
+                co[(size_t)(role - 1) * E2 + g] = gd_pack(gd_add(gd_unpack(cc[2 * g]), gd_unpack(cc[2 * g + 1])));
             }
         }
         __syncthreads();
@@ -800,9 +804,9 @@ __global__ void __launch_bounds__(TPB) k_vscalars(u32 m, const ChunkParams *cp, 
 // ================================================================ micro-benchmark: field multiply rate
 __global__ void __launch_bounds__(TPB) k_bench_femul(u32 iters, const fe *in, fe *out) {
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-    fe a = in[t & 255], b = in[(t + 1) & 255];
-    for (u32 i = 0; i < iters; i++) { a = fe_mul(a, b); b = fe_sq(b); a = fe_mul(a, b); b = fe_mul(b, a); }
-    out[t] = fe_add(a, b);
+    fd a = fd_unpack(in[t & 255]), b = fd_unpack(in[(t + 1) & 255]);
+    for (u32 i = 0; i < iters; i++) { a = fd_mul(a, b); b = fd_sq(b); a = fd_mul(a, b); b = fd_mul(b, a); }
+    out[t] = fd_pack(fd_add(a, b));
 }
 
 }  // namespace rofl

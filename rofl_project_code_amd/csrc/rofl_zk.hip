@@ -1221,6 +1221,28 @@ int rofl_dbg_host_scalarmult_base(const uint8_t k[32], int use_bb, uint8_t out[3
     if (use_bb & 2) { to_tab5(ht.B5, ht.B); to_tab5(ht.Bb5, ht.Bb); h51::encode(out, h_fixed_mul((use_bb & 1) ? ht.Bb5 : ht.B5, sc_frombytes(k))); return 0; }
     ristretto_encode(out, h_fixed_mul32((use_bb & 1) ? ht.Bb : ht.B, sc_frombytes(k))); return 0;
 }
+int rofl_dbg_host_fd_ops(const uint8_t a[32], const uint8_t b[32], uint8_t om[32], uint8_t oq[32], uint8_t oa[32], uint8_t os[32], uint8_t oi[32]) {
+    fe fa = fe_frombytes(a), fb = fe_frombytes(b);
+    fa.v[7] |= (u32)(a[31] & 0x80) << 24; fb.v[7] |= (u32)(b[31] & 0x80) << 24;   // keep bit 255 to exercise the unpack fold
+    fd x = fd_unpack(fa), y = fd_unpack(fb);
+    fe_tobytes(om, fd_pack(fd_mul(fd_sub(fd_add(x, x), x), fd_add(y, fd_zero()))));   // (2x - x) * y with a loose first operand
+    fe_tobytes(oq, fd_pack(fd_sq(x))); fe_tobytes(oa, fd_pack(fd_add(x, y))); fe_tobytes(os, fd_pack(fd_sub(x, y)));
+    fe_tobytes(oi, fd_pack(fd_invert(x)));
+    return 0;
+}
+// double-and-add ladder on the kernel point formulas: exercises gd_double, gd_madd (+/-), gd_add, gd_to_niels
+int rofl_dbg_host_fd_scalarmult(const uint8_t k[32], const uint8_t p[32], uint8_t out[32]) {
+    ge P; if (!ristretto_decode(P, p)) return ROFL_FORMAT_ERROR;
+    nd q = nd_unpack(ge_to_niels(P));
+    sc s = sc_frombytes(k);
+    int8_t naf[256]; int top = sc_naf(naf, s);
+    gd acc = gd_identity();
+    for (int i = top; i >= 0; i--) { acc = gd_double(acc); if (naf[i]) acc = gd_madd(acc, q, naf[i] < 0); }
+    gd twice = gd_add(acc, acc);                   // 2kP by the unified addition
+    gd back = gd_madd(twice, nd_unpack(gd_to_niels(acc)), true);   // 2kP - kP
+    ristretto_encode(out, gd_pack(back));
+    return 0;
+}
 int rofl_dbg_host_decode_encode(const uint8_t in[32], uint8_t out[32]) { ge p; if (!ristretto_decode(p, in)) return ROFL_FORMAT_ERROR; ristretto_encode(out, ge_add(p, ge_identity())); return 0; }
 int rofl_dbg_host_merlin(const uint8_t *label, size_t label_len, const uint8_t *msg, size_t msg_len, uint8_t out[64]) {
     Merlin t((const char *)label, label_len); t.append("msg", msg, msg_len); t.challenge_bytes("chal", out, 64); return 0;

@@ -96,6 +96,22 @@ int rofl_verify_rangeproof_l2(const uint8_t *proof, size_t proof_len, const uint
                               size_t prove_range, unsigned fp_bits, unsigned fp_frac,
                               const uint8_t verifier_seed[32], int *ok_out);
 
+/* ---- per-element Sigma-proofs ----
+ * rand_proof_vec/mod.rs:14-118 (create_randproof_vec, create_randproof_vec_existing, verify_randproof_vec):
+ *   ElGamal pair (L = m B + r Bb, R = r B) + proof of knowledge; proof 128 B = C'.L|C'.R|Z_m|Z_r, commitment 64 B = L|R.
+ * square_rand_proof_vec/mod.rs:18-159 (create_l2rangeproof_vec(_existing), verify_l2rangeproof_vec):
+ *   adds c_sq = m^2 B + r2 Bb; proof 192 B = C'.L|C'.R|c_sq'|Z_m|Z_r1|Z_r2, commitments 96 B = L|R|c_sq.
+ * `existing32` (may be NULL) are value commitments to complete (prove_existing: L = m_com).
+ * Nonce draw order per element i: m', r' (index 2i..) resp. m', r1', r2' (index 3i..), rofl_nonce_t as above. */
+int rofl_create_randproof_vec(const float *values, size_t d, const uint8_t *r32, size_t d_r, const uint8_t *existing32,
+                              unsigned fp_bits, unsigned fp_frac, const rofl_nonce_t *nonce, uint8_t *proofs_out /* d*128 */,
+                              uint8_t *commits_out /* d*64 */);
+int rofl_verify_randproof_vec(const uint8_t *proofs, const uint8_t *commits, size_t d, int *ok_out);
+int rofl_create_squarerandproof_vec(const float *values, size_t d, const uint8_t *r1_32, size_t d_r1, const uint8_t *r2_32,
+                                    const uint8_t *existing32, unsigned fp_bits, unsigned fp_frac, const rofl_nonce_t *nonce,
+                                    uint8_t *proofs_out /* d*192 */, uint8_t *commits_out /* d*96 */);
+int rofl_verify_squarerandproof_vec(const uint8_t *proofs, const uint8_t *commits, size_t d, int *ok_out);
+
 /* ---- pedersen_ops (pedersen_ops.rs) ---- */
 int rofl_commit_vec(const uint8_t *values32, const uint8_t *blindings32 /* NULL: commit_no_blinding_vec */,
                     size_t d, uint8_t *out32);                                   /* :9-25 */

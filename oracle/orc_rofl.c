@@ -628,3 +628,96 @@ int orc_verify_rangeproof_l2(const uint8_t *proof, size_t proof_len, const uint8
     *ok = okc;
     return ORC_OK;
 }
+
+/* ------------------------------------------------------------------ Sigma-proofs (rand_proof, square_rand_proof) */
+static void eg_bytes(uint8_t out[64], const ge *L, const ge *R) { ristretto_encode(out, L); ristretto_encode(out + 32, R); }
+
+int orc_sigma_create(int kind, const float *values, size_t d, const uint8_t *r1_32, size_t d_r1, const uint8_t *r2_32,
+                     const uint8_t *existing32, unsigned fp_bits, unsigned fp_frac, const orc_nonce_t *ns,
+                     uint8_t *proofs_out, uint8_t *commits_out) {
+    orc_init();
+    if (d != d_r1) return ORC_WRONG_NUM_BLINDING;        /* rand_proof_vec/mod.rs:18-20, square_rand_proof_vec/mod.rs:24-26 */
+    size_t plen = kind ? 192 : 128, clen = kind ? 96 : 64, nn = kind ? 3 : 2;
+    for (size_t i = 0; i < d; i++) {
+        sc m, r1, r2 = SC_ZERO, mp, r1p, r2p = SC_ZERO, c, t;
+        int rc = f32_to_sc(values[i], fp_bits, fp_frac, &m);
+        if (rc) return rc;
+        sc_frombytes_modorder(&r1, r1_32 + 32 * i);
+        if (kind) sc_frombytes_modorder(&r2, r2_32 + 32 * i);
+        ge L, R, Csq, Lp, Rp, Csqp, tmp;
+        if (existing32) { if (!ristretto_decode(&L, existing32 + 32 * i)) return ORC_FORMAT_ERROR; }   /* complete_existing */
+        else pedersen_commit(&L, &m, &r1);                                                               /* eg_gens.commit */
+        ge_scalarmult(&R, &r1, &GE_BASE);
+        uint8_t *cm = commits_out + clen * i, *pf = proofs_out + plen * i;
+        eg_bytes(cm, &L, &R);
+        if (kind) { sc msq; sc_mul(&msq, &m, &m); pedersen_commit(&Csq, &msq, &r2); ristretto_encode(cm + 64, &Csq); }
+        /* nonce draw order: m', r1' (, r2') -- party.rs:43-45 / rand_proof/party.rs:23-24 */
+        nonce_get(ns, nn * i, &mp); nonce_get(ns, nn * i + 1, &r1p); if (kind) nonce_get(ns, nn * i + 2, &r2p);
+        pedersen_commit(&Lp, &mp, &r1p); ge_scalarmult(&Rp, &r1p, &GE_BASE);
+        eg_bytes(pf, &Lp, &Rp);
+        if (kind) {   /* c_sq' = m' * c_eg.L + r2' * B_blinding */
+            ge_scalarmult(&Csqp, &mp, &L); ge_scalarmult(&tmp, &r2p, &GE_BBLIND); ge_add(&Csqp, &Csqp, &tmp);
+            ristretto_encode(pf + 64, &Csqp);
+        }
+        merlin_t tr;
+        if (kind) {
+            merlin_init(&tr, (const uint8_t *)"SquareRandProof", 15);
+            merlin_append(&tr, "dom-sep", (const uint8_t *)"randomness proof v1", 19);
+            merlin_append(&tr, "C_eg", cm, 64); merlin_append(&tr, "C_ped", cm + 64, 32);
+            merlin_append(&tr, "C_prime_eg", pf, 64); merlin_append(&tr, "C_prime_ped", pf + 64, 32);
+        } else {
+            merlin_init(&tr, (const uint8_t *)"RandProof", 9);
+            merlin_append(&tr, "dom-sep", (const uint8_t *)"randomness proof v1", 19);
+            merlin_append(&tr, "C", cm, 64); merlin_append(&tr, "C_prime", pf, 64);
+        }
+        merlin_challenge_scalar(&tr, "c", &c);
+        uint8_t *z = pf + (kind ? 96 : 64);
+        sc_mul(&t, &m, &c); sc_add(&t, &t, &mp); sc_tobytes(z, &t);                    /* z_m = m' + m c */
+        sc_mul(&t, &r1, &c); sc_add(&t, &t, &r1p); sc_tobytes(z + 32, &t);             /* z_r1 = r1' + r1 c */
+        if (kind) { sc u; sc_mul(&u, &m, &r1); sc_sub(&u, &r2, &u); sc_mul(&u, &u, &c); sc_add(&u, &u, &r2p); sc_tobytes(z + 64, &u); }
+    }
+    return ORC_OK;
+}
+
+int orc_sigma_verify(int kind, const uint8_t *proofs, const uint8_t *commits, size_t d, int *ok) {
+    orc_init();
+    *ok = 0;
+    size_t plen = kind ? 192 : 128, clen = kind ? 96 : 64;
+    int all = 1;
+    for (size_t i = 0; i < d; i++) {
+        const uint8_t *pf = proofs + plen * i, *cm = commits + clen * i, *z = pf + (kind ? 96 : 64);
+        ge L, R, Csq, Lp, Rp, Csqp;
+        sc zm, zr1, zr2 = SC_ZERO, c;
+        if (!ristretto_decode(&L, cm) || !ristretto_decode(&R, cm + 32) || !ristretto_decode(&Lp, pf) || !ristretto_decode(&Rp, pf + 32)) return ORC_FORMAT_ERROR;
+        if (kind && (!ristretto_decode(&Csq, cm + 64) || !ristretto_decode(&Csqp, pf + 64))) return ORC_FORMAT_ERROR;
+        if (!sc_frombytes_canonical(&zm, z) || !sc_frombytes_canonical(&zr1, z + 32)) return ORC_FORMAT_ERROR;
+        if (kind && !sc_frombytes_canonical(&zr2, z + 64)) return ORC_FORMAT_ERROR;
+        merlin_t tr;
+        if (kind) {
+            merlin_init(&tr, (const uint8_t *)"SquareRandProof", 15);
+            merlin_append(&tr, "dom-sep", (const uint8_t *)"randomness proof v1", 19);
+            merlin_append(&tr, "C_eg", cm, 64); merlin_append(&tr, "C_ped", cm + 64, 32);
+            merlin_append(&tr, "C_prime_eg", pf, 64); merlin_append(&tr, "C_prime_ped", pf + 64, 32);
+        } else {
+            merlin_init(&tr, (const uint8_t *)"RandProof", 9);
+            merlin_append(&tr, "dom-sep", (const uint8_t *)"randomness proof v1", 19);
+            merlin_append(&tr, "C", cm, 64); merlin_append(&tr, "C_prime", pf, 64);
+        }
+        merlin_challenge_scalar(&tr, "c", &c);
+        ge lhs, rhs, t;
+        /* dst = eg_gens.commit(Z_m, Z_r1) ; src = C' + c * C */
+        pedersen_commit(&lhs, &zm, &zr1); ge_scalarmult(&t, &c, &L); ge_add(&rhs, &Lp, &t);
+        int e1 = ge_eq_ristretto(&lhs, &rhs);
+        ge_scalarmult(&lhs, &zr1, &GE_BASE); ge_scalarmult(&t, &c, &R); ge_add(&rhs, &Rp, &t);
+        int e2 = ge_eq_ristretto(&lhs, &rhs);
+        int e3 = 1;
+        if (kind) {   /* Z_m * C.L + Z_r2 * B_blinding == c_sq' + c * c_sq */
+            ge_scalarmult(&lhs, &zm, &L); ge_scalarmult(&t, &zr2, &GE_BBLIND); ge_add(&lhs, &lhs, &t);
+            ge_scalarmult(&t, &c, &Csq); ge_add(&rhs, &Csqp, &t);
+            e3 = ge_eq_ristretto(&lhs, &rhs);
+        }
+        all &= e1 & e2 & e3;
+    }
+    *ok = all;
+    return ORC_OK;
+}

@@ -111,4 +111,18 @@ int orc_create_rangeproof_l2(const float *values, size_t d, const uint8_t *blind
 int orc_verify_rangeproof_l2(const uint8_t *proof, size_t proof_len, const uint8_t commit[32],
                              size_t prove_range, unsigned fp_bits, unsigned fp_frac,
                              const uint8_t c_seed[32], int *ok);
+
+/* ---- per-element Sigma-proofs (rand_proof, square_rand_proof and their _vec wrappers) ----
+ * kind 0: RandProof        (rand_proof/mod.rs:31-85, party.rs:14-85): proof 128 B, commitment = ElGamalPair 64 B,
+ *         nonces per element m', r' ; transcript label "RandProof"
+ * kind 1: SquareRandProof  (square_rand_proof/mod.rs:41-151, party.rs:14-160): proof 192 B, commitments 96 B,
+ *         nonces per element m', r1', r2' ; transcript label "SquareRandProof"
+ * `existing32` (may be NULL) = value commitments to complete (prove_existing: L = m_com). */
+#ifndef ORC_SIGMA_DECL
+#define ORC_SIGMA_DECL
+int orc_sigma_create(int kind, const float *values, size_t d, const uint8_t *r1_32, size_t d_r1, const uint8_t *r2_32,
+                     const uint8_t *existing32, unsigned fp_bits, unsigned fp_frac, const orc_nonce_t *ns,
+                     uint8_t *proofs_out, uint8_t *commits_out);
+int orc_sigma_verify(int kind, const uint8_t *proofs, const uint8_t *commits, size_t d, int *ok);
+#endif
 #endif

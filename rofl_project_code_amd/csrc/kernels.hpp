@@ -801,6 +801,157 @@ __global__ void __launch_bounds__(TPB) k_vscalars(u32 m, const ChunkParams *cp, 
     store_sc(&out[c * stride + j], sc_from_mont(sc_montmul(cp[c].c_zz, sc_pow_tab(cp[c].zpow2, j))));
 }
 
+// ================================================================ K11: per-element Sigma-proofs
+// rand_proof (ElGamal pair + proof of knowledge of (m, r)) and square_rand_proof (adds c_sq = m^2 B + r2 Bb and the
+// proof that it commits to the square of the value in c.L); one thread per element, Merlin transcript on the device
+// (3-4 Keccak-f per element).  Reference: rand_proof/{mod,party,dealer,transcript}.rs, square_rand_proof/{mod,party,dealer}.rs.
+struct DMerlin { u64 st[25]; u32 pos, pos_begin; };
+__device__ __forceinline__ void dm_xor(DMerlin &t, u32 p, u32 b) { t.st[p >> 3] ^= (u64)(b & 0xffu) << (8 * (p & 7)); }
+__device__ inline void dm_run_f(DMerlin &t) {
+    dm_xor(t, t.pos, t.pos_begin); dm_xor(t, t.pos + 1, 0x04); dm_xor(t, 167, 0x80);
+    keccak_f1600(t.st); t.pos = 0; t.pos_begin = 0;
+}
+__device__ inline void dm_absorb(DMerlin &t, const uint8_t *d, u32 n) {
+    for (u32 i = 0; i < n; i++) { dm_xor(t, t.pos, d[i]); if (++t.pos == 166) dm_run_f(t); }
+}
+__device__ inline void dm_begin_op(DMerlin &t, u32 flags) {
+    uint8_t hdr[2] = {(uint8_t)t.pos_begin, (uint8_t)flags};
+    t.pos_begin = t.pos + 1;
+    dm_absorb(t, hdr, 2);
+    if ((flags & (4 | 32)) && t.pos != 0) dm_run_f(t);
+}
+__device__ inline void dm_append(DMerlin &t, const char *label, u32 ll, const uint8_t *msg, u32 len) {
+    uint8_t le[4] = {(uint8_t)len, (uint8_t)(len >> 8), (uint8_t)(len >> 16), (uint8_t)(len >> 24)};
+    dm_begin_op(t, 16 | 2); dm_absorb(t, (const uint8_t *)label, ll);
+    dm_absorb(t, le, 4);                               // meta-AD continued ("more")
+    dm_begin_op(t, 2); dm_absorb(t, msg, len);
+}
+__device__ inline sc dm_challenge_scalar(DMerlin &t, const char *label, u32 ll) {
+    uint8_t le[4] = {64, 0, 0, 0};
+    dm_begin_op(t, 16 | 2); dm_absorb(t, (const uint8_t *)label, ll);
+    dm_absorb(t, le, 4);
+    dm_begin_op(t, 1 | 2 | 4);
+    u32 w[16];
+    for (u32 i = 0; i < 64; i++) {
+        u32 p = t.pos; u32 sh = 8 * (p & 7);
+        u32 b = (u32)(t.st[p >> 3] >> sh) & 0xffu;
+        t.st[p >> 3] &= ~(0xffULL << sh);
+        if ((i & 3) == 0) w[i >> 2] = 0;
+        w[i >> 2] |= b << (8 * (i & 3));
+        if (++t.pos == 166) dm_run_f(t);
+    }
+    sc lo, hi;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { lo.v[i] = w[i]; hi.v[i] = w[8 + i]; }
+    return sc_from_wide(lo, hi);
+}
+__device__ inline gd sg_fixed_mul(const niels *tab, const sc &k) {     // k canonical
+    gd acc = gd_identity(); int carry = 0;
+    for (int i = 0; i < 64; i++) {
+        int v = (int)((k.v[i >> 3] >> ((i & 7) * 4)) & 15) + carry;
+        carry = (v + 8) >> 4;
+        int dgt = v - (carry << 4), ad = dgt < 0 ? -dgt : dgt;
+        if (ad) acc = gd_madd(acc, load_nd(&tab[i * 8 + ad - 1]), dgt < 0);
+    }
+    return acc;
+}
+__device__ inline gd gd_neg(const gd &p) { gd r; r.X = fd_neg(p.X); r.Y = p.Y; r.Z = p.Z; r.T = fd_neg(p.T); return r; }
+// k * P, signed radix-16 windows, k canonical (< 2^253)
+__device__ inline gd sg_var_mul(const sc &k, const gd &P) {
+    ge tab[8];                                          // packed 1P..8P (local memory)
+    gd cur = P; tab[0] = gd_pack(cur);
+    for (int e = 1; e < 8; e++) { cur = gd_add(cur, P); tab[e] = gd_pack(cur); }
+    int8_t dg[65]; int carry = 0;
+    for (int i = 0; i < 64; i++) { int v = (int)((k.v[i >> 3] >> ((i & 7) * 4)) & 15) + carry; carry = (v + 8) >> 4; dg[i] = (int8_t)(v - (carry << 4)); }
+    dg[64] = (int8_t)carry;
+    gd acc = gd_identity();
+    for (int i = 64; i >= 0; i--) {
+        if (i != 64) { acc = gd_double(acc); acc = gd_double(acc); acc = gd_double(acc); acc = gd_double(acc); }
+        int d = dg[i], ad = d < 0 ? -d : d;
+        if (ad) { gd q = gd_unpack(tab[ad - 1]); if (d < 0) q = gd_neg(q); acc = gd_add(acc, q); }
+    }
+    return acc;
+}
+__device__ inline void sg_encode(uint8_t *out, const gd &p) { ristretto_encode(out, gd_pack(p)); }
+__device__ inline bool sg_decode(gd &p, const uint8_t *in) { ge t; bool ok = ristretto_decode(t, in); p = gd_unpack(ok ? t : ge_identity()); return ok; }
+__device__ inline bool sg_is_identity(const gd &p) { ge t = gd_pack(p); return ge_is_identity_ristretto(t); }
+
+__global__ void __launch_bounds__(64) k_sigma_prove(int kind, u32 d, const float *vals, u32 fp_bits, u32 fp_frac, const sc *r1c, const sc *r2c,
+                                                    const uint8_t *existing, int mode, NonceSeed seed, const uint8_t *stream, u64 stream_scalars,
+                                                    DMerlin init, const niels *tabB, const niels *tabBb, uint8_t *proofs, uint8_t *commits, u32 *status) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d) return;
+    u32 plen = kind ? 192 : 128, clen = kind ? 96 : 64, nn = kind ? 3 : 2;
+    float v = vals[i];
+    if (v != v) { atomicOr(status, 2u); return; }
+    // conversion32.rs:11-18
+    double x = fabs((double)v) * (double)(1ULL << fp_frac), lim = ldexp(1.0, (int)fp_bits);
+    u64 maxbits = fp_bits >= 64 ? ~0ULL : ((1ULL << fp_bits) - 1), kq;
+    if (x >= lim) kq = maxbits; else { double r = rint(x); kq = (r >= lim) ? maxbits : (u64)r; }
+    sc m = sc_from_u64(kq); if (v < 0.0f) m = sc_neg(m);
+    sc r1 = load_sc(&r1c[i]), r2 = kind ? load_sc(&r2c[i]) : sc_zero();
+    // nonces m', r1' (, r2')
+    sc nc[3];
+    for (u32 j = 0; j < nn; j++) {
+        u64 idx = (u64)nn * i + j; sc lo, hi;
+        if (mode == 1) {
+            const u64 dom[2] = {0x2f6b7a2d6c666f72ULL, 0x31762f65636e6f6eULL};
+            u64 st[25]; shake256_seeded_block(st, dom, seed.w, idx);
+#pragma unroll
+            for (int q = 0; q < 4; q++) { lo.v[2 * q] = (u32)st[q]; lo.v[2 * q + 1] = (u32)(st[q] >> 32); hi.v[2 * q] = (u32)st[4 + q]; hi.v[2 * q + 1] = (u32)(st[4 + q] >> 32); }
+        } else if (idx < stream_scalars) {
+            const u32 *s = reinterpret_cast<const u32 *>(stream + idx * 64);
+#pragma unroll
+            for (int q = 0; q < 8; q++) { lo.v[q] = s[q]; hi.v[q] = s[8 + q]; }
+        } else { lo = sc_zero(); hi = sc_zero(); }
+        nc[j] = sc_from_wide(lo, hi);
+    }
+    uint8_t *cm = commits + (size_t)clen * i, *pf = proofs + (size_t)plen * i;
+    gd L;
+    if (existing) { if (!sg_decode(L, existing + (size_t)32 * i)) { atomicOr(status, 4u); return; } for (int q = 0; q < 32; q++) cm[q] = existing[(size_t)32 * i + q]; }
+    else { L = gd_add(sg_fixed_mul(tabB, m), sg_fixed_mul(tabBb, r1)); sg_encode(cm, L); }
+    sg_encode(cm + 32, sg_fixed_mul(tabB, r1));
+    if (kind) { sc msq = sc_mul_plain(m, m); sg_encode(cm + 64, gd_add(sg_fixed_mul(tabB, msq), sg_fixed_mul(tabBb, r2))); }
+    sg_encode(pf, gd_add(sg_fixed_mul(tabB, nc[0]), sg_fixed_mul(tabBb, nc[1])));
+    sg_encode(pf + 32, sg_fixed_mul(tabB, nc[1]));
+    if (kind) sg_encode(pf + 64, gd_add(sg_var_mul(nc[0], L), sg_fixed_mul(tabBb, nc[2])));
+    DMerlin t = init;
+    if (kind) { dm_append(t, "C_eg", 4, cm, 64); dm_append(t, "C_ped", 5, cm + 64, 32); dm_append(t, "C_prime_eg", 10, pf, 64); dm_append(t, "C_prime_ped", 11, pf + 64, 32); }
+    else { dm_append(t, "C", 1, cm, 64); dm_append(t, "C_prime", 7, pf, 64); }
+    sc c = dm_challenge_scalar(t, "c", 1);
+    uint8_t *z = pf + (kind ? 96 : 64);
+    sc_tobytes(z, sc_add(nc[0], sc_mul_plain(m, c)));
+    sc_tobytes(z + 32, sc_add(nc[1], sc_mul_plain(r1, c)));
+    if (kind) sc_tobytes(z + 64, sc_add(nc[2], sc_mul_plain(sc_sub(r2, sc_mul_plain(m, r1)), c)));
+}
+
+__global__ void __launch_bounds__(64) k_sigma_verify(int kind, u32 d, const uint8_t *proofs, const uint8_t *commits, DMerlin init,
+                                                     const niels *tabB, const niels *tabBb, u32 *fail_count, u32 *status) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d) return;
+    u32 plen = kind ? 192 : 128, clen = kind ? 96 : 64;
+    const uint8_t *pf = proofs + (size_t)plen * i, *cm = commits + (size_t)clen * i, *z = pf + (kind ? 96 : 64);
+    gd L, R, Csq, Lp, Rp, Csqp;
+    bool okd = sg_decode(L, cm) & sg_decode(R, cm + 32) & sg_decode(Lp, pf) & sg_decode(Rp, pf + 32);
+    if (kind) okd = okd & sg_decode(Csq, cm + 64) & sg_decode(Csqp, pf + 64);
+    sc zm = sc_frombytes(z), zr1 = sc_frombytes(z + 32), zr2 = kind ? sc_frombytes(z + 64) : sc_zero();
+    if (!okd || sc_geq_l(zm.v) || sc_geq_l(zr1.v) || sc_geq_l(zr2.v)) { atomicOr(status, 4u); return; }
+    DMerlin t = init;
+    if (kind) { dm_append(t, "C_eg", 4, cm, 64); dm_append(t, "C_ped", 5, cm + 64, 32); dm_append(t, "C_prime_eg", 10, pf, 64); dm_append(t, "C_prime_ped", 11, pf + 64, 32); }
+    else { dm_append(t, "C", 1, cm, 64); dm_append(t, "C_prime", 7, pf, 64); }
+    sc c = dm_challenge_scalar(t, "c", 1);
+    sc cneg = sc_neg(c);
+    // Z_m B + Z_r1 Bb - c C.L - C'.L == 0 ;  Z_r1 B - c C.R - C'.R == 0
+    gd e1 = gd_add(gd_add(sg_fixed_mul(tabB, zm), sg_fixed_mul(tabBb, zr1)), gd_add(sg_var_mul(cneg, L), gd_neg(Lp)));
+    gd e2 = gd_add(sg_fixed_mul(tabB, zr1), gd_add(sg_var_mul(cneg, R), gd_neg(Rp)));
+    bool ok = sg_is_identity(e1) & sg_is_identity(e2);
+    if (kind) {   // Z_m C.L + Z_r2 Bb - c c_sq - c_sq' == 0
+        gd e3 = gd_add(gd_add(sg_var_mul(zm, L), sg_fixed_mul(tabBb, zr2)), gd_add(sg_var_mul(cneg, Csq), gd_neg(Csqp)));
+        ok = ok & sg_is_identity(e3);
+    }
+    if (!ok) atomicAdd(fail_count, 1u);
+}
+
 // ================================================================ micro-benchmark: field multiply rate
 __global__ void __launch_bounds__(TPB) k_bench_femul(u32 iters, const fe *in, fe *out) {
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;

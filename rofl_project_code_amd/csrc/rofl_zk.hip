@@ -1079,6 +1079,87 @@ int rofl_verify_rangeproof_l2(const uint8_t *proof, size_t proof_len, const uint
     });
 }
 
+namespace {
+DMerlin sigma_init_state(int kind) {
+    Merlin t(kind ? "SquareRandProof" : "RandProof", kind ? 15 : 9);
+    // rand_proof_domain_sep (rand_proof/transcript.rs:20-22) -- but the begin_op of the NEXT append depends on pos_begin,
+    // so the whole state (bytes, pos, pos_begin) is handed to the kernel
+    t.append("dom-sep", (const uint8_t *)"randomness proof v1", 19);
+    DMerlin d; memcpy(d.st, t.st, 200); d.pos = t.pos; d.pos_begin = t.pos_begin;
+    return d;
+}
+int sigma_create(int kind, const float *values, size_t d, const uint8_t *r1, size_t d_r1, const uint8_t *r2, const uint8_t *existing,
+                 unsigned fp_bits, unsigned fp_frac, const rofl_nonce_t *nonce, uint8_t *proofs_out, uint8_t *commits_out) {
+    Ctx &C = ctx(); std::lock_guard<std::mutex> lk(C.mu);
+    if (d != d_r1) return fail(ROFL_WRONG_NUM_BLINDING, "WrongNumBlindingFactors");
+    if (!valid_fp(fp_bits, fp_frac) || !nonce) return fail(ROFL_BAD_PARAM, "bad parameter");
+    if (d == 0) return ROFL_OK;
+    size_t plen = kind ? 192 : 128, clen = kind ? 96 : 64, nn = kind ? 3 : 2;
+    if (nonce->mode == 0 && nonce->stream_scalars < nn * d) return fail(ROFL_NONCE_SHORT, "nonce stream too short");
+    C.init();
+    timing_begin(C);
+    float *dv = C.vals.as<float>(d); sc *dr1 = C.tmp_in.as<sc>(d); sc *dr2 = kind ? C.tmp_in2.as<sc>(d) : nullptr;
+    uint8_t *dex = existing ? C.Cbytes.as<uint8_t>(d * 32) : nullptr;
+    uint8_t *dp = C.aux_pts.as<uint8_t>(d * plen), *dc = C.aux_scal.as<uint8_t>(d * clen);
+    u32 *status = C.status.as<u32>(4);
+    HIPCHK(hipMemsetAsync(status, 0, 16, C.stream));
+    HIPCHK(hipMemcpyAsync(dv, values, 4 * d, hipMemcpyHostToDevice, C.stream));
+    HIPCHK(hipMemcpyAsync(dr1, r1, 32 * d, hipMemcpyHostToDevice, C.stream));
+    if (kind) HIPCHK(hipMemcpyAsync(dr2, r2, 32 * d, hipMemcpyHostToDevice, C.stream));
+    if (dex) HIPCHK(hipMemcpyAsync(dex, existing, 32 * d, hipMemcpyHostToDevice, C.stream));
+    NonceSeed seed{}; const uint8_t *d_stream = nullptr; u64 ss = 0;
+    if (nonce->mode == 1) memcpy(seed.w, nonce->seed, 32);
+    else { ss = nonce->stream_scalars; uint8_t *sb = C.stream_buf.as<uint8_t>(ss * 64 + 64); HIPCHK(hipMemcpyAsync(sb, nonce->stream, ss * 64, hipMemcpyHostToDevice, C.stream)); d_stream = sb; }
+    hipLaunchKernelGGL(k_sigma_prove, dim3((unsigned)((d + 63) / 64)), dim3(64), 0, C.stream, kind, (u32)d, dv, fp_bits, fp_frac, dr1, dr2, dex,
+                       nonce->mode, seed, d_stream, ss, sigma_init_state(kind), C.d_tabB, C.d_tabBb, dp, dc, status);
+    u32 st = 0;
+    HIPCHK(hipMemcpyAsync(proofs_out, dp, d * plen, hipMemcpyDeviceToHost, C.stream));
+    HIPCHK(hipMemcpyAsync(commits_out, dc, d * clen, hipMemcpyDeviceToHost, C.stream));
+    HIPCHK(hipMemcpyAsync(&st, status, 4, hipMemcpyDeviceToHost, C.stream));
+    HIPCHK(hipStreamSynchronize(C.stream));
+    timing_end(C);
+    if (st & 2u) return fail(ROFL_NON_FINITE, "non-finite value (the reference panics in fixed::saturating_from_float)");
+    if (st & 4u) return fail(ROFL_FORMAT_ERROR, "invalid Ristretto encoding");
+    return ROFL_OK;
+}
+int sigma_verify(int kind, const uint8_t *proofs, const uint8_t *commits, size_t d, int *ok_out) {
+    Ctx &C = ctx(); std::lock_guard<std::mutex> lk(C.mu);
+    *ok_out = 0;
+    if (d == 0) { *ok_out = 1; return ROFL_OK; }
+    size_t plen = kind ? 192 : 128, clen = kind ? 96 : 64;
+    C.init();
+    timing_begin(C);
+    uint8_t *dp = C.aux_pts.as<uint8_t>(d * plen), *dc = C.aux_scal.as<uint8_t>(d * clen);
+    u32 *status = C.status.as<u32>(4);
+    HIPCHK(hipMemsetAsync(status, 0, 16, C.stream));
+    HIPCHK(hipMemcpyAsync(dp, proofs, d * plen, hipMemcpyHostToDevice, C.stream));
+    HIPCHK(hipMemcpyAsync(dc, commits, d * clen, hipMemcpyHostToDevice, C.stream));
+    hipLaunchKernelGGL(k_sigma_verify, dim3((unsigned)((d + 63) / 64)), dim3(64), 0, C.stream, kind, (u32)d, dp, dc, sigma_init_state(kind), C.d_tabB, C.d_tabBb, status + 1, status);
+    u32 st[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(st, status, 8, hipMemcpyDeviceToHost, C.stream));
+    HIPCHK(hipStreamSynchronize(C.stream));
+    timing_end(C);
+    if (st[0] & 4u) return fail(ROFL_FORMAT_ERROR, "FormatError: non-canonical scalar or invalid point");
+    *ok_out = st[1] == 0;
+    return ROFL_OK;
+}
+}  // namespace
+
+int rofl_create_randproof_vec(const float *values, size_t d, const uint8_t *r32, size_t d_r, const uint8_t *existing32, unsigned fp_bits, unsigned fp_frac,
+                              const rofl_nonce_t *nonce, uint8_t *proofs_out, uint8_t *commits_out) {
+    return guarded([&]() -> int { return sigma_create(0, values, d, r32, d_r, nullptr, existing32, fp_bits, fp_frac, nonce, proofs_out, commits_out); });
+}
+int rofl_verify_randproof_vec(const uint8_t *proofs, const uint8_t *commits, size_t d, int *ok_out) {
+    return guarded([&]() -> int { return sigma_verify(0, proofs, commits, d, ok_out); });
+}
+int rofl_create_squarerandproof_vec(const float *values, size_t d, const uint8_t *r1_32, size_t d_r1, const uint8_t *r2_32, const uint8_t *existing32,
+                                    unsigned fp_bits, unsigned fp_frac, const rofl_nonce_t *nonce, uint8_t *proofs_out, uint8_t *commits_out) {
+    return guarded([&]() -> int { return sigma_create(1, values, d, r1_32, d_r1, r2_32, existing32, fp_bits, fp_frac, nonce, proofs_out, commits_out); });
+}
+int rofl_verify_squarerandproof_vec(const uint8_t *proofs, const uint8_t *commits, size_t d, int *ok_out) {
+    return guarded([&]() -> int { return sigma_verify(1, proofs, commits, d, ok_out); });
+}
+
 int rofl_commit_vec(const uint8_t *values32, const uint8_t *blindings32, size_t d, uint8_t *out32) {
     return guarded([&]() -> int {
         Ctx &C = ctx(); std::lock_guard<std::mutex> lk(C.mu);

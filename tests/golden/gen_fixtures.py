@@ -163,5 +163,22 @@ for (vals, nb, fb, ff) in (([1.25, 0.5, 0.25], 16, 16, 7), ([7.9], 32, 32, 7), (
     proofs.append({"kind": "l2", "d": len(vals), "prove_range": nb, "n_partition": 4, "fp_bits": fb, "fp_frac": ff,
                    "values": [float(x) for x in vals], "blindings": bl.tobytes().hex(), "seed": seed.hex(),
                    "proofs": pr.tobytes().hex(), "n_proofs": 1, "commits": cm.tobytes().hex()})
+for kind, vals, fb, ff in ((0, [0.25, 1.25, -1.5], 16, 7), (1, [0.25, 1.25, -1.5], 16, 7), (1, [-7.9, 0.0078125], 32, 7)):
+    vals = np.array(vals, dtype=np.float32)
+    r1, r2 = orc.rand_scalars(prng, len(vals)), orc.rand_scalars(prng, len(vals))
+    seed = bytes(prng.integers(0, 256, size=32, dtype=np.uint8))
+    rc, pr, cm = orc.sigma_create(kind, vals, r1, r2 if kind else None, fb, ff, seed=seed)
+    assert rc == 0 and orc.sigma_verify(kind, pr, cm) == (0, True)
+    # independent check of the commitments with libsodium: L = m B + r1 Bb, R = r1 B, c_sq = m^2 B + r2 Bb
+    Bb = from_hash(hashlib.sha3_512(smul_base(1)).digest())
+    for i, v in enumerate(vals):
+        k = int(round(abs(float(v)) * (1 << ff))); m = k if v >= 0 else (-k) % R.L
+        r1i = int.from_bytes(r1[i].tobytes(), "little"); r2i = int.from_bytes(r2[i].tobytes(), "little")
+        Lx = padd(smul_base(m), smul(r1i, Bb)) if m else smul(r1i, Bb)
+        assert cm[i, :32].tobytes() == Lx and cm[i, 32:64].tobytes() == smul_base(r1i)
+        if kind:
+            assert cm[i, 64:].tobytes() == padd(smul_base(m * m % R.L), smul(r2i, Bb))
+    proofs.append({"kind": "rand" if kind == 0 else "sqrand", "d": len(vals), "fp_bits": fb, "fp_frac": ff, "values": [float(x) for x in vals],
+                   "r1": r1.tobytes().hex(), "r2": r2.tobytes().hex(), "seed": seed.hex(), "proofs": pr.tobytes().hex(), "commits": cm.tobytes().hex()})
 json.dump(proofs, open(os.path.join(HERE, "proofs.json"), "w"), indent=0)
 print("wrote primitives.json, proofs.json")

@@ -150,3 +150,26 @@ def msm(scalars32, points32):
     out = np.zeros(32, dtype=np.uint8)
     lib().orc_msm(_p(k), _p(p), _sz(k.shape[0]), _p(out))
     return out
+
+
+def sigma_create(kind, values, r1, r2, fp_bits, fp_frac, seed=None, stream=None, existing=None):
+    v = np.ascontiguousarray(values, dtype=np.float32)
+    r1 = np.ascontiguousarray(r1, dtype=np.uint8).reshape(-1, 32)
+    r2 = None if r2 is None else np.ascontiguousarray(r2, dtype=np.uint8).reshape(-1, 32)
+    ex = None if existing is None else np.ascontiguousarray(existing, dtype=np.uint8).reshape(-1, 32)
+    d = v.size
+    pl, cl = (192, 96) if kind else (128, 64)
+    ns = _nonce(seed, stream)
+    pr = np.zeros((max(d, 1), pl), np.uint8); cm = np.zeros((max(d, 1), cl), np.uint8)
+    rc = lib().orc_sigma_create(kind, _p(v), _sz(d), _p(r1), _sz(r1.shape[0]), None if r2 is None else _p(r2), None if ex is None else _p(ex),
+                                fp_bits, fp_frac, ctypes.byref(ns), _p(pr), _p(cm))
+    return rc, pr[:d], cm[:d]
+
+
+def sigma_verify(kind, proofs, commits):
+    pl, cl = (192, 96) if kind else (128, 64)
+    p = np.ascontiguousarray(proofs, dtype=np.uint8).reshape(-1, pl)
+    c = np.ascontiguousarray(commits, dtype=np.uint8).reshape(-1, cl)
+    ok = ctypes.c_int()
+    rc = lib().orc_sigma_verify(kind, _p(p), _p(c), _sz(p.shape[0]), ctypes.byref(ok))
+    return rc, bool(ok.value)

@@ -91,6 +91,16 @@ def test_explicit_nonce_stream_mode(R):
 def test_golden_fixtures(R, golden_proofs):
     for g in golden_proofs:
         R.api.set_fp(g["fp_bits"], g["fp_frac"])
+        if g["kind"] in ("rand", "sqrand"):
+            r1 = np.frombuffer(H(g["r1"]), np.uint8).reshape(-1, 32); r2 = np.frombuffer(H(g["r2"]), np.uint8).reshape(-1, 32)
+            if g["kind"] == "rand":
+                pr, cm = R.rand_proof_vec.create_randproof_vec(g["values"], r1, nonce=R.Nonce.seeded(H(g["seed"])))
+                assert R.rand_proof_vec.verify_randproof_vec(pr, cm)
+            else:
+                pr, cm = R.square_rand_proof_vec.create_l2rangeproof_vec(g["values"], r1, r2, nonce=R.Nonce.seeded(H(g["seed"])))
+                assert R.square_rand_proof_vec.verify_l2rangeproof_vec(pr, cm)
+            assert pr.tobytes().hex() == g["proofs"] and cm.tobytes().hex() == g["commits"]
+            continue
         bl = np.frombuffer(H(g["blindings"]), np.uint8).reshape(-1, 32)
         if g["kind"] == "linf":
             pr, cm = R.range_proof_vec.create_rangeproof(g["values"], bl, g["prove_range"], g["n_partition"], nonce=R.Nonce.seeded(H(g["seed"])))
@@ -303,4 +313,102 @@ def test_cfg4_shape_batch_verify(R):
     prs[1] = prs[1].copy(); prs[1][3, 77] ^= 1
     cms[2] = cms[2].copy(); cms[2][54999] = cms[2][0]
     assert R.range_proof_vec.verify_rangeproof_batch(prs, cms, nb, verifier_seed=b"\x02" * 32) == [True, False, False]
+    R.api.set_fp(16, 7)
+
+
+@pytest.mark.parametrize("kind,d,fb,ff", [(0, 1, 16, 7), (0, 70, 16, 7), (1, 5, 16, 7), (1, 130, 32, 7), (0, 300, 32, 12)])
+def test_sigma_proofs_bit_exact(R, kind, d, fb, ff):
+    """rand_proof_vec / square_rand_proof_vec: proofs, commitments and verify bits vs the oracle (device Merlin)."""
+    R.api.set_fp(fb, ff)
+    rng = np.random.default_rng(100 * d + kind)
+    vals = rng.uniform(-3, 3, size=d).astype(np.float32)
+    vals[0] = -1.5
+    r1, r2 = orc.rand_scalars(rng, d), orc.rand_scalars(rng, d)
+    seed = bytes(rng.integers(0, 256, 32, dtype=np.uint8))
+    if kind == 0:
+        pr, cm = R.rand_proof_vec.create_randproof_vec(vals, r1, nonce=R.Nonce.seeded(seed))
+        ver = R.rand_proof_vec.verify_randproof_vec
+    else:
+        pr, cm = R.square_rand_proof_vec.create_l2rangeproof_vec(vals, r1, r2, nonce=R.Nonce.seeded(seed))
+        ver = R.square_rand_proof_vec.verify_l2rangeproof_vec
+    rc, opr, ocm = orc.sigma_create(kind, vals, r1, r2 if kind else None, fb, ff, seed=seed)
+    assert rc == 0 and (cm == ocm).all() and (pr == opr).all()
+    assert ver(pr, cm) is True and orc.sigma_verify(kind, pr, cm) == (0, True)
+    # the ElGamal L part is the Pedersen commitment of the range proof path (commit_vec)
+    assert (cm[:, :32] == R.pedersen_ops.commit_vec(R.conversion32.f32_to_scalar_vec(vals), r1)).all()
+    # prove_existing with those commitments reproduces the same proof
+    if kind == 0:
+        pr2, cm2 = R.rand_proof_vec.create_randproof_vec_existing(vals, cm[:, :32], r1, nonce=R.Nonce.seeded(seed))
+    else:
+        pr2, cm2 = R.square_rand_proof_vec.create_l2rangeproof_vec_existing(vals, cm[:, :32], r1, r2, nonce=R.Nonce.seeded(seed))
+    assert (pr2 == pr).all() and (cm2 == cm).all()
+    # tamper: response scalar, prime commitment, real commitment
+    for off in ((64 if kind == 0 else 96) + 3, 5):
+        bad = pr.copy(); bad[d // 2, off] ^= 1
+        try:
+            res = ver(bad, cm)
+        except R.RoflError as e:
+            assert e.code == 5 and orc.sigma_verify(kind, bad, cm)[0] == 5      # flipped into an invalid encoding
+        else:
+            assert res is False and orc.sigma_verify(kind, bad, cm) == (0, False)
+    badc = cm.copy(); badc[0, :32] = cm[-1, :32] if d > 1 else R.pedersen_ops.commit_no_blinding_vec(r1)[0]
+    if d > 1 and not (cm[0, :32] == cm[-1, :32]).all():
+        assert ver(pr, badc) is False
+    # non-canonical response scalar -> FormatError
+    bad = pr.copy(); bad[0, (64 if kind == 0 else 96):(96 if kind == 0 else 128)] = 0xFF
+    with pytest.raises(R.RoflError) as e:
+        ver(bad, cm)
+    assert e.value.code == 5
+    R.api.set_fp(16, 7)
+
+
+def test_sigma_reference_semantics(R):
+    """l2_range_proof_vec/mod.rs:539-561: sum of the c_sq of the square proofs == the L2 range-proof commitment;
+    square_rand_proof_vec/mod.rs:195-208: existing round trip; wrong lengths -> WrongNumBlindingFactors."""
+    R.api.set_fp(16, 7)
+    rng = np.random.default_rng(77)
+    vals = np.array([1.25, -0.5, 0.25], np.float32)
+    zero = np.zeros((3, 32), np.uint8)
+    pr, cm = R.square_rand_proof_vec.create_l2rangeproof_vec(vals, zero, zero, nonce=R.Nonce.seeded(b"\x01" * 32))
+    _, l2c = R.l2_range_proof_vec.create_rangeproof_l2(vals, zero, 16, 4, nonce=R.Nonce.seeded(b"\x02" * 32))
+    s = R.pedersen_ops.add_rp_vec(R.pedersen_ops.add_rp_vec(cm[0:1, 64:], cm[1:2, 64:]), cm[2:3, 64:])
+    assert (s[0] == l2c).all()
+    with pytest.raises(R.RoflError) as e:
+        R.rand_proof_vec.create_randproof_vec(vals, orc.rand_scalars(rng, 2))
+    assert e.value.code == 1
+    # explicit nonce stream
+    stream = rng.integers(0, 256, 3 * 3 * 64, dtype=np.uint8).tobytes()
+    r1, r2 = orc.rand_scalars(rng, 3), orc.rand_scalars(rng, 3)
+    pr, cm = R.square_rand_proof_vec.create_l2rangeproof_vec(vals, r1, r2, nonce=R.Nonce.stream(stream))
+    rc, opr, ocm = orc.sigma_create(1, vals, r1, r2, 16, 7, stream=stream)
+    assert rc == 0 and (pr == opr).all() and (cm == ocm).all()
+
+
+def test_sigma_full_size_cfg3(R):
+    """BASELINE config 3 (L2, d = 25 000): per-element square proofs + the sum proof; properties at full size,
+    oracle parity on a sample of elements (each element is an independent proof)."""
+    R.api.set_fp(32, 7)
+    rng = np.random.default_rng(3)
+    d = 25000
+    vals = (rng.integers(-3, 4, size=d) / 128.0).astype(np.float32)
+    r1 = rng.integers(0, 256, size=(d, 32), dtype=np.uint8); r1[:, 31] &= 0x0F
+    r2 = rng.integers(0, 256, size=(d, 32), dtype=np.uint8); r2[:, 31] &= 0x0F
+    seed = b"\x21" * 32
+    pr, cm = R.square_rand_proof_vec.create_l2rangeproof_vec(vals, r1, r2, nonce=R.Nonce.seeded(seed))
+    assert R.square_rand_proof_vec.verify_l2rangeproof_vec(pr, cm) is True
+    idx = rng.choice(d, 16, replace=False)
+    for i in idx:      # element i uses nonces 3i..3i+2: reproduce with an explicit 3-scalar stream from the oracle's DRBG
+        ns = orc._nonce(seed=seed)
+        raw = b""
+        for j in range(3):
+            out = np.zeros(32, np.uint8)
+            orc.lib().orc_nonce_scalar(ctypes.byref(ns), ctypes.c_uint64(3 * int(i) + j), out.ctypes.data_as(ctypes.c_void_p))
+            raw += out.tobytes() + bytes(32)
+        rc, opr, ocm = orc.sigma_create(1, vals[i:i + 1], r1[i:i + 1], r2[i:i + 1], 32, 7, stream=raw)
+        assert rc == 0 and (opr[0] == pr[i]).all() and (ocm[0] == cm[i]).all()
+    bad = pr.copy(); bad[12345, 100] ^= 1
+    try:
+        assert R.square_rand_proof_vec.verify_l2rangeproof_vec(bad, cm) is False
+    except R.RoflError as e:
+        assert e.code == 5
     R.api.set_fp(16, 7)

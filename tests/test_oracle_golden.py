@@ -100,6 +100,13 @@ def test_reference_values_commit(prim):
 
 def test_golden_proofs_reproduce(golden_proofs):
     for g in golden_proofs:
+        if g["kind"] in ("rand", "sqrand"):
+            kind = 0 if g["kind"] == "rand" else 1
+            r1 = np.frombuffer(H(g["r1"]), np.uint8).reshape(-1, 32); r2 = np.frombuffer(H(g["r2"]), np.uint8).reshape(-1, 32)
+            rc, pr, cm = orc.sigma_create(kind, g["values"], r1, r2 if kind else None, g["fp_bits"], g["fp_frac"], seed=H(g["seed"]))
+            assert rc == 0 and pr.tobytes().hex() == g["proofs"] and cm.tobytes().hex() == g["commits"]
+            assert orc.sigma_verify(kind, pr, cm) == (0, True)
+            continue
         bl = np.frombuffer(H(g["blindings"]), np.uint8).reshape(-1, 32)
         if g["kind"] == "linf":
             rc, pr, cm = orc.create_rangeproof(g["values"], bl, g["prove_range"], g["n_partition"], g["fp_bits"], g["fp_frac"], seed=H(g["seed"]))

@@ -12,6 +12,7 @@
 #include <memory>
 #include <atomic>
 #include <condition_variable>
+#include <exception>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -181,9 +182,16 @@ struct Timing {
     void reset() { t = rofl_timing_t{}; acc_ev.clear(); fold_ev.clear(); acc_tag.clear(); fold_tag.clear(); used = 0; first = last = nullptr; }
 };
 
+// One Ctx = one "lane": a HIP stream with its own workspace, staging buffers, timing and host pool.  The primary
+// lane of a device owns the shared read-only state (fixed-base tables, generator cache); `second` is a sibling lane
+// used to run the two halves of a client's chunks concurrently, so that the latency-bound phases of one half
+// (small rounds, host Horner, folds) overlap the throughput-bound phases of the other.
 struct Ctx {
     int device = 0;
     bool inited = false;
+    Ctx *parent = nullptr;
+    std::vector<Ctx *> sibs;      // additional lanes
+    int nlanes = 2;
     hipStream_t stream = nullptr;
     std::mutex mu;
     HostTables ht;
@@ -232,6 +240,17 @@ struct Ctx {
         if (const char *e = getenv("ROFL_FOLD_UNIT")) fold_unit = atoi(e) != 0;
         if (const char *e = getenv("ROFL_FOLD_K")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) fold_k = v; }
         if (const char *e = getenv("ROFL_FOLD_THREADS")) { long v = atol(e); if (v > 0) fold_threads = v; }
+        if (const char *e = getenv("ROFL_LANES")) { int v = atoi(e); if (v >= 1 && v <= 8) nlanes = v; }
+        inited = true;
+        for (int i = 1; i < nlanes; i++) { Ctx *s = new Ctx(); s->init_lane(*this); sibs.push_back(s); }
+    }
+    void init_lane(Ctx &p) {
+        parent = &p; device = p.device;
+        HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        ht = p.ht; d_tabB = p.d_tabB; d_tabBb = p.d_tabBb; d_two_pow = p.d_two_pow;
+        fold_min = p.fold_min; msm_slots = p.msm_slots; fold_t = p.fold_t; fold_t1 = p.fold_t1; fold_k = p.fold_k; fold_tab = p.fold_tab;
+        fold_unit = p.fold_unit; fold_threads = p.fold_threads; nlanes = 1;
+        { int nt = 6; if (const char *e = getenv("ROFL_HOST_THREADS")) nt = atoi(e); if (nt < 1) nt = 1; pool.reset(new HostPool(nt)); }
         inited = true;
     }
 };
@@ -254,8 +273,9 @@ size_t next_pow2(size_t val) { if (val == 1) return 1; size_t n = val - 1; while
 // ---------------------------------------------------------------- generators
 niels *get_gens(Ctx &C, size_t n, size_t m) {
     auto key = std::make_pair(n, m);
-    auto it = C.gens.find(key);
-    if (it != C.gens.end()) return it->second;
+    auto &gens = C.parent ? C.parent->gens : C.gens;      // the cache lives in the primary lane (filled before lanes fork)
+    auto it = gens.find(key);
+    if (it != gens.end()) return it->second;
     size_t N = n * m;
     niels *tbl; HIPCHK(hipMalloc(&tbl, sizeof(niels) * 2 * N * 16));      // slice 0 = generators, 1..15 = fold tables
     uint8_t *uni = C.uni.as<uint8_t>(2 * N * 64);
@@ -263,7 +283,7 @@ niels *get_gens(Ctx &C, size_t n, size_t m) {
     hipLaunchKernelGGL(k_gens_map, grid1(2 * N), dim3(TPB), 0, C.stream, (u32)(2 * N), uni, tbl);
     hipLaunchKernelGGL(k_gens_tables, grid1(2 * N), dim3(TPB), 0, C.stream, (u32)(2 * N), tbl, (size_t)(2 * N));
     HIPCHK(hipStreamSynchronize(C.stream));
-    C.gens[key] = tbl;
+    gens[key] = tbl;
     return tbl;
 }
 
@@ -840,6 +860,35 @@ void timing_end(Ctx &C) {
     for (size_t i = 0; i < C.tm.fold_ev.size(); i++) { auto &e = C.tm.fold_ev[i]; HIPCHK(hipEventElapsedTime(&ms, e.first, e.second)); C.tm.t.fold_ms += ms; if (trace) fprintf(stderr, "[rofl] %-40s %.3f ms\n", C.tm.fold_tag[i].c_str(), ms); }
 }
 
+// Run f(lane, first_chunk, n_chunks) over the lanes concurrently: the P chunks are split into contiguous groups.
+template <class F> void run_dual(Ctx &C, size_t P, F f) {
+    size_t L = std::min<size_t>(P, 1 + C.sibs.size());
+    if (L < 2) { f(C, (size_t)0, P); return; }
+    std::vector<size_t> start(L + 1);
+    for (size_t l = 0; l <= L; l++) start[l] = l * P / L;
+    std::vector<std::exception_ptr> err(L);
+    std::vector<HipErr> herr(L, HipErr{hipSuccess, nullptr});
+    std::vector<std::thread> th;
+    for (size_t l = 1; l < L; l++) {
+        Ctx *B = C.sibs[l - 1];
+        B->tm.enabled = C.tm.enabled;
+        th.emplace_back([&, l, B] {
+            try { HIPCHK(hipSetDevice(B->device)); timing_begin(*B); f(*B, start[l], start[l + 1] - start[l]); timing_end(*B); }
+            catch (const HipErr &e) { herr[l] = e; }
+            catch (...) { err[l] = std::current_exception(); }
+        });
+    }
+    try { f(C, start[0], start[1] - start[0]); } catch (...) { for (auto &t : th) t.join(); throw; }
+    for (auto &t : th) t.join();
+    for (size_t l = 1; l < L; l++) { if (herr[l].e != hipSuccess) throw herr[l]; if (err[l]) std::rethrow_exception(err[l]); }
+    for (size_t l = 1; l < L; l++) {      // merge the siblings' counters
+        Ctx &B = *C.sibs[l - 1];
+        C.tm.t.msm_accumulate_ms += B.tm.t.msm_accumulate_ms; C.tm.t.msm_accumulate_launches += B.tm.t.msm_accumulate_launches;
+        C.tm.t.msm_terms += B.tm.t.msm_terms; C.tm.t.fold_ms += B.tm.t.fold_ms; C.tm.t.fold_launches += B.tm.t.fold_launches;
+        C.tm.t.fold_point_reads += B.tm.t.fold_point_reads; C.tm.t.host_ms += B.tm.t.host_ms;
+    }
+}
+
 template <class F> int guarded(F f) {
     try { return f(); }
     catch (const HipErr &e) {
@@ -888,9 +937,16 @@ int create_impl(Ctx &C, const float *values, size_t d, const uint8_t *blind, siz
     std::vector<uint8_t> hV(dp * 32);
     HIPCHK(hipMemcpyAsync(hV.data(), Vb, dp * 32, hipMemcpyDeviceToHost, C.stream));
     HIPCHK(hipMemcpyAsync(commits_out, Cb, d * 32, hipMemcpyDeviceToHost, C.stream));
-    prove_chunks(C, "RangeProof", P, prove_range, chunk, vshift, d_blind_buf, nonce, 0, hV.data(), proofs_out);
+    size_t plen = 32 * (9 + 2 * (size_t)lg2u(prove_range * chunk));
+    get_gens(C, prove_range, chunk);
+    HIPCHK(hipStreamSynchronize(C.stream));       // V bytes, vshift and blindings are complete before the lanes fork
+    u64 per_chunk_nonces = (u64)chunk * (2 * prove_range + 4);
+    run_dual(C, P, [&](Ctx &Ln, size_t c0, size_t nc) {
+        prove_chunks(Ln, "RangeProof", nc, prove_range, chunk, vshift + c0 * chunk, d_blind_buf + c0 * chunk, nonce, c0 * per_chunk_nonces,
+                     hV.data() + c0 * chunk * 32, proofs_out + c0 * plen);
+    });
     timing_end(C);
-    *plen_out = 32 * (9 + 2 * (size_t)lg2u(prove_range * chunk)); *np_out = P;
+    *plen_out = plen; *np_out = P;
     return ROFL_OK;
 }
 
@@ -941,7 +997,14 @@ int verify_impl(Ctx &C, size_t n_clients, const uint8_t *const *proofs, size_t p
             cidx[q] = c;
         }
     std::vector<int> okc(P);
-    int rc = verify_chunks(C, "RangeProof", prove_range, P, prove_range, chunk, pf.data(), proof_len, Vh.data(), d_vn2, seed, cidx.data(), okc.data());
+    get_gens(C, prove_range, chunk);
+    HIPCHK(hipStreamSynchronize(C.stream));
+    int rc = 0; std::mutex rc_mu;
+    run_dual(C, P, [&](Ctx &Ln, size_t c0, size_t nc) {
+        int r = verify_chunks(Ln, "RangeProof", prove_range, nc, prove_range, chunk, pf.data() + c0 * proof_len, proof_len, Vh.data() + c0 * chunk * 32,
+                              d_vn2 + c0 * chunk, seed, cidx.data() + c0, okc.data() + c0);
+        if (r) { std::lock_guard<std::mutex> lk2(rc_mu); if (!rc) rc = r; }
+    });
     timing_end(C);
     if (rc) return fail(rc, "proof rejected before verification (format / bitsize)");
     for (size_t i = 0; i < n_clients; i++) { int r = 1; for (size_t c = 0; c < nv; c++) r &= okc[i * nv + c]; ok_out[i] = r; }

@@ -52,6 +52,32 @@ def cpu_baseline(sample_d=2048):
             "sample": f"oracle create+verify, d={sample_d}, 32-bit, P={NPART}, {dt:.1f} s on 1 host thread"}
 
 
+def l2_composite(R, api, reps=3):
+    """BASELINE config 3 (secondary, not the headline): what EncParamsL2::encrypt / verify run per client
+    (rofl_service/src/flserver/params.rs:608-646, 206-234): 8-bit per-element range proof (value_range 8, P = 4) +
+    L2 sum proof (l2_value_range 32) + per-element square proofs, d = 25 000, fp32/frac7."""
+    api.set_fp(FP_BITS, FP_FRAC)
+    rng = np.random.default_rng(5)
+    vals = (rng.integers(-3, 4, size=D) / 128.0).astype(np.float32)       # on the quantisation grid, small L2 norm
+    r1 = rng.integers(0, 256, size=(D, 32), dtype=np.uint8); r1[:, 31] &= 0x0F
+    r2 = rng.integers(0, 256, size=(D, 32), dtype=np.uint8); r2[:, 31] &= 0x0F
+    best = None
+    for rep in range(reps + 1):
+        t0 = time.perf_counter()
+        rp, cm = R.range_proof_vec.create_rangeproof(vals, r1, 8, NPART, nonce=R.Nonce.seeded(b"\x01" * 32))
+        l2p, l2c = R.l2_range_proof_vec.create_rangeproof_l2(vals, r2, 32, NPART, nonce=R.Nonce.seeded(b"\x02" * 32))
+        sp, sc_ = R.square_rand_proof_vec.create_l2rangeproof_vec_existing(vals, cm, r1, r2, nonce=R.Nonce.seeded(b"\x03" * 32))
+        t1 = time.perf_counter()
+        ok = (R.square_rand_proof_vec.verify_l2rangeproof_vec(sp, sc_) and R.range_proof_vec.verify_rangeproof(rp, cm, 8, verifier_seed=b"\x04" * 32)
+              and R.l2_range_proof_vec.verify_rangeproof_l2(l2p, l2c, 32, verifier_seed=b"\x05" * 32))
+        t2 = time.perf_counter()
+        assert ok
+        if rep and (best is None or t2 - t0 < best[0]):
+            best = (t2 - t0, t1 - t0, t2 - t1)
+    return {"workload": "L2 composite d=25000: 8-bit range proof + L2 sum proof + square proofs, create+verify", "elements_per_s": D / best[0],
+            "create_ms": best[1] * 1e3, "verify_ms": best[2] * 1e3}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -59,6 +85,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=2048)
+    ap.add_argument("--no-l2", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -174,6 +201,8 @@ def main():
             out["valu_roofline"] = {"fe_mul_per_s_peak_measured": R.bench_femul(400)}
         except Exception as e:      # noqa: BLE001
             out["valu_roofline"] = {"error": str(e)}
+        if world == 1 and not args.no_l2:
+            out["l2_composite"] = l2_composite(R, api)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample)
         print(json.dumps(out))

@@ -95,7 +95,23 @@ void fe_mul(fe *h, const fe *f, const fe *g) {
     h->v[0] = h0; h->v[1] = h1; h->v[2] = h2; h->v[3] = h3; h->v[4] = h4;
 }
 
-void fe_sq(fe *h, const fe *f) { fe_mul(h, f, f); }
+void fe_sq(fe *h, const fe *f) {
+    u128 f0 = f->v[0], f1 = f->v[1], f2 = f->v[2], f3 = f->v[3], f4 = f->v[4];
+    uint64_t f0_2 = 2 * f->v[0], f1_2 = 2 * f->v[1], f3_19 = 19 * f->v[3], f4_19 = 19 * f->v[4];
+    u128 r0 = f0 * f->v[0] + (u128)f1_2 * f4_19 + (u128)(2 * f->v[2]) * f3_19;
+    u128 r1 = (u128)f0_2 * f->v[1] + (u128)(2 * f->v[2]) * f4_19 + f3 * f3_19;
+    u128 r2 = (u128)f0_2 * f->v[2] + f1 * f->v[1] + (u128)(2 * f->v[3]) * f4_19;
+    u128 r3 = (u128)f0_2 * f->v[3] + (u128)f1_2 * f->v[2] + f4 * f4_19;
+    u128 r4 = (u128)f0_2 * f->v[4] + (u128)f1_2 * f->v[3] + f2 * f->v[2];
+    uint64_t c;
+    r1 += (uint64_t)(r0 >> 51); uint64_t h0 = (uint64_t)r0 & M51;
+    r2 += (uint64_t)(r1 >> 51); uint64_t h1 = (uint64_t)r1 & M51;
+    r3 += (uint64_t)(r2 >> 51); uint64_t h2 = (uint64_t)r2 & M51;
+    r4 += (uint64_t)(r3 >> 51); uint64_t h3 = (uint64_t)r3 & M51;
+    c = (uint64_t)(r4 >> 51); uint64_t h4 = (uint64_t)r4 & M51;
+    h0 += c * 19; c = h0 >> 51; h0 &= M51; h1 += c;
+    h->v[0] = h0; h->v[1] = h1; h->v[2] = h2; h->v[3] = h3; h->v[4] = h4;
+}
 
 static void fe_sqn(fe *h, const fe *f, int n) {
     fe_sq(h, f);
@@ -647,7 +663,7 @@ void merlin_challenge_scalar(merlin_t *t, const char *label, sc *out) {
 /* ===================================================================== */
 static int orc_inited = 0;
 void orc_init(void) {
-    if (orc_inited) return;
+    if (orc_inited) return;   /* call once from the main thread before any parallel region (all entry points do) */
     fe_fromhex(&FE_D, "a3785913ca4deb75abd841414d0a700098e879777940c78c73fe6f2bee6c0352");
     fe_fromhex(&FE_D2, "59f1b226949bd6eb56b183829a14e00030d1f3eef2808e19e7fcdf56dcd90624");
     fe_fromhex(&FE_SQRTM1, "b0a00e4a271beec478e42fad0618432fa7d7fb3d99004d2b0bdfc14f8024832b");

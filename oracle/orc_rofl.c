@@ -525,12 +525,19 @@ int orc_create_rangeproof(const float *values, size_t d, const uint8_t *blind32,
     if (!(prove_range == 8 || prove_range == 16 || prove_range == 32 || prove_range == 64)) { free(v); free(bl); return ORC_INVALID_BITSIZE; }
     size_t plen = orc_proof_size(prove_range, chunk);
     uint8_t *V = malloc(32 * dp);
-    for (size_t c = 0; c < n_proofs; c++) {                                /* :75-78 */
+    int rc_any = 0;
+    /* :75-78 par_iter over chunks (rayon in the reference; OpenMP here, ORC threads = min(P, OMP_NUM_THREADS)) */
+#pragma omp parallel for schedule(dynamic, 1)
+    for (long c = 0; c < (long)n_proofs; c++) {
         int rc = orc_bp_prove((const uint8_t *)"RangeProof", 10, prove_range, v + c * chunk, bl + 32 * c * chunk,
                               chunk, prove_range, ns, c * orc_nonces_per_chunk(prove_range, chunk),
                               proofs_out + c * plen, V + 32 * c * chunk);
-        if (rc) { free(v); free(bl); free(V); return rc; }
+        if (rc) {
+#pragma omp critical
+            rc_any = rc;
+        }
     }
+    if (rc_any) { free(v); free(bl); free(V); return rc_any; }
     /* :96-99 downshift: decompress, add commit(-offset, 0), truncate to d */
     sc noff; sc_neg(&noff, &offset);
     ge inv_off; ge_scalarmult(&inv_off, &noff, &GE_BASE);
@@ -562,14 +569,15 @@ int orc_verify_rangeproof(const uint8_t *proofs, size_t proof_len, size_t n_proo
     size_t n_chunks = (dp + chunk - 1) / chunk;
     size_t nv = n_proofs < n_chunks ? n_proofs : n_chunks;                 /* zip truncates (:173-176) */
     int res = 1; int rc_first = ORC_OK;
-    for (size_t c = 0; c < nv; c++) {
-        size_t mlen = (c + 1) * chunk <= dp ? chunk : dp - c * chunk;
-        int okc = 0;
-        int rc = orc_bp_verify((const uint8_t *)"RangeProof", 10, prove_range, proofs + c * proof_len, proof_len,
-                               V + 32 * c * chunk, mlen, prove_range, c_seed, c, &okc);
-        if (rc && !rc_first) rc_first = rc;
-        res &= okc;
+    int *rcs = calloc(nv, sizeof(int)), *oks = calloc(nv, sizeof(int));
+#pragma omp parallel for schedule(dynamic, 1)
+    for (long c = 0; c < (long)nv; c++) {                                  /* :178-181 par_iter */
+        size_t mlen = ((size_t)c + 1) * chunk <= dp ? chunk : dp - c * chunk;
+        rcs[c] = orc_bp_verify((const uint8_t *)"RangeProof", 10, prove_range, proofs + c * proof_len, proof_len,
+                               V + 32 * c * chunk, mlen, prove_range, c_seed, c, &oks[c]);
     }
+    for (size_t c = 0; c < nv; c++) { if (rcs[c] && !rc_first) rc_first = rcs[c]; res &= oks[c]; }
+    free(rcs); free(oks);
     free(V);
     if (rc_first) return rc_first;
     *ok = res;

@@ -111,6 +111,19 @@ int rofl_create_squarerandproof_vec(const float *values, size_t d, const uint8_t
                                     const uint8_t *existing32, unsigned fp_bits, unsigned fp_frac, const rofl_nonce_t *nonce,
                                     uint8_t *proofs_out /* d*192 */, uint8_t *commits_out /* d*96 */);
 int rofl_verify_squarerandproof_vec(const uint8_t *proofs, const uint8_t *commits, size_t d, int *ok_out);
+/* square_proof_vec/mod.rs:18-159 (create_l2rangeproof_vec(_existing), verify_l2rangeproof_vec over Pedersen commitments only):
+ *   commitments 64 B = c_l|c_sq, proof 160 B = c_l'|c_sq'|Z_m|Z_r1|Z_r2; nonces m', r1', r2' at 3i.. */
+int rofl_create_squareproof_vec(const float *values, size_t d, const uint8_t *r1_32, size_t d_r1, const uint8_t *r2_32,
+                                const uint8_t *existing32, unsigned fp_bits, unsigned fp_frac, const rofl_nonce_t *nonce,
+                                uint8_t *proofs_out /* d*160 */, uint8_t *commits_out /* d*64 */);
+int rofl_verify_squareproof_vec(const uint8_t *proofs, const uint8_t *commits, size_t d, int *ok_out);
+/* compressed_rand_proof/mod.rs:43-102, 134-160 (helper_prove, helper_prove_existing, helper_verify): ONE 128-byte proof
+ * C'.L|C'.R|Z_m|Z_r for all d ElGamal pairs (d*64 B), z = nonce + sum_i x_i c^(i+1); nonces m', r' at index 0, 1.
+ * d < 900 000 (size of the reference's label table UNIQUE_U8_TRIPLETS). */
+int rofl_create_compressed_randproof(const float *values, size_t d, const uint8_t *r32, size_t d_r, const uint8_t *existing32,
+                                     unsigned fp_bits, unsigned fp_frac, const rofl_nonce_t *nonce, uint8_t proof_out[128],
+                                     uint8_t *pairs_out /* d*64 */);
+int rofl_verify_compressed_randproof(const uint8_t proof[128], const uint8_t *pairs, size_t d, int *ok_out);
 
 /* ---- pedersen_ops (pedersen_ops.rs) ---- */
 int rofl_commit_vec(const uint8_t *values32, const uint8_t *blindings32 /* NULL: commit_no_blinding_vec */,

@@ -647,6 +647,7 @@ void merlin_init(merlin_t *t, const uint8_t *label, size_t len) {
 void merlin_append(merlin_t *t, const char *label, const uint8_t *msg, size_t len) {
     merlin_append_raw(t, (const uint8_t *)label, strlen(label), msg, len);
 }
+void merlin_append_lbl(merlin_t *t, const uint8_t *label, size_t ll, const uint8_t *msg, size_t len) { merlin_append_raw(t, label, ll, msg, len); }
 void merlin_append_u64(merlin_t *t, const char *label, uint64_t x) {
     uint8_t b[8]; store64(b, x); merlin_append(t, label, b, 8);
 }

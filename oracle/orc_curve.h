@@ -88,6 +88,7 @@ void shake256_squeeze(shake256_ctx *c, uint8_t *out, size_t len);
 typedef struct { uint8_t st[200]; uint8_t pos, pos_begin, cur_flags; } merlin_t;
 void merlin_init(merlin_t *t, const uint8_t *label, size_t len);
 void merlin_append(merlin_t *t, const char *label, const uint8_t *msg, size_t len);
+void merlin_append_lbl(merlin_t *t, const uint8_t *label, size_t ll, const uint8_t *msg, size_t len);   /* labels that may contain NUL */
 void merlin_append_u64(merlin_t *t, const char *label, uint64_t x);
 void merlin_challenge_bytes(merlin_t *t, const char *label, uint8_t *out, size_t len);
 void merlin_challenge_scalar(merlin_t *t, const char *label, sc *out);

@@ -637,52 +637,65 @@ int orc_verify_rangeproof_l2(const uint8_t *proof, size_t proof_len, const uint8
     return ORC_OK;
 }
 
-/* ------------------------------------------------------------------ Sigma-proofs (rand_proof, square_rand_proof) */
+/* ------------------------------------------------------------------ Sigma-proofs (rand_proof, square_rand_proof, square_proof) */
+/* kind 0 RandProof       : commitments L|R       , proof L'|R'|Z_m|Z_r                    (rand_proof/mod.rs:31-85)
+ * kind 1 SquareRandProof : commitments L|R|c_sq  , proof L'|R'|c_sq'|Z_m|Z_r1|Z_r2        (square_rand_proof/mod.rs:41-151)
+ * kind 2 SquareProof     : commitments c_l|c_sq  , proof c_l'|c_sq'|Z_m|Z_r1|Z_r2          (square_proof/mod.rs, party.rs:14-151) */
 static void eg_bytes(uint8_t out[64], const ge *L, const ge *R) { ristretto_encode(out, L); ristretto_encode(out + 32, R); }
+static void sigma_layout(int kind, size_t *plen, size_t *clen, size_t *nn, int *has_R, int *has_sq) {
+    *has_R = kind != 2; *has_sq = kind != 0;
+    size_t npts = 1 + (size_t)*has_R + (size_t)*has_sq;
+    *clen = 32 * npts; *nn = *has_sq ? 3 : 2; *plen = 32 * (npts + *nn);
+}
+static void sigma_transcript(int kind, merlin_t *tr, const uint8_t *cm, const uint8_t *pf, int has_R) {
+    if (kind == 0) {
+        merlin_init(tr, (const uint8_t *)"RandProof", 9);
+        merlin_append(tr, "dom-sep", (const uint8_t *)"randomness proof v1", 19);
+        merlin_append(tr, "C", cm, 64); merlin_append(tr, "C_prime", pf, 64);
+        return;
+    }
+    size_t w = has_R ? 64 : 32;
+    if (kind == 1) merlin_init(tr, (const uint8_t *)"SquareRandProof", 15); else merlin_init(tr, (const uint8_t *)"SquareProof", 11);
+    merlin_append(tr, "dom-sep", (const uint8_t *)"randomness proof v1", 19);
+    merlin_append(tr, "C_eg", cm, w); merlin_append(tr, "C_ped", cm + w, 32);
+    merlin_append(tr, "C_prime_eg", pf, w); merlin_append(tr, "C_prime_ped", pf + w, 32);
+}
 
 int orc_sigma_create(int kind, const float *values, size_t d, const uint8_t *r1_32, size_t d_r1, const uint8_t *r2_32,
                      const uint8_t *existing32, unsigned fp_bits, unsigned fp_frac, const orc_nonce_t *ns,
                      uint8_t *proofs_out, uint8_t *commits_out) {
     orc_init();
     if (d != d_r1) return ORC_WRONG_NUM_BLINDING;        /* rand_proof_vec/mod.rs:18-20, square_rand_proof_vec/mod.rs:24-26 */
-    size_t plen = kind ? 192 : 128, clen = kind ? 96 : 64, nn = kind ? 3 : 2;
+    size_t plen, clen, nn; int has_R, has_sq;
+    sigma_layout(kind, &plen, &clen, &nn, &has_R, &has_sq);
+    size_t sq_off = has_R ? 64 : 32;
     for (size_t i = 0; i < d; i++) {
         sc m, r1, r2 = SC_ZERO, mp, r1p, r2p = SC_ZERO, c, t;
         int rc = f32_to_sc(values[i], fp_bits, fp_frac, &m);
         if (rc) return rc;
         sc_frombytes_modorder(&r1, r1_32 + 32 * i);
-        if (kind) sc_frombytes_modorder(&r2, r2_32 + 32 * i);
+        if (has_sq) sc_frombytes_modorder(&r2, r2_32 + 32 * i);
         ge L, R, Csq, Lp, Rp, Csqp, tmp;
-        if (existing32) { if (!ristretto_decode(&L, existing32 + 32 * i)) return ORC_FORMAT_ERROR; }   /* complete_existing */
-        else pedersen_commit(&L, &m, &r1);                                                               /* eg_gens.commit */
-        ge_scalarmult(&R, &r1, &GE_BASE);
+        if (existing32) { if (!ristretto_decode(&L, existing32 + 32 * i)) return ORC_FORMAT_ERROR; }   /* complete_existing / p_base = m_com */
+        else pedersen_commit(&L, &m, &r1);
         uint8_t *cm = commits_out + clen * i, *pf = proofs_out + plen * i;
-        eg_bytes(cm, &L, &R);
-        if (kind) { sc msq; sc_mul(&msq, &m, &m); pedersen_commit(&Csq, &msq, &r2); ristretto_encode(cm + 64, &Csq); }
+        ristretto_encode(cm, &L);
+        if (has_R) { ge_scalarmult(&R, &r1, &GE_BASE); ristretto_encode(cm + 32, &R); }
+        if (has_sq) { sc msq; sc_mul(&msq, &m, &m); pedersen_commit(&Csq, &msq, &r2); ristretto_encode(cm + sq_off, &Csq); }
         /* nonce draw order: m', r1' (, r2') -- party.rs:43-45 / rand_proof/party.rs:23-24 */
-        nonce_get(ns, nn * i, &mp); nonce_get(ns, nn * i + 1, &r1p); if (kind) nonce_get(ns, nn * i + 2, &r2p);
-        pedersen_commit(&Lp, &mp, &r1p); ge_scalarmult(&Rp, &r1p, &GE_BASE);
-        eg_bytes(pf, &Lp, &Rp);
-        if (kind) {   /* c_sq' = m' * c_eg.L + r2' * B_blinding */
+        nonce_get(ns, nn * i, &mp); nonce_get(ns, nn * i + 1, &r1p); if (has_sq) nonce_get(ns, nn * i + 2, &r2p);
+        pedersen_commit(&Lp, &mp, &r1p); ristretto_encode(pf, &Lp);
+        if (has_R) { ge_scalarmult(&Rp, &r1p, &GE_BASE); ristretto_encode(pf + 32, &Rp); }
+        if (has_sq) {   /* c_sq' = m' * c.L + r2' * B_blinding */
             ge_scalarmult(&Csqp, &mp, &L); ge_scalarmult(&tmp, &r2p, &GE_BBLIND); ge_add(&Csqp, &Csqp, &tmp);
-            ristretto_encode(pf + 64, &Csqp);
+            ristretto_encode(pf + sq_off, &Csqp);
         }
-        merlin_t tr;
-        if (kind) {
-            merlin_init(&tr, (const uint8_t *)"SquareRandProof", 15);
-            merlin_append(&tr, "dom-sep", (const uint8_t *)"randomness proof v1", 19);
-            merlin_append(&tr, "C_eg", cm, 64); merlin_append(&tr, "C_ped", cm + 64, 32);
-            merlin_append(&tr, "C_prime_eg", pf, 64); merlin_append(&tr, "C_prime_ped", pf + 64, 32);
-        } else {
-            merlin_init(&tr, (const uint8_t *)"RandProof", 9);
-            merlin_append(&tr, "dom-sep", (const uint8_t *)"randomness proof v1", 19);
-            merlin_append(&tr, "C", cm, 64); merlin_append(&tr, "C_prime", pf, 64);
-        }
+        merlin_t tr; sigma_transcript(kind, &tr, cm, pf, has_R);
         merlin_challenge_scalar(&tr, "c", &c);
-        uint8_t *z = pf + (kind ? 96 : 64);
+        uint8_t *z = pf + clen;
         sc_mul(&t, &m, &c); sc_add(&t, &t, &mp); sc_tobytes(z, &t);                    /* z_m = m' + m c */
         sc_mul(&t, &r1, &c); sc_add(&t, &t, &r1p); sc_tobytes(z + 32, &t);             /* z_r1 = r1' + r1 c */
-        if (kind) { sc u; sc_mul(&u, &m, &r1); sc_sub(&u, &r2, &u); sc_mul(&u, &u, &c); sc_add(&u, &u, &r2p); sc_tobytes(z + 64, &u); }
+        if (has_sq) { sc u; sc_mul(&u, &m, &r1); sc_sub(&u, &r2, &u); sc_mul(&u, &u, &c); sc_add(&u, &u, &r2p); sc_tobytes(z + 64, &u); }
     }
     return ORC_OK;
 }
@@ -690,36 +703,26 @@ int orc_sigma_create(int kind, const float *values, size_t d, const uint8_t *r1_
 int orc_sigma_verify(int kind, const uint8_t *proofs, const uint8_t *commits, size_t d, int *ok) {
     orc_init();
     *ok = 0;
-    size_t plen = kind ? 192 : 128, clen = kind ? 96 : 64;
+    size_t plen, clen, nn; int has_R, has_sq;
+    sigma_layout(kind, &plen, &clen, &nn, &has_R, &has_sq);
+    size_t sq_off = has_R ? 64 : 32;
     int all = 1;
     for (size_t i = 0; i < d; i++) {
-        const uint8_t *pf = proofs + plen * i, *cm = commits + clen * i, *z = pf + (kind ? 96 : 64);
+        const uint8_t *pf = proofs + plen * i, *cm = commits + clen * i, *z = pf + clen;
         ge L, R, Csq, Lp, Rp, Csqp;
         sc zm, zr1, zr2 = SC_ZERO, c;
-        if (!ristretto_decode(&L, cm) || !ristretto_decode(&R, cm + 32) || !ristretto_decode(&Lp, pf) || !ristretto_decode(&Rp, pf + 32)) return ORC_FORMAT_ERROR;
-        if (kind && (!ristretto_decode(&Csq, cm + 64) || !ristretto_decode(&Csqp, pf + 64))) return ORC_FORMAT_ERROR;
+        if (!ristretto_decode(&L, cm) || !ristretto_decode(&Lp, pf)) return ORC_FORMAT_ERROR;
+        if (has_R && (!ristretto_decode(&R, cm + 32) || !ristretto_decode(&Rp, pf + 32))) return ORC_FORMAT_ERROR;
+        if (has_sq && (!ristretto_decode(&Csq, cm + sq_off) || !ristretto_decode(&Csqp, pf + sq_off))) return ORC_FORMAT_ERROR;
         if (!sc_frombytes_canonical(&zm, z) || !sc_frombytes_canonical(&zr1, z + 32)) return ORC_FORMAT_ERROR;
-        if (kind && !sc_frombytes_canonical(&zr2, z + 64)) return ORC_FORMAT_ERROR;
-        merlin_t tr;
-        if (kind) {
-            merlin_init(&tr, (const uint8_t *)"SquareRandProof", 15);
-            merlin_append(&tr, "dom-sep", (const uint8_t *)"randomness proof v1", 19);
-            merlin_append(&tr, "C_eg", cm, 64); merlin_append(&tr, "C_ped", cm + 64, 32);
-            merlin_append(&tr, "C_prime_eg", pf, 64); merlin_append(&tr, "C_prime_ped", pf + 64, 32);
-        } else {
-            merlin_init(&tr, (const uint8_t *)"RandProof", 9);
-            merlin_append(&tr, "dom-sep", (const uint8_t *)"randomness proof v1", 19);
-            merlin_append(&tr, "C", cm, 64); merlin_append(&tr, "C_prime", pf, 64);
-        }
+        if (has_sq && !sc_frombytes_canonical(&zr2, z + 64)) return ORC_FORMAT_ERROR;
+        merlin_t tr; sigma_transcript(kind, &tr, cm, pf, has_R);
         merlin_challenge_scalar(&tr, "c", &c);
         ge lhs, rhs, t;
-        /* dst = eg_gens.commit(Z_m, Z_r1) ; src = C' + c * C */
-        pedersen_commit(&lhs, &zm, &zr1); ge_scalarmult(&t, &c, &L); ge_add(&rhs, &Lp, &t);
-        int e1 = ge_eq_ristretto(&lhs, &rhs);
-        ge_scalarmult(&lhs, &zr1, &GE_BASE); ge_scalarmult(&t, &c, &R); ge_add(&rhs, &Rp, &t);
-        int e2 = ge_eq_ristretto(&lhs, &rhs);
-        int e3 = 1;
-        if (kind) {   /* Z_m * C.L + Z_r2 * B_blinding == c_sq' + c * c_sq */
+        pedersen_commit(&lhs, &zm, &zr1); ge_scalarmult(&t, &c, &L); ge_add(&rhs, &Lp, &t);       /* commit(Z_m, Z_r1) == C'.L + c C.L */
+        int e1 = ge_eq_ristretto(&lhs, &rhs), e2 = 1, e3 = 1;
+        if (has_R) { ge_scalarmult(&lhs, &zr1, &GE_BASE); ge_scalarmult(&t, &c, &R); ge_add(&rhs, &Rp, &t); e2 = ge_eq_ristretto(&lhs, &rhs); }
+        if (has_sq) {   /* Z_m * C.L + Z_r2 * B_blinding == c_sq' + c * c_sq */
             ge_scalarmult(&lhs, &zm, &L); ge_scalarmult(&t, &zr2, &GE_BBLIND); ge_add(&lhs, &lhs, &t);
             ge_scalarmult(&t, &c, &Csq); ge_add(&rhs, &Csqp, &t);
             e3 = ge_eq_ristretto(&lhs, &rhs);
@@ -727,5 +730,69 @@ int orc_sigma_verify(int kind, const uint8_t *proofs, const uint8_t *commits, si
         all &= e1 & e2 & e3;
     }
     *ok = all;
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------------------ compressed_rand_proof (mod.rs:43-102, party.rs:54-100, dealer.rs)
+ * ONE proof for all d ElGamal pairs: z_m = m' + sum m_i c^(i+1), z_r likewise; transcript label "CompressedRandProof",
+ * pair i appended under the 3-byte label UNIQUE_U8_TRIPLETS[i] = [(3i)%256, (3i+1)%256, (3i+2)%256]
+ * (generate_unique_u8_triplets.py:8-13; the 900 000-entry table itself is a missing large blob of the reference). */
+static void compressed_transcript(merlin_t *tr, const uint8_t *pairs, size_t d, const uint8_t cprime[64], sc *c) {
+    merlin_init(tr, (const uint8_t *)"CompressedRandProof", 19);
+    merlin_append(tr, "dom-sep", (const uint8_t *)"randomness proof v1", 19);
+    for (size_t i = 0; i < d; i++) {
+        uint8_t lbl[3] = {(uint8_t)(3 * i), (uint8_t)(3 * i + 1), (uint8_t)(3 * i + 2)};
+        merlin_append_lbl(tr, lbl, 3, pairs + 64 * i, 64);
+    }
+    merlin_append(tr, "C_prime_eg", cprime, 64);
+    merlin_challenge_scalar(tr, "c", c);
+}
+int orc_compressed_create(const float *values, size_t d, const uint8_t *r32, size_t d_r, const uint8_t *existing32,
+                          unsigned fp_bits, unsigned fp_frac, const orc_nonce_t *ns, uint8_t proof_out[128], uint8_t *pairs_out) {
+    orc_init();
+    if (d != d_r) return ORC_WRONG_NUM_BLINDING;
+    if (d >= 900000) return ORC_BAD_PARAM;                      /* label table size */
+    sc *m = malloc(sizeof(sc) * (d ? d : 1)), *r = malloc(sizeof(sc) * (d ? d : 1));
+    for (size_t i = 0; i < d; i++) {
+        int rc = f32_to_sc(values[i], fp_bits, fp_frac, &m[i]);
+        if (rc) { free(m); free(r); return rc; }
+        sc_frombytes_modorder(&r[i], r32 + 32 * i);
+        ge L, R;
+        if (existing32) { if (!ristretto_decode(&L, existing32 + 32 * i)) { free(m); free(r); return ORC_FORMAT_ERROR; } }
+        else pedersen_commit(&L, &m[i], &r[i]);
+        ge_scalarmult(&R, &r[i], &GE_BASE);
+        eg_bytes(pairs_out + 64 * i, &L, &R);
+    }
+    sc mp, rp, c; nonce_get(ns, 0, &mp); nonce_get(ns, 1, &rp);
+    ge Lp, Rp; pedersen_commit(&Lp, &mp, &rp); ge_scalarmult(&Rp, &rp, &GE_BASE);
+    eg_bytes(proof_out, &Lp, &Rp);
+    merlin_t tr; compressed_transcript(&tr, pairs_out, d, proof_out, &c);
+    sc zm = mp, zr = rp, pw = c, t;
+    for (size_t i = 0; i < d; i++) { sc_mul(&t, &m[i], &pw); sc_add(&zm, &zm, &t); sc_mul(&t, &r[i], &pw); sc_add(&zr, &zr, &t); sc_mul(&pw, &pw, &c); }
+    sc_tobytes(proof_out + 64, &zm); sc_tobytes(proof_out + 96, &zr);
+    free(m); free(r);
+    return ORC_OK;
+}
+int orc_compressed_verify(const uint8_t proof[128], const uint8_t *pairs, size_t d, int *ok) {
+    orc_init();
+    *ok = 0;
+    ge Lp, Rp; sc zm, zr, c;
+    if (!ristretto_decode(&Lp, proof) || !ristretto_decode(&Rp, proof + 32)) return ORC_FORMAT_ERROR;
+    if (!sc_frombytes_canonical(&zm, proof + 64) || !sc_frombytes_canonical(&zr, proof + 96)) return ORC_FORMAT_ERROR;
+    if (d >= 900000) return ORC_BAD_PARAM;
+    size_t n = d ? d : 1;
+    ge *Ls = malloc(sizeof(ge) * n), *Rs = malloc(sizeof(ge) * n); sc *pw = malloc(sizeof(sc) * n);
+    for (size_t i = 0; i < d; i++)
+        if (!ristretto_decode(&Ls[i], pairs + 64 * i) || !ristretto_decode(&Rs[i], pairs + 64 * i + 32)) { free(Ls); free(Rs); free(pw); return ORC_FORMAT_ERROR; }
+    merlin_t tr; compressed_transcript(&tr, pairs, d, proof, &c);
+    sc p = c; for (size_t i = 0; i < d; i++) { pw[i] = p; sc_mul(&p, &p, &c); }
+    ge sL, sR, lhs, rhs;
+    ge_msm(&sL, pw, Ls, d); ge_msm(&sR, pw, Rs, d);
+    pedersen_commit(&lhs, &zm, &zr); ge_add(&rhs, &Lp, &sL);
+    int e1 = ge_eq_ristretto(&lhs, &rhs);
+    ge_scalarmult(&lhs, &zr, &GE_BASE); ge_add(&rhs, &Rp, &sR);
+    int e2 = ge_eq_ristretto(&lhs, &rhs);
+    *ok = e1 & e2;
+    free(Ls); free(Rs); free(pw);
     return ORC_OK;
 }

@@ -124,5 +124,10 @@ int orc_sigma_create(int kind, const float *values, size_t d, const uint8_t *r1_
                      const uint8_t *existing32, unsigned fp_bits, unsigned fp_frac, const orc_nonce_t *ns,
                      uint8_t *proofs_out, uint8_t *commits_out);
 int orc_sigma_verify(int kind, const uint8_t *proofs, const uint8_t *commits, size_t d, int *ok);
+/* kind 2: SquareProof (square_proof/mod.rs): commitments c_l|c_sq (64 B), proof 160 B */
+/* compressed_rand_proof/mod.rs:43-102: one 128-byte proof for d ElGamal pairs (d*64 B) */
+int orc_compressed_create(const float *values, size_t d, const uint8_t *r32, size_t d_r, const uint8_t *existing32,
+                          unsigned fp_bits, unsigned fp_frac, const orc_nonce_t *ns, uint8_t proof_out[128], uint8_t *pairs_out);
+int orc_compressed_verify(const uint8_t proof[128], const uint8_t *pairs, size_t d, int *ok);
 #endif
 #endif

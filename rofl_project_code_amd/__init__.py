@@ -7,6 +7,6 @@ missing or no HIP device is present the calls fail loudly.
 """
 from . import api  # noqa: F401
 from .api import (  # noqa: F401
-    RoflError, Nonce, lib, range_proof_vec, l2_range_proof_vec, pedersen_ops, conversion32, rand_proof_vec, square_rand_proof_vec,
+    RoflError, Nonce, lib, range_proof_vec, l2_range_proof_vec, pedersen_ops, conversion32, rand_proof_vec, square_rand_proof_vec, square_proof_vec, compressed_rand_proof,
     set_device, last_timing, set_timing, bench_femul,
 )

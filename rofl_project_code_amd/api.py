@@ -291,6 +291,70 @@ class square_rand_proof_vec:
         return bool(ok.value)
 
 
+class square_proof_vec:
+    """square_proof_vec/mod.rs:18-159.  proofs uint8[d,160], commitments uint8[d,64] (c_l | c_sq)."""
+
+    @staticmethod
+    def create_l2rangeproof_vec(values, random_vec, random_vec_2, nonce=None, existing=None):
+        v = np.ascontiguousarray(values, dtype=np.float32)
+        r1, r2 = _u8(random_vec), _u8(random_vec_2)
+        nonce = nonce or Nonce.random()
+        ns = nonce._struct()
+        d = v.size
+        proofs = np.zeros((max(d, 1), 160), dtype=np.uint8)
+        commits = np.zeros((max(d, 1), 64), dtype=np.uint8)
+        ex = None if existing is None else _u8(existing)
+        _check(lib().rofl_create_squareproof_vec(_ptr(v), _sz(d), _ptr(r1), _sz(r1.shape[0] if r1.size else 0), _ptr(r2),
+                                                 None if ex is None else _ptr(ex), _FpConfig.fp_bits, _FpConfig.fp_frac,
+                                                 ctypes.byref(ns), _ptr(proofs), _ptr(commits)))
+        return proofs[:d], commits[:d]
+
+    @staticmethod
+    def create_l2rangeproof_vec_existing(values, existing, random_vec, random_vec_2, nonce=None):
+        return square_proof_vec.create_l2rangeproof_vec(values, random_vec, random_vec_2, nonce=nonce, existing=existing)
+
+    @staticmethod
+    def verify_l2rangeproof_vec(proofs, commits):
+        p = np.ascontiguousarray(proofs, dtype=np.uint8).reshape(-1, 160)
+        c = np.ascontiguousarray(commits, dtype=np.uint8).reshape(-1, 64)
+        if p.shape[0] != c.shape[0]:
+            raise RoflError(1, "WrongNumberOfElGamalPairs")
+        ok = ctypes.c_int()
+        _check(lib().rofl_verify_squareproof_vec(_ptr(p), _ptr(c), _sz(p.shape[0]), ctypes.byref(ok)))
+        return bool(ok.value)
+
+
+class compressed_rand_proof:
+    """compressed_rand_proof/mod.rs:134-160 (CompressedRandProof::helper_prove / helper_prove_existing / helper_verify).
+    proof uint8[128], ElGamal pairs uint8[d,64]."""
+
+    @staticmethod
+    def helper_prove(values, r_vec, nonce=None, existing=None):
+        v = np.ascontiguousarray(values, dtype=np.float32)
+        r = _u8(r_vec)
+        nonce = nonce or Nonce.random()
+        ns = nonce._struct()
+        d = v.size
+        proof = np.zeros(128, dtype=np.uint8)
+        pairs = np.zeros((max(d, 1), 64), dtype=np.uint8)
+        ex = None if existing is None else _u8(existing)
+        _check(lib().rofl_create_compressed_randproof(_ptr(v), _sz(d), _ptr(r), _sz(r.shape[0] if r.size else 0), None if ex is None else _ptr(ex),
+                                                      _FpConfig.fp_bits, _FpConfig.fp_frac, ctypes.byref(ns), _ptr(proof), _ptr(pairs)))
+        return proof, pairs[:d]
+
+    @staticmethod
+    def helper_prove_existing(values, m_com, r_vec, nonce=None):
+        return compressed_rand_proof.helper_prove(values, r_vec, nonce=nonce, existing=m_com)
+
+    @staticmethod
+    def helper_verify(proof, pairs):
+        p = np.ascontiguousarray(proof, dtype=np.uint8).reshape(128)
+        c = np.ascontiguousarray(pairs, dtype=np.uint8).reshape(-1, 64)
+        ok = ctypes.c_int()
+        _check(lib().rofl_verify_compressed_randproof(_ptr(p), _ptr(c), _sz(c.shape[0]), ctypes.byref(ok)))
+        return bool(ok.value)
+
+
 class pedersen_ops:
     @staticmethod
     def commit_vec(scalars, blindings):

@@ -128,6 +128,10 @@ struct Merlin {
         meta_ad(le, 4, true);
         ad(msg, len, false);
     }
+    void append_lbl(const uint8_t *label, size_t ll, const uint8_t *msg, size_t len) {     // labels that may contain NUL bytes
+        uint8_t le[4] = {(uint8_t)len, (uint8_t)(len >> 8), (uint8_t)(len >> 16), (uint8_t)(len >> 24)};
+        meta_ad(label, ll, false); meta_ad(le, 4, true); ad(msg, len, false);
+    }
     void append_u64(const char *label, u64 x) { uint8_t b[8]; memcpy(b, &x, 8); append(label, b, 8); }
     void append_scalar(const char *label, const sc &s) { uint8_t b[32]; sc_tobytes(b, s); append(label, b, 32); }
     void challenge_bytes(const char *label, uint8_t *out, size_t len) {

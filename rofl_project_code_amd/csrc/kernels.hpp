@@ -876,80 +876,131 @@ __device__ inline void sg_encode(uint8_t *out, const gd &p) { ristretto_encode(o
 __device__ inline bool sg_decode(gd &p, const uint8_t *in) { ge t; bool ok = ristretto_decode(t, in); p = gd_unpack(ok ? t : ge_identity()); return ok; }
 __device__ inline bool sg_is_identity(const gd &p) { ge t = gd_pack(p); return ge_is_identity_ristretto(t); }
 
+// kind 0 RandProof (L|R ; L'|R'|Zm|Zr), 1 SquareRandProof (L|R|c_sq ; L'|R'|c_sq'|Zm|Zr1|Zr2), 2 SquareProof (c_l|c_sq ; c_l'|c_sq'|Zm|Zr1|Zr2)
+__device__ inline void sg_transcript(int kind, DMerlin &t, const uint8_t *cm, const uint8_t *pf, bool has_R) {
+    if (kind == 0) { dm_append(t, "C", 1, cm, 64); dm_append(t, "C_prime", 7, pf, 64); return; }
+    u32 w = has_R ? 64 : 32;
+    dm_append(t, "C_eg", 4, cm, w); dm_append(t, "C_ped", 5, cm + w, 32); dm_append(t, "C_prime_eg", 10, pf, w); dm_append(t, "C_prime_ped", 11, pf + w, 32);
+}
+__device__ inline sc sg_f32_to_sc(float v, u32 fp_bits, u32 fp_frac) {     // conversion32.rs:11-18
+    double x = fabs((double)v) * (double)(1ULL << fp_frac), lim = ldexp(1.0, (int)fp_bits);
+    u64 maxbits = fp_bits >= 64 ? ~0ULL : ((1ULL << fp_bits) - 1), kq;
+    if (x >= lim) kq = maxbits; else { double r = rint(x); kq = (r >= lim) ? maxbits : (u64)r; }
+    sc m = sc_from_u64(kq); if (v < 0.0f) m = sc_neg(m);
+    return m;
+}
+__device__ inline sc sg_nonce(int mode, const NonceSeed &seed, const uint8_t *stream, u64 stream_scalars, u64 idx) {
+    sc lo, hi;
+    if (mode == 1) {
+        const u64 dom[2] = {0x2f6b7a2d6c666f72ULL, 0x31762f65636e6f6eULL};
+        u64 st[25]; shake256_seeded_block(st, dom, seed.w, idx);
+#pragma unroll
+        for (int q = 0; q < 4; q++) { lo.v[2 * q] = (u32)st[q]; lo.v[2 * q + 1] = (u32)(st[q] >> 32); hi.v[2 * q] = (u32)st[4 + q]; hi.v[2 * q + 1] = (u32)(st[4 + q] >> 32); }
+    } else if (idx < stream_scalars) {
+        const u32 *s = reinterpret_cast<const u32 *>(stream + idx * 64);
+#pragma unroll
+        for (int q = 0; q < 8; q++) { lo.v[q] = s[q]; hi.v[q] = s[8 + q]; }
+    } else { lo = sc_zero(); hi = sc_zero(); }
+    return sc_from_wide(lo, hi);
+}
 __global__ void __launch_bounds__(64) k_sigma_prove(int kind, u32 d, const float *vals, u32 fp_bits, u32 fp_frac, const sc *r1c, const sc *r2c,
                                                     const uint8_t *existing, int mode, NonceSeed seed, const uint8_t *stream, u64 stream_scalars,
                                                     DMerlin init, const niels *tabB, const niels *tabBb, uint8_t *proofs, uint8_t *commits, u32 *status) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= d) return;
-    u32 plen = kind ? 192 : 128, clen = kind ? 96 : 64, nn = kind ? 3 : 2;
+    bool has_R = kind != 2, has_sq = kind != 0;
+    u32 npts = 1 + (has_R ? 1 : 0) + (has_sq ? 1 : 0), nn = has_sq ? 3 : 2, clen = 32 * npts, plen = 32 * (npts + nn), sq_off = has_R ? 64 : 32;
     float v = vals[i];
     if (v != v) { atomicOr(status, 2u); return; }
-    // conversion32.rs:11-18
-    double x = fabs((double)v) * (double)(1ULL << fp_frac), lim = ldexp(1.0, (int)fp_bits);
-    u64 maxbits = fp_bits >= 64 ? ~0ULL : ((1ULL << fp_bits) - 1), kq;
-    if (x >= lim) kq = maxbits; else { double r = rint(x); kq = (r >= lim) ? maxbits : (u64)r; }
-    sc m = sc_from_u64(kq); if (v < 0.0f) m = sc_neg(m);
-    sc r1 = load_sc(&r1c[i]), r2 = kind ? load_sc(&r2c[i]) : sc_zero();
-    // nonces m', r1' (, r2')
+    sc m = sg_f32_to_sc(v, fp_bits, fp_frac);
+    sc r1 = load_sc(&r1c[i]), r2 = has_sq ? load_sc(&r2c[i]) : sc_zero();
     sc nc[3];
-    for (u32 j = 0; j < nn; j++) {
-        u64 idx = (u64)nn * i + j; sc lo, hi;
-        if (mode == 1) {
-            const u64 dom[2] = {0x2f6b7a2d6c666f72ULL, 0x31762f65636e6f6eULL};
-            u64 st[25]; shake256_seeded_block(st, dom, seed.w, idx);
-#pragma unroll
-            for (int q = 0; q < 4; q++) { lo.v[2 * q] = (u32)st[q]; lo.v[2 * q + 1] = (u32)(st[q] >> 32); hi.v[2 * q] = (u32)st[4 + q]; hi.v[2 * q + 1] = (u32)(st[4 + q] >> 32); }
-        } else if (idx < stream_scalars) {
-            const u32 *s = reinterpret_cast<const u32 *>(stream + idx * 64);
-#pragma unroll
-            for (int q = 0; q < 8; q++) { lo.v[q] = s[q]; hi.v[q] = s[8 + q]; }
-        } else { lo = sc_zero(); hi = sc_zero(); }
-        nc[j] = sc_from_wide(lo, hi);
-    }
+    for (u32 j = 0; j < nn; j++) nc[j] = sg_nonce(mode, seed, stream, stream_scalars, (u64)nn * i + j);   // m', r1' (, r2')
     uint8_t *cm = commits + (size_t)clen * i, *pf = proofs + (size_t)plen * i;
     gd L;
     if (existing) { if (!sg_decode(L, existing + (size_t)32 * i)) { atomicOr(status, 4u); return; } for (int q = 0; q < 32; q++) cm[q] = existing[(size_t)32 * i + q]; }
     else { L = gd_add(sg_fixed_mul(tabB, m), sg_fixed_mul(tabBb, r1)); sg_encode(cm, L); }
-    sg_encode(cm + 32, sg_fixed_mul(tabB, r1));
-    if (kind) { sc msq = sc_mul_plain(m, m); sg_encode(cm + 64, gd_add(sg_fixed_mul(tabB, msq), sg_fixed_mul(tabBb, r2))); }
+    if (has_R) sg_encode(cm + 32, sg_fixed_mul(tabB, r1));
+    if (has_sq) { sc msq = sc_mul_plain(m, m); sg_encode(cm + sq_off, gd_add(sg_fixed_mul(tabB, msq), sg_fixed_mul(tabBb, r2))); }
     sg_encode(pf, gd_add(sg_fixed_mul(tabB, nc[0]), sg_fixed_mul(tabBb, nc[1])));
-    sg_encode(pf + 32, sg_fixed_mul(tabB, nc[1]));
-    if (kind) sg_encode(pf + 64, gd_add(sg_var_mul(nc[0], L), sg_fixed_mul(tabBb, nc[2])));
+    if (has_R) sg_encode(pf + 32, sg_fixed_mul(tabB, nc[1]));
+    if (has_sq) sg_encode(pf + sq_off, gd_add(sg_var_mul(nc[0], L), sg_fixed_mul(tabBb, nc[2])));
     DMerlin t = init;
-    if (kind) { dm_append(t, "C_eg", 4, cm, 64); dm_append(t, "C_ped", 5, cm + 64, 32); dm_append(t, "C_prime_eg", 10, pf, 64); dm_append(t, "C_prime_ped", 11, pf + 64, 32); }
-    else { dm_append(t, "C", 1, cm, 64); dm_append(t, "C_prime", 7, pf, 64); }
+    sg_transcript(kind, t, cm, pf, has_R);
     sc c = dm_challenge_scalar(t, "c", 1);
-    uint8_t *z = pf + (kind ? 96 : 64);
+    uint8_t *z = pf + clen;
     sc_tobytes(z, sc_add(nc[0], sc_mul_plain(m, c)));
     sc_tobytes(z + 32, sc_add(nc[1], sc_mul_plain(r1, c)));
-    if (kind) sc_tobytes(z + 64, sc_add(nc[2], sc_mul_plain(sc_sub(r2, sc_mul_plain(m, r1)), c)));
+    if (has_sq) sc_tobytes(z + 64, sc_add(nc[2], sc_mul_plain(sc_sub(r2, sc_mul_plain(m, r1)), c)));
 }
 
 __global__ void __launch_bounds__(64) k_sigma_verify(int kind, u32 d, const uint8_t *proofs, const uint8_t *commits, DMerlin init,
                                                      const niels *tabB, const niels *tabBb, u32 *fail_count, u32 *status) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= d) return;
-    u32 plen = kind ? 192 : 128, clen = kind ? 96 : 64;
-    const uint8_t *pf = proofs + (size_t)plen * i, *cm = commits + (size_t)clen * i, *z = pf + (kind ? 96 : 64);
+    bool has_R = kind != 2, has_sq = kind != 0;
+    u32 npts = 1 + (has_R ? 1 : 0) + (has_sq ? 1 : 0), nn = has_sq ? 3 : 2, clen = 32 * npts, plen = 32 * (npts + nn), sq_off = has_R ? 64 : 32;
+    const uint8_t *pf = proofs + (size_t)plen * i, *cm = commits + (size_t)clen * i, *z = pf + clen;
     gd L, R, Csq, Lp, Rp, Csqp;
-    bool okd = sg_decode(L, cm) & sg_decode(R, cm + 32) & sg_decode(Lp, pf) & sg_decode(Rp, pf + 32);
-    if (kind) okd = okd & sg_decode(Csq, cm + 64) & sg_decode(Csqp, pf + 64);
-    sc zm = sc_frombytes(z), zr1 = sc_frombytes(z + 32), zr2 = kind ? sc_frombytes(z + 64) : sc_zero();
+    bool okd = sg_decode(L, cm) & sg_decode(Lp, pf);
+    if (has_R) okd = okd & sg_decode(R, cm + 32) & sg_decode(Rp, pf + 32);
+    if (has_sq) okd = okd & sg_decode(Csq, cm + sq_off) & sg_decode(Csqp, pf + sq_off);
+    sc zm = sc_frombytes(z), zr1 = sc_frombytes(z + 32), zr2 = has_sq ? sc_frombytes(z + 64) : sc_zero();
     if (!okd || sc_geq_l(zm.v) || sc_geq_l(zr1.v) || sc_geq_l(zr2.v)) { atomicOr(status, 4u); return; }
     DMerlin t = init;
-    if (kind) { dm_append(t, "C_eg", 4, cm, 64); dm_append(t, "C_ped", 5, cm + 64, 32); dm_append(t, "C_prime_eg", 10, pf, 64); dm_append(t, "C_prime_ped", 11, pf + 64, 32); }
-    else { dm_append(t, "C", 1, cm, 64); dm_append(t, "C_prime", 7, pf, 64); }
+    sg_transcript(kind, t, cm, pf, has_R);
     sc c = dm_challenge_scalar(t, "c", 1);
     sc cneg = sc_neg(c);
     // Z_m B + Z_r1 Bb - c C.L - C'.L == 0 ;  Z_r1 B - c C.R - C'.R == 0
     gd e1 = gd_add(gd_add(sg_fixed_mul(tabB, zm), sg_fixed_mul(tabBb, zr1)), gd_add(sg_var_mul(cneg, L), gd_neg(Lp)));
-    gd e2 = gd_add(sg_fixed_mul(tabB, zr1), gd_add(sg_var_mul(cneg, R), gd_neg(Rp)));
-    bool ok = sg_is_identity(e1) & sg_is_identity(e2);
-    if (kind) {   // Z_m C.L + Z_r2 Bb - c c_sq - c_sq' == 0
+    bool ok = sg_is_identity(e1);
+    if (has_R) { gd e2 = gd_add(sg_fixed_mul(tabB, zr1), gd_add(sg_var_mul(cneg, R), gd_neg(Rp))); ok = ok & sg_is_identity(e2); }
+    if (has_sq) {   // Z_m C.L + Z_r2 Bb - c c_sq - c_sq' == 0
         gd e3 = gd_add(gd_add(sg_var_mul(zm, L), sg_fixed_mul(tabBb, zr2)), gd_add(sg_var_mul(cneg, Csq), gd_neg(Csqp)));
         ok = ok & sg_is_identity(e3);
     }
     if (!ok) atomicAdd(fail_count, 1u);
+}
+
+// ---- compressed_rand_proof: the d ElGamal pairs, the challenge-power dot products, the verification scalars
+__global__ void __launch_bounds__(64) k_eg_pairs(u32 d, const float *vals, u32 fp_bits, u32 fp_frac, const sc *rc, const uint8_t *existing,
+                                                 const niels *tabB, const niels *tabBb, uint8_t *pairs, u32 *status) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d) return;
+    float v = vals[i];
+    if (v != v) { atomicOr(status, 2u); return; }
+    sc m = sg_f32_to_sc(v, fp_bits, fp_frac), r = load_sc(&rc[i]);
+    uint8_t *o = pairs + (size_t)64 * i;
+    if (existing) { gd L; if (!sg_decode(L, existing + (size_t)32 * i)) { atomicOr(status, 4u); return; } for (int q = 0; q < 32; q++) o[q] = existing[(size_t)32 * i + q]; }
+    else sg_encode(o, gd_add(sg_fixed_mul(tabB, m), sg_fixed_mul(tabBb, r)));
+    sg_encode(o + 32, sg_fixed_mul(tabB, r));
+}
+// partial sums of m_i c^(i+1) and r_i c^(i+1)  -> out[blk][2] (Montgomery);  cpow2[b] = c^(2^b) (Montgomery)
+struct CPow { sc sq[MAX_LG]; };
+__global__ void __launch_bounds__(TPB) k_cpow_dot(u32 d, const float *vals, u32 fp_bits, u32 fp_frac, const sc *rc, CPow cp, sc *out) {
+    __shared__ sc lds[TPB * 2];
+    sc v[2] = {sc_zero(), sc_zero()};
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < d; i += gridDim.x * blockDim.x) {
+        sc p = sc_pow_tab(cp.sq, i + 1);
+        sc m = sc_to_mont(sg_f32_to_sc(vals[i], fp_bits, fp_frac)), r = sc_to_mont(load_sc(&rc[i]));
+        v[0] = sc_add(v[0], sc_montmul(m, p)); v[1] = sc_add(v[1], sc_montmul(r, p));
+    }
+    block_sum_sc<2>(v, lds);
+    if (threadIdx.x == 0) { store_sc(&out[blockIdx.x * 2], v[0]); store_sc(&out[blockIdx.x * 2 + 1], v[1]); }
+}
+__global__ void __launch_bounds__(TPB) k_cpow_scalars(u32 d, CPow cp, sc *out_canon) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d) return;
+    store_sc(&out_canon[i], sc_from_mont(sc_pow_tab(cp.sq, i + 1)));
+}
+// de-interleave and decode d ElGamal pairs into two niels arrays
+__global__ void __launch_bounds__(TPB) k_decode_pairs(u32 d, const uint8_t *pairs, niels *Ls, niels *Rs, u32 *status) {
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 2 * d) return;
+    u32 i = t >> 1, which = t & 1;
+    ge p;
+    if (!ristretto_decode(p, pairs + (size_t)64 * i + 32 * which)) { atomicOr(status, 4u); p = ge_identity(); }
+    store_niels(which ? &Rs[i] : &Ls[i], ge_to_niels(p));
 }
 
 // ================================================================ micro-benchmark: field multiply rate

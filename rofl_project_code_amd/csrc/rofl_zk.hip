@@ -1144,7 +1144,8 @@ int rofl_verify_rangeproof_l2(const uint8_t *proof, size_t proof_len, const uint
 
 namespace {
 DMerlin sigma_init_state(int kind) {
-    Merlin t(kind ? "SquareRandProof" : "RandProof", kind ? 15 : 9);
+    const char *lbl = kind == 0 ? "RandProof" : (kind == 1 ? "SquareRandProof" : "SquareProof");
+    Merlin t(lbl, strlen(lbl));
     // rand_proof_domain_sep (rand_proof/transcript.rs:20-22) -- but the begin_op of the NEXT append depends on pos_begin,
     // so the whole state (bytes, pos, pos_begin) is handed to the kernel
     t.append("dom-sep", (const uint8_t *)"randomness proof v1", 19);
@@ -1157,18 +1158,19 @@ int sigma_create(int kind, const float *values, size_t d, const uint8_t *r1, siz
     if (d != d_r1) return fail(ROFL_WRONG_NUM_BLINDING, "WrongNumBlindingFactors");
     if (!valid_fp(fp_bits, fp_frac) || !nonce) return fail(ROFL_BAD_PARAM, "bad parameter");
     if (d == 0) return ROFL_OK;
-    size_t plen = kind ? 192 : 128, clen = kind ? 96 : 64, nn = kind ? 3 : 2;
+    bool has_sq = kind != 0;
+    size_t npts = 1 + (kind != 2) + (has_sq ? 1 : 0), nn = has_sq ? 3 : 2, clen = 32 * npts, plen = 32 * (npts + nn);
     if (nonce->mode == 0 && nonce->stream_scalars < nn * d) return fail(ROFL_NONCE_SHORT, "nonce stream too short");
     C.init();
     timing_begin(C);
-    float *dv = C.vals.as<float>(d); sc *dr1 = C.tmp_in.as<sc>(d); sc *dr2 = kind ? C.tmp_in2.as<sc>(d) : nullptr;
+    float *dv = C.vals.as<float>(d); sc *dr1 = C.tmp_in.as<sc>(d); sc *dr2 = has_sq ? C.tmp_in2.as<sc>(d) : nullptr;
     uint8_t *dex = existing ? C.Cbytes.as<uint8_t>(d * 32) : nullptr;
     uint8_t *dp = C.aux_pts.as<uint8_t>(d * plen), *dc = C.aux_scal.as<uint8_t>(d * clen);
     u32 *status = C.status.as<u32>(4);
     HIPCHK(hipMemsetAsync(status, 0, 16, C.stream));
     HIPCHK(hipMemcpyAsync(dv, values, 4 * d, hipMemcpyHostToDevice, C.stream));
     HIPCHK(hipMemcpyAsync(dr1, r1, 32 * d, hipMemcpyHostToDevice, C.stream));
-    if (kind) HIPCHK(hipMemcpyAsync(dr2, r2, 32 * d, hipMemcpyHostToDevice, C.stream));
+    if (has_sq) HIPCHK(hipMemcpyAsync(dr2, r2, 32 * d, hipMemcpyHostToDevice, C.stream));
     if (dex) HIPCHK(hipMemcpyAsync(dex, existing, 32 * d, hipMemcpyHostToDevice, C.stream));
     NonceSeed seed{}; const uint8_t *d_stream = nullptr; u64 ss = 0;
     if (nonce->mode == 1) memcpy(seed.w, nonce->seed, 32);
@@ -1189,7 +1191,7 @@ int sigma_verify(int kind, const uint8_t *proofs, const uint8_t *commits, size_t
     Ctx &C = ctx(); std::lock_guard<std::mutex> lk(C.mu);
     *ok_out = 0;
     if (d == 0) { *ok_out = 1; return ROFL_OK; }
-    size_t plen = kind ? 192 : 128, clen = kind ? 96 : 64;
+    size_t npts = 1 + (kind != 2) + (kind != 0 ? 1 : 0), clen = 32 * npts, plen = 32 * (npts + (kind != 0 ? 3 : 2));
     C.init();
     timing_begin(C);
     uint8_t *dp = C.aux_pts.as<uint8_t>(d * plen), *dc = C.aux_scal.as<uint8_t>(d * clen);
@@ -1206,8 +1208,121 @@ int sigma_verify(int kind, const uint8_t *proofs, const uint8_t *commits, size_t
     *ok_out = st[1] == 0;
     return ROFL_OK;
 }
+// ---- compressed_rand_proof
+sc compressed_challenge(const uint8_t *pairs, size_t d, const uint8_t cprime[64]) {
+    Merlin t("CompressedRandProof", 19);
+    t.append("dom-sep", (const uint8_t *)"randomness proof v1", 19);
+    for (size_t i = 0; i < d; i++) {      // label = UNIQUE_U8_TRIPLETS[i] (generate_unique_u8_triplets.py:8-13)
+        uint8_t lbl[3] = {(uint8_t)(3 * i), (uint8_t)(3 * i + 1), (uint8_t)(3 * i + 2)};
+        t.append_lbl(lbl, 3, pairs + 64 * i, 64);
+    }
+    t.append("C_prime_eg", cprime, 64);
+    return t.challenge_scalar("c");
+}
+int compressed_create(const float *values, size_t d, const uint8_t *r32, size_t d_r, const uint8_t *existing, unsigned fp_bits, unsigned fp_frac,
+                      const rofl_nonce_t *nonce, uint8_t *proof_out, uint8_t *pairs_out) {
+    Ctx &C = ctx(); std::lock_guard<std::mutex> lk(C.mu);
+    if (d != d_r) return fail(ROFL_WRONG_NUM_BLINDING, "WrongNumBlindingFactors");
+    if (!valid_fp(fp_bits, fp_frac) || !nonce || d >= 900000) return fail(ROFL_BAD_PARAM, "bad parameter");
+    if (nonce->mode == 0 && nonce->stream_scalars < 2) return fail(ROFL_NONCE_SHORT, "nonce stream too short");
+    C.init();
+    timing_begin(C);
+    size_t dd = d ? d : 1;
+    float *dv = C.vals.as<float>(dd); sc *dr = C.tmp_in.as<sc>(dd);
+    uint8_t *dex = existing ? C.Cbytes.as<uint8_t>(dd * 32) : nullptr;
+    uint8_t *dpairs = C.aux_scal.as<uint8_t>(dd * 64);
+    u32 *status = C.status.as<u32>(4);
+    HIPCHK(hipMemsetAsync(status, 0, 16, C.stream));
+    if (d) {
+        HIPCHK(hipMemcpyAsync(dv, values, 4 * d, hipMemcpyHostToDevice, C.stream));
+        HIPCHK(hipMemcpyAsync(dr, r32, 32 * d, hipMemcpyHostToDevice, C.stream));
+        if (dex) HIPCHK(hipMemcpyAsync(dex, existing, 32 * d, hipMemcpyHostToDevice, C.stream));
+        hipLaunchKernelGGL(k_eg_pairs, dim3((unsigned)((d + 63) / 64)), dim3(64), 0, C.stream, (u32)d, dv, fp_bits, fp_frac, dr, dex, C.d_tabB, C.d_tabBb, dpairs, status);
+        HIPCHK(hipMemcpyAsync(pairs_out, dpairs, 64 * d, hipMemcpyDeviceToHost, C.stream));
+    }
+    u32 st = 0;
+    HIPCHK(hipMemcpyAsync(&st, status, 4, hipMemcpyDeviceToHost, C.stream));
+    HIPCHK(hipStreamSynchronize(C.stream));
+    if (st & 2u) return fail(ROFL_NON_FINITE, "non-finite value (the reference panics in fixed::saturating_from_float)");
+    if (st & 4u) return fail(ROFL_FORMAT_ERROR, "invalid Ristretto encoding");
+    // nonces m', r' (party.rs:66-67), C' = commit(m', r')
+    sc nc[2];
+    for (int j = 0; j < 2; j++) {
+        uint8_t b[32];
+        if (nonce->mode == 1) rofl_dbg_host_nonce(nonce->seed, (uint64_t)j, b);
+        else { sc w = sc_from_wide(sc_frombytes(nonce->stream + 64 * j), sc_frombytes(nonce->stream + 64 * j + 32)); sc_tobytes(b, w); }
+        nc[j] = sc_frombytes(b);
+    }
+    h51::encode(proof_out, h51::gadd(h_fixed_mul(C.ht.B5, nc[0]), h_fixed_mul(C.ht.Bb5, nc[1])));
+    h51::encode(proof_out + 32, h_fixed_mul(C.ht.B5, nc[1]));
+    sc c = compressed_challenge(pairs_out, d, proof_out);
+    sc zm = nc[0], zr = nc[1];
+    if (d) {
+        CPow cp; fill_pow2(cp.sq, h_mont(c), MAX_LG);
+        u32 nblk = (u32)std::min<size_t>(64, (d + TPB - 1) / TPB);
+        sc *part = C.tmp_out.as<sc>(64 * 2);
+        hipLaunchKernelGGL(k_cpow_dot, dim3(nblk), dim3(TPB), 0, C.stream, (u32)d, dv, fp_bits, fp_frac, dr, cp, part);
+        sc hp[128];
+        HIPCHK(hipMemcpyAsync(hp, part, sizeof(sc) * nblk * 2, hipMemcpyDeviceToHost, C.stream));
+        HIPCHK(hipStreamSynchronize(C.stream));
+        zm = sc_add(zm, h_canon(sum_partials(hp, nblk, 2, 0))); zr = sc_add(zr, h_canon(sum_partials(hp, nblk, 2, 1)));
+    }
+    sc_tobytes(proof_out + 64, zm); sc_tobytes(proof_out + 96, zr);
+    timing_end(C);
+    return ROFL_OK;
+}
+int compressed_verify(const uint8_t *proof, const uint8_t *pairs, size_t d, int *ok_out) {
+    Ctx &C = ctx(); std::lock_guard<std::mutex> lk(C.mu);
+    *ok_out = 0;
+    ge Lp32, Rp32;
+    if (!ristretto_decode(Lp32, proof) || !ristretto_decode(Rp32, proof + 32) || !sc_is_canonical_bytes(proof + 64) || !sc_is_canonical_bytes(proof + 96))
+        return fail(ROFL_FORMAT_ERROR, "FormatError");
+    if (d >= 900000) return fail(ROFL_BAD_PARAM, "bad parameter");
+    C.init();
+    timing_begin(C);
+    ge5 sumL = h51::identity(), sumR = h51::identity();
+    sc c = compressed_challenge(pairs, d, proof);
+    if (d) {
+        uint8_t *dpairs = C.tmp_in.as<uint8_t>(d * 64);
+        niels *pts = C.aux_pts.as<niels>(2 * d); sc *scal = C.aux_scal.as<sc>(d);
+        u32 *status = C.status.as<u32>(4);
+        HIPCHK(hipMemsetAsync(status, 0, 16, C.stream));
+        HIPCHK(hipMemcpyAsync(dpairs, pairs, 64 * d, hipMemcpyHostToDevice, C.stream));
+        hipLaunchKernelGGL(k_decode_pairs, grid1(2 * d), dim3(TPB), 0, C.stream, (u32)d, dpairs, pts, pts + d, status);
+        CPow cp; fill_pow2(cp.sq, h_mont(c), MAX_LG);
+        hipLaunchKernelGGL(k_cpow_scalars, grid1(d), dim3(TPB), 0, C.stream, (u32)d, cp, scal);
+        u32 st = 0;
+        HIPCHK(hipMemcpyAsync(&st, status, 4, hipMemcpyDeviceToHost, C.stream));
+        HIPCHK(hipStreamSynchronize(C.stream));
+        if (st & 4u) return fail(ROFL_FORMAT_ERROR, "FormatError: invalid ElGamal pair");
+        std::vector<MsmProb> pr = {MsmProb{pts, scal}, MsmProb{pts + d, scal}}; std::vector<ge5> res;
+        msm_run(C, pr, d, res);          // sum_i c^(i+1) L_i and sum_i c^(i+1) R_i share the scalars
+        sumL = res[0]; sumR = res[1];
+    }
+    sc zm = sc_frombytes(proof + 64), zr = sc_frombytes(proof + 96);
+    auto neg5 = [](const ge5 &p) { ge5 r = p; r.X = h51::neg(p.X); r.T = h51::neg(p.T); return r; };
+    ge5 e1 = h51::gadd(h51::gadd(h_fixed_mul(C.ht.B5, zm), h_fixed_mul(C.ht.Bb5, zr)), neg5(h51::gadd(h51::from_ge(Lp32), sumL)));
+    ge5 e2 = h51::gadd(h_fixed_mul(C.ht.B5, zr), neg5(h51::gadd(h51::from_ge(Rp32), sumR)));
+    *ok_out = h51::is_identity_ristretto(e1) && h51::is_identity_ristretto(e2);
+    timing_end(C);
+    return ROFL_OK;
+}
 }  // namespace
 
+int rofl_create_squareproof_vec(const float *values, size_t d, const uint8_t *r1_32, size_t d_r1, const uint8_t *r2_32, const uint8_t *existing32,
+                                unsigned fp_bits, unsigned fp_frac, const rofl_nonce_t *nonce, uint8_t *proofs_out, uint8_t *commits_out) {
+    return guarded([&]() -> int { return sigma_create(2, values, d, r1_32, d_r1, r2_32, existing32, fp_bits, fp_frac, nonce, proofs_out, commits_out); });
+}
+int rofl_verify_squareproof_vec(const uint8_t *proofs, const uint8_t *commits, size_t d, int *ok_out) {
+    return guarded([&]() -> int { return sigma_verify(2, proofs, commits, d, ok_out); });
+}
+int rofl_create_compressed_randproof(const float *values, size_t d, const uint8_t *r32, size_t d_r, const uint8_t *existing32, unsigned fp_bits, unsigned fp_frac,
+                                     const rofl_nonce_t *nonce, uint8_t proof_out[128], uint8_t *pairs_out) {
+    return guarded([&]() -> int { return compressed_create(values, d, r32, d_r, existing32, fp_bits, fp_frac, nonce, proof_out, pairs_out); });
+}
+int rofl_verify_compressed_randproof(const uint8_t proof[128], const uint8_t *pairs, size_t d, int *ok_out) {
+    return guarded([&]() -> int { return compressed_verify(proof, pairs, d, ok_out); });
+}
 int rofl_create_randproof_vec(const float *values, size_t d, const uint8_t *r32, size_t d_r, const uint8_t *existing32, unsigned fp_bits, unsigned fp_frac,
                               const rofl_nonce_t *nonce, uint8_t *proofs_out, uint8_t *commits_out) {
     return guarded([&]() -> int { return sigma_create(0, values, d, r32, d_r, nullptr, existing32, fp_bits, fp_frac, nonce, proofs_out, commits_out); });

@@ -158,7 +158,7 @@ def sigma_create(kind, values, r1, r2, fp_bits, fp_frac, seed=None, stream=None,
     r2 = None if r2 is None else np.ascontiguousarray(r2, dtype=np.uint8).reshape(-1, 32)
     ex = None if existing is None else np.ascontiguousarray(existing, dtype=np.uint8).reshape(-1, 32)
     d = v.size
-    pl, cl = (192, 96) if kind else (128, 64)
+    pl, cl = {0: (128, 64), 1: (192, 96), 2: (160, 64)}[kind]
     ns = _nonce(seed, stream)
     pr = np.zeros((max(d, 1), pl), np.uint8); cm = np.zeros((max(d, 1), cl), np.uint8)
     rc = lib().orc_sigma_create(kind, _p(v), _sz(d), _p(r1), _sz(r1.shape[0]), None if r2 is None else _p(r2), None if ex is None else _p(ex),
@@ -167,9 +167,28 @@ def sigma_create(kind, values, r1, r2, fp_bits, fp_frac, seed=None, stream=None,
 
 
 def sigma_verify(kind, proofs, commits):
-    pl, cl = (192, 96) if kind else (128, 64)
+    pl, cl = {0: (128, 64), 1: (192, 96), 2: (160, 64)}[kind]
     p = np.ascontiguousarray(proofs, dtype=np.uint8).reshape(-1, pl)
     c = np.ascontiguousarray(commits, dtype=np.uint8).reshape(-1, cl)
     ok = ctypes.c_int()
     rc = lib().orc_sigma_verify(kind, _p(p), _p(c), _sz(p.shape[0]), ctypes.byref(ok))
+    return rc, bool(ok.value)
+
+
+def compressed_create(values, r, fp_bits, fp_frac, seed=None, stream=None, existing=None):
+    v = np.ascontiguousarray(values, dtype=np.float32)
+    r = np.ascontiguousarray(r, dtype=np.uint8).reshape(-1, 32)
+    ex = None if existing is None else np.ascontiguousarray(existing, dtype=np.uint8).reshape(-1, 32)
+    d = v.size
+    ns = _nonce(seed, stream)
+    proof = np.zeros(128, np.uint8); pairs = np.zeros((max(d, 1), 64), np.uint8)
+    rc = lib().orc_compressed_create(_p(v), _sz(d), _p(r), _sz(r.shape[0]), None if ex is None else _p(ex), fp_bits, fp_frac, ctypes.byref(ns), _p(proof), _p(pairs))
+    return rc, proof, pairs[:d]
+
+
+def compressed_verify(proof, pairs):
+    p = np.ascontiguousarray(proof, dtype=np.uint8)
+    c = np.ascontiguousarray(pairs, dtype=np.uint8).reshape(-1, 64)
+    ok = ctypes.c_int()
+    rc = lib().orc_compressed_verify(_p(p), _p(c), _sz(c.shape[0]), ctypes.byref(ok))
     return rc, bool(ok.value)

@@ -420,3 +420,56 @@ def test_random_shape_fuzz(R):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "scripts", "gpu_fuzz.py"), "20", "4242"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "fuzz ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("d,fb,ff", [(1, 16, 7), (90, 16, 7), (257, 32, 7)])
+def test_square_proof_bit_exact(R, d, fb, ff):
+    """square_proof_vec (Pedersen-only square proof, the *Compressed enc types' per-element part)."""
+    R.api.set_fp(fb, ff)
+    rng = np.random.default_rng(d)
+    vals = rng.uniform(-3, 3, size=d).astype(np.float32)
+    r1, r2 = orc.rand_scalars(rng, d), orc.rand_scalars(rng, d)
+    seed = bytes(rng.integers(0, 256, 32, dtype=np.uint8))
+    pr, cm = R.square_proof_vec.create_l2rangeproof_vec(vals, r1, r2, nonce=R.Nonce.seeded(seed))
+    rc, opr, ocm = orc.sigma_create(2, vals, r1, r2, fb, ff, seed=seed)
+    assert rc == 0 and (pr == opr).all() and (cm == ocm).all()
+    assert R.square_proof_vec.verify_l2rangeproof_vec(pr, cm) and orc.sigma_verify(2, pr, cm) == (0, True)
+    pr2, cm2 = R.square_proof_vec.create_l2rangeproof_vec_existing(vals, cm[:, :32], r1, r2, nonce=R.Nonce.seeded(seed))
+    assert (pr2 == pr).all() and (cm2 == cm).all()
+    bad = pr.copy(); bad[d // 2, 64 + 7] ^= 1          # Z_m
+    assert R.square_proof_vec.verify_l2rangeproof_vec(bad, cm) is False and orc.sigma_verify(2, bad, cm) == (0, False)
+    # merge() of params.rs:776-788: ElGamal pairs of the compressed proof + square commitments share c_l
+    _, pairs = R.compressed_rand_proof.helper_prove(vals, r1, nonce=R.Nonce.seeded(seed))
+    assert (pairs[:, :32] == cm[:, :32]).all()
+    R.api.set_fp(16, 7)
+
+
+@pytest.mark.parametrize("d,fb,ff", [(1, 16, 7), (3, 16, 7), (100, 16, 7), (700, 32, 7), (5000, 32, 7)])
+def test_compressed_rand_proof(R, d, fb, ff):
+    """compressed_rand_proof: one proof for d ElGamal pairs; verification = two d-term MSMs sharing challenge powers."""
+    R.api.set_fp(fb, ff)
+    rng = np.random.default_rng(31 * d)
+    vals = rng.uniform(-3, 3, size=d).astype(np.float32)
+    r = orc.rand_scalars(rng, d)
+    seed = bytes(rng.integers(0, 256, 32, dtype=np.uint8))
+    pf, pairs = R.compressed_rand_proof.helper_prove(vals, r, nonce=R.Nonce.seeded(seed))
+    rc, opf, opairs = orc.compressed_create(vals, r, fb, ff, seed=seed)
+    assert rc == 0 and (pairs == opairs).all() and (pf == opf).all()
+    assert R.compressed_rand_proof.helper_verify(pf, pairs) is True and orc.compressed_verify(pf, pairs) == (0, True)
+    pf2, pairs2 = R.compressed_rand_proof.helper_prove_existing(vals, pairs[:, :32], r, nonce=R.Nonce.seeded(seed))
+    assert (pf2 == pf).all() and (pairs2 == pairs).all()
+    bad = pf.copy(); bad[64 + 5] ^= 1
+    assert R.compressed_rand_proof.helper_verify(bad, pairs) is False
+    if d > 1:
+        badp = pairs.copy(); badp[0], badp[1] = pairs[1], pairs[0]      # order matters: powers of the challenge
+        if not (pairs[0] == pairs[1]).all():
+            assert R.compressed_rand_proof.helper_verify(pf, badp) is False and orc.compressed_verify(pf, badp) == (0, False)
+    bad = pf.copy(); bad[96:128] = 0xFF
+    with pytest.raises(R.RoflError) as e:
+        R.compressed_rand_proof.helper_verify(bad, pairs)
+    assert e.value.code == 5
+    stream = rng.integers(0, 256, 2 * 64, dtype=np.uint8).tobytes()
+    pf3, _ = R.compressed_rand_proof.helper_prove(vals, r, nonce=R.Nonce.stream(stream))
+    rc, opf3, _ = orc.compressed_create(vals, r, fb, ff, stream=stream)
+    assert (pf3 == opf3).all()
+    R.api.set_fp(16, 7)

@@ -135,6 +135,13 @@ int rofl_scalar_to_f32_vec(const uint8_t *in32, size_t d, unsigned fp_bits, unsi
 int rofl_get_clip_bounds(size_t range, unsigned fp_bits, unsigned fp_frac, float *min_out, float *max_out); /* conversion32.rs:56-60 */
 int rofl_get_l2_clip_bounds(size_t range, unsigned fp_bits, unsigned fp_frac, float *out);  /* conversion32.rs:62-64 */
 
+/* ---- server-side extraction of the aggregate (bsgs32.rs:14-73, pedersen_ops.rs:27-53 discrete_log_vec_table) ----
+ * BSGSTable::new(table_size) is built once per (table_size) on the device and cached; every point goes through
+ * solve_discrete_log_with_neg with max_it = 2^bsgs_bits / table_size giant steps; values wrap to bsgs_bits bits like
+ * BSGS_URawFix.  bsgs_bits = 8 (fp8) or 16 (fp16/fp32/fp64 builds, fp.rs:42-108).  A point whose log is not found in
+ * either direction returns 11 (the reference unwraps None). */
+int rofl_discrete_log_vec(const uint8_t *points32, size_t d, size_t table_size, unsigned bsgs_bits, uint8_t *scalars_out32);
+
 /* ---- measurement hooks (bench.py) ---- */
 /* Time of the kernels of the last create / verify call, from HIP events on the library's stream. */
 typedef struct {

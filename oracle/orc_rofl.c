@@ -796,3 +796,47 @@ int orc_compressed_verify(const uint8_t proof[128], const uint8_t *pairs, size_t
     free(Ls); free(Rs); free(pw);
     return ORC_OK;
 }
+
+/* ------------------------------------------------------------------ bsgs32.rs:14-73 (server-side extraction of the aggregate)
+ * table[compress(x B)] = x for x = 0..m ; solve: up to max_it = 2^bsgs_bits / m giant steps of -mG, value (i*m + pow)
+ * truncated to bsgs_bits bits (BSGS_URawFix); solve_discrete_log_with_neg tries -M second and negates.
+ * Not found in either direction: the reference unwraps None (panic) -> ORC_BAD_PARAM. */
+typedef struct { uint8_t key[32]; uint32_t val; } bsgs_ent;
+static int bsgs_cmp(const void *a, const void *b) { return memcmp(((const bsgs_ent *)a)->key, ((const bsgs_ent *)b)->key, 32); }
+static int bsgs_lookup(const bsgs_ent *tab, size_t n, const ge *p, uint32_t *val) {
+    bsgs_ent k; ristretto_encode(k.key, p);
+    const bsgs_ent *e = bsearch(&k, tab, n, sizeof(bsgs_ent), bsgs_cmp);
+    if (!e) return 0;
+    *val = e->val; return 1;
+}
+int orc_bsgs_solve(const uint8_t *points32, size_t d, size_t m, unsigned bsgs_bits, uint8_t *scalars_out) {
+    orc_init();
+    if (m == 0 || bsgs_bits == 0 || bsgs_bits > 32) return ORC_BAD_PARAM;
+    bsgs_ent *tab = malloc(sizeof(bsgs_ent) * (m + 1));
+    ge cur; ge_identity(&cur);
+    for (size_t x = 0; x <= m; x++) { ristretto_encode(tab[x].key, &cur); tab[x].val = (uint32_t)(x & ((bsgs_bits >= 32) ? 0xffffffffu : ((1u << bsgs_bits) - 1))); ge_add(&cur, &cur, &GE_BASE); }
+    qsort(tab, m + 1, sizeof(bsgs_ent), bsgs_cmp);
+    sc msc; sc_from_u64(&msc, (uint64_t)m & ((bsgs_bits >= 32) ? 0xffffffffull : ((1ull << bsgs_bits) - 1)));   /* Scalar::from(m as BSGS_URawFix) */
+    ge mG; ge_scalarmult(&mG, &msc, &GE_BASE);
+    uint64_t max_it = (1ull << bsgs_bits) / m;
+    uint64_t mask = (bsgs_bits >= 32) ? 0xffffffffull : ((1ull << bsgs_bits) - 1);
+    int rc = ORC_OK;
+    for (size_t i = 0; i < d && !rc; i++) {
+        ge M; if (!ristretto_decode(&M, points32 + 32 * i)) { rc = ORC_FORMAT_ERROR; break; }
+        int found = 0; uint64_t value = 0;
+        for (int neg = 0; neg < 2 && !found; neg++) {
+            ge c = M; if (neg) ge_neg(&c, &M);
+            for (uint64_t it = 0; it < max_it; it++) {
+                uint32_t pw;
+                if (bsgs_lookup(tab, m + 1, &c, &pw)) { value = (it * m + pw) & mask; found = 1 + neg; break; }
+                ge_sub(&c, &c, &mG);
+            }
+        }
+        if (!found) { rc = ORC_BAD_PARAM; break; }
+        sc v; sc_from_u64(&v, value);
+        if (found == 2) sc_neg(&v, &v);
+        sc_tobytes(scalars_out + 32 * i, &v);
+    }
+    free(tab);
+    return rc;
+}

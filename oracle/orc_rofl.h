@@ -129,5 +129,7 @@ int orc_sigma_verify(int kind, const uint8_t *proofs, const uint8_t *commits, si
 int orc_compressed_create(const float *values, size_t d, const uint8_t *r32, size_t d_r, const uint8_t *existing32,
                           unsigned fp_bits, unsigned fp_frac, const orc_nonce_t *ns, uint8_t proof_out[128], uint8_t *pairs_out);
 int orc_compressed_verify(const uint8_t proof[128], const uint8_t *pairs, size_t d, int *ok);
+/* bsgs32.rs: BSGSTable::new(m) + solve_discrete_log_with_neg per point (pedersen_ops.rs:27-53 discrete_log_vec*) */
+int orc_bsgs_solve(const uint8_t *points32, size_t d, size_t m, unsigned bsgs_bits, uint8_t *scalars_out);
 #endif
 #endif

@@ -395,6 +395,21 @@ class pedersen_ops:
         return np.zeros((length, 32), dtype=np.uint8)
 
     @staticmethod
+    def discrete_log_vec(points, table_size, bsgs_bits=16):
+        """pedersen_ops.rs:37-53 (discrete_log_vec / discrete_log_vec_table over BSGSTable::new(table_size))."""
+        p = _u8(points)
+        out = np.zeros_like(p)
+        _check(lib().rofl_discrete_log_vec(_ptr(p), _sz(p.shape[0]), _sz(table_size), bsgs_bits, _ptr(out)))
+        return out
+
+    @staticmethod
+    def default_discrete_log_vec(points):
+        """pedersen_ops.rs:27-35: BSGSTable::default() = 2^(BSGS_N_BITS/2 + PRECOMP_BIAS) entries (fp.rs)."""
+        fb = _FpConfig.fp_bits
+        bits, bias = {8: (8, 3), 16: (16, 7), 32: (16, 7), 64: (16, 0)}[fb]
+        return pedersen_ops.discrete_log_vec(points, 1 << (bits // 2 + bias), bits)
+
+    @staticmethod
     def compute_shifted_values_rp(points, offset):
         p = _u8(points)
         o = np.ascontiguousarray(offset, dtype=np.uint8)

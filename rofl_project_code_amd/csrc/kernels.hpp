@@ -1003,6 +1003,61 @@ __global__ void __launch_bounds__(TPB) k_decode_pairs(u32 d, const uint8_t *pair
     store_niels(which ? &Rs[i] : &Ls[i], ge_to_niels(p));
 }
 
+// ================================================================ BSGS discrete log (bsgs32.rs:14-73, pedersen_ops.rs:27-53)
+// Baby-step table: keys[x] = compress(x B), x = 0..m, indexed by an open-addressing hash table (slot = first 8 key
+// bytes, linear probing) that lives in HBM; one thread per point walks the giant steps.
+__device__ __forceinline__ u64 bsgs_hash(const uint8_t *k) {
+    u64 h = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) h |= (u64)k[i] << (8 * i);
+    return h * 0x9E3779B97F4A7C15ULL;
+}
+__global__ void __launch_bounds__(64) k_bsgs_build(u32 m, const niels *tabB, uint8_t *keys /* [(m+1)][32] */, u32 *slots, u32 slot_mask) {
+    u32 x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x > m) return;
+    gd p = sg_fixed_mul(tabB, sc_from_u64(x));
+    uint8_t *key = keys + (size_t)32 * x;
+    sg_encode(key, p);
+    u32 s = (u32)(bsgs_hash(key) >> 32) & slot_mask;
+    for (;;) { if (atomicCAS(&slots[s], 0u, x + 1) == 0u) break; s = (s + 1) & slot_mask; }
+}
+__device__ inline bool bsgs_find(const uint8_t *enc, const uint8_t *keys, const u32 *slots, u32 slot_mask, u32 &val) {
+    u32 s = (u32)(bsgs_hash(enc) >> 32) & slot_mask;
+    for (;;) {
+        u32 e = slots[s];
+        if (!e) return false;
+        const uint8_t *k = keys + (size_t)32 * (e - 1);
+        bool eq = true;
+        for (int i = 0; i < 32; i++) eq &= (k[i] == enc[i]);
+        if (eq) { val = e - 1; return true; }
+        s = (s + 1) & slot_mask;
+    }
+}
+__global__ void __launch_bounds__(64) k_bsgs_solve(u32 d, const uint8_t *points, u32 m, u32 bsgs_bits, u64 max_it, niels neg_mG, const uint8_t *keys,
+                                                   const u32 *slots, u32 slot_mask, uint8_t *out, u32 *status) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d) return;
+    gd M;
+    if (!sg_decode(M, points + (size_t)32 * i)) { atomicOr(status, 4u); return; }
+    nd step = nd_unpack(neg_mG);
+    u64 mask = bsgs_bits >= 32 ? 0xffffffffULL : ((1ULL << bsgs_bits) - 1);
+    int found = 0; u64 value = 0;
+    for (int neg = 0; neg < 2 && !found; neg++) {
+        gd c = neg ? gd_neg(M) : M;
+        uint8_t enc[32];
+        if (!neg) { for (int q = 0; q < 32; q++) enc[q] = points[(size_t)32 * i + q]; } else sg_encode(enc, c);
+        for (u64 it = 0; it < max_it; it++) {
+            u32 pw;
+            if (bsgs_find(enc, keys, slots, slot_mask, pw)) { value = (it * m + (pw & mask)) & mask; found = 1 + neg; break; }
+            if (it + 1 < max_it) { c = gd_madd(c, step, false); sg_encode(enc, c); }
+        }
+    }
+    if (!found) { atomicOr(status, 8u); return; }
+    sc v = sc_from_u64(value);
+    if (found == 2) v = sc_neg(v);
+    sc_tobytes(out + (size_t)32 * i, v);
+}
+
 // ================================================================ micro-benchmark: field multiply rate
 __global__ void __launch_bounds__(TPB) k_bench_femul(u32 iters, const fe *in, fe *out) {
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;

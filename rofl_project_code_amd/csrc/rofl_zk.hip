@@ -198,6 +198,8 @@ struct Ctx {
     niels *d_tabB = nullptr, *d_tabBb = nullptr;
     sc *d_two_pow = nullptr;
     std::map<std::pair<size_t, size_t>, niels *> gens;   // (n, m) -> [G(N) | H(N)]
+    struct Bsgs { uint8_t *keys; u32 *slots; u32 mask; };
+    std::map<size_t, Bsgs> bsgs;                          // table_size -> baby-step table
     std::unique_ptr<HostPool> pool;
     size_t fold_min = 1024;
     bool msm_slots = true;
@@ -1433,6 +1435,42 @@ int rofl_dbg_msm(const uint8_t *scalars32, const uint8_t *points32, size_t n, ui
         std::vector<MsmProb> pr(1, MsmProb{dn, ds}); std::vector<ge5> res;
         msm_run(C, pr, n, res);
         h51::encode(out32, res[0]);
+        return ROFL_OK;
+    });
+}
+int rofl_discrete_log_vec(const uint8_t *points32, size_t d, size_t table_size, unsigned bsgs_bits, uint8_t *scalars_out32) {
+    return guarded([&]() -> int {
+        Ctx &C = ctx(); std::lock_guard<std::mutex> lk(C.mu);
+        if (table_size == 0 || table_size >= (1u << 30) || !(bsgs_bits == 8 || bsgs_bits == 16 || bsgs_bits == 32)) return fail(ROFL_BAD_PARAM, "bad parameter");
+        if (d == 0) return ROFL_OK;
+        C.init();
+        timing_begin(C);
+        auto it = C.bsgs.find(table_size);
+        if (it == C.bsgs.end()) {
+            Ctx::Bsgs b; u32 nslots = 1; while (nslots < 2 * (table_size + 1)) nslots <<= 1;
+            b.mask = nslots - 1;
+            HIPCHK(hipMalloc(&b.keys, 32 * (table_size + 1))); HIPCHK(hipMalloc(&b.slots, sizeof(u32) * nslots));
+            HIPCHK(hipMemsetAsync(b.slots, 0, sizeof(u32) * nslots, C.stream));
+            hipLaunchKernelGGL(k_bsgs_build, dim3((unsigned)((table_size + 1 + 63) / 64)), dim3(64), 0, C.stream, (u32)table_size, C.d_tabB, b.keys, b.slots, b.mask);
+            it = C.bsgs.emplace(table_size, b).first;
+        }
+        const Ctx::Bsgs &B = it->second;
+        u64 mask = bsgs_bits >= 32 ? 0xffffffffULL : ((1ULL << bsgs_bits) - 1);
+        // mG = B * Scalar::from(m as BSGS_URawFix)  (bsgs32.rs:18): the multiplier wraps to bsgs_bits bits
+        niels neg_mG = h51::to_niels32(h_fixed_mul(C.ht.B5, sc_neg(sc_from_u64((u64)table_size & mask))));
+        u64 max_it = (1ULL << bsgs_bits) / table_size;
+        uint8_t *dp = C.tmp_in.as<uint8_t>(d * 32), *dout = C.Cbytes.as<uint8_t>(d * 32);
+        u32 *status = C.status.as<u32>(4);
+        HIPCHK(hipMemsetAsync(status, 0, 16, C.stream));
+        HIPCHK(hipMemcpyAsync(dp, points32, 32 * d, hipMemcpyHostToDevice, C.stream));
+        hipLaunchKernelGGL(k_bsgs_solve, dim3((unsigned)((d + 63) / 64)), dim3(64), 0, C.stream, (u32)d, dp, (u32)table_size, bsgs_bits, max_it, neg_mG, B.keys, B.slots, B.mask, dout, status);
+        u32 st = 0;
+        HIPCHK(hipMemcpyAsync(scalars_out32, dout, 32 * d, hipMemcpyDeviceToHost, C.stream));
+        HIPCHK(hipMemcpyAsync(&st, status, 4, hipMemcpyDeviceToHost, C.stream));
+        HIPCHK(hipStreamSynchronize(C.stream));
+        timing_end(C);
+        if (st & 4u) return fail(ROFL_FORMAT_ERROR, "invalid Ristretto encoding");
+        if (st & 8u) return fail(ROFL_BAD_PARAM, "discrete log not found (the reference unwraps None)");
         return ROFL_OK;
     });
 }

@@ -192,3 +192,10 @@ def compressed_verify(proof, pairs):
     ok = ctypes.c_int()
     rc = lib().orc_compressed_verify(_p(p), _p(c), _sz(c.shape[0]), ctypes.byref(ok))
     return rc, bool(ok.value)
+
+
+def bsgs_solve(points32, m, bits):
+    p = np.ascontiguousarray(points32, dtype=np.uint8).reshape(-1, 32)
+    out = np.zeros_like(p)
+    rc = lib().orc_bsgs_solve(_p(p), _sz(p.shape[0]), _sz(m), bits, _p(out))
+    return rc, out

@@ -473,3 +473,47 @@ def test_compressed_rand_proof(R, d, fb, ff):
     rc, opf3, _ = orc.compressed_create(vals, r, fb, ff, stream=stream)
     assert (pf3 == opf3).all()
     R.api.set_fp(16, 7)
+
+
+def test_bsgs_discrete_log(R):
+    """bsgs32.rs tests (:89-125) + the reference's dlog-based semantic tests (range_proof_vec/mod.rs:318-332, 369-399) end to end:
+    create_rangeproof with zero / cancelling blindings -> add_rp_vec_vec -> default_discrete_log_vec -> scalar_to_f32."""
+    R.api.set_fp(16, 7)
+    rng = np.random.default_rng(5)
+    fx = (rng.integers(-65535, 65536, size=400)).astype(np.float64) / 128.0
+    vals = fx.astype(np.float32)
+    sc = R.conversion32.f32_to_scalar_vec(vals)
+    pts = R.pedersen_ops.commit_no_blinding_vec(sc)
+    for m in (1 << 15, 1 << 16, 1 << 10, 3000):
+        # a non-dividing table size covers only (2^16 / m) * m + m values: keep the inputs inside it
+        sel = np.abs(fx * 128) <= (65536 // m) * m
+        got = R.pedersen_ops.discrete_log_vec(pts[sel], m, 16)
+        rc, exp = orc.bsgs_solve(pts[sel], m, 16)
+        assert rc == 0 and (got == exp).all() and (got == sc[sel]).all(), m
+    with pytest.raises(R.RoflError):        # 65428 > 21 * 3000 + 3000: the reference unwraps None, so does the oracle
+        R.pedersen_ops.discrete_log_vec(pts, 3000, 16)
+    assert orc.bsgs_solve(pts, 3000, 16)[0] == 11
+    assert (R.pedersen_ops.default_discrete_log_vec(pts) == sc).all()
+    assert list(R.conversion32.scalar_to_f32_vec(R.pedersen_ops.default_discrete_log_vec(pts))) == list(vals)
+    # test_create_rangeproof_correct_shift
+    x = np.array([0.25, 1.25, -1.5], np.float32)
+    _, cm = R.range_proof_vec.create_rangeproof(x, np.zeros((3, 32), np.uint8), 16, 4, nonce=R.Nonce.seeded(b"\x01" * 32))
+    assert list(R.conversion32.scalar_to_f32_vec(R.pedersen_ops.default_discrete_log_vec(cm))) == [0.25, 1.25, -1.5]
+    # test_rangeproof_with_cancelling_blindings
+    b0, b1 = orc.rand_scalars(rng, 3), orc.rand_scalars(rng, 3)
+    b2 = np.stack([np.frombuffer(((-(int.from_bytes(b0[i].tobytes(), "little") + int.from_bytes(b1[i].tobytes(), "little"))) % orc.L_ORDER).to_bytes(32, "little"), np.uint8) for i in range(3)])
+    cms = [R.range_proof_vec.create_rangeproof(v, b, 16, 4, nonce=R.Nonce.seeded(b"\x02" * 32))[1]
+           for v, b in zip(([0.25, 1.25, -1.5], [-0.75, 1.25, -2.0], [0.5, 1.25, -3.0]), (b0, b1, b2))]
+    tot = R.pedersen_ops.add_rp_vec_vec(cms)
+    assert list(R.conversion32.scalar_to_f32_vec(R.pedersen_ops.default_discrete_log_vec(tot))) == [0.0, 3.75, -6.5]
+    # out of table range -> the reference panics (unwrap on None)
+    far = R.pedersen_ops.commit_no_blinding_vec(np.frombuffer((1 << 40).to_bytes(32, "little"), np.uint8).reshape(1, 32))
+    with pytest.raises(R.RoflError) as e:
+        R.pedersen_ops.discrete_log_vec(far, 1 << 10, 16)
+    assert e.value.code == 11 and orc.bsgs_solve(far, 1 << 10, 16)[0] == 11
+    # fp8 flavour: 8-bit values, table 2^(4+3)
+    R.api.set_fp(8, 3)
+    v8 = np.array([0.0, 1.5, -2.25, 15.875, -15.875], np.float32)
+    p8 = R.pedersen_ops.commit_no_blinding_vec(R.conversion32.f32_to_scalar_vec(v8))
+    assert list(R.conversion32.scalar_to_f32_vec(R.pedersen_ops.default_discrete_log_vec(p8))) == list(v8)
+    R.api.set_fp(16, 7)

@@ -48,6 +48,21 @@ def test_cancelling_blindings_homomorphism():   # :369-399
     target = [0.0, 3.75, -6.5]
     expect = orc.commit_vec(np.stack([orc.f32_to_scalar(t, FB, FF)[1] for t in target]), None)
     assert (tot == expect).all()
+    # ... and the reference's actual assertion: discrete log of the sum back to f32 (mod.rs:392-398, bsgs32.rs:14-73)
+    rc, logs = orc.bsgs_solve(tot, 1 << 15, 16)
+    assert rc == 0 and [orc.scalar_to_f32(x, FB, FF) for x in logs] == target
+
+
+def test_bsgs_table_and_neg():   # bsgs32.rs:89-125
+    ints = [0, 1, 77, 32767, 32768, 65535, -1, -77, -65535]
+    sc = np.stack([np.frombuffer((x % orc.L_ORDER).to_bytes(32, "little"), np.uint8) for x in ints])
+    pts = orc.commit_vec(sc, None)
+    for m in (1 << 16, 1 << 15, 1 << 8):
+        rc, out = orc.bsgs_solve(pts, m, 16)
+        assert rc == 0 and (out == sc).all()
+    far = orc.commit_vec(np.frombuffer((1 << 20).to_bytes(32, "little"), np.uint8).reshape(1, 32), None)
+    assert orc.bsgs_solve(far, 1 << 8, 16)[0] == 11            # the reference unwraps None
+    assert orc.bsgs_solve(np.full((1, 32), 0xff, np.uint8), 1 << 8, 16)[0] == 5
 
 
 def test_clipped():   # :402-417

@@ -376,7 +376,7 @@ __global__ void __launch_bounds__(TPB) k_lr_vec(u32 n, u32 m, const ChunkParams 
 // n_k = n_g >> r entries; true G[i] = sum_h stab[0][h] Gc[h*n_k+i], true H[i] = sum_h stab[1][h] y^-j Hc[j].
 // Writes canonical MSM scalars for L (SL) and R (SR) over [Gc | Hc].
 __global__ void __launch_bounds__(TPB) k_ipp_scalars(u32 n_g, u32 n_k, const sc *stab /* [chunk][2][nstab] */, u32 nstab, const sc *a, const sc *b, size_t ab_stride,
-                              const sc *yinvpow, size_t y_stride, sc *SL, sc *SR) {
+                              const sc *yinvpow, size_t y_stride, sc *SL, sc *SR, int merged) {
     u32 c = blockIdx.y;
     u32 j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_g) return;
@@ -385,6 +385,12 @@ __global__ void __launch_bounds__(TPB) k_ipp_scalars(u32 n_g, u32 n_k, const sc 
     sc sG = load_sc(&stab[((size_t)c * 2 + 0) * nstab + h]);
     sc sH = sc_montmul(load_sc(&stab[((size_t)c * 2 + 1) * nstab + h]), load_sc(&yinvpow[c * y_stride + j]));
     sc *sl = SL + (size_t)c * 2 * n_g, *sr = SR + (size_t)c * 2 * n_g;
+    if (merged) {      // one array, every term non-zero; the side of a term is a function of its index (MsmMap)
+        bool lo = i < nh; u32 ii = lo ? nh + i : i - nh;
+        store_sc(&sl[j], sc_from_mont(sc_montmul(load_sc(&ac[ii]), sG)));
+        store_sc(&sl[n_g + j], sc_from_mont(sc_montmul(load_sc(&bc[ii]), sH)));
+        return;
+    }
     sc zero = sc_zero();
     if (i < nh) {
         // G_L / H_L halves: R gets a_R * G_L ; L gets b_R * H_L
@@ -528,6 +534,21 @@ __device__ __forceinline__ void msm_window(const MsmWin &mw, u32 w, u32 &pos, u3
     else if (w < mw.wide) { pos = w * mw.c; width = mw.c; }
     else { pos = mw.wide * mw.c + (w - mw.wide) * (mw.c - 1); width = mw.c - 1; }
 }
+// window table for the fixed-base MSM: wtab[w][g] = 2^(pos_w) * gens[g] for the W windows of `mw` (affine niels)
+__global__ void __launch_bounds__(TPB) k_gens_wtab(u32 total, MsmWin mw, const niels *gens, niels *wtab, size_t stride) {
+    u32 g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    niels p0 = load_niels(&gens[g]);
+    store_niels(&wtab[g], p0);
+    gd cur = gd_unpack(ge_from_niels(p0));
+    u32 at = 0;
+    for (u32 w = 1; w < mw.W; w++) {
+        u32 pos, wid; msm_window(mw, w, pos, wid);
+        for (; at < pos; at++) cur = gd_double(cur);
+        store_niels(&wtab[(size_t)w * stride + g], gd_to_niels(cur));
+    }
+}
+
 // Booth-recoded signed digit of the window [pos, pos + width): in [-2^(width-1), 2^(width-1)]
 __device__ __forceinline__ int msm_digit(const sc &k, u32 wpos, u32 c) {
     int pos = (int)wpos - 1;              // lowest bit needed (b_{pos-1}), -1 for the first window
@@ -546,19 +567,47 @@ __device__ __forceinline__ int msm_digit(const sc &k, u32 wpos, u32 c) {
     return (int)(V & ((1u << (c - 1)) - 1)) + (int)bm1 - (int)(top << (c - 1));
 }
 struct MsmProb { const niels *pts; const sc *scal; };   // per problem: points and canonical scalars
+// How the (term, window) grid maps to bucket arrays.
+//  * lr_nh != 0: "L/R merged" IPP round.  The grid runs over chunks; chunk q owns problems 2q (L) and 2q+1 (R), which
+//    share one scalar array over [Gc | Hc] in which every term is non-zero and belongs to exactly one side
+//    (k_ipp_scalars, merged): G-side term j is L iff (j mod n_k) >= nh, H-side the other way round.
+//  * fb_sets != 0: fixed-base mode.  pts is the window table T[w][i] = 2^(pos_w) P_i (stride fb_stride; the c = 16
+//    window layout of msm_window), and windows [s*wps, (s+1)*wps) of a problem share bucket set s: no doublings are
+//    left between windows, and the bucket reduction runs over fb_sets sets instead of 16 windows.  With lr each side
+//    has its own sets.
+struct MsmMap { u32 lr_nh, lr_ng, fb_sets, fb_wps, fb_stride; };
+struct MsmItem { u32 pw, entry, ad; };                  // bucket array index, slot entry (point index | sign), |digit|
+__device__ __forceinline__ MsmItem msm_item(u32 n, const MsmWin &mw, const MsmMap &mm, const MsmProb *probs, u32 y, u32 i) {
+    u32 q = y / mw.W, w = y % mw.W;
+    u32 side = 0, p = q;
+    if (mm.lr_nh) { bool isL = i < mm.lr_ng ? (i & mm.lr_nh) != 0 : (i & mm.lr_nh) == 0; side = isL ? 0u : 1u; p = 2 * q + side; }
+    sc k = load_sc(&probs[p].scal[i]);
+    MsmItem it;
+    u32 wpos, wwid; msm_window(mw, w, wpos, wwid);
+    int d = msm_digit(k, wpos, wwid);
+    if (mm.fb_sets) {
+        u32 sets_tot = mm.fb_sets * (mm.lr_nh ? 2u : 1u);
+        it.pw = q * sets_tot + side * mm.fb_sets + w / mm.fb_wps;
+        it.entry = w * mm.fb_stride + i;
+    } else {
+        it.pw = p * mw.W + w;
+        it.entry = i;
+    }
+    it.ad = (u32)(d < 0 ? -d : d);
+    if (d < 0) it.entry |= 0x80000000u;
+    return it;
+}
 // Counting sort of (term, window) pairs by bucket.  blockIdx.y = prob * W + window, so the blocks in flight at
 // any time hit one 4*B-byte histogram and one 4*n-byte output region: both stay resident in the XCD L2s
 // instead of spraying partial-line writes over the whole [prob][W][n] array.
-__global__ void __launch_bounds__(TPB) k_msm_count(u32 n, MsmWin mw, const MsmProb *probs, u32 *cnt /* [prob][W][B] */) {
-    u32 W = mw.W, pw = blockIdx.y, p = pw / W, w = pw % W, B = 1u << (mw.c - 1);
+__global__ void __launch_bounds__(TPB) k_msm_count(u32 n, MsmWin mw, MsmMap mm, const MsmProb *probs, u32 *cnt /* [prob][W][B] */) {
+    u32 B = 1u << (mw.c - 1);
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    sc k = load_sc(&probs[p].scal[i]);
-    u32 wpos, wwid; msm_window(mw, w, wpos, wwid);
-    int d = msm_digit(k, wpos, wwid);
-    u32 ad = (u32)(d < 0 ? -d : d);
-    if (ad > B) { atomicAdd(&cnt[(size_t)pw * B + B - 1], 1u); ad -= B; }
-    if (ad) atomicAdd(&cnt[(size_t)pw * B + ad - 1], 1u);
+    MsmItem it = msm_item(n, mw, mm, probs, blockIdx.y, i);
+    u32 ad = it.ad;
+    if (ad > B) { atomicAdd(&cnt[(size_t)it.pw * B + B - 1], 1u); ad -= B; }
+    if (ad) atomicAdd(&cnt[(size_t)it.pw * B + ad - 1], 1u);
 }
 // One block per (prob, window): exclusive scan of the histogram (off, cursor) and a bucket permutation sorted by
 // descending count (perm), so that the 64 lanes of an accumulate wave own buckets of (nearly) equal size.
@@ -600,45 +649,106 @@ __global__ void __launch_bounds__(TPB) k_msm_scan(u32 B, const u32 *cnt, u32 *of
         perm[base + pos] = i;
     }
 }
-__global__ void __launch_bounds__(TPB) k_msm_scatter(u32 n, MsmWin mw, const MsmProb *probs, u32 *cursor, u32 *sorted /* [prob][W][n] */) {
-    u32 W = mw.W, pw = blockIdx.y, p = pw / W, w = pw % W, B = 1u << (mw.c - 1);
+__global__ void __launch_bounds__(TPB) k_msm_scatter(u32 n, MsmWin mw, MsmMap mm, const MsmProb *probs, u32 *cursor, u32 *sorted /* [prob][W][n] */) {
+    u32 B = 1u << (mw.c - 1);
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    sc k = load_sc(&probs[p].scal[i]);
-    u32 wpos, wwid; msm_window(mw, w, wpos, wwid);
-    int d = msm_digit(k, wpos, wwid);
-    u32 ad = (u32)(d < 0 ? -d : d), entry = i | (d < 0 ? 0x80000000u : 0u);
-    if (ad > B) { u32 pos = atomicAdd(&cursor[(size_t)pw * B + B - 1], 1u); sorted[(size_t)pw * n * 2 + pos] = entry; ad -= B; }
-    if (ad) { u32 pos = atomicAdd(&cursor[(size_t)pw * B + ad - 1], 1u); sorted[(size_t)pw * n * 2 + pos] = entry; }
+    MsmItem it = msm_item(n, mw, mm, probs, blockIdx.y, i);
+    u32 ad = it.ad, pw = it.pw;
+    if (ad > B) { u32 pos = atomicAdd(&cursor[(size_t)pw * B + B - 1], 1u); sorted[(size_t)pw * n * 2 + pos] = it.entry; ad -= B; }
+    if (ad) { u32 pos = atomicAdd(&cursor[(size_t)pw * B + ad - 1], 1u); sorted[(size_t)pw * n * 2 + pos] = it.entry; }
 }
 // Single-pass variant: every bucket owns `cap` slots (HBM capacity instead of a counting pass); cursor doubles as the
 // per-bucket count.  The (astronomically rare for hash-derived scalars) entries beyond `cap` go to an overflow list
 // that k_msm_overflow adds afterwards; if even that list overflows the host falls back to the two-pass path.
 struct MsmOvf { u32 bucket; u32 entry; };
-__global__ void __launch_bounds__(TPB) k_msm_scatter_slots(u32 n, MsmWin mw, const MsmProb *probs, u32 *cursor, u32 *slots /* [prob][W][B][cap] */,
+__global__ void __launch_bounds__(TPB) k_msm_scatter_slots(u32 n, MsmWin mw, MsmMap mm, const MsmProb *probs, u32 *cursor, u32 *slots /* [prob][W][B][cap] */,
                                                            u32 cap, u32 *ovf_count, MsmOvf *ovf, u32 ovf_max) {
-    u32 W = mw.W, pw = blockIdx.y, p = pw / W, w = pw % W, B = 1u << (mw.c - 1);
+    u32 B = 1u << (mw.c - 1);
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    sc k = load_sc(&probs[p].scal[i]);
-    u32 wpos, wwid; msm_window(mw, w, wpos, wwid);
-    int d = msm_digit(k, wpos, wwid);
-    u32 ad = (u32)(d < 0 ? -d : d), entry = i | (d < 0 ? 0x80000000u : 0u);
+    MsmItem it = msm_item(n, mw, mm, probs, blockIdx.y, i);
+    u32 ad = it.ad;
     for (int rep = 0; rep < 2; rep++) {
         u32 a1 = rep == 0 ? (ad > B ? B : 0u) : (ad > B ? ad - B : ad);
         if (!a1) continue;
-        u32 bi = pw * B + a1 - 1;
+        u32 bi = it.pw * B + a1 - 1;
         u32 pos = atomicAdd(&cursor[bi], 1u);
-        if (pos < cap) slots[(size_t)bi * cap + pos] = entry;
-        else { u32 o = atomicAdd(ovf_count, 1u); if (o < ovf_max) { ovf[o].bucket = bi; ovf[o].entry = entry; } }
+        if (pos < cap) slots[(size_t)bi * cap + pos] = it.entry;
+        else { u32 o = atomicAdd(ovf_count, 1u); if (o < ovf_max) { ovf[o].bucket = bi; ovf[o].entry = it.entry; } }
+    }
+}
+// Same slot layout, but without one memory-side atomic per item (random-address device atomics retire at ~20 G/s on
+// this chip and were the whole cost of the kernel above).  One 1024-thread block owns a tile of the terms of one
+// bucket array (fixed-base: the `wps` windows of one set; otherwise one window): it ranks its items in an LDS
+// histogram, reserves a range per touched bucket with ONE global atomic per (tile, bucket) -- issued over consecutive
+// buckets, i.e. whole 256-byte wave requests -- and then places the items with LDS atomics only.
+// grid: x = tile, y = (grid problem q, side, set-or-window).  In L/R mode a block enumerates only the terms of its side.
+__device__ __forceinline__ u32 msm_side_term(const MsmMap &mm, u32 side, u32 k) {
+    // k-th term of `side` in the merged array [Gc (lr_ng) | Hc (lr_ng)]; lr_nh is a power of two
+    u32 half = mm.lr_ng / 2, hside = k >= half ? 1u : 0u, kk = k - hside * half;
+    u32 lowmask = mm.lr_nh - 1;
+    u32 j = ((kk & ~lowmask) << 1) | (kk & lowmask);
+    bool bit = hside ? side == 1 : side == 0;       // G side: L has the bit set; H side: R has it
+    if (bit) j |= mm.lr_nh;
+    return hside * mm.lr_ng + j;
+}
+__global__ void __launch_bounds__(1024) k_msm_scatter_lds(u32 n_side, u32 tile_pts, MsmWin mw, MsmMap mm, const MsmProb *probs, u32 *cursor, u32 *slots,
+                                                          u32 cap, u32 *ovf_count, MsmOvf *ovf, u32 ovf_max) {
+    extern __shared__ u32 lcnt[];
+    const u32 B = 1u << (mw.c - 1);
+    u32 nside = mm.lr_nh ? 2u : 1u;
+    u32 per_q = mm.fb_sets ? mm.fb_sets : mw.W;           // bucket arrays per (q, side)
+    u32 y = blockIdx.y, a = y % per_q, side = (y / per_q) % nside, q = y / (per_q * nside);
+    u32 p = mm.lr_nh ? 2 * q + side : q;
+    u32 pw = p * per_q + a;                                // == msm_item's pw for both layouts
+    u32 w0 = mm.fb_sets ? a * mm.fb_wps : a, w1 = mm.fb_sets ? w0 + mm.fb_wps : a + 1;
+    u32 k0 = blockIdx.x * tile_pts, k1 = k0 + tile_pts < n_side ? k0 + tile_pts : n_side;
+    const sc *scal = probs[p].scal;
+    for (u32 b = threadIdx.x; b < B; b += 1024) lcnt[b] = 0;
+    __syncthreads();
+    for (u32 k = k0 + threadIdx.x; k < k1; k += 1024) {
+        u32 i = mm.lr_nh ? msm_side_term(mm, side, k) : k;
+        sc s = load_sc(&scal[i]);
+        for (u32 w = w0; w < w1; w++) {
+            u32 wpos, wwid; msm_window(mw, w, wpos, wwid);
+            int d = msm_digit(s, wpos, wwid);
+            u32 ad = (u32)(d < 0 ? -d : d);
+            if (ad > B) { atomicAdd(&lcnt[B - 1], 1u); ad -= B; }
+            if (ad) atomicAdd(&lcnt[ad - 1], 1u);
+        }
+    }
+    __syncthreads();
+    for (u32 b = threadIdx.x; b < B; b += 1024) {
+        u32 c = lcnt[b];
+        lcnt[b] = c ? atomicAdd(&cursor[(size_t)pw * B + b], c) : 0u;
+    }
+    __syncthreads();
+    for (u32 k = k0 + threadIdx.x; k < k1; k += 1024) {
+        u32 i = mm.lr_nh ? msm_side_term(mm, side, k) : k;
+        sc s = load_sc(&scal[i]);
+        for (u32 w = w0; w < w1; w++) {
+            u32 wpos, wwid; msm_window(mw, w, wpos, wwid);
+            int d = msm_digit(s, wpos, wwid);
+            u32 ad = (u32)(d < 0 ? -d : d);
+            u32 entry = (mm.fb_sets ? w * mm.fb_stride + i : i) | (d < 0 ? 0x80000000u : 0u);
+            for (int rep = 0; rep < 2; rep++) {
+                u32 a1 = rep == 0 ? (ad > B ? B : 0u) : (ad > B ? ad - B : ad);
+                if (!a1) continue;
+                u32 pos = atomicAdd(&lcnt[a1 - 1], 1u);
+                u32 bi = pw * B + a1 - 1;
+                if (pos < cap) slots[(size_t)bi * cap + pos] = entry;
+                else { u32 o = atomicAdd(ovf_count, 1u); if (o < ovf_max) { ovf[o].bucket = bi; ovf[o].entry = entry; } }
+            }
+        }
     }
 }
 // one 64-lane wave; lane l owns the overflow entries whose bucket index is l mod 64 (no two lanes share a bucket)
-__global__ void k_msm_overflow(u32 W, u32 B, const MsmProb *probs, const u32 *ovf_count, const MsmOvf *ovf, u32 ovf_max, ge *buckets) {
+__global__ void k_msm_overflow(u32 W, u32 B, u32 pstep, const MsmProb *probs, const u32 *ovf_count, const MsmOvf *ovf, u32 ovf_max, ge *buckets) {
     if (blockIdx.x) return;
     u32 cnt = *ovf_count; if (cnt > ovf_max) cnt = ovf_max;
     for (u32 o = 0; o < cnt; o++) {
-        u32 bi = ovf[o].bucket, v = ovf[o].entry, p = bi / (W * B);
+        u32 bi = ovf[o].bucket, v = ovf[o].entry, p = bi / (W * B) * pstep;
         if ((bi & 63u) != threadIdx.x) continue;
         gd acc = load_gd(&buckets[bi]);
         acc = gd_madd(acc, load_nd(&probs[p].pts[v & 0x7fffffffu]), (v >> 31) != 0);
@@ -646,7 +756,8 @@ __global__ void k_msm_overflow(u32 W, u32 B, const MsmProb *probs, const u32 *ov
     }
 }
 // one thread per bucket: sum its points.  buckets [prob][W][B] extended.
-__global__ void __launch_bounds__(TPB) k_msm_accumulate(u32 n, u32 c, u32 W, const MsmProb *probs, const u32 *cnt, const u32 *off,
+// blockIdx.y = grid problem q owning W bucket arrays; its points are probs[q * pstep].pts (pstep = 2 for merged L/R pairs)
+__global__ void __launch_bounds__(TPB) k_msm_accumulate(u32 n, u32 c, u32 W, u32 pstep, const MsmProb *probs, const u32 *cnt, const u32 *off,
                                  const u32 *sorted, const u32 *perm, ge *buckets, u32 cap) {
     u32 p = blockIdx.y, B = 1u << (c - 1);
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -657,7 +768,7 @@ __global__ void __launch_bounds__(TPB) k_msm_accumulate(u32 n, u32 c, u32 W, con
     const u32 *lst;
     if (cap) { lst = sorted + bi * cap; if (num > cap) num = cap; }        // slot mode: `sorted` is the slot array
     else lst = sorted + ((size_t)p * W + w) * n * 2 + off[bi];   // stride 2n: a top-window digit may emit two entries
-    const niels *pts = probs[p].pts;
+    const niels *pts = probs[p * pstep].pts;
     gd acc = gd_identity();
     for (u32 e = 0; e < num; e++) {
         u32 v = lst[e];

@@ -198,6 +198,9 @@ struct Ctx {
     niels *d_tabB = nullptr, *d_tabBb = nullptr;
     sc *d_two_pow = nullptr;
     std::map<std::pair<size_t, size_t>, niels *> gens;   // (n, m) -> [G(N) | H(N)]
+    std::map<const niels *, niels *> wtabs;              // generator table -> 16 window slices 2^(16w) P (fixed-base MSM)
+    int msm_lds = 1; size_t msm_lds_min = 8192, msm_lds_tile = 131072;
+    int msm_fb = 1; u32 msm_fb_sets = 4; size_t msm_fb_min = (size_t)1 << 17; int msm_lr = 1;
     struct Bsgs { uint8_t *keys; u32 *slots; u32 mask; };
     std::map<size_t, Bsgs> bsgs;                          // table_size -> baby-step table
     std::unique_ptr<HostPool> pool;
@@ -225,6 +228,7 @@ struct Ctx {
         build_fixed_table(ht.Bb, ht.bblind);
         to_tab5(ht.B5, ht.B); to_tab5(ht.Bb5, ht.Bb);
         HIPCHK(hipFuncSetAttribute((const void *)k_msm_reduce_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void *)k_msm_scatter_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         HIPCHK(hipMalloc(&d_tabB, sizeof(niels) * 512));
         HIPCHK(hipMalloc(&d_tabBb, sizeof(niels) * 512));
         HIPCHK(hipMemcpy(d_tabB, ht.B.data(), sizeof(niels) * 512, hipMemcpyHostToDevice));
@@ -235,6 +239,13 @@ struct Ctx {
         HIPCHK(hipMemcpy(d_two_pow, tp, sizeof(tp), hipMemcpyHostToDevice));
         if (const char *e = getenv("ROFL_FOLD_T")) { int v = atoi(e); if (v >= 1 && v <= 6) fold_t = v; }
         if (const char *e = getenv("ROFL_MSM_SLOTS")) msm_slots = atoi(e) != 0;
+        if (const char *e = getenv("ROFL_MSM_FB")) msm_fb = atoi(e);
+        if (const char *e = getenv("ROFL_MSM_LDS")) msm_lds = atoi(e);
+        if (const char *e = getenv("ROFL_MSM_LDS_MIN")) { long v = atol(e); if (v >= 1) msm_lds_min = (size_t)v; }
+        if (const char *e = getenv("ROFL_MSM_LDS_TILE")) { long v = atol(e); if (v >= 1024) msm_lds_tile = (size_t)v; }
+        if (const char *e = getenv("ROFL_MSM_LR")) msm_lr = atoi(e);
+        if (const char *e = getenv("ROFL_MSM_FB_SETS")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) msm_fb_sets = (u32)v; }
+        if (const char *e = getenv("ROFL_MSM_FB_MIN")) { long v = atol(e); if (v >= 1) msm_fb_min = (size_t)v; }
         if (const char *e = getenv("ROFL_FOLD_MIN")) { long v = atol(e); if (v >= 1) fold_min = (size_t)v; }
         { int nt = 8; if (const char *e = getenv("ROFL_HOST_THREADS")) nt = atoi(e); unsigned hc = std::thread::hardware_concurrency(); if (hc && (unsigned)nt > hc) nt = (int)hc; if (nt < 1) nt = 1; pool.reset(new HostPool(nt)); }
         if (const char *e = getenv("ROFL_FOLD_T1")) { int v = atoi(e); if (v >= 1 && v <= 6) fold_t1 = v; }
@@ -250,6 +261,8 @@ struct Ctx {
         parent = &p; device = p.device;
         HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         ht = p.ht; d_tabB = p.d_tabB; d_tabBb = p.d_tabBb; d_two_pow = p.d_two_pow;
+        msm_lds = p.msm_lds; msm_lds_min = p.msm_lds_min; msm_lds_tile = p.msm_lds_tile;
+        msm_fb = p.msm_fb; msm_fb_sets = p.msm_fb_sets; msm_fb_min = p.msm_fb_min; msm_lr = p.msm_lr;
         fold_min = p.fold_min; msm_slots = p.msm_slots; fold_t = p.fold_t; fold_t1 = p.fold_t1; fold_k = p.fold_k; fold_tab = p.fold_tab;
         fold_unit = p.fold_unit; fold_threads = p.fold_threads; nlanes = 1;
         { int nt = 6; if (const char *e = getenv("ROFL_HOST_THREADS")) nt = atoi(e); if (nt < 1) nt = 1; pool.reset(new HostPool(nt)); }
@@ -273,6 +286,15 @@ bool is_pow2(size_t x) { return x && !(x & (x - 1)); }
 size_t next_pow2(size_t val) { if (val == 1) return 1; size_t n = val - 1; while ((n & (n - 1)) != 0) n &= n - 1; return n << 1; }
 
 // ---------------------------------------------------------------- generators
+struct MsmPlan { u32 c, W, B, levels, wide; };
+MsmPlan msm_plan_c(u32 c) {
+    MsmPlan p; p.c = c;
+    p.W = (253 - p.c + p.c - 1) / p.c + 1;                // top window [253-c, 254) + ceil((253-c)/c) lower windows
+    p.wide = (253 - p.c) - (p.c - 1) * (p.W - 1);          // wide*c + (W-1-wide)*(c-1) = 253 - c
+    p.B = 1u << (p.c - 1);
+    p.levels = (p.c - 1) / 3;
+    return p;
+}
 niels *get_gens(Ctx &C, size_t n, size_t m) {
     auto key = std::make_pair(n, m);
     auto &gens = C.parent ? C.parent->gens : C.gens;      // the cache lives in the primary lane (filled before lanes fork)
@@ -284,13 +306,24 @@ niels *get_gens(Ctx &C, size_t n, size_t m) {
     hipLaunchKernelGGL(k_gens_xof, grid1(2 * m), dim3(TPB), 0, C.stream, (u32)n, (u32)m, uni);
     hipLaunchKernelGGL(k_gens_map, grid1(2 * N), dim3(TPB), 0, C.stream, (u32)(2 * N), uni, tbl);
     hipLaunchKernelGGL(k_gens_tables, grid1(2 * N), dim3(TPB), 0, C.stream, (u32)(2 * N), tbl, (size_t)(2 * N));
+    Ctx &Pm = C.parent ? *C.parent : C;
+    if (Pm.msm_fb && 2 * N >= Pm.msm_fb_min && 2 * N * 16 < ((size_t)1 << 31)) {      // entry index (w * 2N + i) must fit 31 bits
+        niels *wt; HIPCHK(hipMalloc(&wt, sizeof(niels) * 2 * N * 16));
+        MsmPlan fp = msm_plan_c(16);
+        hipLaunchKernelGGL(k_gens_wtab, grid1(2 * N), dim3(TPB), 0, C.stream, (u32)(2 * N), MsmWin{fp.c, fp.W, fp.wide}, tbl, wt, (size_t)(2 * N));
+        Pm.wtabs[tbl] = wt;
+    }
     HIPCHK(hipStreamSynchronize(C.stream));
     gens[key] = tbl;
     return tbl;
 }
+const niels *find_wtab(Ctx &C, const niels *tbl) {
+    Ctx &Pm = C.parent ? *C.parent : C;
+    auto it = Pm.wtabs.find(tbl);
+    return it == Pm.wtabs.end() ? nullptr : it->second;
+}
 
 // ---------------------------------------------------------------- MSM driver
-struct MsmPlan { u32 c, W, B, levels, wide; };
 MsmPlan msm_plan(size_t n) {
     MsmPlan p;
     if (n >= (1u << 17)) p.c = 16; else if (n >= (1u << 13)) p.c = 13; else if (n >= (1u << 9)) p.c = 10; else if (n >= 64) p.c = 7; else p.c = 4;
@@ -303,46 +336,82 @@ MsmPlan msm_plan(size_t n) {
     return p;
 }
 // results[p] = sum_i scal[p][i] * pts[p][i]   (all problems have n terms).  Synchronises the stream.
-void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge5> &results) {
+// opt.lr_nh != 0: `probs` holds (L, R) pairs that share a merged scalar array (see MsmMap); opt.fb: every problem's points
+// are the generator table `opt.fb_gens` (n terms from its start, slice stride opt.fb_stride) for which a window table exists.
+struct MsmOpt { u32 lr_nh = 0, lr_ng = 0; const niels *fb_wtab = nullptr; size_t fb_stride = 0; };
+void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge5> &results, const MsmOpt &opt = MsmOpt()) {
     size_t np = probs.size();
-    MsmPlan P = msm_plan(n);
-    size_t PW = np * P.W;
+    bool lr = opt.lr_nh != 0;
+    size_t nq = lr ? np / 2 : np;                          // grid problems (chunks in lr mode)
     MsmProb *d_probs = C.msm_probs.as<MsmProb>(np);
     MsmProb *h_probs = C.h_probs.as<MsmProb>(np);
-    for (size_t i = 0; i < np; i++) h_probs[i] = probs[i];
-    HIPCHK(hipMemcpyAsync(d_probs, h_probs, sizeof(MsmProb) * np, hipMemcpyHostToDevice, C.stream));
-    u32 *cnt = C.msm_cnt.as<u32>(PW * P.B + 4), *off = C.msm_off.as<u32>(PW * P.B), *cur = C.msm_cur.as<u32>(PW * P.B);
-    u32 *perm = C.msm_perm.as<u32>(PW * P.B);
-    ge *buckets = C.msm_buckets.as<ge>(PW * P.B);
-    MsmWin mw{P.c, P.W, P.wide};
-    // slot mode: capacity 4x the worst-case mean bucket load (all scalars non-zero), clamped to [16, 256]
-    u32 cap = 16; while (cap < 256 && (size_t)cap * P.B < 4 * n) cap *= 2;
-    const u32 OVF_MAX = 4096;
-    bool slots_ok = C.msm_slots && (size_t)PW * P.B * cap * 4 <= ((size_t)8 << 30);
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    for (int attempt = 0; attempt < 2; attempt++) {
+    MsmPlan P{}; size_t PW = 0; bool fb_used = false; u32 sets = 0;
+    for (int attempt = 0; attempt < 3; attempt++) {
+        // attempt 0: fixed-base slots (if available) ; then generic slots ; then the two-pass sort
+        bool fb = attempt == 0 && opt.fb_wtab != nullptr && C.msm_slots;
+        bool slots_mode = attempt <= 1 && C.msm_slots;
+        if (attempt == 0 && !fb) continue;
+        if (attempt == 1 && !slots_mode) continue;
+        MsmMap mm{opt.lr_nh, opt.lr_ng, 0, 0, 0};
+        u32 Wgrid, cap;
+        if (fb) {
+            P = msm_plan_c(16);
+            sets = C.msm_fb_sets;
+            // keep at least ~512k accumulate threads in flight
+            while (sets < 16 && (size_t)nq * (lr ? 2 : 1) * sets * P.B < ((size_t)1 << 19)) sets *= 2;
+            mm.fb_sets = sets; mm.fb_wps = 16 / sets; mm.fb_stride = (u32)opt.fb_stride;
+            PW = nq * (lr ? 2 : 1) * sets; Wgrid = P.W;
+            size_t per_side = lr ? n / 2 : n;
+            cap = 16; while (cap < 2048 && (size_t)cap * P.B < 3 * per_side * mm.fb_wps) cap *= 2;
+            for (size_t i = 0; i < np; i++) h_probs[i] = MsmProb{opt.fb_wtab, probs[i].scal};
+        } else {
+            P = msm_plan(n);
+            PW = np * P.W; Wgrid = P.W;
+            cap = 16; while (cap < 256 && (size_t)cap * P.B < 4 * n) cap *= 2;
+            for (size_t i = 0; i < np; i++) h_probs[i] = probs[i];
+        }
+        if (slots_mode && (size_t)PW * P.B * cap * 4 > ((size_t)8 << 30)) continue;
+        HIPCHK(hipMemcpyAsync(d_probs, h_probs, sizeof(MsmProb) * np, hipMemcpyHostToDevice, C.stream));
+        u32 *cnt = C.msm_cnt.as<u32>(PW * P.B + 4), *off = C.msm_off.as<u32>(PW * P.B), *cur = C.msm_cur.as<u32>(PW * P.B);
+        u32 *perm = C.msm_perm.as<u32>(PW * P.B);
+        ge *buckets = C.msm_buckets.as<ge>(PW * P.B);
+        MsmWin mw{P.c, P.W, P.wide};
+        const u32 OVF_MAX = 4096;
+        u32 Wb = (u32)(PW / nq);                           // bucket arrays per grid problem
         HIPCHK(hipMemsetAsync(cnt, 0, sizeof(u32) * (PW * P.B + 4), C.stream));
-        if (slots_ok) {
+        // accumulate sees `nq` problems of Wb bucket arrays each; its points come from d_probs[q * (np / nq)]
+        if (slots_mode) {
             u32 *slots = C.msm_sorted.as<u32>(PW * P.B * cap);
             MsmOvf *ovf = C.msm_ovf.as<MsmOvf>(OVF_MAX);
             u32 *ovf_count = cnt + PW * P.B;
-            hipLaunchKernelGGL(k_msm_scatter_slots, grid1(n, (u32)PW), dim3(TPB), 0, C.stream, (u32)n, mw, d_probs, cnt, slots, cap, ovf_count, ovf, OVF_MAX);
+            if (C.msm_lds && n >= C.msm_lds_min && (size_t)P.B * 4 <= 128 * 1024) {
+                u32 n_side = (u32)(lr ? n / 2 : n);
+                u32 per_q = fb ? sets : P.W;
+                u32 tile = n_side;
+                // tile so that a block ranks ~128k items at most, and the launch has a few hundred blocks
+                u32 wps = fb ? mm.fb_wps : 1;
+                while (tile > 1024 && ((size_t)tile * wps > (size_t)C.msm_lds_tile || (size_t)((n_side + tile - 1) / tile) * nq * (lr ? 2 : 1) * per_q < 256)) tile /= 2;
+                dim3 grid((n_side + tile - 1) / tile, (u32)(nq * (lr ? 2 : 1) * per_q));
+                hipLaunchKernelGGL(k_msm_scatter_lds, grid, dim3(1024), (size_t)P.B * 4, C.stream, n_side, tile, mw, mm, d_probs, cnt, slots, cap, ovf_count, ovf, OVF_MAX);
+            } else
+            hipLaunchKernelGGL(k_msm_scatter_slots, grid1(n, (u32)(nq * Wgrid)), dim3(TPB), 0, C.stream, (u32)n, mw, mm, d_probs, cnt, slots, cap, ovf_count, ovf, OVF_MAX);
             hipLaunchKernelGGL(k_msm_scan, dim3((unsigned)PW), dim3(TPB), 0, C.stream, P.B, cnt, off, (u32 *)nullptr, perm);
             if (C.tm.enabled) { e0 = C.tm.get(); e1 = C.tm.get(); HIPCHK(hipEventRecord(e0, C.stream)); }
-            hipLaunchKernelGGL(k_msm_accumulate, grid1((size_t)P.W * P.B, (u32)np), dim3(TPB), 0, C.stream, (u32)n, P.c, P.W, d_probs, cnt, off, slots, perm, buckets, cap);
+            hipLaunchKernelGGL(k_msm_accumulate, grid1((size_t)Wb * P.B, (u32)nq), dim3(TPB), 0, C.stream, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, slots, perm, buckets, cap);
             if (C.tm.enabled) HIPCHK(hipEventRecord(e1, C.stream));
-            hipLaunchKernelGGL(k_msm_overflow, dim3(1), dim3(64), 0, C.stream, P.W, P.B, d_probs, ovf_count, ovf, OVF_MAX, buckets);
+            hipLaunchKernelGGL(k_msm_overflow, dim3(1), dim3(64), 0, C.stream, Wb, P.B, (u32)(np / nq), d_probs, ovf_count, ovf, OVF_MAX, buckets);
             HIPCHK(hipMemcpyAsync(C.h_ovf.as<u32>(4), ovf_count, 4, hipMemcpyDeviceToHost, C.stream));
         } else {
             u32 *sorted = C.msm_sorted.as<u32>(PW * n * 2);
-            hipLaunchKernelGGL(k_msm_count, grid1(n, (u32)PW), dim3(TPB), 0, C.stream, (u32)n, mw, d_probs, cnt);
+            hipLaunchKernelGGL(k_msm_count, grid1(n, (u32)(nq * Wgrid)), dim3(TPB), 0, C.stream, (u32)n, mw, mm, d_probs, cnt);
             hipLaunchKernelGGL(k_msm_scan, dim3((unsigned)PW), dim3(TPB), 0, C.stream, P.B, cnt, off, cur, perm);
-            hipLaunchKernelGGL(k_msm_scatter, grid1(n, (u32)PW), dim3(TPB), 0, C.stream, (u32)n, mw, d_probs, cur, sorted);
+            hipLaunchKernelGGL(k_msm_scatter, grid1(n, (u32)(nq * Wgrid)), dim3(TPB), 0, C.stream, (u32)n, mw, mm, d_probs, cur, sorted);
             if (C.tm.enabled) { e0 = C.tm.get(); e1 = C.tm.get(); HIPCHK(hipEventRecord(e0, C.stream)); }
-            hipLaunchKernelGGL(k_msm_accumulate, grid1((size_t)P.W * P.B, (u32)np), dim3(TPB), 0, C.stream, (u32)n, P.c, P.W, d_probs, cnt, off, sorted, perm, buckets, 0u);
+            hipLaunchKernelGGL(k_msm_accumulate, grid1((size_t)Wb * P.B, (u32)nq), dim3(TPB), 0, C.stream, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, sorted, perm, buckets, 0u);
             if (C.tm.enabled) HIPCHK(hipEventRecord(e1, C.stream));
         }
-        if (C.tm.enabled) { C.tm.acc_ev.push_back({e0, e1}); C.tm.t.msm_accumulate_launches++; char tg[96]; snprintf(tg, sizeof tg, "msm np=%zu n=%zu c=%u cap=%u", np, n, P.c, slots_ok ? cap : 0u); C.tm.acc_tag.push_back(tg); }
+        if (C.tm.enabled) { C.tm.acc_ev.push_back({e0, e1}); C.tm.t.msm_accumulate_launches++; char tg[96]; snprintf(tg, sizeof tg, "msm np=%zu n=%zu c=%u cap=%u fb=%u lr=%d", np, n, P.c, slots_mode ? cap : 0u, fb ? sets : 0u, (int)lr); C.tm.acc_tag.push_back(tg); }
         // reduction tree: global levels while more than 512 nodes remain, then one fused launch
         const ge *S_in = buckets; const ge *C_in = nullptr;
         u32 E = P.B, nb = 0, lv = 0;
@@ -363,27 +432,42 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
         HIPCHK(hipMemcpyAsync(hres, S_fin, sizeof(ge) * PW, hipMemcpyDeviceToHost, C.stream));
         HIPCHK(hipMemcpyAsync(hres + PW, C_fin, sizeof(ge) * PW * nb_final, hipMemcpyDeviceToHost, C.stream));
         HIPCHK(hipStreamSynchronize(C.stream));
-        if (slots_ok && getenv("ROFL_TRACE")) fprintf(stderr, "[rofl] msm np=%zu n=%zu c=%u cap=%u overflow=%u\n", np, n, P.c, cap, *C.h_ovf.as<u32>(4));
-        if (slots_ok && *C.h_ovf.as<u32>(4) > OVF_MAX) { slots_ok = false; continue; }    // pathological input: redo with the two-pass sort
+        if (slots_mode && getenv("ROFL_TRACE")) fprintf(stderr, "[rofl] msm np=%zu n=%zu c=%u cap=%u fb=%u lr=%d overflow=%u\n", np, n, P.c, cap, fb ? sets : 0u, (int)lr, *C.h_ovf.as<u32>(4));
+        if (slots_mode && *C.h_ovf.as<u32>(4) > OVF_MAX) continue;    // pathological input: next (slower, always sufficient) variant
+        fb_used = fb;
         break;
     }
     u32 nb = P.c - 1;
     ge *h = C.h_res.as<ge>(PW * (1 + nb));
     double t0 = now_ms();
     results.resize(np);
-    C.pool->run(np, [&](size_t p) {
-        ge5 acc = h51::identity(); bool started = false;
-        for (int w = (int)P.W - 1; w >= 0; w--) {
-            size_t pw = p * P.W + w;
-            int width = (u32)w + 1 == P.W ? (int)P.c + 1 : ((u32)w < P.wide ? (int)P.c : (int)P.c - 1);
-            for (int l = width - 1; l >= 0; l--) {
+    if (fb_used) {
+        // sets of a problem carry equal weight: add them up, then one 16-bit Horner
+        C.pool->run(np, [&](size_t p) {
+            size_t base = p * sets;                         // lr: problem 2q+side owns sets [(2q+side)*sets, ...)
+            ge5 acc = h51::identity(); bool started = false;
+            for (int l = 15; l >= 0; l--) {
                 if (started) acc = h51::gdouble(acc);
-                if (l <= (int)P.c - 2) { acc = h51::gadd(acc, h51::from_ge(h[PW + pw * nb + l])); started = true; }
-                if (l == 0) { acc = h51::gadd(acc, h51::from_ge(h[pw])); started = true; }
+                if (l <= 14) for (u32 s = 0; s < sets; s++) { acc = h51::gadd(acc, h51::from_ge(h[PW + (base + s) * nb + l])); started = true; }
+                if (l == 0) for (u32 s = 0; s < sets; s++) acc = h51::gadd(acc, h51::from_ge(h[base + s]));
             }
-        }
-        results[p] = acc;
-    });
+            results[p] = acc;
+        });
+    } else {
+        C.pool->run(np, [&](size_t p) {
+            ge5 acc = h51::identity(); bool started = false;
+            for (int w = (int)P.W - 1; w >= 0; w--) {
+                size_t pw = p * P.W + w;
+                int width = (u32)w + 1 == P.W ? (int)P.c + 1 : ((u32)w < P.wide ? (int)P.c : (int)P.c - 1);
+                for (int l = width - 1; l >= 0; l--) {
+                    if (started) acc = h51::gdouble(acc);
+                    if (l <= (int)P.c - 2) { acc = h51::gadd(acc, h51::from_ge(h[PW + pw * nb + l])); started = true; }
+                    if (l == 0) { acc = h51::gadd(acc, h51::from_ge(h[pw])); started = true; }
+                }
+            }
+            results[p] = acc;
+        });
+    }
     C.tm.t.host_ms += now_ms() - t0;
 }
 
@@ -405,8 +489,15 @@ sc sum_partials(const sc *p, size_t count, size_t stride, size_t which) {
 void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const u64 *d_vshift, const sc *d_blind,
                   const rofl_nonce_t *nonce, u64 nonce_base0, const uint8_t *h_V /* [P][m][32] host */, uint8_t *proofs_out) {
     size_t N = n * m; unsigned lgN = lg2u(N);
+    static const bool ptrace = getenv("ROFL_TRACE") && atoi(getenv("ROFL_TRACE")) >= 2;
+    double pt0 = now_ms(), ptl = pt0;
+    auto mark = [&](const char *what, long a = -1) {
+        if (!ptrace) return;
+        double t = now_ms(); fprintf(stderr, "[rofl-trace lane=%p] %-14s %6ld  +%.3f ms  (t=%.3f)\n", (void *)&C, what, a, t - ptl, t - pt0); ptl = t;
+    };
     size_t plen = 32 * (9 + 2 * (size_t)lgN);
     niels *tbl = get_gens(C, n, m);
+    const niels *wtab = find_wtab(C, tbl);
     ChunkParams *h_cp = C.h_cp.as<ChunkParams>(P);
     ChunkParams *d_cp = C.cp.as<ChunkParams>(P);
     memset(h_cp, 0, sizeof(ChunkParams) * P);
@@ -441,7 +532,9 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
     std::vector<MsmProb> probs(P); std::vector<ge5> res;
     for (size_t c = 0; c < P; c++) probs[c] = MsmProb{tbl, Scanon + c * 2 * N};
     C.tm.t.msm_terms += P * 2 * N;
+    mark("setup");
     msm_run(C, probs, 2 * N, res);
+    mark("msm S");
 
     double th = now_ms();
     std::vector<Merlin> tr; tr.reserve(P);
@@ -506,6 +599,7 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
     HIPCHK(hipMemcpyAsync(d_cp, h_cp, sizeof(ChunkParams) * P, hipMemcpyHostToDevice, C.stream));
     sc *a = C.a.as<sc>(P * N), *b = C.b.as<sc>(P * N), *yinvpow = C.yinv.as<sc>(P * N);
     hipLaunchKernelGGL(k_lr_vec, grid1(N, (u32)P), dim3(TPB), 0, C.stream, (u32)n, (u32)m, d_cp, d_vshift, sL, sR, C.d_two_pow, a, b, yinvpow);
+    mark("poly/T/x");
 
     // ---- IPP rounds with lazily folded generators
     // Invariant: true G[j] = gscale * Gc[j], true H[j] = hscale * y^-j * Hc[j] for the materialised arrays Gc, Hc.
@@ -542,16 +636,21 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
         }
         HIPCHK(hipMemcpyAsync(d_stab, h_stab, sizeof(sc) * P * 2 * nstab, hipMemcpyHostToDevice, C.stream));
         sc *SL = C.SL.as<sc>(P * 2 * n_g), *SR = C.SR.as<sc>(P * 2 * n_g);
-        hipLaunchKernelGGL(k_ipp_scalars, grid1(n_g, (u32)P), dim3(TPB), 0, C.stream, (u32)n_g, (u32)n_k, d_stab, nstab, a, b, N, yinvpow, N, SL, SR);
+        bool merged = C.msm_lr != 0;
+        hipLaunchKernelGGL(k_ipp_scalars, grid1(n_g, (u32)P), dim3(TPB), 0, C.stream, (u32)n_g, (u32)n_k, d_stab, nstab, a, b, N, yinvpow, N, SL, SR, merged ? 1 : 0);
         u32 nblkI = (u32)std::min<size_t>(32, (nh + TPB - 1) / TPB);
         sc *ipart = C.tmp_out.as<sc>(P * 64 * 3);
         hipLaunchKernelGGL(k_ipp_inner, dim3(nblkI, (u32)P), dim3(TPB), 0, C.stream, (u32)nh, a, b, N, ipart);
         sc *h_ip = C.h_part.as<sc>(P * 64 * 3);
         HIPCHK(hipMemcpyAsync(h_ip, ipart, sizeof(sc) * P * nblkI * 2, hipMemcpyDeviceToHost, C.stream));
         std::vector<MsmProb> pr(2 * P);
-        for (size_t c = 0; c < P; c++) { pr[2 * c] = MsmProb{cur[c], SL + c * 2 * n_g}; pr[2 * c + 1] = MsmProb{cur[c], SR + c * 2 * n_g}; }
+        for (size_t c = 0; c < P; c++) { pr[2 * c] = MsmProb{cur[c], SL + c * 2 * n_g}; pr[2 * c + 1] = MsmProb{cur[c], (merged ? SL : SR) + c * 2 * n_g}; }
         C.tm.t.msm_terms += P * 2 * n_g;
-        msm_run(C, pr, 2 * n_g, res);
+        MsmOpt mo;
+        if (merged) { mo.lr_nh = (u32)nh; mo.lr_ng = (u32)n_g; }
+        if (first_level && wtab) { mo.fb_wtab = wtab; mo.fb_stride = 2 * N; }
+        msm_run(C, pr, 2 * n_g, res, mo);
+        mark("round msm", (long)(2 * n_g));
         th = now_ms();
         C.pool->run(P, [&](size_t c) {
             uint8_t *o = proofs_out + c * plen + 7 * 32 + 64 * round;
@@ -568,6 +667,7 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
         C.tm.t.host_ms += now_ms() - th;
         HIPCHK(hipMemcpyAsync(d_cp, h_cp, sizeof(ChunkParams) * P, hipMemcpyHostToDevice, C.stream));
         hipLaunchKernelGGL(k_ipp_fold_ab, grid1(nh, (u32)P), dim3(TPB), 0, C.stream, (u32)nh, d_cp, a, b, N);
+        mark("round host");
         r++;
         bool last = (round + 1 == lgN);
         unsigned t_now = first_level ? (unsigned)C.fold_t1 : (unsigned)C.fold_t;
@@ -656,6 +756,7 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
             }
             if (C.tm.enabled) { HIPCHK(hipEventRecord(e1, C.stream)); C.tm.fold_ev.push_back({e0, e1}); C.tm.t.fold_launches++; { char tg[96]; snprintf(tg, sizeof tg, "fold n_g=%zu nsrc=%u tab=%d", n_g, nsrc, (int)use_tab); C.tm.fold_tag.push_back(tg); } C.tm.t.fold_point_reads += (uint64_t)2 * P * n_g; }
             HIPCHK(hipStreamSynchronize(C.stream));   // digit / problem staging buffers are reused next time
+            mark("fold", (long)n_new);
             for (size_t c = 0; c < P; c++) { cur[c] = gnew + c * 2 * n_new; pu[c].clear(); pui[c].clear(); }
             n_g = n_new; r = 0; gsel ^= 1; first_level = false;
         }
@@ -706,6 +807,7 @@ int verify_chunks(Ctx &C, const char *label, size_t gens_capacity, size_t P, siz
     std::vector<char> dead(P, 0);
     if (N != ((size_t)1 << lg)) return ROFL_OK;    // VerificationError for every chunk
     niels *tbl = get_gens(C, n, m);
+    const niels *wtab = find_wtab(C, tbl);
     ChunkParams *h_cp = C.h_cp.as<ChunkParams>(P);
     ChunkParams *d_cp = C.cp.as<ChunkParams>(P);
     memset(h_cp, 0, sizeof(ChunkParams) * P);
@@ -793,7 +895,7 @@ int verify_chunks(Ctx &C, const char *label, size_t gens_capacity, size_t P, siz
     std::vector<MsmProb> pr(P); std::vector<ge5> resA, resB;
     for (size_t c = 0; c < P; c++) pr[c] = MsmProb{tbl, gh + c * 2 * N};
     C.tm.t.msm_terms += P * 2 * N;
-    msm_run(C, pr, 2 * N, resA);
+    { MsmOpt mo; if (const niels *wt = find_wtab(C, tbl)) { mo.fb_wtab = wt; mo.fb_stride = 2 * N; } msm_run(C, pr, 2 * N, resA, mo); }
     for (size_t c = 0; c < P; c++) pr[c] = MsmProb{aux_pts + c * naux, aux_scal + c * naux};
     C.tm.t.msm_terms += P * naux;
     msm_run(C, pr, naux, resB);

@@ -1,0 +1,25 @@
+"""Parity of the fixed-base / merged-L-R MSM paths at small sizes (run with ROFL_MSM_FB_MIN=64 etc.)."""
+import sys, os, numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import orc
+import rofl_project_code_amd as R
+R.set_device(0)
+rng = np.random.default_rng(11)
+bad = 0
+for d, nb, P, fb, ff in ((64, 8, 1, 16, 7), (256, 16, 2, 16, 7), (1000, 32, 4, 32, 7), (3000, 8, 4, 16, 7), (4096, 32, 1, 32, 7), (37, 64, 2, 64, 7)):
+    R.api.set_fp(fb, ff)
+    mn, mx = R.conversion32.get_clip_bounds(nb)
+    vals = np.clip(rng.uniform(mn, mx, size=d).astype(np.float32), mn, np.nextafter(np.float32(mx), np.float32(0)))
+    if d == 3000: vals[:] = 0          # structured scalars
+    bl = orc.rand_scalars(rng, d)
+    seed = bytes(rng.integers(0, 256, 32, dtype=np.uint8))
+    pr, cm = R.range_proof_vec.create_rangeproof(vals, bl, nb, P, nonce=R.Nonce.seeded(seed))
+    rc, opr, ocm = orc.create_rangeproof(vals, bl, nb, P, fb, ff, seed=seed)
+    ok = R.range_proof_vec.verify_rangeproof(pr, cm, nb, verifier_seed=b"\x05" * 32)
+    t = pr.copy(); t[0, 40] ^= 1
+    nok = R.range_proof_vec.verify_rangeproof(t, cm, nb, verifier_seed=b"\x05" * 32)
+    good = rc == 0 and (pr == opr).all() and (cm == ocm).all() and ok and not nok
+    print(d, nb, P, "OK" if good else "MISMATCH", flush=True)
+    bad += not good
+print("FB_SMALL", "PASS" if bad == 0 else "FAIL")
+sys.exit(bad)

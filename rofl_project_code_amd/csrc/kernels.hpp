@@ -10,8 +10,36 @@
 namespace rofl {
 
 #define TPB 256
+#ifndef ROFL_ACC_PREFETCH
+#define ROFL_ACC_PREFETCH 0
+#endif
 
 // ---------------------------------------------------------------- small helpers
+// A pointer read out of a descriptor in memory is "generic" to the compiler and its accesses become flat_*; every
+// such pointer here is device memory, and saying so turns them into global_* accesses.
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) v4u g_uint4;
+__device__ __forceinline__ niels gload_niels(const niels *p) {
+    niels r;
+    const g_uint4 *s = (const g_uint4 *)p;
+    v4u *d = reinterpret_cast<v4u *>(&r);
+#pragma unroll
+    for (int i = 0; i < 6; i++) d[i] = s[i];
+    return r;
+}
+__device__ __forceinline__ void gstore_niels(niels *p, const niels &v) {
+    g_uint4 *d = (g_uint4 *)p;
+    const v4u *s = reinterpret_cast<const v4u *>(&v);
+#pragma unroll
+    for (int i = 0; i < 6; i++) d[i] = s[i];
+}
+__device__ __forceinline__ sc gload_sc(const sc *p) {
+    sc r;
+    const g_uint4 *s = (const g_uint4 *)p;
+    v4u *d = reinterpret_cast<v4u *>(&r);
+    d[0] = s[0]; d[1] = s[1];
+    return r;
+}
 __device__ __forceinline__ niels load_niels(const niels *p) {
     niels r;
     const uint4 *s = reinterpret_cast<const uint4 *>(p);
@@ -41,6 +69,7 @@ __device__ __forceinline__ void store_ge(ge *p, const ge &v) {
     for (int i = 0; i < 8; i++) d[i] = s[i];
 }
 __device__ __forceinline__ nd load_nd(const niels *p) { return nd_unpack(load_niels(p)); }
+__device__ __forceinline__ nd gload_nd(const niels *p) { return nd_unpack(gload_niels(p)); }
 __device__ __forceinline__ gd load_gd(const ge *p) { return gd_unpack(load_ge(p)); }
 __device__ __forceinline__ void store_gd(ge *p, const gd &v) { store_ge(p, gd_pack(v)); }
 __device__ __forceinline__ sc load_sc(const sc *p) {
@@ -90,6 +119,8 @@ struct ChunkParams {
     sc yinvpow2[MAX_LG];             // y^-(2^b)
     sc zpow2[MAX_LG];                // z^(2^b)
     sc u[MAX_LG], uinv[MAX_LG];      // IPP challenges (verify: all rounds; prove: current round)
+    sc pend_u[MAX_LG], pend_ui[MAX_LG];   // prove: challenges not yet folded into the materialised generators
+    sc gscale, hscale;               // prove: common factors kept out of the materialised generators
     sc a_fin, b_fin;                 // verify: ipp a, b
     sc c_zz;                         // verify: c * z^2
     u64 nonce_base;                  // index of this chunk's first nonce
@@ -272,7 +303,7 @@ __global__ void __launch_bounds__(TPB) k_bitcommit(u32 n, u32 m, const u64 *vshi
     for (u32 i = 0; i < n; i++) {
         bool bit = (v >> i) & 1;
         const niels *p = bit ? &tbl[(size_t)j * n + i] : &tbl[N + (size_t)j * n + i];
-        acc = gd_madd(acc, load_nd(p), !bit);
+        acc = gd_madd(acc, gload_nd(p), !bit);
     }
     store_gd(&partial[(size_t)c * m + j], acc);
 }
@@ -375,15 +406,22 @@ __global__ void __launch_bounds__(TPB) k_lr_vec(u32 n, u32 m, const ChunkParams 
 // Lazily folded generators: the materialised arrays Gc/Hc have n_g entries; the logical vectors have
 // n_k = n_g >> r entries; true G[i] = sum_h stab[0][h] Gc[h*n_k+i], true H[i] = sum_h stab[1][h] y^-j Hc[j].
 // Writes canonical MSM scalars for L (SL) and R (SR) over [Gc | Hc].
-__global__ void __launch_bounds__(TPB) k_ipp_scalars(u32 n_g, u32 n_k, const sc *stab /* [chunk][2][nstab] */, u32 nstab, const sc *a, const sc *b, size_t ab_stride,
+__global__ void __launch_bounds__(TPB) k_ipp_scalars(u32 n_g, u32 n_k, u32 r, const ChunkParams *cp, const sc *a, const sc *b, size_t ab_stride,
                               const sc *yinvpow, size_t y_stride, sc *SL, sc *SR, int merged) {
     u32 c = blockIdx.y;
     u32 j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_g) return;
     u32 h = j / n_k, i = j % n_k, nh = n_k / 2;
     const sc *ac = a + c * ab_stride, *bc = b + c * ab_stride;
-    sc sG = load_sc(&stab[((size_t)c * 2 + 0) * nstab + h]);
-    sc sH = sc_montmul(load_sc(&stab[((size_t)c * 2 + 1) * nstab + h]), load_sc(&yinvpow[c * y_stride + j]));
+    // s_G(h) = gscale * prod_q (bit_q(h) ? u_q : u_q^-1), s_H(h) with u and u^-1 swapped; challenge q <-> bit r-1-q of h
+    sc sG = load_sc(&cp[c].gscale), sH = load_sc(&cp[c].hscale);
+    for (u32 q = 0; q < r; q++) {
+        bool bit = (h >> (r - 1 - q)) & 1;
+        sc up = load_sc(&cp[c].pend_u[q]), ui = load_sc(&cp[c].pend_ui[q]);
+        sG = sc_montmul(sG, bit ? up : ui);
+        sH = sc_montmul(sH, bit ? ui : up);
+    }
+    sH = sc_montmul(sH, load_sc(&yinvpow[c * y_stride + j]));
     sc *sl = SL + (size_t)c * 2 * n_g, *sr = SR + (size_t)c * 2 * n_g;
     if (merged) {      // one array, every term non-zero; the side of a term is a function of its index (MsmMap)
         bool lo = i < nh; u32 ii = lo ? nh + i : i - nh;
@@ -458,7 +496,7 @@ __global__ void __launch_bounds__(256) k_fold_gens(u32 n_new, u32 nsrc, FoldSeg 
             acc = gd_double(acc);
             for (u32 h = unit_first ? 1 : 0; h < nsrc; h++) {
                 int d = dg[h * 256 + bit];
-                if (d != 0) acc = gd_madd(acc, load_nd(&src[(size_t)h * n_new + i]), d < 0);
+                if (d != 0) acc = gd_madd(acc, gload_nd(&src[(size_t)h * n_new + i]), d < 0);
             }
         }
         for (int t = 0; t < lo; t++) acc = gd_double(acc);
@@ -470,8 +508,8 @@ __global__ void __launch_bounds__(256) k_fold_gens(u32 n_new, u32 nsrc, FoldSeg 
             for (u32 s2 = 1; s2 < K; s2++) acc = gd_add(acc, gd_unpack(lds[(s2 - 1) * 64 + threadIdx.x]));
     }
     if (active && k == 0) {
-        if (unit_first) acc = gd_madd(acc, load_nd(&src[i]), false);   // source 0 has scalar 1 (scale kept aside)
-        store_niels(&probs[q].dst[i], gd_to_niels(acc));
+        if (unit_first) acc = gd_madd(acc, gload_nd(&src[i]), false);   // source 0 has scalar 1 (scale kept aside)
+        gstore_niels(&probs[q].dst[i], gd_to_niels(acc));
     }
 }
 
@@ -502,7 +540,7 @@ __global__ void __launch_bounds__(256) k_fold_gens_tab(u32 n_new, u32 nsrc, Fold
                     int d = dg[(h * 4 + pc) * FOLD_TAB_DIGITS + bit];
                     if (d != 0) {
                         u32 e = (u32)((d < 0 ? -d : d) - 1) >> 1;
-                        acc = gd_madd(acc, load_nd(&src[(size_t)(pc * 4 + e) * stride + (size_t)h * n_new + i]), d < 0);
+                        acc = gd_madd(acc, gload_nd(&src[(size_t)(pc * 4 + e) * stride + (size_t)h * n_new + i]), d < 0);
                     }
                 }
             }
@@ -516,8 +554,8 @@ __global__ void __launch_bounds__(256) k_fold_gens_tab(u32 n_new, u32 nsrc, Fold
             for (u32 s2 = 1; s2 < K; s2++) acc = gd_add(acc, gd_unpack(lds[(s2 - 1) * 64 + threadIdx.x]));
     }
     if (active && k == 0) {
-        if (unit_first) acc = gd_madd(acc, load_nd(&src[i]), false);
-        store_niels(&probs[q].dst[i], gd_to_niels(acc));
+        if (unit_first) acc = gd_madd(acc, gload_nd(&src[i]), false);
+        gstore_niels(&probs[q].dst[i], gd_to_niels(acc));
     }
 }
 
@@ -581,7 +619,7 @@ __device__ __forceinline__ MsmItem msm_item(u32 n, const MsmWin &mw, const MsmMa
     u32 q = y / mw.W, w = y % mw.W;
     u32 side = 0, p = q;
     if (mm.lr_nh) { bool isL = i < mm.lr_ng ? (i & mm.lr_nh) != 0 : (i & mm.lr_nh) == 0; side = isL ? 0u : 1u; p = 2 * q + side; }
-    sc k = load_sc(&probs[p].scal[i]);
+    sc k = gload_sc(&probs[p].scal[i]);
     MsmItem it;
     u32 wpos, wwid; msm_window(mw, w, wpos, wwid);
     int d = msm_digit(k, wpos, wwid);
@@ -709,7 +747,7 @@ __global__ void __launch_bounds__(1024) k_msm_scatter_lds(u32 n_side, u32 tile_p
     __syncthreads();
     for (u32 k = k0 + threadIdx.x; k < k1; k += 1024) {
         u32 i = mm.lr_nh ? msm_side_term(mm, side, k) : k;
-        sc s = load_sc(&scal[i]);
+        sc s = gload_sc(&scal[i]);
         for (u32 w = w0; w < w1; w++) {
             u32 wpos, wwid; msm_window(mw, w, wpos, wwid);
             int d = msm_digit(s, wpos, wwid);
@@ -726,7 +764,7 @@ __global__ void __launch_bounds__(1024) k_msm_scatter_lds(u32 n_side, u32 tile_p
     __syncthreads();
     for (u32 k = k0 + threadIdx.x; k < k1; k += 1024) {
         u32 i = mm.lr_nh ? msm_side_term(mm, side, k) : k;
-        sc s = load_sc(&scal[i]);
+        sc s = gload_sc(&scal[i]);
         for (u32 w = w0; w < w1; w++) {
             u32 wpos, wwid; msm_window(mw, w, wpos, wwid);
             int d = msm_digit(s, wpos, wwid);
@@ -751,7 +789,7 @@ __global__ void k_msm_overflow(u32 W, u32 B, u32 pstep, const MsmProb *probs, co
         u32 bi = ovf[o].bucket, v = ovf[o].entry, p = bi / (W * B) * pstep;
         if ((bi & 63u) != threadIdx.x) continue;
         gd acc = load_gd(&buckets[bi]);
-        acc = gd_madd(acc, load_nd(&probs[p].pts[v & 0x7fffffffu]), (v >> 31) != 0);
+        acc = gd_madd(acc, gload_nd(&probs[p].pts[v & 0x7fffffffu]), (v >> 31) != 0);
         store_gd(&buckets[bi], acc);
     }
 }
@@ -770,10 +808,22 @@ __global__ void __launch_bounds__(TPB) k_msm_accumulate(u32 n, u32 c, u32 W, u32
     else lst = sorted + ((size_t)p * W + w) * n * 2 + off[bi];   // stride 2n: a top-window digit may emit two entries
     const niels *pts = probs[p * pstep].pts;
     gd acc = gd_identity();
+#if ROFL_ACC_PREFETCH
+    // software pipeline: the (random) point load of entry e+1 is in flight while entry e is added
+    u32 v = num ? lst[0] : 0u;
+    niels nxt = gload_niels(&pts[v & 0x7fffffffu]);
+    for (u32 e = 0; e < num; e++) {
+        niels cur = nxt; u32 vc = v;
+        v = lst[e + 1 < num ? e + 1 : e];
+        nxt = gload_niels(&pts[v & 0x7fffffffu]);
+        acc = gd_madd(acc, nd_unpack(cur), (vc >> 31) != 0);
+    }
+#else
     for (u32 e = 0; e < num; e++) {
         u32 v = lst[e];
-        acc = gd_madd(acc, load_nd(&pts[v & 0x7fffffffu]), (v >> 31) != 0);
+        acc = gd_madd(acc, gload_nd(&pts[v & 0x7fffffffu]), (v >> 31) != 0);
     }
+#endif
     store_gd(&buckets[bi], acc);
 }
 // Bucket reduction without doublings: sum_b (b+1) B_b = S + sum_l 2^l D_l, D_l = sum of buckets whose

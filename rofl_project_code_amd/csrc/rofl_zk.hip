@@ -338,7 +338,7 @@ MsmPlan msm_plan(size_t n) {
 // results[p] = sum_i scal[p][i] * pts[p][i]   (all problems have n terms).  Synchronises the stream.
 // opt.lr_nh != 0: `probs` holds (L, R) pairs that share a merged scalar array (see MsmMap); opt.fb: every problem's points
 // are the generator table `opt.fb_gens` (n terms from its start, slice stride opt.fb_stride) for which a window table exists.
-struct MsmOpt { u32 lr_nh = 0, lr_ng = 0; const niels *fb_wtab = nullptr; size_t fb_stride = 0; };
+struct MsmOpt { u32 lr_nh = 0, lr_ng = 0; const niels *fb_wtab = nullptr; size_t fb_stride = 0; std::function<void()> overlap; };   // overlap: host work to run while the kernels execute
 void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge5> &results, const MsmOpt &opt = MsmOpt()) {
     size_t np = probs.size();
     bool lr = opt.lr_nh != 0;
@@ -346,7 +346,7 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
     MsmProb *d_probs = C.msm_probs.as<MsmProb>(np);
     MsmProb *h_probs = C.h_probs.as<MsmProb>(np);
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    MsmPlan P{}; size_t PW = 0; bool fb_used = false; u32 sets = 0;
+    MsmPlan P{}; size_t PW = 0; bool fb_used = false, overlap_done = false; u32 sets = 0;
     for (int attempt = 0; attempt < 3; attempt++) {
         // attempt 0: fixed-base slots (if available) ; then generic slots ; then the two-pass sort
         bool fb = attempt == 0 && opt.fb_wtab != nullptr && C.msm_slots;
@@ -358,8 +358,8 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
         if (fb) {
             P = msm_plan_c(16);
             sets = C.msm_fb_sets;
-            // keep at least ~512k accumulate threads in flight
-            while (sets < 16 && (size_t)nq * (lr ? 2 : 1) * sets * P.B < ((size_t)1 << 19)) sets *= 2;
+            // keep at least ~1M accumulate threads in flight
+            while (sets < 16 && (size_t)nq * (lr ? 2 : 1) * sets * P.B < ((size_t)1 << 20)) sets *= 2;
             mm.fb_sets = sets; mm.fb_wps = 16 / sets; mm.fb_stride = (u32)opt.fb_stride;
             PW = nq * (lr ? 2 : 1) * sets; Wgrid = P.W;
             size_t per_side = lr ? n / 2 : n;
@@ -431,6 +431,7 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
         ge *hres = C.h_res.as<ge>(PW * per);
         HIPCHK(hipMemcpyAsync(hres, S_fin, sizeof(ge) * PW, hipMemcpyDeviceToHost, C.stream));
         HIPCHK(hipMemcpyAsync(hres + PW, C_fin, sizeof(ge) * PW * nb_final, hipMemcpyDeviceToHost, C.stream));
+        if (opt.overlap && !overlap_done) { opt.overlap(); overlap_done = true; }
         HIPCHK(hipStreamSynchronize(C.stream));
         if (slots_mode && getenv("ROFL_TRACE")) fprintf(stderr, "[rofl] msm np=%zu n=%zu c=%u cap=%u fb=%u lr=%d overflow=%u\n", np, n, P.c, cap, fb ? sets : 0u, (int)lr, *C.h_ovf.as<u32>(4));
         if (slots_mode && *C.h_ovf.as<u32>(4) > OVF_MAX) continue;    // pathological input: next (slower, always sufficient) variant
@@ -533,19 +534,29 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
     for (size_t c = 0; c < P; c++) probs[c] = MsmProb{tbl, Scanon + c * 2 * N};
     C.tm.t.msm_terms += P * 2 * N;
     mark("setup");
-    msm_run(C, probs, 2 * N, res);
-    mark("msm S");
-
-    double th = now_ms();
     std::vector<Merlin> tr; tr.reserve(P);
     std::vector<sc> a_bl(P), s_bl(P), y(P), z(P), zz(P), x(P), w(P);
     for (size_t c = 0; c < P; c++) tr.emplace_back(label, strlen(label));
+    {
+        MsmOpt mo; if (wtab) { mo.fb_wtab = wtab; mo.fb_stride = 2 * N; }
+        mo.overlap = [&]() {      // the transcript prefix (m commitments per chunk) does not depend on S: hash it while the MSM runs
+            double t0 = now_ms();
+            C.pool->run(P, [&](size_t c) {
+                Merlin &t = tr[c];
+                t.append("dom-sep", (const uint8_t *)"rangeproof v1", 13);
+                t.append_u64("n", n); t.append_u64("m", m);
+                for (size_t j = 0; j < m; j++) t.append("V", h_V + (c * m + j) * 32, 32);
+            });
+            C.tm.t.host_ms += now_ms() - t0;
+        };
+        msm_run(C, probs, 2 * N, res, mo);
+    }
+    mark("msm S");
+
+    double th = now_ms();
     C.pool->run(P, [&](size_t c) {
         uint8_t *o = proofs_out + c * plen;
         Merlin &t = tr[c];
-        t.append("dom-sep", (const uint8_t *)"rangeproof v1", 13);
-        t.append_u64("n", n); t.append_u64("m", m);
-        for (size_t j = 0; j < m; j++) t.append("V", h_V + (c * m + j) * 32, 32);
         a_bl[c] = h_canon(sum_partials(h_sc + c * nblkS * 3, nblkS, 3, 0));
         s_bl[c] = h_canon(sum_partials(h_sc + c * nblkS * 3, nblkS, 3, 1));
         ge5 A = h_fixed_mul(C.ht.Bb5, a_bl[c]);
@@ -591,6 +602,7 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
         sc_tobytes(o + 128, t_x); sc_tobytes(o + 160, t_x_bl); sc_tobytes(o + 192, e_bl);
         w[c] = t.challenge_scalar("w");
         h_cp[c].x = h_mont(x[c]);
+        h_cp[c].gscale = sc_one_mont(); h_cp[c].hscale = sc_one_mont();
         // InnerProductProof::create
         t.append("dom-sep", (const uint8_t *)"ipp v1", 6);
         t.append_u64("n", N);
@@ -618,26 +630,9 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
     };
     for (unsigned round = 0; round < lgN; round++) {
         size_t n_k = n_g >> r, nh = n_k / 2;
-        // products of the pending challenges: s[h] for h < 2^r, built by doubling (1 multiplication per entry)
-        u32 nstab = 1u << r;
-        sc *h_stab = C.h_stab.as<sc>(P * 2 * nstab);
-        sc *d_stab = C.stab.as<sc>(P * 2 * nstab);
-        for (size_t c = 0; c < P; c++) {
-            sc *sg = h_stab + (c * 2 + 0) * nstab, *sh = h_stab + (c * 2 + 1) * nstab;
-            sg[0] = gscale[c]; sh[0] = hscale[c];
-            for (unsigned q = 0; q < r; q++) {          // challenge q <-> bit (r-1-q) of h; process from the last challenge (bit 0) up
-                unsigned qq = r - 1 - q; u32 half = 1u << q;   // after this step entries [0, 2*half) are valid for bits 0..q
-                for (u32 hlow = 0; hlow < half; hlow++) {
-                    sc g0v = sg[hlow], h0v = sh[hlow];
-                    sg[hlow] = sc_montmul(g0v, pui[c][qq]); sg[hlow + half] = sc_montmul(g0v, pu[c][qq]);
-                    sh[hlow] = sc_montmul(h0v, pu[c][qq]); sh[hlow + half] = sc_montmul(h0v, pui[c][qq]);
-                }
-            }
-        }
-        HIPCHK(hipMemcpyAsync(d_stab, h_stab, sizeof(sc) * P * 2 * nstab, hipMemcpyHostToDevice, C.stream));
         sc *SL = C.SL.as<sc>(P * 2 * n_g), *SR = C.SR.as<sc>(P * 2 * n_g);
         bool merged = C.msm_lr != 0;
-        hipLaunchKernelGGL(k_ipp_scalars, grid1(n_g, (u32)P), dim3(TPB), 0, C.stream, (u32)n_g, (u32)n_k, d_stab, nstab, a, b, N, yinvpow, N, SL, SR, merged ? 1 : 0);
+        hipLaunchKernelGGL(k_ipp_scalars, grid1(n_g, (u32)P), dim3(TPB), 0, C.stream, (u32)n_g, (u32)n_k, r, d_cp, a, b, N, yinvpow, N, SL, SR, merged ? 1 : 0);
         u32 nblkI = (u32)std::min<size_t>(32, (nh + TPB - 1) / TPB);
         sc *ipart = C.tmp_out.as<sc>(P * 64 * 3);
         hipLaunchKernelGGL(k_ipp_inner, dim3(nblkI, (u32)P), dim3(TPB), 0, C.stream, (u32)nh, a, b, N, ipart);
@@ -662,6 +657,7 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
             sc u = tr[c].challenge_scalar("u");
             sc um = h_mont(u), uim = sc_invert_mont(um);
             h_cp[c].u[0] = um; h_cp[c].uinv[0] = uim;
+            h_cp[c].pend_u[pu[c].size()] = um; h_cp[c].pend_ui[pu[c].size()] = uim;
             pu[c].push_back(um); pui[c].push_back(uim);
         });
         C.tm.t.host_ms += now_ms() - th;
@@ -714,7 +710,7 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
                         top = std::max(top, std::max(t1, t2));
                     }
                 }
-                if (unit) { gscale[c] = sc_montmul(gscale[c], g0); hscale[c] = sc_montmul(hscale[c], h0); }
+                if (unit) { gscale[c] = sc_montmul(gscale[c], g0); hscale[c] = sc_montmul(hscale[c], h0); h_cp[c].gscale = gscale[c]; h_cp[c].hscale = hscale[c]; }
                 h_fp[2 * c] = FoldProb{cur[c], gnew + c * 2 * n_new};
                 h_fp[2 * c + 1] = FoldProb{cur[c] + n_g, gnew + c * 2 * n_new + n_new};
                 h_ftp[2 * c] = FoldTabProb{0u, gnew + c * 2 * n_new};
@@ -755,6 +751,7 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
                     hipLaunchKernelGGL(k_fold_gens, grid, block, (K - 1) * 64 * sizeof(ge), C.stream, (u32)n_new, nsrc, seg, (const FoldProb *)d_fpv, d_dig, unit);
             }
             if (C.tm.enabled) { HIPCHK(hipEventRecord(e1, C.stream)); C.tm.fold_ev.push_back({e0, e1}); C.tm.t.fold_launches++; { char tg[96]; snprintf(tg, sizeof tg, "fold n_g=%zu nsrc=%u tab=%d", n_g, nsrc, (int)use_tab); C.tm.fold_tag.push_back(tg); } C.tm.t.fold_point_reads += (uint64_t)2 * P * n_g; }
+            HIPCHK(hipMemcpyAsync(d_cp, h_cp, sizeof(ChunkParams) * P, hipMemcpyHostToDevice, C.stream));   // gscale / hscale
             HIPCHK(hipStreamSynchronize(C.stream));   // digit / problem staging buffers are reused next time
             mark("fold", (long)n_new);
             for (size_t c = 0; c < P; c++) { cur[c] = gnew + c * 2 * n_new; pu[c].clear(); pui[c].clear(); }

@@ -237,6 +237,13 @@ HD gd gd_double(const gd &p) {
     gd r; r.X = fd_mul(cT, cX); r.Y = fd_mul(cY, cZ); r.Z = fd_mul(cT, cZ); r.T = fd_mul(cX, cY);
     return r;
 }
+// affine niels form given 1/Z (batch inversions)
+HDN inline niels gd_to_niels_zinv(const gd &p, const fd &zi) {
+    fd x = fd_mul(p.X, zi), y = fd_mul(p.Y, zi);
+    niels r;
+    r.ypx = fd_pack(fd_add(y, x)); r.ymx = fd_pack(fd_sub(y, x)); r.t2d = fd_pack(fd_mul(fd_mul(x, y), fd_d2()));
+    return r;
+}
 HDN inline niels gd_to_niels(const gd &p) {
     fd zi = fd_invert(p.Z);
     fd x = fd_mul(p.X, zi), y = fd_mul(p.Y, zi);

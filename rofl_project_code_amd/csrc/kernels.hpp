@@ -163,21 +163,31 @@ __global__ void __launch_bounds__(TPB) k_gens_map(u32 total, const uint8_t *uni,
     store_niels(&tbl[t], ge_to_niels(p));
 }
 
-// odd multiples of the 2^(64q)-shifted generators (see k_fold_gens_tab); slice 0 is the plain table
-__global__ void __launch_bounds__(TPB) k_gens_tables(u32 total, niels *tbl16, size_t stride) {
-    u32 g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= total) return;
-    ge cur = ge_from_niels(load_niels(&tbl16[g]));
-    for (u32 q = 0; q < 4; q++) {
-        if (q > 0) store_niels(&tbl16[(size_t)(q * 4) * stride + g], ge_to_niels(cur));
-        ge p2 = ge_double(cur);
-        ge pk = ge_add(cur, p2);
-        store_niels(&tbl16[(size_t)(q * 4 + 1) * stride + g], ge_to_niels(pk));
-        pk = ge_add(pk, p2);
-        store_niels(&tbl16[(size_t)(q * 4 + 2) * stride + g], ge_to_niels(pk));
-        pk = ge_add(pk, p2);
-        store_niels(&tbl16[(size_t)(q * 4 + 3) * stride + g], ge_to_niels(pk));
-        if (q < 3) for (int t = 0; t < 64; t++) cur = ge_double(cur);
+// Fold tables (see k_fold_gens_tab): slice (q * E + e) = (2e + 1) * 2^(PB q) * P for the NP = 256 / PB pieces of a
+// scalar and the E = 2^(w-2) odd multiples of a width-w NAF; slice 0 is the plain generator table.
+// One thread per (generator, piece); the E conversions to affine share one inversion.
+struct FoldTabCfg { u32 pb, w, np, e; };
+#define FOLD_TAB_MAXE 16
+__global__ void __launch_bounds__(TPB) k_gens_tables(u32 total, FoldTabCfg cfg, niels *tbl, size_t stride) {
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 g = t % total, q = t / total;
+    if (q >= cfg.np) return;
+    gd cur = gd_unpack(ge_from_niels(load_niels(&tbl[g])));
+    for (u32 d = 0; d < q * cfg.pb; d++) cur = gd_double(cur);
+    gd p2 = gd_double(cur);
+    ge mult[FOLD_TAB_MAXE]; fd pref[FOLD_TAB_MAXE];
+    gd pk = cur;
+    for (u32 e = 0; e < cfg.e; e++) {
+        if (e) pk = gd_add(pk, p2);
+        mult[e] = gd_pack(pk);
+        pref[e] = e ? fd_mul(pref[e - 1], pk.Z) : pk.Z;
+    }
+    fd inv = fd_invert(pref[cfg.e - 1]);
+    for (int e = (int)cfg.e - 1; e >= 0; e--) {
+        gd m = gd_unpack(mult[e]);
+        fd zi = e ? fd_mul(inv, pref[e - 1]) : inv;
+        inv = fd_mul(inv, m.Z);
+        if (q || e) store_niels(&tbl[(size_t)(q * cfg.e + e) * stride + g], gd_to_niels_zinv(m, zi));
     }
 }
 
@@ -519,8 +529,8 @@ __global__ void __launch_bounds__(256) k_fold_gens(u32 n_new, u32 nsrc, FoldSeg 
 // ~51 instead of ~84 mixed additions per source.  HBM capacity (16 x 50 MB at N = 262144) traded for VALU work.
 #define FOLD_TAB_DIGITS 72
 struct FoldTabProb { u32 src_off; niels *dst; };
-__global__ void __launch_bounds__(256) k_fold_gens_tab(u32 n_new, u32 nsrc, FoldSeg seg, const niels *tbl16, size_t stride,
-                                                       const FoldTabProb *probs, const int8_t *dig /* [prob][nsrc][4][72] */, int unit_first) {
+__global__ void __launch_bounds__(256) k_fold_gens_tab(u32 n_new, u32 nsrc, FoldSeg seg, FoldTabCfg cfg, const niels *tbl16, size_t stride,
+                                                       const FoldTabProb *probs, const int8_t *dig /* [prob][nsrc][np][72] */, int unit_first) {
     extern __shared__ __align__(16) unsigned char smem[];
     ge *lds = reinterpret_cast<ge *>(smem);
     u32 q = blockIdx.y;
@@ -528,19 +538,18 @@ __global__ void __launch_bounds__(256) k_fold_gens_tab(u32 n_new, u32 nsrc, Fold
     u32 k = threadIdx.y, K = blockDim.y;
     bool active = i < n_new;
     const niels *src = tbl16 + probs[q].src_off;
-    const int8_t *dg = dig + (size_t)q * nsrc * 4 * FOLD_TAB_DIGITS;
+    const int8_t *dg = dig + (size_t)q * nsrc * cfg.np * FOLD_TAB_DIGITS;
     gd acc = gd_identity();
     if (active) {
         int lo = seg.lo[k], hi = seg.lo[k + 1] - 1;
         for (int bit = hi; bit >= lo; bit--) {
             acc = gd_double(acc);
             for (u32 h = unit_first ? 1 : 0; h < nsrc; h++) {
-#pragma unroll
-                for (u32 pc = 0; pc < 4; pc++) {
-                    int d = dg[(h * 4 + pc) * FOLD_TAB_DIGITS + bit];
+                for (u32 pc = 0; pc < cfg.np; pc++) {
+                    int d = dg[(h * cfg.np + pc) * FOLD_TAB_DIGITS + bit];
                     if (d != 0) {
                         u32 e = (u32)((d < 0 ? -d : d) - 1) >> 1;
-                        acc = gd_madd(acc, gload_nd(&src[(size_t)(pc * 4 + e) * stride + (size_t)h * n_new + i]), d < 0);
+                        acc = gd_madd(acc, gload_nd(&src[(size_t)(pc * cfg.e + e) * stride + (size_t)h * n_new + i]), d < 0);
                     }
                 }
             }

@@ -62,11 +62,13 @@ int sc_naf(int8_t out[256], const sc &k) {
 }
 
 // width-4 NAF (digits in +-{1,3,5,7}) of a 64-bit piece; returns the highest non-zero position (-1 if zero)
-int wnaf4_u64(int8_t out[FOLD_TAB_DIGITS], u64 piece) {
+// width-w NAF of a piece of at most 64 bits: odd digits |d| < 2^(w-1), at most one non-zero among w consecutive positions
+int wnaf_u64(int8_t out[FOLD_TAB_DIGITS], u64 piece, unsigned w) {
     unsigned __int128 k = piece; int top = -1;
+    const int full = 1 << w, half = 1 << (w - 1);
     for (int pos = 0; pos < FOLD_TAB_DIGITS; pos++) {
         int d = 0;
-        if (k & 1) { d = (int)(k & 15); if (d >= 8) d -= 16; if (d >= 0) k -= (unsigned)d; else k += (unsigned)(-d); top = pos; }
+        if (k & 1) { d = (int)(k & (unsigned)(full - 1)); if (d >= half) d -= full; if (d >= 0) k -= (unsigned)d; else k += (unsigned)(-d); top = pos; }
         out[pos] = (int8_t)d; k >>= 1;
     }
     return top;
@@ -198,6 +200,8 @@ struct Ctx {
     niels *d_tabB = nullptr, *d_tabBb = nullptr;
     sc *d_two_pow = nullptr;
     std::map<std::pair<size_t, size_t>, niels *> gens;   // (n, m) -> [G(N) | H(N)]
+    std::map<const niels *, FoldTabCfg> foldcfg;         // generator table -> layout of its fold slices
+    u32 fold_pb = 32, fold_w = 6;
     std::map<const niels *, niels *> wtabs;              // generator table -> 16 window slices 2^(16w) P (fixed-base MSM)
     int msm_lds = 1; size_t msm_lds_min = 8192, msm_lds_tile = 131072;
     int msm_fb = 1; u32 msm_fb_sets = 4; size_t msm_fb_min = (size_t)1 << 17; int msm_lr = 1;
@@ -250,6 +254,8 @@ struct Ctx {
         { int nt = 8; if (const char *e = getenv("ROFL_HOST_THREADS")) nt = atoi(e); unsigned hc = std::thread::hardware_concurrency(); if (hc && (unsigned)nt > hc) nt = (int)hc; if (nt < 1) nt = 1; pool.reset(new HostPool(nt)); }
         if (const char *e = getenv("ROFL_FOLD_T1")) { int v = atoi(e); if (v >= 1 && v <= 6) fold_t1 = v; }
         if (const char *e = getenv("ROFL_FOLD_TAB")) fold_tab = atoi(e) != 0;
+        if (const char *e = getenv("ROFL_FOLD_PB")) { int v = atoi(e); if (v == 16 || v == 32 || v == 64) fold_pb = (u32)v; }
+        if (const char *e = getenv("ROFL_FOLD_W")) { int v = atoi(e); if (v >= 3 && v <= 6) fold_w = (u32)v; }
         if (const char *e = getenv("ROFL_FOLD_UNIT")) fold_unit = atoi(e) != 0;
         if (const char *e = getenv("ROFL_FOLD_K")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) fold_k = v; }
         if (const char *e = getenv("ROFL_FOLD_THREADS")) { long v = atol(e); if (v > 0) fold_threads = v; }
@@ -301,11 +307,15 @@ niels *get_gens(Ctx &C, size_t n, size_t m) {
     auto it = gens.find(key);
     if (it != gens.end()) return it->second;
     size_t N = n * m;
-    niels *tbl; HIPCHK(hipMalloc(&tbl, sizeof(niels) * 2 * N * 16));      // slice 0 = generators, 1..15 = fold tables
+    Ctx &Pm0 = C.parent ? *C.parent : C;
+    FoldTabCfg fc{Pm0.fold_pb, Pm0.fold_w, 256 / Pm0.fold_pb, 1u << (Pm0.fold_w - 2)};
+    if (sizeof(niels) * 2 * N * fc.np * fc.e > ((size_t)40 << 30)) fc = FoldTabCfg{64, 4, 4, 4};     // very large tables: the compact layout
+    niels *tbl; HIPCHK(hipMalloc(&tbl, sizeof(niels) * 2 * N * fc.np * fc.e));      // slice 0 = generators, the rest = fold tables
+    Pm0.foldcfg[tbl] = fc;
     uint8_t *uni = C.uni.as<uint8_t>(2 * N * 64);
     hipLaunchKernelGGL(k_gens_xof, grid1(2 * m), dim3(TPB), 0, C.stream, (u32)n, (u32)m, uni);
     hipLaunchKernelGGL(k_gens_map, grid1(2 * N), dim3(TPB), 0, C.stream, (u32)(2 * N), uni, tbl);
-    hipLaunchKernelGGL(k_gens_tables, grid1(2 * N), dim3(TPB), 0, C.stream, (u32)(2 * N), tbl, (size_t)(2 * N));
+    hipLaunchKernelGGL(k_gens_tables, grid1(2 * N * fc.np), dim3(TPB), 0, C.stream, (u32)(2 * N), fc, tbl, (size_t)(2 * N));
     Ctx &Pm = C.parent ? *C.parent : C;
     if (Pm.msm_fb && 2 * N >= Pm.msm_fb_min && 2 * N * 16 < ((size_t)1 << 31)) {      // entry index (w * 2N + i) must fit 31 bits
         niels *wt; HIPCHK(hipMalloc(&wt, sizeof(niels) * 2 * N * 16));
@@ -673,7 +683,8 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
             size_t n_new = n_g >> r; u32 nsrc = 1u << r;
             bool use_tab = first_level && C.fold_tab;
             int unit = C.fold_unit;
-            size_t dstride = use_tab ? (size_t)4 * FOLD_TAB_DIGITS : 256;
+            FoldTabCfg fc = (C.parent ? C.parent : &C)->foldcfg[tbl];
+            size_t dstride = use_tab ? (size_t)fc.np * FOLD_TAB_DIGITS : 256;
             th = now_ms();
             int8_t *h_dig = C.h_misc.as<int8_t>(2 * P * nsrc * dstride);
             memset(h_dig, 0, 2 * P * nsrc * dstride);
@@ -698,10 +709,14 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
                     }
                     sc gc = h_canon(g), hc = h_canon(hh);
                     if (use_tab) {
-                        for (int pc = 0; pc < 4; pc++) {
-                            u64 pg = (u64)gc.v[2 * pc] | ((u64)gc.v[2 * pc + 1] << 32), ph = (u64)hc.v[2 * pc] | ((u64)hc.v[2 * pc + 1] << 32);
-                            int t1 = wnaf4_u64(h_dig + (((2 * c) * nsrc + h) * 4 + pc) * FOLD_TAB_DIGITS, pg);
-                            int t2 = wnaf4_u64(h_dig + (((2 * c + 1) * nsrc + h) * 4 + pc) * FOLD_TAB_DIGITS, ph);
+                        for (u32 pc = 0; pc < fc.np; pc++) {
+                            auto piece = [&](const sc &s) {
+                                u32 bit0 = pc * fc.pb; u64 lo = (u64)s.v[bit0 / 32] | ((bit0 / 32 + 1 < 8) ? (u64)s.v[bit0 / 32 + 1] << 32 : 0);
+                                lo >>= (bit0 % 32);
+                                return fc.pb == 64 ? lo : (lo & (((u64)1 << fc.pb) - 1));
+                            };
+                            int t1 = wnaf_u64(h_dig + (((2 * c) * nsrc + h) * fc.np + pc) * FOLD_TAB_DIGITS, piece(gc), fc.w);
+                            int t2 = wnaf_u64(h_dig + (((2 * c + 1) * nsrc + h) * fc.np + pc) * FOLD_TAB_DIGITS, piece(hc), fc.w);
                             top = std::max(top, std::max(t1, t2));
                         }
                     } else {
@@ -732,7 +747,7 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
                 if (C.fold_k > 0) K = (u32)C.fold_k;
                 FoldSeg seg{};
                 double eff = (double)(nsrc - (unit ? 1 : 0));
-                double cst = 1.0 + (use_tab ? eff * 4.0 / 5.0 : eff / 3.0), lo_t = 0, hi_t = (top + 1) * cst + top + 1;
+                double cst = 1.0 + (use_tab ? eff * fc.np / (fc.w + 1.0) : eff / 3.0), lo_t = 0, hi_t = (top + 1) * cst + top + 1;
                 int bounds[FOLD_MAXSEG + 1];
                 for (int it = 0; it < 60; it++) {
                     double T = 0.5 * (lo_t + hi_t), pos = 0;
@@ -745,7 +760,7 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
                 for (u32 k = 0; k <= FOLD_MAXSEG; k++) seg.lo[k] = bounds[k <= K ? k : K];
                 dim3 grid((unsigned)((n_new + 63) / 64), (u32)(2 * P)), block(64, K);
                 if (use_tab)
-                    hipLaunchKernelGGL(k_fold_gens_tab, grid, block, (K - 1) * 64 * sizeof(ge), C.stream, (u32)n_new, nsrc, seg, tbl, (size_t)(2 * N),
+                    hipLaunchKernelGGL(k_fold_gens_tab, grid, block, (K - 1) * 64 * sizeof(ge), C.stream, (u32)n_new, nsrc, seg, fc, tbl, (size_t)(2 * N),
                                        (const FoldTabProb *)d_fpv, d_dig, unit);
                 else
                     hipLaunchKernelGGL(k_fold_gens, grid, block, (K - 1) * 64 * sizeof(ge), C.stream, (u32)n_new, nsrc, seg, (const FoldProb *)d_fpv, d_dig, unit);

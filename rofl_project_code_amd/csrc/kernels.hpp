@@ -122,7 +122,8 @@ struct ChunkParams {
     sc pend_u[MAX_LG], pend_ui[MAX_LG];   // prove: challenges not yet folded into the materialised generators
     sc gscale, hscale;               // prove: common factors kept out of the materialised generators
     sc a_fin, b_fin;                 // verify: ipp a, b
-    sc c_zz;                         // verify: c * z^2
+    sc c_zz;                         // verify: rho * c * z^2
+    sc rz, ra, rb, rzz;              // verify: rho * z, rho * a, rho * b, rho * z^2 (rho = weight of this proof in its batch)
     u64 nonce_base;                  // index of this chunk's first nonce
 };
 
@@ -943,27 +944,32 @@ __global__ void __launch_bounds__(TPB) k_add_points(u32 count, const uint8_t *a,
     ristretto_encode(out + (size_t)i * 32, ge_add(p, q));
 }
 // bulletproofs verify_multiple: g_k = -z - a s_k ; h_k = z + y^-k (zz z^j 2^i - b s_k^-1)  -> canonical [g | h]
-__global__ void __launch_bounds__(TPB) k_verify_scalars(u32 n, u32 m, u32 lgN, const ChunkParams *cp, const sc *two_pow, sc *out) {
-    u32 c = blockIdx.y;
+// One array of 2N scalars per batch of `group` consecutive proofs: sum_c rho_c * (g_c | h_c) -- the proofs of a batch
+// share the generators, so their G/H terms collapse into one MSM (rho_c is folded into rz, ra, rb, rzz by the host).
+__global__ void __launch_bounds__(TPB) k_verify_scalars(u32 n, u32 m, u32 lgN, u32 group, const ChunkParams *cp, const sc *two_pow, sc *out) {
+    u32 gidx = blockIdx.y;
     size_t N = (size_t)n * m;
     u32 k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= N) return;
-    const ChunkParams &P = cp[c];
-    sc s = sc_one_mont(), sinv = sc_one_mont();
-    for (u32 q = 0; q < lgN; q++) {
-        bool bit = (k >> (lgN - 1 - q)) & 1;    // challenge q (creation order) <-> bit lgN-1-q
-        s = sc_montmul(s, bit ? P.u[q] : P.uinv[q]);
-        sinv = sc_montmul(sinv, bit ? P.uinv[q] : P.u[q]);
-    }
     u32 j = k / n, i = k % n;
-    sc g = sc_neg(sc_add(P.z, sc_montmul(P.a_fin, s)));
-    sc zj2 = sc_montmul(sc_montmul(P.zz, sc_pow_tab(P.zpow2, j)), two_pow[i]);
-    sc h = sc_add(P.z, sc_montmul(sc_pow_tab(P.yinvpow2, k), sc_sub(zj2, sc_montmul(P.b_fin, sinv))));
-    sc *o = out + (size_t)c * 2 * N;
-    store_sc(&o[k], sc_from_mont(g));
-    store_sc(&o[N + k], sc_from_mont(h));
+    sc gacc = sc_zero(), hacc = sc_zero();
+    for (u32 cc = 0; cc < group; cc++) {
+        const ChunkParams &P = cp[gidx * group + cc];
+        sc s = sc_one_mont(), sinv = sc_one_mont();
+        for (u32 q = 0; q < lgN; q++) {
+            bool bit = (k >> (lgN - 1 - q)) & 1;    // challenge q (creation order) <-> bit lgN-1-q
+            s = sc_montmul(s, bit ? P.u[q] : P.uinv[q]);
+            sinv = sc_montmul(sinv, bit ? P.uinv[q] : P.u[q]);
+        }
+        sc g = sc_neg(sc_add(P.rz, sc_montmul(P.ra, s)));
+        sc zj2 = sc_montmul(sc_montmul(P.rzz, sc_pow_tab(P.zpow2, j)), two_pow[i]);
+        sc h = sc_add(P.rz, sc_montmul(sc_pow_tab(P.yinvpow2, k), sc_sub(zj2, sc_montmul(P.rb, sinv))));
+        gacc = sc_add(gacc, g); hacc = sc_add(hacc, h);
+    }
+    sc *o = out + (size_t)gidx * 2 * N;
+    store_sc(&o[k], sc_from_mont(gacc));
+    store_sc(&o[N + k], sc_from_mont(hacc));
 }
-// value-commitment scalars c * zz * z^j  -> canonical, written at out[chunk*stride + j]
 __global__ void __launch_bounds__(TPB) k_vscalars(u32 m, const ChunkParams *cp, sc *out, size_t stride) {
     u32 c = blockIdx.y;
     u32 j = blockIdx.x * blockDim.x + threadIdx.x;

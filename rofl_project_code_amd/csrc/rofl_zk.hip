@@ -799,8 +799,12 @@ sc verifier_c(const uint8_t seed[32], u64 idx) {
 }
 
 int verify_chunks(Ctx &C, const char *label, size_t gens_capacity, size_t P, size_t n, size_t m, const uint8_t *proofs, size_t plen,
-                  const uint8_t *h_V, const niels *d_Vniels, const uint8_t seed[32], const u64 *c_index, int *ok) {
+                  const uint8_t *h_V, const niels *d_Vniels, const uint8_t seed[32], const u64 *c_index, int *ok, size_t group = 1) {
+    // `group` consecutive proofs are checked as one batch: sum_c rho_c * (check_c) == 0 with random weights rho_c, so their
+    // generator terms share one MSM.  Every proof of a batch gets the batch's verdict (callers AND them per client anyway).
     for (size_t c = 0; c < P; c++) ok[c] = 0;
+    if (group == 0 || P % group) group = 1;
+    size_t ngroups = P / group;
     // RangeProof::from_bytes / InnerProductProof::from_bytes
     if (plen % 32 != 0 || plen < 7 * 32) return ROFL_FORMAT_ERROR;
     size_t ne = (plen - 7 * 32) / 32;
@@ -848,6 +852,7 @@ int verify_chunks(Ctx &C, const char *label, size_t gens_capacity, size_t P, siz
         t.append("t_x", p + 128, 32); t.append("t_x_blinding", p + 160, 32); t.append("e_blinding", p + 192, 32);
         sc w = t.challenge_scalar("w");
         sc cc = verifier_c(seed, c_index[c]);
+        sc rho = group > 1 ? verifier_c(seed, c_index[c] | (1ULL << 62)) : sc_one_plain();
         t.append("dom-sep", (const uint8_t *)"ipp v1", 6);
         t.append_u64("n", N);
         ChunkParams &cp = h_cp[c];
@@ -864,17 +869,18 @@ int verify_chunks(Ctx &C, const char *label, size_t gens_capacity, size_t P, siz
         cp.yinv = sc_invert_mont(cp.y);
         fill_pow2(cp.ypow2, cp.y, MAX_LG); fill_pow2(cp.yinvpow2, cp.yinv, MAX_LG); fill_pow2(cp.zpow2, cp.z, MAX_LG);
         cp.a_fin = h_mont(a); cp.b_fin = h_mont(b);
-        cp.c_zz = h_mont(h_mul(cc, zz));
+        cp.c_zz = h_mont(h_mul(rho, h_mul(cc, zz)));
+        cp.rz = h_mont(h_mul(rho, z)); cp.ra = h_mont(h_mul(rho, a)); cp.rb = h_mont(h_mul(rho, b)); cp.rzz = h_mont(h_mul(rho, zz));
         // aux points and scalars: A S T1 T2 L* R*
         uint8_t *ac = h_auxc + c * (4 + 2 * lg) * 32; sc *as = h_auxs + c * (4 + 2 * lg);
         memcpy(ac, p, 128);
-        as[0] = sc_one_plain(); as[1] = x; as[2] = h_mul(cc, x); as[3] = h_mul(as[2], x);
+        as[0] = rho; as[1] = h_mul(rho, x); as[2] = h_mul(as[1], cc); as[3] = h_mul(as[2], x);
         for (size_t k = 0; k < lg; k++) {
             memcpy(ac + 128 + 32 * k, ipp + 64 * k, 32); memcpy(ac + 128 + 32 * (lg + k), ipp + 64 * k + 32, 32);
-            as[4 + k] = h_mul(u[k], u[k]); as[4 + lg + k] = h_mul(ui[k], ui[k]);
+            as[4 + k] = h_mul(rho, h_mul(u[k], u[k])); as[4 + lg + k] = h_mul(rho, h_mul(ui[k], ui[k]));
         }
         // B_blinding: -e_bl - c t_x_bl ; B: w (t_x - a b) + c (delta - t_x)
-        sBb[c] = sc_neg(sc_add(e_bl, h_mul(cc, t_x_bl)));
+        sBb[c] = h_mul(rho, sc_neg(sc_add(e_bl, h_mul(cc, t_x_bl))));
         // sum_{i<N} y^i = prod_b (1 + y^(2^b)) for N = 2^lg ; likewise for 2^n and z^m
         auto geo = [&](const sc *pow2tab, unsigned bits) { sc acc = sc_one_mont(); for (unsigned q = 0; q < bits; q++) acc = sc_montmul(acc, sc_add(sc_one_mont(), pow2tab[q])); return h_canon(acc); };
         sc sum_y = geo(cp.ypow2, (unsigned)lg);
@@ -882,12 +888,12 @@ int verify_chunks(Ctx &C, const char *label, size_t gens_capacity, size_t P, siz
         sc twom[MAX_LG]; fill_pow2(twom, h_mont(sc_from_u64(2)), 8);
         sc sum_2 = geo(twom, lg2u(n));
         sc delta = sc_sub(h_mul(sc_sub(z, zz), sum_y), h_mul(h_mul(h_mul(zz, z), sum_2), sum_z));
-        sB[c] = sc_add(h_mul(w, sc_sub(t_x, h_mul(a, b))), h_mul(cc, sc_sub(delta, t_x)));
+        sB[c] = h_mul(rho, sc_add(h_mul(w, sc_sub(t_x, h_mul(a, b))), h_mul(cc, sc_sub(delta, t_x))));
     });
     C.tm.t.host_ms += now_ms() - th;
     HIPCHK(hipMemcpyAsync(d_cp, h_cp, sizeof(ChunkParams) * P, hipMemcpyHostToDevice, C.stream));
-    sc *gh = C.SL.as<sc>(P * 2 * N);
-    hipLaunchKernelGGL(k_verify_scalars, grid1(N, (u32)P), dim3(TPB), 0, C.stream, (u32)n, (u32)m, (u32)lg, d_cp, C.d_two_pow, gh);
+    sc *gh = C.SL.as<sc>(ngroups * 2 * N);
+    hipLaunchKernelGGL(k_verify_scalars, grid1(N, (u32)ngroups), dim3(TPB), 0, C.stream, (u32)n, (u32)m, (u32)lg, (u32)group, d_cp, C.d_two_pow, gh);
     // aux arrays
     niels *aux_pts = C.aux_pts.as<niels>(P * naux);
     sc *aux_scal = C.aux_scal.as<sc>(P * naux);
@@ -904,20 +910,23 @@ int verify_chunks(Ctx &C, const char *label, size_t gens_capacity, size_t P, siz
         HIPCHK(hipMemcpyAsync(aux_scal + c * naux + m, h_auxs + c * (4 + 2 * lg), sizeof(sc) * (4 + 2 * lg), hipMemcpyHostToDevice, C.stream));
     }
     u32 h_status = 0;
-    std::vector<MsmProb> pr(P); std::vector<ge5> resA, resB;
-    for (size_t c = 0; c < P; c++) pr[c] = MsmProb{tbl, gh + c * 2 * N};
-    C.tm.t.msm_terms += P * 2 * N;
+    std::vector<MsmProb> pr(ngroups); std::vector<ge5> resA, resB;
+    for (size_t g = 0; g < ngroups; g++) pr[g] = MsmProb{tbl, gh + g * 2 * N};
+    C.tm.t.msm_terms += ngroups * 2 * N;
     { MsmOpt mo; if (const niels *wt = find_wtab(C, tbl)) { mo.fb_wtab = wt; mo.fb_stride = 2 * N; } msm_run(C, pr, 2 * N, resA, mo); }
-    for (size_t c = 0; c < P; c++) pr[c] = MsmProb{aux_pts + c * naux, aux_scal + c * naux};
+    for (size_t g = 0; g < ngroups; g++) pr[g] = MsmProb{aux_pts + g * group * naux, aux_scal + g * group * naux};
     C.tm.t.msm_terms += P * naux;
-    msm_run(C, pr, naux, resB);
+    msm_run(C, pr, group * naux, resB);
     HIPCHK(hipMemcpy(&h_status, status, 4, hipMemcpyDeviceToHost));
     th = now_ms();
-    for (size_t c = 0; c < P; c++) {
-        ge5 tot = h51::gadd(resA[c], resB[c]);
-        tot = h51::gadd(tot, h_fixed_mul(C.ht.B5, sB[c]));
-        tot = h51::gadd(tot, h_fixed_mul(C.ht.Bb5, sBb[c]));
-        ok[c] = (!dead[c] && h51::is_identity_ristretto(tot)) ? 1 : 0;
+    for (size_t g = 0; g < ngroups; g++) {
+        ge5 tot = h51::gadd(resA[g], resB[g]);
+        sc b1 = sc_zero(), b2 = sc_zero(); bool any_dead = false;
+        for (size_t c = g * group; c < (g + 1) * group; c++) { b1 = sc_add(b1, sB[c]); b2 = sc_add(b2, sBb[c]); any_dead |= dead[c] != 0; }
+        tot = h51::gadd(tot, h_fixed_mul(C.ht.B5, b1));
+        tot = h51::gadd(tot, h_fixed_mul(C.ht.Bb5, b2));
+        int okg = (!any_dead && h51::is_identity_ristretto(tot)) ? 1 : 0;
+        for (size_t c = g * group; c < (g + 1) * group; c++) ok[c] = okg;
     }
     C.tm.t.host_ms += now_ms() - th;
     if (h_status & 4u) {
@@ -925,7 +934,7 @@ int verify_chunks(Ctx &C, const char *label, size_t gens_capacity, size_t P, siz
         // Re-check per chunk on the host to attribute the failure.
         for (size_t c = 0; c < P; c++) {
             const uint8_t *ac = h_auxc + c * (4 + 2 * lg) * 32;
-            for (size_t k = 0; k < 4 + 2 * lg; k++) { ge tmp; if (!ristretto_decode(tmp, ac + 32 * k)) ok[c] = 0; }
+            for (size_t k = 0; k < 4 + 2 * lg; k++) { ge tmp; if (!ristretto_decode(tmp, ac + 32 * k)) for (size_t c2 = c / group * group; c2 < (c / group + 1) * group; c2++) ok[c2] = 0; }
         }
     }
     return ROFL_OK;
@@ -1116,11 +1125,18 @@ int verify_impl(Ctx &C, size_t n_clients, const uint8_t *const *proofs, size_t p
     get_gens(C, prove_range, chunk);
     HIPCHK(hipStreamSynchronize(C.stream));
     int rc = 0; std::mutex rc_mu;
-    run_dual(C, P, [&](Ctx &Ln, size_t c0, size_t nc) {
-        int r = verify_chunks(Ln, "RangeProof", prove_range, nc, prove_range, chunk, pf.data() + c0 * proof_len, proof_len, Vh.data() + c0 * chunk * 32,
-                              d_vn2 + c0 * chunk, seed, cidx.data() + c0, okc.data() + c0);
-        if (r) { std::lock_guard<std::mutex> lk2(rc_mu); if (!rc) rc = r; }
-    });
+    static const bool vbatch = !(getenv("ROFL_VERIFY_BATCH") && atoi(getenv("ROFL_VERIFY_BATCH")) == 0);
+    size_t grp = vbatch ? nv : 1;
+    if (n_clients == 1) {
+        rc = verify_chunks(C, "RangeProof", prove_range, P, prove_range, chunk, pf.data(), proof_len, Vh.data(), d_vn2, seed, cidx.data(), okc.data(), grp);
+    } else {
+        run_dual(C, n_clients, [&](Ctx &Ln, size_t i0, size_t ni) {       // lanes split the clients; a client's chunks stay together
+            size_t c0 = i0 * nv, nc = ni * nv;
+            int r = verify_chunks(Ln, "RangeProof", prove_range, nc, prove_range, chunk, pf.data() + c0 * proof_len, proof_len, Vh.data() + c0 * chunk * 32,
+                                  d_vn2 + c0 * chunk, seed, cidx.data() + c0, okc.data() + c0, grp);
+            if (r) { std::lock_guard<std::mutex> lk2(rc_mu); if (!rc) rc = r; }
+        });
+    }
     timing_end(C);
     if (rc) return fail(rc, "proof rejected before verification (format / bitsize)");
     for (size_t i = 0; i < n_clients; i++) { int r = 1; for (size_t c = 0; c < nv; c++) r &= okc[i * nv + c]; ok_out[i] = r; }

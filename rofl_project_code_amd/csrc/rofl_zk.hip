@@ -336,7 +336,9 @@ const niels *find_wtab(Ctx &C, const niels *tbl) {
 // ---------------------------------------------------------------- MSM driver
 MsmPlan msm_plan(size_t n) {
     MsmPlan p;
-    if (n >= (1u << 17)) p.c = 16; else if (n >= (1u << 13)) p.c = 13; else if (n >= (1u << 9)) p.c = 10; else if (n >= 64) p.c = 7; else p.c = 4;
+    static const size_t t13 = getenv("ROFL_MSM_T13") ? (size_t)atol(getenv("ROFL_MSM_T13")) : ((size_t)1 << 13);
+    static const size_t t10 = getenv("ROFL_MSM_T10") ? (size_t)atol(getenv("ROFL_MSM_T10")) : ((size_t)1 << 9);
+    if (n >= (1u << 17)) p.c = 16; else if (n >= t13) p.c = 13; else if (n >= t10) p.c = 10; else if (n >= 64) p.c = 7; else p.c = 4;
     if (const char *e = getenv("ROFL_MSM_C")) { int v = atoi(e); if (v == 4 || v == 7 || v == 10 || v == 13 || v == 16) p.c = (u32)v; }
     p.W = (254 + p.c - 1) / p.c;
     p.W = (253 - p.c + p.c - 1) / p.c + 1;                // top window [253-c, 254) + ceil((253-c)/c) lower windows
@@ -373,7 +375,9 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
             mm.fb_sets = sets; mm.fb_wps = 16 / sets; mm.fb_stride = (u32)opt.fb_stride;
             PW = nq * (lr ? 2 : 1) * sets; Wgrid = P.W;
             size_t per_side = lr ? n / 2 : n;
-            cap = 16; while (cap < 2048 && (size_t)cap * P.B < 3 * per_side * mm.fb_wps) cap *= 2;
+            // the three (c-1)-bit windows of the layout fill only half of the buckets: twice the mean load there
+            cap = 16; while (cap < 2048 && (size_t)cap * P.B < 3 * per_side * (mm.fb_wps + 1)) cap *= 2;
+            if (mm.fb_wps == 1) cap *= 2;
             for (size_t i = 0; i < np; i++) h_probs[i] = MsmProb{opt.fb_wtab, probs[i].scal};
         } else {
             P = msm_plan(n);

@@ -1,4 +1,6 @@
-"""Parity of the fixed-base / merged-L-R MSM paths at small sizes (run with ROFL_MSM_FB_MIN=64 etc.)."""
+"""Helper for test_gpu_parity.py::test_msm_variants_small_sizes (run in a subprocess: the knobs are read once per process).
+Proofs, commitments and verdicts vs the oracle for small shapes, so that the code paths that normally only run at
+full size (fixed-base window tables, LDS-ranked scatter, two-pass sort, batched verification) are compared bit for bit."""
 import sys, os, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import orc

@@ -517,3 +517,18 @@ def test_bsgs_discrete_log(R):
     p8 = R.pedersen_ops.commit_no_blinding_vec(R.conversion32.f32_to_scalar_vec(v8))
     assert list(R.conversion32.scalar_to_f32_vec(R.pedersen_ops.default_discrete_log_vec(p8))) == list(v8)
     R.api.set_fp(16, 7)
+
+
+@pytest.mark.parametrize("env", [
+    {"ROFL_MSM_FB_MIN": "64", "ROFL_MSM_LDS_MIN": "32"},                 # fixed-base tables + LDS scatter at every size
+    {"ROFL_MSM_FB": "0", "ROFL_MSM_LDS_MIN": "32"},                      # generic windows through the LDS scatter
+    {"ROFL_MSM_FB_MIN": "64", "ROFL_MSM_LDS": "0"},                      # fixed-base through the per-item slot scatter
+    {"ROFL_MSM_SLOTS": "0", "ROFL_MSM_LR": "0"},                         # two-pass counting sort, separate L / R arrays
+    {"ROFL_VERIFY_BATCH": "0", "ROFL_FOLD_PB": "64", "ROFL_FOLD_W": "4", "ROFL_LANES": "1"},
+    {"ROFL_FOLD_PB": "16", "ROFL_FOLD_W": "5", "ROFL_FOLD_T1": "2", "ROFL_FOLD_MIN": "16"},
+])
+def test_msm_variants_small_sizes(R, env):
+    import subprocess, sys
+    e = dict(os.environ); e.update(env)
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "gpu_variant_check.py")], env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "FB_SMALL PASS" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

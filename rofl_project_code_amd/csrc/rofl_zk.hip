@@ -193,7 +193,7 @@ struct Ctx {
     bool inited = false;
     Ctx *parent = nullptr;
     std::vector<Ctx *> sibs;      // additional lanes
-    int nlanes = 2;
+    int nlanes = 1;      // ROFL_LANES: extra lanes only pay when one lane cannot keep the GPU busy (they did before the MSM rewrite)
     hipStream_t stream = nullptr;
     std::mutex mu;
     HostTables ht;

@@ -887,7 +887,25 @@ __global__ void __launch_bounds__(512) k_msm_reduce_fused(u32 E, u32 nb, const g
     // level 1: 8-ary
     u32 E8 = E / 8;
     ge *so = E8 == 1 ? fin_s : buf0, *co = E8 == 1 ? fin_c : buf0 + E8;
-    for (u32 item = threadIdx.x; item < E8 * (1 + nb); item += blockDim.x) msm_reduce_item(E, nb, si, ci, so, co, item);
+    // (latency-bound: the four outputs of an 8-group -- S and the three new bit-sums -- go to four threads, 7 / 3 additions
+    //  deep instead of one thread doing all 11)
+    for (u32 item = threadIdx.x; item < E8 * (4 + nb); item += blockDim.x) {
+        u32 role = item / E8, g = item % E8;
+        if (role >= 4) { msm_reduce_item(E, nb, si, ci, so, co, (role - 3) * E8 + g); continue; }
+        const ge *s = si + (size_t)g * 8;
+        if (role == 0) {
+            gd acc = gd_add(load_gd(&s[0]), load_gd(&s[1]));
+#pragma unroll 1
+            for (int t = 2; t < 8; t++) acc = gd_add(acc, load_gd(&s[t]));
+            so[g] = gd_pack(acc);
+        } else {
+            // bit (role-1) of the child index: children {1,3,5,7}, {2,3,6,7}, {4,5,6,7}
+            u32 b = role - 1, st = 1u << b;
+            u32 i0 = st, i1 = b == 0 ? 3 : (b == 1 ? 3 : 5), i2 = b == 0 ? 5 : 6, i3 = 7;
+            gd acc = gd_add(gd_add(load_gd(&s[i0]), load_gd(&s[i1])), gd_add(load_gd(&s[i2]), load_gd(&s[i3])));
+            co[(size_t)(nb + b) * E8 + g] = gd_pack(acc);
+        }
+    }
     __syncthreads();
     if (E8 == 1) return;
     u32 half = E8 * (1 + nb + 3);

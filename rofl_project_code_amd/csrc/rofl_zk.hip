@@ -201,6 +201,8 @@ struct Ctx {
     sc *d_two_pow = nullptr;
     std::map<std::pair<size_t, size_t>, niels *> gens;   // (n, m) -> [G(N) | H(N)]
     std::map<const niels *, FoldTabCfg> foldcfg;         // generator table -> layout of its fold slices
+    std::map<std::pair<size_t, size_t>, std::pair<u64, size_t>> gens_use;   // (n, m) -> (last use tick, bytes held)
+    u64 gens_tick = 0; size_t gens_budget = (size_t)96 << 30;   // ROFL_GENS_BUDGET_MB: evict least recently used tables beyond this
     u32 fold_pb = 32, fold_w = 6;
     std::map<const niels *, niels *> wtabs;              // generator table -> 16 window slices 2^(16w) P (fixed-base MSM)
     int msm_lds = 1; size_t msm_lds_min = 8192, msm_lds_tile = 131072;
@@ -254,6 +256,7 @@ struct Ctx {
         { int nt = 8; if (const char *e = getenv("ROFL_HOST_THREADS")) nt = atoi(e); unsigned hc = std::thread::hardware_concurrency(); if (hc && (unsigned)nt > hc) nt = (int)hc; if (nt < 1) nt = 1; pool.reset(new HostPool(nt)); }
         if (const char *e = getenv("ROFL_FOLD_T1")) { int v = atoi(e); if (v >= 1 && v <= 6) fold_t1 = v; }
         if (const char *e = getenv("ROFL_FOLD_TAB")) fold_tab = atoi(e) != 0;
+        if (const char *e = getenv("ROFL_GENS_BUDGET_MB")) { long v = atol(e); if (v >= 1) gens_budget = (size_t)v << 20; }
         if (const char *e = getenv("ROFL_FOLD_PB")) { int v = atoi(e); if (v == 16 || v == 32 || v == 64) fold_pb = (u32)v; }
         if (const char *e = getenv("ROFL_FOLD_W")) { int v = atoi(e); if (v >= 3 && v <= 6) fold_w = (u32)v; }
         if (const char *e = getenv("ROFL_FOLD_UNIT")) fold_unit = atoi(e) != 0;
@@ -304,10 +307,10 @@ MsmPlan msm_plan_c(u32 c) {
 niels *get_gens(Ctx &C, size_t n, size_t m) {
     auto key = std::make_pair(n, m);
     auto &gens = C.parent ? C.parent->gens : C.gens;      // the cache lives in the primary lane (filled before lanes fork)
-    auto it = gens.find(key);
-    if (it != gens.end()) return it->second;
-    size_t N = n * m;
     Ctx &Pm0 = C.parent ? *C.parent : C;
+    auto it = gens.find(key);
+    if (it != gens.end()) { Pm0.gens_use[key].first = ++Pm0.gens_tick; return it->second; }
+    size_t N = n * m;
     FoldTabCfg fc{Pm0.fold_pb, Pm0.fold_w, 256 / Pm0.fold_pb, 1u << (Pm0.fold_w - 2)};
     if (sizeof(niels) * 2 * N * fc.np * fc.e > ((size_t)40 << 30)) fc = FoldTabCfg{64, 4, 4, 4};     // very large tables: the compact layout
     niels *tbl; HIPCHK(hipMalloc(&tbl, sizeof(niels) * 2 * N * fc.np * fc.e));      // slice 0 = generators, the rest = fold tables
@@ -325,6 +328,26 @@ niels *get_gens(Ctx &C, size_t n, size_t m) {
     }
     HIPCHK(hipStreamSynchronize(C.stream));
     gens[key] = tbl;
+    size_t held = sizeof(niels) * 2 * N * fc.np * fc.e + (Pm.wtabs.count(tbl) ? sizeof(niels) * 2 * N * 16 : 0);
+    Pm0.gens_use[key] = {++Pm0.gens_tick, held};
+    // Keep the cache inside its HBM budget: drop the least recently used other configurations.  Only the primary lane
+    // creates tables (API entry, context mutex held, no lane running), so nothing can still be reading an evicted one.
+    if (!C.parent) {
+        for (;;) {
+            size_t total = 0; for (auto &u : Pm0.gens_use) total += u.second.second;
+            if (total <= Pm0.gens_budget || Pm0.gens_use.size() <= 1) break;
+            auto victim = Pm0.gens_use.end();
+            for (auto u = Pm0.gens_use.begin(); u != Pm0.gens_use.end(); ++u)
+                if (u->first != key && (victim == Pm0.gens_use.end() || u->second.first < victim->second.first)) victim = u;
+            if (victim == Pm0.gens_use.end()) break;
+            niels *vt = gens[victim->first];
+            auto w = Pm.wtabs.find(vt);
+            if (w != Pm.wtabs.end()) { HIPCHK(hipFree(w->second)); Pm.wtabs.erase(w); }
+            Pm0.foldcfg.erase(vt);
+            HIPCHK(hipFree(vt));
+            gens.erase(victim->first); Pm0.gens_use.erase(victim);
+        }
+    }
     return tbl;
 }
 const niels *find_wtab(Ctx &C, const niels *tbl) {
@@ -440,7 +463,7 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
         ge *S_fin = C.msm_S[lv & 1].as<ge>(PW);
         ge *C_fin = C.msm_C[lv & 1].as<ge>(PW * (size_t)nb_final);
         size_t lds = ((size_t)(E / 8) * (1 + nb + 3) + (size_t)(E / 16) * (1 + nb + 4) + 1) * sizeof(ge);
-        hipLaunchKernelGGL(k_msm_reduce_fused, dim3((unsigned)PW), dim3((E / 8) * (1 + nb) > 256 ? 512 : 256), lds, C.stream, E, nb, S_in, C_in, S_fin, C_fin, nb_final);
+        hipLaunchKernelGGL(k_msm_reduce_fused, dim3((unsigned)PW), dim3((E / 8) * (4 + nb) > 256 ? 512 : 256), lds, C.stream, E, nb, S_in, C_in, S_fin, C_fin, nb_final);
         size_t per = 1 + nb_final;
         ge *hres = C.h_res.as<ge>(PW * per);
         HIPCHK(hipMemcpyAsync(hres, S_fin, sizeof(ge) * PW, hipMemcpyDeviceToHost, C.stream));

@@ -526,6 +526,7 @@ def test_bsgs_discrete_log(R):
     {"ROFL_MSM_SLOTS": "0", "ROFL_MSM_LR": "0"},                         # two-pass counting sort, separate L / R arrays
     {"ROFL_VERIFY_BATCH": "0", "ROFL_FOLD_PB": "64", "ROFL_FOLD_W": "4", "ROFL_LANES": "1"},
     {"ROFL_FOLD_PB": "16", "ROFL_FOLD_W": "5", "ROFL_FOLD_T1": "2", "ROFL_FOLD_MIN": "16"},
+    {"ROFL_GENS_BUDGET_MB": "1", "ROFL_LANES": "2"},                      # every new (n, m) evicts the previous tables
 ])
 def test_msm_variants_small_sizes(R, env):
     import subprocess, sys

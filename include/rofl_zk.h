@@ -129,6 +129,9 @@ int rofl_verify_compressed_randproof(const uint8_t proof[128], const uint8_t *pa
 int rofl_commit_vec(const uint8_t *values32, const uint8_t *blindings32 /* NULL: commit_no_blinding_vec */,
                     size_t d, uint8_t *out32);                                   /* :9-25 */
 int rofl_add_points_vec(const uint8_t *a32, const uint8_t *b32, size_t d, uint8_t *out32);   /* :56-59 */
+/* sum of d compressed points read every `stride` bytes (stride >= 32): `iter().map(|x| x.c_sq).sum()` of params.rs:220, 277
+ * with stride 96 over SquareRandProofCommitments; d = 0 gives the identity. */
+int rofl_sum_points(const uint8_t *points, size_t d, size_t stride, uint8_t out32[32]);
 int rofl_shift_points(const uint8_t *a32, size_t d, const uint8_t offset32[32], uint8_t *out32); /* :103-108 */
 int rofl_f32_to_scalar_vec(const float *in, size_t d, unsigned fp_bits, unsigned fp_frac, uint8_t *out32); /* conversion32.rs:11-22 */
 int rofl_scalar_to_f32_vec(const uint8_t *in32, size_t d, unsigned fp_bits, unsigned fp_frac, float *out); /* conversion32.rs:24-39 */
@@ -141,6 +144,30 @@ int rofl_get_l2_clip_bounds(size_t range, unsigned fp_bits, unsigned fp_frac, fl
  * BSGS_URawFix.  bsgs_bits = 8 (fp8) or 16 (fp16/fp32/fp64 builds, fp.rs:42-108).  A point whose log is not found in
  * either direction returns 11 (the reference unwraps None). */
 int rofl_discrete_log_vec(const uint8_t *points32, size_t d, size_t table_size, unsigned bsgs_bits, uint8_t *scalars_out32);
+
+/* ---- wire formats of the encrypted update containers ----
+ * proto3 messages of rofl_service/proto/roflservice/flservice.proto:75-100, length-delimited as written by
+ * EncParamsRange::serialize (params.rs:513-527; EncParamsRangeCompressed :745-759 uses the same message with the 128-byte
+ * CompressedRandProof in rand_proof), EncParamsL2::serialize (:648-663) and EncParamsL2Compressed::serialize (:840-859).
+ * Payload fields are the to_bytes concatenations the entry points above produce / consume (ElGamalPair 64 B,
+ * SquareRandProofCommitments 96 B, RandProof 128 B, SquareRandProof 192 B, SquareProof 160 B, RangeProof per chunk).
+ * Fields a message kind does not have are ignored on encode and left empty on decode. */
+enum { ROFL_WIRE_ENC_RANGE = 0, ROFL_WIRE_ENC_NORM = 1, ROFL_WIRE_ENC_NORM_COMPRESSED = 2 };
+typedef struct {
+    int kind;
+    const uint8_t *enc_values;          size_t enc_values_len;
+    const uint8_t *rand_proof;          size_t rand_proof_len;
+    const uint8_t *square_proof;        size_t square_proof_len;
+    const uint8_t *range_proofs;        size_t range_proof_len, n_range_proofs;   /* [n][len] contiguous */
+    const uint8_t *square_range_proof;  size_t square_range_proof_len;
+    int32_t range_bits, l2_range_bits;
+    float check_percentage;
+} rofl_wire_msg_t;
+size_t rofl_wire_encoded_size(const rofl_wire_msg_t *m);
+int rofl_wire_encode(const rofl_wire_msg_t *m, uint8_t *out, size_t cap, size_t *len_out);
+/* Decode: spans point into `data`; the repeated range_proof entries are gathered into range_proofs_out (capacity in
+ * bytes; pass NULL first to learn n_range_proofs / range_proof_len).  Returns 5 (FormatError) on malformed input. */
+int rofl_wire_decode(int kind, const uint8_t *data, size_t len, rofl_wire_msg_t *m, uint8_t *range_proofs_out, size_t range_proofs_cap);
 
 /* ---- measurement hooks (bench.py) ---- */
 /* Time of the kernels of the last create / verify call, from HIP events on the library's stream. */

@@ -10,3 +10,5 @@ from .api import (  # noqa: F401
     RoflError, Nonce, lib, range_proof_vec, l2_range_proof_vec, pedersen_ops, conversion32, rand_proof_vec, square_rand_proof_vec, square_proof_vec, compressed_rand_proof,
     set_device, last_timing, set_timing, bench_femul,
 )
+from . import params  # noqa: F401,E402
+from .params import EncParamsRange, EncParamsRangeCompressed, EncParamsL2, EncParamsL2Compressed, EncModelParamsAccumulator, wire  # noqa: F401,E402

@@ -387,6 +387,24 @@ class pedersen_ops:
         return acc
 
     @staticmethod
+    def sum_rp_vec(points):
+        """Iterator::sum over RistrettoPoints (params.rs:220, 277)."""
+        p = _u8(points)
+        out = np.zeros(32, dtype=np.uint8)
+        _check(lib().rofl_sum_points(_ptr(p), _sz(p.shape[0]), _sz(32), _ptr(out)))
+        return out
+
+    @staticmethod
+    def rnd_scalar_vec(length):
+        """pedersen_ops.rs:124-127: Scalar::random = 64 uniform bytes reduced mod l (host RNG, as the reference's thread_rng)."""
+        L = 2 ** 252 + 27742317777372353535851937790883648493
+        raw = os.urandom(64 * length)
+        out = np.zeros((length, 32), dtype=np.uint8)
+        for i in range(length):
+            out[i] = np.frombuffer((int.from_bytes(raw[64 * i:64 * i + 64], "little") % L).to_bytes(32, "little"), dtype=np.uint8)
+        return out
+
+    @staticmethod
     def zero_rp_vec(length):
         return np.zeros((length, 32), dtype=np.uint8)   # identity compresses to 32 zero bytes
 

@@ -336,6 +336,29 @@ __global__ void __launch_bounds__(TPB) k_point_sum(const ge *in, u32 n, ge *out)
     if (t == 0) store_ge(&out[(size_t)p * gridDim.x + blockIdx.x], lds[0]);
 }
 
+// sum of compressed points (params.rs:220, 277: `enc_values.iter().map(|x| x.c_sq).sum()`): decode + grid-stride sum + LDS tree
+__global__ void __launch_bounds__(TPB) k_decode_sum(const uint8_t *in, u32 n, u32 stride, ge *out, u32 *status) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    ge *lds = reinterpret_cast<ge *>(smem);
+    u32 t = threadIdx.x;
+    ge acc = ge_identity();
+    for (u32 i = blockIdx.x * blockDim.x + t; i < n; i += gridDim.x * blockDim.x) {
+        __align__(16) uint8_t b[32];
+        const uint8_t *s = in + (size_t)i * stride;
+        for (int q = 0; q < 32; q++) b[q] = s[q];
+        ge p;
+        if (!ristretto_decode(p, b)) { atomicOr(status, 4u); p = ge_identity(); }
+        acc = ge_add(acc, p);
+    }
+    lds[t] = acc;
+    __syncthreads();
+    for (u32 s = blockDim.x / 2; s > 0; s >>= 1) {
+        if (t < s) lds[t] = ge_add(lds[t], lds[t + s]);
+        __syncthreads();
+    }
+    if (t == 0) store_ge(&out[blockIdx.x], lds[0]);
+}
+
 // ================================================================ party-level scalar sums
 // phase 0: sum a_bl, s_bl              -> out[chunk][blk][0..1]
 // phase 1: sum t1_bl, t2_bl, zz*z^j*vbl -> out[chunk][blk][0..2]

@@ -21,6 +21,7 @@
 
 #include "../../include/rofl_zk.h"
 #include "kernels.hpp"
+#include "wire.hpp"
 #include "host51.hpp"
 
 using namespace rofl;
@@ -1531,6 +1532,30 @@ int rofl_add_points_vec(const uint8_t *a32, const uint8_t *b32, size_t d, uint8_
         return ROFL_OK;
     });
 }
+int rofl_sum_points(const uint8_t *points, size_t d, size_t stride, uint8_t out32[32]) {
+    return guarded([&]() -> int {
+        Ctx &C = ctx(); std::lock_guard<std::mutex> lk(C.mu);
+        if (stride < 32 || !out32 || (d && !points)) return fail(ROFL_BAD_PARAM, "bad parameter");
+        if (d == 0) { memset(out32, 0, 32); return ROFL_OK; }      // empty sum = identity
+        C.init();
+        uint8_t *da = C.tmp_in.as<uint8_t>(d * stride);
+        u32 nblk = (u32)std::min<size_t>(64, (d + TPB - 1) / TPB);
+        ge *part = C.partial2.as<ge>(nblk);
+        u32 *status = C.status.as<u32>(4);
+        HIPCHK(hipMemsetAsync(status, 0, 16, C.stream));
+        HIPCHK(hipMemcpyAsync(da, points, stride * d, hipMemcpyHostToDevice, C.stream));
+        hipLaunchKernelGGL(k_decode_sum, dim3(nblk), dim3(TPB), TPB * sizeof(ge), C.stream, da, (u32)d, (u32)stride, part, status);
+        std::vector<ge> hp(nblk); u32 st = 0;
+        HIPCHK(hipMemcpyAsync(hp.data(), part, sizeof(ge) * nblk, hipMemcpyDeviceToHost, C.stream));
+        HIPCHK(hipMemcpyAsync(&st, status, 4, hipMemcpyDeviceToHost, C.stream));
+        HIPCHK(hipStreamSynchronize(C.stream));
+        if (st & 4u) return fail(ROFL_FORMAT_ERROR, "invalid Ristretto encoding");
+        ge5 acc = h51::identity();
+        for (u32 i = 0; i < nblk; i++) acc = h51::gadd(acc, h51::from_ge(hp[i]));
+        h51::encode(out32, acc);
+        return ROFL_OK;
+    });
+}
 int rofl_shift_points(const uint8_t *a32, size_t d, const uint8_t offset32[32], uint8_t *out32) {
     return guarded([&]() -> int {
         Ctx &C = ctx(); std::lock_guard<std::mutex> lk(C.mu);
@@ -1630,6 +1655,17 @@ int rofl_discrete_log_vec(const uint8_t *points32, size_t d, size_t table_size, 
         if (st & 8u) return fail(ROFL_BAD_PARAM, "discrete log not found (the reference unwraps None)");
         return ROFL_OK;
     });
+}
+size_t rofl_wire_encoded_size(const rofl_wire_msg_t *m) { return m ? wire::encoded_size(*m) : 0; }
+int rofl_wire_encode(const rofl_wire_msg_t *m, uint8_t *out, size_t cap, size_t *len_out) {
+    if (!m || !out) return fail(ROFL_BAD_PARAM, "bad parameter");
+    int rc = wire::encode(*m, out, cap, len_out);
+    return rc ? fail(rc, "wire encode: unknown message kind or output buffer too small") : ROFL_OK;
+}
+int rofl_wire_decode(int kind, const uint8_t *data, size_t len, rofl_wire_msg_t *m, uint8_t *range_proofs_out, size_t range_proofs_cap) {
+    if (!m || !data) return fail(ROFL_BAD_PARAM, "bad parameter");
+    int rc = wire::decode(kind, data, len, m, range_proofs_out, range_proofs_cap);
+    return rc ? fail(rc, rc == ROFL_FORMAT_ERROR ? "malformed message (prost's decode_length_delimited would return Err; the reference unwraps it)" : "bad parameter") : ROFL_OK;
 }
 int rofl_set_timing(int enabled) { return guarded([&]() -> int { Ctx &C = ctx(); std::lock_guard<std::mutex> lk(C.mu); C.tm.enabled = enabled != 0; return ROFL_OK; }); }
 int rofl_last_timing(rofl_timing_t *out) { return guarded([&]() -> int { Ctx &C = ctx(); std::lock_guard<std::mutex> lk(C.mu); *out = C.tm.t; return ROFL_OK; }); }

@@ -1,0 +1,325 @@
+"""Host-side mirror of the encrypted-update containers of rofl_service:
+
+    EncParamsRange / EncParamsRangeCompressed / EncParamsL2 / EncParamsL2Compressed
+        .encrypt(...)  .verify()  .serialize()  .deserialize(data)        rofl_service/src/flserver/params.rs:462-541, 683-775, 544-681, 790-885
+    EncModelParamsAccumulator (.unity, .accumulate_other, .extract)         params.rs:74-138
+
+Same names, argument meaning and composition as the reference; every group operation runs through the C ABI
+(include/rofl_zk.h) on the GPU, the wire codec (proto3, length-delimited) is the library's rofl_wire_* host code.
+Values are numpy byte arrays in the reference's to_bytes layouts: ElGamalPair 64 B (L | R), SquareRandProofCommitments
+96 B (L | R | c_sq), RandProof 128 B, SquareRandProof 192 B, SquareProof 160 B, CompressedRandProof 128 B, RangeProof per chunk.
+"""
+import ctypes
+import hashlib
+import os
+
+import numpy as np
+
+from . import api
+from .api import (RoflError, Nonce, lib, _check, _ptr, _sz, range_proof_vec, l2_range_proof_vec, rand_proof_vec,
+                  square_rand_proof_vec, square_proof_vec, compressed_rand_proof, pedersen_ops, conversion32)
+
+WIRE_ENC_RANGE, WIRE_ENC_NORM, WIRE_ENC_NORM_COMPRESSED = 0, 1, 2
+
+
+class _WireMsg(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int),
+                ("enc_values", ctypes.c_void_p), ("enc_values_len", ctypes.c_size_t),
+                ("rand_proof", ctypes.c_void_p), ("rand_proof_len", ctypes.c_size_t),
+                ("square_proof", ctypes.c_void_p), ("square_proof_len", ctypes.c_size_t),
+                ("range_proofs", ctypes.c_void_p), ("range_proof_len", ctypes.c_size_t), ("n_range_proofs", ctypes.c_size_t),
+                ("square_range_proof", ctypes.c_void_p), ("square_range_proof_len", ctypes.c_size_t),
+                ("range_bits", ctypes.c_int32), ("l2_range_bits", ctypes.c_int32), ("check_percentage", ctypes.c_float)]
+
+
+def _flat(a):
+    return np.ascontiguousarray(a, dtype=np.uint8).reshape(-1)
+
+
+class wire:
+    """rofl_wire_encode / rofl_wire_decode (flservice.proto:75-100)."""
+
+    @staticmethod
+    def encode(kind, enc_values=None, rand_proof=None, square_proof=None, range_proofs=None, square_range_proof=None,
+               range_bits=0, l2_range_bits=0, check_percentage=0.0):
+        keep = []
+        m = _WireMsg(); m.kind = kind
+
+        def put(name, arr):
+            if arr is None:
+                return
+            a = _flat(arr); keep.append(a)
+            setattr(m, name, a.ctypes.data if a.size else None); setattr(m, name + "_len", a.size)
+        put("enc_values", enc_values); put("rand_proof", rand_proof); put("square_proof", square_proof); put("square_range_proof", square_range_proof)
+        if range_proofs is not None:
+            rp = np.ascontiguousarray(range_proofs, dtype=np.uint8)
+            if rp.ndim < 2:
+                rp = rp.reshape(1, -1)
+            elif rp.ndim > 2 or rp.size == 0:
+                rp = rp.reshape(rp.shape[0], int(np.prod(rp.shape[1:])))
+            keep.append(rp)
+            m.range_proofs = rp.ctypes.data if rp.size else None; m.range_proof_len = rp.shape[1]; m.n_range_proofs = rp.shape[0]
+        m.range_bits, m.l2_range_bits, m.check_percentage = int(range_bits), int(l2_range_bits), float(check_percentage)
+        n = lib().rofl_wire_encoded_size(ctypes.byref(m))
+        out = np.zeros(max(n, 1), dtype=np.uint8); ln = ctypes.c_size_t()
+        _check(lib().rofl_wire_encode(ctypes.byref(m), _ptr(out), _sz(out.size), ctypes.byref(ln)))
+        return out[:ln.value].tobytes()
+
+    @staticmethod
+    def decode(kind, data):
+        buf = np.frombuffer(bytes(data), dtype=np.uint8)
+        m = _WireMsg()
+        _check(lib().rofl_wire_decode(kind, _ptr(buf), _sz(buf.size), ctypes.byref(m), None, _sz(0)))
+        rp = np.zeros((m.n_range_proofs, m.range_proof_len), dtype=np.uint8)
+        if rp.size:
+            _check(lib().rofl_wire_decode(kind, _ptr(buf), _sz(buf.size), ctypes.byref(m), _ptr(rp), _sz(rp.size)))
+        base = buf.ctypes.data
+
+        def span(name):
+            p, n = getattr(m, name), getattr(m, name + "_len")
+            return buf[p - base:p - base + n].copy() if p and n else np.zeros(0, dtype=np.uint8)
+        return {"enc_values": span("enc_values"), "rand_proof": span("rand_proof"), "square_proof": span("square_proof"),
+                "square_range_proof": span("square_range_proof"), "range_proofs": rp, "range_bits": m.range_bits,
+                "l2_range_bits": m.l2_range_bits, "check_percentage": m.check_percentage}
+
+
+lib().rofl_wire_encoded_size.restype = ctypes.c_size_t
+
+
+def _sub_nonce(seed, tag):
+    """Independent nonce streams for the proofs of one container (the reference draws all of them from thread_rng)."""
+    if seed is None:
+        return Nonce.random()
+    return Nonce.seeded(hashlib.sha3_256(b"rofl-zk/params/v1" + bytes(seed) + tag).digest())
+
+
+def _sub_seed(seed, tag):
+    return os.urandom(32) if seed is None else hashlib.sha3_256(b"rofl-zk/params/v1" + bytes(seed) + tag).digest()
+
+
+def _num_checked(d, check_percentage):
+    # (len as f32 * check_percentage).round() as usize  -- f32 arithmetic, round half away from zero (params.rs:192-193, 487)
+    x = np.float32(d) * np.float32(check_percentage)
+    return int(np.floor(np.float64(x) + 0.5)) if x >= 0 else 0
+
+
+class EncParamsRange:
+    """params.rs:456-541."""
+    kind = WIRE_ENC_RANGE
+
+    def __init__(self, enc_values, rand_proofs, range_proofs, prove_range, check_percentage):
+        self.enc_values = np.ascontiguousarray(enc_values, dtype=np.uint8).reshape(-1, 64)
+        self.rand_proofs = np.ascontiguousarray(rand_proofs, dtype=np.uint8).reshape(-1, 128)
+        self.range_proofs = np.ascontiguousarray(range_proofs, dtype=np.uint8)
+        self.prove_range, self.check_percentage = int(prove_range), float(check_percentage)
+
+    @classmethod
+    def encrypt(cls, plaintext_vec, blinding_vec, prove_range, n_partition, check_percentage, nonce_seed=None):
+        x = np.ascontiguousarray(plaintext_vec, dtype=np.float32)
+        bl = api._u8(blinding_vec)
+        clipped = range_proof_vec.clip_f32_to_range_vec(x, prove_range)
+        if check_percentage >= 1.0:
+            rp, enc_com = range_proof_vec.create_rangeproof(clipped, bl, prove_range, n_partition, nonce=_sub_nonce(nonce_seed, b"range"))
+            # NB the reference passes the un-clipped plaintext here (params.rs:499)
+            proofs, pairs = rand_proof_vec.create_randproof_vec_existing(x, enc_com, bl, nonce=_sub_nonce(nonce_seed, b"rand"))
+        else:
+            k = _num_checked(x.size, check_percentage)
+            rp, _ = range_proof_vec.create_rangeproof(clipped[:k], bl[:k], prove_range, n_partition, nonce=_sub_nonce(nonce_seed, b"range"))
+            proofs, pairs = rand_proof_vec.create_randproof_vec(x, bl, nonce=_sub_nonce(nonce_seed, b"rand"))
+        return cls(pairs, proofs, rp, prove_range, check_percentage)
+
+    def verify(self, verifier_seed=None):
+        """EncModelParams::verify, EncRange arm (params.rs:185-203): any Err counts as false."""
+        try:
+            ok = rand_proof_vec.verify_randproof_vec(self.rand_proofs, self.enc_values)
+            k = _num_checked(self.enc_values.shape[0], self.check_percentage)
+            ok_range = range_proof_vec.verify_rangeproof(self.range_proofs, self.enc_values[:k, :32], self.prove_range, verifier_seed=_sub_seed(verifier_seed, b"v"))
+        except RoflError:
+            return False
+        return bool(ok and ok_range)
+
+    def serialize(self):
+        return wire.encode(self.kind, enc_values=self.enc_values, rand_proof=self.rand_proofs, range_proofs=self.range_proofs,
+                           range_bits=self.prove_range, check_percentage=self.check_percentage)
+
+    @classmethod
+    def deserialize(cls, data):
+        m = wire.decode(cls.kind, data)
+        if m["enc_values"].size % 64 or m["rand_proof"].size % 128:
+            raise RoflError(5, "FormatError")
+        return cls(m["enc_values"], m["rand_proof"], m["range_proofs"], m["range_bits"], m["check_percentage"])
+
+    def pedersen_part(self):
+        return self.enc_values            # ElGamal pairs: accumulated as they are (gamal_accumulate)
+
+
+class EncParamsRangeCompressed(EncParamsRange):
+    """params.rs:683-775: same message, one CompressedRandProof (128 B) instead of d RandProofs."""
+
+    def __init__(self, enc_values, rand_proof, range_proofs, prove_range, check_percentage):
+        self.enc_values = np.ascontiguousarray(enc_values, dtype=np.uint8).reshape(-1, 64)
+        self.rand_proof = np.ascontiguousarray(rand_proof, dtype=np.uint8).reshape(-1)
+        self.range_proofs = np.ascontiguousarray(range_proofs, dtype=np.uint8)
+        self.prove_range, self.check_percentage = int(prove_range), float(check_percentage)
+
+    @classmethod
+    def encrypt(cls, plaintext_vec, blinding_vec, prove_range, n_partition, check_percentage, nonce_seed=None):
+        x = np.ascontiguousarray(plaintext_vec, dtype=np.float32)
+        bl = api._u8(blinding_vec)
+        clipped = range_proof_vec.clip_f32_to_range_vec(x, prove_range)
+        if check_percentage >= 1.0:
+            rp, enc_com = range_proof_vec.create_rangeproof(clipped, bl, prove_range, n_partition, nonce=_sub_nonce(nonce_seed, b"range"))
+            proof, pairs = compressed_rand_proof.helper_prove_existing(x, enc_com, bl, nonce=_sub_nonce(nonce_seed, b"rand"))
+        else:
+            k = _num_checked(x.size, check_percentage)
+            rp, _ = range_proof_vec.create_rangeproof(clipped[:k], bl[:k], prove_range, n_partition, nonce=_sub_nonce(nonce_seed, b"range"))
+            proof, pairs = compressed_rand_proof.helper_prove(x, bl, nonce=_sub_nonce(nonce_seed, b"rand"))
+        return cls(pairs, proof, rp, prove_range, check_percentage)
+
+    def verify(self, verifier_seed=None):
+        try:
+            if self.rand_proof.size != 128:
+                return False
+            ok = compressed_rand_proof.helper_verify(self.rand_proof, self.enc_values)
+            k = _num_checked(self.enc_values.shape[0], self.check_percentage)
+            ok_range = range_proof_vec.verify_rangeproof(self.range_proofs, self.enc_values[:k, :32], self.prove_range, verifier_seed=_sub_seed(verifier_seed, b"v"))
+        except RoflError:
+            return False
+        return bool(ok and ok_range)
+
+    def serialize(self):
+        return wire.encode(self.kind, enc_values=self.enc_values, rand_proof=self.rand_proof, range_proofs=self.range_proofs,
+                           range_bits=self.prove_range, check_percentage=self.check_percentage)
+
+    @classmethod
+    def deserialize(cls, data):
+        m = wire.decode(cls.kind, data)
+        if m["enc_values"].size % 64 or m["rand_proof"].size != 128:
+            raise RoflError(5, "FormatError")
+        return cls(m["enc_values"], m["rand_proof"], m["range_proofs"], m["range_bits"], m["check_percentage"])
+
+
+class EncParamsL2:
+    """params.rs:544-681: per-element SquareRandProofs, L-inf range proofs, one L2 sum range proof."""
+    kind = WIRE_ENC_NORM
+
+    def __init__(self, enc_values, square_proofs, range_proofs, square_range_proof, prove_range, l2_prove_range):
+        self.enc_values = np.ascontiguousarray(enc_values, dtype=np.uint8).reshape(-1, 96)
+        self.square_proofs = np.ascontiguousarray(square_proofs, dtype=np.uint8).reshape(-1, 192)
+        self.range_proofs = np.ascontiguousarray(range_proofs, dtype=np.uint8)
+        self.square_range_proof = np.ascontiguousarray(square_range_proof, dtype=np.uint8).reshape(-1)
+        self.prove_range, self.l2_prove_range = int(prove_range), int(l2_prove_range)
+
+    @classmethod
+    def encrypt(cls, plaintext_vec, blinding_vec, prove_range, n_partition, l2_range, nonce_seed=None, rand_scalars=None):
+        x = np.ascontiguousarray(plaintext_vec, dtype=np.float32)
+        bl = api._u8(blinding_vec)
+        r2 = pedersen_ops.rnd_scalar_vec(x.size) if rand_scalars is None else api._u8(rand_scalars)
+        clipped = range_proof_vec.clip_f32_to_range_vec(x, prove_range)
+        rp, enc_com = range_proof_vec.create_rangeproof(clipped, bl, prove_range, n_partition, nonce=_sub_nonce(nonce_seed, b"range"))
+        sum_proof, _ = l2_range_proof_vec.create_rangeproof_l2(clipped, r2, l2_range, n_partition, nonce=_sub_nonce(nonce_seed, b"l2"))
+        proofs, commits = square_rand_proof_vec.create_l2rangeproof_vec_existing(clipped, enc_com, bl, r2, nonce=_sub_nonce(nonce_seed, b"sq"))
+        return cls(commits, proofs, rp, sum_proof, prove_range, l2_range)
+
+    def _sum_c_sq(self):
+        return pedersen_ops.sum_rp_vec(self.enc_values[:, 64:96])
+
+    def verify(self, verifier_seed=None):
+        """EncModelParams::verify, EncL2 arm (params.rs:204-232)."""
+        try:
+            ok = square_rand_proof_vec.verify_l2rangeproof_vec(self.square_proofs, self.enc_values)
+            ok_range = range_proof_vec.verify_rangeproof(self.range_proofs, self.enc_values[:, :32], self.prove_range, verifier_seed=_sub_seed(verifier_seed, b"v"))
+            ok_sum = l2_range_proof_vec.verify_rangeproof_l2(self.square_range_proof, self._sum_c_sq(), self.l2_prove_range, verifier_seed=_sub_seed(verifier_seed, b"s"))
+        except RoflError:
+            return False
+        return bool(ok and ok_range and ok_sum)
+
+    def serialize(self):
+        return wire.encode(self.kind, enc_values=self.enc_values, square_proof=self.square_proofs, range_proofs=self.range_proofs,
+                           square_range_proof=self.square_range_proof, range_bits=self.prove_range, l2_range_bits=self.l2_prove_range)
+
+    @classmethod
+    def deserialize(cls, data):
+        m = wire.decode(cls.kind, data)
+        if m["enc_values"].size % 96 or m["square_proof"].size % 192:
+            raise RoflError(5, "FormatError")
+        return cls(m["enc_values"], m["square_proof"], m["range_proofs"], m["square_range_proof"], m["range_bits"], m["l2_range_bits"])
+
+    def pedersen_part(self):
+        return self.enc_values[:, :64]    # the ElGamal pair c of every SquareRandProofCommitments (l2_vec_accumulate)
+
+
+class EncParamsL2Compressed(EncParamsL2):
+    """params.rs:790-885: SquareProofs (160 B) + one CompressedRandProof; commitments kept as SquareRandProofCommitments."""
+    kind = WIRE_ENC_NORM_COMPRESSED
+
+    def __init__(self, enc_values, square_proofs, rand_proof, range_proofs, square_range_proof, prove_range, l2_prove_range):
+        self.enc_values = np.ascontiguousarray(enc_values, dtype=np.uint8).reshape(-1, 96)
+        self.square_proofs = np.ascontiguousarray(square_proofs, dtype=np.uint8).reshape(-1, 160)
+        self.rand_proof = np.ascontiguousarray(rand_proof, dtype=np.uint8).reshape(-1)
+        self.range_proofs = np.ascontiguousarray(range_proofs, dtype=np.uint8)
+        self.square_range_proof = np.ascontiguousarray(square_range_proof, dtype=np.uint8).reshape(-1)
+        self.prove_range, self.l2_prove_range = int(prove_range), int(l2_prove_range)
+
+    @classmethod
+    def encrypt(cls, plaintext_vec, blinding_vec, prove_range, n_partition, l2_range, nonce_seed=None, rand_scalars=None):
+        x = np.ascontiguousarray(plaintext_vec, dtype=np.float32)
+        bl = api._u8(blinding_vec)
+        r2 = pedersen_ops.rnd_scalar_vec(x.size) if rand_scalars is None else api._u8(rand_scalars)
+        clipped = range_proof_vec.clip_f32_to_range_vec(x, prove_range)
+        rp, enc_com = range_proof_vec.create_rangeproof(clipped, bl, prove_range, n_partition, nonce=_sub_nonce(nonce_seed, b"range"))
+        sum_proof, _ = l2_range_proof_vec.create_rangeproof_l2(clipped, r2, l2_range, n_partition, nonce=_sub_nonce(nonce_seed, b"l2"))
+        rand_proof, pairs = compressed_rand_proof.helper_prove_existing(clipped, enc_com, bl, nonce=_sub_nonce(nonce_seed, b"rand"))
+        sq_proofs, sq_commits = square_proof_vec.create_l2rangeproof_vec_existing(clipped, enc_com, bl, r2, nonce=_sub_nonce(nonce_seed, b"sq"))
+        merged = np.concatenate([pairs, sq_commits[:, 32:64]], axis=1)        # merge(): c = ElGamal pair, c_sq from the square proof (params.rs:777-787)
+        return cls(merged, sq_proofs, rand_proof, rp, sum_proof, prove_range, l2_range)
+
+    def verify(self, verifier_seed=None):
+        """EncModelParams::verify, EncL2Compressed arm (params.rs:255-289).  NB: as in the reference, the compressed
+        randomness proof itself is not re-checked here (the arm only verifies the square proofs, the range proofs and the sum)."""
+        try:
+            sqc = np.concatenate([self.enc_values[:, :32], self.enc_values[:, 64:96]], axis=1)      # SquareProofCommitments { c_l: c.L, c_sq }
+            ok = square_proof_vec.verify_l2rangeproof_vec(self.square_proofs, sqc)
+            ok_range = range_proof_vec.verify_rangeproof(self.range_proofs, self.enc_values[:, :32], self.prove_range, verifier_seed=_sub_seed(verifier_seed, b"v"))
+            ok_sum = l2_range_proof_vec.verify_rangeproof_l2(self.square_range_proof, self._sum_c_sq(), self.l2_prove_range, verifier_seed=_sub_seed(verifier_seed, b"s"))
+        except RoflError:
+            return False
+        return bool(ok and ok_range and ok_sum)
+
+    def serialize(self):
+        return wire.encode(self.kind, enc_values=self.enc_values, square_proof=self.square_proofs, rand_proof=self.rand_proof,
+                           range_proofs=self.range_proofs, square_range_proof=self.square_range_proof, range_bits=self.prove_range,
+                           l2_range_bits=self.l2_prove_range)
+
+    @classmethod
+    def deserialize(cls, data):
+        m = wire.decode(cls.kind, data)
+        if m["enc_values"].size % 96 or m["square_proof"].size % 160 or m["rand_proof"].size != 128:
+            raise RoflError(5, "FormatError")
+        return cls(m["enc_values"], m["square_proof"], m["rand_proof"], m["range_proofs"], m["square_range_proof"], m["range_bits"], m["l2_range_bits"])
+
+
+class EncModelParamsAccumulator:
+    """params.rs:74-138 (Enc variant): element-wise sum of ElGamal pairs, then unity check + BSGS extraction."""
+
+    def __init__(self, size):
+        self.acc = np.zeros((size, 64), dtype=np.uint8)        # ElGamalPair::unity() = (identity, identity) = 64 zero bytes
+
+    @classmethod
+    def unity(cls, size):
+        return cls(size)
+
+    def accumulate_other(self, other):
+        pairs = np.ascontiguousarray(other.pedersen_part(), dtype=np.uint8).reshape(-1, 64)
+        n = min(pairs.shape[0], self.acc.shape[0])             # zip() truncates
+        summed = pedersen_ops.add_rp_vec(self.acc[:n].reshape(-1, 32), pairs[:n].reshape(-1, 32))
+        self.acc[:n] = summed.reshape(-1, 64)
+        return True
+
+    def extract(self, table_size=None, bsgs_bits=16):
+        """None when some R component is not the identity (the blindings did not cancel), else the f32 aggregate."""
+        if np.any(self.acc[:, 32:64]):
+            return None
+        pts = np.ascontiguousarray(self.acc[:, :32])
+        sc = pedersen_ops.default_discrete_log_vec(pts) if table_size is None else pedersen_ops.discrete_log_vec(pts, table_size, bsgs_bits)
+        return conversion32.scalar_to_f32_vec(sc)

@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
 """Headline benchmark (BASELINE.json): range-proof elements/sec, create + verify, d = 25 000, 32-bit L-inf, P = 4.
 
-One "step" = one client's create_rangeproof + verify_rangeproof over d = 25 000 synthetic f32 values
-(uniform in the half-open clip interval, as rofl_crypto/benches/rangeproof_bench.rs:41-50), through the C ABI.
+One "step" = a batch of C clients (--clients-per-step, default 2), each running create_rangeproof + verify_rangeproof over
+d = 25 000 synthetic f32 values (uniform in the half-open clip interval, as rofl_crypto/benches/rangeproof_bench.rs:41-50)
+through the C ABI from its own host thread -- the library serves concurrent calls on separate lanes (streams + workspaces),
+which is how the reference's server drives this path (one rayon task per client, server.rs:656-687).  The sequential
+single-client latency is reported next to it (`single_client`).
 N > 1: one process per GPU; every rank runs its own clients (weak scaling), then proofs + commitments are
 all-gathered over RCCL and the verify bits MIN-all-reduced.  value = N * K * d / max-over-ranks wall time.
 """
@@ -79,6 +82,18 @@ def l2_composite(R, api, reps=3):
             "create_ms": best[1] * 1e3, "verify_ms": best[2] * 1e3}
 
 
+def avail_cores():
+    """Host cores this process may use: affinity mask capped by the cgroup CPU quota (the GPU boxes show 256 CPUs under a 16-core quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:      # noqa: BLE001
+        pass
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -87,7 +102,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8192)
     ap.add_argument("--no-l2", action="store_true")
+    ap.add_argument("--clients-per-step", type=int, default=0, help="clients in flight per GPU (0 = 3, fewer when host cores are scarce)")
     args = ap.parse_args()
+    CPS = args.clients_per_step if args.clients_per_step > 0 else max(1, min(3, avail_cores() // (4 * int(os.environ.get("LOCAL_WORLD_SIZE", "1")))))
+    os.environ.setdefault("ROFL_LANES", str(CPS))
 
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -118,7 +136,9 @@ def main():
     R.set_timing(True)
 
     total_steps = args.warmup + args.steps
-    clients = [synth_client(1000 * (s * world + rank)) for s in range(total_steps)]
+    clients = [synth_client(1000 * ((s * world + rank) * CPS + j)) for s in range(total_steps) for j in range(CPS)]
+    from concurrent.futures import ThreadPoolExecutor
+    workers = ThreadPoolExecutor(max_workers=CPS)
     agg = {"msm_accumulate_ms": 0.0, "msm_accumulate_launches": 0, "msm_terms": 0, "fold_ms": 0.0, "fold_launches": 0,
            "fold_point_reads": 0, "host_ms": 0.0, "total_ms": 0.0, "create_ms": 0.0, "verify_ms": 0.0}
 
@@ -128,23 +148,33 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def step(s, timed):
-        vals, bl = clients[s]
+    def one_client(idx, s):
+        """create + verify of one client; runs in a worker thread (ctypes releases the GIL inside the library)."""
+        vals, bl = clients[idx]
         t0 = time.perf_counter()
-        pr, cm = R.range_proof_vec.create_rangeproof(vals, bl, NBITS, NPART, nonce=R.Nonce.seeded(bytes([s % 256]) * 32))
+        pr, cm = R.range_proof_vec.create_rangeproof(vals, bl, NBITS, NPART, nonce=R.Nonce.seeded(bytes([idx % 256]) * 32))
         t1 = time.perf_counter()
         tc = R.last_timing()
         ok = R.range_proof_vec.verify_rangeproof(pr, cm, NBITS, verifier_seed=bytes([s % 256]) * 32)
         t2 = time.perf_counter()
         tv = R.last_timing()
-        if world > 1:       # the exchange step: server-side collection of proof bytes + commitments, verify bits
-            rd.gather_bytes(pr, cdev); rd.gather_bytes(cm, cdev)
-            ok = rd.all_verified(ok, cdev)
-        assert ok, "proof failed to verify"
-        if timed:
-            for k in ("msm_accumulate_ms", "msm_accumulate_launches", "msm_terms", "fold_ms", "fold_launches", "fold_point_reads", "host_ms", "total_ms"):
-                agg[k] += tc[k] + tv[k]
-            agg["create_ms"] += (t1 - t0) * 1e3; agg["verify_ms"] += (t2 - t1) * 1e3
+        return pr, cm, ok, tc, tv, (t1 - t0) * 1e3, (t2 - t1) * 1e3
+
+    def step(s, timed, cps=None):
+        cps = cps or CPS
+        if cps == 1:
+            res = [one_client(s * CPS, s)]
+        else:
+            res = list(workers.map(lambda j: one_client(s * CPS + j, s), range(cps)))
+        for pr, cm, ok, tc, tv, ms_c, ms_v in res:
+            if world > 1:       # the exchange step: server-side collection of proof bytes + commitments, verify bits
+                rd.gather_bytes(pr, cdev); rd.gather_bytes(cm, cdev)
+                ok = rd.all_verified(ok, cdev)
+            assert ok, "proof failed to verify"
+            if timed:
+                for k in ("msm_accumulate_ms", "msm_accumulate_launches", "msm_terms", "fold_ms", "fold_launches", "fold_point_reads", "host_ms", "total_ms"):
+                    agg[k] += tc[k] + tv[k]
+                agg["create_ms"] += ms_c; agg["verify_ms"] += ms_v
 
     for s in range(args.warmup):
         step(s, False)
@@ -159,9 +189,17 @@ def main():
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
 
+    # sequential single-client latency (outside the timed region)
+    single = None
+    if rank == 0 and world == 1:
+        lat = []
+        for s in range(min(3, total_steps)):
+            t = time.perf_counter(); step(s, False, cps=1); lat.append((time.perf_counter() - t) * 1e3)
+        single = {"ms_create_plus_verify": min(lat), "elements_per_s": D / (min(lat) * 1e-3)}
+
     if rank == 0:
         K = args.steps
-        value = world * K * D / elapsed
+        value = world * K * CPS * D / elapsed
         # dominant kernel by accumulated device time
         fold_alg = agg["fold_point_reads"] * 32.0            # generators counted compressed (32 B)
         acc_alg = agg["msm_terms"] * 32.0
@@ -186,11 +224,14 @@ def main():
             "metric": "range-proof elements/sec (create+verify), d=25k 32-bit", "value": value, "unit": "elements/s",
             "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": elapsed / K * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32x8 (255-bit integer field)", "data": "synthetic",
-            "config": {"workload": "L-inf 32-bit range proof, d=25000 (resnet18_intrinsic_25k), 1 client create+verify per step per GPU",
+            "config": {"workload": "L-inf 32-bit range proof, d=25000 (resnet18_intrinsic_25k), %d concurrent clients create+verify per step per GPU" % CPS,
+                       "clients_per_step": CPS, "host_cores": avail_cores(), "concurrency": "one host thread and one library lane (HIP stream + workspace) per client in flight",
                        "d": D, "prove_range": NBITS, "n_partition": NPART, "fp_bits": FP_BITS, "fp_frac": FP_FRAC,
                        "inputs": "host buffers at the C ABI (0.9 MB H2D per step inside the timed region)"},
-            "breakdown_ms_per_step": {"create": agg["create_ms"] / K, "verify": agg["verify_ms"] / K, "device": agg["total_ms"] / K,
-                                      "k_fold_gens": agg["fold_ms"] / K, "k_msm_accumulate": agg["msm_accumulate_ms"] / K, "host": agg["host_ms"] / K},
+            "breakdown_ms_per_client": {"create": agg["create_ms"] / (K * CPS), "verify": agg["verify_ms"] / (K * CPS), "device": agg["total_ms"] / (K * CPS),
+                                        "k_fold_gens": agg["fold_ms"] / (K * CPS), "k_msm_accumulate": agg["msm_accumulate_ms"] / (K * CPS), "host": agg["host_ms"] / (K * CPS),
+                                        "note": "wall / event times of each client while the other clients of the step are in flight"},
+            "single_client": single,
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "avg_launch_ms": kms / max(kl, 1), "launches_per_step": kl / K,

@@ -514,7 +514,7 @@ struct FoldProb { const niels *src; niels *dst; };
 // [seg.lo[k], seg.lo[k+1]) and finishes with seg.lo[k] plain doublings, so K threads share one output and the
 // launch has K times as many waves in flight (the chain is latency-bound at 2 waves/SIMD otherwise).
 struct FoldSeg { int lo[FOLD_MAXSEG + 1]; };
-__global__ void __launch_bounds__(256) k_fold_gens(u32 n_new, u32 nsrc, FoldSeg seg, const FoldProb *probs, const int8_t *naf /* [prob][nsrc][256] */, int unit_first) {
+__global__ void __launch_bounds__(256, 4) k_fold_gens(u32 n_new, u32 nsrc, FoldSeg seg, const FoldProb *probs, const int8_t *naf /* [prob][nsrc][256] */, int unit_first) {
     extern __shared__ __align__(16) unsigned char smem[];
     ge *lds = reinterpret_cast<ge *>(smem);
     u32 q = blockIdx.y;
@@ -553,7 +553,7 @@ __global__ void __launch_bounds__(256) k_fold_gens(u32 n_new, u32 nsrc, FoldSeg 
 // ~51 instead of ~84 mixed additions per source.  HBM capacity (16 x 50 MB at N = 262144) traded for VALU work.
 #define FOLD_TAB_DIGITS 72
 struct FoldTabProb { u32 src_off; niels *dst; };
-__global__ void __launch_bounds__(256) k_fold_gens_tab(u32 n_new, u32 nsrc, FoldSeg seg, FoldTabCfg cfg, const niels *tbl16, size_t stride,
+__global__ void __launch_bounds__(256, 4) k_fold_gens_tab(u32 n_new, u32 nsrc, FoldSeg seg, FoldTabCfg cfg, const niels *tbl16, size_t stride,
                                                        const FoldTabProb *probs, const int8_t *dig /* [prob][nsrc][np][72] */, int unit_first) {
     extern __shared__ __align__(16) unsigned char smem[];
     ge *lds = reinterpret_cast<ge *>(smem);

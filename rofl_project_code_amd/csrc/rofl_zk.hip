@@ -186,15 +186,19 @@ struct Timing {
 };
 
 // One Ctx = one "lane": a HIP stream with its own workspace, staging buffers, timing and host pool.  The primary
-// lane of a device owns the shared read-only state (fixed-base tables, generator cache); `second` is a sibling lane
-// used to run the two halves of a client's chunks concurrently, so that the latency-bound phases of one half
-// (small rounds, host Horner, folds) overlap the throughput-bound phases of the other.
+// lane of a device owns the shared read-only state (fixed-base tables, generator cache).  An API call runs on one
+// lane; concurrent calls from different host threads (the reference's server verifies clients from a thread pool,
+// server.rs:656-687) take different lanes, so the latency-bound phases of one call (small rounds, host Horner,
+// transcripts) overlap the throughput-bound phases of another.  ROFL_LANES = size of the pool.
 struct Ctx {
     int device = 0;
     bool inited = false;
     Ctx *parent = nullptr;
     std::vector<Ctx *> sibs;      // additional lanes
-    int nlanes = 1;      // ROFL_LANES: extra lanes only pay when one lane cannot keep the GPU busy (they did before the MSM rewrite)
+    int nlanes = 3;      // ROFL_LANES: number of calls that can be in flight on this device
+    std::mutex init_mu, gens_mu;      // primary lane only: one-time initialisation; generator-table cache
+    std::atomic<int> active_calls{0};  // primary lane only: calls currently holding a lane
+    std::atomic<unsigned> rr{0};
     hipStream_t stream = nullptr;
     std::mutex mu;
     HostTables ht;
@@ -290,6 +294,30 @@ Ctx &ctx() {
     return *it->second;
 }
 
+// A lane held for the duration of one API call.
+struct LaneLock {
+    Ctx *c = nullptr; Ctx *primary = nullptr; std::unique_lock<std::mutex> lk;
+    LaneLock() = default;
+    LaneLock(LaneLock &&o) noexcept : c(o.c), primary(o.primary), lk(std::move(o.lk)) { o.c = nullptr; o.primary = nullptr; }
+    ~LaneLock() { if (primary) primary->active_calls.fetch_sub(1); }
+};
+LaneLock acquire_lane(bool primary_only = false) {
+    Ctx &P = ctx();
+    { std::lock_guard<std::mutex> g(P.init_mu); P.init(); }
+    HIPCHK(hipSetDevice(P.device));                    // the calling thread may be new to HIP
+    LaneLock ll; ll.primary = &P; P.active_calls.fetch_add(1);
+    size_t L = primary_only ? 1 : 1 + P.sibs.size();
+    for (size_t i = 0; i < L; i++) {
+        Ctx *c = i ? P.sibs[i - 1] : &P;
+        std::unique_lock<std::mutex> t(c->mu, std::try_to_lock);
+        if (t.owns_lock()) { ll.c = c; ll.lk = std::move(t); return ll; }
+    }
+    size_t i = primary_only ? 0 : P.rr.fetch_add(1) % L;    // all busy: queue on one of them
+    Ctx *c = i ? P.sibs[i - 1] : &P;
+    ll.lk = std::unique_lock<std::mutex>(c->mu); ll.c = c;
+    return ll;
+}
+
 inline dim3 grid1(size_t n, u32 y = 1) { return dim3((unsigned)((n + TPB - 1) / TPB), y, 1); }
 unsigned lg2u(size_t x) { unsigned r = 0; while (((size_t)1 << r) < x) r++; return r; }
 bool is_pow2(size_t x) { return x && !(x & (x - 1)); }
@@ -306,6 +334,7 @@ MsmPlan msm_plan_c(u32 c) {
     return p;
 }
 niels *get_gens(Ctx &C, size_t n, size_t m) {
+    std::lock_guard<std::mutex> gens_lock((C.parent ? C.parent : &C)->gens_mu);
     auto key = std::make_pair(n, m);
     auto &gens = C.parent ? C.parent->gens : C.gens;      // the cache lives in the primary lane (filled before lanes fork)
     Ctx &Pm0 = C.parent ? *C.parent : C;
@@ -331,9 +360,9 @@ niels *get_gens(Ctx &C, size_t n, size_t m) {
     gens[key] = tbl;
     size_t held = sizeof(niels) * 2 * N * fc.np * fc.e + (Pm.wtabs.count(tbl) ? sizeof(niels) * 2 * N * 16 : 0);
     Pm0.gens_use[key] = {++Pm0.gens_tick, held};
-    // Keep the cache inside its HBM budget: drop the least recently used other configurations.  Only the primary lane
-    // creates tables (API entry, context mutex held, no lane running), so nothing can still be reading an evicted one.
-    if (!C.parent) {
+    // Keep the cache inside its HBM budget: drop the least recently used other configurations -- only while this is the
+    // one call in flight on the device (a call that starts meanwhile blocks on gens_mu and rebuilds what it needs).
+    if (Pm0.active_calls.load() <= 1) {       // nobody else can be reading a table
         for (;;) {
             size_t total = 0; for (auto &u : Pm0.gens_use) total += u.second.second;
             if (total <= Pm0.gens_budget || Pm0.gens_use.size() <= 1) break;
@@ -353,6 +382,7 @@ niels *get_gens(Ctx &C, size_t n, size_t m) {
 }
 const niels *find_wtab(Ctx &C, const niels *tbl) {
     Ctx &Pm = C.parent ? *C.parent : C;
+    std::lock_guard<std::mutex> gens_lock(Pm.gens_mu);
     auto it = Pm.wtabs.find(tbl);
     return it == Pm.wtabs.end() ? nullptr : it->second;
 }
@@ -711,7 +741,7 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
             size_t n_new = n_g >> r; u32 nsrc = 1u << r;
             bool use_tab = first_level && C.fold_tab;
             int unit = C.fold_unit;
-            FoldTabCfg fc = (C.parent ? C.parent : &C)->foldcfg[tbl];
+            FoldTabCfg fc; { Ctx *Pg = C.parent ? C.parent : &C; std::lock_guard<std::mutex> gens_lock(Pg->gens_mu); fc = Pg->foldcfg[tbl]; }
             size_t dstride = use_tab ? (size_t)fc.np * FOLD_TAB_DIGITS : 256;
             th = now_ms();
             int8_t *h_dig = C.h_misc.as<int8_t>(2 * P * nsrc * dstride);
@@ -999,48 +1029,24 @@ float l2_clip_bound(size_t range, unsigned fp_bits, unsigned fp_frac) {
 }
 bool valid_fp(unsigned fp_bits, unsigned fp_frac) { return (fp_bits == 8 || fp_bits == 16 || fp_bits == 32 || fp_bits == 64) && fp_frac <= 12 && fp_frac < fp_bits; }
 
+thread_local rofl_timing_t g_last_timing{};
 void timing_begin(Ctx &C) {
     C.tm.reset();
     if (C.tm.enabled) { C.tm.first = C.tm.get(); C.tm.last = C.tm.get(); HIPCHK(hipEventRecord(C.tm.first, C.stream)); }
 }
 void timing_end(Ctx &C) {
-    if (!C.tm.enabled) return;
+    if (!C.tm.enabled) { g_last_timing = C.tm.t; return; }
     HIPCHK(hipEventRecord(C.tm.last, C.stream));
     HIPCHK(hipEventSynchronize(C.tm.last));
     float ms = 0; HIPCHK(hipEventElapsedTime(&ms, C.tm.first, C.tm.last)); C.tm.t.total_ms = ms;
     bool trace = getenv("ROFL_TRACE") != nullptr;
     for (size_t i = 0; i < C.tm.acc_ev.size(); i++) { auto &e = C.tm.acc_ev[i]; HIPCHK(hipEventElapsedTime(&ms, e.first, e.second)); C.tm.t.msm_accumulate_ms += ms; if (trace) fprintf(stderr, "[rofl] %-40s accumulate %.3f ms\n", C.tm.acc_tag[i].c_str(), ms); }
     for (size_t i = 0; i < C.tm.fold_ev.size(); i++) { auto &e = C.tm.fold_ev[i]; HIPCHK(hipEventElapsedTime(&ms, e.first, e.second)); C.tm.t.fold_ms += ms; if (trace) fprintf(stderr, "[rofl] %-40s %.3f ms\n", C.tm.fold_tag[i].c_str(), ms); }
+    g_last_timing = C.tm.t;
 }
 
-// Run f(lane, first_chunk, n_chunks) over the lanes concurrently: the P chunks are split into contiguous groups.
-template <class F> void run_dual(Ctx &C, size_t P, F f) {
-    size_t L = std::min<size_t>(P, 1 + C.sibs.size());
-    if (L < 2) { f(C, (size_t)0, P); return; }
-    std::vector<size_t> start(L + 1);
-    for (size_t l = 0; l <= L; l++) start[l] = l * P / L;
-    std::vector<std::exception_ptr> err(L);
-    std::vector<HipErr> herr(L, HipErr{hipSuccess, nullptr});
-    std::vector<std::thread> th;
-    for (size_t l = 1; l < L; l++) {
-        Ctx *B = C.sibs[l - 1];
-        B->tm.enabled = C.tm.enabled;
-        th.emplace_back([&, l, B] {
-            try { HIPCHK(hipSetDevice(B->device)); timing_begin(*B); f(*B, start[l], start[l + 1] - start[l]); timing_end(*B); }
-            catch (const HipErr &e) { herr[l] = e; }
-            catch (...) { err[l] = std::current_exception(); }
-        });
-    }
-    try { f(C, start[0], start[1] - start[0]); } catch (...) { for (auto &t : th) t.join(); throw; }
-    for (auto &t : th) t.join();
-    for (size_t l = 1; l < L; l++) { if (herr[l].e != hipSuccess) throw herr[l]; if (err[l]) std::rethrow_exception(err[l]); }
-    for (size_t l = 1; l < L; l++) {      // merge the siblings' counters
-        Ctx &B = *C.sibs[l - 1];
-        C.tm.t.msm_accumulate_ms += B.tm.t.msm_accumulate_ms; C.tm.t.msm_accumulate_launches += B.tm.t.msm_accumulate_launches;
-        C.tm.t.msm_terms += B.tm.t.msm_terms; C.tm.t.fold_ms += B.tm.t.fold_ms; C.tm.t.fold_launches += B.tm.t.fold_launches;
-        C.tm.t.fold_point_reads += B.tm.t.fold_point_reads; C.tm.t.host_ms += B.tm.t.host_ms;
-    }
-}
+// (the intra-call split over lanes was retired when one lane became able to fill the GPU; lanes now serve concurrent calls)
+template <class F> void run_dual(Ctx &C, size_t P, F f) { f(C, (size_t)0, P); }
 
 template <class F> int guarded(F f) {
     try { return f(); }
@@ -1176,7 +1182,7 @@ int verify_impl(Ctx &C, size_t n_clients, const uint8_t *const *proofs, size_t p
 // ================================================================ C ABI
 extern "C" {
 
-int rofl_set_device(int device) { g_device = device; return guarded([&]() -> int { Ctx &C = ctx(); std::lock_guard<std::mutex> lk(C.mu); C.init(); return ROFL_OK; }); }
+int rofl_set_device(int device) { g_device = device; return guarded([&]() -> int { LaneLock lane_lock = acquire_lane(); Ctx &C = *lane_lock.c; C.init(); return ROFL_OK; }); }
 int rofl_last_error(char *buf, size_t len) { if (!buf || !len) return ROFL_BAD_PARAM; snprintf(buf, len, "%s", g_err.c_str()); return ROFL_OK; }
 size_t rofl_next_pow2(size_t v) { return v ? next_pow2(v) : 0; }
 size_t rofl_rangeproof_chunks(size_t d, size_t n_partition) {
@@ -1190,11 +1196,11 @@ size_t rofl_rangeproof_size(size_t n_bits, size_t d, size_t n_partition) {
 size_t rofl_nonces_per_chunk(size_t n_bits, size_t m) { return m * (2 * n_bits + 4); }
 
 int rofl_bp_gens_prepare(size_t n_bits, size_t m) {
-    return guarded([&]() -> int { Ctx &C = ctx(); std::lock_guard<std::mutex> lk(C.mu); C.init(); if (!n_bits || !m) return fail(ROFL_BAD_PARAM, "bad parameter"); get_gens(C, n_bits, m); return ROFL_OK; });
+    return guarded([&]() -> int { LaneLock lane_lock = acquire_lane(); Ctx &C = *lane_lock.c; C.init(); if (!n_bits || !m) return fail(ROFL_BAD_PARAM, "bad parameter"); get_gens(C, n_bits, m); return ROFL_OK; });
 }
 int rofl_bp_gens_export(size_t n_bits, size_t m, uint8_t *G_out, uint8_t *H_out) {
     return guarded([&]() -> int {
-        Ctx &C = ctx(); std::lock_guard<std::mutex> lk(C.mu); C.init();
+        LaneLock lane_lock = acquire_lane(); Ctx &C = *lane_lock.c; C.init();
         if (!n_bits || !m) return fail(ROFL_BAD_PARAM, "bad parameter");
         niels *tbl = get_gens(C, n_bits, m); size_t N = n_bits * m;
         // encode through the commit path: decode-free -- use k_msm-free helper: copy niels back and encode on host
@@ -1208,17 +1214,17 @@ int rofl_bp_gens_export(size_t n_bits, size_t m, uint8_t *G_out, uint8_t *H_out)
 int rofl_create_rangeproof(const float *values, size_t d, const uint8_t *blindings32, size_t d_blindings, size_t prove_range, size_t n_partition,
                            unsigned fp_bits, unsigned fp_frac, const rofl_nonce_t *nonce, uint8_t *proofs_out, size_t *proof_len_out,
                            size_t *n_proofs_out, uint8_t *commits_out) {
-    return guarded([&]() -> int { Ctx &C = ctx(); std::lock_guard<std::mutex> lk(C.mu);
+    return guarded([&]() -> int { LaneLock lane_lock = acquire_lane(); Ctx &C = *lane_lock.c;
         return create_impl(C, values, d, blindings32, d_blindings, prove_range, n_partition, fp_bits, fp_frac, nonce, proofs_out, proof_len_out, n_proofs_out, commits_out); });
 }
 int rofl_verify_rangeproof(const uint8_t *proofs, size_t proof_len, size_t n_proofs, const uint8_t *commits32, size_t d, size_t prove_range,
                            unsigned fp_bits, unsigned fp_frac, const uint8_t verifier_seed[32], int *ok_out) {
-    return guarded([&]() -> int { Ctx &C = ctx(); std::lock_guard<std::mutex> lk(C.mu);
+    return guarded([&]() -> int { LaneLock lane_lock = acquire_lane(); Ctx &C = *lane_lock.c;
         return verify_impl(C, 1, &proofs, proof_len, n_proofs, &commits32, d, prove_range, fp_bits, fp_frac, verifier_seed, ok_out); });
 }
 int rofl_verify_rangeproof_batch(size_t n_clients, const uint8_t *const *proofs, size_t proof_len, size_t n_proofs, const uint8_t *const *commits32,
                                  size_t d, size_t prove_range, unsigned fp_bits, unsigned fp_frac, const uint8_t verifier_seed[32], int *ok_out) {
-    return guarded([&]() -> int { Ctx &C = ctx(); std::lock_guard<std::mutex> lk(C.mu);
+    return guarded([&]() -> int { LaneLock lane_lock = acquire_lane(); Ctx &C = *lane_lock.c;
         return verify_impl(C, n_clients, proofs, proof_len, n_proofs, commits32, d, prove_range, fp_bits, fp_frac, verifier_seed, ok_out); });
 }
 int rofl_clip_f32(const float *in, size_t d, size_t prove_range, unsigned fp_bits, unsigned fp_frac, float *out) {
@@ -1231,7 +1237,7 @@ int rofl_clip_f32(const float *in, size_t d, size_t prove_range, unsigned fp_bit
 int rofl_create_rangeproof_l2(const float *values, size_t d, const uint8_t *blindings32, size_t d_blindings, size_t prove_range, size_t n_partition,
                               unsigned fp_bits, unsigned fp_frac, const rofl_nonce_t *nonce, uint8_t *proof_out, size_t *proof_len_out, uint8_t commit_out[32]) {
     return guarded([&]() -> int {
-        Ctx &C = ctx(); std::lock_guard<std::mutex> lk(C.mu);
+        LaneLock lane_lock = acquire_lane(); Ctx &C = *lane_lock.c;
         if (d != d_blindings) return fail(ROFL_WRONG_NUM_BLINDING, "WrongNumBlindingFactors");
         if (!valid_fp(fp_bits, fp_frac) || d == 0 || n_partition == 0 || prove_range == 0 || !nonce) return fail(ROFL_BAD_PARAM, "bad parameter (the reference panics here)");
         float mn, mx; clip_bounds(prove_range, fp_bits, fp_frac, &mn, &mx);
@@ -1277,7 +1283,7 @@ int rofl_create_rangeproof_l2(const float *values, size_t d, const uint8_t *blin
 int rofl_verify_rangeproof_l2(const uint8_t *proof, size_t proof_len, const uint8_t commit[32], size_t prove_range, unsigned fp_bits, unsigned fp_frac,
                               const uint8_t verifier_seed[32], int *ok_out) {
     return guarded([&]() -> int {
-        Ctx &C = ctx(); std::lock_guard<std::mutex> lk(C.mu);
+        LaneLock lane_lock = acquire_lane(); Ctx &C = *lane_lock.c;
         *ok_out = 0;
         if (!valid_fp(fp_bits, fp_frac) || prove_range == 0) return fail(ROFL_BAD_PARAM, "bad parameter");
         C.init();
@@ -1314,7 +1320,7 @@ DMerlin sigma_init_state(int kind) {
 }
 int sigma_create(int kind, const float *values, size_t d, const uint8_t *r1, size_t d_r1, const uint8_t *r2, const uint8_t *existing,
                  unsigned fp_bits, unsigned fp_frac, const rofl_nonce_t *nonce, uint8_t *proofs_out, uint8_t *commits_out) {
-    Ctx &C = ctx(); std::lock_guard<std::mutex> lk(C.mu);
+    LaneLock lane_lock = acquire_lane(); Ctx &C = *lane_lock.c;
     if (d != d_r1) return fail(ROFL_WRONG_NUM_BLINDING, "WrongNumBlindingFactors");
     if (!valid_fp(fp_bits, fp_frac) || !nonce) return fail(ROFL_BAD_PARAM, "bad parameter");
     if (d == 0) return ROFL_OK;
@@ -1348,7 +1354,7 @@ int sigma_create(int kind, const float *values, size_t d, const uint8_t *r1, siz
     return ROFL_OK;
 }
 int sigma_verify(int kind, const uint8_t *proofs, const uint8_t *commits, size_t d, int *ok_out) {
-    Ctx &C = ctx(); std::lock_guard<std::mutex> lk(C.mu);
+    LaneLock lane_lock = acquire_lane(); Ctx &C = *lane_lock.c;
     *ok_out = 0;
     if (d == 0) { *ok_out = 1; return ROFL_OK; }
     size_t npts = 1 + (kind != 2) + (kind != 0 ? 1 : 0), clen = 32 * npts, plen = 32 * (npts + (kind != 0 ? 3 : 2));
@@ -1381,7 +1387,7 @@ sc compressed_challenge(const uint8_t *pairs, size_t d, const uint8_t cprime[64]
 }
 int compressed_create(const float *values, size_t d, const uint8_t *r32, size_t d_r, const uint8_t *existing, unsigned fp_bits, unsigned fp_frac,
                       const rofl_nonce_t *nonce, uint8_t *proof_out, uint8_t *pairs_out) {
-    Ctx &C = ctx(); std::lock_guard<std::mutex> lk(C.mu);
+    LaneLock lane_lock = acquire_lane(); Ctx &C = *lane_lock.c;
     if (d != d_r) return fail(ROFL_WRONG_NUM_BLINDING, "WrongNumBlindingFactors");
     if (!valid_fp(fp_bits, fp_frac) || !nonce || d >= 900000) return fail(ROFL_BAD_PARAM, "bad parameter");
     if (nonce->mode == 0 && nonce->stream_scalars < 2) return fail(ROFL_NONCE_SHORT, "nonce stream too short");
@@ -1432,7 +1438,7 @@ int compressed_create(const float *values, size_t d, const uint8_t *r32, size_t 
     return ROFL_OK;
 }
 int compressed_verify(const uint8_t *proof, const uint8_t *pairs, size_t d, int *ok_out) {
-    Ctx &C = ctx(); std::lock_guard<std::mutex> lk(C.mu);
+    LaneLock lane_lock = acquire_lane(); Ctx &C = *lane_lock.c;
     *ok_out = 0;
     ge Lp32, Rp32;
     if (!ristretto_decode(Lp32, proof) || !ristretto_decode(Rp32, proof + 32) || !sc_is_canonical_bytes(proof + 64) || !sc_is_canonical_bytes(proof + 96))
@@ -1500,7 +1506,7 @@ int rofl_verify_squarerandproof_vec(const uint8_t *proofs, const uint8_t *commit
 
 int rofl_commit_vec(const uint8_t *values32, const uint8_t *blindings32, size_t d, uint8_t *out32) {
     return guarded([&]() -> int {
-        Ctx &C = ctx(); std::lock_guard<std::mutex> lk(C.mu);
+        LaneLock lane_lock = acquire_lane(); Ctx &C = *lane_lock.c;
         if (d == 0) return ROFL_OK;
         C.init();
         sc *dv = C.tmp_in.as<sc>(d); sc *db = blindings32 ? C.tmp_in2.as<sc>(d) : nullptr;
@@ -1515,7 +1521,7 @@ int rofl_commit_vec(const uint8_t *values32, const uint8_t *blindings32, size_t 
 }
 int rofl_add_points_vec(const uint8_t *a32, const uint8_t *b32, size_t d, uint8_t *out32) {
     return guarded([&]() -> int {
-        Ctx &C = ctx(); std::lock_guard<std::mutex> lk(C.mu);
+        LaneLock lane_lock = acquire_lane(); Ctx &C = *lane_lock.c;
         if (d == 0) return ROFL_OK;
         C.init();
         uint8_t *da = C.tmp_in.as<uint8_t>(d * 32), *db = C.tmp_in2.as<uint8_t>(d * 32), *o = C.Cbytes.as<uint8_t>(d * 32);
@@ -1534,7 +1540,7 @@ int rofl_add_points_vec(const uint8_t *a32, const uint8_t *b32, size_t d, uint8_
 }
 int rofl_sum_points(const uint8_t *points, size_t d, size_t stride, uint8_t out32[32]) {
     return guarded([&]() -> int {
-        Ctx &C = ctx(); std::lock_guard<std::mutex> lk(C.mu);
+        LaneLock lane_lock = acquire_lane(); Ctx &C = *lane_lock.c;
         if (stride < 32 || !out32 || (d && !points)) return fail(ROFL_BAD_PARAM, "bad parameter");
         if (d == 0) { memset(out32, 0, 32); return ROFL_OK; }      // empty sum = identity
         C.init();
@@ -1558,7 +1564,7 @@ int rofl_sum_points(const uint8_t *points, size_t d, size_t stride, uint8_t out3
 }
 int rofl_shift_points(const uint8_t *a32, size_t d, const uint8_t offset32[32], uint8_t *out32) {
     return guarded([&]() -> int {
-        Ctx &C = ctx(); std::lock_guard<std::mutex> lk(C.mu);
+        LaneLock lane_lock = acquire_lane(); Ctx &C = *lane_lock.c;
         if (d == 0) return ROFL_OK;
         C.init();
         ge off; if (!ristretto_decode(off, offset32)) return fail(ROFL_FORMAT_ERROR, "invalid Ristretto encoding");
@@ -1599,7 +1605,7 @@ int rofl_get_l2_clip_bounds(size_t range, unsigned fp_bits, unsigned fp_frac, fl
 
 int rofl_dbg_msm(const uint8_t *scalars32, const uint8_t *points32, size_t n, uint8_t out32[32]) {
     return guarded([&]() -> int {
-        Ctx &C = ctx(); std::lock_guard<std::mutex> lk(C.mu);
+        LaneLock lane_lock = acquire_lane(); Ctx &C = *lane_lock.c;
         if (n == 0) return fail(ROFL_BAD_PARAM, "bad parameter");
         C.init();
         std::vector<sc> hs(n);
@@ -1622,7 +1628,7 @@ int rofl_dbg_msm(const uint8_t *scalars32, const uint8_t *points32, size_t n, ui
 }
 int rofl_discrete_log_vec(const uint8_t *points32, size_t d, size_t table_size, unsigned bsgs_bits, uint8_t *scalars_out32) {
     return guarded([&]() -> int {
-        Ctx &C = ctx(); std::lock_guard<std::mutex> lk(C.mu);
+        LaneLock lane_lock = acquire_lane(true); Ctx &C = *lane_lock.c;
         if (table_size == 0 || table_size >= (1u << 30) || !(bsgs_bits == 8 || bsgs_bits == 16 || bsgs_bits == 32)) return fail(ROFL_BAD_PARAM, "bad parameter");
         if (d == 0) return ROFL_OK;
         C.init();
@@ -1667,11 +1673,19 @@ int rofl_wire_decode(int kind, const uint8_t *data, size_t len, rofl_wire_msg_t 
     int rc = wire::decode(kind, data, len, m, range_proofs_out, range_proofs_cap);
     return rc ? fail(rc, rc == ROFL_FORMAT_ERROR ? "malformed message (prost's decode_length_delimited would return Err; the reference unwraps it)" : "bad parameter") : ROFL_OK;
 }
-int rofl_set_timing(int enabled) { return guarded([&]() -> int { Ctx &C = ctx(); std::lock_guard<std::mutex> lk(C.mu); C.tm.enabled = enabled != 0; return ROFL_OK; }); }
-int rofl_last_timing(rofl_timing_t *out) { return guarded([&]() -> int { Ctx &C = ctx(); std::lock_guard<std::mutex> lk(C.mu); *out = C.tm.t; return ROFL_OK; }); }
+int rofl_set_timing(int enabled) {
+    return guarded([&]() -> int {
+        Ctx &P = ctx(); { std::lock_guard<std::mutex> g(P.init_mu); P.init(); }
+        { std::lock_guard<std::mutex> lk(P.mu); P.tm.enabled = enabled != 0; }
+        for (Ctx *s : P.sibs) { std::lock_guard<std::mutex> lk(s->mu); s->tm.enabled = enabled != 0; }
+        return ROFL_OK;
+    });
+}
+/* timing of the last instrumented call made by the calling thread */
+int rofl_last_timing(rofl_timing_t *out) { if (!out) return ROFL_BAD_PARAM; *out = g_last_timing; return ROFL_OK; }
 int rofl_bench_femul(unsigned iters, double *out) {
     return guarded([&]() -> int {
-        Ctx &C = ctx(); std::lock_guard<std::mutex> lk(C.mu); C.init();
+        LaneLock lane_lock = acquire_lane(); Ctx &C = *lane_lock.c; C.init();
         const u32 blocks = 256 * 8, threads = blocks * TPB;
         fe *din, *dout; HIPCHK(hipMalloc(&din, sizeof(fe) * 256)); HIPCHK(hipMalloc(&dout, sizeof(fe) * threads));
         std::vector<fe> h(256); for (int i = 0; i < 256; i++) for (int k = 0; k < 8; k++) h[i].v[k] = 0x9e3779b9u * (i * 8 + k + 1);

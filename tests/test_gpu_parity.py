@@ -533,3 +533,47 @@ def test_msm_variants_small_sizes(R, env):
     e = dict(os.environ); e.update(env)
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "gpu_variant_check.py")], env=e, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "FB_SMALL PASS" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_concurrent_calls_use_separate_lanes(R):
+    """The reference's server calls verify from a thread pool (server.rs:656-687): concurrent calls must not disturb each
+    other.  Six threads, different shapes, every proof bit-exact vs the oracle; timing and errors are per thread."""
+    from concurrent.futures import ThreadPoolExecutor
+    shapes = [(300, 8, 4, 16, 7), (1000, 32, 4, 32, 7), (37, 16, 8, 16, 7), (2000, 8, 2, 16, 7), (64, 64, 1, 64, 7), (500, 16, 4, 16, 7)]
+    inputs = []
+    for i, (d, nb, P, fb, ff) in enumerate(shapes):
+        rng = np.random.default_rng(900 + i)
+        R.api.set_fp(fb, ff)
+        mn, mx = R.conversion32.get_clip_bounds(nb)
+        vals = np.clip(rng.uniform(mn, mx, size=d).astype(np.float32), mn, np.nextafter(np.float32(mx), np.float32(0)))
+        inputs.append((vals, orc.rand_scalars(rng, d), bytes(rng.integers(0, 256, 32, dtype=np.uint8))))
+    lib = R.lib()
+
+    def work(i):
+        d, nb, P, fb, ff = shapes[i]
+        vals, bl, seed = inputs[i]
+        out = []
+        for rep in range(3):
+            # fp config is module state in the Python mirror: go through the C ABI directly with explicit (fp_bits, fp_frac)
+            ns = R.Nonce.seeded(seed)._struct()
+            npr = lib.rofl_rangeproof_chunks(ctypes.c_size_t(d), ctypes.c_size_t(P)); plen = lib.rofl_rangeproof_size(ctypes.c_size_t(nb), ctypes.c_size_t(d), ctypes.c_size_t(P))
+            pr = np.zeros((npr, plen), np.uint8); cm = np.zeros((d, 32), np.uint8)
+            a, b = ctypes.c_size_t(), ctypes.c_size_t()
+            rc = lib.rofl_create_rangeproof(vals.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(d), bl.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(d),
+                                            ctypes.c_size_t(nb), ctypes.c_size_t(P), fb, ff, ctypes.byref(ns), pr.ctypes.data_as(ctypes.c_void_p),
+                                            ctypes.byref(a), ctypes.byref(b), cm.ctypes.data_as(ctypes.c_void_p))
+            ok = ctypes.c_int()
+            rc2 = lib.rofl_verify_rangeproof(pr.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(plen), ctypes.c_size_t(npr), cm.ctypes.data_as(ctypes.c_void_p),
+                                             ctypes.c_size_t(d), ctypes.c_size_t(nb), fb, ff, (ctypes.c_uint8 * 32)(*([rep + 1] * 32)), ctypes.byref(ok))
+            out.append((rc, rc2, ok.value, pr, cm))
+        return out
+    lib.rofl_rangeproof_chunks.restype = ctypes.c_size_t; lib.rofl_rangeproof_size.restype = ctypes.c_size_t
+    with ThreadPoolExecutor(max_workers=6) as ex:
+        res = list(ex.map(work, range(len(shapes))))
+    for i, (d, nb, P, fb, ff) in enumerate(shapes):
+        vals, bl, seed = inputs[i]
+        rc, opr, ocm = orc.create_rangeproof(vals, bl, nb, P, fb, ff, seed=seed)
+        assert rc == 0
+        for (rc1, rc2, ok, pr, cm) in res[i]:
+            assert rc1 == 0 and rc2 == 0 and ok == 1 and (pr == opr).all() and (cm == ocm).all(), shapes[i]
+    R.api.set_fp(16, 7)

@@ -179,11 +179,15 @@ def main():
     for s in range(args.warmup):
         step(s, False)
     sync()
+    import resource
+    ru0 = resource.getrusage(resource.RUSAGE_SELF)
     t0 = time.perf_counter()
     for s in range(args.warmup, total_steps):
         step(s, True)
     sync()
     elapsed = time.perf_counter() - t0
+    ru1 = resource.getrusage(resource.RUSAGE_SELF)
+    cpu_busy = ((ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)) / elapsed
     if world > 1:
         te = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
@@ -233,7 +237,7 @@ def main():
             "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": elapsed / K * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32x8 (255-bit integer field)", "data": "synthetic",
             "config": {"workload": "L-inf 32-bit range proof, d=25000 (resnet18_intrinsic_25k), %d concurrent clients create+verify per step per GPU" % CPS,
-                       "clients_per_step": CPS, "host_cores": avail_cores(), "concurrency": "one host thread and one library lane (HIP stream + workspace) per client in flight",
+                       "clients_per_step": CPS, "host_cores": avail_cores(), "host_cores_busy": round(cpu_busy, 2), "concurrency": "one host thread and one library lane (HIP stream + workspace) per client in flight",
                        "d": D, "prove_range": NBITS, "n_partition": NPART, "fp_bits": FP_BITS, "fp_frac": FP_FRAC,
                        "inputs": "host buffers at the C ABI (0.9 MB H2D per step inside the timed region)"},
             "breakdown_ms_per_client": {"create": agg["create_ms"] / (K * CPS), "verify": agg["verify_ms"] / (K * CPS), "device": agg["total_ms"] / (K * CPS),

@@ -892,10 +892,39 @@ __device__ __forceinline__ void msm_reduce_item(u32 E, u32 nb, const ge *S_in, c
         store_gd(&C_out[(size_t)(role - 1) * E8 + g], acc);
     }
 }
+// The same tree level with the four outputs of an 8-group (S and the three new bit-sums) on four work items: 7 / 3 / 3 / 3
+// additions with two live points each instead of one item doing 11 additions with seven live points (256 VGPRs + AGPR
+// spills, 1 wave/SIMD).  item = role * E8 + g; roles 0..3 as described, role r >= 4 = carried bit-sum r - 4.
+__device__ __forceinline__ void msm_reduce_item_split(u32 E, u32 nb, const ge *S_in, const ge *C_in, ge *S_out, ge *C_out, u32 item) {
+    u32 E8 = E / 8, role = item / E8, g = item % E8;
+    if (role >= 4) {      // carried bit-sum role-4: 8 children -> 1
+        const ge *cs = C_in + (size_t)(role - 4) * E + (size_t)g * 8;
+        gd acc = gd_add(load_gd(&cs[0]), load_gd(&cs[1]));
+#pragma unroll 1
+        for (int t = 2; t < 8; t++) acc = gd_add(acc, load_gd(&cs[t]));
+        store_gd(&C_out[(size_t)(role - 4) * E8 + g], acc);
+        return;
+    }
+    const ge *s = S_in + (size_t)g * 8;
+    if (role == 0) {
+        gd acc = gd_add(load_gd(&s[0]), load_gd(&s[1]));
+#pragma unroll 1
+        for (int t = 2; t < 8; t++) acc = gd_add(acc, load_gd(&s[t]));
+        store_gd(&S_out[g], acc);
+    } else {
+        // bit (role-1) of the child index: children {1,3,5,7}, {2,3,6,7}, {4,5,6,7}
+        u32 b = role - 1, st = 1u << b;
+        u32 i0 = st, i1 = b == 2 ? 5 : 3, i2 = b == 0 ? 5 : 6, i3 = 7;
+        gd acc = gd_add(load_gd(&s[i0]), load_gd(&s[i1]));
+        acc = gd_add(acc, load_gd(&s[i2]));
+        acc = gd_add(acc, load_gd(&s[i3]));
+        store_gd(&C_out[(size_t)(nb + b) * E8 + g], acc);
+    }
+}
 __global__ void __launch_bounds__(TPB) k_msm_reduce_level(u32 E, u32 nb, const ge *S_in, const ge *C_in, ge *S_out, ge *C_out) {
     u32 pw = blockIdx.y, E8 = E / 8;
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= E8 * (1 + nb)) return;
+    if (t >= E8 * (1 + nb)) return;       // throughput-bound here: 11 additions per 8-group beat the 16 of the split form
     msm_reduce_item(E, nb, S_in + (size_t)pw * E, C_in + (size_t)pw * nb * E, S_out + (size_t)pw * E8, C_out + (size_t)pw * (nb + 3) * E8, t);
 }
 // All remaining levels (E <= 512) of one (prob, window) in a single block through LDS: one launch instead of three
@@ -912,23 +941,7 @@ __global__ void __launch_bounds__(512) k_msm_reduce_fused(u32 E, u32 nb, const g
     ge *so = E8 == 1 ? fin_s : buf0, *co = E8 == 1 ? fin_c : buf0 + E8;
     // (latency-bound: the four outputs of an 8-group -- S and the three new bit-sums -- go to four threads, 7 / 3 additions
     //  deep instead of one thread doing all 11)
-    for (u32 item = threadIdx.x; item < E8 * (4 + nb); item += blockDim.x) {
-        u32 role = item / E8, g = item % E8;
-        if (role >= 4) { msm_reduce_item(E, nb, si, ci, so, co, (role - 3) * E8 + g); continue; }
-        const ge *s = si + (size_t)g * 8;
-        if (role == 0) {
-            gd acc = gd_add(load_gd(&s[0]), load_gd(&s[1]));
-#pragma unroll 1
-            for (int t = 2; t < 8; t++) acc = gd_add(acc, load_gd(&s[t]));
-            so[g] = gd_pack(acc);
-        } else {
-            // bit (role-1) of the child index: children {1,3,5,7}, {2,3,6,7}, {4,5,6,7}
-            u32 b = role - 1, st = 1u << b;
-            u32 i0 = st, i1 = b == 0 ? 3 : (b == 1 ? 3 : 5), i2 = b == 0 ? 5 : 6, i3 = 7;
-            gd acc = gd_add(gd_add(load_gd(&s[i0]), load_gd(&s[i1])), gd_add(load_gd(&s[i2]), load_gd(&s[i3])));
-            co[(size_t)(nb + b) * E8 + g] = gd_pack(acc);
-        }
-    }
+    for (u32 item = threadIdx.x; item < E8 * (4 + nb); item += blockDim.x) msm_reduce_item_split(E, nb, si, ci, so, co, item);
     __syncthreads();
     if (E8 == 1) return;
     u32 half = E8 * (1 + nb + 3);

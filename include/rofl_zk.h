@@ -136,6 +136,11 @@ int rofl_shift_points(const uint8_t *a32, size_t d, const uint8_t offset32[32], 
 int rofl_f32_to_scalar_vec(const float *in, size_t d, unsigned fp_bits, unsigned fp_frac, uint8_t *out32); /* conversion32.rs:11-22 */
 int rofl_scalar_to_f32_vec(const uint8_t *in32, size_t d, unsigned fp_bits, unsigned fp_frac, float *out); /* conversion32.rs:24-39 */
 int rofl_get_clip_bounds(size_t range, unsigned fp_bits, unsigned fp_frac, float *min_out, float *max_out); /* conversion32.rs:56-60 */
+int rofl_fp_square_vec(const uint8_t *in32, size_t d, unsigned fp_bits, unsigned fp_frac, uint8_t *out32);      /* conversion32.rs:66-88 square; 8 = overflow (the reference panics) */
+int rofl_scalar_powers(const uint8_t value32[32], size_t count, uint8_t *out32);                              /* conversion32.rs:101-122 precompute_exponentiate / exponentiate */
+int rofl_scalar_add_vec(const uint8_t *a32, const uint8_t *b32, size_t d, int subtract, uint8_t *out32);      /* pedersen_ops.rs:78-94 add_scalar_vec(_vec) */
+int rofl_f32_to_fp_vec(const float *in, size_t d, unsigned fp_bits, unsigned fp_frac, uint64_t *out);         /* conversion32.rs:49-54 */
+int rofl_uint_to_f32_vec(const uint64_t *in, size_t d, unsigned fp_bits, unsigned fp_frac, float *out);        /* conversion32.rs:41-47 */
 int rofl_get_l2_clip_bounds(size_t range, unsigned fp_bits, unsigned fp_frac, float *out);  /* conversion32.rs:62-64 */
 
 /* ---- server-side extraction of the aggregate (bsgs32.rs:14-73, pedersen_ops.rs:27-53 discrete_log_vec_table) ----

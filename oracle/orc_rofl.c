@@ -159,6 +159,29 @@ static float sc_to_f32(const sc *s, unsigned fp_bits, unsigned fp_frac) {
     }
     return fix_to_f32(read_from_bytes(b, fp_bits), fp_frac);
 }
+/* conversion32.rs:66-88 square */
+int orc_fp_square(const uint8_t s32[32], unsigned fp_bits, unsigned fp_frac, uint8_t out[32]) {
+    uint8_t b[32]; memcpy(b, s32, 32);
+    if (s32[31] != 0) orc_sc_neg(s32, b);
+    uint64_t v = read_from_bytes(b, fp_bits);
+    unsigned __int128 prod = ((unsigned __int128)v * v) >> fp_frac;       /* fixed 0.3.3 checked_mul: wide product, arithmetic shift */
+    if (prod > (unsigned __int128)fix_max_bits(fp_bits)) return ORC_OVERFLOW;
+    sc r; sc_from_u64(&r, (uint64_t)prod); sc_tobytes(out, &r);
+    return ORC_OK;
+}
+/* conversion32.rs:101-111 precompute_exponentiate */
+void orc_scalar_powers(const uint8_t v32[32], size_t count, uint8_t *out) {
+    sc v, acc = SC_ONE; sc_frombytes_modorder(&v, v32);
+    for (size_t i = 0; i < count; i++) { sc_tobytes(out + 32 * i, &acc); sc t; sc_mul(&t, &acc, &v); acc = t; }
+}
+/* conversion32.rs:49-54 f32_to_fp_vec (Fix is unsigned: negatives saturate to 0) and :41-47 uint_to_f32 */
+int orc_f32_to_fp(float v, unsigned fp_bits, unsigned fp_frac, uint64_t *out) {
+    if (v != v) return ORC_NON_FINITE;
+    if (v < 0.0f) { *out = 0; return ORC_OK; }
+    return fix_from_abs_f32(v, fp_bits, fp_frac, out);
+}
+float orc_uint_to_f32(uint64_t k, unsigned fp_bits, unsigned fp_frac) { return fix_to_f32(k & fix_max_bits(fp_bits), fp_frac); }
+
 int orc_f32_to_scalar(float v, unsigned fp_bits, unsigned fp_frac, uint8_t out[32]) {
     sc s; int rc = f32_to_sc(v, fp_bits, fp_frac, &s); if (rc) return rc; sc_tobytes(out, &s); return 0;
 }

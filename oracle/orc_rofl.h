@@ -79,6 +79,10 @@ int orc_f32_to_scalar(float v, unsigned fp_bits, unsigned fp_frac, uint8_t out[3
 float orc_scalar_to_f32(const uint8_t s[32], unsigned fp_bits, unsigned fp_frac);
 void orc_get_clip_bounds(unsigned range, unsigned fp_bits, unsigned fp_frac, float *mn, float *mx);
 float orc_get_l2_clip_bounds(unsigned range, unsigned fp_bits, unsigned fp_frac);
+int orc_fp_square(const uint8_t s32[32], unsigned fp_bits, unsigned fp_frac, uint8_t out[32]);
+void orc_scalar_powers(const uint8_t v32[32], size_t count, uint8_t *out);
+int orc_f32_to_fp(float v, unsigned fp_bits, unsigned fp_frac, uint64_t *out);
+float orc_uint_to_f32(uint64_t k, unsigned fp_bits, unsigned fp_frac);
 void orc_clip_f32(const float *in, size_t d, unsigned range, unsigned fp_bits, unsigned fp_frac, float *out);
 
 /* pedersen_ops.rs */

@@ -405,6 +405,37 @@ class pedersen_ops:
         return out
 
     @staticmethod
+    def add_scalar_vec(a, b, subtract=False):
+        """pedersen_ops.rs:78-81 (out of place)."""
+        a, b = _u8(a), _u8(b)
+        assert a.shape == b.shape
+        out = np.zeros_like(a)
+        _check(lib().rofl_scalar_add_vec(_ptr(a), _ptr(b), _sz(a.shape[0]), int(bool(subtract)), _ptr(out)))
+        return out
+
+    @staticmethod
+    def add_scalar_vec_vec(vecs):
+        """pedersen_ops.rs:83-91."""
+        acc = pedersen_ops.zero_scalar_vec(_u8(vecs[0]).shape[0])
+        for v in vecs:
+            acc = pedersen_ops.add_scalar_vec(acc, v)
+        return acc
+
+    @staticmethod
+    def generate_cancelling_scalar_vec(n_vec, n_dim):
+        """pedersen_ops.rs:110-122: n_vec random scalar vectors whose element-wise sum is zero."""
+        vecs = [pedersen_ops.rnd_scalar_vec(n_dim) for _ in range(n_vec)]
+        vecs[-1] = pedersen_ops.add_scalar_vec(pedersen_ops.zero_scalar_vec(n_dim), pedersen_ops.add_scalar_vec_vec(vecs[:-1]), subtract=True)
+        return vecs
+
+    @staticmethod
+    def compute_shifted_values_vec(values, offset):
+        """pedersen_ops.rs:97-102 for scalars (the generic T: Add version; points: compute_shifted_values_rp)."""
+        v = _u8(values)
+        off = np.broadcast_to(np.ascontiguousarray(offset, dtype=np.uint8).reshape(1, 32), v.shape)
+        return pedersen_ops.add_scalar_vec(v, np.ascontiguousarray(off))
+
+    @staticmethod
     def zero_rp_vec(length):
         return np.zeros((length, 32), dtype=np.uint8)   # identity compresses to 32 zero bytes
 
@@ -449,6 +480,41 @@ class conversion32:
         s = _u8(scalars)
         out = np.zeros(s.shape[0], dtype=np.float32)
         _check(lib().rofl_scalar_to_f32_vec(_ptr(s), _sz(s.shape[0]), _FpConfig.fp_bits, _FpConfig.fp_frac, _ptr(out)))
+        return out
+
+    @staticmethod
+    def square(scalars):
+        """conversion32.rs:66-88 (element-wise over a vector of scalars); overflow -> RoflError 8 (the reference panics)."""
+        a = _u8(scalars)
+        out = np.zeros_like(a)
+        _check(lib().rofl_fp_square_vec(_ptr(a), _sz(a.shape[0]), _FpConfig.fp_bits, _FpConfig.fp_frac, _ptr(out)))
+        return out
+
+    @staticmethod
+    def precompute_exponentiate(value, exp):
+        """conversion32.rs:101-111: [1, v, ..., v^(exp-1)]."""
+        v = np.ascontiguousarray(value, dtype=np.uint8).reshape(32)
+        out = np.zeros((exp, 32), dtype=np.uint8)
+        _check(lib().rofl_scalar_powers(_ptr(v), _sz(exp), _ptr(out)))
+        return out
+
+    @staticmethod
+    def exponentiate(value, exp):
+        """conversion32.rs:113-122."""
+        return conversion32.precompute_exponentiate(value, exp + 1)[exp]
+
+    @staticmethod
+    def f32_to_fp_vec(values):
+        v = np.ascontiguousarray(values, dtype=np.float32)
+        out = np.zeros(v.size, dtype=np.uint64)
+        _check(lib().rofl_f32_to_fp_vec(_ptr(v), _sz(v.size), _FpConfig.fp_bits, _FpConfig.fp_frac, _ptr(out)))
+        return out
+
+    @staticmethod
+    def uint_to_f32_vec(values):
+        v = np.ascontiguousarray(values, dtype=np.uint64)
+        out = np.zeros(v.size, dtype=np.float32)
+        _check(lib().rofl_uint_to_f32_vec(_ptr(v), _sz(v.size), _FpConfig.fp_bits, _FpConfig.fp_frac, _ptr(out)))
         return out
 
     @staticmethod

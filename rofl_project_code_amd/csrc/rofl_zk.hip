@@ -1594,6 +1594,50 @@ int rofl_scalar_to_f32_vec(const uint8_t *in32, size_t d, unsigned fp_bits, unsi
     for (size_t i = 0; i < d; i++) out[i] = sc_to_f32(sc_frombytes(in32 + 32 * i), fp_bits, fp_frac);
     return ROFL_OK;
 }
+// conversion32::square (conversion32.rs:66-88): |s| as Fix, checked_mul (fixed 0.3.3: wide product >> frac, truncated), panic on overflow
+int rofl_fp_square_vec(const uint8_t *in32, size_t d, unsigned fp_bits, unsigned fp_frac, uint8_t *out32) {
+    if (!valid_fp(fp_bits, fp_frac)) return fail(ROFL_BAD_PARAM, "bad parameter");
+    for (size_t i = 0; i < d; i++) {
+        sc s = sc_frombytes(in32 + 32 * i);
+        u64 v = (s.v[7] >> 24) != 0 ? read_from_bytes(sc_neg(s), fp_bits) : read_from_bytes(s, fp_bits);
+        unsigned __int128 prod = ((unsigned __int128)v * v) >> fp_frac;
+        if (prod > (unsigned __int128)fix_max_bits(fp_bits)) return fail(ROFL_OVERFLOW, "square overflows the fixed-point type (the reference panics)");
+        sc_tobytes(out32 + 32 * i, sc_from_u64((u64)prod));
+    }
+    return ROFL_OK;
+}
+// conversion32::precompute_exponentiate (conversion32.rs:101-111): 1, v, v^2, ..., v^(count-1); exponentiate(v, e) = element e
+int rofl_scalar_powers(const uint8_t value32[32], size_t count, uint8_t *out32) {
+    sc v = h_mont(sc_frombytes(value32)), acc = sc_one_mont();
+    for (size_t i = 0; i < count; i++) { sc_tobytes(out32 + 32 * i, h_canon(acc)); acc = sc_montmul(acc, v); }
+    return ROFL_OK;
+}
+// pedersen_ops::add_scalar_vec (pedersen_ops.rs:78-81); subtract != 0 gives a - b (generate_cancelling_scalar_vec negates a running sum)
+int rofl_scalar_add_vec(const uint8_t *a32, const uint8_t *b32, size_t d, int subtract, uint8_t *out32) {
+    for (size_t i = 0; i < d; i++) {
+        sc a = sc_frombytes(a32 + 32 * i), b = sc_frombytes(b32 + 32 * i);
+        if (sc_geq_l(a.v)) a = sc_from_mont(sc_to_mont(a));
+        if (sc_geq_l(b.v)) b = sc_from_mont(sc_to_mont(b));
+        sc_tobytes(out32 + 32 * i, subtract ? sc_sub(a, b) : sc_add(a, b));
+    }
+    return ROFL_OK;
+}
+// conversion32::f32_to_fp_vec / uint_to_f32_vec (conversion32.rs:41-54): Fix is unsigned, negative inputs saturate to 0
+int rofl_f32_to_fp_vec(const float *in, size_t d, unsigned fp_bits, unsigned fp_frac, uint64_t *out) {
+    if (!valid_fp(fp_bits, fp_frac)) return fail(ROFL_BAD_PARAM, "bad parameter");
+    for (size_t i = 0; i < d; i++) {
+        if (std::isnan(in[i])) return fail(ROFL_NON_FINITE, "non-finite value (the reference panics in fixed::saturating_from_float)");
+        if (in[i] < 0.0f) { out[i] = 0; continue; }
+        sc s; int rc = f32_to_sc(in[i], fp_bits, fp_frac, &s); if (rc) return fail(rc, "non-finite value");
+        out[i] = read_from_bytes(s, fp_bits);
+    }
+    return ROFL_OK;
+}
+int rofl_uint_to_f32_vec(const uint64_t *in, size_t d, unsigned fp_bits, unsigned fp_frac, float *out) {
+    if (!valid_fp(fp_bits, fp_frac)) return fail(ROFL_BAD_PARAM, "bad parameter");
+    for (size_t i = 0; i < d; i++) out[i] = fix_to_f32(in[i] & fix_max_bits(fp_bits), fp_frac);
+    return ROFL_OK;
+}
 int rofl_get_clip_bounds(size_t range, unsigned fp_bits, unsigned fp_frac, float *mn, float *mx) {
     if (!valid_fp(fp_bits, fp_frac) || range == 0 || range > 128) return fail(ROFL_BAD_PARAM, "bad parameter");
     clip_bounds(range, fp_bits, fp_frac, mn, mx); return ROFL_OK;

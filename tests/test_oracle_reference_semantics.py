@@ -121,3 +121,37 @@ def test_format_errors():
     assert orc.verify_rangeproof(pr[:, :-32], cm, 8, FB, FF)[0] == 5
     bad = pr.copy(); bad[0, 0:32] = 0                    # identity A -> VerificationError -> Ok(false)
     assert orc.verify_rangeproof(bad, cm, 8, FB, FF) == (0, False)
+
+
+def test_host_scalar_utilities_match_oracle(hiplib):
+    """conversion32::{square, precompute_exponentiate, f32_to_fp_vec, uint_to_f32_vec}, pedersen_ops::{add_scalar_vec,
+    generate_cancelling_scalar_vec}: host code of the library (no GPU) against the oracle."""
+    import ctypes
+    import rofl_project_code_amd as R
+    o = orc.lib(); o.orc_uint_to_f32.restype = ctypes.c_float
+    r = np.random.default_rng(21)
+    for fb, ff in ((8, 3), (16, 7), (32, 7), (32, 12), (64, 7)):
+        R.api.set_fp(fb, ff)
+        mx = float(R.conversion32.uint_to_f32_vec([2 ** fb - 1])[0])
+        vals = np.concatenate([r.uniform(-mx, mx, 40), [0.0, mx, -mx, 0.5, -0.5, 1e30, -1e30]]).astype(np.float32)
+        sc = R.conversion32.f32_to_scalar_vec(vals)
+        for i, v in enumerate(vals):
+            exp = np.zeros(32, np.uint8)
+            rc = o.orc_fp_square(sc[i].ctypes.data_as(ctypes.c_void_p), fb, ff, exp.ctypes.data_as(ctypes.c_void_p))
+            try:
+                got = R.conversion32.square(sc[i:i + 1])[0]; grc = 0
+            except R.RoflError as e:
+                got, grc = None, e.code
+            assert grc == rc and (rc != 0 or (got == exp).all()), (fb, ff, v)
+            q = ctypes.c_uint64()
+            assert o.orc_f32_to_fp(ctypes.c_float(v), fb, ff, ctypes.byref(q)) == 0 and int(R.conversion32.f32_to_fp_vec([v])[0]) == q.value
+            assert R.conversion32.uint_to_f32_vec([q.value])[0] == np.float32(o.orc_uint_to_f32(ctypes.c_uint64(q.value), fb, ff))
+    R.api.set_fp(16, 7)
+    c = orc.rand_scalars(r, 1)[0]
+    exp = np.zeros((9, 32), np.uint8); o.orc_scalar_powers(c.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(9), exp.ctypes.data_as(ctypes.c_void_p))
+    assert (R.conversion32.precompute_exponentiate(c, 9) == exp).all()
+    a, b = orc.rand_scalars(r, 16), orc.rand_scalars(r, 16)
+    ai = [int.from_bytes(x.tobytes(), "little") for x in a]; bi = [int.from_bytes(x.tobytes(), "little") for x in b]
+    assert [int.from_bytes(x.tobytes(), "little") for x in R.pedersen_ops.add_scalar_vec(a, b)] == [(x + y) % orc.L_ORDER for x, y in zip(ai, bi)]
+    assert [int.from_bytes(x.tobytes(), "little") for x in R.pedersen_ops.add_scalar_vec(a, b, subtract=True)] == [(x - y) % orc.L_ORDER for x, y in zip(ai, bi)]
+    assert not R.pedersen_ops.add_scalar_vec_vec(R.pedersen_ops.generate_cancelling_scalar_vec(5, 11)).any()

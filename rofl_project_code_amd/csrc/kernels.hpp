@@ -10,9 +10,6 @@
 namespace rofl {
 
 #define TPB 256
-#ifndef ROFL_ACC_PREFETCH
-#define ROFL_ACC_PREFETCH 0
-#endif
 
 // ---------------------------------------------------------------- small helpers
 // A pointer read out of a descriptor in memory is "generic" to the compiler and its accesses become flat_*; every
@@ -438,7 +435,7 @@ __global__ void __launch_bounds__(TPB) k_lr_vec(u32 n, u32 m, const ChunkParams 
 
 // ================================================================ K7: inner-product argument
 // Lazily folded generators: the materialised arrays Gc/Hc have n_g entries; the logical vectors have
-// n_k = n_g >> r entries; true G[i] = sum_h stab[0][h] Gc[h*n_k+i], true H[i] = sum_h stab[1][h] y^-j Hc[j].
+// n_k = n_g >> r entries; true G[i] = sum_h s_G(h) Gc[h*n_k+i], true H[i] = sum_h s_H(h) y^-j Hc[j].
 // Writes canonical MSM scalars for L (SL) and R (SR) over [Gc | Hc].
 __global__ void __launch_bounds__(TPB) k_ipp_scalars(u32 n_g, u32 n_k, u32 r, const ChunkParams *cp, const sc *a, const sc *b, size_t ab_stride,
                               const sc *yinvpow, size_t y_stride, sc *SL, sc *SR, int merged) {
@@ -841,22 +838,11 @@ __global__ void __launch_bounds__(TPB) k_msm_accumulate(u32 n, u32 c, u32 W, u32
     else lst = sorted + ((size_t)p * W + w) * n * 2 + off[bi];   // stride 2n: a top-window digit may emit two entries
     const niels *pts = probs[p * pstep].pts;
     gd acc = gd_identity();
-#if ROFL_ACC_PREFETCH
-    // software pipeline: the (random) point load of entry e+1 is in flight while entry e is added
-    u32 v = num ? lst[0] : 0u;
-    niels nxt = gload_niels(&pts[v & 0x7fffffffu]);
-    for (u32 e = 0; e < num; e++) {
-        niels cur = nxt; u32 vc = v;
-        v = lst[e + 1 < num ? e + 1 : e];
-        nxt = gload_niels(&pts[v & 0x7fffffffu]);
-        acc = gd_madd(acc, nd_unpack(cur), (vc >> 31) != 0);
-    }
-#else
+    // (a software-pipelined variant that keeps the next point load in flight costs 12 VGPRs -> 3 waves/SIMD and was slower)
     for (u32 e = 0; e < num; e++) {
         u32 v = lst[e];
         acc = gd_madd(acc, gload_nd(&pts[v & 0x7fffffffu]), (v >> 31) != 0);
     }
-#endif
     store_gd(&buckets[bi], acc);
 }
 // Bucket reduction without doublings: sum_b (b+1) B_b = S + sum_l 2^l D_l, D_l = sum of buckets whose

@@ -221,9 +221,9 @@ struct Ctx {
     Timing tm;
     // workspace
     DevBuf cp, sL, sR, party, Scanon, vshift, blind, Vbytes, Cbytes, status, partial, partial2, scpart, a, b, yinv,
-        SL, SR, msm_cnt, msm_off, msm_cur, msm_perm, msm_sorted, msm_ovf, msm_buckets, msm_S[2], msm_C[2], stab, msm_probs, foldprobs, naf,
+        SL, SR, msm_cnt, msm_off, msm_cur, msm_perm, msm_sorted, msm_ovf, msm_buckets, msm_S[2], msm_C[2], msm_probs, foldprobs, naf,
         gbuf[2], aux_pts, aux_scal, vscal, tmp_in, tmp_in2, tmp_out, vals, uni, stream_buf;
-    PinBuf h_cp, h_res, h_part, h_misc, h_misc2, h_probs, h_auxc, h_auxs, h_stab, h_ovf;
+    PinBuf h_cp, h_res, h_part, h_misc, h_misc2, h_probs, h_auxc, h_auxs, h_ovf;
 
     void init() {
         if (inited) return;
@@ -1045,8 +1045,6 @@ void timing_end(Ctx &C) {
     g_last_timing = C.tm.t;
 }
 
-// (the intra-call split over lanes was retired when one lane became able to fill the GPU; lanes now serve concurrent calls)
-template <class F> void run_dual(Ctx &C, size_t P, F f) { f(C, (size_t)0, P); }
 
 template <class F> int guarded(F f) {
     try { return f(); }
@@ -1098,12 +1096,8 @@ int create_impl(Ctx &C, const float *values, size_t d, const uint8_t *blind, siz
     HIPCHK(hipMemcpyAsync(commits_out, Cb, d * 32, hipMemcpyDeviceToHost, C.stream));
     size_t plen = 32 * (9 + 2 * (size_t)lg2u(prove_range * chunk));
     get_gens(C, prove_range, chunk);
-    HIPCHK(hipStreamSynchronize(C.stream));       // V bytes, vshift and blindings are complete before the lanes fork
-    u64 per_chunk_nonces = (u64)chunk * (2 * prove_range + 4);
-    run_dual(C, P, [&](Ctx &Ln, size_t c0, size_t nc) {
-        prove_chunks(Ln, "RangeProof", nc, prove_range, chunk, vshift + c0 * chunk, d_blind_buf + c0 * chunk, nonce, c0 * per_chunk_nonces,
-                     hV.data() + c0 * chunk * 32, proofs_out + c0 * plen);
-    });
+    HIPCHK(hipStreamSynchronize(C.stream));       // V bytes (host copy) are complete
+    prove_chunks(C, "RangeProof", P, prove_range, chunk, vshift, d_blind_buf, nonce, 0, hV.data(), proofs_out);
     timing_end(C);
     *plen_out = plen; *np_out = P;
     return ROFL_OK;
@@ -1158,19 +1152,10 @@ int verify_impl(Ctx &C, size_t n_clients, const uint8_t *const *proofs, size_t p
     std::vector<int> okc(P);
     get_gens(C, prove_range, chunk);
     HIPCHK(hipStreamSynchronize(C.stream));
-    int rc = 0; std::mutex rc_mu;
     static const bool vbatch = !(getenv("ROFL_VERIFY_BATCH") && atoi(getenv("ROFL_VERIFY_BATCH")) == 0);
     size_t grp = vbatch ? nv : 1;
-    if (n_clients == 1) {
-        rc = verify_chunks(C, "RangeProof", prove_range, P, prove_range, chunk, pf.data(), proof_len, Vh.data(), d_vn2, seed, cidx.data(), okc.data(), grp);
-    } else {
-        run_dual(C, n_clients, [&](Ctx &Ln, size_t i0, size_t ni) {       // lanes split the clients; a client's chunks stay together
-            size_t c0 = i0 * nv, nc = ni * nv;
-            int r = verify_chunks(Ln, "RangeProof", prove_range, nc, prove_range, chunk, pf.data() + c0 * proof_len, proof_len, Vh.data() + c0 * chunk * 32,
-                                  d_vn2 + c0 * chunk, seed, cidx.data() + c0, okc.data() + c0, grp);
-            if (r) { std::lock_guard<std::mutex> lk2(rc_mu); if (!rc) rc = r; }
-        });
-    }
+    // all (client, chunk) pairs in one pass; a client's chunks form one batch of the random-weighted check
+    int rc = verify_chunks(C, "RangeProof", prove_range, P, prove_range, chunk, pf.data(), proof_len, Vh.data(), d_vn2, seed, cidx.data(), okc.data(), grp);
     timing_end(C);
     if (rc) return fail(rc, "proof rejected before verification (format / bitsize)");
     for (size_t i = 0; i < n_clients; i++) { int r = 1; for (size_t c = 0; c < nv; c++) r &= okc[i * nv + c]; ok_out[i] = r; }

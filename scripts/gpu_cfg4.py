@@ -20,6 +20,12 @@ t=time.time(); oks=R.range_proof_vec.verify_rangeproof_batch(prs,cms,nb,verifier
 print(f"batch verify {ncl} clients: {tv*1e3:.1f} ms -> {ncl*d/tv:.0f} elem/s", oks, R.last_timing())
 t=time.time(); ok1=[R.range_proof_vec.verify_rangeproof(prs[i],cms[i],nb,verifier_seed=b'\x01'*32) for i in range(ncl)]; tv1=time.time()-t
 print(f"one-by-one verify: {tv1*1e3:.1f} ms -> {ncl*d/tv1:.0f} elem/s", ok1)
+from concurrent.futures import ThreadPoolExecutor
+for nthr in (2, 3):
+    with ThreadPoolExecutor(max_workers=nthr) as ex:
+        list(ex.map(lambda i: R.range_proof_vec.verify_rangeproof(prs[i],cms[i],nb,verifier_seed=b'\x01'*32), range(ncl)))   # warm the lanes
+        t=time.time(); okc=list(ex.map(lambda i: R.range_proof_vec.verify_rangeproof(prs[i],cms[i],nb,verifier_seed=b'\x01'*32), range(ncl))); tvc=time.time()-t
+    print(f"verify from {nthr} threads (one lane each): {tvc*1e3:.1f} ms -> {ncl*d/tvc:.0f} elem/s", okc)
 prs[1]=prs[1].copy(); prs[1][3,77]^=1
 cms[4]=cms[4].copy(); cms[4][54999]=cms[4][0]
 print("tampered batch:", R.range_proof_vec.verify_rangeproof_batch(prs,cms,nb,verifier_seed=b'\x02'*32))

@@ -211,13 +211,15 @@ struct Ctx {
     u32 fold_pb = 32, fold_w = 6;
     std::map<const niels *, niels *> wtabs;              // generator table -> 16 window slices 2^(16w) P (fixed-base MSM)
     int msm_lds = 1; size_t msm_lds_min = 8192, msm_lds_tile = 131072;
-    int msm_fb = 1; u32 msm_fb_sets = 4; size_t msm_fb_min = (size_t)1 << 17; int msm_lr = 1;
+    size_t msm_fb_threads = (size_t)1 << 19;
+    int msm_fb = 1; u32 msm_fb_sets = 2; size_t msm_fb_min = (size_t)1 << 17; int msm_lr = 1;
+    bool crowded() const { const Ctx *P = parent ? parent : this; return P->active_calls.load() > 1; }   // other calls in flight on this device
     struct Bsgs { uint8_t *keys; u32 *slots; u32 mask; };
     std::map<size_t, Bsgs> bsgs;                          // table_size -> baby-step table
     std::unique_ptr<HostPool> pool;
     size_t fold_min = 1024;
     bool msm_slots = true;
-    int fold_t = 2, fold_t1 = 3, fold_k = 0, fold_tab = 1, fold_unit = 1; long fold_threads = 524288;
+    int fold_t = 2, fold_t1 = 3, fold_k = 0, fold_tab = 1, fold_unit = 1; long fold_threads = 131072;
     Timing tm;
     // workspace
     DevBuf cp, sL, sR, party, Scanon, vshift, blind, Vbytes, Cbytes, status, partial, partial2, scpart, a, b, yinv,
@@ -251,6 +253,7 @@ struct Ctx {
         if (const char *e = getenv("ROFL_FOLD_T")) { int v = atoi(e); if (v >= 1 && v <= 6) fold_t = v; }
         if (const char *e = getenv("ROFL_MSM_SLOTS")) msm_slots = atoi(e) != 0;
         if (const char *e = getenv("ROFL_MSM_FB")) msm_fb = atoi(e);
+        if (const char *e = getenv("ROFL_MSM_FB_THREADS")) { long v = atol(e); if (v >= 1) msm_fb_threads = (size_t)v; }
         if (const char *e = getenv("ROFL_MSM_LDS")) msm_lds = atoi(e);
         if (const char *e = getenv("ROFL_MSM_LDS_MIN")) { long v = atol(e); if (v >= 1) msm_lds_min = (size_t)v; }
         if (const char *e = getenv("ROFL_MSM_LDS_TILE")) { long v = atol(e); if (v >= 1024) msm_lds_tile = (size_t)v; }
@@ -276,6 +279,7 @@ struct Ctx {
         HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         ht = p.ht; d_tabB = p.d_tabB; d_tabBb = p.d_tabBb; d_two_pow = p.d_two_pow;
         msm_lds = p.msm_lds; msm_lds_min = p.msm_lds_min; msm_lds_tile = p.msm_lds_tile;
+        msm_fb_threads = p.msm_fb_threads;
         msm_fb = p.msm_fb; msm_fb_sets = p.msm_fb_sets; msm_fb_min = p.msm_fb_min; msm_lr = p.msm_lr;
         fold_min = p.fold_min; msm_slots = p.msm_slots; fold_t = p.fold_t; fold_t1 = p.fold_t1; fold_k = p.fold_k; fold_tab = p.fold_tab;
         fold_unit = p.fold_unit; fold_threads = p.fold_threads; nlanes = 1;
@@ -423,9 +427,12 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
         u32 Wgrid, cap;
         if (fb) {
             P = msm_plan_c(16);
-            sets = C.msm_fb_sets;
-            // keep at least ~1M accumulate threads in flight
-            while (sets < 16 && (size_t)nq * (lr ? 2 : 1) * sets * P.B < ((size_t)1 << 20)) sets *= 2;
+            // Fewer sets = less bucket-reduction work but fewer accumulate threads.  Alone on the device the call wants the
+            // threads (latency); with other calls in flight the GPU is full anyway and the work is what counts.
+            bool crowded = C.crowded();
+            sets = crowded ? std::max<u32>(1, C.msm_fb_sets / 2) : C.msm_fb_sets;
+            size_t want = crowded ? C.msm_fb_threads / 2 : C.msm_fb_threads;
+            while (sets < 16 && (size_t)nq * (lr ? 2 : 1) * sets * P.B < want) sets *= 2;
             mm.fb_sets = sets; mm.fb_wps = 16 / sets; mm.fb_stride = (u32)opt.fb_stride;
             PW = nq * (lr ? 2 : 1) * sets; Wgrid = P.W;
             size_t per_side = lr ? n / 2 : n;
@@ -801,7 +808,8 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
                 // segment the digit positions so that K threads share one output with equal work
                 u32 K = 1;
                 size_t thr = (size_t)2 * P * n_new;
-                while (K < FOLD_MAXSEG && thr * K < (size_t)C.fold_threads) K *= 2;
+                // (segments trade extra doublings for parallelism: not worth it while other calls keep the GPU busy)
+                while (K < FOLD_MAXSEG && thr * K < (size_t)C.fold_threads / (C.crowded() ? 2 : 1)) K *= 2;
                 if (C.fold_k > 0) K = (u32)C.fold_k;
                 FoldSeg seg{};
                 double eff = (double)(nsrc - (unit ? 1 : 0));

@@ -174,6 +174,12 @@ int rofl_wire_encode(const rofl_wire_msg_t *m, uint8_t *out, size_t cap, size_t 
  * bytes; pass NULL first to learn n_range_proofs / range_proof_len).  Returns 5 (FormatError) on malformed input. */
 int rofl_wire_decode(int kind, const uint8_t *data, size_t len, rofl_wire_msg_t *m, uint8_t *range_proofs_out, size_t range_proofs_cap);
 
+/* Memory spaces.  The per-element INPUT arrays of rofl_create_rangeproof (values, blindings), rofl_verify_rangeproof(_batch)
+ * (proofs, commitments) and of the per-element Sigma-proof entry points (values, randomness, existing commitments, proofs,
+ * commitments) may live in host memory or in device memory of the library's device (HIP unified addressing): a caller that
+ * already holds the update on the GPU passes device pointers and nothing crosses PCIe on the way in.  Outputs are written to
+ * host memory. */
+
 /* ---- measurement hooks (bench.py) ---- */
 /* Time of the kernels of the last create / verify call, from HIP events on the library's stream. */
 typedef struct {

@@ -115,6 +115,18 @@ def _ptr(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
+def _is_dev(x):
+    """a torch tensor living on the GPU (anything with data_ptr() and is_cuda): handed to the library as a device pointer"""
+    return hasattr(x, "data_ptr") and getattr(x, "is_cuda", False)
+
+
+def _dev_arg(x, elem_bytes, row=1):
+    """(pointer, rows) of a contiguous device tensor holding rows of `row` elements of `elem_bytes` bytes"""
+    if not x.is_contiguous() or x.element_size() != elem_bytes:
+        raise ValueError("device inputs must be contiguous tensors of the expected element type")
+    return ctypes.c_void_p(x.data_ptr()), x.numel() // row
+
+
 def set_device(dev):
     _check(lib().rofl_set_device(int(dev)))
 
@@ -159,18 +171,22 @@ class range_proof_vec:
 
     @staticmethod
     def create_rangeproof(values, blindings, prove_range, n_partition, nonce=None):
-        """-> (proofs uint8[n_proofs, proof_len], commitments uint8[d, 32])"""
-        v = np.ascontiguousarray(values, dtype=np.float32)
-        b = _u8(blindings)
+        """-> (proofs uint8[n_proofs, proof_len], commitments uint8[d, 32]).  `values` (f32[d]) and `blindings` (u8[d,32]) may be
+        numpy arrays or torch tensors on the library's GPU (no host round trip on the way in)."""
+        if _is_dev(values) and _is_dev(blindings):
+            (vp, d), (bp, db) = _dev_arg(values, 4), _dev_arg(blindings, 1, 32)
+        else:
+            v = np.ascontiguousarray(values, dtype=np.float32)
+            b = _u8(blindings)
+            vp, d, bp, db = _ptr(v), v.size, _ptr(b), (b.shape[0] if b.size else 0)
         nonce = nonce or Nonce.random()
         ns = nonce._struct()
-        d = v.size
         npr = lib().rofl_rangeproof_chunks(_sz(max(d, 1)), _sz(max(n_partition, 1)))
         plen = lib().rofl_rangeproof_size(_sz(max(prove_range, 1)), _sz(max(d, 1)), _sz(max(n_partition, 1)))
         proofs = np.zeros((max(npr, 1), max(plen, 32)), dtype=np.uint8)
         commits = np.zeros((max(d, 1), 32), dtype=np.uint8)
         plen_o, npr_o = _sz(), _sz()
-        _check(lib().rofl_create_rangeproof(_ptr(v), _sz(d), _ptr(b), _sz(b.shape[0] if b.size else 0), _sz(prove_range),
+        _check(lib().rofl_create_rangeproof(vp, _sz(d), bp, _sz(db), _sz(prove_range),
                                             _sz(n_partition), _FpConfig.fp_bits, _FpConfig.fp_frac, ctypes.byref(ns),
                                             _ptr(proofs), ctypes.byref(plen_o), ctypes.byref(npr_o), _ptr(commits)))
         assert plen_o.value == plen and npr_o.value == npr
@@ -179,10 +195,14 @@ class range_proof_vec:
     @staticmethod
     def verify_rangeproof(proofs, commits, prove_range, verifier_seed=None):
         p = np.ascontiguousarray(proofs, dtype=np.uint8)
-        c = _u8(commits)
+        if _is_dev(commits):
+            cptr, dc = _dev_arg(commits, 1, 32)
+        else:
+            c = _u8(commits)
+            cptr, dc = _ptr(c), c.shape[0]
         seed = bytes(verifier_seed) if verifier_seed is not None else os.urandom(32)
         ok = ctypes.c_int()
-        _check(lib().rofl_verify_rangeproof(_ptr(p), _sz(p.shape[1]), _sz(p.shape[0]), _ptr(c), _sz(c.shape[0]),
+        _check(lib().rofl_verify_rangeproof(_ptr(p), _sz(p.shape[1]), _sz(p.shape[0]), cptr, _sz(dc),
                                             _sz(prove_range), _FpConfig.fp_bits, _FpConfig.fp_frac, seed, ctypes.byref(ok)))
         return bool(ok.value)
 

@@ -1075,11 +1075,11 @@ int create_impl(Ctx &C, const float *values, size_t d, const uint8_t *blind, siz
     C.init();
     timing_begin(C);
     float *d_vals = C.vals.as<float>(d);
-    HIPCHK(hipMemcpyAsync(d_vals, values, sizeof(float) * d, hipMemcpyHostToDevice, C.stream));
+    HIPCHK(hipMemcpyAsync(d_vals, values, sizeof(float) * d, hipMemcpyDefault, C.stream));      // caller's array: host or device memory
     u64 *vshift = C.vshift.as<u64>(dp);
     sc *d_blind_buf = C.blind.as<sc>(dp);
     HIPCHK(hipMemsetAsync(d_blind_buf, 0, sizeof(sc) * dp, C.stream));
-    HIPCHK(hipMemcpyAsync(d_blind_buf, blind, 32 * d, hipMemcpyHostToDevice, C.stream));
+    HIPCHK(hipMemcpyAsync(d_blind_buf, blind, 32 * d, hipMemcpyDefault, C.stream));
     u32 *status = C.status.as<u32>(4);
     HIPCHK(hipMemsetAsync(status, 0, 16, C.stream));
     hipLaunchKernelGGL(k_quantize_shift, grid1(dp), dim3(TPB), 0, C.stream, d_vals, (u32)d, (u32)dp, (u32)prove_range, fp_bits, fp_frac, mn, mx, vshift, status);
@@ -1136,7 +1136,7 @@ int verify_impl(Ctx &C, size_t n_clients, const uint8_t *const *proofs, size_t p
     HIPCHK(hipMemsetAsync(status, 0, 16, C.stream));
     std::vector<uint8_t> hV(tot * 32);
     for (size_t i = 0; i < n_clients; i++) {
-        HIPCHK(hipMemcpyAsync(d_in + i * dp * 32, commits[i], d * 32, hipMemcpyHostToDevice, C.stream));
+        HIPCHK(hipMemcpyAsync(d_in + i * dp * 32, commits[i], d * 32, hipMemcpyDefault, C.stream));
         hipLaunchKernelGGL(k_decode, grid1(dp), dim3(TPB), 0, C.stream, (u32)dp, (u32)d, d_in + i * dp * 32, d_shift, d_vn + i * dp, d_enc + i * dp * 32, status);
     }
     HIPCHK(hipMemcpyAsync(hV.data(), d_enc, tot * 32, hipMemcpyDeviceToHost, C.stream));
@@ -1152,7 +1152,7 @@ int verify_impl(Ctx &C, size_t n_clients, const uint8_t *const *proofs, size_t p
     for (size_t i = 0; i < n_clients; i++)
         for (size_t c = 0; c < nv; c++) {
             size_t q = i * nv + c;
-            memcpy(&pf[q * proof_len], proofs[i] + c * proof_len, proof_len);
+            HIPCHK(hipMemcpy(&pf[q * proof_len], proofs[i] + c * proof_len, proof_len, hipMemcpyDefault));   // host or device memory
             memcpy(&Vh[q * chunk * 32], &hV[(i * dp + c * chunk) * 32], chunk * 32);
             HIPCHK(hipMemcpyAsync(d_vn2 + q * chunk, d_vn + i * dp + c * chunk, sizeof(niels) * chunk, hipMemcpyDeviceToDevice, C.stream));
             cidx[q] = c;
@@ -1327,10 +1327,10 @@ int sigma_create(int kind, const float *values, size_t d, const uint8_t *r1, siz
     uint8_t *dp = C.aux_pts.as<uint8_t>(d * plen), *dc = C.aux_scal.as<uint8_t>(d * clen);
     u32 *status = C.status.as<u32>(4);
     HIPCHK(hipMemsetAsync(status, 0, 16, C.stream));
-    HIPCHK(hipMemcpyAsync(dv, values, 4 * d, hipMemcpyHostToDevice, C.stream));
-    HIPCHK(hipMemcpyAsync(dr1, r1, 32 * d, hipMemcpyHostToDevice, C.stream));
-    if (has_sq) HIPCHK(hipMemcpyAsync(dr2, r2, 32 * d, hipMemcpyHostToDevice, C.stream));
-    if (dex) HIPCHK(hipMemcpyAsync(dex, existing, 32 * d, hipMemcpyHostToDevice, C.stream));
+    HIPCHK(hipMemcpyAsync(dv, values, 4 * d, hipMemcpyDefault, C.stream));
+    HIPCHK(hipMemcpyAsync(dr1, r1, 32 * d, hipMemcpyDefault, C.stream));
+    if (has_sq) HIPCHK(hipMemcpyAsync(dr2, r2, 32 * d, hipMemcpyDefault, C.stream));
+    if (dex) HIPCHK(hipMemcpyAsync(dex, existing, 32 * d, hipMemcpyDefault, C.stream));
     NonceSeed seed{}; const uint8_t *d_stream = nullptr; u64 ss = 0;
     if (nonce->mode == 1) memcpy(seed.w, nonce->seed, 32);
     else { ss = nonce->stream_scalars; uint8_t *sb = C.stream_buf.as<uint8_t>(ss * 64 + 64); HIPCHK(hipMemcpyAsync(sb, nonce->stream, ss * 64, hipMemcpyHostToDevice, C.stream)); d_stream = sb; }
@@ -1356,8 +1356,8 @@ int sigma_verify(int kind, const uint8_t *proofs, const uint8_t *commits, size_t
     uint8_t *dp = C.aux_pts.as<uint8_t>(d * plen), *dc = C.aux_scal.as<uint8_t>(d * clen);
     u32 *status = C.status.as<u32>(4);
     HIPCHK(hipMemsetAsync(status, 0, 16, C.stream));
-    HIPCHK(hipMemcpyAsync(dp, proofs, d * plen, hipMemcpyHostToDevice, C.stream));
-    HIPCHK(hipMemcpyAsync(dc, commits, d * clen, hipMemcpyHostToDevice, C.stream));
+    HIPCHK(hipMemcpyAsync(dp, proofs, d * plen, hipMemcpyDefault, C.stream));
+    HIPCHK(hipMemcpyAsync(dc, commits, d * clen, hipMemcpyDefault, C.stream));
     hipLaunchKernelGGL(k_sigma_verify, dim3((unsigned)((d + 63) / 64)), dim3(64), 0, C.stream, kind, (u32)d, dp, dc, sigma_init_state(kind), C.d_tabB, C.d_tabBb, status + 1, status);
     u32 st[2] = {0, 0};
     HIPCHK(hipMemcpyAsync(st, status, 8, hipMemcpyDeviceToHost, C.stream));

@@ -577,3 +577,11 @@ def test_concurrent_calls_use_separate_lanes(R):
         for (rc1, rc2, ok, pr, cm) in res[i]:
             assert rc1 == 0 and rc2 == 0 and ok == 1 and (pr == opr).all() and (cm == ocm).all(), shapes[i]
     R.api.set_fp(16, 7)
+
+
+def test_device_resident_inputs(R):
+    """values / blindings / commitments handed over as device pointers (torch CUDA tensors) give the same bytes.
+    (Own process: torch has to bring up its HIP runtime before the library's is loaded, as in bench.py.)"""
+    import subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "gpu_device_inputs_check.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "DEVICE_INPUTS PASS" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -102,9 +102,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8192)
     ap.add_argument("--no-l2", action="store_true")
-    ap.add_argument("--clients-per-step", type=int, default=0, help="clients in flight per GPU (0 = 3, fewer when host cores are scarce)")
+    ap.add_argument("--clients-per-step", type=int, default=0, help="clients in flight per GPU (0 = 3; fewer when there are less than ~2 host cores per client in flight: one uses ~1.6)")
     args = ap.parse_args()
-    CPS = args.clients_per_step if args.clients_per_step > 0 else max(1, min(3, avail_cores() // (4 * int(os.environ.get("LOCAL_WORLD_SIZE", "1")))))
+    CPS = args.clients_per_step if args.clients_per_step > 0 else max(1, min(3, avail_cores() // (2 * int(os.environ.get("LOCAL_WORLD_SIZE", "1")))))
     os.environ.setdefault("ROFL_LANES", str(CPS))
 
     import torch

@@ -207,6 +207,7 @@ int rofl_dbg_host_sc_mul(const uint8_t a[32], const uint8_t b[32], uint8_t out[3
 int rofl_dbg_host_sc_wide(const uint8_t in[64], uint8_t out[32]);
 int rofl_dbg_host_from_uniform(const uint8_t in[64], uint8_t out[32]);
 int rofl_dbg_host_scalarmult_base(const uint8_t k[32], int use_blinding_base, uint8_t out[32]);
+int rofl_dbg_host_fd_codec(const uint8_t in[32], uint8_t out[32]);
 int rofl_dbg_host_decode_encode(const uint8_t in[32], uint8_t out[32]);   /* returns 5 if invalid */
 /* radix-2^25.5 kernel arithmetic (fe26.hpp) compiled for the host with bound assertions enabled */
 int rofl_dbg_host_fd_ops(const uint8_t a[32], const uint8_t b[32], uint8_t out_mul[32], uint8_t out_sq[32], uint8_t out_add[32], uint8_t out_sub[32], uint8_t out_inv[32]);

@@ -252,4 +252,82 @@ HDN inline niels gd_to_niels(const gd &p) {
     return r;
 }
 
+// ---------------------------------------------------------------- Ristretto codec in the register radix
+// (RFC 9496 4.3.1 / 4.3.2, same steps as fe32.hpp's ristretto_decode / ristretto_encode: the 254-step square-root chain
+//  runs on fd_sq -- ~110 VALU instructions instead of ~320 for the saturated form.)  Every fd_sub subtrahend and every
+//  multiplication operand below is a product (tight) or a sum of two tight values; comparisons go through the canonical bytes.
+HD bool fd_iszero(const fd &a) { return fe_iszero(fd_pack(a)); }
+HD bool fd_isneg(const fd &a) { return fe_isneg(fd_pack(a)); }
+HD bool fd_eq(const fd &a, const fd &b) { return fe_iszero(fe_sub(fd_pack(a), fd_pack(b))); }
+HD fd fd_abs(const fd &a) { fd t = fd_carry(a); return fd_select(t, fd_carry(fd_neg(t)), fd_isneg(t)); }
+HDN inline fd fd_pow22523(const fd &z) {      // z^((p-5)/8) = z^(2^252 - 3)
+    fd z2 = fd_sq(z);
+    fd z9 = fd_mul(fd_sqn(z2, 2), z);
+    fd z11 = fd_mul(z9, z2);
+    fd z_5_0 = fd_mul(fd_sq(z11), z9);
+    fd z_10_0 = fd_mul(fd_sqn(z_5_0, 5), z_5_0);
+    fd z_20_0 = fd_mul(fd_sqn(z_10_0, 10), z_10_0);
+    fd z_40_0 = fd_mul(fd_sqn(z_20_0, 20), z_20_0);
+    fd z_50_0 = fd_mul(fd_sqn(z_40_0, 10), z_10_0);
+    fd z_100_0 = fd_mul(fd_sqn(z_50_0, 50), z_50_0);
+    fd z_200_0 = fd_mul(fd_sqn(z_100_0, 100), z_100_0);
+    fd z_250_0 = fd_mul(fd_sqn(z_200_0, 50), z_50_0);
+    return fd_mul(fd_sqn(z_250_0, 2), z);
+}
+// SQRT_RATIO_M1; u, v tight.  Returns was_square; out = |sqrt(u/v)| or |sqrt(i u/v)|, tight.
+HDN inline bool fd_sqrt_ratio_i(fd &out, const fd &u, const fd &v) {
+    fd sqrtm1 = fd_unpack(fe_sqrtm1());
+    fd v3 = fd_mul(fd_sq(v), v);
+    fd v7 = fd_mul(fd_sq(v3), v);
+    fd r = fd_mul(fd_mul(u, v3), fd_pow22523(fd_mul(u, v7)));
+    fd check = fd_mul(v, fd_sq(r));
+    fd neg_u = fd_carry(fd_neg(u));
+    bool correct = fd_eq(check, u);
+    bool flipped = fd_eq(check, neg_u);
+    bool flipped_i = fd_eq(check, fd_mul(neg_u, sqrtm1));
+    fd r_prime = fd_mul(r, sqrtm1);
+    r = fd_select(r, r_prime, flipped || flipped_i);
+    out = fd_abs(r);
+    return correct || flipped;
+}
+HDN inline void gd_ristretto_encode(uint8_t *s, const gd &p) {
+    fd sqrtm1 = fd_unpack(fe_sqrtm1());
+    fd X = fd_carry(p.X), Y = fd_carry(p.Y), Z = fd_carry(p.Z), T = fd_carry(p.T);
+    fd u1 = fd_mul(fd_add(Z, Y), fd_sub(Z, Y));
+    fd u2 = fd_mul(X, Y);
+    fd invsqrt; fd_sqrt_ratio_i(invsqrt, fd_one(), fd_mul(u1, fd_sq(u2)));
+    fd den1 = fd_mul(invsqrt, u1), den2 = fd_mul(invsqrt, u2);
+    fd z_inv = fd_mul(fd_mul(den1, den2), T);
+    fd ix0 = fd_mul(X, sqrtm1), iy0 = fd_mul(Y, sqrtm1);
+    fd ench = fd_mul(den1, fd_unpack(fe_invsqrt_a_minus_d()));
+    bool rotate = fd_isneg(fd_mul(T, z_inv));
+    fd x = fd_select(X, iy0, rotate), y = fd_select(Y, ix0, rotate);
+    fd den_inv = fd_select(den2, ench, rotate);
+    if (fd_isneg(fd_mul(x, z_inv))) y = fd_carry(fd_neg(y));
+    fd sres = fd_abs(fd_mul(den_inv, fd_sub(Z, y)));
+    fe_tobytes(s, fd_pack(sres));
+}
+// Output has Z = 1 and tight coordinates.
+HDN inline bool gd_ristretto_decode(gd &p, const uint8_t *sb) {
+    fe s8 = fe_frombytes(sb);
+    uint8_t chk[32]; fe_tobytes(chk, s8);
+    bool canon = true;
+    for (int i = 0; i < 32; i++) canon &= (chk[i] == sb[i]);
+    if (!canon || (sb[0] & 1)) return false;
+    fd s = fd_unpack(s8);
+    fd ss = fd_sq(s);
+    fd u1 = fd_carry(fd_sub(fd_one(), ss)), u2 = fd_carry(fd_add(fd_one(), ss));
+    fd u2s = fd_sq(u2);
+    fd v = fd_carry(fd_sub(fd_carry(fd_neg(fd_mul(fd_unpack(fe_d()), fd_sq(u1)))), u2s));
+    fd invsqrt; bool ok = fd_sqrt_ratio_i(invsqrt, fd_one(), fd_mul(v, u2s));
+    fd dx = fd_mul(invsqrt, u2);
+    fd dy = fd_mul(fd_mul(invsqrt, dx), v);
+    fd x = fd_abs(fd_mul(fd_add(s, s), dx));
+    fd y = fd_mul(u1, dy);
+    fd t = fd_mul(x, y);
+    if (!ok || fd_isneg(t) || fd_iszero(y)) return false;
+    p.X = x; p.Y = y; p.Z = fd_one(); p.T = t;
+    return true;
+}
+
 }  // namespace rofl

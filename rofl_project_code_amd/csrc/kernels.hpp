@@ -264,7 +264,7 @@ __global__ void __launch_bounds__(TPB) k_quantize_shift(const float *vals, u32 d
 
 // ================================================================ K3: Pedersen commit (fixed-base)
 // tables: radix-16 signed digits, tab[w][e] = (e+1) * 16^w * P, w < 64, e < 8  (affine niels)
-__device__ __forceinline__ ge fixed_base_mul_acc(ge acc, const niels *tab, const sc &k, int nwin) {
+__device__ __forceinline__ gd fixed_base_mul_acc(gd acc, const niels *tab, const sc &k, int nwin) {
     // k canonical (< 2^253 when nwin == 64 so the carry digit is zero)
     int carry = 0;
     for (int i = 0; i < nwin; i++) {
@@ -272,15 +272,9 @@ __device__ __forceinline__ ge fixed_base_mul_acc(ge acc, const niels *tab, const
         carry = (v + 8) >> 4;
         int dgt = v - (carry << 4);
         int ad = dgt < 0 ? -dgt : dgt;
-        if (ad) {
-            niels q = load_niels(&tab[i * 8 + ad - 1]);
-            acc = ge_madd(acc, q, dgt < 0);
-        }
+        if (ad) acc = gd_madd(acc, load_nd(&tab[i * 8 + ad - 1]), dgt < 0);
     }
-    if (carry && nwin < 64) {
-        niels q = load_niels(&tab[nwin * 8 + 0]);
-        acc = ge_madd(acc, q, false);
-    }
+    if (carry && nwin < 64) acc = gd_madd(acc, load_nd(&tab[nwin * 8 + 0]), false);
     return acc;
 }
 // V_j = v_j*B + r_j*Bb (compressed), and optionally C_j = V_j + shift (compressed)
@@ -289,14 +283,14 @@ __global__ void __launch_bounds__(TPB) k_commit(u32 count, const u64 *v64, const
                          uint8_t *V_out /* may be null */, uint8_t *C_out /* may be null */, u32 c_count) {
     u32 j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= count) return;
-    ge acc = ge_identity();
+    gd acc = gd_identity();
     if (v64) { sc v = sc_from_u64(v64[j]); acc = fixed_base_mul_acc(acc, tabB, v, 16); }
     else { sc v = load_sc(&v256_canon[j]); acc = fixed_base_mul_acc(acc, tabB, v, 64); }
     if (blind_canon) { sc r = load_sc(&blind_canon[j]); acc = fixed_base_mul_acc(acc, tabBb, r, 64); }
-    if (V_out) ristretto_encode(V_out + (size_t)j * 32, acc);
+    if (V_out) gd_ristretto_encode(V_out + (size_t)j * 32, acc);
     if (C_out && j < c_count) {
-        ge cpt = shift ? ge_madd(acc, load_niels(shift), false) : acc;
-        ristretto_encode(C_out + (size_t)j * 32, cpt);
+        gd cpt = shift ? gd_madd(acc, load_nd(shift), false) : acc;
+        gd_ristretto_encode(C_out + (size_t)j * 32, cpt);
     }
 }
 
@@ -338,16 +332,16 @@ __global__ void __launch_bounds__(TPB) k_decode_sum(const uint8_t *in, u32 n, u3
     extern __shared__ __align__(16) unsigned char smem[];
     ge *lds = reinterpret_cast<ge *>(smem);
     u32 t = threadIdx.x;
-    ge acc = ge_identity();
+    gd gacc = gd_identity();
     for (u32 i = blockIdx.x * blockDim.x + t; i < n; i += gridDim.x * blockDim.x) {
         __align__(16) uint8_t b[32];
         const uint8_t *s = in + (size_t)i * stride;
         for (int q = 0; q < 32; q++) b[q] = s[q];
-        ge p;
-        if (!ristretto_decode(p, b)) { atomicOr(status, 4u); p = ge_identity(); }
-        acc = ge_add(acc, p);
+        gd p;
+        if (!gd_ristretto_decode(p, b)) { atomicOr(status, 4u); p = gd_identity(); }
+        gacc = gd_add(gacc, p);
     }
-    lds[t] = acc;
+    lds[t] = gd_pack(gacc);
     __syncthreads();
     for (u32 s = blockDim.x / 2; s > 0; s >>= 1) {
         if (t < s) lds[t] = ge_add(lds[t], lds[t + s]);
@@ -968,20 +962,20 @@ __global__ void __launch_bounds__(TPB) k_decode(u32 count, u32 valid_count, cons
     __align__(16) uint8_t b[32];
     const uint4 *s = reinterpret_cast<const uint4 *>(in + (size_t)i * 32);
     reinterpret_cast<uint4 *>(b)[0] = s[0]; reinterpret_cast<uint4 *>(b)[1] = s[1];
-    ge p;
-    if (!ristretto_decode(p, b)) { atomicOr(status, 4u); p = ge_identity(); }
-    if (shift) p = ge_madd(p, load_niels(shift), false);
-    if (out_enc) ristretto_encode(out_enc + (size_t)i * 32, p);
-    if (out_niels) store_niels(&out_niels[i], ge_to_niels(p));
+    gd p;
+    if (!gd_ristretto_decode(p, b)) { atomicOr(status, 4u); p = gd_identity(); }
+    if (shift) p = gd_madd(p, load_nd(shift), false);
+    if (out_enc) gd_ristretto_encode(out_enc + (size_t)i * 32, p);
+    if (out_niels) store_niels(&out_niels[i], gd_to_niels(p));
 }
 // out = a + b (compressed in/out): pedersen_ops.rs:56-59 add_rp_vec
 __global__ void __launch_bounds__(TPB) k_add_points(u32 count, const uint8_t *a, const uint8_t *b, uint8_t *out, u32 *status) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
-    ge p, q;
-    if (!ristretto_decode(p, a + (size_t)i * 32)) { atomicOr(status, 4u); p = ge_identity(); }
-    if (!ristretto_decode(q, b + (size_t)i * 32)) { atomicOr(status, 4u); q = ge_identity(); }
-    ristretto_encode(out + (size_t)i * 32, ge_add(p, q));
+    gd p, q;
+    if (!gd_ristretto_decode(p, a + (size_t)i * 32)) { atomicOr(status, 4u); p = gd_identity(); }
+    if (!gd_ristretto_decode(q, b + (size_t)i * 32)) { atomicOr(status, 4u); q = gd_identity(); }
+    gd_ristretto_encode(out + (size_t)i * 32, gd_add(p, q));
 }
 // bulletproofs verify_multiple: g_k = -z - a s_k ; h_k = z + y^-k (zz z^j 2^i - b s_k^-1)  -> canonical [g | h]
 // One array of 2N scalars per batch of `group` consecutive proofs: sum_c rho_c * (g_c | h_c) -- the proofs of a batch
@@ -1088,8 +1082,8 @@ __device__ inline gd sg_var_mul(const sc &k, const gd &P) {
     }
     return acc;
 }
-__device__ inline void sg_encode(uint8_t *out, const gd &p) { ristretto_encode(out, gd_pack(p)); }
-__device__ inline bool sg_decode(gd &p, const uint8_t *in) { ge t; bool ok = ristretto_decode(t, in); p = gd_unpack(ok ? t : ge_identity()); return ok; }
+__device__ inline void sg_encode(uint8_t *out, const gd &p) { gd_ristretto_encode(out, p); }
+__device__ inline bool sg_decode(gd &p, const uint8_t *in) { bool ok = gd_ristretto_decode(p, in); if (!ok) p = gd_identity(); return ok; }
 __device__ inline bool sg_is_identity(const gd &p) { ge t = gd_pack(p); return ge_is_identity_ristretto(t); }
 
 // kind 0 RandProof (L|R ; L'|R'|Zm|Zr), 1 SquareRandProof (L|R|c_sq ; L'|R'|c_sq'|Zm|Zr1|Zr2), 2 SquareProof (c_l|c_sq ; c_l'|c_sq'|Zm|Zr1|Zr2)
@@ -1214,9 +1208,9 @@ __global__ void __launch_bounds__(TPB) k_decode_pairs(u32 d, const uint8_t *pair
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= 2 * d) return;
     u32 i = t >> 1, which = t & 1;
-    ge p;
-    if (!ristretto_decode(p, pairs + (size_t)64 * i + 32 * which)) { atomicOr(status, 4u); p = ge_identity(); }
-    store_niels(which ? &Rs[i] : &Ls[i], ge_to_niels(p));
+    gd p;
+    if (!gd_ristretto_decode(p, pairs + (size_t)64 * i + 32 * which)) { atomicOr(status, 4u); p = gd_identity(); }
+    store_niels(which ? &Rs[i] : &Ls[i], gd_to_niels(p));
 }
 
 // ================================================================ BSGS discrete log (bsgs32.rs:14-73, pedersen_ops.rs:27-53)

@@ -1784,6 +1784,12 @@ int rofl_dbg_host_fd_scalarmult(const uint8_t k[32], const uint8_t p[32], uint8_
     ristretto_encode(out, gd_pack(back));
     return 0;
 }
+// the register-radix codec on the host (limb bounds asserted): decode, add the identity, re-encode
+int rofl_dbg_host_fd_codec(const uint8_t in[32], uint8_t out[32]) {
+    gd p; if (!gd_ristretto_decode(p, in)) return ROFL_FORMAT_ERROR;
+    gd q = gd_add(gd_double(p), gd_madd(gd_identity(), nd_unpack(gd_to_niels(p)), true));     // 2P - P through the kernel formulas
+    gd_ristretto_encode(out, q); return 0;
+}
 int rofl_dbg_host_decode_encode(const uint8_t in[32], uint8_t out[32]) { ge p; if (!ristretto_decode(p, in)) return ROFL_FORMAT_ERROR; ristretto_encode(out, ge_add(p, ge_identity())); return 0; }
 int rofl_dbg_host_merlin(const uint8_t *label, size_t label_len, const uint8_t *msg, size_t msg_len, uint8_t out[64]) {
     Merlin t((const char *)label, label_len); t.append("msg", msg, msg_len); t.challenge_bytes("chal", out, 64); return 0;

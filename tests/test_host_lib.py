@@ -43,6 +43,8 @@ def test_host_field_and_group_math(hiplib, prim):
         assert (rc == 0) == e["valid"]
         if e["valid"]:
             assert out.raw == H(e["enc"])
+        out = buf(); rc = L.rofl_dbg_host_fd_codec(H(e["enc"]), out)          # the register-radix codec used by the kernels
+        assert (rc == 0) == e["valid"] and (not e["valid"] or out.raw == H(e["enc"]))
     P = 2 ** 255 - 19
     rng = np.random.default_rng(3)
     for i in range(64):
@@ -118,3 +120,22 @@ def test_no_cpu_fallback_in_product():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "liborc" not in txt and "oracle/" not in txt and "import orc" not in txt, f
+
+
+def test_register_radix_codec_random(hiplib, prim):
+    """gd_ristretto_decode / gd_ristretto_encode (fe26.hpp) on the host build, limb bounds asserted: round trip through
+    2P - P on random group elements, and the same accept / reject decisions as the saturated-form codec on random strings."""
+    import orc
+    L = hiplib
+    rng = np.random.default_rng(17)
+    pts = orc.commit_vec(orc.rand_scalars(rng, 200), orc.rand_scalars(rng, 200))
+    for e in pts:
+        out = ctypes.create_string_buffer(32)
+        assert L.rofl_dbg_host_fd_codec(e.tobytes(), out) == 0 and out.raw == e.tobytes()
+    for i in range(300):
+        raw = bytearray(rng.integers(0, 256, 32, dtype=np.uint8).tobytes())
+        if i % 3 == 0: raw[31] &= 0x7f
+        if i % 3 == 1: raw[0] &= 0xfe; raw[31] &= 0x7f
+        o1, o2 = ctypes.create_string_buffer(32), ctypes.create_string_buffer(32)
+        r1, r2 = L.rofl_dbg_host_decode_encode(bytes(raw), o1), L.rofl_dbg_host_fd_codec(bytes(raw), o2)
+        assert r1 == r2 and (r1 != 0 or o1.raw == o2.raw == bytes(raw))

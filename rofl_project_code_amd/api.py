@@ -89,7 +89,7 @@ def lib():
             raise RuntimeError(f"{_LIB_PATH} not found: build it with `python -m rofl_project_code_amd.build` "
                                "(hipcc --offload-arch=gfx950); there is no CPU fallback")
         _lib = ctypes.CDLL(_LIB_PATH)
-        for name in ("rofl_next_pow2", "rofl_rangeproof_chunks", "rofl_rangeproof_size", "rofl_nonces_per_chunk"):
+        for name in ("rofl_next_pow2", "rofl_rangeproof_chunks", "rofl_rangeproof_size", "rofl_nonces_per_chunk", "rofl_wire_encoded_size"):
             getattr(_lib, name).restype = ctypes.c_size_t
     return _lib
 

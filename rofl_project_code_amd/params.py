@@ -83,9 +83,6 @@ class wire:
                 "l2_range_bits": m.l2_range_bits, "check_percentage": m.check_percentage}
 
 
-lib().rofl_wire_encoded_size.restype = ctypes.c_size_t
-
-
 def _sub_nonce(seed, tag):
     """Independent nonce streams for the proofs of one container (the reference draws all of them from thread_rng)."""
     if seed is None:

@@ -212,7 +212,7 @@ struct Ctx {
     std::map<const niels *, niels *> wtabs;              // generator table -> 16 window slices 2^(16w) P (fixed-base MSM)
     int msm_lds = 1; size_t msm_lds_min = 8192, msm_lds_tile = 131072;
     size_t msm_fb_threads = (size_t)1 << 19;
-    int msm_fb = 1; u32 msm_fb_sets = 2; size_t msm_fb_min = (size_t)1 << 17; int msm_lr = 1;
+    int msm_fb = 1; u32 msm_fb_sets = 2; size_t msm_fb_min = (size_t)1 << 12; int msm_lr = 1;   // window tables for every (n, m) with 2N >= 4096: many small chunks (n_partition = 64) share them
     bool crowded() const { const Ctx *P = parent ? parent : this; return P->active_calls.load() > 1; }   // other calls in flight on this device
     struct Bsgs { uint8_t *keys; u32 *slots; u32 mask; };
     std::map<size_t, Bsgs> bsgs;                          // table_size -> baby-step table
@@ -433,6 +433,7 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
             sets = crowded ? std::max<u32>(1, C.msm_fb_sets / 2) : C.msm_fb_sets;
             size_t want = crowded ? C.msm_fb_threads / 2 : C.msm_fb_threads;
             while (sets < 16 && (size_t)nq * (lr ? 2 : 1) * sets * P.B < want) sets *= 2;
+            while (sets > 1 && (size_t)nq * (lr ? 2 : 1) * (sets / 2) * P.B >= want) sets /= 2;      // many problems (n_partition = 64): one set each is plenty
             mm.fb_sets = sets; mm.fb_wps = 16 / sets; mm.fb_stride = (u32)opt.fb_stride;
             PW = nq * (lr ? 2 : 1) * sets; Wgrid = P.W;
             size_t per_side = lr ? n / 2 : n;

@@ -237,6 +237,19 @@ HD gd gd_double(const gd &p) {
     gd r; r.X = fd_mul(cT, cX); r.Y = fd_mul(cY, cZ); r.Z = fd_mul(cT, cZ); r.T = fd_mul(cX, cY);
     return r;
 }
+// doubling inside a chain of doublings: the next doubling reads X, Y, Z only, so the T product is skipped (7 instead of 8
+// multiplications); the result's T is stale and must not feed an addition
+HD gd gd_double_not(const gd &p) {
+    fd XX = fd_sq(p.X), YY = fd_sq(p.Y), ZZ = fd_sq(p.Z);
+    fd ZZ2 = fd_add(ZZ, ZZ);
+    fd S = fd_sq(fd_add(p.X, p.Y));
+    fd cY = fd_carry(fd_add(YY, XX));
+    fd cZ = fd_carry(fd_sub(YY, XX));
+    fd cX = fd_sub(S, cY);
+    fd cT = fd_sub(ZZ2, cZ);
+    gd r; r.X = fd_mul(cT, cX); r.Y = fd_mul(cY, cZ); r.Z = fd_mul(cT, cZ); r.T = p.T;
+    return r;
+}
 // affine niels form given 1/Z (batch inversions)
 HDN inline niels gd_to_niels_zinv(const gd &p, const fd &zi) {
     fd x = fd_mul(p.X, zi), y = fd_mul(p.Y, zi);

@@ -606,6 +606,7 @@ __global__ void __launch_bounds__(TPB) k_gens_wtab(u32 total, MsmWin mw, const n
     u32 at = 0;
     for (u32 w = 1; w < mw.W; w++) {
         u32 pos, wid; msm_window(mw, w, pos, wid);
+        for (; at + 1 < pos; at++) cur = gd_double_not(cur);
         for (; at < pos; at++) cur = gd_double(cur);
         store_niels(&wtab[(size_t)w * stride + g], gd_to_niels(cur));
     }
@@ -945,6 +946,34 @@ __global__ void __launch_bounds__(512) k_msm_reduce_fused(u32 E, u32 nb, const g
         __syncthreads();
         si = so; ci = co; E = E2; nb += 1; sel ^= 1;
     }
+}
+
+// Finish an MSM on the device when a launch carries many problems (n_partition = 64: 128 L/R problems per IPP round, whose
+// 253-step Horner chains would otherwise queue on the host pool).  One block per problem, one thread per window: thread w
+// folds its window's bit-sums (S + sum_l 2^l D_l), shifts the result to the window position (pos_w doublings -- the chains
+// of the W windows run side by side, so the launch is as deep as ONE chain) and the block adds the W terms through LDS.
+__global__ void __launch_bounds__(64) k_msm_horner(MsmWin mw, const ge *S_fin, const ge *C_fin, u32 nb, ge *out) {
+    __shared__ ge sh[64];
+    u32 p = blockIdx.x, w = threadIdx.x;
+    if (w < mw.W) {
+        size_t pw = (size_t)p * mw.W + w;
+        gd acc = load_gd(&C_fin[pw * nb + nb - 1]);
+#pragma unroll 1
+        for (int l = (int)nb - 2; l >= 0; l--) acc = gd_add(gd_double(acc), load_gd(&C_fin[pw * nb + l]));
+        acc = gd_add(acc, load_gd(&S_fin[pw]));
+        u32 pos, wid; msm_window(mw, w, pos, wid);
+#pragma unroll 1
+        for (u32 i = 0; i + 1 < pos; i++) acc = gd_double_not(acc);
+        if (pos) acc = gd_double(acc);
+        sh[w] = gd_pack(acc);
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (u32 s = 32; s >= 1; s >>= 1) {
+        if (w < s && w + s < mw.W) sh[w] = gd_pack(gd_add(gd_unpack(sh[w]), gd_unpack(sh[w + s])));
+        __syncthreads();
+    }
+    if (w == 0) out[p] = sh[0];
 }
 
 // ================================================================ K8/K9: verification

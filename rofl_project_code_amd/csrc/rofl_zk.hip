@@ -218,12 +218,13 @@ struct Ctx {
     std::map<size_t, Bsgs> bsgs;                          // table_size -> baby-step table
     std::unique_ptr<HostPool> pool;
     size_t fold_min = 1024;
+    size_t msm_dev_horner_min = 32;   // ROFL_MSM_DEV_HORNER_MIN: launches with at least this many problems finish their Horner chains on the device
     bool msm_slots = true;
     int fold_t = 2, fold_t1 = 3, fold_k = 0, fold_tab = 1, fold_unit = 1; long fold_threads = 131072;
     Timing tm;
     // workspace
     DevBuf cp, sL, sR, party, Scanon, vshift, blind, Vbytes, Cbytes, status, partial, partial2, scpart, a, b, yinv,
-        SL, SR, msm_cnt, msm_off, msm_cur, msm_perm, msm_sorted, msm_ovf, msm_buckets, msm_S[2], msm_C[2], msm_probs, foldprobs, naf,
+        SL, SR, msm_cnt, msm_off, msm_cur, msm_perm, msm_sorted, msm_ovf, msm_buckets, msm_S[2], msm_C[2], msm_fin, msm_probs, foldprobs, naf,
         gbuf[2], aux_pts, aux_scal, vscal, tmp_in, tmp_in2, tmp_out, vals, uni, stream_buf;
     PinBuf h_cp, h_res, h_part, h_misc, h_misc2, h_probs, h_auxc, h_auxs, h_ovf;
 
@@ -261,6 +262,7 @@ struct Ctx {
         if (const char *e = getenv("ROFL_MSM_FB_SETS")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) msm_fb_sets = (u32)v; }
         if (const char *e = getenv("ROFL_MSM_FB_MIN")) { long v = atol(e); if (v >= 1) msm_fb_min = (size_t)v; }
         if (const char *e = getenv("ROFL_FOLD_MIN")) { long v = atol(e); if (v >= 1) fold_min = (size_t)v; }
+        if (const char *e = getenv("ROFL_MSM_DEV_HORNER_MIN")) { long v = atol(e); if (v >= 1) msm_dev_horner_min = (size_t)v; }
         { int nt = 8; if (const char *e = getenv("ROFL_HOST_THREADS")) nt = atoi(e); unsigned hc = std::thread::hardware_concurrency(); if (hc && (unsigned)nt > hc) nt = (int)hc; if (nt < 1) nt = 1; pool.reset(new HostPool(nt)); }
         if (const char *e = getenv("ROFL_FOLD_T1")) { int v = atoi(e); if (v >= 1 && v <= 6) fold_t1 = v; }
         if (const char *e = getenv("ROFL_FOLD_TAB")) fold_tab = atoi(e) != 0;
@@ -281,7 +283,7 @@ struct Ctx {
         msm_lds = p.msm_lds; msm_lds_min = p.msm_lds_min; msm_lds_tile = p.msm_lds_tile;
         msm_fb_threads = p.msm_fb_threads;
         msm_fb = p.msm_fb; msm_fb_sets = p.msm_fb_sets; msm_fb_min = p.msm_fb_min; msm_lr = p.msm_lr;
-        fold_min = p.fold_min; msm_slots = p.msm_slots; fold_t = p.fold_t; fold_t1 = p.fold_t1; fold_k = p.fold_k; fold_tab = p.fold_tab;
+        fold_min = p.fold_min; msm_dev_horner_min = p.msm_dev_horner_min; msm_slots = p.msm_slots; fold_t = p.fold_t; fold_t1 = p.fold_t1; fold_k = p.fold_k; fold_tab = p.fold_tab;
         fold_unit = p.fold_unit; fold_threads = p.fold_threads; nlanes = 1;
         { int nt = 6; if (const char *e = getenv("ROFL_HOST_THREADS")) nt = atoi(e); if (nt < 1) nt = 1; pool.reset(new HostPool(nt)); }
         inited = true;
@@ -416,7 +418,7 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
     MsmProb *d_probs = C.msm_probs.as<MsmProb>(np);
     MsmProb *h_probs = C.h_probs.as<MsmProb>(np);
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    MsmPlan P{}; size_t PW = 0; bool fb_used = false, overlap_done = false; u32 sets = 0;
+    MsmPlan P{}; size_t PW = 0; bool fb_used = false, overlap_done = false, dev_horner = false; u32 sets = 0;
     for (int attempt = 0; attempt < 3; attempt++) {
         // attempt 0: fixed-base slots (if available) ; then generic slots ; then the two-pass sort
         bool fb = attempt == 0 && opt.fb_wtab != nullptr && C.msm_slots;
@@ -501,12 +503,22 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
         u32 nb_final = P.c - 1;
         ge *S_fin = C.msm_S[lv & 1].as<ge>(PW);
         ge *C_fin = C.msm_C[lv & 1].as<ge>(PW * (size_t)nb_final);
+        // block size = first-level work items (small bucket arrays, c = 7: 32 items -- a 256-thread block would idle 7 of its 8
+        // waves and, at 163 VGPRs, hold a whole CU: thousands of such blocks (n_partition = 64) ran 18 deep per CU)
+        u32 fused_items = (E / 8) * (4 + nb), fused_threads = fused_items > 256 ? 512 : fused_items > 128 ? 256 : fused_items > 64 ? 128 : 64;
         size_t lds = ((size_t)(E / 8) * (1 + nb + 3) + (size_t)(E / 16) * (1 + nb + 4) + 1) * sizeof(ge);
-        hipLaunchKernelGGL(k_msm_reduce_fused, dim3((unsigned)PW), dim3((E / 8) * (4 + nb) > 256 ? 512 : 256), lds, C.stream, E, nb, S_in, C_in, S_fin, C_fin, nb_final);
+        hipLaunchKernelGGL(k_msm_reduce_fused, dim3((unsigned)PW), dim3(fused_threads), lds, C.stream, E, nb, S_in, C_in, S_fin, C_fin, nb_final);
         size_t per = 1 + nb_final;
         ge *hres = C.h_res.as<ge>(PW * per);
-        HIPCHK(hipMemcpyAsync(hres, S_fin, sizeof(ge) * PW, hipMemcpyDeviceToHost, C.stream));
-        HIPCHK(hipMemcpyAsync(hres + PW, C_fin, sizeof(ge) * PW * nb_final, hipMemcpyDeviceToHost, C.stream));
+        dev_horner = !fb && np >= C.msm_dev_horner_min && P.W <= 64;
+        if (dev_horner) {      // many problems: their Horner chains run side by side on the device, one point per problem comes back
+            ge *d_fin = C.msm_fin.as<ge>(np);
+            hipLaunchKernelGGL(k_msm_horner, dim3((unsigned)np), dim3(64), 0, C.stream, mw, (const ge *)S_fin, (const ge *)C_fin, nb_final, d_fin);
+            HIPCHK(hipMemcpyAsync(hres, d_fin, sizeof(ge) * np, hipMemcpyDeviceToHost, C.stream));
+        } else {
+            HIPCHK(hipMemcpyAsync(hres, S_fin, sizeof(ge) * PW, hipMemcpyDeviceToHost, C.stream));
+            HIPCHK(hipMemcpyAsync(hres + PW, C_fin, sizeof(ge) * PW * nb_final, hipMemcpyDeviceToHost, C.stream));
+        }
         if (opt.overlap && !overlap_done) { opt.overlap(); overlap_done = true; }
         HIPCHK(hipStreamSynchronize(C.stream));
         if (slots_mode && getenv("ROFL_TRACE")) fprintf(stderr, "[rofl] msm np=%zu n=%zu c=%u cap=%u fb=%u lr=%d overflow=%u\n", np, n, P.c, cap, fb ? sets : 0u, (int)lr, *C.h_ovf.as<u32>(4));
@@ -518,7 +530,9 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
     ge *h = C.h_res.as<ge>(PW * (1 + nb));
     double t0 = now_ms();
     results.resize(np);
-    if (fb_used) {
+    if (dev_horner) {
+        for (size_t p = 0; p < np; p++) results[p] = h51::from_ge(h[p]);
+    } else if (fb_used) {
         // sets of a problem carry equal weight: add them up, then one 16-bit Horner
         C.pool->run(np, [&](size_t p) {
             size_t base = p * sets;                         // lr: problem 2q+side owns sets [(2q+side)*sets, ...)
@@ -743,7 +757,11 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
         r++;
         bool last = (round + 1 == lgN);
         unsigned t_now = first_level ? (unsigned)C.fold_t1 : (unsigned)C.fold_t;
-        if (!last && r >= t_now && (n_g >> r) >= C.fold_min) {
+        // fold_min is a per-chunk size chosen for P = 4 (below it the fold kernel is latency-bound); what matters is the number of
+        // outputs in the launch, so many small chunks (n_partition = 64) keep folding down to 64 generators each
+        size_t n_after = n_g >> r;
+        bool fold_pays = n_after >= C.fold_min || (n_after >= 64 && 2 * P * n_after >= 8 * C.fold_min);
+        if (!last && r >= t_now && fold_pays) {
             // materialise: new[i] = sum_h s_h * cur[h*n_new + i]; with fold_unit the common factor s_0 moves into
             // gscale / hscale so that source 0 needs a single addition
             size_t n_new = n_g >> r; u32 nsrc = 1u << r;

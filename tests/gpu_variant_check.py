@@ -8,7 +8,8 @@ import rofl_project_code_amd as R
 R.set_device(0)
 rng = np.random.default_rng(11)
 bad = 0
-for d, nb, P, fb, ff in ((64, 8, 1, 16, 7), (256, 16, 2, 16, 7), (500, 32, 4, 32, 7), (700, 8, 4, 16, 7), (512, 32, 1, 32, 7), (37, 64, 2, 64, 7)):
+for d, nb, P, fb, ff in ((64, 8, 1, 16, 7), (256, 16, 2, 16, 7), (500, 32, 4, 32, 7), (700, 8, 4, 16, 7), (512, 32, 1, 32, 7), (37, 64, 2, 64, 7),
+                         (2100, 8, 64, 16, 7)):       # many small chunks (the e2e n_partition): device-side Horner, folds down to 64 generators
     R.api.set_fp(fb, ff)
     mn, mx = R.conversion32.get_clip_bounds(nb)
     vals = np.clip(rng.uniform(mn, mx, size=d).astype(np.float32), mn, np.nextafter(np.float32(mx), np.float32(0)))

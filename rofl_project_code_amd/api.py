@@ -131,6 +131,12 @@ def set_device(dev):
     _check(lib().rofl_set_device(int(dev)))
 
 
+def bp_gens_prepare(n_bits, m):
+    """Build (or touch) the cached BulletproofGens::new(n, m) tables on the device -- the reference recomputes them in every
+    create / verify call (range_proof_vec/mod.rs:126,201)."""
+    _check(lib().rofl_bp_gens_prepare(_sz(n_bits), _sz(m)))
+
+
 def set_timing(on):
     _check(lib().rofl_set_timing(int(bool(on))))
 

@@ -821,7 +821,7 @@ __global__ void k_msm_overflow(u32 W, u32 B, u32 pstep, const MsmProb *probs, co
 // one thread per bucket: sum its points.  buckets [prob][W][B] extended.
 // blockIdx.y = grid problem q owning W bucket arrays; its points are probs[q * pstep].pts (pstep = 2 for merged L/R pairs)
 __global__ void __launch_bounds__(TPB) k_msm_accumulate(u32 n, u32 c, u32 W, u32 pstep, const MsmProb *probs, const u32 *cnt, const u32 *off,
-                                 const u32 *sorted, const u32 *perm, ge *buckets, u32 cap) {
+                                 const u32 *sorted, const u32 *perm, ge *buckets, u32 cap, u32 idx_mask) {
     u32 p = blockIdx.y, B = 1u << (c - 1);
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= W * B) return;
@@ -836,7 +836,7 @@ __global__ void __launch_bounds__(TPB) k_msm_accumulate(u32 n, u32 c, u32 W, u32
     // (a software-pipelined variant that keeps the next point load in flight costs 12 VGPRs -> 3 waves/SIMD and was slower)
     for (u32 e = 0; e < num; e++) {
         u32 v = lst[e];
-        acc = gd_madd(acc, gload_nd(&pts[v & 0x7fffffffu]), (v >> 31) != 0);
+        acc = gd_madd(acc, gload_nd(&pts[v & idx_mask]), (v >> 31) != 0);
     }
     store_gd(&buckets[bi], acc);
 }

@@ -1,0 +1,88 @@
+//! `extern "C"` declarations for include/rofl_zk.h, plus the marshalling helpers shared by the overlay modules.
+//! Scalars travel as 32-byte little-endian canonical strings, points as 32-byte compressed Ristretto, proofs in their
+//! upstream `to_bytes` layouts; every output buffer is allocated by the caller.
+use crate::fp::{Frac, N_BITS};
+use curve25519_dalek_ng::ristretto::{CompressedRistretto, RistrettoPoint};
+use curve25519_dalek_ng::scalar::Scalar;
+use rand::RngCore;
+use std::os::raw::{c_char, c_float, c_int, c_uint};
+use fixed::frac::Unsigned;          // fixed re-exports typenum (fp.rs:3 takes U0..U12 from the same module)
+
+#[repr(C)]
+pub struct RoflNonce {
+    pub mode: c_int,            // 0: explicit 64-byte wide scalars in the upstream draw order; 1: 32-byte seed
+    pub stream: *const u8,
+    pub stream_scalars: usize,
+    pub seed: [u8; 32],
+}
+
+extern "C" {
+    pub fn rofl_set_device(device: c_int) -> c_int;
+    pub fn rofl_last_error(buf: *mut c_char, len: usize) -> c_int;
+    pub fn rofl_bp_gens_prepare(n_bits: usize, m: usize) -> c_int;
+    pub fn rofl_rangeproof_chunks(d: usize, n_partition: usize) -> usize;
+    pub fn rofl_rangeproof_size(n_bits: usize, d: usize, n_partition: usize) -> usize;
+    pub fn rofl_create_rangeproof(values: *const c_float, d: usize, blindings32: *const u8, d_blindings: usize,
+        prove_range: usize, n_partition: usize, fp_bits: c_uint, fp_frac: c_uint, nonce: *const RoflNonce,
+        proofs_out: *mut u8, proof_len_out: *mut usize, n_proofs_out: *mut usize, commits_out: *mut u8) -> c_int;
+    pub fn rofl_verify_rangeproof(proofs: *const u8, proof_len: usize, n_proofs: usize, commits32: *const u8, d: usize,
+        prove_range: usize, fp_bits: c_uint, fp_frac: c_uint, verifier_seed: *const u8, ok_out: *mut c_int) -> c_int;
+    pub fn rofl_verify_rangeproof_batch(n_clients: usize, proofs: *const *const u8, proof_len: usize, n_proofs: usize,
+        commits32: *const *const u8, d: usize, prove_range: usize, fp_bits: c_uint, fp_frac: c_uint,
+        verifier_seed: *const u8, ok_out: *mut c_int) -> c_int;
+    pub fn rofl_create_rangeproof_l2(values: *const c_float, d: usize, blindings32: *const u8, d_blindings: usize,
+        prove_range: usize, n_partition: usize, fp_bits: c_uint, fp_frac: c_uint, nonce: *const RoflNonce,
+        proof_out: *mut u8, proof_len_out: *mut usize, commit_out: *mut u8) -> c_int;
+    pub fn rofl_verify_rangeproof_l2(proof: *const u8, proof_len: usize, commit: *const u8, prove_range: usize,
+        fp_bits: c_uint, fp_frac: c_uint, verifier_seed: *const u8, ok_out: *mut c_int) -> c_int;
+    pub fn rofl_create_randproof_vec(values: *const c_float, d: usize, r32: *const u8, d_r: usize, existing32: *const u8,
+        fp_bits: c_uint, fp_frac: c_uint, nonce: *const RoflNonce, proofs_out: *mut u8, pairs_out: *mut u8) -> c_int;
+    pub fn rofl_verify_randproof_vec(proofs: *const u8, pairs: *const u8, d: usize, ok_out: *mut c_int) -> c_int;
+    pub fn rofl_create_squarerandproof_vec(values: *const c_float, d: usize, r1_32: *const u8, d_r1: usize, r2_32: *const u8,
+        existing32: *const u8, fp_bits: c_uint, fp_frac: c_uint, nonce: *const RoflNonce, proofs_out: *mut u8,
+        commits_out: *mut u8) -> c_int;
+    pub fn rofl_verify_squarerandproof_vec(proofs: *const u8, commits: *const u8, d: usize, ok_out: *mut c_int) -> c_int;
+    pub fn rofl_commit_vec(values32: *const u8, blindings32: *const u8, d: usize, out32: *mut u8) -> c_int;
+    pub fn rofl_add_points_vec(a32: *const u8, b32: *const u8, d: usize, out32: *mut u8) -> c_int;
+    pub fn rofl_shift_points(a32: *const u8, d: usize, offset32: *const u8, out32: *mut u8) -> c_int;
+    pub fn rofl_discrete_log_vec(points32: *const u8, d: usize, table_size: usize, bsgs_bits: c_uint, scalars_out32: *mut u8) -> c_int;
+}
+
+// return codes of include/rofl_zk.h
+pub const ROFL_OK: c_int = 0;
+pub const ROFL_WRONG_NUM_BLINDING_FACTORS: c_int = 1;
+pub const ROFL_VALUE_OUT_OF_RANGE: c_int = 2;
+pub const ROFL_INVALID_BITSIZE: c_int = 3;
+pub const ROFL_INVALID_AGGREGATION: c_int = 4;
+pub const ROFL_FORMAT_ERROR: c_int = 5;
+pub const ROFL_INVALID_GENERATORS_LENGTH: c_int = 6;
+pub const ROFL_NORM_OUT_OF_RANGE: c_int = 7;
+pub const ROFL_OVERFLOW: c_int = 8;
+pub const ROFL_SUM_ERROR: c_int = 9;
+
+pub fn fp_bits() -> c_uint { N_BITS as c_uint }
+pub fn fp_frac() -> c_uint { <Frac as Unsigned>::U32 }
+
+/// What `thread_rng()` was to the upstream prover: fresh randomness per call, expanded on the device.
+pub fn fresh_nonce() -> RoflNonce {
+    let mut seed = [0u8; 32];
+    rand::thread_rng().fill_bytes(&mut seed);
+    RoflNonce { mode: 1, stream: std::ptr::null(), stream_scalars: 0, seed }
+}
+pub fn fresh_seed() -> [u8; 32] {
+    let mut seed = [0u8; 32];
+    rand::thread_rng().fill_bytes(&mut seed);
+    seed
+}
+pub fn scalars_to_bytes(v: &[Scalar]) -> Vec<u8> { v.iter().flat_map(|s| s.to_bytes().to_vec()).collect() }
+pub fn points_to_bytes(v: &[RistrettoPoint]) -> Vec<u8> { v.iter().flat_map(|p| p.compress().to_bytes().to_vec()).collect() }
+pub fn bytes_to_points(b: &[u8]) -> Vec<RistrettoPoint> {
+    b.chunks(32).map(|c| CompressedRistretto::from_slice(c).decompress().expect("librofl_zk returns valid encodings")).collect()
+}
+pub fn bytes_to_scalars(b: &[u8]) -> Vec<Scalar> {
+    b.chunks(32).map(|c| { let mut a = [0u8; 32]; a.copy_from_slice(c); Scalar::from_canonical_bytes(a).expect("canonical") }).collect()
+}
+pub fn last_error() -> String {
+    let mut buf = vec![0 as c_char; 512];
+    unsafe { rofl_last_error(buf.as_mut_ptr(), buf.len()); std::ffi::CStr::from_ptr(buf.as_ptr()).to_string_lossy().into_owned() }
+}

@@ -124,6 +124,42 @@ struct ChunkParams {
     u64 nonce_base;                  // index of this chunk's first nonce
 };
 
+// Radix-128 power tables of a chunk's challenges: x^k = T[0][k & 127] * T[1][(k >> 7) & 127] * T[2][(k >> 14) & 127] -- two
+// multiplications per index instead of one per set bit (up to 18 at N = 2^18) in every per-slot kernel.  `s` is the verifier's
+// IPP table: the product over the rounds of u_q or u_q^-1 selected by the index bits (its inverse = the same table at ~k).
+#define PT_W 7
+#define PT_E 128
+#define PT_L 3
+struct PowTabs { sc y[PT_L][PT_E], yinv[PT_L][PT_E], z[PT_L][PT_E], s[PT_L][PT_E]; };     // Montgomery form
+__global__ void __launch_bounds__(TPB) k_pow_tables(const ChunkParams *cp, PowTabs *pt, u32 lgN, int with_s) {
+    u32 c = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 kind = t / (PT_L * PT_E), lvl = (t / PT_E) % PT_L, e = t % PT_E;
+    if (kind >= 4 || (kind == 3 && !with_s)) return;
+    const ChunkParams &P = cp[c];
+    sc acc = sc_one_mont();
+    for (u32 b = 0; b < PT_W; b++) {
+        u32 p = PT_W * lvl + b;              // bit position of the index
+        bool bit = (e >> b) & 1;
+        if (kind == 3) {
+            if (p < lgN) { u32 q = lgN - 1 - p; acc = sc_montmul(acc, bit ? load_sc(&P.u[q]) : load_sc(&P.uinv[q])); }
+        } else if (bit && p < MAX_LG) {
+            acc = sc_montmul(acc, load_sc(kind == 0 ? &P.ypow2[p] : kind == 1 ? &P.yinvpow2[p] : &P.zpow2[p]));
+        }
+    }
+    sc *dst = kind == 0 ? &pt[c].y[lvl][e] : kind == 1 ? &pt[c].yinv[lvl][e] : kind == 2 ? &pt[c].z[lvl][e] : &pt[c].s[lvl][e];
+    store_sc(dst, acc);
+}
+// x^e from a chunk's table; index bits above 21 (N > 2^21) fall back to the squarings table
+__device__ __forceinline__ sc pt_pow(const sc (*tab)[PT_E], const sc *sq, u32 e) {
+    sc acc = load_sc(&tab[0][e & (PT_E - 1)]);
+    if (e >> PT_W) acc = sc_montmul(acc, load_sc(&tab[1][(e >> PT_W) & (PT_E - 1)]));
+    if (e >> (2 * PT_W)) acc = sc_montmul(acc, load_sc(&tab[2][(e >> (2 * PT_W)) & (PT_E - 1)]));
+    e >>= 3 * PT_W;
+    for (int b = 3 * PT_W; e; b++, e >>= 1)
+        if (e & 1) acc = sc_montmul(acc, sq[b]);
+    return acc;
+}
+
 // ================================================================ K1: generators
 // bulletproofs GeneratorsChain: SHAKE256("GeneratorsChain" || label5), 64 B per generator.
 // One thread per (which, party): sequential XOF squeeze, n <= 64 generators.
@@ -353,7 +389,7 @@ __global__ void __launch_bounds__(TPB) k_decode_sum(const uint8_t *in, u32 n, u3
 // ================================================================ party-level scalar sums
 // phase 0: sum a_bl, s_bl              -> out[chunk][blk][0..1]
 // phase 1: sum t1_bl, t2_bl, zz*z^j*vbl -> out[chunk][blk][0..2]
-__global__ void __launch_bounds__(TPB) k_party_sums(u32 m, int phase, const ChunkParams *cp, const sc *party, const sc *blind_canon /* [chunk][m] */, sc *out) {
+__global__ void __launch_bounds__(TPB) k_party_sums(u32 m, int phase, const ChunkParams *cp, const PowTabs *pt, const sc *party, const sc *blind_canon /* [chunk][m] */, sc *out) {
     __shared__ sc lds[TPB * 3];
     u32 c = blockIdx.y;
     sc v[3] = {sc_zero(), sc_zero(), sc_zero()};
@@ -364,7 +400,7 @@ __global__ void __launch_bounds__(TPB) k_party_sums(u32 m, int phase, const Chun
         } else {
             v[0] = sc_add(v[0], load_sc(&party[((size_t)c * 4 + 2) * m + j]));
             v[1] = sc_add(v[1], load_sc(&party[((size_t)c * 4 + 3) * m + j]));
-            sc zj = sc_montmul(cp[c].zz, sc_pow_tab(cp[c].zpow2, j));
+            sc zj = sc_montmul(cp[c].zz, pt_pow(pt[c].z, cp[c].zpow2, j));
             sc bl = sc_to_mont(load_sc(&blind_canon[(size_t)c * m + j]));
             v[2] = sc_add(v[2], sc_montmul(zj, bl));
         }
@@ -378,21 +414,21 @@ __global__ void __launch_bounds__(TPB) k_party_sums(u32 m, int phase, const Chun
 
 // ================================================================ K6: polynomial vectors
 // bulletproofs party.rs apply_challenge: l0 = aL - z, l1 = sL, r0 = y^k (aR + z) + z^(2+j) 2^i, r1 = y^k sR
-__device__ __forceinline__ void slot_vectors(const ChunkParams &P, u32 n, u32 k, u64 v, const sc &sR,
+__device__ __forceinline__ void slot_vectors(const ChunkParams &P, const PowTabs &T, u32 n, u32 k, u64 v, const sc &sR,
                                              sc &l0, sc &r0, sc &r1, const sc *two_pow) {
     u32 j = k / n, i = k % n;
     bool bit = (v >> i) & 1;
     sc one = sc_one_mont();
     sc aL = bit ? one : sc_zero();
     sc aR = bit ? sc_zero() : sc_neg(one);
-    sc yk = sc_pow_tab(P.ypow2, k);
+    sc yk = pt_pow(T.y, P.ypow2, k);
     l0 = sc_sub(aL, P.z);
-    sc zj2 = sc_montmul(sc_montmul(P.zz, sc_pow_tab(P.zpow2, j)), two_pow[i]);
+    sc zj2 = sc_montmul(sc_montmul(P.zz, pt_pow(T.z, P.zpow2, j)), two_pow[i]);
     r0 = sc_add(sc_montmul(yk, sc_add(aR, P.z)), zj2);
     r1 = sc_montmul(yk, sR);
 }
 // t0,t1,t2 partial sums -> out[chunk][blk][3]
-__global__ void __launch_bounds__(TPB) k_poly_t(u32 n, u32 m, const ChunkParams *cp, const u64 *vshift, const sc *sL, const sc *sR,
+__global__ void __launch_bounds__(TPB) k_poly_t(u32 n, u32 m, const ChunkParams *cp, const PowTabs *pt, const u64 *vshift, const sc *sL, const sc *sR,
                          const sc *two_pow, sc *out) {
     __shared__ sc lds[TPB * 3];
     u32 c = blockIdx.y;
@@ -401,7 +437,7 @@ __global__ void __launch_bounds__(TPB) k_poly_t(u32 n, u32 m, const ChunkParams 
     for (u32 k = blockIdx.x * blockDim.x + threadIdx.x; k < N; k += gridDim.x * blockDim.x) {
         sc l0, r0, r1;
         sc l1 = load_sc(&sL[c * N + k]);
-        slot_vectors(cp[c], n, k, vshift[(size_t)c * m + k / n], load_sc(&sR[c * N + k]), l0, r0, r1, two_pow);
+        slot_vectors(cp[c], pt[c], n, k, vshift[(size_t)c * m + k / n], load_sc(&sR[c * N + k]), l0, r0, r1, two_pow);
         v[0] = sc_add(v[0], sc_montmul(l0, r0));
         v[1] = sc_add(v[1], sc_add(sc_montmul(l0, r1), sc_montmul(l1, r0)));
         v[2] = sc_add(v[2], sc_montmul(l1, r1));
@@ -413,7 +449,7 @@ __global__ void __launch_bounds__(TPB) k_poly_t(u32 n, u32 m, const ChunkParams 
     }
 }
 // a = l(x), b = r(x); also yinv^k table
-__global__ void __launch_bounds__(TPB) k_lr_vec(u32 n, u32 m, const ChunkParams *cp, const u64 *vshift, const sc *sL, const sc *sR,
+__global__ void __launch_bounds__(TPB) k_lr_vec(u32 n, u32 m, const ChunkParams *cp, const PowTabs *pt, const u64 *vshift, const sc *sL, const sc *sR,
                          const sc *two_pow, sc *a, sc *b, sc *yinvpow) {
     u32 c = blockIdx.y;
     size_t N = (size_t)n * m;
@@ -421,10 +457,10 @@ __global__ void __launch_bounds__(TPB) k_lr_vec(u32 n, u32 m, const ChunkParams 
     if (k >= N) return;
     sc l0, r0, r1;
     sc l1 = load_sc(&sL[c * N + k]);
-    slot_vectors(cp[c], n, k, vshift[(size_t)c * m + k / n], load_sc(&sR[c * N + k]), l0, r0, r1, two_pow);
+    slot_vectors(cp[c], pt[c], n, k, vshift[(size_t)c * m + k / n], load_sc(&sR[c * N + k]), l0, r0, r1, two_pow);
     store_sc(&a[c * N + k], sc_add(l0, sc_montmul(l1, cp[c].x)));
     store_sc(&b[c * N + k], sc_add(r0, sc_montmul(r1, cp[c].x)));
-    store_sc(&yinvpow[c * N + k], sc_pow_tab(cp[c].yinvpow2, k));
+    store_sc(&yinvpow[c * N + k], pt_pow(pt[c].yinv, cp[c].yinvpow2, k));
 }
 
 // ================================================================ K7: inner-product argument
@@ -1009,7 +1045,7 @@ __global__ void __launch_bounds__(TPB) k_add_points(u32 count, const uint8_t *a,
 // bulletproofs verify_multiple: g_k = -z - a s_k ; h_k = z + y^-k (zz z^j 2^i - b s_k^-1)  -> canonical [g | h]
 // One array of 2N scalars per batch of `group` consecutive proofs: sum_c rho_c * (g_c | h_c) -- the proofs of a batch
 // share the generators, so their G/H terms collapse into one MSM (rho_c is folded into rz, ra, rb, rzz by the host).
-__global__ void __launch_bounds__(TPB) k_verify_scalars(u32 n, u32 m, u32 lgN, u32 group, const ChunkParams *cp, const sc *two_pow, sc *out) {
+__global__ void __launch_bounds__(TPB) k_verify_scalars(u32 n, u32 m, u32 lgN, u32 group, const ChunkParams *cp, const PowTabs *pt, const sc *two_pow, sc *out) {
     u32 gidx = blockIdx.y;
     size_t N = (size_t)n * m;
     u32 k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1018,26 +1054,30 @@ __global__ void __launch_bounds__(TPB) k_verify_scalars(u32 n, u32 m, u32 lgN, u
     sc gacc = sc_zero(), hacc = sc_zero();
     for (u32 cc = 0; cc < group; cc++) {
         const ChunkParams &P = cp[gidx * group + cc];
-        sc s = sc_one_mont(), sinv = sc_one_mont();
-        for (u32 q = 0; q < lgN; q++) {
-            bool bit = (k >> (lgN - 1 - q)) & 1;    // challenge q (creation order) <-> bit lgN-1-q
+        const PowTabs &T = pt[gidx * group + cc];
+        // s = prod_q (bit_{lgN-1-q}(k) ? u_q : u_q^-1) (challenge q in creation order), 1/s = the same product at ~k
+        u32 kc = ~k;
+        sc s = sc_montmul(sc_montmul(load_sc(&T.s[0][k & (PT_E - 1)]), load_sc(&T.s[1][(k >> PT_W) & (PT_E - 1)])), load_sc(&T.s[2][(k >> (2 * PT_W)) & (PT_E - 1)]));
+        sc sinv = sc_montmul(sc_montmul(load_sc(&T.s[0][kc & (PT_E - 1)]), load_sc(&T.s[1][(kc >> PT_W) & (PT_E - 1)])), load_sc(&T.s[2][(kc >> (2 * PT_W)) & (PT_E - 1)]));
+        for (u32 q = 0; q + 3 * PT_W < lgN; q++) {       // index bits beyond the tables (N > 2^21)
+            bool bit = (k >> (lgN - 1 - q)) & 1;
             s = sc_montmul(s, bit ? P.u[q] : P.uinv[q]);
             sinv = sc_montmul(sinv, bit ? P.uinv[q] : P.u[q]);
         }
         sc g = sc_neg(sc_add(P.rz, sc_montmul(P.ra, s)));
-        sc zj2 = sc_montmul(sc_montmul(P.rzz, sc_pow_tab(P.zpow2, j)), two_pow[i]);
-        sc h = sc_add(P.rz, sc_montmul(sc_pow_tab(P.yinvpow2, k), sc_sub(zj2, sc_montmul(P.rb, sinv))));
+        sc zj2 = sc_montmul(sc_montmul(P.rzz, pt_pow(T.z, P.zpow2, j)), two_pow[i]);
+        sc h = sc_add(P.rz, sc_montmul(pt_pow(T.yinv, P.yinvpow2, k), sc_sub(zj2, sc_montmul(P.rb, sinv))));
         gacc = sc_add(gacc, g); hacc = sc_add(hacc, h);
     }
     sc *o = out + (size_t)gidx * 2 * N;
     store_sc(&o[k], sc_from_mont(gacc));
     store_sc(&o[N + k], sc_from_mont(hacc));
 }
-__global__ void __launch_bounds__(TPB) k_vscalars(u32 m, const ChunkParams *cp, sc *out, size_t stride) {
+__global__ void __launch_bounds__(TPB) k_vscalars(u32 m, const ChunkParams *cp, const PowTabs *pt, sc *out, size_t stride) {
     u32 c = blockIdx.y;
     u32 j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m) return;
-    store_sc(&out[c * stride + j], sc_from_mont(sc_montmul(cp[c].c_zz, sc_pow_tab(cp[c].zpow2, j))));
+    store_sc(&out[c * stride + j], sc_from_mont(sc_montmul(cp[c].c_zz, pt_pow(pt[c].z, cp[c].zpow2, j))));
 }
 
 // ================================================================ K11: per-element Sigma-proofs

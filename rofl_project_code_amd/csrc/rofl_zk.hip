@@ -224,7 +224,7 @@ struct Ctx {
     Timing tm;
     // workspace
     DevBuf cp, sL, sR, party, Scanon, vshift, blind, Vbytes, Cbytes, status, partial, partial2, scpart, a, b, yinv,
-        SL, SR, msm_cnt, msm_off, msm_cur, msm_perm, msm_sorted, msm_ovf, msm_buckets, msm_S[2], msm_C[2], msm_fin, msm_probs, foldprobs, naf,
+        SL, SR, msm_cnt, msm_off, msm_cur, msm_perm, msm_sorted, msm_ovf, msm_buckets, msm_S[2], msm_C[2], msm_fin, msm_probs, powtabs, foldprobs, naf,
         gbuf[2], aux_pts, aux_scal, vscal, tmp_in, tmp_in2, tmp_out, vals, uni, stream_buf;
     PinBuf h_cp, h_res, h_part, h_misc, h_misc2, h_probs, h_auxc, h_auxs, h_ovf;
 
@@ -615,7 +615,8 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
     hipLaunchKernelGGL(k_point_sum, dim3(nblkA, (u32)P), dim3(TPB), TPB * sizeof(ge), C.stream, partial, (u32)m, partial2);
     u32 nblkS = (u32)std::min<size_t>(16, (m + TPB - 1) / TPB);
     sc *scpart = C.scpart.as<sc>(P * 64 * 3);
-    hipLaunchKernelGGL(k_party_sums, dim3(nblkS, (u32)P), dim3(TPB), 0, C.stream, (u32)m, 0, d_cp, party, d_blind, scpart);
+    PowTabs *d_pt = C.powtabs.as<PowTabs>(P);
+    hipLaunchKernelGGL(k_party_sums, dim3(nblkS, (u32)P), dim3(TPB), 0, C.stream, (u32)m, 0, d_cp, (const PowTabs *)d_pt, party, d_blind, scpart);
     ge *h_A = C.h_part.as<ge>(P * nblkA);
     sc *h_sc = C.h_misc2.as<sc>(P * 64 * 3);
     HIPCHK(hipMemcpyAsync(h_A, partial2, sizeof(ge) * P * nblkA, hipMemcpyDeviceToHost, C.stream));
@@ -665,8 +666,9 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
     HIPCHK(hipMemcpyAsync(d_cp, h_cp, sizeof(ChunkParams) * P, hipMemcpyHostToDevice, C.stream));
     u32 nblkT = (u32)std::min<size_t>(64, (N + TPB - 1) / TPB);
     sc *tpart = C.tmp_out.as<sc>(P * 64 * 3);
-    hipLaunchKernelGGL(k_poly_t, dim3(nblkT, (u32)P), dim3(TPB), 0, C.stream, (u32)n, (u32)m, d_cp, d_vshift, sL, sR, C.d_two_pow, tpart);
-    hipLaunchKernelGGL(k_party_sums, dim3(nblkS, (u32)P), dim3(TPB), 0, C.stream, (u32)m, 1, d_cp, party, d_blind, scpart);
+    hipLaunchKernelGGL(k_pow_tables, dim3((4 * PT_L * PT_E + TPB - 1) / TPB, (u32)P), dim3(TPB), 0, C.stream, d_cp, d_pt, lgN, 0);
+    hipLaunchKernelGGL(k_poly_t, dim3(nblkT, (u32)P), dim3(TPB), 0, C.stream, (u32)n, (u32)m, d_cp, (const PowTabs *)d_pt, d_vshift, sL, sR, C.d_two_pow, tpart);
+    hipLaunchKernelGGL(k_party_sums, dim3(nblkS, (u32)P), dim3(TPB), 0, C.stream, (u32)m, 1, d_cp, (const PowTabs *)d_pt, party, d_blind, scpart);
     sc *h_t = C.h_part.as<sc>(P * 64 * 3);
     HIPCHK(hipMemcpyAsync(h_t, tpart, sizeof(sc) * P * nblkT * 3, hipMemcpyDeviceToHost, C.stream));
     HIPCHK(hipMemcpyAsync(h_sc, scpart, sizeof(sc) * P * nblkS * 3, hipMemcpyDeviceToHost, C.stream));
@@ -701,7 +703,7 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
     C.tm.t.host_ms += now_ms() - th;
     HIPCHK(hipMemcpyAsync(d_cp, h_cp, sizeof(ChunkParams) * P, hipMemcpyHostToDevice, C.stream));
     sc *a = C.a.as<sc>(P * N), *b = C.b.as<sc>(P * N), *yinvpow = C.yinv.as<sc>(P * N);
-    hipLaunchKernelGGL(k_lr_vec, grid1(N, (u32)P), dim3(TPB), 0, C.stream, (u32)n, (u32)m, d_cp, d_vshift, sL, sR, C.d_two_pow, a, b, yinvpow);
+    hipLaunchKernelGGL(k_lr_vec, grid1(N, (u32)P), dim3(TPB), 0, C.stream, (u32)n, (u32)m, d_cp, (const PowTabs *)d_pt, d_vshift, sL, sR, C.d_two_pow, a, b, yinvpow);
     mark("poly/T/x");
 
     // ---- IPP rounds with lazily folded generators
@@ -979,7 +981,9 @@ int verify_chunks(Ctx &C, const char *label, size_t gens_capacity, size_t P, siz
     C.tm.t.host_ms += now_ms() - th;
     HIPCHK(hipMemcpyAsync(d_cp, h_cp, sizeof(ChunkParams) * P, hipMemcpyHostToDevice, C.stream));
     sc *gh = C.SL.as<sc>(ngroups * 2 * N);
-    hipLaunchKernelGGL(k_verify_scalars, grid1(N, (u32)ngroups), dim3(TPB), 0, C.stream, (u32)n, (u32)m, (u32)lg, (u32)group, d_cp, C.d_two_pow, gh);
+    PowTabs *d_pt = C.powtabs.as<PowTabs>(P);
+    hipLaunchKernelGGL(k_pow_tables, dim3((4 * PT_L * PT_E + TPB - 1) / TPB, (u32)P), dim3(TPB), 0, C.stream, d_cp, d_pt, (u32)lg, 1);
+    hipLaunchKernelGGL(k_verify_scalars, grid1(N, (u32)ngroups), dim3(TPB), 0, C.stream, (u32)n, (u32)m, (u32)lg, (u32)group, d_cp, (const PowTabs *)d_pt, C.d_two_pow, gh);
     // aux arrays
     niels *aux_pts = C.aux_pts.as<niels>(P * naux);
     sc *aux_scal = C.aux_scal.as<sc>(P * naux);
@@ -989,7 +993,7 @@ int verify_chunks(Ctx &C, const char *label, size_t gens_capacity, size_t P, siz
     HIPCHK(hipMemsetAsync(status, 0, 16, C.stream));
     HIPCHK(hipMemcpyAsync(d_auxc, h_auxc, P * (4 + 2 * lg) * 32, hipMemcpyHostToDevice, C.stream));
     hipLaunchKernelGGL(k_decode, grid1(P * (4 + 2 * lg)), dim3(TPB), 0, C.stream, (u32)(P * (4 + 2 * lg)), (u32)(P * (4 + 2 * lg)), d_auxc, (const niels *)nullptr, d_auxn, (uint8_t *)nullptr, status);
-    hipLaunchKernelGGL(k_vscalars, grid1(m, (u32)P), dim3(TPB), 0, C.stream, (u32)m, d_cp, aux_scal, naux);
+    hipLaunchKernelGGL(k_vscalars, grid1(m, (u32)P), dim3(TPB), 0, C.stream, (u32)m, d_cp, (const PowTabs *)d_pt, aux_scal, naux);
     for (size_t c = 0; c < P; c++) {
         HIPCHK(hipMemcpyAsync(aux_pts + c * naux, d_Vniels + c * m, sizeof(niels) * m, hipMemcpyDeviceToDevice, C.stream));
         HIPCHK(hipMemcpyAsync(aux_pts + c * naux + m, d_auxn + c * (4 + 2 * lg), sizeof(niels) * (4 + 2 * lg), hipMemcpyDeviceToDevice, C.stream));

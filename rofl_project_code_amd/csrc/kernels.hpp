@@ -210,18 +210,22 @@ __global__ void __launch_bounds__(TPB) k_gens_tables(u32 total, FoldTabCfg cfg, 
     for (u32 d = 0; d < q * cfg.pb; d++) cur = gd_double(cur);
     gd p2 = gd_double(cur);
     ge mult[FOLD_TAB_MAXE]; fd pref[FOLD_TAB_MAXE];
-    gd pk = cur;
-    for (u32 e = 0; e < cfg.e; e++) {
-        if (e) pk = gd_add(pk, p2);
-        mult[e] = gd_pack(pk);
-        pref[e] = e ? fd_mul(pref[e - 1], pk.Z) : pk.Z;
-    }
-    fd inv = fd_invert(pref[cfg.e - 1]);
-    for (int e = (int)cfg.e - 1; e >= 0; e--) {
-        gd m = gd_unpack(mult[e]);
-        fd zi = e ? fd_mul(inv, pref[e - 1]) : inv;
-        inv = fd_mul(inv, m.Z);
-        if (q || e) store_niels(&tbl[(size_t)(q * cfg.e + e) * stride + g], gd_to_niels_zinv(m, zi));
+    gd pk = cur;                      // (2e + 1) * cur, walked in groups of FOLD_TAB_MAXE with one inversion per group
+    for (u32 e0 = 0; e0 < cfg.e; e0 += FOLD_TAB_MAXE) {
+        u32 cnt = cfg.e - e0 < FOLD_TAB_MAXE ? cfg.e - e0 : FOLD_TAB_MAXE;
+        for (u32 j = 0; j < cnt; j++) {
+            if (e0 + j) pk = gd_add(pk, p2);
+            mult[j] = gd_pack(pk);
+            pref[j] = j ? fd_mul(pref[j - 1], pk.Z) : pk.Z;
+        }
+        fd inv = fd_invert(pref[cnt - 1]);
+        for (int j = (int)cnt - 1; j >= 0; j--) {
+            gd m = gd_unpack(mult[j]);
+            fd zi = j ? fd_mul(inv, pref[j - 1]) : inv;
+            inv = fd_mul(inv, m.Z);
+            u32 e = e0 + (u32)j;
+            if (q || e) store_niels(&tbl[(size_t)(q * cfg.e + e) * stride + g], gd_to_niels_zinv(m, zi));
+        }
     }
 }
 
@@ -869,7 +873,8 @@ __global__ void __launch_bounds__(TPB) k_msm_accumulate(u32 n, u32 c, u32 W, u32
     else lst = sorted + ((size_t)p * W + w) * n * 2 + off[bi];   // stride 2n: a top-window digit may emit two entries
     const niels *pts = probs[p * pstep].pts;
     gd acc = gd_identity();
-    // (a software-pipelined variant that keeps the next point load in flight costs 12 VGPRs -> 3 waves/SIMD and was slower)
+    // (a software-pipelined variant that keeps the next point load in flight costs 12 VGPRs -> 3 waves/SIMD and was slower;
+    //  forcing 5 waves/SIMD -- 96 VGPRs, 136 B/lane of scratch -- takes 1.65x as long)
     for (u32 e = 0; e < num; e++) {
         u32 v = lst[e];
         acc = gd_madd(acc, gload_nd(&pts[v & idx_mask]), (v >> 31) != 0);

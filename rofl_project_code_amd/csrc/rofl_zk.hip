@@ -208,7 +208,7 @@ struct Ctx {
     std::map<const niels *, FoldTabCfg> foldcfg;         // generator table -> layout of its fold slices
     std::map<std::pair<size_t, size_t>, std::pair<u64, size_t>> gens_use;   // (n, m) -> (last use tick, bytes held)
     u64 gens_tick = 0; size_t gens_budget = (size_t)96 << 30;   // ROFL_GENS_BUDGET_MB: evict least recently used tables beyond this
-    u32 fold_pb = 32, fold_w = 6;
+    u32 fold_pb = 32, fold_w = 8; size_t fold_tab_budget = (size_t)32 << 30;   // widest NAF whose table fits the per-(n, m) budget (ROFL_FOLD_W, ROFL_FOLD_TAB_MB)
     std::map<const niels *, niels *> wtabs;              // generator table -> 16 window slices 2^(16w) P (fixed-base MSM)
     int msm_lds = 1; size_t msm_lds_min = 8192, msm_lds_tile = 131072;
     size_t msm_fb_threads = (size_t)1 << 19;
@@ -268,7 +268,8 @@ struct Ctx {
         if (const char *e = getenv("ROFL_FOLD_TAB")) fold_tab = atoi(e) != 0;
         if (const char *e = getenv("ROFL_GENS_BUDGET_MB")) { long v = atol(e); if (v >= 1) gens_budget = (size_t)v << 20; }
         if (const char *e = getenv("ROFL_FOLD_PB")) { int v = atoi(e); if (v == 16 || v == 32 || v == 64) fold_pb = (u32)v; }
-        if (const char *e = getenv("ROFL_FOLD_W")) { int v = atoi(e); if (v >= 3 && v <= 6) fold_w = (u32)v; }
+        if (const char *e = getenv("ROFL_FOLD_W")) { int v = atoi(e); if (v >= 3 && v <= 8) fold_w = (u32)v; }
+        if (const char *e = getenv("ROFL_FOLD_TAB_MB")) { long v = atol(e); if (v >= 1) fold_tab_budget = (size_t)v << 20; }
         if (const char *e = getenv("ROFL_FOLD_UNIT")) fold_unit = atoi(e) != 0;
         if (const char *e = getenv("ROFL_FOLD_K")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) fold_k = v; }
         if (const char *e = getenv("ROFL_FOLD_THREADS")) { long v = atol(e); if (v > 0) fold_threads = v; }
@@ -348,6 +349,8 @@ niels *get_gens(Ctx &C, size_t n, size_t m) {
     if (it != gens.end()) { Pm0.gens_use[key].first = ++Pm0.gens_tick; return it->second; }
     size_t N = n * m;
     FoldTabCfg fc{Pm0.fold_pb, Pm0.fold_w, 256 / Pm0.fold_pb, 1u << (Pm0.fold_w - 2)};
+    // HBM capacity for VALU work: a width-w NAF needs 2^(w-2) odd multiples per piece and leaves 1/(w+1) of the digits non-zero
+    while (fc.w > 6 && sizeof(niels) * 2 * N * fc.np * fc.e > Pm0.fold_tab_budget) { fc.w--; fc.e = 1u << (fc.w - 2); }
     if (sizeof(niels) * 2 * N * fc.np * fc.e > ((size_t)40 << 30)) fc = FoldTabCfg{64, 4, 4, 4};     // very large tables: the compact layout
     niels *tbl; HIPCHK(hipMalloc(&tbl, sizeof(niels) * 2 * N * fc.np * fc.e));      // slice 0 = generators, the rest = fold tables
     Pm0.foldcfg[tbl] = fc;

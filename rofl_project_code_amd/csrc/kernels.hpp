@@ -797,7 +797,7 @@ __device__ __forceinline__ u32 msm_side_term(const MsmMap &mm, u32 side, u32 k) 
     return hside * mm.lr_ng + j;
 }
 __global__ void __launch_bounds__(1024) k_msm_scatter_lds(u32 n_side, u32 tile_pts, MsmWin mw, MsmMap mm, const MsmProb *probs, u32 *cursor, u32 *slots,
-                                                          u32 cap, u32 *ovf_count, MsmOvf *ovf, u32 ovf_max) {
+                                                          u32 cap, u32 *ovf_count, MsmOvf *ovf, u32 ovf_max, u32 dbg) {
     extern __shared__ u32 lcnt[];
     const u32 B = 1u << (mw.c - 1);
     u32 nside = mm.lr_nh ? 2u : 1u;
@@ -824,7 +824,7 @@ __global__ void __launch_bounds__(1024) k_msm_scatter_lds(u32 n_side, u32 tile_p
     __syncthreads();
     for (u32 b = threadIdx.x; b < B; b += 1024) {
         u32 c = lcnt[b];
-        lcnt[b] = c ? atomicAdd(&cursor[(size_t)pw * B + b], c) : 0u;
+        lcnt[b] = (c && !(dbg & 1)) ? atomicAdd(&cursor[(size_t)pw * B + b], c) : 0u;
     }
     __syncthreads();
     for (u32 k = k0 + threadIdx.x; k < k1; k += 1024) {
@@ -840,6 +840,7 @@ __global__ void __launch_bounds__(1024) k_msm_scatter_lds(u32 n_side, u32 tile_p
                 if (!a1) continue;
                 u32 pos = atomicAdd(&lcnt[a1 - 1], 1u);
                 u32 bi = pw * B + a1 - 1;
+                if (dbg & 2) { if (pos == 0xffffffffu) slots[0] = entry; continue; }
                 if (pos < cap) slots[(size_t)bi * cap + pos] = entry;
                 else { u32 o = atomicAdd(ovf_count, 1u); if (o < ovf_max) { ovf[o].bucket = bi; ovf[o].entry = entry; } }
             }

@@ -417,6 +417,7 @@ struct MsmOpt { u32 lr_nh = 0, lr_ng = 0; const niels *fb_wtab = nullptr; size_t
 void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge5> &results, const MsmOpt &opt = MsmOpt()) {
     size_t np = probs.size();
     static const u32 dbg_mask = getenv("ROFL_DBG_IDX_MASK") ? (u32)strtoul(getenv("ROFL_DBG_IDX_MASK"), nullptr, 0) : 0x7fffffffu;   // timing experiments only (wrong results): gathers confined to a cache-resident prefix
+    static const u32 dbg_scatter = getenv("ROFL_DBG_SCATTER") ? (u32)atoi(getenv("ROFL_DBG_SCATTER")) : 0u;   // timing experiments only: 1 = no range reservation, 2 = no slot stores
     bool lr = opt.lr_nh != 0;
     size_t nq = lr ? np / 2 : np;                          // grid problems (chunks in lr mode)
     MsmProb *d_probs = C.msm_probs.as<MsmProb>(np);
@@ -475,7 +476,7 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
                 u32 wps = fb ? mm.fb_wps : 1;
                 while (tile > 1024 && ((size_t)tile * wps > (size_t)C.msm_lds_tile || (size_t)((n_side + tile - 1) / tile) * nq * (lr ? 2 : 1) * per_q < 256)) tile /= 2;
                 dim3 grid((n_side + tile - 1) / tile, (u32)(nq * (lr ? 2 : 1) * per_q));
-                hipLaunchKernelGGL(k_msm_scatter_lds, grid, dim3(1024), (size_t)P.B * 4, C.stream, n_side, tile, mw, mm, d_probs, cnt, slots, cap, ovf_count, ovf, OVF_MAX);
+                hipLaunchKernelGGL(k_msm_scatter_lds, grid, dim3(1024), (size_t)P.B * 4, C.stream, n_side, tile, mw, mm, d_probs, cnt, slots, cap, ovf_count, ovf, OVF_MAX, dbg_scatter);
             } else
             hipLaunchKernelGGL(k_msm_scatter_slots, grid1(n, (u32)(nq * Wgrid)), dim3(TPB), 0, C.stream, (u32)n, mw, mm, d_probs, cnt, slots, cap, ovf_count, ovf, OVF_MAX);
             hipLaunchKernelGGL(k_msm_scan, dim3((unsigned)PW), dim3(TPB), 0, C.stream, P.B, cnt, off, (u32 *)nullptr, perm);

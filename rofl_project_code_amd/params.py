@@ -83,6 +83,23 @@ class wire:
                 "l2_range_bits": m.l2_range_bits, "check_percentage": m.check_percentage}
 
 
+_pool = None
+
+
+def _concurrently(*thunks):
+    """Run independent proof calls on separate library lanes (each call takes a free lane: HIP stream + workspace).  The
+    reference runs them one after the other, each spread over the rayon pool; on the GPU the latency-bound tails of one proof
+    (a 5-round sum proof, the per-element Sigma-proof kernels) overlap the throughput-bound phases of another."""
+    global _pool
+    if len(thunks) == 1:
+        return [thunks[0]()]
+    if _pool is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _pool = ThreadPoolExecutor(max_workers=3, thread_name_prefix="rofl-params")
+    futs = [_pool.submit(t) for t in thunks]
+    return [f.result() for f in futs]
+
+
 def _sub_nonce(seed, tag):
     """Independent nonce streams for the proofs of one container (the reference draws all of them from thread_rng)."""
     if seed is None:
@@ -213,9 +230,14 @@ class EncParamsL2:
         bl = api._u8(blinding_vec)
         r2 = pedersen_ops.rnd_scalar_vec(x.size) if rand_scalars is None else api._u8(rand_scalars)
         clipped = range_proof_vec.clip_f32_to_range_vec(x, prove_range)
-        rp, enc_com = range_proof_vec.create_rangeproof(clipped, bl, prove_range, n_partition, nonce=_sub_nonce(nonce_seed, b"range"))
-        sum_proof, _ = l2_range_proof_vec.create_rangeproof_l2(clipped, r2, l2_range, n_partition, nonce=_sub_nonce(nonce_seed, b"l2"))
-        proofs, commits = square_rand_proof_vec.create_l2rangeproof_vec_existing(clipped, enc_com, bl, r2, nonce=_sub_nonce(nonce_seed, b"sq"))
+        # the square proofs take the range proof's commitments (params.rs:623-637); committing first (same points) lets the
+        # three proofs run side by side
+        enc_com = pedersen_ops.commit_vec(conversion32.f32_to_scalar_vec(clipped), bl)
+        (rp, rp_com), (sum_proof, _), (proofs, commits) = _concurrently(
+            lambda: range_proof_vec.create_rangeproof(clipped, bl, prove_range, n_partition, nonce=_sub_nonce(nonce_seed, b"range")),
+            lambda: l2_range_proof_vec.create_rangeproof_l2(clipped, r2, l2_range, n_partition, nonce=_sub_nonce(nonce_seed, b"l2")),
+            lambda: square_rand_proof_vec.create_l2rangeproof_vec_existing(clipped, enc_com, bl, r2, nonce=_sub_nonce(nonce_seed, b"sq")))
+        assert (rp_com == enc_com).all()
         return cls(commits, proofs, rp, sum_proof, prove_range, l2_range)
 
     def _sum_c_sq(self):
@@ -224,9 +246,10 @@ class EncParamsL2:
     def verify(self, verifier_seed=None):
         """EncModelParams::verify, EncL2 arm (params.rs:204-232)."""
         try:
-            ok = square_rand_proof_vec.verify_l2rangeproof_vec(self.square_proofs, self.enc_values)
-            ok_range = range_proof_vec.verify_rangeproof(self.range_proofs, self.enc_values[:, :32], self.prove_range, verifier_seed=_sub_seed(verifier_seed, b"v"))
-            ok_sum = l2_range_proof_vec.verify_rangeproof_l2(self.square_range_proof, self._sum_c_sq(), self.l2_prove_range, verifier_seed=_sub_seed(verifier_seed, b"s"))
+            ok, ok_range, ok_sum = _concurrently(
+                lambda: square_rand_proof_vec.verify_l2rangeproof_vec(self.square_proofs, self.enc_values),
+                lambda: range_proof_vec.verify_rangeproof(self.range_proofs, self.enc_values[:, :32], self.prove_range, verifier_seed=_sub_seed(verifier_seed, b"v")),
+                lambda: l2_range_proof_vec.verify_rangeproof_l2(self.square_range_proof, self._sum_c_sq(), self.l2_prove_range, verifier_seed=_sub_seed(verifier_seed, b"s")))
         except RoflError:
             return False
         return bool(ok and ok_range and ok_sum)

@@ -7,7 +7,7 @@ import json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import rofl_project_code_amd as R
-from rofl_project_code_amd import api
+from rofl_project_code_amd import api, params
 
 R.set_device(0)
 SAMPLES = 4
@@ -75,15 +75,10 @@ def l2(name, d, P, clients=1):
     for s in range(SAMPLES + 1):
         t0 = time.perf_counter(); outs = []
         for vals, r1, r2 in ins:
-            rp, cm = R.range_proof_vec.create_rangeproof(vals, r1, 8, P, nonce=R.Nonce.seeded(b"\x01" * 32))
-            l2p, l2c = R.l2_range_proof_vec.create_rangeproof_l2(vals, r2, 32, P, nonce=R.Nonce.seeded(b"\x02" * 32))
-            sp, sc_ = R.square_rand_proof_vec.create_l2rangeproof_vec_existing(vals, cm, r1, r2, nonce=R.Nonce.seeded(b"\x03" * 32))
-            outs.append((rp, cm, l2p, l2c, sp, sc_))
+            outs.append(params.EncParamsL2.encrypt(vals, r1, 8, P, 32, nonce_seed=b"\x01" * 32, rand_scalars=r2))
         t1 = time.perf_counter()
-        for rp, cm, l2p, l2c, sp, sc_ in outs:
-            assert R.square_rand_proof_vec.verify_l2rangeproof_vec(sp, sc_)
-            assert R.range_proof_vec.verify_rangeproof(rp, cm, 8, verifier_seed=b"\x04" * 32)
-            assert R.l2_range_proof_vec.verify_rangeproof_l2(l2p, l2c, 32, verifier_seed=b"\x05" * 32)
+        for upd in outs:
+            assert upd.verify(verifier_seed=b"\x04" * 32)
         t2 = time.perf_counter()
         if s == 0:
             cold = ((t1 - t0) * 1e3, (t2 - t1) * 1e3); continue

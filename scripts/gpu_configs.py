@@ -85,7 +85,7 @@ def l2(name, d, P, clients=1):
         tc.append((t1 - t0) * 1e3 / clients); tv.append((t2 - t1) * 1e3 / clients)
     return {"config": name, "d": d, "n_partition": P, "fp": [32, 7], "clients_on_this_gpu": clients, "value_range": 8, "l2_value_range": 32,
             "create_ms_per_client": med(tc), "verify_ms_per_client": med(tv), "create_plus_verify_elements_per_s": d / (med(tc) + med(tv)) * 1e3,
-            "cold_create_ms": cold[0], "cold_verify_ms": cold[1], "protocol": "1 warm-up (the cold pass), 4 samples, median; sequential clients"}
+            "cold_create_ms": cold[0], "cold_verify_ms": cold[1], "protocol": "1 warm-up (the cold pass), 4 samples, median; sequential clients, the three proofs of a client on separate lanes (EncParamsL2.encrypt / verify)"}
 
 
 res = [

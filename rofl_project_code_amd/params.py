@@ -133,21 +133,26 @@ class EncParamsRange:
         bl = api._u8(blinding_vec)
         clipped = range_proof_vec.clip_f32_to_range_vec(x, prove_range)
         if check_percentage >= 1.0:
-            rp, enc_com = range_proof_vec.create_rangeproof(clipped, bl, prove_range, n_partition, nonce=_sub_nonce(nonce_seed, b"range"))
+            enc_com = pedersen_ops.commit_vec(conversion32.f32_to_scalar_vec(clipped), bl)      # == the range proof's commitments
             # NB the reference passes the un-clipped plaintext here (params.rs:499)
-            proofs, pairs = rand_proof_vec.create_randproof_vec_existing(x, enc_com, bl, nonce=_sub_nonce(nonce_seed, b"rand"))
+            (rp, rp_com), (proofs, pairs) = _concurrently(
+                lambda: range_proof_vec.create_rangeproof(clipped, bl, prove_range, n_partition, nonce=_sub_nonce(nonce_seed, b"range")),
+                lambda: rand_proof_vec.create_randproof_vec_existing(x, enc_com, bl, nonce=_sub_nonce(nonce_seed, b"rand")))
+            assert (rp_com == enc_com).all()
         else:
             k = _num_checked(x.size, check_percentage)
-            rp, _ = range_proof_vec.create_rangeproof(clipped[:k], bl[:k], prove_range, n_partition, nonce=_sub_nonce(nonce_seed, b"range"))
-            proofs, pairs = rand_proof_vec.create_randproof_vec(x, bl, nonce=_sub_nonce(nonce_seed, b"rand"))
+            (rp, _), (proofs, pairs) = _concurrently(
+                lambda: range_proof_vec.create_rangeproof(clipped[:k], bl[:k], prove_range, n_partition, nonce=_sub_nonce(nonce_seed, b"range")),
+                lambda: rand_proof_vec.create_randproof_vec(x, bl, nonce=_sub_nonce(nonce_seed, b"rand")))
         return cls(pairs, proofs, rp, prove_range, check_percentage)
 
     def verify(self, verifier_seed=None):
         """EncModelParams::verify, EncRange arm (params.rs:185-203): any Err counts as false."""
         try:
-            ok = rand_proof_vec.verify_randproof_vec(self.rand_proofs, self.enc_values)
             k = _num_checked(self.enc_values.shape[0], self.check_percentage)
-            ok_range = range_proof_vec.verify_rangeproof(self.range_proofs, self.enc_values[:k, :32], self.prove_range, verifier_seed=_sub_seed(verifier_seed, b"v"))
+            ok, ok_range = _concurrently(
+                lambda: rand_proof_vec.verify_randproof_vec(self.rand_proofs, self.enc_values),
+                lambda: range_proof_vec.verify_rangeproof(self.range_proofs, self.enc_values[:k, :32], self.prove_range, verifier_seed=_sub_seed(verifier_seed, b"v")))
         except RoflError:
             return False
         return bool(ok and ok_range)
@@ -182,21 +187,26 @@ class EncParamsRangeCompressed(EncParamsRange):
         bl = api._u8(blinding_vec)
         clipped = range_proof_vec.clip_f32_to_range_vec(x, prove_range)
         if check_percentage >= 1.0:
-            rp, enc_com = range_proof_vec.create_rangeproof(clipped, bl, prove_range, n_partition, nonce=_sub_nonce(nonce_seed, b"range"))
-            proof, pairs = compressed_rand_proof.helper_prove_existing(x, enc_com, bl, nonce=_sub_nonce(nonce_seed, b"rand"))
+            enc_com = pedersen_ops.commit_vec(conversion32.f32_to_scalar_vec(clipped), bl)
+            (rp, rp_com), (proof, pairs) = _concurrently(
+                lambda: range_proof_vec.create_rangeproof(clipped, bl, prove_range, n_partition, nonce=_sub_nonce(nonce_seed, b"range")),
+                lambda: compressed_rand_proof.helper_prove_existing(x, enc_com, bl, nonce=_sub_nonce(nonce_seed, b"rand")))
+            assert (rp_com == enc_com).all()
         else:
             k = _num_checked(x.size, check_percentage)
-            rp, _ = range_proof_vec.create_rangeproof(clipped[:k], bl[:k], prove_range, n_partition, nonce=_sub_nonce(nonce_seed, b"range"))
-            proof, pairs = compressed_rand_proof.helper_prove(x, bl, nonce=_sub_nonce(nonce_seed, b"rand"))
+            (rp, _), (proof, pairs) = _concurrently(
+                lambda: range_proof_vec.create_rangeproof(clipped[:k], bl[:k], prove_range, n_partition, nonce=_sub_nonce(nonce_seed, b"range")),
+                lambda: compressed_rand_proof.helper_prove(x, bl, nonce=_sub_nonce(nonce_seed, b"rand")))
         return cls(pairs, proof, rp, prove_range, check_percentage)
 
     def verify(self, verifier_seed=None):
         try:
             if self.rand_proof.size != 128:
                 return False
-            ok = compressed_rand_proof.helper_verify(self.rand_proof, self.enc_values)
             k = _num_checked(self.enc_values.shape[0], self.check_percentage)
-            ok_range = range_proof_vec.verify_rangeproof(self.range_proofs, self.enc_values[:k, :32], self.prove_range, verifier_seed=_sub_seed(verifier_seed, b"v"))
+            ok, ok_range = _concurrently(
+                lambda: compressed_rand_proof.helper_verify(self.rand_proof, self.enc_values),
+                lambda: range_proof_vec.verify_rangeproof(self.range_proofs, self.enc_values[:k, :32], self.prove_range, verifier_seed=_sub_seed(verifier_seed, b"v")))
         except RoflError:
             return False
         return bool(ok and ok_range)
@@ -287,9 +297,12 @@ class EncParamsL2Compressed(EncParamsL2):
         bl = api._u8(blinding_vec)
         r2 = pedersen_ops.rnd_scalar_vec(x.size) if rand_scalars is None else api._u8(rand_scalars)
         clipped = range_proof_vec.clip_f32_to_range_vec(x, prove_range)
-        rp, enc_com = range_proof_vec.create_rangeproof(clipped, bl, prove_range, n_partition, nonce=_sub_nonce(nonce_seed, b"range"))
-        sum_proof, _ = l2_range_proof_vec.create_rangeproof_l2(clipped, r2, l2_range, n_partition, nonce=_sub_nonce(nonce_seed, b"l2"))
-        rand_proof, pairs = compressed_rand_proof.helper_prove_existing(clipped, enc_com, bl, nonce=_sub_nonce(nonce_seed, b"rand"))
+        enc_com = pedersen_ops.commit_vec(conversion32.f32_to_scalar_vec(clipped), bl)
+        (rp, rp_com), (sum_proof, _), (rand_proof, pairs) = _concurrently(
+            lambda: range_proof_vec.create_rangeproof(clipped, bl, prove_range, n_partition, nonce=_sub_nonce(nonce_seed, b"range")),
+            lambda: l2_range_proof_vec.create_rangeproof_l2(clipped, r2, l2_range, n_partition, nonce=_sub_nonce(nonce_seed, b"l2")),
+            lambda: compressed_rand_proof.helper_prove_existing(clipped, enc_com, bl, nonce=_sub_nonce(nonce_seed, b"rand")))
+        assert (rp_com == enc_com).all()
         sq_proofs, sq_commits = square_proof_vec.create_l2rangeproof_vec_existing(clipped, enc_com, bl, r2, nonce=_sub_nonce(nonce_seed, b"sq"))
         merged = np.concatenate([pairs, sq_commits[:, 32:64]], axis=1)        # merge(): c = ElGamal pair, c_sq from the square proof (params.rs:777-787)
         return cls(merged, sq_proofs, rand_proof, rp, sum_proof, prove_range, l2_range)
@@ -299,9 +312,10 @@ class EncParamsL2Compressed(EncParamsL2):
         randomness proof itself is not re-checked here (the arm only verifies the square proofs, the range proofs and the sum)."""
         try:
             sqc = np.concatenate([self.enc_values[:, :32], self.enc_values[:, 64:96]], axis=1)      # SquareProofCommitments { c_l: c.L, c_sq }
-            ok = square_proof_vec.verify_l2rangeproof_vec(self.square_proofs, sqc)
-            ok_range = range_proof_vec.verify_rangeproof(self.range_proofs, self.enc_values[:, :32], self.prove_range, verifier_seed=_sub_seed(verifier_seed, b"v"))
-            ok_sum = l2_range_proof_vec.verify_rangeproof_l2(self.square_range_proof, self._sum_c_sq(), self.l2_prove_range, verifier_seed=_sub_seed(verifier_seed, b"s"))
+            ok, ok_range, ok_sum = _concurrently(
+                lambda: square_proof_vec.verify_l2rangeproof_vec(self.square_proofs, sqc),
+                lambda: range_proof_vec.verify_rangeproof(self.range_proofs, self.enc_values[:, :32], self.prove_range, verifier_seed=_sub_seed(verifier_seed, b"v")),
+                lambda: l2_range_proof_vec.verify_rangeproof_l2(self.square_range_proof, self._sum_c_sq(), self.l2_prove_range, verifier_seed=_sub_seed(verifier_seed, b"s")))
         except RoflError:
             return False
         return bool(ok and ok_range and ok_sum)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark (BASELINE.json): range-proof elements/sec, create + verify, d = 25 000, 32-bit L-inf, P = 4.
 
-One "step" = a batch of C clients (--clients-per-step, default 2), each running create_rangeproof + verify_rangeproof over
+One "step" = a batch of C clients (--clients-per-step, default 6 when the host has the cores), each running create_rangeproof + verify_rangeproof over
 d = 25 000 synthetic f32 values (uniform in the half-open clip interval, as rofl_crypto/benches/rangeproof_bench.rs:41-50)
 through the C ABI from its own host thread -- the library serves concurrent calls on separate lanes (streams + workspaces),
 which is how the reference's server drives this path (one rayon task per client, server.rs:656-687).  The sequential
@@ -100,9 +100,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8192)
     ap.add_argument("--no-l2", action="store_true")
-    ap.add_argument("--clients-per-step", type=int, default=0, help="clients in flight per GPU (0 = 3; fewer when there are less than ~2 host cores per client in flight: one uses ~1.6)")
+    ap.add_argument("--clients-per-step", type=int, default=0, help="clients in flight per GPU (0 = 6; fewer when there are less than ~2.5 host cores per client in flight: one uses ~1.3)")
     args = ap.parse_args()
-    CPS = args.clients_per_step if args.clients_per_step > 0 else max(1, min(3, avail_cores() // (2 * int(os.environ.get("LOCAL_WORLD_SIZE", "1")))))
+    CPS = args.clients_per_step if args.clients_per_step > 0 else max(1, min(6, int(avail_cores() / (2.5 * int(os.environ.get("LOCAL_WORLD_SIZE", "1"))))))
     os.environ.setdefault("ROFL_LANES", str(CPS))
 
     import torch

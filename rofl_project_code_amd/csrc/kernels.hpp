@@ -67,6 +67,32 @@ __device__ __forceinline__ void store_ge(ge *p, const ge &v) {
 }
 __device__ __forceinline__ nd load_nd(const niels *p) { return nd_unpack(load_niels(p)); }
 __device__ __forceinline__ nd gload_nd(const niels *p) { return nd_unpack(gload_niels(p)); }
+// Window-table entry of the fixed-base MSM: the affine niels triple already in the register radix (3 x 10 limbs + 2 words
+// of padding = 128 B, one cache line per gather; the 96-byte packed form straddles two 64-byte sectors just the same and
+// costs 66 VALU instructions per addition to unpack).
+struct ndm { u32 v[32]; };
+__device__ __forceinline__ nd gload_ndm(const ndm *p) {
+    v4u w[8];
+    const g_uint4 *s = (const g_uint4 *)p;
+#pragma unroll
+    for (int i = 0; i < 8; i++) w[i] = s[i];
+    const u32 *f = reinterpret_cast<const u32 *>(w);
+    nd r;
+#pragma unroll
+    for (int i = 0; i < 10; i++) { r.ypx.v[i] = f[i]; r.ymx.v[i] = f[10 + i]; r.t2d.v[i] = f[20 + i]; }
+    return r;
+}
+__device__ __forceinline__ void store_ndm(ndm *p, const niels &q) {
+    nd t = nd_unpack(q);
+    u32 f[32];
+#pragma unroll
+    for (int i = 0; i < 10; i++) { f[i] = t.ypx.v[i]; f[10 + i] = t.ymx.v[i]; f[20 + i] = t.t2d.v[i]; }
+    f[30] = 0; f[31] = 0;
+    uint4 *d = reinterpret_cast<uint4 *>(p);
+    const uint4 *s = reinterpret_cast<const uint4 *>(f);
+#pragma unroll
+    for (int i = 0; i < 8; i++) d[i] = s[i];
+}
 __device__ __forceinline__ gd load_gd(const ge *p) { return gd_unpack(load_ge(p)); }
 __device__ __forceinline__ void store_gd(ge *p, const gd &v) { store_ge(p, gd_pack(v)); }
 __device__ __forceinline__ sc load_sc(const sc *p) {
@@ -637,18 +663,18 @@ __device__ __forceinline__ void msm_window(const MsmWin &mw, u32 w, u32 &pos, u3
     else { pos = mw.wide * mw.c + (w - mw.wide) * (mw.c - 1); width = mw.c - 1; }
 }
 // window table for the fixed-base MSM: wtab[w][g] = 2^(pos_w) * gens[g] for the W windows of `mw` (affine niels)
-__global__ void __launch_bounds__(TPB) k_gens_wtab(u32 total, MsmWin mw, const niels *gens, niels *wtab, size_t stride) {
+__global__ void __launch_bounds__(TPB) k_gens_wtab(u32 total, MsmWin mw, const niels *gens, ndm *wtab, size_t stride) {
     u32 g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= total) return;
     niels p0 = load_niels(&gens[g]);
-    store_niels(&wtab[g], p0);
+    store_ndm(&wtab[g], p0);
     gd cur = gd_unpack(ge_from_niels(p0));
     u32 at = 0;
     for (u32 w = 1; w < mw.W; w++) {
         u32 pos, wid; msm_window(mw, w, pos, wid);
         for (; at + 1 < pos; at++) cur = gd_double_not(cur);
         for (; at < pos; at++) cur = gd_double(cur);
-        store_niels(&wtab[(size_t)w * stride + g], gd_to_niels(cur));
+        store_ndm(&wtab[(size_t)w * stride + g], gd_to_niels(cur));
     }
 }
 
@@ -848,20 +874,21 @@ __global__ void __launch_bounds__(1024) k_msm_scatter_lds(u32 n_side, u32 tile_p
     }
 }
 // one 64-lane wave; lane l owns the overflow entries whose bucket index is l mod 64 (no two lanes share a bucket)
-__global__ void k_msm_overflow(u32 W, u32 B, u32 pstep, const MsmProb *probs, const u32 *ovf_count, const MsmOvf *ovf, u32 ovf_max, ge *buckets) {
+__global__ void k_msm_overflow(u32 W, u32 B, u32 pstep, const MsmProb *probs, const u32 *ovf_count, const MsmOvf *ovf, u32 ovf_max, ge *buckets, int fb) {
     if (blockIdx.x) return;
     u32 cnt = *ovf_count; if (cnt > ovf_max) cnt = ovf_max;
     for (u32 o = 0; o < cnt; o++) {
         u32 bi = ovf[o].bucket, v = ovf[o].entry, p = bi / (W * B) * pstep;
         if ((bi & 63u) != threadIdx.x) continue;
         gd acc = load_gd(&buckets[bi]);
-        acc = gd_madd(acc, gload_nd(&probs[p].pts[v & 0x7fffffffu]), (v >> 31) != 0);
+        u32 idx = v & 0x7fffffffu;
+        acc = gd_madd(acc, fb ? gload_ndm(reinterpret_cast<const ndm *>(probs[p].pts) + idx) : gload_nd(&probs[p].pts[idx]), (v >> 31) != 0);
         store_gd(&buckets[bi], acc);
     }
 }
 // one thread per bucket: sum its points.  buckets [prob][W][B] extended.
 // blockIdx.y = grid problem q owning W bucket arrays; its points are probs[q * pstep].pts (pstep = 2 for merged L/R pairs)
-__global__ void __launch_bounds__(TPB) k_msm_accumulate(u32 n, u32 c, u32 W, u32 pstep, const MsmProb *probs, const u32 *cnt, const u32 *off,
+template <bool FB> __global__ void __launch_bounds__(TPB) k_msm_accumulate(u32 n, u32 c, u32 W, u32 pstep, const MsmProb *probs, const u32 *cnt, const u32 *off,
                                  const u32 *sorted, const u32 *perm, ge *buckets, u32 cap, u32 idx_mask) {
     u32 p = blockIdx.y, B = 1u << (c - 1);
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -878,7 +905,8 @@ __global__ void __launch_bounds__(TPB) k_msm_accumulate(u32 n, u32 c, u32 W, u32
     //  forcing 5 waves/SIMD -- 96 VGPRs, 136 B/lane of scratch -- takes 1.65x as long)
     for (u32 e = 0; e < num; e++) {
         u32 v = lst[e];
-        acc = gd_madd(acc, gload_nd(&pts[v & idx_mask]), (v >> 31) != 0);
+        u32 idx = v & idx_mask;
+        acc = gd_madd(acc, FB ? gload_ndm(reinterpret_cast<const ndm *>(pts) + idx) : gload_nd(&pts[idx]), (v >> 31) != 0);
     }
     store_gd(&buckets[bi], acc);
 }

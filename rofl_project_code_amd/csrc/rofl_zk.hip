@@ -360,14 +360,14 @@ niels *get_gens(Ctx &C, size_t n, size_t m) {
     hipLaunchKernelGGL(k_gens_tables, grid1(2 * N * fc.np), dim3(TPB), 0, C.stream, (u32)(2 * N), fc, tbl, (size_t)(2 * N));
     Ctx &Pm = C.parent ? *C.parent : C;
     if (Pm.msm_fb && 2 * N >= Pm.msm_fb_min && 2 * N * 16 < ((size_t)1 << 31)) {      // entry index (w * 2N + i) must fit 31 bits
-        niels *wt; HIPCHK(hipMalloc(&wt, sizeof(niels) * 2 * N * 16));
+        ndm *wt; HIPCHK(hipMalloc(&wt, sizeof(ndm) * 2 * N * 16));
         MsmPlan fp = msm_plan_c(16);
         hipLaunchKernelGGL(k_gens_wtab, grid1(2 * N), dim3(TPB), 0, C.stream, (u32)(2 * N), MsmWin{fp.c, fp.W, fp.wide}, tbl, wt, (size_t)(2 * N));
-        Pm.wtabs[tbl] = wt;
+        Pm.wtabs[tbl] = reinterpret_cast<niels *>(wt);      // opaque to the host: entries are 128-byte ndm records
     }
     HIPCHK(hipStreamSynchronize(C.stream));
     gens[key] = tbl;
-    size_t held = sizeof(niels) * 2 * N * fc.np * fc.e + (Pm.wtabs.count(tbl) ? sizeof(niels) * 2 * N * 16 : 0);
+    size_t held = sizeof(niels) * 2 * N * fc.np * fc.e + (Pm.wtabs.count(tbl) ? sizeof(ndm) * 2 * N * 16 : 0);
     Pm0.gens_use[key] = {++Pm0.gens_tick, held};
     // Keep the cache inside its HBM budget: drop the least recently used other configurations -- only while this is the
     // one call in flight on the device (a call that starts meanwhile blocks on gens_mu and rebuilds what it needs).
@@ -481,9 +481,10 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
             hipLaunchKernelGGL(k_msm_scatter_slots, grid1(n, (u32)(nq * Wgrid)), dim3(TPB), 0, C.stream, (u32)n, mw, mm, d_probs, cnt, slots, cap, ovf_count, ovf, OVF_MAX);
             hipLaunchKernelGGL(k_msm_scan, dim3((unsigned)PW), dim3(TPB), 0, C.stream, P.B, cnt, off, (u32 *)nullptr, perm);
             if (C.tm.enabled) { e0 = C.tm.get(); e1 = C.tm.get(); HIPCHK(hipEventRecord(e0, C.stream)); }
-            hipLaunchKernelGGL(k_msm_accumulate, grid1((size_t)Wb * P.B, (u32)nq), dim3(TPB), 0, C.stream, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, slots, perm, buckets, cap, dbg_mask);
+            if (fb) hipLaunchKernelGGL(k_msm_accumulate<true>, grid1((size_t)Wb * P.B, (u32)nq), dim3(TPB), 0, C.stream, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, slots, perm, buckets, cap, dbg_mask);
+            else hipLaunchKernelGGL(k_msm_accumulate<false>, grid1((size_t)Wb * P.B, (u32)nq), dim3(TPB), 0, C.stream, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, slots, perm, buckets, cap, dbg_mask);
             if (C.tm.enabled) HIPCHK(hipEventRecord(e1, C.stream));
-            hipLaunchKernelGGL(k_msm_overflow, dim3(1), dim3(64), 0, C.stream, Wb, P.B, (u32)(np / nq), d_probs, ovf_count, ovf, OVF_MAX, buckets);
+            hipLaunchKernelGGL(k_msm_overflow, dim3(1), dim3(64), 0, C.stream, Wb, P.B, (u32)(np / nq), d_probs, ovf_count, ovf, OVF_MAX, buckets, fb ? 1 : 0);
             HIPCHK(hipMemcpyAsync(C.h_ovf.as<u32>(4), ovf_count, 4, hipMemcpyDeviceToHost, C.stream));
         } else {
             u32 *sorted = C.msm_sorted.as<u32>(PW * n * 2);
@@ -491,7 +492,7 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
             hipLaunchKernelGGL(k_msm_scan, dim3((unsigned)PW), dim3(TPB), 0, C.stream, P.B, cnt, off, cur, perm);
             hipLaunchKernelGGL(k_msm_scatter, grid1(n, (u32)(nq * Wgrid)), dim3(TPB), 0, C.stream, (u32)n, mw, mm, d_probs, cur, sorted);
             if (C.tm.enabled) { e0 = C.tm.get(); e1 = C.tm.get(); HIPCHK(hipEventRecord(e0, C.stream)); }
-            hipLaunchKernelGGL(k_msm_accumulate, grid1((size_t)Wb * P.B, (u32)nq), dim3(TPB), 0, C.stream, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, sorted, perm, buckets, 0u, dbg_mask);
+            hipLaunchKernelGGL(k_msm_accumulate<false>, grid1((size_t)Wb * P.B, (u32)nq), dim3(TPB), 0, C.stream, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, sorted, perm, buckets, 0u, dbg_mask);
             if (C.tm.enabled) HIPCHK(hipEventRecord(e1, C.stream));
         }
         if (C.tm.enabled) { C.tm.acc_ev.push_back({e0, e1}); C.tm.t.msm_accumulate_launches++; char tg[96]; snprintf(tg, sizeof tg, "msm np=%zu n=%zu c=%u cap=%u fb=%u lr=%d", np, n, P.c, slots_mode ? cap : 0u, fb ? sets : 0u, (int)lr); C.tm.acc_tag.push_back(tg); }

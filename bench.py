@@ -232,9 +232,10 @@ def main():
         try:
             import glob
             pj = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))[-1]
-            ent = json.load(open(pj)).get("rofl::" + kname)
-            if ent:
-                traffic = (2.0 * ent["fetch_kb_per_launch"] + ent["write_kb_per_launch"]) * 1024.0
+            ents = [v for k, v in json.load(open(pj)).items() if ("rofl::" + kname) in k]      # template instances (k<true>, k<false>) are separate rows
+            nl = sum(e["launches"] for e in ents)
+            if nl:
+                traffic = sum(e["launches"] * (2.0 * e["fetch_kb_per_launch"] + e["write_kb_per_launch"]) for e in ents) * 1024.0 / nl
         except Exception:      # noqa: BLE001
             traffic = None
         out = {

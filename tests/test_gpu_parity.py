@@ -259,10 +259,42 @@ def test_full_size_properties_cfg2(R):
     assert (R.pedersen_ops.commit_vec(sc, bl) == cm).all()
     idx = rng.choice(d, 64, replace=False)
     assert (orc.commit_vec(sc[idx], bl[idx]) == cm[idx]).all()
+    # chunk 0 at full size against the oracle, bit for bit (its nonces start at index 0, so it equals the single-chunk proof
+    # over the first 8192 values; ~8 s of CPU)
+    rc, opr, ocm = orc.create_rangeproof(vals[:8192], bl[:8192], nb, 1, 32, 7, seed=b"\x11" * 32)
+    assert rc == 0 and (opr[0] == pr[0]).all() and (ocm == cm[:8192]).all()
     # a different nonce seed changes the proof but not the commitments
     pr3, cm3 = R.range_proof_vec.create_rangeproof(vals, bl, nb, P, nonce=R.Nonce.seeded(b"\x12" * 32))
     assert (cm3 == cm).all() and not (pr3 == pr).all()
     assert R.range_proof_vec.verify_rangeproof(pr3, cm3, nb, verifier_seed=b"\x01" * 32)
+    R.api.set_fp(16, 7)
+
+
+def test_full_size_properties_cfg2_e2e_partition(R):
+    """The same workload at the reference's e2e partition count (n_partition = 64, cifar_large.yml:39-46): 64 chunks of
+    m = 512 -- fixed-base tables shared by all chunks, device-side Horner for the 128 problems of a round, folds down to
+    64 generators.  Chunk 0 is compared with the oracle bit for bit (its nonces start at index 0, so it equals a
+    single-chunk proof over the first 512 values); the rest through the size-independent properties."""
+    R.api.set_fp(32, 7)
+    rng = np.random.default_rng(25064)
+    d, nb, P = 25000, 32, 64
+    vals, _ = _inputs(R, rng, d, nb, 32, 7)
+    bl = rng.integers(0, 256, size=(d, 32), dtype=np.uint8); bl[:, 31] &= 0x0F
+    seed = b"\x21" * 32
+    pr, cm = R.range_proof_vec.create_rangeproof(vals, bl, nb, P, nonce=R.Nonce.seeded(seed))
+    assert pr.shape == (64, 32 * (9 + 2 * 14))
+    pr2, cm2 = R.range_proof_vec.create_rangeproof(vals, bl, nb, P, nonce=R.Nonce.seeded(seed))
+    assert (pr == pr2).all() and (cm == cm2).all()
+    rc, opr, ocm = orc.create_rangeproof(vals[:512], bl[:512], nb, 1, 32, 7, seed=seed)
+    assert rc == 0 and (opr[0] == pr[0]).all() and (ocm == cm[:512]).all()
+    assert R.range_proof_vec.verify_rangeproof(pr, cm, nb, verifier_seed=b"\x01" * 32)
+    assert orc.verify_rangeproof(pr[:1], cm[:512], nb, 32, 7) == (0, True)
+    bad = pr.copy(); bad[37, 9 * 32 + 1] ^= 1
+    assert not R.range_proof_vec.verify_rangeproof(bad, cm, nb, verifier_seed=b"\x01" * 32)
+    # the commitments do not depend on the partition
+    pr4, cm4 = R.range_proof_vec.create_rangeproof(vals, bl, nb, 4, nonce=R.Nonce.seeded(seed))
+    assert (cm4 == cm).all()
+    assert R.range_proof_vec.verify_rangeproof_batch([pr, pr2], [cm, cm2], nb, verifier_seed=b"\x03" * 32) == [True, True]
     R.api.set_fp(16, 7)
 
 

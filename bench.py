@@ -137,7 +137,7 @@ def main():
     clients = [synth_client(1000 * ((s * world + rank) * CPS + j)) for s in range(total_steps) for j in range(CPS)]
     from concurrent.futures import ThreadPoolExecutor
     workers = ThreadPoolExecutor(max_workers=CPS)
-    agg = {"msm_accumulate_ms": 0.0, "msm_accumulate_launches": 0, "msm_terms": 0, "fold_ms": 0.0, "fold_launches": 0,
+    agg = {"msm_accumulate_ms": 0.0, "msm_accumulate_launches": 0, "msm_terms": 0, "msm_additions": 0, "fold_ms": 0.0, "fold_launches": 0,
            "fold_point_reads": 0, "host_ms": 0.0, "total_ms": 0.0, "create_ms": 0.0, "verify_ms": 0.0}
 
     def sync():
@@ -174,7 +174,7 @@ def main():
                 ok = rd.all_verified(ok, cdev)
             assert ok, "proof failed to verify"
             if timed:
-                for k in ("msm_accumulate_ms", "msm_accumulate_launches", "msm_terms", "fold_ms", "fold_launches", "fold_point_reads", "host_ms", "total_ms"):
+                for k in ("msm_accumulate_ms", "msm_accumulate_launches", "msm_terms", "msm_additions", "fold_ms", "fold_launches", "fold_point_reads", "host_ms", "total_ms"):
                     agg[k] += tc[k] + tv[k]
                 agg["create_ms"] += ms_c; agg["verify_ms"] += ms_v
 
@@ -212,7 +212,8 @@ def main():
                   # the same kernel with nothing else on the GPU: event time == kernel time
                   "k_msm_accumulate_avg_launch_ms": seq["msm_accumulate_ms"] / max(seq["msm_accumulate_launches"], 1),
                   "k_msm_accumulate_GBps_algorithmic": seq["msm_terms"] * 32.0 / max(seq["msm_accumulate_ms"] * 1e-3, 1e-12) / 1e9,
-                  "k_msm_accumulate_ms_per_client": seq["msm_accumulate_ms"] / nseq, "k_fold_gens_ms_per_client": seq["fold_ms"] / nseq}
+                  "k_msm_accumulate_ms_per_client": seq["msm_accumulate_ms"] / nseq, "k_fold_gens_ms_per_client": seq["fold_ms"] / nseq,
+                  "k_msm_accumulate_fe_mul_per_s": seq["msm_additions"] * 7.0 / max(seq["msm_accumulate_ms"] * 1e-3, 1e-12)}
 
     if rank == 0:
         K = args.steps
@@ -263,7 +264,12 @@ def main():
             "other_configs": "profiles/r01_configs.json (scripts/gpu_configs.py): all five BASELINE configs and the e2e partition count P=64, reference bench protocol",
         }
         try:
-            out["valu_roofline"] = {"fe_mul_per_s_peak_measured": R.bench_femul(400)}
+            peak = R.bench_femul(400)
+            out["valu_roofline"] = {"fe_mul_per_s_peak_measured": peak, "kernel": "k_msm_accumulate",
+                                    "achieved_fe_mul_per_s": single["k_msm_accumulate_fe_mul_per_s"] if single else None,
+                                    "frac": (single["k_msm_accumulate_fe_mul_per_s"] / peak) if single else None,
+                                    "note": "the binding resource: 7 field multiplications per mixed addition x (terms x windows) / kernel time of one sequential client, "
+                                            "against a multiplication-only microbenchmark at 8 waves/SIMD (rofl_bench_femul); an addition also issues ~23 % non-multiplication instructions"}
         except Exception as e:      # noqa: BLE001
             out["valu_roofline"] = {"error": str(e)}
         if world == 1 and not args.no_l2:

@@ -191,6 +191,7 @@ typedef struct {
     uint64_t fold_launches;
     uint64_t fold_point_reads;   /* niels points read by k_fold_gens (96 B each) */
     double host_ms;           /* host-side (transcript, Horner, fixed-base) time */
+    uint64_t msm_additions;   /* mixed point additions executed by k_msm_accumulate: terms x windows (7 field multiplications each) */
 } rofl_timing_t;
 int rofl_last_timing(rofl_timing_t *out);
 int rofl_set_timing(int enabled);

@@ -39,7 +39,7 @@ class _Timing(ctypes.Structure):
     _fields_ = [("total_ms", ctypes.c_double), ("msm_accumulate_ms", ctypes.c_double),
                 ("msm_accumulate_launches", ctypes.c_uint64), ("msm_terms", ctypes.c_uint64),
                 ("fold_ms", ctypes.c_double), ("fold_launches", ctypes.c_uint64),
-                ("fold_point_reads", ctypes.c_uint64), ("host_ms", ctypes.c_double)]
+                ("fold_point_reads", ctypes.c_uint64), ("host_ms", ctypes.c_double), ("msm_additions", ctypes.c_uint64)]
 
 
 class Nonce:

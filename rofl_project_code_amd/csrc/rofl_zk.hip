@@ -495,7 +495,7 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
             hipLaunchKernelGGL(k_msm_accumulate<false>, grid1((size_t)Wb * P.B, (u32)nq), dim3(TPB), 0, C.stream, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, sorted, perm, buckets, 0u, dbg_mask);
             if (C.tm.enabled) HIPCHK(hipEventRecord(e1, C.stream));
         }
-        if (C.tm.enabled) { C.tm.acc_ev.push_back({e0, e1}); C.tm.t.msm_accumulate_launches++; char tg[96]; snprintf(tg, sizeof tg, "msm np=%zu n=%zu c=%u cap=%u fb=%u lr=%d", np, n, P.c, slots_mode ? cap : 0u, fb ? sets : 0u, (int)lr); C.tm.acc_tag.push_back(tg); }
+        if (C.tm.enabled) { C.tm.acc_ev.push_back({e0, e1}); C.tm.t.msm_accumulate_launches++; C.tm.t.msm_additions += (uint64_t)(lr ? nq : np) * n * (fb ? 16u : P.W); char tg[96]; snprintf(tg, sizeof tg, "msm np=%zu n=%zu c=%u cap=%u fb=%u lr=%d", np, n, P.c, slots_mode ? cap : 0u, fb ? sets : 0u, (int)lr); C.tm.acc_tag.push_back(tg); }
         // reduction tree: global levels while more than 512 nodes remain, then one fused launch
         const ge *S_in = buckets; const ge *C_in = nullptr;
         u32 E = P.B, nb = 0, lv = 0;

@@ -981,12 +981,8 @@ __global__ void __launch_bounds__(TPB) k_msm_reduce_level(u32 E, u32 nb, const g
 // All remaining levels (E <= 512) of one (prob, window) in a single block through LDS: one launch instead of three
 // or four latency-bound ones.  First level 8-ary (global -> LDS), the rest binary (one addition deep per level):
 // S'[g] = S[2g] + S[2g+1], new bit-sum = S[2g+1], carried bit-sums pairwise.  Output: S_fin [PW], C_fin [PW][nb_final].
-__global__ void __launch_bounds__(512) k_msm_reduce_fused(u32 E, u32 nb, const ge *S_in, const ge *C_in, ge *S_fin, ge *C_fin, u32 nb_final) {
-    extern __shared__ __align__(16) unsigned char smem[];
+__device__ __forceinline__ void msm_reduce_fused_body(u32 E, u32 nb, const ge *si, const ge *ci, ge *fin_s, ge *fin_c, unsigned char *smem) {
     ge *buf0 = reinterpret_cast<ge *>(smem);
-    u32 pw = blockIdx.x;
-    const ge *si = S_in + (size_t)pw * E, *ci = C_in + (size_t)pw * nb * E;
-    ge *fin_s = S_fin + pw, *fin_c = C_fin + (size_t)pw * nb_final;
     // level 1: 8-ary
     u32 E8 = E / 8;
     ge *so = E8 == 1 ? fin_s : buf0, *co = E8 == 1 ? fin_c : buf0 + E8;
@@ -1016,6 +1012,56 @@ __global__ void __launch_bounds__(512) k_msm_reduce_fused(u32 E, u32 nb, const g
         __syncthreads();
         si = so; ci = co; E = E2; nb += 1; sel ^= 1;
     }
+}
+__global__ void __launch_bounds__(512) k_msm_reduce_fused(u32 E, u32 nb, const ge *S_in, const ge *C_in, ge *S_fin, ge *C_fin, u32 nb_final) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    u32 pw = blockIdx.x;
+    msm_reduce_fused_body(E, nb, S_in + (size_t)pw * E, C_in + (size_t)pw * nb * E, S_fin + pw, C_fin + (size_t)pw * nb_final, smem);
+}
+// A small MSM (the IPP tail: a few thousand terms per problem) in ONE launch instead of memset / scatter / scan / accumulate /
+// overflow / reduce: block = one (problem, window) bucket array (generic window layout, c <= 10).  The window's digits are
+// ranked into per-bucket lists in LDS (SMALL_CAP entries each), thread b sums bucket b's points in a uniform loop, the buckets
+// go to HBM and the same block runs the bucket reduction of k_msm_reduce_fused over them.  A list overflow (scalars built
+// to collide) raises *overflow and the host repeats the MSM through the general pipeline.
+#define MSM_SMALL_CAP 64      /* mean load <= 16 (n_side <= 8 B, narrow windows fill half of the buckets): P(overflow) ~ 1e-18 per bucket */
+__global__ void __launch_bounds__(512) k_msm_small(u32 n_side, MsmWin mw, MsmMap mm, const MsmProb *probs, ge *buckets, ge *S_fin, ge *C_fin,
+                                                   u32 nb_final, u32 *overflow) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const u32 B = 1u << (mw.c - 1);
+    u32 pw = blockIdx.x, p = pw / mw.W, w = pw % mw.W;
+    u32 side = mm.lr_nh ? (p & 1u) : 0u;
+    u32 *lcnt = reinterpret_cast<u32 *>(smem);                       // [B]
+    u32 *lst = lcnt + B;                                             // [B][MSM_SMALL_CAP]: term index | sign
+    for (u32 b = threadIdx.x; b < B; b += blockDim.x) lcnt[b] = 0;
+    __syncthreads();
+    u32 wpos, wwid; msm_window(mw, w, wpos, wwid);
+    const sc *scal = probs[p].scal;
+    for (u32 k = threadIdx.x; k < n_side; k += blockDim.x) {
+        u32 i = mm.lr_nh ? msm_side_term(mm, side, k) : k;
+        int d = msm_digit(gload_sc(&scal[i]), wpos, wwid);
+        u32 ad = (u32)(d < 0 ? -d : d), entry = i | (d < 0 ? 0x80000000u : 0u);
+        for (int rep = 0; rep < 2; rep++) {
+            u32 a1 = rep == 0 ? (ad > B ? B : 0u) : (ad > B ? ad - B : ad);
+            if (!a1) continue;
+            u32 pos = atomicAdd(&lcnt[a1 - 1], 1u);
+            if (pos < MSM_SMALL_CAP) lst[(a1 - 1) * MSM_SMALL_CAP + pos] = entry;
+            else atomicAdd(overflow, 1u);
+        }
+    }
+    __syncthreads();
+    const niels *pts = probs[p].pts;
+    for (u32 b = threadIdx.x; b < B; b += blockDim.x) {
+        u32 num = lcnt[b]; if (num > MSM_SMALL_CAP) num = MSM_SMALL_CAP;
+        gd acc = gd_identity();
+        for (u32 e = 0; e < num; e++) {
+            u32 v = lst[b * MSM_SMALL_CAP + e];
+            acc = gd_madd(acc, gload_nd(&pts[v & 0x7fffffffu]), (v >> 31) != 0);
+        }
+        store_gd(&buckets[(size_t)pw * B + b], acc);
+    }
+    __threadfence_block();
+    __syncthreads();
+    msm_reduce_fused_body(B, 0, buckets + (size_t)pw * B, nullptr, S_fin + pw, C_fin + (size_t)pw * nb_final, smem);
 }
 
 // Finish an MSM on the device when a launch carries many problems (n_partition = 64: 128 L/R problems per IPP round, whose

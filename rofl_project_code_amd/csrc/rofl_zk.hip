@@ -218,6 +218,7 @@ struct Ctx {
     std::map<size_t, Bsgs> bsgs;                          // table_size -> baby-step table
     std::unique_ptr<HostPool> pool;
     size_t fold_min = 1024;
+    size_t msm_small_max = 4096;      // ROFL_MSM_SMALL_MAX: generic MSMs with at most this many terms per problem side run as one fused launch (0 = off)
     size_t msm_dev_horner_min = 32;   // ROFL_MSM_DEV_HORNER_MIN: launches with at least this many problems finish their Horner chains on the device
     bool msm_slots = true;
     int fold_t = 2, fold_t1 = 3, fold_k = 0, fold_tab = 1, fold_unit = 1; long fold_threads = 131072;
@@ -242,6 +243,7 @@ struct Ctx {
         build_fixed_table(ht.Bb, ht.bblind);
         to_tab5(ht.B5, ht.B); to_tab5(ht.Bb5, ht.Bb);
         HIPCHK(hipFuncSetAttribute((const void *)k_msm_reduce_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void *)k_msm_small, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void *)k_msm_scatter_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         HIPCHK(hipMalloc(&d_tabB, sizeof(niels) * 512));
         HIPCHK(hipMalloc(&d_tabBb, sizeof(niels) * 512));
@@ -263,6 +265,7 @@ struct Ctx {
         if (const char *e = getenv("ROFL_MSM_FB_MIN")) { long v = atol(e); if (v >= 1) msm_fb_min = (size_t)v; }
         if (const char *e = getenv("ROFL_FOLD_MIN")) { long v = atol(e); if (v >= 1) fold_min = (size_t)v; }
         if (const char *e = getenv("ROFL_MSM_DEV_HORNER_MIN")) { long v = atol(e); if (v >= 1) msm_dev_horner_min = (size_t)v; }
+        if (const char *e = getenv("ROFL_MSM_SMALL_MAX")) { long v = atol(e); if (v >= 0) msm_small_max = (size_t)v; }
         { int nt = 8; if (const char *e = getenv("ROFL_HOST_THREADS")) nt = atoi(e); unsigned hc = std::thread::hardware_concurrency(); if (hc && (unsigned)nt > hc) nt = (int)hc; if (nt < 1) nt = 1; pool.reset(new HostPool(nt)); }
         if (const char *e = getenv("ROFL_FOLD_T1")) { int v = atoi(e); if (v >= 1 && v <= 6) fold_t1 = v; }
         if (const char *e = getenv("ROFL_FOLD_TAB")) fold_tab = atoi(e) != 0;
@@ -284,7 +287,7 @@ struct Ctx {
         msm_lds = p.msm_lds; msm_lds_min = p.msm_lds_min; msm_lds_tile = p.msm_lds_tile;
         msm_fb_threads = p.msm_fb_threads;
         msm_fb = p.msm_fb; msm_fb_sets = p.msm_fb_sets; msm_fb_min = p.msm_fb_min; msm_lr = p.msm_lr;
-        fold_min = p.fold_min; msm_dev_horner_min = p.msm_dev_horner_min; msm_slots = p.msm_slots; fold_t = p.fold_t; fold_t1 = p.fold_t1; fold_k = p.fold_k; fold_tab = p.fold_tab;
+        fold_min = p.fold_min; msm_dev_horner_min = p.msm_dev_horner_min; msm_small_max = p.msm_small_max; msm_slots = p.msm_slots; fold_t = p.fold_t; fold_t1 = p.fold_t1; fold_k = p.fold_k; fold_tab = p.fold_tab;
         fold_unit = p.fold_unit; fold_threads = p.fold_threads; nlanes = 1;
         { int nt = 6; if (const char *e = getenv("ROFL_HOST_THREADS")) nt = atoi(e); if (nt < 1) nt = 1; pool.reset(new HostPool(nt)); }
         inited = true;
@@ -423,7 +426,7 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
     MsmProb *d_probs = C.msm_probs.as<MsmProb>(np);
     MsmProb *h_probs = C.h_probs.as<MsmProb>(np);
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    MsmPlan P{}; size_t PW = 0; bool fb_used = false, overlap_done = false, dev_horner = false; u32 sets = 0;
+    MsmPlan P{}; size_t PW = 0; bool fb_used = false, overlap_done = false, dev_horner = false, allow_small = true; u32 sets = 0;
     for (int attempt = 0; attempt < 3; attempt++) {
         // attempt 0: fixed-base slots (if available) ; then generic slots ; then the two-pass sort
         bool fb = attempt == 0 && opt.fb_wtab != nullptr && C.msm_slots;
@@ -462,6 +465,21 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
         MsmWin mw{P.c, P.W, P.wide};
         const u32 OVF_MAX = 4096;
         u32 Wb = (u32)(PW / nq);                           // bucket arrays per grid problem
+        // the IPP tail (a few thousand terms per problem): one launch instead of memset / scatter / scan / accumulate / overflow / reduce
+        u32 nside_small = (u32)(lr ? n / 2 : n);
+        bool small = !fb && slots_mode && allow_small && C.msm_small_max && nside_small <= C.msm_small_max && P.c <= 10 && nside_small <= 8 * P.B;
+        if (small) {
+            HIPCHK(hipMemsetAsync(cnt, 0, 16, C.stream));                 // cnt[0] = list-overflow flag
+            ge *S_fin_s = C.msm_S[0].as<ge>(PW);
+            ge *C_fin_s = C.msm_C[0].as<ge>(PW * (size_t)(P.c - 1));
+            size_t lds_lists = (size_t)P.B * 4 * (1 + MSM_SMALL_CAP);
+            size_t lds_red = ((size_t)(P.B / 8) * 4 + (size_t)(P.B / 16) * 5 + 1) * sizeof(ge);
+            if (C.tm.enabled) { e0 = C.tm.get(); e1 = C.tm.get(); HIPCHK(hipEventRecord(e0, C.stream)); }
+            hipLaunchKernelGGL(k_msm_small, dim3((unsigned)PW), dim3(P.B < 64 ? 64 : P.B), std::max(lds_lists, lds_red), C.stream, nside_small, mw, mm, d_probs, buckets,
+                               S_fin_s, C_fin_s, P.c - 1, cnt);
+            if (C.tm.enabled) HIPCHK(hipEventRecord(e1, C.stream));
+            HIPCHK(hipMemcpyAsync(C.h_ovf.as<u32>(4), cnt, 4, hipMemcpyDeviceToHost, C.stream));
+        } else {
         HIPCHK(hipMemsetAsync(cnt, 0, sizeof(u32) * (PW * P.B + 4), C.stream));
         // accumulate sees `nq` problems of Wb bucket arrays each; its points come from d_probs[q * (np / nq)]
         if (slots_mode) {
@@ -495,11 +513,12 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
             hipLaunchKernelGGL(k_msm_accumulate<false>, grid1((size_t)Wb * P.B, (u32)nq), dim3(TPB), 0, C.stream, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, sorted, perm, buckets, 0u, dbg_mask);
             if (C.tm.enabled) HIPCHK(hipEventRecord(e1, C.stream));
         }
+        }
         if (C.tm.enabled) { C.tm.acc_ev.push_back({e0, e1}); C.tm.t.msm_accumulate_launches++; C.tm.t.msm_additions += (uint64_t)(lr ? nq : np) * n * (fb ? 16u : P.W); char tg[96]; snprintf(tg, sizeof tg, "msm np=%zu n=%zu c=%u cap=%u fb=%u lr=%d", np, n, P.c, slots_mode ? cap : 0u, fb ? sets : 0u, (int)lr); C.tm.acc_tag.push_back(tg); }
         // reduction tree: global levels while more than 512 nodes remain, then one fused launch
         const ge *S_in = buckets; const ge *C_in = nullptr;
         u32 E = P.B, nb = 0, lv = 0;
-        while (E > 512) {
+        while (!small && E > 512) {
             u32 E8 = E / 8;
             ge *S_out = C.msm_S[lv & 1].as<ge>(PW * E8);
             ge *C_out = C.msm_C[lv & 1].as<ge>(PW * (size_t)(nb + 3) * E8);
@@ -513,7 +532,7 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
         // waves and, at 163 VGPRs, hold a whole CU: thousands of such blocks (n_partition = 64) ran 18 deep per CU)
         u32 fused_items = (E / 8) * (4 + nb), fused_threads = fused_items > 256 ? 512 : fused_items > 128 ? 256 : fused_items > 64 ? 128 : 64;
         size_t lds = ((size_t)(E / 8) * (1 + nb + 3) + (size_t)(E / 16) * (1 + nb + 4) + 1) * sizeof(ge);
-        hipLaunchKernelGGL(k_msm_reduce_fused, dim3((unsigned)PW), dim3(fused_threads), lds, C.stream, E, nb, S_in, C_in, S_fin, C_fin, nb_final);
+        if (!small) hipLaunchKernelGGL(k_msm_reduce_fused, dim3((unsigned)PW), dim3(fused_threads), lds, C.stream, E, nb, S_in, C_in, S_fin, C_fin, nb_final);
         size_t per = 1 + nb_final;
         ge *hres = C.h_res.as<ge>(PW * per);
         dev_horner = !fb && np >= C.msm_dev_horner_min && P.W <= 64;
@@ -528,6 +547,9 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
         if (opt.overlap && !overlap_done) { opt.overlap(); overlap_done = true; }
         HIPCHK(hipStreamSynchronize(C.stream));
         if (slots_mode && getenv("ROFL_TRACE")) fprintf(stderr, "[rofl] msm np=%zu n=%zu c=%u cap=%u fb=%u lr=%d overflow=%u\n", np, n, P.c, cap, fb ? sets : 0u, (int)lr, *C.h_ovf.as<u32>(4));
+        if (small) {
+            if (*C.h_ovf.as<u32>(4) != 0) { allow_small = false; attempt = 0; continue; }     // a bucket list overflowed: repeat through the general pipeline
+        } else
         if (slots_mode && *C.h_ovf.as<u32>(4) > OVF_MAX) continue;    // pathological input: next (slower, always sufficient) variant
         fb_used = fb;
         break;

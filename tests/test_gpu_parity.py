@@ -561,6 +561,7 @@ def test_bsgs_discrete_log(R):
     {"ROFL_GENS_BUDGET_MB": "1", "ROFL_LANES": "2"},                      # every new (n, m) evicts the previous tables
     {"ROFL_MSM_DEV_HORNER_MIN": "1", "ROFL_MSM_FB": "0"},                 # every MSM finishes its Horner chains on the device
     {"ROFL_MSM_DEV_HORNER_MIN": "1", "ROFL_MSM_FB_MIN": "64"},
+    {"ROFL_MSM_SMALL_MAX": "0"},                                          # the general pipeline at the sizes the fused small-MSM launch normally takes
 ])
 def test_msm_variants_small_sizes(R, env):
     import subprocess, sys

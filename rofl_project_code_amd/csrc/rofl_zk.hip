@@ -467,7 +467,8 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
         u32 Wb = (u32)(PW / nq);                           // bucket arrays per grid problem
         // the IPP tail (a few thousand terms per problem): one launch instead of memset / scatter / scan / accumulate / overflow / reduce
         u32 nside_small = (u32)(lr ? n / 2 : n);
-        bool small = !fb && slots_mode && allow_small && C.msm_small_max && nside_small <= C.msm_small_max && P.c <= 10 && nside_small <= 8 * P.B;
+        // (its blocks hold up to 130 KB of LDS, one per CU: with thousands of bucket arrays -- n_partition = 64 -- the general pipeline is faster)
+        bool small = !fb && slots_mode && allow_small && C.msm_small_max && nside_small <= C.msm_small_max && P.c <= 10 && nside_small <= 8 * P.B && PW <= 512;
         if (small) {
             HIPCHK(hipMemsetAsync(cnt, 0, 16, C.stream));                 // cnt[0] = list-overflow flag
             ge *S_fin_s = C.msm_S[0].as<ge>(PW);
@@ -514,7 +515,7 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
             if (C.tm.enabled) HIPCHK(hipEventRecord(e1, C.stream));
         }
         }
-        if (C.tm.enabled) { C.tm.acc_ev.push_back({e0, e1}); C.tm.t.msm_accumulate_launches++; C.tm.t.msm_additions += (uint64_t)(lr ? nq : np) * n * (fb ? 16u : P.W); char tg[96]; snprintf(tg, sizeof tg, "msm np=%zu n=%zu c=%u cap=%u fb=%u lr=%d", np, n, P.c, slots_mode ? cap : 0u, fb ? sets : 0u, (int)lr); C.tm.acc_tag.push_back(tg); }
+        if (C.tm.enabled && !small) { C.tm.acc_ev.push_back({e0, e1}); C.tm.t.msm_accumulate_launches++; C.tm.t.msm_additions += (uint64_t)(lr ? nq : np) * n * (fb ? 16u : P.W); char tg[96]; snprintf(tg, sizeof tg, "msm np=%zu n=%zu c=%u cap=%u fb=%u lr=%d", np, n, P.c, slots_mode ? cap : 0u, fb ? sets : 0u, (int)lr); C.tm.acc_tag.push_back(tg); }
         // reduction tree: global levels while more than 512 nodes remain, then one fused launch
         const ge *S_in = buckets; const ge *C_in = nullptr;
         u32 E = P.B, nb = 0, lv = 0;

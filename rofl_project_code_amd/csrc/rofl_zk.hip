@@ -121,7 +121,19 @@ ge h_fixed_mul32(const std::vector<niels> &tab, const sc &k_canon) {
 class HostPool {
     std::vector<std::thread> workers; std::mutex mu; std::condition_variable cv;
     std::function<void(size_t)> fn; std::atomic<size_t> count{0}, next{0}, done{0}; std::atomic<int> active{0}; uint64_t gen = 0; bool stop = false;
-    void work() { active.fetch_add(1); for (;;) { size_t i = next.fetch_add(1); if (i >= count.load()) break; fn(i); done.fetch_add(1); } active.fetch_sub(1); }
+    // An index is claimed only after it has been checked against `count` (compare-and-swap, not fetch-add): a worker that wakes
+    // late and arrives while run() is resetting the job (count == 0 in that window) must not consume an index of the next job --
+    // with a blind fetch-add it could take index 0 between `next = 0` and `count = n` and drop it, and run() would wait forever.
+    void work() {
+        active.fetch_add(1);
+        for (;;) {
+            size_t i = next.load();
+            if (i >= count.load()) break;
+            if (!next.compare_exchange_weak(i, i + 1)) continue;
+            fn(i); done.fetch_add(1);
+        }
+        active.fetch_sub(1);
+    }
     void loop() {
         uint64_t seen = 0;
         for (;;) {

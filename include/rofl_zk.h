@@ -202,6 +202,7 @@ int rofl_dbg_msm(const uint8_t *scalars32, const uint8_t *points32, size_t n, ui
 int rofl_bench_femul(unsigned iters, double *fe_mul_per_sec_out);
 
 /* ---- host-side self-test hooks (same source as the device math, compiled for the CPU) ---- */
+int rofl_dbg_host_pool_stress(unsigned threads, unsigned jobs);   /* host thread pool: every index of every job runs exactly once */
 int rofl_dbg_host_fe_mul(const uint8_t a[32], const uint8_t b[32], uint8_t out[32]);
 int rofl_dbg_host_fe_ops(const uint8_t a[32], const uint8_t b[32], uint8_t out_add[32], uint8_t out_sub[32], uint8_t out_sq[32], uint8_t out_inv[32]);
 int rofl_dbg_host_sc_mul(const uint8_t a[32], const uint8_t b[32], uint8_t out[32]);

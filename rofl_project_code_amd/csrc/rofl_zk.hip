@@ -1805,6 +1805,18 @@ int rofl_bench_femul(unsigned iters, double *out) {
 }
 
 // ---- host-side self-tests of the shared host/device math (no GPU needed)
+int rofl_dbg_host_pool_stress(unsigned threads, unsigned jobs) {
+    // many tiny jobs back to back: every index of every job must run exactly once (a lost index would hang run())
+    HostPool pool((int)threads);
+    for (unsigned it = 0; it < jobs; it++) {
+        size_t n = 2 + it % 7;
+        std::atomic<int> hits[8];
+        for (auto &h : hits) h = 0;
+        pool.run(n, [&](size_t i) { hits[i].fetch_add(1); });
+        for (size_t i = 0; i < n; i++) if (hits[i].load() != 1) return ROFL_BAD_PARAM;
+    }
+    return ROFL_OK;
+}
 int rofl_dbg_host_fe_mul(const uint8_t a[32], const uint8_t b[32], uint8_t out[32]) { fe_tobytes(out, fe_mul(fe_frombytes(a), fe_frombytes(b))); return 0; }
 int rofl_dbg_host_fe_ops(const uint8_t a[32], const uint8_t b[32], uint8_t oa[32], uint8_t os[32], uint8_t oq[32], uint8_t oi[32]) {
     fe x = fe_frombytes(a), y = fe_frombytes(b);

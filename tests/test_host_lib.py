@@ -139,3 +139,12 @@ def test_register_radix_codec_random(hiplib, prim):
         o1, o2 = ctypes.create_string_buffer(32), ctypes.create_string_buffer(32)
         r1, r2 = L.rofl_dbg_host_decode_encode(bytes(raw), o1), L.rofl_dbg_host_fd_codec(bytes(raw), o2)
         assert r1 == r2 and (r1 != 0 or o1.raw == o2.raw == bytes(raw))
+
+
+@pytest.mark.timeout(120)
+def test_host_pool_runs_every_index_once():
+    """The per-round host work (Horner chains, transcripts) runs on a small thread pool; a worker that wakes late must not
+    swallow an index of the next job (that would leave the caller waiting forever).  200 000 tiny jobs back to back."""
+    import ctypes
+    from rofl_project_code_amd import api
+    assert api.lib().rofl_dbg_host_pool_stress(ctypes.c_uint(8), ctypes.c_uint(200000)) == 0

@@ -257,7 +257,10 @@ def main():
                          "algorithmic_bytes_per_launch": alg / max(kl, 1), "layout_bytes_per_launch": layout / max(kl, 1),
                          "note": "255-bit modular integer path: VALU-issue bound, HBM fraction is tiny by construction (SURVEY 8(d)); "
                                  "measured with HIP events on the lane's stream over the timed region, i.e. while the other clients' kernels share the GPU "
-                                 "(the interval includes waiting for CUs; single_client has the uncontended figure)"},
+                                 "(the interval includes waiting for CUs; single_client has the uncontended figure). traffic >> algorithmic bytes is not re-reading: in the "
+                                 "fixed-base launches every term is gathered once from each of 16 precomputed window slices (128-byte records, 16 different "
+                                 "points) -- HBM capacity and bandwidth spent to remove every doubling; with the gathers confined to L2 the kernel is only 12 % "
+                                 "faster (DESIGN.md section 5); the binding roofline is valu_roofline"},
             "end_to_end_algorithmic_GBps": value * (ALG_BYTES_CREATE + ALG_BYTES_VERIFY) / 1e9,
             "cold": {"gens_tables_build_ms": gens_build_ms, "first_client_create_plus_verify_ms": first_client_ms,
                      "note": "generator + fold + window tables for (n=32, m=8192), built once per process and cached in HBM; the reference recomputes its generators in every call"},

@@ -102,6 +102,8 @@ def main():
     ap.add_argument("--no-l2", action="store_true")
     ap.add_argument("--clients-per-step", type=int, default=0, help="clients in flight per GPU (0 = 6; fewer when there are less than ~2.5 host cores per client in flight: one uses ~1.3)")
     args = ap.parse_args()
+    import faulthandler
+    faulthandler.dump_traceback_later(1500, exit=True)      # never sit on a GPU box forever: dump the stacks and leave after 25 min
     CPS = args.clients_per_step if args.clients_per_step > 0 else max(1, min(6, int(avail_cores() / (2.5 * int(os.environ.get("LOCAL_WORLD_SIZE", "1"))))))
     os.environ.setdefault("ROFL_LANES", str(CPS))
 

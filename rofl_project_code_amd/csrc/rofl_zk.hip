@@ -306,6 +306,11 @@ struct Ctx {
     }
 };
 
+// The HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and reads the variable once, when it
+// initialises: lanes that share a queue serialise each other's kernels.  Ask for 8 when the library is loaded before the first HIP call
+// and the host has not chosen a value (a host that initialises HIP earlier sets the variable itself: INTEGRATION.md, section 6).
+__attribute__((constructor)) void rofl_hw_queues_default() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
 std::mutex g_ctx_mu;
 std::map<int, Ctx *> g_ctxs;
 int g_device = 0;

@@ -194,6 +194,13 @@ typedef struct {
     uint64_t msm_additions;   /* mixed point additions executed by k_msm_accumulate: terms x windows (7 field multiplications each) */
 } rofl_timing_t;
 int rofl_last_timing(rofl_timing_t *out);
+/* Per-kernel table of the last instrumented call of the calling thread: HIP-event time, launches and the ALGORITHMIC work of
+ * those launches -- field multiplications (7 per mixed point addition, 8 per doubling, 9 per extended addition) and the bytes
+ * a launch has to move at least once (32 B per scalar or point, 4 B per bucket-list entry). */
+enum { ROFL_TK_MSM_ACCUMULATE_FB = 0, ROFL_TK_MSM_ACCUMULATE_GEN = 1, ROFL_TK_MSM_SCATTER = 2, ROFL_TK_MSM_REDUCE = 3,
+       ROFL_TK_MSM_SMALL = 4, ROFL_TK_FOLD_TAB = 5, ROFL_TK_FOLD = 6, ROFL_TK_OTHER = 7, ROFL_TK_COUNT = 8 };
+typedef struct { double ms; uint64_t launches, fe_muls, bytes; } rofl_kernel_time_t;
+int rofl_last_kernel_times(rofl_kernel_time_t out[ROFL_TK_COUNT]);
 int rofl_set_timing(int enabled);
 /* GPU multi-scalar multiplication sum_i k_i * P_i through the production Pippenger pipeline (dalek
  * vartime_multiscalar_mul as used by upstream verify_multiple); test hook for skewed / extreme scalars. */

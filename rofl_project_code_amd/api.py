@@ -10,6 +10,7 @@ Errors that the reference reports as Err(..) (or panics) raise RoflError(code).
 """
 import ctypes
 import os
+import threading
 
 import numpy as np
 
@@ -147,20 +148,52 @@ def last_timing():
     return {f[0]: getattr(t, f[0]) for f in _Timing._fields_}
 
 
+class _KernelTime(ctypes.Structure):
+    _fields_ = [("ms", ctypes.c_double), ("launches", ctypes.c_uint64), ("fe_muls", ctypes.c_uint64), ("bytes", ctypes.c_uint64)]
+
+
+KERNEL_KINDS = ("k_msm_accumulate_fb", "k_msm_accumulate_gen", "k_msm_scatter_lds", "k_msm_reduce_level+fused", "k_msm_small",
+                "k_fold_gens_tab", "k_fold_gens", "other")
+
+
+def last_kernel_times():
+    """{kernel kind: {ms, launches, fe_muls, bytes}} of the calling thread's last instrumented call (rofl_last_kernel_times)."""
+    arr = (_KernelTime * len(KERNEL_KINDS))()
+    _check(lib().rofl_last_kernel_times(arr))
+    return {k: {"ms": arr[i].ms, "launches": arr[i].launches, "fe_muls": arr[i].fe_muls, "bytes": arr[i].bytes} for i, k in enumerate(KERNEL_KINDS)}
+
+
 def bench_femul(iters=2000):
     out = ctypes.c_double()
     _check(lib().rofl_bench_femul(ctypes.c_uint(iters), ctypes.byref(out)))
     return out.value
 
 
-class _FpConfig:
-    """The reference selects (N_BITS, frac) with cargo features (fp.rs); here it is module state."""
+class _FpDefault(threading.local):
+    """Per-thread default of the reference's cargo features (N_BITS, frac) (fp.rs:8-139).  Every function that depends on
+    them takes an explicit `fp=(fp_bits, fp_frac)` argument; `set_fp` only sets the calling thread's default for calls that
+    omit it (threads start at the reference's default feature set fp16 / frac7), so concurrent callers never share state."""
     fp_bits = 16
     fp_frac = 7
 
 
+_fp_default = _FpDefault()
+
+
 def set_fp(fp_bits, fp_frac):
-    _FpConfig.fp_bits, _FpConfig.fp_frac = int(fp_bits), int(fp_frac)
+    """Default (fp_bits, fp_frac) of the CALLING THREAD for calls without an explicit fp= argument."""
+    _fp_default.fp_bits, _fp_default.fp_frac = int(fp_bits), int(fp_frac)
+
+
+def get_fp():
+    return _fp_default.fp_bits, _fp_default.fp_frac
+
+
+def _fp(fp):
+    if fp is None:
+        return _fp_default.fp_bits, _fp_default.fp_frac
+    b, f = fp
+    return int(b), int(f)
 
 
 class range_proof_vec:
@@ -169,14 +202,14 @@ class range_proof_vec:
         return lib().rofl_next_pow2(_sz(v))
 
     @staticmethod
-    def clip_f32_to_range_vec(values, prove_range):
+    def clip_f32_to_range_vec(values, prove_range, fp=None):
         v = np.ascontiguousarray(values, dtype=np.float32)
         out = np.empty_like(v)
-        _check(lib().rofl_clip_f32(_ptr(v), _sz(v.size), _sz(prove_range), _FpConfig.fp_bits, _FpConfig.fp_frac, _ptr(out)))
+        _check(lib().rofl_clip_f32(_ptr(v), _sz(v.size), _sz(prove_range), *_fp(fp), _ptr(out)))
         return out
 
     @staticmethod
-    def create_rangeproof(values, blindings, prove_range, n_partition, nonce=None):
+    def create_rangeproof(values, blindings, prove_range, n_partition, nonce=None, fp=None):
         """-> (proofs uint8[n_proofs, proof_len], commitments uint8[d, 32]).  `values` (f32[d]) and `blindings` (u8[d,32]) may be
         numpy arrays or torch tensors on the library's GPU (no host round trip on the way in)."""
         if _is_dev(values) and _is_dev(blindings):
@@ -193,13 +226,13 @@ class range_proof_vec:
         commits = np.zeros((max(d, 1), 32), dtype=np.uint8)
         plen_o, npr_o = _sz(), _sz()
         _check(lib().rofl_create_rangeproof(vp, _sz(d), bp, _sz(db), _sz(prove_range),
-                                            _sz(n_partition), _FpConfig.fp_bits, _FpConfig.fp_frac, ctypes.byref(ns),
+                                            _sz(n_partition), *_fp(fp), ctypes.byref(ns),
                                             _ptr(proofs), ctypes.byref(plen_o), ctypes.byref(npr_o), _ptr(commits)))
         assert plen_o.value == plen and npr_o.value == npr
         return proofs, commits[:d]
 
     @staticmethod
-    def verify_rangeproof(proofs, commits, prove_range, verifier_seed=None):
+    def verify_rangeproof(proofs, commits, prove_range, verifier_seed=None, fp=None):
         p = np.ascontiguousarray(proofs, dtype=np.uint8)
         if _is_dev(commits):
             cptr, dc = _dev_arg(commits, 1, 32)
@@ -209,26 +242,49 @@ class range_proof_vec:
         seed = bytes(verifier_seed) if verifier_seed is not None else os.urandom(32)
         ok = ctypes.c_int()
         _check(lib().rofl_verify_rangeproof(_ptr(p), _sz(p.shape[1]), _sz(p.shape[0]), cptr, _sz(dc),
-                                            _sz(prove_range), _FpConfig.fp_bits, _FpConfig.fp_frac, seed, ctypes.byref(ok)))
+                                            _sz(prove_range), *_fp(fp), seed, ctypes.byref(ok)))
         return bool(ok.value)
 
     @staticmethod
-    def verify_rangeproof_batch(proofs_list, commits_list, prove_range, verifier_seed=None):
+    def verify_rangeproof_batch(proofs_list, commits_list, prove_range, verifier_seed=None, fp=None):
+        """One verdict per client (server.rs:656-687 verifies one client per pool task).  The C entry point takes ONE
+        (n_proofs, proof_len, d) for the whole batch and reads that many bytes from every client's pointers, and all three are
+        attacker-chosen on the wire: clients whose shapes differ from the majority shape are verified on their own (a malformed
+        set counts as not verified), never handed to the batch call with somebody else's lengths."""
+        if len(proofs_list) != len(commits_list):
+            raise ValueError("one commitment vector per proof set")
         ps = [np.ascontiguousarray(p, dtype=np.uint8) for p in proofs_list]
         cs = [_u8(c) for c in commits_list]
         n = len(ps)
+        if n == 0:
+            return []
         seed = bytes(verifier_seed) if verifier_seed is not None else os.urandom(32)
-        pp = (ctypes.c_void_p * n)(*[p.ctypes.data for p in ps])
-        cp = (ctypes.c_void_p * n)(*[c.ctypes.data for c in cs])
-        ok = (ctypes.c_int * n)()
-        _check(lib().rofl_verify_rangeproof_batch(_sz(n), pp, _sz(ps[0].shape[1]), _sz(ps[0].shape[0]), cp, _sz(cs[0].shape[0]),
-                                                  _sz(prove_range), _FpConfig.fp_bits, _FpConfig.fp_frac, seed, ok))
-        return [bool(x) for x in ok]
+        shapes = [(p.shape if p.ndim == 2 else None, c.shape if c.ndim == 2 and c.shape[1:] == (32,) else None) for p, c in zip(ps, cs)]
+        valid = [sh for sh in shapes if sh[0] is not None and sh[1] is not None and sh[0][0] > 0 and sh[1][0] > 0]
+        res = [False] * n
+        if not valid:
+            return res
+        major = max(set(valid), key=valid.count)
+        idx = [i for i, sh in enumerate(shapes) if sh == major]
+        for i, sh in enumerate(shapes):
+            if sh != major and sh in valid:          # a different but well-formed shape: its own call
+                try:
+                    res[i] = range_proof_vec.verify_rangeproof(ps[i], cs[i], prove_range, verifier_seed=seed, fp=fp)
+                except RoflError:
+                    res[i] = False
+        pp = (ctypes.c_void_p * len(idx))(*[ps[i].ctypes.data for i in idx])
+        cp = (ctypes.c_void_p * len(idx))(*[cs[i].ctypes.data for i in idx])
+        ok = (ctypes.c_int * len(idx))()
+        _check(lib().rofl_verify_rangeproof_batch(_sz(len(idx)), pp, _sz(major[0][1]), _sz(major[0][0]), cp, _sz(major[1][0]),
+                                                  _sz(prove_range), *_fp(fp), seed, ok))
+        for k, i in enumerate(idx):
+            res[i] = bool(ok[k])
+        return res
 
 
 class l2_range_proof_vec:
     @staticmethod
-    def create_rangeproof_l2(values, blindings, prove_range, n_partition, nonce=None):
+    def create_rangeproof_l2(values, blindings, prove_range, n_partition, nonce=None, fp=None):
         v = np.ascontiguousarray(values, dtype=np.float32)
         b = _u8(blindings)
         nonce = nonce or Nonce.random()
@@ -237,18 +293,17 @@ class l2_range_proof_vec:
         commit = np.zeros(32, dtype=np.uint8)
         plen = _sz()
         _check(lib().rofl_create_rangeproof_l2(_ptr(v), _sz(v.size), _ptr(b), _sz(b.shape[0] if b.size else 0), _sz(prove_range),
-                                               _sz(n_partition), _FpConfig.fp_bits, _FpConfig.fp_frac, ctypes.byref(ns),
+                                               _sz(n_partition), *_fp(fp), ctypes.byref(ns),
                                                _ptr(proof), ctypes.byref(plen), _ptr(commit)))
         return proof[:plen.value].copy(), commit
 
     @staticmethod
-    def verify_rangeproof_l2(proof, commit, prove_range, verifier_seed=None):
+    def verify_rangeproof_l2(proof, commit, prove_range, verifier_seed=None, fp=None):
         p = np.ascontiguousarray(proof, dtype=np.uint8)
         c = np.ascontiguousarray(commit, dtype=np.uint8)
         seed = bytes(verifier_seed) if verifier_seed is not None else os.urandom(32)
         ok = ctypes.c_int()
-        _check(lib().rofl_verify_rangeproof_l2(_ptr(p), _sz(p.size), _ptr(c), _sz(prove_range), _FpConfig.fp_bits,
-                                               _FpConfig.fp_frac, seed, ctypes.byref(ok)))
+        _check(lib().rofl_verify_rangeproof_l2(_ptr(p), _sz(p.size), _ptr(c), _sz(prove_range), *_fp(fp), seed, ctypes.byref(ok)))
         return bool(ok.value)
 
 
@@ -256,7 +311,7 @@ class rand_proof_vec:
     """rand_proof_vec/mod.rs:14-118.  proofs uint8[d,128], ElGamal pairs uint8[d,64]."""
 
     @staticmethod
-    def create_randproof_vec(values, random_vec, nonce=None, existing=None):
+    def create_randproof_vec(values, random_vec, nonce=None, existing=None, fp=None):
         v = np.ascontiguousarray(values, dtype=np.float32)
         r = _u8(random_vec)
         nonce = nonce or Nonce.random()
@@ -266,7 +321,7 @@ class rand_proof_vec:
         pairs = np.zeros((max(d, 1), 64), dtype=np.uint8)
         ex = None if existing is None else _u8(existing)
         _check(lib().rofl_create_randproof_vec(_ptr(v), _sz(d), _ptr(r), _sz(r.shape[0] if r.size else 0), None if ex is None else _ptr(ex),
-                                               _FpConfig.fp_bits, _FpConfig.fp_frac, ctypes.byref(ns), _ptr(proofs), _ptr(pairs)))
+                                               *_fp(fp), ctypes.byref(ns), _ptr(proofs), _ptr(pairs)))
         return proofs[:d], pairs[:d]
 
     @staticmethod
@@ -288,7 +343,7 @@ class square_rand_proof_vec:
     """square_rand_proof_vec/mod.rs:18-159.  proofs uint8[d,192], commitments uint8[d,96] (L | R | c_sq)."""
 
     @staticmethod
-    def create_l2rangeproof_vec(values, random_vec, random_vec_2, nonce=None, existing=None):
+    def create_l2rangeproof_vec(values, random_vec, random_vec_2, nonce=None, existing=None, fp=None):
         v = np.ascontiguousarray(values, dtype=np.float32)
         r1, r2 = _u8(random_vec), _u8(random_vec_2)
         nonce = nonce or Nonce.random()
@@ -298,7 +353,7 @@ class square_rand_proof_vec:
         commits = np.zeros((max(d, 1), 96), dtype=np.uint8)
         ex = None if existing is None else _u8(existing)
         _check(lib().rofl_create_squarerandproof_vec(_ptr(v), _sz(d), _ptr(r1), _sz(r1.shape[0] if r1.size else 0), _ptr(r2),
-                                                     None if ex is None else _ptr(ex), _FpConfig.fp_bits, _FpConfig.fp_frac,
+                                                     None if ex is None else _ptr(ex), *_fp(fp),
                                                      ctypes.byref(ns), _ptr(proofs), _ptr(commits)))
         return proofs[:d], commits[:d]
 
@@ -321,7 +376,7 @@ class square_proof_vec:
     """square_proof_vec/mod.rs:18-159.  proofs uint8[d,160], commitments uint8[d,64] (c_l | c_sq)."""
 
     @staticmethod
-    def create_l2rangeproof_vec(values, random_vec, random_vec_2, nonce=None, existing=None):
+    def create_l2rangeproof_vec(values, random_vec, random_vec_2, nonce=None, existing=None, fp=None):
         v = np.ascontiguousarray(values, dtype=np.float32)
         r1, r2 = _u8(random_vec), _u8(random_vec_2)
         nonce = nonce or Nonce.random()
@@ -331,7 +386,7 @@ class square_proof_vec:
         commits = np.zeros((max(d, 1), 64), dtype=np.uint8)
         ex = None if existing is None else _u8(existing)
         _check(lib().rofl_create_squareproof_vec(_ptr(v), _sz(d), _ptr(r1), _sz(r1.shape[0] if r1.size else 0), _ptr(r2),
-                                                 None if ex is None else _ptr(ex), _FpConfig.fp_bits, _FpConfig.fp_frac,
+                                                 None if ex is None else _ptr(ex), *_fp(fp),
                                                  ctypes.byref(ns), _ptr(proofs), _ptr(commits)))
         return proofs[:d], commits[:d]
 
@@ -355,7 +410,7 @@ class compressed_rand_proof:
     proof uint8[128], ElGamal pairs uint8[d,64]."""
 
     @staticmethod
-    def helper_prove(values, r_vec, nonce=None, existing=None):
+    def helper_prove(values, r_vec, nonce=None, existing=None, fp=None):
         v = np.ascontiguousarray(values, dtype=np.float32)
         r = _u8(r_vec)
         nonce = nonce or Nonce.random()
@@ -365,7 +420,7 @@ class compressed_rand_proof:
         pairs = np.zeros((max(d, 1), 64), dtype=np.uint8)
         ex = None if existing is None else _u8(existing)
         _check(lib().rofl_create_compressed_randproof(_ptr(v), _sz(d), _ptr(r), _sz(r.shape[0] if r.size else 0), None if ex is None else _ptr(ex),
-                                                      _FpConfig.fp_bits, _FpConfig.fp_frac, ctypes.byref(ns), _ptr(proof), _ptr(pairs)))
+                                                      *_fp(fp), ctypes.byref(ns), _ptr(proof), _ptr(pairs)))
         return proof, pairs[:d]
 
     @staticmethod
@@ -478,9 +533,9 @@ class pedersen_ops:
         return out
 
     @staticmethod
-    def default_discrete_log_vec(points):
+    def default_discrete_log_vec(points, fp=None):
         """pedersen_ops.rs:27-35: BSGSTable::default() = 2^(BSGS_N_BITS/2 + PRECOMP_BIAS) entries (fp.rs)."""
-        fb = _FpConfig.fp_bits
+        fb = _fp(fp)[0]
         bits, bias = {8: (8, 3), 16: (16, 7), 32: (16, 7), 64: (16, 0)}[fb]
         return pedersen_ops.discrete_log_vec(points, 1 << (bits // 2 + bias), bits)
 
@@ -495,25 +550,25 @@ class pedersen_ops:
 
 class conversion32:
     @staticmethod
-    def f32_to_scalar_vec(values):
+    def f32_to_scalar_vec(values, fp=None):
         v = np.ascontiguousarray(values, dtype=np.float32)
         out = np.zeros((v.size, 32), dtype=np.uint8)
-        _check(lib().rofl_f32_to_scalar_vec(_ptr(v), _sz(v.size), _FpConfig.fp_bits, _FpConfig.fp_frac, _ptr(out)))
+        _check(lib().rofl_f32_to_scalar_vec(_ptr(v), _sz(v.size), *_fp(fp), _ptr(out)))
         return out
 
     @staticmethod
-    def scalar_to_f32_vec(scalars):
+    def scalar_to_f32_vec(scalars, fp=None):
         s = _u8(scalars)
         out = np.zeros(s.shape[0], dtype=np.float32)
-        _check(lib().rofl_scalar_to_f32_vec(_ptr(s), _sz(s.shape[0]), _FpConfig.fp_bits, _FpConfig.fp_frac, _ptr(out)))
+        _check(lib().rofl_scalar_to_f32_vec(_ptr(s), _sz(s.shape[0]), *_fp(fp), _ptr(out)))
         return out
 
     @staticmethod
-    def square(scalars):
+    def square(scalars, fp=None):
         """conversion32.rs:66-88 (element-wise over a vector of scalars); overflow -> RoflError 8 (the reference panics)."""
         a = _u8(scalars)
         out = np.zeros_like(a)
-        _check(lib().rofl_fp_square_vec(_ptr(a), _sz(a.shape[0]), _FpConfig.fp_bits, _FpConfig.fp_frac, _ptr(out)))
+        _check(lib().rofl_fp_square_vec(_ptr(a), _sz(a.shape[0]), *_fp(fp), _ptr(out)))
         return out
 
     @staticmethod
@@ -530,27 +585,27 @@ class conversion32:
         return conversion32.precompute_exponentiate(value, exp + 1)[exp]
 
     @staticmethod
-    def f32_to_fp_vec(values):
+    def f32_to_fp_vec(values, fp=None):
         v = np.ascontiguousarray(values, dtype=np.float32)
         out = np.zeros(v.size, dtype=np.uint64)
-        _check(lib().rofl_f32_to_fp_vec(_ptr(v), _sz(v.size), _FpConfig.fp_bits, _FpConfig.fp_frac, _ptr(out)))
+        _check(lib().rofl_f32_to_fp_vec(_ptr(v), _sz(v.size), *_fp(fp), _ptr(out)))
         return out
 
     @staticmethod
-    def uint_to_f32_vec(values):
+    def uint_to_f32_vec(values, fp=None):
         v = np.ascontiguousarray(values, dtype=np.uint64)
         out = np.zeros(v.size, dtype=np.float32)
-        _check(lib().rofl_uint_to_f32_vec(_ptr(v), _sz(v.size), _FpConfig.fp_bits, _FpConfig.fp_frac, _ptr(out)))
+        _check(lib().rofl_uint_to_f32_vec(_ptr(v), _sz(v.size), *_fp(fp), _ptr(out)))
         return out
 
     @staticmethod
-    def get_clip_bounds(prove_range):
+    def get_clip_bounds(prove_range, fp=None):
         mn, mx = ctypes.c_float(), ctypes.c_float()
-        _check(lib().rofl_get_clip_bounds(_sz(prove_range), _FpConfig.fp_bits, _FpConfig.fp_frac, ctypes.byref(mn), ctypes.byref(mx)))
+        _check(lib().rofl_get_clip_bounds(_sz(prove_range), *_fp(fp), ctypes.byref(mn), ctypes.byref(mx)))
         return mn.value, mx.value
 
     @staticmethod
-    def get_l2_clip_bounds(prove_range):
+    def get_l2_clip_bounds(prove_range, fp=None):
         out = ctypes.c_float()
-        _check(lib().rofl_get_l2_clip_bounds(_sz(prove_range), _FpConfig.fp_bits, _FpConfig.fp_frac, ctypes.byref(out)))
+        _check(lib().rofl_get_l2_clip_bounds(_sz(prove_range), *_fp(fp), ctypes.byref(out)))
         return out.value

@@ -11,6 +11,14 @@ namespace rofl {
 
 #define TPB 256
 
+// Kernel groups: the library is built from one translation unit per group (build.py compiles them in parallel) plus the host
+// translation unit, which only sees the prototypes (kernel_protos.hpp, generated from this file).  ROFL_KGROUP: 0 = every kernel
+// is defined here (single-TU builds), g > 0 = only group g, -1 = none.
+#ifndef ROFL_KGROUP
+#define ROFL_KGROUP 0
+#endif
+#define ROFL_KG(g) (ROFL_KGROUP == 0 || ROFL_KGROUP == (g))
+
 // ---------------------------------------------------------------- small helpers
 // A pointer read out of a descriptor in memory is "generic" to the compiler and its accesses become flat_*; every
 // such pointer here is device memory, and saying so turns them into global_* accesses.
@@ -102,6 +110,8 @@ __device__ __forceinline__ sc load_sc(const sc *p) {
     d[0] = s[0]; d[1] = s[1];
     return r;
 }
+// a scalar handed over the C ABI as raw bytes: reduced mod l if it is not canonical
+__device__ __forceinline__ sc load_sc_reduced(const sc *p) { sc r = load_sc(p); if (sc_geq_l(r.v)) r = sc_from_mont(sc_to_mont(r)); return r; }
 __device__ __forceinline__ void store_sc(sc *p, const sc &v) {
     uint4 *d = reinterpret_cast<uint4 *>(p);
     const uint4 *s = reinterpret_cast<const uint4 *>(&v);
@@ -157,6 +167,7 @@ struct ChunkParams {
 #define PT_E 128
 #define PT_L 3
 struct PowTabs { sc y[PT_L][PT_E], yinv[PT_L][PT_E], z[PT_L][PT_E], s[PT_L][PT_E]; };     // Montgomery form
+#if ROFL_KG(4)
 __global__ void __launch_bounds__(TPB) k_pow_tables(const ChunkParams *cp, PowTabs *pt, u32 lgN, int with_s) {
     u32 c = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
     u32 kind = t / (PT_L * PT_E), lvl = (t / PT_E) % PT_L, e = t % PT_E;
@@ -175,6 +186,7 @@ __global__ void __launch_bounds__(TPB) k_pow_tables(const ChunkParams *cp, PowTa
     sc *dst = kind == 0 ? &pt[c].y[lvl][e] : kind == 1 ? &pt[c].yinv[lvl][e] : kind == 2 ? &pt[c].z[lvl][e] : &pt[c].s[lvl][e];
     store_sc(dst, acc);
 }
+#endif
 // x^e from a chunk's table; index bits above 21 (N > 2^21) fall back to the squarings table
 __device__ __forceinline__ sc pt_pow(const sc (*tab)[PT_E], const sc *sq, u32 e) {
     sc acc = load_sc(&tab[0][e & (PT_E - 1)]);
@@ -189,6 +201,7 @@ __device__ __forceinline__ sc pt_pow(const sc (*tab)[PT_E], const sc *sq, u32 e)
 // ================================================================ K1: generators
 // bulletproofs GeneratorsChain: SHAKE256("GeneratorsChain" || label5), 64 B per generator.
 // One thread per (which, party): sequential XOF squeeze, n <= 64 generators.
+#if ROFL_KG(2)
 __global__ void __launch_bounds__(TPB) k_gens_xof(u32 n, u32 m, uint8_t *uni /* [2][m][n][64] */) {
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= 2 * m) return;
@@ -215,19 +228,23 @@ __global__ void __launch_bounds__(TPB) k_gens_xof(u32 n, u32 m, uint8_t *uni /* 
         out[i] = st[pos++];
     }
 }
+#endif
 // uniform bytes -> affine niels table [G(N) | H(N)]
+#if ROFL_KG(2)
 __global__ void __launch_bounds__(TPB) k_gens_map(u32 total, const uint8_t *uni, niels *tbl) {
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;
     ge p = ristretto_from_uniform(uni + (size_t)t * 64);
     store_niels(&tbl[t], ge_to_niels(p));
 }
+#endif
 
 // Fold tables (see k_fold_gens_tab): slice (q * E + e) = (2e + 1) * 2^(PB q) * P for the NP = 256 / PB pieces of a
 // scalar and the E = 2^(w-2) odd multiples of a width-w NAF; slice 0 is the plain generator table.
 // One thread per (generator, piece); the E conversions to affine share one inversion.
 struct FoldTabCfg { u32 pb, w, np, e; };
 #define FOLD_TAB_MAXE 16
+#if ROFL_KG(2)
 __global__ void __launch_bounds__(TPB) k_gens_tables(u32 total, FoldTabCfg cfg, niels *tbl, size_t stride) {
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     u32 g = t % total, q = t / total;
@@ -254,12 +271,14 @@ __global__ void __launch_bounds__(TPB) k_gens_tables(u32 total, FoldTabCfg cfg, 
         }
     }
 }
+#endif
 
 // ================================================================ nonces
 // mode 1: SHAKE256("rofl-zk/nonce/v1" || seed || u64le(idx)) ; mode 0: explicit 64-byte stream.
 // Reference draw order (bulletproofs party.rs): per party j: a_bl, s_bl, s_L[0..n), s_R[0..n);
 // then per party: t1_bl, t2_bl.
 struct NonceSeed { u64 w[4]; };
+#if ROFL_KG(4)
 __global__ void __launch_bounds__(TPB) k_nonce_expand(u32 n, u32 m, int mode, NonceSeed seed, const uint8_t *stream, u64 stream_scalars,
                                const ChunkParams *cp, sc *sL, sc *sR, sc *party /* [chunk][4][m] */, sc *S_canon /* [chunk][2N] */) {
     u32 c = blockIdx.y;
@@ -296,9 +315,11 @@ __global__ void __launch_bounds__(TPB) k_nonce_expand(u32 n, u32 m, int mode, No
         store_sc(&party[((size_t)c * 4 + 2 + (q & 1)) * m + j], v);
     }
 }
+#endif
 
 // ================================================================ K2: quantize + shift
 // conversion32.rs:11-18 f32_to_scalar, range_proof_vec/mod.rs:27-43.  status bits: 1 out-of-range, 2 NaN.
+#if ROFL_KG(4)
 __global__ void __launch_bounds__(TPB) k_quantize_shift(const float *vals, u32 d, u32 dpad, u32 prove_range, u32 fp_bits, u32 fp_frac,
                                  float clip_min, float clip_max, u64 *vshift, u32 *status) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -327,6 +348,7 @@ __global__ void __launch_bounds__(TPB) k_quantize_shift(const float *vals, u32 d
     } else lowbits = k + off;   // k, off < 2^63 for fp_bits <= 63; fp64 wraps like the u64 cast chain
     vshift[i] = lowbits & maxbits;
 }
+#endif
 
 // ================================================================ K3: Pedersen commit (fixed-base)
 // tables: radix-16 signed digits, tab[w][e] = (e+1) * 16^w * P, w < 64, e < 8  (affine niels)
@@ -344,23 +366,28 @@ __device__ __forceinline__ gd fixed_base_mul_acc(gd acc, const niels *tab, const
     return acc;
 }
 // V_j = v_j*B + r_j*Bb (compressed), and optionally C_j = V_j + shift (compressed)
+#if ROFL_KG(4)
 __global__ void __launch_bounds__(TPB) k_commit(u32 count, const u64 *v64, const sc *v256_canon, const sc *blind_canon /* may be null */,
                          const niels *tabB, const niels *tabBb, const niels *shift /* may be null */,
                          uint8_t *V_out /* may be null */, uint8_t *C_out /* may be null */, u32 c_count) {
     u32 j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= count) return;
     gd acc = gd_identity();
+    // scalars arrive from the C ABI as 32 raw bytes: anything >= l is reduced (a dalek Scalar is always < l; the windows below
+    // assume < 2^253)
     if (v64) { sc v = sc_from_u64(v64[j]); acc = fixed_base_mul_acc(acc, tabB, v, 16); }
-    else { sc v = load_sc(&v256_canon[j]); acc = fixed_base_mul_acc(acc, tabB, v, 64); }
-    if (blind_canon) { sc r = load_sc(&blind_canon[j]); acc = fixed_base_mul_acc(acc, tabBb, r, 64); }
+    else { sc v = load_sc_reduced(&v256_canon[j]); acc = fixed_base_mul_acc(acc, tabB, v, 64); }
+    if (blind_canon) { sc r = load_sc_reduced(&blind_canon[j]); acc = fixed_base_mul_acc(acc, tabBb, r, 64); }
     if (V_out) gd_ristretto_encode(V_out + (size_t)j * 32, acc);
     if (C_out && j < c_count) {
         gd cpt = shift ? gd_madd(acc, load_nd(shift), false) : acc;
         gd_ristretto_encode(C_out + (size_t)j * 32, cpt);
     }
 }
+#endif
 
 // ================================================================ K4: A = sum (bit ? G : -H)
+#if ROFL_KG(4)
 __global__ void __launch_bounds__(TPB) k_bitcommit(u32 n, u32 m, const u64 *vshift /* [chunk][m] */, const niels *tbl, ge *partial /* [chunk][m] */) {
     u32 c = blockIdx.y;
     u32 j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -375,8 +402,10 @@ __global__ void __launch_bounds__(TPB) k_bitcommit(u32 n, u32 m, const u64 *vshi
     }
     store_gd(&partial[(size_t)c * m + j], acc);
 }
+#endif
 
 // generic point reduction: in [prob][n] -> out [prob][gridDim.x]
+#if ROFL_KG(4)
 __global__ void __launch_bounds__(TPB) k_point_sum(const ge *in, u32 n, ge *out) {
     extern __shared__ __align__(16) unsigned char smem[];
     ge *lds = reinterpret_cast<ge *>(smem);
@@ -392,8 +421,10 @@ __global__ void __launch_bounds__(TPB) k_point_sum(const ge *in, u32 n, ge *out)
     }
     if (t == 0) store_ge(&out[(size_t)p * gridDim.x + blockIdx.x], lds[0]);
 }
+#endif
 
 // sum of compressed points (params.rs:220, 277: `enc_values.iter().map(|x| x.c_sq).sum()`): decode + grid-stride sum + LDS tree
+#if ROFL_KG(4)
 __global__ void __launch_bounds__(TPB) k_decode_sum(const uint8_t *in, u32 n, u32 stride, ge *out, u32 *status) {
     extern __shared__ __align__(16) unsigned char smem[];
     ge *lds = reinterpret_cast<ge *>(smem);
@@ -415,10 +446,12 @@ __global__ void __launch_bounds__(TPB) k_decode_sum(const uint8_t *in, u32 n, u3
     }
     if (t == 0) store_ge(&out[blockIdx.x], lds[0]);
 }
+#endif
 
 // ================================================================ party-level scalar sums
 // phase 0: sum a_bl, s_bl              -> out[chunk][blk][0..1]
 // phase 1: sum t1_bl, t2_bl, zz*z^j*vbl -> out[chunk][blk][0..2]
+#if ROFL_KG(4)
 __global__ void __launch_bounds__(TPB) k_party_sums(u32 m, int phase, const ChunkParams *cp, const PowTabs *pt, const sc *party, const sc *blind_canon /* [chunk][m] */, sc *out) {
     __shared__ sc lds[TPB * 3];
     u32 c = blockIdx.y;
@@ -441,6 +474,7 @@ __global__ void __launch_bounds__(TPB) k_party_sums(u32 m, int phase, const Chun
         for (int k = 0; k < 3; k++) store_sc(&out[((size_t)c * gridDim.x + blockIdx.x) * 3 + k], v[k]);
     }
 }
+#endif
 
 // ================================================================ K6: polynomial vectors
 // bulletproofs party.rs apply_challenge: l0 = aL - z, l1 = sL, r0 = y^k (aR + z) + z^(2+j) 2^i, r1 = y^k sR
@@ -458,6 +492,7 @@ __device__ __forceinline__ void slot_vectors(const ChunkParams &P, const PowTabs
     r1 = sc_montmul(yk, sR);
 }
 // t0,t1,t2 partial sums -> out[chunk][blk][3]
+#if ROFL_KG(4)
 __global__ void __launch_bounds__(TPB) k_poly_t(u32 n, u32 m, const ChunkParams *cp, const PowTabs *pt, const u64 *vshift, const sc *sL, const sc *sR,
                          const sc *two_pow, sc *out) {
     __shared__ sc lds[TPB * 3];
@@ -478,7 +513,9 @@ __global__ void __launch_bounds__(TPB) k_poly_t(u32 n, u32 m, const ChunkParams 
         for (int k = 0; k < 3; k++) store_sc(&out[((size_t)c * gridDim.x + blockIdx.x) * 3 + k], v[k]);
     }
 }
+#endif
 // a = l(x), b = r(x); also yinv^k table
+#if ROFL_KG(4)
 __global__ void __launch_bounds__(TPB) k_lr_vec(u32 n, u32 m, const ChunkParams *cp, const PowTabs *pt, const u64 *vshift, const sc *sL, const sc *sR,
                          const sc *two_pow, sc *a, sc *b, sc *yinvpow) {
     u32 c = blockIdx.y;
@@ -492,11 +529,13 @@ __global__ void __launch_bounds__(TPB) k_lr_vec(u32 n, u32 m, const ChunkParams 
     store_sc(&b[c * N + k], sc_add(r0, sc_montmul(r1, cp[c].x)));
     store_sc(&yinvpow[c * N + k], pt_pow(pt[c].yinv, cp[c].yinvpow2, k));
 }
+#endif
 
 // ================================================================ K7: inner-product argument
 // Lazily folded generators: the materialised arrays Gc/Hc have n_g entries; the logical vectors have
 // n_k = n_g >> r entries; true G[i] = sum_h s_G(h) Gc[h*n_k+i], true H[i] = sum_h s_H(h) y^-j Hc[j].
 // Writes canonical MSM scalars for L (SL) and R (SR) over [Gc | Hc].
+#if ROFL_KG(4)
 __global__ void __launch_bounds__(TPB) k_ipp_scalars(u32 n_g, u32 n_k, u32 r, const ChunkParams *cp, const sc *a, const sc *b, size_t ab_stride,
                               const sc *yinvpow, size_t y_stride, sc *SL, sc *SR, int merged) {
     u32 c = blockIdx.y;
@@ -535,7 +574,9 @@ __global__ void __launch_bounds__(TPB) k_ipp_scalars(u32 n_g, u32 n_k, u32 r, co
         store_sc(&sl[n_g + j], zero);
     }
 }
+#endif
 // c_L = <a_L, b_R>, c_R = <a_R, b_L>  -> out[chunk][blk][2]
+#if ROFL_KG(4)
 __global__ void __launch_bounds__(TPB) k_ipp_inner(u32 nh, const sc *a, const sc *b, size_t ab_stride, sc *out) {
     __shared__ sc lds[TPB * 2];
     u32 c = blockIdx.y;
@@ -551,7 +592,9 @@ __global__ void __launch_bounds__(TPB) k_ipp_inner(u32 nh, const sc *a, const sc
         store_sc(&out[((size_t)c * gridDim.x + blockIdx.x) * 2 + 1], v[1]);
     }
 }
+#endif
 // a_L = a_L u + u^-1 a_R ; b_L = b_L u^-1 + u b_R   (cp.u[0], cp.uinv[0] = this round's challenge)
+#if ROFL_KG(4)
 __global__ void __launch_bounds__(TPB) k_ipp_fold_ab(u32 nh, const ChunkParams *cp, sc *a, sc *b, size_t ab_stride) {
     u32 c = blockIdx.y;
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -561,6 +604,7 @@ __global__ void __launch_bounds__(TPB) k_ipp_fold_ab(u32 nh, const ChunkParams *
     store_sc(&ac[i], sc_add(sc_montmul(load_sc(&ac[i]), u), sc_montmul(load_sc(&ac[nh + i]), ui)));
     store_sc(&bc[i], sc_add(sc_montmul(load_sc(&bc[i]), ui), sc_montmul(load_sc(&bc[nh + i]), u)));
 }
+#endif
 
 // Materialise folded generators: dst[i] = sum_{h < nsrc} s_h * src[h*n_new + i], all outputs of a problem
 // share the scalars s_h (given as NAF digits, wave-uniform control flow => no divergence).
@@ -571,6 +615,7 @@ struct FoldProb { const niels *src; niels *dst; };
 // [seg.lo[k], seg.lo[k+1]) and finishes with seg.lo[k] plain doublings, so K threads share one output and the
 // launch has K times as many waves in flight (the chain is latency-bound at 2 waves/SIMD otherwise).
 struct FoldSeg { int lo[FOLD_MAXSEG + 1]; };
+#if ROFL_KG(2)
 __global__ void __launch_bounds__(256, 4) k_fold_gens(u32 n_new, u32 nsrc, FoldSeg seg, const FoldProb *probs, const int8_t *naf /* [prob][nsrc][256] */, int unit_first) {
     extern __shared__ __align__(16) unsigned char smem[];
     ge *lds = reinterpret_cast<ge *>(smem);
@@ -603,6 +648,7 @@ __global__ void __launch_bounds__(256, 4) k_fold_gens(u32 n_new, u32 nsrc, FoldS
         gstore_niels(&probs[q].dst[i], gd_to_niels(acc));
     }
 }
+#endif
 
 // First materialisation: the sources are the FIXED generators, for which get_gens precomputed
 //   tbl16[(q*4+e)*stride + g] = (2e+1) * 2^(64q) * G_g      (q < 4, e < 4; affine niels)
@@ -610,6 +656,7 @@ __global__ void __launch_bounds__(256, 4) k_fold_gens(u32 n_new, u32 nsrc, FoldS
 // ~51 instead of ~84 mixed additions per source.  HBM capacity (16 x 50 MB at N = 262144) traded for VALU work.
 #define FOLD_TAB_DIGITS 72
 struct FoldTabProb { u32 src_off; niels *dst; };
+#if ROFL_KG(2)
 __global__ void __launch_bounds__(256, 4) k_fold_gens_tab(u32 n_new, u32 nsrc, FoldSeg seg, FoldTabCfg cfg, const niels *tbl16, size_t stride,
                                                        const FoldTabProb *probs, const int8_t *dig /* [prob][nsrc][np][72] */, int unit_first) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -648,6 +695,7 @@ __global__ void __launch_bounds__(256, 4) k_fold_gens_tab(u32 n_new, u32 nsrc, F
         gstore_niels(&probs[q].dst[i], gd_to_niels(acc));
     }
 }
+#endif
 
 // ================================================================ K5: Pippenger MSM
 // Booth-recoded signed c-bit digit of window w: in [-2^(c-1), 2^(c-1)]
@@ -663,6 +711,7 @@ __device__ __forceinline__ void msm_window(const MsmWin &mw, u32 w, u32 &pos, u3
     else { pos = mw.wide * mw.c + (w - mw.wide) * (mw.c - 1); width = mw.c - 1; }
 }
 // window table for the fixed-base MSM: wtab[w][g] = 2^(pos_w) * gens[g] for the W windows of `mw` (affine niels)
+#if ROFL_KG(2)
 __global__ void __launch_bounds__(TPB) k_gens_wtab(u32 total, MsmWin mw, const niels *gens, ndm *wtab, size_t stride) {
     u32 g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= total) return;
@@ -677,6 +726,7 @@ __global__ void __launch_bounds__(TPB) k_gens_wtab(u32 total, MsmWin mw, const n
         store_ndm(&wtab[(size_t)w * stride + g], gd_to_niels(cur));
     }
 }
+#endif
 
 // Booth-recoded signed digit of the window [pos, pos + width): in [-2^(width-1), 2^(width-1)]
 __device__ __forceinline__ int msm_digit(const sc &k, u32 wpos, u32 c) {
@@ -729,6 +779,7 @@ __device__ __forceinline__ MsmItem msm_item(u32 n, const MsmWin &mw, const MsmMa
 // Counting sort of (term, window) pairs by bucket.  blockIdx.y = prob * W + window, so the blocks in flight at
 // any time hit one 4*B-byte histogram and one 4*n-byte output region: both stay resident in the XCD L2s
 // instead of spraying partial-line writes over the whole [prob][W][n] array.
+#if ROFL_KG(1)
 __global__ void __launch_bounds__(TPB) k_msm_count(u32 n, MsmWin mw, MsmMap mm, const MsmProb *probs, u32 *cnt /* [prob][W][B] */) {
     u32 B = 1u << (mw.c - 1);
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -738,8 +789,10 @@ __global__ void __launch_bounds__(TPB) k_msm_count(u32 n, MsmWin mw, MsmMap mm, 
     if (ad > B) { atomicAdd(&cnt[(size_t)it.pw * B + B - 1], 1u); ad -= B; }
     if (ad) atomicAdd(&cnt[(size_t)it.pw * B + ad - 1], 1u);
 }
+#endif
 // One block per (prob, window): exclusive scan of the histogram (off, cursor) and a bucket permutation sorted by
 // descending count (perm), so that the 64 lanes of an accumulate wave own buckets of (nearly) equal size.
+#if ROFL_KG(1)
 __global__ void __launch_bounds__(TPB) k_msm_scan(u32 B, const u32 *cnt, u32 *off, u32 *cursor, u32 *perm) {
     __shared__ u32 part[TPB];
     __shared__ u32 hist[256];
@@ -778,6 +831,8 @@ __global__ void __launch_bounds__(TPB) k_msm_scan(u32 B, const u32 *cnt, u32 *of
         perm[base + pos] = i;
     }
 }
+#endif
+#if ROFL_KG(1)
 __global__ void __launch_bounds__(TPB) k_msm_scatter(u32 n, MsmWin mw, MsmMap mm, const MsmProb *probs, u32 *cursor, u32 *sorted /* [prob][W][n] */) {
     u32 B = 1u << (mw.c - 1);
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -787,10 +842,12 @@ __global__ void __launch_bounds__(TPB) k_msm_scatter(u32 n, MsmWin mw, MsmMap mm
     if (ad > B) { u32 pos = atomicAdd(&cursor[(size_t)pw * B + B - 1], 1u); sorted[(size_t)pw * n * 2 + pos] = it.entry; ad -= B; }
     if (ad) { u32 pos = atomicAdd(&cursor[(size_t)pw * B + ad - 1], 1u); sorted[(size_t)pw * n * 2 + pos] = it.entry; }
 }
+#endif
 // Single-pass variant: every bucket owns `cap` slots (HBM capacity instead of a counting pass); cursor doubles as the
 // per-bucket count.  The (astronomically rare for hash-derived scalars) entries beyond `cap` go to an overflow list
 // that k_msm_overflow adds afterwards; if even that list overflows the host falls back to the two-pass path.
 struct MsmOvf { u32 bucket; u32 entry; };
+#if ROFL_KG(1)
 __global__ void __launch_bounds__(TPB) k_msm_scatter_slots(u32 n, MsmWin mw, MsmMap mm, const MsmProb *probs, u32 *cursor, u32 *slots /* [prob][W][B][cap] */,
                                                            u32 cap, u32 *ovf_count, MsmOvf *ovf, u32 ovf_max) {
     u32 B = 1u << (mw.c - 1);
@@ -807,6 +864,7 @@ __global__ void __launch_bounds__(TPB) k_msm_scatter_slots(u32 n, MsmWin mw, Msm
         else { u32 o = atomicAdd(ovf_count, 1u); if (o < ovf_max) { ovf[o].bucket = bi; ovf[o].entry = it.entry; } }
     }
 }
+#endif
 // Same slot layout, but without one memory-side atomic per item (random-address device atomics retire at ~20 G/s on
 // this chip and were the whole cost of the kernel above).  One 1024-thread block owns a tile of the terms of one
 // bucket array (fixed-base: the `wps` windows of one set; otherwise one window): it ranks its items in an LDS
@@ -822,6 +880,7 @@ __device__ __forceinline__ u32 msm_side_term(const MsmMap &mm, u32 side, u32 k) 
     if (bit) j |= mm.lr_nh;
     return hside * mm.lr_ng + j;
 }
+#if ROFL_KG(1)
 __global__ void __launch_bounds__(1024) k_msm_scatter_lds(u32 n_side, u32 tile_pts, MsmWin mw, MsmMap mm, const MsmProb *probs, u32 *cursor, u32 *slots,
                                                           u32 cap, u32 *ovf_count, MsmOvf *ovf, u32 ovf_max, u32 dbg) {
     extern __shared__ u32 lcnt[];
@@ -873,7 +932,9 @@ __global__ void __launch_bounds__(1024) k_msm_scatter_lds(u32 n_side, u32 tile_p
         }
     }
 }
+#endif
 // one 64-lane wave; lane l owns the overflow entries whose bucket index is l mod 64 (no two lanes share a bucket)
+#if ROFL_KG(1)
 __global__ void k_msm_overflow(u32 W, u32 B, u32 pstep, const MsmProb *probs, const u32 *ovf_count, const MsmOvf *ovf, u32 ovf_max, ge *buckets, int fb) {
     if (blockIdx.x) return;
     u32 cnt = *ovf_count; if (cnt > ovf_max) cnt = ovf_max;
@@ -886,9 +947,10 @@ __global__ void k_msm_overflow(u32 W, u32 B, u32 pstep, const MsmProb *probs, co
         store_gd(&buckets[bi], acc);
     }
 }
+#endif
 // one thread per bucket: sum its points.  buckets [prob][W][B] extended.
 // blockIdx.y = grid problem q owning W bucket arrays; its points are probs[q * pstep].pts (pstep = 2 for merged L/R pairs)
-template <bool FB> __global__ void __launch_bounds__(TPB) k_msm_accumulate(u32 n, u32 c, u32 W, u32 pstep, const MsmProb *probs, const u32 *cnt, const u32 *off,
+template <bool FB> __device__ __forceinline__ void msm_accumulate_body(u32 n, u32 c, u32 W, u32 pstep, const MsmProb *probs, const u32 *cnt, const u32 *off,
                                  const u32 *sorted, const u32 *perm, ge *buckets, u32 cap, u32 idx_mask) {
     u32 p = blockIdx.y, B = 1u << (c - 1);
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -910,6 +972,18 @@ template <bool FB> __global__ void __launch_bounds__(TPB) k_msm_accumulate(u32 n
     }
     store_gd(&buckets[bi], acc);
 }
+#if ROFL_KG(1)
+__global__ void __launch_bounds__(TPB) k_msm_accumulate_fb(u32 n, u32 c, u32 W, u32 pstep, const MsmProb *probs, const u32 *cnt, const u32 *off,
+                                 const u32 *sorted, const u32 *perm, ge *buckets, u32 cap, u32 idx_mask) {
+    msm_accumulate_body<true>(n, c, W, pstep, probs, cnt, off, sorted, perm, buckets, cap, idx_mask);
+}
+#endif
+#if ROFL_KG(1)
+__global__ void __launch_bounds__(TPB) k_msm_accumulate_gen(u32 n, u32 c, u32 W, u32 pstep, const MsmProb *probs, const u32 *cnt, const u32 *off,
+                                 const u32 *sorted, const u32 *perm, ge *buckets, u32 cap, u32 idx_mask) {
+    msm_accumulate_body<false>(n, c, W, pstep, probs, cnt, off, sorted, perm, buckets, cap, idx_mask);
+}
+#endif
 // Bucket reduction without doublings: sum_b (b+1) B_b = S + sum_l 2^l D_l, D_l = sum of buckets whose
 // index has bit l set.  One 8-ary tree level per launch:
 //   role 0 threads: 8 children of S_in -> S_out, and the three new bit-sums (11 adds)
@@ -972,12 +1046,14 @@ __device__ __forceinline__ void msm_reduce_item_split(u32 E, u32 nb, const ge *S
         store_gd(&C_out[(size_t)(nb + b) * E8 + g], acc);
     }
 }
+#if ROFL_KG(1)
 __global__ void __launch_bounds__(TPB) k_msm_reduce_level(u32 E, u32 nb, const ge *S_in, const ge *C_in, ge *S_out, ge *C_out) {
     u32 pw = blockIdx.y, E8 = E / 8;
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= E8 * (1 + nb)) return;       // throughput-bound here: 11 additions per 8-group beat the 16 of the split form
     msm_reduce_item(E, nb, S_in + (size_t)pw * E, C_in + (size_t)pw * nb * E, S_out + (size_t)pw * E8, C_out + (size_t)pw * (nb + 3) * E8, t);
 }
+#endif
 // All remaining levels (E <= 512) of one (prob, window) in a single block through LDS: one launch instead of three
 // or four latency-bound ones.  First level 8-ary (global -> LDS), the rest binary (one addition deep per level):
 // S'[g] = S[2g] + S[2g+1], new bit-sum = S[2g+1], carried bit-sums pairwise.  Output: S_fin [PW], C_fin [PW][nb_final].
@@ -1013,17 +1089,20 @@ __device__ __forceinline__ void msm_reduce_fused_body(u32 E, u32 nb, const ge *s
         si = so; ci = co; E = E2; nb += 1; sel ^= 1;
     }
 }
+#if ROFL_KG(1)
 __global__ void __launch_bounds__(512) k_msm_reduce_fused(u32 E, u32 nb, const ge *S_in, const ge *C_in, ge *S_fin, ge *C_fin, u32 nb_final) {
     extern __shared__ __align__(16) unsigned char smem[];
     u32 pw = blockIdx.x;
     msm_reduce_fused_body(E, nb, S_in + (size_t)pw * E, C_in + (size_t)pw * nb * E, S_fin + pw, C_fin + (size_t)pw * nb_final, smem);
 }
+#endif
 // A small MSM (the IPP tail: a few thousand terms per problem) in ONE launch instead of memset / scatter / scan / accumulate /
 // overflow / reduce: block = one (problem, window) bucket array (generic window layout, c <= 10).  The window's digits are
 // ranked into per-bucket lists in LDS (SMALL_CAP entries each), thread b sums bucket b's points in a uniform loop, the buckets
 // go to HBM and the same block runs the bucket reduction of k_msm_reduce_fused over them.  A list overflow (scalars built
 // to collide) raises *overflow and the host repeats the MSM through the general pipeline.
 #define MSM_SMALL_CAP 64      /* mean load <= 16 (n_side <= 8 B, narrow windows fill half of the buckets): P(overflow) ~ 1e-18 per bucket */
+#if ROFL_KG(1)
 __global__ void __launch_bounds__(512) k_msm_small(u32 n_side, MsmWin mw, MsmMap mm, const MsmProb *probs, ge *buckets, ge *S_fin, ge *C_fin,
                                                    u32 nb_final, u32 *overflow) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1063,11 +1142,13 @@ __global__ void __launch_bounds__(512) k_msm_small(u32 n_side, MsmWin mw, MsmMap
     __syncthreads();
     msm_reduce_fused_body(B, 0, buckets + (size_t)pw * B, nullptr, S_fin + pw, C_fin + (size_t)pw * nb_final, smem);
 }
+#endif
 
 // Finish an MSM on the device when a launch carries many problems (n_partition = 64: 128 L/R problems per IPP round, whose
 // 253-step Horner chains would otherwise queue on the host pool).  One block per problem, one thread per window: thread w
 // folds its window's bit-sums (S + sum_l 2^l D_l), shifts the result to the window position (pos_w doublings -- the chains
 // of the W windows run side by side, so the launch is as deep as ONE chain) and the block adds the W terms through LDS.
+#if ROFL_KG(1)
 __global__ void __launch_bounds__(64) k_msm_horner(MsmWin mw, const ge *S_fin, const ge *C_fin, u32 nb, ge *out) {
     __shared__ ge sh[64];
     u32 p = blockIdx.x, w = threadIdx.x;
@@ -1091,10 +1172,12 @@ __global__ void __launch_bounds__(64) k_msm_horner(MsmWin mw, const ge *S_fin, c
     }
     if (w == 0) out[p] = sh[0];
 }
+#endif
 
 // ================================================================ K8/K9: verification
 // decode compressed points into affine niels (+ validity); optional shift (adds `shift` before use)
 // and optional re-encode of the shifted point (verify_rangeproof: range_proof_vec/mod.rs:155-167).
+#if ROFL_KG(4)
 __global__ void __launch_bounds__(TPB) k_decode(u32 count, u32 valid_count, const uint8_t *in, const niels *shift, niels *out_niels,
                          uint8_t *out_enc, u32 *status) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1113,7 +1196,9 @@ __global__ void __launch_bounds__(TPB) k_decode(u32 count, u32 valid_count, cons
     if (out_enc) gd_ristretto_encode(out_enc + (size_t)i * 32, p);
     if (out_niels) store_niels(&out_niels[i], gd_to_niels(p));
 }
+#endif
 // out = a + b (compressed in/out): pedersen_ops.rs:56-59 add_rp_vec
+#if ROFL_KG(4)
 __global__ void __launch_bounds__(TPB) k_add_points(u32 count, const uint8_t *a, const uint8_t *b, uint8_t *out, u32 *status) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
@@ -1122,9 +1207,11 @@ __global__ void __launch_bounds__(TPB) k_add_points(u32 count, const uint8_t *a,
     if (!gd_ristretto_decode(q, b + (size_t)i * 32)) { atomicOr(status, 4u); q = gd_identity(); }
     gd_ristretto_encode(out + (size_t)i * 32, gd_add(p, q));
 }
+#endif
 // bulletproofs verify_multiple: g_k = -z - a s_k ; h_k = z + y^-k (zz z^j 2^i - b s_k^-1)  -> canonical [g | h]
 // One array of 2N scalars per batch of `group` consecutive proofs: sum_c rho_c * (g_c | h_c) -- the proofs of a batch
 // share the generators, so their G/H terms collapse into one MSM (rho_c is folded into rz, ra, rb, rzz by the host).
+#if ROFL_KG(4)
 __global__ void __launch_bounds__(TPB) k_verify_scalars(u32 n, u32 m, u32 lgN, u32 group, const ChunkParams *cp, const PowTabs *pt, const sc *two_pow, sc *out) {
     u32 gidx = blockIdx.y;
     size_t N = (size_t)n * m;
@@ -1153,12 +1240,15 @@ __global__ void __launch_bounds__(TPB) k_verify_scalars(u32 n, u32 m, u32 lgN, u
     store_sc(&o[k], sc_from_mont(gacc));
     store_sc(&o[N + k], sc_from_mont(hacc));
 }
+#endif
+#if ROFL_KG(4)
 __global__ void __launch_bounds__(TPB) k_vscalars(u32 m, const ChunkParams *cp, const PowTabs *pt, sc *out, size_t stride) {
     u32 c = blockIdx.y;
     u32 j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m) return;
     store_sc(&out[c * stride + j], sc_from_mont(sc_montmul(cp[c].c_zz, pt_pow(pt[c].z, cp[c].zpow2, j))));
 }
+#endif
 
 // ================================================================ K11: per-element Sigma-proofs
 // rand_proof (ElGamal pair + proof of knowledge of (m, r)) and square_rand_proof (adds c_sq = m^2 B + r2 Bb and the
@@ -1262,6 +1352,7 @@ __device__ inline sc sg_nonce(int mode, const NonceSeed &seed, const uint8_t *st
     } else { lo = sc_zero(); hi = sc_zero(); }
     return sc_from_wide(lo, hi);
 }
+#if ROFL_KG(3)
 __global__ void __launch_bounds__(64) k_sigma_prove(int kind, u32 d, const float *vals, u32 fp_bits, u32 fp_frac, const sc *r1c, const sc *r2c,
                                                     const uint8_t *existing, int mode, NonceSeed seed, const uint8_t *stream, u64 stream_scalars,
                                                     DMerlin init, const niels *tabB, const niels *tabBb, uint8_t *proofs, uint8_t *commits, u32 *status) {
@@ -1272,7 +1363,7 @@ __global__ void __launch_bounds__(64) k_sigma_prove(int kind, u32 d, const float
     float v = vals[i];
     if (v != v) { atomicOr(status, 2u); return; }
     sc m = sg_f32_to_sc(v, fp_bits, fp_frac);
-    sc r1 = load_sc(&r1c[i]), r2 = has_sq ? load_sc(&r2c[i]) : sc_zero();
+    sc r1 = load_sc_reduced(&r1c[i]), r2 = has_sq ? load_sc_reduced(&r2c[i]) : sc_zero();
     sc nc[3];
     for (u32 j = 0; j < nn; j++) nc[j] = sg_nonce(mode, seed, stream, stream_scalars, (u64)nn * i + j);   // m', r1' (, r2')
     uint8_t *cm = commits + (size_t)clen * i, *pf = proofs + (size_t)plen * i;
@@ -1292,7 +1383,9 @@ __global__ void __launch_bounds__(64) k_sigma_prove(int kind, u32 d, const float
     sc_tobytes(z + 32, sc_add(nc[1], sc_mul_plain(r1, c)));
     if (has_sq) sc_tobytes(z + 64, sc_add(nc[2], sc_mul_plain(sc_sub(r2, sc_mul_plain(m, r1)), c)));
 }
+#endif
 
+#if ROFL_KG(3)
 __global__ void __launch_bounds__(64) k_sigma_verify(int kind, u32 d, const uint8_t *proofs, const uint8_t *commits, DMerlin init,
                                                      const niels *tabB, const niels *tabBb, u32 *fail_count, u32 *status) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1320,22 +1413,26 @@ __global__ void __launch_bounds__(64) k_sigma_verify(int kind, u32 d, const uint
     }
     if (!ok) atomicAdd(fail_count, 1u);
 }
+#endif
 
 // ---- compressed_rand_proof: the d ElGamal pairs, the challenge-power dot products, the verification scalars
+#if ROFL_KG(3)
 __global__ void __launch_bounds__(64) k_eg_pairs(u32 d, const float *vals, u32 fp_bits, u32 fp_frac, const sc *rc, const uint8_t *existing,
                                                  const niels *tabB, const niels *tabBb, uint8_t *pairs, u32 *status) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= d) return;
     float v = vals[i];
     if (v != v) { atomicOr(status, 2u); return; }
-    sc m = sg_f32_to_sc(v, fp_bits, fp_frac), r = load_sc(&rc[i]);
+    sc m = sg_f32_to_sc(v, fp_bits, fp_frac), r = load_sc_reduced(&rc[i]);
     uint8_t *o = pairs + (size_t)64 * i;
     if (existing) { gd L; if (!sg_decode(L, existing + (size_t)32 * i)) { atomicOr(status, 4u); return; } for (int q = 0; q < 32; q++) o[q] = existing[(size_t)32 * i + q]; }
     else sg_encode(o, gd_add(sg_fixed_mul(tabB, m), sg_fixed_mul(tabBb, r)));
     sg_encode(o + 32, sg_fixed_mul(tabB, r));
 }
+#endif
 // partial sums of m_i c^(i+1) and r_i c^(i+1)  -> out[blk][2] (Montgomery);  cpow2[b] = c^(2^b) (Montgomery)
 struct CPow { sc sq[MAX_LG]; };
+#if ROFL_KG(3)
 __global__ void __launch_bounds__(TPB) k_cpow_dot(u32 d, const float *vals, u32 fp_bits, u32 fp_frac, const sc *rc, CPow cp, sc *out) {
     __shared__ sc lds[TPB * 2];
     sc v[2] = {sc_zero(), sc_zero()};
@@ -1347,12 +1444,16 @@ __global__ void __launch_bounds__(TPB) k_cpow_dot(u32 d, const float *vals, u32 
     block_sum_sc<2>(v, lds);
     if (threadIdx.x == 0) { store_sc(&out[blockIdx.x * 2], v[0]); store_sc(&out[blockIdx.x * 2 + 1], v[1]); }
 }
+#endif
+#if ROFL_KG(3)
 __global__ void __launch_bounds__(TPB) k_cpow_scalars(u32 d, CPow cp, sc *out_canon) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= d) return;
     store_sc(&out_canon[i], sc_from_mont(sc_pow_tab(cp.sq, i + 1)));
 }
+#endif
 // de-interleave and decode d ElGamal pairs into two niels arrays
+#if ROFL_KG(3)
 __global__ void __launch_bounds__(TPB) k_decode_pairs(u32 d, const uint8_t *pairs, niels *Ls, niels *Rs, u32 *status) {
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= 2 * d) return;
@@ -1361,6 +1462,7 @@ __global__ void __launch_bounds__(TPB) k_decode_pairs(u32 d, const uint8_t *pair
     if (!gd_ristretto_decode(p, pairs + (size_t)64 * i + 32 * which)) { atomicOr(status, 4u); p = gd_identity(); }
     store_niels(which ? &Rs[i] : &Ls[i], gd_to_niels(p));
 }
+#endif
 
 // ================================================================ BSGS discrete log (bsgs32.rs:14-73, pedersen_ops.rs:27-53)
 // Baby-step table: keys[x] = compress(x B), x = 0..m, indexed by an open-addressing hash table (slot = first 8 key
@@ -1371,6 +1473,7 @@ __device__ __forceinline__ u64 bsgs_hash(const uint8_t *k) {
     for (int i = 0; i < 8; i++) h |= (u64)k[i] << (8 * i);
     return h * 0x9E3779B97F4A7C15ULL;
 }
+#if ROFL_KG(3)
 __global__ void __launch_bounds__(64) k_bsgs_build(u32 m, const niels *tabB, uint8_t *keys /* [(m+1)][32] */, u32 *slots, u32 slot_mask) {
     u32 x = blockIdx.x * blockDim.x + threadIdx.x;
     if (x > m) return;
@@ -1380,6 +1483,7 @@ __global__ void __launch_bounds__(64) k_bsgs_build(u32 m, const niels *tabB, uin
     u32 s = (u32)(bsgs_hash(key) >> 32) & slot_mask;
     for (;;) { if (atomicCAS(&slots[s], 0u, x + 1) == 0u) break; s = (s + 1) & slot_mask; }
 }
+#endif
 __device__ inline bool bsgs_find(const uint8_t *enc, const uint8_t *keys, const u32 *slots, u32 slot_mask, u32 &val) {
     u32 s = (u32)(bsgs_hash(enc) >> 32) & slot_mask;
     for (;;) {
@@ -1392,6 +1496,7 @@ __device__ inline bool bsgs_find(const uint8_t *enc, const uint8_t *keys, const 
         s = (s + 1) & slot_mask;
     }
 }
+#if ROFL_KG(3)
 __global__ void __launch_bounds__(64) k_bsgs_solve(u32 d, const uint8_t *points, u32 m, u32 bsgs_bits, u64 max_it, niels neg_mG, const uint8_t *keys,
                                                    const u32 *slots, u32 slot_mask, uint8_t *out, u32 *status) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1416,13 +1521,16 @@ __global__ void __launch_bounds__(64) k_bsgs_solve(u32 d, const uint8_t *points,
     if (found == 2) v = sc_neg(v);
     sc_tobytes(out + (size_t)32 * i, v);
 }
+#endif
 
 // ================================================================ micro-benchmark: field multiply rate
+#if ROFL_KG(4)
 __global__ void __launch_bounds__(TPB) k_bench_femul(u32 iters, const fe *in, fe *out) {
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     fd a = fd_unpack(in[t & 255]), b = fd_unpack(in[(t + 1) & 255]);
     for (u32 i = 0; i < iters; i++) { a = fd_mul(a, b); b = fd_sq(b); a = fd_mul(a, b); b = fd_mul(b, a); }
     out[t] = fd_pack(fd_add(a, b));
 }
+#endif
 
 }  // namespace rofl

@@ -100,11 +100,22 @@ def _concurrently(*thunks):
     return [f.result() for f in futs]
 
 
-def _sub_nonce(seed, tag):
-    """Independent nonce streams for the proofs of one container (the reference draws all of them from thread_rng)."""
+def witness_digest(*arrays):
+    """SHA3-256 over the raw bytes of the witness arrays (values, blindings, ...) of one container."""
+    h = hashlib.sha3_256()
+    for a in arrays:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.digest()
+
+
+def _sub_nonce(seed, tag, witness):
+    """Independent nonce streams for the proofs of one container (the reference draws all of them from thread_rng).
+    `nonce_seed` is for reproducible tests / benchmarks only; even then the effective seed is bound to the witness
+    (values and blindings), like bulletproofs' witness-rekeyed transcript RNG: re-using a seed with different inputs
+    never repeats a nonce (two proofs with equal nonces and different challenges would reveal the witness)."""
     if seed is None:
         return Nonce.random()
-    return Nonce.seeded(hashlib.sha3_256(b"rofl-zk/params/v1" + bytes(seed) + tag).digest())
+    return Nonce.seeded(hashlib.sha3_256(b"rofl-zk/params/v2" + bytes(seed) + tag + witness).digest())
 
 
 def _sub_seed(seed, tag):
@@ -113,8 +124,13 @@ def _sub_seed(seed, tag):
 
 def _num_checked(d, check_percentage):
     # (len as f32 * check_percentage).round() as usize  -- f32 arithmetic, round half away from zero (params.rs:192-193, 487)
-    x = np.float32(d) * np.float32(check_percentage)
-    return int(np.floor(np.float64(x) + 0.5)) if x >= 0 else 0
+    # The field comes off the wire: NaN / inf / values outside [0, 1] (the reference would slice out of bounds and panic) are
+    # a malformed message here.
+    cp = np.float32(check_percentage)
+    if not np.isfinite(cp) or cp < 0 or cp > 1:
+        raise RoflError(11, "check_percentage outside [0, 1]")
+    x = np.float32(d) * cp
+    return min(int(d), int(np.floor(np.float64(x) + 0.5)))
 
 
 class EncParamsRange:
@@ -128,32 +144,36 @@ class EncParamsRange:
         self.prove_range, self.check_percentage = int(prove_range), float(check_percentage)
 
     @classmethod
-    def encrypt(cls, plaintext_vec, blinding_vec, prove_range, n_partition, check_percentage, nonce_seed=None):
+    def encrypt(cls, plaintext_vec, blinding_vec, prove_range, n_partition, check_percentage, nonce_seed=None, fp=None):
+        fp = api._fp(fp)                       # resolved in the caller's thread; the proof calls below run on pool threads
         x = np.ascontiguousarray(plaintext_vec, dtype=np.float32)
         bl = api._u8(blinding_vec)
-        clipped = range_proof_vec.clip_f32_to_range_vec(x, prove_range)
+        wd = witness_digest(x, bl) if nonce_seed is not None else b""
+        clipped = range_proof_vec.clip_f32_to_range_vec(x, prove_range, fp=fp)
         if check_percentage >= 1.0:
-            enc_com = pedersen_ops.commit_vec(conversion32.f32_to_scalar_vec(clipped), bl)      # == the range proof's commitments
+            enc_com = pedersen_ops.commit_vec(conversion32.f32_to_scalar_vec(clipped, fp=fp), bl)      # == the range proof's commitments
             # NB the reference passes the un-clipped plaintext here (params.rs:499)
             (rp, rp_com), (proofs, pairs) = _concurrently(
-                lambda: range_proof_vec.create_rangeproof(clipped, bl, prove_range, n_partition, nonce=_sub_nonce(nonce_seed, b"range")),
-                lambda: rand_proof_vec.create_randproof_vec_existing(x, enc_com, bl, nonce=_sub_nonce(nonce_seed, b"rand")))
+                lambda: range_proof_vec.create_rangeproof(clipped, bl, prove_range, n_partition, nonce=_sub_nonce(nonce_seed, b"range", wd), fp=fp),
+                lambda: rand_proof_vec.create_randproof_vec_existing(x, enc_com, bl, nonce=_sub_nonce(nonce_seed, b"rand", wd), fp=fp))
             assert (rp_com == enc_com).all()
         else:
             k = _num_checked(x.size, check_percentage)
             (rp, _), (proofs, pairs) = _concurrently(
-                lambda: range_proof_vec.create_rangeproof(clipped[:k], bl[:k], prove_range, n_partition, nonce=_sub_nonce(nonce_seed, b"range")),
-                lambda: rand_proof_vec.create_randproof_vec(x, bl, nonce=_sub_nonce(nonce_seed, b"rand")))
+                lambda: range_proof_vec.create_rangeproof(clipped[:k], bl[:k], prove_range, n_partition, nonce=_sub_nonce(nonce_seed, b"range", wd), fp=fp),
+                lambda: rand_proof_vec.create_randproof_vec(x, bl, nonce=_sub_nonce(nonce_seed, b"rand", wd), fp=fp))
         return cls(pairs, proofs, rp, prove_range, check_percentage)
 
-    def verify(self, verifier_seed=None):
-        """EncModelParams::verify, EncRange arm (params.rs:185-203): any Err counts as false."""
+    def verify(self, verifier_seed=None, fp=None):
+        """EncModelParams::verify, EncRange arm (params.rs:185-203): any Err counts as false (and so does anything else a
+        crafted message can provoke while it is parsed)."""
+        fp = api._fp(fp)
         try:
             k = _num_checked(self.enc_values.shape[0], self.check_percentage)
             ok, ok_range = _concurrently(
                 lambda: rand_proof_vec.verify_randproof_vec(self.rand_proofs, self.enc_values),
-                lambda: range_proof_vec.verify_rangeproof(self.range_proofs, self.enc_values[:k, :32], self.prove_range, verifier_seed=_sub_seed(verifier_seed, b"v")))
-        except RoflError:
+                lambda: range_proof_vec.verify_rangeproof(self.range_proofs, self.enc_values[:k, :32], self.prove_range, verifier_seed=_sub_seed(verifier_seed, b"v"), fp=fp))
+        except (RoflError, ValueError, OverflowError, IndexError):
             return False
         return bool(ok and ok_range)
 
@@ -182,32 +202,35 @@ class EncParamsRangeCompressed(EncParamsRange):
         self.prove_range, self.check_percentage = int(prove_range), float(check_percentage)
 
     @classmethod
-    def encrypt(cls, plaintext_vec, blinding_vec, prove_range, n_partition, check_percentage, nonce_seed=None):
+    def encrypt(cls, plaintext_vec, blinding_vec, prove_range, n_partition, check_percentage, nonce_seed=None, fp=None):
+        fp = api._fp(fp)
         x = np.ascontiguousarray(plaintext_vec, dtype=np.float32)
         bl = api._u8(blinding_vec)
-        clipped = range_proof_vec.clip_f32_to_range_vec(x, prove_range)
+        wd = witness_digest(x, bl) if nonce_seed is not None else b""
+        clipped = range_proof_vec.clip_f32_to_range_vec(x, prove_range, fp=fp)
         if check_percentage >= 1.0:
-            enc_com = pedersen_ops.commit_vec(conversion32.f32_to_scalar_vec(clipped), bl)
+            enc_com = pedersen_ops.commit_vec(conversion32.f32_to_scalar_vec(clipped, fp=fp), bl)
             (rp, rp_com), (proof, pairs) = _concurrently(
-                lambda: range_proof_vec.create_rangeproof(clipped, bl, prove_range, n_partition, nonce=_sub_nonce(nonce_seed, b"range")),
-                lambda: compressed_rand_proof.helper_prove_existing(x, enc_com, bl, nonce=_sub_nonce(nonce_seed, b"rand")))
+                lambda: range_proof_vec.create_rangeproof(clipped, bl, prove_range, n_partition, nonce=_sub_nonce(nonce_seed, b"range", wd), fp=fp),
+                lambda: compressed_rand_proof.helper_prove_existing(x, enc_com, bl, nonce=_sub_nonce(nonce_seed, b"rand", wd), fp=fp))
             assert (rp_com == enc_com).all()
         else:
             k = _num_checked(x.size, check_percentage)
             (rp, _), (proof, pairs) = _concurrently(
-                lambda: range_proof_vec.create_rangeproof(clipped[:k], bl[:k], prove_range, n_partition, nonce=_sub_nonce(nonce_seed, b"range")),
-                lambda: compressed_rand_proof.helper_prove(x, bl, nonce=_sub_nonce(nonce_seed, b"rand")))
+                lambda: range_proof_vec.create_rangeproof(clipped[:k], bl[:k], prove_range, n_partition, nonce=_sub_nonce(nonce_seed, b"range", wd), fp=fp),
+                lambda: compressed_rand_proof.helper_prove(x, bl, nonce=_sub_nonce(nonce_seed, b"rand", wd), fp=fp))
         return cls(pairs, proof, rp, prove_range, check_percentage)
 
-    def verify(self, verifier_seed=None):
+    def verify(self, verifier_seed=None, fp=None):
+        fp = api._fp(fp)
         try:
             if self.rand_proof.size != 128:
                 return False
             k = _num_checked(self.enc_values.shape[0], self.check_percentage)
             ok, ok_range = _concurrently(
                 lambda: compressed_rand_proof.helper_verify(self.rand_proof, self.enc_values),
-                lambda: range_proof_vec.verify_rangeproof(self.range_proofs, self.enc_values[:k, :32], self.prove_range, verifier_seed=_sub_seed(verifier_seed, b"v")))
-        except RoflError:
+                lambda: range_proof_vec.verify_rangeproof(self.range_proofs, self.enc_values[:k, :32], self.prove_range, verifier_seed=_sub_seed(verifier_seed, b"v"), fp=fp))
+        except (RoflError, ValueError, OverflowError, IndexError):
             return False
         return bool(ok and ok_range)
 
@@ -235,32 +258,35 @@ class EncParamsL2:
         self.prove_range, self.l2_prove_range = int(prove_range), int(l2_prove_range)
 
     @classmethod
-    def encrypt(cls, plaintext_vec, blinding_vec, prove_range, n_partition, l2_range, nonce_seed=None, rand_scalars=None):
+    def encrypt(cls, plaintext_vec, blinding_vec, prove_range, n_partition, l2_range, nonce_seed=None, rand_scalars=None, fp=None):
+        fp = api._fp(fp)
         x = np.ascontiguousarray(plaintext_vec, dtype=np.float32)
         bl = api._u8(blinding_vec)
         r2 = pedersen_ops.rnd_scalar_vec(x.size) if rand_scalars is None else api._u8(rand_scalars)
-        clipped = range_proof_vec.clip_f32_to_range_vec(x, prove_range)
+        wd = witness_digest(x, bl, r2) if nonce_seed is not None else b""
+        clipped = range_proof_vec.clip_f32_to_range_vec(x, prove_range, fp=fp)
         # the square proofs take the range proof's commitments (params.rs:623-637); committing first (same points) lets the
         # three proofs run side by side
-        enc_com = pedersen_ops.commit_vec(conversion32.f32_to_scalar_vec(clipped), bl)
+        enc_com = pedersen_ops.commit_vec(conversion32.f32_to_scalar_vec(clipped, fp=fp), bl)
         (rp, rp_com), (sum_proof, _), (proofs, commits) = _concurrently(
-            lambda: range_proof_vec.create_rangeproof(clipped, bl, prove_range, n_partition, nonce=_sub_nonce(nonce_seed, b"range")),
-            lambda: l2_range_proof_vec.create_rangeproof_l2(clipped, r2, l2_range, n_partition, nonce=_sub_nonce(nonce_seed, b"l2")),
-            lambda: square_rand_proof_vec.create_l2rangeproof_vec_existing(clipped, enc_com, bl, r2, nonce=_sub_nonce(nonce_seed, b"sq")))
+            lambda: range_proof_vec.create_rangeproof(clipped, bl, prove_range, n_partition, nonce=_sub_nonce(nonce_seed, b"range", wd), fp=fp),
+            lambda: l2_range_proof_vec.create_rangeproof_l2(clipped, r2, l2_range, n_partition, nonce=_sub_nonce(nonce_seed, b"l2", wd), fp=fp),
+            lambda: square_rand_proof_vec.create_l2rangeproof_vec_existing(clipped, enc_com, bl, r2, nonce=_sub_nonce(nonce_seed, b"sq", wd), fp=fp))
         assert (rp_com == enc_com).all()
         return cls(commits, proofs, rp, sum_proof, prove_range, l2_range)
 
     def _sum_c_sq(self):
         return pedersen_ops.sum_rp_vec(self.enc_values[:, 64:96])
 
-    def verify(self, verifier_seed=None):
+    def verify(self, verifier_seed=None, fp=None):
         """EncModelParams::verify, EncL2 arm (params.rs:204-232)."""
+        fp = api._fp(fp)
         try:
             ok, ok_range, ok_sum = _concurrently(
                 lambda: square_rand_proof_vec.verify_l2rangeproof_vec(self.square_proofs, self.enc_values),
-                lambda: range_proof_vec.verify_rangeproof(self.range_proofs, self.enc_values[:, :32], self.prove_range, verifier_seed=_sub_seed(verifier_seed, b"v")),
-                lambda: l2_range_proof_vec.verify_rangeproof_l2(self.square_range_proof, self._sum_c_sq(), self.l2_prove_range, verifier_seed=_sub_seed(verifier_seed, b"s")))
-        except RoflError:
+                lambda: range_proof_vec.verify_rangeproof(self.range_proofs, self.enc_values[:, :32], self.prove_range, verifier_seed=_sub_seed(verifier_seed, b"v"), fp=fp),
+                lambda: l2_range_proof_vec.verify_rangeproof_l2(self.square_range_proof, self._sum_c_sq(), self.l2_prove_range, verifier_seed=_sub_seed(verifier_seed, b"s"), fp=fp))
+        except (RoflError, ValueError, OverflowError, IndexError):
             return False
         return bool(ok and ok_range and ok_sum)
 
@@ -292,31 +318,34 @@ class EncParamsL2Compressed(EncParamsL2):
         self.prove_range, self.l2_prove_range = int(prove_range), int(l2_prove_range)
 
     @classmethod
-    def encrypt(cls, plaintext_vec, blinding_vec, prove_range, n_partition, l2_range, nonce_seed=None, rand_scalars=None):
+    def encrypt(cls, plaintext_vec, blinding_vec, prove_range, n_partition, l2_range, nonce_seed=None, rand_scalars=None, fp=None):
+        fp = api._fp(fp)
         x = np.ascontiguousarray(plaintext_vec, dtype=np.float32)
         bl = api._u8(blinding_vec)
         r2 = pedersen_ops.rnd_scalar_vec(x.size) if rand_scalars is None else api._u8(rand_scalars)
-        clipped = range_proof_vec.clip_f32_to_range_vec(x, prove_range)
-        enc_com = pedersen_ops.commit_vec(conversion32.f32_to_scalar_vec(clipped), bl)
+        wd = witness_digest(x, bl, r2) if nonce_seed is not None else b""
+        clipped = range_proof_vec.clip_f32_to_range_vec(x, prove_range, fp=fp)
+        enc_com = pedersen_ops.commit_vec(conversion32.f32_to_scalar_vec(clipped, fp=fp), bl)
         (rp, rp_com), (sum_proof, _), (rand_proof, pairs) = _concurrently(
-            lambda: range_proof_vec.create_rangeproof(clipped, bl, prove_range, n_partition, nonce=_sub_nonce(nonce_seed, b"range")),
-            lambda: l2_range_proof_vec.create_rangeproof_l2(clipped, r2, l2_range, n_partition, nonce=_sub_nonce(nonce_seed, b"l2")),
-            lambda: compressed_rand_proof.helper_prove_existing(clipped, enc_com, bl, nonce=_sub_nonce(nonce_seed, b"rand")))
+            lambda: range_proof_vec.create_rangeproof(clipped, bl, prove_range, n_partition, nonce=_sub_nonce(nonce_seed, b"range", wd), fp=fp),
+            lambda: l2_range_proof_vec.create_rangeproof_l2(clipped, r2, l2_range, n_partition, nonce=_sub_nonce(nonce_seed, b"l2", wd), fp=fp),
+            lambda: compressed_rand_proof.helper_prove_existing(clipped, enc_com, bl, nonce=_sub_nonce(nonce_seed, b"rand", wd), fp=fp))
         assert (rp_com == enc_com).all()
-        sq_proofs, sq_commits = square_proof_vec.create_l2rangeproof_vec_existing(clipped, enc_com, bl, r2, nonce=_sub_nonce(nonce_seed, b"sq"))
+        sq_proofs, sq_commits = square_proof_vec.create_l2rangeproof_vec_existing(clipped, enc_com, bl, r2, nonce=_sub_nonce(nonce_seed, b"sq", wd), fp=fp)
         merged = np.concatenate([pairs, sq_commits[:, 32:64]], axis=1)        # merge(): c = ElGamal pair, c_sq from the square proof (params.rs:777-787)
         return cls(merged, sq_proofs, rand_proof, rp, sum_proof, prove_range, l2_range)
 
-    def verify(self, verifier_seed=None):
+    def verify(self, verifier_seed=None, fp=None):
         """EncModelParams::verify, EncL2Compressed arm (params.rs:255-289).  NB: as in the reference, the compressed
         randomness proof itself is not re-checked here (the arm only verifies the square proofs, the range proofs and the sum)."""
+        fp = api._fp(fp)
         try:
             sqc = np.concatenate([self.enc_values[:, :32], self.enc_values[:, 64:96]], axis=1)      # SquareProofCommitments { c_l: c.L, c_sq }
             ok, ok_range, ok_sum = _concurrently(
                 lambda: square_proof_vec.verify_l2rangeproof_vec(self.square_proofs, sqc),
-                lambda: range_proof_vec.verify_rangeproof(self.range_proofs, self.enc_values[:, :32], self.prove_range, verifier_seed=_sub_seed(verifier_seed, b"v")),
-                lambda: l2_range_proof_vec.verify_rangeproof_l2(self.square_range_proof, self._sum_c_sq(), self.l2_prove_range, verifier_seed=_sub_seed(verifier_seed, b"s")))
-        except RoflError:
+                lambda: range_proof_vec.verify_rangeproof(self.range_proofs, self.enc_values[:, :32], self.prove_range, verifier_seed=_sub_seed(verifier_seed, b"v"), fp=fp),
+                lambda: l2_range_proof_vec.verify_rangeproof_l2(self.square_range_proof, self._sum_c_sq(), self.l2_prove_range, verifier_seed=_sub_seed(verifier_seed, b"s"), fp=fp))
+        except (RoflError, ValueError, OverflowError, IndexError):
             return False
         return bool(ok and ok_range and ok_sum)
 
@@ -350,10 +379,11 @@ class EncModelParamsAccumulator:
         self.acc[:n] = summed.reshape(-1, 64)
         return True
 
-    def extract(self, table_size=None, bsgs_bits=16):
+    def extract(self, table_size=None, bsgs_bits=16, fp=None):
         """None when some R component is not the identity (the blindings did not cancel), else the f32 aggregate."""
+        fp = api._fp(fp)
         if np.any(self.acc[:, 32:64]):
             return None
         pts = np.ascontiguousarray(self.acc[:, :32])
-        sc = pedersen_ops.default_discrete_log_vec(pts) if table_size is None else pedersen_ops.discrete_log_vec(pts, table_size, bsgs_bits)
-        return conversion32.scalar_to_f32_vec(sc)
+        sc = pedersen_ops.default_discrete_log_vec(pts, fp=fp) if table_size is None else pedersen_ops.discrete_log_vec(pts, table_size, bsgs_bits)
+        return conversion32.scalar_to_f32_vec(sc, fp=fp)

@@ -1,0 +1,91 @@
+"""The N > 1 path with the HIP PRODUCT: two ranks on the one GPU of the test box (gloo collectives,
+ROFL_BENCH_SAME_DEVICE hook), clients sharded round-robin (server.rs:656-687), every rank proves its clients on the GPU,
+proof bytes + commitments are all-gathered and each rank verifies -- on the GPU -- what the OTHER rank produced.
+Also: bench.py --gpus 2 starts its own two ranks and reports n_gpus = 2."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    import orc
+    import rofl_project_code_amd as R
+    from rofl_project_code_amd import dist as rd
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    R.set_device(0)                              # both ranks share GPU 0 on the one-GPU test box
+    fp = (16, 7)
+    n_clients, d, nb, P = 5, 300, 8, 4
+    plen = R.lib().rofl_rangeproof_size(nb, d, P)
+    mine = rd.shard_clients(n_clients, rank, world)
+    inputs = {}
+    for c in range(n_clients):
+        rng = np.random.default_rng(1000 * c)
+        inputs[c] = (rng.uniform(-0.9, 0.9, d).astype(np.float32), orc.rand_scalars(rng, d))
+    slots = (n_clients + world - 1) // world
+    buf_p = np.zeros((slots, P, plen), np.uint8); buf_c = np.zeros((slots, d, 32), np.uint8)
+    ok_local = True
+    for s, c in enumerate(mine):
+        pr, cm = R.range_proof_vec.create_rangeproof(inputs[c][0], inputs[c][1], nb, P, nonce=R.Nonce.seeded(bytes([c]) * 32), fp=fp)
+        buf_p[s], buf_c[s] = pr, cm
+        ok_local &= R.range_proof_vec.verify_rangeproof(pr, cm, nb, fp=fp)
+    all_p = rd.gather_bytes(buf_p, "cpu"); all_c = rd.gather_bytes(buf_c, "cpu")
+    assert len(all_p) == world
+    checked = 0
+    for r in range(world):
+        if r == rank:
+            continue
+        pp = all_p[r].reshape(slots, P, plen); cc = all_c[r].reshape(slots, d, 32)
+        theirs = rd.shard_clients(n_clients, r, world)
+        oks = R.range_proof_vec.verify_rangeproof_batch([pp[s] for s in range(len(theirs))], [cc[s] for s in range(len(theirs))], nb, fp=fp)
+        assert oks == [True] * len(theirs)
+        for s, c in enumerate(theirs):          # and they are the proofs the oracle makes from the same inputs
+            rc, opr, ocm = orc.create_rangeproof(inputs[c][0], inputs[c][1], nb, P, 16, 7, seed=bytes([c]) * 32)
+            assert rc == 0 and (opr == pp[s]).all() and (ocm == cc[s]).all()
+            checked += 1
+        bad = pp[0].copy(); bad[1, 40] ^= 1
+        assert R.range_proof_vec.verify_rangeproof(bad, cc[0], nb, fp=fp) is False
+    assert checked == n_clients - len(mine)
+    assert rd.all_verified(ok_local, "cpu") is True
+    assert rd.all_verified(rank != 1, "cpu") is False
+    dist.barrier(); dist.destroy_process_group()
+    q.put(rank)
+
+
+def test_two_ranks_hip_product_cross_verify():
+    from rofl_project_code_amd import build
+    build.build()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    assert sorted(q.get() for _ in range(2)) == [0, 1]
+
+
+def test_bench_gpus2_starts_two_ranks():
+    """bench.py --gpus 2 (no torchrun): the launcher starts two ranks; here both use GPU 0 and gloo collectives."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update({"ROFL_BENCH_BACKEND": "gloo", "ROFL_BENCH_SAME_DEVICE": "1"})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-extras"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["rccl_world_size"] == 2 and line["steps"] == 2
+    assert line["value"] > 0 and "cfg 2" in line["config"]["workload"]

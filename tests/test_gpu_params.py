@@ -23,8 +23,10 @@ def R():
     return R
 
 
-def _sub(seed, tag):
-    return hashlib.sha3_256(b"rofl-zk/params/v1" + seed + tag).digest()
+def _sub(seed, tag, *witness):
+    """params._sub_nonce restated: the seeded streams are bound to the witness arrays (values, blindings, ...)."""
+    wd = hashlib.sha3_256(b"".join(np.ascontiguousarray(a).tobytes() for a in witness)).digest()
+    return hashlib.sha3_256(b"rofl-zk/params/v2" + seed + tag + wd).digest()
 
 
 def _clip(vals, n):
@@ -49,10 +51,10 @@ def test_enc_params_range_vs_oracle(R, check):
     enc = R.EncParamsRange.encrypt(x, bl, n, P, check, nonce_seed=seed)
     clipped = _clip(x, n)
     k = d if check >= 1.0 else int(np.floor(np.float32(d) * np.float32(check) + 0.5))
-    rc, opr, ocm = orc.create_rangeproof(clipped[:k], bl[:k], n, P, FB, FF, seed=_sub(seed, b"range"))
+    rc, opr, ocm = orc.create_rangeproof(clipped[:k], bl[:k], n, P, FB, FF, seed=_sub(seed, b"range", x, bl))
     assert rc == 0 and (enc.range_proofs == opr).all()
     # rand proofs over the UN-clipped plaintext (params.rs:499), completing the range-proof commitments when everything is checked
-    rc, opf, opairs = orc.sigma_create(0, x, bl, None, FB, FF, seed=_sub(seed, b"rand"), existing=ocm if check >= 1.0 else None)
+    rc, opf, opairs = orc.sigma_create(0, x, bl, None, FB, FF, seed=_sub(seed, b"rand", x, bl), existing=ocm if check >= 1.0 else None)
     assert rc == 0 and (enc.rand_proofs == opf).all() and (enc.enc_values == opairs).all()
     wire = enc.serialize()
     back = R.EncParamsRange.deserialize(wire)
@@ -107,17 +109,17 @@ def test_enc_params_l2(R, compressed):
         seed = b"\x21" * 32
         enc = cls.encrypt(x, bl, n, P, l2n, nonce_seed=seed, rand_scalars=r2)
         # components vs the oracle, composed as params.rs:615-646 / 797-838
-        rc, opr, ocm = orc.create_rangeproof(x, bl, n, P, 32, 7, seed=_sub(seed, b"range"))
+        rc, opr, ocm = orc.create_rangeproof(x, bl, n, P, 32, 7, seed=_sub(seed, b"range", x, bl, r2))
         assert rc == 0 and (enc.range_proofs == opr).all()
-        rc, ol2, ol2c = orc.create_rangeproof_l2(x, r2, l2n, P, 32, 7, seed=_sub(seed, b"l2"))
+        rc, ol2, ol2c = orc.create_rangeproof_l2(x, r2, l2n, P, 32, 7, seed=_sub(seed, b"l2", x, bl, r2))
         assert rc == 0 and (enc.square_range_proof == ol2.reshape(-1)).all()
         if compressed:
-            rc, osq, osqc = orc.sigma_create(2, x, bl, r2, 32, 7, seed=_sub(seed, b"sq"), existing=ocm)
-            rc2, ocp, opairs = orc.compressed_create(x, bl, 32, 7, seed=_sub(seed, b"rand"), existing=ocm)
+            rc, osq, osqc = orc.sigma_create(2, x, bl, r2, 32, 7, seed=_sub(seed, b"sq", x, bl, r2), existing=ocm)
+            rc2, ocp, opairs = orc.compressed_create(x, bl, 32, 7, seed=_sub(seed, b"rand", x, bl, r2), existing=ocm)
             assert rc == 0 and rc2 == 0 and (enc.square_proofs == osq).all() and (enc.rand_proof == ocp).all()
             assert (enc.enc_values[:, :64] == opairs).all() and (enc.enc_values[:, 64:] == osqc[:, 32:]).all()
         else:
-            rc, osq, osqc = orc.sigma_create(1, x, bl, r2, 32, 7, seed=_sub(seed, b"sq"), existing=ocm)
+            rc, osq, osqc = orc.sigma_create(1, x, bl, r2, 32, 7, seed=_sub(seed, b"sq", x, bl, r2), existing=ocm)
             assert rc == 0 and (enc.square_proofs == osq).all() and (enc.enc_values == osqc).all()
         # sum of the square commitments is the commitment of the L2 proof (l2_range_proof_vec/mod.rs:539-561)
         assert (R.pedersen_ops.sum_rp_vec(enc.enc_values[:, 64:96]) == ol2c.reshape(-1)).all()

@@ -325,8 +325,8 @@ class rand_proof_vec:
         return proofs[:d], pairs[:d]
 
     @staticmethod
-    def create_randproof_vec_existing(values, existing, random_vec, nonce=None):
-        return rand_proof_vec.create_randproof_vec(values, random_vec, nonce=nonce, existing=existing)
+    def create_randproof_vec_existing(values, existing, random_vec, nonce=None, fp=None):
+        return rand_proof_vec.create_randproof_vec(values, random_vec, nonce=nonce, existing=existing, fp=fp)
 
     @staticmethod
     def verify_randproof_vec(proofs, pairs):
@@ -358,8 +358,8 @@ class square_rand_proof_vec:
         return proofs[:d], commits[:d]
 
     @staticmethod
-    def create_l2rangeproof_vec_existing(values, existing, random_vec, random_vec_2, nonce=None):
-        return square_rand_proof_vec.create_l2rangeproof_vec(values, random_vec, random_vec_2, nonce=nonce, existing=existing)
+    def create_l2rangeproof_vec_existing(values, existing, random_vec, random_vec_2, nonce=None, fp=None):
+        return square_rand_proof_vec.create_l2rangeproof_vec(values, random_vec, random_vec_2, nonce=nonce, existing=existing, fp=fp)
 
     @staticmethod
     def verify_l2rangeproof_vec(proofs, commits):
@@ -391,8 +391,8 @@ class square_proof_vec:
         return proofs[:d], commits[:d]
 
     @staticmethod
-    def create_l2rangeproof_vec_existing(values, existing, random_vec, random_vec_2, nonce=None):
-        return square_proof_vec.create_l2rangeproof_vec(values, random_vec, random_vec_2, nonce=nonce, existing=existing)
+    def create_l2rangeproof_vec_existing(values, existing, random_vec, random_vec_2, nonce=None, fp=None):
+        return square_proof_vec.create_l2rangeproof_vec(values, random_vec, random_vec_2, nonce=nonce, existing=existing, fp=fp)
 
     @staticmethod
     def verify_l2rangeproof_vec(proofs, commits):
@@ -424,8 +424,8 @@ class compressed_rand_proof:
         return proof, pairs[:d]
 
     @staticmethod
-    def helper_prove_existing(values, m_com, r_vec, nonce=None):
-        return compressed_rand_proof.helper_prove(values, r_vec, nonce=nonce, existing=m_com)
+    def helper_prove_existing(values, m_com, r_vec, nonce=None, fp=None):
+        return compressed_rand_proof.helper_prove(values, r_vec, nonce=nonce, existing=m_com, fp=fp)
 
     @staticmethod
     def helper_verify(proof, pairs):

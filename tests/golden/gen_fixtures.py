@@ -180,5 +180,67 @@ for kind, vals, fb, ff in ((0, [0.25, 1.25, -1.5], 16, 7), (1, [0.25, 1.25, -1.5
             assert cm[i, 64:].tobytes() == padd(smul_base(m * m % R.L), smul(r2i, Bb))
     proofs.append({"kind": "rand" if kind == 0 else "sqrand", "d": len(vals), "fp_bits": fb, "fp_frac": ff, "values": [float(x) for x in vals],
                    "r1": r1.tobytes().hex(), "r2": r2.tobytes().hex(), "seed": seed.hex(), "proofs": pr.tobytes().hex(), "commits": cm.tobytes().hex()})
+# ---- mode-0 fixtures: EXPLICIT nonce streams (64-byte wide scalars in the upstream draw order).  These are the ones a maintainer can
+# replay through bulletproofs' prove_multiple_with_rng / rofl_crypto's Sigma-proof parties (scripts/crosscheck_rust) and that the
+# libsodium implementation (tests/golden/sodium_bp.py) reproduces byte for byte.
+import sodium_bp as SB  # noqa: E402
+srng = np.random.default_rng(20261002)
+for (d, nb, P, fb, ff) in ((2, 8, 2, 16, 7), (3, 8, 4, 16, 7), (2, 32, 1, 32, 7), (3, 16, 2, 16, 7)):
+    mn, mx = orc.clip_bounds(nb, fb, ff)
+    vals = srng.uniform(max(mn, -100), min(mx, 100), size=d).astype(np.float32)
+    bl = orc.rand_scalars(srng, d)
+    dp = SB.next_pow2(d); m = dp // min(dp, P)
+    stream = srng.integers(0, 256, (dp // m) * m * (2 * nb + 4) * 64, dtype=np.uint8).tobytes()
+    rc, pr, cm = orc.create_rangeproof(vals, bl, nb, P, fb, ff, stream=stream)
+    assert rc == 0 and orc.verify_rangeproof(pr, cm, nb, fb, ff) == (0, True)
+    spr, scm = SB.create_rangeproof([float(v) for v in vals], [int.from_bytes(b.tobytes(), "little") for b in bl], nb, P, fb, ff, stream)
+    assert b"".join(spr) == pr.tobytes() and b"".join(scm) == cm.tobytes()          # oracle == libsodium implementation
+    proofs.append({"kind": "linf", "nonce": "stream", "d": d, "prove_range": nb, "n_partition": P, "fp_bits": fb, "fp_frac": ff,
+                   "values": [float(x) for x in vals], "blindings": bl.tobytes().hex(), "stream": stream.hex(),
+                   "proofs": pr.tobytes().hex(), "n_proofs": int(pr.shape[0]), "commits": cm.tobytes().hex()})
+for (vals, nb, fb, ff) in (([1.25, 0.5, 0.25], 16, 16, 7), ([3.5, -2.25], 32, 32, 7)):
+    vals = np.array(vals, dtype=np.float32)
+    bl = orc.rand_scalars(srng, len(vals))
+    stream = srng.integers(0, 256, (2 * nb + 4) * 64, dtype=np.uint8).tobytes()
+    rc, pr, cm = orc.create_rangeproof_l2(vals, bl, nb, 4, fb, ff, stream=stream)
+    assert rc == 0 and orc.verify_rangeproof_l2(pr, cm, nb, fb, ff) == (0, True)
+    # third implementation: the L2 proof is one (n, m = 1) proof over sum x^2 with blinding sum(blindings), label "L2RangeProof"
+    val = sum(SB.f32_to_scalar(float(v), fb, ff) ** 2 for v in vals) % R.L
+    spr, sV = SB.prove_single([val & ((1 << fb) - 1)], [sum(int.from_bytes(b.tobytes(), "little") for b in bl) % R.L], nb, SB.StreamRng(stream), label=b"L2RangeProof")
+    assert spr == pr.tobytes() and sV[0] == cm.tobytes()
+    proofs.append({"kind": "l2", "nonce": "stream", "d": len(vals), "prove_range": nb, "n_partition": 4, "fp_bits": fb, "fp_frac": ff,
+                   "values": [float(x) for x in vals], "blindings": bl.tobytes().hex(), "stream": stream.hex(),
+                   "proofs": pr.tobytes().hex(), "n_proofs": 1, "commits": cm.tobytes().hex()})
+for kind, vals, fb, ff in ((0, [0.25, -1.5], 16, 7), (1, [0.25, 1.25, -1.5], 16, 7)):
+    vals = np.array(vals, dtype=np.float32)
+    r1, r2 = orc.rand_scalars(srng, len(vals)), orc.rand_scalars(srng, len(vals))
+    nn = 3 if kind else 2
+    stream = srng.integers(0, 256, nn * len(vals) * 64, dtype=np.uint8).tobytes()
+    rc, pr, cm = orc.sigma_create(kind, vals, r1, r2 if kind else None, fb, ff, stream=stream)
+    assert rc == 0 and orc.sigma_verify(kind, pr, cm) == (0, True)
+    for i, v in enumerate(vals):
+        mi = SB.f32_to_scalar(float(v), fb, ff); r1i = int.from_bytes(r1[i].tobytes(), "little"); r2i = int.from_bytes(r2[i].tobytes(), "little")
+        rg = SB.StreamRng(stream[nn * 64 * i:nn * 64 * (i + 1)])
+        sp, sc_ = SB.create_squarerandproof(mi, r1i, r2i, rg) if kind else SB.create_randproof(mi, r1i, rg)
+        assert sp == pr[i].tobytes() and sc_ == cm[i].tobytes()
+    proofs.append({"kind": "rand" if kind == 0 else "sqrand", "nonce": "stream", "d": len(vals), "fp_bits": fb, "fp_frac": ff, "values": [float(x) for x in vals],
+                   "r1": r1.tobytes().hex(), "r2": r2.tobytes().hex(), "stream": stream.hex(), "proofs": pr.tobytes().hex(), "commits": cm.tobytes().hex()})
+# ---- f32 -> fixed ties: values exactly half-way between two grid points.  fixed 0.3.3's saturating_from_float is taken to round
+# half to EVEN (the reference pins only |error| <= 2^-(frac+1), conversion32.rs:196-214); a maintainer with the crate checks these
+# first (scripts/crosscheck_rust prints them): a different tie rule changes the commitment of every such value.
+ties = []
+for fb, ff in ((16, 7), (32, 7), (32, 12), (8, 3)):
+    for k in (0, 1, 2, 3, 4, 5, 126, 127):
+        v = np.float32((k + 0.5) / (1 << ff))
+        assert float(v) * (1 << ff) == k + 0.5                      # exactly representable: a true tie
+        for sign in (1, -1):
+            rc_buf = np.zeros(32, np.uint8)
+            assert orc.lib().orc_f32_to_scalar(ctypes.c_float(sign * float(v)), fb, ff, rc_buf.ctypes.data_as(ctypes.c_void_p)) == 0
+            want = k + (k & 1)                                        # half to even
+            got = int.from_bytes(rc_buf.tobytes(), "little")
+            assert got == (want if sign > 0 else (-want) % R.L)
+            ties.append({"fp_bits": fb, "fp_frac": ff, "v": sign * float(v), "bits_half_even": want, "bits_half_away": k + 1,
+                         "scalar": rc_buf.tobytes().hex(), "assumes": "half-to-even"})
+proofs.append({"kind": "tie_cases", "cases": ties})
 json.dump(proofs, open(os.path.join(HERE, "proofs.json"), "w"), indent=0)
 print("wrote primitives.json, proofs.json")

@@ -89,25 +89,32 @@ def test_explicit_nonce_stream_mode(R):
 
 
 def test_golden_fixtures(R, golden_proofs):
+    def nonce(g):
+        return R.Nonce.stream(H(g["stream"])) if g.get("nonce") == "stream" else R.Nonce.seeded(H(g["seed"]))
     for g in golden_proofs:
+        if g["kind"] == "tie_cases":
+            for c in g["cases"]:
+                got = R.conversion32.f32_to_scalar_vec(np.array([c["v"]], np.float32), fp=(c["fp_bits"], c["fp_frac"]))
+                assert got[0].tobytes().hex() == c["scalar"]
+            continue
         R.api.set_fp(g["fp_bits"], g["fp_frac"])
         if g["kind"] in ("rand", "sqrand"):
             r1 = np.frombuffer(H(g["r1"]), np.uint8).reshape(-1, 32); r2 = np.frombuffer(H(g["r2"]), np.uint8).reshape(-1, 32)
             if g["kind"] == "rand":
-                pr, cm = R.rand_proof_vec.create_randproof_vec(g["values"], r1, nonce=R.Nonce.seeded(H(g["seed"])))
+                pr, cm = R.rand_proof_vec.create_randproof_vec(g["values"], r1, nonce=nonce(g))
                 assert R.rand_proof_vec.verify_randproof_vec(pr, cm)
             else:
-                pr, cm = R.square_rand_proof_vec.create_l2rangeproof_vec(g["values"], r1, r2, nonce=R.Nonce.seeded(H(g["seed"])))
+                pr, cm = R.square_rand_proof_vec.create_l2rangeproof_vec(g["values"], r1, r2, nonce=nonce(g))
                 assert R.square_rand_proof_vec.verify_l2rangeproof_vec(pr, cm)
             assert pr.tobytes().hex() == g["proofs"] and cm.tobytes().hex() == g["commits"]
             continue
         bl = np.frombuffer(H(g["blindings"]), np.uint8).reshape(-1, 32)
         if g["kind"] == "linf":
-            pr, cm = R.range_proof_vec.create_rangeproof(g["values"], bl, g["prove_range"], g["n_partition"], nonce=R.Nonce.seeded(H(g["seed"])))
+            pr, cm = R.range_proof_vec.create_rangeproof(g["values"], bl, g["prove_range"], g["n_partition"], nonce=nonce(g))
             assert pr.tobytes().hex() == g["proofs"] and cm.tobytes().hex() == g["commits"]
             assert R.range_proof_vec.verify_rangeproof(pr, cm, g["prove_range"], verifier_seed=b"\x07" * 32)
         else:
-            pr, cm = R.l2_range_proof_vec.create_rangeproof_l2(g["values"], bl, g["prove_range"], g["n_partition"], nonce=R.Nonce.seeded(H(g["seed"])))
+            pr, cm = R.l2_range_proof_vec.create_rangeproof_l2(g["values"], bl, g["prove_range"], g["n_partition"], nonce=nonce(g))
             assert pr.tobytes().hex() == g["proofs"] and cm.tobytes().hex() == g["commits"]
             assert R.l2_range_proof_vec.verify_rangeproof_l2(pr, cm, g["prove_range"], verifier_seed=b"\x07" * 32)
 

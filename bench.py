@@ -234,7 +234,7 @@ def run_rank(args):
     if world > 1:
         dist.barrier()
     R.set_device(local_rank)
-    R.set_timing(True)
+    R.set_timing(os.environ.get("ROFL_BENCH_NOTIMING") != "1")      # HIP events around the kernels of the timed steps (per-kernel table)
     rpv = R.range_proof_vec
 
     total_steps = args.warmup + args.steps

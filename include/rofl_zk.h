@@ -71,6 +71,18 @@ int rofl_create_rangeproof(const float *values, size_t d, const uint8_t *blindin
                            size_t prove_range, size_t n_partition, unsigned fp_bits, unsigned fp_frac,
                            const rofl_nonce_t *nonce, uint8_t *proofs_out, size_t *proof_len_out,
                            size_t *n_proofs_out, uint8_t *commits_out /* d*32 */);
+/* Client-side batch: n_clients independent updates of one shape (d, prove_range, n_partition) proved as ONE launch sequence -- the
+ * counterpart of rofl_verify_rangeproof_batch for hosts that run many clients per process (rofl_service's client binary hosts its
+ * clients as tasks of one process, client.rs:265-266; the server hands one client per pool thread, server.rs:513-521, 656-687).
+ * values[i] / blindings32[i]: d floats / d scalars of client i (host or device memory); nonces[i]: its prover randomness;
+ * proofs_out[i] (n_proofs * proof_len bytes) and commits_out[i] (d * 32 bytes): its results; rc_out[i]: its own outcome
+ * (0, 2 ValueOutOfRangeError, 10 non-finite, 12 nonce stream too short) -- a client that fails is left out, the others are proved.
+ * The return value is non-zero only for errors of the whole call.  Each client's proof is bit-identical to what
+ * rofl_create_rangeproof returns for it. */
+int rofl_create_rangeproof_batch(size_t n_clients, const float *const *values, size_t d, const uint8_t *const *blindings32,
+                                 size_t prove_range, size_t n_partition, unsigned fp_bits, unsigned fp_frac,
+                                 const rofl_nonce_t *nonces /* [n_clients] */, uint8_t *const *proofs_out, size_t *proof_len_out,
+                                 size_t *n_proofs_out, uint8_t *const *commits_out, int *rc_out /* [n_clients] */);
 /* verify_rangeproof(&Vec<RangeProof>, &Vec<RistrettoPoint>, prove_range) :149-191.
  * verifier_seed[32] derives the batching scalar c that upstream draws from thread_rng. */
 int rofl_verify_rangeproof(const uint8_t *proofs, size_t proof_len, size_t n_proofs,
@@ -212,6 +224,7 @@ int rofl_bench_femul(unsigned iters, double *fe_mul_per_sec_out);
 int rofl_dbg_host_pool_stress(unsigned threads, unsigned jobs);   /* host thread pool: every index of every job runs exactly once */
 int rofl_dbg_host_fe_mul(const uint8_t a[32], const uint8_t b[32], uint8_t out[32]);
 int rofl_dbg_host_fe_ops(const uint8_t a[32], const uint8_t b[32], uint8_t out_add[32], uint8_t out_sub[32], uint8_t out_sq[32], uint8_t out_inv[32]);
+int rofl_dbg_host_sc_invert(const uint8_t a[32], uint8_t out_ref[32], uint8_t out_fast[32], double *ns_ref, double *ns_fast);
 int rofl_dbg_host_sc_mul(const uint8_t a[32], const uint8_t b[32], uint8_t out[32]);
 int rofl_dbg_host_sc_wide(const uint8_t in[64], uint8_t out[32]);
 int rofl_dbg_host_from_uniform(const uint8_t in[64], uint8_t out[32]);

@@ -232,6 +232,45 @@ class range_proof_vec:
         return proofs, commits[:d]
 
     @staticmethod
+    def create_rangeproof_batch(values_list, blindings_list, prove_range, n_partition, nonces=None, fp=None):
+        """rofl_create_rangeproof_batch: the updates of several clients (same d) proved as one launch sequence.
+        -> list of (proofs, commitments) per client; a client whose own inputs are rejected (out of range, NaN, short nonce
+        stream) gets a RoflError instance in its place, the others are proved.  Bit-identical to per-client create_rangeproof."""
+        nc = len(values_list)
+        if nc == 0:
+            return []
+        keep, vptrs, bptrs = [], [], []
+        d = None
+        for v, b in zip(values_list, blindings_list):
+            if _is_dev(v) and _is_dev(b):
+                (vp, dv), (bp, db) = _dev_arg(v, 4), _dev_arg(b, 1, 32)
+                vptrs.append(vp.value); bptrs.append(bp.value)
+            else:
+                va = np.ascontiguousarray(v, dtype=np.float32); ba = _u8(b)
+                keep += [va, ba]
+                dv, db = va.size, (ba.shape[0] if ba.size else 0)
+                vptrs.append(va.ctypes.data); bptrs.append(ba.ctypes.data)
+            if dv != db:
+                raise RoflError(1, "WrongNumBlindingFactors")
+            if d is not None and dv != d:
+                raise ValueError("the clients of a batch have the same number of values")
+            d = dv
+        nonces = nonces or [Nonce.random() for _ in range(nc)]
+        ns = (_NonceStruct * nc)(*[n._struct() for n in nonces])
+        npr = lib().rofl_rangeproof_chunks(_sz(max(d, 1)), _sz(max(n_partition, 1)))
+        plen = lib().rofl_rangeproof_size(_sz(max(prove_range, 1)), _sz(max(d, 1)), _sz(max(n_partition, 1)))
+        proofs = [np.zeros((max(npr, 1), max(plen, 32)), dtype=np.uint8) for _ in range(nc)]
+        commits = [np.zeros((max(d, 1), 32), dtype=np.uint8) for _ in range(nc)]
+        vp = (ctypes.c_void_p * nc)(*vptrs); bp = (ctypes.c_void_p * nc)(*bptrs)
+        pp = (ctypes.c_void_p * nc)(*[p.ctypes.data for p in proofs]); cp = (ctypes.c_void_p * nc)(*[c.ctypes.data for c in commits])
+        rcs = (ctypes.c_int * nc)()
+        plen_o, npr_o = _sz(), _sz()
+        _check(lib().rofl_create_rangeproof_batch(_sz(nc), vp, _sz(d), bp, _sz(prove_range), _sz(n_partition), *_fp(fp), ns, pp,
+                                                  ctypes.byref(plen_o), ctypes.byref(npr_o), cp, rcs))
+        assert plen_o.value == plen and npr_o.value == npr
+        return [(proofs[i], commits[i][:d]) if rcs[i] == 0 else RoflError(rcs[i], "client %d of the batch" % i) for i in range(nc)]
+
+    @staticmethod
     def verify_rangeproof(proofs, commits, prove_range, verifier_seed=None, fp=None):
         p = np.ascontiguousarray(proofs, dtype=np.uint8)
         if _is_dev(commits):

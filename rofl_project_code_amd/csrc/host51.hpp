@@ -160,5 +160,48 @@ inline niels5 to_niels5(const ge5 &p) {
 }
 inline niels to_niels32(const ge5 &p) { niels5 q = to_niels5(p); niels r; r.ypx = to_fe(q.ypx); r.ymx = to_fe(q.ymx); r.t2d = to_fe(q.t2d); return r; }
 
+
+// ---------------------------------------------------------------- scalars mod l on the host: 4 x 64-bit Montgomery (R = 2^256, the same
+// Montgomery form as the 8 x 32-bit device code, so values pass between the two unchanged).  The per-round challenge inversion
+// u -> u^-1 of the inner-product argument sits on the critical path of every host hop: 253 squarings + 63 multiplications here
+// (~6 us) instead of ~380 of the portable 8 x 32 routine (~60 us).
+struct s4 { u64 v[4]; };
+inline const u64 *l64() { static const u64 L[4] = {0x5812631a5cf5d3edULL, 0x14def9dea2f79cd6ULL, 0ULL, 0x1000000000000000ULL}; return L; }
+inline u64 linv64() { static const u64 k = [] { u64 inv = 1; for (int i = 0; i < 7; i++) inv *= 2 - l64()[0] * inv; return (u64)0 - inv; }(); return k; }
+inline s4 s4_from(const sc &a) { s4 r; for (int i = 0; i < 4; i++) r.v[i] = (u64)a.v[2 * i] | ((u64)a.v[2 * i + 1] << 32); return r; }
+inline sc s4_to(const s4 &a) { sc r; for (int i = 0; i < 4; i++) { r.v[2 * i] = (u32)a.v[i]; r.v[2 * i + 1] = (u32)(a.v[i] >> 32); } return r; }
+inline s4 s4_montmul(const s4 &a, const s4 &b) {
+    const u64 *L = l64(); const u64 li = linv64();
+    u64 t[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; i++) {
+        u64 carry = 0;
+        for (int j = 0; j < 4; j++) { u128 x = (u128)a.v[j] * b.v[i] + t[j] + carry; t[j] = (u64)x; carry = (u64)(x >> 64); }
+        u128 y = (u128)t[4] + carry; t[4] = (u64)y; t[5] = (u64)(y >> 64);
+        u64 m = t[0] * li;
+        u128 x = (u128)m * L[0] + t[0]; carry = (u64)(x >> 64);
+        for (int j = 1; j < 4; j++) { x = (u128)m * L[j] + t[j] + carry; t[j - 1] = (u64)x; carry = (u64)(x >> 64); }
+        y = (u128)t[4] + carry; t[3] = (u64)y; t[4] = t[5] + (u64)(y >> 64); t[5] = 0;
+    }
+    bool ge_l = t[4] != 0;
+    if (!ge_l) { ge_l = true; for (int i = 3; i >= 0; i--) { if (t[i] > L[i]) break; if (t[i] < L[i]) { ge_l = false; break; } } }
+    s4 r;
+    if (ge_l) { u64 bw = 0; for (int i = 0; i < 4; i++) { u128 d = (u128)t[i] - L[i] - bw; r.v[i] = (u64)d; bw = (u64)(d >> 64) & 1; } }
+    else for (int i = 0; i < 4; i++) r.v[i] = t[i];
+    return r;
+}
+// a^(l-2), Montgomery in / out; fixed 4-bit windows over the public exponent (variable time in the exponent only)
+inline sc sc_invert_mont_fast(const sc &a_mont) {
+    static const u64 E[4] = {0x5812631a5cf5d3edULL - 2, 0x14def9dea2f79cd6ULL, 0ULL, 0x1000000000000000ULL};
+    s4 tab[16]; tab[1] = s4_from(a_mont); tab[0] = s4_from(sc_one_mont());
+    for (int i = 2; i < 16; i++) tab[i] = s4_montmul(tab[i - 1], tab[1]);
+    s4 acc = tab[(E[3] >> 60) & 15];
+    for (int nib = 62; nib >= 0; nib--) {
+        acc = s4_montmul(acc, acc); acc = s4_montmul(acc, acc); acc = s4_montmul(acc, acc); acc = s4_montmul(acc, acc);
+        u32 d = (u32)(E[nib >> 4] >> ((nib & 15) * 4)) & 15;
+        if (d) acc = s4_montmul(acc, tab[d]);
+    }
+    return s4_to(acc);
+}
+
 }  // namespace h51
 }  // namespace rofl

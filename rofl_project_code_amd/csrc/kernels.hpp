@@ -146,6 +146,7 @@ __device__ __forceinline__ void block_sum_sc(sc (&v)[NS], sc *lds /* TPB*NS */) 
 
 // ---------------------------------------------------------------- per-chunk parameter block
 #define MAX_LG 32
+struct NonceSeed { u64 w[4]; };
 struct ChunkParams {
     sc y, z, zz, x, yinv;            // Montgomery
     sc ypow2[MAX_LG];                // y^(2^b)
@@ -157,7 +158,11 @@ struct ChunkParams {
     sc a_fin, b_fin;                 // verify: ipp a, b
     sc c_zz;                         // verify: rho * c * z^2
     sc rz, ra, rb, rzz;              // verify: rho * z, rho * a, rho * b, rho * z^2 (rho = weight of this proof in its batch)
-    u64 nonce_base;                  // index of this chunk's first nonce
+    u64 nonce_base;                  // index of this chunk's first nonce in its client's nonce space
+    NonceSeed nonce_seed;            // mode 1: the client's seed
+    const uint8_t *nonce_stream;     // mode 0: the client's explicit stream (device memory), nonce_stream_scalars wide scalars
+    u64 nonce_stream_scalars;
+    int nonce_mode;
 };
 
 // Radix-128 power tables of a chunk's challenges: x^k = T[0][k & 127] * T[1][(k >> 7) & 127] * T[2][(k >> 14) & 127] -- two
@@ -277,20 +282,22 @@ __global__ void __launch_bounds__(TPB) k_gens_tables(u32 total, FoldTabCfg cfg, 
 // mode 1: SHAKE256("rofl-zk/nonce/v1" || seed || u64le(idx)) ; mode 0: explicit 64-byte stream.
 // Reference draw order (bulletproofs party.rs): per party j: a_bl, s_bl, s_L[0..n), s_R[0..n);
 // then per party: t1_bl, t2_bl.
-struct NonceSeed { u64 w[4]; };
 #if ROFL_KG(4)
-__global__ void __launch_bounds__(TPB) k_nonce_expand(u32 n, u32 m, int mode, NonceSeed seed, const uint8_t *stream, u64 stream_scalars,
-                               const ChunkParams *cp, sc *sL, sc *sR, sc *party /* [chunk][4][m] */, sc *S_canon /* [chunk][2N] */) {
+__global__ void __launch_bounds__(TPB) k_nonce_expand(u32 n, u32 m, const ChunkParams *cp, sc *sL, sc *sR, sc *party /* [chunk][4][m] */, sc *S_canon /* [chunk][2N] */) {
     u32 c = blockIdx.y;
     u64 per = (u64)m * (2 * n + 4);
     u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= per) return;
+    // every chunk names its own nonce source: the chunks of a launch may belong to different clients (batched create)
     u64 idx = cp[c].nonce_base + k;
+    const int mode = cp[c].nonce_mode;
+    const uint8_t *stream = cp[c].nonce_stream; const u64 stream_scalars = cp[c].nonce_stream_scalars;
     sc lo, hi;
     if (mode == 1) {
         const u64 dom[2] = {0x2f6b7a2d6c666f72ULL, 0x31762f65636e6f6eULL};  // "rofl-zk/" "nonce/v1"
         u64 st[25];
-        shake256_seeded_block(st, dom, seed.w, idx);
+        u64 sw[4] = {cp[c].nonce_seed.w[0], cp[c].nonce_seed.w[1], cp[c].nonce_seed.w[2], cp[c].nonce_seed.w[3]};
+        shake256_seeded_block(st, dom, sw, idx);
 #pragma unroll
         for (int i = 0; i < 4; i++) { lo.v[2 * i] = (u32)st[i]; lo.v[2 * i + 1] = (u32)(st[i] >> 32); hi.v[2 * i] = (u32)st[4 + i]; hi.v[2 * i + 1] = (u32)(st[4 + i] >> 32); }
     } else {
@@ -324,6 +331,7 @@ __global__ void __launch_bounds__(TPB) k_quantize_shift(const float *vals, u32 d
                                  float clip_min, float clip_max, u64 *vshift, u32 *status) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= dpad) return;
+    vals += (size_t)blockIdx.y * d; vshift += (size_t)blockIdx.y * dpad; status += blockIdx.y;      // one client per grid row
     if (i >= d) { vshift[i] = 0; return; }
     float v = vals[i];
     u32 st = 0;
@@ -369,7 +377,8 @@ __device__ __forceinline__ gd fixed_base_mul_acc(gd acc, const niels *tab, const
 #if ROFL_KG(4)
 __global__ void __launch_bounds__(TPB) k_commit(u32 count, const u64 *v64, const sc *v256_canon, const sc *blind_canon /* may be null */,
                          const niels *tabB, const niels *tabBb, const niels *shift /* may be null */,
-                         uint8_t *V_out /* may be null */, uint8_t *C_out /* may be null */, u32 c_count) {
+                         uint8_t *V_out /* may be null */, uint8_t *C_out /* may be null */, u32 c_count, u32 c_period) {
+    // C_out is written for the first c_count entries of every c_period (batched create: c_period = padded length of one client)
     u32 j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= count) return;
     gd acc = gd_identity();
@@ -379,7 +388,7 @@ __global__ void __launch_bounds__(TPB) k_commit(u32 count, const u64 *v64, const
     else { sc v = load_sc_reduced(&v256_canon[j]); acc = fixed_base_mul_acc(acc, tabB, v, 64); }
     if (blind_canon) { sc r = load_sc_reduced(&blind_canon[j]); acc = fixed_base_mul_acc(acc, tabBb, r, 64); }
     if (V_out) gd_ristretto_encode(V_out + (size_t)j * 32, acc);
-    if (C_out && j < c_count) {
+    if (C_out && (j % c_period) < c_count) {
         gd cpt = shift ? gd_madd(acc, load_nd(shift), false) : acc;
         gd_ristretto_encode(C_out + (size_t)j * 32, cpt);
     }

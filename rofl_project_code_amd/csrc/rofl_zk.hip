@@ -43,7 +43,7 @@ double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::
 sc h_mont(const sc &canon) { return sc_to_mont(canon); }
 sc h_canon(const sc &mont) { return sc_from_mont(mont); }
 sc h_mul(const sc &a, const sc &b) { return sc_mul_plain(a, b); }          // canonical * canonical
-sc h_inv(const sc &canon) { return h_canon(sc_invert_mont(h_mont(canon))); }
+sc h_inv(const sc &canon) { return h_canon(h51::sc_invert_mont_fast(h_mont(canon))); }
 bool sc_is_canonical_bytes(const uint8_t *b) { sc s = sc_frombytes(b); return !sc_geq_l(s.v); }
 
 // width-2 NAF (digits -1,0,1) of a canonical scalar; returns index of the highest non-zero digit (-1 if zero)
@@ -258,7 +258,7 @@ struct Ctx {
     DevBuf cp, sL, sR, party, Scanon, vshift, blind, Vbytes, Cbytes, status, partial, partial2, scpart, a, b, yinv,
         SL, SR, msm_cnt, msm_off, msm_cur, msm_perm, msm_sorted, msm_ovf, msm_buckets, msm_S[2], msm_C[2], msm_fin, msm_probs, powtabs, foldprobs, naf,
         gbuf[2], aux_pts, aux_scal, vscal, tmp_in, tmp_in2, tmp_out, vals, uni, stream_buf;
-    PinBuf h_cp, h_res, h_part, h_misc, h_misc2, h_probs, h_auxc, h_auxs, h_ovf;
+    PinBuf h_cp, h_res, h_part, h_misc, h_misc2, h_probs, h_auxc, h_auxs, h_ovf, h_V;
 
     void init() {
         if (inited) return;
@@ -688,8 +688,11 @@ sc sum_partials(const sc *p, size_t count, size_t stride, size_t which) {
 // ================================================================ prover (bulletproofs RangeProof::prove_multiple)
 // P chunks of m values each; vshift [P][m] (device), blind_canon [P][m] (device).
 // Outputs: proofs (host, P*plen), V bytes (host, P*m*32).
+// nonces[c]: where chunk c draws its nonces (a device-resident stream or a seed, and the index of its first nonce);
+// proofs_out[c]: where chunk c's proof goes (host).  The chunks may belong to different clients (batched create).
+struct ChunkNonce { int mode; NonceSeed seed; const uint8_t *d_stream; u64 stream_scalars, base; };
 void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const u64 *d_vshift, const sc *d_blind,
-                  const rofl_nonce_t *nonce, u64 nonce_base0, const uint8_t *h_V /* [P][m][32] host */, uint8_t *proofs_out) {
+                  const std::vector<ChunkNonce> &nonces, const uint8_t *h_V /* [P][m][32] host */, uint8_t *const *proofs_out) {
     size_t N = n * m; unsigned lgN = lg2u(N);
     static const bool ptrace = getenv("ROFL_TRACE") && atoi(getenv("ROFL_TRACE")) >= 2;
     double pt0 = now_ms(), ptl = pt0;
@@ -705,19 +708,13 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
     ChunkParams *d_cp = C.cp.as<ChunkParams>(P);
     memset(h_cp, 0, sizeof(ChunkParams) * P);
     u64 per = (u64)m * (2 * n + 4);
-    for (size_t c = 0; c < P; c++) h_cp[c].nonce_base = nonce_base0 + c * per;
-    HIPCHK(hipMemcpyAsync(d_cp, h_cp, sizeof(ChunkParams) * P, hipMemcpyHostToDevice, C.stream));
-    // nonces
-    NonceSeed seed{}; const uint8_t *d_stream = nullptr; u64 stream_scalars = 0;
-    if (nonce->mode == 1) memcpy(seed.w, nonce->seed, 32);
-    else {
-        stream_scalars = nonce->stream_scalars;
-        uint8_t *sb = C.stream_buf.as<uint8_t>(stream_scalars * 64 + 64);
-        HIPCHK(hipMemcpyAsync(sb, nonce->stream, stream_scalars * 64, hipMemcpyHostToDevice, C.stream));
-        d_stream = sb;
+    for (size_t c = 0; c < P; c++) {
+        h_cp[c].nonce_base = nonces[c].base; h_cp[c].nonce_mode = nonces[c].mode; h_cp[c].nonce_seed = nonces[c].seed;
+        h_cp[c].nonce_stream = nonces[c].d_stream; h_cp[c].nonce_stream_scalars = nonces[c].stream_scalars;
     }
+    HIPCHK(hipMemcpyAsync(d_cp, h_cp, sizeof(ChunkParams) * P, hipMemcpyHostToDevice, C.stream));
     sc *sL = C.sL.as<sc>(P * N), *sR = C.sR.as<sc>(P * N), *party = C.party.as<sc>(P * 4 * m), *Scanon = C.Scanon.as<sc>(P * 2 * N);
-    hipLaunchKernelGGL(k_nonce_expand, grid1(per, (u32)P), dim3(TPB), 0, C.stream, (u32)n, (u32)m, nonce->mode, seed, d_stream, stream_scalars, d_cp, sL, sR, party, Scanon);
+    hipLaunchKernelGGL(k_nonce_expand, grid1(per, (u32)P), dim3(TPB), 0, C.stream, (u32)n, (u32)m, d_cp, sL, sR, party, Scanon);
     // A partials
     ge *partial = C.partial.as<ge>(P * m);
     hipLaunchKernelGGL(k_bitcommit, grid1(m, (u32)P), dim3(TPB), 0, C.stream, (u32)n, (u32)m, d_vshift, tbl, partial);
@@ -758,7 +755,7 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
 
     double th = now_ms();
     C.pool->run(P, [&](size_t c) {
-        uint8_t *o = proofs_out + c * plen;
+        uint8_t *o = proofs_out[c];
         Merlin &t = tr[c];
         a_bl[c] = h_canon(sum_partials(h_sc + c * nblkS * 3, nblkS, 3, 0));
         s_bl[c] = h_canon(sum_partials(h_sc + c * nblkS * 3, nblkS, 3, 1));
@@ -786,7 +783,7 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
     HIPCHK(hipStreamSynchronize(C.stream));
     th = now_ms();
     C.pool->run(P, [&](size_t c) {
-        uint8_t *o = proofs_out + c * plen;
+        uint8_t *o = proofs_out[c];
         Merlin &t = tr[c];
         sc t0 = h_canon(sum_partials(h_t + c * nblkT * 3, nblkT, 3, 0));
         sc t1 = h_canon(sum_partials(h_t + c * nblkT * 3, nblkT, 3, 1));
@@ -852,14 +849,14 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
         mark("round msm", (long)(2 * n_g));
         th = now_ms();
         C.pool->run(P, [&](size_t c) {
-            uint8_t *o = proofs_out + c * plen + 7 * 32 + 64 * round;
+            uint8_t *o = proofs_out[c] + 7 * 32 + 64 * round;
             sc cL = h_canon(sum_partials(h_ip + c * nblkI * 2, nblkI, 2, 0));
             sc cR = h_canon(sum_partials(h_ip + c * nblkI * 2, nblkI, 2, 1));
             ge5 L = h51::gadd(res[2 * c], h_fixed_mul(C.ht.B5, h_mul(cL, w[c])));
             ge5 R = h51::gadd(res[2 * c + 1], h_fixed_mul(C.ht.B5, h_mul(cR, w[c])));
             tr_append_point(tr[c], "L", L, o); tr_append_point(tr[c], "R", R, o + 32);
             sc u = tr[c].challenge_scalar("u");
-            sc um = h_mont(u), uim = sc_invert_mont(um);
+            sc um = h_mont(u), uim = h51::sc_invert_mont_fast(um);
             h_cp[c].u[0] = um; h_cp[c].uinv[0] = uim;
             h_cp[c].pend_u[pu[c].size()] = um; h_cp[c].pend_ui[pu[c].size()] = uim;
             pu[c].push_back(um); pui[c].push_back(uim);
@@ -960,8 +957,9 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
                 dim3 grid((unsigned)((n_new + 63) / 64), (u32)(2 * P)), block(64, K);
                 uint64_t nz = 0;
                 if (C.tm.enabled) { size_t tot_d = 2 * P * nsrc * dstride; for (size_t q = 0; q < tot_d; q++) nz += h_dig[q] != 0; }
-                // per output: the non-zero digits of its problem (mixed additions), top+1 doublings per segment chain, K-1 recombinations
-                uint64_t fold_muls = (nz * 7 / (2 * P) + (uint64_t)(top + 1) * 8 * K + (K - 1) * 9 + 7) * (uint64_t)(2 * P * n_new);
+                // algorithmic work per output: the non-zero digits of its problem (mixed additions) and ONE chain of top+1 doublings
+                // (the K-1 redundant chains of a segmented launch buy latency, they are not work)
+                uint64_t fold_muls = (nz * 7 / (2 * P) + (uint64_t)(top + 1) * 8 + 7) * (uint64_t)(2 * P * n_new);
                 KSpan ks_fold(C.tm, C.stream, use_tab ? ROFL_TK_FOLD_TAB : ROFL_TK_FOLD, fold_muls, (uint64_t)2 * P * n_g * 32 + (uint64_t)2 * P * n_new * 32);
                 if (use_tab)
                     hipLaunchKernelGGL(k_fold_gens_tab, grid, block, (K - 1) * 64 * sizeof(ge), C.stream, (u32)n_new, nsrc, seg, fc, tbl, (size_t)(2 * N),
@@ -985,7 +983,7 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
     }
     HIPCHK(hipStreamSynchronize(C.stream));
     for (size_t c = 0; c < P; c++) {
-        uint8_t *o = proofs_out + c * plen + 7 * 32 + 64 * lgN;
+        uint8_t *o = proofs_out[c] + 7 * 32 + 64 * lgN;
         sc_tobytes(o, h_canon(h_ab[2 * c])); sc_tobytes(o + 32, h_canon(h_ab[2 * c + 1]));
     }
 }
@@ -1066,12 +1064,12 @@ int verify_chunks(Ctx &C, const char *label, size_t gens_capacity, size_t P, siz
         for (size_t k = 0; k < lg; k++) {
             t.append("L", ipp + 64 * k, 32); t.append("R", ipp + 64 * k + 32, 32);
             u[k] = t.challenge_scalar("u");
-            cp.u[k] = h_mont(u[k]); cp.uinv[k] = sc_invert_mont(cp.u[k]);
+            cp.u[k] = h_mont(u[k]); cp.uinv[k] = h51::sc_invert_mont_fast(cp.u[k]);
             ui[k] = h_canon(cp.uinv[k]);
         }
         sc zz = h_mul(z, z);
         cp.y = h_mont(y); cp.z = h_mont(z); cp.zz = h_mont(zz); cp.x = h_mont(x);
-        cp.yinv = sc_invert_mont(cp.y);
+        cp.yinv = h51::sc_invert_mont_fast(cp.y);
         fill_pow2(cp.ypow2, cp.y, MAX_LG); fill_pow2(cp.yinvpow2, cp.yinv, MAX_LG); fill_pow2(cp.zpow2, cp.z, MAX_LG);
         cp.a_fin = h_mont(a); cp.b_fin = h_mont(b);
         cp.c_zz = h_mont(h_mul(rho, h_mul(cc, zz)));
@@ -1210,10 +1208,16 @@ template <class F> int guarded(F f) {
     catch (const std::exception &e) { return fail(ROFL_HIP_ERROR, std::string("exception: ") + e.what()); }
 }
 
-int create_impl(Ctx &C, const float *values, size_t d, const uint8_t *blind, size_t d_blind, size_t prove_range, size_t n_partition,
-                unsigned fp_bits, unsigned fp_frac, const rofl_nonce_t *nonce, uint8_t *proofs_out, size_t *plen_out, size_t *np_out, uint8_t *commits_out) {
-    if (d != d_blind) return fail(ROFL_WRONG_NUM_BLINDING, "WrongNumBlindingFactors");
-    if (!valid_fp(fp_bits, fp_frac) || d == 0 || n_partition == 0 || prove_range == 0 || prove_range > fp_bits || !nonce)
+// create_rangeproof for `nc` clients of one shape (d, prove_range, n_partition) as ONE launch sequence: the clients' chunks are laid
+// side by side ([client][chunk]), every kernel of the proof covers all of them (blockIdx.y = chunk), and every IPP round carries the
+// L / R problems of all clients -- the host hops, the latency-bound tail and the launch overheads are paid once per batch instead of
+// once per client.  rcs[i] = the per-client outcome (ValueOutOfRange, NaN, nonce stream too short); clients that fail are left out,
+// the others are proved.  Returns non-zero only for errors that concern the whole call.
+int create_impl(Ctx &C, size_t nc, const float *const *values, size_t d, const uint8_t *const *blind, size_t prove_range, size_t n_partition,
+                unsigned fp_bits, unsigned fp_frac, const rofl_nonce_t *nonces, uint8_t *const *proofs_out, size_t *plen_out, size_t *np_out,
+                uint8_t *const *commits_out, int *rcs) {
+    for (size_t i = 0; i < nc; i++) rcs[i] = ROFL_OK;
+    if (!valid_fp(fp_bits, fp_frac) || d == 0 || n_partition == 0 || prove_range == 0 || prove_range > fp_bits || !nonces || nc == 0)
         return fail(ROFL_BAD_PARAM, "bad parameter (the reference panics here)");
     size_t dp = next_pow2(d);
     size_t n_chunks = std::min(dp, n_partition), chunk = dp / n_chunks;
@@ -1221,40 +1225,75 @@ int create_impl(Ctx &C, const float *values, size_t d, const uint8_t *blind, siz
     float mn, mx; clip_bounds(prove_range, fp_bits, fp_frac, &mn, &mx);
     C.init();
     timing_begin(C);
-    float *d_vals = C.vals.as<float>(d);
-    HIPCHK(hipMemcpyAsync(d_vals, values, sizeof(float) * d, hipMemcpyDefault, C.stream));      // caller's array: host or device memory
-    u64 *vshift = C.vshift.as<u64>(dp);
-    sc *d_blind_buf = C.blind.as<sc>(dp);
-    HIPCHK(hipMemsetAsync(d_blind_buf, 0, sizeof(sc) * dp, C.stream));
-    HIPCHK(hipMemcpyAsync(d_blind_buf, blind, 32 * d, hipMemcpyDefault, C.stream));
-    u32 *status = C.status.as<u32>(4);
-    HIPCHK(hipMemsetAsync(status, 0, 16, C.stream));
-    hipLaunchKernelGGL(k_quantize_shift, grid1(dp), dim3(TPB), 0, C.stream, d_vals, (u32)d, (u32)dp, (u32)prove_range, fp_bits, fp_frac, mn, mx, vshift, status);
-    u32 h_status = 0;
-    HIPCHK(hipMemcpyAsync(C.h_misc.as<u32>(4), status, 4, hipMemcpyDeviceToHost, C.stream));
+    float *d_vals = C.vals.as<float>(nc * d);
+    u64 *vshift = C.vshift.as<u64>(nc * dp);
+    sc *d_blind_buf = C.blind.as<sc>(nc * dp);
+    HIPCHK(hipMemsetAsync(d_blind_buf, 0, sizeof(sc) * nc * dp, C.stream));
+    for (size_t i = 0; i < nc; i++) {      // the callers' arrays: host or device memory
+        HIPCHK(hipMemcpyAsync(d_vals + i * d, values[i], sizeof(float) * d, hipMemcpyDefault, C.stream));
+        HIPCHK(hipMemcpyAsync(d_blind_buf + i * dp, blind[i], 32 * d, hipMemcpyDefault, C.stream));
+    }
+    u32 *status = C.status.as<u32>(nc + 4);
+    HIPCHK(hipMemsetAsync(status, 0, 4 * (nc + 4), C.stream));
+    hipLaunchKernelGGL(k_quantize_shift, grid1(dp, (u32)nc), dim3(TPB), 0, C.stream, d_vals, (u32)d, (u32)dp, (u32)prove_range, fp_bits, fp_frac, mn, mx, vshift, status);
+    u32 *h_status = C.h_misc.as<u32>(nc + 4);
+    HIPCHK(hipMemcpyAsync(h_status, status, 4 * nc, hipMemcpyDeviceToHost, C.stream));
     HIPCHK(hipStreamSynchronize(C.stream));
-    h_status = *C.h_misc.as<u32>(4);
-    if (h_status & 1) return fail(ROFL_VALUE_OUT_OF_RANGE, "ValueOutOfRangeError");
-    if (h_status & 2) return fail(ROFL_NON_FINITE, "non-finite value (the reference panics in fixed::saturating_from_float)");
+    // the reference's order of checks (range_proof_vec/mod.rs:22-29, then the upstream errors)
+    bool any = false;
+    for (size_t i = 0; i < nc; i++) {
+        if (h_status[i] & 1) rcs[i] = ROFL_VALUE_OUT_OF_RANGE;
+        else if (h_status[i] & 2) rcs[i] = ROFL_NON_FINITE;
+        any |= rcs[i] == ROFL_OK;
+    }
+    if (nc == 1 && rcs[0] == ROFL_VALUE_OUT_OF_RANGE) return fail(ROFL_VALUE_OUT_OF_RANGE, "ValueOutOfRangeError");
+    if (nc == 1 && rcs[0] == ROFL_NON_FINITE) return fail(ROFL_NON_FINITE, "non-finite value (the reference panics in fixed::saturating_from_float)");
     if (!is_pow2(chunk) || dp % chunk) return fail(ROFL_INVALID_AGGREGATION, "InvalidAggregation (the reference panics)");
     if (!(prove_range == 8 || prove_range == 16 || prove_range == 32 || prove_range == 64)) return fail(ROFL_INVALID_BITSIZE, "InvalidBitsize");
-    if (nonce->mode == 0 && nonce->stream_scalars < P * chunk * (2 * prove_range + 4)) return fail(ROFL_NONCE_SHORT, "nonce stream too short");
+    for (size_t i = 0; i < nc; i++)
+        if (rcs[i] == ROFL_OK && nonces[i].mode == 0 && nonces[i].stream_scalars < P * chunk * (2 * prove_range + 4)) {
+            rcs[i] = ROFL_NONCE_SHORT;
+            if (nc == 1) return fail(ROFL_NONCE_SHORT, "nonce stream too short");
+        }
+    size_t plen = 32 * (9 + 2 * (size_t)lg2u(prove_range * chunk));
+    *plen_out = plen; *np_out = P;
+    std::vector<size_t> act;
+    for (size_t i = 0; i < nc; i++) if (rcs[i] == ROFL_OK) act.push_back(i);
+    if (act.empty()) { timing_end(C); return ROFL_OK; }
+    size_t na = act.size();
+    if (na != nc)      // close the gaps: the proof kernels index chunks densely
+        for (size_t k = 0; k < na; k++) if (act[k] != k) {
+            HIPCHK(hipMemcpyAsync(vshift + k * dp, vshift + act[k] * dp, 8 * dp, hipMemcpyDeviceToDevice, C.stream));
+            HIPCHK(hipMemcpyAsync(d_blind_buf + k * dp, d_blind_buf + act[k] * dp, 32 * dp, hipMemcpyDeviceToDevice, C.stream));
+        }
+    // explicit nonce streams go to the device once
+    std::vector<ChunkNonce> cn(na * P);
+    { size_t tot = 0; for (size_t k = 0; k < na; k++) if (nonces[act[k]].mode == 0) tot += nonces[act[k]].stream_scalars * 64;
+      uint8_t *sb = tot ? C.stream_buf.as<uint8_t>(tot + 64) : nullptr; size_t off = 0;
+      u64 per = (u64)chunk * (2 * prove_range + 4);
+      for (size_t k = 0; k < na; k++) {
+          const rofl_nonce_t &nn = nonces[act[k]];
+          ChunkNonce base{}; base.mode = nn.mode;
+          if (nn.mode == 1) memcpy(base.seed.w, nn.seed, 32);
+          else { HIPCHK(hipMemcpyAsync(sb + off, nn.stream, nn.stream_scalars * 64, hipMemcpyHostToDevice, C.stream)); base.d_stream = sb + off; base.stream_scalars = nn.stream_scalars; off += nn.stream_scalars * 64; }
+          for (size_t c = 0; c < P; c++) { cn[k * P + c] = base; cn[k * P + c].base = c * per; }
+      } }
     // V_j and un-shifted commitments C_j = V_j - 2^(range-1) B   (range_proof_vec/mod.rs:96-99)
     sc negoff = sc_neg(sc_from_u64(1ULL << (prove_range - 1)));
     niels h_shift = h51::to_niels32(h_fixed_mul(C.ht.B5, negoff));
     niels *d_shift = C.tmp_in.as<niels>(1);
     HIPCHK(hipMemcpyAsync(d_shift, &h_shift, sizeof(niels), hipMemcpyHostToDevice, C.stream));
-    uint8_t *Vb = C.Vbytes.as<uint8_t>(dp * 32), *Cb = C.Cbytes.as<uint8_t>(dp * 32);
-    hipLaunchKernelGGL(k_commit, grid1(dp), dim3(TPB), 0, C.stream, (u32)dp, vshift, (const sc *)nullptr, d_blind_buf, C.d_tabB, C.d_tabBb, d_shift, Vb, Cb, (u32)d);
-    std::vector<uint8_t> hV(dp * 32);
-    HIPCHK(hipMemcpyAsync(hV.data(), Vb, dp * 32, hipMemcpyDeviceToHost, C.stream));
-    HIPCHK(hipMemcpyAsync(commits_out, Cb, d * 32, hipMemcpyDeviceToHost, C.stream));
-    size_t plen = 32 * (9 + 2 * (size_t)lg2u(prove_range * chunk));
+    uint8_t *Vb = C.Vbytes.as<uint8_t>(na * dp * 32), *Cb = C.Cbytes.as<uint8_t>(na * dp * 32);
+    hipLaunchKernelGGL(k_commit, grid1(na * dp), dim3(TPB), 0, C.stream, (u32)(na * dp), vshift, (const sc *)nullptr, d_blind_buf, C.d_tabB, C.d_tabBb, d_shift, Vb, Cb, (u32)d, (u32)dp);
+    uint8_t *hV = C.h_V.as<uint8_t>(na * dp * 32);
+    HIPCHK(hipMemcpyAsync(hV, Vb, na * dp * 32, hipMemcpyDeviceToHost, C.stream));
+    for (size_t k = 0; k < na; k++) HIPCHK(hipMemcpyAsync(commits_out[act[k]], Cb + k * dp * 32, d * 32, hipMemcpyDeviceToHost, C.stream));
     GensPin gens_pin = get_gens(C, prove_range, chunk);
     HIPCHK(hipStreamSynchronize(C.stream));       // V bytes (host copy) are complete
-    prove_chunks(C, "RangeProof", P, prove_range, chunk, vshift, d_blind_buf, nonce, 0, hV.data(), proofs_out);
+    std::vector<uint8_t *> pout(na * P);
+    for (size_t k = 0; k < na; k++) for (size_t c = 0; c < P; c++) pout[k * P + c] = proofs_out[act[k]] + c * plen;
+    prove_chunks(C, "RangeProof", na * P, prove_range, chunk, vshift, d_blind_buf, cn, hV, pout.data());
     timing_end(C);
-    *plen_out = plen; *np_out = P;
     return ROFL_OK;
 }
 
@@ -1384,7 +1423,17 @@ int rofl_create_rangeproof(const float *values, size_t d, const uint8_t *blindin
                            unsigned fp_bits, unsigned fp_frac, const rofl_nonce_t *nonce, uint8_t *proofs_out, size_t *proof_len_out,
                            size_t *n_proofs_out, uint8_t *commits_out) {
     return guarded([&]() -> int { LaneLock lane_lock = acquire_lane(); Ctx &C = *lane_lock.c;
-        return create_impl(C, values, d, blindings32, d_blindings, prove_range, n_partition, fp_bits, fp_frac, nonce, proofs_out, proof_len_out, n_proofs_out, commits_out); });
+        if (d != d_blindings) return fail(ROFL_WRONG_NUM_BLINDING, "WrongNumBlindingFactors");
+        int rc1 = ROFL_OK;
+        int rc = create_impl(C, 1, &values, d, &blindings32, prove_range, n_partition, fp_bits, fp_frac, nonce, &proofs_out, proof_len_out, n_proofs_out, &commits_out, &rc1);
+        return rc ? rc : rc1; });
+}
+int rofl_create_rangeproof_batch(size_t n_clients, const float *const *values, size_t d, const uint8_t *const *blindings32, size_t prove_range,
+                                 size_t n_partition, unsigned fp_bits, unsigned fp_frac, const rofl_nonce_t *nonces, uint8_t *const *proofs_out,
+                                 size_t *proof_len_out, size_t *n_proofs_out, uint8_t *const *commits_out, int *rc_out) {
+    return guarded([&]() -> int { LaneLock lane_lock = acquire_lane(); Ctx &C = *lane_lock.c;
+        if (!values || !blindings32 || !proofs_out || !commits_out || !rc_out || !proof_len_out || !n_proofs_out) return fail(ROFL_BAD_PARAM, "bad parameter");
+        return create_impl(C, n_clients, values, d, blindings32, prove_range, n_partition, fp_bits, fp_frac, nonces, proofs_out, proof_len_out, n_proofs_out, commits_out, rc_out); });
 }
 int rofl_verify_rangeproof(const uint8_t *proofs, size_t proof_len, size_t n_proofs, const uint8_t *commits32, size_t d, size_t prove_range,
                            unsigned fp_bits, unsigned fp_frac, const uint8_t verifier_seed[32], int *ok_out) {
@@ -1436,13 +1485,17 @@ int rofl_create_rangeproof_l2(const float *values, size_t d, const uint8_t *blin
         HIPCHK(hipMemcpyAsync(vshift, &v, 8, hipMemcpyHostToDevice, C.stream));
         HIPCHK(hipMemcpyAsync(d_bl, &bsum, 32, hipMemcpyHostToDevice, C.stream));
         uint8_t *Vb = C.Vbytes.as<uint8_t>(32);
-        hipLaunchKernelGGL(k_commit, grid1(1), dim3(TPB), 0, C.stream, 1u, vshift, (const sc *)nullptr, d_bl, C.d_tabB, C.d_tabBb, (const niels *)nullptr, Vb, (uint8_t *)nullptr, 0u);
+        hipLaunchKernelGGL(k_commit, grid1(1), dim3(TPB), 0, C.stream, 1u, vshift, (const sc *)nullptr, d_bl, C.d_tabB, C.d_tabBb, (const niels *)nullptr, Vb, (uint8_t *)nullptr, 0u, 1u);
         uint8_t hV[32];
         HIPCHK(hipMemcpyAsync(hV, Vb, 32, hipMemcpyDeviceToHost, C.stream));
         HIPCHK(hipStreamSynchronize(C.stream));
         // BulletproofGens::new(64, 1), label "L2RangeProof" (l2_range_proof_vec/mod.rs:156-171): the first
         // prove_range generators of party 0 are the same chain prefix.
-        prove_chunks(C, "L2RangeProof", 1, prove_range, 1, vshift, d_bl, nonce, 0, hV, proof_out);
+        ChunkNonce cn{}; cn.mode = nonce->mode;
+        if (nonce->mode == 1) memcpy(cn.seed.w, nonce->seed, 32);
+        else { uint8_t *sb = C.stream_buf.as<uint8_t>(nonce->stream_scalars * 64 + 64); HIPCHK(hipMemcpyAsync(sb, nonce->stream, nonce->stream_scalars * 64, hipMemcpyHostToDevice, C.stream)); cn.d_stream = sb; cn.stream_scalars = nonce->stream_scalars; }
+        uint8_t *pout = proof_out;
+        prove_chunks(C, "L2RangeProof", 1, prove_range, 1, vshift, d_bl, std::vector<ChunkNonce>(1, cn), hV, &pout);
         timing_end(C);
         memcpy(commit_out, hV, 32);
         *proof_len_out = 32 * (9 + 2 * (size_t)lg2u(prove_range));
@@ -1682,7 +1735,7 @@ int rofl_commit_vec(const uint8_t *values32, const uint8_t *blindings32, size_t 
         uint8_t *o = C.Cbytes.as<uint8_t>(d * 32);
         HIPCHK(hipMemcpyAsync(dv, values32, 32 * d, hipMemcpyHostToDevice, C.stream));
         if (db) HIPCHK(hipMemcpyAsync(db, blindings32, 32 * d, hipMemcpyHostToDevice, C.stream));
-        hipLaunchKernelGGL(k_commit, grid1(d), dim3(TPB), 0, C.stream, (u32)d, (const u64 *)nullptr, dv, db, C.d_tabB, C.d_tabBb, (const niels *)nullptr, (uint8_t *)nullptr, o, (u32)d);
+        hipLaunchKernelGGL(k_commit, grid1(d), dim3(TPB), 0, C.stream, (u32)d, (const u64 *)nullptr, dv, db, C.d_tabB, C.d_tabBb, (const niels *)nullptr, (uint8_t *)nullptr, o, (u32)d, (u32)d);
         HIPCHK(hipMemcpyAsync(out32, o, 32 * d, hipMemcpyDeviceToHost, C.stream));
         HIPCHK(hipStreamSynchronize(C.stream));
         return ROFL_OK;
@@ -1935,6 +1988,19 @@ int rofl_dbg_host_fe_ops(const uint8_t a[32], const uint8_t b[32], uint8_t oa[32
     fe x = fe_frombytes(a), y = fe_frombytes(b);
     // exercise the non-canonical range as well: add 2p-ish slack by doubling through fe_add
     fe_tobytes(oa, fe_add(x, y)); fe_tobytes(os, fe_sub(x, y)); fe_tobytes(oq, fe_sq(x)); fe_tobytes(oi, fe_invert(x)); return 0;
+}
+// both inversion routines (canonical in / out) and their timings in nanoseconds per call
+int rofl_dbg_host_sc_invert(const uint8_t a[32], uint8_t out_ref[32], uint8_t out_fast[32], double *ns_ref, double *ns_fast) {
+    sc am = h_mont(sc_frombytes(a));
+    sc r1 = sc_invert_mont(am), r2 = h51::sc_invert_mont_fast(am);
+    sc_tobytes(out_ref, h_canon(r1)); sc_tobytes(out_fast, h_canon(r2));
+    if (ns_ref && ns_fast) {
+        const int reps = 200; volatile u32 sink = 0;
+        double t0 = now_ms(); for (int i = 0; i < reps; i++) { am.v[0] ^= (u32)i; sink += sc_invert_mont(am).v[0]; } double t1 = now_ms();
+        for (int i = 0; i < reps; i++) { am.v[0] ^= (u32)i; sink += h51::sc_invert_mont_fast(am).v[0]; } double t2 = now_ms();
+        *ns_ref = (t1 - t0) * 1e6 / reps; *ns_fast = (t2 - t1) * 1e6 / reps; (void)sink;
+    }
+    return 0;
 }
 int rofl_dbg_host_sc_mul(const uint8_t a[32], const uint8_t b[32], uint8_t out[32]) { sc_tobytes(out, h_mul(sc_frombytes(a), sc_frombytes(b))); return 0; }
 int rofl_dbg_host_sc_wide(const uint8_t in[64], uint8_t out[32]) { sc_tobytes(out, sc_from_wide(sc_frombytes(in), sc_frombytes(in + 32))); return 0; }

@@ -131,3 +131,38 @@ def test_wire_check_percentage_out_of_range_does_not_raise(R):
     for cp in (float("inf"), float("nan"), -0.5, 1.5, 1e30):
         enc.check_percentage = cp
         assert enc.verify(fp=fp) is False
+
+
+def test_create_batch_is_bit_identical_to_single_calls(R):
+    """rofl_create_rangeproof_batch: several clients in one launch sequence; every client's proofs and commitments equal what
+    rofl_create_rangeproof returns for it (and therefore the oracle's), bad clients are singled out."""
+    for (d, nb, P, fp, nc) in ((37, 8, 4, (16, 7), 5), (300, 32, 4, (32, 7), 3), (1000, 16, 8, (16, 7), 4), (5, 8, 1, (16, 7), 6)):
+        rng = np.random.default_rng(d)
+        mn, mx = R.conversion32.get_clip_bounds(nb, fp=fp)
+        vals = [np.clip(rng.uniform(mn, mx, d).astype(np.float32), mn, np.nextafter(np.float32(mx), np.float32(0))) for _ in range(nc)]
+        bls = [orc.rand_scalars(rng, d) for _ in range(nc)]
+        nonces = [R.Nonce.seeded(bytes([40 + i]) * 32) for i in range(nc)]
+        if d == 37:      # one client with an explicit stream
+            m = 64 // 4
+            nonces[2] = R.Nonce.stream(rng.integers(0, 256, 4 * m * (2 * nb + 4) * 64, dtype=np.uint8).tobytes())
+        res = R.range_proof_vec.create_rangeproof_batch(vals, bls, nb, P, nonces=nonces, fp=fp)
+        for i in range(nc):
+            pr, cm = R.range_proof_vec.create_rangeproof(vals[i], bls[i], nb, P, nonce=nonces[i], fp=fp)
+            assert (res[i][0] == pr).all() and (res[i][1] == cm).all(), (d, i)
+        kw = {"stream": nonces[2]._stream.tobytes()} if d == 37 else {"seed": bytes([42]) * 32}
+        rc, opr, ocm = orc.create_rangeproof(vals[2], bls[2], nb, P, fp[0], fp[1], **kw)
+        assert rc == 0 and (opr == res[2][0]).all() and (ocm == res[2][1]).all()
+        assert R.range_proof_vec.verify_rangeproof_batch([r[0] for r in res], [r[1] for r in res], nb, fp=fp) == [True] * nc
+    # per-client failures do not sink the batch
+    fp = (16, 7)
+    rng = np.random.default_rng(99)
+    vals = [rng.uniform(-0.9, 0.9, 20).astype(np.float32) for _ in range(4)]
+    bls = [orc.rand_scalars(rng, 20) for _ in range(4)]
+    vals[1] = vals[1].copy(); vals[1][7] = 5.0             # out of the 8-bit range
+    vals[3] = vals[3].copy(); vals[3][0] = np.nan
+    nonces = [R.Nonce.seeded(bytes([i]) * 32) for i in range(4)]
+    res = R.range_proof_vec.create_rangeproof_batch(vals, bls, 8, 4, nonces=nonces, fp=fp)
+    assert isinstance(res[1], R.RoflError) and res[1].code == 2 and isinstance(res[3], R.RoflError) and res[3].code == 10
+    for i in (0, 2):
+        pr, cm = R.range_proof_vec.create_rangeproof(vals[i], bls[i], 8, 4, nonce=nonces[i], fp=fp)
+        assert (res[i][0] == pr).all() and (res[i][1] == cm).all()

@@ -942,6 +942,117 @@ __global__ void __launch_bounds__(1024) k_msm_scatter_lds(u32 n_side, u32 tile_p
     }
 }
 #endif
+// ---- Two-level bucket sort of the fixed-base MSM (round 2).  k_msm_scatter_lds places every (term, window) item straight into its
+// bucket's slot list: a tile holds ~4 items per bucket, so each (tile, bucket) pair dirties a 64-byte sector for 16 useful bytes
+// (PMC: 600 MB written per launch for 134 MB of entries) and the scalars are decoded twice (count pass, place pass).  Here:
+//   level 1 (k_msm_bin_l1): one pass over the scalars; an item goes to the COARSE BIN of its bucket (bucket >> fbits; 256 bins per
+//     bucket array) through per-bin staging rows in LDS that are flushed as contiguous runs of ~48 items (one atomic per (iteration,
+//     bin) reserves the run in the bin's HBM region).  An item is one u32: entry (window-table index, `ebits` bits) | fine bucket
+//     (fbits bits) | sign (bit 31).
+//   level 2 (k_msm_bin_l2): one block per (bucket array, bin) loads the bin (~8 K items), ranks it by fine bucket in LDS and writes
+//     it back IN PLACE as per-bucket lists, plus the count and the absolute list offset of each of its buckets.
+// Every entry is written to HBM twice, in full lines (2 x 134 MB), and k_msm_accumulate reads compact lists (cap == MSM_LIST_ABS).
+// A bin that outgrows its region (scalars built to collide) raises *overflow and the host repeats the MSM on the slot path.
+struct Msm2L { u32 nbins, fbits, ebits, cap_bin, stage; };      // stage = LDS staging slots per bin
+#define MSM_LIST_ABS 0xffffffffu
+#if ROFL_KG(1)
+__global__ void __launch_bounds__(1024) k_msm_bin_l1(u32 n_side, u32 tile_pts, u32 iter_pts, MsmWin mw, MsmMap mm, const MsmProb *probs, u32 *bin_cursor /* [PW][nbins] */,
+                                                     u32 *bins /* [PW][nbins][cap_bin] */, Msm2L L, u32 *overflow) {
+    extern __shared__ u32 sm2[];
+    u32 *lcnt = sm2, *stage = sm2 + L.nbins;                       // [nbins], [nbins][L.stage]
+    const u32 B = 1u << (mw.c - 1);
+    u32 nside = mm.lr_nh ? 2u : 1u;
+    u32 per_q = mm.fb_sets;                                        // bucket arrays per (q, side)
+    u32 y = blockIdx.y, a = y % per_q, side = (y / per_q) % nside, q = y / (per_q * nside);
+    u32 p = mm.lr_nh ? 2 * q + side : q;
+    u32 pw = p * per_q + a;
+    u32 w0 = a * mm.fb_wps, w1 = w0 + mm.fb_wps;
+    u32 k0 = blockIdx.x * tile_pts, k1 = k0 + tile_pts < n_side ? k0 + tile_pts : n_side;
+    const sc *scal = probs[p].scal;
+    u32 *cur = bin_cursor + (size_t)pw * L.nbins;
+    u32 *reg = bins + (size_t)pw * L.nbins * L.cap_bin;
+    const u32 fmask = (1u << L.fbits) - 1;
+    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
+    for (u32 base = k0; base < k1; base += iter_pts) {
+        for (u32 b = threadIdx.x; b < L.nbins; b += blockDim.x) lcnt[b] = 0;
+        __syncthreads();
+        u32 kend = base + iter_pts < k1 ? base + iter_pts : k1;
+        for (u32 k = base + threadIdx.x; k < kend; k += blockDim.x) {
+            u32 i = mm.lr_nh ? msm_side_term(mm, side, k) : k;
+            sc s = gload_sc(&scal[i]);
+            for (u32 w = w0; w < w1; w++) {
+                u32 wpos, wwid; msm_window(mw, w, wpos, wwid);
+                int d = msm_digit(s, wpos, wwid);
+                u32 ad = (u32)(d < 0 ? -d : d);
+                u32 entry = (w * mm.fb_stride + i) | (d < 0 ? 0x80000000u : 0u);
+                for (int rep = 0; rep < 2; rep++) {
+                    u32 a1 = rep == 0 ? (ad > B ? B : 0u) : (ad > B ? ad - B : ad);
+                    if (!a1) continue;
+                    u32 bkt = a1 - 1, bin = bkt >> L.fbits;
+                    u32 item = entry | ((bkt & fmask) << L.ebits);
+                    u32 pos = atomicAdd(&lcnt[bin], 1u);
+                    if (pos < L.stage) stage[bin * L.stage + pos] = item;
+                    else {                                          // a staging row ran full (skewed digits): straight to the bin
+                        u32 g = atomicAdd(&cur[bin], 1u);
+                        if (g < L.cap_bin) reg[(size_t)bin * L.cap_bin + g] = item; else atomicOr(overflow, 1u);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        for (u32 bin = wave; bin < L.nbins; bin += nwaves) {        // flush: one wave per bin, one reservation per (iteration, bin)
+            u32 c = lcnt[bin]; if (c > L.stage) c = L.stage;
+            if (!c) continue;
+            u32 g = 0;
+            if (lane == 0) g = atomicAdd(&cur[bin], c);
+            g = __shfl(g, 0);
+            for (u32 j = lane; j < c; j += 64) {
+                if (g + j < L.cap_bin) reg[(size_t)bin * L.cap_bin + g + j] = stage[bin * L.stage + j];
+                else atomicOr(overflow, 1u);
+            }
+        }
+        __syncthreads();
+    }
+}
+#endif
+#if ROFL_KG(1)
+__global__ void __launch_bounds__(512) k_msm_bin_l2(Msm2L L, u32 B, const u32 *bin_cursor, u32 *bins, u32 *cnt /* [PW][B] */, u32 *off /* [PW][B] */) {
+    extern __shared__ u32 sm2[];
+    const u32 FB = 1u << L.fbits;
+    u32 *hist = sm2, *ofs = sm2 + FB, *out = sm2 + 2 * FB;          // [FB], [FB], [cap_bin]
+    u32 bin = blockIdx.x, pw = blockIdx.y;
+    u32 n = bin_cursor[(size_t)pw * L.nbins + bin]; if (n > L.cap_bin) n = L.cap_bin;
+    size_t rbase = ((size_t)pw * L.nbins + bin) * L.cap_bin;
+    u32 *reg = bins + rbase;
+    const u32 fmask = FB - 1, keep = ~(fmask << L.ebits);
+    for (u32 f = threadIdx.x; f < FB; f += blockDim.x) hist[f] = 0;
+    __syncthreads();
+    for (u32 j = threadIdx.x; j < n; j += blockDim.x) atomicAdd(&hist[(reg[j] >> L.ebits) & fmask], 1u);
+    __syncthreads();
+    if (threadIdx.x < 64) {                                          // exclusive scan of FB <= 128 counters by one wave
+        u32 per = (FB + 63) / 64, lo = threadIdx.x * per, sum = 0;
+        for (u32 f = lo; f < lo + per && f < FB; f++) sum += hist[f];
+        u32 incl = sum;
+        for (u32 dlt = 1; dlt < 64; dlt <<= 1) { u32 v = __shfl_up(incl, dlt); if (threadIdx.x >= dlt) incl += v; }
+        u32 run = incl - sum;
+        for (u32 f = lo; f < lo + per && f < FB; f++) { ofs[f] = run; run += hist[f]; }
+    }
+    __syncthreads();
+    for (u32 f = threadIdx.x; f < FB; f += blockDim.x) {
+        size_t bi = (size_t)pw * B + (size_t)bin * FB + f;
+        cnt[bi] = hist[f];
+        off[bi] = (u32)(rbase + ofs[f]);
+    }
+    __syncthreads();
+    for (u32 j = threadIdx.x; j < n; j += blockDim.x) {
+        u32 v = reg[j];
+        u32 pos = atomicAdd(&ofs[(v >> L.ebits) & fmask], 1u);
+        out[pos] = v & keep;
+    }
+    __syncthreads();
+    for (u32 j = threadIdx.x; j < n; j += blockDim.x) reg[j] = out[j];
+}
+#endif
 // one 64-lane wave; lane l owns the overflow entries whose bucket index is l mod 64 (no two lanes share a bucket)
 #if ROFL_KG(1)
 __global__ void k_msm_overflow(u32 W, u32 B, u32 pstep, const MsmProb *probs, const u32 *ovf_count, const MsmOvf *ovf, u32 ovf_max, ge *buckets, int fb) {
@@ -968,7 +1079,8 @@ template <bool FB> __device__ __forceinline__ void msm_accumulate_body(u32 n, u3
     size_t bi = ((size_t)p * W + w) * B + perm[(size_t)p * W * B + t];
     u32 num = cnt[bi];
     const u32 *lst;
-    if (cap) { lst = sorted + bi * cap; if (num > cap) num = cap; }        // slot mode: `sorted` is the slot array
+    if (cap == MSM_LIST_ABS) lst = sorted + off[bi];                        // two-level sort: compact lists, absolute offsets
+    else if (cap) { lst = sorted + bi * cap; if (num > cap) num = cap; }        // slot mode: `sorted` is the slot array
     else lst = sorted + ((size_t)p * W + w) * n * 2 + off[bi];   // stride 2n: a top-window digit may emit two entries
     const niels *pts = probs[p * pstep].pts;
     gd acc = gd_identity();

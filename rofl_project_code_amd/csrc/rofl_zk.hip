@@ -241,7 +241,7 @@ struct Ctx {
     std::map<std::pair<size_t, size_t>, std::unique_ptr<GensEntry>> gens;   // (n, m) -> tables; primary lane only, under gens_mu
     u64 gens_tick = 0; size_t gens_budget = (size_t)96 << 30;   // ROFL_GENS_BUDGET_MB: evict least recently used (unpinned) tables beyond this
     u32 fold_pb = 32, fold_w = 8; size_t fold_tab_budget = (size_t)32 << 30;   // widest NAF whose table fits the per-(n, m) budget (ROFL_FOLD_W, ROFL_FOLD_TAB_MB)
-    int msm_lds = 1; size_t msm_lds_min = 8192, msm_lds_tile = 131072;
+    int msm_lds = 1, msm_two_level = 1; size_t msm_lds_min = 8192, msm_lds_tile = 131072;
     size_t msm_fb_threads = (size_t)1 << 19;
     int msm_fb = 1; u32 msm_fb_sets = 2; size_t msm_fb_min = (size_t)1 << 12; int msm_lr = 1;   // window tables for every (n, m) with 2N >= 4096: many small chunks (n_partition = 64) share them
     bool crowded() const { const Ctx *P = parent ? parent : this; return P->active_calls.load() > 1; }   // other calls in flight on this device
@@ -276,6 +276,8 @@ struct Ctx {
         HIPCHK(hipFuncSetAttribute((const void *)k_msm_reduce_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void *)k_msm_small, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void *)k_msm_scatter_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void *)k_msm_bin_l1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void *)k_msm_bin_l2, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         HIPCHK(hipMalloc(&d_tabB, sizeof(niels) * 512));
         HIPCHK(hipMalloc(&d_tabBb, sizeof(niels) * 512));
         HIPCHK(hipMemcpy(d_tabB, ht.B.data(), sizeof(niels) * 512, hipMemcpyHostToDevice));
@@ -289,6 +291,7 @@ struct Ctx {
         if (const char *e = getenv("ROFL_MSM_FB")) msm_fb = atoi(e);
         if (const char *e = getenv("ROFL_MSM_FB_THREADS")) { long v = atol(e); if (v >= 1) msm_fb_threads = (size_t)v; }
         if (const char *e = getenv("ROFL_MSM_LDS")) msm_lds = atoi(e);
+        if (const char *e = getenv("ROFL_MSM_TWO_LEVEL")) msm_two_level = atoi(e);
         if (const char *e = getenv("ROFL_MSM_LDS_MIN")) { long v = atol(e); if (v >= 1) msm_lds_min = (size_t)v; }
         if (const char *e = getenv("ROFL_MSM_LDS_TILE")) { long v = atol(e); if (v >= 1024) msm_lds_tile = (size_t)v; }
         if (const char *e = getenv("ROFL_MSM_LR")) msm_lr = atoi(e);
@@ -315,7 +318,7 @@ struct Ctx {
         parent = &p; device = p.device;
         HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         ht = p.ht; d_tabB = p.d_tabB; d_tabBb = p.d_tabBb; d_two_pow = p.d_two_pow;
-        msm_lds = p.msm_lds; msm_lds_min = p.msm_lds_min; msm_lds_tile = p.msm_lds_tile;
+        msm_lds = p.msm_lds; msm_two_level = p.msm_two_level; msm_lds_min = p.msm_lds_min; msm_lds_tile = p.msm_lds_tile;
         msm_fb_threads = p.msm_fb_threads;
         msm_fb = p.msm_fb; msm_fb_sets = p.msm_fb_sets; msm_fb_min = p.msm_fb_min; msm_lr = p.msm_lr;
         fold_min = p.fold_min; msm_dev_horner_min = p.msm_dev_horner_min; msm_small_max = p.msm_small_max; msm_slots = p.msm_slots; fold_t = p.fold_t; fold_t1 = p.fold_t1; fold_k = p.fold_k; fold_tab = p.fold_tab;
@@ -495,7 +498,7 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
     MsmProb *d_probs = C.msm_probs.as<MsmProb>(np);
     MsmProb *h_probs = C.h_probs.as<MsmProb>(np);
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    MsmPlan P{}; size_t PW = 0; bool fb_used = false, overlap_done = false, dev_horner = false, allow_small = true; u32 sets = 0;
+    MsmPlan P{}; size_t PW = 0; bool fb_used = false, overlap_done = false, dev_horner = false, allow_small = true, allow_two = true, two_used = false; u32 sets = 0;
     for (int attempt = 0; attempt < 3; attempt++) {
         // attempt 0: fixed-base slots (if available) ; then generic slots ; then the two-pass sort
         bool fb = attempt == 0 && opt.fb_wtab != nullptr && C.msm_slots;
@@ -552,6 +555,40 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
             }
             HIPCHK(hipMemcpyAsync(C.h_ovf.as<u32>(4), cnt, 4, hipMemcpyDeviceToHost, C.stream));
         } else {
+        // fixed-base launches: two-level bucket sort (coarse bins through HBM in full lines, then per-bin ranking in LDS)
+        bool two = fb && allow_two && C.msm_two_level && 16 * opt.fb_stride <= ((size_t)1 << 24) && P.B == 32768;
+        Msm2L tl{256, 7, 24, 0, 144};
+        u32 n_side2 = (u32)(lr ? n / 2 : n);
+        if (two) {
+            size_t avg = (size_t)n_side2 * mm.fb_wps / tl.nbins;
+            tl.cap_bin = (u32)((2 * avg + 256 + 63) / 64 * 64);
+            if ((size_t)tl.cap_bin * 4 + 1024 > 96 * 1024 || n_side2 < 8192) two = false;
+        }
+        two_used = two;
+        if (two) {
+            u32 *bins = C.msm_sorted.as<u32>(PW * tl.nbins * tl.cap_bin);
+            u32 *bcur = C.msm_cur.as<u32>(PW * tl.nbins);
+            u32 *ovf_flag = cnt + PW * P.B;
+            HIPCHK(hipMemsetAsync(bcur, 0, sizeof(u32) * PW * tl.nbins, C.stream));
+            HIPCHK(hipMemsetAsync(ovf_flag, 0, 16, C.stream));
+            u32 iter_pts = 16384 / mm.fb_wps; if (iter_pts < 1024) iter_pts = 1024;
+            u32 tile = iter_pts;
+            while ((size_t)((n_side2 + tile - 1) / tile) * PW > 512 && tile < n_side2) tile *= 2;
+            dim3 grid((n_side2 + tile - 1) / tile, (u32)PW);
+            uint64_t terms = (uint64_t)(lr ? nq : np) * n, items = terms * 16u;
+            { KSpan ks(C.tm, C.stream, ROFL_TK_MSM_SCATTER, 0, terms * 32 + items * 4);
+              hipLaunchKernelGGL(k_msm_bin_l1, grid, dim3(1024), (size_t)(tl.nbins + tl.nbins * tl.stage) * 4, C.stream, n_side2, tile, iter_pts, mw, mm, d_probs, bcur, bins, tl, ovf_flag);
+              hipLaunchKernelGGL(k_msm_bin_l2, dim3(tl.nbins, (u32)PW), dim3(512), (size_t)(2 * 128 + tl.cap_bin) * 4, C.stream, tl, P.B, bcur, bins, cnt, off); }
+            hipLaunchKernelGGL(k_msm_scan, dim3((unsigned)PW), dim3(TPB), 0, C.stream, P.B, cnt, off, (u32 *)nullptr, perm);
+            if (C.tm.enabled) { e0 = C.tm.get(); e1 = C.tm.get(); HIPCHK(hipEventRecord(e0, C.stream)); }
+            {
+                uint64_t acc_adds = (uint64_t)(lr ? nq : np) * n * 16u;
+                KSpan ks_acc(C.tm, C.stream, ROFL_TK_MSM_ACCUMULATE_FB, acc_adds * 7, (uint64_t)(lr ? nq : np) * n * 32);
+                hipLaunchKernelGGL(k_msm_accumulate_fb, grid1((size_t)Wb * P.B, (u32)nq), dim3(TPB), 0, C.stream, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, bins, perm, buckets, MSM_LIST_ABS, dbg_mask);
+            }
+            if (C.tm.enabled) HIPCHK(hipEventRecord(e1, C.stream));
+            HIPCHK(hipMemcpyAsync(C.h_ovf.as<u32>(4), ovf_flag, 4, hipMemcpyDeviceToHost, C.stream));
+        } else {
         HIPCHK(hipMemsetAsync(cnt, 0, sizeof(u32) * (PW * P.B + 4), C.stream));
         // accumulate sees `nq` problems of Wb bucket arrays each; its points come from d_probs[q * (np / nq)]
         if (slots_mode) {
@@ -590,6 +627,7 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
             if (C.tm.enabled) { e0 = C.tm.get(); e1 = C.tm.get(); HIPCHK(hipEventRecord(e0, C.stream)); }
             hipLaunchKernelGGL(k_msm_accumulate_gen, grid1((size_t)Wb * P.B, (u32)nq), dim3(TPB), 0, C.stream, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, sorted, perm, buckets, 0u, dbg_mask);
             if (C.tm.enabled) HIPCHK(hipEventRecord(e1, C.stream));
+        }
         }
         }
         if (C.tm.enabled && !small) { C.tm.acc_ev.push_back({e0, e1}); C.tm.t.msm_accumulate_launches++; C.tm.t.msm_additions += (uint64_t)(lr ? nq : np) * n * (fb ? 16u : P.W); char tg[96]; snprintf(tg, sizeof tg, "msm np=%zu n=%zu c=%u cap=%u fb=%u lr=%d", np, n, P.c, slots_mode ? cap : 0u, fb ? sets : 0u, (int)lr); C.tm.acc_tag.push_back(tg); }
@@ -632,6 +670,8 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
         if (slots_mode && getenv("ROFL_TRACE")) fprintf(stderr, "[rofl] msm np=%zu n=%zu c=%u cap=%u fb=%u lr=%d overflow=%u\n", np, n, P.c, cap, fb ? sets : 0u, (int)lr, *C.h_ovf.as<u32>(4));
         if (small) {
             if (*C.h_ovf.as<u32>(4) != 0) { allow_small = false; attempt = 0; continue; }     // a bucket list overflowed: repeat through the general pipeline
+        } else if (two_used) {
+            if (*C.h_ovf.as<u32>(4) != 0) { allow_two = false; attempt = -1; continue; }      // a coarse bin overflowed (skewed scalars): repeat on the slot path
         } else
         if (slots_mode && *C.h_ovf.as<u32>(4) > OVF_MAX) continue;    // pathological input: next (slower, always sufficient) variant
         fb_used = fb;

@@ -602,16 +602,76 @@ __global__ void __launch_bounds__(TPB) k_ipp_inner(u32 nh, const sc *a, const sc
     }
 }
 #endif
-// a_L = a_L u + u^-1 a_R ; b_L = b_L u^-1 + u b_R   (cp.u[0], cp.uinv[0] = this round's challenge)
+// a_L = a_L u + u^-1 a_R ; b_L = b_L u^-1 + u b_R.  This round's challenge (u, u^-1; Montgomery) is read from `round_ch`
+// [chunk][2] -- mapped host memory the host wrote after the transcript step, so no H2D copy sits on the hop -- and recorded as
+// pending challenge number `pend_idx` of the chunk (k_ipp_scalars of the next rounds reads the pending list from device memory).
 #if ROFL_KG(4)
-__global__ void __launch_bounds__(TPB) k_ipp_fold_ab(u32 nh, const ChunkParams *cp, sc *a, sc *b, size_t ab_stride) {
+__global__ void __launch_bounds__(TPB) k_ipp_fold_ab(u32 nh, ChunkParams *cp, const sc *round_ch, u32 pend_idx, sc *a, sc *b, size_t ab_stride) {
     u32 c = blockIdx.y;
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    sc u = load_sc(&round_ch[2 * c]), ui = load_sc(&round_ch[2 * c + 1]);
+    if (i == 0) { store_sc(&cp[c].pend_u[pend_idx], u); store_sc(&cp[c].pend_ui[pend_idx], ui); }
     if (i >= nh) return;
     sc *ac = a + c * ab_stride, *bc = b + c * ab_stride;
-    sc u = cp[c].u[0], ui = cp[c].uinv[0];
     store_sc(&ac[i], sc_add(sc_montmul(load_sc(&ac[i]), u), sc_montmul(load_sc(&ac[nh + i]), ui)));
     store_sc(&bc[i], sc_add(sc_montmul(load_sc(&bc[i]), ui), sc_montmul(load_sc(&bc[nh + i]), u)));
+}
+#endif
+
+// One launch per IPP round (rounds >= 1, merged L/R layout) instead of k_ipp_fold_ab + k_ipp_scalars + k_ipp_inner and an H2D copy
+// of the challenge:  (1) fold a, b with the previous round's challenge u -- read from mapped host memory, once per block -- into the
+// other ping-pong buffer; (2) the MSM scalars of THIS round over the materialised generators, i.e. the folded values times the
+// products of the pending challenges (those already on the device plus, unless the generators were re-materialised in between, u);
+// (3) the partial sums of c_L = <a_L, b_R>, c_R = <a_R, b_L> -> ip_out [chunk][gridDim.x][2] (mapped host memory).
+// n_k = logical vector length of this round (the inputs have 2 n_k entries).  Every thread folds what it needs itself, so nothing
+// in the launch depends on another thread's output.
+#if ROFL_KG(4)
+__global__ void __launch_bounds__(TPB) k_ipp_round(u32 n_g, u32 n_k, u32 r_prev, int use_new, ChunkParams *cp, const sc *round_ch, const sc *a_in, const sc *b_in,
+                                                   sc *a_out, sc *b_out, size_t ab_stride, const sc *yinvpow, size_t y_stride, sc *SL, sc *ip_out) {
+    __shared__ sc lds[TPB * 2];
+    __shared__ sc s_u[2];
+    u32 c = blockIdx.y;
+    if (threadIdx.x == 0) { s_u[0] = load_sc(&round_ch[2 * c]); s_u[1] = load_sc(&round_ch[2 * c + 1]); }
+    __syncthreads();
+    const sc u = s_u[0], ui = s_u[1];
+    if (use_new && blockIdx.x == 0 && threadIdx.x == 0) { store_sc(&cp[c].pend_u[r_prev], u); store_sc(&cp[c].pend_ui[r_prev], ui); }   // read by later launches only
+    const sc *ai = a_in + c * ab_stride, *bi = b_in + c * ab_stride;
+    sc *ao = a_out + c * ab_stride, *bo = b_out + c * ab_stride;
+    const u32 nh = n_k / 2, r = r_prev + (use_new ? 1u : 0u);
+    const sc gs = load_sc(&cp[c].gscale), hs = load_sc(&cp[c].hscale);
+    sc *sl = SL + (size_t)c * 2 * n_g;
+    sc v[2] = {sc_zero(), sc_zero()};
+    for (u32 j = blockIdx.x * blockDim.x + threadIdx.x; j < n_g; j += gridDim.x * blockDim.x) {
+        u32 h = j / n_k, i = j % n_k;
+        bool lo = i < nh; u32 ii = lo ? nh + i : i - nh;
+        sc af = sc_add(sc_montmul(load_sc(&ai[ii]), u), sc_montmul(load_sc(&ai[n_k + ii]), ui));
+        sc bf = sc_add(sc_montmul(load_sc(&bi[ii]), ui), sc_montmul(load_sc(&bi[n_k + ii]), u));
+        sc sG = gs, sH = hs;
+        for (u32 q = 0; q < r_prev; q++) {          // challenge q <-> bit r-1-q of h
+            bool bit = (h >> (r - 1 - q)) & 1;
+            sc up = load_sc(&cp[c].pend_u[q]), upi = load_sc(&cp[c].pend_ui[q]);
+            sG = sc_montmul(sG, bit ? up : upi);
+            sH = sc_montmul(sH, bit ? upi : up);
+        }
+        if (use_new) { bool bit = h & 1; sG = sc_montmul(sG, bit ? u : ui); sH = sc_montmul(sH, bit ? ui : u); }
+        sH = sc_montmul(sH, load_sc(&yinvpow[c * y_stride + j]));
+        store_sc(&sl[j], sc_from_mont(sc_montmul(af, sG)));
+        store_sc(&sl[n_g + j], sc_from_mont(sc_montmul(bf, sH)));
+        if (h == 0) {
+            store_sc(&ao[ii], af); store_sc(&bo[ii], bf);
+            if (lo) {      // this thread holds a'[nh+i], b'[nh+i]; with a'[i], b'[i] it owns one term of each inner product
+                sc al = sc_add(sc_montmul(load_sc(&ai[i]), u), sc_montmul(load_sc(&ai[n_k + i]), ui));
+                sc bl = sc_add(sc_montmul(load_sc(&bi[i]), ui), sc_montmul(load_sc(&bi[n_k + i]), u));
+                v[0] = sc_add(v[0], sc_montmul(al, bf));
+                v[1] = sc_add(v[1], sc_montmul(af, bl));
+            }
+        }
+    }
+    block_sum_sc<2>(v, lds);
+    if (threadIdx.x == 0) {
+        store_sc(&ip_out[((size_t)c * gridDim.x + blockIdx.x) * 2 + 0], v[0]);
+        store_sc(&ip_out[((size_t)c * gridDim.x + blockIdx.x) * 2 + 1], v[1]);
+    }
 }
 #endif
 
@@ -994,7 +1054,7 @@ __global__ void __launch_bounds__(1024) k_msm_bin_l1(u32 n_side, u32 tile_pts, u
                     if (pos < L.stage) stage[bin * L.stage + pos] = item;
                     else {                                          // a staging row ran full (skewed digits): straight to the bin
                         u32 g = atomicAdd(&cur[bin], 1u);
-                        if (g < L.cap_bin) reg[(size_t)bin * L.cap_bin + g] = item; else atomicOr(overflow, 1u);
+                        if (g < L.cap_bin) reg[(size_t)bin * L.cap_bin + g] = item; else *(volatile u32 *)overflow = 1u;
                     }
                 }
             }
@@ -1008,7 +1068,7 @@ __global__ void __launch_bounds__(1024) k_msm_bin_l1(u32 n_side, u32 tile_pts, u
             g = __shfl(g, 0);
             for (u32 j = lane; j < c; j += 64) {
                 if (g + j < L.cap_bin) reg[(size_t)bin * L.cap_bin + g + j] = stage[bin * L.stage + j];
-                else atomicOr(overflow, 1u);
+                else *(volatile u32 *)overflow = 1u;      // mapped host memory: plain, idempotent store
             }
         }
         __syncthreads();
@@ -1245,7 +1305,7 @@ __global__ void __launch_bounds__(512) k_msm_small(u32 n_side, MsmWin mw, MsmMap
             if (!a1) continue;
             u32 pos = atomicAdd(&lcnt[a1 - 1], 1u);
             if (pos < MSM_SMALL_CAP) lst[(a1 - 1) * MSM_SMALL_CAP + pos] = entry;
-            else atomicAdd(overflow, 1u);
+            else *(volatile u32 *)overflow = 1u;          // mapped host memory: a plain store (idempotent)
         }
     }
     __syncthreads();

@@ -173,17 +173,21 @@ struct DevBuf {
     }
     template <class T> T *as(size_t count) { return reinterpret_cast<T *>(ensure(count * sizeof(T))); }
 };
+// Pinned host memory that kernels can address directly (mapped, coherent): small per-round results go from the kernels straight
+// into it and per-round challenges are read from it -- no hipMemcpyAsync on the hop (each costs 10-15 us of host time).
 struct PinBuf {
-    void *p = nullptr; size_t cap = 0;
+    void *p = nullptr, *dp = nullptr; size_t cap = 0;
     void *ensure(size_t bytes) {
         if (bytes > cap) {
             if (p) HIPCHK(hipHostFree(p));
-            p = nullptr; cap = 0;
-            HIPCHK(hipHostMalloc(&p, bytes + 256, hipHostMallocDefault)); cap = bytes + 256;
+            p = nullptr; dp = nullptr; cap = 0;
+            HIPCHK(hipHostMalloc(&p, bytes + 256, hipHostMallocMapped)); cap = bytes + 256;
+            HIPCHK(hipHostGetDevicePointer(&dp, p, 0));
         }
         return p;
     }
     template <class T> T *as(size_t count) { return reinterpret_cast<T *>(ensure(count * sizeof(T))); }
+    template <class T> T *dev(size_t count) { ensure(count * sizeof(T)); return reinterpret_cast<T *>(dp); }      // the same memory, as the device sees it
 };
 
 struct Timing {
@@ -254,11 +258,13 @@ struct Ctx {
     bool msm_slots = true;
     int fold_t = 2, fold_t1 = 3, fold_k = 0, fold_tab = 1, fold_unit = 1; long fold_threads = 131072;
     Timing tm;
+    struct HopStats { double enqueue = 0, sync = 0, horner_wall = 0, horner_cpu = 0, host_wall = 0, host_cpu = 0; int n = 0; } hs;      // ROFL_TRACE: where the host hops go
     // workspace
-    DevBuf cp, sL, sR, party, Scanon, vshift, blind, Vbytes, Cbytes, status, partial, partial2, scpart, a, b, yinv,
+    DevBuf cp, sL, sR, party, Scanon, vshift, blind, Vbytes, Cbytes, status, partial, partial2, scpart, a, b, a2, b2, yinv,
         SL, SR, msm_cnt, msm_off, msm_cur, msm_perm, msm_sorted, msm_ovf, msm_buckets, msm_S[2], msm_C[2], msm_fin, msm_probs, powtabs, foldprobs, naf,
         gbuf[2], aux_pts, aux_scal, vscal, tmp_in, tmp_in2, tmp_out, vals, uni, stream_buf;
-    PinBuf h_cp, h_res, h_part, h_misc, h_misc2, h_probs, h_auxc, h_auxs, h_ovf, h_V;
+    PinBuf h_cp, h_res, h_part, h_misc, h_misc2, h_probs, h_auxc, h_auxs, h_ovf, h_V, h_ip, h_round, h_fdig, h_fprob;
+    std::vector<MsmProb> probs_on_dev;      // what d_probs holds: an unchanged problem list is not uploaded again
 
     void init() {
         if (inited) return;
@@ -491,6 +497,7 @@ MsmPlan msm_plan(size_t n) {
 struct MsmOpt { u32 lr_nh = 0, lr_ng = 0; const niels *fb_wtab = nullptr; size_t fb_stride = 0; std::function<void()> overlap; };   // overlap: host work to run while the kernels execute
 void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge5> &results, const MsmOpt &opt = MsmOpt()) {
     size_t np = probs.size();
+    double t_enter = now_ms();
     static const u32 dbg_mask = getenv("ROFL_DBG_IDX_MASK") ? (u32)strtoul(getenv("ROFL_DBG_IDX_MASK"), nullptr, 0) : 0x7fffffffu;   // timing experiments only (wrong results): gathers confined to a cache-resident prefix
     static const u32 dbg_scatter = getenv("ROFL_DBG_SCATTER") ? (u32)atoi(getenv("ROFL_DBG_SCATTER")) : 0u;   // timing experiments only: 1 = no range reservation, 2 = no slot stores
     bool lr = opt.lr_nh != 0;
@@ -530,30 +537,37 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
             for (size_t i = 0; i < np; i++) h_probs[i] = probs[i];
         }
         if (slots_mode && (size_t)PW * P.B * cap * 4 > ((size_t)8 << 30)) continue;
-        HIPCHK(hipMemcpyAsync(d_probs, h_probs, sizeof(MsmProb) * np, hipMemcpyHostToDevice, C.stream));
+        if (C.probs_on_dev.size() != np || memcmp(C.probs_on_dev.data(), h_probs, sizeof(MsmProb) * np) != 0) {
+            HIPCHK(hipMemcpyAsync(d_probs, h_probs, sizeof(MsmProb) * np, hipMemcpyHostToDevice, C.stream));
+            C.probs_on_dev.assign(h_probs, h_probs + np);
+        }
         u32 *cnt = C.msm_cnt.as<u32>(PW * P.B + 4), *off = C.msm_off.as<u32>(PW * P.B), *cur = C.msm_cur.as<u32>(PW * P.B);
         u32 *perm = C.msm_perm.as<u32>(PW * P.B);
         ge *buckets = C.msm_buckets.as<ge>(PW * P.B);
         MsmWin mw{P.c, P.W, P.wide};
         const u32 OVF_MAX = 4096;
+        // results and flags go from the kernels straight into mapped host memory (no D2H copies on the hop); with many problems the
+        // Horner chains run on the device and only one point per problem comes back
+        dev_horner = !fb && np >= C.msm_dev_horner_min && P.W <= 64;
+        ge *hres_dev = C.h_res.dev<ge>(PW * (size_t)P.c + np);
+        u32 *h_flag = C.h_ovf.as<u32>(4), *d_flag = C.h_ovf.dev<u32>(4);
         u32 Wb = (u32)(PW / nq);                           // bucket arrays per grid problem
         // the IPP tail (a few thousand terms per problem): one launch instead of memset / scatter / scan / accumulate / overflow / reduce
         u32 nside_small = (u32)(lr ? n / 2 : n);
         // (its blocks hold up to 130 KB of LDS, one per CU: with thousands of bucket arrays -- n_partition = 64 -- the general pipeline is faster)
         bool small = !fb && slots_mode && allow_small && C.msm_small_max && nside_small <= C.msm_small_max && P.c <= 10 && nside_small <= 8 * P.B && PW <= 512;
         if (small) {
-            HIPCHK(hipMemsetAsync(cnt, 0, 16, C.stream));                 // cnt[0] = list-overflow flag
-            ge *S_fin_s = C.msm_S[0].as<ge>(PW);
-            ge *C_fin_s = C.msm_C[0].as<ge>(PW * (size_t)(P.c - 1));
+            *h_flag = 0;                                                  // list-overflow flag, in mapped host memory (plain stores from the kernel)
+            ge *S_fin_s = dev_horner ? C.msm_S[0].as<ge>(PW) : hres_dev;
+            ge *C_fin_s = dev_horner ? C.msm_C[0].as<ge>(PW * (size_t)(P.c - 1)) : hres_dev + PW;
             size_t lds_lists = (size_t)P.B * 4 * (1 + MSM_SMALL_CAP);
             size_t lds_red = ((size_t)(P.B / 8) * 4 + (size_t)(P.B / 16) * 5 + 1) * sizeof(ge);
             {
                 uint64_t items = (uint64_t)np * nside_small * P.W;
                 KSpan ks(C.tm, C.stream, ROFL_TK_MSM_SMALL, items * 7 + (uint64_t)PW * P.B * 10, (uint64_t)np * nside_small * (32 + 96));
                 hipLaunchKernelGGL(k_msm_small, dim3((unsigned)PW), dim3(P.B < 64 ? 64 : P.B), std::max(lds_lists, lds_red), C.stream, nside_small, mw, mm, d_probs, buckets,
-                                   S_fin_s, C_fin_s, P.c - 1, cnt);
+                                   S_fin_s, C_fin_s, P.c - 1, d_flag);
             }
-            HIPCHK(hipMemcpyAsync(C.h_ovf.as<u32>(4), cnt, 4, hipMemcpyDeviceToHost, C.stream));
         } else {
         // fixed-base launches: two-level bucket sort (coarse bins through HBM in full lines, then per-bin ranking in LDS)
         bool two = fb && allow_two && C.msm_two_level && 16 * opt.fb_stride <= ((size_t)1 << 24) && P.B == 32768;
@@ -568,9 +582,9 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
         if (two) {
             u32 *bins = C.msm_sorted.as<u32>(PW * tl.nbins * tl.cap_bin);
             u32 *bcur = C.msm_cur.as<u32>(PW * tl.nbins);
-            u32 *ovf_flag = cnt + PW * P.B;
+            u32 *ovf_flag = d_flag;
+            *h_flag = 0;
             HIPCHK(hipMemsetAsync(bcur, 0, sizeof(u32) * PW * tl.nbins, C.stream));
-            HIPCHK(hipMemsetAsync(ovf_flag, 0, 16, C.stream));
             u32 iter_pts = 16384 / mm.fb_wps; if (iter_pts < 1024) iter_pts = 1024;
             u32 tile = iter_pts;
             while ((size_t)((n_side2 + tile - 1) / tile) * PW > 512 && tile < n_side2) tile *= 2;
@@ -587,7 +601,6 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
                 hipLaunchKernelGGL(k_msm_accumulate_fb, grid1((size_t)Wb * P.B, (u32)nq), dim3(TPB), 0, C.stream, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, bins, perm, buckets, MSM_LIST_ABS, dbg_mask);
             }
             if (C.tm.enabled) HIPCHK(hipEventRecord(e1, C.stream));
-            HIPCHK(hipMemcpyAsync(C.h_ovf.as<u32>(4), ovf_flag, 4, hipMemcpyDeviceToHost, C.stream));
         } else {
         HIPCHK(hipMemsetAsync(cnt, 0, sizeof(u32) * (PW * P.B + 4), C.stream));
         // accumulate sees `nq` problems of Wb bucket arrays each; its points come from d_probs[q * (np / nq)]
@@ -646,27 +659,20 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
             S_in = S_out; C_in = C_out; E = E8; nb += 3; lv++;
         }
         u32 nb_final = P.c - 1;
-        ge *S_fin = C.msm_S[lv & 1].as<ge>(PW);
-        ge *C_fin = C.msm_C[lv & 1].as<ge>(PW * (size_t)nb_final);
+        ge *S_fin = dev_horner ? C.msm_S[lv & 1].as<ge>(PW) : hres_dev;
+        ge *C_fin = dev_horner ? C.msm_C[lv & 1].as<ge>(PW * (size_t)nb_final) : hres_dev + PW;
         // block size = first-level work items (small bucket arrays, c = 7: 32 items -- a 256-thread block would idle 7 of its 8
         // waves and, at 163 VGPRs, hold a whole CU: thousands of such blocks (n_partition = 64) ran 18 deep per CU)
         u32 fused_items = (E / 8) * (4 + nb), fused_threads = fused_items > 256 ? 512 : fused_items > 128 ? 256 : fused_items > 64 ? 128 : 64;
         size_t lds = ((size_t)(E / 8) * (1 + nb + 3) + (size_t)(E / 16) * (1 + nb + 4) + 1) * sizeof(ge);
         if (!small) hipLaunchKernelGGL(k_msm_reduce_fused, dim3((unsigned)PW), dim3(fused_threads), lds, C.stream, E, nb, S_in, C_in, S_fin, C_fin, nb_final);
         ks_red.reset();
-        size_t per = 1 + nb_final;
-        ge *hres = C.h_res.as<ge>(PW * per);
-        dev_horner = !fb && np >= C.msm_dev_horner_min && P.W <= 64;
-        if (dev_horner) {      // many problems: their Horner chains run side by side on the device, one point per problem comes back
-            ge *d_fin = C.msm_fin.as<ge>(np);
-            hipLaunchKernelGGL(k_msm_horner, dim3((unsigned)np), dim3(64), 0, C.stream, mw, (const ge *)S_fin, (const ge *)C_fin, nb_final, d_fin);
-            HIPCHK(hipMemcpyAsync(hres, d_fin, sizeof(ge) * np, hipMemcpyDeviceToHost, C.stream));
-        } else {
-            HIPCHK(hipMemcpyAsync(hres, S_fin, sizeof(ge) * PW, hipMemcpyDeviceToHost, C.stream));
-            HIPCHK(hipMemcpyAsync(hres + PW, C_fin, sizeof(ge) * PW * nb_final, hipMemcpyDeviceToHost, C.stream));
-        }
+        if (dev_horner)      // many problems: their Horner chains run side by side on the device, one point per problem comes back
+            hipLaunchKernelGGL(k_msm_horner, dim3((unsigned)np), dim3(64), 0, C.stream, mw, (const ge *)S_fin, (const ge *)C_fin, nb_final, hres_dev);
         if (opt.overlap && !overlap_done) { opt.overlap(); overlap_done = true; }
+        double t_sync0 = now_ms(); C.hs.enqueue += t_sync0 - t_enter;
         HIPCHK(hipStreamSynchronize(C.stream));
+        C.hs.sync += now_ms() - t_sync0; t_enter = now_ms();
         if (slots_mode && getenv("ROFL_TRACE")) fprintf(stderr, "[rofl] msm np=%zu n=%zu c=%u cap=%u fb=%u lr=%d overflow=%u\n", np, n, P.c, cap, fb ? sets : 0u, (int)lr, *C.h_ovf.as<u32>(4));
         if (small) {
             if (*C.h_ovf.as<u32>(4) != 0) { allow_small = false; attempt = 0; continue; }     // a bucket list overflowed: repeat through the general pipeline
@@ -678,14 +684,16 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
         break;
     }
     u32 nb = P.c - 1;
-    ge *h = C.h_res.as<ge>(PW * (1 + nb));
+    ge *h = C.h_res.as<ge>(PW * (size_t)P.c + np);
     double t0 = now_ms();
     results.resize(np);
+    std::vector<double> cpu_each(np, 0.0);
     if (dev_horner) {
         for (size_t p = 0; p < np; p++) results[p] = h51::from_ge(h[p]);
     } else if (fb_used) {
         // sets of a problem carry equal weight: add them up, then one 16-bit Horner
         C.pool->run(np, [&](size_t p) {
+            double tc0 = now_ms();
             size_t base = p * sets;                         // lr: problem 2q+side owns sets [(2q+side)*sets, ...)
             ge5 acc = h51::identity(); bool started = false;
             for (int l = 15; l >= 0; l--) {
@@ -693,10 +701,11 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
                 if (l <= 14) for (u32 s = 0; s < sets; s++) { acc = h51::gadd(acc, h51::from_ge(h[PW + (base + s) * nb + l])); started = true; }
                 if (l == 0) for (u32 s = 0; s < sets; s++) acc = h51::gadd(acc, h51::from_ge(h[base + s]));
             }
-            results[p] = acc;
+            results[p] = acc; cpu_each[p] = now_ms() - tc0;
         });
     } else {
         C.pool->run(np, [&](size_t p) {
+            double tc0 = now_ms();
             ge5 acc = h51::identity(); bool started = false;
             for (int w = (int)P.W - 1; w >= 0; w--) {
                 size_t pw = p * P.W + w;
@@ -707,10 +716,11 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
                     if (l == 0) { acc = h51::gadd(acc, h51::from_ge(h[pw])); started = true; }
                 }
             }
-            results[p] = acc;
+            results[p] = acc; cpu_each[p] = now_ms() - tc0;
         });
     }
     C.tm.t.host_ms += now_ms() - t0;
+    C.hs.horner_wall += now_ms() - t0; { double mx = 0; for (double v : cpu_each) mx = std::max(mx, v); C.hs.horner_cpu += mx; } C.hs.n++;
 }
 
 // ---------------------------------------------------------------- transcript helpers
@@ -869,16 +879,29 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
             hh = sc_montmul(hh, bit ? pui[c][q] : pu[c][q]);
         }
     };
+    sc *h_round = C.h_round.as<sc>(2 * P);
+    sc *a2 = C.a2.as<sc>(P * N), *b2 = C.b2.as<sc>(P * N);      // ping-pong partners of a, b (k_ipp_round folds out of place)
+    static const bool ipp_fused = !(getenv("ROFL_IPP_FUSED") && atoi(getenv("ROFL_IPP_FUSED")) == 0);
+    bool just_materialised = false;
     for (unsigned round = 0; round < lgN; round++) {
         size_t n_k = n_g >> r, nh = n_k / 2;
         sc *SL = C.SL.as<sc>(P * 2 * n_g), *SR = C.SR.as<sc>(P * 2 * n_g);
         bool merged = C.msm_lr != 0;
-        hipLaunchKernelGGL(k_ipp_scalars, grid1(n_g, (u32)P), dim3(TPB), 0, C.stream, (u32)n_g, (u32)n_k, r, d_cp, a, b, N, yinvpow, N, SL, SR, merged ? 1 : 0);
-        u32 nblkI = (u32)std::min<size_t>(32, (nh + TPB - 1) / TPB);
-        sc *ipart = C.tmp_out.as<sc>(P * 64 * 3);
-        hipLaunchKernelGGL(k_ipp_inner, dim3(nblkI, (u32)P), dim3(TPB), 0, C.stream, (u32)nh, a, b, N, ipart);
-        sc *h_ip = C.h_part.as<sc>(P * 64 * 3);
-        HIPCHK(hipMemcpyAsync(h_ip, ipart, sizeof(sc) * P * nblkI * 2, hipMemcpyDeviceToHost, C.stream));
+        bool fused = merged && ipp_fused && round > 0;           // one launch: fold by the previous challenge + this round's scalars + inner products
+        u32 nblkI;
+        sc *h_ip = C.h_ip.as<sc>(P * 256 * 2);                     // the partial sums land in mapped host memory
+        if (fused) {
+            nblkI = (u32)std::min<size_t>(256, std::max<size_t>(1, (n_g + 2 * TPB - 1) / (2 * TPB)));
+            int use_new = just_materialised ? 0 : 1;
+            hipLaunchKernelGGL(k_ipp_round, dim3(nblkI, (u32)P), dim3(TPB), 0, C.stream, (u32)n_g, (u32)n_k, use_new ? r - 1 : 0u, use_new, d_cp,
+                               (const sc *)C.h_round.dev<sc>(2 * P), (const sc *)a, (const sc *)b, a2, b2, N, yinvpow, N, SL, C.h_ip.dev<sc>(P * 256 * 2));
+            std::swap(a, a2); std::swap(b, b2);
+        } else {
+            hipLaunchKernelGGL(k_ipp_scalars, grid1(n_g, (u32)P), dim3(TPB), 0, C.stream, (u32)n_g, (u32)n_k, r, d_cp, a, b, N, yinvpow, N, SL, SR, merged ? 1 : 0);
+            nblkI = (u32)std::min<size_t>(32, (nh + TPB - 1) / TPB);
+            hipLaunchKernelGGL(k_ipp_inner, dim3(nblkI, (u32)P), dim3(TPB), 0, C.stream, (u32)nh, a, b, N, C.h_ip.dev<sc>(P * 256 * 2));
+        }
+        just_materialised = false;
         std::vector<MsmProb> pr(2 * P);
         for (size_t c = 0; c < P; c++) { pr[2 * c] = MsmProb{cur[c], SL + c * 2 * n_g}; pr[2 * c + 1] = MsmProb{cur[c], (merged ? SL : SR) + c * 2 * n_g}; }
         C.tm.t.msm_terms += P * 2 * n_g;
@@ -888,7 +911,9 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
         msm_run(C, pr, 2 * n_g, res, mo);
         mark("round msm", (long)(2 * n_g));
         th = now_ms();
+        std::vector<double> rh_cpu(P, 0.0);
         C.pool->run(P, [&](size_t c) {
+            double tc0 = now_ms();
             uint8_t *o = proofs_out[c] + 7 * 32 + 64 * round;
             sc cL = h_canon(sum_partials(h_ip + c * nblkI * 2, nblkI, 2, 0));
             sc cR = h_canon(sum_partials(h_ip + c * nblkI * 2, nblkI, 2, 1));
@@ -897,16 +922,20 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
             tr_append_point(tr[c], "L", L, o); tr_append_point(tr[c], "R", R, o + 32);
             sc u = tr[c].challenge_scalar("u");
             sc um = h_mont(u), uim = h51::sc_invert_mont_fast(um);
-            h_cp[c].u[0] = um; h_cp[c].uinv[0] = uim;
+            h_round[2 * c] = um; h_round[2 * c + 1] = uim;          // mapped: k_ipp_fold_ab reads it and records it in the chunk's pending list
             h_cp[c].pend_u[pu[c].size()] = um; h_cp[c].pend_ui[pu[c].size()] = uim;
             pu[c].push_back(um); pui[c].push_back(uim);
+            rh_cpu[c] = now_ms() - tc0;
         });
         C.tm.t.host_ms += now_ms() - th;
-        HIPCHK(hipMemcpyAsync(d_cp, h_cp, sizeof(ChunkParams) * P, hipMemcpyHostToDevice, C.stream));
-        hipLaunchKernelGGL(k_ipp_fold_ab, grid1(nh, (u32)P), dim3(TPB), 0, C.stream, (u32)nh, d_cp, a, b, N);
+        C.hs.host_wall += now_ms() - th; { double mx = 0; for (double v : rh_cpu) mx = std::max(mx, v); C.hs.host_cpu += mx; }
+        bool last = (round + 1 == lgN);
+        // the fold of a, b by this challenge happens inside the next round's k_ipp_round; only the old three-kernel path and the
+        // last round (whose result is the proof's final a, b) fold here
+        if (last || !(merged && ipp_fused))
+            hipLaunchKernelGGL(k_ipp_fold_ab, grid1(nh, (u32)P), dim3(TPB), 0, C.stream, (u32)nh, d_cp, (const sc *)C.h_round.dev<sc>(2 * P), r, a, b, N);
         mark("round host");
         r++;
-        bool last = (round + 1 == lgN);
         unsigned t_now = first_level ? (unsigned)C.fold_t1 : (unsigned)C.fold_t;
         // fold_min is a per-chunk size chosen for P = 4 (below it the fold kernel is latency-bound); what matters is the number of
         // outputs in the launch, so many small chunks (n_partition = 64) keep folding down to 64 generators each
@@ -1012,7 +1041,7 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
             HIPCHK(hipStreamSynchronize(C.stream));   // digit / problem staging buffers are reused next time
             mark("fold", (long)n_new);
             for (size_t c = 0; c < P; c++) { cur[c] = gnew + c * 2 * n_new; pu[c].clear(); pui[c].clear(); }
-            n_g = n_new; r = 0; gsel ^= 1; first_level = false;
+            n_g = n_new; r = 0; gsel ^= 1; first_level = false; just_materialised = true;
         }
     }
     // a[0], b[0]
@@ -1025,6 +1054,11 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
     for (size_t c = 0; c < P; c++) {
         uint8_t *o = proofs_out[c] + 7 * 32 + 64 * lgN;
         sc_tobytes(o, h_canon(h_ab[2 * c])); sc_tobytes(o + 32, h_canon(h_ab[2 * c + 1]));
+    }
+    if (ptrace) {
+        fprintf(stderr, "[rofl-hops] %d msm calls: enqueue %.3f ms, sync wait %.3f, horner wall %.3f (max task cpu %.3f), round-host wall %.3f (max task cpu %.3f)\n",
+                C.hs.n, C.hs.enqueue, C.hs.sync, C.hs.horner_wall, C.hs.horner_cpu, C.hs.host_wall, C.hs.host_cpu);
+        C.hs = Ctx::HopStats();
     }
 }
 

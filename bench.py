@@ -402,6 +402,28 @@ def run_rank(args):
             out["clients_in_flight"] = {"clients": CIF, "elements_per_s": nb * CIF * D / el, "ms_per_batch": el / nb * 1e3,
                                         "host_cores_busy": round(((ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)) / el, 2),
                                         "note": "NOT the BASELINE metric: C independent clients create+verify concurrently on one GPU (separate figure)"}
+        # (c) the same C clients as ONE batched call each way (rofl_create_rangeproof_batch / rofl_verify_rangeproof_batch): one host thread,
+        #     one launch sequence, every IPP round carries the L / R problems of all clients
+        if CIF > 1:
+            more = [synth_client(88000 + j) for j in range(CIF)]
+            nonces = [R.Nonce.seeded(bytes([100 + j]) * 32) for j in range(CIF)]
+
+            def batched(tag):
+                res = rpv.create_rangeproof_batch([m[0] for m in more], [m[1] for m in more], NBITS, NPART, nonces=nonces, fp=FP)
+                oks = rpv.verify_rangeproof_batch([r[0] for r in res], [r[1] for r in res], NBITS, verifier_seed=bytes([tag % 256]) * 32, fp=FP)
+                assert all(oks)
+            batched(0); batched(1)
+            nb = max(3, K // 2)
+            ru0 = resource.getrusage(resource.RUSAGE_SELF)
+            t0 = time.perf_counter()
+            for b in range(nb):
+                batched(b + 2)
+            el = time.perf_counter() - t0
+            ru1 = resource.getrusage(resource.RUSAGE_SELF)
+            out["batched_clients"] = {"clients": CIF, "elements_per_s": nb * CIF * D / el, "ms_per_batch": el / nb * 1e3,
+                                      "host_cores_busy": round(((ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)) / el, 2),
+                                      "note": "NOT the BASELINE metric: C clients proved by one rofl_create_rangeproof_batch call and verified by one "
+                                              "rofl_verify_rangeproof_batch call from a single host thread"}
         if not args.no_l2:
             out["l2_composite"] = l2_composite(R)
         if not args.no_cpu_baseline:

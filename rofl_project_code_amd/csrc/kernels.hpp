@@ -1228,10 +1228,15 @@ __device__ __forceinline__ void msm_reduce_item_split(u32 E, u32 nb, const ge *S
     }
 }
 #if ROFL_KG(1)
-__global__ void __launch_bounds__(TPB) k_msm_reduce_level(u32 E, u32 nb, const ge *S_in, const ge *C_in, ge *S_out, ge *C_out) {
+__global__ void __launch_bounds__(TPB) k_msm_reduce_level(u32 E, u32 nb, const ge *S_in, const ge *C_in, ge *S_out, ge *C_out, int split) {
     u32 pw = blockIdx.y, E8 = E / 8;
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= E8 * (1 + nb)) return;       // throughput-bound here: 11 additions per 8-group beat the 16 of the split form
+    if (split) {      // the four outputs of an 8-group on four threads: 7 / 3 / 3 / 3 additions deep instead of 11 on one thread
+        if (t >= E8 * (4 + nb)) return;
+        msm_reduce_item_split(E, nb, S_in + (size_t)pw * E, C_in + (size_t)pw * nb * E, S_out + (size_t)pw * E8, C_out + (size_t)pw * (nb + 3) * E8, t);
+        return;
+    }
+    if (t >= E8 * (1 + nb)) return;
     msm_reduce_item(E, nb, S_in + (size_t)pw * E, C_in + (size_t)pw * nb * E, S_out + (size_t)pw * E8, C_out + (size_t)pw * (nb + 3) * E8, t);
 }
 #endif
@@ -1275,6 +1280,35 @@ __global__ void __launch_bounds__(512) k_msm_reduce_fused(u32 E, u32 nb, const g
     extern __shared__ __align__(16) unsigned char smem[];
     u32 pw = blockIdx.x;
     msm_reduce_fused_body(E, nb, S_in + (size_t)pw * E, C_in + (size_t)pw * nb * E, S_fin + pw, C_fin + (size_t)pw * nb_final, smem);
+}
+#endif
+// Two-launch bucket reduction (round 2) for arrays of B = 512 * G buckets: k_msm_reduce_fused treats every run of 512 buckets as an
+// array of its own (E = 512, nb = 0: one block each, 64 x 16 blocks at B = 32768 instead of the 16 blocks that used to finish the
+// tree), then this kernel combines the G groups of an array: S = sum_g S_g; bit-sums 0..8 = sum_g D_(l,g); bit-sum 9 + t = sum of
+// the S_g of the groups whose index has bit t set (a bucket's 0-based index is g * 512 + low bits).  One block per array, one
+// output per threadIdx.y, G / 2 lanes per output + LDS tree.
+#if ROFL_KG(1)
+__global__ void __launch_bounds__(512) k_msm_reduce_groups(u32 G, u32 gbits, const ge *GS /* [PW][G] */, const ge *GC /* [PW][G][9] */, ge *S_fin, ge *C_fin, u32 nb_final) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    ge *lds = reinterpret_cast<ge *>(smem);                  // [nout][half]
+    u32 pw = blockIdx.x, o = threadIdx.y, t = threadIdx.x, half = blockDim.x;      // half = max(G / 2, 1)
+    const ge *gs = GS + (size_t)pw * G, *gc = GC + (size_t)pw * G * 9;
+    gd acc = gd_identity();
+    for (u32 g = t; g < G; g += half) {
+        if (o == 0) acc = gd_add(acc, load_gd(&gs[g]));
+        else if (o <= 9) acc = gd_add(acc, load_gd(&gc[(size_t)g * 9 + (o - 1)]));
+        else if ((g >> (o - 10)) & 1) acc = gd_add(acc, load_gd(&gs[g]));
+    }
+    lds[o * half + t] = gd_pack(acc);
+    __syncthreads();
+    for (u32 s2 = half / 2; s2 >= 1; s2 >>= 1) {
+        if (t < s2) lds[o * half + t] = gd_pack(gd_add(gd_unpack(lds[o * half + t]), gd_unpack(lds[o * half + t + s2])));
+        __syncthreads();
+    }
+    if (t == 0) {
+        if (o == 0) store_ge(&S_fin[pw], lds[0]);
+        else store_ge(&C_fin[(size_t)pw * nb_final + (o - 1)], lds[o * half]);
+    }
 }
 #endif
 // A small MSM (the IPP tail: a few thousand terms per problem) in ONE launch instead of memset / scatter / scan / accumulate /

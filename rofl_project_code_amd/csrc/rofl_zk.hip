@@ -245,7 +245,7 @@ struct Ctx {
     std::map<std::pair<size_t, size_t>, std::unique_ptr<GensEntry>> gens;   // (n, m) -> tables; primary lane only, under gens_mu
     u64 gens_tick = 0; size_t gens_budget = (size_t)96 << 30;   // ROFL_GENS_BUDGET_MB: evict least recently used (unpinned) tables beyond this
     u32 fold_pb = 32, fold_w = 8; size_t fold_tab_budget = (size_t)32 << 30;   // widest NAF whose table fits the per-(n, m) budget (ROFL_FOLD_W, ROFL_FOLD_TAB_MB)
-    int msm_lds = 1, msm_two_level = 1; size_t msm_lds_min = 8192, msm_lds_tile = 131072;
+    int msm_lds = 1, msm_two_level = 1, msm_group_reduce = 0; size_t msm_lds_min = 8192, msm_lds_tile = 131072;
     size_t msm_fb_threads = (size_t)1 << 19;
     int msm_fb = 1; u32 msm_fb_sets = 2; size_t msm_fb_min = (size_t)1 << 12; int msm_lr = 1;   // window tables for every (n, m) with 2N >= 4096: many small chunks (n_partition = 64) share them
     bool crowded() const { const Ctx *P = parent ? parent : this; return P->active_calls.load() > 1; }   // other calls in flight on this device
@@ -282,6 +282,7 @@ struct Ctx {
         HIPCHK(hipFuncSetAttribute((const void *)k_msm_reduce_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void *)k_msm_small, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void *)k_msm_scatter_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void *)k_msm_reduce_groups, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         HIPCHK(hipFuncSetAttribute((const void *)k_msm_bin_l1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void *)k_msm_bin_l2, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         HIPCHK(hipMalloc(&d_tabB, sizeof(niels) * 512));
@@ -298,6 +299,7 @@ struct Ctx {
         if (const char *e = getenv("ROFL_MSM_FB_THREADS")) { long v = atol(e); if (v >= 1) msm_fb_threads = (size_t)v; }
         if (const char *e = getenv("ROFL_MSM_LDS")) msm_lds = atoi(e);
         if (const char *e = getenv("ROFL_MSM_TWO_LEVEL")) msm_two_level = atoi(e);
+        if (const char *e = getenv("ROFL_MSM_GROUP_REDUCE")) msm_group_reduce = atoi(e);
         if (const char *e = getenv("ROFL_MSM_LDS_MIN")) { long v = atol(e); if (v >= 1) msm_lds_min = (size_t)v; }
         if (const char *e = getenv("ROFL_MSM_LDS_TILE")) { long v = atol(e); if (v >= 1024) msm_lds_tile = (size_t)v; }
         if (const char *e = getenv("ROFL_MSM_LR")) msm_lr = atoi(e);
@@ -324,7 +326,7 @@ struct Ctx {
         parent = &p; device = p.device;
         HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         ht = p.ht; d_tabB = p.d_tabB; d_tabBb = p.d_tabBb; d_two_pow = p.d_two_pow;
-        msm_lds = p.msm_lds; msm_two_level = p.msm_two_level; msm_lds_min = p.msm_lds_min; msm_lds_tile = p.msm_lds_tile;
+        msm_lds = p.msm_lds; msm_two_level = p.msm_two_level; msm_group_reduce = p.msm_group_reduce; msm_lds_min = p.msm_lds_min; msm_lds_tile = p.msm_lds_tile;
         msm_fb_threads = p.msm_fb_threads;
         msm_fb = p.msm_fb; msm_fb_sets = p.msm_fb_sets; msm_fb_min = p.msm_fb_min; msm_lr = p.msm_lr;
         fold_min = p.fold_min; msm_dev_horner_min = p.msm_dev_horner_min; msm_small_max = p.msm_small_max; msm_slots = p.msm_slots; fold_t = p.fold_t; fold_t1 = p.fold_t1; fold_k = p.fold_k; fold_tab = p.fold_tab;
@@ -651,21 +653,37 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
         { u32 e = P.B, b = 0; while (e > 512) { red_adds += (uint64_t)(e / 8) * (11 + 7 * b); e /= 8; b += 3; }
           red_adds += (uint64_t)(e / 8) * (16 + 7 * b); e /= 8; b += 3; while (e > 1) { red_adds += (uint64_t)(e / 2) * (1 + b); e /= 2; b++; } }
         std::unique_ptr<KSpan> ks_red(small ? nullptr : new KSpan(C.tm, C.stream, ROFL_TK_MSM_REDUCE, red_adds * PW * 9, (uint64_t)PW * P.B * 128));
+        u32 nb_final = P.c - 1;
+        ge *S_fin = dev_horner ? C.msm_S[1].as<ge>(PW) : hres_dev;
+        ge *C_fin = dev_horner ? C.msm_C[1].as<ge>(PW * (size_t)nb_final) : hres_dev + PW;
+        if (!small && C.msm_group_reduce && P.B >= 1024) {
+            // every run of 512 buckets reduced by its own block, then one block per array combines the groups (two launches, the
+            // first at full occupancy, instead of a chain of three whose last one ran on PW blocks)
+            u32 G = P.B / 512, gbits = P.c - 1 - 9;
+            ge *GS = C.msm_S[0].as<ge>(PW * G);
+            ge *GC = C.msm_C[0].as<ge>(PW * (size_t)G * 9);
+            size_t lds_a = ((size_t)64 * 4 + (size_t)32 * 5 + 1) * sizeof(ge);
+            hipLaunchKernelGGL(k_msm_reduce_fused, dim3((unsigned)(PW * G)), dim3(256), lds_a, C.stream, 512u, 0u, (const ge *)buckets, (const ge *)nullptr, GS, GC, 9u);
+            u32 half = G / 2 ? G / 2 : 1, nout = 10 + gbits;
+            hipLaunchKernelGGL(k_msm_reduce_groups, dim3((unsigned)PW), dim3(half, nout), (size_t)nout * half * sizeof(ge), C.stream, G, gbits, (const ge *)GS, (const ge *)GC, S_fin, C_fin, nb_final);
+        } else {
         while (!small && E > 512) {
             u32 E8 = E / 8;
             ge *S_out = C.msm_S[lv & 1].as<ge>(PW * E8);
             ge *C_out = C.msm_C[lv & 1].as<ge>(PW * (size_t)(nb + 3) * E8);
-            hipLaunchKernelGGL(k_msm_reduce_level, grid1((size_t)E8 * (1 + nb), (u32)PW), dim3(TPB), 0, C.stream, E, nb, S_in, C_in, S_out, C_out);
+            static const int red_split = getenv("ROFL_RED_SPLIT") ? atoi(getenv("ROFL_RED_SPLIT")) : 0;
+            hipLaunchKernelGGL(k_msm_reduce_level, grid1((size_t)E8 * ((red_split ? 4 : 1) + nb), (u32)PW), dim3(TPB), 0, C.stream, E, nb, S_in, C_in, S_out, C_out, red_split);
             S_in = S_out; C_in = C_out; E = E8; nb += 3; lv++;
         }
-        u32 nb_final = P.c - 1;
-        ge *S_fin = dev_horner ? C.msm_S[lv & 1].as<ge>(PW) : hres_dev;
-        ge *C_fin = dev_horner ? C.msm_C[lv & 1].as<ge>(PW * (size_t)nb_final) : hres_dev + PW;
+        if (dev_horner) { S_fin = C.msm_S[lv & 1].as<ge>(PW); C_fin = C.msm_C[lv & 1].as<ge>(PW * (size_t)nb_final); }
         // block size = first-level work items (small bucket arrays, c = 7: 32 items -- a 256-thread block would idle 7 of its 8
         // waves and, at 163 VGPRs, hold a whole CU: thousands of such blocks (n_partition = 64) ran 18 deep per CU)
+        static const u32 red_fused_max = getenv("ROFL_RED_FUSED_T") ? (u32)atoi(getenv("ROFL_RED_FUSED_T")) : 512u;
         u32 fused_items = (E / 8) * (4 + nb), fused_threads = fused_items > 256 ? 512 : fused_items > 128 ? 256 : fused_items > 64 ? 128 : 64;
+        if (fused_threads > red_fused_max) fused_threads = red_fused_max;
         size_t lds = ((size_t)(E / 8) * (1 + nb + 3) + (size_t)(E / 16) * (1 + nb + 4) + 1) * sizeof(ge);
         if (!small) hipLaunchKernelGGL(k_msm_reduce_fused, dim3((unsigned)PW), dim3(fused_threads), lds, C.stream, E, nb, S_in, C_in, S_fin, C_fin, nb_final);
+        }
         ks_red.reset();
         if (dev_horner)      // many problems: their Horner chains run side by side on the device, one point per problem comes back
             hipLaunchKernelGGL(k_msm_horner, dim3((unsigned)np), dim3(64), 0, C.stream, mw, (const ge *)S_fin, (const ge *)C_fin, nb_final, hres_dev);

@@ -202,6 +202,10 @@ def run_rank(args):
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     extras = rank == 0 and world == 1 and not args.no_extras
     CIF = args.clients_in_flight if args.clients_in_flight > 0 else max(1, min(6, int(avail_cores() / (2.5 * local_world))))
+    if avail_cores() / max(local_world, 1) < 2.5:
+        # a lone call spins while it waits for the GPU (lowest latency, ~2 host cores per rank with its pool threads); when the ranks of a
+        # node share fewer cores than that, wait by sleeping instead (+1 ms per client, ~0.9 cores per rank)
+        os.environ.setdefault("ROFL_BLOCKING_SYNC", "1")
     if extras:
         os.environ.setdefault("ROFL_LANES", str(max(3, CIF)))
         # one hardware queue per lane: the HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES (default 4) queues, read
@@ -320,7 +324,7 @@ def run_rank(args):
         "rccl_world_size": rccl_world, "collective_backend": backend if world > 1 else None,
         "config": {"workload": "BASELINE cfg 2: L-inf 32-bit range proof, d=25000 (resnet18_intrinsic_25k), 1 client create+verify per step per GPU, inputs handed over as host buffers (H2D inside the timed region)",
                    "d": D, "prove_range": NBITS, "n_partition": NPART, "fp_bits": FP_BITS, "fp_frac": FP_FRAC, "clients_per_step_per_gpu": 1,
-                   "host_cores": avail_cores(), "host_cores_busy": round(cpu_busy, 2),
+                   "host_cores": avail_cores(), "host_cores_busy": round(cpu_busy, 2), "wait_policy": "sleep" if os.environ.get("ROFL_BLOCKING_SYNC") == "1" else "spin",
                    "protocol": "warm-up steps, then K timed steps back to back; value = N*K*d / wall time of the K steps (max over ranks); median_ms_per_step = the reference bench's statistic (benches/rangeproof_bench.rs:53-85)"},
         "median_ms_per_step": median_ms, "min_ms_per_step": step_sorted[0], "max_ms_per_step": step_sorted[-1],
         "elements_per_s_at_median": D / (median_ms * 1e-3),

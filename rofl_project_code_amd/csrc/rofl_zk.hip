@@ -5,6 +5,7 @@
 // B_blinding, proof (de)serialisation.  Everything proportional to d * n_bits runs in kernels.hpp.
 #include <hip/hip_runtime.h>
 #include <chrono>
+#include <time.h>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -249,6 +250,25 @@ struct Ctx {
     size_t msm_fb_threads = (size_t)1 << 19;
     int msm_fb = 1; u32 msm_fb_sets = 2; size_t msm_fb_min = (size_t)1 << 12; int msm_lr = 1;   // window tables for every (n, m) with 2N >= 4096: many small chunks (n_partition = 64) share them
     bool crowded() const { const Ctx *P = parent ? parent : this; return P->active_calls.load() > 1; }   // other calls in flight on this device
+    // Waiting for the lane's stream.  hipStreamSynchronize spins (lowest latency: right for a call that is alone on the device); with
+    // other calls in flight -- or when the host asked for it (ROFL_BLOCKING_SYNC=1) -- the thread sleeps on a blocking event instead, so
+    // a server that keeps several clients in flight does not burn one host core per client on busy-waiting (ROFL_BLOCKING_SYNC=0: always spin).
+    int blocking_sync = -1; hipEvent_t ev_block = nullptr; bool batch_mode = false;
+    void sync() {
+        const Ctx *P = parent ? parent : this;
+        bool block = P->blocking_sync == 1 || (P->blocking_sync < 0 && (crowded() || batch_mode));
+        if (!block) { HIPCHK(hipStreamSynchronize(stream)); return; }
+        // (hipEventSynchronize on a hipEventBlockingSync event still keeps the calling thread runnable on this runtime -- measured: 100 %
+        //  of a core either way -- so the wait is a query loop with short sleeps: ~50 us of extra latency per wait, no CPU)
+        if (!ev_block) HIPCHK(hipEventCreateWithFlags(&ev_block, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(ev_block, stream));
+        for (;;) {
+            hipError_t q = hipEventQuery(ev_block);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) throw HipErr{q, "hipEventQuery"};
+            struct timespec ts = {0, 20000}; nanosleep(&ts, nullptr);
+        }
+    }
     struct Bsgs { uint8_t *keys; u32 *slots; u32 mask; };
     std::map<size_t, Bsgs> bsgs;                          // table_size -> baby-step table
     std::unique_ptr<HostPool> pool;
@@ -319,6 +339,7 @@ struct Ctx {
         if (const char *e = getenv("ROFL_FOLD_K")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) fold_k = v; }
         if (const char *e = getenv("ROFL_FOLD_THREADS")) { long v = atol(e); if (v > 0) fold_threads = v; }
         if (const char *e = getenv("ROFL_LANES")) { int v = atoi(e); if (v >= 1 && v <= 8) nlanes = v; }
+        if (const char *e = getenv("ROFL_BLOCKING_SYNC")) blocking_sync = atoi(e) != 0;
         inited = true;
         for (int i = 1; i < nlanes; i++) { Ctx *s = new Ctx(); s->init_lane(*this); sibs.push_back(s); }
     }
@@ -366,11 +387,11 @@ LaneLock acquire_lane(bool primary_only = false) {
     for (size_t i = 0; i < L; i++) {
         Ctx *c = i ? P.sibs[i - 1] : &P;
         std::unique_lock<std::mutex> t(c->mu, std::try_to_lock);
-        if (t.owns_lock()) { ll.c = c; ll.lk = std::move(t); return ll; }
+        if (t.owns_lock()) { ll.c = c; ll.lk = std::move(t); c->batch_mode = false; return ll; }
     }
     size_t i = primary_only ? 0 : P.rr.fetch_add(1) % L;    // all busy: queue on one of them
     Ctx *c = i ? P.sibs[i - 1] : &P;
-    ll.lk = std::unique_lock<std::mutex>(c->mu); ll.c = c;
+    ll.lk = std::unique_lock<std::mutex>(c->mu); ll.c = c; c->batch_mode = false;
     return ll;
 }
 
@@ -470,7 +491,7 @@ GensPin get_gens(Ctx &C, size_t n, size_t m) {
                 ent->wtab = wt; ent->bytes += sizeof(ndm) * 2 * N * 16;
             }
         }
-        HIPCHK(hipStreamSynchronize(C.stream));
+        C.sync();
     } catch (...) { gens_free_entry(ent.get()); throw; }
     ent->tick = ++P0.gens_tick; ent->users = 1;
     GensEntry *raw = ent.get();
@@ -689,7 +710,7 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
             hipLaunchKernelGGL(k_msm_horner, dim3((unsigned)np), dim3(64), 0, C.stream, mw, (const ge *)S_fin, (const ge *)C_fin, nb_final, hres_dev);
         if (opt.overlap && !overlap_done) { opt.overlap(); overlap_done = true; }
         double t_sync0 = now_ms(); C.hs.enqueue += t_sync0 - t_enter;
-        HIPCHK(hipStreamSynchronize(C.stream));
+        C.sync();
         C.hs.sync += now_ms() - t_sync0; t_enter = now_ms();
         if (slots_mode && getenv("ROFL_TRACE")) fprintf(stderr, "[rofl] msm np=%zu n=%zu c=%u cap=%u fb=%u lr=%d overflow=%u\n", np, n, P.c, cap, fb ? sets : 0u, (int)lr, *C.h_ovf.as<u32>(4));
         if (small) {
@@ -848,7 +869,7 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
     sc *h_t = C.h_part.as<sc>(P * 64 * 3);
     HIPCHK(hipMemcpyAsync(h_t, tpart, sizeof(sc) * P * nblkT * 3, hipMemcpyDeviceToHost, C.stream));
     HIPCHK(hipMemcpyAsync(h_sc, scpart, sizeof(sc) * P * nblkS * 3, hipMemcpyDeviceToHost, C.stream));
-    HIPCHK(hipStreamSynchronize(C.stream));
+    C.sync();
     th = now_ms();
     C.pool->run(P, [&](size_t c) {
         uint8_t *o = proofs_out[c];
@@ -1056,7 +1077,7 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
             }
             if (C.tm.enabled) { HIPCHK(hipEventRecord(e1, C.stream)); C.tm.fold_ev.push_back({e0, e1}); C.tm.t.fold_launches++; { char tg[96]; snprintf(tg, sizeof tg, "fold n_g=%zu nsrc=%u tab=%d", n_g, nsrc, (int)use_tab); C.tm.fold_tag.push_back(tg); } C.tm.t.fold_point_reads += (uint64_t)2 * P * n_g; }
             HIPCHK(hipMemcpyAsync(d_cp, h_cp, sizeof(ChunkParams) * P, hipMemcpyHostToDevice, C.stream));   // gscale / hscale
-            HIPCHK(hipStreamSynchronize(C.stream));   // digit / problem staging buffers are reused next time
+            C.sync();   // digit / problem staging buffers are reused next time
             mark("fold", (long)n_new);
             for (size_t c = 0; c < P; c++) { cur[c] = gnew + c * 2 * n_new; pu[c].clear(); pui[c].clear(); }
             n_g = n_new; r = 0; gsel ^= 1; first_level = false; just_materialised = true;
@@ -1068,7 +1089,7 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
         HIPCHK(hipMemcpyAsync(h_ab + 2 * c, a + c * N, sizeof(sc), hipMemcpyDeviceToHost, C.stream));
         HIPCHK(hipMemcpyAsync(h_ab + 2 * c + 1, b + c * N, sizeof(sc), hipMemcpyDeviceToHost, C.stream));
     }
-    HIPCHK(hipStreamSynchronize(C.stream));
+    C.sync();
     for (size_t c = 0; c < P; c++) {
         uint8_t *o = proofs_out[c] + 7 * 32 + 64 * lgN;
         sc_tobytes(o, h_canon(h_ab[2 * c])); sc_tobytes(o + 32, h_canon(h_ab[2 * c + 1]));
@@ -1316,6 +1337,7 @@ int create_impl(Ctx &C, size_t nc, const float *const *values, size_t d, const u
     size_t P = (dp + chunk - 1) / chunk;
     float mn, mx; clip_bounds(prove_range, fp_bits, fp_frac, &mn, &mx);
     C.init();
+    C.batch_mode = nc > 1;
     timing_begin(C);
     float *d_vals = C.vals.as<float>(nc * d);
     u64 *vshift = C.vshift.as<u64>(nc * dp);
@@ -1330,7 +1352,7 @@ int create_impl(Ctx &C, size_t nc, const float *const *values, size_t d, const u
     hipLaunchKernelGGL(k_quantize_shift, grid1(dp, (u32)nc), dim3(TPB), 0, C.stream, d_vals, (u32)d, (u32)dp, (u32)prove_range, fp_bits, fp_frac, mn, mx, vshift, status);
     u32 *h_status = C.h_misc.as<u32>(nc + 4);
     HIPCHK(hipMemcpyAsync(h_status, status, 4 * nc, hipMemcpyDeviceToHost, C.stream));
-    HIPCHK(hipStreamSynchronize(C.stream));
+    C.sync();
     // the reference's order of checks (range_proof_vec/mod.rs:22-29, then the upstream errors)
     bool any = false;
     for (size_t i = 0; i < nc; i++) {
@@ -1381,7 +1403,7 @@ int create_impl(Ctx &C, size_t nc, const float *const *values, size_t d, const u
     HIPCHK(hipMemcpyAsync(hV, Vb, na * dp * 32, hipMemcpyDeviceToHost, C.stream));
     for (size_t k = 0; k < na; k++) HIPCHK(hipMemcpyAsync(commits_out[act[k]], Cb + k * dp * 32, d * 32, hipMemcpyDeviceToHost, C.stream));
     GensPin gens_pin = get_gens(C, prove_range, chunk);
-    HIPCHK(hipStreamSynchronize(C.stream));       // V bytes (host copy) are complete
+    C.sync();       // V bytes (host copy) are complete
     std::vector<uint8_t *> pout(na * P);
     for (size_t k = 0; k < na; k++) for (size_t c = 0; c < P; c++) pout[k * P + c] = proofs_out[act[k]] + c * plen;
     prove_chunks(C, "RangeProof", na * P, prove_range, chunk, vshift, d_blind_buf, cn, hV, pout.data());
@@ -1428,6 +1450,7 @@ int verify_impl(Ctx &C, size_t n_clients, const uint8_t *const *proofs, size_t p
     if (!(prove_range == 8 || prove_range == 16 || prove_range == 32 || prove_range == 64)) return fail(ROFL_INVALID_BITSIZE, "proof rejected before verification (format / bitsize)");
     if (prove_range * chunk != ((size_t)1 << lg)) return ROFL_OK;      // VerificationError for every chunk -> Ok(false)
     C.init();
+    C.batch_mode = n_clients > 1;
     timing_begin(C);
     // shift up by 2^(range-1) B, pad with identity, compress (:155-167)
     niels h_shift = h51::to_niels32(h_fixed_mul(C.ht.B5, sc_from_u64(1ULL << (prove_range - 1))));
@@ -1447,7 +1470,7 @@ int verify_impl(Ctx &C, size_t n_clients, const uint8_t *const *proofs, size_t p
     HIPCHK(hipMemcpyAsync(hV.data(), d_enc, tot * 32, hipMemcpyDeviceToHost, C.stream));
     u32 *h_st = C.h_misc.as<u32>(n_clients + 4);
     HIPCHK(hipMemcpyAsync(h_st, status, 4 * n_clients, hipMemcpyDeviceToHost, C.stream));
-    HIPCHK(hipStreamSynchronize(C.stream));
+    C.sync();
     std::vector<char> bad_commit(n_clients, 0);
     for (size_t i = 0; i < n_clients; i++) bad_commit[i] = (h_st[i] & 4u) != 0;
     // a single set with an invalid encoding: the reference cannot even build its Vec<RistrettoPoint> (decompress fails) -> FormatError;
@@ -1466,7 +1489,7 @@ int verify_impl(Ctx &C, size_t n_clients, const uint8_t *const *proofs, size_t p
         }
     std::vector<int> okc(P);
     GensPin gens_pin = get_gens(C, prove_range, chunk);
-    HIPCHK(hipStreamSynchronize(C.stream));
+    C.sync();
     static const bool vbatch = !(getenv("ROFL_VERIFY_BATCH") && atoi(getenv("ROFL_VERIFY_BATCH")) == 0);
     size_t grp = vbatch ? nv : 1;
     // all (client, chunk) pairs in one pass; a client's chunks form one batch of the random-weighted check
@@ -1580,7 +1603,7 @@ int rofl_create_rangeproof_l2(const float *values, size_t d, const uint8_t *blin
         hipLaunchKernelGGL(k_commit, grid1(1), dim3(TPB), 0, C.stream, 1u, vshift, (const sc *)nullptr, d_bl, C.d_tabB, C.d_tabBb, (const niels *)nullptr, Vb, (uint8_t *)nullptr, 0u, 1u);
         uint8_t hV[32];
         HIPCHK(hipMemcpyAsync(hV, Vb, 32, hipMemcpyDeviceToHost, C.stream));
-        HIPCHK(hipStreamSynchronize(C.stream));
+        C.sync();
         // BulletproofGens::new(64, 1), label "L2RangeProof" (l2_range_proof_vec/mod.rs:156-171): the first
         // prove_range generators of party 0 are the same chain prefix.
         ChunkNonce cn{}; cn.mode = nonce->mode;
@@ -1611,7 +1634,7 @@ int rofl_verify_rangeproof_l2(const uint8_t *proof, size_t proof_len, const uint
         uint8_t hV[32]; u32 st = 0;
         HIPCHK(hipMemcpyAsync(hV, d_enc, 32, hipMemcpyDeviceToHost, C.stream));
         HIPCHK(hipMemcpyAsync(&st, status, 4, hipMemcpyDeviceToHost, C.stream));
-        HIPCHK(hipStreamSynchronize(C.stream));
+        C.sync();
         if (st & 4u) return fail(ROFL_FORMAT_ERROR, "commitment is not a valid Ristretto encoding");
         u64 cidx = 0; int ok = 0;
         int rc = verify_chunks(C, "L2RangeProof", 64, 1, prove_range, 1, proof, proof_len, hV, d_vn, verifier_seed, &cidx, &ok);
@@ -1661,7 +1684,7 @@ int sigma_create(int kind, const float *values, size_t d, const uint8_t *r1, siz
     HIPCHK(hipMemcpyAsync(proofs_out, dp, d * plen, hipMemcpyDeviceToHost, C.stream));
     HIPCHK(hipMemcpyAsync(commits_out, dc, d * clen, hipMemcpyDeviceToHost, C.stream));
     HIPCHK(hipMemcpyAsync(&st, status, 4, hipMemcpyDeviceToHost, C.stream));
-    HIPCHK(hipStreamSynchronize(C.stream));
+    C.sync();
     timing_end(C);
     if (st & 2u) return fail(ROFL_NON_FINITE, "non-finite value (the reference panics in fixed::saturating_from_float)");
     if (st & 4u) return fail(ROFL_FORMAT_ERROR, "invalid Ristretto encoding");
@@ -1682,7 +1705,7 @@ int sigma_verify(int kind, const uint8_t *proofs, const uint8_t *commits, size_t
     hipLaunchKernelGGL(k_sigma_verify, dim3((unsigned)((d + 63) / 64)), dim3(64), 0, C.stream, kind, (u32)d, dp, dc, sigma_init_state(kind), C.d_tabB, C.d_tabBb, status + 1, status);
     u32 st[2] = {0, 0};
     HIPCHK(hipMemcpyAsync(st, status, 8, hipMemcpyDeviceToHost, C.stream));
-    HIPCHK(hipStreamSynchronize(C.stream));
+    C.sync();
     timing_end(C);
     if (st[0] & 4u) return fail(ROFL_FORMAT_ERROR, "FormatError: non-canonical scalar or invalid point");
     *ok_out = st[1] == 0;
@@ -1722,7 +1745,7 @@ int compressed_create(const float *values, size_t d, const uint8_t *r32, size_t 
     }
     u32 st = 0;
     HIPCHK(hipMemcpyAsync(&st, status, 4, hipMemcpyDeviceToHost, C.stream));
-    HIPCHK(hipStreamSynchronize(C.stream));
+    C.sync();
     if (st & 2u) return fail(ROFL_NON_FINITE, "non-finite value (the reference panics in fixed::saturating_from_float)");
     if (st & 4u) return fail(ROFL_FORMAT_ERROR, "invalid Ristretto encoding");
     // nonces m', r' (party.rs:66-67), C' = commit(m', r')
@@ -1744,7 +1767,7 @@ int compressed_create(const float *values, size_t d, const uint8_t *r32, size_t 
         hipLaunchKernelGGL(k_cpow_dot, dim3(nblk), dim3(TPB), 0, C.stream, (u32)d, dv, fp_bits, fp_frac, dr, cp, part);
         sc hp[128];
         HIPCHK(hipMemcpyAsync(hp, part, sizeof(sc) * nblk * 2, hipMemcpyDeviceToHost, C.stream));
-        HIPCHK(hipStreamSynchronize(C.stream));
+        C.sync();
         zm = sc_add(zm, h_canon(sum_partials(hp, nblk, 2, 0))); zr = sc_add(zr, h_canon(sum_partials(hp, nblk, 2, 1)));
     }
     sc_tobytes(proof_out + 64, zm); sc_tobytes(proof_out + 96, zr);
@@ -1773,7 +1796,7 @@ int compressed_verify(const uint8_t *proof, const uint8_t *pairs, size_t d, int 
         hipLaunchKernelGGL(k_cpow_scalars, grid1(d), dim3(TPB), 0, C.stream, (u32)d, cp, scal);
         u32 st = 0;
         HIPCHK(hipMemcpyAsync(&st, status, 4, hipMemcpyDeviceToHost, C.stream));
-        HIPCHK(hipStreamSynchronize(C.stream));
+        C.sync();
         if (st & 4u) return fail(ROFL_FORMAT_ERROR, "FormatError: invalid ElGamal pair");
         std::vector<MsmProb> pr = {MsmProb{pts, scal}, MsmProb{pts + d, scal}}; std::vector<ge5> res;
         msm_run(C, pr, d, res);          // sum_i c^(i+1) L_i and sum_i c^(i+1) R_i share the scalars
@@ -1829,7 +1852,7 @@ int rofl_commit_vec(const uint8_t *values32, const uint8_t *blindings32, size_t 
         if (db) HIPCHK(hipMemcpyAsync(db, blindings32, 32 * d, hipMemcpyHostToDevice, C.stream));
         hipLaunchKernelGGL(k_commit, grid1(d), dim3(TPB), 0, C.stream, (u32)d, (const u64 *)nullptr, dv, db, C.d_tabB, C.d_tabBb, (const niels *)nullptr, (uint8_t *)nullptr, o, (u32)d, (u32)d);
         HIPCHK(hipMemcpyAsync(out32, o, 32 * d, hipMemcpyDeviceToHost, C.stream));
-        HIPCHK(hipStreamSynchronize(C.stream));
+        C.sync();
         return ROFL_OK;
     });
 }
@@ -1847,7 +1870,7 @@ int rofl_add_points_vec(const uint8_t *a32, const uint8_t *b32, size_t d, uint8_
         u32 st = 0;
         HIPCHK(hipMemcpyAsync(out32, o, 32 * d, hipMemcpyDeviceToHost, C.stream));
         HIPCHK(hipMemcpyAsync(&st, status, 4, hipMemcpyDeviceToHost, C.stream));
-        HIPCHK(hipStreamSynchronize(C.stream));
+        C.sync();
         if (st & 4u) return fail(ROFL_FORMAT_ERROR, "invalid Ristretto encoding");
         return ROFL_OK;
     });
@@ -1868,7 +1891,7 @@ int rofl_sum_points(const uint8_t *points, size_t d, size_t stride, uint8_t out3
         std::vector<ge> hp(nblk); u32 st = 0;
         HIPCHK(hipMemcpyAsync(hp.data(), part, sizeof(ge) * nblk, hipMemcpyDeviceToHost, C.stream));
         HIPCHK(hipMemcpyAsync(&st, status, 4, hipMemcpyDeviceToHost, C.stream));
-        HIPCHK(hipStreamSynchronize(C.stream));
+        C.sync();
         if (st & 4u) return fail(ROFL_FORMAT_ERROR, "invalid Ristretto encoding");
         ge5 acc = h51::identity();
         for (u32 i = 0; i < nblk; i++) acc = h51::gadd(acc, h51::from_ge(hp[i]));
@@ -1893,7 +1916,7 @@ int rofl_shift_points(const uint8_t *a32, size_t d, const uint8_t offset32[32], 
         u32 st = 0;
         HIPCHK(hipMemcpyAsync(out32, o, 32 * d, hipMemcpyDeviceToHost, C.stream));
         HIPCHK(hipMemcpyAsync(&st, status, 4, hipMemcpyDeviceToHost, C.stream));
-        HIPCHK(hipStreamSynchronize(C.stream));
+        C.sync();
         if (st & 4u) return fail(ROFL_FORMAT_ERROR, "invalid Ristretto encoding");
         return ROFL_OK;
     });
@@ -1976,7 +1999,7 @@ int rofl_dbg_msm(const uint8_t *scalars32, const uint8_t *points32, size_t n, ui
         hipLaunchKernelGGL(k_decode, grid1(n), dim3(TPB), 0, C.stream, (u32)n, (u32)n, dp, (const niels *)nullptr, dn, (uint8_t *)nullptr, status);
         u32 st = 0;
         HIPCHK(hipMemcpyAsync(&st, status, 4, hipMemcpyDeviceToHost, C.stream));
-        HIPCHK(hipStreamSynchronize(C.stream));
+        C.sync();
         if (st & 4u) return fail(ROFL_FORMAT_ERROR, "invalid Ristretto encoding");
         std::vector<MsmProb> pr(1, MsmProb{dn, ds}); std::vector<ge5> res;
         msm_run(C, pr, n, res);
@@ -2013,7 +2036,7 @@ int rofl_discrete_log_vec(const uint8_t *points32, size_t d, size_t table_size, 
         u32 st = 0;
         HIPCHK(hipMemcpyAsync(scalars_out32, dout, 32 * d, hipMemcpyDeviceToHost, C.stream));
         HIPCHK(hipMemcpyAsync(&st, status, 4, hipMemcpyDeviceToHost, C.stream));
-        HIPCHK(hipStreamSynchronize(C.stream));
+        C.sync();
         timing_end(C);
         if (st & 4u) return fail(ROFL_FORMAT_ERROR, "invalid Ristretto encoding");
         if (st & 8u) return fail(ROFL_BAD_PARAM, "discrete log not found (the reference unwraps None)");

@@ -814,6 +814,23 @@ __device__ __forceinline__ int msm_digit(const sc &k, u32 wpos, u32 c) {
     u32 V = x >> 1, bm1 = x & 1, top = (V >> (c - 1)) & 1;
     return (int)(V & ((1u << (c - 1)) - 1)) + (int)bm1 - (int)(top << (c - 1));
 }
+// the same digit with the scalar's 32-bit words read from memory at run-time indices: indexing a register-resident sc with a
+// run-time limb number makes the compiler spill it to scratch (36 B/lane in the sort kernels, and PMC showed the spills as HBM writes)
+__device__ __forceinline__ int msm_digit_mem(const u32 *kw, u32 wpos, u32 c) {
+    int pos = (int)wpos - 1;
+    u32 need = c + 1;
+    u64 bits;
+    if (pos < 0) {
+        bits = ((u64)kw[0] | ((u64)kw[1] << 32)) << 1;
+    } else {
+        u32 limb = (u32)pos >> 5, off = (u32)pos & 31;
+        u64 lo = limb < 8 ? kw[limb] : 0, mid = limb + 1 < 8 ? kw[limb + 1] : 0;
+        bits = (lo >> off) | (mid << (32 - off));
+    }
+    u32 x = (u32)(bits & ((1ULL << need) - 1));
+    u32 V = x >> 1, bm1 = x & 1, top = (V >> (c - 1)) & 1;
+    return (int)(V & ((1u << (c - 1)) - 1)) + (int)bm1 - (int)(top << (c - 1));
+}
 struct MsmProb { const niels *pts; const sc *scal; };   // per problem: points and canonical scalars
 // How the (term, window) grid maps to bucket arrays.
 //  * lr_nh != 0: "L/R merged" IPP round.  The grid runs over chunks; chunk q owns problems 2q (L) and 2q+1 (R), which
@@ -966,10 +983,10 @@ __global__ void __launch_bounds__(1024) k_msm_scatter_lds(u32 n_side, u32 tile_p
     __syncthreads();
     for (u32 k = k0 + threadIdx.x; k < k1; k += 1024) {
         u32 i = mm.lr_nh ? msm_side_term(mm, side, k) : k;
-        sc s = gload_sc(&scal[i]);
+        const u32 *kw = reinterpret_cast<const u32 *>(&scal[i]);
         for (u32 w = w0; w < w1; w++) {
             u32 wpos, wwid; msm_window(mw, w, wpos, wwid);
-            int d = msm_digit(s, wpos, wwid);
+            int d = msm_digit_mem(kw, wpos, wwid);
             u32 ad = (u32)(d < 0 ? -d : d);
             if (ad > B) { atomicAdd(&lcnt[B - 1], 1u); ad -= B; }
             if (ad) atomicAdd(&lcnt[ad - 1], 1u);
@@ -983,10 +1000,10 @@ __global__ void __launch_bounds__(1024) k_msm_scatter_lds(u32 n_side, u32 tile_p
     __syncthreads();
     for (u32 k = k0 + threadIdx.x; k < k1; k += 1024) {
         u32 i = mm.lr_nh ? msm_side_term(mm, side, k) : k;
-        sc s = gload_sc(&scal[i]);
+        const u32 *kw = reinterpret_cast<const u32 *>(&scal[i]);
         for (u32 w = w0; w < w1; w++) {
             u32 wpos, wwid; msm_window(mw, w, wpos, wwid);
-            int d = msm_digit(s, wpos, wwid);
+            int d = msm_digit_mem(kw, wpos, wwid);
             u32 ad = (u32)(d < 0 ? -d : d);
             u32 entry = (mm.fb_sets ? w * mm.fb_stride + i : i) | (d < 0 ? 0x80000000u : 0u);
             for (int rep = 0; rep < 2; rep++) {
@@ -1006,8 +1023,9 @@ __global__ void __launch_bounds__(1024) k_msm_scatter_lds(u32 n_side, u32 tile_p
 // bucket's slot list: a tile holds ~4 items per bucket, so each (tile, bucket) pair dirties a 64-byte sector for 16 useful bytes
 // (PMC: 600 MB written per launch for 134 MB of entries) and the scalars are decoded twice (count pass, place pass).  Here:
 //   level 1 (k_msm_bin_l1): one pass over the scalars; an item goes to the COARSE BIN of its bucket (bucket >> fbits; 256 bins per
-//     bucket array) through per-bin staging rows in LDS that are flushed as contiguous runs of ~48 items (one atomic per (iteration,
-//     bin) reserves the run in the bin's HBM region).  An item is one u32: entry (window-table index, `ebits` bits) | fine bucket
+//     bucket array) through per-bin staging rows in LDS that are flushed in whole 128-byte lines (one atomic per (iteration, bin)
+//     reserves a multiple of 32 entries in the bin's HBM region, so every line is written once; the < 32 left-overs of a tile go
+//     to the bin's small tail region).  An item is one u32: entry (window-table index, `ebits` bits) | fine bucket
 //     (fbits bits) | sign (bit 31).
 //   level 2 (k_msm_bin_l2): one block per (bucket array, bin) loads the bin (~8 K items), ranks it by fine bucket in LDS and writes
 //     it back IN PLACE as per-bucket lists, plus the count and the absolute list offset of each of its buckets.
@@ -1015,9 +1033,10 @@ __global__ void __launch_bounds__(1024) k_msm_scatter_lds(u32 n_side, u32 tile_p
 // A bin that outgrows its region (scalars built to collide) raises *overflow and the host repeats the MSM on the slot path.
 struct Msm2L { u32 nbins, fbits, ebits, cap_bin, stage; };      // stage = LDS staging slots per bin
 #define MSM_LIST_ABS 0xffffffffu
+#define MSM_BIN_TAIL 1024u      /* entries of a coarse bin's tail region: the < 32 left-overs of every tile, and staging-row spills */
 #if ROFL_KG(1)
-__global__ void __launch_bounds__(1024) k_msm_bin_l1(u32 n_side, u32 tile_pts, u32 iter_pts, MsmWin mw, MsmMap mm, const MsmProb *probs, u32 *bin_cursor /* [PW][nbins] */,
-                                                     u32 *bins /* [PW][nbins][cap_bin] */, Msm2L L, u32 *overflow) {
+__global__ void __launch_bounds__(1024) k_msm_bin_l1(u32 n_side, u32 tile_pts, u32 iter_pts, MsmWin mw, MsmMap mm, const MsmProb *probs, u32 *bin_cursor /* [PW][nbins][2] */,
+                                                     u32 *bins /* [PW][nbins][cap_bin] */, u32 *tails /* [PW][nbins][MSM_BIN_TAIL] */, Msm2L L, u32 *overflow) {
     extern __shared__ u32 sm2[];
     u32 *lcnt = sm2, *stage = sm2 + L.nbins;                       // [nbins], [nbins][L.stage]
     const u32 B = 1u << (mw.c - 1);
@@ -1029,20 +1048,21 @@ __global__ void __launch_bounds__(1024) k_msm_bin_l1(u32 n_side, u32 tile_pts, u
     u32 w0 = a * mm.fb_wps, w1 = w0 + mm.fb_wps;
     u32 k0 = blockIdx.x * tile_pts, k1 = k0 + tile_pts < n_side ? k0 + tile_pts : n_side;
     const sc *scal = probs[p].scal;
-    u32 *cur = bin_cursor + (size_t)pw * L.nbins;
+    u32 *cur = bin_cursor + (size_t)pw * L.nbins * 2;              // [bin][0] = entries in the bin's main region, [bin][1] = in its tail
     u32 *reg = bins + (size_t)pw * L.nbins * L.cap_bin;
+    u32 *tail = tails + (size_t)pw * L.nbins * MSM_BIN_TAIL;
     const u32 fmask = (1u << L.fbits) - 1;
     const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
+    for (u32 b = threadIdx.x; b < L.nbins; b += blockDim.x) lcnt[b] = 0;
+    __syncthreads();
     for (u32 base = k0; base < k1; base += iter_pts) {
-        for (u32 b = threadIdx.x; b < L.nbins; b += blockDim.x) lcnt[b] = 0;
-        __syncthreads();
         u32 kend = base + iter_pts < k1 ? base + iter_pts : k1;
         for (u32 k = base + threadIdx.x; k < kend; k += blockDim.x) {
             u32 i = mm.lr_nh ? msm_side_term(mm, side, k) : k;
-            sc s = gload_sc(&scal[i]);
+            const u32 *kw = reinterpret_cast<const u32 *>(&scal[i]);
             for (u32 w = w0; w < w1; w++) {
                 u32 wpos, wwid; msm_window(mw, w, wpos, wwid);
-                int d = msm_digit(s, wpos, wwid);
+                int d = msm_digit_mem(kw, wpos, wwid);
                 u32 ad = (u32)(d < 0 ? -d : d);
                 u32 entry = (w * mm.fb_stride + i) | (d < 0 ? 0x80000000u : 0u);
                 for (int rep = 0; rep < 2; rep++) {
@@ -1052,23 +1072,39 @@ __global__ void __launch_bounds__(1024) k_msm_bin_l1(u32 n_side, u32 tile_pts, u
                     u32 item = entry | ((bkt & fmask) << L.ebits);
                     u32 pos = atomicAdd(&lcnt[bin], 1u);
                     if (pos < L.stage) stage[bin * L.stage + pos] = item;
-                    else {                                          // a staging row ran full (skewed digits): straight to the bin
-                        u32 g = atomicAdd(&cur[bin], 1u);
-                        if (g < L.cap_bin) reg[(size_t)bin * L.cap_bin + g] = item; else *(volatile u32 *)overflow = 1u;
+                    else {                                          // a staging row ran full (skewed digits): one entry straight to the bin's tail
+                        u32 g = atomicAdd(&cur[2 * bin + 1], 1u);
+                        if (g < MSM_BIN_TAIL) tail[(size_t)bin * MSM_BIN_TAIL + g] = item; else *(volatile u32 *)overflow = 1u;
                     }
                 }
             }
         }
         __syncthreads();
-        for (u32 bin = wave; bin < L.nbins; bin += nwaves) {        // flush: one wave per bin, one reservation per (iteration, bin)
+        // Flush whole 128-byte lines only: every reservation in the main region is a multiple of 32 entries, so runs start
+        // line-aligned and no line is written twice.  What is left (< 32) stays at the front of the row for the next iteration;
+        // after the last iteration it goes to the bin's tail.
+        bool last_iter = kend == k1;
+        for (u32 bin = wave; bin < L.nbins; bin += nwaves) {
             u32 c = lcnt[bin]; if (c > L.stage) c = L.stage;
-            if (!c) continue;
-            u32 g = 0;
-            if (lane == 0) g = atomicAdd(&cur[bin], c);
-            g = __shfl(g, 0);
-            for (u32 j = lane; j < c; j += 64) {
-                if (g + j < L.cap_bin) reg[(size_t)bin * L.cap_bin + g + j] = stage[bin * L.stage + j];
-                else *(volatile u32 *)overflow = 1u;      // mapped host memory: plain, idempotent store
+            u32 full = c & ~31u, rem = c - full, g = 0;
+            if (full) {
+                if (lane == 0) g = atomicAdd(&cur[2 * bin], full);
+                g = __shfl(g, 0);
+                bool fits = g + full <= L.cap_bin;
+                if (!fits && lane == 0) *(volatile u32 *)overflow = 1u;      // mapped host memory: plain, idempotent store
+                for (u32 j = lane; j < full && fits; j += 64) reg[(size_t)bin * L.cap_bin + g + j] = stage[bin * L.stage + j];
+            }
+            u32 carry = (lane < rem) ? stage[bin * L.stage + full + lane] : 0u;      // rem < 32 <= 64 lanes
+            if (last_iter) {
+                if (rem) {
+                    if (lane == 0) g = atomicAdd(&cur[2 * bin + 1], rem);
+                    g = __shfl(g, 0);
+                    if (g + rem <= MSM_BIN_TAIL) { if (lane < rem) tail[(size_t)bin * MSM_BIN_TAIL + g + lane] = carry; }
+                    else if (lane == 0) *(volatile u32 *)overflow = 1u;
+                }
+            } else {
+                if (lane < rem) stage[bin * L.stage + lane] = carry;
+                if (lane == 0) lcnt[bin] = rem;
             }
         }
         __syncthreads();
@@ -1076,18 +1112,22 @@ __global__ void __launch_bounds__(1024) k_msm_bin_l1(u32 n_side, u32 tile_pts, u
 }
 #endif
 #if ROFL_KG(1)
-__global__ void __launch_bounds__(512) k_msm_bin_l2(Msm2L L, u32 B, const u32 *bin_cursor, u32 *bins, u32 *cnt /* [PW][B] */, u32 *off /* [PW][B] */) {
+__global__ void __launch_bounds__(512) k_msm_bin_l2(Msm2L L, u32 B, const u32 *bin_cursor, u32 *bins, const u32 *tails, u32 *cnt /* [PW][B] */, u32 *off /* [PW][B] */, u32 *overflow) {
     extern __shared__ u32 sm2[];
     const u32 FB = 1u << L.fbits;
     u32 *hist = sm2, *ofs = sm2 + FB, *out = sm2 + 2 * FB;          // [FB], [FB], [cap_bin]
     u32 bin = blockIdx.x, pw = blockIdx.y;
-    u32 n = bin_cursor[(size_t)pw * L.nbins + bin]; if (n > L.cap_bin) n = L.cap_bin;
+    u32 n = bin_cursor[((size_t)pw * L.nbins + bin) * 2], n2 = bin_cursor[((size_t)pw * L.nbins + bin) * 2 + 1];
+    if (n > L.cap_bin) n = L.cap_bin;
+    if (n2 > MSM_BIN_TAIL) n2 = MSM_BIN_TAIL;
+    if (n + n2 > L.cap_bin) { if (threadIdx.x == 0) *(volatile u32 *)overflow = 1u; n2 = L.cap_bin - n; }
     size_t rbase = ((size_t)pw * L.nbins + bin) * L.cap_bin;
     u32 *reg = bins + rbase;
+    const u32 *tl = tails + ((size_t)pw * L.nbins + bin) * MSM_BIN_TAIL;
     const u32 fmask = FB - 1, keep = ~(fmask << L.ebits);
     for (u32 f = threadIdx.x; f < FB; f += blockDim.x) hist[f] = 0;
     __syncthreads();
-    for (u32 j = threadIdx.x; j < n; j += blockDim.x) atomicAdd(&hist[(reg[j] >> L.ebits) & fmask], 1u);
+    for (u32 j = threadIdx.x; j < n + n2; j += blockDim.x) atomicAdd(&hist[((j < n ? reg[j] : tl[j - n]) >> L.ebits) & fmask], 1u);
     __syncthreads();
     if (threadIdx.x < 64) {                                          // exclusive scan of FB <= 128 counters by one wave
         u32 per = (FB + 63) / 64, lo = threadIdx.x * per, sum = 0;
@@ -1104,13 +1144,13 @@ __global__ void __launch_bounds__(512) k_msm_bin_l2(Msm2L L, u32 B, const u32 *b
         off[bi] = (u32)(rbase + ofs[f]);
     }
     __syncthreads();
-    for (u32 j = threadIdx.x; j < n; j += blockDim.x) {
-        u32 v = reg[j];
+    for (u32 j = threadIdx.x; j < n + n2; j += blockDim.x) {
+        u32 v = j < n ? reg[j] : tl[j - n];
         u32 pos = atomicAdd(&ofs[(v >> L.ebits) & fmask], 1u);
         out[pos] = v & keep;
     }
     __syncthreads();
-    for (u32 j = threadIdx.x; j < n; j += blockDim.x) reg[j] = out[j];
+    for (u32 j = threadIdx.x; j < n + n2; j += blockDim.x) reg[j] = out[j];
 }
 #endif
 // one 64-lane wave; lane l owns the overflow entries whose bucket index is l mod 64 (no two lanes share a bucket)
@@ -1146,8 +1186,12 @@ template <bool FB> __device__ __forceinline__ void msm_accumulate_body(u32 n, u3
     gd acc = gd_identity();
     // (a software-pipelined variant that keeps the next point load in flight costs 12 VGPRs -> 3 waves/SIMD and was slower;
     //  forcing 5 waves/SIMD -- 96 VGPRs, 136 B/lane of scratch -- takes 1.65x as long)
+    // the list entry of the NEXT addition is fetched one iteration ahead (one register): the entry -> point gather chain is two
+    // dependent memory latencies per addition otherwise
+    u32 vnext = num ? lst[0] : 0u;
     for (u32 e = 0; e < num; e++) {
-        u32 v = lst[e];
+        u32 v = vnext;
+        if (e + 1 < num) vnext = lst[e + 1];
         u32 idx = v & idx_mask;
         acc = gd_madd(acc, FB ? gload_ndm(reinterpret_cast<const ndm *>(pts) + idx) : gload_nd(&pts[idx]), (v >> 31) != 0);
     }
@@ -1332,7 +1376,7 @@ __global__ void __launch_bounds__(512) k_msm_small(u32 n_side, MsmWin mw, MsmMap
     const sc *scal = probs[p].scal;
     for (u32 k = threadIdx.x; k < n_side; k += blockDim.x) {
         u32 i = mm.lr_nh ? msm_side_term(mm, side, k) : k;
-        int d = msm_digit(gload_sc(&scal[i]), wpos, wwid);
+        int d = msm_digit_mem(reinterpret_cast<const u32 *>(&scal[i]), wpos, wwid);
         u32 ad = (u32)(d < 0 ? -d : d), entry = i | (d < 0 ? 0x80000000u : 0u);
         for (int rep = 0; rep < 2; rep++) {
             u32 a1 = rep == 0 ? (ad > B ? B : 0u) : (ad > B ? ad - B : ad);

@@ -281,7 +281,7 @@ struct Ctx {
     struct HopStats { double enqueue = 0, sync = 0, horner_wall = 0, horner_cpu = 0, host_wall = 0, host_cpu = 0; int n = 0; } hs;      // ROFL_TRACE: where the host hops go
     // workspace
     DevBuf cp, sL, sR, party, Scanon, vshift, blind, Vbytes, Cbytes, status, partial, partial2, scpart, a, b, a2, b2, yinv,
-        SL, SR, msm_cnt, msm_off, msm_cur, msm_perm, msm_sorted, msm_ovf, msm_buckets, msm_S[2], msm_C[2], msm_fin, msm_probs, powtabs, foldprobs, naf,
+        SL, SR, msm_cnt, msm_off, msm_cur, msm_tail, msm_perm, msm_sorted, msm_ovf, msm_buckets, msm_S[2], msm_C[2], msm_fin, msm_probs, powtabs, foldprobs, naf,
         gbuf[2], aux_pts, aux_scal, vscal, tmp_in, tmp_in2, tmp_out, vals, uni, stream_buf;
     PinBuf h_cp, h_res, h_part, h_misc, h_misc2, h_probs, h_auxc, h_auxs, h_ovf, h_V, h_ip, h_round, h_fdig, h_fprob;
     std::vector<MsmProb> probs_on_dev;      // what d_probs holds: an unchanged problem list is not uploaded again
@@ -604,18 +604,19 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
         two_used = two;
         if (two) {
             u32 *bins = C.msm_sorted.as<u32>(PW * tl.nbins * tl.cap_bin);
-            u32 *bcur = C.msm_cur.as<u32>(PW * tl.nbins);
+            u32 *bcur = C.msm_cur.as<u32>(PW * tl.nbins * 2);
+            u32 *btail = C.msm_tail.as<u32>(PW * tl.nbins * (size_t)MSM_BIN_TAIL);
             u32 *ovf_flag = d_flag;
             *h_flag = 0;
-            HIPCHK(hipMemsetAsync(bcur, 0, sizeof(u32) * PW * tl.nbins, C.stream));
+            HIPCHK(hipMemsetAsync(bcur, 0, sizeof(u32) * PW * tl.nbins * 2, C.stream));
             u32 iter_pts = 16384 / mm.fb_wps; if (iter_pts < 1024) iter_pts = 1024;
             u32 tile = iter_pts;
-            while ((size_t)((n_side2 + tile - 1) / tile) * PW > 512 && tile < n_side2) tile *= 2;
+            while (((size_t)((n_side2 + tile - 1) / tile) * PW > 512 || (n_side2 + tile - 1) / tile > 32) && tile < n_side2) tile *= 2;      // <= 32 tiles per array: their left-overs fit the bin tails
             dim3 grid((n_side2 + tile - 1) / tile, (u32)PW);
             uint64_t terms = (uint64_t)(lr ? nq : np) * n, items = terms * 16u;
             { KSpan ks(C.tm, C.stream, ROFL_TK_MSM_SCATTER, 0, terms * 32 + items * 4);
-              hipLaunchKernelGGL(k_msm_bin_l1, grid, dim3(1024), (size_t)(tl.nbins + tl.nbins * tl.stage) * 4, C.stream, n_side2, tile, iter_pts, mw, mm, d_probs, bcur, bins, tl, ovf_flag);
-              hipLaunchKernelGGL(k_msm_bin_l2, dim3(tl.nbins, (u32)PW), dim3(512), (size_t)(2 * 128 + tl.cap_bin) * 4, C.stream, tl, P.B, bcur, bins, cnt, off); }
+              hipLaunchKernelGGL(k_msm_bin_l1, grid, dim3(1024), (size_t)(tl.nbins + tl.nbins * tl.stage) * 4, C.stream, n_side2, tile, iter_pts, mw, mm, d_probs, bcur, bins, btail, tl, ovf_flag);
+              hipLaunchKernelGGL(k_msm_bin_l2, dim3(tl.nbins, (u32)PW), dim3(512), (size_t)(2 * 128 + tl.cap_bin) * 4, C.stream, tl, P.B, bcur, bins, (const u32 *)btail, cnt, off, ovf_flag); }
             hipLaunchKernelGGL(k_msm_scan, dim3((unsigned)PW), dim3(TPB), 0, C.stream, P.B, cnt, off, (u32 *)nullptr, perm);
             if (C.tm.enabled) { e0 = C.tm.get(); e1 = C.tm.get(); HIPCHK(hipEventRecord(e0, C.stream)); }
             {

@@ -25,6 +25,10 @@ extern "C" {
     pub fn rofl_create_rangeproof(values: *const c_float, d: usize, blindings32: *const u8, d_blindings: usize,
         prove_range: usize, n_partition: usize, fp_bits: c_uint, fp_frac: c_uint, nonce: *const RoflNonce,
         proofs_out: *mut u8, proof_len_out: *mut usize, n_proofs_out: *mut usize, commits_out: *mut u8) -> c_int;
+    pub fn rofl_create_rangeproof_batch(n_clients: usize, values: *const *const c_float, d: usize, blindings32: *const *const u8,
+        prove_range: usize, n_partition: usize, fp_bits: c_uint, fp_frac: c_uint, nonces: *const RoflNonce,
+        proofs_out: *const *mut u8, proof_len_out: *mut usize, n_proofs_out: *mut usize, commits_out: *const *mut u8,
+        rc_out: *mut c_int) -> c_int;
     pub fn rofl_verify_rangeproof(proofs: *const u8, proof_len: usize, n_proofs: usize, commits32: *const u8, d: usize,
         prove_range: usize, fp_bits: c_uint, fp_frac: c_uint, verifier_seed: *const u8, ok_out: *mut c_int) -> c_int;
     pub fn rofl_verify_rangeproof_batch(n_clients: usize, proofs: *const *const u8, proof_len: usize, n_proofs: usize,

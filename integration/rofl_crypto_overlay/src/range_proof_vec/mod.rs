@@ -62,6 +62,10 @@ pub fn verify_rangeproof(
 }
 
 /// Not in the reference: all clients of a round in one call (server.rs:656-687 runs one pool task per client instead).
+/// The C entry point takes ONE (n_proofs, proof_len, d) for the whole batch and reads that many bytes from every client's
+/// buffers -- and all three are chosen by the clients (params.rs:513-541 deserialises whatever arrives).  So the clients are
+/// grouped by shape: the largest group goes through the batch entry, every other client through its own `verify_rangeproof`
+/// call (a malformed set counts as "not verified"), and nobody is ever read with somebody else's lengths.
 pub fn verify_rangeproof_batch(
     clients: &[(&Vec<RangeProof>, &Vec<RistrettoPoint>)],
     prove_range: usize,
@@ -69,14 +73,73 @@ pub fn verify_rangeproof_batch(
     if clients.is_empty() { return Ok(vec![]); }
     let pbs: Vec<Vec<u8>> = clients.iter().map(|(p, _)| p.iter().flat_map(|x| x.to_bytes()).collect()).collect();
     let cbs: Vec<Vec<u8>> = clients.iter().map(|(_, c)| points_to_bytes(c)).collect();
-    let pp: Vec<*const u8> = pbs.iter().map(|v| v.as_ptr()).collect();
-    let cp: Vec<*const u8> = cbs.iter().map(|v| v.as_ptr()).collect();
-    let (n_proofs, d) = (clients[0].0.len(), clients[0].1.len());
-    let seed = fresh_seed();
-    let mut ok = vec![0 as std::os::raw::c_int; clients.len()];
-    let rc = unsafe {
-        rofl_verify_rangeproof_batch(clients.len(), pp.as_ptr(), pbs[0].len() / n_proofs.max(1), n_proofs, cp.as_ptr(), d, prove_range,
-                                     fp_bits(), fp_frac(), seed.as_ptr(), ok.as_mut_ptr())
+    // shape of a client: (number of proofs, bytes per proof, number of commitments)
+    let shape = |i: usize| -> Option<(usize, usize, usize)> {
+        let (np, d) = (clients[i].0.len(), clients[i].1.len());
+        if np == 0 || d == 0 || pbs[i].len() % np != 0 { return None; }
+        Some((np, pbs[i].len() / np, d))
     };
-    match rc { ROFL_OK => Ok(ok.iter().map(|&b| b != 0).collect()), ROFL_FORMAT_ERROR => Err(ProofError::FormatError), _ => panic!("rofl_zk: {}", last_error()) }
+    let shapes: Vec<Option<(usize, usize, usize)>> = (0..clients.len()).map(shape).collect();
+    let mut major: Option<(usize, usize, usize)> = None; let mut best = 0;
+    for s in shapes.iter().flatten() {
+        let n = shapes.iter().filter(|t| **t == Some(*s)).count();
+        if n > best { best = n; major = Some(*s); }
+    }
+    let mut res = vec![false; clients.len()];
+    let (np, plen, d) = match major { Some(m) => m, None => return Ok(res) };
+    let idx: Vec<usize> = (0..clients.len()).filter(|&i| shapes[i] == major).collect();
+    for i in 0..clients.len() {
+        if shapes[i].is_some() && shapes[i] != major {
+            res[i] = verify_rangeproof(clients[i].0, clients[i].1, prove_range).unwrap_or(false);
+        }
+    }
+    let pp: Vec<*const u8> = idx.iter().map(|&i| pbs[i].as_ptr()).collect();
+    let cp: Vec<*const u8> = idx.iter().map(|&i| cbs[i].as_ptr()).collect();
+    let seed = fresh_seed();
+    let mut ok = vec![0 as std::os::raw::c_int; idx.len()];
+    let rc = unsafe {
+        rofl_verify_rangeproof_batch(idx.len(), pp.as_ptr(), plen, np, cp.as_ptr(), d, prove_range, fp_bits(), fp_frac(), seed.as_ptr(), ok.as_mut_ptr())
+    };
+    match rc {
+        ROFL_OK => { for (k, &i) in idx.iter().enumerate() { res[i] = ok[k] != 0; } Ok(res) }
+        ROFL_FORMAT_ERROR => Err(ProofError::FormatError),
+        ROFL_INVALID_BITSIZE => Err(ProofError::InvalidBitsize),
+        _ => panic!("rofl_zk: {}", last_error()),
+    }
+}
+
+/// Not in the reference: the updates of several clients hosted by one process (client.rs:265-266 runs them as tasks of one
+/// runtime) proved as ONE launch sequence.  Every client's result is bit-identical to `create_rangeproof` for it; a client whose own
+/// input is rejected gets its own `Err`, the others are proved.
+pub fn create_rangeproof_batch(
+    clients: &[(&Vec<f32>, &Vec<Scalar>)],
+    prove_range: usize,
+    n_partition: usize,
+) -> Vec<Result<(Vec<RangeProof>, Vec<RistrettoPoint>), RangeProofError>> {
+    if clients.is_empty() { return vec![]; }
+    let d = clients[0].0.len();
+    assert!(clients.iter().all(|(v, b)| v.len() == d && b.len() == d), "the clients of a batch have d values and d blindings each");
+    let bls: Vec<Vec<u8>> = clients.iter().map(|(_, b)| scalars_to_bytes(b)).collect();
+    let (n_proofs, plen) = unsafe { (rofl_rangeproof_chunks(d, n_partition), rofl_rangeproof_size(prove_range, d, n_partition)) };
+    let mut proofs: Vec<Vec<u8>> = clients.iter().map(|_| vec![0u8; n_proofs * plen]).collect();
+    let mut commits: Vec<Vec<u8>> = clients.iter().map(|_| vec![0u8; d * 32]).collect();
+    let nonces: Vec<RoflNonce> = clients.iter().map(|_| fresh_nonce()).collect();
+    let vp: Vec<*const f32> = clients.iter().map(|(v, _)| v.as_ptr()).collect();
+    let bp: Vec<*const u8> = bls.iter().map(|b| b.as_ptr()).collect();
+    let pp: Vec<*mut u8> = proofs.iter_mut().map(|p| p.as_mut_ptr()).collect();
+    let cp: Vec<*mut u8> = commits.iter_mut().map(|c| c.as_mut_ptr()).collect();
+    let mut rcs = vec![0 as std::os::raw::c_int; clients.len()];
+    let (mut plen_out, mut n_out) = (0usize, 0usize);
+    let rc = unsafe {
+        rofl_create_rangeproof_batch(clients.len(), vp.as_ptr(), d, bp.as_ptr(), prove_range, n_partition, fp_bits(), fp_frac(), nonces.as_ptr(),
+                                     pp.as_ptr(), &mut plen_out, &mut n_out, cp.as_ptr(), rcs.as_mut_ptr())
+    };
+    if rc == ROFL_INVALID_BITSIZE { return clients.iter().map(|_| Err(ProofError::InvalidBitsize.into())).collect(); }
+    if rc != ROFL_OK { panic!("Should not get here: {}", last_error()); }
+    (0..clients.len()).map(|i| match rcs[i] {
+        ROFL_OK => Ok((proofs[i][..n_out * plen_out].chunks(plen_out).map(|p| RangeProof::from_bytes(p).expect("librofl_zk proof layout")).collect(),
+                       bytes_to_points(&commits[i]))),
+        ROFL_VALUE_OUT_OF_RANGE => Err(RangeProofError::ValueOutOfRangeError),
+        _ => panic!("Should not get here: client {} of the batch, code {}", i, rcs[i]),
+    }).collect()
 }

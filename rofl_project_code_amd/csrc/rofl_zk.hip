@@ -251,12 +251,14 @@ struct Ctx {
     int msm_fb = 1; u32 msm_fb_sets = 2; size_t msm_fb_min = (size_t)1 << 12; int msm_lr = 1;   // window tables for every (n, m) with 2N >= 4096: many small chunks (n_partition = 64) share them
     bool crowded() const { const Ctx *P = parent ? parent : this; return P->active_calls.load() > 1; }   // other calls in flight on this device
     // Waiting for the lane's stream.  hipStreamSynchronize spins (lowest latency: right for a call that is alone on the device); with
-    // other calls in flight -- or when the host asked for it (ROFL_BLOCKING_SYNC=1) -- the thread sleeps on a blocking event instead, so
+    // more than three calls in flight -- or when the host asked for it (ROFL_BLOCKING_SYNC=1) -- the thread sleeps between queries instead, so
     // a server that keeps several clients in flight does not burn one host core per client on busy-waiting (ROFL_BLOCKING_SYNC=0: always spin).
     int blocking_sync = -1; hipEvent_t ev_block = nullptr; bool batch_mode = false;
     void sync() {
         const Ctx *P = parent ? parent : this;
-        bool block = P->blocking_sync == 1 || (P->blocking_sync < 0 && (crowded() || batch_mode));
+        // (up to three calls in flight still spin: the three proofs of ONE client's L2 update run side by side -- EncParamsL2::encrypt --
+        //  and that is a latency case; a server with more clients in flight is a throughput case)
+        bool block = P->blocking_sync == 1 || (P->blocking_sync < 0 && (P->active_calls.load() > 3 || batch_mode));
         if (!block) { HIPCHK(hipStreamSynchronize(stream)); return; }
         // (hipEventSynchronize on a hipEventBlockingSync event still keeps the calling thread runnable on this runtime -- measured: 100 %
         //  of a core either way -- so the wait is a query loop with short sleeps: ~50 us of extra latency per wait, no CPU)

@@ -67,8 +67,8 @@ def test_cfg4_chunk0_vs_oracle(R):
 
 
 def _sub(seed, tag, *witness):
-    wd = hashlib.sha3_256(b"".join(np.ascontiguousarray(a).tobytes() for a in witness)).digest()
-    return hashlib.sha3_256(b"rofl-zk/params/v2" + seed + tag + wd).digest()
+    from rofl_project_code_amd.params import witness_digest      # XXH3-128 / BLAKE2b over the raw witness bytes
+    return hashlib.sha3_256(b"rofl-zk/params/v2" + seed + tag + witness_digest(*witness)).digest()
 
 
 @pytest.mark.parametrize("d", [25000, 55000])

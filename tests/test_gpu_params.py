@@ -25,8 +25,8 @@ def R():
 
 def _sub(seed, tag, *witness):
     """params._sub_nonce restated: the seeded streams are bound to the witness arrays (values, blindings, ...)."""
-    wd = hashlib.sha3_256(b"".join(np.ascontiguousarray(a).tobytes() for a in witness)).digest()
-    return hashlib.sha3_256(b"rofl-zk/params/v2" + seed + tag + wd).digest()
+    from rofl_project_code_amd.params import witness_digest      # XXH3-128 / BLAKE2b over the raw witness bytes
+    return hashlib.sha3_256(b"rofl-zk/params/v2" + seed + tag + witness_digest(*witness)).digest()
 
 
 def _clip(vals, n):

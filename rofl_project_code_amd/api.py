@@ -152,7 +152,7 @@ class _KernelTime(ctypes.Structure):
     _fields_ = [("ms", ctypes.c_double), ("launches", ctypes.c_uint64), ("fe_muls", ctypes.c_uint64), ("bytes", ctypes.c_uint64)]
 
 
-KERNEL_KINDS = ("k_msm_accumulate_fb", "k_msm_accumulate_gen", "k_msm_scatter_lds", "k_msm_reduce_level+fused", "k_msm_small",
+KERNEL_KINDS = ("k_msm_accumulate_fb", "k_msm_accumulate_gen", "k_msm_bin_l1+l2 / k_msm_scatter_lds", "k_msm_reduce_level+fused", "k_msm_small",
                 "k_fold_gens_tab", "k_fold_gens", "other")
 
 

@@ -719,6 +719,46 @@ __global__ void __launch_bounds__(256, 4) k_fold_gens(u32 n_new, u32 nsrc, FoldS
 }
 #endif
 
+// The same fold for nsrc = 4 with the unit scalar on source 0 (every fold after the first at the default schedule): the three
+// sources that carry a scalar are loaded ONCE into registers (3 x 30 limbs) instead of being gathered again for each of the ~250
+// additions of the chain -- the chain is then pure VALU work with no memory latency in it.  Needs ~230 VGPRs: two waves per SIMD,
+// which is what the launch offers anyway (the digit positions are split into K segments to have more chains in flight).
+#if ROFL_KG(2)
+__global__ void __launch_bounds__(256, 2) k_fold_gens4(u32 n_new, FoldSeg seg, const FoldProb *probs, const int8_t *naf /* [prob][4][256] */) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    ge *lds = reinterpret_cast<ge *>(smem);
+    u32 q = blockIdx.y;
+    u32 i = blockIdx.x * 64 + threadIdx.x;
+    u32 k = threadIdx.y, K = blockDim.y;
+    bool active = i < n_new;
+    const niels *src = probs[q].src;
+    const int8_t *dg = naf + (size_t)q * 4 * 256;
+    gd acc = gd_identity();
+    if (active) {
+        const nd s1 = gload_nd(&src[(size_t)1 * n_new + i]), s2 = gload_nd(&src[(size_t)2 * n_new + i]), s3 = gload_nd(&src[(size_t)3 * n_new + i]);
+        int lo = seg.lo[k], hi = seg.lo[k + 1] - 1;
+        for (int bit = hi; bit >= lo; bit--) {
+            acc = gd_double(acc);
+            int d1 = dg[256 + bit], d2 = dg[512 + bit], d3 = dg[768 + bit];      // wave-uniform
+            if (d1 != 0) acc = gd_madd(acc, s1, d1 < 0);
+            if (d2 != 0) acc = gd_madd(acc, s2, d2 < 0);
+            if (d3 != 0) acc = gd_madd(acc, s3, d3 < 0);
+        }
+        for (int t = 0; t < lo; t++) acc = gd_double(acc);
+    }
+    if (K > 1) {
+        if (k > 0) lds[(k - 1) * 64 + threadIdx.x] = gd_pack(acc);
+        __syncthreads();
+        if (k == 0)
+            for (u32 s2i = 1; s2i < K; s2i++) acc = gd_add(acc, gd_unpack(lds[(s2i - 1) * 64 + threadIdx.x]));
+    }
+    if (active && k == 0) {
+        acc = gd_madd(acc, gload_nd(&src[i]), false);   // source 0 has scalar 1 (scale kept aside)
+        gstore_niels(&probs[q].dst[i], gd_to_niels(acc));
+    }
+}
+#endif
+
 // First materialisation: the sources are the FIXED generators, for which get_gens precomputed
 //   tbl16[(q*4+e)*stride + g] = (2e+1) * 2^(64q) * G_g      (q < 4, e < 4; affine niels)
 // so a 253-bit scalar becomes four 64-bit pieces in width-4 NAF: 64 doublings per output instead of 253 and

@@ -924,6 +924,7 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
     sc *h_round = C.h_round.as<sc>(2 * P);
     sc *a2 = C.a2.as<sc>(P * N), *b2 = C.b2.as<sc>(P * N);      // ping-pong partners of a, b (k_ipp_round folds out of place)
     static const bool ipp_fused = !(getenv("ROFL_IPP_FUSED") && atoi(getenv("ROFL_IPP_FUSED")) == 0);
+    static const bool fold_regs = !(getenv("ROFL_FOLD_REGS") && atoi(getenv("ROFL_FOLD_REGS")) == 0);
     bool just_materialised = false;
     for (unsigned round = 0; round < lgN; round++) {
         size_t n_k = n_g >> r, nh = n_k / 2;
@@ -1075,6 +1076,8 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
                 if (use_tab)
                     hipLaunchKernelGGL(k_fold_gens_tab, grid, block, (K - 1) * 64 * sizeof(ge), C.stream, (u32)n_new, nsrc, seg, fc, tbl, (size_t)(2 * N),
                                        (const FoldTabProb *)d_fpv, d_dig, unit);
+                else if (nsrc == 4 && unit && fold_regs)      // three scalar-carrying sources, kept in registers
+                    hipLaunchKernelGGL(k_fold_gens4, grid, block, (K - 1) * 64 * sizeof(ge), C.stream, (u32)n_new, seg, (const FoldProb *)d_fpv, d_dig);
                 else
                     hipLaunchKernelGGL(k_fold_gens, grid, block, (K - 1) * 64 * sizeof(ge), C.stream, (u32)n_new, nsrc, seg, (const FoldProb *)d_fpv, d_dig, unit);
             }

@@ -1622,6 +1622,8 @@ __device__ inline gd sg_var_mul(const sc &k, const gd &P) {
 }
 __device__ inline void sg_encode(uint8_t *out, const gd &p) { gd_ristretto_encode(out, p); }
 __device__ inline bool sg_decode(gd &p, const uint8_t *in) { bool ok = gd_ristretto_decode(p, in); if (!ok) p = gd_identity(); return ok; }
+// niels form of a freshly decoded point (gd_ristretto_decode leaves Z = 1: no inversion)
+__device__ inline niels sg_affine_niels(const gd &p) { niels r; r.ypx = fd_pack(fd_add(p.Y, p.X)); r.ymx = fd_pack(fd_sub(p.Y, p.X)); r.t2d = fd_pack(fd_mul(p.T, fd_d2())); return r; }
 __device__ inline bool sg_is_identity(const gd &p) { ge t = gd_pack(p); return ge_is_identity_ristretto(t); }
 
 // kind 0 RandProof (L|R ; L'|R'|Zm|Zr), 1 SquareRandProof (L|R|c_sq ; L'|R'|c_sq'|Zm|Zr1|Zr2), 2 SquareProof (c_l|c_sq ; c_l'|c_sq'|Zm|Zr1|Zr2)
@@ -1714,6 +1716,69 @@ __global__ void __launch_bounds__(64) k_sigma_verify(int kind, u32 d, const uint
 }
 #endif
 
+// Batched verification of the per-element Sigma-proofs (round 2).  The reference checks every element on its own (one task per
+// element, rand_proof_vec/mod.rs:93-118, square_rand_proof_vec/mod.rs:131-159) and returns ONE bool for the vector; each check costs
+// 2-4 variable-base scalar multiplications (~325 point operations each).  Here the 2-3 group equations of all d elements are folded
+// into a single random linear combination  sum_i (w1_i e1_i + w2_i e2_i + w3_i e3_i) == 0  -- one Pippenger MSM over the 4-6 d decoded
+// points (~16 mixed additions per point) plus two fixed-base terms -- exactly the trick upstream's verify_multiple uses for range
+// proofs.  A forged element passes with probability 2^-252 (the weights come from fresh OS randomness).  This kernel does the
+// per-element part: decode + validity (FormatError), the element's Merlin transcript -> c_i, the weights, the MSM scalars, and the
+// block partial sums of the B / B_blinding coefficients.
+//   e1: Z_m B + Z_r1 Bb - c L - L' = 0        e2 (kinds 0, 1): Z_r1 B - c R - R' = 0        e3 (kinds 1, 2): Z_m L + Z_r2 Bb - c Csq - Csq' = 0
+// point / scalar slot k of element i at index k * d + i;  slots: L, L', [R, R'], [Csq, Csq'].
+#if ROFL_KG(3)
+__global__ void __launch_bounds__(TPB) k_sigma_vprep(int kind, u32 d, const uint8_t *proofs, const uint8_t *commits, DMerlin init, NonceSeed wseed,
+                                                      niels *pts, sc *scal_canon, sc *fixed_part /* [gridDim.x][2] Montgomery */, u32 *status) {
+    __shared__ sc lds[TPB * 2];
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool has_R = kind != 2, has_sq = kind != 0;
+    u32 npts = 1 + (has_R ? 1 : 0) + (has_sq ? 1 : 0), nn = has_sq ? 3 : 2, clen = 32 * npts, plen = 32 * (npts + nn), sq_off = has_R ? 64 : 32;
+    sc v[2] = {sc_zero(), sc_zero()};
+    if (i < d) {
+        const uint8_t *pf = proofs + (size_t)plen * i, *cm = commits + (size_t)clen * i, *z = pf + clen;
+        sc zm = sc_frombytes(z), zr1 = sc_frombytes(z + 32), zr2 = has_sq ? sc_frombytes(z + 64) : sc_zero();
+        bool okf = !sc_geq_l(zm.v) && !sc_geq_l(zr1.v) && !sc_geq_l(zr2.v);
+        sc c;
+        { DMerlin t = init; sg_transcript(kind, t, cm, pf, has_R); c = dm_challenge_scalar(t, "c", 1); }      // needs the bytes only
+        // weights: SHAKE256("rofl-zk/sgbatch" || seed || 3 i + k), wide-reduced
+        sc w[3];
+        const u64 dom[2] = {0x2f6b7a2d6c666f72ULL, 0x686374616267732fULL};      // "rofl-zk/" "/sgbatch"
+        for (int k = 0; k < 3; k++) {
+            u64 st[25]; shake256_seeded_block(st, dom, wseed.w, 3ull * i + k);
+            sc lo, hi;
+#pragma unroll
+            for (int q = 0; q < 4; q++) { lo.v[2 * q] = (u32)st[q]; lo.v[2 * q + 1] = (u32)(st[q] >> 32); hi.v[2 * q] = (u32)st[4 + q]; hi.v[2 * q + 1] = (u32)(st[4 + q] >> 32); }
+            w[k] = sc_from_wide(lo, hi);
+        }
+        if (!has_R) w[1] = sc_zero();
+        if (!has_sq) w[2] = sc_zero();
+        // B: w1 Z_m + w2 Z_r1 ; Bb: w1 Z_r1 + w3 Z_r2
+        v[0] = sc_to_mont(sc_add(sc_mul_plain(w[0], zm), sc_mul_plain(w[1], zr1)));
+        v[1] = sc_to_mont(sc_add(sc_mul_plain(w[0], zr1), sc_mul_plain(w[2], zr2)));
+        // one point at a time (six live points would not fit the register file): decode, store its niels form and its scalar
+        u32 slot = 0; gd p;
+        okf &= sg_decode(p, cm);                   // L: -w1 c + w3 Z_m
+        store_niels(&pts[(size_t)slot * d + i], sg_affine_niels(p)); store_sc(&scal_canon[(size_t)slot * d + i], sc_sub(sc_mul_plain(w[2], zm), sc_mul_plain(w[0], c))); slot++;
+        okf &= sg_decode(p, pf);                   // L': -w1
+        store_niels(&pts[(size_t)slot * d + i], sg_affine_niels(p)); store_sc(&scal_canon[(size_t)slot * d + i], sc_neg(w[0])); slot++;
+        if (has_R) {
+            okf &= sg_decode(p, cm + 32);          // R: -w2 c
+            store_niels(&pts[(size_t)slot * d + i], sg_affine_niels(p)); store_sc(&scal_canon[(size_t)slot * d + i], sc_neg(sc_mul_plain(w[1], c))); slot++;
+            okf &= sg_decode(p, pf + 32);          // R': -w2
+            store_niels(&pts[(size_t)slot * d + i], sg_affine_niels(p)); store_sc(&scal_canon[(size_t)slot * d + i], sc_neg(w[1])); slot++;
+        }
+        if (has_sq) {
+            okf &= sg_decode(p, cm + sq_off);      // Csq: -w3 c
+            store_niels(&pts[(size_t)slot * d + i], sg_affine_niels(p)); store_sc(&scal_canon[(size_t)slot * d + i], sc_neg(sc_mul_plain(w[2], c))); slot++;
+            okf &= sg_decode(p, pf + sq_off);      // Csq': -w3
+            store_niels(&pts[(size_t)slot * d + i], sg_affine_niels(p)); store_sc(&scal_canon[(size_t)slot * d + i], sc_neg(w[2])); slot++;
+        }
+        if (!okf) atomicOr(status, 4u);            // FormatError: the host ignores the sum
+    }
+    block_sum_sc<2>(v, lds);
+    if (threadIdx.x == 0) { store_sc(&fixed_part[blockIdx.x * 2], v[0]); store_sc(&fixed_part[blockIdx.x * 2 + 1], v[1]); }
+}
+#endif
 // ---- compressed_rand_proof: the d ElGamal pairs, the challenge-power dot products, the verification scalars
 #if ROFL_KG(3)
 __global__ void __launch_bounds__(64) k_eg_pairs(u32 d, const float *vals, u32 fp_bits, u32 fp_frac, const sc *rc, const uint8_t *existing,

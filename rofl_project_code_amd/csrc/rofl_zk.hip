@@ -1708,6 +1708,32 @@ int sigma_verify(int kind, const uint8_t *proofs, const uint8_t *commits, size_t
     HIPCHK(hipMemsetAsync(status, 0, 16, C.stream));
     HIPCHK(hipMemcpyAsync(dp, proofs, d * plen, hipMemcpyDefault, C.stream));
     HIPCHK(hipMemcpyAsync(dc, commits, d * clen, hipMemcpyDefault, C.stream));
+    static const bool sg_batch = !(getenv("ROFL_SIGMA_BATCH") && atoi(getenv("ROFL_SIGMA_BATCH")) == 0);
+    if (sg_batch) {
+        // one random linear combination of all elements' equations: decode + transcripts per element on the device, then ONE Pippenger MSM
+        // over the 4-6 d points and two fixed-base terms (k_sigma_vprep); the weights come from fresh OS randomness
+        size_t nslots = 2 * npts, nblk = (d + TPB - 1) / TPB;
+        NonceSeed ws{};
+        { FILE *f = fopen("/dev/urandom", "rb"); bool got = f && fread(ws.w, 1, 32, f) == 32; if (f) fclose(f);
+          if (!got) return fail(ROFL_HIP_ERROR, "no randomness for the batched Sigma-proof check"); }
+        niels *pts = C.gbuf[0].as<niels>(nslots * d);
+        sc *scal = C.SL.as<sc>(nslots * d);
+        sc *d_fixed = C.tmp_out.as<sc>(nblk * 2);
+        hipLaunchKernelGGL(k_sigma_vprep, dim3((unsigned)nblk), dim3(TPB), 0, C.stream, kind, (u32)d, dp, dc, sigma_init_state(kind), ws, pts, scal, d_fixed, status);
+        std::vector<sc> h_fixed(nblk * 2);
+        u32 st0 = 0;
+        HIPCHK(hipMemcpyAsync(h_fixed.data(), d_fixed, sizeof(sc) * nblk * 2, hipMemcpyDeviceToHost, C.stream));
+        HIPCHK(hipMemcpyAsync(&st0, status, 4, hipMemcpyDeviceToHost, C.stream));
+        C.sync();
+        if (st0 & 4u) { timing_end(C); return fail(ROFL_FORMAT_ERROR, "FormatError: non-canonical scalar or invalid point"); }
+        std::vector<MsmProb> pr(1, MsmProb{pts, scal}); std::vector<ge5> res;
+        msm_run(C, pr, nslots * d, res);
+        sc sB = h_canon(sum_partials(h_fixed.data(), nblk, 2, 0)), sBb = h_canon(sum_partials(h_fixed.data(), nblk, 2, 1));
+        ge5 tot = h51::gadd(res[0], h51::gadd(h_fixed_mul(C.ht.B5, sB), h_fixed_mul(C.ht.Bb5, sBb)));
+        timing_end(C);
+        *ok_out = h51::is_identity_ristretto(tot) ? 1 : 0;
+        return ROFL_OK;
+    }
     hipLaunchKernelGGL(k_sigma_verify, dim3((unsigned)((d + 63) / 64)), dim3(64), 0, C.stream, kind, (u32)d, dp, dc, sigma_init_state(kind), C.d_tabB, C.d_tabBb, status + 1, status);
     u32 st[2] = {0, 0};
     HIPCHK(hipMemcpyAsync(st, status, 8, hipMemcpyDeviceToHost, C.stream));

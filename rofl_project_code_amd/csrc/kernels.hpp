@@ -627,7 +627,8 @@ __global__ void __launch_bounds__(TPB) k_ipp_fold_ab(u32 nh, ChunkParams *cp, co
 // in the launch depends on another thread's output.
 #if ROFL_KG(4)
 __global__ void __launch_bounds__(TPB) k_ipp_round(u32 n_g, u32 n_k, u32 r_prev, int use_new, ChunkParams *cp, const sc *round_ch, const sc *a_in, const sc *b_in,
-                                                   sc *a_out, sc *b_out, size_t ab_stride, const sc *yinvpow, size_t y_stride, sc *SL, sc *ip_out) {
+                                                   sc *a_out, sc *b_out, size_t ab_stride, const sc *yinvpow, size_t y_stride, sc *SL, sc *ip_out,
+                                                   const sc *ptab_in, sc *ptab_out, size_t ptab_stride) {
     __shared__ sc lds[TPB * 2];
     __shared__ sc s_u[2];
     u32 c = blockIdx.y;
@@ -637,7 +638,7 @@ __global__ void __launch_bounds__(TPB) k_ipp_round(u32 n_g, u32 n_k, u32 r_prev,
     if (use_new && blockIdx.x == 0 && threadIdx.x == 0) { store_sc(&cp[c].pend_u[r_prev], u); store_sc(&cp[c].pend_ui[r_prev], ui); }   // read by later launches only
     const sc *ai = a_in + c * ab_stride, *bi = b_in + c * ab_stride;
     sc *ao = a_out + c * ab_stride, *bo = b_out + c * ab_stride;
-    const u32 nh = n_k / 2, r = r_prev + (use_new ? 1u : 0u);
+    const u32 nh = n_k / 2;
     const sc gs = load_sc(&cp[c].gscale), hs = load_sc(&cp[c].hscale);
     sc *sl = SL + (size_t)c * 2 * n_g;
     sc v[2] = {sc_zero(), sc_zero()};
@@ -646,14 +647,15 @@ __global__ void __launch_bounds__(TPB) k_ipp_round(u32 n_g, u32 n_k, u32 r_prev,
         bool lo = i < nh; u32 ii = lo ? nh + i : i - nh;
         sc af = sc_add(sc_montmul(load_sc(&ai[ii]), u), sc_montmul(load_sc(&ai[n_k + ii]), ui));
         sc bf = sc_add(sc_montmul(load_sc(&bi[ii]), ui), sc_montmul(load_sc(&bi[n_k + ii]), u));
-        sc sG = gs, sH = hs;
-        for (u32 q = 0; q < r_prev; q++) {          // challenge q <-> bit r-1-q of h
-            bool bit = (h >> (r - 1 - q)) & 1;
-            sc up = load_sc(&cp[c].pend_u[q]), upi = load_sc(&cp[c].pend_ui[q]);
-            sG = sc_montmul(sG, bit ? up : upi);
-            sH = sc_montmul(sH, bit ? upi : up);
-        }
-        if (use_new) { bool bit = h & 1; sG = sc_montmul(sG, bit ? u : ui); sH = sc_montmul(sH, bit ? ui : u); }
+        // product of the pending challenges selected by the bits of h (challenge q <-> bit r-1-q): the table of the previous round
+        // (2^r_prev entries per chunk and side, written by that round's launch) extended by the newest challenge -- one multiplication
+        // per element instead of r of them (r reaches 11 in the tail)
+        u32 hp = use_new ? h >> 1 : h;
+        sc tG = r_prev ? load_sc(&ptab_in[(size_t)c * 2 * ptab_stride + hp]) : sc_one_mont();
+        sc tH = r_prev ? load_sc(&ptab_in[(size_t)c * 2 * ptab_stride + ptab_stride + hp]) : sc_one_mont();
+        if (use_new) { bool bit = h & 1; tG = sc_montmul(tG, bit ? u : ui); tH = sc_montmul(tH, bit ? ui : u); }
+        if (i == 0) { store_sc(&ptab_out[(size_t)c * 2 * ptab_stride + h], tG); store_sc(&ptab_out[(size_t)c * 2 * ptab_stride + ptab_stride + h], tH); }
+        sc sG = sc_montmul(gs, tG), sH = sc_montmul(hs, tH);
         sH = sc_montmul(sH, load_sc(&yinvpow[c * y_stride + j]));
         store_sc(&sl[j], sc_from_mont(sc_montmul(af, sG)));
         store_sc(&sl[n_g + j], sc_from_mont(sc_montmul(bf, sH)));
@@ -1431,9 +1433,14 @@ __global__ void __launch_bounds__(512) k_msm_small(u32 n_side, MsmWin mw, MsmMap
     for (u32 b = threadIdx.x; b < B; b += blockDim.x) {
         u32 num = lcnt[b]; if (num > MSM_SMALL_CAP) num = MSM_SMALL_CAP;
         gd acc = gd_identity();
+        // the next point is in flight while the current one is added (the block runs at 2 waves/SIMD: registers are not the limit here,
+        // the gather latency in front of every addition was)
+        u32 v = num ? lst[b * MSM_SMALL_CAP] : 0u;
+        nd nxt = gload_nd(&pts[v & 0x7fffffffu]);
         for (u32 e = 0; e < num; e++) {
-            u32 v = lst[b * MSM_SMALL_CAP + e];
-            acc = gd_madd(acc, gload_nd(&pts[v & 0x7fffffffu]), (v >> 31) != 0);
+            nd q = nxt; bool ng = (v >> 31) != 0;
+            if (e + 1 < num) { v = lst[b * MSM_SMALL_CAP + e + 1]; nxt = gload_nd(&pts[v & 0x7fffffffu]); }
+            acc = gd_madd(acc, q, ng);
         }
         store_gd(&buckets[(size_t)pw * B + b], acc);
     }

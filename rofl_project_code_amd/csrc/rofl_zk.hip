@@ -282,7 +282,7 @@ struct Ctx {
     Timing tm;
     struct HopStats { double enqueue = 0, sync = 0, horner_wall = 0, horner_cpu = 0, host_wall = 0, host_cpu = 0; int n = 0; } hs;      // ROFL_TRACE: where the host hops go
     // workspace
-    DevBuf cp, sL, sR, party, Scanon, vshift, blind, Vbytes, Cbytes, status, partial, partial2, scpart, a, b, a2, b2, yinv,
+    DevBuf cp, sL, sR, party, Scanon, vshift, blind, Vbytes, Cbytes, status, partial, partial2, scpart, a, b, a2, b2, ptab[2], yinv,
         SL, SR, msm_cnt, msm_off, msm_cur, msm_tail, msm_perm, msm_sorted, msm_ovf, msm_buckets, msm_S[2], msm_C[2], msm_fin, msm_probs, powtabs, foldprobs, naf,
         gbuf[2], aux_pts, aux_scal, vscal, tmp_in, tmp_in2, tmp_out, vals, uni, stream_buf;
     PinBuf h_cp, h_res, h_part, h_misc, h_misc2, h_probs, h_auxc, h_auxs, h_ovf, h_V, h_ip, h_round, h_fdig, h_fprob;
@@ -731,7 +731,7 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
     results.resize(np);
     std::vector<double> cpu_each(np, 0.0);
     if (dev_horner) {
-        for (size_t p = 0; p < np; p++) results[p] = h51::from_ge(h[p]);
+        for (size_t p = 0; p < np; p++) results[p] = h51::from_ge_loose(h[p]);
     } else if (fb_used) {
         // sets of a problem carry equal weight: add them up, then one 16-bit Horner
         C.pool->run(np, [&](size_t p) {
@@ -740,8 +740,8 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
             ge5 acc = h51::identity(); bool started = false;
             for (int l = 15; l >= 0; l--) {
                 if (started) acc = h51::gdouble(acc);
-                if (l <= 14) for (u32 s = 0; s < sets; s++) { acc = h51::gadd(acc, h51::from_ge(h[PW + (base + s) * nb + l])); started = true; }
-                if (l == 0) for (u32 s = 0; s < sets; s++) acc = h51::gadd(acc, h51::from_ge(h[base + s]));
+                if (l <= 14) for (u32 s = 0; s < sets; s++) { acc = h51::gadd(acc, h51::from_ge_loose(h[PW + (base + s) * nb + l])); started = true; }
+                if (l == 0) for (u32 s = 0; s < sets; s++) acc = h51::gadd(acc, h51::from_ge_loose(h[base + s]));
             }
             results[p] = acc; cpu_each[p] = now_ms() - tc0;
         });
@@ -754,8 +754,8 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
                 int width = (u32)w + 1 == P.W ? (int)P.c + 1 : ((u32)w < P.wide ? (int)P.c : (int)P.c - 1);
                 for (int l = width - 1; l >= 0; l--) {
                     if (started) acc = h51::gdouble(acc);
-                    if (l <= (int)P.c - 2) { acc = h51::gadd(acc, h51::from_ge(h[PW + pw * nb + l])); started = true; }
-                    if (l == 0) { acc = h51::gadd(acc, h51::from_ge(h[pw])); started = true; }
+                    if (l <= (int)P.c - 2) { acc = h51::gadd(acc, h51::from_ge_loose(h[PW + pw * nb + l])); started = true; }
+                    if (l == 0) { acc = h51::gadd(acc, h51::from_ge_loose(h[pw])); started = true; }
                 }
             }
             results[p] = acc; cpu_each[p] = now_ms() - tc0;
@@ -926,6 +926,7 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
     static const bool ipp_fused = !(getenv("ROFL_IPP_FUSED") && atoi(getenv("ROFL_IPP_FUSED")) == 0);
     static const bool fold_regs = !(getenv("ROFL_FOLD_REGS") && atoi(getenv("ROFL_FOLD_REGS")) == 0);
     bool just_materialised = false;
+    sc *ptab[2] = {C.ptab[0].as<sc>(P * 2 * N), C.ptab[1].as<sc>(P * 2 * N)}; int psel = 0;      // pending-challenge product tables (ping-pong)
     for (unsigned round = 0; round < lgN; round++) {
         size_t n_k = n_g >> r, nh = n_k / 2;
         sc *SL = C.SL.as<sc>(P * 2 * n_g), *SR = C.SR.as<sc>(P * 2 * n_g);
@@ -937,8 +938,9 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
             nblkI = (u32)std::min<size_t>(256, std::max<size_t>(1, (n_g + 2 * TPB - 1) / (2 * TPB)));
             int use_new = just_materialised ? 0 : 1;
             hipLaunchKernelGGL(k_ipp_round, dim3(nblkI, (u32)P), dim3(TPB), 0, C.stream, (u32)n_g, (u32)n_k, use_new ? r - 1 : 0u, use_new, d_cp,
-                               (const sc *)C.h_round.dev<sc>(2 * P), (const sc *)a, (const sc *)b, a2, b2, N, yinvpow, N, SL, C.h_ip.dev<sc>(P * 256 * 2));
-            std::swap(a, a2); std::swap(b, b2);
+                               (const sc *)C.h_round.dev<sc>(2 * P), (const sc *)a, (const sc *)b, a2, b2, N, yinvpow, N, SL, C.h_ip.dev<sc>(P * 256 * 2),
+                               (const sc *)ptab[psel], ptab[psel ^ 1], N);
+            std::swap(a, a2); std::swap(b, b2); psel ^= 1;
         } else {
             hipLaunchKernelGGL(k_ipp_scalars, grid1(n_g, (u32)P), dim3(TPB), 0, C.stream, (u32)n_g, (u32)n_k, r, d_cp, a, b, N, yinvpow, N, SL, SR, merged ? 1 : 0);
             nblkI = (u32)std::min<size_t>(32, (nh + TPB - 1) / TPB);

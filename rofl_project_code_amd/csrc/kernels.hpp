@@ -1397,6 +1397,44 @@ __global__ void __launch_bounds__(512) k_msm_reduce_groups(u32 G, u32 gbits, con
     }
 }
 #endif
+// The same reduction as msm_reduce_fused_body with binary levels from the start (first level global -> LDS): log2(E) levels of ONE
+// addition each instead of a 7-deep 8-ary first level -- for a block that is alone on its CU the depth of the dependency chain is the
+// cost (E = 512: 9 additions deep instead of 13).  Level k: S'[g] = S[2g] + S[2g+1], new bit-sum k = S[2g+1], carried bit-sums pairwise.
+__device__ __forceinline__ void msm_reduce_binary_body(u32 E, const ge *si_g, ge *fin_s, ge *fin_c, unsigned char *smem) {
+    ge *buf0 = reinterpret_cast<ge *>(smem);
+    u32 E2 = E / 2;
+    ge *bufs[2] = {buf0, buf0 + (size_t)E2 * 2};                   // level-1 output: S[E2] | C[1][E2]; the next one is smaller
+    {
+        ge *so = bufs[0], *co = bufs[0] + E2;
+        for (u32 g = threadIdx.x; g < E2; g += blockDim.x) {
+            ge lo = load_ge(&si_g[2 * g]), hi = load_ge(&si_g[2 * g + 1]);
+            so[g] = gd_pack(gd_add(gd_unpack(lo), gd_unpack(hi)));
+            co[g] = hi;
+        }
+    }
+    __syncthreads();
+    const ge *si = bufs[0], *ci = bufs[0] + E2;
+    u32 nb = 1; int sel = 1;
+    E = E2;
+    while (E > 1) {
+        E2 = E / 2;
+        ge *so, *co;
+        if (E2 == 1) { so = fin_s; co = fin_c; } else { so = bufs[sel]; co = bufs[sel] + E2; }
+        for (u32 item = threadIdx.x; item < E2 * (1 + nb); item += blockDim.x) {
+            u32 role = item / E2, g = item % E2;
+            if (role == 0) {
+                ge lo = si[2 * g], hi = si[2 * g + 1];
+                so[g] = gd_pack(gd_add(gd_unpack(lo), gd_unpack(hi)));
+                co[(size_t)nb * E2 + g] = hi;
+            } else {
+                const ge *cc = ci + (size_t)(role - 1) * E;
+                co[(size_t)(role - 1) * E2 + g] = gd_pack(gd_add(gd_unpack(cc[2 * g]), gd_unpack(cc[2 * g + 1])));
+            }
+        }
+        __syncthreads();
+        si = so; ci = co; E = E2; nb += 1; sel ^= 1;
+    }
+}
 // A small MSM (the IPP tail: a few thousand terms per problem) in ONE launch instead of memset / scatter / scan / accumulate /
 // overflow / reduce: block = one (problem, window) bucket array (generic window layout, c <= 10).  The window's digits are
 // ranked into per-bucket lists in LDS (SMALL_CAP entries each), thread b sums bucket b's points in a uniform loop, the buckets
@@ -1430,7 +1468,27 @@ __global__ void __launch_bounds__(512) k_msm_small(u32 n_side, MsmWin mw, MsmMap
     }
     __syncthreads();
     const niels *pts = probs[p].pts;
-    for (u32 b = threadIdx.x; b < B; b += blockDim.x) {
+    // Balance the bucket sums over the block's waves (blockDim == B = 512: 8 waves, two per SIMD).  A wave runs as long as its fullest
+    // bucket (mean 4 entries, ~10 in every wave of 64 unsorted buckets); with the buckets sorted by load, wave w < 4 takes the w-th
+    // heaviest group of 64 and its SIMD partner w + 4 the (7 - w)-th: every SIMD sees ~11 additions' worth of issue instead of ~20.
+    u32 my_b = threadIdx.x;
+    if (blockDim.x == 512 && B == 512) {
+        __shared__ u32 chist[MSM_SMALL_CAP + 2], cbase[MSM_SMALL_CAP + 2];
+        __shared__ unsigned short order[512];
+        if (threadIdx.x < MSM_SMALL_CAP + 2) chist[threadIdx.x] = 0;
+        __syncthreads();
+        u32 mycnt = lcnt[threadIdx.x]; if (mycnt > MSM_SMALL_CAP) mycnt = MSM_SMALL_CAP;
+        u32 rank_in = atomicAdd(&chist[mycnt], 1u);
+        __syncthreads();
+        if (threadIdx.x == 0) { u32 run = 0; for (int cval = MSM_SMALL_CAP; cval >= 0; cval--) { cbase[cval] = run; run += chist[cval]; } }      // descending load
+        __syncthreads();
+        order[cbase[mycnt] + rank_in] = (unsigned short)threadIdx.x;
+        __syncthreads();
+        u32 wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+        u32 grp = wv < 4 ? wv : 11 - wv;
+        my_b = order[grp * 64 + ln];
+    }
+    for (u32 b = my_b; b < B; b += blockDim.x) {
         u32 num = lcnt[b]; if (num > MSM_SMALL_CAP) num = MSM_SMALL_CAP;
         gd acc = gd_identity();
         // the next point is in flight while the current one is added (the block runs at 2 waves/SIMD: registers are not the limit here,
@@ -1446,6 +1504,7 @@ __global__ void __launch_bounds__(512) k_msm_small(u32 n_side, MsmWin mw, MsmMap
     }
     __threadfence_block();
     __syncthreads();
+    if (B >= 16) { msm_reduce_binary_body(B, buckets + (size_t)pw * B, S_fin + pw, C_fin + (size_t)pw * nb_final, smem); return; }
     msm_reduce_fused_body(B, 0, buckets + (size_t)pw * B, nullptr, S_fin + pw, C_fin + (size_t)pw * nb_final, smem);
 }
 #endif

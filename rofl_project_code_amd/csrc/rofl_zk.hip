@@ -302,7 +302,7 @@ struct Ctx {
         build_fixed_table(ht.Bb, ht.bblind);
         to_tab5(ht.B5, ht.B); to_tab5(ht.Bb5, ht.Bb);
         HIPCHK(hipFuncSetAttribute((const void *)k_msm_reduce_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPCHK(hipFuncSetAttribute((const void *)k_msm_small, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void *)k_msm_small, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));      // + 2.5 KB of static LDS (bucket order)
         HIPCHK(hipFuncSetAttribute((const void *)k_msm_scatter_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         HIPCHK(hipFuncSetAttribute((const void *)k_msm_reduce_groups, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         HIPCHK(hipFuncSetAttribute((const void *)k_msm_bin_l1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -586,7 +586,7 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
             ge *S_fin_s = dev_horner ? C.msm_S[0].as<ge>(PW) : hres_dev;
             ge *C_fin_s = dev_horner ? C.msm_C[0].as<ge>(PW * (size_t)(P.c - 1)) : hres_dev + PW;
             size_t lds_lists = (size_t)P.B * 4 * (1 + MSM_SMALL_CAP);
-            size_t lds_red = ((size_t)(P.B / 8) * 4 + (size_t)(P.B / 16) * 5 + 1) * sizeof(ge);
+            size_t lds_red = std::max(((size_t)(P.B / 8) * 4 + (size_t)(P.B / 16) * 5 + 1) * sizeof(ge), ((size_t)P.B + (size_t)P.B * 3 / 4 + 1) * sizeof(ge));      // fused / binary reduction trees
             {
                 uint64_t items = (uint64_t)np * nside_small * P.W;
                 KSpan ks(C.tm, C.stream, ROFL_TK_MSM_SMALL, items * 7 + (uint64_t)PW * P.B * 10, (uint64_t)np * nside_small * (32 + 96));

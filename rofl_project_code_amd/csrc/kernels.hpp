@@ -1540,8 +1540,8 @@ __global__ void __launch_bounds__(64) k_msm_horner(MsmWin mw, const ge *S_fin, c
 #endif
 
 // ================================================================ K8/K9: verification
-// decode compressed points into affine niels (+ validity); optional shift (adds `shift` before use)
-// and optional re-encode of the shifted point (verify_rangeproof: range_proof_vec/mod.rs:155-167).
+// decode compressed points into affine niels (+ validity); optional re-encode of the point shifted by `shift`
+// (verify_rangeproof: range_proof_vec/mod.rs:155-167).  out_niels is the UNSHIFTED point.
 #if ROFL_KG(4)
 __global__ void __launch_bounds__(TPB) k_decode(u32 count, u32 valid_count, const uint8_t *in, const niels *shift, niels *out_niels,
                          uint8_t *out_enc, u32 *status) {
@@ -1557,9 +1557,11 @@ __global__ void __launch_bounds__(TPB) k_decode(u32 count, u32 valid_count, cons
     reinterpret_cast<uint4 *>(b)[0] = s[0]; reinterpret_cast<uint4 *>(b)[1] = s[1];
     gd p;
     if (!gd_ristretto_decode(p, b)) { atomicOr(status, 4u); p = gd_identity(); }
+    // the niels form is that of the DECODED point (Z = 1: no inversion chain); a caller that wants sum_j s_j (P_j + shift) from an MSM
+    // over these points adds (sum_j s_j) * shift itself (verify_chunks does: the shift is a multiple of B)
+    if (out_niels) { niels r; r.ypx = fd_pack(fd_add(p.Y, p.X)); r.ymx = fd_pack(fd_sub(p.Y, p.X)); r.t2d = fd_pack(fd_mul(p.T, fd_d2())); store_niels(&out_niels[i], r); }
     if (shift) p = gd_madd(p, load_nd(shift), false);
     if (out_enc) gd_ristretto_encode(out_enc + (size_t)i * 32, p);
-    if (out_niels) store_niels(&out_niels[i], gd_to_niels(p));
 }
 #endif
 // out = a + b (compressed in/out): pedersen_ops.rs:56-59 add_rp_vec

@@ -1121,8 +1121,11 @@ sc verifier_c(const uint8_t seed[32], u64 idx) {
     return sc_from_wide(lo, hi);
 }
 
+// d_Vniels holds the UNSHIFTED commitments C_j (k_decode); h_V the encodings of V_j = C_j + v_shift * B for the first v_real[c] values of
+// chunk c (identity padding after them): the check needs sum_j s_j V_j, which is the MSM over the C_j plus (sum_{j < v_real} s_j) * v_shift on B.
 int verify_chunks(Ctx &C, const char *label, size_t gens_capacity, size_t P, size_t n, size_t m, const uint8_t *proofs, size_t plen,
-                  const uint8_t *h_V, const niels *d_Vniels, const uint8_t seed[32], const u64 *c_index, int *ok, size_t group = 1) {
+                  const uint8_t *h_V, const niels *d_Vniels, const uint8_t seed[32], const u64 *c_index, int *ok, size_t group = 1,
+                  const sc *v_shift = nullptr, const u64 *v_real = nullptr) {
     // `group` consecutive proofs are checked as one batch: sum_c rho_c * (check_c) == 0 with random weights rho_c, so their
     // generator terms share one MSM.  Every proof of a batch gets the batch's verdict (callers AND them per client anyway).
     for (size_t c = 0; c < P; c++) ok[c] = 0;
@@ -1213,6 +1216,15 @@ int verify_chunks(Ctx &C, const char *label, size_t gens_capacity, size_t P, siz
         sc sum_2 = geo(twom, lg2u(n));
         sc delta = sc_sub(h_mul(sc_sub(z, zz), sum_y), h_mul(h_mul(h_mul(zz, z), sum_2), sum_z));
         sB[c] = h_mul(rho, sc_add(h_mul(w, sc_sub(t_x, h_mul(a, b))), h_mul(cc, sc_sub(delta, t_x))));
+        if (v_shift && v_real && v_real[c]) {
+            // sum_{j < cnt} rho c z^(2+j) = rho c z^2 (z^cnt - 1) / (z - 1)
+            sc zm = h_mont(z), zc = sc_one_mont();
+            for (u64 e = v_real[c], bidx = 0; e; e >>= 1, bidx++) if (e & 1) zc = sc_montmul(zc, cp.zpow2[bidx]);
+            sc num = sc_sub(h_canon(zc), sc_one_plain()), den = sc_sub(z, sc_one_plain());
+            sc geo_z = sc_iszero(den) ? sc_from_u64(v_real[c]) : h_mul(num, h_inv(den));
+            (void)zm;
+            sB[c] = sc_add(sB[c], h_mul(h_mul(h_mul(rho, h_mul(cc, zz)), geo_z), *v_shift));
+        }
     });
     C.tm.t.host_ms += now_ms() - th;
     HIPCHK(hipMemcpyAsync(d_cp, h_cp, sizeof(ChunkParams) * P, hipMemcpyHostToDevice, C.stream));
@@ -1501,7 +1513,10 @@ int verify_impl(Ctx &C, size_t n_clients, const uint8_t *const *proofs, size_t p
     static const bool vbatch = !(getenv("ROFL_VERIFY_BATCH") && atoi(getenv("ROFL_VERIFY_BATCH")) == 0);
     size_t grp = vbatch ? nv : 1;
     // all (client, chunk) pairs in one pass; a client's chunks form one batch of the random-weighted check
-    int rc = verify_chunks(C, "RangeProof", prove_range, P, prove_range, chunk, pf.data(), proof_len, Vh.data(), d_vn2, seed, cidx.data(), okc.data(), grp);
+    sc v_shift = sc_from_u64(1ULL << (prove_range - 1));
+    std::vector<u64> v_real(P);
+    for (size_t q = 0; q < P; q++) { size_t lo = cidx[q] * chunk; v_real[q] = lo >= d ? 0 : std::min(chunk, d - lo); }
+    int rc = verify_chunks(C, "RangeProof", prove_range, P, prove_range, chunk, pf.data(), proof_len, Vh.data(), d_vn2, seed, cidx.data(), okc.data(), grp, &v_shift, v_real.data());
     timing_end(C);
     if (rc) return fail(rc, "proof rejected before verification (format / bitsize)");
     for (size_t i = 0; i < n_clients; i++) { int r = bad_commit[i] ? 0 : 1; for (size_t c = 0; c < nv; c++) r &= okc[i * nv + c]; ok_out[i] = r; }

@@ -2122,9 +2122,13 @@ int rofl_bench_femul(unsigned iters, double *out) {
         std::vector<fe> h(256); for (int i = 0; i < 256; i++) for (int k = 0; k < 8; k++) h[i].v[k] = 0x9e3779b9u * (i * 8 + k + 1);
         HIPCHK(hipMemcpy(din, h.data(), sizeof(fe) * 256, hipMemcpyHostToDevice));
         hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-        hipLaunchKernelGGL(k_bench_femul, dim3(blocks), dim3(TPB), 0, C.stream, 8u, din, dout);
+        // ROFL_FEMUL_LDS: dynamic LDS per block, to hold the microbenchmark at the occupancy of a real kernel (40960 -> 4 blocks per CU =
+        // 4 waves/SIMD, what k_msm_accumulate's 127 VGPRs allow); default 0 = 8 waves/SIMD
+        static const size_t fl = getenv("ROFL_FEMUL_LDS") ? (size_t)atol(getenv("ROFL_FEMUL_LDS")) : 0;
+        if (fl) HIPCHK(hipFuncSetAttribute((const void *)k_bench_femul, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl));
+        hipLaunchKernelGGL(k_bench_femul, dim3(blocks), dim3(TPB), fl, C.stream, 8u, din, dout);
         HIPCHK(hipEventRecord(e0, C.stream));
-        hipLaunchKernelGGL(k_bench_femul, dim3(blocks), dim3(TPB), 0, C.stream, iters, din, dout);
+        hipLaunchKernelGGL(k_bench_femul, dim3(blocks), dim3(TPB), fl, C.stream, iters, din, dout);
         HIPCHK(hipEventRecord(e1, C.stream));
         HIPCHK(hipEventSynchronize(e1));
         float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));

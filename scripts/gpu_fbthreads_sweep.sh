@@ -1,0 +1,13 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
+run() { tag=$1; shift; env "$@" python3 bench.py --no-extras --steps 8 --warmup 2 > gpurun_out/fbt_$tag.json 2>/dev/null; python3 - <<PY
+import json
+j=json.load(open("gpurun_out/fbt_$tag.json"))
+k={r["kernel"][:18]:round(r["ms_per_client"],2) for r in j["kernels"]["top"]}
+print("$tag", round(j["median_ms_per_step"],2), k)
+PY
+}
+run t256k ROFL_MSM_FB_THREADS=262144
+run t512k ROFL_MSM_FB_THREADS=524288
+run t1m ROFL_MSM_FB_THREADS=1048576
+run t2m ROFL_MSM_FB_THREADS=2097152

@@ -1213,11 +1213,19 @@ __global__ void k_msm_overflow(u32 W, u32 B, u32 pstep, const MsmProb *probs, co
 // one thread per bucket: sum its points.  buckets [prob][W][B] extended.
 // blockIdx.y = grid problem q owning W bucket arrays; its points are probs[q * pstep].pts (pstep = 2 for merged L/R pairs)
 template <bool FB> __device__ __forceinline__ void msm_accumulate_body(u32 n, u32 c, u32 W, u32 pstep, const MsmProb *probs, const u32 *cnt, const u32 *off,
-                                 const u32 *sorted, const u32 *perm, ge *buckets, u32 cap, u32 idx_mask) {
+                                 const u32 *sorted, const u32 *perm, ge *buckets, u32 cap, u32 idx_mask, u32 balance) {
     u32 p = blockIdx.y, B = 1u << (c - 1);
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= W * B) return;
     u32 w = t / B;
+    if (balance && B >= 1024) {
+        // perm lists an array's buckets by descending count, so consecutive waves -- and blocks -- get lighter and lighter and the launch
+        // ends on a long tail of half-empty CUs.  Give every block the same work instead: block j of an array takes the waves ranked
+        // j, nw-1-j, nw/2-1-j and nw/2+j of its nw (two symmetric pairs around the median), rotated by j so that a SIMD sees all four classes.
+        u32 tb = t & (B - 1), nw = B / 64, j = tb / TPB, k = ((tb / 64) + j) & 3;
+        u32 sw = k == 0 ? j : k == 1 ? nw - 1 - j : k == 2 ? nw / 2 - 1 - j : nw / 2 + j;
+        t = w * B + sw * 64 + (tb & 63);
+    }
     size_t bi = ((size_t)p * W + w) * B + perm[(size_t)p * W * B + t];
     u32 num = cnt[bi];
     const u32 *lst;
@@ -1241,14 +1249,14 @@ template <bool FB> __device__ __forceinline__ void msm_accumulate_body(u32 n, u3
 }
 #if ROFL_KG(1)
 __global__ void __launch_bounds__(TPB) k_msm_accumulate_fb(u32 n, u32 c, u32 W, u32 pstep, const MsmProb *probs, const u32 *cnt, const u32 *off,
-                                 const u32 *sorted, const u32 *perm, ge *buckets, u32 cap, u32 idx_mask) {
-    msm_accumulate_body<true>(n, c, W, pstep, probs, cnt, off, sorted, perm, buckets, cap, idx_mask);
+                                 const u32 *sorted, const u32 *perm, ge *buckets, u32 cap, u32 idx_mask, u32 balance) {
+    msm_accumulate_body<true>(n, c, W, pstep, probs, cnt, off, sorted, perm, buckets, cap, idx_mask, balance);
 }
 #endif
 #if ROFL_KG(1)
 __global__ void __launch_bounds__(TPB) k_msm_accumulate_gen(u32 n, u32 c, u32 W, u32 pstep, const MsmProb *probs, const u32 *cnt, const u32 *off,
-                                 const u32 *sorted, const u32 *perm, ge *buckets, u32 cap, u32 idx_mask) {
-    msm_accumulate_body<false>(n, c, W, pstep, probs, cnt, off, sorted, perm, buckets, cap, idx_mask);
+                                 const u32 *sorted, const u32 *perm, ge *buckets, u32 cap, u32 idx_mask, u32 balance) {
+    msm_accumulate_body<false>(n, c, W, pstep, probs, cnt, off, sorted, perm, buckets, cap, idx_mask, balance);
 }
 #endif
 // Bucket reduction without doublings: sum_b (b+1) B_b = S + sum_l 2^l D_l, D_l = sum of buckets whose
@@ -1962,6 +1970,19 @@ __global__ void __launch_bounds__(TPB) k_bench_femul(u32 iters, const fe *in, fe
     fd a = fd_unpack(in[t & 255]), b = fd_unpack(in[(t + 1) & 255]);
     for (u32 i = 0; i < iters; i++) { a = fd_mul(a, b); b = fd_sq(b); a = fd_mul(a, b); b = fd_mul(b, a); }
     out[t] = fd_pack(fd_add(a, b));
+}
+// the same for the 7-multiplication mixed addition k_msm_accumulate_fb runs: reload = 0 keeps one table entry in registers (ALU only),
+// reload = 1 fetches a (cache-resident) 128-byte entry per addition like the real loop does
+__global__ void __launch_bounds__(TPB) k_bench_madd(u32 iters, u32 reload, const ndm *tbl, ge *out) {
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    gd acc = gd_identity();
+    if (reload) {
+        for (u32 i = 0; i < iters; i++) acc = gd_madd(acc, gload_ndm(tbl + ((t * 7 + i * 13) & 255)), ((t + i) & 1) != 0);
+    } else {
+        nd q = gload_ndm(tbl + (t & 255));
+        for (u32 i = 0; i < iters; i++) acc = gd_madd(acc, q, ((t + i) & 1) != 0);
+    }
+    store_gd(&out[t], acc);
 }
 #endif
 

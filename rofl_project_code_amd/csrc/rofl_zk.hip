@@ -523,6 +523,7 @@ struct MsmOpt { u32 lr_nh = 0, lr_ng = 0; const niels *fb_wtab = nullptr; size_t
 void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge5> &results, const MsmOpt &opt = MsmOpt()) {
     size_t np = probs.size();
     double t_enter = now_ms();
+    static const u32 acc_balance = getenv("ROFL_ACC_BALANCE") ? (u32)atoi(getenv("ROFL_ACC_BALANCE")) : 1u;   // equal-work blocks in k_msm_accumulate (0 = plain descending order)
     static const u32 dbg_mask = getenv("ROFL_DBG_IDX_MASK") ? (u32)strtoul(getenv("ROFL_DBG_IDX_MASK"), nullptr, 0) : 0x7fffffffu;   // timing experiments only (wrong results): gathers confined to a cache-resident prefix
     static const u32 dbg_scatter = getenv("ROFL_DBG_SCATTER") ? (u32)atoi(getenv("ROFL_DBG_SCATTER")) : 0u;   // timing experiments only: 1 = no range reservation, 2 = no slot stores
     bool lr = opt.lr_nh != 0;
@@ -599,9 +600,12 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
         Msm2L tl{256, 7, 24, 0, 144};
         u32 n_side2 = (u32)(lr ? n / 2 : n);
         if (two) {
-            size_t avg = (size_t)n_side2 * mm.fb_wps / tl.nbins;
-            tl.cap_bin = (u32)((2 * avg + 256 + 63) / 64 * 64);
-            if ((size_t)tl.cap_bin * 4 + 1024 > 96 * 1024 || n_side2 < 8192) two = false;
+            // a coarse bin has to fit one block's LDS in level 2: 256 bins of 128 buckets while that holds (<= 4 windows per array at
+            // 2^19 terms), 512 bins of 64 buckets with half the staging row for arrays that take 8 windows (two sets per problem)
+            auto size_bins = [&]() { size_t avg = (size_t)n_side2 * mm.fb_wps / tl.nbins; tl.cap_bin = (u32)((2 * avg + 256 + 63) / 64 * 64); return (size_t)tl.cap_bin * 4 + 1024 <= 96 * 1024; };
+            bool fits = size_bins();
+            if (!fits) { tl = Msm2L{512, 6, 24, 0, 72}; fits = size_bins(); }
+            if (!fits || n_side2 < 8192) two = false;
         }
         two_used = two;
         if (two) {
@@ -611,7 +615,7 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
             u32 *ovf_flag = d_flag;
             *h_flag = 0;
             HIPCHK(hipMemsetAsync(bcur, 0, sizeof(u32) * PW * tl.nbins * 2, C.stream));
-            u32 iter_pts = 16384 / mm.fb_wps; if (iter_pts < 1024) iter_pts = 1024;
+            u32 iter_pts = (tl.stage >= 144 ? 16384u : 12288u) / mm.fb_wps; if (iter_pts < 1024) iter_pts = 1024;      // ~ 64 (48) new items per bin and iteration against a row of 144 (72)
             u32 tile = iter_pts;
             while (((size_t)((n_side2 + tile - 1) / tile) * PW > 512 || (n_side2 + tile - 1) / tile > 32) && tile < n_side2) tile *= 2;      // <= 32 tiles per array: their left-overs fit the bin tails
             dim3 grid((n_side2 + tile - 1) / tile, (u32)PW);
@@ -624,7 +628,7 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
             {
                 uint64_t acc_adds = (uint64_t)(lr ? nq : np) * n * 16u;
                 KSpan ks_acc(C.tm, C.stream, ROFL_TK_MSM_ACCUMULATE_FB, acc_adds * 7, (uint64_t)(lr ? nq : np) * n * 32);
-                hipLaunchKernelGGL(k_msm_accumulate_fb, grid1((size_t)Wb * P.B, (u32)nq), dim3(TPB), 0, C.stream, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, bins, perm, buckets, MSM_LIST_ABS, dbg_mask);
+                hipLaunchKernelGGL(k_msm_accumulate_fb, grid1((size_t)Wb * P.B, (u32)nq), dim3(TPB), 0, C.stream, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, bins, perm, buckets, MSM_LIST_ABS, dbg_mask, acc_balance);
             }
             if (C.tm.enabled) HIPCHK(hipEventRecord(e1, C.stream));
         } else {
@@ -652,8 +656,8 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
             {
                 uint64_t acc_adds = (uint64_t)(lr ? nq : np) * n * (fb ? 16u : P.W);
                 KSpan ks_acc(C.tm, C.stream, fb ? ROFL_TK_MSM_ACCUMULATE_FB : ROFL_TK_MSM_ACCUMULATE_GEN, acc_adds * 7, (uint64_t)(lr ? nq : np) * n * 32);
-                if (fb) hipLaunchKernelGGL(k_msm_accumulate_fb, grid1((size_t)Wb * P.B, (u32)nq), dim3(TPB), 0, C.stream, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, slots, perm, buckets, cap, dbg_mask);
-                else hipLaunchKernelGGL(k_msm_accumulate_gen, grid1((size_t)Wb * P.B, (u32)nq), dim3(TPB), 0, C.stream, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, slots, perm, buckets, cap, dbg_mask);
+                if (fb) hipLaunchKernelGGL(k_msm_accumulate_fb, grid1((size_t)Wb * P.B, (u32)nq), dim3(TPB), 0, C.stream, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, slots, perm, buckets, cap, dbg_mask, acc_balance);
+                else hipLaunchKernelGGL(k_msm_accumulate_gen, grid1((size_t)Wb * P.B, (u32)nq), dim3(TPB), 0, C.stream, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, slots, perm, buckets, cap, dbg_mask, acc_balance);
             }
             if (C.tm.enabled) HIPCHK(hipEventRecord(e1, C.stream));
             hipLaunchKernelGGL(k_msm_overflow, dim3(1), dim3(64), 0, C.stream, Wb, P.B, (u32)(np / nq), d_probs, ovf_count, ovf, OVF_MAX, buckets, fb ? 1 : 0);
@@ -664,7 +668,7 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
             hipLaunchKernelGGL(k_msm_scan, dim3((unsigned)PW), dim3(TPB), 0, C.stream, P.B, cnt, off, cur, perm);
             hipLaunchKernelGGL(k_msm_scatter, grid1(n, (u32)(nq * Wgrid)), dim3(TPB), 0, C.stream, (u32)n, mw, mm, d_probs, cur, sorted);
             if (C.tm.enabled) { e0 = C.tm.get(); e1 = C.tm.get(); HIPCHK(hipEventRecord(e0, C.stream)); }
-            hipLaunchKernelGGL(k_msm_accumulate_gen, grid1((size_t)Wb * P.B, (u32)nq), dim3(TPB), 0, C.stream, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, sorted, perm, buckets, 0u, dbg_mask);
+            hipLaunchKernelGGL(k_msm_accumulate_gen, grid1((size_t)Wb * P.B, (u32)nq), dim3(TPB), 0, C.stream, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, sorted, perm, buckets, 0u, dbg_mask, acc_balance);
             if (C.tm.enabled) HIPCHK(hipEventRecord(e1, C.stream));
         }
         }
@@ -2126,6 +2130,23 @@ int rofl_bench_femul(unsigned iters, double *out) {
         // 4 waves/SIMD, what k_msm_accumulate's 127 VGPRs allow); default 0 = 8 waves/SIMD
         static const size_t fl = getenv("ROFL_FEMUL_LDS") ? (size_t)atol(getenv("ROFL_FEMUL_LDS")) : 0;
         if (fl) HIPCHK(hipFuncSetAttribute((const void *)k_bench_femul, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl));
+        // ROFL_FEMUL_MODE = 1 / 2: the 7-multiplication mixed addition instead (entry held in registers / fetched per addition from a 32 KB table)
+        static const int mode = getenv("ROFL_FEMUL_MODE") ? atoi(getenv("ROFL_FEMUL_MODE")) : 0;
+        if (mode) {
+            ndm *dt; ge *dg; HIPCHK(hipMalloc(&dt, sizeof(ndm) * 256)); HIPCHK(hipMalloc(&dg, sizeof(ge) * threads));
+            std::vector<ndm> ht(256); for (int i = 0; i < 256; i++) for (int k = 0; k < 32; k++) ht[i].v[k] = (0x9e3779b9u * (i * 32 + k + 1)) >> 8;
+            HIPCHK(hipMemcpy(dt, ht.data(), sizeof(ndm) * 256, hipMemcpyHostToDevice));
+            if (fl) HIPCHK(hipFuncSetAttribute((const void *)k_bench_madd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl));
+            hipLaunchKernelGGL(k_bench_madd, dim3(blocks), dim3(TPB), fl, C.stream, 8u, (u32)(mode == 2), dt, dg);
+            HIPCHK(hipEventRecord(e0, C.stream));
+            hipLaunchKernelGGL(k_bench_madd, dim3(blocks), dim3(TPB), fl, C.stream, iters, (u32)(mode == 2), dt, dg);
+            HIPCHK(hipEventRecord(e1, C.stream));
+            HIPCHK(hipEventSynchronize(e1));
+            float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+            *out = (double)threads * iters * 7.0 / (ms * 1e-3);
+            HIPCHK(hipFree(dt)); HIPCHK(hipFree(dg)); HIPCHK(hipFree(din)); HIPCHK(hipFree(dout)); HIPCHK(hipEventDestroy(e0)); HIPCHK(hipEventDestroy(e1));
+            return ROFL_OK;
+        }
         hipLaunchKernelGGL(k_bench_femul, dim3(blocks), dim3(TPB), fl, C.stream, 8u, din, dout);
         HIPCHK(hipEventRecord(e0, C.stream));
         hipLaunchKernelGGL(k_bench_femul, dim3(blocks), dim3(TPB), fl, C.stream, iters, din, dout);

@@ -577,6 +577,25 @@ def test_msm_variants_small_sizes(R, env):
     assert r.returncode == 0 and "FB_SMALL PASS" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_two_level_sort_bin_shapes(R):
+    """The two-level bucket sort of the fixed-base launches at its three shapes -- 4 windows per bucket array (256 coarse bins, the
+    single-client default), 8 and 16 windows per array (512 bins; what calls in flight next to others and single-set plans take) --
+    and the one-level LDS scatter: all bit-identical to the oracle on one chunk of 2^19 terms."""
+    import subprocess, sys
+    helper = os.path.join(os.path.dirname(__file__), "gpu_two_level_check.py")
+    def run(env, *args):
+        e = dict(os.environ); e.update(env)
+        r = subprocess.run([sys.executable, helper, *args], env=e, capture_output=True, text=True, timeout=900)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("DIGEST")]
+        assert r.returncode == 0 and lines, r.stdout[-2000:] + r.stderr[-2000:]
+        return lines[0].split()[1:]
+    want = run({}, "oracle")[0]
+    for env in ({}, {"ROFL_MSM_FB_SETS": "2", "ROFL_MSM_FB_THREADS": "65536"}, {"ROFL_MSM_FB_SETS": "1", "ROFL_MSM_FB_THREADS": "32768"},
+                {"ROFL_MSM_TWO_LEVEL": "0"}, {"ROFL_ACC_BALANCE": "0"}):
+        got = run(env)
+        assert got == [want, "1", "0"], (env, got)
+
+
 def test_concurrent_calls_use_separate_lanes(R):
     """The reference's server calls verify from a thread pool (server.rs:656-687): concurrent calls must not disturb each
     other.  Six threads, different shapes, every proof bit-exact vs the oracle; timing and errors are per thread."""

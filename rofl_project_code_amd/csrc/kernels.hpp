@@ -1126,12 +1126,20 @@ __global__ void __launch_bounds__(1024) k_msm_bin_l1(u32 n_side, u32 tile_pts, u
         // line-aligned and no line is written twice.  What is left (< 32) stays at the front of the row for the next iteration;
         // after the last iteration it goes to the bin's tail.
         bool last_iter = kend == k1;
-        for (u32 bin = wave; bin < L.nbins; bin += nwaves) {
-            u32 c = lcnt[bin]; if (c > L.stage) c = L.stage;
-            u32 full = c & ~31u, rem = c - full, g = 0;
+        // a wave owns the bins wave, wave + nwaves, ...: lane l reserves for the l-th of them, so the global atomics of a flush are
+        // one round trip per wave instead of one per bin
+        u32 my_bin = wave + lane * nwaves, my_c = 0, my_gm = 0, my_gt = 0;
+        if (my_bin < L.nbins) {
+            my_c = lcnt[my_bin]; if (my_c > L.stage) my_c = L.stage;
+            u32 full = my_c & ~31u, rem = my_c - full;
+            if (full) my_gm = atomicAdd(&cur[2 * my_bin], full);
+            if (last_iter && rem) my_gt = atomicAdd(&cur[2 * my_bin + 1], rem);
+        }
+        u32 kbin = 0;
+        for (u32 bin = wave; bin < L.nbins; bin += nwaves, kbin++) {
+            u32 c = __shfl(my_c, kbin), g = __shfl(my_gm, kbin), gt = __shfl(my_gt, kbin);
+            u32 full = c & ~31u, rem = c - full;
             if (full) {
-                if (lane == 0) g = atomicAdd(&cur[2 * bin], full);
-                g = __shfl(g, 0);
                 bool fits = g + full <= L.cap_bin;
                 if (!fits && lane == 0) *(volatile u32 *)overflow = 1u;      // mapped host memory: plain, idempotent store
                 for (u32 j = lane; j < full && fits; j += 64) reg[(size_t)bin * L.cap_bin + g + j] = stage[bin * L.stage + j];
@@ -1139,9 +1147,7 @@ __global__ void __launch_bounds__(1024) k_msm_bin_l1(u32 n_side, u32 tile_pts, u
             u32 carry = (lane < rem) ? stage[bin * L.stage + full + lane] : 0u;      // rem < 32 <= 64 lanes
             if (last_iter) {
                 if (rem) {
-                    if (lane == 0) g = atomicAdd(&cur[2 * bin + 1], rem);
-                    g = __shfl(g, 0);
-                    if (g + rem <= MSM_BIN_TAIL) { if (lane < rem) tail[(size_t)bin * MSM_BIN_TAIL + g + lane] = carry; }
+                    if (gt + rem <= MSM_BIN_TAIL) { if (lane < rem) tail[(size_t)bin * MSM_BIN_TAIL + gt + lane] = carry; }
                     else if (lane == 0) *(volatile u32 *)overflow = 1u;
                 }
             } else {

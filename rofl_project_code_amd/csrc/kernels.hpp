@@ -1259,6 +1259,22 @@ __global__ void __launch_bounds__(TPB) k_msm_accumulate_fb(u32 n, u32 c, u32 W, 
     msm_accumulate_body<true>(n, c, W, pstep, probs, cnt, off, sorted, perm, buckets, cap, idx_mask, balance);
 }
 #endif
+// debugging aid (ROFL_DBG_ACC_TIMELINE): the same launch with one record per wave -- start / end on the 100 MHz wall clock, HW_ID, XCC_ID
+#if ROFL_KG(1)
+__global__ void __launch_bounds__(TPB) k_msm_accumulate_fb_dbg(u32 n, u32 c, u32 W, u32 pstep, const MsmProb *probs, const u32 *cnt, const u32 *off,
+                                 const u32 *sorted, const u32 *perm, ge *buckets, u32 cap, u32 idx_mask, u32 balance, unsigned long long *rec) {
+    unsigned long long t0 = wall_clock64();
+    msm_accumulate_body<true>(n, c, W, pstep, probs, cnt, off, sorted, perm, buckets, cap, idx_mask, balance);
+    unsigned long long t1 = wall_clock64();
+    if ((threadIdx.x & 63) == 0) {
+        u32 hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        size_t wv = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (TPB / 64) + threadIdx.x / 64;
+        rec[wv * 4 + 0] = t0; rec[wv * 4 + 1] = t1; rec[wv * 4 + 2] = hw; rec[wv * 4 + 3] = xcc;
+    }
+}
+#endif
 #if ROFL_KG(1)
 __global__ void __launch_bounds__(TPB) k_msm_accumulate_gen(u32 n, u32 c, u32 W, u32 pstep, const MsmProb *probs, const u32 *cnt, const u32 *off,
                                  const u32 *sorted, const u32 *perm, ge *buckets, u32 cap, u32 idx_mask, u32 balance) {
@@ -1977,12 +1993,16 @@ __global__ void __launch_bounds__(TPB) k_bench_femul(u32 iters, const fe *in, fe
     for (u32 i = 0; i < iters; i++) { a = fd_mul(a, b); b = fd_sq(b); a = fd_mul(a, b); b = fd_mul(b, a); }
     out[t] = fd_pack(fd_add(a, b));
 }
-// the same for the 7-multiplication mixed addition k_msm_accumulate_fb runs: reload = 0 keeps one table entry in registers (ALU only),
-// reload = 1 fetches a (cache-resident) 128-byte entry per addition like the real loop does
-__global__ void __launch_bounds__(TPB) k_bench_madd(u32 iters, u32 reload, const ndm *tbl, ge *out) {
+// the same for the 7-multiplication mixed addition k_msm_accumulate_fb runs, at its shape (4 blocks per CU = 4 waves/SIMD, 128 VGPRs):
+// MODE 0 keeps one table entry in registers (ALU only), 1 fetches a cache-resident 128-byte entry per addition (32 KB table), 2 gathers
+// uniformly at random from a table of `entries` (power of two) records like the window table is gathered
+template <int MODE> __device__ __forceinline__ void bench_madd_body(u32 iters, u32 entries, const ndm *tbl, ge *out) {
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     gd acc = gd_identity();
-    if (reload) {
+    if (MODE == 2) {
+        u32 h = t * 2654435761u + 12345u;
+        for (u32 i = 0; i < iters; i++) { h = h * 1664525u + 1013904223u; acc = gd_madd(acc, gload_ndm(tbl + ((h >> 7) & (entries - 1))), (h >> 31) != 0); }
+    } else if (MODE == 1) {
         for (u32 i = 0; i < iters; i++) acc = gd_madd(acc, gload_ndm(tbl + ((t * 7 + i * 13) & 255)), ((t + i) & 1) != 0);
     } else {
         nd q = gload_ndm(tbl + (t & 255));
@@ -1990,6 +2010,9 @@ __global__ void __launch_bounds__(TPB) k_bench_madd(u32 iters, u32 reload, const
     }
     store_gd(&out[t], acc);
 }
+__global__ void __launch_bounds__(TPB, 4) k_bench_madd_regs(u32 iters, u32 entries, const ndm *tbl, ge *out) { bench_madd_body<0>(iters, entries, tbl, out); }
+__global__ void __launch_bounds__(TPB, 4) k_bench_madd_l1(u32 iters, u32 entries, const ndm *tbl, ge *out) { bench_madd_body<1>(iters, entries, tbl, out); }
+__global__ void __launch_bounds__(TPB, 4) k_bench_madd_gather(u32 iters, u32 entries, const ndm *tbl, ge *out) { bench_madd_body<2>(iters, entries, tbl, out); }
 #endif
 
 }  // namespace rofl

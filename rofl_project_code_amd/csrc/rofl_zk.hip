@@ -523,7 +523,7 @@ struct MsmOpt { u32 lr_nh = 0, lr_ng = 0; const niels *fb_wtab = nullptr; size_t
 void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge5> &results, const MsmOpt &opt = MsmOpt()) {
     size_t np = probs.size();
     double t_enter = now_ms();
-    static const u32 acc_balance = getenv("ROFL_ACC_BALANCE") ? (u32)atoi(getenv("ROFL_ACC_BALANCE")) : 1u;   // equal-work blocks in k_msm_accumulate (0 = plain descending order)
+    static const u32 acc_balance = getenv("ROFL_ACC_BALANCE") ? (atoi(getenv("ROFL_ACC_BALANCE")) ? 1u : 0u) : 1u;   // equal-work blocks in k_msm_accumulate (0 = plain descending order)
     static const u32 dbg_mask = getenv("ROFL_DBG_IDX_MASK") ? (u32)strtoul(getenv("ROFL_DBG_IDX_MASK"), nullptr, 0) : 0x7fffffffu;   // timing experiments only (wrong results): gathers confined to a cache-resident prefix
     static const u32 dbg_scatter = getenv("ROFL_DBG_SCATTER") ? (u32)atoi(getenv("ROFL_DBG_SCATTER")) : 0u;   // timing experiments only: 1 = no range reservation, 2 = no slot stores
     bool lr = opt.lr_nh != 0;
@@ -628,6 +628,17 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
             {
                 uint64_t acc_adds = (uint64_t)(lr ? nq : np) * n * 16u;
                 KSpan ks_acc(C.tm, C.stream, ROFL_TK_MSM_ACCUMULATE_FB, acc_adds * 7, (uint64_t)(lr ? nq : np) * n * 32);
+                static const char *timeline = getenv("ROFL_DBG_ACC_TIMELINE");      // debugging: per-wave start / end / placement of every launch, appended to this file
+                if (timeline) {
+                    dim3 g = grid1((size_t)Wb * P.B, (u32)nq);
+                    size_t waves = (size_t)g.x * g.y * (TPB / 64);
+                    unsigned long long *rec; HIPCHK(hipMalloc(&rec, waves * 32)); HIPCHK(hipMemsetAsync(rec, 0, waves * 32, C.stream));
+                    hipLaunchKernelGGL(k_msm_accumulate_fb_dbg, g, dim3(TPB), 0, C.stream, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, bins, perm, buckets, MSM_LIST_ABS, dbg_mask, acc_balance, rec);
+                    std::vector<unsigned long long> h(waves * 4);
+                    HIPCHK(hipMemcpyAsync(h.data(), rec, waves * 32, hipMemcpyDeviceToHost, C.stream)); HIPCHK(hipStreamSynchronize(C.stream));
+                    if (FILE *f = fopen(timeline, "ab")) { unsigned long long hdr[4] = {0x54494d45ull, waves, g.x, g.y}; fwrite(hdr, 8, 4, f); fwrite(h.data(), 8, h.size(), f); fclose(f); }
+                    HIPCHK(hipFree(rec));
+                } else
                 hipLaunchKernelGGL(k_msm_accumulate_fb, grid1((size_t)Wb * P.B, (u32)nq), dim3(TPB), 0, C.stream, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, bins, perm, buckets, MSM_LIST_ABS, dbg_mask, acc_balance);
             }
             if (C.tm.enabled) HIPCHK(hipEventRecord(e1, C.stream));
@@ -2133,13 +2144,21 @@ int rofl_bench_femul(unsigned iters, double *out) {
         // ROFL_FEMUL_MODE = 1 / 2: the 7-multiplication mixed addition instead (entry held in registers / fetched per addition from a 32 KB table)
         static const int mode = getenv("ROFL_FEMUL_MODE") ? atoi(getenv("ROFL_FEMUL_MODE")) : 0;
         if (mode) {
-            ndm *dt; ge *dg; HIPCHK(hipMalloc(&dt, sizeof(ndm) * 256)); HIPCHK(hipMalloc(&dg, sizeof(ge) * threads));
+            // mode 3: ROFL_FEMUL_TABLE entries (power of two, default 2^21 = 256 MB) gathered at random, like the window table is
+            static const size_t tab = getenv("ROFL_FEMUL_TABLE") ? (size_t)atol(getenv("ROFL_FEMUL_TABLE")) : ((size_t)1 << 21);
+            size_t entries = mode == 3 ? tab : 256;
+            ndm *dt; ge *dg; HIPCHK(hipMalloc(&dt, sizeof(ndm) * entries)); HIPCHK(hipMalloc(&dg, sizeof(ge) * threads));
+            HIPCHK(hipMemset(dt, 0x11, sizeof(ndm) * entries));
             std::vector<ndm> ht(256); for (int i = 0; i < 256; i++) for (int k = 0; k < 32; k++) ht[i].v[k] = (0x9e3779b9u * (i * 32 + k + 1)) >> 8;
             HIPCHK(hipMemcpy(dt, ht.data(), sizeof(ndm) * 256, hipMemcpyHostToDevice));
-            if (fl) HIPCHK(hipFuncSetAttribute((const void *)k_bench_madd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl));
-            hipLaunchKernelGGL(k_bench_madd, dim3(blocks), dim3(TPB), fl, C.stream, 8u, (u32)(mode == 2), dt, dg);
+            auto launch = [&](u32 it) {
+                if (mode == 3) hipLaunchKernelGGL(k_bench_madd_gather, dim3(blocks), dim3(TPB), fl, C.stream, it, (u32)entries, dt, dg);
+                else if (mode == 2) hipLaunchKernelGGL(k_bench_madd_l1, dim3(blocks), dim3(TPB), fl, C.stream, it, (u32)entries, dt, dg);
+                else hipLaunchKernelGGL(k_bench_madd_regs, dim3(blocks), dim3(TPB), fl, C.stream, it, (u32)entries, dt, dg);
+            };
+            launch(8u);
             HIPCHK(hipEventRecord(e0, C.stream));
-            hipLaunchKernelGGL(k_bench_madd, dim3(blocks), dim3(TPB), fl, C.stream, iters, (u32)(mode == 2), dt, dg);
+            launch(iters);
             HIPCHK(hipEventRecord(e1, C.stream));
             HIPCHK(hipEventSynchronize(e1));
             float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));

@@ -12,7 +12,7 @@ from rofl_project_code_amd import api
 import bench
 R.set_device(0); api.set_fp(32, 7)
 os.environ["ROFL_FEMUL_MODE"] = "2"
-R.bench_femul(64)
+R.bench_femul(64)  # ROFL_FEMUL_MODE: 2 = cache-resident entries, 3 = random gathers from ROFL_FEMUL_TABLE entries
 vals, bl = bench.synth_client(1)
 for i in range(3):
     pr, cm = R.range_proof_vec.create_rangeproof(vals, bl, 32, 4, nonce=R.Nonce.seeded(b"\x01" * 32))
@@ -24,7 +24,7 @@ for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_
   python3 - <<PY
 import csv, glob, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); dur = collections.defaultdict(float); nd = collections.Counter()
-want = ("k_msm_accumulate_fb", "k_bench_madd")
+want = ("k_msm_accumulate_fb", "k_bench_madd_l1", "k_bench_madd_gather")
 for f in glob.glob("gpurun_out/pmc_$tag/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0].replace("rofl::", "")

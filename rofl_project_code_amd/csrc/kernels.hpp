@@ -1227,8 +1227,11 @@ template <bool FB> __device__ __forceinline__ void msm_accumulate_body(u32 n, u3
     if (balance && B >= 1024) {
         // perm lists an array's buckets by descending count, so consecutive waves -- and blocks -- get lighter and lighter and the launch
         // ends on a long tail of half-empty CUs.  Give every block the same work instead: block j of an array takes the waves ranked
-        // j, nw-1-j, nw/2-1-j and nw/2+j of its nw (two symmetric pairs around the median), rotated by j so that a SIMD sees all four classes.
-        u32 tb = t & (B - 1), nw = B / 64, j = tb / TPB, k = ((tb / 64) + j) & 3;
+        // j, nw-1-j, nw/2-1-j and nw/2+j of its nw (two symmetric pairs around the median).  No rotation of the classes over a block's
+        // waves: the dispatcher already starts each of the four blocks that share a CU (256 apart in launch order) on a different SIMD
+        // (timeline: waves 0..3 -> SIMDs 1,3,0,2 / 3,0,2,1 / 0,2,1,3 / 2,1,3,0), so every SIMD gets one wave of each class; rotating by
+        // (block id >> 8) cancels exactly that and costs 20 %.
+        u32 tb = t & (B - 1), nw = B / 64, j = tb / TPB, k = (tb / 64) & 3;
         u32 sw = k == 0 ? j : k == 1 ? nw - 1 - j : k == 2 ? nw / 2 - 1 - j : nw / 2 + j;
         t = w * B + sw * 64 + (tb & 63);
     }

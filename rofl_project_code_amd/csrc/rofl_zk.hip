@@ -1010,10 +1010,10 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
             FoldTabCfg fc = gens.fc();
             size_t dstride = use_tab ? (size_t)fc.np * FOLD_TAB_DIGITS : 256;
             th = now_ms();
-            int8_t *h_dig = C.h_misc.as<int8_t>(2 * P * nsrc * dstride);
+            int8_t *h_dig = C.h_fdig.as<int8_t>(2 * P * nsrc * dstride);      // the fold's own pinned staging: nothing else writes them while its copies are queued
             memset(h_dig, 0, 2 * P * nsrc * dstride);
-            FoldProb *h_fp = C.h_misc2.as<FoldProb>(2 * P);
-            FoldTabProb *h_ftp = C.h_probs.as<FoldTabProb>(2 * P);
+            FoldProb *h_fp = C.h_fprob.as<FoldProb>(2 * P + 2 * P);
+            FoldTabProb *h_ftp = reinterpret_cast<FoldTabProb *>(h_fp + 2 * P);
             niels *gnew = C.gbuf[gsel].as<niels>(P * 2 * n_new);
             int top = 0;
             for (size_t c = 0; c < P; c++) {
@@ -1100,7 +1100,9 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
             }
             if (C.tm.enabled) { HIPCHK(hipEventRecord(e1, C.stream)); C.tm.fold_ev.push_back({e0, e1}); C.tm.t.fold_launches++; { char tg[96]; snprintf(tg, sizeof tg, "fold n_g=%zu nsrc=%u tab=%d", n_g, nsrc, (int)use_tab); C.tm.fold_tag.push_back(tg); } C.tm.t.fold_point_reads += (uint64_t)2 * P * n_g; }
             HIPCHK(hipMemcpyAsync(d_cp, h_cp, sizeof(ChunkParams) * P, hipMemcpyHostToDevice, C.stream));   // gscale / hscale
-            C.sync();   // digit / problem staging buffers are reused next time
+            // no sync here: the next round's launches queue up behind the fold on the same stream (their enqueue cost hides under it); the
+            // pinned digit / problem staging buffers are not written again before the next fold, at least two synchronised rounds away
+            if (ptrace) C.sync();      // the phase trace wants the fold's own wall time
             mark("fold", (long)n_new);
             for (size_t c = 0; c < P; c++) { cur[c] = gnew + c * 2 * n_new; pu[c].clear(); pui[c].clear(); }
             n_g = n_new; r = 0; gsel ^= 1; first_level = false; just_materialised = true;

@@ -219,6 +219,8 @@ int rofl_set_timing(int enabled);
 int rofl_dbg_msm(const uint8_t *scalars32, const uint8_t *points32, size_t n, uint8_t out32[32]);
 /* field-multiply micro-benchmark: returns GF(2^255-19) multiplications per second on the device */
 int rofl_bench_femul(unsigned iters, double *fe_mul_per_sec_out);
+/* self-test of the quad-parallel point arithmetic (csrc/quad26.hpp): pair i = (P, Q) -> 2^doublings P + Q, one thread per pair and one quad of lanes per pair */
+int rofl_dbg_quad_ops(const uint8_t *pairs64, size_t pairs, unsigned doublings, uint8_t *out_serial32, uint8_t *out_quad32);
 
 /* ---- host-side self-test hooks (same source as the device math, compiled for the CPU) ---- */
 int rofl_dbg_host_pool_stress(unsigned threads, unsigned jobs);   /* host thread pool: every index of every job runs exactly once */

@@ -5,6 +5,7 @@
 #pragma once
 #include "fe32.hpp"
 #include "fe26.hpp"
+#include "quad26.hpp"
 #include "keccak.hpp"
 
 namespace rofl {
@@ -1543,32 +1544,61 @@ __global__ void __launch_bounds__(512) k_msm_small(u32 n_side, MsmWin mw, MsmMap
 #endif
 
 // Finish an MSM on the device when a launch carries many problems (n_partition = 64: 128 L/R problems per IPP round, whose
-// 253-step Horner chains would otherwise queue on the host pool).  One block per problem, one thread per window: thread w
-// folds its window's bit-sums (S + sum_l 2^l D_l), shifts the result to the window position (pos_w doublings -- the chains
-// of the W windows run side by side, so the launch is as deep as ONE chain) and the block adds the W terms through LDS.
+// 253-step Horner chains would otherwise queue on the host pool).  One block per problem, one QUAD of lanes per window (quad26.hpp:
+// lane q holds coordinate q, a doubling is one squaring + one multiplication deep): quad w folds its window's bit-sums
+// (S + sum_l 2^l D_l), shifts the result to the window position (pos_w doublings -- the chains of the W windows run side by side, so
+// the launch is as deep as ONE chain) and the block adds the W terms through LDS.
 #if ROFL_KG(1)
-__global__ void __launch_bounds__(64) k_msm_horner(MsmWin mw, const ge *S_fin, const ge *C_fin, u32 nb, ge *out) {
+__global__ void __launch_bounds__(256) k_msm_horner(MsmWin mw, const ge *S_fin, const ge *C_fin, u32 nb, ge *out) {
     __shared__ ge sh[64];
-    u32 p = blockIdx.x, w = threadIdx.x;
+    const u32 p = blockIdx.x, w = threadIdx.x >> 2, q = threadIdx.x & 3;
+    auto coord = [&](const ge *pt) { gq r; r.v = fd_unpack(reinterpret_cast<const fe *>(pt)[q]); return r; };      // this lane's coordinate of *pt
+    gq acc;
     if (w < mw.W) {
         size_t pw = (size_t)p * mw.W + w;
-        gd acc = load_gd(&C_fin[pw * nb + nb - 1]);
+        acc = coord(&C_fin[pw * nb + nb - 1]);
 #pragma unroll 1
-        for (int l = (int)nb - 2; l >= 0; l--) acc = gd_add(gd_double(acc), load_gd(&C_fin[pw * nb + l]));
-        acc = gd_add(acc, load_gd(&S_fin[pw]));
+        for (int l = (int)nb - 2; l >= 0; l--) acc = gq_add(gq_double(acc, q), coord(&C_fin[pw * nb + l]), q);
+        acc = gq_add(acc, coord(&S_fin[pw]), q);
         u32 pos, wid; msm_window(mw, w, pos, wid);
 #pragma unroll 1
-        for (u32 i = 0; i + 1 < pos; i++) acc = gd_double_not(acc);
-        if (pos) acc = gd_double(acc);
-        sh[w] = gd_pack(acc);
+        for (u32 i = 0; i < pos; i++) acc = gq_double(acc, q);
+        reinterpret_cast<fe *>(&sh[w])[q] = fd_pack(acc.v);
     }
     __syncthreads();
 #pragma unroll 1
     for (u32 s = 32; s >= 1; s >>= 1) {
-        if (w < s && w + s < mw.W) sh[w] = gd_pack(gd_add(gd_unpack(sh[w]), gd_unpack(sh[w + s])));
+        if (w < s && w + s < mw.W) {
+            acc = gq_add(acc, coord(&sh[w + s]), q);
+            reinterpret_cast<fe *>(&sh[w])[q] = fd_pack(acc.v);
+        }
         __syncthreads();
     }
-    if (w == 0) out[p] = sh[0];
+    if (w == 0) reinterpret_cast<fe *>(&out[p])[q] = fd_pack(acc.v);
+}
+#endif
+
+// self-test of quad26.hpp: pair i = (P, Q) -> 2^doublings P + Q, once with one thread per pair (gd_*), once with one quad per pair (gq_*)
+#if ROFL_KG(4)
+__global__ void __launch_bounds__(TPB) k_dbg_quad(u32 pairs, u32 doublings, const uint8_t *in /* [pairs][2][32] */, uint8_t *out_serial, uint8_t *out_quad, u32 *status) {
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 i = t >> 2, q = t & 3;
+    if (i >= pairs) return;
+    __align__(16) uint8_t b[64];
+    for (int k = 0; k < 64; k++) b[k] = in[(size_t)i * 64 + k];
+    gd P, Q;
+    if (!gd_ristretto_decode(P, b) || !gd_ristretto_decode(Q, b + 32)) { atomicOr(status, 4u); return; }
+    gq a = gq_from_gd(P, q), c = gq_from_gd(Q, q);
+    for (u32 k = 0; k < doublings; k++) a = gq_double(a, q);
+    a = gq_add(a, c, q);
+    gd R = gq_to_gd(a);
+    if (q == 0) {
+        gd_ristretto_encode(out_quad + (size_t)i * 32, R);
+        gd S = P;
+        for (u32 k = 0; k < doublings; k++) S = gd_double(S);
+        S = gd_add(S, Q);
+        gd_ristretto_encode(out_serial + (size_t)i * 32, S);
+    }
 }
 #endif
 

@@ -725,7 +725,7 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
         }
         ks_red.reset();
         if (dev_horner)      // many problems: their Horner chains run side by side on the device, one point per problem comes back
-            hipLaunchKernelGGL(k_msm_horner, dim3((unsigned)np), dim3(64), 0, C.stream, mw, (const ge *)S_fin, (const ge *)C_fin, nb_final, hres_dev);
+            hipLaunchKernelGGL(k_msm_horner, dim3((unsigned)np), dim3(256), 0, C.stream, mw, (const ge *)S_fin, (const ge *)C_fin, nb_final, hres_dev);
         if (opt.overlap && !overlap_done) { opt.overlap(); overlap_done = true; }
         double t_sync0 = now_ms(); C.hs.enqueue += t_sync0 - t_enter;
         C.sync();
@@ -2070,6 +2070,26 @@ int rofl_dbg_msm(const uint8_t *scalars32, const uint8_t *points32, size_t n, ui
         std::vector<MsmProb> pr(1, MsmProb{dn, ds}); std::vector<ge5> res;
         msm_run(C, pr, n, res);
         h51::encode(out32, res[0]);
+        return ROFL_OK;
+    });
+}
+int rofl_dbg_quad_ops(const uint8_t *pairs64, size_t pairs, unsigned doublings, uint8_t *out_serial32, uint8_t *out_quad32) {
+    return guarded([&]() -> int {
+        LaneLock lane_lock = acquire_lane(); Ctx &C = *lane_lock.c;
+        if (pairs == 0) return fail(ROFL_BAD_PARAM, "bad parameter");
+        C.init();
+        uint8_t *din = C.tmp_in.as<uint8_t>(pairs * 64), *dout = C.tmp_out.as<uint8_t>(pairs * 64);
+        u32 *status = C.status.as<u32>(4);
+        HIPCHK(hipMemsetAsync(status, 0, 16, C.stream));
+        HIPCHK(hipMemsetAsync(dout, 0, pairs * 64, C.stream));
+        HIPCHK(hipMemcpyAsync(din, pairs64, pairs * 64, hipMemcpyHostToDevice, C.stream));
+        hipLaunchKernelGGL(k_dbg_quad, grid1(pairs * 4), dim3(TPB), 0, C.stream, (u32)pairs, doublings, (const uint8_t *)din, dout, dout + pairs * 32, status);
+        u32 st = 0;
+        HIPCHK(hipMemcpyAsync(&st, status, 4, hipMemcpyDeviceToHost, C.stream));
+        HIPCHK(hipMemcpyAsync(out_serial32, dout, pairs * 32, hipMemcpyDeviceToHost, C.stream));
+        HIPCHK(hipMemcpyAsync(out_quad32, dout + pairs * 32, pairs * 32, hipMemcpyDeviceToHost, C.stream));
+        C.sync();
+        if (st & 4u) return fail(ROFL_FORMAT_ERROR, "invalid Ristretto encoding");
         return ROFL_OK;
     });
 }

@@ -305,6 +305,28 @@ def test_full_size_properties_cfg2_e2e_partition(R):
     R.api.set_fp(16, 7)
 
 
+def test_quad_parallel_point_ops(R):
+    """csrc/quad26.hpp (a point spread over four lanes, used by the device-side Horner chains): 2^k P + Q for random and special
+    points, one quad per pair against one thread per pair, and both against the oracle's scalar arithmetic (P = a B, Q = b B)."""
+    rng = np.random.default_rng(99)
+    pairs = 200
+    a = orc.rand_scalars(rng, pairs); b = orc.rand_scalars(rng, pairs)
+    a[0] = 0; b[1] = 0; a[2] = 0; b[2] = 0                      # identity operands
+    b[3] = a[3]                                                  # P == Q
+    L = orc.L_ORDER
+    b[4] = np.frombuffer(((L - int.from_bytes(a[4].tobytes(), "little") * 2 ** 7) % L).to_bytes(32, "little"), np.uint8)      # 2^7 P + Q = identity
+    P = orc.commit_vec(a, None); Q = orc.commit_vec(b, None)
+    inp = np.ascontiguousarray(np.stack([P, Q], axis=1).reshape(pairs, 64))
+    for k in (0, 1, 7, 64):
+        o1 = np.zeros((pairs, 32), np.uint8); o2 = np.zeros((pairs, 32), np.uint8)
+        rc = R.lib().rofl_dbg_quad_ops(inp.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(pairs), ctypes.c_uint(k), o1.ctypes.data_as(ctypes.c_void_p), o2.ctypes.data_as(ctypes.c_void_p))
+        assert rc == 0
+        want = np.stack([np.frombuffer(((int.from_bytes(a[i].tobytes(), "little") * 2 ** k + int.from_bytes(b[i].tobytes(), "little")) % L).to_bytes(32, "little"), np.uint8) for i in range(pairs)])
+        ref = orc.commit_vec(want, None)
+        assert (o1 == ref).all(), k
+        assert (o2 == ref).all(), k
+
+
 def _gpu_msm(R, k, p):
     out = np.zeros(32, np.uint8)
     rc = R.lib().rofl_dbg_msm(k.ctypes.data_as(ctypes.c_void_p), p.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(k.shape[0]), out.ctypes.data_as(ctypes.c_void_p))

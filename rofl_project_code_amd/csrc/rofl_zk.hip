@@ -581,7 +581,9 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
         // the IPP tail (a few thousand terms per problem): one launch instead of memset / scatter / scan / accumulate / overflow / reduce
         u32 nside_small = (u32)(lr ? n / 2 : n);
         // (its blocks hold up to 130 KB of LDS, one per CU: with thousands of bucket arrays -- n_partition = 64 -- the general pipeline is faster)
-        bool small = !fb && slots_mode && allow_small && C.msm_small_max && nside_small <= C.msm_small_max && P.c <= 10 && nside_small <= 8 * P.B && PW <= 512;
+        // ... unless the blocks are small: at c <= 7 a block needs < 24 KB, eight of them share a CU and thousands of arrays go through in a few batches
+        size_t small_lds = std::max((size_t)P.B * 4 * (1 + MSM_SMALL_CAP), std::max(((size_t)(P.B / 8) * 4 + (size_t)(P.B / 16) * 5 + 1) * sizeof(ge), ((size_t)P.B + (size_t)P.B * 3 / 4 + 1) * sizeof(ge)));
+        bool small = !fb && slots_mode && allow_small && C.msm_small_max && nside_small <= C.msm_small_max && P.c <= 10 && nside_small <= 8 * P.B && (PW <= 512 || small_lds <= 24 * 1024);
         if (small) {
             *h_flag = 0;                                                  // list-overflow flag, in mapped host memory (plain stores from the kernel)
             ge *S_fin_s = dev_horner ? C.msm_S[0].as<ge>(PW) : hres_dev;
@@ -1110,10 +1112,9 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
     }
     // a[0], b[0]
     sc *h_ab = C.h_part.as<sc>(2 * P);
-    for (size_t c = 0; c < P; c++) {
-        HIPCHK(hipMemcpyAsync(h_ab + 2 * c, a + c * N, sizeof(sc), hipMemcpyDeviceToHost, C.stream));
-        HIPCHK(hipMemcpyAsync(h_ab + 2 * c + 1, b + c * N, sizeof(sc), hipMemcpyDeviceToHost, C.stream));
-    }
+    // element 0 of every chunk: two strided copies (one copy per chunk and vector costs ~7 us of stream time each -- 0.9 ms at n_partition = 64)
+    HIPCHK(hipMemcpy2DAsync(h_ab, 2 * sizeof(sc), a, N * sizeof(sc), sizeof(sc), P, hipMemcpyDeviceToHost, C.stream));
+    HIPCHK(hipMemcpy2DAsync(h_ab + 1, 2 * sizeof(sc), b, N * sizeof(sc), sizeof(sc), P, hipMemcpyDeviceToHost, C.stream));
     C.sync();
     for (size_t c = 0; c < P; c++) {
         uint8_t *o = proofs_out[c] + 7 * 32 + 64 * lgN;
@@ -1259,10 +1260,11 @@ int verify_chunks(Ctx &C, const char *label, size_t gens_capacity, size_t P, siz
     HIPCHK(hipMemcpyAsync(d_auxc, h_auxc, P * (4 + 2 * lg) * 32, hipMemcpyHostToDevice, C.stream));
     hipLaunchKernelGGL(k_decode, grid1(P * (4 + 2 * lg)), dim3(TPB), 0, C.stream, (u32)(P * (4 + 2 * lg)), (u32)(P * (4 + 2 * lg)), d_auxc, (const niels *)nullptr, d_auxn, (uint8_t *)nullptr, status);
     hipLaunchKernelGGL(k_vscalars, grid1(m, (u32)P), dim3(TPB), 0, C.stream, (u32)m, d_cp, (const PowTabs *)d_pt, aux_scal, naux);
-    for (size_t c = 0; c < P; c++) {
-        HIPCHK(hipMemcpyAsync(aux_pts + c * naux, d_Vniels + c * m, sizeof(niels) * m, hipMemcpyDeviceToDevice, C.stream));
-        HIPCHK(hipMemcpyAsync(aux_pts + c * naux + m, d_auxn + c * (4 + 2 * lg), sizeof(niels) * (4 + 2 * lg), hipMemcpyDeviceToDevice, C.stream));
-        HIPCHK(hipMemcpyAsync(aux_scal + c * naux + m, h_auxs + c * (4 + 2 * lg), sizeof(sc) * (4 + 2 * lg), hipMemcpyHostToDevice, C.stream));
+    {   // per chunk: [m commitments | 4 + 2 lg proof points] and the scalars of the latter -- three strided copies for all chunks
+        const size_t na2 = 4 + 2 * lg;
+        HIPCHK(hipMemcpy2DAsync(aux_pts, naux * sizeof(niels), d_Vniels, m * sizeof(niels), m * sizeof(niels), P, hipMemcpyDeviceToDevice, C.stream));
+        HIPCHK(hipMemcpy2DAsync(aux_pts + m, naux * sizeof(niels), d_auxn, na2 * sizeof(niels), na2 * sizeof(niels), P, hipMemcpyDeviceToDevice, C.stream));
+        HIPCHK(hipMemcpy2DAsync(aux_scal + m, naux * sizeof(sc), h_auxs, na2 * sizeof(sc), na2 * sizeof(sc), P, hipMemcpyHostToDevice, C.stream));
     }
     u32 h_status = 0;
     std::vector<MsmProb> pr(ngroups); std::vector<ge5> resA, resB;
@@ -1521,9 +1523,10 @@ int verify_impl(Ctx &C, size_t n_clients, const uint8_t *const *proofs, size_t p
         for (size_t c = 0; c < nv; c++) {
             size_t q = i * nv + c;
             memcpy(&Vh[q * chunk * 32], &hV[(i * dp + c * chunk) * 32], chunk * 32);
-            HIPCHK(hipMemcpyAsync(d_vn2 + q * chunk, d_vn + i * dp + c * chunk, sizeof(niels) * chunk, hipMemcpyDeviceToDevice, C.stream));
             cidx[q] = c;
         }
+    // a client's verified chunks are a prefix of its dp commitments: one strided copy (a plain one when the proofs cover everything)
+    HIPCHK(hipMemcpy2DAsync(d_vn2, nv * chunk * sizeof(niels), d_vn, dp * sizeof(niels), nv * chunk * sizeof(niels), n_clients, hipMemcpyDeviceToDevice, C.stream));
     std::vector<int> okc(P);
     GensPin gens_pin = get_gens(C, prove_range, chunk);
     C.sync();

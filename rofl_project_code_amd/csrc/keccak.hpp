@@ -97,12 +97,26 @@ inline void sha3_512(uint8_t out[64], const uint8_t *in, size_t n) { Sponge s(72
 
 // STROBE-128 as restricted by merlin 3.0.0 (strobe.rs): only AD, meta-AD and PRF.
 struct Merlin {
-    uint8_t st[200]; uint8_t pos, pos_begin, cur_flags;
+    u64 stw[25];                                               // the sponge state; bytes through b() (Keccak-f runs on it in place)
+    uint8_t pos, pos_begin, cur_flags;
     static const int R = 166;
-    void perm() { u64 w[25]; memcpy(w, st, 200); keccak_f1600(w); memcpy(st, w, 200); }
-    void run_f() { st[pos] ^= pos_begin; st[pos + 1] ^= 0x04; st[R + 1] ^= 0x80; perm(); pos = 0; pos_begin = 0; }
-    void absorb(const uint8_t *d, size_t n) { for (size_t i = 0; i < n; i++) { st[pos++] ^= d[i]; if (pos == R) run_f(); } }
-    void squeeze(uint8_t *d, size_t n) { for (size_t i = 0; i < n; i++) { d[i] = st[pos]; st[pos] = 0; pos++; if (pos == R) run_f(); } }
+    uint8_t *b() { return reinterpret_cast<uint8_t *>(stw); }
+    const uint8_t *b() const { return reinterpret_cast<const uint8_t *>(stw); }
+    void perm() { keccak_f1600(stw); }
+    void run_f() { uint8_t *st = b(); st[pos] ^= pos_begin; st[pos + 1] ^= 0x04; st[R + 1] ^= 0x80; perm(); pos = 0; pos_begin = 0; }
+    // runs of bytes up to the end of the rate block, eight at a time (the verifier appends 8 192 commitments per chunk: 41 bytes each)
+    void absorb(const uint8_t *d, size_t n) {
+        while (n) {
+            size_t take = (size_t)R - pos; if (take > n) take = n;
+            uint8_t *st = b() + pos;
+            size_t i = 0;
+            for (; i + 8 <= take; i += 8) { u64 x, y; memcpy(&x, st + i, 8); memcpy(&y, d + i, 8); x ^= y; memcpy(st + i, &x, 8); }
+            for (; i < take; i++) st[i] ^= d[i];
+            pos = (uint8_t)(pos + take); d += take; n -= take;
+            if (pos == R) run_f();
+        }
+    }
+    void squeeze(uint8_t *d, size_t n) { uint8_t *st = b(); for (size_t i = 0; i < n; i++) { d[i] = st[pos]; st[pos] = 0; pos++; if (pos == R) run_f(); } }
     void begin_op(uint8_t flags, bool more) {
         if (more) return;
         uint8_t hdr[2] = {pos_begin, flags};
@@ -115,9 +129,9 @@ struct Merlin {
     void prf(uint8_t *d, size_t n) { begin_op(1 | 2 | 4, false); squeeze(d, n); }
 
     explicit Merlin(const char *label, size_t len) {
-        memset(st, 0, 200); pos = pos_begin = cur_flags = 0;
+        memset(stw, 0, 200); pos = pos_begin = cur_flags = 0;
         const uint8_t hdr[6] = {1, R + 2, 1, 0, 1, 96};
-        memcpy(st, hdr, 6); memcpy(st + 6, "STROBEv1.0.2", 12);
+        memcpy(b(), hdr, 6); memcpy(b() + 6, "STROBEv1.0.2", 12);
         perm();
         meta_ad((const uint8_t *)"Merlin v1.0", 11, false);
         append("dom-sep", (const uint8_t *)label, len);

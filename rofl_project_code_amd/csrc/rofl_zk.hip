@@ -1695,7 +1695,7 @@ DMerlin sigma_init_state(int kind) {
     // rand_proof_domain_sep (rand_proof/transcript.rs:20-22) -- but the begin_op of the NEXT append depends on pos_begin,
     // so the whole state (bytes, pos, pos_begin) is handed to the kernel
     t.append("dom-sep", (const uint8_t *)"randomness proof v1", 19);
-    DMerlin d; memcpy(d.st, t.st, 200); d.pos = t.pos; d.pos_begin = t.pos_begin;
+    DMerlin d; memcpy(d.st, t.b(), 200); d.pos = t.pos; d.pos_begin = t.pos_begin;
     return d;
 }
 int sigma_create(int kind, const float *values, size_t d, const uint8_t *r1, size_t d_r1, const uint8_t *r2, const uint8_t *existing,

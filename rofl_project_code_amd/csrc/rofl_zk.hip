@@ -1206,12 +1206,22 @@ int verify_chunks(Ctx &C, const char *label, size_t gens_capacity, size_t P, siz
         for (size_t k = 0; k < lg; k++) {
             t.append("L", ipp + 64 * k, 32); t.append("R", ipp + 64 * k + 32, 32);
             u[k] = t.challenge_scalar("u");
-            cp.u[k] = h_mont(u[k]); cp.uinv[k] = h51::sc_invert_mont_fast(cp.u[k]);
-            ui[k] = h_canon(cp.uinv[k]);
+            cp.u[k] = h_mont(u[k]);
         }
         sc zz = h_mul(z, z);
         cp.y = h_mont(y); cp.z = h_mont(z); cp.zz = h_mont(zz); cp.x = h_mont(x);
-        cp.yinv = h51::sc_invert_mont_fast(cp.y);
+        {   // u_0^-1 .. u_(lg-1)^-1 and y^-1 with ONE inversion (10 us each otherwise, on the verifier's critical path): prefix products,
+            // invert the last, walk back.  A zero challenge (probability 2^-252) makes every inverse zero, as the single inversions would.
+            std::vector<sc> pre(lg + 1);
+            sc run = cp.y; pre[0] = run;
+            for (size_t k = 0; k < lg; k++) { run = sc_montmul(run, cp.u[k]); pre[k + 1] = run; }
+            bool any_zero = sc_iszero(h_canon(run));
+            sc inv = any_zero ? sc_zero() : h51::sc_invert_mont_fast(run);
+            for (size_t k = lg; k >= 1; k--) { cp.uinv[k - 1] = sc_montmul(inv, pre[k - 1]); inv = sc_montmul(inv, cp.u[k - 1]); }
+            cp.yinv = inv;
+            if (any_zero) { cp.yinv = h51::sc_invert_mont_fast(cp.y); for (size_t k = 0; k < lg; k++) cp.uinv[k] = h51::sc_invert_mont_fast(cp.u[k]); }
+            for (size_t k = 0; k < lg; k++) ui[k] = h_canon(cp.uinv[k]);
+        }
         fill_pow2(cp.ypow2, cp.y, MAX_LG); fill_pow2(cp.yinvpow2, cp.yinv, MAX_LG); fill_pow2(cp.zpow2, cp.z, MAX_LG);
         cp.a_fin = h_mont(a); cp.b_fin = h_mont(b);
         cp.c_zz = h_mont(h_mul(rho, h_mul(cc, zz)));

@@ -1076,7 +1076,7 @@ __global__ void __launch_bounds__(1024) k_msm_scatter_lds(u32 n_side, u32 tile_p
 // A bin that outgrows its region (scalars built to collide) raises *overflow and the host repeats the MSM on the slot path.
 struct Msm2L { u32 nbins, fbits, ebits, cap_bin, stage; };      // stage = LDS staging slots per bin
 #define MSM_LIST_ABS 0xffffffffu
-#define MSM_BIN_TAIL 1024u      /* entries of a coarse bin's tail region: the < 32 left-overs of every tile, and staging-row spills */
+#define MSM_BIN_TAIL 2048u      /* entries of a coarse bin's tail region: the < 32 left-overs of every tile (<= 48 tiles per array), and staging-row spills */
 #if ROFL_KG(1)
 __global__ void __launch_bounds__(1024) k_msm_bin_l1(u32 n_side, u32 tile_pts, u32 iter_pts, MsmWin mw, MsmMap mm, const MsmProb *probs, u32 *bin_cursor /* [PW][nbins][2] */,
                                                      u32 *bins /* [PW][nbins][cap_bin] */, u32 *tails /* [PW][nbins][MSM_BIN_TAIL] */, Msm2L L, u32 *overflow) {

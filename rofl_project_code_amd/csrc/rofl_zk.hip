@@ -619,7 +619,7 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
             HIPCHK(hipMemsetAsync(bcur, 0, sizeof(u32) * PW * tl.nbins * 2, C.stream));
             u32 iter_pts = (tl.stage >= 144 ? 16384u : 12288u) / mm.fb_wps; if (iter_pts < 1024) iter_pts = 1024;      // ~ 64 (48) new items per bin and iteration against a row of 144 (72)
             u32 tile = iter_pts;
-            while (((size_t)((n_side2 + tile - 1) / tile) * PW > 512 || (n_side2 + tile - 1) / tile > 32) && tile < n_side2) tile *= 2;      // <= 32 tiles per array: their left-overs fit the bin tails
+            while (((size_t)((n_side2 + tile - 1) / tile) * PW > 512 || (n_side2 + tile - 1) / tile > 48) && tile < n_side2) tile *= 2;      // <= 48 tiles per array: their left-overs (< 32 each) fit the bin tails with room for row spills
             dim3 grid((n_side2 + tile - 1) / tile, (u32)PW);
             uint64_t terms = (uint64_t)(lr ? nq : np) * n, items = terms * 16u;
             { KSpan ks(C.tm, C.stream, ROFL_TK_MSM_SCATTER, 0, terms * 32 + items * 4);

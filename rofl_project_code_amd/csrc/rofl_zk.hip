@@ -253,7 +253,7 @@ struct Ctx {
     // Waiting for the lane's stream.  hipStreamSynchronize spins (lowest latency: right for a call that is alone on the device); with
     // more than three calls in flight -- or when the host asked for it (ROFL_BLOCKING_SYNC=1) -- the thread sleeps between queries instead, so
     // a server that keeps several clients in flight does not burn one host core per client on busy-waiting (ROFL_BLOCKING_SYNC=0: always spin).
-    int blocking_sync = -1; hipEvent_t ev_block = nullptr; bool batch_mode = false;
+    int blocking_sync = -1; hipEvent_t ev_block = nullptr, ev_v = nullptr; bool batch_mode = false;
     void sync() {
         const Ctx *P = parent ? parent : this;
         // (up to three calls in flight still spin: the three proofs of ONE client's L2 update run side by side -- EncParamsL2::encrypt --
@@ -801,7 +801,8 @@ sc sum_partials(const sc *p, size_t count, size_t stride, size_t which) {
 // proofs_out[c]: where chunk c's proof goes (host).  The chunks may belong to different clients (batched create).
 struct ChunkNonce { int mode; NonceSeed seed; const uint8_t *d_stream; u64 stream_scalars, base; };
 void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const u64 *d_vshift, const sc *d_blind,
-                  const std::vector<ChunkNonce> &nonces, const uint8_t *h_V /* [P][m][32] host */, uint8_t *const *proofs_out) {
+                  const std::vector<ChunkNonce> &nonces, const uint8_t *h_V /* [P][m][32] host */, uint8_t *const *proofs_out,
+                  hipEvent_t v_ready = nullptr /* recorded after the copy that fills h_V; nullptr: already complete */) {
     size_t N = n * m; unsigned lgN = lg2u(N);
     static const bool ptrace = getenv("ROFL_TRACE") && atoi(getenv("ROFL_TRACE")) >= 2;
     double pt0 = now_ms(), ptl = pt0;
@@ -850,6 +851,7 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
         MsmOpt mo; if (wtab) { mo.fb_wtab = wtab; mo.fb_stride = 2 * N; }
         mo.overlap = [&]() {      // the transcript prefix (m commitments per chunk) does not depend on S: hash it while the MSM runs
             double t0 = now_ms();
+            if (v_ready) HIPCHK(hipEventSynchronize(v_ready));      // first in the stream: long done by the time the S launches are enqueued
             C.pool->run(P, [&](size_t c) {
                 Merlin &t = tr[c];
                 t.append("dom-sep", (const uint8_t *)"rangeproof v1", 13);
@@ -1452,10 +1454,13 @@ int create_impl(Ctx &C, size_t nc, const float *const *values, size_t d, const u
     HIPCHK(hipMemcpyAsync(hV, Vb, na * dp * 32, hipMemcpyDeviceToHost, C.stream));
     for (size_t k = 0; k < na; k++) HIPCHK(hipMemcpyAsync(commits_out[act[k]], Cb + k * dp * 32, d * 32, hipMemcpyDeviceToHost, C.stream));
     GensPin gens_pin = get_gens(C, prove_range, chunk);
-    C.sync();       // V bytes (host copy) are complete
+    // no sync here: the prover's first kernels (nonces, A, the S MSM) queue up behind the commitments; the host needs the V bytes only
+    // when it hashes them into the transcripts, while the S MSM runs
+    if (!C.ev_v) HIPCHK(hipEventCreateWithFlags(&C.ev_v, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(C.ev_v, C.stream));
     std::vector<uint8_t *> pout(na * P);
     for (size_t k = 0; k < na; k++) for (size_t c = 0; c < P; c++) pout[k * P + c] = proofs_out[act[k]] + c * plen;
-    prove_chunks(C, "RangeProof", na * P, prove_range, chunk, vshift, d_blind_buf, cn, hV, pout.data());
+    prove_chunks(C, "RangeProof", na * P, prove_range, chunk, vshift, d_blind_buf, cn, hV, pout.data(), C.ev_v);
     timing_end(C);
     return ROFL_OK;
 }

@@ -177,9 +177,8 @@ def dry_run(args, world, rank):
     cdev = torch.device("cpu")
     t0 = time.perf_counter()
     for s in range(args.steps):
-        got = rd.gather_bytes(np.full(64, rank, np.uint8), cdev)
-        assert [int(g[0]) for g in got] == list(range(world))
-        assert rd.all_verified(True, cdev)
+        ok, got = rd.exchange_round([np.full(64, rank, np.uint8), np.full(7, 100 + rank, np.uint8)], True, cdev)
+        assert ok and [int(g[0][0]) for g in got] == list(range(world)) and [int(g[1][6]) for g in got] == [100 + r for r in range(world)]
     elapsed = time.perf_counter() - t0
     rccl_world = 1
     if world > 1:
@@ -276,8 +275,7 @@ def run_rank(args):
         vals, bl = (inputs or clients)[s]
         pr, cm, ok = one_client(vals, bl, s, s, record)
         if world > 1:       # the exchange step: server-side collection of proof bytes + commitments, verify bits
-            rd.gather_bytes(pr, cdev); rd.gather_bytes(cm, cdev)
-            ok = rd.all_verified(ok, cdev)
+            ok, _ = rd.exchange_round([pr, cm], ok, cdev)      # one all-gather: [verify bit | proof bytes | commitments] of every rank
         assert ok, "proof failed to verify"
 
     # cold figures: the reference rebuilds BulletproofGens in every call; here the tables are built once per (n, m)

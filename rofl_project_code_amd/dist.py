@@ -30,3 +30,47 @@ def all_verified(ok_local, device, group=None):
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
     return bool(t.item())
+
+
+_round_bufs = {}
+
+
+def exchange_round(payloads, ok_local, device, group=None):
+    """One collective per round instead of three: every rank contributes [verify bit | payload_0 | payload_1 ...] (equal sizes on all
+    ranks), the pieces are all-gathered into ONE preallocated device buffer and come back in one copy.  Returns (ok_all, per_rank) with
+    ok_all = MIN over the ranks' verify bits (server.rs:474-484: one failing client fails the round) and per_rank[r] = the list of rank r's
+    payloads as numpy views."""
+    parts = [np.ascontiguousarray(p, dtype=np.uint8).reshape(-1) for p in payloads]
+    sizes = [p.size for p in parts]
+    n = 1 + sum(sizes)
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    key = (n, world, str(device))
+    if key not in _round_bufs:
+        _round_bufs[key] = (torch.empty(n, dtype=torch.uint8, device=device), torch.empty(n * world, dtype=torch.uint8, device=device),
+                            torch.empty(n, dtype=torch.uint8).pin_memory() if str(device) != "cpu" else torch.empty(n, dtype=torch.uint8))
+    loc, allb, stage = _round_bufs[key]
+    host = stage.numpy()
+    host[0] = 1 if ok_local else 0
+    o = 1
+    for p in parts:
+        host[o:o + p.size] = p; o += p.size
+    loc.copy_(stage, non_blocking=True)
+    if world == 1:
+        allb.copy_(loc)
+    elif dist.get_backend(group) == "gloo":
+        outs = list(allb.view(world, n).unbind(0))
+        dist.all_gather(outs, loc, group=group)
+    else:
+        try:
+            dist.all_gather_into_tensor(allb, loc, group=group)
+        except (RuntimeError, AttributeError):      # a backend without the flat form: per-rank views of the same buffer
+            dist.all_gather(list(allb.view(world, n).unbind(0)), loc, group=group)
+    got = allb.cpu().numpy().reshape(world, n)
+    ok_all = bool(got[:, 0].min() == 1)
+    per_rank = []
+    for r in range(world):
+        o = 1; lst = []
+        for sz in sizes:
+            lst.append(got[r, o:o + sz]); o += sz
+        per_rank.append(lst)
+    return ok_all, per_rank

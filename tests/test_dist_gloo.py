@@ -41,6 +41,13 @@ def _worker(rank, world, port, q):
             assert orc.verify_rangeproof(pp[s], cc[s], nb, fb, ff) == (0, True)
     assert rd.all_verified(ok_local, "cpu") is True
     assert rd.all_verified(rank != 1, "cpu") is False     # one failing rank fails the round (server.rs:474-484)
+    # the same round as ONE collective (what bench.py times): verify bit + both payloads of every rank in one all-gather
+    ok_all, per_rank = rd.exchange_round([buf_p, buf_c], ok_local, "cpu")
+    assert ok_all is True and len(per_rank) == world
+    for r in range(world):
+        assert (per_rank[r][0] == np.asarray(all_p[r]).reshape(-1)).all() and (per_rank[r][1] == np.asarray(all_c[r]).reshape(-1)).all()
+    ok_all, _ = rd.exchange_round([buf_p, buf_c], rank != 1, "cpu")
+    assert ok_all is False
     dist.barrier(); dist.destroy_process_group()
     q.put(rank)
 

@@ -238,7 +238,7 @@ struct Ctx {
     std::mutex init_mu, gens_mu;      // primary lane only: one-time initialisation; generator-table cache
     std::atomic<int> active_calls{0};  // primary lane only: calls currently holding a lane
     std::atomic<unsigned> rr{0};
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, stream2 = nullptr;      // stream2: side stream for work that may run beside the main one (created on first use)
     std::mutex mu;
     HostTables ht;
     niels *d_tabB = nullptr, *d_tabBb = nullptr;
@@ -253,7 +253,7 @@ struct Ctx {
     // Waiting for the lane's stream.  hipStreamSynchronize spins (lowest latency: right for a call that is alone on the device); with
     // more than three calls in flight -- or when the host asked for it (ROFL_BLOCKING_SYNC=1) -- the thread sleeps between queries instead, so
     // a server that keeps several clients in flight does not burn one host core per client on busy-waiting (ROFL_BLOCKING_SYNC=0: always spin).
-    int blocking_sync = -1; hipEvent_t ev_block = nullptr, ev_v = nullptr; bool batch_mode = false;
+    int blocking_sync = -1; hipEvent_t ev_block = nullptr, ev_v = nullptr, ev_fork = nullptr; bool batch_mode = false;
     void sync() {
         const Ctx *P = parent ? parent : this;
         // (up to three calls in flight still spin: the three proofs of ONE client's L2 update run side by side -- EncParamsL2::encrypt --
@@ -1447,20 +1447,27 @@ int create_impl(Ctx &C, size_t nc, const float *const *values, size_t d, const u
     sc negoff = sc_neg(sc_from_u64(1ULL << (prove_range - 1)));
     niels h_shift = h51::to_niels32(h_fixed_mul(C.ht.B5, negoff));
     niels *d_shift = C.tmp_in.as<niels>(1);
-    HIPCHK(hipMemcpyAsync(d_shift, &h_shift, sizeof(niels), hipMemcpyHostToDevice, C.stream));
     uint8_t *Vb = C.Vbytes.as<uint8_t>(na * dp * 32), *Cb = C.Cbytes.as<uint8_t>(na * dp * 32);
-    hipLaunchKernelGGL(k_commit, grid1(na * dp), dim3(TPB), 0, C.stream, (u32)(na * dp), vshift, (const sc *)nullptr, d_blind_buf, C.d_tabB, C.d_tabBb, d_shift, Vb, Cb, (u32)d, (u32)dp);
+    // The commitment kernel is a latency chain on d threads (two fixed-base multiplications and two encodings each: 0.4 ms on a tenth
+    // of the chip) and nothing in the prover reads its output on the device: it runs on the side stream, beside the nonce expansion and the
+    // A / S launches.  The host needs the V bytes when it hashes them into the transcripts (ev_v), the caller's commitment arrays when the
+    // call returns.
+    if (!C.stream2) HIPCHK(hipStreamCreateWithFlags(&C.stream2, hipStreamNonBlocking));
+    if (!C.ev_v) { HIPCHK(hipEventCreateWithFlags(&C.ev_v, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&C.ev_fork, hipEventDisableTiming)); }
+    HIPCHK(hipEventRecord(C.ev_fork, C.stream));                  // inputs quantised (and compacted)
+    HIPCHK(hipStreamWaitEvent(C.stream2, C.ev_fork, 0));
+    HIPCHK(hipMemcpyAsync(d_shift, &h_shift, sizeof(niels), hipMemcpyHostToDevice, C.stream2));
+    hipLaunchKernelGGL(k_commit, grid1(na * dp), dim3(TPB), 0, C.stream2, (u32)(na * dp), vshift, (const sc *)nullptr, d_blind_buf, C.d_tabB, C.d_tabBb, d_shift, Vb, Cb, (u32)d, (u32)dp);
     uint8_t *hV = C.h_V.as<uint8_t>(na * dp * 32);
-    HIPCHK(hipMemcpyAsync(hV, Vb, na * dp * 32, hipMemcpyDeviceToHost, C.stream));
-    for (size_t k = 0; k < na; k++) HIPCHK(hipMemcpyAsync(commits_out[act[k]], Cb + k * dp * 32, d * 32, hipMemcpyDeviceToHost, C.stream));
+    HIPCHK(hipMemcpyAsync(hV, Vb, na * dp * 32, hipMemcpyDeviceToHost, C.stream2));
+    HIPCHK(hipEventRecord(C.ev_v, C.stream2));
+    for (size_t k = 0; k < na; k++) HIPCHK(hipMemcpyAsync(commits_out[act[k]], Cb + k * dp * 32, d * 32, hipMemcpyDeviceToHost, C.stream2));
     GensPin gens_pin = get_gens(C, prove_range, chunk);
-    // no sync here: the prover's first kernels (nonces, A, the S MSM) queue up behind the commitments; the host needs the V bytes only
-    // when it hashes them into the transcripts, while the S MSM runs
-    if (!C.ev_v) HIPCHK(hipEventCreateWithFlags(&C.ev_v, hipEventDisableTiming));
-    HIPCHK(hipEventRecord(C.ev_v, C.stream));
     std::vector<uint8_t *> pout(na * P);
     for (size_t k = 0; k < na; k++) for (size_t c = 0; c < P; c++) pout[k * P + c] = proofs_out[act[k]] + c * plen;
+    struct Join { hipStream_t s; ~Join() { (void)hipStreamSynchronize(s); } } join{C.stream2};      // also on the error paths: the copies target caller memory
     prove_chunks(C, "RangeProof", na * P, prove_range, chunk, vshift, d_blind_buf, cn, hV, pout.data(), C.ev_v);
+    HIPCHK(hipStreamSynchronize(C.stream2));
     timing_end(C);
     return ROFL_OK;
 }

@@ -253,7 +253,7 @@ struct Ctx {
     // Waiting for the lane's stream.  hipStreamSynchronize spins (lowest latency: right for a call that is alone on the device); with
     // more than three calls in flight -- or when the host asked for it (ROFL_BLOCKING_SYNC=1) -- the thread sleeps between queries instead, so
     // a server that keeps several clients in flight does not burn one host core per client on busy-waiting (ROFL_BLOCKING_SYNC=0: always spin).
-    int blocking_sync = -1; hipEvent_t ev_block = nullptr, ev_v = nullptr, ev_fork = nullptr; bool batch_mode = false;
+    int blocking_sync = -1; hipEvent_t ev_block = nullptr, ev_v = nullptr, ev_fork = nullptr, ev_a = nullptr, ev_a0 = nullptr; bool batch_mode = false;
     void sync() {
         const Ctx *P = parent ? parent : this;
         // (up to three calls in flight still spin: the three proofs of ONE client's L2 update run side by side -- EncParamsL2::encrypt --
@@ -825,19 +825,24 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
     HIPCHK(hipMemcpyAsync(d_cp, h_cp, sizeof(ChunkParams) * P, hipMemcpyHostToDevice, C.stream));
     sc *sL = C.sL.as<sc>(P * N), *sR = C.sR.as<sc>(P * N), *party = C.party.as<sc>(P * 4 * m), *Scanon = C.Scanon.as<sc>(P * 2 * N);
     hipLaunchKernelGGL(k_nonce_expand, grid1(per, (u32)P), dim3(TPB), 0, C.stream, (u32)n, (u32)m, d_cp, sL, sR, party, Scanon);
-    // A partials
+    // A partials: they depend on the values only and the host reads them after the S MSM -- side stream, beside the nonce expansion
+    if (!C.stream2) HIPCHK(hipStreamCreateWithFlags(&C.stream2, hipStreamNonBlocking));
+    if (!C.ev_a) { HIPCHK(hipEventCreateWithFlags(&C.ev_a, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&C.ev_a0, hipEventDisableTiming)); }
+    HIPCHK(hipEventRecord(C.ev_a0, C.stream));                    // d_vshift is ready (and the previous call's reads of `partial` are done)
+    HIPCHK(hipStreamWaitEvent(C.stream2, C.ev_a0, 0));
     ge *partial = C.partial.as<ge>(P * m);
-    hipLaunchKernelGGL(k_bitcommit, grid1(m, (u32)P), dim3(TPB), 0, C.stream, (u32)n, (u32)m, d_vshift, tbl, partial);
+    hipLaunchKernelGGL(k_bitcommit, grid1(m, (u32)P), dim3(TPB), 0, C.stream2, (u32)n, (u32)m, d_vshift, tbl, partial);
     u32 nblkA = (u32)std::min<size_t>(16, (m + TPB - 1) / TPB);
     ge *partial2 = C.partial2.as<ge>(P * nblkA);
-    hipLaunchKernelGGL(k_point_sum, dim3(nblkA, (u32)P), dim3(TPB), TPB * sizeof(ge), C.stream, partial, (u32)m, partial2);
+    hipLaunchKernelGGL(k_point_sum, dim3(nblkA, (u32)P), dim3(TPB), TPB * sizeof(ge), C.stream2, partial, (u32)m, partial2);
+    ge *h_A = C.h_part.as<ge>(P * nblkA);
+    HIPCHK(hipMemcpyAsync(h_A, partial2, sizeof(ge) * P * nblkA, hipMemcpyDeviceToHost, C.stream2));
+    HIPCHK(hipEventRecord(C.ev_a, C.stream2));
     u32 nblkS = (u32)std::min<size_t>(16, (m + TPB - 1) / TPB);
     sc *scpart = C.scpart.as<sc>(P * 64 * 3);
     PowTabs *d_pt = C.powtabs.as<PowTabs>(P);
     hipLaunchKernelGGL(k_party_sums, dim3(nblkS, (u32)P), dim3(TPB), 0, C.stream, (u32)m, 0, d_cp, (const PowTabs *)d_pt, party, d_blind, scpart);
-    ge *h_A = C.h_part.as<ge>(P * nblkA);
     sc *h_sc = C.h_misc2.as<sc>(P * 64 * 3);
-    HIPCHK(hipMemcpyAsync(h_A, partial2, sizeof(ge) * P * nblkA, hipMemcpyDeviceToHost, C.stream));
     HIPCHK(hipMemcpyAsync(h_sc, scpart, sizeof(sc) * P * nblkS * 3, hipMemcpyDeviceToHost, C.stream));
     // S = <sL,G> + <sR,H> + s_bl * Bb
     std::vector<MsmProb> probs(P); std::vector<ge5> res;
@@ -863,6 +868,7 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
         msm_run(C, probs, 2 * N, res, mo);
     }
     mark("msm S");
+    HIPCHK(hipEventSynchronize(C.ev_a));      // the A partials (side stream: done long before the S MSM)
 
     double th = now_ms();
     C.pool->run(P, [&](size_t c) {

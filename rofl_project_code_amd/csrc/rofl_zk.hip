@@ -1185,6 +1185,19 @@ int verify_chunks(Ctx &C, const char *label, size_t gens_capacity, size_t P, siz
     sc *h_auxs = C.h_auxs.as<sc>(P * (4 + 2 * lg));
     std::vector<sc> sB(P), sBb(P);
     static const uint8_t zero32[32] = {0};
+    // the proof points A S T1 T2 L* R* of every chunk go to the device and are decoded while the host hashes the transcripts
+    for (size_t c = 0; c < P; c++) {
+        const uint8_t *p = proofs + c * plen; const uint8_t *ipp = p + 7 * 32;
+        uint8_t *ac = h_auxc + c * (4 + 2 * lg) * 32;
+        memcpy(ac, p, 128);
+        for (size_t k = 0; k < lg; k++) { memcpy(ac + 128 + 32 * k, ipp + 64 * k, 32); memcpy(ac + 128 + 32 * (lg + k), ipp + 64 * k + 32, 32); }
+    }
+    uint8_t *d_auxc = C.tmp_in.as<uint8_t>(P * (4 + 2 * lg) * 32);
+    niels *d_auxn = C.tmp_in2.as<niels>(P * (4 + 2 * lg));
+    u32 *status = C.status.as<u32>(4);
+    HIPCHK(hipMemsetAsync(status, 0, 16, C.stream));
+    HIPCHK(hipMemcpyAsync(d_auxc, h_auxc, P * (4 + 2 * lg) * 32, hipMemcpyHostToDevice, C.stream));
+    hipLaunchKernelGGL(k_decode, grid1(P * (4 + 2 * lg)), dim3(TPB), 0, C.stream, (u32)(P * (4 + 2 * lg)), (u32)(P * (4 + 2 * lg)), d_auxc, (const niels *)nullptr, d_auxn, (uint8_t *)nullptr, status);
     double th = now_ms();
     C.pool->run(P, [&](size_t c) {
         const uint8_t *p = proofs + c * plen; const uint8_t *ipp = p + 7 * 32;
@@ -1235,13 +1248,9 @@ int verify_chunks(Ctx &C, const char *label, size_t gens_capacity, size_t P, siz
         cp.c_zz = h_mont(h_mul(rho, h_mul(cc, zz)));
         cp.rz = h_mont(h_mul(rho, z)); cp.ra = h_mont(h_mul(rho, a)); cp.rb = h_mont(h_mul(rho, b)); cp.rzz = h_mont(h_mul(rho, zz));
         // aux points and scalars: A S T1 T2 L* R*
-        uint8_t *ac = h_auxc + c * (4 + 2 * lg) * 32; sc *as = h_auxs + c * (4 + 2 * lg);
-        memcpy(ac, p, 128);
+        sc *as = h_auxs + c * (4 + 2 * lg);
         as[0] = rho; as[1] = h_mul(rho, x); as[2] = h_mul(as[1], cc); as[3] = h_mul(as[2], x);
-        for (size_t k = 0; k < lg; k++) {
-            memcpy(ac + 128 + 32 * k, ipp + 64 * k, 32); memcpy(ac + 128 + 32 * (lg + k), ipp + 64 * k + 32, 32);
-            as[4 + k] = h_mul(rho, h_mul(u[k], u[k])); as[4 + lg + k] = h_mul(rho, h_mul(ui[k], ui[k]));
-        }
+        for (size_t k = 0; k < lg; k++) { as[4 + k] = h_mul(rho, h_mul(u[k], u[k])); as[4 + lg + k] = h_mul(rho, h_mul(ui[k], ui[k])); }
         // B_blinding: -e_bl - c t_x_bl ; B: w (t_x - a b) + c (delta - t_x)
         sBb[c] = h_mul(rho, sc_neg(sc_add(e_bl, h_mul(cc, t_x_bl))));
         // sum_{i<N} y^i = prod_b (1 + y^(2^b)) for N = 2^lg ; likewise for 2^n and z^m
@@ -1271,12 +1280,6 @@ int verify_chunks(Ctx &C, const char *label, size_t gens_capacity, size_t P, siz
     // aux arrays
     niels *aux_pts = C.aux_pts.as<niels>(P * naux);
     sc *aux_scal = C.aux_scal.as<sc>(P * naux);
-    uint8_t *d_auxc = C.tmp_in.as<uint8_t>(P * (4 + 2 * lg) * 32);
-    niels *d_auxn = C.tmp_in2.as<niels>(P * (4 + 2 * lg));
-    u32 *status = C.status.as<u32>(4);
-    HIPCHK(hipMemsetAsync(status, 0, 16, C.stream));
-    HIPCHK(hipMemcpyAsync(d_auxc, h_auxc, P * (4 + 2 * lg) * 32, hipMemcpyHostToDevice, C.stream));
-    hipLaunchKernelGGL(k_decode, grid1(P * (4 + 2 * lg)), dim3(TPB), 0, C.stream, (u32)(P * (4 + 2 * lg)), (u32)(P * (4 + 2 * lg)), d_auxc, (const niels *)nullptr, d_auxn, (uint8_t *)nullptr, status);
     hipLaunchKernelGGL(k_vscalars, grid1(m, (u32)P), dim3(TPB), 0, C.stream, (u32)m, d_cp, (const PowTabs *)d_pt, aux_scal, naux);
     {   // per chunk: [m commitments | 4 + 2 lg proof points] and the scalars of the latter -- three strided copies for all chunks
         const size_t na2 = 4 + 2 * lg;

@@ -895,7 +895,7 @@ __device__ __forceinline__ MsmItem msm_item(u32 n, const MsmWin &mw, const MsmMa
     int d = msm_digit(k, wpos, wwid);
     if (mm.fb_sets) {
         u32 sets_tot = mm.fb_sets * (mm.lr_nh ? 2u : 1u);
-        it.pw = q * sets_tot + side * mm.fb_sets + w / mm.fb_wps;
+        it.pw = q * sets_tot + side * mm.fb_sets + w % mm.fb_sets;      // set a = windows a, a + sets, a + 2 sets, ... (see k_msm_bin_l1)
         it.entry = w * mm.fb_stride + i;
     } else {
         it.pw = p * mw.W + w;
@@ -1019,7 +1019,8 @@ __global__ void __launch_bounds__(1024) k_msm_scatter_lds(u32 n_side, u32 tile_p
     u32 y = blockIdx.y, a = y % per_q, side = (y / per_q) % nside, q = y / (per_q * nside);
     u32 p = mm.lr_nh ? 2 * q + side : q;
     u32 pw = p * per_q + a;                                // == msm_item's pw for both layouts
-    u32 w0 = mm.fb_sets ? a * mm.fb_wps : a, w1 = mm.fb_sets ? w0 + mm.fb_wps : a + 1;
+    // fixed-base: set a takes the windows a, a + sets, a + 2 sets, ... ; generic: array a is window a
+    const u32 wn = mm.fb_sets ? mm.fb_wps : 1u, wstep = mm.fb_sets ? mm.fb_sets : 1u;
     u32 k0 = blockIdx.x * tile_pts, k1 = k0 + tile_pts < n_side ? k0 + tile_pts : n_side;
     const sc *scal = probs[p].scal;
     for (u32 b = threadIdx.x; b < B; b += 1024) lcnt[b] = 0;
@@ -1027,7 +1028,8 @@ __global__ void __launch_bounds__(1024) k_msm_scatter_lds(u32 n_side, u32 tile_p
     for (u32 k = k0 + threadIdx.x; k < k1; k += 1024) {
         u32 i = mm.lr_nh ? msm_side_term(mm, side, k) : k;
         const u32 *kw = reinterpret_cast<const u32 *>(&scal[i]);
-        for (u32 w = w0; w < w1; w++) {
+        for (u32 wk = 0; wk < wn; wk++) {
+            u32 w = a + wk * wstep;
             u32 wpos, wwid; msm_window(mw, w, wpos, wwid);
             int d = msm_digit_mem(kw, wpos, wwid);
             u32 ad = (u32)(d < 0 ? -d : d);
@@ -1044,7 +1046,8 @@ __global__ void __launch_bounds__(1024) k_msm_scatter_lds(u32 n_side, u32 tile_p
     for (u32 k = k0 + threadIdx.x; k < k1; k += 1024) {
         u32 i = mm.lr_nh ? msm_side_term(mm, side, k) : k;
         const u32 *kw = reinterpret_cast<const u32 *>(&scal[i]);
-        for (u32 w = w0; w < w1; w++) {
+        for (u32 wk = 0; wk < wn; wk++) {
+            u32 w = a + wk * wstep;
             u32 wpos, wwid; msm_window(mw, w, wpos, wwid);
             int d = msm_digit_mem(kw, wpos, wwid);
             u32 ad = (u32)(d < 0 ? -d : d);
@@ -1088,7 +1091,9 @@ __global__ void __launch_bounds__(1024) k_msm_bin_l1(u32 n_side, u32 tile_pts, u
     u32 y = blockIdx.y, a = y % per_q, side = (y / per_q) % nside, q = y / (per_q * nside);
     u32 p = mm.lr_nh ? 2 * q + side : q;
     u32 pw = p * per_q + a;
-    u32 w0 = a * mm.fb_wps, w1 = w0 + mm.fb_wps;
+    // set a takes the windows a, a + sets, a + 2 sets, ...: the three 15-bit windows of the c = 16 layout (12, 13, 14: their digits fill only the
+    // lower half of the buckets, at twice the load) land in three different sets instead of all in the last one, whose lower buckets would
+    // carry 112 entries against 16 in the upper half (S launch: 1.92 ms against 1.70 for the others)
     u32 k0 = blockIdx.x * tile_pts, k1 = k0 + tile_pts < n_side ? k0 + tile_pts : n_side;
     const sc *scal = probs[p].scal;
     u32 *cur = bin_cursor + (size_t)pw * L.nbins * 2;              // [bin][0] = entries in the bin's main region, [bin][1] = in its tail
@@ -1103,7 +1108,8 @@ __global__ void __launch_bounds__(1024) k_msm_bin_l1(u32 n_side, u32 tile_pts, u
         for (u32 k = base + threadIdx.x; k < kend; k += blockDim.x) {
             u32 i = mm.lr_nh ? msm_side_term(mm, side, k) : k;
             const u32 *kw = reinterpret_cast<const u32 *>(&scal[i]);
-            for (u32 w = w0; w < w1; w++) {
+            for (u32 wk = 0; wk < mm.fb_wps; wk++) {
+                u32 w = a + wk * mm.fb_sets;
                 u32 wpos, wwid; msm_window(mw, w, wpos, wwid);
                 int d = msm_digit_mem(kw, wpos, wwid);
                 u32 ad = (u32)(d < 0 ? -d : d);

@@ -1480,16 +1480,17 @@ __device__ __forceinline__ void msm_reduce_binary_body(u32 E, const ge *si_g, ge
 // ranked into per-bucket lists in LDS (SMALL_CAP entries each), thread b sums bucket b's points in a uniform loop, the buckets
 // go to HBM and the same block runs the bucket reduction of k_msm_reduce_fused over them.  A list overflow (scalars built
 // to collide) raises *overflow and the host repeats the MSM through the general pipeline.
-#define MSM_SMALL_CAP 64      /* mean load <= 16 (n_side <= 8 B, narrow windows fill half of the buckets): P(overflow) ~ 1e-18 per bucket */
+#define MSM_SMALL_CAP 64      /* list entries per bucket at a mean load <= 16 (n_side <= 8 B, narrow windows fill half of the buckets): P(overflow) ~ 1e-18 per bucket */
+#define MSM_SMALL_CAP_MAX 80  /* upper bound of the run-time `cap` (72 at n_side <= 16 B: mean load <= 32, P(overflow) ~ 1e-12) */
 #if ROFL_KG(1)
 __global__ void __launch_bounds__(512) k_msm_small(u32 n_side, MsmWin mw, MsmMap mm, const MsmProb *probs, ge *buckets, ge *S_fin, ge *C_fin,
-                                                   u32 nb_final, u32 *overflow) {
+                                                   u32 nb_final, u32 *overflow, u32 cap) {
     extern __shared__ __align__(16) unsigned char smem[];
     const u32 B = 1u << (mw.c - 1);
     u32 pw = blockIdx.x, p = pw / mw.W, w = pw % mw.W;
     u32 side = mm.lr_nh ? (p & 1u) : 0u;
     u32 *lcnt = reinterpret_cast<u32 *>(smem);                       // [B]
-    u32 *lst = lcnt + B;                                             // [B][MSM_SMALL_CAP]: term index | sign
+    u32 *lst = lcnt + B;                                             // [B][cap]: term index | sign
     for (u32 b = threadIdx.x; b < B; b += blockDim.x) lcnt[b] = 0;
     __syncthreads();
     u32 wpos, wwid; msm_window(mw, w, wpos, wwid);
@@ -1502,7 +1503,7 @@ __global__ void __launch_bounds__(512) k_msm_small(u32 n_side, MsmWin mw, MsmMap
             u32 a1 = rep == 0 ? (ad > B ? B : 0u) : (ad > B ? ad - B : ad);
             if (!a1) continue;
             u32 pos = atomicAdd(&lcnt[a1 - 1], 1u);
-            if (pos < MSM_SMALL_CAP) lst[(a1 - 1) * MSM_SMALL_CAP + pos] = entry;
+            if (pos < cap) lst[(a1 - 1) * cap + pos] = entry;
             else *(volatile u32 *)overflow = 1u;          // mapped host memory: a plain store (idempotent)
         }
     }
@@ -1513,14 +1514,14 @@ __global__ void __launch_bounds__(512) k_msm_small(u32 n_side, MsmWin mw, MsmMap
     // heaviest group of 64 and its SIMD partner w + 4 the (7 - w)-th: every SIMD sees ~11 additions' worth of issue instead of ~20.
     u32 my_b = threadIdx.x;
     if (blockDim.x == 512 && B == 512) {
-        __shared__ u32 chist[MSM_SMALL_CAP + 2], cbase[MSM_SMALL_CAP + 2];
+        __shared__ u32 chist[MSM_SMALL_CAP_MAX + 2], cbase[MSM_SMALL_CAP_MAX + 2];
         __shared__ unsigned short order[512];
-        if (threadIdx.x < MSM_SMALL_CAP + 2) chist[threadIdx.x] = 0;
+        if (threadIdx.x < MSM_SMALL_CAP_MAX + 2) chist[threadIdx.x] = 0;
         __syncthreads();
-        u32 mycnt = lcnt[threadIdx.x]; if (mycnt > MSM_SMALL_CAP) mycnt = MSM_SMALL_CAP;
+        u32 mycnt = lcnt[threadIdx.x]; if (mycnt > cap) mycnt = cap;
         u32 rank_in = atomicAdd(&chist[mycnt], 1u);
         __syncthreads();
-        if (threadIdx.x == 0) { u32 run = 0; for (int cval = MSM_SMALL_CAP; cval >= 0; cval--) { cbase[cval] = run; run += chist[cval]; } }      // descending load
+        if (threadIdx.x == 0) { u32 run = 0; for (int cval = (int)cap; cval >= 0; cval--) { cbase[cval] = run; run += chist[cval]; } }      // descending load
         __syncthreads();
         order[cbase[mycnt] + rank_in] = (unsigned short)threadIdx.x;
         __syncthreads();
@@ -1529,15 +1530,15 @@ __global__ void __launch_bounds__(512) k_msm_small(u32 n_side, MsmWin mw, MsmMap
         my_b = order[grp * 64 + ln];
     }
     for (u32 b = my_b; b < B; b += blockDim.x) {
-        u32 num = lcnt[b]; if (num > MSM_SMALL_CAP) num = MSM_SMALL_CAP;
+        u32 num = lcnt[b]; if (num > cap) num = cap;
         gd acc = gd_identity();
         // the next point is in flight while the current one is added (the block runs at 2 waves/SIMD: registers are not the limit here,
         // the gather latency in front of every addition was)
-        u32 v = num ? lst[b * MSM_SMALL_CAP] : 0u;
+        u32 v = num ? lst[b * cap] : 0u;
         nd nxt = gload_nd(&pts[v & 0x7fffffffu]);
         for (u32 e = 0; e < num; e++) {
             nd q = nxt; bool ng = (v >> 31) != 0;
-            if (e + 1 < num) { v = lst[b * MSM_SMALL_CAP + e + 1]; nxt = gload_nd(&pts[v & 0x7fffffffu]); }
+            if (e + 1 < num) { v = lst[b * cap + e + 1]; nxt = gload_nd(&pts[v & 0x7fffffffu]); }
             acc = gd_madd(acc, q, ng);
         }
         store_gd(&buckets[(size_t)pw * B + b], acc);

@@ -275,7 +275,7 @@ struct Ctx {
     std::map<size_t, Bsgs> bsgs;                          // table_size -> baby-step table
     std::unique_ptr<HostPool> pool;
     size_t fold_min = 1024;
-    size_t msm_small_max = 4096;      // ROFL_MSM_SMALL_MAX: generic MSMs with at most this many terms per problem side run as one fused launch (0 = off)
+    size_t msm_small_max = 8192;      // ROFL_MSM_SMALL_MAX: generic MSMs with at most this many terms per problem side run as one fused launch (0 = off)
     size_t msm_dev_horner_min = 32;   // ROFL_MSM_DEV_HORNER_MIN: launches with at least this many problems finish their Horner chains on the device
     bool msm_slots = true;
     int fold_t = 2, fold_t1 = 3, fold_k = 0, fold_tab = 1, fold_unit = 1; long fold_threads = 131072;
@@ -558,6 +558,8 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
             for (size_t i = 0; i < np; i++) h_probs[i] = MsmProb{opt.fb_wtab, probs[i].scal};
         } else {
             P = msm_plan(n);
+            // up to msm_small_max terms per side the fused small-MSM launch takes the problem: that wants 10-bit windows (512 buckets = one block)
+            if (C.msm_small_max && allow_small && slots_mode && (lr ? n / 2 : n) <= C.msm_small_max && P.c > 10 && np * 26 <= 512) P = msm_plan_c(10);
             PW = np * P.W; Wgrid = P.W;
             cap = 16; while (cap < 256 && (size_t)cap * P.B < 4 * n) cap *= 2;
             for (size_t i = 0; i < np; i++) h_probs[i] = probs[i];
@@ -582,19 +584,20 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
         u32 nside_small = (u32)(lr ? n / 2 : n);
         // (its blocks hold up to 130 KB of LDS, one per CU: with thousands of bucket arrays -- n_partition = 64 -- the general pipeline is faster)
         // ... unless the blocks are small: at c <= 7 a block needs < 24 KB, eight of them share a CU and thousands of arrays go through in a few batches
-        size_t small_lds = std::max((size_t)P.B * 4 * (1 + MSM_SMALL_CAP), std::max(((size_t)(P.B / 8) * 4 + (size_t)(P.B / 16) * 5 + 1) * sizeof(ge), ((size_t)P.B + (size_t)P.B * 3 / 4 + 1) * sizeof(ge)));
-        bool small = !fb && slots_mode && allow_small && C.msm_small_max && nside_small <= C.msm_small_max && P.c <= 10 && nside_small <= 8 * P.B && (PW <= 512 || small_lds <= 24 * 1024);
+        const u32 small_cap = nside_small <= 8 * P.B ? (u32)MSM_SMALL_CAP : 72u;      // list entries per bucket: mean load <= 16 / <= 32
+        size_t small_lds = std::max((size_t)P.B * 4 * (1 + small_cap), std::max(((size_t)(P.B / 8) * 4 + (size_t)(P.B / 16) * 5 + 1) * sizeof(ge), ((size_t)P.B + (size_t)P.B * 3 / 4 + 1) * sizeof(ge)));
+        bool small = !fb && slots_mode && allow_small && C.msm_small_max && nside_small <= C.msm_small_max && P.c <= 10 && nside_small <= 16 * P.B && (PW <= 512 || small_lds <= 24 * 1024);
         if (small) {
             *h_flag = 0;                                                  // list-overflow flag, in mapped host memory (plain stores from the kernel)
             ge *S_fin_s = dev_horner ? C.msm_S[0].as<ge>(PW) : hres_dev;
             ge *C_fin_s = dev_horner ? C.msm_C[0].as<ge>(PW * (size_t)(P.c - 1)) : hres_dev + PW;
-            size_t lds_lists = (size_t)P.B * 4 * (1 + MSM_SMALL_CAP);
+            size_t lds_lists = (size_t)P.B * 4 * (1 + small_cap);
             size_t lds_red = std::max(((size_t)(P.B / 8) * 4 + (size_t)(P.B / 16) * 5 + 1) * sizeof(ge), ((size_t)P.B + (size_t)P.B * 3 / 4 + 1) * sizeof(ge));      // fused / binary reduction trees
             {
                 uint64_t items = (uint64_t)np * nside_small * P.W;
                 KSpan ks(C.tm, C.stream, ROFL_TK_MSM_SMALL, items * 7 + (uint64_t)PW * P.B * 10, (uint64_t)np * nside_small * (32 + 96));
                 hipLaunchKernelGGL(k_msm_small, dim3((unsigned)PW), dim3(P.B < 64 ? 64 : P.B), std::max(lds_lists, lds_red), C.stream, nside_small, mw, mm, d_probs, buckets,
-                                   S_fin_s, C_fin_s, P.c - 1, d_flag);
+                                   S_fin_s, C_fin_s, P.c - 1, d_flag, small_cap);
             }
         } else {
         // fixed-base launches: two-level bucket sort (coarse bins through HBM in full lines, then per-bin ranking in LDS)

@@ -334,7 +334,7 @@ def _gpu_msm(R, k, p):
     return out
 
 
-@pytest.mark.parametrize("n", [1, 5, 63, 64, 300, 513, 2000, 9000])
+@pytest.mark.parametrize("n", [1, 5, 63, 64, 300, 513, 2000, 6000, 8192, 9000])
 def test_msm_extreme_scalars(R, n):
     """The Pippenger pipeline on inputs the proof path never produces: heavy bucket skew (slot overflow list /
     two-pass fallback), scalars in [2^252, l) (split top-window digit), zeros, small and all-ones scalars."""

@@ -214,30 +214,22 @@ enum { ROFL_TK_MSM_ACCUMULATE_FB = 0, ROFL_TK_MSM_ACCUMULATE_GEN = 1, ROFL_TK_MS
 typedef struct { double ms; uint64_t launches, fe_muls, bytes; } rofl_kernel_time_t;
 int rofl_last_kernel_times(rofl_kernel_time_t out[ROFL_TK_COUNT]);
 int rofl_set_timing(int enabled);
-/* GPU multi-scalar multiplication sum_i k_i * P_i through the production Pippenger pipeline (dalek
- * vartime_multiscalar_mul as used by upstream verify_multiple); test hook for skewed / extreme scalars. */
-int rofl_dbg_msm(const uint8_t *scalars32, const uint8_t *points32, size_t n, uint8_t out32[32]);
-/* field-multiply micro-benchmark: returns GF(2^255-19) multiplications per second on the device */
-int rofl_bench_femul(unsigned iters, double *fe_mul_per_sec_out);
-/* self-test of the quad-parallel point arithmetic (csrc/quad26.hpp): pair i = (P, Q) -> 2^doublings P + Q, one thread per pair and one quad of lanes per pair */
-int rofl_dbg_quad_ops(const uint8_t *pairs64, size_t pairs, unsigned doublings, uint8_t *out_serial32, uint8_t *out_quad32);
-
-/* ---- host-side self-test hooks (same source as the device math, compiled for the CPU) ---- */
-int rofl_dbg_host_pool_stress(unsigned threads, unsigned jobs);   /* host thread pool: every index of every job runs exactly once */
-int rofl_dbg_host_fe_mul(const uint8_t a[32], const uint8_t b[32], uint8_t out[32]);
-int rofl_dbg_host_fe_ops(const uint8_t a[32], const uint8_t b[32], uint8_t out_add[32], uint8_t out_sub[32], uint8_t out_sq[32], uint8_t out_inv[32]);
-int rofl_dbg_host_sc_invert(const uint8_t a[32], uint8_t out_ref[32], uint8_t out_fast[32], double *ns_ref, double *ns_fast);
-int rofl_dbg_host_sc_mul(const uint8_t a[32], const uint8_t b[32], uint8_t out[32]);
-int rofl_dbg_host_sc_wide(const uint8_t in[64], uint8_t out[32]);
-int rofl_dbg_host_from_uniform(const uint8_t in[64], uint8_t out[32]);
-int rofl_dbg_host_scalarmult_base(const uint8_t k[32], int use_blinding_base, uint8_t out[32]);
-int rofl_dbg_host_fd_codec(const uint8_t in[32], uint8_t out[32]);
-int rofl_dbg_host_decode_encode(const uint8_t in[32], uint8_t out[32]);   /* returns 5 if invalid */
-/* radix-2^25.5 kernel arithmetic (fe26.hpp) compiled for the host with bound assertions enabled */
-int rofl_dbg_host_fd_ops(const uint8_t a[32], const uint8_t b[32], uint8_t out_mul[32], uint8_t out_sq[32], uint8_t out_add[32], uint8_t out_sub[32], uint8_t out_inv[32]);
-int rofl_dbg_host_fd_scalarmult(const uint8_t k[32], const uint8_t p[32], uint8_t out[32]);
-int rofl_dbg_host_merlin(const uint8_t *label, size_t label_len, const uint8_t *msg, size_t msg_len, uint8_t out[64]);
-int rofl_dbg_host_nonce(const uint8_t seed[32], uint64_t idx, uint8_t out[32]);
+/* ---- behaviour options ----
+ * Switches that change WHAT a call returns or how it waits are part of the ABI, not of the process environment.  `key` is one of the
+ * names below; the environment variable of the same name in upper case with the ROFL_ prefix (ROFL_VERIFY_ZIP_TRUNCATE, ...) only
+ * provides the default that is read once, when the device context is created.  Options are per device context and may be changed
+ * between calls (not while calls are in flight).  Returns 11 (bad parameter) for an unknown key or an out-of-range value.
+ *   "verify_zip_truncate"  0 (default): a proof set that does not cover every chunk of the padded commitment vector does not verify
+ *                          (ok = 0); 1: the reference's behaviour, zip-truncation (range_proof_vec/mod.rs:169-176), bit for bit
+ *   "verify_batch"         1 (default): one random-weighted check per client (a client's chunks share one MSM); 0: one check per proof,
+ *                          as upstream verify_multiple does
+ *   "sigma_batch"          1 (default): the per-element Sigma-proofs of a vector are verified as one random linear combination; 0: one
+ *                          check per element (rand_proof_vec/mod.rs:93-118)
+ *   "blocking_sync"        -1 (default): spin while at most three calls are in flight, sleep between polls beyond that; 0: always spin;
+ *                          1: always sleep (one host core per waiting call is not burned; ~50 us more latency per wait)
+ * The remaining ROFL_* environment variables are tuning knobs that never change results ("Tuning knobs"). */
+int rofl_set_option(const char *key, long value);
+int rofl_get_option(const char *key, long *value_out);
 
 #ifdef __cplusplus
 }

@@ -239,6 +239,8 @@ class range_proof_vec:
         nc = len(values_list)
         if nc == 0:
             return []
+        if len(blindings_list) != nc or (nonces is not None and len(nonces) != nc):
+            raise ValueError("values_list, blindings_list and nonces must have one entry per client")
         keep, vptrs, bptrs = [], [], []
         d = None
         for v, b in zip(values_list, blindings_list):

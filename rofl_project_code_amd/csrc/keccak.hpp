@@ -81,12 +81,49 @@ HD void shake256_seeded_block(u64 st[25], const u64 dom[2], const u64 seed[4], u
 }
 
 // ---------------------------------------------------------------- host-only sponge helpers
+// Host-only Keccak-f[1600] for the transcripts: two rounds per iteration with the state in locals (clang keeps the in-place form above,
+// which the kernels use, ~25 % slower on x86-64 -- and the verifier hashes 8 192 commitments per chunk with the GPU waiting).
+inline u64 rol(u64 x, int n) { return (x << n) | (x >> (64 - n)); }
+#define ROUND(A, E, rc) \
+    { u64 Ca = A##ba ^ A##ga ^ A##ka ^ A##ma ^ A##sa, Ce = A##be ^ A##ge ^ A##ke ^ A##me ^ A##se, Ci = A##bi ^ A##gi ^ A##ki ^ A##mi ^ A##si, \
+          Co = A##bo ^ A##go ^ A##ko ^ A##mo ^ A##so, Cu = A##bu ^ A##gu ^ A##ku ^ A##mu ^ A##su; \
+      u64 Da = Cu ^ rol(Ce, 1), De = Ca ^ rol(Ci, 1), Di = Ce ^ rol(Co, 1), Do = Ci ^ rol(Cu, 1), Du = Co ^ rol(Ca, 1); \
+      u64 B0, B1, B2, B3, B4; \
+      B0 = A##ba ^ Da; B1 = rol(A##ge ^ De, 44); B2 = rol(A##ki ^ Di, 43); B3 = rol(A##mo ^ Do, 21); B4 = rol(A##su ^ Du, 14); \
+      E##ba = B0 ^ (~B1 & B2) ^ rc; E##be = B1 ^ (~B2 & B3); E##bi = B2 ^ (~B3 & B4); E##bo = B3 ^ (~B4 & B0); E##bu = B4 ^ (~B0 & B1); \
+      B0 = rol(A##bo ^ Do, 28); B1 = rol(A##gu ^ Du, 20); B2 = rol(A##ka ^ Da, 3); B3 = rol(A##me ^ De, 45); B4 = rol(A##si ^ Di, 61); \
+      E##ga = B0 ^ (~B1 & B2); E##ge = B1 ^ (~B2 & B3); E##gi = B2 ^ (~B3 & B4); E##go = B3 ^ (~B4 & B0); E##gu = B4 ^ (~B0 & B1); \
+      B0 = rol(A##be ^ De, 1); B1 = rol(A##gi ^ Di, 6); B2 = rol(A##ko ^ Do, 25); B3 = rol(A##mu ^ Du, 8); B4 = rol(A##sa ^ Da, 18); \
+      E##ka = B0 ^ (~B1 & B2); E##ke = B1 ^ (~B2 & B3); E##ki = B2 ^ (~B3 & B4); E##ko = B3 ^ (~B4 & B0); E##ku = B4 ^ (~B0 & B1); \
+      B0 = rol(A##bu ^ Du, 27); B1 = rol(A##ga ^ Da, 36); B2 = rol(A##ke ^ De, 10); B3 = rol(A##mi ^ Di, 15); B4 = rol(A##so ^ Do, 56); \
+      E##ma = B0 ^ (~B1 & B2); E##me = B1 ^ (~B2 & B3); E##mi = B2 ^ (~B3 & B4); E##mo = B3 ^ (~B4 & B0); E##mu = B4 ^ (~B0 & B1); \
+      B0 = rol(A##bi ^ Di, 62); B1 = rol(A##go ^ Do, 55); B2 = rol(A##ku ^ Du, 39); B3 = rol(A##ma ^ Da, 41); B4 = rol(A##se ^ De, 2); \
+      E##sa = B0 ^ (~B1 & B2); E##se = B1 ^ (~B2 & B3); E##si = B2 ^ (~B3 & B4); E##so = B3 ^ (~B4 & B0); E##su = B4 ^ (~B0 & B1); }
+inline void keccak_f1600_host(u64 s[25]) {
+    static const u64 RC[24] = {
+        0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808AULL, 0x8000000080008000ULL,
+        0x000000000000808BULL, 0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL,
+        0x000000000000008AULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000AULL,
+        0x000000008000808BULL, 0x800000000000008BULL, 0x8000000000008089ULL, 0x8000000000008003ULL,
+        0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800AULL, 0x800000008000000AULL,
+        0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+    u64 Aba = s[0], Abe = s[1], Abi = s[2], Abo = s[3], Abu = s[4], Aga = s[5], Age = s[6], Agi = s[7], Ago = s[8], Agu = s[9];
+    u64 Aka = s[10], Ake = s[11], Aki = s[12], Ako = s[13], Aku = s[14], Ama = s[15], Ame = s[16], Ami = s[17], Amo = s[18], Amu = s[19];
+    u64 Asa = s[20], Ase = s[21], Asi = s[22], Aso = s[23], Asu = s[24];
+    u64 Eba, Ebe, Ebi, Ebo, Ebu, Ega, Ege, Egi, Ego, Egu, Eka, Eke, Eki, Eko, Eku, Ema, Eme, Emi, Emo, Emu, Esa, Ese, Esi, Eso, Esu;
+    for (int r = 0; r < 24; r += 2) { ROUND(A, E, RC[r]) ROUND(E, A, RC[r + 1]) }
+    s[0] = Aba; s[1] = Abe; s[2] = Abi; s[3] = Abo; s[4] = Abu; s[5] = Aga; s[6] = Age; s[7] = Agi; s[8] = Ago; s[9] = Agu;
+    s[10] = Aka; s[11] = Ake; s[12] = Aki; s[13] = Ako; s[14] = Aku; s[15] = Ama; s[16] = Ame; s[17] = Ami; s[18] = Amo; s[19] = Amu;
+    s[20] = Asa; s[21] = Ase; s[22] = Asi; s[23] = Aso; s[24] = Asu;
+}
+#undef ROUND
+
 struct Sponge {
     u64 st[25]; size_t pos, rate; bool squeezing; uint8_t suffix;
     Sponge(size_t rate_, uint8_t suffix_) : pos(0), rate(rate_), squeezing(false), suffix(suffix_) { memset(st, 0, sizeof st); }
     void xor_byte(size_t p, uint8_t b) { st[p >> 3] ^= (u64)b << (8 * (p & 7)); }
     void absorb(const uint8_t *d, size_t n) {
-        for (size_t i = 0; i < n; i++) { xor_byte(pos++, d[i]); if (pos == rate) { keccak_f1600(st); pos = 0; } }
+        for (size_t i = 0; i < n; i++) { xor_byte(pos++, d[i]); if (pos == rate) { keccak_f1600_host(st); pos = 0; } }
     }
     void squeeze(uint8_t *o, size_t n) {
         if (!squeezing) { xor_byte(pos, suffix); xor_byte(rate - 1, 0x80); keccak_f1600(st); pos = 0; squeezing = true; }
@@ -102,7 +139,7 @@ struct Merlin {
     static const int R = 166;
     uint8_t *b() { return reinterpret_cast<uint8_t *>(stw); }
     const uint8_t *b() const { return reinterpret_cast<const uint8_t *>(stw); }
-    void perm() { keccak_f1600(stw); }
+    void perm() { keccak_f1600_host(stw); }
     void run_f() { uint8_t *st = b(); st[pos] ^= pos_begin; st[pos + 1] ^= 0x04; st[R + 1] ^= 0x80; perm(); pos = 0; pos_begin = 0; }
     // runs of bytes up to the end of the rate block, eight at a time (the verifier appends 8 192 commitments per chunk: 41 bytes each)
     void absorb(const uint8_t *d, size_t n) {
@@ -145,6 +182,24 @@ struct Merlin {
     void append_lbl(const uint8_t *label, size_t ll, const uint8_t *msg, size_t len) {     // labels that may contain NUL bytes
         uint8_t le[4] = {(uint8_t)len, (uint8_t)(len >> 8), (uint8_t)(len >> 16), (uint8_t)(len >> 24)};
         meta_ad(label, ll, false); meta_ad(le, 4, true); ad(msg, len, false);
+    }
+    // == count x append("<label>", msg + 32 j, 32) for a one-character label (the m commitments V_j of a chunk: 8 192 appends of 41
+    // transcript bytes each).  While the 2 + 1 + 4 + 2 + 32 bytes of an operation stay inside the rate block they are XORed in as one
+    // record with the two STROBE headers computed directly; an operation that reaches the end of the block takes the general path.
+    void append32_run(char label, const uint8_t *msg, size_t count) {
+        for (size_t j = 0; j < count; j++, msg += 32) {
+            if ((unsigned)pos + 41 < (unsigned)R) {
+                uint8_t rec[48] = {pos_begin, 16 | 2, (uint8_t)label, 32, 0, 0, 0, (uint8_t)(pos + 1), 2};
+                memcpy(rec + 9, msg, 32);
+                uint8_t *st = b() + pos;
+                for (int i = 0; i < 40; i += 8) { u64 x, y; memcpy(&x, st + i, 8); memcpy(&y, rec + i, 8); x ^= y; memcpy(st + i, &x, 8); }
+                st[40] ^= rec[40];
+                pos_begin = (uint8_t)(pos + 8); cur_flags = 2; pos = (uint8_t)(pos + 41);
+            } else {
+                const char lb[2] = {label, 0};
+                append(lb, msg, 32);
+            }
+        }
     }
     void append_u64(const char *label, u64 x) { uint8_t b[8]; memcpy(b, &x, 8); append(label, b, 8); }
     void append_scalar(const char *label, const sc &s) { uint8_t b[32]; sc_tobytes(b, s); append(label, b, 32); }

@@ -1173,10 +1173,20 @@ __global__ void __launch_bounds__(512) k_msm_bin_l2(Msm2L L, u32 B, const u32 *b
     u32 *hist = sm2, *ofs = sm2 + FB, *out = sm2 + 2 * FB;          // [FB], [FB], [cap_bin]
     u32 bin = blockIdx.x, pw = blockIdx.y;
     u32 n = bin_cursor[((size_t)pw * L.nbins + bin) * 2], n2 = bin_cursor[((size_t)pw * L.nbins + bin) * 2 + 1];
-    if (n > L.cap_bin) n = L.cap_bin;
-    if (n2 > MSM_BIN_TAIL) n2 = MSM_BIN_TAIL;
-    if (n + n2 > L.cap_bin) { if (threadIdx.x == 0) *(volatile u32 *)overflow = 1u; n2 = L.cap_bin - n; }
     size_t rbase = ((size_t)pw * L.nbins + bin) * L.cap_bin;
+    // A bin that outgrew its region (scalars built to collide: a proof with a = 0 gives every G term the same scalar) has HOLES: level 1
+    // skips a reservation that straddles cap_bin and a tail flush beyond MSM_BIN_TAIL, so parts of [0, n) were never written and hold
+    // stale words of an earlier launch (or of a fresh allocation).  Such a bin must not reach the accumulation, which gathers
+    // window-table entries by these words before the host has seen the flag: its buckets are reported empty and the MSM is repeated
+    // on the slot path anyway.
+    if (n > L.cap_bin || n2 > MSM_BIN_TAIL || n + n2 > L.cap_bin) {
+        if (threadIdx.x == 0) *(volatile u32 *)overflow = 1u;
+        for (u32 f = threadIdx.x; f < (1u << L.fbits); f += blockDim.x) {
+            size_t bi = (size_t)pw * B + (size_t)bin * (1u << L.fbits) + f;
+            cnt[bi] = 0; off[bi] = (u32)rbase;
+        }
+        return;
+    }
     u32 *reg = bins + rbase;
     const u32 *tl = tails + ((size_t)pw * L.nbins + bin) * MSM_BIN_TAIL;
     const u32 fmask = FB - 1, keep = ~(fmask << L.ebits);

@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "../../include/rofl_zk.h"
+#include "../../include/rofl_zk_debug.h"
 #include "kernels.hpp"
 #if ROFL_KGROUP != 0
 #include "kernel_protos.hpp"      // kernels live in their own translation units (build.py)
@@ -221,8 +222,15 @@ struct KSpan {
     KSpan(const KSpan &) = delete; KSpan &operator=(const KSpan &) = delete;
 };
 
+// Workspace of one MSM in flight on a lane (a lane holds two: the verifier queues its two MSMs behind one synchronisation)
+struct MsmWs {
+    DevBuf cnt, off, cur, tail, perm, sorted, ovf, buckets, S[2], Cacc[2], probs;
+    PinBuf h_res, h_ovf, h_probs;
+    std::vector<MsmProb> probs_on_dev;      // what `probs` holds on the device: an unchanged problem list is not uploaded again
+};
+
 // One cached BulletproofGens::new(n, m): [G(N) | H(N)] + fold slices (tbl), the 16 window slices of the fixed-base MSM (wtab)
-struct GensEntry { niels *tbl = nullptr; ndm *wtab = nullptr; FoldTabCfg fc{}; size_t bytes = 0, n = 0, m = 0; u64 tick = 0; int users = 0; };
+struct GensEntry { niels *tbl = nullptr; ndm *wtab = nullptr; u32 wc = 16; FoldTabCfg fc{}; size_t bytes = 0, n = 0, m = 0; u64 tick = 0; int users = 0; };
 
 // One Ctx = one "lane": a HIP stream with its own workspace, staging buffers, timing and host pool.  The primary
 // lane of a device owns the shared read-only state (fixed-base tables, generator cache).  An API call runs on one
@@ -253,6 +261,8 @@ struct Ctx {
     // Waiting for the lane's stream.  hipStreamSynchronize spins (lowest latency: right for a call that is alone on the device); with
     // more than three calls in flight -- or when the host asked for it (ROFL_BLOCKING_SYNC=1) -- the thread sleeps between queries instead, so
     // a server that keeps several clients in flight does not burn one host core per client on busy-waiting (ROFL_BLOCKING_SYNC=0: always spin).
+    // behaviour options (rofl_set_option; primary lane only -- the lanes read their parent's): the environment only provides defaults
+    int opt_zip_truncate = 0, opt_verify_batch = 1, opt_sigma_batch = 1;
     int blocking_sync = -1; hipEvent_t ev_block = nullptr, ev_v = nullptr, ev_fork = nullptr, ev_a = nullptr, ev_a0 = nullptr; bool batch_mode = false;
     void sync() {
         const Ctx *P = parent ? parent : this;
@@ -283,10 +293,10 @@ struct Ctx {
     struct HopStats { double enqueue = 0, sync = 0, horner_wall = 0, horner_cpu = 0, host_wall = 0, host_cpu = 0; int n = 0; } hs;      // ROFL_TRACE: where the host hops go
     // workspace
     DevBuf cp, sL, sR, party, Scanon, vshift, blind, Vbytes, Cbytes, status, partial, partial2, scpart, a, b, a2, b2, ptab[2], yinv,
-        SL, SR, msm_cnt, msm_off, msm_cur, msm_tail, msm_perm, msm_sorted, msm_ovf, msm_buckets, msm_S[2], msm_C[2], msm_fin, msm_probs, powtabs, foldprobs, naf,
+        SL, SR, powtabs, foldprobs, naf,
         gbuf[2], aux_pts, aux_scal, vscal, tmp_in, tmp_in2, tmp_out, vals, uni, stream_buf;
-    PinBuf h_cp, h_res, h_part, h_misc, h_misc2, h_probs, h_auxc, h_auxs, h_ovf, h_V, h_ip, h_round, h_fdig, h_fprob;
-    std::vector<MsmProb> probs_on_dev;      // what d_probs holds: an unchanged problem list is not uploaded again
+    PinBuf h_cp, h_part, h_misc, h_misc2, h_auxc, h_auxs, h_V, h_ip, h_round, h_fdig, h_fprob;
+    MsmWs mws[2];
 
     void init() {
         if (inited) return;
@@ -342,6 +352,9 @@ struct Ctx {
         if (const char *e = getenv("ROFL_FOLD_THREADS")) { long v = atol(e); if (v > 0) fold_threads = v; }
         if (const char *e = getenv("ROFL_LANES")) { int v = atoi(e); if (v >= 1 && v <= 8) nlanes = v; }
         if (const char *e = getenv("ROFL_BLOCKING_SYNC")) blocking_sync = atoi(e) != 0;
+        if (const char *e = getenv("ROFL_VERIFY_ZIP_TRUNCATE")) opt_zip_truncate = atoi(e) != 0;
+        if (const char *e = getenv("ROFL_VERIFY_BATCH")) opt_verify_batch = atoi(e) != 0;
+        if (const char *e = getenv("ROFL_SIGMA_BATCH")) opt_sigma_batch = atoi(e) != 0;
         inited = true;
         for (int i = 1; i < nlanes; i++) { Ctx *s = new Ctx(); s->init_lane(*this); sibs.push_back(s); }
     }
@@ -412,6 +425,11 @@ MsmPlan msm_plan_c(u32 c) {
     p.levels = (p.c - 1) / 3;
     return p;
 }
+u32 fb_window_c(size_t gens) {
+    static const int force = getenv("ROFL_MSM_FB_C") ? atoi(getenv("ROFL_MSM_FB_C")) : 0;      // tuning: 13 or 16 for every table
+    if (force == 13 || force == 16) return (u32)force;
+    return gens >= ((size_t)1 << 17) ? 16u : 13u;
+}
 // Generator-table cache, shared by the lanes of a device.  An entry is pinned (users > 0) for the duration of every call that
 // reads it; eviction (LRU, beyond gens_budget, or to make room after a failed hipMalloc) only ever frees unpinned entries, so it is
 // safe with any number of calls in flight.  (n, m) reach this point from untrusted wire messages: callers validate the proof
@@ -455,6 +473,7 @@ struct GensPin {
     void release() { if (e) { std::lock_guard<std::mutex> lk(P0->gens_mu); e->users--; } e = nullptr; }
     niels *tbl() const { return e->tbl; }
     const niels *wtab() const { return reinterpret_cast<const niels *>(e->wtab); }      // opaque to the host: 128-byte ndm records
+    u32 wc() const { return e->wc; }                                                    // window width of the window table's layout
     const FoldTabCfg &fc() const { return e->fc; }
 };
 GensPin get_gens(Ctx &C, size_t n, size_t m) {
@@ -484,13 +503,17 @@ GensPin get_gens(Ctx &C, size_t n, size_t m) {
         hipLaunchKernelGGL(k_gens_xof, grid1(2 * m), dim3(TPB), 0, C.stream, (u32)n, (u32)m, uni);
         hipLaunchKernelGGL(k_gens_map, grid1(2 * N), dim3(TPB), 0, C.stream, (u32)(2 * N), uni, tbl);
         hipLaunchKernelGGL(k_gens_tables, grid1(2 * N * fc.np), dim3(TPB), 0, C.stream, (u32)(2 * N), fc, tbl, (size_t)(2 * N));
-        if (P0.msm_fb && 2 * N >= P0.msm_fb_min && 2 * N * 16 < ((size_t)1 << 31)) {      // entry index (w * 2N + i) must fit 31 bits
+        // Window table of the fixed-base MSM.  Its window width follows the size of the generator set: 16-bit windows (16 slices, 32 768
+        // buckets per set) from 2^17 generators on; 13-bit windows (20 slices, 4 096 buckets) below -- many small chunks (n_partition = 64:
+        // 128 L / R problems of 16 384 terms per round) would otherwise spread 8 entries per bucket over 4 M buckets, and the bucket
+        // reduction, not the accumulation, was the cost of such a launch.
+        MsmPlan fp = msm_plan_c(fb_window_c(2 * N));
+        if (P0.msm_fb && 2 * N >= P0.msm_fb_min && 2 * N * fp.W < ((size_t)1 << 31)) {      // entry index (w * 2N + i) must fit 31 bits
             void *wtv = nullptr;
-            if (gens_malloc(P0, &wtv, sizeof(ndm) * 2 * N * 16, ent.get()) == hipSuccess) {      // without it the MSMs over these generators run in generic mode
+            if (gens_malloc(P0, &wtv, sizeof(ndm) * 2 * N * fp.W, ent.get()) == hipSuccess) {      // without it the MSMs over these generators run in generic mode
                 ndm *wt = reinterpret_cast<ndm *>(wtv);
-                MsmPlan fp = msm_plan_c(16);
                 hipLaunchKernelGGL(k_gens_wtab, grid1(2 * N), dim3(TPB), 0, C.stream, (u32)(2 * N), MsmWin{fp.c, fp.W, fp.wide}, tbl, wt, (size_t)(2 * N));
-                ent->wtab = wt; ent->bytes += sizeof(ndm) * 2 * N * 16;
+                ent->wtab = wt; ent->wc = fp.c; ent->bytes += sizeof(ndm) * 2 * N * fp.W;
             }
         }
         C.sync();
@@ -516,254 +539,283 @@ MsmPlan msm_plan(size_t n) {
     p.levels = (p.c - 1) / 3;
     return p;
 }
-// results[p] = sum_i scal[p][i] * pts[p][i]   (all problems have n terms).  Synchronises the stream.
+// results[p] = sum_i scal[p][i] * pts[p][i]   (all problems have n terms).
 // opt.lr_nh != 0: `probs` holds (L, R) pairs that share a merged scalar array (see MsmMap); opt.fb: every problem's points
 // are the generator table `opt.fb_gens` (n terms from its start, slice stride opt.fb_stride) for which a window table exists.
-struct MsmOpt { u32 lr_nh = 0, lr_ng = 0; const niels *fb_wtab = nullptr; size_t fb_stride = 0; std::function<void()> overlap; };   // overlap: host work to run while the kernels execute
-void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge5> &results, const MsmOpt &opt = MsmOpt()) {
-    size_t np = probs.size();
-    double t_enter = now_ms();
-    static const u32 acc_balance = getenv("ROFL_ACC_BALANCE") ? (atoi(getenv("ROFL_ACC_BALANCE")) ? 1u : 0u) : 1u;   // equal-work blocks in k_msm_accumulate (0 = plain descending order)
-    static const u32 dbg_mask = getenv("ROFL_DBG_IDX_MASK") ? (u32)strtoul(getenv("ROFL_DBG_IDX_MASK"), nullptr, 0) : 0x7fffffffu;   // timing experiments only (wrong results): gathers confined to a cache-resident prefix
-    static const u32 dbg_scatter = getenv("ROFL_DBG_SCATTER") ? (u32)atoi(getenv("ROFL_DBG_SCATTER")) : 0u;   // timing experiments only: 1 = no range reservation, 2 = no slot stores
-    bool lr = opt.lr_nh != 0;
-    size_t nq = lr ? np / 2 : np;                          // grid problems (chunks in lr mode)
-    MsmProb *d_probs = C.msm_probs.as<MsmProb>(np);
-    MsmProb *h_probs = C.h_probs.as<MsmProb>(np);
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    MsmPlan P{}; size_t PW = 0; bool fb_used = false, overlap_done = false, dev_horner = false, allow_small = true, allow_two = true, two_used = false; u32 sets = 0;
-    for (int attempt = 0; attempt < 3; attempt++) {
-        // attempt 0: fixed-base slots (if available) ; then generic slots ; then the two-pass sort
-        bool fb = attempt == 0 && opt.fb_wtab != nullptr && C.msm_slots;
-        bool slots_mode = attempt <= 1 && C.msm_slots;
-        if (attempt == 0 && !fb) continue;
-        if (attempt == 1 && !slots_mode) continue;
-        MsmMap mm{opt.lr_nh, opt.lr_ng, 0, 0, 0};
-        u32 Wgrid, cap;
-        if (fb) {
-            P = msm_plan_c(16);
-            // Fewer sets = less bucket-reduction work but fewer accumulate threads.  Alone on the device the call wants the
-            // threads (latency); with other calls in flight the GPU is full anyway and the work is what counts.
-            bool crowded = C.crowded();
-            sets = crowded ? std::max<u32>(1, C.msm_fb_sets / 2) : C.msm_fb_sets;
-            size_t want = crowded ? C.msm_fb_threads / 2 : C.msm_fb_threads;
-            while (sets < 16 && (size_t)nq * (lr ? 2 : 1) * sets * P.B < want) sets *= 2;
-            while (sets > 1 && (size_t)nq * (lr ? 2 : 1) * (sets / 2) * P.B >= want) sets /= 2;      // many problems (n_partition = 64): one set each is plenty
-            mm.fb_sets = sets; mm.fb_wps = 16 / sets; mm.fb_stride = (u32)opt.fb_stride;
-            PW = nq * (lr ? 2 : 1) * sets; Wgrid = P.W;
-            size_t per_side = lr ? n / 2 : n;
-            // the three (c-1)-bit windows of the layout fill only half of the buckets: twice the mean load there
-            cap = 16; while (cap < 2048 && (size_t)cap * P.B < 3 * per_side * (mm.fb_wps + 1)) cap *= 2;
-            if (mm.fb_wps == 1) cap *= 2;
-            for (size_t i = 0; i < np; i++) h_probs[i] = MsmProb{opt.fb_wtab, probs[i].scal};
-        } else {
-            P = msm_plan(n);
-            // up to msm_small_max terms per side the fused small-MSM launch takes the problem: that wants 10-bit windows (512 buckets = one block)
-            if (C.msm_small_max && allow_small && slots_mode && (lr ? n / 2 : n) <= C.msm_small_max && P.c > 10 && np * 26 <= 512) P = msm_plan_c(10);
-            PW = np * P.W; Wgrid = P.W;
-            cap = 16; while (cap < 256 && (size_t)cap * P.B < 4 * n) cap *= 2;
-            for (size_t i = 0; i < np; i++) h_probs[i] = probs[i];
-        }
-        if (slots_mode && (size_t)PW * P.B * cap * 4 > ((size_t)8 << 30)) continue;
-        if (C.probs_on_dev.size() != np || memcmp(C.probs_on_dev.data(), h_probs, sizeof(MsmProb) * np) != 0) {
-            HIPCHK(hipMemcpyAsync(d_probs, h_probs, sizeof(MsmProb) * np, hipMemcpyHostToDevice, C.stream));
-            C.probs_on_dev.assign(h_probs, h_probs + np);
-        }
-        u32 *cnt = C.msm_cnt.as<u32>(PW * P.B + 4), *off = C.msm_off.as<u32>(PW * P.B), *cur = C.msm_cur.as<u32>(PW * P.B);
-        u32 *perm = C.msm_perm.as<u32>(PW * P.B);
-        ge *buckets = C.msm_buckets.as<ge>(PW * P.B);
-        MsmWin mw{P.c, P.W, P.wide};
-        const u32 OVF_MAX = 4096;
-        // results and flags go from the kernels straight into mapped host memory (no D2H copies on the hop); with many problems the
-        // Horner chains run on the device and only one point per problem comes back
-        dev_horner = !fb && np >= C.msm_dev_horner_min && P.W <= 64;
-        ge *hres_dev = C.h_res.dev<ge>(PW * (size_t)P.c + np);
-        u32 *h_flag = C.h_ovf.as<u32>(4), *d_flag = C.h_ovf.dev<u32>(4);
-        u32 Wb = (u32)(PW / nq);                           // bucket arrays per grid problem
-        // the IPP tail (a few thousand terms per problem): one launch instead of memset / scatter / scan / accumulate / overflow / reduce
-        u32 nside_small = (u32)(lr ? n / 2 : n);
-        // (its blocks hold up to 130 KB of LDS, one per CU: with thousands of bucket arrays -- n_partition = 64 -- the general pipeline is faster)
-        // ... unless the blocks are small: at c <= 7 a block needs < 24 KB, eight of them share a CU and thousands of arrays go through in a few batches
-        const u32 small_cap = nside_small <= 8 * P.B ? (u32)MSM_SMALL_CAP : 72u;      // list entries per bucket: mean load <= 16 / <= 32
-        size_t small_lds = std::max((size_t)P.B * 4 * (1 + small_cap), std::max(((size_t)(P.B / 8) * 4 + (size_t)(P.B / 16) * 5 + 1) * sizeof(ge), ((size_t)P.B + (size_t)P.B * 3 / 4 + 1) * sizeof(ge)));
-        bool small = !fb && slots_mode && allow_small && C.msm_small_max && nside_small <= C.msm_small_max && P.c <= 10 && nside_small <= 16 * P.B && (PW <= 512 || small_lds <= 24 * 1024);
-        if (small) {
-            *h_flag = 0;                                                  // list-overflow flag, in mapped host memory (plain stores from the kernel)
-            ge *S_fin_s = dev_horner ? C.msm_S[0].as<ge>(PW) : hres_dev;
-            ge *C_fin_s = dev_horner ? C.msm_C[0].as<ge>(PW * (size_t)(P.c - 1)) : hres_dev + PW;
-            size_t lds_lists = (size_t)P.B * 4 * (1 + small_cap);
-            size_t lds_red = std::max(((size_t)(P.B / 8) * 4 + (size_t)(P.B / 16) * 5 + 1) * sizeof(ge), ((size_t)P.B + (size_t)P.B * 3 / 4 + 1) * sizeof(ge));      // fused / binary reduction trees
-            {
-                uint64_t items = (uint64_t)np * nside_small * P.W;
-                KSpan ks(C.tm, C.stream, ROFL_TK_MSM_SMALL, items * 7 + (uint64_t)PW * P.B * 10, (uint64_t)np * nside_small * (32 + 96));
-                hipLaunchKernelGGL(k_msm_small, dim3((unsigned)PW), dim3(P.B < 64 ? 64 : P.B), std::max(lds_lists, lds_red), C.stream, nside_small, mw, mm, d_probs, buckets,
-                                   S_fin_s, C_fin_s, P.c - 1, d_flag, small_cap);
-            }
-        } else {
-        // fixed-base launches: two-level bucket sort (coarse bins through HBM in full lines, then per-bin ranking in LDS)
-        bool two = fb && allow_two && C.msm_two_level && 16 * opt.fb_stride <= ((size_t)1 << 24) && P.B == 32768;
-        Msm2L tl{256, 7, 24, 0, 144};
-        u32 n_side2 = (u32)(lr ? n / 2 : n);
+// overlap: host work to run while the kernels execute; post(p): runs on the pool thread that finished problem p's window combination,
+// right after results[p] is final (the caller's per-problem tail -- encoding, transcript -- without a second pool hand-off on the hop)
+struct MsmOpt { u32 lr_nh = 0, lr_ng = 0; const niels *fb_wtab = nullptr; size_t fb_stride = 0; u32 fb_c = 16; std::function<void()> overlap; std::function<void(size_t)> post; };
+
+// An MSM goes through four stages: PLAN (which variant, window layout, bucket sets, capacities) -> SORT (digits into per-bucket lists)
+// -> ACCUMULATE (one thread per bucket) -> REDUCE (bit-sum tree; the window combination is left to the host, or to k_msm_horner when a
+// launch carries many problems).  msm_enqueue runs plan + the launches of one attempt on the lane's stream and returns an MsmJob;
+// after the stream has been synchronised msm_retry says whether the attempt overflowed one of its fixed-size structures (scalars built
+// to collide) and which variants are still allowed, and msm_finish turns the partial sums in mapped host memory into results.
+// Variants, fastest first: fixed-base (two-level sort, or slot sort) | fused small-MSM launch | generic slot sort | count / scan / scatter.
+struct MsmAllow { bool fb = true, small = true, two = true, slots = true; };
+enum class MsmKind { FixedBase, Small, Slots, CountSort };
+struct MsmJob {
+    MsmWs *ws = nullptr; size_t np = 0, nq = 0, n = 0, PW = 0; MsmPlan P{}; MsmKind kind = MsmKind::CountSort; bool lr = false, two = false, dev_horner = false;
+    u32 sets = 0, cap = 0;
+    bool fb() const { return kind == MsmKind::FixedBase; }
+};
+static const u32 MSM_OVF_MAX = 4096;
+
+// ---- plan
+bool msm_plan_job(Ctx &C, MsmJob &J, const MsmOpt &opt, const MsmAllow &al, MsmMap &mm, u32 &small_cap, Msm2L &tl) {
+    const size_t np = J.np, n = J.n; const bool lr = J.lr; const size_t nq = J.nq;
+    const size_t per_side = lr ? n / 2 : n;
+    mm = MsmMap{opt.lr_nh, opt.lr_ng, 0, 0, 0};
+    J.two = false; J.sets = 0;
+    bool want_fb = al.fb && opt.fb_wtab != nullptr && C.msm_slots;
+    if (want_fb) {
+        J.kind = MsmKind::FixedBase;
+        J.P = msm_plan_c(opt.fb_c);
+        // Fewer sets = less bucket-reduction work but fewer accumulate threads.  Alone on the device the call wants the
+        // threads (latency); with other calls in flight the GPU is full anyway and the work is what counts: the smallest number of
+        // sets (a divisor of the window count: every set takes the same number of windows) that gives `want` accumulate threads.
+        bool crowded = C.crowded();
+        size_t want = crowded ? C.msm_fb_threads / 2 : C.msm_fb_threads;
+        u32 sets = J.P.W;
+        for (u32 sdiv = 1; sdiv <= J.P.W; sdiv++)
+            if (J.P.W % sdiv == 0 && (size_t)nq * (lr ? 2 : 1) * sdiv * J.P.B >= want) { sets = sdiv; break; }      // many problems (n_partition = 64): one set each is plenty
+        J.sets = sets;
+        mm.fb_sets = sets; mm.fb_wps = J.P.W / sets; mm.fb_stride = (u32)opt.fb_stride;
+        J.PW = nq * (lr ? 2 : 1) * sets;
+        // the three (c-1)-bit windows of the layout fill only half of the buckets: twice the mean load there
+        u32 cap = 16; while (cap < 2048 && (size_t)cap * J.P.B < 3 * per_side * (mm.fb_wps + 1)) cap *= 2;
+        if (mm.fb_wps == 1) cap *= 2;
+        J.cap = cap;
+        // two-level bucket sort (coarse bins through HBM in full lines, then per-bin ranking in LDS)
+        bool two = al.two && C.msm_two_level && J.P.W * opt.fb_stride <= ((size_t)1 << 24) && J.P.B == 32768;
+        tl = Msm2L{256, 7, 24, 0, 144};
         if (two) {
             // a coarse bin has to fit one block's LDS in level 2: 256 bins of 128 buckets while that holds (<= 4 windows per array at
             // 2^19 terms), 512 bins of 64 buckets with half the staging row for arrays that take 8 windows (two sets per problem)
-            auto size_bins = [&]() { size_t avg = (size_t)n_side2 * mm.fb_wps / tl.nbins; tl.cap_bin = (u32)((2 * avg + 256 + 63) / 64 * 64); return (size_t)tl.cap_bin * 4 + 1024 <= 96 * 1024; };
+            auto size_bins = [&]() { size_t avg = per_side * mm.fb_wps / tl.nbins; tl.cap_bin = (u32)((2 * avg + 256 + 63) / 64 * 64); return (size_t)tl.cap_bin * 4 + 1024 <= 96 * 1024; };
             bool fits = size_bins();
             if (!fits) { tl = Msm2L{512, 6, 24, 0, 72}; fits = size_bins(); }
-            if (!fits || n_side2 < 8192) two = false;
+            if (!fits || per_side < 8192) two = false;
         }
-        two_used = two;
-        if (two) {
-            u32 *bins = C.msm_sorted.as<u32>(PW * tl.nbins * tl.cap_bin);
-            u32 *bcur = C.msm_cur.as<u32>(PW * tl.nbins * 2);
-            u32 *btail = C.msm_tail.as<u32>(PW * tl.nbins * (size_t)MSM_BIN_TAIL);
-            u32 *ovf_flag = d_flag;
-            *h_flag = 0;
-            HIPCHK(hipMemsetAsync(bcur, 0, sizeof(u32) * PW * tl.nbins * 2, C.stream));
-            u32 iter_pts = (tl.stage >= 144 ? 16384u : 12288u) / mm.fb_wps; if (iter_pts < 1024) iter_pts = 1024;      // ~ 64 (48) new items per bin and iteration against a row of 144 (72)
-            u32 tile = iter_pts;
-            while (((size_t)((n_side2 + tile - 1) / tile) * PW > 512 || (n_side2 + tile - 1) / tile > 48) && tile < n_side2) tile *= 2;      // <= 48 tiles per array: their left-overs (< 32 each) fit the bin tails with room for row spills
-            dim3 grid((n_side2 + tile - 1) / tile, (u32)PW);
-            uint64_t terms = (uint64_t)(lr ? nq : np) * n, items = terms * 16u;
-            { KSpan ks(C.tm, C.stream, ROFL_TK_MSM_SCATTER, 0, terms * 32 + items * 4);
-              hipLaunchKernelGGL(k_msm_bin_l1, grid, dim3(1024), (size_t)(tl.nbins + tl.nbins * tl.stage) * 4, C.stream, n_side2, tile, iter_pts, mw, mm, d_probs, bcur, bins, btail, tl, ovf_flag);
-              hipLaunchKernelGGL(k_msm_bin_l2, dim3(tl.nbins, (u32)PW), dim3(512), (size_t)(2 * 128 + tl.cap_bin) * 4, C.stream, tl, P.B, bcur, bins, (const u32 *)btail, cnt, off, ovf_flag); }
-            hipLaunchKernelGGL(k_msm_scan, dim3((unsigned)PW), dim3(TPB), 0, C.stream, P.B, cnt, off, (u32 *)nullptr, perm);
-            if (C.tm.enabled) { e0 = C.tm.get(); e1 = C.tm.get(); HIPCHK(hipEventRecord(e0, C.stream)); }
-            {
-                uint64_t acc_adds = (uint64_t)(lr ? nq : np) * n * 16u;
-                KSpan ks_acc(C.tm, C.stream, ROFL_TK_MSM_ACCUMULATE_FB, acc_adds * 7, (uint64_t)(lr ? nq : np) * n * 32);
-                static const char *timeline = getenv("ROFL_DBG_ACC_TIMELINE");      // debugging: per-wave start / end / placement of every launch, appended to this file
-                if (timeline) {
-                    dim3 g = grid1((size_t)Wb * P.B, (u32)nq);
-                    size_t waves = (size_t)g.x * g.y * (TPB / 64);
-                    unsigned long long *rec; HIPCHK(hipMalloc(&rec, waves * 32)); HIPCHK(hipMemsetAsync(rec, 0, waves * 32, C.stream));
-                    hipLaunchKernelGGL(k_msm_accumulate_fb_dbg, g, dim3(TPB), 0, C.stream, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, bins, perm, buckets, MSM_LIST_ABS, dbg_mask, acc_balance, rec);
-                    std::vector<unsigned long long> h(waves * 4);
-                    HIPCHK(hipMemcpyAsync(h.data(), rec, waves * 32, hipMemcpyDeviceToHost, C.stream)); HIPCHK(hipStreamSynchronize(C.stream));
-                    if (FILE *f = fopen(timeline, "ab")) { unsigned long long hdr[4] = {0x54494d45ull, waves, g.x, g.y}; fwrite(hdr, 8, 4, f); fwrite(h.data(), 8, h.size(), f); fclose(f); }
-                    HIPCHK(hipFree(rec));
-                } else
-                hipLaunchKernelGGL(k_msm_accumulate_fb, grid1((size_t)Wb * P.B, (u32)nq), dim3(TPB), 0, C.stream, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, bins, perm, buckets, MSM_LIST_ABS, dbg_mask, acc_balance);
-            }
-            if (C.tm.enabled) HIPCHK(hipEventRecord(e1, C.stream));
-        } else {
-        HIPCHK(hipMemsetAsync(cnt, 0, sizeof(u32) * (PW * P.B + 4), C.stream));
-        // accumulate sees `nq` problems of Wb bucket arrays each; its points come from d_probs[q * (np / nq)]
-        if (slots_mode) {
-            u32 *slots = C.msm_sorted.as<u32>(PW * P.B * cap);
-            MsmOvf *ovf = C.msm_ovf.as<MsmOvf>(OVF_MAX);
-            u32 *ovf_count = cnt + PW * P.B;
-            if (C.msm_lds && n >= C.msm_lds_min && (size_t)P.B * 4 <= 128 * 1024) {
-                u32 n_side = (u32)(lr ? n / 2 : n);
-                u32 per_q = fb ? sets : P.W;
-                u32 tile = n_side;
-                // tile so that a block ranks ~128k items at most, and the launch has a few hundred blocks
-                u32 wps = fb ? mm.fb_wps : 1;
-                while (tile > 1024 && ((size_t)tile * wps > (size_t)C.msm_lds_tile || (size_t)((n_side + tile - 1) / tile) * nq * (lr ? 2 : 1) * per_q < 256)) tile /= 2;
-                dim3 grid((n_side + tile - 1) / tile, (u32)(nq * (lr ? 2 : 1) * per_q));
-                uint64_t terms = (uint64_t)(lr ? nq : np) * n, items = terms * (fb ? 16u : P.W);
-                { KSpan ks(C.tm, C.stream, ROFL_TK_MSM_SCATTER, 0, terms * 32 + items * 4);
-                  hipLaunchKernelGGL(k_msm_scatter_lds, grid, dim3(1024), (size_t)P.B * 4, C.stream, n_side, tile, mw, mm, d_probs, cnt, slots, cap, ovf_count, ovf, OVF_MAX, dbg_scatter); }
+        J.two = two;
+        if (!two && (size_t)J.PW * J.P.B * J.cap * 4 > ((size_t)8 << 30)) return false;      // slot array too large: next variant
+        return true;
+    }
+    bool slots_mode = al.slots && C.msm_slots;
+    J.P = msm_plan(n);
+    // up to msm_small_max terms per side the fused small-MSM launch takes the problem: that wants 10-bit windows (512 buckets = one block)
+    if (C.msm_small_max && al.small && slots_mode && per_side <= C.msm_small_max && J.P.c > 10 && np * 26 <= 512) J.P = msm_plan_c(10);
+    J.PW = np * J.P.W;
+    { u32 cap = 16; while (cap < 256 && (size_t)cap * J.P.B < 4 * n) cap *= 2; J.cap = cap; }
+    // the IPP tail (a few thousand terms per problem): one launch instead of memset / scatter / scan / accumulate / overflow / reduce
+    // (its blocks hold up to 130 KB of LDS, one per CU: with thousands of bucket arrays -- n_partition = 64 -- the general pipeline is faster)
+    // ... unless the blocks are small: at c <= 7 a block needs < 24 KB, eight of them share a CU and thousands of arrays go through in a few batches
+    small_cap = per_side <= 8 * J.P.B ? (u32)MSM_SMALL_CAP : 72u;      // list entries per bucket: mean load <= 16 / <= 32
+    size_t small_lds = std::max((size_t)J.P.B * 4 * (1 + small_cap), std::max(((size_t)(J.P.B / 8) * 4 + (size_t)(J.P.B / 16) * 5 + 1) * sizeof(ge), ((size_t)J.P.B + (size_t)J.P.B * 3 / 4 + 1) * sizeof(ge)));
+    bool small = slots_mode && al.small && C.msm_small_max && per_side <= C.msm_small_max && J.P.c <= 10 && per_side <= 16 * J.P.B && (J.PW <= 512 || small_lds <= 24 * 1024);
+    J.kind = small ? MsmKind::Small : slots_mode ? MsmKind::Slots : MsmKind::CountSort;
+    if (J.kind == MsmKind::Slots && (size_t)J.PW * J.P.B * J.cap * 4 > ((size_t)8 << 30)) return false;
+    return true;
+}
+
+// ---- sort + accumulate + reduce of one attempt, enqueued on the lane's stream (no synchronisation)
+MsmJob msm_enqueue(Ctx &C, MsmWs &W, const std::vector<MsmProb> &probs, size_t n, const MsmOpt &opt, MsmAllow &al) {
+    static const u32 acc_balance = getenv("ROFL_ACC_BALANCE") ? (atoi(getenv("ROFL_ACC_BALANCE")) ? 1u : 0u) : 1u;   // equal-work blocks in k_msm_accumulate (0 = plain descending order)
+    static const u32 dbg_mask = getenv("ROFL_DBG_IDX_MASK") ? (u32)strtoul(getenv("ROFL_DBG_IDX_MASK"), nullptr, 0) : 0x7fffffffu;   // timing experiments only (wrong results): gathers confined to a cache-resident prefix
+    static const u32 dbg_scatter = getenv("ROFL_DBG_SCATTER") ? (u32)atoi(getenv("ROFL_DBG_SCATTER")) : 0u;   // timing experiments only: 1 = no range reservation, 2 = no slot stores
+    MsmJob J; J.ws = &W; J.np = probs.size(); J.n = n; J.lr = opt.lr_nh != 0; J.nq = J.lr ? J.np / 2 : J.np;
+    const size_t np = J.np, nq = J.nq; const bool lr = J.lr;
+    MsmMap mm{}; u32 small_cap = 0; Msm2L tl{};
+    while (!msm_plan_job(C, J, opt, al, mm, small_cap, tl)) {      // a variant whose structures would not fit: the next one
+        if (al.fb && opt.fb_wtab && C.msm_slots) al.fb = false; else al.slots = false;
+    }
+    const MsmPlan &P = J.P; const size_t PW = J.PW; const bool fb = J.fb();
+    MsmProb *d_probs = W.probs.as<MsmProb>(np);
+    MsmProb *h_probs = W.h_probs.as<MsmProb>(np);
+    for (size_t i = 0; i < np; i++) h_probs[i] = fb ? MsmProb{opt.fb_wtab, probs[i].scal} : probs[i];
+    if (W.probs_on_dev.size() != np || memcmp(W.probs_on_dev.data(), h_probs, sizeof(MsmProb) * np) != 0) {      // an unchanged problem list (constant within a fold level) is not uploaded again
+        HIPCHK(hipMemcpyAsync(d_probs, h_probs, sizeof(MsmProb) * np, hipMemcpyHostToDevice, C.stream));
+        W.probs_on_dev.assign(h_probs, h_probs + np);
+    }
+    u32 *cnt = W.cnt.as<u32>(PW * P.B + 4), *off = W.off.as<u32>(PW * P.B), *cur = W.cur.as<u32>(PW * P.B);
+    u32 *perm = W.perm.as<u32>(PW * P.B);
+    ge *buckets = W.buckets.as<ge>(PW * P.B);
+    MsmWin mw{P.c, P.W, P.wide};
+    // results and flags go from the kernels straight into mapped host memory (no D2H copies on the hop); with many problems the
+    // Horner chains run on the device and only one point per problem comes back
+    J.dev_horner = !fb && np >= C.msm_dev_horner_min && P.W <= 64;
+    ge *hres_dev = W.h_res.dev<ge>(PW * (size_t)P.c + np);
+    u32 *h_flag = W.h_ovf.as<u32>(4), *d_flag = W.h_ovf.dev<u32>(4);
+    const u32 Wb = (u32)(PW / nq);                           // bucket arrays per grid problem
+    const u32 n_side = (u32)(lr ? n / 2 : n);
+    const u32 nb_final = P.c - 1;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    *h_flag = 0;
+    if (J.kind == MsmKind::Small) {
+        ge *S_fin_s = J.dev_horner ? W.S[0].as<ge>(PW) : hres_dev;
+        ge *C_fin_s = J.dev_horner ? W.Cacc[0].as<ge>(PW * (size_t)nb_final) : hres_dev + PW;
+        size_t lds_lists = (size_t)P.B * 4 * (1 + small_cap);
+        size_t lds_red = std::max(((size_t)(P.B / 8) * 4 + (size_t)(P.B / 16) * 5 + 1) * sizeof(ge), ((size_t)P.B + (size_t)P.B * 3 / 4 + 1) * sizeof(ge));      // fused / binary reduction trees
+        uint64_t items = (uint64_t)np * n_side * P.W;
+        KSpan ks(C.tm, C.stream, ROFL_TK_MSM_SMALL, items * 7 + (uint64_t)PW * P.B * 10, (uint64_t)np * n_side * (32 + 96));
+        hipLaunchKernelGGL(k_msm_small, dim3((unsigned)PW), dim3(P.B < 64 ? 64 : P.B), std::max(lds_lists, lds_red), C.stream, n_side, mw, mm, d_probs, buckets,
+                           S_fin_s, C_fin_s, nb_final, d_flag, small_cap);
+        if (J.dev_horner) hipLaunchKernelGGL(k_msm_horner, dim3((unsigned)np), dim3(256), 0, C.stream, mw, (const ge *)S_fin_s, (const ge *)C_fin_s, nb_final, hres_dev);
+        return J;
+    }
+    // ---- SORT (+ ACCUMULATE: its list format depends on the sort)
+    const uint64_t terms = (uint64_t)(lr ? nq : np) * n;
+    if (J.two) {
+        u32 *bins = W.sorted.as<u32>(PW * tl.nbins * tl.cap_bin);
+        u32 *bcur = W.cur.as<u32>(PW * tl.nbins * 2);
+        u32 *btail = W.tail.as<u32>(PW * tl.nbins * (size_t)MSM_BIN_TAIL);
+        HIPCHK(hipMemsetAsync(bcur, 0, sizeof(u32) * PW * tl.nbins * 2, C.stream));
+        u32 iter_pts = (tl.stage >= 144 ? 16384u : 12288u) / mm.fb_wps; if (iter_pts < 1024) iter_pts = 1024;      // ~ 64 (48) new items per bin and iteration against a row of 144 (72)
+        u32 tile = iter_pts;
+        while (((size_t)((n_side + tile - 1) / tile) * PW > 512 || (n_side + tile - 1) / tile > 48) && tile < n_side) tile *= 2;      // <= 48 tiles per array: their left-overs (< 32 each) fit the bin tails with room for row spills
+        dim3 grid((n_side + tile - 1) / tile, (u32)PW);
+        { KSpan ks(C.tm, C.stream, ROFL_TK_MSM_SCATTER, 0, terms * 32 + terms * P.W * 4);
+          hipLaunchKernelGGL(k_msm_bin_l1, grid, dim3(1024), (size_t)(tl.nbins + tl.nbins * tl.stage) * 4, C.stream, n_side, tile, iter_pts, mw, mm, d_probs, bcur, bins, btail, tl, d_flag);
+          hipLaunchKernelGGL(k_msm_bin_l2, dim3(tl.nbins, (u32)PW), dim3(512), (size_t)(2 * 128 + tl.cap_bin) * 4, C.stream, tl, P.B, bcur, bins, (const u32 *)btail, cnt, off, d_flag); }
+        hipLaunchKernelGGL(k_msm_scan, dim3((unsigned)PW), dim3(TPB), 0, C.stream, P.B, cnt, off, (u32 *)nullptr, perm);
+        if (C.tm.enabled) { e0 = C.tm.get(); e1 = C.tm.get(); HIPCHK(hipEventRecord(e0, C.stream)); }
+        {
+            KSpan ks_acc(C.tm, C.stream, ROFL_TK_MSM_ACCUMULATE_FB, terms * P.W * 7, terms * 32);
+            static const char *timeline = getenv("ROFL_DBG_ACC_TIMELINE");      // debugging: per-wave start / end / placement of every launch, appended to this file
+            if (timeline) {
+                dim3 g = grid1((size_t)Wb * P.B, (u32)nq);
+                size_t waves = (size_t)g.x * g.y * (TPB / 64);
+                unsigned long long *rec; HIPCHK(hipMalloc(&rec, waves * 32)); HIPCHK(hipMemsetAsync(rec, 0, waves * 32, C.stream));
+                hipLaunchKernelGGL(k_msm_accumulate_fb_dbg, g, dim3(TPB), 0, C.stream, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, bins, perm, buckets, MSM_LIST_ABS, dbg_mask, acc_balance, rec);
+                std::vector<unsigned long long> h(waves * 4);
+                HIPCHK(hipMemcpyAsync(h.data(), rec, waves * 32, hipMemcpyDeviceToHost, C.stream)); HIPCHK(hipStreamSynchronize(C.stream));
+                if (FILE *f = fopen(timeline, "ab")) { unsigned long long hdr[4] = {0x54494d45ull, waves, g.x, g.y}; fwrite(hdr, 8, 4, f); fwrite(h.data(), 8, h.size(), f); fclose(f); }
+                HIPCHK(hipFree(rec));
             } else
-            hipLaunchKernelGGL(k_msm_scatter_slots, grid1(n, (u32)(nq * Wgrid)), dim3(TPB), 0, C.stream, (u32)n, mw, mm, d_probs, cnt, slots, cap, ovf_count, ovf, OVF_MAX);
-            hipLaunchKernelGGL(k_msm_scan, dim3((unsigned)PW), dim3(TPB), 0, C.stream, P.B, cnt, off, (u32 *)nullptr, perm);
-            if (C.tm.enabled) { e0 = C.tm.get(); e1 = C.tm.get(); HIPCHK(hipEventRecord(e0, C.stream)); }
-            {
-                uint64_t acc_adds = (uint64_t)(lr ? nq : np) * n * (fb ? 16u : P.W);
-                KSpan ks_acc(C.tm, C.stream, fb ? ROFL_TK_MSM_ACCUMULATE_FB : ROFL_TK_MSM_ACCUMULATE_GEN, acc_adds * 7, (uint64_t)(lr ? nq : np) * n * 32);
-                if (fb) hipLaunchKernelGGL(k_msm_accumulate_fb, grid1((size_t)Wb * P.B, (u32)nq), dim3(TPB), 0, C.stream, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, slots, perm, buckets, cap, dbg_mask, acc_balance);
-                else hipLaunchKernelGGL(k_msm_accumulate_gen, grid1((size_t)Wb * P.B, (u32)nq), dim3(TPB), 0, C.stream, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, slots, perm, buckets, cap, dbg_mask, acc_balance);
-            }
-            if (C.tm.enabled) HIPCHK(hipEventRecord(e1, C.stream));
-            hipLaunchKernelGGL(k_msm_overflow, dim3(1), dim3(64), 0, C.stream, Wb, P.B, (u32)(np / nq), d_probs, ovf_count, ovf, OVF_MAX, buckets, fb ? 1 : 0);
-            HIPCHK(hipMemcpyAsync(C.h_ovf.as<u32>(4), ovf_count, 4, hipMemcpyDeviceToHost, C.stream));
-        } else {
-            u32 *sorted = C.msm_sorted.as<u32>(PW * n * 2);
-            hipLaunchKernelGGL(k_msm_count, grid1(n, (u32)(nq * Wgrid)), dim3(TPB), 0, C.stream, (u32)n, mw, mm, d_probs, cnt);
-            hipLaunchKernelGGL(k_msm_scan, dim3((unsigned)PW), dim3(TPB), 0, C.stream, P.B, cnt, off, cur, perm);
-            hipLaunchKernelGGL(k_msm_scatter, grid1(n, (u32)(nq * Wgrid)), dim3(TPB), 0, C.stream, (u32)n, mw, mm, d_probs, cur, sorted);
-            if (C.tm.enabled) { e0 = C.tm.get(); e1 = C.tm.get(); HIPCHK(hipEventRecord(e0, C.stream)); }
-            hipLaunchKernelGGL(k_msm_accumulate_gen, grid1((size_t)Wb * P.B, (u32)nq), dim3(TPB), 0, C.stream, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, sorted, perm, buckets, 0u, dbg_mask, acc_balance);
-            if (C.tm.enabled) HIPCHK(hipEventRecord(e1, C.stream));
+            hipLaunchKernelGGL(k_msm_accumulate_fb, grid1((size_t)Wb * P.B, (u32)nq), dim3(TPB), 0, C.stream, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, bins, perm, buckets, MSM_LIST_ABS, dbg_mask, acc_balance);
         }
+        if (C.tm.enabled) HIPCHK(hipEventRecord(e1, C.stream));
+    } else if (J.kind != MsmKind::CountSort) {      // slot sort (fixed-base or generic)
+        HIPCHK(hipMemsetAsync(cnt, 0, sizeof(u32) * (PW * P.B + 4), C.stream));
+        const u32 cap = J.cap;
+        u32 *slots = W.sorted.as<u32>(PW * P.B * cap);
+        MsmOvf *ovf = W.ovf.as<MsmOvf>(MSM_OVF_MAX);
+        u32 *ovf_count = cnt + PW * P.B;
+        if (C.msm_lds && n >= C.msm_lds_min && (size_t)P.B * 4 <= 128 * 1024) {
+            u32 per_q = fb ? J.sets : P.W;
+            u32 tile = n_side;
+            // tile so that a block ranks ~128k items at most, and the launch has a few hundred blocks
+            u32 wps = fb ? mm.fb_wps : 1;
+            while (tile > 1024 && ((size_t)tile * wps > (size_t)C.msm_lds_tile || (size_t)((n_side + tile - 1) / tile) * nq * (lr ? 2 : 1) * per_q < 256)) tile /= 2;
+            dim3 grid((n_side + tile - 1) / tile, (u32)(nq * (lr ? 2 : 1) * per_q));
+            uint64_t items = terms * P.W;
+            KSpan ks(C.tm, C.stream, ROFL_TK_MSM_SCATTER, 0, terms * 32 + items * 4);
+            hipLaunchKernelGGL(k_msm_scatter_lds, grid, dim3(1024), (size_t)P.B * 4, C.stream, n_side, tile, mw, mm, d_probs, cnt, slots, cap, ovf_count, ovf, MSM_OVF_MAX, dbg_scatter);
+        } else
+            hipLaunchKernelGGL(k_msm_scatter_slots, grid1(n, (u32)(nq * P.W)), dim3(TPB), 0, C.stream, (u32)n, mw, mm, d_probs, cnt, slots, cap, ovf_count, ovf, MSM_OVF_MAX);
+        hipLaunchKernelGGL(k_msm_scan, dim3((unsigned)PW), dim3(TPB), 0, C.stream, P.B, cnt, off, (u32 *)nullptr, perm);
+        if (C.tm.enabled) { e0 = C.tm.get(); e1 = C.tm.get(); HIPCHK(hipEventRecord(e0, C.stream)); }
+        {
+            uint64_t acc_adds = terms * P.W;
+            KSpan ks_acc(C.tm, C.stream, fb ? ROFL_TK_MSM_ACCUMULATE_FB : ROFL_TK_MSM_ACCUMULATE_GEN, acc_adds * 7, terms * 32);
+            if (fb) hipLaunchKernelGGL(k_msm_accumulate_fb, grid1((size_t)Wb * P.B, (u32)nq), dim3(TPB), 0, C.stream, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, slots, perm, buckets, cap, dbg_mask, acc_balance);
+            else hipLaunchKernelGGL(k_msm_accumulate_gen, grid1((size_t)Wb * P.B, (u32)nq), dim3(TPB), 0, C.stream, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, slots, perm, buckets, cap, dbg_mask, acc_balance);
         }
-        }
-        if (C.tm.enabled && !small) { C.tm.acc_ev.push_back({e0, e1}); C.tm.t.msm_accumulate_launches++; C.tm.t.msm_additions += (uint64_t)(lr ? nq : np) * n * (fb ? 16u : P.W); char tg[96]; snprintf(tg, sizeof tg, "msm np=%zu n=%zu c=%u cap=%u fb=%u lr=%d", np, n, P.c, slots_mode ? cap : 0u, fb ? sets : 0u, (int)lr); C.tm.acc_tag.push_back(tg); }
-        // reduction tree: global levels while more than 512 nodes remain, then one fused launch
-        const ge *S_in = buckets; const ge *C_in = nullptr;
-        u32 E = P.B, nb = 0, lv = 0;
-        uint64_t red_adds = 0;
-        { u32 e = P.B, b = 0; while (e > 512) { red_adds += (uint64_t)(e / 8) * (11 + 7 * b); e /= 8; b += 3; }
-          red_adds += (uint64_t)(e / 8) * (16 + 7 * b); e /= 8; b += 3; while (e > 1) { red_adds += (uint64_t)(e / 2) * (1 + b); e /= 2; b++; } }
-        std::unique_ptr<KSpan> ks_red(small ? nullptr : new KSpan(C.tm, C.stream, ROFL_TK_MSM_REDUCE, red_adds * PW * 9, (uint64_t)PW * P.B * 128));
-        u32 nb_final = P.c - 1;
-        ge *S_fin = dev_horner ? C.msm_S[1].as<ge>(PW) : hres_dev;
-        ge *C_fin = dev_horner ? C.msm_C[1].as<ge>(PW * (size_t)nb_final) : hres_dev + PW;
-        if (!small && C.msm_group_reduce && P.B >= 1024) {
+        if (C.tm.enabled) HIPCHK(hipEventRecord(e1, C.stream));
+        hipLaunchKernelGGL(k_msm_overflow, dim3(1), dim3(64), 0, C.stream, Wb, P.B, (u32)(np / nq), d_probs, ovf_count, ovf, MSM_OVF_MAX, buckets, fb ? 1 : 0);
+        HIPCHK(hipMemcpyAsync(h_flag, ovf_count, 4, hipMemcpyDeviceToHost, C.stream));
+    } else {      // count / scan / scatter: no fixed-size structure, always sufficient
+        HIPCHK(hipMemsetAsync(cnt, 0, sizeof(u32) * (PW * P.B + 4), C.stream));
+        u32 *sorted = W.sorted.as<u32>(PW * n * 2);
+        hipLaunchKernelGGL(k_msm_count, grid1(n, (u32)(nq * P.W)), dim3(TPB), 0, C.stream, (u32)n, mw, mm, d_probs, cnt);
+        hipLaunchKernelGGL(k_msm_scan, dim3((unsigned)PW), dim3(TPB), 0, C.stream, P.B, cnt, off, cur, perm);
+        hipLaunchKernelGGL(k_msm_scatter, grid1(n, (u32)(nq * P.W)), dim3(TPB), 0, C.stream, (u32)n, mw, mm, d_probs, cur, sorted);
+        if (C.tm.enabled) { e0 = C.tm.get(); e1 = C.tm.get(); HIPCHK(hipEventRecord(e0, C.stream)); }
+        hipLaunchKernelGGL(k_msm_accumulate_gen, grid1((size_t)Wb * P.B, (u32)nq), dim3(TPB), 0, C.stream, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, sorted, perm, buckets, 0u, dbg_mask, acc_balance);
+        if (C.tm.enabled) HIPCHK(hipEventRecord(e1, C.stream));
+    }
+    if (C.tm.enabled) {
+        C.tm.acc_ev.push_back({e0, e1}); C.tm.t.msm_accumulate_launches++; C.tm.t.msm_additions += terms * P.W;
+        char tg[96]; snprintf(tg, sizeof tg, "msm np=%zu n=%zu c=%u cap=%u fb=%u lr=%d", np, n, P.c, J.kind != MsmKind::CountSort ? J.cap : 0u, fb ? J.sets : 0u, (int)lr); C.tm.acc_tag.push_back(tg);
+    }
+    // ---- REDUCE: bit-sum tree, global 8-ary levels while more than 512 nodes remain, then one fused launch per bucket array
+    const ge *S_in = buckets; const ge *C_in = nullptr;
+    u32 E = P.B, nb = 0, lv = 0;
+    uint64_t red_adds = 0;
+    { u32 e = P.B, b = 0; while (e > 512) { red_adds += (uint64_t)(e / 8) * (11 + 7 * b); e /= 8; b += 3; }
+      red_adds += (uint64_t)(e / 8) * (16 + 7 * b); e /= 8; b += 3; while (e > 1) { red_adds += (uint64_t)(e / 2) * (1 + b); e /= 2; b++; } }
+    ge *S_fin = J.dev_horner ? W.S[1].as<ge>(PW) : hres_dev;
+    ge *C_fin = J.dev_horner ? W.Cacc[1].as<ge>(PW * (size_t)nb_final) : hres_dev + PW;
+    {
+        KSpan ks_red(C.tm, C.stream, ROFL_TK_MSM_REDUCE, red_adds * PW * 9, (uint64_t)PW * P.B * 128);
+        if (C.msm_group_reduce && P.B >= 1024) {
             // every run of 512 buckets reduced by its own block, then one block per array combines the groups (two launches, the
             // first at full occupancy, instead of a chain of three whose last one ran on PW blocks)
             u32 G = P.B / 512, gbits = P.c - 1 - 9;
-            ge *GS = C.msm_S[0].as<ge>(PW * G);
-            ge *GC = C.msm_C[0].as<ge>(PW * (size_t)G * 9);
+            ge *GS = W.S[0].as<ge>(PW * G);
+            ge *GC = W.Cacc[0].as<ge>(PW * (size_t)G * 9);
             size_t lds_a = ((size_t)64 * 4 + (size_t)32 * 5 + 1) * sizeof(ge);
             hipLaunchKernelGGL(k_msm_reduce_fused, dim3((unsigned)(PW * G)), dim3(256), lds_a, C.stream, 512u, 0u, (const ge *)buckets, (const ge *)nullptr, GS, GC, 9u);
             u32 half = G / 2 ? G / 2 : 1, nout = 10 + gbits;
             hipLaunchKernelGGL(k_msm_reduce_groups, dim3((unsigned)PW), dim3(half, nout), (size_t)nout * half * sizeof(ge), C.stream, G, gbits, (const ge *)GS, (const ge *)GC, S_fin, C_fin, nb_final);
         } else {
-        while (!small && E > 512) {
-            u32 E8 = E / 8;
-            ge *S_out = C.msm_S[lv & 1].as<ge>(PW * E8);
-            ge *C_out = C.msm_C[lv & 1].as<ge>(PW * (size_t)(nb + 3) * E8);
-            static const int red_split = getenv("ROFL_RED_SPLIT") ? atoi(getenv("ROFL_RED_SPLIT")) : 0;
-            hipLaunchKernelGGL(k_msm_reduce_level, grid1((size_t)E8 * ((red_split ? 4 : 1) + nb), (u32)PW), dim3(TPB), 0, C.stream, E, nb, S_in, C_in, S_out, C_out, red_split);
-            S_in = S_out; C_in = C_out; E = E8; nb += 3; lv++;
+            while (E > 512) {
+                u32 E8 = E / 8;
+                ge *S_out = W.S[lv & 1].as<ge>(PW * E8);
+                ge *C_out = W.Cacc[lv & 1].as<ge>(PW * (size_t)(nb + 3) * E8);
+                static const int red_split = getenv("ROFL_RED_SPLIT") ? atoi(getenv("ROFL_RED_SPLIT")) : 0;
+                hipLaunchKernelGGL(k_msm_reduce_level, grid1((size_t)E8 * ((red_split ? 4 : 1) + nb), (u32)PW), dim3(TPB), 0, C.stream, E, nb, S_in, C_in, S_out, C_out, red_split);
+                S_in = S_out; C_in = C_out; E = E8; nb += 3; lv++;
+            }
+            if (J.dev_horner) { S_fin = W.S[lv & 1].as<ge>(PW); C_fin = W.Cacc[lv & 1].as<ge>(PW * (size_t)nb_final); }
+            // block size = first-level work items (small bucket arrays, c = 7: 32 items -- a 256-thread block would idle 7 of its 8
+            // waves and, at 163 VGPRs, hold a whole CU: thousands of such blocks (n_partition = 64) ran 18 deep per CU)
+            static const u32 red_fused_max = getenv("ROFL_RED_FUSED_T") ? (u32)atoi(getenv("ROFL_RED_FUSED_T")) : 512u;
+            u32 fused_items = (E / 8) * (4 + nb), fused_threads = fused_items > 256 ? 512 : fused_items > 128 ? 256 : fused_items > 64 ? 128 : 64;
+            if (fused_threads > red_fused_max) fused_threads = red_fused_max;
+            size_t lds = ((size_t)(E / 8) * (1 + nb + 3) + (size_t)(E / 16) * (1 + nb + 4) + 1) * sizeof(ge);
+            hipLaunchKernelGGL(k_msm_reduce_fused, dim3((unsigned)PW), dim3(fused_threads), lds, C.stream, E, nb, S_in, C_in, S_fin, C_fin, nb_final);
         }
-        if (dev_horner) { S_fin = C.msm_S[lv & 1].as<ge>(PW); C_fin = C.msm_C[lv & 1].as<ge>(PW * (size_t)nb_final); }
-        // block size = first-level work items (small bucket arrays, c = 7: 32 items -- a 256-thread block would idle 7 of its 8
-        // waves and, at 163 VGPRs, hold a whole CU: thousands of such blocks (n_partition = 64) ran 18 deep per CU)
-        static const u32 red_fused_max = getenv("ROFL_RED_FUSED_T") ? (u32)atoi(getenv("ROFL_RED_FUSED_T")) : 512u;
-        u32 fused_items = (E / 8) * (4 + nb), fused_threads = fused_items > 256 ? 512 : fused_items > 128 ? 256 : fused_items > 64 ? 128 : 64;
-        if (fused_threads > red_fused_max) fused_threads = red_fused_max;
-        size_t lds = ((size_t)(E / 8) * (1 + nb + 3) + (size_t)(E / 16) * (1 + nb + 4) + 1) * sizeof(ge);
-        if (!small) hipLaunchKernelGGL(k_msm_reduce_fused, dim3((unsigned)PW), dim3(fused_threads), lds, C.stream, E, nb, S_in, C_in, S_fin, C_fin, nb_final);
-        }
-        ks_red.reset();
-        if (dev_horner)      // many problems: their Horner chains run side by side on the device, one point per problem comes back
-            hipLaunchKernelGGL(k_msm_horner, dim3((unsigned)np), dim3(256), 0, C.stream, mw, (const ge *)S_fin, (const ge *)C_fin, nb_final, hres_dev);
-        if (opt.overlap && !overlap_done) { opt.overlap(); overlap_done = true; }
-        double t_sync0 = now_ms(); C.hs.enqueue += t_sync0 - t_enter;
-        C.sync();
-        C.hs.sync += now_ms() - t_sync0; t_enter = now_ms();
-        if (slots_mode && getenv("ROFL_TRACE")) fprintf(stderr, "[rofl] msm np=%zu n=%zu c=%u cap=%u fb=%u lr=%d overflow=%u\n", np, n, P.c, cap, fb ? sets : 0u, (int)lr, *C.h_ovf.as<u32>(4));
-        if (small) {
-            if (*C.h_ovf.as<u32>(4) != 0) { allow_small = false; attempt = 0; continue; }     // a bucket list overflowed: repeat through the general pipeline
-        } else if (two_used) {
-            if (*C.h_ovf.as<u32>(4) != 0) { allow_two = false; attempt = -1; continue; }      // a coarse bin overflowed (skewed scalars): repeat on the slot path
-        } else
-        if (slots_mode && *C.h_ovf.as<u32>(4) > OVF_MAX) continue;    // pathological input: next (slower, always sufficient) variant
-        fb_used = fb;
-        break;
     }
+    if (J.dev_horner)      // many problems: their Horner chains run side by side on the device, one point per problem comes back
+        hipLaunchKernelGGL(k_msm_horner, dim3((unsigned)np), dim3(256), 0, C.stream, mw, (const ge *)S_fin, (const ge *)C_fin, nb_final, hres_dev);
+    return J;
+}
+
+// after the stream has been synchronised: did the attempt overflow one of its fixed-size structures?  (then `al` has lost that variant)
+bool msm_retry(const MsmJob &J, MsmAllow &al) {
+    u32 flag = *J.ws->h_ovf.as<u32>(4);
+    if (getenv("ROFL_TRACE") && J.kind != MsmKind::CountSort) fprintf(stderr, "[rofl] msm np=%zu n=%zu c=%u cap=%u fb=%u lr=%d overflow=%u\n", J.np, J.n, J.P.c, J.cap, J.fb() ? J.sets : 0u, (int)J.lr, flag);
+    if (J.kind == MsmKind::Small) { if (flag) { al.small = false; return true; } return false; }      // a bucket list overflowed: repeat through the general pipeline
+    if (J.two) { if (flag) { al.two = false; return true; } return false; }                              // a coarse bin overflowed (skewed scalars): repeat on the slot path
+    if (J.kind == MsmKind::CountSort) return false;
+    if (flag > MSM_OVF_MAX) { if (J.fb()) al.fb = false; else al.slots = false; return true; }           // pathological input: the next (slower, always sufficient) variant
+    return false;
+}
+
+// ---- window combination on the host (the device already did it for launches with many problems)
+void msm_finish(Ctx &C, const MsmJob &J, std::vector<ge5> &results, const MsmOpt &opt) {
+    const size_t np = J.np, PW = J.PW; const MsmPlan &P = J.P; const u32 sets = J.sets;
     u32 nb = P.c - 1;
-    ge *h = C.h_res.as<ge>(PW * (size_t)P.c + np);
+    ge *h = J.ws->h_res.as<ge>(PW * (size_t)P.c + np);
     double t0 = now_ms();
     results.resize(np);
     std::vector<double> cpu_each(np, 0.0);
-    if (dev_horner) {
-        for (size_t p = 0; p < np; p++) results[p] = h51::from_ge_loose(h[p]);
-    } else if (fb_used) {
-        // sets of a problem carry equal weight: add them up, then one 16-bit Horner
+    if (J.dev_horner) {
+        if (opt.post) C.pool->run(np, [&](size_t p) { results[p] = h51::from_ge_loose(h[p]); opt.post(p); });
+        else for (size_t p = 0; p < np; p++) results[p] = h51::from_ge_loose(h[p]);
+    } else if (J.fb()) {
+        // sets of a problem carry equal weight: add them up, then one Horner over the c - 1 bit-sums
         C.pool->run(np, [&](size_t p) {
             double tc0 = now_ms();
             size_t base = p * sets;                         // lr: problem 2q+side owns sets [(2q+side)*sets, ...)
             ge5 acc = h51::identity(); bool started = false;
-            for (int l = 15; l >= 0; l--) {
+            for (int l = (int)nb - 1; l >= 0; l--) {
                 if (started) acc = h51::gdouble(acc);
-                if (l <= 14) for (u32 s = 0; s < sets; s++) { acc = h51::gadd(acc, h51::from_ge_loose(h[PW + (base + s) * nb + l])); started = true; }
+                for (u32 s = 0; s < sets; s++) { acc = h51::gadd(acc, h51::from_ge_loose(h[PW + (base + s) * nb + l])); started = true; }
                 if (l == 0) for (u32 s = 0; s < sets; s++) acc = h51::gadd(acc, h51::from_ge_loose(h[base + s]));
             }
-            results[p] = acc; cpu_each[p] = now_ms() - tc0;
+            results[p] = acc; if (opt.post) opt.post(p); cpu_each[p] = now_ms() - tc0;
         });
     } else {
         C.pool->run(np, [&](size_t p) {
@@ -778,11 +830,44 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
                     if (l == 0) { acc = h51::gadd(acc, h51::from_ge_loose(h[pw])); started = true; }
                 }
             }
-            results[p] = acc; cpu_each[p] = now_ms() - tc0;
+            results[p] = acc; if (opt.post) opt.post(p); cpu_each[p] = now_ms() - tc0;
         });
     }
     C.tm.t.host_ms += now_ms() - t0;
     C.hs.horner_wall += now_ms() - t0; { double mx = 0; for (double v : cpu_each) mx = std::max(mx, v); C.hs.horner_cpu += mx; } C.hs.n++;
+}
+
+// one MSM, start to finish: enqueue, wait, repeat through the next variant if a fixed-size structure overflowed, combine.
+void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge5> &results, const MsmOpt &opt = MsmOpt()) {
+    MsmAllow al; bool overlap_done = false;
+    for (;;) {
+        double t_enter = now_ms();
+        MsmJob J = msm_enqueue(C, C.mws[0], probs, n, opt, al);
+        if (opt.overlap && !overlap_done) { opt.overlap(); overlap_done = true; }
+        double t_sync0 = now_ms(); C.hs.enqueue += t_sync0 - t_enter;
+        C.sync();
+        C.hs.sync += now_ms() - t_sync0;
+        if (msm_retry(J, al)) continue;
+        msm_finish(C, J, results, opt);
+        return;
+    }
+}
+// two independent MSMs behind ONE synchronisation (the verifier's generator MSM and its proof-point MSM): their launches queue back
+// to back on the lane's stream, each with its own workspace; an overflow in either repeats that one on its own.
+void msm_run2(Ctx &C, const std::vector<MsmProb> &pa, size_t na, const MsmOpt &oa, std::vector<ge5> &ra,
+              const std::vector<MsmProb> &pb, size_t nb, const MsmOpt &ob, std::vector<ge5> &rb) {
+    MsmAllow ala, alb;
+    double t_enter = now_ms();
+    MsmJob Ja = msm_enqueue(C, C.mws[0], pa, na, oa, ala);
+    MsmJob Jb = msm_enqueue(C, C.mws[1], pb, nb, ob, alb);
+    double t_sync0 = now_ms(); C.hs.enqueue += t_sync0 - t_enter;
+    C.sync();
+    C.hs.sync += now_ms() - t_sync0;
+    bool again_a = msm_retry(Ja, ala), again_b = msm_retry(Jb, alb);
+    if (!again_a) msm_finish(C, Ja, ra, oa);
+    if (!again_b) msm_finish(C, Jb, rb, ob);
+    if (again_a) { for (;;) { MsmJob J = msm_enqueue(C, C.mws[0], pa, na, oa, ala); C.sync(); if (msm_retry(J, ala)) continue; msm_finish(C, J, ra, oa); break; } }
+    if (again_b) { for (;;) { MsmJob J = msm_enqueue(C, C.mws[1], pb, nb, ob, alb); C.sync(); if (msm_retry(J, alb)) continue; msm_finish(C, J, rb, ob); break; } }
 }
 
 // ---------------------------------------------------------------- transcript helpers
@@ -856,7 +941,7 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
     std::vector<sc> a_bl(P), s_bl(P), y(P), z(P), zz(P), x(P), w(P);
     for (size_t c = 0; c < P; c++) tr.emplace_back(label, strlen(label));
     {
-        MsmOpt mo; if (wtab) { mo.fb_wtab = wtab; mo.fb_stride = 2 * N; }
+        MsmOpt mo; if (wtab) { mo.fb_wtab = wtab; mo.fb_stride = 2 * N; mo.fb_c = gens.wc(); }
         mo.overlap = [&]() {      // the transcript prefix (m commitments per chunk) does not depend on S: hash it while the MSM runs
             double t0 = now_ms();
             if (v_ready) HIPCHK(hipEventSynchronize(v_ready));      // first in the stream: long done by the time the S launches are enqueued
@@ -864,7 +949,7 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
                 Merlin &t = tr[c];
                 t.append("dom-sep", (const uint8_t *)"rangeproof v1", 13);
                 t.append_u64("n", n); t.append_u64("m", m);
-                for (size_t j = 0; j < m; j++) t.append("V", h_V + (c * m + j) * 32, 32);
+                t.append32_run('V', h_V + c * m * 32, m);
             });
             C.tm.t.host_ms += now_ms() - t0;
         };
@@ -955,6 +1040,7 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
     static const bool fold_regs = !(getenv("ROFL_FOLD_REGS") && atoi(getenv("ROFL_FOLD_REGS")) == 0);
     bool just_materialised = false;
     sc *ptab[2] = {C.ptab[0].as<sc>(P * 2 * N), C.ptab[1].as<sc>(P * 2 * N)}; int psel = 0;      // pending-challenge product tables (ping-pong)
+    std::unique_ptr<std::atomic<int>[]> lr_done(new std::atomic<int>[P]);
     for (unsigned round = 0; round < lgN; round++) {
         size_t n_k = n_g >> r, nh = n_k / 2;
         sc *SL = C.SL.as<sc>(P * 2 * n_g), *SR = C.SR.as<sc>(P * 2 * n_g);
@@ -980,34 +1066,31 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
         C.tm.t.msm_terms += P * 2 * n_g;
         MsmOpt mo;
         if (merged) { mo.lr_nh = (u32)nh; mo.lr_ng = (u32)n_g; }
-        if (first_level && wtab) { mo.fb_wtab = wtab; mo.fb_stride = 2 * N; }
-        msm_run(C, pr, 2 * n_g, res, mo);
-        mark("round msm", (long)(2 * n_g));
-        th = now_ms();
-        std::vector<double> rh_cpu(P, 0.0);
-        C.pool->run(P, [&](size_t c) {
-            double tc0 = now_ms();
+        if (first_level && wtab) { mo.fb_wtab = wtab; mo.fb_stride = 2 * N; mo.fb_c = gens.wc(); }
+        // The host tail of the round runs inside the MSM's own pool tasks: the thread that finishes problem 2c (+1) adds c_L w B (c_R w B)
+        // and encodes L (R); the second of a chunk's two to get there hashes both into the transcript, draws u and inverts it.  L and R
+        // of a chunk are encoded side by side and the hop has one pool hand-off instead of two.
+        for (size_t c = 0; c < P; c++) lr_done[c].store(0);
+        mo.post = [&](size_t p) {
+            size_t c = p >> 1; int side = (int)(p & 1);
             uint8_t *o = proofs_out[c] + 7 * 32 + 64 * round;
-            sc cL = h_canon(sum_partials(h_ip + c * nblkI * 2, nblkI, 2, 0));
-            sc cR = h_canon(sum_partials(h_ip + c * nblkI * 2, nblkI, 2, 1));
-            ge5 L = h51::gadd(res[2 * c], h_fixed_mul(C.ht.B5, h_mul(cL, w[c])));
-            ge5 R = h51::gadd(res[2 * c + 1], h_fixed_mul(C.ht.B5, h_mul(cR, w[c])));
-            tr_append_point(tr[c], "L", L, o); tr_append_point(tr[c], "R", R, o + 32);
+            sc cx = h_canon(sum_partials(h_ip + c * nblkI * 2, nblkI, 2, (size_t)side));
+            h51::encode(o + 32 * side, h51::gadd(res[p], h_fixed_mul(C.ht.B5, h_mul(cx, w[c]))));
+            if (lr_done[c].fetch_add(1) != 1) return;          // the chunk's other point is still on its way
+            tr[c].append("L", o, 32); tr[c].append("R", o + 32, 32);
             sc u = tr[c].challenge_scalar("u");
             sc um = h_mont(u), uim = h51::sc_invert_mont_fast(um);
             h_round[2 * c] = um; h_round[2 * c + 1] = uim;          // mapped: k_ipp_fold_ab reads it and records it in the chunk's pending list
             h_cp[c].pend_u[pu[c].size()] = um; h_cp[c].pend_ui[pu[c].size()] = uim;
             pu[c].push_back(um); pui[c].push_back(uim);
-            rh_cpu[c] = now_ms() - tc0;
-        });
-        C.tm.t.host_ms += now_ms() - th;
-        C.hs.host_wall += now_ms() - th; { double mx = 0; for (double v : rh_cpu) mx = std::max(mx, v); C.hs.host_cpu += mx; }
+        };
+        msm_run(C, pr, 2 * n_g, res, mo);
+        mark("round msm", (long)(2 * n_g));
         bool last = (round + 1 == lgN);
         // the fold of a, b by this challenge happens inside the next round's k_ipp_round; only the old three-kernel path and the
         // last round (whose result is the proof's final a, b) fold here
         if (last || !(merged && ipp_fused))
             hipLaunchKernelGGL(k_ipp_fold_ab, grid1(nh, (u32)P), dim3(TPB), 0, C.stream, (u32)nh, d_cp, (const sc *)C.h_round.dev<sc>(2 * P), r, a, b, N);
-        mark("round host");
         r++;
         unsigned t_now = first_level ? (unsigned)C.fold_t1 : (unsigned)C.fold_t;
         // fold_min is a per-chunk size chosen for P = 4 (below it the fold kernel is latency-bound); what matters is the number of
@@ -1158,6 +1241,9 @@ int verify_chunks(Ctx &C, const char *label, size_t gens_capacity, size_t P, siz
     // `group` consecutive proofs are checked as one batch: sum_c rho_c * (check_c) == 0 with random weights rho_c, so their
     // generator terms share one MSM.  Every proof of a batch gets the batch's verdict (callers AND them per client anyway).
     for (size_t c = 0; c < P; c++) ok[c] = 0;
+    static const bool vtrace = getenv("ROFL_TRACE") && atoi(getenv("ROFL_TRACE")) >= 2;
+    double vt0 = now_ms(), vtl = vt0;
+    auto vmark = [&](const char *what) { if (!vtrace) return; double t = now_ms(); fprintf(stderr, "[rofl-trace verify] %-14s +%.3f ms  (t=%.3f)\n", what, t - vtl, t - vt0); vtl = t; };
     if (group == 0 || P % group) group = 1;
     size_t ngroups = P / group;
     // RangeProof::from_bytes / InnerProductProof::from_bytes
@@ -1207,7 +1293,7 @@ int verify_chunks(Ctx &C, const char *label, size_t gens_capacity, size_t P, siz
         Merlin t(label, strlen(label));
         t.append("dom-sep", (const uint8_t *)"rangeproof v1", 13);
         t.append_u64("n", n); t.append_u64("m", m);
-        for (size_t j = 0; j < m; j++) t.append("V", h_V + (c * m + j) * 32, 32);
+        t.append32_run('V', h_V + c * m * 32, m);
         // validate_and_append_point rejects the identity encoding
         bool bad = false;
         for (int i = 0; i < 4; i++) if (!memcmp(p + 32 * i, zero32, 32)) bad = true;
@@ -1275,6 +1361,7 @@ int verify_chunks(Ctx &C, const char *label, size_t gens_capacity, size_t P, siz
         }
     });
     C.tm.t.host_ms += now_ms() - th;
+    vmark("transcripts");
     HIPCHK(hipMemcpyAsync(d_cp, h_cp, sizeof(ChunkParams) * P, hipMemcpyHostToDevice, C.stream));
     sc *gh = C.SL.as<sc>(ngroups * 2 * N);
     PowTabs *d_pt = C.powtabs.as<PowTabs>(P);
@@ -1290,15 +1377,16 @@ int verify_chunks(Ctx &C, const char *label, size_t gens_capacity, size_t P, siz
         HIPCHK(hipMemcpy2DAsync(aux_pts + m, naux * sizeof(niels), d_auxn, na2 * sizeof(niels), na2 * sizeof(niels), P, hipMemcpyDeviceToDevice, C.stream));
         HIPCHK(hipMemcpy2DAsync(aux_scal + m, naux * sizeof(sc), h_auxs, na2 * sizeof(sc), na2 * sizeof(sc), P, hipMemcpyHostToDevice, C.stream));
     }
-    u32 h_status = 0;
-    std::vector<MsmProb> pr(ngroups); std::vector<ge5> resA, resB;
+    u32 *h_stat = C.h_misc2.as<u32>(4);
+    HIPCHK(hipMemcpyAsync(h_stat, status, 4, hipMemcpyDeviceToHost, C.stream));      // k_decode's verdict on the proof points
+    std::vector<MsmProb> pr(ngroups), prB(ngroups); std::vector<ge5> resA, resB;
     for (size_t g = 0; g < ngroups; g++) pr[g] = MsmProb{tbl, gh + g * 2 * N};
-    C.tm.t.msm_terms += ngroups * 2 * N;
-    { MsmOpt mo; if (wtab) { mo.fb_wtab = wtab; mo.fb_stride = 2 * N; } msm_run(C, pr, 2 * N, resA, mo); }
-    for (size_t g = 0; g < ngroups; g++) pr[g] = MsmProb{aux_pts + g * group * naux, aux_scal + g * group * naux};
-    C.tm.t.msm_terms += P * naux;
-    msm_run(C, pr, group * naux, resB);
-    HIPCHK(hipMemcpy(&h_status, status, 4, hipMemcpyDeviceToHost));
+    for (size_t g = 0; g < ngroups; g++) prB[g] = MsmProb{aux_pts + g * group * naux, aux_scal + g * group * naux};
+    C.tm.t.msm_terms += ngroups * 2 * N + P * naux;
+    // the generator MSM (2N terms per group, fixed-base) and the proof-point MSM (commitments, A, S, T, L, R) queue back to back: one wait
+    { MsmOpt mo; if (wtab) { mo.fb_wtab = wtab; mo.fb_stride = 2 * N; mo.fb_c = gens.wc(); } msm_run2(C, pr, 2 * N, mo, resA, prB, group * naux, MsmOpt(), resB); }
+    vmark("msm");
+    const u32 h_status = *h_stat;
     th = now_ms();
     for (size_t g = 0; g < ngroups; g++) {
         ge5 tot = h51::gadd(resA[g], resB[g]);
@@ -1466,6 +1554,8 @@ int create_impl(Ctx &C, size_t nc, const float *const *values, size_t d, const u
     // call returns.
     if (!C.stream2) HIPCHK(hipStreamCreateWithFlags(&C.stream2, hipStreamNonBlocking));
     if (!C.ev_v) { HIPCHK(hipEventCreateWithFlags(&C.ev_v, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&C.ev_fork, hipEventDisableTiming)); }
+    GensPin gens_pin = get_gens(C, prove_range, chunk);           // may throw (allocation): before anything is queued on the side stream
+    struct Join { hipStream_t s; ~Join() { (void)hipStreamSynchronize(s); } } join{C.stream2};      // also on the error paths: the side stream copies into caller memory
     HIPCHK(hipEventRecord(C.ev_fork, C.stream));                  // inputs quantised (and compacted)
     HIPCHK(hipStreamWaitEvent(C.stream2, C.ev_fork, 0));
     HIPCHK(hipMemcpyAsync(d_shift, &h_shift, sizeof(niels), hipMemcpyHostToDevice, C.stream2));
@@ -1474,10 +1564,8 @@ int create_impl(Ctx &C, size_t nc, const float *const *values, size_t d, const u
     HIPCHK(hipMemcpyAsync(hV, Vb, na * dp * 32, hipMemcpyDeviceToHost, C.stream2));
     HIPCHK(hipEventRecord(C.ev_v, C.stream2));
     for (size_t k = 0; k < na; k++) HIPCHK(hipMemcpyAsync(commits_out[act[k]], Cb + k * dp * 32, d * 32, hipMemcpyDeviceToHost, C.stream2));
-    GensPin gens_pin = get_gens(C, prove_range, chunk);
     std::vector<uint8_t *> pout(na * P);
     for (size_t k = 0; k < na; k++) for (size_t c = 0; c < P; c++) pout[k * P + c] = proofs_out[act[k]] + c * plen;
-    struct Join { hipStream_t s; ~Join() { (void)hipStreamSynchronize(s); } } join{C.stream2};      // also on the error paths: the copies target caller memory
     prove_chunks(C, "RangeProof", na * P, prove_range, chunk, vshift, d_blind_buf, cn, hV, pout.data(), C.ev_v);
     HIPCHK(hipStreamSynchronize(C.stream2));
     timing_end(C);
@@ -1488,7 +1576,7 @@ int create_impl(Ctx &C, size_t nc, const float *const *values, size_t d, const u
 // not divide the padded length the zip silently drops the tail, i.e. commitments that NO proof covers are accepted (3 proofs for
 // 8 commitments check 6 of them; dp/2 + 1 proofs check half).  The proof count comes off the wire, so that is a soundness hole, not
 // a format quirk: here a set whose proofs do not cover every chunk exactly is reported as "does not verify" (ok = 0, return code 0).
-// ROFL_VERIFY_ZIP_TRUNCATE=1 restores the reference's behaviour bit for bit (tests only).
+// rofl_set_option("verify_zip_truncate", 1) restores the reference's behaviour bit for bit (byte-level comparisons).
 int verify_impl(Ctx &C, size_t n_clients, const uint8_t *const *proofs, size_t proof_len, size_t n_proofs, const uint8_t *const *commits,
                 size_t d, size_t prove_range, unsigned fp_bits, unsigned fp_frac, const uint8_t seed[32], int *ok_out) {
     for (size_t i = 0; i < n_clients; i++) ok_out[i] = 0;
@@ -1499,7 +1587,8 @@ int verify_impl(Ctx &C, size_t n_clients, const uint8_t *const *proofs, size_t p
     if (chunk == 0) return fail(ROFL_BAD_PARAM, "more proofs than padded commitments (the reference panics in chunks(0))");
     size_t n_chunks = (dp + chunk - 1) / chunk;
     size_t nv = std::min(n_proofs, n_chunks);            // zip truncates (range_proof_vec/mod.rs:173-176)
-    static const bool zip_truncate = getenv("ROFL_VERIFY_ZIP_TRUNCATE") && atoi(getenv("ROFL_VERIFY_ZIP_TRUNCATE")) != 0;
+    const Ctx &P0 = C.parent ? *C.parent : C;
+    const bool zip_truncate = P0.opt_zip_truncate != 0;      // rofl_set_option("verify_zip_truncate")
     if (n_proofs * chunk != dp) {
         if (!zip_truncate) { g_err = "proof count does not cover the padded commitment vector: not verified"; return ROFL_OK; }
         if (dp % chunk) return fail(ROFL_BAD_PARAM, "ragged chunks are not supported");
@@ -1514,11 +1603,19 @@ int verify_impl(Ctx &C, size_t n_clients, const uint8_t *const *proofs, size_t p
     std::vector<uint8_t> pf(P * proof_len);
     for (size_t i = 0; i < n_clients; i++)
         HIPCHK(hipMemcpy(&pf[i * nv * proof_len], proofs[i], nv * proof_len, hipMemcpyDefault));   // host or device memory
+    // RangeProof::from_bytes rejects non-canonical scalars.  A single set: FormatError, as the reference (the caller cannot even build
+    // its Vec<RangeProof>).  In a batch every client has its own verdict (server.rs:656-687 verifies each client on its own): the
+    // offender gets ok = 0 and the others are still verified -- its scalars are zeroed in the local copy so that the shared launch
+    // sequence stays well-formed (its check then fails on its own; clients never share a check).
+    std::vector<char> bad_format(n_clients, 0);
     for (size_t q = 0; q < P; q++) {
-        const uint8_t *pb = &pf[q * proof_len];
-        if (!sc_is_canonical_bytes(pb + 128) || !sc_is_canonical_bytes(pb + 160) || !sc_is_canonical_bytes(pb + 192) ||
-            !sc_is_canonical_bytes(pb + 7 * 32 + 64 * lg) || !sc_is_canonical_bytes(pb + 7 * 32 + 64 * lg + 32))
-            return fail(ROFL_FORMAT_ERROR, "proof rejected before verification (format / bitsize)");
+        uint8_t *pb = &pf[q * proof_len];
+        const size_t offs[5] = {128, 160, 192, 7 * 32 + 64 * lg, 7 * 32 + 64 * lg + 32};
+        for (size_t o : offs)
+            if (!sc_is_canonical_bytes(pb + o)) {
+                if (n_clients == 1) return fail(ROFL_FORMAT_ERROR, "proof rejected before verification (format / bitsize)");
+                bad_format[q / nv] = 1; memset(pb + o, 0, 32);
+            }
     }
     if (!(prove_range == 8 || prove_range == 16 || prove_range == 32 || prove_range == 64)) return fail(ROFL_INVALID_BITSIZE, "proof rejected before verification (format / bitsize)");
     if (prove_range * chunk != ((size_t)1 << lg)) return ROFL_OK;      // VerificationError for every chunk -> Ok(false)
@@ -1564,7 +1661,7 @@ int verify_impl(Ctx &C, size_t n_clients, const uint8_t *const *proofs, size_t p
     std::vector<int> okc(P);
     GensPin gens_pin = get_gens(C, prove_range, chunk);
     C.sync();
-    static const bool vbatch = !(getenv("ROFL_VERIFY_BATCH") && atoi(getenv("ROFL_VERIFY_BATCH")) == 0);
+    const bool vbatch = P0.opt_verify_batch != 0;             // rofl_set_option("verify_batch")
     size_t grp = vbatch ? nv : 1;
     // all (client, chunk) pairs in one pass; a client's chunks form one batch of the random-weighted check
     sc v_shift = sc_from_u64(1ULL << (prove_range - 1));
@@ -1573,7 +1670,7 @@ int verify_impl(Ctx &C, size_t n_clients, const uint8_t *const *proofs, size_t p
     int rc = verify_chunks(C, "RangeProof", prove_range, P, prove_range, chunk, pf.data(), proof_len, Vh.data(), d_vn2, seed, cidx.data(), okc.data(), grp, &v_shift, v_real.data());
     timing_end(C);
     if (rc) return fail(rc, "proof rejected before verification (format / bitsize)");
-    for (size_t i = 0; i < n_clients; i++) { int r = bad_commit[i] ? 0 : 1; for (size_t c = 0; c < nv; c++) r &= okc[i * nv + c]; ok_out[i] = r; }
+    for (size_t i = 0; i < n_clients; i++) { int r = (bad_commit[i] || bad_format[i]) ? 0 : 1; for (size_t c = 0; c < nv; c++) r &= okc[i * nv + c]; ok_out[i] = r; }
     return ROFL_OK;
 }
 
@@ -1779,7 +1876,7 @@ int sigma_verify(int kind, const uint8_t *proofs, const uint8_t *commits, size_t
     HIPCHK(hipMemsetAsync(status, 0, 16, C.stream));
     HIPCHK(hipMemcpyAsync(dp, proofs, d * plen, hipMemcpyDefault, C.stream));
     HIPCHK(hipMemcpyAsync(dc, commits, d * clen, hipMemcpyDefault, C.stream));
-    static const bool sg_batch = !(getenv("ROFL_SIGMA_BATCH") && atoi(getenv("ROFL_SIGMA_BATCH")) == 0);
+    const bool sg_batch = (C.parent ? C.parent : &C)->opt_sigma_batch != 0;      // rofl_set_option("sigma_batch")
     if (sg_batch) {
         // one random linear combination of all elements' equations: decode + transcripts per element on the device, then ONE Pippenger MSM
         // over the 4-6 d points and two fixed-base terms (k_sigma_vprep); the weights come from fresh OS randomness
@@ -2177,6 +2274,31 @@ int rofl_wire_decode(int kind, const uint8_t *data, size_t len, rofl_wire_msg_t 
     int rc = wire::decode(kind, data, len, m, range_proofs_out, range_proofs_cap);
     return rc ? fail(rc, rc == ROFL_FORMAT_ERROR ? "malformed message (prost's decode_length_delimited would return Err; the reference unwraps it)" : "bad parameter") : ROFL_OK;
 }
+namespace {
+int *option_slot(Ctx &P, const char *key, long *lo, long *hi) {
+    struct { const char *k; int Ctx::*f; long lo, hi; } tab[] = {
+        {"verify_zip_truncate", &Ctx::opt_zip_truncate, 0, 1}, {"verify_batch", &Ctx::opt_verify_batch, 0, 1},
+        {"sigma_batch", &Ctx::opt_sigma_batch, 0, 1}, {"blocking_sync", &Ctx::blocking_sync, -1, 1}};
+    for (auto &t : tab) if (key && !strcmp(key, t.k)) { *lo = t.lo; *hi = t.hi; return &(P.*(t.f)); }
+    return nullptr;
+}
+}  // namespace
+int rofl_set_option(const char *key, long value) {
+    return guarded([&]() -> int {
+        Ctx &P = ctx(); { std::lock_guard<std::mutex> g(P.init_mu); P.init(); }
+        long lo, hi; int *slot = option_slot(P, key, &lo, &hi);
+        if (!slot || value < lo || value > hi) return fail(ROFL_BAD_PARAM, "unknown option or value out of range");
+        *slot = (int)value; return ROFL_OK;
+    });
+}
+int rofl_get_option(const char *key, long *value_out) {
+    return guarded([&]() -> int {
+        Ctx &P = ctx(); { std::lock_guard<std::mutex> g(P.init_mu); P.init(); }
+        long lo, hi; int *slot = option_slot(P, key, &lo, &hi);
+        if (!slot || !value_out) return fail(ROFL_BAD_PARAM, "unknown option");
+        *value_out = *slot; return ROFL_OK;
+    });
+}
 int rofl_set_timing(int enabled) {
     return guarded([&]() -> int {
         Ctx &P = ctx(); { std::lock_guard<std::mutex> g(P.init_mu); P.init(); }
@@ -2248,6 +2370,33 @@ int rofl_dbg_host_pool_stress(unsigned threads, unsigned jobs) {
         pool.run(n, [&](size_t i) { hits[i].fetch_add(1); });
         for (size_t i = 0; i < n; i++) if (hits[i].load() != 1) return ROFL_BAD_PARAM;
     }
+    return ROFL_OK;
+}
+int rofl_dbg_host_bench(int what, unsigned iters, double *ns_out) {
+    if (!ns_out || !iters) return ROFL_BAD_PARAM;
+    static const uint8_t Bc[32] = {0xe2, 0xf2, 0xae, 0x0a, 0x6a, 0xbc, 0x4e, 0x71, 0xa8, 0x84, 0xa9, 0x61, 0xc5, 0x00, 0x51, 0x5f,
+                                   0x58, 0xe3, 0x0b, 0x6a, 0xa5, 0x82, 0xdd, 0x8d, 0xb6, 0xa6, 0x59, 0x45, 0xe0, 0x8d, 0x2d, 0x76};
+    ge b; ristretto_decode(b, Bc);
+    ge5 p = h51::from_ge(b), q = h51::gdouble(p);
+    volatile u64 sink = 0;
+    double t0 = now_ms();
+    if (what == 0) { u64 st[25]; memset(st, 1, sizeof st); for (unsigned i = 0; i < iters; i++) keccak_f1600_host(st); sink = st[0]; }
+    else if (what == 1) { for (unsigned i = 0; i < iters; i++) p = h51::gdouble(p); sink = p.X.v[0]; }
+    else if (what == 2) { for (unsigned i = 0; i < iters; i++) p = h51::gadd(p, q); sink = p.X.v[0]; }
+    else if (what == 3) { uint8_t e[32]; for (unsigned i = 0; i < iters; i++) { h51::encode(e, p); p = h51::gadd(p, q); } sink = p.X.v[0]; }
+    else if (what == 4) {
+        std::vector<niels> T; std::vector<niels5> T5; build_fixed_table(T, b); to_tab5(T5, T);
+        sc k = sc_from_u64(0x123456789abcdefULL); t0 = now_ms();
+        for (unsigned i = 0; i < iters; i++) { ge5 r = h_fixed_mul(T5, k); k.v[3] ^= (u32)r.X.v[0]; k.v[7] &= 0x0fffffffu; } sink = k.v[3];
+    } else if (what == 5) { sc a = h_mont(sc_from_u64(0xdeadbeefcafeULL)); for (unsigned i = 0; i < iters; i++) { a = h51::sc_invert_mont_fast(a); a.v[0] |= 1; } sink = a.v[0]; }
+    else if (what == 6) {
+        std::vector<uint8_t> V((size_t)iters * 32); for (size_t i = 0; i < V.size(); i++) V[i] = (uint8_t)(i * 131 + 7);
+        t0 = now_ms();
+        Merlin t("RangeProof", 10);
+        t.append32_run('V', V.data(), iters);
+        sink = t.stw[0];
+    } else return ROFL_BAD_PARAM;
+    *ns_out = (now_ms() - t0) * 1e6 / iters; (void)sink;
     return ROFL_OK;
 }
 int rofl_dbg_host_fe_mul(const uint8_t a[32], const uint8_t b[32], uint8_t out[32]) { fe_tobytes(out, fe_mul(fe_frombytes(a), fe_frombytes(b))); return 0; }

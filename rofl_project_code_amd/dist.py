@@ -65,7 +65,9 @@ def exchange_round(payloads, ok_local, device, group=None):
             dist.all_gather_into_tensor(allb, loc, group=group)
         except (RuntimeError, AttributeError):      # a backend without the flat form: per-rank views of the same buffer
             dist.all_gather(list(allb.view(world, n).unbind(0)), loc, group=group)
-    got = allb.cpu().numpy().reshape(world, n)
+    # (a CPU device -- the gloo tests -- would hand out views of the cached buffer, which the next round overwrites: copy there;
+    #  from the GPU, .cpu() is a fresh tensor already)
+    got = (allb.cpu() if allb.is_cuda else allb.clone()).numpy().reshape(world, n)
     ok_all = bool(got[:, 0].min() == 1)
     per_rank = []
     for r in range(world):

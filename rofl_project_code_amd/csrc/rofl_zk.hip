@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <time.h>
+#include <sched.h>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -121,11 +122,24 @@ ge h_fixed_mul32(const std::vector<niels> &tab, const sc &k_canon) {
     return acc;
 }
 
+// cores this process may use: the affinity mask, capped by the cgroup v2 CPU quota (the GPU boxes show 256 CPUs under a 16-core quota)
+int usable_cores() {
+    int n = (int)std::thread::hardware_concurrency(); if (n < 1) n = 1;
+    cpu_set_t set; CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof set, &set) == 0) { int c = CPU_COUNT(&set); if (c > 0 && c < n) n = c; }
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[64]; long per = 0;
+        if (fscanf(f, "%63s %ld", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) { long c = atol(q) / per; if (c >= 1 && c < n) n = (int)c; }
+        fclose(f);
+    }
+    return n;
+}
 // ---------------------------------------------------------------- small host thread pool
 // The per-round host tails (one Horner chain + transcript per chunk) are independent across chunks.
 class HostPool {
     std::vector<std::thread> workers; std::mutex mu; std::condition_variable cv;
-    std::function<void(size_t)> fn; std::atomic<size_t> count{0}, next{0}, done{0}; std::atomic<int> active{0}; uint64_t gen = 0; bool stop = false;
+    std::function<void(size_t)> fn; std::atomic<size_t> count{0}, next{0}, done{0}; std::atomic<int> active{0}; std::atomic<uint64_t> gen{0}; bool stop = false;
+    double spin_us = 150.0;      // ROFL_POOL_SPIN_US: how long an idle worker polls for the next job before it sleeps
     // An index is claimed only after it has been checked against `count` (compare-and-swap, not fetch-add): a worker that wakes
     // late and arrives while run() is resetting the job (count == 0 in that window) must not consume an index of the next job --
     // with a blind fetch-add it could take index 0 between `next = 0` and `count = n` and drop it, and run() would wait forever.
@@ -139,15 +153,28 @@ class HostPool {
         }
         active.fetch_sub(1);
     }
+    // A worker that has just finished a job polls for the next one for a short while before it sleeps: the hops of a proof follow each
+    // other at 0.1-0.3 ms, and a sleeping thread has to be put back on a CPU by the scheduler first -- on a busy host (the GPU boxes run
+    // at a load average above 20) that wake-up is where multi-millisecond outliers of a 25 ms proof came from.
     void loop() {
         uint64_t seen = 0;
         for (;;) {
-            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return stop || gen != seen; }); if (stop) return; seen = gen; }
+            if (spin_us > 0) {
+                auto t0 = std::chrono::steady_clock::now();
+                while (gen.load(std::memory_order_acquire) == seen) {
+                    __builtin_ia32_pause();
+                    if (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > spin_us) break;
+                }
+            }
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return stop || gen.load() != seen; }); if (stop) return; seen = gen.load(); }
             work();
         }
     }
 public:
-    explicit HostPool(int nthreads) { for (int i = 1; i < nthreads; i++) workers.emplace_back([this] { loop(); }); }
+    explicit HostPool(int nthreads) {
+        if (const char *e = getenv("ROFL_POOL_SPIN_US")) spin_us = atof(e);
+        for (int i = 1; i < nthreads; i++) workers.emplace_back([this] { loop(); });
+    }
     ~HostPool() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); for (auto &t : workers) t.join(); }
     void run(size_t n, std::function<void(size_t)> f) {
         if (n <= 1 || workers.empty()) { for (size_t i = 0; i < n; i++) f(i); return; }
@@ -340,7 +367,13 @@ struct Ctx {
         if (const char *e = getenv("ROFL_FOLD_MIN")) { long v = atol(e); if (v >= 1) fold_min = (size_t)v; }
         if (const char *e = getenv("ROFL_MSM_DEV_HORNER_MIN")) { long v = atol(e); if (v >= 1) msm_dev_horner_min = (size_t)v; }
         if (const char *e = getenv("ROFL_MSM_SMALL_MAX")) { long v = atol(e); if (v >= 0) msm_small_max = (size_t)v; }
-        { int nt = 8; if (const char *e = getenv("ROFL_HOST_THREADS")) nt = atoi(e); unsigned hc = std::thread::hardware_concurrency(); if (hc && (unsigned)nt > hc) nt = (int)hc; if (nt < 1) nt = 1; pool.reset(new HostPool(nt)); }
+        {   // host pool of the primary lane: the per-round tails of many chunks (n_partition = 64: 128 window combinations, 128 encodings,
+            // 64 transcripts per round) scale with it -- 8 -> 14 threads took 3 ms off a 35 ms proof.  Default: the cores this process may
+            // use (affinity mask capped by the cgroup CPU quota) minus two for the calling thread and the HIP runtime, within [2, 16].
+            int nt = std::min(16, std::max(2, usable_cores() - 2));
+            if (const char *e = getenv("ROFL_HOST_THREADS")) nt = atoi(e);
+            if (nt < 1) nt = 1; if (nt > 64) nt = 64;
+            pool.reset(new HostPool(nt)); }
         if (const char *e = getenv("ROFL_FOLD_T1")) { int v = atoi(e); if (v >= 1 && v <= 6) fold_t1 = v; }
         if (const char *e = getenv("ROFL_FOLD_TAB")) fold_tab = atoi(e) != 0;
         if (const char *e = getenv("ROFL_GENS_BUDGET_MB")) { long v = atol(e); if (v >= 1) gens_budget = (size_t)v << 20; }
@@ -428,7 +461,11 @@ MsmPlan msm_plan_c(u32 c) {
 u32 fb_window_c(size_t gens) {
     static const int force = getenv("ROFL_MSM_FB_C") ? atoi(getenv("ROFL_MSM_FB_C")) : 0;      // tuning: 13 or 16 for every table
     if (force == 13 || force == 16) return (u32)force;
-    return gens >= ((size_t)1 << 17) ? 16u : 13u;
+    // Small generator sets (many small chunks: n_partition = 64 gives 128 L / R problems of 16 384 terms per round) spread 8 entries
+    // per bucket over 4 M buckets at c = 16 and the bucket REDUCTION (0.85 ms per round) rivals the accumulation: 15-bit windows halve
+    // the buckets for one more window (17 slices).  (13-bit windows were measured too: their 4 096-bucket arrays fall off the two-level
+    // sort and the narrow windows unbalance the lists -- 3.5 ms per round against 3.0.)
+    return gens >= ((size_t)1 << 17) ? 16u : 15u;
 }
 // Generator-table cache, shared by the lanes of a device.  An entry is pinned (users > 0) for the duration of every call that
 // reads it; eviction (LRU, beyond gens_budget, or to make room after a failed hipMalloc) only ever frees unpinned entries, so it is
@@ -587,14 +624,15 @@ bool msm_plan_job(Ctx &C, MsmJob &J, const MsmOpt &opt, const MsmAllow &al, MsmM
         if (mm.fb_wps == 1) cap *= 2;
         J.cap = cap;
         // two-level bucket sort (coarse bins through HBM in full lines, then per-bin ranking in LDS)
-        bool two = al.two && C.msm_two_level && J.P.W * opt.fb_stride <= ((size_t)1 << 24) && J.P.B == 32768;
-        tl = Msm2L{256, 7, 24, 0, 144};
+        bool two = al.two && C.msm_two_level && J.P.W * opt.fb_stride <= ((size_t)1 << 24) && (J.P.B == 32768 || J.P.B == 16384);
+        const u32 fb0 = J.P.B == 32768 ? 7u : 6u;      // 256 coarse bins of 128 (64) buckets
+        tl = Msm2L{256, fb0, 24, 0, 144};
         if (two) {
             // a coarse bin has to fit one block's LDS in level 2: 256 bins of 128 buckets while that holds (<= 4 windows per array at
             // 2^19 terms), 512 bins of 64 buckets with half the staging row for arrays that take 8 windows (two sets per problem)
             auto size_bins = [&]() { size_t avg = per_side * mm.fb_wps / tl.nbins; tl.cap_bin = (u32)((2 * avg + 256 + 63) / 64 * 64); return (size_t)tl.cap_bin * 4 + 1024 <= 96 * 1024; };
             bool fits = size_bins();
-            if (!fits) { tl = Msm2L{512, 6, 24, 0, 72}; fits = size_bins(); }
+            if (!fits) { tl = Msm2L{512, fb0 - 1, 24, 0, 72}; fits = size_bins(); }
             if (!fits || per_side < 8192) two = false;
         }
         J.two = two;
@@ -1111,8 +1149,10 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
             FoldProb *h_fp = C.h_fprob.as<FoldProb>(2 * P + 2 * P);
             FoldTabProb *h_ftp = reinterpret_cast<FoldTabProb *>(h_fp + 2 * P);
             niels *gnew = C.gbuf[gsel].as<niels>(P * 2 * n_new);
-            int top = 0;
-            for (size_t c = 0; c < P; c++) {
+            // (per chunk and independent: on the pool -- at n_partition = 64 this loop was 1.0-1.4 ms of one thread with the GPU idle, three times per proof)
+            std::vector<int> topc(P, 0);
+            C.pool->run(P, [&](size_t c) {
+                int top = 0;
                 sc yn = sc_one_mont();                       // y^-(h*n_new), stepping by y^-n_new
                 sc ystep = sc_one_mont();
                 { size_t e = n_new; int bidx = 0; while (e) { if (e & 1) ystep = sc_montmul(ystep, h_cp[c].yinvpow2[bidx]); e >>= 1; bidx++; } }
@@ -1150,7 +1190,9 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
                 h_fp[2 * c + 1] = FoldProb{cur[c] + n_g, gnew + c * 2 * n_new + n_new};
                 h_ftp[2 * c] = FoldTabProb{0u, gnew + c * 2 * n_new};
                 h_ftp[2 * c + 1] = FoldTabProb{(u32)n_g, gnew + c * 2 * n_new + n_new};
-            }
+                topc[c] = top;
+            });
+            int top = 0; for (int t : topc) top = std::max(top, t);
             C.tm.t.host_ms += now_ms() - th;
             int8_t *d_dig = C.naf.as<int8_t>(2 * P * nsrc * dstride);
             HIPCHK(hipMemcpyAsync(d_dig, h_dig, 2 * P * nsrc * dstride, hipMemcpyHostToDevice, C.stream));

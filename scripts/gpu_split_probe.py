@@ -16,10 +16,13 @@ vals = np.concatenate([vals, vals[:7768]]); bl = np.concatenate([bl, bl[:7768]])
 ex = ThreadPoolExecutor(max_workers=4)
 
 
+PT = int(sys.argv[1]) if len(sys.argv) > 1 else 4      # n_partition of the whole client
+
+
 def run(groups):
     per = 32768 // groups
     def one(g):
-        return rpv.create_rangeproof(vals[g * per:(g + 1) * per], bl[g * per:(g + 1) * per], 32, 4 // groups, nonce=R.Nonce.seeded(bytes([g + 1]) * 32), fp=FP)
+        return rpv.create_rangeproof(vals[g * per:(g + 1) * per], bl[g * per:(g + 1) * per], 32, PT // groups, nonce=R.Nonce.seeded(bytes([g + 1]) * 32), fp=FP)
     ts = []
     for rep in range(8):
         t0 = time.perf_counter()

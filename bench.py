@@ -46,6 +46,11 @@ def parse_args():
     ap.add_argument("--no-l2", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline only (profiling runs)")
     ap.add_argument("--clients-in-flight", type=int, default=0, help="C of the separate concurrent-clients figure (0 = 6, fewer when host cores are scarce)")
+    ap.add_argument("--config", type=int, default=2, choices=(2, 4, 5),
+                    help="BASELINE.json config: 2 = the headline (1 client, L-inf 32-bit, d = 25 000); 4 = 48 clients, L-inf 32-bit, d = 55 000, sharded over the ranks, "
+                         "batch create -> all-gather -> every rank batch-verifies another rank's share; 5 = the same with the L2 composite (EncParamsL2)")
+    ap.add_argument("--n-partition", type=int, default=NPART, help="n_partition of configs 4 / 5 (reference bench: 4; its e2e experiments: 64)")
+    ap.add_argument("--clients", type=int, default=48, help="clients of configs 4 / 5 (cifar_large.yml: 48)")
     return ap.parse_args()
 
 
@@ -100,10 +105,12 @@ def synth_client(client):
     return vals, bl
 
 
-def cpu_baseline(sample_d):
+def cpu_baseline(sample_d, R=None):
     """CPU path timed on this box's host cores.  Preferred: the reference itself (cargo bench); it needs cargo, the reference
     checkout and its crates -- none of which exist on the GPU boxes -- so the probe result is recorded and the oracle (the plain-C
-    restatement, kind "port", one thread per chunk like the reference's rayon par_iter) is timed instead."""
+    restatement, kind "port", one thread per chunk like the reference's rayon par_iter) is timed instead.  The bytes the oracle
+    produced are then compared with what the HIP path returns for the same (values, blindings, nonce seed): whole-proof parity
+    on the headline workload in every run (`parity_checked`)."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     probe = {"cargo": shutil.which("cargo") or "absent", "reference_checkout": os.path.isdir("/root/reference/rofl_crypto"),
@@ -118,7 +125,15 @@ def cpu_baseline(sample_d):
     rc2, ok = orc.verify_rangeproof(pr, cm, NBITS, FP_BITS, FP_FRAC)
     dt = time.time() - t
     assert rc == 0 and rc2 == 0 and ok
-    return {"value": sample_d / dt, "unit": "elements/s", "cores": NPART, "kind": "port",
+    parity = None
+    if R is not None:      # the product on the same inputs: every proof byte and every commitment must equal the oracle's
+        gpr, gcm = R.range_proof_vec.create_rangeproof(vals, bl, NBITS, NPART, nonce=R.Nonce.seeded(b"\x01" * 32), fp=FP)
+        parity = bool(gpr.shape == pr.shape and (gpr == pr).all() and (gcm == cm).all())
+        assert parity, "HIP proofs / commitments differ from the oracle on the benchmark workload"
+        assert R.range_proof_vec.verify_rangeproof(pr, cm, NBITS, verifier_seed=b"\x07" * 32, fp=FP)      # the oracle's proof through the HIP verifier
+    return {"value": sample_d / dt, "unit": "elements/s", "cores": NPART, "kind": "port", "parity_checked": parity,
+            "parity_note": "HIP create_rangeproof on the same (values, blindings, nonce seed): all %d proofs (%d bytes each) and %d commitments bit-identical to the oracle's; "
+                           "the oracle's proofs accepted by the HIP verifier" % (pr.shape[0], pr.shape[1], cm.shape[0]) if parity else None,
             "sample": f"oracle (plain-C restatement) create+verify of d={sample_d} of the workload's {D} elements, 32-bit, P={NPART}: "
                       f"create {t1 - t:.1f} s + verify {dt - (t1 - t):.1f} s on {NPART} host threads (one per chunk, as the reference's rayon par_iter)",
             "reference_probe": probe}
@@ -160,6 +175,129 @@ def avail_cores():
     except Exception:      # noqa: BLE001
         pass
     return n
+
+
+# ---------------------------------------------------------------------------------------------------------------- configs 4 / 5
+D_MULTI = 55000      # resnet18_intrinsic_55k (BASELINE.json configs[3], configs[4])
+
+
+def synth_multi(cfg, client, step):
+    """Client `client` of step `step` (seed 1000 * client + step): cfg 4 -- values ~ U[fp_min, fp_max) as in
+    benches/rangeproof_bench.rs:41-50; cfg 5 -- values on the quantisation grid with a small L2 norm (benches/l2rangeproof_bench.rs:43-48
+    draws inside the l2 bound the same way), a second randomness vector for the square commitments."""
+    import numpy as np
+    rng = np.random.default_rng(1000 * client + step)
+    if cfg == 4:
+        mx = np.float32(16777216.0)
+        vals = np.clip(rng.uniform(-mx, mx, size=D_MULTI).astype(np.float32), -mx, np.nextafter(mx, np.float32(0)))
+    else:
+        vals = (rng.integers(-3, 4, size=D_MULTI) / 128.0).astype(np.float32)
+    r1 = rng.integers(0, 256, size=(D_MULTI, 32), dtype=np.uint8); r1[:, 31] &= 0x0F
+    r2 = None
+    if cfg == 5:
+        r2 = rng.integers(0, 256, size=(D_MULTI, 32), dtype=np.uint8); r2[:, 31] &= 0x0F
+    return vals, r1, r2
+
+
+def run_multi_client(args, R, rd, dist, cdev, world, rank, backend):
+    """BASELINE configs 4 / 5: `--clients` (48) seeded clients of d = 55 000 sharded round-robin over the ranks (dist.shard_clients;
+    the server hands one client per pool task, server.rs:656-687).  One step = one round of the protocol:
+      every rank creates the proofs of ITS clients (cfg 4: rofl_create_rangeproof_batch in groups of 6; cfg 5: EncParamsL2.encrypt +
+      serialize, params.rs:608-663) -> ONE all-gather of [proof bytes | commitments] (cfg 5: the wire messages) -> every rank verifies
+      the share of ANOTHER rank (rank + 1; cfg 4: rofl_verify_rangeproof_batch, cfg 5: deserialize + verify) -> MIN all-reduce of the
+      verdicts (one failing client fails the round, server.rs:474-484).
+    value = clients * d * K / wall time: the total work is fixed, so N > 1 is STRONG scaling."""
+    import numpy as np
+    import torch
+    from rofl_project_code_amd import params
+    cfg, NC, P = args.config, args.clients, args.n_partition
+    assert NC % world == 0, "--clients must be a multiple of the number of ranks (equal payloads per rank)"
+    rpv = R.range_proof_vec
+    mine = rd.shard_clients(NC, rank, world)
+    src = (rank + 1) % world
+    group = 6
+    total_steps = args.warmup + args.steps
+    phase = {"create": 0.0, "exchange": 0.0, "verify": 0.0, "payload": 0}
+
+    def step(s, record):
+        t0 = time.perf_counter()
+        ins = [synth_multi(cfg, c, s) for c in mine]
+        t_in = time.perf_counter()
+        if cfg == 4:
+            prs, cms = [], []
+            for g0 in range(0, len(mine), group):
+                g = list(range(g0, min(g0 + group, len(mine))))
+                res = rpv.create_rangeproof_batch([ins[k][0] for k in g], [ins[k][1] for k in g], NBITS, P,
+                                                  nonces=[R.Nonce.seeded(bytes([(mine[k] + 1) % 256]) * 32) for k in g], fp=FP)
+                for r_ in res:
+                    assert not isinstance(r_, Exception), r_
+                    prs.append(r_[0]); cms.append(r_[1])
+            payloads = [np.stack(prs), np.stack(cms)]
+        else:
+            blobs = []
+            for k, c in enumerate(mine):
+                upd = params.EncParamsL2.encrypt(ins[k][0], ins[k][1], 8, P, 32, nonce_seed=bytes([(c + 1) % 256]) * 32, rand_scalars=ins[k][2], fp=FP)
+                blobs.append(np.frombuffer(upd.serialize(), dtype=np.uint8))
+            assert len({b.size for b in blobs}) == 1
+            payloads = [np.stack(blobs)]
+        t1 = time.perf_counter()
+        phase["payload"] = sum(int(x.size) for x in payloads)
+        _, per_rank = rd.exchange_round(payloads, True, cdev)      # every rank's proofs and commitments (wire messages) to every rank
+        t2 = time.perf_counter()
+        theirs = per_rank[src]
+        n_their = len(rd.shard_clients(NC, src, world))
+        if cfg == 4:
+            pp = theirs[0].reshape((n_their,) + payloads[0].shape[1:]); cc = theirs[1].reshape((n_their,) + payloads[1].shape[1:])
+            oks = []
+            for g0 in range(0, n_their, group):
+                oks += rpv.verify_rangeproof_batch([pp[k] for k in range(g0, min(g0 + group, n_their))], [cc[k] for k in range(g0, min(g0 + group, n_their))],
+                                                   NBITS, verifier_seed=bytes([s % 256]) * 32, fp=FP)
+            ok = all(oks)
+        else:
+            bb = theirs[0].reshape(n_their, -1)
+            ok = all(params.EncParamsL2.deserialize(bytes(bb[k])).verify(verifier_seed=bytes([s % 256]) * 32, fp=FP) for k in range(n_their))
+        ok = rd.all_verified(ok, cdev)
+        t3 = time.perf_counter()
+        assert ok, "a client's proofs failed to verify"
+        if record:
+            phase["create"] += t1 - t_in; phase["exchange"] += t2 - t1; phase["verify"] += t3 - t2
+        return t_in - t0
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier(); torch.cuda.synchronize()
+
+    for s in range(args.warmup):
+        step(s, False)
+    sync()
+    gen_s = 0.0
+    t0 = time.perf_counter()
+    for s in range(args.warmup, total_steps):
+        gen_s += step(s, True)
+    sync()
+    elapsed = time.perf_counter() - t0 - gen_s      # drawing the synthetic inputs (numpy RNG on the host) is not part of the path
+    rccl_world = 1
+    if world > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=cdev); dist.all_reduce(te, op=dist.ReduceOp.MAX); elapsed = float(te.item())
+        ones = torch.ones(1, dtype=torch.int32, device=cdev); dist.all_reduce(ones); rccl_world = int(ones.item())
+        assert rccl_world == world
+    if rank == 0:
+        K = args.steps
+        kind = "L-inf 32-bit range proofs" if cfg == 4 else "L2 composite (EncParamsL2: 8-bit range proof + L2 sum proof + square proofs)"
+        out = {"metric": "range-proof elements/sec (create+verify), %d clients d=55k" % NC, "value": NC * D_MULTI * K / elapsed, "unit": "elements/s",
+               "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "strong",
+               "vs_baseline": None, "dtype": "u32x8 (255-bit integer field)", "data": "synthetic", "rccl_world_size": rccl_world,
+               "collective_backend": backend if world > 1 else None,
+               "config": {"workload": "BASELINE cfg %d: %s, d=55000 (resnet18_intrinsic_55k), %d clients sharded over %d rank(s): batch create -> one all-gather of "
+                                      "proof bytes + commitments -> every rank batch-verifies the share of rank+1 -> MIN all-reduce of the verdicts" % (cfg, kind, NC, world),
+                          "d": D_MULTI, "clients": NC, "clients_per_rank": len(mine), "prove_range": NBITS if cfg == 4 else 8, "l2_range": None if cfg == 4 else 32,
+                          "n_partition": P, "fp_bits": FP_BITS, "fp_frac": FP_FRAC, "host_cores": avail_cores()},
+               "breakdown_ms_per_step_rank0": {k: phase[k] / K * 1e3 for k in ("create", "exchange", "verify")},
+               "all_gather_bytes_per_rank": int(phase["payload"])}
+        print(json.dumps(out)); sys.stdout.flush()
+    if world > 1:
+        dist.barrier(); dist.destroy_process_group()
 
 
 # ---------------------------------------------------------------------------------------------------------------- one rank
@@ -205,6 +343,8 @@ def run_rank(args):
         # a lone call spins while it waits for the GPU (lowest latency, ~2 host cores per rank with its pool threads); when the ranks of a
         # node share fewer cores than that, wait by sleeping instead (+1 ms per client, ~0.9 cores per rank)
         os.environ.setdefault("ROFL_BLOCKING_SYNC", "1")
+    if local_world > 1:      # the library sizes its host pool from the cores of the process; ranks of one node share them
+        os.environ.setdefault("ROFL_HOST_THREADS", str(max(2, min(14, int(avail_cores() / local_world) - 1))))
     if extras:
         os.environ.setdefault("ROFL_LANES", str(max(3, CIF)))
         # one hardware queue per lane: the HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES (default 4) queues, read
@@ -239,6 +379,8 @@ def run_rank(args):
     R.set_device(local_rank)
     R.set_timing(os.environ.get("ROFL_BENCH_NOTIMING") != "1")      # HIP events around the kernels of the timed steps (per-kernel table)
     rpv = R.range_proof_vec
+    if args.config != 2:
+        return run_multi_client(args, R, rd, dist, cdev, world, rank, backend)
 
     total_steps = args.warmup + args.steps
     clients = [synth_client(1000 * (s * world + rank)) for s in range(total_steps)]
@@ -331,7 +473,8 @@ def run_rank(args):
         "breakdown_ms_per_client": {"create": agg["create_ms"] / K, "verify": agg["verify_ms"] / K, "device_span": agg["device_ms"] / K, "host": agg["host_ms"] / K},
         "end_to_end_algorithmic_GBps": value * (ALG_BYTES_CREATE + ALG_BYTES_VERIFY) / 1e9,
         "cold": {"gens_tables_build_ms": gens_build_ms, "first_client_create_plus_verify_ms": first_client_ms,
-                 "note": "generator + fold + window tables for (n=32, m=8192), built once per process and cached in HBM; the reference recomputes its generators in every call"},
+                 "tables_bytes": api.bp_gens_table_bytes(NBITS, rpv.next_pow2(D) // NPART),
+                 "note": "generator + fold + window tables for (n=32, m=8192), built once per process and cached in HBM (tables_bytes); the reference recomputes its generators in every call"},
     }
 
     # ---- per-kernel table over the timed steps (HIP events on the library's stream) and the roofline of the dominant kernel
@@ -354,9 +497,11 @@ def run_rank(args):
     dom = table[0] if table else None
     traffic = None
     if dom:
-        try:      # HBM bytes per launch from the committed rocprofv3 PMC passes of this command (profiles/*_pmc_traffic.json; reads x2 per the gfx950 note)
+        pmc_src = None
+        try:      # HBM bytes per launch from the committed rocprofv3 PMC passes of this command (profiles/*_pmc_traffic.json)
             import glob
             pj = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))[-1]
+            pmc_src = os.path.basename(pj)
             key = dom["kernel"].split("+")[0].replace("k_msm_reduce_level", "k_msm_reduce")
             ents = [v for k, v in json.load(open(pj)).items() if ("rofl::" + key) in k]
             nl = sum(e["launches"] for e in ents)
@@ -365,14 +510,36 @@ def run_rank(args):
         except Exception:      # noqa: BLE001
             traffic = None
         e = ktot[dom["kernel"]]
+        launch_s = dom["avg_launch_ms"] * 1e-3
+        # physical minimum of the layout for the fixed-base accumulation: every (term, window) pair gathers one 128-byte table record
+        # (the window table trades 16 gathers of a precomputed multiple for all doublings between windows) and reads one 4-byte list entry;
+        # every bucket is written once (128 B)
+        adds_per_launch = (e["fe_muls"] / 7.0) / e["launches"] if e["launches"] else 0.0
+        layout_min = adds_per_launch * (128 + 4) if dom["kernel"].startswith("k_msm_accumulate_fb") else None
         out["roofline"] = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["algorithmic_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                            "frac": dom["hbm_frac"], "traffic": traffic, "avg_launch_ms": dom["avg_launch_ms"],
                            "algorithmic_bytes_per_launch": e["bytes"] / e["launches"],
-                           "note": "255-bit modular integer path: VALU-issue bound, the HBM fraction is small by construction (SURVEY 8(d)); launch time from HIP events on the "
-                                   "library's stream over the timed steps (one client at a time: nothing else on the GPU).  traffic >> algorithmic bytes is not re-reading: a "
-                                   "fixed-base term is gathered once from each of 16 precomputed 128-byte window slices.  The binding figure is fe_mul_frac_of_peak in `kernels`."}
+                           "traffic_GBps": (traffic / launch_s / 1e9) if traffic else None,
+                           "traffic_frac": (traffic / launch_s / 1e9 / HBM_PEAK_GBPS) if traffic else None,
+                           "layout_min_bytes_per_launch": layout_min,
+                           "layout_min_frac": (layout_min / launch_s / 1e9 / HBM_PEAK_GBPS) if layout_min else None,
+                           "pmc_source": pmc_src,
+                           "counter_correction": "FETCH_SIZE and WRITE_SIZE in KiB from separate rocprofv3 --pmc passes; traffic = 2 x FETCH_SIZE + WRITE_SIZE "
+                                                 "(the gfx950 read counter reports half of the fetched bytes, MI355X_MICROARCH.md), per launch, averaged over the launches of the command",
+                           "note": "Two memory figures: `frac` prices the ALGORITHMIC bytes (32 B per scalar or point touched, SURVEY 8(d)); `traffic_frac` is what the "
+                                   "kernel really pulls from HBM per the PMC passes and `layout_min_frac` the least this table layout can move (one 128-byte window-table "
+                                   "record per (term, window) pair).  The accumulation is co-bound: random 128-byte gathers at traffic_frac of the HBM peak and the "
+                                   "field-multiplication issue rate at valu_roofline.frac of its measured ceiling.  Launch time from HIP events on the library's stream "
+                                   "over the timed steps (one client at a time: nothing else on the GPU)."}
+        # end-to-end VALU utilisation: the algorithmic field multiplications of ALL instrumented kernels of the timed steps against the
+        # measured multiplication ceiling over the WALL time of those steps (gaps between kernels and host hops included)
+        all_muls = sum(v["fe_muls"] for v in ktot.values())
         out["valu_roofline"] = {"fe_mul_per_s_peak_measured": peak_mul, "kernel": dom["kernel"], "achieved_fe_mul_per_s": dom["achieved_fe_mul_per_s"],
-                                "frac": dom["fe_mul_frac_of_peak"]}
+                                "frac": dom["fe_mul_frac_of_peak"],
+                                "end_to_end_fe_muls_per_step": all_muls / K,
+                                "end_to_end_frac": (all_muls / elapsed / peak_mul) if peak_mul else None,
+                                "note": "frac: the dominant kernel against the multiplication-only micro-benchmark run in this process; end_to_end_frac: algorithmic "
+                                        "field multiplications of all kernels / (ceiling x wall time of the timed steps)"}
 
     if extras:
         # (a) the same steps with the inputs already resident in HBM (device pointers at the C ABI)
@@ -431,8 +598,8 @@ def run_rank(args):
         if not args.no_l2:
             out["l2_composite"] = l2_composite(R)
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample)
-    out["other_configs"] = "profiles/r02_configs.json (scripts/gpu_configs.py): all five BASELINE configs and the e2e partition count P=64, reference bench protocol"
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, R)
+    out["other_configs"] = "bench.py --config 4 | 5 (48 clients sharded over the ranks); profiles/r03_configs.json (scripts/gpu_configs.py): all five BASELINE configs and the e2e partition count P=64, reference bench protocol"
     print(json.dumps(out))
     sys.stdout.flush()
     if world > 1:

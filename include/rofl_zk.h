@@ -56,6 +56,8 @@ int rofl_last_error(char *buf, size_t len);            /* human-readable text of
 /* BulletproofGens::new(n_bits, m) (generators.rs; re-run by the reference on every helper call,
  * range_proof_vec/mod.rs:126,201) -- built once on the device and cached per (n_bits, m). */
 int rofl_bp_gens_prepare(size_t n_bits, size_t m);
+/* HBM held by the cached tables of (n_bits, m): generators + fold slices + window slices; 0 if they have not been built */
+int rofl_bp_gens_table_bytes(size_t n_bits, size_t m, size_t *bytes_out);
 /* copy the cached generators back, compressed, party-major: G_out/H_out n_bits*m*32 bytes each */
 int rofl_bp_gens_export(size_t n_bits, size_t m, uint8_t *G_out, uint8_t *H_out);
 

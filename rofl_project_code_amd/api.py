@@ -132,6 +132,13 @@ def set_device(dev):
     _check(lib().rofl_set_device(int(dev)))
 
 
+def bp_gens_table_bytes(n_bits, m):
+    """HBM bytes of the cached tables of (n_bits, m) (0 if not built)."""
+    out = _sz()
+    _check(lib().rofl_bp_gens_table_bytes(_sz(n_bits), _sz(m), ctypes.byref(out)))
+    return out.value
+
+
 def bp_gens_prepare(n_bits, m):
     """Build (or touch) the cached BulletproofGens::new(n, m) tables on the device -- the reference recomputes them in every
     create / verify call (range_proof_vec/mod.rs:126,201)."""

@@ -290,7 +290,7 @@ struct Ctx {
     // a server that keeps several clients in flight does not burn one host core per client on busy-waiting (ROFL_BLOCKING_SYNC=0: always spin).
     // behaviour options (rofl_set_option; primary lane only -- the lanes read their parent's): the environment only provides defaults
     int opt_zip_truncate = 0, opt_verify_batch = 1, opt_sigma_batch = 1;
-    int blocking_sync = -1; hipEvent_t ev_block = nullptr, ev_v = nullptr, ev_fork = nullptr, ev_a = nullptr, ev_a0 = nullptr; bool batch_mode = false;
+    int blocking_sync = -1; hipEvent_t ev_block = nullptr, ev_v = nullptr, ev_fork = nullptr, ev_a = nullptr, ev_a0 = nullptr, ev_m2 = nullptr, ev_m2j = nullptr; bool batch_mode = false;
     void sync() {
         const Ctx *P = parent ? parent : this;
         // (up to three calls in flight still spin: the three proofs of ONE client's L2 update run side by side -- EncParamsL2::encrypt --
@@ -657,7 +657,8 @@ bool msm_plan_job(Ctx &C, MsmJob &J, const MsmOpt &opt, const MsmAllow &al, MsmM
 }
 
 // ---- sort + accumulate + reduce of one attempt, enqueued on the lane's stream (no synchronisation)
-MsmJob msm_enqueue(Ctx &C, MsmWs &W, const std::vector<MsmProb> &probs, size_t n, const MsmOpt &opt, MsmAllow &al) {
+MsmJob msm_enqueue(Ctx &C, MsmWs &W, const std::vector<MsmProb> &probs, size_t n, const MsmOpt &opt, MsmAllow &al, hipStream_t st = nullptr) {
+    if (!st) st = C.stream;
     static const u32 acc_balance = getenv("ROFL_ACC_BALANCE") ? (atoi(getenv("ROFL_ACC_BALANCE")) ? 1u : 0u) : 1u;   // equal-work blocks in k_msm_accumulate (0 = plain descending order)
     static const u32 dbg_mask = getenv("ROFL_DBG_IDX_MASK") ? (u32)strtoul(getenv("ROFL_DBG_IDX_MASK"), nullptr, 0) : 0x7fffffffu;   // timing experiments only (wrong results): gathers confined to a cache-resident prefix
     static const u32 dbg_scatter = getenv("ROFL_DBG_SCATTER") ? (u32)atoi(getenv("ROFL_DBG_SCATTER")) : 0u;   // timing experiments only: 1 = no range reservation, 2 = no slot stores
@@ -672,7 +673,7 @@ MsmJob msm_enqueue(Ctx &C, MsmWs &W, const std::vector<MsmProb> &probs, size_t n
     MsmProb *h_probs = W.h_probs.as<MsmProb>(np);
     for (size_t i = 0; i < np; i++) h_probs[i] = fb ? MsmProb{opt.fb_wtab, probs[i].scal} : probs[i];
     if (W.probs_on_dev.size() != np || memcmp(W.probs_on_dev.data(), h_probs, sizeof(MsmProb) * np) != 0) {      // an unchanged problem list (constant within a fold level) is not uploaded again
-        HIPCHK(hipMemcpyAsync(d_probs, h_probs, sizeof(MsmProb) * np, hipMemcpyHostToDevice, C.stream));
+        HIPCHK(hipMemcpyAsync(d_probs, h_probs, sizeof(MsmProb) * np, hipMemcpyHostToDevice, st));
         W.probs_on_dev.assign(h_probs, h_probs + np);
     }
     u32 *cnt = W.cnt.as<u32>(PW * P.B + 4), *off = W.off.as<u32>(PW * P.B), *cur = W.cur.as<u32>(PW * P.B);
@@ -695,10 +696,10 @@ MsmJob msm_enqueue(Ctx &C, MsmWs &W, const std::vector<MsmProb> &probs, size_t n
         size_t lds_lists = (size_t)P.B * 4 * (1 + small_cap);
         size_t lds_red = std::max(((size_t)(P.B / 8) * 4 + (size_t)(P.B / 16) * 5 + 1) * sizeof(ge), ((size_t)P.B + (size_t)P.B * 3 / 4 + 1) * sizeof(ge));      // fused / binary reduction trees
         uint64_t items = (uint64_t)np * n_side * P.W;
-        KSpan ks(C.tm, C.stream, ROFL_TK_MSM_SMALL, items * 7 + (uint64_t)PW * P.B * 10, (uint64_t)np * n_side * (32 + 96));
-        hipLaunchKernelGGL(k_msm_small, dim3((unsigned)PW), dim3(P.B < 64 ? 64 : P.B), std::max(lds_lists, lds_red), C.stream, n_side, mw, mm, d_probs, buckets,
+        KSpan ks(C.tm, st, ROFL_TK_MSM_SMALL, items * 7 + (uint64_t)PW * P.B * 10, (uint64_t)np * n_side * (32 + 96));
+        hipLaunchKernelGGL(k_msm_small, dim3((unsigned)PW), dim3(P.B < 64 ? 64 : P.B), std::max(lds_lists, lds_red), st, n_side, mw, mm, d_probs, buckets,
                            S_fin_s, C_fin_s, nb_final, d_flag, small_cap);
-        if (J.dev_horner) hipLaunchKernelGGL(k_msm_horner, dim3((unsigned)np), dim3(256), 0, C.stream, mw, (const ge *)S_fin_s, (const ge *)C_fin_s, nb_final, hres_dev);
+        if (J.dev_horner) hipLaunchKernelGGL(k_msm_horner, dim3((unsigned)np), dim3(256), 0, st, mw, (const ge *)S_fin_s, (const ge *)C_fin_s, nb_final, hres_dev);
         return J;
     }
     // ---- SORT (+ ACCUMULATE: its list format depends on the sort)
@@ -707,34 +708,34 @@ MsmJob msm_enqueue(Ctx &C, MsmWs &W, const std::vector<MsmProb> &probs, size_t n
         u32 *bins = W.sorted.as<u32>(PW * tl.nbins * tl.cap_bin);
         u32 *bcur = W.cur.as<u32>(PW * tl.nbins * 2);
         u32 *btail = W.tail.as<u32>(PW * tl.nbins * (size_t)MSM_BIN_TAIL);
-        HIPCHK(hipMemsetAsync(bcur, 0, sizeof(u32) * PW * tl.nbins * 2, C.stream));
+        HIPCHK(hipMemsetAsync(bcur, 0, sizeof(u32) * PW * tl.nbins * 2, st));
         u32 iter_pts = (tl.stage >= 144 ? 16384u : 12288u) / mm.fb_wps; if (iter_pts < 1024) iter_pts = 1024;      // ~ 64 (48) new items per bin and iteration against a row of 144 (72)
         u32 tile = iter_pts;
         while (((size_t)((n_side + tile - 1) / tile) * PW > 512 || (n_side + tile - 1) / tile > 48) && tile < n_side) tile *= 2;      // <= 48 tiles per array: their left-overs (< 32 each) fit the bin tails with room for row spills
         dim3 grid((n_side + tile - 1) / tile, (u32)PW);
-        { KSpan ks(C.tm, C.stream, ROFL_TK_MSM_SCATTER, 0, terms * 32 + terms * P.W * 4);
-          hipLaunchKernelGGL(k_msm_bin_l1, grid, dim3(1024), (size_t)(tl.nbins + tl.nbins * tl.stage) * 4, C.stream, n_side, tile, iter_pts, mw, mm, d_probs, bcur, bins, btail, tl, d_flag);
-          hipLaunchKernelGGL(k_msm_bin_l2, dim3(tl.nbins, (u32)PW), dim3(512), (size_t)(2 * 128 + tl.cap_bin) * 4, C.stream, tl, P.B, bcur, bins, (const u32 *)btail, cnt, off, d_flag); }
-        hipLaunchKernelGGL(k_msm_scan, dim3((unsigned)PW), dim3(TPB), 0, C.stream, P.B, cnt, off, (u32 *)nullptr, perm);
-        if (C.tm.enabled) { e0 = C.tm.get(); e1 = C.tm.get(); HIPCHK(hipEventRecord(e0, C.stream)); }
+        { KSpan ks(C.tm, st, ROFL_TK_MSM_SCATTER, 0, terms * 32 + terms * P.W * 4);
+          hipLaunchKernelGGL(k_msm_bin_l1, grid, dim3(1024), (size_t)(tl.nbins + tl.nbins * tl.stage) * 4, st, n_side, tile, iter_pts, mw, mm, d_probs, bcur, bins, btail, tl, d_flag);
+          hipLaunchKernelGGL(k_msm_bin_l2, dim3(tl.nbins, (u32)PW), dim3(512), (size_t)(2 * 128 + tl.cap_bin) * 4, st, tl, P.B, bcur, bins, (const u32 *)btail, cnt, off, d_flag); }
+        hipLaunchKernelGGL(k_msm_scan, dim3((unsigned)PW), dim3(TPB), 0, st, P.B, cnt, off, (u32 *)nullptr, perm);
+        if (C.tm.enabled) { e0 = C.tm.get(); e1 = C.tm.get(); HIPCHK(hipEventRecord(e0, st)); }
         {
-            KSpan ks_acc(C.tm, C.stream, ROFL_TK_MSM_ACCUMULATE_FB, terms * P.W * 7, terms * 32);
+            KSpan ks_acc(C.tm, st, ROFL_TK_MSM_ACCUMULATE_FB, terms * P.W * 7, terms * 32);
             static const char *timeline = getenv("ROFL_DBG_ACC_TIMELINE");      // debugging: per-wave start / end / placement of every launch, appended to this file
             if (timeline) {
                 dim3 g = grid1((size_t)Wb * P.B, (u32)nq);
                 size_t waves = (size_t)g.x * g.y * (TPB / 64);
-                unsigned long long *rec; HIPCHK(hipMalloc(&rec, waves * 32)); HIPCHK(hipMemsetAsync(rec, 0, waves * 32, C.stream));
-                hipLaunchKernelGGL(k_msm_accumulate_fb_dbg, g, dim3(TPB), 0, C.stream, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, bins, perm, buckets, MSM_LIST_ABS, dbg_mask, acc_balance, rec);
+                unsigned long long *rec; HIPCHK(hipMalloc(&rec, waves * 32)); HIPCHK(hipMemsetAsync(rec, 0, waves * 32, st));
+                hipLaunchKernelGGL(k_msm_accumulate_fb_dbg, g, dim3(TPB), 0, st, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, bins, perm, buckets, MSM_LIST_ABS, dbg_mask, acc_balance, rec);
                 std::vector<unsigned long long> h(waves * 4);
-                HIPCHK(hipMemcpyAsync(h.data(), rec, waves * 32, hipMemcpyDeviceToHost, C.stream)); HIPCHK(hipStreamSynchronize(C.stream));
+                HIPCHK(hipMemcpyAsync(h.data(), rec, waves * 32, hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st));
                 if (FILE *f = fopen(timeline, "ab")) { unsigned long long hdr[4] = {0x54494d45ull, waves, g.x, g.y}; fwrite(hdr, 8, 4, f); fwrite(h.data(), 8, h.size(), f); fclose(f); }
                 HIPCHK(hipFree(rec));
             } else
-            hipLaunchKernelGGL(k_msm_accumulate_fb, grid1((size_t)Wb * P.B, (u32)nq), dim3(TPB), 0, C.stream, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, bins, perm, buckets, MSM_LIST_ABS, dbg_mask, acc_balance);
+            hipLaunchKernelGGL(k_msm_accumulate_fb, grid1((size_t)Wb * P.B, (u32)nq), dim3(TPB), 0, st, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, bins, perm, buckets, MSM_LIST_ABS, dbg_mask, acc_balance);
         }
-        if (C.tm.enabled) HIPCHK(hipEventRecord(e1, C.stream));
+        if (C.tm.enabled) HIPCHK(hipEventRecord(e1, st));
     } else if (J.kind != MsmKind::CountSort) {      // slot sort (fixed-base or generic)
-        HIPCHK(hipMemsetAsync(cnt, 0, sizeof(u32) * (PW * P.B + 4), C.stream));
+        HIPCHK(hipMemsetAsync(cnt, 0, sizeof(u32) * (PW * P.B + 4), st));
         const u32 cap = J.cap;
         u32 *slots = W.sorted.as<u32>(PW * P.B * cap);
         MsmOvf *ovf = W.ovf.as<MsmOvf>(MSM_OVF_MAX);
@@ -747,30 +748,30 @@ MsmJob msm_enqueue(Ctx &C, MsmWs &W, const std::vector<MsmProb> &probs, size_t n
             while (tile > 1024 && ((size_t)tile * wps > (size_t)C.msm_lds_tile || (size_t)((n_side + tile - 1) / tile) * nq * (lr ? 2 : 1) * per_q < 256)) tile /= 2;
             dim3 grid((n_side + tile - 1) / tile, (u32)(nq * (lr ? 2 : 1) * per_q));
             uint64_t items = terms * P.W;
-            KSpan ks(C.tm, C.stream, ROFL_TK_MSM_SCATTER, 0, terms * 32 + items * 4);
-            hipLaunchKernelGGL(k_msm_scatter_lds, grid, dim3(1024), (size_t)P.B * 4, C.stream, n_side, tile, mw, mm, d_probs, cnt, slots, cap, ovf_count, ovf, MSM_OVF_MAX, dbg_scatter);
+            KSpan ks(C.tm, st, ROFL_TK_MSM_SCATTER, 0, terms * 32 + items * 4);
+            hipLaunchKernelGGL(k_msm_scatter_lds, grid, dim3(1024), (size_t)P.B * 4, st, n_side, tile, mw, mm, d_probs, cnt, slots, cap, ovf_count, ovf, MSM_OVF_MAX, dbg_scatter);
         } else
-            hipLaunchKernelGGL(k_msm_scatter_slots, grid1(n, (u32)(nq * P.W)), dim3(TPB), 0, C.stream, (u32)n, mw, mm, d_probs, cnt, slots, cap, ovf_count, ovf, MSM_OVF_MAX);
-        hipLaunchKernelGGL(k_msm_scan, dim3((unsigned)PW), dim3(TPB), 0, C.stream, P.B, cnt, off, (u32 *)nullptr, perm);
-        if (C.tm.enabled) { e0 = C.tm.get(); e1 = C.tm.get(); HIPCHK(hipEventRecord(e0, C.stream)); }
+            hipLaunchKernelGGL(k_msm_scatter_slots, grid1(n, (u32)(nq * P.W)), dim3(TPB), 0, st, (u32)n, mw, mm, d_probs, cnt, slots, cap, ovf_count, ovf, MSM_OVF_MAX);
+        hipLaunchKernelGGL(k_msm_scan, dim3((unsigned)PW), dim3(TPB), 0, st, P.B, cnt, off, (u32 *)nullptr, perm);
+        if (C.tm.enabled) { e0 = C.tm.get(); e1 = C.tm.get(); HIPCHK(hipEventRecord(e0, st)); }
         {
             uint64_t acc_adds = terms * P.W;
-            KSpan ks_acc(C.tm, C.stream, fb ? ROFL_TK_MSM_ACCUMULATE_FB : ROFL_TK_MSM_ACCUMULATE_GEN, acc_adds * 7, terms * 32);
-            if (fb) hipLaunchKernelGGL(k_msm_accumulate_fb, grid1((size_t)Wb * P.B, (u32)nq), dim3(TPB), 0, C.stream, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, slots, perm, buckets, cap, dbg_mask, acc_balance);
-            else hipLaunchKernelGGL(k_msm_accumulate_gen, grid1((size_t)Wb * P.B, (u32)nq), dim3(TPB), 0, C.stream, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, slots, perm, buckets, cap, dbg_mask, acc_balance);
+            KSpan ks_acc(C.tm, st, fb ? ROFL_TK_MSM_ACCUMULATE_FB : ROFL_TK_MSM_ACCUMULATE_GEN, acc_adds * 7, terms * 32);
+            if (fb) hipLaunchKernelGGL(k_msm_accumulate_fb, grid1((size_t)Wb * P.B, (u32)nq), dim3(TPB), 0, st, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, slots, perm, buckets, cap, dbg_mask, acc_balance);
+            else hipLaunchKernelGGL(k_msm_accumulate_gen, grid1((size_t)Wb * P.B, (u32)nq), dim3(TPB), 0, st, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, slots, perm, buckets, cap, dbg_mask, acc_balance);
         }
-        if (C.tm.enabled) HIPCHK(hipEventRecord(e1, C.stream));
-        hipLaunchKernelGGL(k_msm_overflow, dim3(1), dim3(64), 0, C.stream, Wb, P.B, (u32)(np / nq), d_probs, ovf_count, ovf, MSM_OVF_MAX, buckets, fb ? 1 : 0);
-        HIPCHK(hipMemcpyAsync(h_flag, ovf_count, 4, hipMemcpyDeviceToHost, C.stream));
+        if (C.tm.enabled) HIPCHK(hipEventRecord(e1, st));
+        hipLaunchKernelGGL(k_msm_overflow, dim3(1), dim3(64), 0, st, Wb, P.B, (u32)(np / nq), d_probs, ovf_count, ovf, MSM_OVF_MAX, buckets, fb ? 1 : 0);
+        HIPCHK(hipMemcpyAsync(h_flag, ovf_count, 4, hipMemcpyDeviceToHost, st));
     } else {      // count / scan / scatter: no fixed-size structure, always sufficient
-        HIPCHK(hipMemsetAsync(cnt, 0, sizeof(u32) * (PW * P.B + 4), C.stream));
+        HIPCHK(hipMemsetAsync(cnt, 0, sizeof(u32) * (PW * P.B + 4), st));
         u32 *sorted = W.sorted.as<u32>(PW * n * 2);
-        hipLaunchKernelGGL(k_msm_count, grid1(n, (u32)(nq * P.W)), dim3(TPB), 0, C.stream, (u32)n, mw, mm, d_probs, cnt);
-        hipLaunchKernelGGL(k_msm_scan, dim3((unsigned)PW), dim3(TPB), 0, C.stream, P.B, cnt, off, cur, perm);
-        hipLaunchKernelGGL(k_msm_scatter, grid1(n, (u32)(nq * P.W)), dim3(TPB), 0, C.stream, (u32)n, mw, mm, d_probs, cur, sorted);
-        if (C.tm.enabled) { e0 = C.tm.get(); e1 = C.tm.get(); HIPCHK(hipEventRecord(e0, C.stream)); }
-        hipLaunchKernelGGL(k_msm_accumulate_gen, grid1((size_t)Wb * P.B, (u32)nq), dim3(TPB), 0, C.stream, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, sorted, perm, buckets, 0u, dbg_mask, acc_balance);
-        if (C.tm.enabled) HIPCHK(hipEventRecord(e1, C.stream));
+        hipLaunchKernelGGL(k_msm_count, grid1(n, (u32)(nq * P.W)), dim3(TPB), 0, st, (u32)n, mw, mm, d_probs, cnt);
+        hipLaunchKernelGGL(k_msm_scan, dim3((unsigned)PW), dim3(TPB), 0, st, P.B, cnt, off, cur, perm);
+        hipLaunchKernelGGL(k_msm_scatter, grid1(n, (u32)(nq * P.W)), dim3(TPB), 0, st, (u32)n, mw, mm, d_probs, cur, sorted);
+        if (C.tm.enabled) { e0 = C.tm.get(); e1 = C.tm.get(); HIPCHK(hipEventRecord(e0, st)); }
+        hipLaunchKernelGGL(k_msm_accumulate_gen, grid1((size_t)Wb * P.B, (u32)nq), dim3(TPB), 0, st, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, sorted, perm, buckets, 0u, dbg_mask, acc_balance);
+        if (C.tm.enabled) HIPCHK(hipEventRecord(e1, st));
     }
     if (C.tm.enabled) {
         C.tm.acc_ev.push_back({e0, e1}); C.tm.t.msm_accumulate_launches++; C.tm.t.msm_additions += terms * P.W;
@@ -785,7 +786,7 @@ MsmJob msm_enqueue(Ctx &C, MsmWs &W, const std::vector<MsmProb> &probs, size_t n
     ge *S_fin = J.dev_horner ? W.S[1].as<ge>(PW) : hres_dev;
     ge *C_fin = J.dev_horner ? W.Cacc[1].as<ge>(PW * (size_t)nb_final) : hres_dev + PW;
     {
-        KSpan ks_red(C.tm, C.stream, ROFL_TK_MSM_REDUCE, red_adds * PW * 9, (uint64_t)PW * P.B * 128);
+        KSpan ks_red(C.tm, st, ROFL_TK_MSM_REDUCE, red_adds * PW * 9, (uint64_t)PW * P.B * 128);
         if (C.msm_group_reduce && P.B >= 1024) {
             // every run of 512 buckets reduced by its own block, then one block per array combines the groups (two launches, the
             // first at full occupancy, instead of a chain of three whose last one ran on PW blocks)
@@ -793,16 +794,16 @@ MsmJob msm_enqueue(Ctx &C, MsmWs &W, const std::vector<MsmProb> &probs, size_t n
             ge *GS = W.S[0].as<ge>(PW * G);
             ge *GC = W.Cacc[0].as<ge>(PW * (size_t)G * 9);
             size_t lds_a = ((size_t)64 * 4 + (size_t)32 * 5 + 1) * sizeof(ge);
-            hipLaunchKernelGGL(k_msm_reduce_fused, dim3((unsigned)(PW * G)), dim3(256), lds_a, C.stream, 512u, 0u, (const ge *)buckets, (const ge *)nullptr, GS, GC, 9u);
+            hipLaunchKernelGGL(k_msm_reduce_fused, dim3((unsigned)(PW * G)), dim3(256), lds_a, st, 512u, 0u, (const ge *)buckets, (const ge *)nullptr, GS, GC, 9u);
             u32 half = G / 2 ? G / 2 : 1, nout = 10 + gbits;
-            hipLaunchKernelGGL(k_msm_reduce_groups, dim3((unsigned)PW), dim3(half, nout), (size_t)nout * half * sizeof(ge), C.stream, G, gbits, (const ge *)GS, (const ge *)GC, S_fin, C_fin, nb_final);
+            hipLaunchKernelGGL(k_msm_reduce_groups, dim3((unsigned)PW), dim3(half, nout), (size_t)nout * half * sizeof(ge), st, G, gbits, (const ge *)GS, (const ge *)GC, S_fin, C_fin, nb_final);
         } else {
             while (E > 512) {
                 u32 E8 = E / 8;
                 ge *S_out = W.S[lv & 1].as<ge>(PW * E8);
                 ge *C_out = W.Cacc[lv & 1].as<ge>(PW * (size_t)(nb + 3) * E8);
                 static const int red_split = getenv("ROFL_RED_SPLIT") ? atoi(getenv("ROFL_RED_SPLIT")) : 0;
-                hipLaunchKernelGGL(k_msm_reduce_level, grid1((size_t)E8 * ((red_split ? 4 : 1) + nb), (u32)PW), dim3(TPB), 0, C.stream, E, nb, S_in, C_in, S_out, C_out, red_split);
+                hipLaunchKernelGGL(k_msm_reduce_level, grid1((size_t)E8 * ((red_split ? 4 : 1) + nb), (u32)PW), dim3(TPB), 0, st, E, nb, S_in, C_in, S_out, C_out, red_split);
                 S_in = S_out; C_in = C_out; E = E8; nb += 3; lv++;
             }
             if (J.dev_horner) { S_fin = W.S[lv & 1].as<ge>(PW); C_fin = W.Cacc[lv & 1].as<ge>(PW * (size_t)nb_final); }
@@ -812,11 +813,11 @@ MsmJob msm_enqueue(Ctx &C, MsmWs &W, const std::vector<MsmProb> &probs, size_t n
             u32 fused_items = (E / 8) * (4 + nb), fused_threads = fused_items > 256 ? 512 : fused_items > 128 ? 256 : fused_items > 64 ? 128 : 64;
             if (fused_threads > red_fused_max) fused_threads = red_fused_max;
             size_t lds = ((size_t)(E / 8) * (1 + nb + 3) + (size_t)(E / 16) * (1 + nb + 4) + 1) * sizeof(ge);
-            hipLaunchKernelGGL(k_msm_reduce_fused, dim3((unsigned)PW), dim3(fused_threads), lds, C.stream, E, nb, S_in, C_in, S_fin, C_fin, nb_final);
+            hipLaunchKernelGGL(k_msm_reduce_fused, dim3((unsigned)PW), dim3(fused_threads), lds, st, E, nb, S_in, C_in, S_fin, C_fin, nb_final);
         }
     }
     if (J.dev_horner)      // many problems: their Horner chains run side by side on the device, one point per problem comes back
-        hipLaunchKernelGGL(k_msm_horner, dim3((unsigned)np), dim3(256), 0, C.stream, mw, (const ge *)S_fin, (const ge *)C_fin, nb_final, hres_dev);
+        hipLaunchKernelGGL(k_msm_horner, dim3((unsigned)np), dim3(256), 0, st, mw, (const ge *)S_fin, (const ge *)C_fin, nb_final, hres_dev);
     return J;
 }
 
@@ -896,8 +897,16 @@ void msm_run2(Ctx &C, const std::vector<MsmProb> &pa, size_t na, const MsmOpt &o
               const std::vector<MsmProb> &pb, size_t nb, const MsmOpt &ob, std::vector<ge5> &rb) {
     MsmAllow ala, alb;
     double t_enter = now_ms();
+    // the second one (small, latency-bound launches) runs on the side stream beside the first one's kernels and joins before the wait
+    if (!C.stream2) HIPCHK(hipStreamCreateWithFlags(&C.stream2, hipStreamNonBlocking));
+    if (!C.ev_m2) { HIPCHK(hipEventCreateWithFlags(&C.ev_m2, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&C.ev_m2j, hipEventDisableTiming)); }
+    struct Join { hipStream_t s; ~Join() { (void)hipStreamSynchronize(s); } } join{C.stream2};      // nothing of the side stream outlives the call, error paths included
+    HIPCHK(hipEventRecord(C.ev_m2, C.stream));                    // inputs of both are ready
+    HIPCHK(hipStreamWaitEvent(C.stream2, C.ev_m2, 0));
+    MsmJob Jb = msm_enqueue(C, C.mws[1], pb, nb, ob, alb, C.stream2);
+    HIPCHK(hipEventRecord(C.ev_m2j, C.stream2));
     MsmJob Ja = msm_enqueue(C, C.mws[0], pa, na, oa, ala);
-    MsmJob Jb = msm_enqueue(C, C.mws[1], pb, nb, ob, alb);
+    HIPCHK(hipStreamWaitEvent(C.stream, C.ev_m2j, 0));
     double t_sync0 = now_ms(); C.hs.enqueue += t_sync0 - t_enter;
     C.sync();
     C.hs.sync += now_ms() - t_sync0;
@@ -1736,6 +1745,16 @@ size_t rofl_nonces_per_chunk(size_t n_bits, size_t m) { return m * (2 * n_bits +
 
 int rofl_bp_gens_prepare(size_t n_bits, size_t m) {
     return guarded([&]() -> int { LaneLock lane_lock = acquire_lane(); Ctx &C = *lane_lock.c; C.init(); if (!n_bits || !m) return fail(ROFL_BAD_PARAM, "bad parameter"); get_gens(C, n_bits, m); return ROFL_OK; });
+}
+int rofl_bp_gens_table_bytes(size_t n_bits, size_t m, size_t *bytes_out) {
+    return guarded([&]() -> int {
+        if (!bytes_out) return fail(ROFL_BAD_PARAM, "bad parameter");
+        Ctx &P = ctx(); { std::lock_guard<std::mutex> g(P.init_mu); P.init(); }
+        std::lock_guard<std::mutex> lk(P.gens_mu);
+        auto it = P.gens.find(std::make_pair(n_bits, m));
+        *bytes_out = it == P.gens.end() ? 0 : it->second->bytes;
+        return ROFL_OK;
+    });
 }
 int rofl_bp_gens_export(size_t n_bits, size_t m, uint8_t *G_out, uint8_t *H_out) {
     return guarded([&]() -> int {

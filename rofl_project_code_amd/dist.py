@@ -24,10 +24,11 @@ def gather_bytes(local_u8, device, group=None):
     return [o.cpu().numpy() for o in outs]
 
 
-def all_verified(ok_local, device, group=None):
-    """MIN all-reduce of verify bits: True iff every rank's local proofs verified."""
+def all_verified(ok_local, device, group=None, force_collective=False):
+    """MIN all-reduce of verify bits: True iff every rank's local proofs verified.  force_collective: run the collective even in
+    a group of one (the RCCL smoke test on a single GPU)."""
     t = torch.tensor([1 if ok_local else 0], dtype=torch.int32, device=device)
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_initialized() and (dist.get_world_size(group) > 1 or force_collective):
         dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
     return bool(t.item())
 
@@ -35,11 +36,12 @@ def all_verified(ok_local, device, group=None):
 _round_bufs = {}
 
 
-def exchange_round(payloads, ok_local, device, group=None):
+def exchange_round(payloads, ok_local, device, group=None, force_collective=False):
     """One collective per round instead of three: every rank contributes [verify bit | payload_0 | payload_1 ...] (equal sizes on all
     ranks), the pieces are all-gathered into ONE preallocated device buffer and come back in one copy.  Returns (ok_all, per_rank) with
     ok_all = MIN over the ranks' verify bits (server.rs:474-484: one failing client fails the round) and per_rank[r] = the list of rank r's
-    payloads as numpy views."""
+    payloads as numpy arrays.  force_collective: go through the backend's all-gather even in a group of one (tests/test_gpu_dist.py
+    forms a world-size-1 `nccl` group on the GPU so that the first multi-GPU run is not also RCCL's first run)."""
     parts = [np.ascontiguousarray(p, dtype=np.uint8).reshape(-1) for p in payloads]
     sizes = [p.size for p in parts]
     n = 1 + sum(sizes)
@@ -55,7 +57,7 @@ def exchange_round(payloads, ok_local, device, group=None):
     for p in parts:
         host[o:o + p.size] = p; o += p.size
     loc.copy_(stage, non_blocking=True)
-    if world == 1:
+    if world == 1 and not (force_collective and dist.is_initialized()):
         allb.copy_(loc)
     elif dist.get_backend(group) == "gloo":
         outs = list(allb.view(world, n).unbind(0))

@@ -89,3 +89,64 @@ def test_bench_gpus2_starts_two_ranks():
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["rccl_world_size"] == 2 and line["steps"] == 2
     assert line["value"] > 0 and "cfg 2" in line["config"]["workload"]
+
+
+def _bench_two_ranks(*argv):
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update({"ROFL_BENCH_BACKEND": "gloo", "ROFL_BENCH_SAME_DEVICE": "1"})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", *argv], env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_bench_config4_two_ranks():
+    """BASELINE cfg 4 as a multi-rank workload: clients sharded over two ranks, batch create, one all-gather, each rank batch-verifies
+    the OTHER rank's share on the GPU (bench.py asserts every verdict), MIN all-reduce.  Four clients of d = 55 000 here; 48 in a real run."""
+    line = _bench_two_ranks("--config", "4", "--clients", "4", "--steps", "1", "--warmup", "1")
+    assert line["n_gpus"] == 2 and line["rccl_world_size"] == 2 and line["scaling"] == "strong"
+    assert "cfg 4" in line["config"]["workload"] and line["config"]["clients_per_rank"] == 2 and line["config"]["d"] == 55000
+    assert line["value"] > 0 and line["all_gather_bytes_per_rank"] == 2 * (4 * 1504 + 55000 * 32)
+
+
+def test_bench_config5_two_ranks():
+    """BASELINE cfg 5: the L2 composite (EncParamsL2.encrypt -> wire message -> all-gather -> deserialize + verify on the other rank)."""
+    line = _bench_two_ranks("--config", "5", "--clients", "2", "--steps", "1", "--warmup", "0")
+    assert line["n_gpus"] == 2 and "cfg 5" in line["config"]["workload"] and line["value"] > 0
+
+
+def _nccl_world1(q):
+    sys.path.insert(0, ROOT)
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(29500 + (os.getpid() % 2000)), "RANK": "0", "WORLD_SIZE": "1",
+                       "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+    import torch
+    import torch.distributed as dist
+    from rofl_project_code_amd import dist as rd
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", device_id=dev)          # backend "nccl" IS RCCL on ROCm
+    assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+    rng = np.random.default_rng(7)
+    pr = rng.integers(0, 256, size=(4, 1440), dtype=np.uint8); cm = rng.integers(0, 256, size=(25000, 32), dtype=np.uint8)
+    for ok_local in (True, False):
+        ok_all, per_rank = rd.exchange_round([pr, cm], ok_local, dev, force_collective=True)      # all_gather_into_tensor on uint8 through RCCL
+        assert ok_all is ok_local and len(per_rank) == 1
+        assert (per_rank[0][0] == pr.reshape(-1)).all() and (per_rank[0][1] == cm.reshape(-1)).all()
+    assert rd.all_verified(True, dev, force_collective=True) is True and rd.all_verified(False, dev, force_collective=True) is False
+    got = rd.gather_bytes(pr, dev)
+    assert len(got) == 1 and (got[0] == pr.reshape(-1)).all()
+    t = torch.ones(1, dtype=torch.int32, device=dev); dist.all_reduce(t); assert int(t.item()) == 1
+    dist.barrier(); dist.destroy_process_group()
+    q.put("ok")
+
+
+def test_rccl_world_size_one_exchange():
+    """The `nccl` (= RCCL) branch of dist.exchange_round / all_verified on the real GPU in a group of one, so that the first 8-GPU run
+    of bench.py is not also the first time RCCL executes this code (missing item 2)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_world1, args=(q,))
+    p.start(); p.join(600)
+    assert p.exitcode == 0
+    assert q.get(timeout=5) == "ok"

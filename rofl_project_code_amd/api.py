@@ -145,6 +145,18 @@ def bp_gens_prepare(n_bits, m):
     _check(lib().rofl_bp_gens_prepare(_sz(n_bits), _sz(m)))
 
 
+def set_option(key, value):
+    """rofl_set_option: behaviour switches of the library (include/rofl_zk.h): "verify_zip_truncate", "verify_batch", "sigma_batch",
+    "blocking_sync".  The ROFL_* environment variables of the same names only provide the defaults."""
+    _check(lib().rofl_set_option(str(key).encode(), ctypes.c_long(int(value))))
+
+
+def get_option(key):
+    out = ctypes.c_long()
+    _check(lib().rofl_get_option(str(key).encode(), ctypes.byref(out)))
+    return out.value
+
+
 def set_timing(on):
     _check(lib().rofl_set_timing(int(bool(on))))
 

@@ -61,6 +61,28 @@ def create_rangeproof(values, blindings, prove_range, n_partition, fp_bits, fp_f
     return 0, proofs[:plen.value * npr.value].reshape(npr.value, plen.value).copy(), commits[:d]
 
 
+def prove_chunk(values, blindings, prove_range, chunk_index, fp_frac, seed, n_real=None):
+    """Chunk `chunk_index` of a multi-chunk range proof on its own: upstream prove_multiple over that chunk's (already padded) values,
+    drawing its nonces from where the chunk's share of the client's nonce space starts (orc_create_rangeproof does exactly this per
+    chunk, range_proof_vec/mod.rs:75-78).  values: the chunk's m floats inside the clip range, of which the first n_real are the
+    client's (the padding behind them is the SHIFTED value 0 with blinding 0: extend_vec_to_pow2(.., 0), mod.rs:45-50);
+    -> (proof bytes, V bytes [m][32] of the SHIFTED commitments).  Lets a test compare chunks 31 and 63 of a 64-chunk proof without the oracle proving all of them."""
+    v = np.ascontiguousarray(values, dtype=np.float32)
+    b = np.ascontiguousarray(blindings, dtype=np.uint8).reshape(-1, 32)
+    m = v.size
+    k = np.rint(np.abs(v.astype(np.float64)) * float(1 << fp_frac)).astype(np.int64)      # conversion32.rs:11-18 (round to nearest even)
+    shifted = (np.where(v < 0, -k, k) + (1 << (prove_range - 1))).astype(np.uint64)        # range_proof_vec/mod.rs:36-43
+    if n_real is not None:
+        shifted[n_real:] = 0; b = b.copy(); b[n_real:] = 0
+    ns = _nonce(seed, None)
+    plen = lib().orc_proof_size(_sz(prove_range), _sz(m))
+    proof = np.zeros(plen, dtype=np.uint8)
+    V = np.zeros((m, 32), dtype=np.uint8)
+    base = ctypes.c_uint64(chunk_index * lib().orc_nonces_per_chunk(_sz(prove_range), _sz(m)))
+    rc = lib().orc_bp_prove(b"RangeProof", _sz(10), _sz(prove_range), _p(shifted), _p(b), _sz(m), _sz(prove_range), ctypes.byref(ns), base, _p(proof), _p(V))
+    return rc, proof, V
+
+
 def verify_rangeproof(proofs, commits, prove_range, fp_bits, fp_frac, seed=b"\x05" * 32):
     p = np.ascontiguousarray(proofs, dtype=np.uint8)
     c = np.ascontiguousarray(commits, dtype=np.uint8).reshape(-1, 32)

@@ -66,6 +66,71 @@ def test_cfg4_chunk0_vs_oracle(R):
     assert R.range_proof_vec.verify_rangeproof(opr, ocm, nb, verifier_seed=b"\x02" * 32, fp=fp)
 
 
+def test_cfg2_whole_proof_full_size_vs_oracle(R):
+    """BASELINE cfg 2 (the headline): d = 25 000, 32-bit, P = 4 -- ALL four chunks and all commitments against the oracle, bit for
+    bit (chunks 1-3 used to be covered by round trip / tamper only).  The oracle proves the chunks on four threads."""
+    import os
+    os.environ.setdefault("OMP_NUM_THREADS", "4")
+    fp = (32, 7)
+    rng = np.random.default_rng(250004)
+    d, nb, P = 25000, 32, 4
+    vals = _uniform(R, rng, d, nb, fp)
+    bl = rng.integers(0, 256, size=(d, 32), dtype=np.uint8); bl[:, 31] &= 0x0F
+    seed = b"\x51" * 32
+    pr, cm = R.range_proof_vec.create_rangeproof(vals, bl, nb, P, nonce=R.Nonce.seeded(seed), fp=fp)
+    rc, opr, ocm = orc.create_rangeproof(vals, bl, nb, P, 32, 7, seed=seed)
+    assert rc == 0 and opr.shape == pr.shape == (4, 1440)
+    for c in range(4):
+        assert (opr[c] == pr[c]).all(), "chunk %d differs from the oracle" % c
+    assert (ocm == cm).all()
+    assert orc.verify_rangeproof(pr, cm, nb, 32, 7) == (0, True)
+
+
+def test_cfg4_whole_proof_full_size_vs_oracle(R):
+    """BASELINE cfg 4 shape, one client: d = 55 000 (m = 16 384 per chunk, N = 2^19), 32-bit, P = 4 -- all four chunks bit for bit."""
+    import os
+    os.environ.setdefault("OMP_NUM_THREADS", "4")
+    fp = (32, 7)
+    rng = np.random.default_rng(550004)
+    d, nb, P = 55000, 32, 4
+    vals = _uniform(R, rng, d, nb, fp)
+    bl = rng.integers(0, 256, size=(d, 32), dtype=np.uint8); bl[:, 31] &= 0x0F
+    seed = b"\x52" * 32
+    pr, cm = R.range_proof_vec.create_rangeproof(vals, bl, nb, P, nonce=R.Nonce.seeded(seed), fp=fp)
+    rc, opr, ocm = orc.create_rangeproof(vals, bl, nb, P, 32, 7, seed=seed)
+    assert rc == 0 and opr.shape == pr.shape == (4, 1504)
+    for c in range(4):
+        assert (opr[c] == pr[c]).all(), "chunk %d differs from the oracle" % c
+    assert (ocm == cm).all()
+
+
+@pytest.mark.parametrize("d", [25000, 55000])
+def test_e2e_partition_chunks_vs_oracle(R, d):
+    """n_partition = 64 (cifar_large.yml:39-46) at d = 25 000 and d = 55 000: chunks 0, 31 and 63 against the oracle proving exactly that
+    chunk from its own position in the client's nonce space (orc.prove_chunk), the last one with its padding (shifted value 0,
+    blinding 0: range_proof_vec/mod.rs:45-50)."""
+    fp = (32, 7)
+    rng = np.random.default_rng(640000 + d)
+    nb, P = 32, 64
+    vals = _uniform(R, rng, d, nb, fp)
+    bl = rng.integers(0, 256, size=(d, 32), dtype=np.uint8); bl[:, 31] &= 0x0F
+    seed = b"\x53" * 32
+    pr, cm = R.range_proof_vec.create_rangeproof(vals, bl, nb, P, nonce=R.Nonce.seeded(seed), fp=fp)
+    dp = 1 << (d - 1).bit_length(); m = dp // P
+    assert pr.shape[0] == 64
+    vp = np.zeros(dp, np.float32); vp[:d] = vals
+    bp = np.zeros((dp, 32), np.uint8); bp[:d] = bl
+    # 2^(n-1) B, the shift between the API's commitments C_j and the V_j the proof is about (range_proof_vec/mod.rs:96-99, 155-167)
+    off_pt = R.pedersen_ops.commit_vec(np.frombuffer((1 << (nb - 1)).to_bytes(32, "little"), np.uint8).reshape(1, 32), np.zeros((1, 32), np.uint8))[0]
+    for c in (0, 31, 63):
+        lo, hi = c * m, min((c + 1) * m, d)
+        rc, oproof, oV = orc.prove_chunk(vp[c * m:(c + 1) * m], bp[c * m:(c + 1) * m], nb, c, 7, seed, n_real=max(hi - lo, 0))
+        assert rc == 0 and (oproof == pr[c]).all(), "chunk %d differs from the oracle" % c
+        if hi > lo:      # the oracle's V_j of the real values are the returned commitments shifted up
+            assert (R.pedersen_ops.compute_shifted_values_rp(cm[lo:hi], off_pt) == oV[:hi - lo]).all()
+    assert R.range_proof_vec.verify_rangeproof(pr, cm, nb, verifier_seed=b"\x01" * 32, fp=fp)
+
+
 def _sub(seed, tag, *witness):
     from rofl_project_code_amd.params import witness_digest      # XXH3-128 / BLAKE2b over the raw witness bytes
     return hashlib.sha3_256(b"rofl-zk/params/v2" + seed + tag + witness_digest(*witness)).digest()

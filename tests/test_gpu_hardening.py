@@ -166,3 +166,81 @@ def test_create_batch_is_bit_identical_to_single_calls(R):
     for i in (0, 2):
         pr, cm = R.range_proof_vec.create_rangeproof(vals[i], bls[i], 8, 4, nonce=nonces[i], fp=fp)
         assert (res[i][0] == pr).all() and (res[i][1] == cm).all()
+
+
+def test_behaviour_options_are_abi_calls(R):
+    """switches that change what a call returns are set through rofl_set_option, not the process environment.
+    "verify_zip_truncate" = 1 restores the reference's zip-truncation bit for bit (the oracle restates it); "verify_batch" = 0 checks
+    every proof on its own like upstream verify_multiple; unknown keys and out-of-range values are BadParameter."""
+    fp = (16, 7)
+    rng = np.random.default_rng(11)
+    d, nb = 8, 8
+    vals = rng.uniform(-0.9, 0.9, d).astype(np.float32)
+    bl = orc.rand_scalars(rng, d)
+    pr4, cm = R.range_proof_vec.create_rangeproof(vals, bl, nb, 4, nonce=R.Nonce.seeded(b"\x01" * 32), fp=fp)
+    assert R.get_option("verify_zip_truncate") == 0 and R.get_option("verify_batch") == 1
+    assert R.range_proof_vec.verify_rangeproof(pr4[:3], cm, nb, fp=fp) is False
+    try:
+        R.set_option("verify_zip_truncate", 1)
+        assert R.range_proof_vec.verify_rangeproof(pr4[:3], cm, nb, fp=fp) is True            # == orc / the reference
+        assert orc.verify_rangeproof(pr4[:3], cm, nb, 16, 7) == (0, True)
+        bad = cm.copy(); bad[1] = cm[0]                                                          # a covered commitment: still caught
+        assert R.range_proof_vec.verify_rangeproof(pr4[:3], bad, nb, fp=fp) is False
+    finally:
+        R.set_option("verify_zip_truncate", 0)
+    try:
+        R.set_option("verify_batch", 0)
+        assert R.range_proof_vec.verify_rangeproof(pr4, cm, nb, fp=fp) is True
+        t = pr4.copy(); t[2, 50] ^= 1
+        assert R.range_proof_vec.verify_rangeproof(t, cm, nb, fp=fp) is False
+    finally:
+        R.set_option("verify_batch", 1)
+    for key, val in (("no_such_option", 1), ("verify_batch", 7), ("blocking_sync", -2)):
+        with pytest.raises(R.RoflError) as e:
+            R.set_option(key, val)
+        assert e.value.code == 11
+
+
+def test_batch_member_with_non_canonical_scalar_fails_alone(R):
+    """ADVICE r2: a proof whose t_x / a / b bytes are not canonical scalars is a FormatError for a single set (RangeProof::from_bytes), but in
+    a batch it must only cost THAT client its verdict -- the server verifies each client on its own (server.rs:656-687)."""
+    fp = (16, 7)
+    a = _client(R, 21, d=16, nb=8, P=4, fp=fp); b = _client(R, 22, d=16, nb=8, P=4, fp=fp); c = _client(R, 23, d=16, nb=8, P=4, fp=fp)
+    evil = b[0].copy(); evil[1, 128:160] = 0xFF                     # t_x of chunk 1 >= l
+    assert R.range_proof_vec.verify_rangeproof_batch([a[0], evil, c[0]], [a[1], b[1], c[1]], 8, verifier_seed=b"\x03" * 32, fp=fp) == [True, False, True]
+    evil2 = c[0].copy(); evil2[3, -32:] = 0xFF                       # the final b of the last chunk
+    assert R.range_proof_vec.verify_rangeproof_batch([evil2, a[0]], [c[1], a[1]], 8, verifier_seed=b"\x03" * 32, fp=fp) == [False, True]
+    with pytest.raises(R.RoflError) as e:
+        R.range_proof_vec.verify_rangeproof(evil, b[1], 8, fp=fp)
+    assert e.value.code == 5
+
+
+def test_colliding_scalars_do_not_reach_the_gather(R):
+    """a proof with a = 0 gives every G term of the verifier's generator MSM the same scalar (-z): all 2^18 items of a
+    window land in ONE bucket, the coarse bin of the two-level sort overflows, and what the overflowed bin leaves behind must not be used as
+    window-table indices by the accumulation that runs before the host sees the flag.  The call has to come back (verdict: false), and
+    the lane must be healthy afterwards."""
+    fp = (32, 7)
+    rng = np.random.default_rng(77)
+    d, nb, P = 16384, 32, 1                                            # one chunk of 2^19 terms: the fixed-base launches take the two-level sort
+    mx = np.float32(((1 << 31) - 1) / 128.0)
+    vals = np.clip(rng.uniform(-mx, mx, size=d).astype(np.float32), -mx, np.nextafter(mx, np.float32(0)))
+    bl = orc.rand_scalars(rng, d)
+    pr, cm = R.range_proof_vec.create_rangeproof(vals, bl, nb, P, nonce=R.Nonce.seeded(b"\x61" * 32), fp=fp)
+    assert R.range_proof_vec.verify_rangeproof(pr, cm, nb, verifier_seed=b"\x01" * 32, fp=fp) is True
+    for which in (-64, -32):                                           # a = 0, then b = 0 (every H term then carries z + y^-k zz 2^i z^j: distinct; a = 0 is the colliding one)
+        evil = pr.copy(); evil[0, which:(which + 32) or None] = 0
+        assert R.range_proof_vec.verify_rangeproof(evil, cm, nb, verifier_seed=b"\x01" * 32, fp=fp) is False
+    both = pr.copy(); both[0, -64:] = 0
+    assert R.range_proof_vec.verify_rangeproof(both, cm, nb, verifier_seed=b"\x02" * 32, fp=fp) is False
+    assert R.range_proof_vec.verify_rangeproof(pr, cm, nb, verifier_seed=b"\x03" * 32, fp=fp) is True
+    pr2, cm2 = R.range_proof_vec.create_rangeproof(vals, bl, nb, P, nonce=R.Nonce.seeded(b"\x61" * 32), fp=fp)
+    assert (pr2 == pr).all() and (cm2 == cm).all()
+
+
+def test_batch_argument_lengths_are_checked(R):
+    vals = np.zeros(4, np.float32); bl = np.zeros((4, 32), np.uint8)
+    with pytest.raises(ValueError):
+        R.range_proof_vec.create_rangeproof_batch([vals, vals], [bl], 8, 1, fp=(16, 7))
+    with pytest.raises(ValueError):
+        R.range_proof_vec.create_rangeproof_batch([vals, vals], [bl, bl], 8, 1, nonces=[R.Nonce.seeded(b"\x01" * 32)], fp=(16, 7))

@@ -20,6 +20,12 @@ extern "C" {
     pub fn rofl_set_device(device: c_int) -> c_int;
     pub fn rofl_last_error(buf: *mut c_char, len: usize) -> c_int;
     pub fn rofl_bp_gens_prepare(n_bits: usize, m: usize) -> c_int;
+    pub fn rofl_bp_gens_table_bytes(n_bits: usize, m: usize, bytes_out: *mut usize) -> c_int;
+    /// behaviour options ("verify_zip_truncate", "verify_batch", "sigma_batch", "blocking_sync"); the ROFL_* environment variables
+    /// only provide defaults.  A server that wants the reference's zip-truncating verify bit for bit calls
+    /// `rofl_set_option(b"verify_zip_truncate\0".as_ptr() as *const c_char, 1)` once after `rofl_set_device`.
+    pub fn rofl_set_option(key: *const c_char, value: std::os::raw::c_long) -> c_int;
+    pub fn rofl_get_option(key: *const c_char, value_out: *mut std::os::raw::c_long) -> c_int;
     pub fn rofl_rangeproof_chunks(d: usize, n_partition: usize) -> usize;
     pub fn rofl_rangeproof_size(n_bits: usize, d: usize, n_partition: usize) -> usize;
     pub fn rofl_create_rangeproof(values: *const c_float, d: usize, blindings32: *const u8, d_blindings: usize,

@@ -34,6 +34,69 @@ using namespace rofl;
 
 namespace {
 
+// ---------------------------------------------------------------- tuning knobs
+// Every ROFL_* environment variable the library reads, in ONE table (scripts/gen_knob_table.py turns it into the table of DESIGN.md and
+// tests/test_host_lib.py checks that no other name is read).  Knobs never change results -- proofs, commitments and verdicts are the same
+// for every setting (the behaviour switches of rofl_set_option are the exception and are marked "option") -- they move work between
+// variants, and most of them exist because an experiment in DESIGN.md needed them.  Read once per process (or per device context).
+struct Knob { const char *name, *dflt, *what; };
+static const Knob KNOBS[] = {
+    {"ROFL_LANES", "3", "calls that can be in flight on a device (HIP stream + workspace each); 1..8"},
+    {"ROFL_HOST_THREADS", "usable cores - 2, in [2, 16]", "threads of the primary lane's host pool (window combination, encodings, transcripts of a round); other lanes: 6"},
+    {"ROFL_POOL_SPIN_US", "150", "how long an idle pool worker polls for the next job before it sleeps (0 = sleep at once)"},
+    {"ROFL_BLOCKING_SYNC", "-1", "option blocking_sync: -1 spin while <= 3 calls are in flight, 0 always spin, 1 sleep between polls"},
+    {"ROFL_VERIFY_ZIP_TRUNCATE", "0", "option verify_zip_truncate: 1 = the reference's zip-truncating verify_rangeproof"},
+    {"ROFL_VERIFY_BATCH", "1", "option verify_batch: 0 = one check per proof instead of one per client"},
+    {"ROFL_SIGMA_BATCH", "1", "option sigma_batch: 0 = one check per element in the Sigma-proof verifiers"},
+    {"ROFL_GENS_BUDGET_MB", "98304", "HBM budget of the generator-table cache (LRU eviction of unpinned entries beyond it)"},
+    {"ROFL_FOLD_T1", "3", "IPP rounds before the first generator fold (1..6)"},
+    {"ROFL_FOLD_T", "2", "IPP rounds between later folds (1..6)"},
+    {"ROFL_FOLD_MIN", "1024", "no fold once fewer generators per chunk would remain (launches with many chunks fold down to 64)"},
+    {"ROFL_FOLD_TAB", "1", "0 = first fold without the precomputed odd-multiple slices"},
+    {"ROFL_FOLD_PB", "32", "piece width of the fold table in bits (16, 32, 64)"},
+    {"ROFL_FOLD_W", "8", "NAF width of the fold table (3..8; narrowed until the table fits ROFL_FOLD_TAB_MB)"},
+    {"ROFL_FOLD_TAB_MB", "32768", "HBM budget of one (n, m) fold table"},
+    {"ROFL_FOLD_UNIT", "1", "0 = do not keep the common factor s_0 of a fold in gscale / hscale"},
+    {"ROFL_FOLD_K", "0", "digit-position segments per fold output (1, 2, 4; 0 = by launch size)"},
+    {"ROFL_FOLD_THREADS", "131072", "fold launches with fewer threads split their chains into segments"},
+    {"ROFL_FOLD_REGS", "1", "0 = the generic fold kernel instead of the three-sources-in-registers one"},
+    {"ROFL_IPP_FUSED", "1", "0 = k_ipp_fold_ab + k_ipp_scalars + k_ipp_inner instead of one k_ipp_round per round"},
+    {"ROFL_MSM_LR", "1", "0 = separate L and R scalar arrays (with zeros) instead of the merged layout"},
+    {"ROFL_MSM_FB", "1", "0 = no window tables (every MSM generic)"},
+    {"ROFL_MSM_FB_MIN", "4096", "generator sets smaller than this get no window table"},
+    {"ROFL_MSM_FB_C", "0", "window width of the window tables (13, 15, 16; 0 = 16 from 2^17 generators on, 15 below)"},
+    {"ROFL_MSM_FB_THREADS", "524288", "accumulate threads a fixed-base launch aims for (decides the number of bucket sets)"},
+    {"ROFL_MSM_TWO_LEVEL", "1", "0 = slot sort instead of the two-level bucket sort in fixed-base launches"},
+    {"ROFL_MSM_SLOTS", "1", "0 = count / scan / scatter sort only (no fixed-capacity structures)"},
+    {"ROFL_MSM_LDS", "1", "0 = per-item global atomics instead of LDS ranking in the slot sort"},
+    {"ROFL_MSM_LDS_MIN", "8192", "MSMs with fewer terms use the per-item slot sort"},
+    {"ROFL_MSM_LDS_TILE", "131072", "items one block of the LDS slot sort ranks"},
+    {"ROFL_MSM_SMALL_MAX", "8192", "terms per side up to which a generic MSM runs as one fused launch (0 = off)"},
+    {"ROFL_MSM_DEV_HORNER_MIN", "32", "launches with at least this many problems combine their windows on the device"},
+    {"ROFL_MSM_T13", "8192", "generic MSMs from this many terms on use 13-bit windows"},
+    {"ROFL_MSM_T10", "512", "generic MSMs from this many terms on use 10-bit windows (7-bit below, 4-bit below 64)"},
+    {"ROFL_MSM_C", "0", "window width of every generic MSM (4, 7, 10, 13, 16; 0 = by size)"},
+    {"ROFL_MSM_GROUP_REDUCE", "0", "1 = two-launch bucket reduction by groups of 512 (measured slower)"},
+    {"ROFL_RED_SPLIT", "0", "1 = four threads per 8-group in k_msm_reduce_level (measured slower)"},
+    {"ROFL_RED_FUSED_T", "512", "largest block of k_msm_reduce_fused"},
+    {"ROFL_ACC_BALANCE", "1", "0 = accumulate blocks in plain descending-load order instead of equal-work blocks"},
+    {"ROFL_TRACE", "0", "1 = one line per MSM on stderr, 2 = per-phase host timeline of every proof / verification"},
+    {"ROFL_DBG_IDX_MASK", "0x7fffffff", "timing experiments only (WRONG results): confines the table gathers to a prefix"},
+    {"ROFL_DBG_SCATTER", "0", "timing experiments only (WRONG results): 1 = no range reservation, 2 = no slot stores"},
+    {"ROFL_DBG_ACC_TIMELINE", "", "file to append per-wave start / end / placement records of every fixed-base accumulate launch to"},
+    {"ROFL_FEMUL_LDS", "0", "rofl_bench_femul: dynamic LDS per block (pins the micro-benchmark's occupancy)"},
+    {"ROFL_FEMUL_MODE", "0", "rofl_bench_femul: 0 multiplication chain, 1-3 mixed addition from registers / a 32 KB table / a gathered table"},
+    {"ROFL_FEMUL_TABLE", "2097152", "rofl_bench_femul mode 3: table entries (128 B each)"},
+};
+// getenv restricted to the table above
+const char *knob(const char *name) {
+#ifndef NDEBUG
+    bool known = false; for (const Knob &k : KNOBS) known |= !strcmp(k.name, name);
+    if (!known) { fprintf(stderr, "librofl_zk: unregistered knob %s\n", name); abort(); }
+#endif
+    return getenv(name);
+}
+
 // ---------------------------------------------------------------- error plumbing
 thread_local std::string g_err;
 int fail(int code, const std::string &msg) { g_err = msg; return code; }
@@ -172,7 +235,7 @@ class HostPool {
     }
 public:
     explicit HostPool(int nthreads) {
-        if (const char *e = getenv("ROFL_POOL_SPIN_US")) spin_us = atof(e);
+        if (const char *e = knob("ROFL_POOL_SPIN_US")) spin_us = atof(e);
         for (int i = 1; i < nthreads; i++) workers.emplace_back([this] { loop(); });
     }
     ~HostPool() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); for (auto &t : workers) t.join(); }
@@ -283,7 +346,7 @@ struct Ctx {
     u32 fold_pb = 32, fold_w = 8; size_t fold_tab_budget = (size_t)32 << 30;   // widest NAF whose table fits the per-(n, m) budget (ROFL_FOLD_W, ROFL_FOLD_TAB_MB)
     int msm_lds = 1, msm_two_level = 1, msm_group_reduce = 0; size_t msm_lds_min = 8192, msm_lds_tile = 131072;
     size_t msm_fb_threads = (size_t)1 << 19;
-    int msm_fb = 1; u32 msm_fb_sets = 2; size_t msm_fb_min = (size_t)1 << 12; int msm_lr = 1;   // window tables for every (n, m) with 2N >= 4096: many small chunks (n_partition = 64) share them
+    int msm_fb = 1; size_t msm_fb_min = (size_t)1 << 12; int msm_lr = 1;   // window tables for every (n, m) with 2N >= 4096: many small chunks (n_partition = 64) share them
     bool crowded() const { const Ctx *P = parent ? parent : this; return P->active_calls.load() > 1; }   // other calls in flight on this device
     // Waiting for the lane's stream.  hipStreamSynchronize spins (lowest latency: right for a call that is alone on the device); with
     // more than three calls in flight -- or when the host asked for it (ROFL_BLOCKING_SYNC=1) -- the thread sleeps between queries instead, so
@@ -352,42 +415,41 @@ struct Ctx {
         for (int i = 1; i < 64; i++) tp[i] = sc_montmul(tp[i - 1], two);
         HIPCHK(hipMalloc(&d_two_pow, sizeof(tp)));
         HIPCHK(hipMemcpy(d_two_pow, tp, sizeof(tp), hipMemcpyHostToDevice));
-        if (const char *e = getenv("ROFL_FOLD_T")) { int v = atoi(e); if (v >= 1 && v <= 6) fold_t = v; }
-        if (const char *e = getenv("ROFL_MSM_SLOTS")) msm_slots = atoi(e) != 0;
-        if (const char *e = getenv("ROFL_MSM_FB")) msm_fb = atoi(e);
-        if (const char *e = getenv("ROFL_MSM_FB_THREADS")) { long v = atol(e); if (v >= 1) msm_fb_threads = (size_t)v; }
-        if (const char *e = getenv("ROFL_MSM_LDS")) msm_lds = atoi(e);
-        if (const char *e = getenv("ROFL_MSM_TWO_LEVEL")) msm_two_level = atoi(e);
-        if (const char *e = getenv("ROFL_MSM_GROUP_REDUCE")) msm_group_reduce = atoi(e);
-        if (const char *e = getenv("ROFL_MSM_LDS_MIN")) { long v = atol(e); if (v >= 1) msm_lds_min = (size_t)v; }
-        if (const char *e = getenv("ROFL_MSM_LDS_TILE")) { long v = atol(e); if (v >= 1024) msm_lds_tile = (size_t)v; }
-        if (const char *e = getenv("ROFL_MSM_LR")) msm_lr = atoi(e);
-        if (const char *e = getenv("ROFL_MSM_FB_SETS")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) msm_fb_sets = (u32)v; }
-        if (const char *e = getenv("ROFL_MSM_FB_MIN")) { long v = atol(e); if (v >= 1) msm_fb_min = (size_t)v; }
-        if (const char *e = getenv("ROFL_FOLD_MIN")) { long v = atol(e); if (v >= 1) fold_min = (size_t)v; }
-        if (const char *e = getenv("ROFL_MSM_DEV_HORNER_MIN")) { long v = atol(e); if (v >= 1) msm_dev_horner_min = (size_t)v; }
-        if (const char *e = getenv("ROFL_MSM_SMALL_MAX")) { long v = atol(e); if (v >= 0) msm_small_max = (size_t)v; }
+        if (const char *e = knob("ROFL_FOLD_T")) { int v = atoi(e); if (v >= 1 && v <= 6) fold_t = v; }
+        if (const char *e = knob("ROFL_MSM_SLOTS")) msm_slots = atoi(e) != 0;
+        if (const char *e = knob("ROFL_MSM_FB")) msm_fb = atoi(e);
+        if (const char *e = knob("ROFL_MSM_FB_THREADS")) { long v = atol(e); if (v >= 1) msm_fb_threads = (size_t)v; }
+        if (const char *e = knob("ROFL_MSM_LDS")) msm_lds = atoi(e);
+        if (const char *e = knob("ROFL_MSM_TWO_LEVEL")) msm_two_level = atoi(e);
+        if (const char *e = knob("ROFL_MSM_GROUP_REDUCE")) msm_group_reduce = atoi(e);
+        if (const char *e = knob("ROFL_MSM_LDS_MIN")) { long v = atol(e); if (v >= 1) msm_lds_min = (size_t)v; }
+        if (const char *e = knob("ROFL_MSM_LDS_TILE")) { long v = atol(e); if (v >= 1024) msm_lds_tile = (size_t)v; }
+        if (const char *e = knob("ROFL_MSM_LR")) msm_lr = atoi(e);
+        if (const char *e = knob("ROFL_MSM_FB_MIN")) { long v = atol(e); if (v >= 1) msm_fb_min = (size_t)v; }
+        if (const char *e = knob("ROFL_FOLD_MIN")) { long v = atol(e); if (v >= 1) fold_min = (size_t)v; }
+        if (const char *e = knob("ROFL_MSM_DEV_HORNER_MIN")) { long v = atol(e); if (v >= 1) msm_dev_horner_min = (size_t)v; }
+        if (const char *e = knob("ROFL_MSM_SMALL_MAX")) { long v = atol(e); if (v >= 0) msm_small_max = (size_t)v; }
         {   // host pool of the primary lane: the per-round tails of many chunks (n_partition = 64: 128 window combinations, 128 encodings,
             // 64 transcripts per round) scale with it -- 8 -> 14 threads took 3 ms off a 35 ms proof.  Default: the cores this process may
             // use (affinity mask capped by the cgroup CPU quota) minus two for the calling thread and the HIP runtime, within [2, 16].
             int nt = std::min(16, std::max(2, usable_cores() - 2));
-            if (const char *e = getenv("ROFL_HOST_THREADS")) nt = atoi(e);
+            if (const char *e = knob("ROFL_HOST_THREADS")) nt = atoi(e);
             if (nt < 1) nt = 1; if (nt > 64) nt = 64;
             pool.reset(new HostPool(nt)); }
-        if (const char *e = getenv("ROFL_FOLD_T1")) { int v = atoi(e); if (v >= 1 && v <= 6) fold_t1 = v; }
-        if (const char *e = getenv("ROFL_FOLD_TAB")) fold_tab = atoi(e) != 0;
-        if (const char *e = getenv("ROFL_GENS_BUDGET_MB")) { long v = atol(e); if (v >= 1) gens_budget = (size_t)v << 20; }
-        if (const char *e = getenv("ROFL_FOLD_PB")) { int v = atoi(e); if (v == 16 || v == 32 || v == 64) fold_pb = (u32)v; }
-        if (const char *e = getenv("ROFL_FOLD_W")) { int v = atoi(e); if (v >= 3 && v <= 8) fold_w = (u32)v; }
-        if (const char *e = getenv("ROFL_FOLD_TAB_MB")) { long v = atol(e); if (v >= 1) fold_tab_budget = (size_t)v << 20; }
-        if (const char *e = getenv("ROFL_FOLD_UNIT")) fold_unit = atoi(e) != 0;
-        if (const char *e = getenv("ROFL_FOLD_K")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) fold_k = v; }
-        if (const char *e = getenv("ROFL_FOLD_THREADS")) { long v = atol(e); if (v > 0) fold_threads = v; }
-        if (const char *e = getenv("ROFL_LANES")) { int v = atoi(e); if (v >= 1 && v <= 8) nlanes = v; }
-        if (const char *e = getenv("ROFL_BLOCKING_SYNC")) blocking_sync = atoi(e) != 0;
-        if (const char *e = getenv("ROFL_VERIFY_ZIP_TRUNCATE")) opt_zip_truncate = atoi(e) != 0;
-        if (const char *e = getenv("ROFL_VERIFY_BATCH")) opt_verify_batch = atoi(e) != 0;
-        if (const char *e = getenv("ROFL_SIGMA_BATCH")) opt_sigma_batch = atoi(e) != 0;
+        if (const char *e = knob("ROFL_FOLD_T1")) { int v = atoi(e); if (v >= 1 && v <= 6) fold_t1 = v; }
+        if (const char *e = knob("ROFL_FOLD_TAB")) fold_tab = atoi(e) != 0;
+        if (const char *e = knob("ROFL_GENS_BUDGET_MB")) { long v = atol(e); if (v >= 1) gens_budget = (size_t)v << 20; }
+        if (const char *e = knob("ROFL_FOLD_PB")) { int v = atoi(e); if (v == 16 || v == 32 || v == 64) fold_pb = (u32)v; }
+        if (const char *e = knob("ROFL_FOLD_W")) { int v = atoi(e); if (v >= 3 && v <= 8) fold_w = (u32)v; }
+        if (const char *e = knob("ROFL_FOLD_TAB_MB")) { long v = atol(e); if (v >= 1) fold_tab_budget = (size_t)v << 20; }
+        if (const char *e = knob("ROFL_FOLD_UNIT")) fold_unit = atoi(e) != 0;
+        if (const char *e = knob("ROFL_FOLD_K")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) fold_k = v; }
+        if (const char *e = knob("ROFL_FOLD_THREADS")) { long v = atol(e); if (v > 0) fold_threads = v; }
+        if (const char *e = knob("ROFL_LANES")) { int v = atoi(e); if (v >= 1 && v <= 8) nlanes = v; }
+        if (const char *e = knob("ROFL_BLOCKING_SYNC")) blocking_sync = atoi(e) != 0;
+        if (const char *e = knob("ROFL_VERIFY_ZIP_TRUNCATE")) opt_zip_truncate = atoi(e) != 0;
+        if (const char *e = knob("ROFL_VERIFY_BATCH")) opt_verify_batch = atoi(e) != 0;
+        if (const char *e = knob("ROFL_SIGMA_BATCH")) opt_sigma_batch = atoi(e) != 0;
         inited = true;
         for (int i = 1; i < nlanes; i++) { Ctx *s = new Ctx(); s->init_lane(*this); sibs.push_back(s); }
     }
@@ -397,10 +459,10 @@ struct Ctx {
         ht = p.ht; d_tabB = p.d_tabB; d_tabBb = p.d_tabBb; d_two_pow = p.d_two_pow;
         msm_lds = p.msm_lds; msm_two_level = p.msm_two_level; msm_group_reduce = p.msm_group_reduce; msm_lds_min = p.msm_lds_min; msm_lds_tile = p.msm_lds_tile;
         msm_fb_threads = p.msm_fb_threads;
-        msm_fb = p.msm_fb; msm_fb_sets = p.msm_fb_sets; msm_fb_min = p.msm_fb_min; msm_lr = p.msm_lr;
+        msm_fb = p.msm_fb; msm_fb_min = p.msm_fb_min; msm_lr = p.msm_lr;
         fold_min = p.fold_min; msm_dev_horner_min = p.msm_dev_horner_min; msm_small_max = p.msm_small_max; msm_slots = p.msm_slots; fold_t = p.fold_t; fold_t1 = p.fold_t1; fold_k = p.fold_k; fold_tab = p.fold_tab;
         fold_unit = p.fold_unit; fold_threads = p.fold_threads; nlanes = 1;
-        { int nt = 6; if (const char *e = getenv("ROFL_HOST_THREADS")) nt = atoi(e); if (nt < 1) nt = 1; pool.reset(new HostPool(nt)); }
+        { int nt = 6; if (const char *e = knob("ROFL_HOST_THREADS")) nt = atoi(e); if (nt < 1) nt = 1; pool.reset(new HostPool(nt)); }
         inited = true;
     }
 };
@@ -459,7 +521,7 @@ MsmPlan msm_plan_c(u32 c) {
     return p;
 }
 u32 fb_window_c(size_t gens) {
-    static const int force = getenv("ROFL_MSM_FB_C") ? atoi(getenv("ROFL_MSM_FB_C")) : 0;      // tuning: 13 or 16 for every table
+    static const int force = knob("ROFL_MSM_FB_C") ? atoi(knob("ROFL_MSM_FB_C")) : 0;      // tuning: 13 or 16 for every table
     if (force == 13 || force == 16) return (u32)force;
     // Small generator sets (many small chunks: n_partition = 64 gives 128 L / R problems of 16 384 terms per round) spread 8 entries
     // per bucket over 4 M buckets at c = 16 and the bucket REDUCTION (0.85 ms per round) rivals the accumulation: 15-bit windows halve
@@ -565,10 +627,10 @@ GensPin get_gens(Ctx &C, size_t n, size_t m) {
 // ---------------------------------------------------------------- MSM driver
 MsmPlan msm_plan(size_t n) {
     MsmPlan p;
-    static const size_t t13 = getenv("ROFL_MSM_T13") ? (size_t)atol(getenv("ROFL_MSM_T13")) : ((size_t)1 << 13);
-    static const size_t t10 = getenv("ROFL_MSM_T10") ? (size_t)atol(getenv("ROFL_MSM_T10")) : ((size_t)1 << 9);
+    static const size_t t13 = knob("ROFL_MSM_T13") ? (size_t)atol(knob("ROFL_MSM_T13")) : ((size_t)1 << 13);
+    static const size_t t10 = knob("ROFL_MSM_T10") ? (size_t)atol(knob("ROFL_MSM_T10")) : ((size_t)1 << 9);
     if (n >= (1u << 17)) p.c = 16; else if (n >= t13) p.c = 13; else if (n >= t10) p.c = 10; else if (n >= 64) p.c = 7; else p.c = 4;
-    if (const char *e = getenv("ROFL_MSM_C")) { int v = atoi(e); if (v == 4 || v == 7 || v == 10 || v == 13 || v == 16) p.c = (u32)v; }
+    if (const char *e = knob("ROFL_MSM_C")) { int v = atoi(e); if (v == 4 || v == 7 || v == 10 || v == 13 || v == 16) p.c = (u32)v; }
     p.W = (254 + p.c - 1) / p.c;
     p.W = (253 - p.c + p.c - 1) / p.c + 1;                // top window [253-c, 254) + ceil((253-c)/c) lower windows
     p.wide = (253 - p.c) - (p.c - 1) * (p.W - 1);          // wide*c + (W-1-wide)*(c-1) = 253 - c
@@ -659,9 +721,9 @@ bool msm_plan_job(Ctx &C, MsmJob &J, const MsmOpt &opt, const MsmAllow &al, MsmM
 // ---- sort + accumulate + reduce of one attempt, enqueued on the lane's stream (no synchronisation)
 MsmJob msm_enqueue(Ctx &C, MsmWs &W, const std::vector<MsmProb> &probs, size_t n, const MsmOpt &opt, MsmAllow &al, hipStream_t st = nullptr) {
     if (!st) st = C.stream;
-    static const u32 acc_balance = getenv("ROFL_ACC_BALANCE") ? (atoi(getenv("ROFL_ACC_BALANCE")) ? 1u : 0u) : 1u;   // equal-work blocks in k_msm_accumulate (0 = plain descending order)
-    static const u32 dbg_mask = getenv("ROFL_DBG_IDX_MASK") ? (u32)strtoul(getenv("ROFL_DBG_IDX_MASK"), nullptr, 0) : 0x7fffffffu;   // timing experiments only (wrong results): gathers confined to a cache-resident prefix
-    static const u32 dbg_scatter = getenv("ROFL_DBG_SCATTER") ? (u32)atoi(getenv("ROFL_DBG_SCATTER")) : 0u;   // timing experiments only: 1 = no range reservation, 2 = no slot stores
+    static const u32 acc_balance = knob("ROFL_ACC_BALANCE") ? (atoi(knob("ROFL_ACC_BALANCE")) ? 1u : 0u) : 1u;   // equal-work blocks in k_msm_accumulate (0 = plain descending order)
+    static const u32 dbg_mask = knob("ROFL_DBG_IDX_MASK") ? (u32)strtoul(knob("ROFL_DBG_IDX_MASK"), nullptr, 0) : 0x7fffffffu;   // timing experiments only (wrong results): gathers confined to a cache-resident prefix
+    static const u32 dbg_scatter = knob("ROFL_DBG_SCATTER") ? (u32)atoi(knob("ROFL_DBG_SCATTER")) : 0u;   // timing experiments only: 1 = no range reservation, 2 = no slot stores
     MsmJob J; J.ws = &W; J.np = probs.size(); J.n = n; J.lr = opt.lr_nh != 0; J.nq = J.lr ? J.np / 2 : J.np;
     const size_t np = J.np, nq = J.nq; const bool lr = J.lr;
     MsmMap mm{}; u32 small_cap = 0; Msm2L tl{};
@@ -720,7 +782,7 @@ MsmJob msm_enqueue(Ctx &C, MsmWs &W, const std::vector<MsmProb> &probs, size_t n
         if (C.tm.enabled) { e0 = C.tm.get(); e1 = C.tm.get(); HIPCHK(hipEventRecord(e0, st)); }
         {
             KSpan ks_acc(C.tm, st, ROFL_TK_MSM_ACCUMULATE_FB, terms * P.W * 7, terms * 32);
-            static const char *timeline = getenv("ROFL_DBG_ACC_TIMELINE");      // debugging: per-wave start / end / placement of every launch, appended to this file
+            static const char *timeline = knob("ROFL_DBG_ACC_TIMELINE");      // debugging: per-wave start / end / placement of every launch, appended to this file
             if (timeline) {
                 dim3 g = grid1((size_t)Wb * P.B, (u32)nq);
                 size_t waves = (size_t)g.x * g.y * (TPB / 64);
@@ -802,14 +864,14 @@ MsmJob msm_enqueue(Ctx &C, MsmWs &W, const std::vector<MsmProb> &probs, size_t n
                 u32 E8 = E / 8;
                 ge *S_out = W.S[lv & 1].as<ge>(PW * E8);
                 ge *C_out = W.Cacc[lv & 1].as<ge>(PW * (size_t)(nb + 3) * E8);
-                static const int red_split = getenv("ROFL_RED_SPLIT") ? atoi(getenv("ROFL_RED_SPLIT")) : 0;
+                static const int red_split = knob("ROFL_RED_SPLIT") ? atoi(knob("ROFL_RED_SPLIT")) : 0;
                 hipLaunchKernelGGL(k_msm_reduce_level, grid1((size_t)E8 * ((red_split ? 4 : 1) + nb), (u32)PW), dim3(TPB), 0, st, E, nb, S_in, C_in, S_out, C_out, red_split);
                 S_in = S_out; C_in = C_out; E = E8; nb += 3; lv++;
             }
             if (J.dev_horner) { S_fin = W.S[lv & 1].as<ge>(PW); C_fin = W.Cacc[lv & 1].as<ge>(PW * (size_t)nb_final); }
             // block size = first-level work items (small bucket arrays, c = 7: 32 items -- a 256-thread block would idle 7 of its 8
             // waves and, at 163 VGPRs, hold a whole CU: thousands of such blocks (n_partition = 64) ran 18 deep per CU)
-            static const u32 red_fused_max = getenv("ROFL_RED_FUSED_T") ? (u32)atoi(getenv("ROFL_RED_FUSED_T")) : 512u;
+            static const u32 red_fused_max = knob("ROFL_RED_FUSED_T") ? (u32)atoi(knob("ROFL_RED_FUSED_T")) : 512u;
             u32 fused_items = (E / 8) * (4 + nb), fused_threads = fused_items > 256 ? 512 : fused_items > 128 ? 256 : fused_items > 64 ? 128 : 64;
             if (fused_threads > red_fused_max) fused_threads = red_fused_max;
             size_t lds = ((size_t)(E / 8) * (1 + nb + 3) + (size_t)(E / 16) * (1 + nb + 4) + 1) * sizeof(ge);
@@ -824,7 +886,7 @@ MsmJob msm_enqueue(Ctx &C, MsmWs &W, const std::vector<MsmProb> &probs, size_t n
 // after the stream has been synchronised: did the attempt overflow one of its fixed-size structures?  (then `al` has lost that variant)
 bool msm_retry(const MsmJob &J, MsmAllow &al) {
     u32 flag = *J.ws->h_ovf.as<u32>(4);
-    if (getenv("ROFL_TRACE") && J.kind != MsmKind::CountSort) fprintf(stderr, "[rofl] msm np=%zu n=%zu c=%u cap=%u fb=%u lr=%d overflow=%u\n", J.np, J.n, J.P.c, J.cap, J.fb() ? J.sets : 0u, (int)J.lr, flag);
+    if (knob("ROFL_TRACE") && J.kind != MsmKind::CountSort) fprintf(stderr, "[rofl] msm np=%zu n=%zu c=%u cap=%u fb=%u lr=%d overflow=%u\n", J.np, J.n, J.P.c, J.cap, J.fb() ? J.sets : 0u, (int)J.lr, flag);
     if (J.kind == MsmKind::Small) { if (flag) { al.small = false; return true; } return false; }      // a bucket list overflowed: repeat through the general pipeline
     if (J.two) { if (flag) { al.two = false; return true; } return false; }                              // a coarse bin overflowed (skewed scalars): repeat on the slot path
     if (J.kind == MsmKind::CountSort) return false;
@@ -939,7 +1001,7 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
                   const std::vector<ChunkNonce> &nonces, const uint8_t *h_V /* [P][m][32] host */, uint8_t *const *proofs_out,
                   hipEvent_t v_ready = nullptr /* recorded after the copy that fills h_V; nullptr: already complete */) {
     size_t N = n * m; unsigned lgN = lg2u(N);
-    static const bool ptrace = getenv("ROFL_TRACE") && atoi(getenv("ROFL_TRACE")) >= 2;
+    static const bool ptrace = knob("ROFL_TRACE") && atoi(knob("ROFL_TRACE")) >= 2;
     double pt0 = now_ms(), ptl = pt0;
     auto mark = [&](const char *what, long a = -1) {
         if (!ptrace) return;
@@ -1083,8 +1145,8 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
     };
     sc *h_round = C.h_round.as<sc>(2 * P);
     sc *a2 = C.a2.as<sc>(P * N), *b2 = C.b2.as<sc>(P * N);      // ping-pong partners of a, b (k_ipp_round folds out of place)
-    static const bool ipp_fused = !(getenv("ROFL_IPP_FUSED") && atoi(getenv("ROFL_IPP_FUSED")) == 0);
-    static const bool fold_regs = !(getenv("ROFL_FOLD_REGS") && atoi(getenv("ROFL_FOLD_REGS")) == 0);
+    static const bool ipp_fused = !(knob("ROFL_IPP_FUSED") && atoi(knob("ROFL_IPP_FUSED")) == 0);
+    static const bool fold_regs = !(knob("ROFL_FOLD_REGS") && atoi(knob("ROFL_FOLD_REGS")) == 0);
     bool just_materialised = false;
     sc *ptab[2] = {C.ptab[0].as<sc>(P * 2 * N), C.ptab[1].as<sc>(P * 2 * N)}; int psel = 0;      // pending-challenge product tables (ping-pong)
     std::unique_ptr<std::atomic<int>[]> lr_done(new std::atomic<int>[P]);
@@ -1292,7 +1354,7 @@ int verify_chunks(Ctx &C, const char *label, size_t gens_capacity, size_t P, siz
     // `group` consecutive proofs are checked as one batch: sum_c rho_c * (check_c) == 0 with random weights rho_c, so their
     // generator terms share one MSM.  Every proof of a batch gets the batch's verdict (callers AND them per client anyway).
     for (size_t c = 0; c < P; c++) ok[c] = 0;
-    static const bool vtrace = getenv("ROFL_TRACE") && atoi(getenv("ROFL_TRACE")) >= 2;
+    static const bool vtrace = knob("ROFL_TRACE") && atoi(knob("ROFL_TRACE")) >= 2;
     double vt0 = now_ms(), vtl = vt0;
     auto vmark = [&](const char *what) { if (!vtrace) return; double t = now_ms(); fprintf(stderr, "[rofl-trace verify] %-14s +%.3f ms  (t=%.3f)\n", what, t - vtl, t - vt0); vtl = t; };
     if (group == 0 || P % group) group = 1;
@@ -1502,7 +1564,7 @@ void timing_end(Ctx &C) {
     HIPCHK(hipEventRecord(C.tm.last, C.stream));
     HIPCHK(hipEventSynchronize(C.tm.last));
     float ms = 0; HIPCHK(hipEventElapsedTime(&ms, C.tm.first, C.tm.last)); C.tm.t.total_ms = ms;
-    bool trace = getenv("ROFL_TRACE") != nullptr;
+    bool trace = knob("ROFL_TRACE") != nullptr;
     for (size_t i = 0; i < C.tm.acc_ev.size(); i++) { auto &e = C.tm.acc_ev[i]; HIPCHK(hipEventElapsedTime(&ms, e.first, e.second)); C.tm.t.msm_accumulate_ms += ms; if (trace) fprintf(stderr, "[rofl] %-40s accumulate %.3f ms\n", C.tm.acc_tag[i].c_str(), ms); }
     for (size_t i = 0; i < C.tm.fold_ev.size(); i++) { auto &e = C.tm.fold_ev[i]; HIPCHK(hipEventElapsedTime(&ms, e.first, e.second)); C.tm.t.fold_ms += ms; if (trace) fprintf(stderr, "[rofl] %-40s %.3f ms\n", C.tm.fold_tag[i].c_str(), ms); }
     for (auto &k : C.tm.kev) {
@@ -2381,13 +2443,13 @@ int rofl_bench_femul(unsigned iters, double *out) {
         hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
         // ROFL_FEMUL_LDS: dynamic LDS per block, to hold the microbenchmark at the occupancy of a real kernel (40960 -> 4 blocks per CU =
         // 4 waves/SIMD, what k_msm_accumulate's 127 VGPRs allow); default 0 = 8 waves/SIMD
-        static const size_t fl = getenv("ROFL_FEMUL_LDS") ? (size_t)atol(getenv("ROFL_FEMUL_LDS")) : 0;
+        static const size_t fl = knob("ROFL_FEMUL_LDS") ? (size_t)atol(knob("ROFL_FEMUL_LDS")) : 0;
         if (fl) HIPCHK(hipFuncSetAttribute((const void *)k_bench_femul, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl));
         // ROFL_FEMUL_MODE = 1 / 2: the 7-multiplication mixed addition instead (entry held in registers / fetched per addition from a 32 KB table)
-        static const int mode = getenv("ROFL_FEMUL_MODE") ? atoi(getenv("ROFL_FEMUL_MODE")) : 0;
+        static const int mode = knob("ROFL_FEMUL_MODE") ? atoi(knob("ROFL_FEMUL_MODE")) : 0;
         if (mode) {
             // mode 3: ROFL_FEMUL_TABLE entries (power of two, default 2^21 = 256 MB) gathered at random, like the window table is
-            static const size_t tab = getenv("ROFL_FEMUL_TABLE") ? (size_t)atol(getenv("ROFL_FEMUL_TABLE")) : ((size_t)1 << 21);
+            static const size_t tab = knob("ROFL_FEMUL_TABLE") ? (size_t)atol(knob("ROFL_FEMUL_TABLE")) : ((size_t)1 << 21);
             size_t entries = mode == 3 ? tab : 256;
             ndm *dt; ge *dg; HIPCHK(hipMalloc(&dt, sizeof(ndm) * entries)); HIPCHK(hipMalloc(&dg, sizeof(ge) * threads));
             HIPCHK(hipMemset(dt, 0x11, sizeof(ndm) * entries));

@@ -1,0 +1,40 @@
+"""The tuning-knob table of DESIGN.md, generated from the KNOBS registry in csrc/rofl_zk.hip.
+    python scripts/gen_knob_table.py          -> prints the markdown table
+    python scripts/gen_knob_table.py --write  -> rewrites the block between <!-- knobs:begin --> and <!-- knobs:end --> in DESIGN.md"""
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "rofl_project_code_amd", "csrc", "rofl_zk.hip")
+
+
+def knobs():
+    s = open(SRC).read()
+    body = s[s.index("static const Knob KNOBS[] = {"):]
+    body = body[:body.index("\n};")]
+    return re.findall(r'\{"(ROFL_[A-Z0-9_]+)",\s*"([^"]*)",\s*"((?:[^"\\]|\\.)*)"\}', body)
+
+
+def reads():
+    """every name the sources pass to knob()"""
+    s = open(SRC).read()
+    return sorted(set(re.findall(r'knob\("(ROFL_[A-Z0-9_]+)"\)', s)))
+
+
+def table():
+    rows = ["| variable | default | meaning |", "|---|---|---|"]
+    for name, dflt, what in knobs():
+        rows.append("| `%s` | %s | %s |" % (name, ("`%s`" % dflt) if dflt else "(unset)", what.replace("|", "\\|")))
+    return "\n".join(rows)
+
+
+if __name__ == "__main__":
+    t = table()
+    if "--write" in sys.argv:
+        p = os.path.join(ROOT, "DESIGN.md")
+        d = open(p).read()
+        a, b = d.index("<!-- knobs:begin -->") + len("<!-- knobs:begin -->"), d.index("<!-- knobs:end -->")
+        open(p, "w").write(d[:a] + "\n" + t + "\n" + d[b:])
+    else:
+        print(t)

@@ -612,7 +612,7 @@ def test_two_level_sort_bin_shapes(R):
         assert r.returncode == 0 and lines, r.stdout[-2000:] + r.stderr[-2000:]
         return lines[0].split()[1:]
     want = run({}, "oracle")[0]
-    for env in ({}, {"ROFL_MSM_FB_SETS": "2", "ROFL_MSM_FB_THREADS": "65536"}, {"ROFL_MSM_FB_SETS": "1", "ROFL_MSM_FB_THREADS": "32768"},
+    for env in ({}, {"ROFL_MSM_FB_THREADS": "65536"}, {"ROFL_MSM_FB_THREADS": "32768"},      # two sets / one set per problem: 8 and 16 windows per bucket array
                 {"ROFL_MSM_TWO_LEVEL": "0"}, {"ROFL_ACC_BALANCE": "0"}):
         got = run(env)
         assert got == [want, "1", "0"], (env, got)

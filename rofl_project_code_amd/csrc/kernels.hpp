@@ -629,7 +629,7 @@ __global__ void __launch_bounds__(TPB) k_ipp_fold_ab(u32 nh, ChunkParams *cp, co
 #if ROFL_KG(4)
 __global__ void __launch_bounds__(TPB) k_ipp_round(u32 n_g, u32 n_k, u32 r_prev, int use_new, ChunkParams *cp, const sc *round_ch, const sc *a_in, const sc *b_in,
                                                    sc *a_out, sc *b_out, size_t ab_stride, const sc *yinvpow, size_t y_stride, sc *SL, sc *ip_out,
-                                                   const sc *ptab_in, sc *ptab_out, size_t ptab_stride) {
+                                                   const sc *ptab_in, sc *ptab_out, size_t ptab_stride, sc *ab_host) {
     __shared__ sc lds[TPB * 2];
     __shared__ sc s_u[2];
     u32 c = blockIdx.y;
@@ -662,6 +662,9 @@ __global__ void __launch_bounds__(TPB) k_ipp_round(u32 n_g, u32 n_k, u32 r_prev,
         store_sc(&sl[n_g + j], sc_from_mont(sc_montmul(bf, sH)));
         if (h == 0) {
             store_sc(&ao[ii], af); store_sc(&bo[ii], bf);
+            // last round (n_k == 2): the two entries of a and b also go to mapped host memory -- the host applies the final challenge
+            // itself (a = a_0 u + a_1 u^-1, b = b_0 u^-1 + b_1 u) instead of one more launch, two copies and a wait at the end of every proof
+            if (ab_host && n_k == 2) { store_sc(&ab_host[c * 4 + ii], af); store_sc(&ab_host[c * 4 + 2 + ii], bf); }
             if (lo) {      // this thread holds a'[nh+i], b'[nh+i]; with a'[i], b'[i] it owns one term of each inner product
                 sc al = sc_add(sc_montmul(load_sc(&ai[i]), u), sc_montmul(load_sc(&ai[n_k + i]), ui));
                 sc bl = sc_add(sc_montmul(load_sc(&bi[i]), ui), sc_montmul(load_sc(&bi[n_k + i]), u));

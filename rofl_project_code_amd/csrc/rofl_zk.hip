@@ -385,7 +385,7 @@ struct Ctx {
     DevBuf cp, sL, sR, party, Scanon, vshift, blind, Vbytes, Cbytes, status, partial, partial2, scpart, a, b, a2, b2, ptab[2], yinv,
         SL, SR, powtabs, foldprobs, naf,
         gbuf[2], aux_pts, aux_scal, vscal, tmp_in, tmp_in2, tmp_out, vals, uni, stream_buf;
-    PinBuf h_cp, h_part, h_misc, h_misc2, h_auxc, h_auxs, h_V, h_ip, h_round, h_fdig, h_fprob;
+    PinBuf h_cp, h_part, h_misc, h_misc2, h_auxc, h_auxs, h_V, h_ip, h_round, h_fdig, h_fprob, h_abfin;
     MsmWs mws[2];
 
     void init() {
@@ -919,10 +919,12 @@ void msm_finish(Ctx &C, const MsmJob &J, std::vector<ge5> &results, const MsmOpt
             results[p] = acc; if (opt.post) opt.post(p); cpu_each[p] = now_ms() - tc0;
         });
     } else {
-        C.pool->run(np, [&](size_t p) {
-            double tc0 = now_ms();
+        // One 253-step chain per problem: sum_w 2^(pos_w) (S_w + sum_l 2^l D_(w,l)).  With few problems (the IPP rounds of a client with four
+        // chunks: eight) the chain is split over TWO pool threads: the upper windows (about three eighths of them: that part also carries the
+        // doublings down to bit 0) and the lower ones; the second to finish adds the halves.  46 -> ~30 us on the hop.
+        auto horner_range = [&](size_t p, int w_hi, int w_lo, bool down_to_zero) {      // windows [w_lo, w_hi], result scaled by 2^(pos of w_lo) unless down_to_zero
             ge5 acc = h51::identity(); bool started = false;
-            for (int w = (int)P.W - 1; w >= 0; w--) {
+            for (int w = w_hi; w >= w_lo; w--) {
                 size_t pw = p * P.W + w;
                 int width = (u32)w + 1 == P.W ? (int)P.c + 1 : ((u32)w < P.wide ? (int)P.c : (int)P.c - 1);
                 for (int l = width - 1; l >= 0; l--) {
@@ -931,8 +933,31 @@ void msm_finish(Ctx &C, const MsmJob &J, std::vector<ge5> &results, const MsmOpt
                     if (l == 0) { acc = h51::gadd(acc, h51::from_ge_loose(h[pw])); started = true; }
                 }
             }
-            results[p] = acc; if (opt.post) opt.post(p); cpu_each[p] = now_ms() - tc0;
-        });
+            if (down_to_zero && w_lo > 0 && started) {
+                u32 pos = (u32)w_lo < P.wide ? (u32)w_lo * P.c : P.wide * P.c + ((u32)w_lo - P.wide) * (P.c - 1);      // msm_window's layout
+                for (u32 i = 0; i < pos; i++) acc = h51::gdouble(acc);
+            }
+            return acc;
+        };
+        const bool split = np * 2 <= 32 && P.W >= 8;
+        if (!split) {
+            C.pool->run(np, [&](size_t p) {
+                double tc0 = now_ms();
+                results[p] = horner_range(p, (int)P.W - 1, 0, false); if (opt.post) opt.post(p); cpu_each[p] = now_ms() - tc0;
+            });
+        } else {
+            const int w_split = (int)P.W - (int)(P.W * 3 / 8);      // windows [w_split, W) on one thread, [0, w_split) on another
+            std::vector<ge5> part(2 * np);
+            std::unique_ptr<std::atomic<int>[]> half_done(new std::atomic<int>[np]);
+            for (size_t p = 0; p < np; p++) half_done[p].store(0);
+            C.pool->run(2 * np, [&](size_t t) {
+                double tc0 = now_ms();
+                size_t p = t >> 1; bool upper = (t & 1) != 0;
+                part[t] = upper ? horner_range(p, (int)P.W - 1, w_split, true) : horner_range(p, w_split - 1, 0, false);
+                if (half_done[p].fetch_add(1) == 1) { results[p] = h51::gadd(part[2 * p], part[2 * p + 1]); if (opt.post) opt.post(p); }
+                double dt = now_ms() - tc0; if (dt > cpu_each[p]) cpu_each[p] = dt;
+            });
+        }
     }
     C.tm.t.host_ms += now_ms() - t0;
     C.hs.horner_wall += now_ms() - t0; { double mx = 0; for (double v : cpu_each) mx = std::max(mx, v); C.hs.horner_cpu += mx; } C.hs.n++;
@@ -1147,7 +1172,7 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
     sc *a2 = C.a2.as<sc>(P * N), *b2 = C.b2.as<sc>(P * N);      // ping-pong partners of a, b (k_ipp_round folds out of place)
     static const bool ipp_fused = !(knob("ROFL_IPP_FUSED") && atoi(knob("ROFL_IPP_FUSED")) == 0);
     static const bool fold_regs = !(knob("ROFL_FOLD_REGS") && atoi(knob("ROFL_FOLD_REGS")) == 0);
-    bool just_materialised = false;
+    bool just_materialised = false, ab_on_host = false;
     sc *ptab[2] = {C.ptab[0].as<sc>(P * 2 * N), C.ptab[1].as<sc>(P * 2 * N)}; int psel = 0;      // pending-challenge product tables (ping-pong)
     std::unique_ptr<std::atomic<int>[]> lr_done(new std::atomic<int>[P]);
     for (unsigned round = 0; round < lgN; round++) {
@@ -1162,7 +1187,8 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
             int use_new = just_materialised ? 0 : 1;
             hipLaunchKernelGGL(k_ipp_round, dim3(nblkI, (u32)P), dim3(TPB), 0, C.stream, (u32)n_g, (u32)n_k, use_new ? r - 1 : 0u, use_new, d_cp,
                                (const sc *)C.h_round.dev<sc>(2 * P), (const sc *)a, (const sc *)b, a2, b2, N, yinvpow, N, SL, C.h_ip.dev<sc>(P * 256 * 2),
-                               (const sc *)ptab[psel], ptab[psel ^ 1], N);
+                               (const sc *)ptab[psel], ptab[psel ^ 1], N, n_k == 2 ? C.h_abfin.dev<sc>(4 * P) : (sc *)nullptr);
+            if (n_k == 2) ab_on_host = true;
             std::swap(a, a2); std::swap(b, b2); psel ^= 1;
         } else {
             hipLaunchKernelGGL(k_ipp_scalars, grid1(n_g, (u32)P), dim3(TPB), 0, C.stream, (u32)n_g, (u32)n_k, r, d_cp, a, b, N, yinvpow, N, SL, SR, merged ? 1 : 0);
@@ -1198,7 +1224,7 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
         bool last = (round + 1 == lgN);
         // the fold of a, b by this challenge happens inside the next round's k_ipp_round; only the old three-kernel path and the
         // last round (whose result is the proof's final a, b) fold here
-        if (last || !(merged && ipp_fused))
+        if ((last && !ab_on_host) || !(merged && ipp_fused))
             hipLaunchKernelGGL(k_ipp_fold_ab, grid1(nh, (u32)P), dim3(TPB), 0, C.stream, (u32)nh, d_cp, (const sc *)C.h_round.dev<sc>(2 * P), r, a, b, N);
         r++;
         unsigned t_now = first_level ? (unsigned)C.fold_t1 : (unsigned)C.fold_t;
@@ -1318,6 +1344,21 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
         }
     }
     // a[0], b[0]
+    if (ab_on_host) {      // the last round's kernel left a_0, a_1, b_0, b_1 (Montgomery) in mapped host memory, the hop left u, u^-1 in h_round
+        const sc *q = C.h_abfin.as<sc>(4 * P);
+        for (size_t c = 0; c < P; c++) {
+            uint8_t *o = proofs_out[c] + 7 * 32 + 64 * lgN;
+            const sc &um = h_round[2 * c], &uim = h_round[2 * c + 1];
+            sc_tobytes(o, h_canon(sc_add(sc_montmul(q[4 * c], um), sc_montmul(q[4 * c + 1], uim))));
+            sc_tobytes(o + 32, h_canon(sc_add(sc_montmul(q[4 * c + 2], uim), sc_montmul(q[4 * c + 3], um))));
+        }
+        if (ptrace) {
+            fprintf(stderr, "[rofl-hops] %d msm calls: enqueue %.3f ms, sync wait %.3f, horner wall %.3f (max task cpu %.3f), round-host wall %.3f (max task cpu %.3f)\n",
+                    C.hs.n, C.hs.enqueue, C.hs.sync, C.hs.horner_wall, C.hs.horner_cpu, C.hs.host_wall, C.hs.host_cpu);
+            C.hs = Ctx::HopStats();
+        }
+        return;
+    }
     sc *h_ab = C.h_part.as<sc>(2 * P);
     // element 0 of every chunk: two strided copies (one copy per chunk and vector costs ~7 us of stream time each -- 0.9 ms at n_partition = 64)
     HIPCHK(hipMemcpy2DAsync(h_ab, 2 * sizeof(sc), a, N * sizeof(sc), sizeof(sc), P, hipMemcpyDeviceToHost, C.stream));

@@ -36,7 +36,8 @@ int rofl_dbg_host_nonce(const uint8_t seed[32], uint64_t idx, uint8_t out[32]);
 
 /* host micro-benchmarks of the code the per-round hops run (nanoseconds per operation on the calling core).
  * what: 0 Keccak-f[1600]; 1 point doubling, 2 point addition, 3 Ristretto encoding (51-bit host arithmetic);
- *       4 fixed-base scalar multiplication; 5 scalar inversion; 6 Merlin transcript prefix of `iters` commitments (ns per commitment) */
+ *       4 fixed-base scalar multiplication; 5 scalar inversion; 6 Merlin transcript prefix of `iters` commitments (ns per commitment);
+ *       7 / 8 / 9 one pool hand-off of a hop: 16 tasks of 30 us after a 300 us / 30 us wait of the caller, 128 tasks of 8 us after 300 us */
 int rofl_dbg_host_bench(int what, unsigned iters, double *ns_out);
 
 #ifdef __cplusplus

@@ -42,8 +42,8 @@ namespace {
 struct Knob { const char *name, *dflt, *what; };
 static const Knob KNOBS[] = {
     {"ROFL_LANES", "3", "calls that can be in flight on a device (HIP stream + workspace each); 1..8"},
-    {"ROFL_HOST_THREADS", "usable cores - 2, in [2, 16]", "threads of the primary lane's host pool (window combination, encodings, transcripts of a round); other lanes: 6"},
-    {"ROFL_POOL_SPIN_US", "150", "how long an idle pool worker polls for the next job before it sleeps (0 = sleep at once)"},
+    {"ROFL_HOST_THREADS", "usable cores, in [2, 16]", "threads of the primary lane's host pool (window combination, encodings, transcripts of a round); other lanes: 6"},
+    {"ROFL_POOL_SPIN_US", "400", "how long an idle pool worker polls for the next job before it sleeps (0 = sleep at once)"},
     {"ROFL_BLOCKING_SYNC", "-1", "option blocking_sync: -1 spin while <= 3 calls are in flight, 0 always spin, 1 sleep between polls"},
     {"ROFL_VERIFY_ZIP_TRUNCATE", "0", "option verify_zip_truncate: 1 = the reference's zip-truncating verify_rangeproof"},
     {"ROFL_VERIFY_BATCH", "1", "option verify_batch: 0 = one check per proof instead of one per client"},
@@ -202,7 +202,7 @@ int usable_cores() {
 class HostPool {
     std::vector<std::thread> workers; std::mutex mu; std::condition_variable cv;
     std::function<void(size_t)> fn; std::atomic<size_t> count{0}, next{0}, done{0}; std::atomic<int> active{0}; std::atomic<uint64_t> gen{0}; bool stop = false;
-    double spin_us = 150.0;      // ROFL_POOL_SPIN_US: how long an idle worker polls for the next job before it sleeps
+    double spin_us = 400.0;      // ROFL_POOL_SPIN_US: how long an idle worker polls for the next job before it sleeps
     // An index is claimed only after it has been checked against `count` (compare-and-swap, not fetch-add): a worker that wakes
     // late and arrives while run() is resetting the job (count == 0 in that window) must not consume an index of the next job --
     // with a blind fetch-add it could take index 0 between `next = 0` and `count = n` and drop it, and run() would wait forever.
@@ -431,8 +431,8 @@ struct Ctx {
         if (const char *e = knob("ROFL_MSM_SMALL_MAX")) { long v = atol(e); if (v >= 0) msm_small_max = (size_t)v; }
         {   // host pool of the primary lane: the per-round tails of many chunks (n_partition = 64: 128 window combinations, 128 encodings,
             // 64 transcripts per round) scale with it -- 8 -> 14 threads took 3 ms off a 35 ms proof.  Default: the cores this process may
-            // use (affinity mask capped by the cgroup CPU quota) minus two for the calling thread and the HIP runtime, within [2, 16].
-            int nt = std::min(16, std::max(2, usable_cores() - 2));
+            // use (affinity mask capped by the cgroup CPU quota; the calling thread is one of the pool's executors), within [2, 16].
+            int nt = std::min(16, std::max(2, usable_cores()));
             if (const char *e = knob("ROFL_HOST_THREADS")) nt = atoi(e);
             if (nt < 1) nt = 1; if (nt > 64) nt = 64;
             pool.reset(new HostPool(nt)); }
@@ -2559,6 +2559,21 @@ int rofl_dbg_host_bench(int what, unsigned iters, double *ns_out) {
         Merlin t("RangeProof", 10);
         t.append32_run('V', V.data(), iters);
         sink = t.stw[0];
+    } else if (what >= 7 && what <= 9) {
+        // the pool hand-off of a hop: `iters` times { the caller busy-waits 300 us (what = 7, 9) or 30 us (8) as it does for the GPU, then runs 16
+        // tasks of ~30 us (7, 8) or 128 tasks of ~8 us (9) }; result = ns per hand-off beyond nothing (ideal: 16 x 30 / threads, at least 30 us)
+        int nt = std::min(16, std::max(2, usable_cores())); if (const char *e = knob("ROFL_HOST_THREADS")) nt = atoi(e);
+        HostPool pool(nt);
+        auto spin = [](double us) { double t = now_ms(); while ((now_ms() - t) * 1e3 < us) __builtin_ia32_pause(); };
+        const size_t ntask = what == 9 ? 128 : 16; const double task_us = what == 9 ? 8.0 : 30.0, gap_us = what == 8 ? 30.0 : 300.0;
+        double tot = 0;
+        for (unsigned i = 0; i < iters; i++) {
+            spin(gap_us);
+            double a = now_ms();
+            pool.run(ntask, [&](size_t) { spin(task_us); });
+            tot += now_ms() - a;
+        }
+        *ns_out = tot * 1e6 / iters; return ROFL_OK;
     } else return ROFL_BAD_PARAM;
     *ns_out = (now_ms() - t0) * 1e6 / iters; (void)sink;
     return ROFL_OK;

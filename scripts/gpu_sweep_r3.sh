@@ -1,5 +1,5 @@
 #!/bin/bash
-# knob sweep (latency of sequential clients): how long idle pool workers poll
+# host pool: threads x idle polling window (latency of sequential clients)
 for P in 4 64; do
-  for us in 150 400 1000 3000; do ROFL_POOL_SPIN_US=$us python scripts/gpu_lat.py $P 16; done
+  for ht in 14 16; do for us in 150 400; do ROFL_HOST_THREADS=$ht ROFL_POOL_SPIN_US=$us python scripts/gpu_lat.py $P 20; done; done
 done

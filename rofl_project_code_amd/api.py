@@ -15,7 +15,7 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "librofl_zk.so")
+_LIB_PATH = os.environ.get("ROFL_ZK_LIB") or os.path.join(_HERE, "librofl_zk.so")      # ROFL_ZK_LIB: another build of the same library (same-box A/B runs)
 
 ERROR_NAMES = {
     1: "WrongNumBlindingFactors", 2: "ValueOutOfRangeError", 3: "InvalidBitsize", 4: "InvalidAggregation",

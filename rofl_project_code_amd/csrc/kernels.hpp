@@ -1379,6 +1379,38 @@ __global__ void __launch_bounds__(TPB) k_msm_reduce_level(u32 E, u32 nb, const g
     msm_reduce_item(E, nb, S_in + (size_t)pw * E, C_in + (size_t)pw * nb * E, S_out + (size_t)pw * E8, C_out + (size_t)pw * (nb + 3) * E8, t);
 }
 #endif
+// One binary level of the bit-sum tree inside a block: S'[g] = S[2g] + S[2g+1], new bit-sum nb = S[2g+1], carried bit-sums pairwise.
+// While the level has more work items than a quarter of the block, one thread per item; from there on (the last levels, where most of
+// the block would idle: E2 (1 + nb) <= blockDim / 4) FOUR lanes per item -- lane q adds coordinate q (quad26.hpp: three
+// multiplications deep instead of nine; 7.3 -> ~3.5 us per level in k_msm_small, whose nine levels were half of its 130 us).
+__device__ __forceinline__ void msm_binary_level(u32 E, u32 nb, const ge *si, const ge *ci, ge *so, ge *co) {
+    const u32 E2 = E / 2, items = E2 * (1 + nb);
+    if (items * 4 <= blockDim.x) {
+        const u32 item = threadIdx.x >> 2, q = threadIdx.x & 3;
+        if (item < items) {
+            const u32 role = item / E2, g = item % E2;
+            const ge *pa, *pb; ge *dst;
+            if (role == 0) { pa = &si[2 * g]; pb = &si[2 * g + 1]; dst = &so[g]; }
+            else { const ge *cc = ci + (size_t)(role - 1) * E; pa = &cc[2 * g]; pb = &cc[2 * g + 1]; dst = &co[(size_t)(role - 1) * E2 + g]; }
+            const fe fa = reinterpret_cast<const fe *>(pa)[q], fb = reinterpret_cast<const fe *>(pb)[q];
+            gq a, b; a.v = fd_unpack(fa); b.v = fd_unpack(fb);
+            reinterpret_cast<fe *>(dst)[q] = fd_pack(gq_add(a, b, q).v);
+            if (role == 0) reinterpret_cast<fe *>(&co[(size_t)nb * E2 + g])[q] = fb;
+        }
+        return;
+    }
+    for (u32 item = threadIdx.x; item < items; item += blockDim.x) {
+        u32 role = item / E2, g = item % E2;
+        if (role == 0) {
+            ge lo = si[2 * g], hi = si[2 * g + 1];
+            so[g] = gd_pack(gd_add(gd_unpack(lo), gd_unpack(hi)));
+            co[(size_t)nb * E2 + g] = hi;
+        } else {
+            const ge *cc = ci + (size_t)(role - 1) * E;
+            co[(size_t)(role - 1) * E2 + g] = gd_pack(gd_add(gd_unpack(cc[2 * g]), gd_unpack(cc[2 * g + 1])));
+        }
+    }
+}
 // All remaining levels (E <= 512) of one (prob, window) in a single block through LDS: one launch instead of three
 // or four latency-bound ones.  First level 8-ary (global -> LDS), the rest binary (one addition deep per level):
 // S'[g] = S[2g] + S[2g+1], new bit-sum = S[2g+1], carried bit-sums pairwise.  Output: S_fin [PW], C_fin [PW][nb_final].
@@ -1399,17 +1431,7 @@ __device__ __forceinline__ void msm_reduce_fused_body(u32 E, u32 nb, const ge *s
     while (E > 1) {
         u32 E2 = E / 2;
         if (E2 == 1) { so = fin_s; co = fin_c; } else { so = bufs[sel]; co = bufs[sel] + E2; }
-        for (u32 item = threadIdx.x; item < E2 * (1 + nb); item += blockDim.x) {
-            u32 role = item / E2, g = item % E2;
-            if (role == 0) {
-                ge lo = si[2 * g], hi = si[2 * g + 1];
-                so[g] = gd_pack(gd_add(gd_unpack(lo), gd_unpack(hi)));
-                co[(size_t)nb * E2 + g] = hi;
-            } else {
-                const ge *cc = ci + (size_t)(role - 1) * E;
-                co[(size_t)(role - 1) * E2 + g] = gd_pack(gd_add(gd_unpack(cc[2 * g]), gd_unpack(cc[2 * g + 1])));
-            }
-        }
+        msm_binary_level(E, nb, si, ci, so, co);
         __syncthreads();
         si = so; ci = co; E = E2; nb += 1; sel ^= 1;
     }
@@ -1473,17 +1495,7 @@ __device__ __forceinline__ void msm_reduce_binary_body(u32 E, const ge *si_g, ge
         E2 = E / 2;
         ge *so, *co;
         if (E2 == 1) { so = fin_s; co = fin_c; } else { so = bufs[sel]; co = bufs[sel] + E2; }
-        for (u32 item = threadIdx.x; item < E2 * (1 + nb); item += blockDim.x) {
-            u32 role = item / E2, g = item % E2;
-            if (role == 0) {
-                ge lo = si[2 * g], hi = si[2 * g + 1];
-                so[g] = gd_pack(gd_add(gd_unpack(lo), gd_unpack(hi)));
-                co[(size_t)nb * E2 + g] = hi;
-            } else {
-                const ge *cc = ci + (size_t)(role - 1) * E;
-                co[(size_t)(role - 1) * E2 + g] = gd_pack(gd_add(gd_unpack(cc[2 * g]), gd_unpack(cc[2 * g + 1])));
-            }
-        }
+        msm_binary_level(E, nb, si, ci, so, co);
         __syncthreads();
         si = so; ci = co; E = E2; nb += 1; sel ^= 1;
     }
@@ -1497,8 +1509,11 @@ __device__ __forceinline__ void msm_reduce_binary_body(u32 E, const ge *si_g, ge
 #define MSM_SMALL_CAP_MAX 80  /* upper bound of the run-time `cap` (72 at n_side <= 16 B: mean load <= 32, P(overflow) ~ 1e-12) */
 #if ROFL_KG(1)
 __global__ void __launch_bounds__(512) k_msm_small(u32 n_side, MsmWin mw, MsmMap mm, const MsmProb *probs, ge *buckets, ge *S_fin, ge *C_fin,
-                                                   u32 nb_final, u32 *overflow, u32 cap) {
+                                                   u32 nb_final, u32 *overflow, u32 cap, unsigned long long *dbg) {
     extern __shared__ __align__(16) unsigned char smem[];
+    // debugging aid (ROFL_DBG_SMALL_TIMELINE): 100 MHz wall-clock stamps of the block's phases -- start, ranked, buckets summed, reduced
+    auto stamp = [&](int k) { if (dbg && threadIdx.x == 0) dbg[(size_t)blockIdx.x * 4 + k] = wall_clock64(); };
+    stamp(0);
     const u32 B = 1u << (mw.c - 1);
     u32 pw = blockIdx.x, p = pw / mw.W, w = pw % mw.W;
     u32 side = mm.lr_nh ? (p & 1u) : 0u;
@@ -1521,6 +1536,7 @@ __global__ void __launch_bounds__(512) k_msm_small(u32 n_side, MsmWin mw, MsmMap
         }
     }
     __syncthreads();
+    stamp(1);
     const niels *pts = probs[p].pts;
     // Balance the bucket sums over the block's waves (blockDim == B = 512: 8 waves, two per SIMD).  A wave runs as long as its fullest
     // bucket (mean 4 entries, ~10 in every wave of 64 unsorted buckets); with the buckets sorted by load, wave w < 4 takes the w-th
@@ -1558,8 +1574,10 @@ __global__ void __launch_bounds__(512) k_msm_small(u32 n_side, MsmWin mw, MsmMap
     }
     __threadfence_block();
     __syncthreads();
-    if (B >= 16) { msm_reduce_binary_body(B, buckets + (size_t)pw * B, S_fin + pw, C_fin + (size_t)pw * nb_final, smem); return; }
-    msm_reduce_fused_body(B, 0, buckets + (size_t)pw * B, nullptr, S_fin + pw, C_fin + (size_t)pw * nb_final, smem);
+    stamp(2);
+    if (B >= 16) msm_reduce_binary_body(B, buckets + (size_t)pw * B, S_fin + pw, C_fin + (size_t)pw * nb_final, smem);
+    else msm_reduce_fused_body(B, 0, buckets + (size_t)pw * B, nullptr, S_fin + pw, C_fin + (size_t)pw * nb_final, smem);
+    stamp(3);
 }
 #endif
 

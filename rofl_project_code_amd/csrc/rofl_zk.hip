@@ -83,6 +83,7 @@ static const Knob KNOBS[] = {
     {"ROFL_TRACE", "0", "1 = one line per MSM on stderr, 2 = per-phase host timeline of every proof / verification"},
     {"ROFL_DBG_IDX_MASK", "0x7fffffff", "timing experiments only (WRONG results): confines the table gathers to a prefix"},
     {"ROFL_DBG_SCATTER", "0", "timing experiments only (WRONG results): 1 = no range reservation, 2 = no slot stores"},
+    {"ROFL_DBG_SMALL_TIMELINE", "", "set: per-phase block timings of every fused small-MSM launch on stderr (synchronises; debugging)"},
     {"ROFL_DBG_ACC_TIMELINE", "", "file to append per-wave start / end / placement records of every fixed-base accumulate launch to"},
     {"ROFL_FEMUL_LDS", "0", "rofl_bench_femul: dynamic LDS per block (pins the micro-benchmark's occupancy)"},
     {"ROFL_FEMUL_MODE", "0", "rofl_bench_femul: 0 multiplication chain, 1-3 mixed addition from registers / a 32 KB table / a gathered table"},
@@ -759,8 +760,19 @@ MsmJob msm_enqueue(Ctx &C, MsmWs &W, const std::vector<MsmProb> &probs, size_t n
         size_t lds_red = std::max(((size_t)(P.B / 8) * 4 + (size_t)(P.B / 16) * 5 + 1) * sizeof(ge), ((size_t)P.B + (size_t)P.B * 3 / 4 + 1) * sizeof(ge));      // fused / binary reduction trees
         uint64_t items = (uint64_t)np * n_side * P.W;
         KSpan ks(C.tm, st, ROFL_TK_MSM_SMALL, items * 7 + (uint64_t)PW * P.B * 10, (uint64_t)np * n_side * (32 + 96));
+        static const bool small_tl = knob("ROFL_DBG_SMALL_TIMELINE") != nullptr;
+        unsigned long long *tl_dev = nullptr;
+        if (small_tl) { HIPCHK(hipMalloc(&tl_dev, PW * 32)); HIPCHK(hipMemsetAsync(tl_dev, 0, PW * 32, st)); }
         hipLaunchKernelGGL(k_msm_small, dim3((unsigned)PW), dim3(P.B < 64 ? 64 : P.B), std::max(lds_lists, lds_red), st, n_side, mw, mm, d_probs, buckets,
-                           S_fin_s, C_fin_s, nb_final, d_flag, small_cap);
+                           S_fin_s, C_fin_s, nb_final, d_flag, small_cap, tl_dev);
+        if (small_tl) {      // mean phase durations over the blocks of this launch (100 MHz clock)
+            std::vector<unsigned long long> hts(PW * 4);
+            HIPCHK(hipMemcpyAsync(hts.data(), tl_dev, PW * 32, hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st)); HIPCHK(hipFree(tl_dev));
+            double ph[3] = {0, 0, 0}; unsigned long long t_lo = ~0ull, t_hi = 0;
+            for (size_t b = 0; b < PW; b++) { for (int k = 0; k < 3; k++) ph[k] += (double)(hts[b * 4 + k + 1] - hts[b * 4 + k]); t_lo = std::min(t_lo, hts[b * 4]); t_hi = std::max(t_hi, hts[b * 4 + 3]); }
+            fprintf(stderr, "[rofl] k_msm_small PW=%zu n_side=%u c=%u: rank %.1f us, bucket sums %.1f us, reduce %.1f us (block means); first start -> last end %.1f us\n",
+                    PW, n_side, P.c, ph[0] / PW * 0.01, ph[1] / PW * 0.01, ph[2] / PW * 0.01, (double)(t_hi - t_lo) * 0.01);
+        }
         if (J.dev_horner) hipLaunchKernelGGL(k_msm_horner, dim3((unsigned)np), dim3(256), 0, st, mw, (const ge *)S_fin_s, (const ge *)C_fin_s, nb_final, hres_dev);
         return J;
     }

@@ -64,7 +64,7 @@ static const Knob KNOBS[] = {
     {"ROFL_MSM_LR", "1", "0 = separate L and R scalar arrays (with zeros) instead of the merged layout"},
     {"ROFL_MSM_FB", "1", "0 = no window tables (every MSM generic)"},
     {"ROFL_MSM_FB_MIN", "4096", "generator sets smaller than this get no window table"},
-    {"ROFL_MSM_FB_C", "0", "window width of the window tables (13, 15, 16; 0 = 16 from 2^17 generators on, 15 below)"},
+    {"ROFL_MSM_FB_C", "0", "one window width (13, 15, 16) for every window table; 0 = 16-bit tables, plus a 15-bit one for generator sets below 2^17 that launches with many problems and the verifier use"},
     {"ROFL_MSM_FB_THREADS", "524288", "accumulate threads a fixed-base launch aims for (decides the number of bucket sets)"},
     {"ROFL_MSM_TWO_LEVEL", "1", "0 = slot sort instead of the two-level bucket sort in fixed-base launches"},
     {"ROFL_MSM_SLOTS", "1", "0 = count / scan / scatter sort only (no fixed-capacity structures)"},
@@ -204,6 +204,7 @@ class HostPool {
     std::vector<std::thread> workers; std::mutex mu; std::condition_variable cv;
     std::function<void(size_t)> fn; std::atomic<size_t> count{0}, next{0}, done{0}; std::atomic<int> active{0}; std::atomic<uint64_t> gen{0}; bool stop = false;
     double spin_us = 400.0;      // ROFL_POOL_SPIN_US: how long an idle worker polls for the next job before it sleeps
+    const std::atomic<int> *calls_in_flight = nullptr;      // polling is for a call that is alone on the device: with several in flight the pools of the lanes would fight over the cores
     // An index is claimed only after it has been checked against `count` (compare-and-swap, not fetch-add): a worker that wakes
     // late and arrives while run() is resetting the job (count == 0 in that window) must not consume an index of the next job --
     // with a blind fetch-add it could take index 0 between `next = 0` and `count = n` and drop it, and run() would wait forever.
@@ -223,7 +224,7 @@ class HostPool {
     void loop() {
         uint64_t seen = 0;
         for (;;) {
-            if (spin_us > 0) {
+            if (spin_us > 0 && (!calls_in_flight || calls_in_flight->load(std::memory_order_relaxed) <= 1)) {
                 auto t0 = std::chrono::steady_clock::now();
                 while (gen.load(std::memory_order_acquire) == seen) {
                     __builtin_ia32_pause();
@@ -235,7 +236,7 @@ class HostPool {
         }
     }
 public:
-    explicit HostPool(int nthreads) {
+    explicit HostPool(int nthreads, const std::atomic<int> *in_flight = nullptr) : calls_in_flight(in_flight) {
         if (const char *e = knob("ROFL_POOL_SPIN_US")) spin_us = atof(e);
         for (int i = 1; i < nthreads; i++) workers.emplace_back([this] { loop(); });
     }
@@ -321,7 +322,7 @@ struct MsmWs {
 };
 
 // One cached BulletproofGens::new(n, m): [G(N) | H(N)] + fold slices (tbl), the 16 window slices of the fixed-base MSM (wtab)
-struct GensEntry { niels *tbl = nullptr; ndm *wtab = nullptr; u32 wc = 16; FoldTabCfg fc{}; size_t bytes = 0, n = 0, m = 0; u64 tick = 0; int users = 0; };
+struct GensEntry { niels *tbl = nullptr; ndm *wtab = nullptr, *wtab_many = nullptr; u32 wc = 16, wc_many = 0; FoldTabCfg fc{}; size_t bytes = 0, n = 0, m = 0; u64 tick = 0; int users = 0; };
 
 // One Ctx = one "lane": a HIP stream with its own workspace, staging buffers, timing and host pool.  The primary
 // lane of a device owns the shared read-only state (fixed-base tables, generator cache).  An API call runs on one
@@ -436,7 +437,7 @@ struct Ctx {
             int nt = std::min(16, std::max(2, usable_cores()));
             if (const char *e = knob("ROFL_HOST_THREADS")) nt = atoi(e);
             if (nt < 1) nt = 1; if (nt > 64) nt = 64;
-            pool.reset(new HostPool(nt)); }
+            pool.reset(new HostPool(nt, &active_calls)); }
         if (const char *e = knob("ROFL_FOLD_T1")) { int v = atoi(e); if (v >= 1 && v <= 6) fold_t1 = v; }
         if (const char *e = knob("ROFL_FOLD_TAB")) fold_tab = atoi(e) != 0;
         if (const char *e = knob("ROFL_GENS_BUDGET_MB")) { long v = atol(e); if (v >= 1) gens_budget = (size_t)v << 20; }
@@ -463,7 +464,7 @@ struct Ctx {
         msm_fb = p.msm_fb; msm_fb_min = p.msm_fb_min; msm_lr = p.msm_lr;
         fold_min = p.fold_min; msm_dev_horner_min = p.msm_dev_horner_min; msm_small_max = p.msm_small_max; msm_slots = p.msm_slots; fold_t = p.fold_t; fold_t1 = p.fold_t1; fold_k = p.fold_k; fold_tab = p.fold_tab;
         fold_unit = p.fold_unit; fold_threads = p.fold_threads; nlanes = 1;
-        { int nt = 6; if (const char *e = knob("ROFL_HOST_THREADS")) nt = atoi(e); if (nt < 1) nt = 1; pool.reset(new HostPool(nt)); }
+        { int nt = 6; if (const char *e = knob("ROFL_HOST_THREADS")) nt = atoi(e); if (nt < 1) nt = 1; pool.reset(new HostPool(nt, &p.active_calls)); }
         inited = true;
     }
 };
@@ -521,14 +522,11 @@ MsmPlan msm_plan_c(u32 c) {
     p.levels = (p.c - 1) / 3;
     return p;
 }
+// 0 = the default layouts (16-bit windows; small generator sets also get a 15-bit table for launches with many problems)
 u32 fb_window_c(size_t gens) {
-    static const int force = knob("ROFL_MSM_FB_C") ? atoi(knob("ROFL_MSM_FB_C")) : 0;      // tuning: 13 or 16 for every table
-    if (force == 13 || force == 16) return (u32)force;
-    // Small generator sets (many small chunks: n_partition = 64 gives 128 L / R problems of 16 384 terms per round) spread 8 entries
-    // per bucket over 4 M buckets at c = 16 and the bucket REDUCTION (0.85 ms per round) rivals the accumulation: 15-bit windows halve
-    // the buckets for one more window (17 slices).  (13-bit windows were measured too: their 4 096-bucket arrays fall off the two-level
-    // sort and the narrow windows unbalance the lists -- 3.5 ms per round against 3.0.)
-    return gens >= ((size_t)1 << 17) ? 16u : 15u;
+    static const int force = knob("ROFL_MSM_FB_C") ? atoi(knob("ROFL_MSM_FB_C")) : 0;      // tuning: one layout (13, 15 or 16) for every table and launch
+    (void)gens;
+    return (force == 13 || force == 15 || force == 16) ? (u32)force : 0u;
 }
 // Generator-table cache, shared by the lanes of a device.  An entry is pinned (users > 0) for the duration of every call that
 // reads it; eviction (LRU, beyond gens_budget, or to make room after a failed hipMalloc) only ever frees unpinned entries, so it is
@@ -537,6 +535,8 @@ u32 fb_window_c(size_t gens) {
 // no window table) instead of leaving the device full.
 void gens_free_entry(GensEntry *e) {
     if (e->wtab) (void)hipFree(e->wtab);
+    if (e->wtab_many) (void)hipFree(e->wtab_many);
+    e->wtab_many = nullptr;
     if (e->tbl) (void)hipFree(e->tbl);
     e->wtab = nullptr; e->tbl = nullptr;
 }
@@ -574,6 +574,12 @@ struct GensPin {
     niels *tbl() const { return e->tbl; }
     const niels *wtab() const { return reinterpret_cast<const niels *>(e->wtab); }      // opaque to the host: 128-byte ndm records
     u32 wc() const { return e->wc; }                                                    // window width of the window table's layout
+    // the table to use for a launch of `problems` bucket-array owners: small generator sets carry a second, 15-bit layout for launches with
+    // many problems (n_partition = 64), where 16-bit windows would spread a handful of entries per bucket over millions of buckets
+    void fb_for(size_t problems, const niels **tab, u32 *c) const {
+        if (e->wtab_many && problems >= 32) { *tab = reinterpret_cast<const niels *>(e->wtab_many); *c = e->wc_many; }
+        else { *tab = reinterpret_cast<const niels *>(e->wtab); *c = e->wc; }
+    }
     const FoldTabCfg &fc() const { return e->fc; }
 };
 GensPin get_gens(Ctx &C, size_t n, size_t m) {
@@ -607,13 +613,27 @@ GensPin get_gens(Ctx &C, size_t n, size_t m) {
         // buckets per set) from 2^17 generators on; 13-bit windows (20 slices, 4 096 buckets) below -- many small chunks (n_partition = 64:
         // 128 L / R problems of 16 384 terms per round) would otherwise spread 8 entries per bucket over 4 M buckets, and the bucket
         // reduction, not the accumulation, was the cost of such a launch.
-        MsmPlan fp = msm_plan_c(fb_window_c(2 * N));
+        const u32 c_force = fb_window_c(2 * N);
+        MsmPlan fp = msm_plan_c(c_force ? c_force : 16);
         if (P0.msm_fb && 2 * N >= P0.msm_fb_min && 2 * N * fp.W < ((size_t)1 << 31)) {      // entry index (w * 2N + i) must fit 31 bits
             void *wtv = nullptr;
             if (gens_malloc(P0, &wtv, sizeof(ndm) * 2 * N * fp.W, ent.get()) == hipSuccess) {      // without it the MSMs over these generators run in generic mode
                 ndm *wt = reinterpret_cast<ndm *>(wtv);
                 hipLaunchKernelGGL(k_gens_wtab, grid1(2 * N), dim3(TPB), 0, C.stream, (u32)(2 * N), MsmWin{fp.c, fp.W, fp.wide}, tbl, wt, (size_t)(2 * N));
                 ent->wtab = wt; ent->wc = fp.c; ent->bytes += sizeof(ndm) * 2 * N * fp.W;
+                // Small generator sets also get a 15-bit layout (17 slices; 71 MB at 2N = 32 768).  Many small chunks (n_partition = 64: 128 L / R
+                // problems of 16 384 terms per round) spread 8 entries per bucket over 4 M buckets at c = 16 and the bucket REDUCTION (0.85 ms
+                // per round) rivals the accumulation; 15-bit windows halve the buckets for one more window: 3.2 -> 2.8 ms per round.  (13-bit
+                // windows were measured too: their 4 096-bucket arrays fall off the two-level sort and the narrow windows unbalance the
+                // lists -- 3.5 ms per round.)  A client with FEW chunks of this size (cfg 1: four chunks of 2 048 8-bit values) keeps c = 16.
+                if (!c_force && 2 * N < ((size_t)1 << 17)) {
+                    MsmPlan f2 = msm_plan_c(15);
+                    void *w2 = nullptr;
+                    if (gens_malloc(P0, &w2, sizeof(ndm) * 2 * N * f2.W, ent.get()) == hipSuccess) {
+                        hipLaunchKernelGGL(k_gens_wtab, grid1(2 * N), dim3(TPB), 0, C.stream, (u32)(2 * N), MsmWin{f2.c, f2.W, f2.wide}, tbl, reinterpret_cast<ndm *>(w2), (size_t)(2 * N));
+                        ent->wtab_many = reinterpret_cast<ndm *>(w2); ent->wc_many = f2.c; ent->bytes += sizeof(ndm) * 2 * N * f2.W;
+                    }
+                }
             }
         }
         C.sync();
@@ -1087,7 +1107,7 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
     std::vector<sc> a_bl(P), s_bl(P), y(P), z(P), zz(P), x(P), w(P);
     for (size_t c = 0; c < P; c++) tr.emplace_back(label, strlen(label));
     {
-        MsmOpt mo; if (wtab) { mo.fb_wtab = wtab; mo.fb_stride = 2 * N; mo.fb_c = gens.wc(); }
+        MsmOpt mo; if (wtab) { gens.fb_for(P, &mo.fb_wtab, &mo.fb_c); mo.fb_stride = 2 * N; }
         mo.overlap = [&]() {      // the transcript prefix (m commitments per chunk) does not depend on S: hash it while the MSM runs
             double t0 = now_ms();
             if (v_ready) HIPCHK(hipEventSynchronize(v_ready));      // first in the stream: long done by the time the S launches are enqueued
@@ -1213,7 +1233,7 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
         C.tm.t.msm_terms += P * 2 * n_g;
         MsmOpt mo;
         if (merged) { mo.lr_nh = (u32)nh; mo.lr_ng = (u32)n_g; }
-        if (first_level && wtab) { mo.fb_wtab = wtab; mo.fb_stride = 2 * N; mo.fb_c = gens.wc(); }
+        if (first_level && wtab) { gens.fb_for(2 * P, &mo.fb_wtab, &mo.fb_c); mo.fb_stride = 2 * N; }
         // The host tail of the round runs inside the MSM's own pool tasks: the thread that finishes problem 2c (+1) adds c_L w B (c_R w B)
         // and encodes L (R); the second of a chunk's two to get there hashes both into the transcript, draws u and inverts it.  L and R
         // of a chunk are encoded side by side and the hop has one pool hand-off instead of two.
@@ -1550,7 +1570,8 @@ int verify_chunks(Ctx &C, const char *label, size_t gens_capacity, size_t P, siz
     for (size_t g = 0; g < ngroups; g++) prB[g] = MsmProb{aux_pts + g * group * naux, aux_scal + g * group * naux};
     C.tm.t.msm_terms += ngroups * 2 * N + P * naux;
     // the generator MSM (2N terms per group, fixed-base) and the proof-point MSM (commitments, A, S, T, L, R) queue back to back: one wait
-    { MsmOpt mo; if (wtab) { mo.fb_wtab = wtab; mo.fb_stride = 2 * N; mo.fb_c = gens.wc(); } msm_run2(C, pr, 2 * N, mo, resA, prB, group * naux, MsmOpt(), resB); }
+    // (one problem per client with every window in its own bucket set: the 15-bit layout's smaller arrays win here whenever it exists)
+    { MsmOpt mo; if (wtab) { gens.fb_for(1000, &mo.fb_wtab, &mo.fb_c); mo.fb_stride = 2 * N; } msm_run2(C, pr, 2 * N, mo, resA, prB, group * naux, MsmOpt(), resB); }
     vmark("msm");
     const u32 h_status = *h_stat;
     th = now_ms();

@@ -1215,7 +1215,7 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
         u32 nblkI;
         sc *h_ip = C.h_ip.as<sc>(P * 256 * 2);                     // the partial sums land in mapped host memory
         if (fused) {
-            nblkI = (u32)std::min<size_t>(256, std::max<size_t>(1, (n_g + 2 * TPB - 1) / (2 * TPB)));
+            nblkI = (u32)std::min<size_t>(256, std::max<size_t>(1, (n_g + TPB - 1) / TPB));      // one slot per thread while the 256 partial-sum rows last (the tail rounds are one 13-multiplication chain deep)
             int use_new = just_materialised ? 0 : 1;
             hipLaunchKernelGGL(k_ipp_round, dim3(nblkI, (u32)P), dim3(TPB), 0, C.stream, (u32)n_g, (u32)n_k, use_new ? r - 1 : 0u, use_new, d_cp,
                                (const sc *)C.h_round.dev<sc>(2 * P), (const sc *)a, (const sc *)b, a2, b2, N, yinvpow, N, SL, C.h_ip.dev<sc>(P * 256 * 2),

@@ -215,6 +215,8 @@ enum { ROFL_TK_MSM_ACCUMULATE_FB = 0, ROFL_TK_MSM_ACCUMULATE_GEN = 1, ROFL_TK_MS
        ROFL_TK_MSM_SMALL = 4, ROFL_TK_FOLD_TAB = 5, ROFL_TK_FOLD = 6, ROFL_TK_OTHER = 7, ROFL_TK_COUNT = 8 };
 typedef struct { double ms; uint64_t launches, fe_muls, bytes; } rofl_kernel_time_t;
 int rofl_last_kernel_times(rofl_kernel_time_t out[ROFL_TK_COUNT]);
+/* 0 = off; 1 = HIP events around every instrumented launch (~150 event records per proof: ~0.7 ms of a 25 ms proof); 2 = only around the
+ * fixed-base accumulation, the kernel bench.py prices against the roofline (ten records per proof) */
 int rofl_set_timing(int enabled);
 /* ---- behaviour options ----
  * Switches that change WHAT a call returns or how it waits are part of the ABI, not of the process environment.  `key` is one of the

@@ -158,7 +158,8 @@ def get_option(key):
 
 
 def set_timing(on):
-    _check(lib().rofl_set_timing(int(bool(on))))
+    """0 / False = off, 1 / True = every instrumented launch, 2 = only the fixed-base accumulation (cheap enough for timed steps)"""
+    _check(lib().rofl_set_timing(int(on)))
 
 
 def last_timing():

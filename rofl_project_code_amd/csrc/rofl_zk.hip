@@ -285,7 +285,8 @@ struct PinBuf {
 };
 
 struct Timing {
-    bool enabled = false;
+    bool enabled = false;      // the full instrumentation: per-kind spans, accumulate / fold events, first / last
+    bool acc_only = false;     // only the spans of the fixed-base accumulation (rofl_set_timing(2)): ten event records per proof instead of ~150
     rofl_timing_t t{};
     std::vector<std::pair<hipEvent_t, hipEvent_t>> acc_ev, fold_ev;
     std::vector<std::string> acc_tag, fold_tag;
@@ -305,7 +306,7 @@ struct Timing {
 struct KSpan {
     Timing *tm = nullptr; hipStream_t s = nullptr; size_t idx = 0;
     KSpan(Timing &t, hipStream_t st, int kind, uint64_t fe_muls, uint64_t bytes) {
-        if (!t.enabled) return;
+        if (!t.enabled && !(t.acc_only && kind == ROFL_TK_MSM_ACCUMULATE_FB)) return;
         tm = &t; s = st; idx = t.kev.size();
         t.kev.push_back(Timing::KEv{kind, t.get(), t.get(), fe_muls, bytes});
         HIPCHK(hipEventRecord(t.kev[idx].e0, s));
@@ -1634,7 +1635,17 @@ void timing_begin(Ctx &C) {
     if (C.tm.enabled) { C.tm.first = C.tm.get(); C.tm.last = C.tm.get(); HIPCHK(hipEventRecord(C.tm.first, C.stream)); }
 }
 void timing_end(Ctx &C) {
-    if (!C.tm.enabled) { g_last_timing = C.tm.t; memset(g_last_ktimes, 0, sizeof g_last_ktimes); return; }
+    if (!C.tm.enabled) {
+        g_last_timing = C.tm.t; memset(g_last_ktimes, 0, sizeof g_last_ktimes);
+        if (C.tm.acc_only && !C.tm.kev.empty()) {      // the stream has been synchronised by the caller's last wait: the few recorded spans are complete
+            float ms = 0;
+            for (auto &k : C.tm.kev) {
+                if (hipEventSynchronize(k.e1) != hipSuccess || hipEventElapsedTime(&ms, k.e0, k.e1) != hipSuccess) continue;
+                rofl_kernel_time_t &o = g_last_ktimes[k.kind]; o.ms += ms; o.launches++; o.fe_muls += k.fe_muls; o.bytes += k.bytes;
+            }
+        }
+        return;
+    }
     HIPCHK(hipEventRecord(C.tm.last, C.stream));
     HIPCHK(hipEventSynchronize(C.tm.last));
     float ms = 0; HIPCHK(hipEventElapsedTime(&ms, C.tm.first, C.tm.last)); C.tm.t.total_ms = ms;
@@ -2499,8 +2510,8 @@ int rofl_get_option(const char *key, long *value_out) {
 int rofl_set_timing(int enabled) {
     return guarded([&]() -> int {
         Ctx &P = ctx(); { std::lock_guard<std::mutex> g(P.init_mu); P.init(); }
-        { std::lock_guard<std::mutex> lk(P.mu); P.tm.enabled = enabled != 0; }
-        for (Ctx *s : P.sibs) { std::lock_guard<std::mutex> lk(s->mu); s->tm.enabled = enabled != 0; }
+        { std::lock_guard<std::mutex> lk(P.mu); P.tm.enabled = enabled == 1; P.tm.acc_only = enabled == 2; }
+        for (Ctx *s : P.sibs) { std::lock_guard<std::mutex> lk(s->mu); s->tm.enabled = enabled == 1; s->tm.acc_only = enabled == 2; }
         return ROFL_OK;
     });
 }

@@ -181,8 +181,8 @@ def test_cfg3_cfg5_l2_composite_vs_oracle(R, d):
 def test_many_chunk_shapes_fuzz(R):
     """Random shapes with 16 .. 128 chunks of 2^11 .. 2^15 generators (the regime of the reference's e2e runs: 15-bit window tables for
     launches with many problems, device-side Horner, folds down to 64 generators per chunk): three chunks per case against the oracle's
-    single-chunk prover, round trip and tamper (scripts/gpu_fuzz_many_chunks.py, 45 s here; 75 cases in 300 s when run on its own)."""
+    single-chunk prover, round trip and tamper (tests/gpu_fuzz_many_chunks.py, 45 s here; 75 cases in 300 s when run on its own)."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "gpu_fuzz_many_chunks.py"), "45", "2026"], capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "gpu_fuzz_many_chunks.py"), "45", "2026"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "fuzz ok:" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]

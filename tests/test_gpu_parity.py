@@ -476,10 +476,10 @@ def test_sigma_full_size_cfg3(R):
 
 
 def test_random_shape_fuzz(R):
-    """Time-boxed randomised parity (scripts/gpu_fuzz.py): random (d, bits, P, fp) incl. error codes and bit-flip tampering."""
+    """Time-boxed randomised parity (tests/gpu_fuzz.py): random (d, bits, P, fp) incl. error codes and bit-flip tampering."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "gpu_fuzz.py"), "20", "4242"], capture_output=True, text=True, timeout=300)
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "gpu_fuzz.py"), "20", "4242"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "fuzz ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 

@@ -39,6 +39,9 @@ int rofl_dbg_host_nonce(const uint8_t seed[32], uint64_t idx, uint8_t out[32]);
  *       4 fixed-base scalar multiplication; 5 scalar inversion; 6 Merlin transcript prefix of `iters` commitments (ns per commitment);
  *       7 / 8 / 9 one pool hand-off of a hop: 16 tasks of 30 us after a 300 us / 30 us wait of the caller, 128 tasks of 8 us after 300 us */
 int rofl_dbg_host_bench(int what, unsigned iters, double *ns_out);
+/* csrc/host51x8.hpp (eight window chains per AVX-512 IFMA stream) against the scalar chain of host51.hpp on 8 x W pseudo-random points,
+ * windows c bits apart: 0 = all `lanes` results agree, 1 = mismatch, -1 = the CPU has no AVX-512 IFMA (nothing tested) */
+int rofl_dbg_host_horner8_selftest(unsigned W, unsigned c, int lanes, double *us_simd, double *us_scalar);
 
 #ifdef __cplusplus
 }

@@ -1616,6 +1616,22 @@ __global__ void __launch_bounds__(256) k_msm_horner(MsmWin mw, const ge *S_fin, 
 }
 #endif
 
+// The first step of k_msm_horner alone: one quad of lanes per (problem, window) adds up the window's bit-sums, W_w = S + sum_l 2^l D_l
+// (c - 1 doublings deep), and writes it to `out` [PW] -- mapped host memory: the 253-step chains across the windows run on the host, eight
+// problems per AVX-512 IFMA instruction stream (host51x8.hpp).
+#if ROFL_KG(1)
+__global__ void __launch_bounds__(256) k_msm_wsum(u32 PW, const ge *S_fin, const ge *C_fin, u32 nb, ge *out) {
+    const u32 pw = (blockIdx.x * blockDim.x + threadIdx.x) >> 2, q = threadIdx.x & 3;
+    if (pw >= PW) return;                               // whole quads
+    auto coord = [&](const ge *pt) { gq r; r.v = fd_unpack(reinterpret_cast<const fe *>(pt)[q]); return r; };
+    gq acc = coord(&C_fin[(size_t)pw * nb + nb - 1]);
+#pragma unroll 1
+    for (int l = (int)nb - 2; l >= 0; l--) acc = gq_add(gq_double(acc, q), coord(&C_fin[(size_t)pw * nb + l]), q);
+    acc = gq_add(acc, coord(&S_fin[pw]), q);
+    reinterpret_cast<fe *>(&out[pw])[q] = fd_pack(acc.v);
+}
+#endif
+
 // self-test of quad26.hpp: pair i = (P, Q) -> 2^doublings P + Q, once with one thread per pair (gd_*), once with one quad per pair (gq_*)
 #if ROFL_KG(4)
 __global__ void __launch_bounds__(TPB) k_dbg_quad(u32 pairs, u32 doublings, const uint8_t *in /* [pairs][2][32] */, uint8_t *out_serial, uint8_t *out_quad, u32 *status) {

@@ -29,6 +29,7 @@
 #endif
 #include "wire.hpp"
 #include "host51.hpp"
+#include "host51x8.hpp"
 
 using namespace rofl;
 
@@ -72,6 +73,7 @@ static const Knob KNOBS[] = {
     {"ROFL_MSM_LDS_MIN", "8192", "MSMs with fewer terms use the per-item slot sort"},
     {"ROFL_MSM_LDS_TILE", "131072", "items one block of the LDS slot sort ranks"},
     {"ROFL_MSM_SMALL_MAX", "8192", "terms per side up to which a generic MSM runs as one fused launch (0 = off)"},
+    {"ROFL_MSM_HOST8", "1", "0 = launches with many problems combine their windows on the device (k_msm_horner) even when the host has AVX-512 IFMA"},
     {"ROFL_MSM_DEV_HORNER_MIN", "32", "launches with at least this many problems combine their windows on the device"},
     {"ROFL_MSM_T13", "8192", "generic MSMs from this many terms on use 13-bit windows"},
     {"ROFL_MSM_T10", "512", "generic MSMs from this many terms on use 10-bit windows (7-bit below, 4-bit below 64)"},
@@ -677,6 +679,7 @@ struct MsmAllow { bool fb = true, small = true, two = true, slots = true; };
 enum class MsmKind { FixedBase, Small, Slots, CountSort };
 struct MsmJob {
     MsmWs *ws = nullptr; size_t np = 0, nq = 0, n = 0, PW = 0; MsmPlan P{}; MsmKind kind = MsmKind::CountSort; bool lr = false, two = false, dev_horner = false;
+    bool host8 = false;      // dev_horner launches whose chains come back to the host, eight per SIMD stream (k_msm_wsum + h8::horner8)
     u32 sets = 0, cap = 0;
     bool fb() const { return kind == MsmKind::FixedBase; }
 };
@@ -767,6 +770,8 @@ MsmJob msm_enqueue(Ctx &C, MsmWs &W, const std::vector<MsmProb> &probs, size_t n
     // results and flags go from the kernels straight into mapped host memory (no D2H copies on the hop); with many problems the
     // Horner chains run on the device and only one point per problem comes back
     J.dev_horner = !fb && np >= C.msm_dev_horner_min && P.W <= 64;
+    static const bool host8_on = h8::available() && !(knob("ROFL_MSM_HOST8") && atoi(knob("ROFL_MSM_HOST8")) == 0);
+    J.host8 = J.dev_horner && host8_on;
     ge *hres_dev = W.h_res.dev<ge>(PW * (size_t)P.c + np);
     u32 *h_flag = W.h_ovf.as<u32>(4), *d_flag = W.h_ovf.dev<u32>(4);
     const u32 Wb = (u32)(PW / nq);                           // bucket arrays per grid problem
@@ -794,7 +799,8 @@ MsmJob msm_enqueue(Ctx &C, MsmWs &W, const std::vector<MsmProb> &probs, size_t n
             fprintf(stderr, "[rofl] k_msm_small PW=%zu n_side=%u c=%u: rank %.1f us, bucket sums %.1f us, reduce %.1f us (block means); first start -> last end %.1f us\n",
                     PW, n_side, P.c, ph[0] / PW * 0.01, ph[1] / PW * 0.01, ph[2] / PW * 0.01, (double)(t_hi - t_lo) * 0.01);
         }
-        if (J.dev_horner) hipLaunchKernelGGL(k_msm_horner, dim3((unsigned)np), dim3(256), 0, st, mw, (const ge *)S_fin_s, (const ge *)C_fin_s, nb_final, hres_dev);
+        if (J.host8) hipLaunchKernelGGL(k_msm_wsum, grid1(PW * 4), dim3(TPB), 0, st, (u32)PW, (const ge *)S_fin_s, (const ge *)C_fin_s, nb_final, hres_dev);
+        else if (J.dev_horner) hipLaunchKernelGGL(k_msm_horner, dim3((unsigned)np), dim3(256), 0, st, mw, (const ge *)S_fin_s, (const ge *)C_fin_s, nb_final, hres_dev);
         return J;
     }
     // ---- SORT (+ ACCUMULATE: its list format depends on the sort)
@@ -911,7 +917,9 @@ MsmJob msm_enqueue(Ctx &C, MsmWs &W, const std::vector<MsmProb> &probs, size_t n
             hipLaunchKernelGGL(k_msm_reduce_fused, dim3((unsigned)PW), dim3(fused_threads), lds, st, E, nb, S_in, C_in, S_fin, C_fin, nb_final);
         }
     }
-    if (J.dev_horner)      // many problems: their Horner chains run side by side on the device, one point per problem comes back
+    if (J.host8)           // many problems, AVX-512 IFMA host: the device adds up each window's bit-sums, the chains across the windows go to the host
+        hipLaunchKernelGGL(k_msm_wsum, grid1(PW * 4), dim3(TPB), 0, st, (u32)PW, (const ge *)S_fin, (const ge *)C_fin, nb_final, hres_dev);
+    else if (J.dev_horner)      // many problems: their Horner chains run side by side on the device, one point per problem comes back
         hipLaunchKernelGGL(k_msm_horner, dim3((unsigned)np), dim3(256), 0, st, mw, (const ge *)S_fin, (const ge *)C_fin, nb_final, hres_dev);
     return J;
 }
@@ -935,7 +943,17 @@ void msm_finish(Ctx &C, const MsmJob &J, std::vector<ge5> &results, const MsmOpt
     double t0 = now_ms();
     results.resize(np);
     std::vector<double> cpu_each(np, 0.0);
-    if (J.dev_horner) {
+    if (J.host8) {
+        // h holds one point per (problem, window): eight problems per task run their 253-step chains in the lanes of one AVX-512 stream
+        u32 pos[64];
+        for (u32 w = 0; w < P.W; w++) pos[w] = w + 1 == P.W ? 253 - P.c : (w < P.wide ? w * P.c : P.wide * P.c + (w - P.wide) * (P.c - 1));      // msm_window's layout
+        C.pool->run((np + 7) / 8, [&](size_t b) {
+            size_t p0 = b * 8; int lanes = (int)std::min<size_t>(8, np - p0);
+            ge5 out[8];
+            h8::horner8(out, lanes, (int)P.W, pos, [&](int l, int w) { return (const ge *)&h[(p0 + (size_t)l) * P.W + (size_t)w]; });
+            for (int l = 0; l < lanes; l++) { results[p0 + l] = out[l]; if (opt.post) opt.post(p0 + l); }
+        });
+    } else if (J.dev_horner) {
         if (opt.post) C.pool->run(np, [&](size_t p) { results[p] = h51::from_ge_loose(h[p]); opt.post(p); });
         else for (size_t p = 0; p < np; p++) results[p] = h51::from_ge_loose(h[p]);
     } else if (J.fb()) {
@@ -2621,6 +2639,41 @@ int rofl_dbg_host_bench(int what, unsigned iters, double *ns_out) {
     } else return ROFL_BAD_PARAM;
     *ns_out = (now_ms() - t0) * 1e6 / iters; (void)sink;
     return ROFL_OK;
+}
+// host51x8.hpp against host51.hpp: 8 x W pseudo-random window sums through the SIMD chain and through the scalar one.
+// Returns 0 when all eight results agree, 1 on a mismatch, -1 when the CPU has no AVX-512 IFMA (nothing tested).
+int rofl_dbg_host_horner8_selftest(unsigned W, unsigned c, int lanes, double *us_simd, double *us_scalar) {
+    if (!h8::available()) return -1;
+    if (W < 2 || W > 64 || c < 2 || c > 16 || lanes < 1 || lanes > 8) return ROFL_BAD_PARAM;
+    static const uint8_t Bc[32] = {0xe2, 0xf2, 0xae, 0x0a, 0x6a, 0xbc, 0x4e, 0x71, 0xa8, 0x84, 0xa9, 0x61, 0xc5, 0x00, 0x51, 0x5f,
+                                   0x58, 0xe3, 0x0b, 0x6a, 0xa5, 0x82, 0xdd, 0x8d, 0xb6, 0xa6, 0x59, 0x45, 0xe0, 0x8d, 0x2d, 0x76};
+    ge b; ristretto_decode(b, Bc);
+    u32 pos[64]; for (unsigned w = 0; w < W; w++) pos[w] = w * c;
+    std::vector<ge> pts(8 * W);
+    ge5 cur = h51::from_ge(b);
+    for (size_t i = 0; i < pts.size(); i++) {
+        cur = h51::gadd(h51::gdouble(cur), h51::from_ge(b)); if (i % 3 == 0) cur = h51::gdouble(cur);
+        pts[i] = h51::to_ge(cur);
+        if (i % 4 == 1) { u64 cy = 0; const u32 pw[8] = {0xffffffedu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0x7fffffffu};      // a loose representative: X + p
+                          for (int k = 0; k < 8; k++) { cy += (u64)pts[i].X.v[k] + pw[k]; pts[i].X.v[k] = (u32)cy; cy >>= 32; } }
+    }
+    auto wsum = [&](int l, int w) { return (const ge *)&pts[(size_t)l * W + w]; };
+    uint8_t ref[8][32], got[8][32];
+    double t0 = now_ms();
+    for (int l = 0; l < lanes; l++) {
+        ge5 acc = h51::from_ge_loose(*wsum(l, (int)W - 1));
+        for (int w = (int)W - 2; w >= 0; w--) { for (u32 i = pos[w]; i < pos[w + 1]; i++) acc = h51::gdouble(acc); acc = h51::gadd(acc, h51::from_ge_loose(*wsum(l, w))); }
+        h51::encode(ref[l], acc);
+    }
+    double t1 = now_ms();
+    ge5 out[8];
+    h8::horner8(out, lanes, (int)W, pos, wsum);
+    double t2 = now_ms();
+    int bad = 0;
+    for (int l = 0; l < lanes; l++) { h51::encode(got[l], out[l]); bad |= memcmp(got[l], ref[l], 32) != 0; }
+    if (us_simd) *us_simd = (t2 - t1) * 1e3;
+    if (us_scalar) *us_scalar = (t1 - t0) * 1e3;
+    return bad;
 }
 int rofl_dbg_host_fe_mul(const uint8_t a[32], const uint8_t b[32], uint8_t out[32]) { fe_tobytes(out, fe_mul(fe_frombytes(a), fe_frombytes(b))); return 0; }
 int rofl_dbg_host_fe_ops(const uint8_t a[32], const uint8_t b[32], uint8_t oa[32], uint8_t os[32], uint8_t oq[32], uint8_t oi[32]) {

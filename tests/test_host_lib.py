@@ -187,3 +187,15 @@ def test_knob_registry_is_complete_and_documented():
     design = open(os.path.join(ROOT, "DESIGN.md")).read()
     a, b = design.index("<!-- knobs:begin -->") + len("<!-- knobs:begin -->"), design.index("<!-- knobs:end -->")
     assert design[a:b].strip() == g.table().strip(), "run: python scripts/gen_knob_table.py --write"
+
+
+def test_simd_window_chains_match_the_scalar_ones(hiplib):
+    """csrc/host51x8.hpp: eight 253-step window chains per AVX-512 IFMA instruction stream (what a launch with many problems hands back to the
+    host) against the scalar chain of host51.hpp -- tight and loose input representatives, full and partial lane counts, the window layouts
+    the MSMs use.  Skipped (return code -1) on a CPU without AVX-512 IFMA, where the library keeps the device-side chains."""
+    L = hiplib
+    us = (ctypes.c_double(), ctypes.c_double())
+    rcs = [L.rofl_dbg_host_horner8_selftest(W, c, lanes, ctypes.byref(us[0]), ctypes.byref(us[1])) for W, c, lanes in ((37, 7, 8), (26, 10, 8), (20, 13, 5), (16, 16, 1), (64, 4, 3), (2, 16, 8))]
+    if rcs[0] == -1:
+        pytest.skip("no AVX-512 IFMA on this CPU")
+    assert rcs == [0] * len(rcs), rcs

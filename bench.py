@@ -467,7 +467,9 @@ def run_rank(args):
     for name in ktot:
         ktot[name] = {"ms": 0.0, "launches": 0, "fe_muls": 0, "bytes": 0}
     KI = min(K, 6)
-    if os.environ.get("ROFL_BENCH_NOTIMING") != "1":
+    if world > 1:      # (rank 0 alone past this point: no more collectives, hence no more steps -- the table then holds the timed steps' kernel only)
+        ktot["k_msm_accumulate_fb"] = dict(dom_timed); agg.update(agg_timed); KI = K; instr_elapsed = None
+    elif os.environ.get("ROFL_BENCH_NOTIMING") != "1":
         R.set_timing(1)
         step(args.warmup, False)
         ti0 = time.perf_counter()

@@ -1,0 +1,374 @@
+// The prover of librofl_zk.so (bulletproofs RangeProof::prove_multiple with lazily folded generators): transcript helpers + prove_chunks.
+// Included by rofl_zk.hip inside its anonymous namespace, after host_msm.hpp.
+#pragma once
+
+// ---------------------------------------------------------------- transcript helpers
+void tr_append_point(Merlin &t, const char *label, const ge5 &p, uint8_t *enc_out) {
+    uint8_t e[32]; h51::encode(e, p); t.append(label, e, 32); if (enc_out) memcpy(enc_out, e, 32);
+}
+void fill_pow2(sc *tab, sc base_mont, int count) { tab[0] = base_mont; for (int i = 1; i < count; i++) tab[i] = sc_montmul(tab[i - 1], tab[i - 1]); }
+
+sc sum_partials(const sc *p, size_t count, size_t stride, size_t which) {
+    sc acc = sc_zero();
+    for (size_t i = 0; i < count; i++) acc = sc_add(acc, p[i * stride + which]);
+    return acc;
+}
+
+// ================================================================ prover (bulletproofs RangeProof::prove_multiple)
+// P chunks of m values each; vshift [P][m] (device), blind_canon [P][m] (device).
+// Outputs: proofs (host, P*plen), V bytes (host, P*m*32).
+// nonces[c]: where chunk c draws its nonces (a device-resident stream or a seed, and the index of its first nonce);
+// proofs_out[c]: where chunk c's proof goes (host).  The chunks may belong to different clients (batched create).
+struct ChunkNonce { int mode; NonceSeed seed; const uint8_t *d_stream; u64 stream_scalars, base; };
+void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const u64 *d_vshift, const sc *d_blind,
+                  const std::vector<ChunkNonce> &nonces, const uint8_t *h_V /* [P][m][32] host */, uint8_t *const *proofs_out,
+                  hipEvent_t v_ready = nullptr /* recorded after the copy that fills h_V; nullptr: already complete */) {
+    size_t N = n * m; unsigned lgN = lg2u(N);
+    static const bool ptrace = knob("ROFL_TRACE") && atoi(knob("ROFL_TRACE")) >= 2;
+    double pt0 = now_ms(), ptl = pt0;
+    auto mark = [&](const char *what, long a = -1) {
+        if (!ptrace) return;
+        double t = now_ms(); fprintf(stderr, "[rofl-trace lane=%p] %-14s %6ld  +%.3f ms  (t=%.3f)\n", (void *)&C, what, a, t - ptl, t - pt0); ptl = t;
+    };
+    size_t plen = 32 * (9 + 2 * (size_t)lgN);
+    GensPin gens = get_gens(C, n, m);            // pinned until the proofs are done
+    niels *tbl = gens.tbl();
+    const niels *wtab = gens.wtab();
+    ChunkParams *h_cp = C.h_cp.as<ChunkParams>(P);
+    ChunkParams *d_cp = C.cp.as<ChunkParams>(P);
+    memset(h_cp, 0, sizeof(ChunkParams) * P);
+    u64 per = (u64)m * (2 * n + 4);
+    for (size_t c = 0; c < P; c++) {
+        h_cp[c].nonce_base = nonces[c].base; h_cp[c].nonce_mode = nonces[c].mode; h_cp[c].nonce_seed = nonces[c].seed;
+        h_cp[c].nonce_stream = nonces[c].d_stream; h_cp[c].nonce_stream_scalars = nonces[c].stream_scalars;
+    }
+    HIPCHK(hipMemcpyAsync(d_cp, h_cp, sizeof(ChunkParams) * P, hipMemcpyHostToDevice, C.stream));
+    sc *sL = C.sL.as<sc>(P * N), *sR = C.sR.as<sc>(P * N), *party = C.party.as<sc>(P * 4 * m), *Scanon = C.Scanon.as<sc>(P * 2 * N);
+    hipLaunchKernelGGL(k_nonce_expand, grid1(per, (u32)P), dim3(TPB), 0, C.stream, (u32)n, (u32)m, d_cp, sL, sR, party, Scanon);
+    // A partials: they depend on the values only and the host reads them after the S MSM -- side stream, beside the nonce expansion
+    if (!C.stream2) HIPCHK(hipStreamCreateWithFlags(&C.stream2, hipStreamNonBlocking));
+    if (!C.ev_a) { HIPCHK(hipEventCreateWithFlags(&C.ev_a, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&C.ev_a0, hipEventDisableTiming)); }
+    HIPCHK(hipEventRecord(C.ev_a0, C.stream));                    // d_vshift is ready (and the previous call's reads of `partial` are done)
+    HIPCHK(hipStreamWaitEvent(C.stream2, C.ev_a0, 0));
+    ge *partial = C.partial.as<ge>(P * m);
+    hipLaunchKernelGGL(k_bitcommit, grid1(m, (u32)P), dim3(TPB), 0, C.stream2, (u32)n, (u32)m, d_vshift, tbl, partial);
+    u32 nblkA = (u32)std::min<size_t>(16, (m + TPB - 1) / TPB);
+    ge *partial2 = C.partial2.as<ge>(P * nblkA);
+    hipLaunchKernelGGL(k_point_sum, dim3(nblkA, (u32)P), dim3(TPB), TPB * sizeof(ge), C.stream2, partial, (u32)m, partial2);
+    ge *h_A = C.h_part.as<ge>(P * nblkA);
+    HIPCHK(hipMemcpyAsync(h_A, partial2, sizeof(ge) * P * nblkA, hipMemcpyDeviceToHost, C.stream2));
+    HIPCHK(hipEventRecord(C.ev_a, C.stream2));
+    u32 nblkS = (u32)std::min<size_t>(16, (m + TPB - 1) / TPB);
+    sc *scpart = C.scpart.as<sc>(P * 64 * 3);
+    PowTabs *d_pt = C.powtabs.as<PowTabs>(P);
+    hipLaunchKernelGGL(k_party_sums, dim3(nblkS, (u32)P), dim3(TPB), 0, C.stream, (u32)m, 0, d_cp, (const PowTabs *)d_pt, party, d_blind, scpart);
+    sc *h_sc = C.h_misc2.as<sc>(P * 64 * 3);
+    HIPCHK(hipMemcpyAsync(h_sc, scpart, sizeof(sc) * P * nblkS * 3, hipMemcpyDeviceToHost, C.stream));
+    // S = <sL,G> + <sR,H> + s_bl * Bb
+    std::vector<MsmProb> probs(P); std::vector<ge5> res;
+    for (size_t c = 0; c < P; c++) probs[c] = MsmProb{tbl, Scanon + c * 2 * N};
+    C.tm.t.msm_terms += P * 2 * N;
+    mark("setup");
+    std::vector<Merlin> tr; tr.reserve(P);
+    std::vector<sc> a_bl(P), s_bl(P), y(P), z(P), zz(P), x(P), w(P);
+    for (size_t c = 0; c < P; c++) tr.emplace_back(label, strlen(label));
+    {
+        MsmOpt mo; if (wtab) { gens.fb_for(P, &mo.fb_wtab, &mo.fb_c); mo.fb_stride = 2 * N; }
+        mo.overlap = [&]() {      // the transcript prefix (m commitments per chunk) does not depend on S: hash it while the MSM runs
+            double t0 = now_ms();
+            if (v_ready) HIPCHK(hipEventSynchronize(v_ready));      // first in the stream: long done by the time the S launches are enqueued
+            C.pool->run(P, [&](size_t c) {
+                Merlin &t = tr[c];
+                t.append("dom-sep", (const uint8_t *)"rangeproof v1", 13);
+                t.append_u64("n", n); t.append_u64("m", m);
+                t.append32_run('V', h_V + c * m * 32, m);
+            });
+            C.tm.t.host_ms += now_ms() - t0;
+        };
+        msm_run(C, probs, 2 * N, res, mo);
+    }
+    mark("msm S");
+    HIPCHK(hipEventSynchronize(C.ev_a));      // the A partials (side stream: done long before the S MSM)
+
+    double th = now_ms();
+    C.pool->run(P, [&](size_t c) {
+        uint8_t *o = proofs_out[c];
+        Merlin &t = tr[c];
+        a_bl[c] = h_canon(sum_partials(h_sc + c * nblkS * 3, nblkS, 3, 0));
+        s_bl[c] = h_canon(sum_partials(h_sc + c * nblkS * 3, nblkS, 3, 1));
+        ge5 A = h_fixed_mul(C.ht.Bb5, a_bl[c]);
+        for (u32 k = 0; k < nblkA; k++) A = h51::gadd(A, h51::from_ge(h_A[c * nblkA + k]));
+        ge5 S = h51::gadd(res[c], h_fixed_mul(C.ht.Bb5, s_bl[c]));
+        tr_append_point(t, "A", A, o); tr_append_point(t, "S", S, o + 32);
+        y[c] = t.challenge_scalar("y"); z[c] = t.challenge_scalar("z");
+        zz[c] = h_mul(z[c], z[c]);
+        ChunkParams &cp = h_cp[c];
+        cp.y = h_mont(y[c]); cp.z = h_mont(z[c]); cp.zz = h_mont(zz[c]);
+        cp.yinv = h_mont(h_inv(y[c]));
+        fill_pow2(cp.ypow2, cp.y, MAX_LG); fill_pow2(cp.yinvpow2, cp.yinv, MAX_LG); fill_pow2(cp.zpow2, cp.z, MAX_LG);
+    });
+    C.tm.t.host_ms += now_ms() - th;
+    HIPCHK(hipMemcpyAsync(d_cp, h_cp, sizeof(ChunkParams) * P, hipMemcpyHostToDevice, C.stream));
+    u32 nblkT = (u32)std::min<size_t>(64, (N + TPB - 1) / TPB);
+    sc *tpart = C.tmp_out.as<sc>(P * 64 * 3);
+    hipLaunchKernelGGL(k_pow_tables, dim3((4 * PT_L * PT_E + TPB - 1) / TPB, (u32)P), dim3(TPB), 0, C.stream, d_cp, d_pt, lgN, 0);
+    hipLaunchKernelGGL(k_poly_t, dim3(nblkT, (u32)P), dim3(TPB), 0, C.stream, (u32)n, (u32)m, d_cp, (const PowTabs *)d_pt, d_vshift, sL, sR, C.d_two_pow, tpart);
+    hipLaunchKernelGGL(k_party_sums, dim3(nblkS, (u32)P), dim3(TPB), 0, C.stream, (u32)m, 1, d_cp, (const PowTabs *)d_pt, party, d_blind, scpart);
+    sc *h_t = C.h_part.as<sc>(P * 64 * 3);
+    HIPCHK(hipMemcpyAsync(h_t, tpart, sizeof(sc) * P * nblkT * 3, hipMemcpyDeviceToHost, C.stream));
+    HIPCHK(hipMemcpyAsync(h_sc, scpart, sizeof(sc) * P * nblkS * 3, hipMemcpyDeviceToHost, C.stream));
+    C.sync();
+    th = now_ms();
+    C.pool->run(P, [&](size_t c) {
+        uint8_t *o = proofs_out[c];
+        Merlin &t = tr[c];
+        sc t0 = h_canon(sum_partials(h_t + c * nblkT * 3, nblkT, 3, 0));
+        sc t1 = h_canon(sum_partials(h_t + c * nblkT * 3, nblkT, 3, 1));
+        sc t2 = h_canon(sum_partials(h_t + c * nblkT * 3, nblkT, 3, 2));
+        sc t1_bl = h_canon(sum_partials(h_sc + c * nblkS * 3, nblkS, 3, 0));
+        sc t2_bl = h_canon(sum_partials(h_sc + c * nblkS * 3, nblkS, 3, 1));
+        sc zvbl = h_canon(sum_partials(h_sc + c * nblkS * 3, nblkS, 3, 2));
+        ge5 T1 = h51::gadd(h_fixed_mul(C.ht.B5, t1), h_fixed_mul(C.ht.Bb5, t1_bl));
+        ge5 T2 = h51::gadd(h_fixed_mul(C.ht.B5, t2), h_fixed_mul(C.ht.Bb5, t2_bl));
+        tr_append_point(t, "T_1", T1, o + 64); tr_append_point(t, "T_2", T2, o + 96);
+        x[c] = t.challenge_scalar("x");
+        sc xx = h_mul(x[c], x[c]);
+        sc t_x = sc_add(sc_add(t0, h_mul(t1, x[c])), h_mul(t2, xx));
+        sc t_x_bl = sc_add(sc_add(zvbl, h_mul(t1_bl, x[c])), h_mul(t2_bl, xx));
+        sc e_bl = sc_add(a_bl[c], h_mul(s_bl[c], x[c]));
+        t.append_scalar("t_x", t_x); t.append_scalar("t_x_blinding", t_x_bl); t.append_scalar("e_blinding", e_bl);
+        sc_tobytes(o + 128, t_x); sc_tobytes(o + 160, t_x_bl); sc_tobytes(o + 192, e_bl);
+        w[c] = t.challenge_scalar("w");
+        h_cp[c].x = h_mont(x[c]);
+        h_cp[c].gscale = sc_one_mont(); h_cp[c].hscale = sc_one_mont();
+        // InnerProductProof::create
+        t.append("dom-sep", (const uint8_t *)"ipp v1", 6);
+        t.append_u64("n", N);
+    });
+    C.tm.t.host_ms += now_ms() - th;
+    HIPCHK(hipMemcpyAsync(d_cp, h_cp, sizeof(ChunkParams) * P, hipMemcpyHostToDevice, C.stream));
+    sc *a = C.a.as<sc>(P * N), *b = C.b.as<sc>(P * N), *yinvpow = C.yinv.as<sc>(P * N);
+    hipLaunchKernelGGL(k_lr_vec, grid1(N, (u32)P), dim3(TPB), 0, C.stream, (u32)n, (u32)m, d_cp, (const PowTabs *)d_pt, d_vshift, sL, sR, C.d_two_pow, a, b, yinvpow);
+    mark("poly/T/x");
+
+    // ---- IPP rounds with lazily folded generators
+    // Invariant: true G[j] = gscale * Gc[j], true H[j] = hscale * y^-j * Hc[j] for the materialised arrays Gc, Hc.
+    size_t n_g = N; unsigned r = 0;
+    std::vector<const niels *> cur(P, tbl);
+    std::vector<std::vector<sc>> pu(P), pui(P);    // pending challenges (Montgomery)
+    std::vector<sc> gscale(P, sc_one_mont()), hscale(P, sc_one_mont());
+    int gsel = 0; bool first_level = true;
+    auto stab = [&](size_t c, u32 h, sc &g, sc &hh) {
+        g = sc_one_mont(); hh = sc_one_mont();
+        for (unsigned q = 0; q < r; q++) {
+            bool bit = (h >> (r - 1 - q)) & 1;
+            g = sc_montmul(g, bit ? pu[c][q] : pui[c][q]);
+            hh = sc_montmul(hh, bit ? pui[c][q] : pu[c][q]);
+        }
+    };
+    sc *h_round = C.h_round.as<sc>(2 * P);
+    sc *a2 = C.a2.as<sc>(P * N), *b2 = C.b2.as<sc>(P * N);      // ping-pong partners of a, b (k_ipp_round folds out of place)
+    static const bool ipp_fused = !(knob("ROFL_IPP_FUSED") && atoi(knob("ROFL_IPP_FUSED")) == 0);
+    static const bool fold_regs = !(knob("ROFL_FOLD_REGS") && atoi(knob("ROFL_FOLD_REGS")) == 0);
+    bool just_materialised = false, ab_on_host = false;
+    sc *ptab[2] = {C.ptab[0].as<sc>(P * 2 * N), C.ptab[1].as<sc>(P * 2 * N)}; int psel = 0;      // pending-challenge product tables (ping-pong)
+    std::unique_ptr<std::atomic<int>[]> lr_done(new std::atomic<int>[P]);
+    for (unsigned round = 0; round < lgN; round++) {
+        size_t n_k = n_g >> r, nh = n_k / 2;
+        sc *SL = C.SL.as<sc>(P * 2 * n_g), *SR = C.SR.as<sc>(P * 2 * n_g);
+        bool merged = C.msm_lr != 0;
+        bool fused = merged && ipp_fused && round > 0;           // one launch: fold by the previous challenge + this round's scalars + inner products
+        u32 nblkI;
+        sc *h_ip = C.h_ip.as<sc>(P * 256 * 2);                     // the partial sums land in mapped host memory
+        if (fused) {
+            nblkI = (u32)std::min<size_t>(256, std::max<size_t>(1, (n_g + TPB - 1) / TPB));      // one slot per thread while the 256 partial-sum rows last (the tail rounds are one 13-multiplication chain deep)
+            int use_new = just_materialised ? 0 : 1;
+            hipLaunchKernelGGL(k_ipp_round, dim3(nblkI, (u32)P), dim3(TPB), 0, C.stream, (u32)n_g, (u32)n_k, use_new ? r - 1 : 0u, use_new, d_cp,
+                               (const sc *)C.h_round.dev<sc>(2 * P), (const sc *)a, (const sc *)b, a2, b2, N, yinvpow, N, SL, C.h_ip.dev<sc>(P * 256 * 2),
+                               (const sc *)ptab[psel], ptab[psel ^ 1], N, n_k == 2 ? C.h_abfin.dev<sc>(4 * P) : (sc *)nullptr);
+            if (n_k == 2) ab_on_host = true;
+            std::swap(a, a2); std::swap(b, b2); psel ^= 1;
+        } else {
+            hipLaunchKernelGGL(k_ipp_scalars, grid1(n_g, (u32)P), dim3(TPB), 0, C.stream, (u32)n_g, (u32)n_k, r, d_cp, a, b, N, yinvpow, N, SL, SR, merged ? 1 : 0);
+            nblkI = (u32)std::min<size_t>(32, (nh + TPB - 1) / TPB);
+            hipLaunchKernelGGL(k_ipp_inner, dim3(nblkI, (u32)P), dim3(TPB), 0, C.stream, (u32)nh, a, b, N, C.h_ip.dev<sc>(P * 256 * 2));
+        }
+        just_materialised = false;
+        std::vector<MsmProb> pr(2 * P);
+        for (size_t c = 0; c < P; c++) { pr[2 * c] = MsmProb{cur[c], SL + c * 2 * n_g}; pr[2 * c + 1] = MsmProb{cur[c], (merged ? SL : SR) + c * 2 * n_g}; }
+        C.tm.t.msm_terms += P * 2 * n_g;
+        MsmOpt mo;
+        if (merged) { mo.lr_nh = (u32)nh; mo.lr_ng = (u32)n_g; }
+        if (first_level && wtab) { gens.fb_for(2 * P, &mo.fb_wtab, &mo.fb_c); mo.fb_stride = 2 * N; }
+        // The host tail of the round runs inside the MSM's own pool tasks: the thread that finishes problem 2c (+1) adds c_L w B (c_R w B)
+        // and encodes L (R); the second of a chunk's two to get there hashes both into the transcript, draws u and inverts it.  L and R
+        // of a chunk are encoded side by side and the hop has one pool hand-off instead of two.
+        for (size_t c = 0; c < P; c++) lr_done[c].store(0);
+        mo.post = [&](size_t p) {
+            size_t c = p >> 1; int side = (int)(p & 1);
+            uint8_t *o = proofs_out[c] + 7 * 32 + 64 * round;
+            sc cx = h_canon(sum_partials(h_ip + c * nblkI * 2, nblkI, 2, (size_t)side));
+            h51::encode(o + 32 * side, h51::gadd(res[p], h_fixed_mul(C.ht.B5, h_mul(cx, w[c]))));
+            if (lr_done[c].fetch_add(1) != 1) return;          // the chunk's other point is still on its way
+            tr[c].append("L", o, 32); tr[c].append("R", o + 32, 32);
+            sc u = tr[c].challenge_scalar("u");
+            sc um = h_mont(u), uim = h51::sc_invert_mont_fast(um);
+            h_round[2 * c] = um; h_round[2 * c + 1] = uim;          // mapped: k_ipp_fold_ab reads it and records it in the chunk's pending list
+            h_cp[c].pend_u[pu[c].size()] = um; h_cp[c].pend_ui[pu[c].size()] = uim;
+            pu[c].push_back(um); pui[c].push_back(uim);
+        };
+        msm_run(C, pr, 2 * n_g, res, mo);
+        mark("round msm", (long)(2 * n_g));
+        bool last = (round + 1 == lgN);
+        // the fold of a, b by this challenge happens inside the next round's k_ipp_round; only the old three-kernel path and the
+        // last round (whose result is the proof's final a, b) fold here
+        if ((last && !ab_on_host) || !(merged && ipp_fused))
+            hipLaunchKernelGGL(k_ipp_fold_ab, grid1(nh, (u32)P), dim3(TPB), 0, C.stream, (u32)nh, d_cp, (const sc *)C.h_round.dev<sc>(2 * P), r, a, b, N);
+        r++;
+        unsigned t_now = first_level ? (unsigned)C.fold_t1 : (unsigned)C.fold_t;
+        // fold_min is a per-chunk size chosen for P = 4 (below it the fold kernel is latency-bound); what matters is the number of
+        // outputs in the launch, so many small chunks (n_partition = 64) keep folding down to 64 generators each
+        size_t n_after = n_g >> r;
+        bool fold_pays = n_after >= C.fold_min || (n_after >= 64 && 2 * P * n_after >= 8 * C.fold_min);
+        if (!last && r >= t_now && fold_pays) {
+            // materialise: new[i] = sum_h s_h * cur[h*n_new + i]; with fold_unit the common factor s_0 moves into
+            // gscale / hscale so that source 0 needs a single addition
+            size_t n_new = n_g >> r; u32 nsrc = 1u << r;
+            bool use_tab = first_level && C.fold_tab;
+            int unit = C.fold_unit;
+            FoldTabCfg fc = gens.fc();
+            size_t dstride = use_tab ? (size_t)fc.np * FOLD_TAB_DIGITS : 256;
+            th = now_ms();
+            int8_t *h_dig = C.h_fdig.as<int8_t>(2 * P * nsrc * dstride);      // the fold's own pinned staging: nothing else writes them while its copies are queued
+            memset(h_dig, 0, 2 * P * nsrc * dstride);
+            FoldProb *h_fp = C.h_fprob.as<FoldProb>(2 * P + 2 * P);
+            FoldTabProb *h_ftp = reinterpret_cast<FoldTabProb *>(h_fp + 2 * P);
+            niels *gnew = C.gbuf[gsel].as<niels>(P * 2 * n_new);
+            // (per chunk and independent: on the pool -- at n_partition = 64 this loop was 1.0-1.4 ms of one thread with the GPU idle, three times per proof)
+            std::vector<int> topc(P, 0);
+            C.pool->run(P, [&](size_t c) {
+                int top = 0;
+                sc yn = sc_one_mont();                       // y^-(h*n_new), stepping by y^-n_new
+                sc ystep = sc_one_mont();
+                { size_t e = n_new; int bidx = 0; while (e) { if (e & 1) ystep = sc_montmul(ystep, h_cp[c].yinvpow2[bidx]); e >>= 1; bidx++; } }
+                // s_G(0) = prod uinv and s_G(all ones) = prod u = 1 / s_G(0); for H the roles of u and uinv swap
+                sc g0, h0; stab(c, 0, g0, h0);
+                sc gall, hall; stab(c, nsrc - 1, gall, hall);
+                for (u32 h = 0; h < nsrc; h++) {
+                    sc g, hh; stab(c, h, g, hh);
+                    hh = sc_montmul(hh, yn);
+                    yn = sc_montmul(yn, ystep);
+                    if (unit) {
+                        if (h == 0) continue;                 // scalar 1: handled by one addition in the kernel
+                        g = sc_montmul(g, gall); hh = sc_montmul(hh, hall);
+                    }
+                    sc gc = h_canon(g), hc = h_canon(hh);
+                    if (use_tab) {
+                        for (u32 pc = 0; pc < fc.np; pc++) {
+                            auto piece = [&](const sc &s) {
+                                u32 bit0 = pc * fc.pb; u64 lo = (u64)s.v[bit0 / 32] | ((bit0 / 32 + 1 < 8) ? (u64)s.v[bit0 / 32 + 1] << 32 : 0);
+                                lo >>= (bit0 % 32);
+                                return fc.pb == 64 ? lo : (lo & (((u64)1 << fc.pb) - 1));
+                            };
+                            int t1 = wnaf_u64(h_dig + (((2 * c) * nsrc + h) * fc.np + pc) * FOLD_TAB_DIGITS, piece(gc), fc.w);
+                            int t2 = wnaf_u64(h_dig + (((2 * c + 1) * nsrc + h) * fc.np + pc) * FOLD_TAB_DIGITS, piece(hc), fc.w);
+                            top = std::max(top, std::max(t1, t2));
+                        }
+                    } else {
+                        int t1 = sc_naf(h_dig + ((2 * c) * nsrc + h) * 256, gc);
+                        int t2 = sc_naf(h_dig + ((2 * c + 1) * nsrc + h) * 256, hc);
+                        top = std::max(top, std::max(t1, t2));
+                    }
+                }
+                if (unit) { gscale[c] = sc_montmul(gscale[c], g0); hscale[c] = sc_montmul(hscale[c], h0); h_cp[c].gscale = gscale[c]; h_cp[c].hscale = hscale[c]; }
+                h_fp[2 * c] = FoldProb{cur[c], gnew + c * 2 * n_new};
+                h_fp[2 * c + 1] = FoldProb{cur[c] + n_g, gnew + c * 2 * n_new + n_new};
+                h_ftp[2 * c] = FoldTabProb{0u, gnew + c * 2 * n_new};
+                h_ftp[2 * c + 1] = FoldTabProb{(u32)n_g, gnew + c * 2 * n_new + n_new};
+                topc[c] = top;
+            });
+            int top = 0; for (int t : topc) top = std::max(top, t);
+            C.tm.t.host_ms += now_ms() - th;
+            int8_t *d_dig = C.naf.as<int8_t>(2 * P * nsrc * dstride);
+            HIPCHK(hipMemcpyAsync(d_dig, h_dig, 2 * P * nsrc * dstride, hipMemcpyHostToDevice, C.stream));
+            void *d_fpv = C.foldprobs.ensure(2 * P * 16);
+            if (use_tab) HIPCHK(hipMemcpyAsync(d_fpv, h_ftp, sizeof(FoldTabProb) * 2 * P, hipMemcpyHostToDevice, C.stream));
+            else HIPCHK(hipMemcpyAsync(d_fpv, h_fp, sizeof(FoldProb) * 2 * P, hipMemcpyHostToDevice, C.stream));
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (C.tm.enabled) { e0 = C.tm.get(); e1 = C.tm.get(); HIPCHK(hipEventRecord(e0, C.stream)); }
+            {
+                // segment the digit positions so that K threads share one output with equal work
+                u32 K = 1;
+                size_t thr = (size_t)2 * P * n_new;
+                // (segments trade extra doublings for parallelism: not worth it while other calls keep the GPU busy)
+                while (K < FOLD_MAXSEG && thr * K < (size_t)C.fold_threads / (C.crowded() ? 2 : 1)) K *= 2;
+                if (C.fold_k > 0) K = (u32)C.fold_k;
+                FoldSeg seg{};
+                double eff = (double)(nsrc - (unit ? 1 : 0));
+                double cst = 1.0 + (use_tab ? eff * fc.np / (fc.w + 1.0) : eff / 3.0), lo_t = 0, hi_t = (top + 1) * cst + top + 1;
+                int bounds[FOLD_MAXSEG + 1];
+                for (int it = 0; it < 60; it++) {
+                    double T = 0.5 * (lo_t + hi_t), pos = 0;
+                    for (u32 k = 0; k < K; k++) { double len = (T - pos) / cst; if (len < 0) len = 0; pos += len; }
+                    if (pos >= top + 1) hi_t = T; else lo_t = T;
+                }
+                { double pos = 0; bounds[0] = 0; for (u32 k = 0; k < K; k++) { double len = (hi_t - pos) / cst; if (len < 0) len = 0; pos += len; bounds[k + 1] = (int)(pos + 0.5); } }
+                bounds[K] = top + 1;
+                for (u32 k = 1; k <= K; k++) if (bounds[k] < bounds[k - 1]) bounds[k] = bounds[k - 1];
+                for (u32 k = 0; k <= FOLD_MAXSEG; k++) seg.lo[k] = bounds[k <= K ? k : K];
+                dim3 grid((unsigned)((n_new + 63) / 64), (u32)(2 * P)), block(64, K);
+                uint64_t nz = 0;
+                if (C.tm.enabled) { size_t tot_d = 2 * P * nsrc * dstride; for (size_t q = 0; q < tot_d; q++) nz += h_dig[q] != 0; }
+                // algorithmic work per output: the non-zero digits of its problem (mixed additions) and ONE chain of top+1 doublings
+                // (the K-1 redundant chains of a segmented launch buy latency, they are not work)
+                uint64_t fold_muls = (nz * 7 / (2 * P) + (uint64_t)(top + 1) * 8 + 7) * (uint64_t)(2 * P * n_new);
+                KSpan ks_fold(C.tm, C.stream, use_tab ? ROFL_TK_FOLD_TAB : ROFL_TK_FOLD, fold_muls, (uint64_t)2 * P * n_g * 32 + (uint64_t)2 * P * n_new * 32);
+                if (use_tab)
+                    hipLaunchKernelGGL(k_fold_gens_tab, grid, block, (K - 1) * 64 * sizeof(ge), C.stream, (u32)n_new, nsrc, seg, fc, tbl, (size_t)(2 * N),
+                                       (const FoldTabProb *)d_fpv, d_dig, unit);
+                else if (nsrc == 4 && unit && fold_regs)      // three scalar-carrying sources, kept in registers
+                    hipLaunchKernelGGL(k_fold_gens4, grid, block, (K - 1) * 64 * sizeof(ge), C.stream, (u32)n_new, seg, (const FoldProb *)d_fpv, d_dig);
+                else
+                    hipLaunchKernelGGL(k_fold_gens, grid, block, (K - 1) * 64 * sizeof(ge), C.stream, (u32)n_new, nsrc, seg, (const FoldProb *)d_fpv, d_dig, unit);
+            }
+            if (C.tm.enabled) { HIPCHK(hipEventRecord(e1, C.stream)); C.tm.fold_ev.push_back({e0, e1}); C.tm.t.fold_launches++; { char tg[96]; snprintf(tg, sizeof tg, "fold n_g=%zu nsrc=%u tab=%d", n_g, nsrc, (int)use_tab); C.tm.fold_tag.push_back(tg); } C.tm.t.fold_point_reads += (uint64_t)2 * P * n_g; }
+            HIPCHK(hipMemcpyAsync(d_cp, h_cp, sizeof(ChunkParams) * P, hipMemcpyHostToDevice, C.stream));   // gscale / hscale
+            // no sync here: the next round's launches queue up behind the fold on the same stream (their enqueue cost hides under it); the
+            // pinned digit / problem staging buffers are not written again before the next fold, at least two synchronised rounds away
+            if (ptrace) C.sync();      // the phase trace wants the fold's own wall time
+            mark("fold", (long)n_new);
+            for (size_t c = 0; c < P; c++) { cur[c] = gnew + c * 2 * n_new; pu[c].clear(); pui[c].clear(); }
+            n_g = n_new; r = 0; gsel ^= 1; first_level = false; just_materialised = true;
+        }
+    }
+    // a[0], b[0]
+    if (ab_on_host) {      // the last round's kernel left a_0, a_1, b_0, b_1 (Montgomery) in mapped host memory, the hop left u, u^-1 in h_round
+        const sc *q = C.h_abfin.as<sc>(4 * P);
+        for (size_t c = 0; c < P; c++) {
+            uint8_t *o = proofs_out[c] + 7 * 32 + 64 * lgN;
+            const sc &um = h_round[2 * c], &uim = h_round[2 * c + 1];
+            sc_tobytes(o, h_canon(sc_add(sc_montmul(q[4 * c], um), sc_montmul(q[4 * c + 1], uim))));
+            sc_tobytes(o + 32, h_canon(sc_add(sc_montmul(q[4 * c + 2], uim), sc_montmul(q[4 * c + 3], um))));
+        }
+        if (ptrace) {
+            fprintf(stderr, "[rofl-hops] %d msm calls: enqueue %.3f ms, sync wait %.3f, horner wall %.3f (max task cpu %.3f), round-host wall %.3f (max task cpu %.3f)\n",
+                    C.hs.n, C.hs.enqueue, C.hs.sync, C.hs.horner_wall, C.hs.horner_cpu, C.hs.host_wall, C.hs.host_cpu);
+            C.hs = Ctx::HopStats();
+        }
+        return;
+    }
+    sc *h_ab = C.h_part.as<sc>(2 * P);
+    // element 0 of every chunk: two strided copies (one copy per chunk and vector costs ~7 us of stream time each -- 0.9 ms at n_partition = 64)
+    HIPCHK(hipMemcpy2DAsync(h_ab, 2 * sizeof(sc), a, N * sizeof(sc), sizeof(sc), P, hipMemcpyDeviceToHost, C.stream));
+    HIPCHK(hipMemcpy2DAsync(h_ab + 1, 2 * sizeof(sc), b, N * sizeof(sc), sizeof(sc), P, hipMemcpyDeviceToHost, C.stream));
+    C.sync();
+    for (size_t c = 0; c < P; c++) {
+        uint8_t *o = proofs_out[c] + 7 * 32 + 64 * lgN;
+        sc_tobytes(o, h_canon(h_ab[2 * c])); sc_tobytes(o + 32, h_canon(h_ab[2 * c + 1]));
+    }
+    if (ptrace) {
+        fprintf(stderr, "[rofl-hops] %d msm calls: enqueue %.3f ms, sync wait %.3f, horner wall %.3f (max task cpu %.3f), round-host wall %.3f (max task cpu %.3f)\n",
+                C.hs.n, C.hs.enqueue, C.hs.sync, C.hs.horner_wall, C.hs.horner_cpu, C.hs.host_wall, C.hs.host_cpu);
+        C.hs = Ctx::HopStats();
+    }
+}

@@ -1,0 +1,616 @@
+// Host runtime of librofl_zk.so: tuning-knob registry, error plumbing, host scalar / point helpers, the per-lane thread pool, device and
+// pinned buffers, timing, the lane context (Ctx) and the generator-table cache.  Included by rofl_zk.hip inside its anonymous namespace.
+#pragma once
+
+// ---------------------------------------------------------------- tuning knobs
+// Every ROFL_* environment variable the library reads, in ONE table (scripts/gen_knob_table.py turns it into the table of DESIGN.md and
+// tests/test_host_lib.py checks that no other name is read).  Knobs never change results -- proofs, commitments and verdicts are the same
+// for every setting (the behaviour switches of rofl_set_option are the exception and are marked "option") -- they move work between
+// variants, and most of them exist because an experiment in DESIGN.md needed them.  Read once per process (or per device context).
+struct Knob { const char *name, *dflt, *what; };
+static const Knob KNOBS[] = {
+    {"ROFL_LANES", "3", "calls that can be in flight on a device (HIP stream + workspace each); 1..8"},
+    {"ROFL_HOST_THREADS", "usable cores, in [2, 16]", "threads of the primary lane's host pool (window combination, encodings, transcripts of a round); other lanes: 6"},
+    {"ROFL_POOL_SPIN_US", "400", "how long an idle pool worker polls for the next job before it sleeps (0 = sleep at once)"},
+    {"ROFL_BLOCKING_SYNC", "-1", "option blocking_sync: -1 spin while <= 3 calls are in flight, 0 always spin, 1 sleep between polls"},
+    {"ROFL_VERIFY_ZIP_TRUNCATE", "0", "option verify_zip_truncate: 1 = the reference's zip-truncating verify_rangeproof"},
+    {"ROFL_VERIFY_BATCH", "1", "option verify_batch: 0 = one check per proof instead of one per client"},
+    {"ROFL_SIGMA_BATCH", "1", "option sigma_batch: 0 = one check per element in the Sigma-proof verifiers"},
+    {"ROFL_GENS_BUDGET_MB", "98304", "HBM budget of the generator-table cache (LRU eviction of unpinned entries beyond it)"},
+    {"ROFL_FOLD_T1", "3", "IPP rounds before the first generator fold (1..6)"},
+    {"ROFL_FOLD_T", "2", "IPP rounds between later folds (1..6)"},
+    {"ROFL_FOLD_MIN", "1024", "no fold once fewer generators per chunk would remain (launches with many chunks fold down to 64)"},
+    {"ROFL_FOLD_TAB", "1", "0 = first fold without the precomputed odd-multiple slices"},
+    {"ROFL_FOLD_PB", "32", "piece width of the fold table in bits (16, 32, 64)"},
+    {"ROFL_FOLD_W", "8", "NAF width of the fold table (3..8; narrowed until the table fits ROFL_FOLD_TAB_MB)"},
+    {"ROFL_FOLD_TAB_MB", "32768", "HBM budget of one (n, m) fold table"},
+    {"ROFL_FOLD_UNIT", "1", "0 = do not keep the common factor s_0 of a fold in gscale / hscale"},
+    {"ROFL_FOLD_K", "0", "digit-position segments per fold output (1, 2, 4; 0 = by launch size)"},
+    {"ROFL_FOLD_THREADS", "131072", "fold launches with fewer threads split their chains into segments"},
+    {"ROFL_FOLD_REGS", "1", "0 = the generic fold kernel instead of the three-sources-in-registers one"},
+    {"ROFL_IPP_FUSED", "1", "0 = k_ipp_fold_ab + k_ipp_scalars + k_ipp_inner instead of one k_ipp_round per round"},
+    {"ROFL_MSM_LR", "1", "0 = separate L and R scalar arrays (with zeros) instead of the merged layout"},
+    {"ROFL_MSM_FB", "1", "0 = no window tables (every MSM generic)"},
+    {"ROFL_MSM_FB_MIN", "4096", "generator sets smaller than this get no window table"},
+    {"ROFL_MSM_FB_C", "0", "one window width (13, 15, 16) for every window table; 0 = 16-bit tables, plus a 15-bit one for generator sets below 2^17 that launches with many problems and the verifier use"},
+    {"ROFL_MSM_FB_THREADS", "524288", "accumulate threads a fixed-base launch aims for (decides the number of bucket sets)"},
+    {"ROFL_MSM_TWO_LEVEL", "1", "0 = slot sort instead of the two-level bucket sort in fixed-base launches"},
+    {"ROFL_MSM_SLOTS", "1", "0 = count / scan / scatter sort only (no fixed-capacity structures)"},
+    {"ROFL_MSM_LDS", "1", "0 = per-item global atomics instead of LDS ranking in the slot sort"},
+    {"ROFL_MSM_LDS_MIN", "8192", "MSMs with fewer terms use the per-item slot sort"},
+    {"ROFL_MSM_LDS_TILE", "131072", "items one block of the LDS slot sort ranks"},
+    {"ROFL_MSM_SMALL_MAX", "8192", "terms per side up to which a generic MSM runs as one fused launch (0 = off)"},
+    {"ROFL_MSM_HOST8", "1", "0 = launches with many problems combine their windows on the device (k_msm_horner) even when the host has AVX-512 IFMA"},
+    {"ROFL_MSM_DEV_HORNER_MIN", "32", "launches with at least this many problems combine their windows on the device"},
+    {"ROFL_MSM_T13", "8192", "generic MSMs from this many terms on use 13-bit windows"},
+    {"ROFL_MSM_T10", "512", "generic MSMs from this many terms on use 10-bit windows (7-bit below, 4-bit below 64)"},
+    {"ROFL_MSM_C", "0", "window width of every generic MSM (4, 7, 10, 13, 16; 0 = by size)"},
+    {"ROFL_MSM_GROUP_REDUCE", "0", "1 = two-launch bucket reduction by groups of 512 (measured slower)"},
+    {"ROFL_RED_SPLIT", "0", "1 = four threads per 8-group in k_msm_reduce_level (measured slower)"},
+    {"ROFL_RED_FUSED_T", "512", "largest block of k_msm_reduce_fused"},
+    {"ROFL_ACC_BALANCE", "1", "0 = accumulate blocks in plain descending-load order instead of equal-work blocks"},
+    {"ROFL_TRACE", "0", "1 = one line per MSM on stderr, 2 = per-phase host timeline of every proof / verification"},
+    {"ROFL_DBG_IDX_MASK", "0x7fffffff", "timing experiments only (WRONG results): confines the table gathers to a prefix"},
+    {"ROFL_DBG_SCATTER", "0", "timing experiments only (WRONG results): 1 = no range reservation, 2 = no slot stores"},
+    {"ROFL_DBG_SMALL_TIMELINE", "", "set: per-phase block timings of every fused small-MSM launch on stderr (synchronises; debugging)"},
+    {"ROFL_DBG_ACC_TIMELINE", "", "file to append per-wave start / end / placement records of every fixed-base accumulate launch to"},
+    {"ROFL_FEMUL_LDS", "0", "rofl_bench_femul: dynamic LDS per block (pins the micro-benchmark's occupancy)"},
+    {"ROFL_FEMUL_MODE", "0", "rofl_bench_femul: 0 multiplication chain, 1-3 mixed addition from registers / a 32 KB table / a gathered table"},
+    {"ROFL_FEMUL_TABLE", "2097152", "rofl_bench_femul mode 3: table entries (128 B each)"},
+};
+// getenv restricted to the table above
+const char *knob(const char *name) {
+#ifndef NDEBUG
+    bool known = false; for (const Knob &k : KNOBS) known |= !strcmp(k.name, name);
+    if (!known) { fprintf(stderr, "librofl_zk: unregistered knob %s\n", name); abort(); }
+#endif
+    return getenv(name);
+}
+
+// ---------------------------------------------------------------- error plumbing
+thread_local std::string g_err;
+int fail(int code, const std::string &msg) { g_err = msg; return code; }
+struct HipErr { hipError_t e; const char *what; };
+#define HIPCHK(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) throw HipErr{e__, #x}; } while (0)
+
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// ---------------------------------------------------------------- host scalar helpers (canonical <-> Montgomery)
+sc h_mont(const sc &canon) { return sc_to_mont(canon); }
+sc h_canon(const sc &mont) { return sc_from_mont(mont); }
+sc h_mul(const sc &a, const sc &b) { return sc_mul_plain(a, b); }          // canonical * canonical
+sc h_inv(const sc &canon) { return h_canon(h51::sc_invert_mont_fast(h_mont(canon))); }
+bool sc_is_canonical_bytes(const uint8_t *b) { sc s = sc_frombytes(b); return !sc_geq_l(s.v); }
+
+// width-2 NAF (digits -1,0,1) of a canonical scalar; returns index of the highest non-zero digit (-1 if zero)
+int sc_naf(int8_t out[256], const sc &k) {
+    u32 x[9]; for (int i = 0; i < 8; i++) x[i] = k.v[i]; x[8] = 0;
+    int top = -1;
+    for (int pos = 0; pos < 256; pos++) {
+        int d = 0;
+        if (x[0] & 1) {
+            d = 2 - (int)(x[0] & 3);          // 1 -> +1, 3 -> -1
+            if (d > 0) { x[0] -= 1; }
+            else { u64 c = 1; for (int i = 0; i < 9 && c; i++) { c += x[i]; x[i] = (u32)c; c >>= 32; } }
+            top = pos;
+        }
+        out[pos] = (int8_t)d;
+        for (int i = 0; i < 8; i++) x[i] = (x[i] >> 1) | (x[i + 1] << 31);
+        x[8] >>= 1;
+    }
+    return top;
+}
+
+// width-4 NAF (digits in +-{1,3,5,7}) of a 64-bit piece; returns the highest non-zero position (-1 if zero)
+// width-w NAF of a piece of at most 64 bits: odd digits |d| < 2^(w-1), at most one non-zero among w consecutive positions
+int wnaf_u64(int8_t out[FOLD_TAB_DIGITS], u64 piece, unsigned w) {
+    unsigned __int128 k = piece; int top = -1;
+    const int full = 1 << w, half = 1 << (w - 1);
+    for (int pos = 0; pos < FOLD_TAB_DIGITS; pos++) {
+        int d = 0;
+        if (k & 1) { d = (int)(k & (unsigned)(full - 1)); if (d >= half) d -= full; if (d >= 0) k -= (unsigned)d; else k += (unsigned)(-d); top = pos; }
+        out[pos] = (int8_t)d; k >>= 1;
+    }
+    return top;
+}
+
+// ---------------------------------------------------------------- host point helpers
+using h51::ge5; using h51::niels5;
+struct HostTables { std::vector<niels> B, Bb; std::vector<niels5> B5, Bb5; ge base, bblind; };
+
+void build_fixed_table(std::vector<niels> &tab, ge P) {
+    tab.resize(64 * 8);
+    for (int w = 0; w < 64; w++) {
+        ge acc = P;
+        for (int e = 0; e < 8; e++) {
+            tab[w * 8 + e] = ge_to_niels(acc);
+            acc = ge_add(acc, P);
+        }
+        for (int k = 0; k < 4; k++) P = ge_double(P);
+    }
+}
+ge5 h_fixed_mul(const std::vector<niels5> &tab, const sc &k_canon) {
+    ge5 acc = h51::identity();
+    int carry = 0;
+    for (int i = 0; i < 64; i++) {
+        int v = (int)((k_canon.v[i >> 3] >> ((i & 7) * 4)) & 15) + carry;
+        carry = (v + 8) >> 4;
+        int d = v - (carry << 4);
+        if (d > 0) acc = h51::gmadd(acc, tab[i * 8 + d - 1], false);
+        else if (d < 0) acc = h51::gmadd(acc, tab[i * 8 - d - 1], true);
+    }
+    return acc;
+}
+void to_tab5(std::vector<niels5> &o, const std::vector<niels> &t) { o.resize(t.size()); for (size_t i = 0; i < t.size(); i++) o[i] = h51::from_niels(t[i]); }
+ge h_fixed_mul32(const std::vector<niels> &tab, const sc &k_canon) {
+    ge acc = ge_identity();
+    int carry = 0;
+    for (int i = 0; i < 64; i++) {
+        int v = (int)((k_canon.v[i >> 3] >> ((i & 7) * 4)) & 15) + carry;
+        carry = (v + 8) >> 4;
+        int d = v - (carry << 4);
+        if (d > 0) acc = ge_madd(acc, tab[i * 8 + d - 1], false);
+        else if (d < 0) acc = ge_madd(acc, tab[i * 8 - d - 1], true);
+    }
+    return acc;
+}
+
+// cores this process may use: the affinity mask, capped by the cgroup v2 CPU quota (the GPU boxes show 256 CPUs under a 16-core quota)
+int usable_cores() {
+    int n = (int)std::thread::hardware_concurrency(); if (n < 1) n = 1;
+    cpu_set_t set; CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof set, &set) == 0) { int c = CPU_COUNT(&set); if (c > 0 && c < n) n = c; }
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[64]; long per = 0;
+        if (fscanf(f, "%63s %ld", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) { long c = atol(q) / per; if (c >= 1 && c < n) n = (int)c; }
+        fclose(f);
+    }
+    return n;
+}
+// ---------------------------------------------------------------- small host thread pool
+// The per-round host tails (one Horner chain + transcript per chunk) are independent across chunks.
+class HostPool {
+    std::vector<std::thread> workers; std::mutex mu; std::condition_variable cv;
+    std::function<void(size_t)> fn; std::atomic<size_t> count{0}, next{0}, done{0}; std::atomic<int> active{0}; std::atomic<uint64_t> gen{0}; bool stop = false;
+    double spin_us = 400.0;      // ROFL_POOL_SPIN_US: how long an idle worker polls for the next job before it sleeps
+    const std::atomic<int> *calls_in_flight = nullptr;      // polling is for a call that is alone on the device: with several in flight the pools of the lanes would fight over the cores
+    // An index is claimed only after it has been checked against `count` (compare-and-swap, not fetch-add): a worker that wakes
+    // late and arrives while run() is resetting the job (count == 0 in that window) must not consume an index of the next job --
+    // with a blind fetch-add it could take index 0 between `next = 0` and `count = n` and drop it, and run() would wait forever.
+    void work() {
+        active.fetch_add(1);
+        for (;;) {
+            size_t i = next.load();
+            if (i >= count.load()) break;
+            if (!next.compare_exchange_weak(i, i + 1)) continue;
+            fn(i); done.fetch_add(1);
+        }
+        active.fetch_sub(1);
+    }
+    // A worker that has just finished a job polls for the next one for a short while before it sleeps: the hops of a proof follow each
+    // other at 0.1-0.3 ms, and a sleeping thread has to be put back on a CPU by the scheduler first -- on a busy host (the GPU boxes run
+    // at a load average above 20) that wake-up is where multi-millisecond outliers of a 25 ms proof came from.
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            if (spin_us > 0 && (!calls_in_flight || calls_in_flight->load(std::memory_order_relaxed) <= 1)) {
+                auto t0 = std::chrono::steady_clock::now();
+                while (gen.load(std::memory_order_acquire) == seen) {
+                    __builtin_ia32_pause();
+                    if (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > spin_us) break;
+                }
+            }
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return stop || gen.load() != seen; }); if (stop) return; seen = gen.load(); }
+            work();
+        }
+    }
+public:
+    explicit HostPool(int nthreads, const std::atomic<int> *in_flight = nullptr) : calls_in_flight(in_flight) {
+        if (const char *e = knob("ROFL_POOL_SPIN_US")) spin_us = atof(e);
+        for (int i = 1; i < nthreads; i++) workers.emplace_back([this] { loop(); });
+    }
+    ~HostPool() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); for (auto &t : workers) t.join(); }
+    void run(size_t n, std::function<void(size_t)> f) {
+        if (n <= 1 || workers.empty()) { for (size_t i = 0; i < n; i++) f(i); return; }
+        while (active.load() > 0) std::this_thread::yield();     // no straggler of the previous job may still look at fn
+        { std::lock_guard<std::mutex> lk(mu); count = 0; fn = std::move(f); done = 0; next = 0; count = n; gen++; }
+        cv.notify_all();
+        work();
+        while (done.load() < n) std::this_thread::yield();
+        // workers that woke late see next >= count and go back to sleep; make sure none is still inside work()
+        // with a stale fn before the next run() replaces it: done == n implies every claimed index finished.
+    }
+};
+
+// ---------------------------------------------------------------- device buffers
+struct DevBuf {
+    void *p = nullptr; size_t cap = 0;
+    void *ensure(size_t bytes) {
+        if (bytes > cap) {
+            if (p) HIPCHK(hipFree(p));
+            p = nullptr; cap = 0;
+            size_t want = bytes + bytes / 8 + 256;
+            HIPCHK(hipMalloc(&p, want)); cap = want;
+        }
+        return p;
+    }
+    template <class T> T *as(size_t count) { return reinterpret_cast<T *>(ensure(count * sizeof(T))); }
+};
+// Pinned host memory that kernels can address directly (mapped, coherent): small per-round results go from the kernels straight
+// into it and per-round challenges are read from it -- no hipMemcpyAsync on the hop (each costs 10-15 us of host time).
+struct PinBuf {
+    void *p = nullptr, *dp = nullptr; size_t cap = 0;
+    void *ensure(size_t bytes) {
+        if (bytes > cap) {
+            if (p) HIPCHK(hipHostFree(p));
+            p = nullptr; dp = nullptr; cap = 0;
+            HIPCHK(hipHostMalloc(&p, bytes + 256, hipHostMallocMapped)); cap = bytes + 256;
+            HIPCHK(hipHostGetDevicePointer(&dp, p, 0));
+        }
+        return p;
+    }
+    template <class T> T *as(size_t count) { return reinterpret_cast<T *>(ensure(count * sizeof(T))); }
+    template <class T> T *dev(size_t count) { ensure(count * sizeof(T)); return reinterpret_cast<T *>(dp); }      // the same memory, as the device sees it
+};
+
+struct Timing {
+    bool enabled = false;      // the full instrumentation: per-kind spans, accumulate / fold events, first / last
+    bool acc_only = false;     // only the spans of the fixed-base accumulation (rofl_set_timing(2)): ten event records per proof instead of ~150
+    rofl_timing_t t{};
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> acc_ev, fold_ev;
+    std::vector<std::string> acc_tag, fold_tag;
+    struct KEv { int kind; hipEvent_t e0, e1; uint64_t fe_muls, bytes; };
+    std::vector<KEv> kev;                                  // per-kernel-kind spans (rofl_last_kernel_times)
+    rofl_kernel_time_t kt[ROFL_TK_COUNT]{};
+    hipEvent_t first = nullptr, last = nullptr;
+    std::vector<hipEvent_t> pool; size_t used = 0;
+    hipEvent_t get() {
+        if (used == pool.size()) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); pool.push_back(e); }
+        return pool[used++];
+    }
+    void reset() { t = rofl_timing_t{}; acc_ev.clear(); fold_ev.clear(); acc_tag.clear(); fold_tag.clear(); kev.clear(); for (auto &k : kt) k = rofl_kernel_time_t{}; used = 0; first = last = nullptr; }
+};
+// HIP events around the launches of one kernel kind, with the algorithmic work of those launches (field multiplications: 7 per
+// mixed addition, 8 per doubling, 9 per extended addition; bytes: the data the launch has to read and write at least once)
+struct KSpan {
+    Timing *tm = nullptr; hipStream_t s = nullptr; size_t idx = 0;
+    KSpan(Timing &t, hipStream_t st, int kind, uint64_t fe_muls, uint64_t bytes) {
+        if (!t.enabled && !(t.acc_only && kind == ROFL_TK_MSM_ACCUMULATE_FB)) return;
+        tm = &t; s = st; idx = t.kev.size();
+        t.kev.push_back(Timing::KEv{kind, t.get(), t.get(), fe_muls, bytes});
+        HIPCHK(hipEventRecord(t.kev[idx].e0, s));
+    }
+    ~KSpan() { if (tm) (void)hipEventRecord(tm->kev[idx].e1, s); }
+    KSpan(const KSpan &) = delete; KSpan &operator=(const KSpan &) = delete;
+};
+
+// Workspace of one MSM in flight on a lane (a lane holds two: the verifier queues its two MSMs behind one synchronisation)
+struct MsmWs {
+    DevBuf cnt, off, cur, tail, perm, sorted, ovf, buckets, S[2], Cacc[2], probs;
+    PinBuf h_res, h_ovf, h_probs;
+    std::vector<MsmProb> probs_on_dev;      // what `probs` holds on the device: an unchanged problem list is not uploaded again
+};
+
+// One cached BulletproofGens::new(n, m): [G(N) | H(N)] + fold slices (tbl), the 16 window slices of the fixed-base MSM (wtab)
+struct GensEntry { niels *tbl = nullptr; ndm *wtab = nullptr, *wtab_many = nullptr; u32 wc = 16, wc_many = 0; FoldTabCfg fc{}; size_t bytes = 0, n = 0, m = 0; u64 tick = 0; int users = 0; };
+
+// One Ctx = one "lane": a HIP stream with its own workspace, staging buffers, timing and host pool.  The primary
+// lane of a device owns the shared read-only state (fixed-base tables, generator cache).  An API call runs on one
+// lane; concurrent calls from different host threads (the reference's server verifies clients from a thread pool,
+// server.rs:656-687) take different lanes, so the latency-bound phases of one call (small rounds, host Horner,
+// transcripts) overlap the throughput-bound phases of another.  ROFL_LANES = size of the pool.
+struct Ctx {
+    int device = 0;
+    bool inited = false;
+    Ctx *parent = nullptr;
+    std::vector<Ctx *> sibs;      // additional lanes
+    int nlanes = 3;      // ROFL_LANES: number of calls that can be in flight on this device
+    std::mutex init_mu, gens_mu;      // primary lane only: one-time initialisation; generator-table cache
+    std::atomic<int> active_calls{0};  // primary lane only: calls currently holding a lane
+    std::atomic<unsigned> rr{0};
+    hipStream_t stream = nullptr, stream2 = nullptr;      // stream2: side stream for work that may run beside the main one (created on first use)
+    std::mutex mu;
+    HostTables ht;
+    niels *d_tabB = nullptr, *d_tabBb = nullptr;
+    sc *d_two_pow = nullptr;
+    std::map<std::pair<size_t, size_t>, std::unique_ptr<GensEntry>> gens;   // (n, m) -> tables; primary lane only, under gens_mu
+    u64 gens_tick = 0; size_t gens_budget = (size_t)96 << 30;   // ROFL_GENS_BUDGET_MB: evict least recently used (unpinned) tables beyond this
+    u32 fold_pb = 32, fold_w = 8; size_t fold_tab_budget = (size_t)32 << 30;   // widest NAF whose table fits the per-(n, m) budget (ROFL_FOLD_W, ROFL_FOLD_TAB_MB)
+    int msm_lds = 1, msm_two_level = 1, msm_group_reduce = 0; size_t msm_lds_min = 8192, msm_lds_tile = 131072;
+    size_t msm_fb_threads = (size_t)1 << 19;
+    int msm_fb = 1; size_t msm_fb_min = (size_t)1 << 12; int msm_lr = 1;   // window tables for every (n, m) with 2N >= 4096: many small chunks (n_partition = 64) share them
+    bool crowded() const { const Ctx *P = parent ? parent : this; return P->active_calls.load() > 1; }   // other calls in flight on this device
+    // Waiting for the lane's stream.  hipStreamSynchronize spins (lowest latency: right for a call that is alone on the device); with
+    // more than three calls in flight -- or when the host asked for it (ROFL_BLOCKING_SYNC=1) -- the thread sleeps between queries instead, so
+    // a server that keeps several clients in flight does not burn one host core per client on busy-waiting (ROFL_BLOCKING_SYNC=0: always spin).
+    // behaviour options (rofl_set_option; primary lane only -- the lanes read their parent's): the environment only provides defaults
+    int opt_zip_truncate = 0, opt_verify_batch = 1, opt_sigma_batch = 1;
+    int blocking_sync = -1; hipEvent_t ev_block = nullptr, ev_v = nullptr, ev_fork = nullptr, ev_a = nullptr, ev_a0 = nullptr, ev_m2 = nullptr, ev_m2j = nullptr; bool batch_mode = false;
+    void sync() {
+        const Ctx *P = parent ? parent : this;
+        // (up to three calls in flight still spin: the three proofs of ONE client's L2 update run side by side -- EncParamsL2::encrypt --
+        //  and that is a latency case; a server with more clients in flight is a throughput case)
+        bool block = P->blocking_sync == 1 || (P->blocking_sync < 0 && (P->active_calls.load() > 3 || batch_mode));
+        if (!block) { HIPCHK(hipStreamSynchronize(stream)); return; }
+        // (hipEventSynchronize on a hipEventBlockingSync event still keeps the calling thread runnable on this runtime -- measured: 100 %
+        //  of a core either way -- so the wait is a query loop with short sleeps: ~50 us of extra latency per wait, no CPU)
+        if (!ev_block) HIPCHK(hipEventCreateWithFlags(&ev_block, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(ev_block, stream));
+        for (;;) {
+            hipError_t q = hipEventQuery(ev_block);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) throw HipErr{q, "hipEventQuery"};
+            struct timespec ts = {0, 20000}; nanosleep(&ts, nullptr);
+        }
+    }
+    struct Bsgs { uint8_t *keys; u32 *slots; u32 mask; };
+    std::map<size_t, Bsgs> bsgs;                          // table_size -> baby-step table
+    std::unique_ptr<HostPool> pool;
+    size_t fold_min = 1024;
+    size_t msm_small_max = 8192;      // ROFL_MSM_SMALL_MAX: generic MSMs with at most this many terms per problem side run as one fused launch (0 = off)
+    size_t msm_dev_horner_min = 32;   // ROFL_MSM_DEV_HORNER_MIN: launches with at least this many problems finish their Horner chains on the device
+    bool msm_slots = true;
+    int fold_t = 2, fold_t1 = 3, fold_k = 0, fold_tab = 1, fold_unit = 1; long fold_threads = 131072;
+    Timing tm;
+    struct HopStats { double enqueue = 0, sync = 0, horner_wall = 0, horner_cpu = 0, host_wall = 0, host_cpu = 0; int n = 0; } hs;      // ROFL_TRACE: where the host hops go
+    // workspace
+    DevBuf cp, sL, sR, party, Scanon, vshift, blind, Vbytes, Cbytes, status, partial, partial2, scpart, a, b, a2, b2, ptab[2], yinv,
+        SL, SR, powtabs, foldprobs, naf,
+        gbuf[2], aux_pts, aux_scal, vscal, tmp_in, tmp_in2, tmp_out, vals, uni, stream_buf;
+    PinBuf h_cp, h_part, h_misc, h_misc2, h_auxc, h_auxs, h_V, h_ip, h_round, h_fdig, h_fprob, h_abfin;
+    MsmWs mws[2];
+
+    void init() {
+        if (inited) return;
+        HIPCHK(hipSetDevice(device));
+        HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        // PedersenGens::default(): B = Ristretto basepoint, B_blinding = hash_from_bytes::<Sha3_512>(B)
+        static const uint8_t Bc[32] = {0xe2, 0xf2, 0xae, 0x0a, 0x6a, 0xbc, 0x4e, 0x71, 0xa8, 0x84, 0xa9, 0x61, 0xc5, 0x00, 0x51, 0x5f,
+                                       0x58, 0xe3, 0x0b, 0x6a, 0xa5, 0x82, 0xdd, 0x8d, 0xb6, 0xa6, 0x59, 0x45, 0xe0, 0x8d, 0x2d, 0x76};
+        ristretto_decode(ht.base, Bc);
+        uint8_t h[64]; sha3_512(h, Bc, 32);
+        ht.bblind = ristretto_from_uniform(h);
+        build_fixed_table(ht.B, ht.base);
+        build_fixed_table(ht.Bb, ht.bblind);
+        to_tab5(ht.B5, ht.B); to_tab5(ht.Bb5, ht.Bb);
+        HIPCHK(hipFuncSetAttribute((const void *)k_msm_reduce_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void *)k_msm_small, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));      // + 2.5 KB of static LDS (bucket order)
+        HIPCHK(hipFuncSetAttribute((const void *)k_msm_scatter_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void *)k_msm_reduce_groups, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void *)k_msm_bin_l1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void *)k_msm_bin_l2, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        HIPCHK(hipMalloc(&d_tabB, sizeof(niels) * 512));
+        HIPCHK(hipMalloc(&d_tabBb, sizeof(niels) * 512));
+        HIPCHK(hipMemcpy(d_tabB, ht.B.data(), sizeof(niels) * 512, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d_tabBb, ht.Bb.data(), sizeof(niels) * 512, hipMemcpyHostToDevice));
+        sc tp[64]; sc two = h_mont(sc_from_u64(2)); tp[0] = sc_one_mont();
+        for (int i = 1; i < 64; i++) tp[i] = sc_montmul(tp[i - 1], two);
+        HIPCHK(hipMalloc(&d_two_pow, sizeof(tp)));
+        HIPCHK(hipMemcpy(d_two_pow, tp, sizeof(tp), hipMemcpyHostToDevice));
+        if (const char *e = knob("ROFL_FOLD_T")) { int v = atoi(e); if (v >= 1 && v <= 6) fold_t = v; }
+        if (const char *e = knob("ROFL_MSM_SLOTS")) msm_slots = atoi(e) != 0;
+        if (const char *e = knob("ROFL_MSM_FB")) msm_fb = atoi(e);
+        if (const char *e = knob("ROFL_MSM_FB_THREADS")) { long v = atol(e); if (v >= 1) msm_fb_threads = (size_t)v; }
+        if (const char *e = knob("ROFL_MSM_LDS")) msm_lds = atoi(e);
+        if (const char *e = knob("ROFL_MSM_TWO_LEVEL")) msm_two_level = atoi(e);
+        if (const char *e = knob("ROFL_MSM_GROUP_REDUCE")) msm_group_reduce = atoi(e);
+        if (const char *e = knob("ROFL_MSM_LDS_MIN")) { long v = atol(e); if (v >= 1) msm_lds_min = (size_t)v; }
+        if (const char *e = knob("ROFL_MSM_LDS_TILE")) { long v = atol(e); if (v >= 1024) msm_lds_tile = (size_t)v; }
+        if (const char *e = knob("ROFL_MSM_LR")) msm_lr = atoi(e);
+        if (const char *e = knob("ROFL_MSM_FB_MIN")) { long v = atol(e); if (v >= 1) msm_fb_min = (size_t)v; }
+        if (const char *e = knob("ROFL_FOLD_MIN")) { long v = atol(e); if (v >= 1) fold_min = (size_t)v; }
+        if (const char *e = knob("ROFL_MSM_DEV_HORNER_MIN")) { long v = atol(e); if (v >= 1) msm_dev_horner_min = (size_t)v; }
+        if (const char *e = knob("ROFL_MSM_SMALL_MAX")) { long v = atol(e); if (v >= 0) msm_small_max = (size_t)v; }
+        {   // host pool of the primary lane: the per-round tails of many chunks (n_partition = 64: 128 window combinations, 128 encodings,
+            // 64 transcripts per round) scale with it -- 8 -> 14 threads took 3 ms off a 35 ms proof.  Default: the cores this process may
+            // use (affinity mask capped by the cgroup CPU quota; the calling thread is one of the pool's executors), within [2, 16].
+            int nt = std::min(16, std::max(2, usable_cores()));
+            if (const char *e = knob("ROFL_HOST_THREADS")) nt = atoi(e);
+            if (nt < 1) nt = 1; if (nt > 64) nt = 64;
+            pool.reset(new HostPool(nt, &active_calls)); }
+        if (const char *e = knob("ROFL_FOLD_T1")) { int v = atoi(e); if (v >= 1 && v <= 6) fold_t1 = v; }
+        if (const char *e = knob("ROFL_FOLD_TAB")) fold_tab = atoi(e) != 0;
+        if (const char *e = knob("ROFL_GENS_BUDGET_MB")) { long v = atol(e); if (v >= 1) gens_budget = (size_t)v << 20; }
+        if (const char *e = knob("ROFL_FOLD_PB")) { int v = atoi(e); if (v == 16 || v == 32 || v == 64) fold_pb = (u32)v; }
+        if (const char *e = knob("ROFL_FOLD_W")) { int v = atoi(e); if (v >= 3 && v <= 8) fold_w = (u32)v; }
+        if (const char *e = knob("ROFL_FOLD_TAB_MB")) { long v = atol(e); if (v >= 1) fold_tab_budget = (size_t)v << 20; }
+        if (const char *e = knob("ROFL_FOLD_UNIT")) fold_unit = atoi(e) != 0;
+        if (const char *e = knob("ROFL_FOLD_K")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) fold_k = v; }
+        if (const char *e = knob("ROFL_FOLD_THREADS")) { long v = atol(e); if (v > 0) fold_threads = v; }
+        if (const char *e = knob("ROFL_LANES")) { int v = atoi(e); if (v >= 1 && v <= 8) nlanes = v; }
+        if (const char *e = knob("ROFL_BLOCKING_SYNC")) blocking_sync = atoi(e) != 0;
+        if (const char *e = knob("ROFL_VERIFY_ZIP_TRUNCATE")) opt_zip_truncate = atoi(e) != 0;
+        if (const char *e = knob("ROFL_VERIFY_BATCH")) opt_verify_batch = atoi(e) != 0;
+        if (const char *e = knob("ROFL_SIGMA_BATCH")) opt_sigma_batch = atoi(e) != 0;
+        inited = true;
+        for (int i = 1; i < nlanes; i++) { Ctx *s = new Ctx(); s->init_lane(*this); sibs.push_back(s); }
+    }
+    void init_lane(Ctx &p) {
+        parent = &p; device = p.device;
+        HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        ht = p.ht; d_tabB = p.d_tabB; d_tabBb = p.d_tabBb; d_two_pow = p.d_two_pow;
+        msm_lds = p.msm_lds; msm_two_level = p.msm_two_level; msm_group_reduce = p.msm_group_reduce; msm_lds_min = p.msm_lds_min; msm_lds_tile = p.msm_lds_tile;
+        msm_fb_threads = p.msm_fb_threads;
+        msm_fb = p.msm_fb; msm_fb_min = p.msm_fb_min; msm_lr = p.msm_lr;
+        fold_min = p.fold_min; msm_dev_horner_min = p.msm_dev_horner_min; msm_small_max = p.msm_small_max; msm_slots = p.msm_slots; fold_t = p.fold_t; fold_t1 = p.fold_t1; fold_k = p.fold_k; fold_tab = p.fold_tab;
+        fold_unit = p.fold_unit; fold_threads = p.fold_threads; nlanes = 1;
+        { int nt = 6; if (const char *e = knob("ROFL_HOST_THREADS")) nt = atoi(e); if (nt < 1) nt = 1; pool.reset(new HostPool(nt, &p.active_calls)); }
+        inited = true;
+    }
+};
+
+// NB the HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and reads the variable once, when
+// it initialises; lanes that share a queue serialise each other's kernels.  The library does not touch the process environment:
+// a host that wants more than four calls in flight exports GPU_MAX_HW_QUEUES itself before the first HIP call.
+
+std::mutex g_ctx_mu;
+std::map<int, Ctx *> g_ctxs;
+int g_device = 0;
+Ctx &ctx() {
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    auto it = g_ctxs.find(g_device);
+    if (it == g_ctxs.end()) { Ctx *c = new Ctx(); c->device = g_device; it = g_ctxs.emplace(g_device, c).first; }
+    return *it->second;
+}
+
+// A lane held for the duration of one API call.
+struct LaneLock {
+    Ctx *c = nullptr; Ctx *primary = nullptr; std::unique_lock<std::mutex> lk;
+    LaneLock() = default;
+    LaneLock(LaneLock &&o) noexcept : c(o.c), primary(o.primary), lk(std::move(o.lk)) { o.c = nullptr; o.primary = nullptr; }
+    ~LaneLock() { if (primary) primary->active_calls.fetch_sub(1); }
+};
+LaneLock acquire_lane(bool primary_only = false) {
+    Ctx &P = ctx();
+    { std::lock_guard<std::mutex> g(P.init_mu); P.init(); }
+    HIPCHK(hipSetDevice(P.device));                    // the calling thread may be new to HIP
+    LaneLock ll; ll.primary = &P; P.active_calls.fetch_add(1);
+    size_t L = primary_only ? 1 : 1 + P.sibs.size();
+    for (size_t i = 0; i < L; i++) {
+        Ctx *c = i ? P.sibs[i - 1] : &P;
+        std::unique_lock<std::mutex> t(c->mu, std::try_to_lock);
+        if (t.owns_lock()) { ll.c = c; ll.lk = std::move(t); c->batch_mode = false; return ll; }
+    }
+    size_t i = primary_only ? 0 : P.rr.fetch_add(1) % L;    // all busy: queue on one of them
+    Ctx *c = i ? P.sibs[i - 1] : &P;
+    ll.lk = std::unique_lock<std::mutex>(c->mu); ll.c = c; c->batch_mode = false;
+    return ll;
+}
+
+inline dim3 grid1(size_t n, u32 y = 1) { return dim3((unsigned)((n + TPB - 1) / TPB), y, 1); }
+unsigned lg2u(size_t x) { unsigned r = 0; while (((size_t)1 << r) < x) r++; return r; }
+bool is_pow2(size_t x) { return x && !(x & (x - 1)); }
+size_t next_pow2(size_t val) { if (val == 1) return 1; size_t n = val - 1; while ((n & (n - 1)) != 0) n &= n - 1; return n << 1; }
+
+// ---------------------------------------------------------------- generators
+struct MsmPlan { u32 c, W, B, levels, wide; };
+MsmPlan msm_plan_c(u32 c) {
+    MsmPlan p; p.c = c;
+    p.W = (253 - p.c + p.c - 1) / p.c + 1;                // top window [253-c, 254) + ceil((253-c)/c) lower windows
+    p.wide = (253 - p.c) - (p.c - 1) * (p.W - 1);          // wide*c + (W-1-wide)*(c-1) = 253 - c
+    p.B = 1u << (p.c - 1);
+    p.levels = (p.c - 1) / 3;
+    return p;
+}
+// 0 = the default layouts (16-bit windows; small generator sets also get a 15-bit table for launches with many problems)
+u32 fb_window_c(size_t gens) {
+    static const int force = knob("ROFL_MSM_FB_C") ? atoi(knob("ROFL_MSM_FB_C")) : 0;      // tuning: one layout (13, 15 or 16) for every table and launch
+    (void)gens;
+    return (force == 13 || force == 15 || force == 16) ? (u32)force : 0u;
+}
+// Generator-table cache, shared by the lanes of a device.  An entry is pinned (users > 0) for the duration of every call that
+// reads it; eviction (LRU, beyond gens_budget, or to make room after a failed hipMalloc) only ever frees unpinned entries, so it is
+// safe with any number of calls in flight.  (n, m) reach this point from untrusted wire messages: callers validate the proof
+// format against (n, m) BEFORE asking for tables, and an allocation failure degrades (evict, then the compact table layout, then
+// no window table) instead of leaving the device full.
+void gens_free_entry(GensEntry *e) {
+    if (e->wtab) (void)hipFree(e->wtab);
+    if (e->wtab_many) (void)hipFree(e->wtab_many);
+    e->wtab_many = nullptr;
+    if (e->tbl) (void)hipFree(e->tbl);
+    e->wtab = nullptr; e->tbl = nullptr;
+}
+// caller holds gens_mu.  Frees unpinned entries, least recently used first, until `keep_bytes` or less are held.
+void gens_evict(Ctx &P0, size_t keep_bytes, const GensEntry *spare) {
+    for (;;) {
+        size_t total = 0; for (auto &kv : P0.gens) total += kv.second->bytes;
+        if (total <= keep_bytes) return;
+        auto victim = P0.gens.end();
+        for (auto it = P0.gens.begin(); it != P0.gens.end(); ++it)
+            if (it->second.get() != spare && it->second->users == 0 && (victim == P0.gens.end() || it->second->tick < victim->second->tick)) victim = it;
+        if (victim == P0.gens.end()) return;       // everything left is in use
+        gens_free_entry(victim->second.get());
+        P0.gens.erase(victim);
+    }
+}
+hipError_t gens_malloc(Ctx &P0, void **p, size_t bytes, const GensEntry *spare) {
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipSuccess) return e;
+    (void)hipGetLastError();
+    gens_evict(P0, 0, spare);                      // drop every table nobody is reading, then try once more
+    e = hipMalloc(p, bytes);
+    if (e != hipSuccess) (void)hipGetLastError();
+    return e;
+}
+struct GensPin {
+    Ctx *P0 = nullptr; GensEntry *e = nullptr;
+    GensPin() = default;
+    GensPin(Ctx *p, GensEntry *en) : P0(p), e(en) {}
+    GensPin(GensPin &&o) noexcept : P0(o.P0), e(o.e) { o.P0 = nullptr; o.e = nullptr; }
+    GensPin &operator=(GensPin &&o) noexcept { release(); P0 = o.P0; e = o.e; o.P0 = nullptr; o.e = nullptr; return *this; }
+    GensPin(const GensPin &) = delete; GensPin &operator=(const GensPin &) = delete;
+    ~GensPin() { release(); }
+    void release() { if (e) { std::lock_guard<std::mutex> lk(P0->gens_mu); e->users--; } e = nullptr; }
+    niels *tbl() const { return e->tbl; }
+    const niels *wtab() const { return reinterpret_cast<const niels *>(e->wtab); }      // opaque to the host: 128-byte ndm records
+    u32 wc() const { return e->wc; }                                                    // window width of the window table's layout
+    // the table to use for a launch of `problems` bucket-array owners: small generator sets carry a second, 15-bit layout for launches with
+    // many problems (n_partition = 64), where 16-bit windows would spread a handful of entries per bucket over millions of buckets
+    void fb_for(size_t problems, const niels **tab, u32 *c) const {
+        if (e->wtab_many && problems >= 32) { *tab = reinterpret_cast<const niels *>(e->wtab_many); *c = e->wc_many; }
+        else { *tab = reinterpret_cast<const niels *>(e->wtab); *c = e->wc; }
+    }
+    const FoldTabCfg &fc() const { return e->fc; }
+};
+GensPin get_gens(Ctx &C, size_t n, size_t m) {
+    Ctx &P0 = C.parent ? *C.parent : C;
+    std::lock_guard<std::mutex> gens_lock(P0.gens_mu);
+    auto key = std::make_pair(n, m);
+    auto it = P0.gens.find(key);
+    if (it != P0.gens.end()) { it->second->tick = ++P0.gens_tick; it->second->users++; return GensPin(&P0, it->second.get()); }
+    size_t N = n * m;
+    std::unique_ptr<GensEntry> ent(new GensEntry());
+    FoldTabCfg fc{P0.fold_pb, P0.fold_w, 256 / P0.fold_pb, 1u << (P0.fold_w - 2)};
+    // HBM capacity for VALU work: a width-w NAF needs 2^(w-2) odd multiples per piece and leaves 1/(w+1) of the digits non-zero
+    while (fc.w > 6 && sizeof(niels) * 2 * N * fc.np * fc.e > P0.fold_tab_budget) { fc.w--; fc.e = 1u << (fc.w - 2); }
+    if (sizeof(niels) * 2 * N * fc.np * fc.e > ((size_t)40 << 30)) fc = FoldTabCfg{64, 4, 4, 4};     // very large tables: the compact layout
+    void *tblv = nullptr;
+    hipError_t me = gens_malloc(P0, &tblv, sizeof(niels) * 2 * N * fc.np * fc.e, nullptr);      // slice 0 = generators, the rest = fold tables
+    if (me != hipSuccess && !(fc.pb == 64 && fc.w == 4)) {      // HBM is short even after eviction: the compact fold-table layout (16 slices)
+        fc = FoldTabCfg{64, 4, 4, 4};
+        me = gens_malloc(P0, &tblv, sizeof(niels) * 2 * N * fc.np * fc.e, nullptr);
+    }
+    if (me != hipSuccess) throw HipErr{me, "hipMalloc(generator tables)"};
+    niels *tbl = reinterpret_cast<niels *>(tblv);
+    ent->tbl = tbl; ent->fc = fc; ent->n = n; ent->m = m;
+    ent->bytes = sizeof(niels) * 2 * N * fc.np * fc.e;
+    try {
+        uint8_t *uni = C.uni.as<uint8_t>(2 * N * 64);
+        hipLaunchKernelGGL(k_gens_xof, grid1(2 * m), dim3(TPB), 0, C.stream, (u32)n, (u32)m, uni);
+        hipLaunchKernelGGL(k_gens_map, grid1(2 * N), dim3(TPB), 0, C.stream, (u32)(2 * N), uni, tbl);
+        hipLaunchKernelGGL(k_gens_tables, grid1(2 * N * fc.np), dim3(TPB), 0, C.stream, (u32)(2 * N), fc, tbl, (size_t)(2 * N));
+        // Window table of the fixed-base MSM.  Its window width follows the size of the generator set: 16-bit windows (16 slices, 32 768
+        // buckets per set) from 2^17 generators on; 13-bit windows (20 slices, 4 096 buckets) below -- many small chunks (n_partition = 64:
+        // 128 L / R problems of 16 384 terms per round) would otherwise spread 8 entries per bucket over 4 M buckets, and the bucket
+        // reduction, not the accumulation, was the cost of such a launch.
+        const u32 c_force = fb_window_c(2 * N);
+        MsmPlan fp = msm_plan_c(c_force ? c_force : 16);
+        if (P0.msm_fb && 2 * N >= P0.msm_fb_min && 2 * N * fp.W < ((size_t)1 << 31)) {      // entry index (w * 2N + i) must fit 31 bits
+            void *wtv = nullptr;
+            if (gens_malloc(P0, &wtv, sizeof(ndm) * 2 * N * fp.W, ent.get()) == hipSuccess) {      // without it the MSMs over these generators run in generic mode
+                ndm *wt = reinterpret_cast<ndm *>(wtv);
+                hipLaunchKernelGGL(k_gens_wtab, grid1(2 * N), dim3(TPB), 0, C.stream, (u32)(2 * N), MsmWin{fp.c, fp.W, fp.wide}, tbl, wt, (size_t)(2 * N));
+                ent->wtab = wt; ent->wc = fp.c; ent->bytes += sizeof(ndm) * 2 * N * fp.W;
+                // Small generator sets also get a 15-bit layout (17 slices; 71 MB at 2N = 32 768).  Many small chunks (n_partition = 64: 128 L / R
+                // problems of 16 384 terms per round) spread 8 entries per bucket over 4 M buckets at c = 16 and the bucket REDUCTION (0.85 ms
+                // per round) rivals the accumulation; 15-bit windows halve the buckets for one more window: 3.2 -> 2.8 ms per round.  (13-bit
+                // windows were measured too: their 4 096-bucket arrays fall off the two-level sort and the narrow windows unbalance the
+                // lists -- 3.5 ms per round.)  A client with FEW chunks of this size (cfg 1: four chunks of 2 048 8-bit values) keeps c = 16.
+                if (!c_force && 2 * N < ((size_t)1 << 17)) {
+                    MsmPlan f2 = msm_plan_c(15);
+                    void *w2 = nullptr;
+                    if (gens_malloc(P0, &w2, sizeof(ndm) * 2 * N * f2.W, ent.get()) == hipSuccess) {
+                        hipLaunchKernelGGL(k_gens_wtab, grid1(2 * N), dim3(TPB), 0, C.stream, (u32)(2 * N), MsmWin{f2.c, f2.W, f2.wide}, tbl, reinterpret_cast<ndm *>(w2), (size_t)(2 * N));
+                        ent->wtab_many = reinterpret_cast<ndm *>(w2); ent->wc_many = f2.c; ent->bytes += sizeof(ndm) * 2 * N * f2.W;
+                    }
+                }
+            }
+        }
+        C.sync();
+    } catch (...) { gens_free_entry(ent.get()); throw; }
+    ent->tick = ++P0.gens_tick; ent->users = 1;
+    GensEntry *raw = ent.get();
+    P0.gens[key] = std::move(ent);
+    gens_evict(P0, P0.gens_budget, raw);            // keep the cache inside its HBM budget (unpinned entries only)
+    return GensPin(&P0, raw);
+}

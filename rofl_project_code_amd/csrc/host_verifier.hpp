@@ -1,0 +1,192 @@
+// The verifier of librofl_zk.so (bulletproofs RangeProof::verify_multiple, one random-weighted check per client): verify_chunks.
+// Included by rofl_zk.hip inside its anonymous namespace, after host_prover.hpp.
+#pragma once
+
+// ================================================================ verifier (RangeProof::verify_multiple)
+// P chunks; proofs host [P][plen]; V bytes host [P][m][32]; V niels device [P][m].
+// results: ok[P] (0/1); returns error code (format etc.)
+sc verifier_c(const uint8_t seed[32], u64 idx) {
+    const u64 dom[2] = {0x2f6b7a2d6c666f72ULL, 0x31762f6379667276ULL};  // "rofl-zk/" "vrfyc/v1"
+    u64 sd[4]; memcpy(sd, seed, 32);
+    u64 st[25]; shake256_seeded_block(st, dom, sd, idx);
+    sc lo, hi;
+    for (int i = 0; i < 4; i++) { lo.v[2 * i] = (u32)st[i]; lo.v[2 * i + 1] = (u32)(st[i] >> 32); hi.v[2 * i] = (u32)st[4 + i]; hi.v[2 * i + 1] = (u32)(st[4 + i] >> 32); }
+    return sc_from_wide(lo, hi);
+}
+
+// d_Vniels holds the UNSHIFTED commitments C_j (k_decode); h_V the encodings of V_j = C_j + v_shift * B for the first v_real[c] values of
+// chunk c (identity padding after them): the check needs sum_j s_j V_j, which is the MSM over the C_j plus (sum_{j < v_real} s_j) * v_shift on B.
+int verify_chunks(Ctx &C, const char *label, size_t gens_capacity, size_t P, size_t n, size_t m, const uint8_t *proofs, size_t plen,
+                  const uint8_t *h_V, const niels *d_Vniels, const uint8_t seed[32], const u64 *c_index, int *ok, size_t group = 1,
+                  const sc *v_shift = nullptr, const u64 *v_real = nullptr) {
+    // `group` consecutive proofs are checked as one batch: sum_c rho_c * (check_c) == 0 with random weights rho_c, so their
+    // generator terms share one MSM.  Every proof of a batch gets the batch's verdict (callers AND them per client anyway).
+    for (size_t c = 0; c < P; c++) ok[c] = 0;
+    static const bool vtrace = knob("ROFL_TRACE") && atoi(knob("ROFL_TRACE")) >= 2;
+    double vt0 = now_ms(), vtl = vt0;
+    auto vmark = [&](const char *what) { if (!vtrace) return; double t = now_ms(); fprintf(stderr, "[rofl-trace verify] %-14s +%.3f ms  (t=%.3f)\n", what, t - vtl, t - vt0); vtl = t; };
+    if (group == 0 || P % group) group = 1;
+    size_t ngroups = P / group;
+    // RangeProof::from_bytes / InnerProductProof::from_bytes
+    if (plen % 32 != 0 || plen < 7 * 32) return ROFL_FORMAT_ERROR;
+    size_t ne = (plen - 7 * 32) / 32;
+    if (ne < 2 || (ne - 2) % 2 != 0) return ROFL_FORMAT_ERROR;
+    size_t lg = (ne - 2) / 2;
+    if (lg >= 32) return ROFL_FORMAT_ERROR;
+    for (size_t c = 0; c < P; c++) {
+        const uint8_t *p = proofs + c * plen;
+        if (!sc_is_canonical_bytes(p + 128) || !sc_is_canonical_bytes(p + 160) || !sc_is_canonical_bytes(p + 192) ||
+            !sc_is_canonical_bytes(p + 7 * 32 + 64 * lg) || !sc_is_canonical_bytes(p + 7 * 32 + 64 * lg + 32))
+            return ROFL_FORMAT_ERROR;
+    }
+    if (!(n == 8 || n == 16 || n == 32 || n == 64)) return ROFL_INVALID_BITSIZE;
+    if (gens_capacity < n) return ROFL_INVALID_GENS_LENGTH;
+    size_t N = n * m;
+    std::vector<char> dead(P, 0);
+    if (N != ((size_t)1 << lg)) return ROFL_OK;    // VerificationError for every chunk
+    GensPin gens = get_gens(C, n, m);
+    niels *tbl = gens.tbl();
+    const niels *wtab = gens.wtab();
+    ChunkParams *h_cp = C.h_cp.as<ChunkParams>(P);
+    ChunkParams *d_cp = C.cp.as<ChunkParams>(P);
+    memset(h_cp, 0, sizeof(ChunkParams) * P);
+    size_t naux = m + 4 + 2 * lg;
+    uint8_t *h_auxc = C.h_auxc.as<uint8_t>(P * (4 + 2 * lg) * 32);
+    sc *h_auxs = C.h_auxs.as<sc>(P * (4 + 2 * lg));
+    std::vector<sc> sB(P), sBb(P);
+    static const uint8_t zero32[32] = {0};
+    // the proof points A S T1 T2 L* R* of every chunk go to the device and are decoded while the host hashes the transcripts
+    for (size_t c = 0; c < P; c++) {
+        const uint8_t *p = proofs + c * plen; const uint8_t *ipp = p + 7 * 32;
+        uint8_t *ac = h_auxc + c * (4 + 2 * lg) * 32;
+        memcpy(ac, p, 128);
+        for (size_t k = 0; k < lg; k++) { memcpy(ac + 128 + 32 * k, ipp + 64 * k, 32); memcpy(ac + 128 + 32 * (lg + k), ipp + 64 * k + 32, 32); }
+    }
+    uint8_t *d_auxc = C.tmp_in.as<uint8_t>(P * (4 + 2 * lg) * 32);
+    niels *d_auxn = C.tmp_in2.as<niels>(P * (4 + 2 * lg));
+    u32 *status = C.status.as<u32>(4);
+    HIPCHK(hipMemsetAsync(status, 0, 16, C.stream));
+    HIPCHK(hipMemcpyAsync(d_auxc, h_auxc, P * (4 + 2 * lg) * 32, hipMemcpyHostToDevice, C.stream));
+    hipLaunchKernelGGL(k_decode, grid1(P * (4 + 2 * lg)), dim3(TPB), 0, C.stream, (u32)(P * (4 + 2 * lg)), (u32)(P * (4 + 2 * lg)), d_auxc, (const niels *)nullptr, d_auxn, (uint8_t *)nullptr, status);
+    double th = now_ms();
+    C.pool->run(P, [&](size_t c) {
+        const uint8_t *p = proofs + c * plen; const uint8_t *ipp = p + 7 * 32;
+        Merlin t(label, strlen(label));
+        t.append("dom-sep", (const uint8_t *)"rangeproof v1", 13);
+        t.append_u64("n", n); t.append_u64("m", m);
+        t.append32_run('V', h_V + c * m * 32, m);
+        // validate_and_append_point rejects the identity encoding
+        bool bad = false;
+        for (int i = 0; i < 4; i++) if (!memcmp(p + 32 * i, zero32, 32)) bad = true;
+        for (size_t k = 0; k < 2 * lg; k++) if (!memcmp(ipp + 32 * k, zero32, 32)) bad = true;
+        if (bad) { dead[c] = 1; }
+        t.append("A", p, 32); t.append("S", p + 32, 32);
+        sc y = t.challenge_scalar("y"), z = t.challenge_scalar("z");
+        t.append("T_1", p + 64, 32); t.append("T_2", p + 96, 32);
+        sc x = t.challenge_scalar("x");
+        sc t_x = sc_frombytes(p + 128), t_x_bl = sc_frombytes(p + 160), e_bl = sc_frombytes(p + 192);
+        t.append("t_x", p + 128, 32); t.append("t_x_blinding", p + 160, 32); t.append("e_blinding", p + 192, 32);
+        sc w = t.challenge_scalar("w");
+        sc cc = verifier_c(seed, c_index[c]);
+        sc rho = group > 1 ? verifier_c(seed, c_index[c] | (1ULL << 62)) : sc_one_plain();
+        t.append("dom-sep", (const uint8_t *)"ipp v1", 6);
+        t.append_u64("n", N);
+        ChunkParams &cp = h_cp[c];
+        sc a = sc_frombytes(ipp + 64 * lg), b = sc_frombytes(ipp + 64 * lg + 32);
+        std::vector<sc> u(lg), ui(lg);
+        for (size_t k = 0; k < lg; k++) {
+            t.append("L", ipp + 64 * k, 32); t.append("R", ipp + 64 * k + 32, 32);
+            u[k] = t.challenge_scalar("u");
+            cp.u[k] = h_mont(u[k]);
+        }
+        sc zz = h_mul(z, z);
+        cp.y = h_mont(y); cp.z = h_mont(z); cp.zz = h_mont(zz); cp.x = h_mont(x);
+        {   // u_0^-1 .. u_(lg-1)^-1 and y^-1 with ONE inversion (10 us each otherwise, on the verifier's critical path): prefix products,
+            // invert the last, walk back.  A zero challenge (probability 2^-252) makes every inverse zero, as the single inversions would.
+            std::vector<sc> pre(lg + 1);
+            sc run = cp.y; pre[0] = run;
+            for (size_t k = 0; k < lg; k++) { run = sc_montmul(run, cp.u[k]); pre[k + 1] = run; }
+            bool any_zero = sc_iszero(h_canon(run));
+            sc inv = any_zero ? sc_zero() : h51::sc_invert_mont_fast(run);
+            for (size_t k = lg; k >= 1; k--) { cp.uinv[k - 1] = sc_montmul(inv, pre[k - 1]); inv = sc_montmul(inv, cp.u[k - 1]); }
+            cp.yinv = inv;
+            if (any_zero) { cp.yinv = h51::sc_invert_mont_fast(cp.y); for (size_t k = 0; k < lg; k++) cp.uinv[k] = h51::sc_invert_mont_fast(cp.u[k]); }
+            for (size_t k = 0; k < lg; k++) ui[k] = h_canon(cp.uinv[k]);
+        }
+        fill_pow2(cp.ypow2, cp.y, MAX_LG); fill_pow2(cp.yinvpow2, cp.yinv, MAX_LG); fill_pow2(cp.zpow2, cp.z, MAX_LG);
+        cp.a_fin = h_mont(a); cp.b_fin = h_mont(b);
+        cp.c_zz = h_mont(h_mul(rho, h_mul(cc, zz)));
+        cp.rz = h_mont(h_mul(rho, z)); cp.ra = h_mont(h_mul(rho, a)); cp.rb = h_mont(h_mul(rho, b)); cp.rzz = h_mont(h_mul(rho, zz));
+        // aux points and scalars: A S T1 T2 L* R*
+        sc *as = h_auxs + c * (4 + 2 * lg);
+        as[0] = rho; as[1] = h_mul(rho, x); as[2] = h_mul(as[1], cc); as[3] = h_mul(as[2], x);
+        for (size_t k = 0; k < lg; k++) { as[4 + k] = h_mul(rho, h_mul(u[k], u[k])); as[4 + lg + k] = h_mul(rho, h_mul(ui[k], ui[k])); }
+        // B_blinding: -e_bl - c t_x_bl ; B: w (t_x - a b) + c (delta - t_x)
+        sBb[c] = h_mul(rho, sc_neg(sc_add(e_bl, h_mul(cc, t_x_bl))));
+        // sum_{i<N} y^i = prod_b (1 + y^(2^b)) for N = 2^lg ; likewise for 2^n and z^m
+        auto geo = [&](const sc *pow2tab, unsigned bits) { sc acc = sc_one_mont(); for (unsigned q = 0; q < bits; q++) acc = sc_montmul(acc, sc_add(sc_one_mont(), pow2tab[q])); return h_canon(acc); };
+        sc sum_y = geo(cp.ypow2, (unsigned)lg);
+        sc sum_z = geo(cp.zpow2, lg2u(m));
+        sc twom[MAX_LG]; fill_pow2(twom, h_mont(sc_from_u64(2)), 8);
+        sc sum_2 = geo(twom, lg2u(n));
+        sc delta = sc_sub(h_mul(sc_sub(z, zz), sum_y), h_mul(h_mul(h_mul(zz, z), sum_2), sum_z));
+        sB[c] = h_mul(rho, sc_add(h_mul(w, sc_sub(t_x, h_mul(a, b))), h_mul(cc, sc_sub(delta, t_x))));
+        if (v_shift && v_real && v_real[c]) {
+            // sum_{j < cnt} rho c z^(2+j) = rho c z^2 (z^cnt - 1) / (z - 1)
+            sc zm = h_mont(z), zc = sc_one_mont();
+            for (u64 e = v_real[c], bidx = 0; e; e >>= 1, bidx++) if (e & 1) zc = sc_montmul(zc, cp.zpow2[bidx]);
+            sc num = sc_sub(h_canon(zc), sc_one_plain()), den = sc_sub(z, sc_one_plain());
+            sc geo_z = sc_iszero(den) ? sc_from_u64(v_real[c]) : h_mul(num, h_inv(den));
+            (void)zm;
+            sB[c] = sc_add(sB[c], h_mul(h_mul(h_mul(rho, h_mul(cc, zz)), geo_z), *v_shift));
+        }
+    });
+    C.tm.t.host_ms += now_ms() - th;
+    vmark("transcripts");
+    HIPCHK(hipMemcpyAsync(d_cp, h_cp, sizeof(ChunkParams) * P, hipMemcpyHostToDevice, C.stream));
+    sc *gh = C.SL.as<sc>(ngroups * 2 * N);
+    PowTabs *d_pt = C.powtabs.as<PowTabs>(P);
+    hipLaunchKernelGGL(k_pow_tables, dim3((4 * PT_L * PT_E + TPB - 1) / TPB, (u32)P), dim3(TPB), 0, C.stream, d_cp, d_pt, (u32)lg, 1);
+    hipLaunchKernelGGL(k_verify_scalars, grid1(N, (u32)ngroups), dim3(TPB), 0, C.stream, (u32)n, (u32)m, (u32)lg, (u32)group, d_cp, (const PowTabs *)d_pt, C.d_two_pow, gh);
+    // aux arrays
+    niels *aux_pts = C.aux_pts.as<niels>(P * naux);
+    sc *aux_scal = C.aux_scal.as<sc>(P * naux);
+    hipLaunchKernelGGL(k_vscalars, grid1(m, (u32)P), dim3(TPB), 0, C.stream, (u32)m, d_cp, (const PowTabs *)d_pt, aux_scal, naux);
+    {   // per chunk: [m commitments | 4 + 2 lg proof points] and the scalars of the latter -- three strided copies for all chunks
+        const size_t na2 = 4 + 2 * lg;
+        HIPCHK(hipMemcpy2DAsync(aux_pts, naux * sizeof(niels), d_Vniels, m * sizeof(niels), m * sizeof(niels), P, hipMemcpyDeviceToDevice, C.stream));
+        HIPCHK(hipMemcpy2DAsync(aux_pts + m, naux * sizeof(niels), d_auxn, na2 * sizeof(niels), na2 * sizeof(niels), P, hipMemcpyDeviceToDevice, C.stream));
+        HIPCHK(hipMemcpy2DAsync(aux_scal + m, naux * sizeof(sc), h_auxs, na2 * sizeof(sc), na2 * sizeof(sc), P, hipMemcpyHostToDevice, C.stream));
+    }
+    u32 *h_stat = C.h_misc2.as<u32>(4);
+    HIPCHK(hipMemcpyAsync(h_stat, status, 4, hipMemcpyDeviceToHost, C.stream));      // k_decode's verdict on the proof points
+    std::vector<MsmProb> pr(ngroups), prB(ngroups); std::vector<ge5> resA, resB;
+    for (size_t g = 0; g < ngroups; g++) pr[g] = MsmProb{tbl, gh + g * 2 * N};
+    for (size_t g = 0; g < ngroups; g++) prB[g] = MsmProb{aux_pts + g * group * naux, aux_scal + g * group * naux};
+    C.tm.t.msm_terms += ngroups * 2 * N + P * naux;
+    // the generator MSM (2N terms per group, fixed-base) and the proof-point MSM (commitments, A, S, T, L, R) queue back to back: one wait
+    // (one problem per client with every window in its own bucket set: the 15-bit layout's smaller arrays win here whenever it exists)
+    { MsmOpt mo; if (wtab) { gens.fb_for(1000, &mo.fb_wtab, &mo.fb_c); mo.fb_stride = 2 * N; } msm_run2(C, pr, 2 * N, mo, resA, prB, group * naux, MsmOpt(), resB); }
+    vmark("msm");
+    const u32 h_status = *h_stat;
+    th = now_ms();
+    for (size_t g = 0; g < ngroups; g++) {
+        ge5 tot = h51::gadd(resA[g], resB[g]);
+        sc b1 = sc_zero(), b2 = sc_zero(); bool any_dead = false;
+        for (size_t c = g * group; c < (g + 1) * group; c++) { b1 = sc_add(b1, sB[c]); b2 = sc_add(b2, sBb[c]); any_dead |= dead[c] != 0; }
+        tot = h51::gadd(tot, h_fixed_mul(C.ht.B5, b1));
+        tot = h51::gadd(tot, h_fixed_mul(C.ht.Bb5, b2));
+        int okg = (!any_dead && h51::is_identity_ristretto(tot)) ? 1 : 0;
+        for (size_t c = g * group; c < (g + 1) * group; c++) ok[c] = okg;
+    }
+    C.tm.t.host_ms += now_ms() - th;
+    if (h_status & 4u) {
+        // some proof point failed to decompress: upstream returns VerificationError for that proof.
+        // Re-check per chunk on the host to attribute the failure.
+        for (size_t c = 0; c < P; c++) {
+            const uint8_t *ac = h_auxc + c * (4 + 2 * lg) * 32;
+            for (size_t k = 0; k < 4 + 2 * lg; k++) { ge tmp; if (!ristretto_decode(tmp, ac + 32 * k)) for (size_t c2 = c / group * group; c2 < (c / group + 1) * group; c2++) ok[c2] = 0; }
+        }
+    }
+    return ROFL_OK;
+}

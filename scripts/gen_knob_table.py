@@ -1,4 +1,4 @@
-"""The tuning-knob table of DESIGN.md, generated from the KNOBS registry in csrc/rofl_zk.hip.
+"""The tuning-knob table of DESIGN.md, generated from the KNOBS registry in csrc/host_rt.hpp.
     python scripts/gen_knob_table.py          -> prints the markdown table
     python scripts/gen_knob_table.py --write  -> rewrites the block between <!-- knobs:begin --> and <!-- knobs:end --> in DESIGN.md"""
 import os
@@ -6,7 +6,9 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "rofl_project_code_amd", "csrc", "rofl_zk.hip")
+CSRC = os.path.join(ROOT, "rofl_project_code_amd", "csrc")
+SRC = os.path.join(CSRC, "host_rt.hpp")                                               # the KNOBS registry
+HOST_SOURCES = ["rofl_zk.hip", "host_rt.hpp", "host_msm.hpp", "host_prover.hpp", "host_verifier.hpp"]      # everything that may call knob()
 
 
 def knobs():
@@ -18,7 +20,7 @@ def knobs():
 
 def reads():
     """every name the sources pass to knob()"""
-    s = open(SRC).read()
+    s = "".join(open(os.path.join(CSRC, f)).read() for f in HOST_SOURCES)
     return sorted(set(re.findall(r'knob\("(ROFL_[A-Z0-9_]+)"\)', s)))
 
 

@@ -173,16 +173,17 @@ def test_fast_scalar_inversion_matches_reference_and_python(hiplib):
 
 
 def test_knob_registry_is_complete_and_documented():
-    """Every ROFL_* variable the library reads is registered in ONE table (csrc/rofl_zk.hip: KNOBS), nothing else is read from the
+    """Every ROFL_* variable the library reads is registered in ONE table (csrc/host_rt.hpp: KNOBS), nothing else is read from the
     environment, and the table of DESIGN.md is the one scripts/gen_knob_table.py generates from it."""
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
     import gen_knob_table as g
     names = [k[0] for k in g.knobs()]
     assert len(names) == len(set(names)) >= 40
     assert set(g.reads()) == set(names)
-    for f in ("rofl_zk.hip", "kernels.hpp", "host51.hpp", "keccak.hpp", "fe32.hpp", "fe26.hpp", "quad26.hpp", "wire.hpp"):
+    for f in ("rofl_zk.hip", "host_rt.hpp", "host_msm.hpp", "host_prover.hpp", "host_verifier.hpp", "kernels.hpp", "host51.hpp", "host51x8.hpp",
+              "keccak.hpp", "fe32.hpp", "fe26.hpp", "quad26.hpp", "wire.hpp"):
         src = open(os.path.join(ROOT, "rofl_project_code_amd", "csrc", f)).read()
-        assert len(re.findall(r"\bgetenv\(", src)) == (1 if f == "rofl_zk.hip" else 0), f      # the one inside knob()
+        assert len(re.findall(r"\bgetenv\(", src)) == (1 if f == "host_rt.hpp" else 0), f      # the one inside knob()
         assert "setenv(" not in src and "putenv(" not in src
     design = open(os.path.join(ROOT, "DESIGN.md")).read()
     a, b = design.index("<!-- knobs:begin -->") + len("<!-- knobs:begin -->"), design.index("<!-- knobs:end -->")

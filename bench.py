@@ -39,8 +39,8 @@ ALG_BYTES_VERIFY = 32 + 64 * NBITS
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=25000, help="elements of the workload the CPU baseline proves and verifies (25 000 = all of it, ~25 s on 4 threads)")
     ap.add_argument("--no-l2", action="store_true")

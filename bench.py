@@ -268,6 +268,15 @@ def run_multi_client(args, R, rd, dist, cdev, world, rank, backend):
         if world > 1:
             dist.barrier(); torch.cuda.synchronize()
 
+    # cold figures: tables of this config's (n, m) built once per process, then the first round
+    from rofl_project_code_amd import api
+    m_chunk = rpv.next_pow2(D_MULTI) // P
+    cold_sets = [(NBITS, m_chunk)] if cfg == 4 else [(8, m_chunk), (32, 1)]
+    t_c0 = time.perf_counter()
+    for nb_, m_ in cold_sets:
+        api.bp_gens_prepare(nb_, m_)
+    gens_build_ms = (time.perf_counter() - t_c0) * 1e3
+    t_c0 = time.perf_counter(); first_gen = step(0, False); first_round_ms = (time.perf_counter() - t_c0 - first_gen) * 1e3
     for s in range(args.warmup):
         step(s, False)
     sync()
@@ -294,7 +303,10 @@ def run_multi_client(args, R, rd, dist, cdev, world, rank, backend):
                           "d": D_MULTI, "clients": NC, "clients_per_rank": len(mine), "prove_range": NBITS if cfg == 4 else 8, "l2_range": None if cfg == 4 else 32,
                           "n_partition": P, "fp_bits": FP_BITS, "fp_frac": FP_FRAC, "host_cores": avail_cores()},
                "breakdown_ms_per_step_rank0": {k: phase[k] / K * 1e3 for k in ("create", "exchange", "verify")},
-               "all_gather_bytes_per_rank": int(phase["payload"])}
+               "all_gather_bytes_per_rank": int(phase["payload"]),
+               "cold": {"gens_tables_build_ms": gens_build_ms, "first_round_ms": first_round_ms,
+                        "tables_bytes": {"%dx%d" % (nb_, m_): int(api.bp_gens_table_bytes(nb_, m_)) for nb_, m_ in cold_sets},
+                        "note": "rank 0, once per process: generator + window + fold tables of this config's (n_bits, m), then the first round (sigma-proof tables, workspaces)"}}
         print(json.dumps(out)); sys.stdout.flush()
     if world > 1:
         dist.barrier(); dist.destroy_process_group()

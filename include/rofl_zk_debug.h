@@ -42,6 +42,8 @@ int rofl_dbg_host_bench(int what, unsigned iters, double *ns_out);
 /* csrc/host51x8.hpp (eight window chains per AVX-512 IFMA stream) against the scalar chain of host51.hpp on 8 x W pseudo-random points,
  * windows c bits apart: 0 = all `lanes` results agree, 1 = mismatch, -1 = the CPU has no AVX-512 IFMA (nothing tested) */
 int rofl_dbg_host_horner8_selftest(unsigned W, unsigned c, int lanes, double *us_simd, double *us_scalar);
+/* h8::encode8 (eight Ristretto encodings per AVX-512 IFMA stream) against the scalar host encoder: 0 = all equal, 1 = mismatch, -1 = no IFMA */
+int rofl_dbg_host_encode8_selftest(unsigned batches, double *us_simd, double *us_scalar);
 
 #ifdef __cplusplus
 }

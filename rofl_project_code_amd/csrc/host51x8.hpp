@@ -12,6 +12,7 @@
 // < 2^51 + 2^14.  Column sums in mul: <= 5 low halves (< 2^52 each) plus twice <= 5 high halves, < 2^56; after the 19-fold < 2^61.
 #pragma once
 #include <immintrin.h>
+#include <string.h>
 #include "host51.hpp"
 
 namespace rofl {
@@ -156,6 +157,81 @@ ROFL_H8 void horner8(h51::ge5 out[8], int lanes, int W, const u32 *pos, GetPt ws
         acc = gadd(acc, load8(p8), d2);
     }
     store8(out, acc);
+}
+
+// ---- Ristretto encodings eight at a time (h51::encode, operand for operand; the lane-wise choices become mask blends)
+typedef __mmask8 M8;
+// canonical limbs (value in [0, p), every limb below 2^51): the steps of h51::to_fe
+ROFL_H8 fe8 freeze(fe8 t) {
+    const V M = bc(h51::M51);
+    carry(t); carry(t);
+    t.v[0] = _mm512_add_epi64(t.v[0], bc(19)); carry(t);                                // (h mod p) + 19, below 2^255
+    t.v[0] = _mm512_add_epi64(t.v[0], bc((1ULL << 51) - 19));                           // + p = (h mod p) + 2^255
+    for (int i = 1; i < 5; i++) t.v[i] = _mm512_add_epi64(t.v[i], bc((1ULL << 51) - 1));
+    V c;
+    c = _mm512_srli_epi64(t.v[0], 51); t.v[0] = _mm512_and_si512(t.v[0], M); t.v[1] = _mm512_add_epi64(t.v[1], c);
+    c = _mm512_srli_epi64(t.v[1], 51); t.v[1] = _mm512_and_si512(t.v[1], M); t.v[2] = _mm512_add_epi64(t.v[2], c);
+    c = _mm512_srli_epi64(t.v[2], 51); t.v[2] = _mm512_and_si512(t.v[2], M); t.v[3] = _mm512_add_epi64(t.v[3], c);
+    c = _mm512_srli_epi64(t.v[3], 51); t.v[3] = _mm512_and_si512(t.v[3], M); t.v[4] = _mm512_add_epi64(t.v[4], c);
+    t.v[4] = _mm512_and_si512(t.v[4], M);                                               // drops the 2^255
+    return t;
+}
+ROFL_H8 M8 isneg(const fe8 &a) { fe8 c = freeze(a); return _mm512_test_epi64_mask(c.v[0], bc(1)); }
+ROFL_H8 M8 iszero(const fe8 &a) {
+    fe8 c = freeze(a);
+    V o = _mm512_or_si512(_mm512_or_si512(c.v[0], c.v[1]), _mm512_or_si512(_mm512_or_si512(c.v[2], c.v[3]), c.v[4]));
+    return _mm512_testn_epi64_mask(o, o);
+}
+ROFL_H8 M8 eq(const fe8 &a, const fe8 &b) { return iszero(sub(a, b)); }
+ROFL_H8 fe8 blend(M8 pick_b, const fe8 &a, const fe8 &b) { fe8 r; for (int i = 0; i < 5; i++) r.v[i] = _mm512_mask_blend_epi64(pick_b, a.v[i], b.v[i]); return r; }
+ROFL_H8 fe8 fabs8(const fe8 &a) { return blend(isneg(a), a, neg(a)); }
+ROFL_H8 fe8 sqn(fe8 a, int n) { for (int i = 0; i < n; i++) a = sq(a); return a; }
+ROFL_H8 fe8 one() { fe8 r = zero(); r.v[0] = bc(1); return r; }
+ROFL_H8 fe8 pow22523(const fe8 &z) {      // z^((p - 5) / 8): h51::pow_2_250_1, then two squarings and z
+    fe8 z2 = sq(z), z9 = mul(sqn(z2, 2), z), z11 = mul(z9, z2);
+    fe8 z_5_0 = mul(sq(z11), z9), z_10_0 = mul(sqn(z_5_0, 5), z_5_0), z_20_0 = mul(sqn(z_10_0, 10), z_10_0);
+    fe8 z_40_0 = mul(sqn(z_20_0, 20), z_20_0), z_50_0 = mul(sqn(z_40_0, 10), z_10_0), z_100_0 = mul(sqn(z_50_0, 50), z_50_0);
+    fe8 z_200_0 = mul(sqn(z_100_0, 100), z_100_0);
+    fe8 t = mul(sqn(z_200_0, 50), z_50_0);
+    return mul(sqn(t, 2), z);
+}
+// 1 / sqrt(v) as h51::sqrt_ratio_i(out, 1, v) leaves it (the flag is not needed by the encoding)
+ROFL_H8 fe8 invsqrt(const fe8 &v, const fe8 &sqrtm1) {
+    fe8 v3 = mul(sq(v), v), v7 = mul(sq(v3), v);
+    fe8 r = mul(v3, pow22523(v7));
+    fe8 check = mul(v, sq(r)), neg_one = neg(one());
+    M8 flipped = eq(check, neg_one), flipped_i = eq(check, mul(neg_one, sqrtm1));
+    r = blend((M8)(flipped | flipped_i), r, mul(r, sqrtm1));
+    return fabs8(r);
+}
+ROFL_H8 ge8 load8(const h51::ge5 pts[8]) {
+    alignas(64) u64 t[4][5][8];
+    for (int l = 0; l < 8; l++) {
+        const h51::fe5 *co[4] = {&pts[l].X, &pts[l].Y, &pts[l].Z, &pts[l].T};
+        for (int c = 0; c < 4; c++) for (int i = 0; i < 5; i++) t[c][i][l] = co[c]->v[i];
+    }
+    ge8 r; fe8 *dst[4] = {&r.X, &r.Y, &r.Z, &r.T};
+    for (int c = 0; c < 4; c++) { for (int i = 0; i < 5; i++) dst[c]->v[i] = _mm512_load_si512((const void *)t[c][i]); carry(*dst[c]); }
+    return r;
+}
+// out[l] = the canonical Ristretto encoding of pts[l] (limbs below 2^52 on entry, as every h51 routine leaves them)
+ROFL_H8 void encode8(uint8_t out[8][32], const h51::ge5 pts[8]) {
+    const fe8 sqrtm1 = bcast(h51::K().sqrtm1), iamd = bcast(h51::K().invsqrt_a_minus_d);
+    ge8 p = load8(pts);
+    fe8 u1 = mul(add(p.Z, p.Y), sub(p.Z, p.Y)), u2 = mul(p.X, p.Y);
+    fe8 is = invsqrt(mul(u1, sq(u2)), sqrtm1);
+    fe8 den1 = mul(is, u1), den2 = mul(is, u2), z_inv = mul(mul(den1, den2), p.T);
+    fe8 ix0 = mul(p.X, sqrtm1), iy0 = mul(p.Y, sqrtm1), ench = mul(den1, iamd);
+    M8 rotate = isneg(mul(p.T, z_inv));
+    fe8 x = blend(rotate, p.X, iy0), y = blend(rotate, p.Y, ix0), den_inv = blend(rotate, den2, ench);
+    y = blend(isneg(mul(x, z_inv)), y, neg(y));
+    fe8 s = freeze(fabs8(mul(den_inv, sub(p.Z, y))));
+    alignas(64) u64 t[5][8];
+    for (int i = 0; i < 5; i++) _mm512_store_si512((void *)t[i], s.v[i]);
+    for (int l = 0; l < 8; l++) {
+        u64 w[4] = {t[0][l] | (t[1][l] << 51), (t[1][l] >> 13) | (t[2][l] << 38), (t[2][l] >> 26) | (t[3][l] << 25), (t[3][l] >> 39) | (t[4][l] << 12)};
+        memcpy(out[l], w, 32);
+    }
 }
 
 }  // namespace h8

@@ -21,7 +21,8 @@ MsmPlan msm_plan(size_t n) {
 // are the generator table `opt.fb_gens` (n terms from its start, slice stride opt.fb_stride) for which a window table exists.
 // overlap: host work to run while the kernels execute; post(p): runs on the pool thread that finished problem p's window combination,
 // right after results[p] is final (the caller's per-problem tail -- encoding, transcript -- without a second pool hand-off on the hop)
-struct MsmOpt { u32 lr_nh = 0, lr_ng = 0; const niels *fb_wtab = nullptr; size_t fb_stride = 0; u32 fb_c = 16; std::function<void()> overlap; std::function<void(size_t)> post; };
+struct MsmOpt { u32 lr_nh = 0, lr_ng = 0; const niels *fb_wtab = nullptr; size_t fb_stride = 0; u32 fb_c = 16; std::function<void()> overlap; std::function<void(size_t)> post;
+                std::function<void(size_t, int)> post8; };      // post8(p0, count): the finisher of problems p0 .. p0 + count - 1 (p0 a multiple of 8) of a host8 task, instead of `count` calls of post
 
 // An MSM goes through four stages: PLAN (which variant, window layout, bucket sets, capacities) -> SORT (digits into per-bucket lists)
 // -> ACCUMULATE (one thread per bucket) -> REDUCE (bit-sum tree; the window combination is left to the host, or to k_msm_horner when a
@@ -302,10 +303,14 @@ void msm_finish(Ctx &C, const MsmJob &J, std::vector<ge5> &results, const MsmOpt
         u32 pos[64];
         for (u32 w = 0; w < P.W; w++) pos[w] = w + 1 == P.W ? 253 - P.c : (w < P.wide ? w * P.c : P.wide * P.c + (w - P.wide) * (P.c - 1));      // msm_window's layout
         C.pool->run((np + 7) / 8, [&](size_t b) {
+            double tc0 = now_ms();
             size_t p0 = b * 8; int lanes = (int)std::min<size_t>(8, np - p0);
             ge5 out[8];
             h8::horner8(out, lanes, (int)P.W, pos, [&](int l, int w) { return (const ge *)&h[(p0 + (size_t)l) * P.W + (size_t)w]; });
-            for (int l = 0; l < lanes; l++) { results[p0 + l] = out[l]; if (opt.post) opt.post(p0 + l); }
+            for (int l = 0; l < lanes; l++) results[p0 + l] = out[l];
+            if (opt.post8) opt.post8(p0, lanes);
+            else if (opt.post) for (int l = 0; l < lanes; l++) opt.post(p0 + l);
+            cpu_each[p0] = now_ms() - tc0;
         });
     } else if (J.dev_horner) {
         if (opt.post) C.pool->run(np, [&](size_t p) { results[p] = h51::from_ge_loose(h[p]); opt.post(p); });

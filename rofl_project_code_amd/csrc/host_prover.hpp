@@ -217,6 +217,43 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
             h_cp[c].pend_u[pu[c].size()] = um; h_cp[c].pend_ui[pu[c].size()] = uim;
             pu[c].push_back(um); pui[c].push_back(uim);
         };
+        // Launches whose window chains come back eight problems per task (host8: n_partition = 64) finish those eight together: the eight
+        // encodings in the lanes of one AVX-512 stream (the 254-step inverse square root is 80 % of an encoding) and the four challenge
+        // inversions of the task's four chunks behind ONE inversion (Montgomery's trick).  Problems 2c, 2c + 1 always share a task.
+        mo.post8 = [&](size_t p0, int cnt) {
+            ge5 pts[8];
+            for (int l = 0; l < 8; l++) {
+                if (l >= cnt) { pts[l] = h51::identity(); continue; }
+                size_t p = p0 + (size_t)l, c = p >> 1;
+                sc cx = h_canon(sum_partials(h_ip + c * nblkI * 2, nblkI, 2, p & 1));
+                pts[l] = h51::gadd(res[p], h_fixed_mul(C.ht.B5, h_mul(cx, w[c])));
+            }
+            uint8_t enc[8][32];
+            h8::encode8(enc, pts);
+            const int nch = cnt / 2;
+            sc um[4], pre[4];
+            for (int k = 0; k < nch; k++) {
+                size_t c = (p0 >> 1) + (size_t)k;
+                uint8_t *o = proofs_out[c] + 7 * 32 + 64 * round;
+                memcpy(o, enc[2 * k], 32); memcpy(o + 32, enc[2 * k + 1], 32);
+                tr[c].append("L", o, 32); tr[c].append("R", o + 32, 32);
+                um[k] = h_mont(tr[c].challenge_scalar("u"));
+                pre[k] = k ? sc_montmul(pre[k - 1], um[k]) : um[k];
+            }
+            sc uim[4];
+            if (nch && !sc_iszero(h_canon(pre[nch - 1]))) {
+                sc inv = h51::sc_invert_mont_fast(pre[nch - 1]);
+                for (int k = nch - 1; k >= 1; k--) { uim[k] = sc_montmul(inv, pre[k - 1]); inv = sc_montmul(inv, um[k]); }
+                uim[0] = inv;
+            } else
+                for (int k = 0; k < nch; k++) uim[k] = h51::sc_invert_mont_fast(um[k]);      // a zero challenge (probability 2^-252): one by one, as post does
+            for (int k = 0; k < nch; k++) {
+                size_t c = (p0 >> 1) + (size_t)k;
+                h_round[2 * c] = um[k]; h_round[2 * c + 1] = uim[k];
+                h_cp[c].pend_u[pu[c].size()] = um[k]; h_cp[c].pend_ui[pu[c].size()] = uim[k];
+                pu[c].push_back(um[k]); pui[c].push_back(uim[k]);
+            }
+        };
         msm_run(C, pr, 2 * n_g, res, mo);
         mark("round msm", (long)(2 * n_g));
         bool last = (round + 1 == lgN);

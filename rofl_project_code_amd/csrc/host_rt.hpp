@@ -195,10 +195,14 @@ class HostPool {
         for (;;) {
             if (spin_us > 0 && (!calls_in_flight || calls_in_flight->load(std::memory_order_relaxed) <= 1)) {
                 auto t0 = std::chrono::steady_clock::now();
-                while (gen.load(std::memory_order_acquire) == seen) {
+                uint64_t g;
+                while ((g = gen.load(std::memory_order_acquire)) == seen) {
                     __builtin_ia32_pause();
                     if (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > spin_us) break;
                 }
+                // a job seen while polling is taken without the mutex (fifteen pollers queueing for it cost the hop tens of microseconds): run()
+                // publishes fn / count / next before it bumps gen, and the acquire load above orders this thread's reads after that
+                if (g != seen) { seen = g; work(); continue; }
             }
             { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return stop || gen.load() != seen; }); if (stop) return; seen = gen.load(); }
             work();

@@ -1102,6 +1102,35 @@ int rofl_dbg_host_horner8_selftest(unsigned W, unsigned c, int lanes, double *us
     if (us_scalar) *us_scalar = (t1 - t0) * 1e3;
     return bad;
 }
+// h8::encode8 against h51::encode on `batches` x 8 points of a pseudo-random walk (arbitrary Z), the identity and small multiples included.
+// Returns 0 when every encoding agrees, 1 on a mismatch, -1 without AVX-512 IFMA.
+int rofl_dbg_host_encode8_selftest(unsigned batches, double *us_simd, double *us_scalar) {
+    if (!h8::available()) return -1;
+    static const uint8_t Bc[32] = {0xe2, 0xf2, 0xae, 0x0a, 0x6a, 0xbc, 0x4e, 0x71, 0xa8, 0x84, 0xa9, 0x61, 0xc5, 0x00, 0x51, 0x5f,
+                                   0x58, 0xe3, 0x0b, 0x6a, 0xa5, 0x82, 0xdd, 0x8d, 0xb6, 0xa6, 0x59, 0x45, 0xe0, 0x8d, 0x2d, 0x76};
+    ge b; ristretto_decode(b, Bc);
+    ge5 b5 = h51::from_ge(b), cur = b5;
+    int bad = 0; double ts = 0, tv = 0;
+    for (unsigned it = 0; it < batches; it++) {
+        ge5 pts[8];
+        for (int l = 0; l < 8; l++) {
+            cur = h51::gadd(h51::gdouble(cur), b5); if ((it + l) % 3 == 0) cur = h51::gdouble(cur);
+            pts[l] = cur;
+        }
+        if (it == 0) { pts[0] = h51::identity(); pts[1] = b5; pts[2] = h51::gdouble(b5); pts[3] = h51::gadd(b5, h51::identity()); }
+        uint8_t ref[8][32], got[8][32];
+        double t0 = now_ms();
+        for (int l = 0; l < 8; l++) h51::encode(ref[l], pts[l]);
+        double t1 = now_ms();
+        h8::encode8(got, pts);
+        double t2 = now_ms();
+        ts += t1 - t0; tv += t2 - t1;
+        bad |= memcmp(ref, got, sizeof ref) != 0;
+    }
+    if (us_simd) *us_simd = tv * 1e3 / (batches ? batches : 1);
+    if (us_scalar) *us_scalar = ts * 1e3 / (batches ? batches : 1);
+    return bad;
+}
 int rofl_dbg_host_fe_mul(const uint8_t a[32], const uint8_t b[32], uint8_t out[32]) { fe_tobytes(out, fe_mul(fe_frombytes(a), fe_frombytes(b))); return 0; }
 int rofl_dbg_host_fe_ops(const uint8_t a[32], const uint8_t b[32], uint8_t oa[32], uint8_t os[32], uint8_t oq[32], uint8_t oi[32]) {
     fe x = fe_frombytes(a), y = fe_frombytes(b);

@@ -200,3 +200,16 @@ def test_simd_window_chains_match_the_scalar_ones(hiplib):
     if rcs[0] == -1:
         pytest.skip("no AVX-512 IFMA on this CPU")
     assert rcs == [0] * len(rcs), rcs
+
+
+def test_host_encode8_matches_scalar_encoder(hiplib):
+    """csrc/host51x8.hpp encode8 (eight Ristretto encodings per AVX-512 IFMA stream: the finisher of the n_partition = 64 hops) against the
+    scalar host encoder on 8 x 300 points of a pseudo-random walk (arbitrary Z), the identity and small multiples of the base point included."""
+    L = hiplib
+    us = (ctypes.c_double(), ctypes.c_double())
+    L.rofl_dbg_host_encode8_selftest.argtypes = [ctypes.c_uint, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+    rc = L.rofl_dbg_host_encode8_selftest(300, ctypes.byref(us[0]), ctypes.byref(us[1]))
+    if rc == -1:
+        pytest.skip("no AVX-512 IFMA on this CPU")
+    assert rc == 0
+

@@ -20,6 +20,7 @@ static const Knob KNOBS[] = {
     {"ROFL_FOLD_T1", "3", "IPP rounds before the first generator fold (1..6)"},
     {"ROFL_FOLD_T", "2", "IPP rounds between later folds (1..6)"},
     {"ROFL_FOLD_MIN", "1024", "no fold once fewer generators per chunk would remain (launches with many chunks fold down to 64)"},
+    {"ROFL_SYNC_POLL", "0", "1 = wait for the lane's stream with hipStreamQuery in a pause loop instead of hipStreamSynchronize"},
     {"ROFL_FOLD_TAB", "1", "0 = first fold without the precomputed odd-multiple slices"},
     {"ROFL_FOLD_PB", "32", "piece width of the fold table in bits (16, 32, 64)"},
     {"ROFL_FOLD_W", "8", "NAF width of the fold table (3..8; narrowed until the table fits ROFL_FOLD_TAB_MB)"},
@@ -208,6 +209,14 @@ class HostPool {
             work();
         }
     }
+    // The waits of run() last microseconds: pause-spin.  (sched_yield hands the CPU to whatever else is runnable on it -- on a host that other
+    // tenants load, that is a full time slice of theirs: milliseconds in the middle of a 0.2 ms hop.)  Only a wait that drags on -- a worker
+    // that lost its CPU in mid-task -- starts yielding.
+    template <class Pred> static void spin_until(Pred ready) {
+        for (unsigned i = 0; !ready(); i++) {
+            if (i < 20000) __builtin_ia32_pause(); else std::this_thread::yield();
+        }
+    }
 public:
     explicit HostPool(int nthreads, const std::atomic<int> *in_flight = nullptr) : calls_in_flight(in_flight) {
         if (const char *e = knob("ROFL_POOL_SPIN_US")) spin_us = atof(e);
@@ -216,11 +225,11 @@ public:
     ~HostPool() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); for (auto &t : workers) t.join(); }
     void run(size_t n, std::function<void(size_t)> f) {
         if (n <= 1 || workers.empty()) { for (size_t i = 0; i < n; i++) f(i); return; }
-        while (active.load() > 0) std::this_thread::yield();     // no straggler of the previous job may still look at fn
+        spin_until([&] { return active.load() == 0; });     // no straggler of the previous job may still look at fn
         { std::lock_guard<std::mutex> lk(mu); count = 0; fn = std::move(f); done = 0; next = 0; count = n; gen++; }
         cv.notify_all();
         work();
-        while (done.load() < n) std::this_thread::yield();
+        spin_until([&] { return done.load() >= n; });
         // workers that woke late see next >= count and go back to sleep; make sure none is still inside work()
         // with a stale fn before the next run() replaces it: done == n implies every claimed index finished.
     }
@@ -335,7 +344,16 @@ struct Ctx {
         // (up to three calls in flight still spin: the three proofs of ONE client's L2 update run side by side -- EncParamsL2::encrypt --
         //  and that is a latency case; a server with more clients in flight is a throughput case)
         bool block = P->blocking_sync == 1 || (P->blocking_sync < 0 && (P->active_calls.load() > 3 || batch_mode));
-        if (!block) { HIPCHK(hipStreamSynchronize(stream)); return; }
+        if (!block) {
+            static const bool poll = knob("ROFL_SYNC_POLL") && atoi(knob("ROFL_SYNC_POLL")) != 0;
+            if (!poll) { HIPCHK(hipStreamSynchronize(stream)); return; }
+            for (;;) {      // hipStreamQuery in a pause loop: never gives the CPU away
+                hipError_t q = hipStreamQuery(stream);
+                if (q == hipSuccess) return;
+                if (q != hipErrorNotReady) throw HipErr{q, "hipStreamQuery"};
+                for (int i = 0; i < 16; i++) __builtin_ia32_pause();
+            }
+        }
         // (hipEventSynchronize on a hipEventBlockingSync event still keeps the calling thread runnable on this runtime -- measured: 100 %
         //  of a core either way -- so the wait is a query loop with short sleeps: ~50 us of extra latency per wait, no CPU)
         if (!ev_block) HIPCHK(hipEventCreateWithFlags(&ev_block, hipEventDisableTiming));

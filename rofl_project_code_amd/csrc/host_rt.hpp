@@ -266,6 +266,43 @@ struct PinBuf {
     template <class T> T *dev(size_t count) { ensure(count * sizeof(T)); return reinterpret_cast<T *>(dp); }      // the same memory, as the device sees it
 };
 
+// Caller memory never goes to the HIP runtime directly.  A hipMemcpyAsync on ordinary (pageable) host memory makes the runtime pin the
+// caller's pages for the DMA -- and when the caller frees such a buffer later, the driver's MMU notifier tears the mapping down inside
+// munmap.  Both showed on the path: the first call after a process had released its previous results waited 20-30 ms in a 0.5 ms
+// rofl_commit_vec, and a caller that kept its results alive (fresh pages for every output) ran every L2 composite at 40 ms instead of 12
+// (profiles/r03_experiments.txt item 26).  Large transfers are staged through the lane's own pinned memory instead: one CPU copy
+// (~10 GB/s) on the way in, one on the way out after the call's last synchronisation.  Device pointers pass through untouched.
+struct Stage {
+    struct Chunk { void *p = nullptr; size_t cap = 0, used = 0; };
+    struct Pending { void *user; const void *stage; size_t n; };
+    std::vector<Chunk> chunks; std::vector<Pending> pend; bool dirty = false;
+    static constexpr size_t kMin = 32 << 10;      // below this the runtime's own bounce buffers do the same job
+    void *alloc(size_t n) {
+        n = (n + 255) & ~(size_t)255; dirty = true;
+        for (auto &c : chunks) if (c.cap - c.used >= n) { void *r = (char *)c.p + c.used; c.used += n; return r; }
+        Chunk c; c.cap = std::max<size_t>(n, (size_t)4 << 20);      // never moves or frees a chunk that copies in flight may still use
+        HIPCHK(hipHostMalloc(&c.p, c.cap, hipHostMallocDefault));
+        c.used = n; chunks.push_back(c); return c.p;
+    }
+    // after the call's last synchronisation: hand the results over, recycle the arena (several chunks -> one of their total size next time)
+    void finish(bool deliver) {
+        if (deliver) for (auto &q : pend) memcpy(q.user, q.stage, q.n);
+        pend.clear();
+        if (chunks.size() > 1) {
+            size_t tot = 0; for (auto &c : chunks) { tot += c.cap; (void)hipHostFree(c.p); }
+            chunks.clear();
+            Chunk c; c.cap = tot; if (hipHostMalloc(&c.p, c.cap, hipHostMallocDefault) == hipSuccess) chunks.push_back(c);
+        }
+        for (auto &c : chunks) c.used = 0;
+        dirty = false;
+    }
+};
+inline bool is_device_ptr(const void *p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }      // unregistered host memory
+    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+
 struct Timing {
     bool enabled = false;      // the full instrumentation: per-kind spans, accumulate / fold events, first / last
     bool acc_only = false;     // only the spans of the fixed-base accumulation (rofl_set_timing(2)): ten event records per proof instead of ~150
@@ -315,6 +352,22 @@ struct GensEntry { niels *tbl = nullptr; ndm *wtab = nullptr, *wtab_many = nullp
 struct Ctx {
     int device = 0;
     bool inited = false;
+    Stage stg;      // staging of caller memory for this lane's current call (see Stage)
+    // caller memory (host or device) -> device
+    void up(void *dst_dev, const void *src, size_t n, hipStream_t st) {
+        if (n < Stage::kMin || is_device_ptr(src)) { HIPCHK(hipMemcpyAsync(dst_dev, src, n, hipMemcpyDefault, st)); return; }
+        void *s = stg.alloc(n); memcpy(s, src, n);
+        HIPCHK(hipMemcpyAsync(dst_dev, s, n, hipMemcpyHostToDevice, st));
+    }
+    // device -> caller memory (host): delivered by Stage::finish when the lane is released
+    // Returns where the bytes are readable once `st` has been synchronised (the staging copy, or dst_user itself for a small transfer).
+    const void *down(void *dst_user, const void *src_dev, size_t n, hipStream_t st) {
+        if (n < Stage::kMin) { HIPCHK(hipMemcpyAsync(dst_user, src_dev, n, hipMemcpyDeviceToHost, st)); return dst_user; }
+        void *s = stg.alloc(n);
+        HIPCHK(hipMemcpyAsync(s, src_dev, n, hipMemcpyDeviceToHost, st));
+        stg.pend.push_back({dst_user, s, n});
+        return s;
+    }
     Ctx *parent = nullptr;
     std::vector<Ctx *> sibs;      // additional lanes
     int nlanes = 3;      // ROFL_LANES: number of calls that can be in flight on this device
@@ -480,15 +533,30 @@ struct LaneLock {
     Ctx *c = nullptr; Ctx *primary = nullptr; std::unique_lock<std::mutex> lk;
     LaneLock() = default;
     LaneLock(LaneLock &&o) noexcept : c(o.c), primary(o.primary), lk(std::move(o.lk)) { o.c = nullptr; o.primary = nullptr; }
-    ~LaneLock() { if (primary) primary->active_calls.fetch_sub(1); }
+    // the call is over (every API function synchronises its streams before it returns or unwinds): results staged for the caller are
+    // copied out unless an exception is in flight, and the staging arena is recycled
+    ~LaneLock() {
+        if (c && (c->stg.dirty || !c->stg.pend.empty())) {
+            // (near no-ops on the normal path; an error path may leave before its waits: nothing may still read or write the arena)
+            if (c->stream) (void)hipStreamSynchronize(c->stream);
+            if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+            c->stg.finish(std::uncaught_exceptions() == 0);
+        }
+        if (primary) primary->active_calls.fetch_sub(1);
+    }
 };
-LaneLock acquire_lane(bool primary_only = false) {
+// `side`: a call that hardly uses the host pool (one-value sum proofs, the per-element Sigma-proof kernels) looks for a free sibling lane
+// first and leaves the primary lane -- the one with the big pool -- to a range proof over a whole update.  The three proofs of an L2
+// composite start on three threads at once; which of them found the primary lane free used to be a race, and a range proof that lost it
+// ran its 19 hops on a sibling's six threads (one client in six at 28 ms instead of 20).
+LaneLock acquire_lane(bool primary_only = false, bool side = false) {
     Ctx &P = ctx();
     { std::lock_guard<std::mutex> g(P.init_mu); P.init(); }
     HIPCHK(hipSetDevice(P.device));                    // the calling thread may be new to HIP
     LaneLock ll; ll.primary = &P; P.active_calls.fetch_add(1);
     size_t L = primary_only ? 1 : 1 + P.sibs.size();
-    for (size_t i = 0; i < L; i++) {
+    for (size_t k = 0; k < L; k++) {
+        size_t i = side && L > 1 ? (k + 1) % L : k;      // side calls: siblings first, the primary lane last
         Ctx *c = i ? P.sibs[i - 1] : &P;
         std::unique_lock<std::mutex> t(c->mu, std::try_to_lock);
         if (t.owns_lock()) { ll.c = c; ll.lk = std::move(t); c->batch_mode = false; return ll; }

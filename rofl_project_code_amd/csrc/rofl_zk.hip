@@ -138,8 +138,8 @@ int create_impl(Ctx &C, size_t nc, const float *const *values, size_t d, const u
     sc *d_blind_buf = C.blind.as<sc>(nc * dp);
     HIPCHK(hipMemsetAsync(d_blind_buf, 0, sizeof(sc) * nc * dp, C.stream));
     for (size_t i = 0; i < nc; i++) {      // the callers' arrays: host or device memory
-        HIPCHK(hipMemcpyAsync(d_vals + i * d, values[i], sizeof(float) * d, hipMemcpyDefault, C.stream));
-        HIPCHK(hipMemcpyAsync(d_blind_buf + i * dp, blind[i], 32 * d, hipMemcpyDefault, C.stream));
+        C.up(d_vals + i * d, values[i], sizeof(float) * d, C.stream);
+        C.up(d_blind_buf + i * dp, blind[i], 32 * d, C.stream);
     }
     u32 *status = C.status.as<u32>(nc + 4);
     HIPCHK(hipMemsetAsync(status, 0, 4 * (nc + 4), C.stream));
@@ -206,7 +206,7 @@ int create_impl(Ctx &C, size_t nc, const float *const *values, size_t d, const u
     uint8_t *hV = C.h_V.as<uint8_t>(na * dp * 32);
     HIPCHK(hipMemcpyAsync(hV, Vb, na * dp * 32, hipMemcpyDeviceToHost, C.stream2));
     HIPCHK(hipEventRecord(C.ev_v, C.stream2));
-    for (size_t k = 0; k < na; k++) HIPCHK(hipMemcpyAsync(commits_out[act[k]], Cb + k * dp * 32, d * 32, hipMemcpyDeviceToHost, C.stream2));
+    for (size_t k = 0; k < na; k++) C.down(commits_out[act[k]], Cb + k * dp * 32, d * 32, C.stream2);
     std::vector<uint8_t *> pout(na * P);
     for (size_t k = 0; k < na; k++) for (size_t c = 0; c < P; c++) pout[k * P + c] = proofs_out[act[k]] + c * plen;
     prove_chunks(C, "RangeProof", na * P, prove_range, chunk, vshift, d_blind_buf, cn, hV, pout.data(), C.ev_v);
@@ -277,7 +277,7 @@ int verify_impl(Ctx &C, size_t n_clients, const uint8_t *const *proofs, size_t p
     HIPCHK(hipMemsetAsync(status, 0, 4 * (n_clients + 4), C.stream));
     std::vector<uint8_t> hV(tot * 32);
     for (size_t i = 0; i < n_clients; i++) {
-        HIPCHK(hipMemcpyAsync(d_in + i * dp * 32, commits[i], d * 32, hipMemcpyDefault, C.stream));
+        C.up(d_in + i * dp * 32, commits[i], d * 32, C.stream);
         hipLaunchKernelGGL(k_decode, grid1(dp), dim3(TPB), 0, C.stream, (u32)dp, (u32)d, d_in + i * dp * 32, d_shift, d_vn + i * dp, d_enc + i * dp * 32, status + i);
     }
     HIPCHK(hipMemcpyAsync(hV.data(), d_enc, tot * 32, hipMemcpyDeviceToHost, C.stream));
@@ -397,7 +397,7 @@ int rofl_clip_f32(const float *in, size_t d, size_t prove_range, unsigned fp_bit
 int rofl_create_rangeproof_l2(const float *values, size_t d, const uint8_t *blindings32, size_t d_blindings, size_t prove_range, size_t n_partition,
                               unsigned fp_bits, unsigned fp_frac, const rofl_nonce_t *nonce, uint8_t *proof_out, size_t *proof_len_out, uint8_t commit_out[32]) {
     return guarded([&]() -> int {
-        LaneLock lane_lock = acquire_lane(); Ctx &C = *lane_lock.c;
+        LaneLock lane_lock = acquire_lane(false, true); Ctx &C = *lane_lock.c;
         if (d != d_blindings) return fail(ROFL_WRONG_NUM_BLINDING, "WrongNumBlindingFactors");
         if (!valid_fp(fp_bits, fp_frac) || d == 0 || n_partition == 0 || prove_range == 0 || !nonce) return fail(ROFL_BAD_PARAM, "bad parameter (the reference panics here)");
         float mn, mx; clip_bounds(prove_range, fp_bits, fp_frac, &mn, &mx);
@@ -447,7 +447,7 @@ int rofl_create_rangeproof_l2(const float *values, size_t d, const uint8_t *blin
 int rofl_verify_rangeproof_l2(const uint8_t *proof, size_t proof_len, const uint8_t commit[32], size_t prove_range, unsigned fp_bits, unsigned fp_frac,
                               const uint8_t verifier_seed[32], int *ok_out) {
     return guarded([&]() -> int {
-        LaneLock lane_lock = acquire_lane(); Ctx &C = *lane_lock.c;
+        LaneLock lane_lock = acquire_lane(false, true); Ctx &C = *lane_lock.c;
         *ok_out = 0;
         if (!valid_fp(fp_bits, fp_frac) || prove_range == 0) return fail(ROFL_BAD_PARAM, "bad parameter");
         C.init();
@@ -484,7 +484,7 @@ DMerlin sigma_init_state(int kind) {
 }
 int sigma_create(int kind, const float *values, size_t d, const uint8_t *r1, size_t d_r1, const uint8_t *r2, const uint8_t *existing,
                  unsigned fp_bits, unsigned fp_frac, const rofl_nonce_t *nonce, uint8_t *proofs_out, uint8_t *commits_out) {
-    LaneLock lane_lock = acquire_lane(); Ctx &C = *lane_lock.c;
+    LaneLock lane_lock = acquire_lane(false, true); Ctx &C = *lane_lock.c;
     if (d != d_r1) return fail(ROFL_WRONG_NUM_BLINDING, "WrongNumBlindingFactors");
     if (!valid_fp(fp_bits, fp_frac) || !nonce) return fail(ROFL_BAD_PARAM, "bad parameter");
     if (d == 0) return ROFL_OK;
@@ -498,18 +498,18 @@ int sigma_create(int kind, const float *values, size_t d, const uint8_t *r1, siz
     uint8_t *dp = C.aux_pts.as<uint8_t>(d * plen), *dc = C.aux_scal.as<uint8_t>(d * clen);
     u32 *status = C.status.as<u32>(4);
     HIPCHK(hipMemsetAsync(status, 0, 16, C.stream));
-    HIPCHK(hipMemcpyAsync(dv, values, 4 * d, hipMemcpyDefault, C.stream));
-    HIPCHK(hipMemcpyAsync(dr1, r1, 32 * d, hipMemcpyDefault, C.stream));
-    if (has_sq) HIPCHK(hipMemcpyAsync(dr2, r2, 32 * d, hipMemcpyDefault, C.stream));
-    if (dex) HIPCHK(hipMemcpyAsync(dex, existing, 32 * d, hipMemcpyDefault, C.stream));
+    C.up(dv, values, 4 * d, C.stream);
+    C.up(dr1, r1, 32 * d, C.stream);
+    if (has_sq) C.up(dr2, r2, 32 * d, C.stream);
+    if (dex) C.up(dex, existing, 32 * d, C.stream);
     NonceSeed seed{}; const uint8_t *d_stream = nullptr; u64 ss = 0;
     if (nonce->mode == 1) memcpy(seed.w, nonce->seed, 32);
     else { ss = nonce->stream_scalars; uint8_t *sb = C.stream_buf.as<uint8_t>(ss * 64 + 64); HIPCHK(hipMemcpyAsync(sb, nonce->stream, ss * 64, hipMemcpyHostToDevice, C.stream)); d_stream = sb; }
     hipLaunchKernelGGL(k_sigma_prove, dim3((unsigned)((d + 63) / 64)), dim3(64), 0, C.stream, kind, (u32)d, dv, fp_bits, fp_frac, dr1, dr2, dex,
                        nonce->mode, seed, d_stream, ss, sigma_init_state(kind), C.d_tabB, C.d_tabBb, dp, dc, status);
     u32 st = 0;
-    HIPCHK(hipMemcpyAsync(proofs_out, dp, d * plen, hipMemcpyDeviceToHost, C.stream));
-    HIPCHK(hipMemcpyAsync(commits_out, dc, d * clen, hipMemcpyDeviceToHost, C.stream));
+    C.down(proofs_out, dp, d * plen, C.stream);
+    C.down(commits_out, dc, d * clen, C.stream);
     HIPCHK(hipMemcpyAsync(&st, status, 4, hipMemcpyDeviceToHost, C.stream));
     C.sync();
     timing_end(C);
@@ -518,7 +518,7 @@ int sigma_create(int kind, const float *values, size_t d, const uint8_t *r1, siz
     return ROFL_OK;
 }
 int sigma_verify(int kind, const uint8_t *proofs, const uint8_t *commits, size_t d, int *ok_out) {
-    LaneLock lane_lock = acquire_lane(); Ctx &C = *lane_lock.c;
+    LaneLock lane_lock = acquire_lane(false, true); Ctx &C = *lane_lock.c;
     *ok_out = 0;
     if (d == 0) { *ok_out = 1; return ROFL_OK; }
     size_t npts = 1 + (kind != 2) + (kind != 0 ? 1 : 0), clen = 32 * npts, plen = 32 * (npts + (kind != 0 ? 3 : 2));
@@ -527,8 +527,8 @@ int sigma_verify(int kind, const uint8_t *proofs, const uint8_t *commits, size_t
     uint8_t *dp = C.aux_pts.as<uint8_t>(d * plen), *dc = C.aux_scal.as<uint8_t>(d * clen);
     u32 *status = C.status.as<u32>(4);
     HIPCHK(hipMemsetAsync(status, 0, 16, C.stream));
-    HIPCHK(hipMemcpyAsync(dp, proofs, d * plen, hipMemcpyDefault, C.stream));
-    HIPCHK(hipMemcpyAsync(dc, commits, d * clen, hipMemcpyDefault, C.stream));
+    C.up(dp, proofs, d * plen, C.stream);
+    C.up(dc, commits, d * clen, C.stream);
     const bool sg_batch = (C.parent ? C.parent : &C)->opt_sigma_batch != 0;      // rofl_set_option("sigma_batch")
     if (sg_batch) {
         // one random linear combination of all elements' equations: decode + transcripts per element on the device, then ONE Pippenger MSM
@@ -577,7 +577,7 @@ sc compressed_challenge(const uint8_t *pairs, size_t d, const uint8_t cprime[64]
 }
 int compressed_create(const float *values, size_t d, const uint8_t *r32, size_t d_r, const uint8_t *existing, unsigned fp_bits, unsigned fp_frac,
                       const rofl_nonce_t *nonce, uint8_t *proof_out, uint8_t *pairs_out) {
-    LaneLock lane_lock = acquire_lane(); Ctx &C = *lane_lock.c;
+    LaneLock lane_lock = acquire_lane(false, true); Ctx &C = *lane_lock.c;
     if (d != d_r) return fail(ROFL_WRONG_NUM_BLINDING, "WrongNumBlindingFactors");
     if (!valid_fp(fp_bits, fp_frac) || !nonce || d >= 900000) return fail(ROFL_BAD_PARAM, "bad parameter");
     if (nonce->mode == 0 && nonce->stream_scalars < 2) return fail(ROFL_NONCE_SHORT, "nonce stream too short");
@@ -589,12 +589,13 @@ int compressed_create(const float *values, size_t d, const uint8_t *r32, size_t 
     uint8_t *dpairs = C.aux_scal.as<uint8_t>(dd * 64);
     u32 *status = C.status.as<u32>(4);
     HIPCHK(hipMemsetAsync(status, 0, 16, C.stream));
+    const uint8_t *pairs_host = pairs_out;      // where the pairs can be read on the host after the wait (the staging copy of a large transfer)
     if (d) {
-        HIPCHK(hipMemcpyAsync(dv, values, 4 * d, hipMemcpyHostToDevice, C.stream));
-        HIPCHK(hipMemcpyAsync(dr, r32, 32 * d, hipMemcpyHostToDevice, C.stream));
-        if (dex) HIPCHK(hipMemcpyAsync(dex, existing, 32 * d, hipMemcpyHostToDevice, C.stream));
+        C.up(dv, values, 4 * d, C.stream);
+        C.up(dr, r32, 32 * d, C.stream);
+        if (dex) C.up(dex, existing, 32 * d, C.stream);
         hipLaunchKernelGGL(k_eg_pairs, dim3((unsigned)((d + 63) / 64)), dim3(64), 0, C.stream, (u32)d, dv, fp_bits, fp_frac, dr, dex, C.d_tabB, C.d_tabBb, dpairs, status);
-        HIPCHK(hipMemcpyAsync(pairs_out, dpairs, 64 * d, hipMemcpyDeviceToHost, C.stream));
+        pairs_host = (const uint8_t *)C.down(pairs_out, dpairs, 64 * d, C.stream);
     }
     u32 st = 0;
     HIPCHK(hipMemcpyAsync(&st, status, 4, hipMemcpyDeviceToHost, C.stream));
@@ -611,7 +612,7 @@ int compressed_create(const float *values, size_t d, const uint8_t *r32, size_t 
     }
     h51::encode(proof_out, h51::gadd(h_fixed_mul(C.ht.B5, nc[0]), h_fixed_mul(C.ht.Bb5, nc[1])));
     h51::encode(proof_out + 32, h_fixed_mul(C.ht.B5, nc[1]));
-    sc c = compressed_challenge(pairs_out, d, proof_out);
+    sc c = compressed_challenge(pairs_host, d, proof_out);
     sc zm = nc[0], zr = nc[1];
     if (d) {
         CPow cp; fill_pow2(cp.sq, h_mont(c), MAX_LG);
@@ -628,7 +629,7 @@ int compressed_create(const float *values, size_t d, const uint8_t *r32, size_t 
     return ROFL_OK;
 }
 int compressed_verify(const uint8_t *proof, const uint8_t *pairs, size_t d, int *ok_out) {
-    LaneLock lane_lock = acquire_lane(); Ctx &C = *lane_lock.c;
+    LaneLock lane_lock = acquire_lane(false, true); Ctx &C = *lane_lock.c;
     *ok_out = 0;
     ge Lp32, Rp32;
     if (!ristretto_decode(Lp32, proof) || !ristretto_decode(Rp32, proof + 32) || !sc_is_canonical_bytes(proof + 64) || !sc_is_canonical_bytes(proof + 96))
@@ -643,7 +644,7 @@ int compressed_verify(const uint8_t *proof, const uint8_t *pairs, size_t d, int 
         niels *pts = C.aux_pts.as<niels>(2 * d); sc *scal = C.aux_scal.as<sc>(d);
         u32 *status = C.status.as<u32>(4);
         HIPCHK(hipMemsetAsync(status, 0, 16, C.stream));
-        HIPCHK(hipMemcpyAsync(dpairs, pairs, 64 * d, hipMemcpyHostToDevice, C.stream));
+        C.up(dpairs, pairs, 64 * d, C.stream);
         hipLaunchKernelGGL(k_decode_pairs, grid1(2 * d), dim3(TPB), 0, C.stream, (u32)d, dpairs, pts, pts + d, status);
         CPow cp; fill_pow2(cp.sq, h_mont(c), MAX_LG);
         hipLaunchKernelGGL(k_cpow_scalars, grid1(d), dim3(TPB), 0, C.stream, (u32)d, cp, scal);
@@ -701,10 +702,10 @@ int rofl_commit_vec(const uint8_t *values32, const uint8_t *blindings32, size_t 
         C.init();
         sc *dv = C.tmp_in.as<sc>(d); sc *db = blindings32 ? C.tmp_in2.as<sc>(d) : nullptr;
         uint8_t *o = C.Cbytes.as<uint8_t>(d * 32);
-        HIPCHK(hipMemcpyAsync(dv, values32, 32 * d, hipMemcpyHostToDevice, C.stream));
-        if (db) HIPCHK(hipMemcpyAsync(db, blindings32, 32 * d, hipMemcpyHostToDevice, C.stream));
+        C.up(dv, values32, 32 * d, C.stream);
+        if (db) C.up(db, blindings32, 32 * d, C.stream);
         hipLaunchKernelGGL(k_commit, grid1(d), dim3(TPB), 0, C.stream, (u32)d, (const u64 *)nullptr, dv, db, C.d_tabB, C.d_tabBb, (const niels *)nullptr, (uint8_t *)nullptr, o, (u32)d, (u32)d);
-        HIPCHK(hipMemcpyAsync(out32, o, 32 * d, hipMemcpyDeviceToHost, C.stream));
+        C.down(out32, o, 32 * d, C.stream);
         C.sync();
         return ROFL_OK;
     });
@@ -717,11 +718,11 @@ int rofl_add_points_vec(const uint8_t *a32, const uint8_t *b32, size_t d, uint8_
         uint8_t *da = C.tmp_in.as<uint8_t>(d * 32), *db = C.tmp_in2.as<uint8_t>(d * 32), *o = C.Cbytes.as<uint8_t>(d * 32);
         u32 *status = C.status.as<u32>(4);
         HIPCHK(hipMemsetAsync(status, 0, 16, C.stream));
-        HIPCHK(hipMemcpyAsync(da, a32, 32 * d, hipMemcpyHostToDevice, C.stream));
-        HIPCHK(hipMemcpyAsync(db, b32, 32 * d, hipMemcpyHostToDevice, C.stream));
+        C.up(da, a32, 32 * d, C.stream);
+        C.up(db, b32, 32 * d, C.stream);
         hipLaunchKernelGGL(k_add_points, grid1(d), dim3(TPB), 0, C.stream, (u32)d, da, db, o, status);
         u32 st = 0;
-        HIPCHK(hipMemcpyAsync(out32, o, 32 * d, hipMemcpyDeviceToHost, C.stream));
+        C.down(out32, o, 32 * d, C.stream);
         HIPCHK(hipMemcpyAsync(&st, status, 4, hipMemcpyDeviceToHost, C.stream));
         C.sync();
         if (st & 4u) return fail(ROFL_FORMAT_ERROR, "invalid Ristretto encoding");
@@ -739,7 +740,7 @@ int rofl_sum_points(const uint8_t *points, size_t d, size_t stride, uint8_t out3
         ge *part = C.partial2.as<ge>(nblk);
         u32 *status = C.status.as<u32>(4);
         HIPCHK(hipMemsetAsync(status, 0, 16, C.stream));
-        HIPCHK(hipMemcpyAsync(da, points, stride * d, hipMemcpyHostToDevice, C.stream));
+        C.up(da, points, stride * d, C.stream);
         hipLaunchKernelGGL(k_decode_sum, dim3(nblk), dim3(TPB), TPB * sizeof(ge), C.stream, da, (u32)d, (u32)stride, part, status);
         std::vector<ge> hp(nblk); u32 st = 0;
         HIPCHK(hipMemcpyAsync(hp.data(), part, sizeof(ge) * nblk, hipMemcpyDeviceToHost, C.stream));
@@ -764,10 +765,10 @@ int rofl_shift_points(const uint8_t *a32, size_t d, const uint8_t offset32[32], 
         u32 *status = C.status.as<u32>(4);
         HIPCHK(hipMemsetAsync(status, 0, 16, C.stream));
         HIPCHK(hipMemcpyAsync(ds, &hs, sizeof hs, hipMemcpyHostToDevice, C.stream));
-        HIPCHK(hipMemcpyAsync(da, a32, 32 * d, hipMemcpyHostToDevice, C.stream));
+        C.up(da, a32, 32 * d, C.stream);
         hipLaunchKernelGGL(k_decode, grid1(d), dim3(TPB), 0, C.stream, (u32)d, (u32)d, da, ds, (niels *)nullptr, o, status);
         u32 st = 0;
-        HIPCHK(hipMemcpyAsync(out32, o, 32 * d, hipMemcpyDeviceToHost, C.stream));
+        C.down(out32, o, 32 * d, C.stream);
         HIPCHK(hipMemcpyAsync(&st, status, 4, hipMemcpyDeviceToHost, C.stream));
         C.sync();
         if (st & 4u) return fail(ROFL_FORMAT_ERROR, "invalid Ristretto encoding");
@@ -847,8 +848,8 @@ int rofl_dbg_msm(const uint8_t *scalars32, const uint8_t *points32, size_t n, ui
         uint8_t *dp = C.tmp_in.as<uint8_t>(n * 32); niels *dn = C.aux_pts.as<niels>(n); sc *ds = C.aux_scal.as<sc>(n);
         u32 *status = C.status.as<u32>(4);
         HIPCHK(hipMemsetAsync(status, 0, 16, C.stream));
-        HIPCHK(hipMemcpyAsync(dp, points32, n * 32, hipMemcpyHostToDevice, C.stream));
-        HIPCHK(hipMemcpyAsync(ds, hs.data(), n * 32, hipMemcpyHostToDevice, C.stream));
+        C.up(dp, points32, n * 32, C.stream);
+        C.up(ds, hs.data(), n * 32, C.stream);
         hipLaunchKernelGGL(k_decode, grid1(n), dim3(TPB), 0, C.stream, (u32)n, (u32)n, dp, (const niels *)nullptr, dn, (uint8_t *)nullptr, status);
         u32 st = 0;
         HIPCHK(hipMemcpyAsync(&st, status, 4, hipMemcpyDeviceToHost, C.stream));
@@ -904,10 +905,10 @@ int rofl_discrete_log_vec(const uint8_t *points32, size_t d, size_t table_size, 
         uint8_t *dp = C.tmp_in.as<uint8_t>(d * 32), *dout = C.Cbytes.as<uint8_t>(d * 32);
         u32 *status = C.status.as<u32>(4);
         HIPCHK(hipMemsetAsync(status, 0, 16, C.stream));
-        HIPCHK(hipMemcpyAsync(dp, points32, 32 * d, hipMemcpyHostToDevice, C.stream));
+        C.up(dp, points32, 32 * d, C.stream);
         hipLaunchKernelGGL(k_bsgs_solve, dim3((unsigned)((d + 63) / 64)), dim3(64), 0, C.stream, (u32)d, dp, (u32)table_size, bsgs_bits, max_it, neg_mG, B.keys, B.slots, B.mask, dout, status);
         u32 st = 0;
-        HIPCHK(hipMemcpyAsync(scalars_out32, dout, 32 * d, hipMemcpyDeviceToHost, C.stream));
+        C.down(scalars_out32, dout, 32 * d, C.stream);
         HIPCHK(hipMemcpyAsync(&st, status, 4, hipMemcpyDeviceToHost, C.stream));
         C.sync();
         timing_end(C);

@@ -40,7 +40,7 @@ def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=25000, help="elements of the workload the CPU baseline proves and verifies (25 000 = all of it, ~25 s on 4 threads)")
     ap.add_argument("--no-l2", action="store_true")
@@ -438,11 +438,12 @@ def run_rank(args):
     # cold figures: the reference rebuilds BulletproofGens in every call; here the tables are built once per (n, m)
     t_c0 = time.perf_counter(); api.bp_gens_prepare(NBITS, rpv.next_pow2(D) // NPART); gens_build_ms = (time.perf_counter() - t_c0) * 1e3
     t_c0 = time.perf_counter(); step(0, False); first_client_ms = (time.perf_counter() - t_c0) * 1e3
-    for s in range(args.warmup):
-        step(s, False)
-    sync()
     import resource, gc
-    gc.collect(); gc.disable()          # no collector pauses inside the timed steps (a 31.8 ms step among 27.2 ms ones otherwise)
+    sync()      # (also torch's lazy device initialisation: its first synchronize used to fall between the warm-up and the timed steps)
+    gc.collect(); gc.disable()          # no collector pauses inside the timed steps (a 31.8 ms step among 27.2 ms ones otherwise) -- and none
+    for s in range(args.warmup):        # between the warm-up and the timed steps either: a pause there lets the device and the host pool go idle,
+        step(s, False)                  # and the first timed step then took +8 ms
+    sync()
     ru0 = resource.getrusage(resource.RUSAGE_SELF)
     step_ms = []
     t0 = time.perf_counter()

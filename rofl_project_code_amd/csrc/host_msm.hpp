@@ -3,10 +3,13 @@
 #pragma once
 
 // ---------------------------------------------------------------- MSM driver
-MsmPlan msm_plan(size_t n) {
+MsmPlan msm_plan(size_t n, size_t np = 1) {
     MsmPlan p;
     static const size_t t13 = knob("ROFL_MSM_T13") ? (size_t)atol(knob("ROFL_MSM_T13")) : ((size_t)1 << 13);
-    static const size_t t10 = knob("ROFL_MSM_T10") ? (size_t)atol(knob("ROFL_MSM_T10")) : ((size_t)1 << 9);
+    // 10-bit windows from 512 terms on -- from 2 048 on when the launch carries many problems (n_partition = 64: 128 problems of 1 024 terms
+    // run as 4 736 one-wave blocks of 64 buckets rather than 3 328 eight-wave blocks of 512: create 25.1 / 25.9 -> 24.5 ms same-box)
+    static const size_t t10_knob = knob("ROFL_MSM_T10") ? (size_t)atol(knob("ROFL_MSM_T10")) : 0;
+    const size_t t10 = t10_knob ? t10_knob : (np >= 32 ? (size_t)1 << 11 : (size_t)1 << 9);
     if (n >= (1u << 17)) p.c = 16; else if (n >= t13) p.c = 13; else if (n >= t10) p.c = 10; else if (n >= 64) p.c = 7; else p.c = 4;
     if (const char *e = knob("ROFL_MSM_C")) { int v = atoi(e); if (v == 4 || v == 7 || v == 10 || v == 13 || v == 16) p.c = (u32)v; }
     p.W = (254 + p.c - 1) / p.c;
@@ -82,7 +85,7 @@ bool msm_plan_job(Ctx &C, MsmJob &J, const MsmOpt &opt, const MsmAllow &al, MsmM
         return true;
     }
     bool slots_mode = al.slots && C.msm_slots;
-    J.P = msm_plan(n);
+    J.P = msm_plan(n, J.np);
     // up to msm_small_max terms per side the fused small-MSM launch takes the problem: that wants 10-bit windows (512 buckets = one block)
     if (C.msm_small_max && al.small && slots_mode && per_side <= C.msm_small_max && J.P.c > 10 && np * 26 <= 512) J.P = msm_plan_c(10);
     J.PW = np * J.P.W;

@@ -44,7 +44,7 @@ static const Knob KNOBS[] = {
     {"ROFL_MSM_HOST8", "1", "0 = launches with many problems combine their windows on the device (k_msm_horner) even when the host has AVX-512 IFMA"},
     {"ROFL_MSM_DEV_HORNER_MIN", "32", "launches with at least this many problems combine their windows on the device"},
     {"ROFL_MSM_T13", "8192", "generic MSMs from this many terms on use 13-bit windows"},
-    {"ROFL_MSM_T10", "512", "generic MSMs from this many terms on use 10-bit windows (7-bit below, 4-bit below 64)"},
+    {"ROFL_MSM_T10", "512 / 2048", "generic MSMs from this many terms on use 10-bit windows (7-bit below, 4-bit below 64); default 2048 for launches with >= 32 problems"},
     {"ROFL_MSM_C", "0", "window width of every generic MSM (4, 7, 10, 13, 16; 0 = by size)"},
     {"ROFL_MSM_GROUP_REDUCE", "0", "1 = two-launch bucket reduction by groups of 512 (measured slower)"},
     {"ROFL_RED_SPLIT", "0", "1 = four threads per 8-group in k_msm_reduce_level (measured slower)"},

@@ -11,7 +11,10 @@
  * (fp.rs:8-139), taken at run time here (mirrors ModelConfig.fp_bits/fp_frac, flservice.proto:54-55).
  *
  * All buffers are caller-owned host memory unless the name ends in _dev (HIP device pointers on the
- * library's current device).  The library never retains caller pointers after return.
+ * library's current device).  The library never retains caller pointers after return, and it never
+ * hands caller memory to the HIP runtime: host buffers may be ordinary (pageable, freshly allocated)
+ * memory; transfers of 32 KB and more are staged through the library's own pinned memory, inputs are
+ * consumed and outputs complete when the call returns.
  * No C++ exceptions cross this boundary.  Calls are serialised per device context (thread-safe).
  *
  * Return codes: 0 ok; 1 WrongNumBlindingFactors; 2 ValueOutOfRangeError; 3 InvalidBitsize;

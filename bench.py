@@ -41,6 +41,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--multi-inflight", type=int, default=0, help="--config 4: batched calls (6 clients each) in flight at a time, default 3; --config 5: clients whose L2 updates are created / verified concurrently, default 4; 1 = one after the other")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=25000, help="elements of the workload the CPU baseline proves and verifies (25 000 = all of it, ~25 s on 4 threads)")
     ap.add_argument("--no-l2", action="store_true")
@@ -202,8 +203,8 @@ def synth_multi(cfg, client, step):
 def run_multi_client(args, R, rd, dist, cdev, world, rank, backend):
     """BASELINE configs 4 / 5: `--clients` (48) seeded clients of d = 55 000 sharded round-robin over the ranks (dist.shard_clients;
     the server hands one client per pool task, server.rs:656-687).  One step = one round of the protocol:
-      every rank creates the proofs of ITS clients (cfg 4: rofl_create_rangeproof_batch in groups of 6; cfg 5: EncParamsL2.encrypt +
-      serialize, params.rs:608-663) -> ONE all-gather of [proof bytes | commitments] (cfg 5: the wire messages) -> every rank verifies
+      every rank creates the proofs of ITS clients (cfg 4: rofl_create_rangeproof_batch in groups of 6, --multi-inflight (3) such calls in
+      flight on host threads; cfg 5: EncParamsL2.encrypt + serialize, params.rs:608-663, --multi-inflight (4) clients in flight) -> ONE all-gather of [proof bytes | commitments] (cfg 5: the wire messages) -> every rank verifies
       the share of ANOTHER rank (rank + 1; cfg 4: rofl_verify_rangeproof_batch, cfg 5: deserialize + verify) -> MIN all-reduce of the
       verdicts (one failing client fails the round, server.rs:474-484).
     value = clients * d * K / wall time: the total work is fixed, so N > 1 is STRONG scaling."""
@@ -218,26 +219,32 @@ def run_multi_client(args, R, rd, dist, cdev, world, rank, backend):
     group = 6
     total_steps = args.warmup + args.steps
     phase = {"create": 0.0, "exchange": 0.0, "verify": 0.0, "payload": 0}
+    cpool = None
+    if args.multi_inflight > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        cpool = ThreadPoolExecutor(max_workers=args.multi_inflight, thread_name_prefix="bench-client")
 
     def step(s, record):
         t0 = time.perf_counter()
         ins = [synth_multi(cfg, c, s) for c in mine]
         t_in = time.perf_counter()
         if cfg == 4:
-            prs, cms = [], []
-            for g0 in range(0, len(mine), group):
+            def make_group(g0):
                 g = list(range(g0, min(g0 + group, len(mine))))
                 res = rpv.create_rangeproof_batch([ins[k][0] for k in g], [ins[k][1] for k in g], NBITS, P,
                                                   nonces=[R.Nonce.seeded(bytes([(mine[k] + 1) % 256]) * 32) for k in g], fp=FP)
                 for r_ in res:
                     assert not isinstance(r_, Exception), r_
-                    prs.append(r_[0]); cms.append(r_[1])
+                return res
+            starts = list(range(0, len(mine), group))
+            groups = list(cpool.map(make_group, starts)) if cpool else [make_group(g0) for g0 in starts]
+            prs = [r_[0] for res in groups for r_ in res]; cms = [r_[1] for res in groups for r_ in res]
             payloads = [np.stack(prs), np.stack(cms)]
         else:
-            blobs = []
-            for k, c in enumerate(mine):
-                upd = params.EncParamsL2.encrypt(ins[k][0], ins[k][1], 8, P, 32, nonce_seed=bytes([(c + 1) % 256]) * 32, rand_scalars=ins[k][2], fp=FP)
-                blobs.append(np.frombuffer(upd.serialize(), dtype=np.uint8))
+            def make(k):
+                upd = params.EncParamsL2.encrypt(ins[k][0], ins[k][1], 8, P, 32, nonce_seed=bytes([(mine[k] + 1) % 256]) * 32, rand_scalars=ins[k][2], fp=FP)
+                return np.frombuffer(upd.serialize(), dtype=np.uint8)
+            blobs = list(cpool.map(make, range(len(mine)))) if cpool else [make(k) for k in range(len(mine))]
             assert len({b.size for b in blobs}) == 1
             payloads = [np.stack(blobs)]
         t1 = time.perf_counter()
@@ -248,14 +255,15 @@ def run_multi_client(args, R, rd, dist, cdev, world, rank, backend):
         n_their = len(rd.shard_clients(NC, src, world))
         if cfg == 4:
             pp = theirs[0].reshape((n_their,) + payloads[0].shape[1:]); cc = theirs[1].reshape((n_their,) + payloads[1].shape[1:])
-            oks = []
-            for g0 in range(0, n_their, group):
-                oks += rpv.verify_rangeproof_batch([pp[k] for k in range(g0, min(g0 + group, n_their))], [cc[k] for k in range(g0, min(g0 + group, n_their))],
-                                                   NBITS, verifier_seed=bytes([s % 256]) * 32, fp=FP)
+            check_group = lambda g0: rpv.verify_rangeproof_batch([pp[k] for k in range(g0, min(g0 + group, n_their))], [cc[k] for k in range(g0, min(g0 + group, n_their))],
+                                                                 NBITS, verifier_seed=bytes([s % 256]) * 32, fp=FP)
+            vstarts = list(range(0, n_their, group))
+            oks = [o for res in (cpool.map(check_group, vstarts) if cpool else map(check_group, vstarts)) for o in res]
             ok = all(oks)
         else:
             bb = theirs[0].reshape(n_their, -1)
-            ok = all(params.EncParamsL2.deserialize(bytes(bb[k])).verify(verifier_seed=bytes([s % 256]) * 32, fp=FP) for k in range(n_their))
+            check = lambda k: params.EncParamsL2.deserialize(bytes(bb[k])).verify(verifier_seed=bytes([s % 256]) * 32, fp=FP)
+            ok = all(cpool.map(check, range(n_their))) if cpool else all(check(k) for k in range(n_their))
         ok = rd.all_verified(ok, cdev)
         t3 = time.perf_counter()
         assert ok, "a client's proofs failed to verify"
@@ -301,7 +309,8 @@ def run_multi_client(args, R, rd, dist, cdev, world, rank, backend):
                "config": {"workload": "BASELINE cfg %d: %s, d=55000 (resnet18_intrinsic_55k), %d clients sharded over %d rank(s): batch create -> one all-gather of "
                                       "proof bytes + commitments -> every rank batch-verifies the share of rank+1 -> MIN all-reduce of the verdicts" % (cfg, kind, NC, world),
                           "d": D_MULTI, "clients": NC, "clients_per_rank": len(mine), "prove_range": NBITS if cfg == 4 else 8, "l2_range": None if cfg == 4 else 32,
-                          "n_partition": P, "fp_bits": FP_BITS, "fp_frac": FP_FRAC, "host_cores": avail_cores()},
+                          "n_partition": P, "fp_bits": FP_BITS, "fp_frac": FP_FRAC, "host_cores": avail_cores(),
+                          "clients_in_flight_per_rank": (args.multi_inflight if cfg == 5 else ("%d batched calls of 6 clients" % args.multi_inflight if cpool else "one batched call of 6 clients at a time"))},
                "breakdown_ms_per_step_rank0": {k: phase[k] / K * 1e3 for k in ("create", "exchange", "verify")},
                "all_gather_bytes_per_rank": int(phase["payload"]),
                "cold": {"gens_tables_build_ms": gens_build_ms, "first_round_ms": first_round_ms,
@@ -357,6 +366,18 @@ def run_rank(args):
         os.environ.setdefault("ROFL_BLOCKING_SYNC", "1")
     if local_world > 1:      # the library sizes its host pool from the cores of the process; ranks of one node share them
         os.environ.setdefault("ROFL_HOST_THREADS", str(max(2, min(14, int(avail_cores() / local_world) - 1))))
+    if args.multi_inflight <= 0:
+        args.multi_inflight = 3 if args.config == 4 else 4
+    if args.config == 4:
+        # cfg 4: the clients of a rank go through rofl_create_rangeproof_batch / rofl_verify_rangeproof_batch six at a time, `multi_inflight` such
+        # calls in flight on separate lanes (host threads): the latency-bound tail of one call overlaps the throughput-bound phases of another
+        os.environ.setdefault("ROFL_LANES", str(max(3, args.multi_inflight)))
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(4, args.multi_inflight + 2)))
+    if args.config == 5:
+        # cfg 5: a client's L2 update is three proofs on three lanes; `multi_inflight` clients are in flight at a time (the reference's server
+        # verifies its clients from a rayon pool, server.rs:656-687; its clients prove on their own machines)
+        os.environ.setdefault("ROFL_LANES", str(3 * max(1, args.multi_inflight)))
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(4, 3 * max(1, args.multi_inflight) + 2)))
     if extras:
         os.environ.setdefault("ROFL_LANES", str(max(3, CIF)))
         # one hardware queue per lane: the HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES (default 4) queues, read

@@ -95,7 +95,7 @@ def _concurrently(*thunks):
         return [thunks[0]()]
     if _pool is None:
         from concurrent.futures import ThreadPoolExecutor
-        _pool = ThreadPoolExecutor(max_workers=3, thread_name_prefix="rofl-params")
+        _pool = ThreadPoolExecutor(max_workers=12, thread_name_prefix="rofl-params")      # three proofs per container, up to four containers in flight (threads start on demand)
     futs = [_pool.submit(t) for t in thunks]
     return [f.result() for f in futs]
 

@@ -244,3 +244,21 @@ def test_batch_argument_lengths_are_checked(R):
         R.range_proof_vec.create_rangeproof_batch([vals, vals], [bl], 8, 1, fp=(16, 7))
     with pytest.raises(ValueError):
         R.range_proof_vec.create_rangeproof_batch([vals, vals], [bl, bl], 8, 1, nonces=[R.Nonce.seeded(b"\x01" * 32)], fp=(16, 7))
+
+
+def test_caller_memory_is_staged_for_any_size(R):
+    """Transfers between caller memory and the device go through the lane's pinned staging arena from 32 KB on and straight through
+    below that (csrc/host_rt.hpp `Stage`): sizes on both sides of the threshold, a transfer larger than the arena's first chunk (the
+    arena grows, then coalesces its chunks when the call ends), fresh output arrays every time, results dropped in between -- the
+    bytes must be the oracle's every time.  (Pageable buffers handed to hipMemcpyAsync used to cost 20-30 ms after a free.)"""
+    rng = np.random.default_rng(20261002)
+    for d in (5, 900, 1100, 30000, 200000, 1100, 200000, 7):
+        v = rng.integers(0, 256, size=(d, 32), dtype=np.uint8); v[:, 31] &= 0x0F
+        b = rng.integers(0, 256, size=(d, 32), dtype=np.uint8); b[:, 31] &= 0x0F
+        got = R.pedersen_ops.commit_vec(v, b)
+        pick = np.unique(np.concatenate([np.arange(min(d, 40)), np.arange(max(0, d - 40), d), rng.integers(0, d, size=60)]))
+        want = orc.commit_vec(v[pick], b[pick])
+        assert (got[pick] == want).all(), d
+        s = R.pedersen_ops.add_rp_vec(got, got)          # two staged inputs, one staged output
+        assert (s[pick] == orc.add_points_vec(want, want)[1]).all(), d
+        del got, s

@@ -61,6 +61,15 @@ bool msm_plan_job(Ctx &C, MsmJob &J, const MsmOpt &opt, const MsmAllow &al, MsmM
         u32 sets = J.P.W;
         for (u32 sdiv = 1; sdiv <= J.P.W; sdiv++)
             if (J.P.W % sdiv == 0 && (size_t)nq * (lr ? 2 : 1) * sdiv * J.P.B >= want) { sets = sdiv; break; }      // many problems (n_partition = 64): one set each is plenty
+        // ... but the two-level sort needs a coarse bin to fit a block's LDS: with many problems of many terms (a batched call of cfg-4 clients:
+        // 48 problems of 2^19 terms a side) one set per problem means 16 windows per array and bins of 131 KB -- the launch fell back to the slot
+        // sort (a 6.4 GB slot array, 3x the sort time).  More sets per problem until the bins fit (ROFL_MSM_FB_FITSETS=0: as before).
+        static const bool fitsets = !(knob("ROFL_MSM_FB_FITSETS") && atoi(knob("ROFL_MSM_FB_FITSETS")) == 0);
+        if (fitsets && al.two && C.msm_two_level && (J.P.B == 32768 || J.P.B == 16384) && per_side >= 8192)
+            while (sets < J.P.W && ((2 * (per_side * (J.P.W / sets) / 512) + 256 + 63) / 64 * 64) * 4 + 1024 > 96 * 1024) {
+                u32 nx = sets + 1; while (nx < J.P.W && J.P.W % nx) nx++;
+                sets = nx;
+            }
         J.sets = sets;
         mm.fb_sets = sets; mm.fb_wps = J.P.W / sets; mm.fb_stride = (u32)opt.fb_stride;
         J.PW = nq * (lr ? 2 : 1) * sets;

@@ -20,6 +20,7 @@ static const Knob KNOBS[] = {
     {"ROFL_FOLD_T1", "3", "IPP rounds before the first generator fold (1..6)"},
     {"ROFL_FOLD_T", "2", "IPP rounds between later folds (1..6)"},
     {"ROFL_FOLD_MIN", "1024", "no fold once fewer generators per chunk would remain (launches with many chunks fold down to 64)"},
+    {"ROFL_MSM_FB_FITSETS", "1", "0 = do not add bucket sets to a fixed-base launch whose coarse bins would not fit the two-level sort"},
     {"ROFL_SYNC_POLL", "0", "1 = wait for the lane's stream with hipStreamQuery in a pause loop instead of hipStreamSynchronize"},
     {"ROFL_FOLD_TAB", "1", "0 = first fold without the precomputed odd-multiple slices"},
     {"ROFL_FOLD_PB", "32", "piece width of the fold table in bits (16, 32, 64)"},

@@ -11,6 +11,7 @@ import numpy as np
 import rofl_project_code_amd as R
 import bench
 R.set_device(0)
+if os.environ.get("THR_D"): bench.D = int(os.environ["THR_D"])      # e.g. 55000: the cfg 4 client size
 rpv = R.range_proof_vec; FP = bench.FP; D = bench.D
 cl = [bench.synth_client(5000 + j) for j in range(C)]
 nonces = [R.Nonce.seeded(bytes([j + 1]) * 32) for j in range(C)]

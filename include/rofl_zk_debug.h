@@ -44,6 +44,9 @@ int rofl_dbg_host_bench(int what, unsigned iters, double *ns_out);
 int rofl_dbg_host_horner8_selftest(unsigned W, unsigned c, int lanes, double *us_simd, double *us_scalar);
 /* h8::encode8 (eight Ristretto encodings per AVX-512 IFMA stream) against the scalar host encoder: 0 = all equal, 1 = mismatch, -1 = no IFMA */
 int rofl_dbg_host_encode8_selftest(unsigned batches, double *us_simd, double *us_scalar);
+/* host share of the hops of the calling thread's last create / verify: out[0] hops, [1] enqueue ms, [2] wait ms, [3] window-combination wall ms,
+ * [4] sum of each hop's slowest pool task ms, [5..8] the maxima over the hops of enqueue, wait, combination wall, slowest task */
+int rofl_dbg_last_hops(double out[10]);
 
 #ifdef __cplusplus
 }

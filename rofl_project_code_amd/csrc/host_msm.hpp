@@ -24,7 +24,7 @@ MsmPlan msm_plan(size_t n, size_t np = 1) {
 // are the generator table `opt.fb_gens` (n terms from its start, slice stride opt.fb_stride) for which a window table exists.
 // overlap: host work to run while the kernels execute; post(p): runs on the pool thread that finished problem p's window combination,
 // right after results[p] is final (the caller's per-problem tail -- encoding, transcript -- without a second pool hand-off on the hop)
-struct MsmOpt { u32 lr_nh = 0, lr_ng = 0; const niels *fb_wtab = nullptr; size_t fb_stride = 0; u32 fb_c = 16; std::function<void()> overlap; std::function<void(size_t)> post;
+struct MsmOpt { u32 lr_nh = 0, lr_ng = 0; const niels *fb_wtab = nullptr; size_t fb_stride = 0; u32 fb_c = 16; std::function<void()> overlap; std::function<void(size_t)> post; u32 tag = 0;      /* tag: which hop of its caller this is (0 = unknown): keys the wait-time estimate */
                 std::function<void(size_t, int)> post8; };      // post8(p0, count): the finisher of problems p0 .. p0 + count - 1 (p0 a multiple of 8) of a host8 task, instead of `count` calls of post
 
 // An MSM goes through four stages: PLAN (which variant, window layout, bucket sets, capacities) -> SORT (digits into per-bucket lists)
@@ -382,7 +382,7 @@ void msm_finish(Ctx &C, const MsmJob &J, std::vector<ge5> &results, const MsmOpt
         }
     }
     C.tm.t.host_ms += now_ms() - t0;
-    C.hs.horner_wall += now_ms() - t0; { double mx = 0; for (double v : cpu_each) mx = std::max(mx, v); C.hs.horner_cpu += mx; } C.hs.n++;
+    { double w = now_ms() - t0; C.hs.horner_wall += w; C.hs.max_horner = std::max(C.hs.max_horner, w); double mx = 0; for (double v : cpu_each) mx = std::max(mx, v); C.hs.horner_cpu += mx; C.hs.max_task = std::max(C.hs.max_task, mx); } C.hs.n++;
 }
 
 // one MSM, start to finish: enqueue, wait, repeat through the next variant if a fixed-size structure overflowed, combine.
@@ -392,9 +392,12 @@ void msm_run(Ctx &C, const std::vector<MsmProb> &probs, size_t n, std::vector<ge
         double t_enter = now_ms();
         MsmJob J = msm_enqueue(C, C.mws[0], probs, n, opt, al);
         if (opt.overlap && !overlap_done) { opt.overlap(); overlap_done = true; }
-        double t_sync0 = now_ms(); C.hs.enqueue += t_sync0 - t_enter;
+        double t_sync0 = now_ms(); C.hs.enqueue += t_sync0 - t_enter; C.hs.max_enqueue = std::max(C.hs.max_enqueue, t_sync0 - t_enter);
+        const uint64_t wkey = ((uint64_t)opt.tag << 40) ^ ((uint64_t)probs.size() << 28) ^ (uint64_t)n;
+        if (opt.tag) { auto it = C.wait_ms.find(wkey); C.pool->expect_gap(it == C.wait_ms.end() ? 0.0 : it->second * 1e3); }
         C.sync();
-        C.hs.sync += now_ms() - t_sync0;
+        { double w = now_ms() - t_sync0; C.hs.sync += w; C.hs.max_sync = std::max(C.hs.max_sync, w);
+          if (opt.tag) { double &e = C.wait_ms[wkey]; e = e == 0 ? w : std::min(w, 0.5 * (e + w)); } }
         if (msm_retry(J, al)) continue;
         msm_finish(C, J, results, opt);
         return;

@@ -73,7 +73,7 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
     std::vector<sc> a_bl(P), s_bl(P), y(P), z(P), zz(P), x(P), w(P);
     for (size_t c = 0; c < P; c++) tr.emplace_back(label, strlen(label));
     {
-        MsmOpt mo; if (wtab) { gens.fb_for(P, &mo.fb_wtab, &mo.fb_c); mo.fb_stride = 2 * N; }
+        MsmOpt mo; mo.tag = 99; if (wtab) { gens.fb_for(P, &mo.fb_wtab, &mo.fb_c); mo.fb_stride = 2 * N; }
         mo.overlap = [&]() {      // the transcript prefix (m commitments per chunk) does not depend on S: hash it while the MSM runs
             double t0 = now_ms();
             if (v_ready) HIPCHK(hipEventSynchronize(v_ready));      // first in the stream: long done by the time the S launches are enqueued
@@ -199,6 +199,7 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
         C.tm.t.msm_terms += P * 2 * n_g;
         MsmOpt mo;
         if (merged) { mo.lr_nh = (u32)nh; mo.lr_ng = (u32)n_g; }
+        mo.tag = 100 + round;
         if (first_level && wtab) { gens.fb_for(2 * P, &mo.fb_wtab, &mo.fb_c); mo.fb_stride = 2 * N; }
         // The host tail of the round runs inside the MSM's own pool tasks: the thread that finishes problem 2c (+1) adds c_L w B (c_R w B)
         // and encodes L (R); the second of a chunk's two to get there hashes both into the transcript, draws u and inverts it.  L and R

@@ -21,6 +21,7 @@ static const Knob KNOBS[] = {
     {"ROFL_FOLD_T", "2", "IPP rounds between later folds (1..6)"},
     {"ROFL_FOLD_MIN", "1024", "no fold once fewer generators per chunk would remain (launches with many chunks fold down to 64)"},
     {"ROFL_MSM_FB_FITSETS", "1", "0 = do not add bucket sets to a fixed-base launch whose coarse bins would not fit the two-level sort"},
+    {"ROFL_POOL_NAP", "1", "0 = pool workers do not nap through a wait whose length the caller announced (they poll for ROFL_POOL_SPIN_US, then sleep until woken)"},
     {"ROFL_SYNC_POLL", "0", "1 = wait for the lane's stream with hipStreamQuery in a pause loop instead of hipStreamSynchronize"},
     {"ROFL_FOLD_TAB", "1", "0 = first fold without the precomputed odd-multiple slices"},
     {"ROFL_FOLD_PB", "32", "piece width of the fold table in bits (16, 32, 64)"},
@@ -175,6 +176,7 @@ class HostPool {
     std::vector<std::thread> workers; std::mutex mu; std::condition_variable cv;
     std::function<void(size_t)> fn; std::atomic<size_t> count{0}, next{0}, done{0}; std::atomic<int> active{0}; std::atomic<uint64_t> gen{0}; bool stop = false;
     double spin_us = 400.0;      // ROFL_POOL_SPIN_US: how long an idle worker polls for the next job before it sleeps
+    std::atomic<uint64_t> hint_seq{0}; std::atomic<double> gap_us{0.0};      // expect_gap(): the caller's estimate of its coming wait for the device
     const std::atomic<int> *calls_in_flight = nullptr;      // polling is for a call that is alone on the device: with several in flight the pools of the lanes would fight over the cores
     // An index is claimed only after it has been checked against `count` (compare-and-swap, not fetch-add): a worker that wakes
     // late and arrives while run() is resetting the job (count == 0 in that window) must not consume an index of the next job --
@@ -193,13 +195,27 @@ class HostPool {
     // other at 0.1-0.3 ms, and a sleeping thread has to be put back on a CPU by the scheduler first -- on a busy host (the GPU boxes run
     // at a load average above 20) that wake-up is where multi-millisecond outliers of a 25 ms proof came from.
     void loop() {
-        uint64_t seen = 0;
+        uint64_t seen = 0, my_hint = 0;
         for (;;) {
             if (spin_us > 0 && (!calls_in_flight || calls_in_flight->load(std::memory_order_relaxed) <= 1)) {
                 auto t0 = std::chrono::steady_clock::now();
                 uint64_t g;
                 while ((g = gen.load(std::memory_order_acquire)) == seen) {
                     __builtin_ia32_pause();
+                    // the caller is about to wait ~gap_us for the device (expect_gap): sleep through most of it and be polling again when the
+                    // next job arrives -- no wake-up has to come from the caller's thread (fifteen futex wake-ups on the hop, and on a loaded
+                    // host the woken threads landing on the waker's CPU, were the 1.5-2 ms hops of the slow steps)
+                    uint64_t hs = hint_seq.load(std::memory_order_acquire);
+                    if (hs != my_hint) {
+                        my_hint = hs;
+                        double gap = gap_us.load(std::memory_order_relaxed);
+                        if (gap > 700.0) {
+                            double ns = std::min(gap - 350.0, 6000.0) * 1e3;
+                            struct timespec ts = {0, (long)ns}; nanosleep(&ts, nullptr);
+                            t0 = std::chrono::steady_clock::now();
+                            continue;
+                        }
+                    }
                     if (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > spin_us) break;
                 }
                 // a job seen while polling is taken without the mutex (fifteen pollers queueing for it cost the hop tens of microseconds): run()
@@ -221,9 +237,13 @@ class HostPool {
 public:
     explicit HostPool(int nthreads, const std::atomic<int> *in_flight = nullptr) : calls_in_flight(in_flight) {
         if (const char *e = knob("ROFL_POOL_SPIN_US")) spin_us = atof(e);
+        if (const char *e = knob("ROFL_POOL_NAP")) nap = atoi(e) != 0;
         for (int i = 1; i < nthreads; i++) workers.emplace_back([this] { loop(); });
     }
     ~HostPool() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); for (auto &t : workers) t.join(); }
+    // called right before the caller starts a wait it expects to last `us` microseconds (0 = unknown): polling workers nap through it
+    void expect_gap(double us) { if (!nap) return; gap_us.store(us, std::memory_order_relaxed); hint_seq.fetch_add(1, std::memory_order_release); }
+    bool nap = true;      // ROFL_POOL_NAP=0: workers only poll / sleep on the condition variable, as before
     void run(size_t n, std::function<void(size_t)> f) {
         if (n <= 1 || workers.empty()) { for (size_t i = 0; i < n; i++) f(i); return; }
         spin_until([&] { return active.load() == 0; });     // no straggler of the previous job may still look at fn
@@ -428,13 +448,14 @@ struct Ctx {
     bool msm_slots = true;
     int fold_t = 2, fold_t1 = 3, fold_k = 0, fold_tab = 1, fold_unit = 1; long fold_threads = 131072;
     Timing tm;
-    struct HopStats { double enqueue = 0, sync = 0, horner_wall = 0, horner_cpu = 0, host_wall = 0, host_cpu = 0; int n = 0; } hs;      // ROFL_TRACE: where the host hops go
+    struct HopStats { double enqueue = 0, sync = 0, horner_wall = 0, horner_cpu = 0, host_wall = 0, host_cpu = 0, max_enqueue = 0, max_sync = 0, max_horner = 0, max_task = 0; int n = 0; } hs;      // where the host hops of the current call go (ROFL_TRACE, rofl_dbg_last_hops)
     // workspace
     DevBuf cp, sL, sR, party, Scanon, vshift, blind, Vbytes, Cbytes, status, partial, partial2, scpart, a, b, a2, b2, ptab[2], yinv,
         SL, SR, powtabs, foldprobs, naf,
         gbuf[2], aux_pts, aux_scal, vscal, tmp_in, tmp_in2, tmp_out, vals, uni, stream_buf;
     PinBuf h_cp, h_part, h_misc, h_misc2, h_auxc, h_auxs, h_V, h_ip, h_round, h_fdig, h_fprob, h_abfin;
     MsmWs mws[2];
+    std::map<uint64_t, double> wait_ms;      // how long the wait of a tagged hop took the last times (hint for the pool workers' naps)
 
     void init() {
         if (inited) return;

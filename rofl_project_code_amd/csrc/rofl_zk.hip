@@ -74,12 +74,14 @@ float l2_clip_bound(size_t range, unsigned fp_bits, unsigned fp_frac) {
 bool valid_fp(unsigned fp_bits, unsigned fp_frac) { return (fp_bits == 8 || fp_bits == 16 || fp_bits == 32 || fp_bits == 64) && fp_frac <= 12 && fp_frac < fp_bits; }
 
 thread_local rofl_timing_t g_last_timing{};
+thread_local double g_last_hops[10] = {0};      // rofl_dbg_last_hops: the HopStats of the calling thread's last range-proof call
 thread_local rofl_kernel_time_t g_last_ktimes[ROFL_TK_COUNT]{};
 void timing_begin(Ctx &C) {
     C.tm.reset();
     if (C.tm.enabled) { C.tm.first = C.tm.get(); C.tm.last = C.tm.get(); HIPCHK(hipEventRecord(C.tm.first, C.stream)); }
 }
 void timing_end(Ctx &C) {
+    { const auto &h = C.hs; double v[10] = {(double)h.n, h.enqueue, h.sync, h.horner_wall, h.horner_cpu, h.max_enqueue, h.max_sync, h.max_horner, h.max_task, 0}; memcpy(g_last_hops, v, sizeof v); C.hs = Ctx::HopStats(); }
     if (!C.tm.enabled) {
         g_last_timing = C.tm.t; memset(g_last_ktimes, 0, sizeof g_last_ktimes);
         if (C.tm.acc_only && !C.tm.kev.empty()) {      // the stream has been synchronised by the caller's last wait: the few recorded spans are complete
@@ -1132,6 +1134,9 @@ int rofl_dbg_host_encode8_selftest(unsigned batches, double *us_simd, double *us
     if (us_scalar) *us_scalar = ts * 1e3 / (batches ? batches : 1);
     return bad;
 }
+// the host hops of the calling thread's last create / verify call: out[0..8] = number of MSM hops, enqueue ms, wait ms, window-combination
+// wall ms, sum of each hop's slowest task ms, then the maxima over the hops: enqueue, wait, combination wall, slowest task
+int rofl_dbg_last_hops(double out[10]) { if (!out) return fail(ROFL_BAD_PARAM, "bad parameter"); memcpy(out, g_last_hops, sizeof g_last_hops); return ROFL_OK; }
 int rofl_dbg_host_fe_mul(const uint8_t a[32], const uint8_t b[32], uint8_t out[32]) { fe_tobytes(out, fe_mul(fe_frombytes(a), fe_frombytes(b))); return 0; }
 int rofl_dbg_host_fe_ops(const uint8_t a[32], const uint8_t b[32], uint8_t oa[32], uint8_t os[32], uint8_t oq[32], uint8_t oi[32]) {
     fe x = fe_frombytes(a), y = fe_frombytes(b);

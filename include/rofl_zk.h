@@ -15,7 +15,8 @@
  * hands caller memory to the HIP runtime: host buffers may be ordinary (pageable, freshly allocated)
  * memory; transfers of 32 KB and more are staged through the library's own pinned memory, inputs are
  * consumed and outputs complete when the call returns.
- * No C++ exceptions cross this boundary.  Calls are serialised per device context (thread-safe).
+ * No C++ exceptions cross this boundary.  Every entry point is thread-safe; concurrent calls run side by side on the lanes (HIP stream +
+ * workspace) of their device, ROFL_LANES of them per device.
  *
  * Return codes: 0 ok; 1 WrongNumBlindingFactors; 2 ValueOutOfRangeError; 3 InvalidBitsize;
  * 4 InvalidAggregation; 5 FormatError; 6 InvalidGeneratorsLength; 7 NormOutOfRangeError;
@@ -53,9 +54,16 @@ typedef struct {
     uint8_t seed[32];
 } rofl_nonce_t;
 
-/* ---- context / device ---- */
-int rofl_set_device(int device);                       /* select the HIP device used by later calls */
-int rofl_last_error(char *buf, size_t len);            /* human-readable text of the last failure */
+/* ---- context / device ----
+ * One process drives any number of GPUs (the reference's server is ONE process that hands its clients to a verification pool,
+ * rofl_service/src/flserver/server.rs:379-384, 513-521, 656-687).  The device a call runs on is a property of the CALLING THREAD, as with
+ * hipSetDevice: rofl_set_device(d) binds the calling thread to device d, brings that device's context up (an unusable device is reported
+ * here and leaves the binding unchanged) and makes d the default of threads that never called it -- a one-GPU host sets it once and calls
+ * from any thread; a multi-GPU server binds each pool thread to its device, or lists the devices in rofl_set_option("devices", mask) and
+ * lets rofl_create_rangeproof_batch / rofl_verify_rangeproof_batch spread their clients.  Generator tables are cached per device. */
+int rofl_set_device(int device);
+int rofl_get_device(int *device_out);                  /* the device the calling thread's next call runs on */
+int rofl_last_error(char *buf, size_t len);            /* human-readable text of the calling thread's last failure */
 /* BulletproofGens::new(n_bits, m) (generators.rs; re-run by the reference on every helper call,
  * range_proof_vec/mod.rs:126,201) -- built once on the device and cached per (n_bits, m). */
 int rofl_bp_gens_prepare(size_t n_bits, size_t m);
@@ -83,7 +91,8 @@ int rofl_create_rangeproof(const float *values, size_t d, const uint8_t *blindin
  * proofs_out[i] (n_proofs * proof_len bytes) and commits_out[i] (d * 32 bytes): its results; rc_out[i]: its own outcome
  * (0, 2 ValueOutOfRangeError, 10 non-finite, 12 nonce stream too short) -- a client that fails is left out, the others are proved.
  * The return value is non-zero only for errors of the whole call.  Each client's proof is bit-identical to what
- * rofl_create_rangeproof returns for it. */
+ * rofl_create_rangeproof returns for it.  With rofl_set_option("devices", mask) the clients are dealt round-robin to the listed devices
+ * and proved there side by side (one internal thread per device); results arrive in the caller's arrays as before. */
 int rofl_create_rangeproof_batch(size_t n_clients, const float *const *values, size_t d, const uint8_t *const *blindings32,
                                  size_t prove_range, size_t n_partition, unsigned fp_bits, unsigned fp_frac,
                                  const rofl_nonce_t *nonces /* [n_clients] */, uint8_t *const *proofs_out, size_t *proof_len_out,
@@ -94,7 +103,11 @@ int rofl_verify_rangeproof(const uint8_t *proofs, size_t proof_len, size_t n_pro
                            const uint8_t *commits32, size_t d, size_t prove_range, unsigned fp_bits,
                            unsigned fp_frac, const uint8_t verifier_seed[32], int *ok_out);
 /* server-side batch (server.rs:656-687 hands one client per pool thread): n_clients independent
- * (proofs, commits) sets with identical (d, prove_range, n_proofs); ok_out[n_clients] */
+ * (proofs, commits) sets with identical (d, prove_range, n_proofs); ok_out[n_clients] = each client's own verdict (a malformed member
+ * fails alone).  rofl_set_option("verify_batch", 2) checks the whole batch with ONE random-weighted equation -- one generator MSM per
+ * batch instead of one per client -- and looks closer only when that fails, so the verdicts are the same as with per-client checks;
+ * rofl_set_option("devices", mask) deals the clients round-robin to the listed devices (one internal thread per device, verdicts gathered
+ * in ok_out: no collective is needed inside one process). */
 int rofl_verify_rangeproof_batch(size_t n_clients, const uint8_t *const *proofs, size_t proof_len,
                                  size_t n_proofs, const uint8_t *const *commits32, size_t d,
                                  size_t prove_range, unsigned fp_bits, unsigned fp_frac,
@@ -197,43 +210,27 @@ int rofl_wire_decode(int kind, const uint8_t *data, size_t len, rofl_wire_msg_t 
  * already holds the update on the GPU passes device pointers and nothing crosses PCIe on the way in.  Outputs are written to
  * host memory. */
 
-/* ---- measurement hooks (bench.py) ---- */
-/* Time of the kernels of the last create / verify call, from HIP events on the library's stream. */
-typedef struct {
-    double total_ms;          /* first launch -> last completion, device clock */
-    double msm_accumulate_ms; /* sum over launches of k_msm_accumulate */
-    uint64_t msm_accumulate_launches;
-    uint64_t msm_terms;       /* non-trivial (scalar, point) terms fed to Pippenger */
-    double fold_ms;           /* sum over launches of k_fold_gens */
-    uint64_t fold_launches;
-    uint64_t fold_point_reads;   /* niels points read by k_fold_gens (96 B each) */
-    double host_ms;           /* host-side (transcript, Horner, fixed-base) time */
-    uint64_t msm_additions;   /* mixed point additions executed by k_msm_accumulate: terms x windows (7 field multiplications each) */
-} rofl_timing_t;
-int rofl_last_timing(rofl_timing_t *out);
-/* Per-kernel table of the last instrumented call of the calling thread: HIP-event time, launches and the ALGORITHMIC work of
- * those launches -- field multiplications (7 per mixed point addition, 8 per doubling, 9 per extended addition) and the bytes
- * a launch has to move at least once (32 B per scalar or point, 4 B per bucket-list entry). */
-enum { ROFL_TK_MSM_ACCUMULATE_FB = 0, ROFL_TK_MSM_ACCUMULATE_GEN = 1, ROFL_TK_MSM_SCATTER = 2, ROFL_TK_MSM_REDUCE = 3,
-       ROFL_TK_MSM_SMALL = 4, ROFL_TK_FOLD_TAB = 5, ROFL_TK_FOLD = 6, ROFL_TK_OTHER = 7, ROFL_TK_COUNT = 8 };
-typedef struct { double ms; uint64_t launches, fe_muls, bytes; } rofl_kernel_time_t;
-int rofl_last_kernel_times(rofl_kernel_time_t out[ROFL_TK_COUNT]);
-/* 0 = off; 1 = HIP events around every instrumented launch (~150 event records per proof: ~0.7 ms of a 25 ms proof); 2 = only around the
- * fixed-base accumulation, the kernel bench.py prices against the roofline (ten records per proof) */
-int rofl_set_timing(int enabled);
 /* ---- behaviour options ----
  * Switches that change WHAT a call returns or how it waits are part of the ABI, not of the process environment.  `key` is one of the
  * names below; the environment variable of the same name in upper case with the ROFL_ prefix (ROFL_VERIFY_ZIP_TRUNCATE, ...) only
- * provides the default that is read once, when the device context is created.  Options are per device context and may be changed
- * between calls (not while calls are in flight).  Returns 11 (bad parameter) for an unknown key or an out-of-range value.
+ * provides the default that is read once, when the first option is touched.  Options are process-wide (a server that drives several
+ * devices sets them once) and may be changed between calls (not while calls are in flight).  Returns 11 (bad parameter) for an unknown
+ * key or an out-of-range value.
  *   "verify_zip_truncate"  0 (default): a proof set that does not cover every chunk of the padded commitment vector does not verify
  *                          (ok = 0); 1: the reference's behaviour, zip-truncation (range_proof_vec/mod.rs:169-176), bit for bit
  *   "verify_batch"         1 (default): one random-weighted check per client (a client's chunks share one MSM); 0: one check per proof,
- *                          as upstream verify_multiple does
+ *                          as upstream verify_multiple does; 2: rofl_verify_rangeproof_batch checks all of its clients with one equation
+ *                          and, when that fails, groups of ~sqrt(n) clients and then the clients of the failing groups -- per-client
+ *                          verdicts as with 1 (the reference's server rejects the round on any failure, server.rs:474-484, so the common
+ *                          case is one generator MSM per batch)
+ *   "devices"              bit mask of logical devices (bit d = device d); 0 (default): batch calls run on the calling thread's device;
+ *                          otherwise rofl_create_rangeproof_batch / rofl_verify_rangeproof_batch deal their clients round-robin to the
+ *                          listed devices
  *   "sigma_batch"          1 (default): the per-element Sigma-proofs of a vector are verified as one random linear combination; 0: one
  *                          check per element (rand_proof_vec/mod.rs:93-118)
  *   "blocking_sync"        -1 (default): spin while at most three calls are in flight, sleep between polls beyond that; 0: always spin;
  *                          1: always sleep (one host core per waiting call is not burned; ~50 us more latency per wait)
+ * rofl_get_option also answers the read-only key "lanes": the calls that can be in flight on the calling thread's device (ROFL_LANES).
  * The remaining ROFL_* environment variables are tuning knobs that never change results ("Tuning knobs"). */
 int rofl_set_option(const char *key, long value);
 int rofl_get_option(const char *key, long *value_out);

@@ -9,6 +9,38 @@
 extern "C" {
 #endif
 
+/* ---- measurement hooks (bench.py) ---- */
+/* Time of the kernels of the last create / verify call, from HIP events on the library's stream. */
+typedef struct {
+    double total_ms;          /* first launch -> last completion, device clock */
+    double msm_accumulate_ms; /* sum over launches of k_msm_accumulate */
+    uint64_t msm_accumulate_launches;
+    uint64_t msm_terms;       /* non-trivial (scalar, point) terms fed to Pippenger */
+    double fold_ms;           /* sum over launches of k_fold_gens */
+    uint64_t fold_launches;
+    uint64_t fold_point_reads;   /* niels points read by k_fold_gens (96 B each) */
+    double host_ms;           /* host-side (transcript, Horner, fixed-base) time */
+    uint64_t msm_additions;   /* mixed point additions executed by k_msm_accumulate: terms x windows (7 field multiplications each) */
+} rofl_timing_t;
+int rofl_last_timing(rofl_timing_t *out);
+/* Per-kernel table of the last instrumented call of the calling thread: HIP-event time, launches and the ALGORITHMIC work of
+ * those launches -- field multiplications (7 per mixed point addition, 8 per doubling, 9 per extended addition) and the bytes
+ * a launch has to move at least once (32 B per scalar or point, 4 B per bucket-list entry). */
+enum { ROFL_TK_MSM_ACCUMULATE_FB = 0, ROFL_TK_MSM_ACCUMULATE_GEN = 1, ROFL_TK_MSM_SCATTER = 2, ROFL_TK_MSM_REDUCE = 3,
+       ROFL_TK_MSM_SMALL = 4, ROFL_TK_FOLD_TAB = 5, ROFL_TK_FOLD = 6, ROFL_TK_OTHER = 7, ROFL_TK_COUNT = 8 };
+typedef struct { double ms; uint64_t launches, fe_muls, bytes; } rofl_kernel_time_t;
+int rofl_last_kernel_times(rofl_kernel_time_t out[ROFL_TK_COUNT]);
+/* 0 = off; 1 = HIP events around every instrumented launch (~150 event records per proof: ~0.7 ms of a 25 ms proof); 2 = only around the
+ * fixed-base accumulation, the kernel bench.py prices against the roofline (ten records per proof) */
+int rofl_set_timing(int enabled);
+/* ---- devices on a one-GPU test box ----
+ * rofl_dbg_map_device: logical device `logical` (what rofl_set_device and the "devices" option name) is HIP device `physical`; allowed
+ * until the logical device is first used (ROFL_DEVICE_MAP="0,0,..." does the same from the environment).  Two logical devices on GPU 0
+ * are two full device contexts -- own streams, workspaces and generator tables -- which is how the multi-device paths are tested here.
+ * rofl_dbg_bind_device: the thread-binding half of rofl_set_device without touching HIP (-1 = unbind). */
+int rofl_dbg_map_device(int logical, int physical);
+int rofl_dbg_bind_device(int device);
+
 /* GPU multi-scalar multiplication sum_i k_i * P_i through the production Pippenger pipeline (dalek
  * vartime_multiscalar_mul as used by upstream verify_multiple); test hook for skewed / extreme scalars. */
 int rofl_dbg_msm(const uint8_t *scalars32, const uint8_t *points32, size_t n, uint8_t out32[32]);

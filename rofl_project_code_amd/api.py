@@ -129,7 +129,24 @@ def _dev_arg(x, elem_bytes, row=1):
 
 
 def set_device(dev):
+    """rofl_set_device: bind the CALLING THREAD to logical device `dev` (and make it the default of threads without a binding)."""
     _check(lib().rofl_set_device(int(dev)))
+
+
+def get_device():
+    out = ctypes.c_int()
+    _check(lib().rofl_get_device(ctypes.byref(out)))
+    return out.value
+
+
+def map_device(logical, physical):
+    """test hook (include/rofl_zk_debug.h): logical device -> HIP device, before the logical device is first used"""
+    _check(lib().rofl_dbg_map_device(int(logical), int(physical)))
+
+
+def bind_device(dev):
+    """test hook: the thread-binding half of set_device without touching HIP (-1 = unbind)"""
+    _check(lib().rofl_dbg_bind_device(int(dev)))
 
 
 def bp_gens_table_bytes(n_bits, m):
@@ -146,8 +163,10 @@ def bp_gens_prepare(n_bits, m):
 
 
 def set_option(key, value):
-    """rofl_set_option: behaviour switches of the library (include/rofl_zk.h): "verify_zip_truncate", "verify_batch", "sigma_batch",
-    "blocking_sync".  The ROFL_* environment variables of the same names only provide the defaults."""
+    """rofl_set_option: process-wide behaviour switches of the library (include/rofl_zk.h): "verify_zip_truncate", "verify_batch"
+    (0 per proof, 1 per client, 2 per batch with a closer look on failure), "sigma_batch", "blocking_sync", "devices" (bit mask of the
+    logical devices the batch entry points spread their clients over).  The ROFL_* environment variables of the same names only
+    provide the defaults."""
     _check(lib().rofl_set_option(str(key).encode(), ctypes.c_long(int(value))))
 
 

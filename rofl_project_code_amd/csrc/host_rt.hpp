@@ -9,12 +9,14 @@
 // variants, and most of them exist because an experiment in DESIGN.md needed them.  Read once per process (or per device context).
 struct Knob { const char *name, *dflt, *what; };
 static const Knob KNOBS[] = {
-    {"ROFL_LANES", "3", "calls that can be in flight on a device (HIP stream + workspace each); 1..8"},
+    {"ROFL_LANES", "3", "calls that can be in flight on a device (HIP stream + workspace each); 1..16, larger values are clamped (with a note on stderr)"},
+    {"ROFL_DEVICES", "0", "option devices: bit mask of the logical devices the batch entry points shard their clients over (0 = the calling thread's device only)"},
+    {"ROFL_DEVICE_MAP", "", "logical -> physical HIP device, comma separated (0,0 = two logical devices on GPU 0: how the multi-device paths are tested on a one-GPU box); default: identity"},
     {"ROFL_HOST_THREADS", "usable cores, in [2, 16]", "threads of the primary lane's host pool (window combination, encodings, transcripts of a round); other lanes: 6"},
     {"ROFL_POOL_SPIN_US", "400", "how long an idle pool worker polls for the next job before it sleeps (0 = sleep at once)"},
     {"ROFL_BLOCKING_SYNC", "-1", "option blocking_sync: -1 spin while <= 3 calls are in flight, 0 always spin, 1 sleep between polls"},
     {"ROFL_VERIFY_ZIP_TRUNCATE", "0", "option verify_zip_truncate: 1 = the reference's zip-truncating verify_rangeproof"},
-    {"ROFL_VERIFY_BATCH", "1", "option verify_batch: 0 = one check per proof instead of one per client"},
+    {"ROFL_VERIFY_BATCH", "1", "option verify_batch: 0 = one check per proof, 1 = one per client, 2 = one per batch of clients (bisecting down to per-client checks on failure)"},
     {"ROFL_SIGMA_BATCH", "1", "option sigma_batch: 0 = one check per element in the Sigma-proof verifiers"},
     {"ROFL_GENS_BUDGET_MB", "98304", "HBM budget of the generator-table cache (LRU eviction of unpinned entries beyond it)"},
     {"ROFL_FOLD_T1", "3", "IPP rounds before the first generator fold (1..6)"},
@@ -365,13 +367,32 @@ struct MsmWs {
 // One cached BulletproofGens::new(n, m): [G(N) | H(N)] + fold slices (tbl), the 16 window slices of the fixed-base MSM (wtab)
 struct GensEntry { niels *tbl = nullptr; ndm *wtab = nullptr, *wtab_many = nullptr; u32 wc = 16, wc_many = 0; FoldTabCfg fc{}; size_t bytes = 0, n = 0, m = 0; u64 tick = 0; int users = 0; };
 
+// Behaviour options (rofl_set_option): process-wide, so that a server that drives several devices sets them once.  The environment
+// only provides the defaults, read when the first option is touched.
+struct Options {
+    std::atomic<int> zip_truncate{0}, verify_batch{1}, sigma_batch{1}, blocking_sync{-1};
+    std::atomic<long> devices{0};      // bit d = logical device d takes a share of the batch entry points' clients
+};
+Options &opts() {
+    static Options o;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        if (const char *e = knob("ROFL_BLOCKING_SYNC")) o.blocking_sync = atoi(e) != 0;
+        if (const char *e = knob("ROFL_VERIFY_ZIP_TRUNCATE")) o.zip_truncate = atoi(e) != 0;
+        if (const char *e = knob("ROFL_VERIFY_BATCH")) { int v = atoi(e); o.verify_batch = v < 0 ? 0 : v > 2 ? 2 : v; }
+        if (const char *e = knob("ROFL_SIGMA_BATCH")) o.sigma_batch = atoi(e) != 0;
+        if (const char *e = knob("ROFL_DEVICES")) { long v = strtol(e, nullptr, 0); if (v >= 0) o.devices = v; }
+    });
+    return o;
+}
+
 // One Ctx = one "lane": a HIP stream with its own workspace, staging buffers, timing and host pool.  The primary
 // lane of a device owns the shared read-only state (fixed-base tables, generator cache).  An API call runs on one
 // lane; concurrent calls from different host threads (the reference's server verifies clients from a thread pool,
 // server.rs:656-687) take different lanes, so the latency-bound phases of one call (small rounds, host Horner,
 // transcripts) overlap the throughput-bound phases of another.  ROFL_LANES = size of the pool.
 struct Ctx {
-    int device = 0;
+    int device = 0, phys = 0;      // logical device (the key of the context table) and the HIP device behind it (ROFL_DEVICE_MAP / rofl_dbg_map_device)
     bool inited = false;
     Stage stg;      // staging of caller memory for this lane's current call (see Stage)
     // caller memory (host or device) -> device
@@ -391,7 +412,8 @@ struct Ctx {
     }
     Ctx *parent = nullptr;
     std::vector<Ctx *> sibs;      // additional lanes
-    int nlanes = 3;      // ROFL_LANES: number of calls that can be in flight on this device
+    static constexpr int kMaxLanes = 16;
+    int nlanes = 3;      // ROFL_LANES: number of calls that can be in flight on this device (1..kMaxLanes)
     std::mutex init_mu, gens_mu;      // primary lane only: one-time initialisation; generator-table cache
     std::atomic<int> active_calls{0};  // primary lane only: calls currently holding a lane
     std::atomic<unsigned> rr{0};
@@ -410,14 +432,13 @@ struct Ctx {
     // Waiting for the lane's stream.  hipStreamSynchronize spins (lowest latency: right for a call that is alone on the device); with
     // more than three calls in flight -- or when the host asked for it (ROFL_BLOCKING_SYNC=1) -- the thread sleeps between queries instead, so
     // a server that keeps several clients in flight does not burn one host core per client on busy-waiting (ROFL_BLOCKING_SYNC=0: always spin).
-    // behaviour options (rofl_set_option; primary lane only -- the lanes read their parent's): the environment only provides defaults
-    int opt_zip_truncate = 0, opt_verify_batch = 1, opt_sigma_batch = 1;
-    int blocking_sync = -1; hipEvent_t ev_block = nullptr, ev_v = nullptr, ev_fork = nullptr, ev_a = nullptr, ev_a0 = nullptr, ev_m2 = nullptr, ev_m2j = nullptr; bool batch_mode = false;
+    hipEvent_t ev_block = nullptr, ev_v = nullptr, ev_fork = nullptr, ev_a = nullptr, ev_a0 = nullptr, ev_m2 = nullptr, ev_m2j = nullptr; bool batch_mode = false;
     void sync() {
         const Ctx *P = parent ? parent : this;
         // (up to three calls in flight still spin: the three proofs of ONE client's L2 update run side by side -- EncParamsL2::encrypt --
         //  and that is a latency case; a server with more clients in flight is a throughput case)
-        bool block = P->blocking_sync == 1 || (P->blocking_sync < 0 && (P->active_calls.load() > 3 || batch_mode));
+        const int bs = opts().blocking_sync.load(std::memory_order_relaxed);
+        bool block = bs == 1 || (bs < 0 && (P->active_calls.load() > 3 || batch_mode));
         if (!block) {
             static const bool poll = knob("ROFL_SYNC_POLL") && atoi(knob("ROFL_SYNC_POLL")) != 0;
             if (!poll) { HIPCHK(hipStreamSynchronize(stream)); return; }
@@ -452,14 +473,14 @@ struct Ctx {
     // workspace
     DevBuf cp, sL, sR, party, Scanon, vshift, blind, Vbytes, Cbytes, status, partial, partial2, scpart, a, b, a2, b2, ptab[2], yinv,
         SL, SR, powtabs, foldprobs, naf,
-        gbuf[2], aux_pts, aux_scal, vscal, tmp_in, tmp_in2, tmp_out, vals, uni, stream_buf;
-    PinBuf h_cp, h_part, h_misc, h_misc2, h_auxc, h_auxs, h_V, h_ip, h_round, h_fdig, h_fprob, h_abfin;
+        gbuf[2], aux_pts, aux_scal, vscal, tmp_in, tmp_in2, tmp_out, vals, uni, stream_buf, vgroups;
+    PinBuf h_cp, h_part, h_misc, h_misc2, h_auxc, h_auxs, h_V, h_ip, h_round, h_fdig, h_fprob, h_abfin, h_vgrp;
     MsmWs mws[2];
     std::map<uint64_t, double> wait_ms;      // how long the wait of a tagged hop took the last times (hint for the pool workers' naps)
 
     void init() {
         if (inited) return;
-        HIPCHK(hipSetDevice(device));
+        HIPCHK(hipSetDevice(phys));
         HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         // PedersenGens::default(): B = Ristretto basepoint, B_blinding = hash_from_bytes::<Sha3_512>(B)
         static const uint8_t Bc[32] = {0xe2, 0xf2, 0xae, 0x0a, 0x6a, 0xbc, 0x4e, 0x71, 0xa8, 0x84, 0xa9, 0x61, 0xc5, 0x00, 0x51, 0x5f,
@@ -514,16 +535,16 @@ struct Ctx {
         if (const char *e = knob("ROFL_FOLD_UNIT")) fold_unit = atoi(e) != 0;
         if (const char *e = knob("ROFL_FOLD_K")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) fold_k = v; }
         if (const char *e = knob("ROFL_FOLD_THREADS")) { long v = atol(e); if (v > 0) fold_threads = v; }
-        if (const char *e = knob("ROFL_LANES")) { int v = atoi(e); if (v >= 1 && v <= 8) nlanes = v; }
-        if (const char *e = knob("ROFL_BLOCKING_SYNC")) blocking_sync = atoi(e) != 0;
-        if (const char *e = knob("ROFL_VERIFY_ZIP_TRUNCATE")) opt_zip_truncate = atoi(e) != 0;
-        if (const char *e = knob("ROFL_VERIFY_BATCH")) opt_verify_batch = atoi(e) != 0;
-        if (const char *e = knob("ROFL_SIGMA_BATCH")) opt_sigma_batch = atoi(e) != 0;
+        if (const char *e = knob("ROFL_LANES")) {      // out-of-range values are clamped, not ignored: the caller sized its thread pool by them
+            int v = atoi(e), w = v < 1 ? 1 : v > kMaxLanes ? kMaxLanes : v;
+            if (w != v) fprintf(stderr, "librofl_zk: ROFL_LANES=%d is outside 1..%d, using %d\n", v, kMaxLanes, w);
+            nlanes = w;
+        }
         inited = true;
         for (int i = 1; i < nlanes; i++) { Ctx *s = new Ctx(); s->init_lane(*this); sibs.push_back(s); }
     }
     void init_lane(Ctx &p) {
-        parent = &p; device = p.device;
+        parent = &p; device = p.device; phys = p.phys;
         HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         ht = p.ht; d_tabB = p.d_tabB; d_tabBb = p.d_tabBb; d_two_pow = p.d_two_pow;
         msm_lds = p.msm_lds; msm_two_level = p.msm_two_level; msm_group_reduce = p.msm_group_reduce; msm_lds_min = p.msm_lds_min; msm_lds_tile = p.msm_lds_tile;
@@ -540,15 +561,36 @@ struct Ctx {
 // it initialises; lanes that share a queue serialise each other's kernels.  The library does not touch the process environment:
 // a host that wants more than four calls in flight exports GPU_MAX_HW_QUEUES itself before the first HIP call.
 
+// Devices.  One context (primary lane + siblings, generator cache) per LOGICAL device, created on first use.  Which device a call runs on
+// is a property of the calling thread: rofl_set_device binds the thread (as hipSetDevice does) and also becomes the process default that
+// threads without a binding of their own follow -- so a one-device host keeps its "set once, call from any thread" behaviour, and a
+// server process that drives N GPUs (the reference's server is ONE process with a verification pool, server.rs:379-384, 656-687) binds
+// each pool thread to its device, or lists the devices in rofl_set_option("devices", mask) and lets the batch entry points shard.
+// Logical device i is HIP device g_devmap[i] (identity unless ROFL_DEVICE_MAP / rofl_dbg_map_device say otherwise).
+constexpr int kMaxDevices = 64;
 std::mutex g_ctx_mu;
 std::map<int, Ctx *> g_ctxs;
-int g_device = 0;
-Ctx &ctx() {
+std::atomic<int> g_default_device{0};
+thread_local int t_device = -1;
+int g_devmap[kMaxDevices];
+std::once_flag g_devmap_once;
+void devmap_init() {
+    std::call_once(g_devmap_once, [] {
+        for (int i = 0; i < kMaxDevices; i++) g_devmap[i] = i;
+        if (const char *e = knob("ROFL_DEVICE_MAP")) { int i = 0; for (const char *p = e; *p && i < kMaxDevices; i++) { g_devmap[i] = atoi(p); while (*p && *p != ',') p++; if (*p == ',') p++; } }
+    });
+}
+int current_device() { return t_device >= 0 ? t_device : g_default_device.load(std::memory_order_relaxed); }
+Ctx &ctx_of(int dev) {
+    devmap_init();
     std::lock_guard<std::mutex> lk(g_ctx_mu);
-    auto it = g_ctxs.find(g_device);
-    if (it == g_ctxs.end()) { Ctx *c = new Ctx(); c->device = g_device; it = g_ctxs.emplace(g_device, c).first; }
+    auto it = g_ctxs.find(dev);
+    if (it == g_ctxs.end()) { Ctx *c = new Ctx(); c->device = dev; c->phys = g_devmap[dev]; it = g_ctxs.emplace(dev, c).first; }
     return *it->second;
 }
+Ctx &ctx() { return ctx_of(current_device()); }
+// binds the calling thread for the lifetime of the object (the worker threads of a sharded batch call)
+struct DeviceBinding { int saved; explicit DeviceBinding(int dev) : saved(t_device) { t_device = dev; } ~DeviceBinding() { t_device = saved; } };
 
 // A lane held for the duration of one API call.
 struct LaneLock {
@@ -574,7 +616,7 @@ struct LaneLock {
 LaneLock acquire_lane(bool primary_only = false, bool side = false) {
     Ctx &P = ctx();
     { std::lock_guard<std::mutex> g(P.init_mu); P.init(); }
-    HIPCHK(hipSetDevice(P.device));                    // the calling thread may be new to HIP
+    HIPCHK(hipSetDevice(P.phys));                      // the calling thread may be new to HIP, or last used another device
     LaneLock ll; ll.primary = &P; P.active_calls.fetch_add(1);
     size_t L = primary_only ? 1 : 1 + P.sibs.size();
     for (size_t k = 0; k < L; k++) {

@@ -16,17 +16,26 @@ sc verifier_c(const uint8_t seed[32], u64 idx) {
 
 // d_Vniels holds the UNSHIFTED commitments C_j (k_decode); h_V the encodings of V_j = C_j + v_shift * B for the first v_real[c] values of
 // chunk c (identity padding after them): the check needs sum_j s_j V_j, which is the MSM over the C_j plus (sum_{j < v_real} s_j) * v_shift on B.
+//
+// `group` consecutive proofs form a UNIT (a client's chunks: the reference returns one bool per client) that is checked as one batch:
+// sum_c rho_c * (check_c) == 0 with random weights rho_c, so the generator terms of its proofs share one MSM.  Every proof of a unit gets
+// the unit's verdict.  `hier` (rofl_set_option("verify_batch", 2), the server role: server.rs:474-484 fails the whole round on one bad
+// client, so the common case is "everything verifies") first checks ALL units as one batch -- one generator MSM for the whole call instead
+// of one per client -- and only when that fails looks closer: groups of ~sqrt(units) units, then the units of the groups that failed, so
+// that every unit still gets its own verdict, identical to the per-unit check's.  rho_index[c] (default c_index[c]) keys proof c's weight:
+// proofs that share a check need distinct ones.  skip[c] != 0 takes proof c out of every check (weight 0) and fails its unit -- a batch
+// member the caller already knows to be malformed must not make its neighbours pay for the closer look.
 int verify_chunks(Ctx &C, const char *label, size_t gens_capacity, size_t P, size_t n, size_t m, const uint8_t *proofs, size_t plen,
                   const uint8_t *h_V, const niels *d_Vniels, const uint8_t seed[32], const u64 *c_index, int *ok, size_t group = 1,
-                  const sc *v_shift = nullptr, const u64 *v_real = nullptr) {
-    // `group` consecutive proofs are checked as one batch: sum_c rho_c * (check_c) == 0 with random weights rho_c, so their
-    // generator terms share one MSM.  Every proof of a batch gets the batch's verdict (callers AND them per client anyway).
+                  const sc *v_shift = nullptr, const u64 *v_real = nullptr, const u64 *rho_index = nullptr, bool hier = false,
+                  const char *skip = nullptr) {
     for (size_t c = 0; c < P; c++) ok[c] = 0;
     static const bool vtrace = knob("ROFL_TRACE") && atoi(knob("ROFL_TRACE")) >= 2;
     double vt0 = now_ms(), vtl = vt0;
     auto vmark = [&](const char *what) { if (!vtrace) return; double t = now_ms(); fprintf(stderr, "[rofl-trace verify] %-14s +%.3f ms  (t=%.3f)\n", what, t - vtl, t - vt0); vtl = t; };
     if (group == 0 || P % group) group = 1;
-    size_t ngroups = P / group;
+    const size_t units = P / group;
+    if (units < 2) hier = false;
     // RangeProof::from_bytes / InnerProductProof::from_bytes
     if (plen % 32 != 0 || plen < 7 * 32) return ROFL_FORMAT_ERROR;
     size_t ne = (plen - 7 * 32) / 32;
@@ -79,7 +88,7 @@ int verify_chunks(Ctx &C, const char *label, size_t gens_capacity, size_t P, siz
         bool bad = false;
         for (int i = 0; i < 4; i++) if (!memcmp(p + 32 * i, zero32, 32)) bad = true;
         for (size_t k = 0; k < 2 * lg; k++) if (!memcmp(ipp + 32 * k, zero32, 32)) bad = true;
-        if (bad) { dead[c] = 1; }
+        if (bad || (skip && skip[c])) { dead[c] = 1; }
         t.append("A", p, 32); t.append("S", p + 32, 32);
         sc y = t.challenge_scalar("y"), z = t.challenge_scalar("z");
         t.append("T_1", p + 64, 32); t.append("T_2", p + 96, 32);
@@ -88,7 +97,8 @@ int verify_chunks(Ctx &C, const char *label, size_t gens_capacity, size_t P, siz
         t.append("t_x", p + 128, 32); t.append("t_x_blinding", p + 160, 32); t.append("e_blinding", p + 192, 32);
         sc w = t.challenge_scalar("w");
         sc cc = verifier_c(seed, c_index[c]);
-        sc rho = group > 1 ? verifier_c(seed, c_index[c] | (1ULL << 62)) : sc_one_plain();
+        sc rho = (group > 1 || hier) ? verifier_c(seed, (rho_index ? rho_index[c] : c_index[c]) | (1ULL << 62)) : sc_one_plain();
+        if (dead[c]) rho = sc_zero();      // out of every shared check (all of its scalars below become zero); its unit fails through dead[]
         t.append("dom-sep", (const uint8_t *)"ipp v1", 6);
         t.append_u64("n", N);
         ChunkParams &cp = h_cp[c];
@@ -144,15 +154,17 @@ int verify_chunks(Ctx &C, const char *label, size_t gens_capacity, size_t P, siz
     C.tm.t.host_ms += now_ms() - th;
     vmark("transcripts");
     HIPCHK(hipMemcpyAsync(d_cp, h_cp, sizeof(ChunkParams) * P, hipMemcpyHostToDevice, C.stream));
-    sc *gh = C.SL.as<sc>(ngroups * 2 * N);
     PowTabs *d_pt = C.powtabs.as<PowTabs>(P);
     hipLaunchKernelGGL(k_pow_tables, dim3((4 * PT_L * PT_E + TPB - 1) / TPB, (u32)P), dim3(TPB), 0, C.stream, d_cp, d_pt, (u32)lg, 1);
-    hipLaunchKernelGGL(k_verify_scalars, grid1(N, (u32)ngroups), dim3(TPB), 0, C.stream, (u32)n, (u32)m, (u32)lg, (u32)group, d_cp, (const PowTabs *)d_pt, C.d_two_pow, gh);
-    // aux arrays
-    niels *aux_pts = C.aux_pts.as<niels>(P * naux);
-    sc *aux_scal = C.aux_scal.as<sc>(P * naux);
+    // aux arrays: per proof [m commitments | 4 + 2 lg proof points] and their scalars.  The closer look of `hier` checks runs of units whose
+    // last one may be shorter: the arrays end in one group's worth of zero scalars, so every MSM problem of a launch can take the same length.
+    const size_t gB = hier ? (size_t)std::ceil(std::sqrt((double)units)) : 1;      // units per group of the middle level
+    const size_t pad = hier ? gB * group : 0;
+    niels *aux_pts = C.aux_pts.as<niels>((P + pad) * naux);
+    sc *aux_scal = C.aux_scal.as<sc>((P + pad) * naux);
+    if (pad) HIPCHK(hipMemsetAsync(aux_scal + P * naux, 0, sizeof(sc) * pad * naux, C.stream));
     hipLaunchKernelGGL(k_vscalars, grid1(m, (u32)P), dim3(TPB), 0, C.stream, (u32)m, d_cp, (const PowTabs *)d_pt, aux_scal, naux);
-    {   // per chunk: [m commitments | 4 + 2 lg proof points] and the scalars of the latter -- three strided copies for all chunks
+    {   // three strided copies for all proofs
         const size_t na2 = 4 + 2 * lg;
         HIPCHK(hipMemcpy2DAsync(aux_pts, naux * sizeof(niels), d_Vniels, m * sizeof(niels), m * sizeof(niels), P, hipMemcpyDeviceToDevice, C.stream));
         HIPCHK(hipMemcpy2DAsync(aux_pts + m, naux * sizeof(niels), d_auxn, na2 * sizeof(niels), na2 * sizeof(niels), P, hipMemcpyDeviceToDevice, C.stream));
@@ -160,26 +172,70 @@ int verify_chunks(Ctx &C, const char *label, size_t gens_capacity, size_t P, siz
     }
     u32 *h_stat = C.h_misc2.as<u32>(4);
     HIPCHK(hipMemcpyAsync(h_stat, status, 4, hipMemcpyDeviceToHost, C.stream));      // k_decode's verdict on the proof points
-    std::vector<MsmProb> pr(ngroups), prB(ngroups); std::vector<ge5> resA, resB;
-    for (size_t g = 0; g < ngroups; g++) pr[g] = MsmProb{tbl, gh + g * 2 * N};
-    for (size_t g = 0; g < ngroups; g++) prB[g] = MsmProb{aux_pts + g * group * naux, aux_scal + g * group * naux};
-    C.tm.t.msm_terms += ngroups * 2 * N + P * naux;
-    // the generator MSM (2N terms per group, fixed-base) and the proof-point MSM (commitments, A, S, T, L, R) queue back to back: one wait
-    // (one problem per client with every window in its own bucket set: the 15-bit layout's smaller arrays win here whenever it exists)
-    { MsmOpt mo; if (wtab) { gens.fb_for(1000, &mo.fb_wtab, &mo.fb_c); mo.fb_stride = 2 * N; } msm_run2(C, pr, 2 * N, mo, resA, prB, group * naux, MsmOpt(), resB); }
+    // One pass over a list of groups (start proof, proof count; equal counts, except that a group ending at P may be shorter): the generator
+    // MSM (2N terms per group, fixed-base) and the proof-point MSM (commitments, A, S, T, L, R) of every group queue back to back behind one wait.
+    struct Grp { u32 start, count; };
+    auto check = [&](const std::vector<Grp> &groups, std::vector<int> &verdict) {
+        const size_t ng = groups.size();
+        size_t maxc = 0; for (auto &g : groups) maxc = std::max<size_t>(maxc, g.count);
+        sc *gh = C.SL.as<sc>(ng * 2 * N);
+        Grp *d_grp = C.vgroups.as<Grp>(ng);
+        Grp *h_grp = C.h_vgrp.as<Grp>(ng);
+        memcpy(h_grp, groups.data(), sizeof(Grp) * ng);
+        HIPCHK(hipMemcpyAsync(d_grp, h_grp, sizeof(Grp) * ng, hipMemcpyHostToDevice, C.stream));
+        hipLaunchKernelGGL(k_verify_scalars, grid1(N, (u32)ng), dim3(TPB), 0, C.stream, (u32)n, (u32)m, (u32)lg, reinterpret_cast<const uint2 *>(d_grp), d_cp, (const PowTabs *)d_pt, C.d_two_pow, gh);
+        std::vector<MsmProb> pr(ng), prB(ng); std::vector<ge5> resA, resB;
+        for (size_t g = 0; g < ng; g++) pr[g] = MsmProb{tbl, gh + g * 2 * N};
+        for (size_t g = 0; g < ng; g++) prB[g] = MsmProb{aux_pts + (size_t)groups[g].start * naux, aux_scal + (size_t)groups[g].start * naux};
+        C.tm.t.msm_terms += ng * 2 * N + ng * maxc * naux;
+        // (one problem per group with every window in its own bucket set: the 15-bit layout's smaller arrays win here whenever it exists)
+        { MsmOpt mo; if (wtab) { gens.fb_for(1000, &mo.fb_wtab, &mo.fb_c); mo.fb_stride = 2 * N; } msm_run2(C, pr, 2 * N, mo, resA, prB, maxc * naux, MsmOpt(), resB); }
+        double th2 = now_ms();
+        verdict.assign(ng, 0);
+        for (size_t g = 0; g < ng; g++) {
+            ge5 tot = h51::gadd(resA[g], resB[g]);
+            sc b1 = sc_zero(), b2 = sc_zero();
+            for (size_t c = groups[g].start; c < (size_t)groups[g].start + groups[g].count; c++) { b1 = sc_add(b1, sB[c]); b2 = sc_add(b2, sBb[c]); }
+            tot = h51::gadd(tot, h_fixed_mul(C.ht.B5, b1));
+            tot = h51::gadd(tot, h_fixed_mul(C.ht.Bb5, b2));
+            verdict[g] = h51::is_identity_ristretto(tot) ? 1 : 0;
+        }
+        C.tm.t.host_ms += now_ms() - th2;
+    };
+    std::vector<int> unit_ok(units, 0), verdict;
+    if (!hier) {
+        std::vector<Grp> all(units);
+        for (size_t u = 0; u < units; u++) all[u] = Grp{(u32)(u * group), (u32)group};
+        check(all, verdict);
+        unit_ok = verdict;
+    } else {
+        check({Grp{0u, (u32)P}}, verdict);
+        vmark("batch check");
+        if (verdict[0]) unit_ok.assign(units, 1);
+        else {
+            std::vector<size_t> suspects;
+            if (units > 3) {
+                std::vector<Grp> mid;
+                for (size_t u0 = 0; u0 < units; u0 += gB) mid.push_back(Grp{(u32)(u0 * group), (u32)(std::min(gB, units - u0) * group)});
+                check(mid, verdict);
+                for (size_t g = 0; g < mid.size(); g++)
+                    for (size_t u = g * gB; u < std::min(units, (g + 1) * gB); u++) { if (verdict[g]) unit_ok[u] = 1; else suspects.push_back(u); }
+            } else for (size_t u = 0; u < units; u++) suspects.push_back(u);
+            if (!suspects.empty()) {
+                std::vector<Grp> one(suspects.size());
+                for (size_t k = 0; k < suspects.size(); k++) one[k] = Grp{(u32)(suspects[k] * group), (u32)group};
+                check(one, verdict);
+                for (size_t k = 0; k < suspects.size(); k++) unit_ok[suspects[k]] = verdict[k];
+            }
+        }
+    }
     vmark("msm");
     const u32 h_status = *h_stat;
-    th = now_ms();
-    for (size_t g = 0; g < ngroups; g++) {
-        ge5 tot = h51::gadd(resA[g], resB[g]);
-        sc b1 = sc_zero(), b2 = sc_zero(); bool any_dead = false;
-        for (size_t c = g * group; c < (g + 1) * group; c++) { b1 = sc_add(b1, sB[c]); b2 = sc_add(b2, sBb[c]); any_dead |= dead[c] != 0; }
-        tot = h51::gadd(tot, h_fixed_mul(C.ht.B5, b1));
-        tot = h51::gadd(tot, h_fixed_mul(C.ht.Bb5, b2));
-        int okg = (!any_dead && h51::is_identity_ristretto(tot)) ? 1 : 0;
-        for (size_t c = g * group; c < (g + 1) * group; c++) ok[c] = okg;
+    for (size_t u = 0; u < units; u++) {
+        bool any_dead = false;
+        for (size_t c = u * group; c < (u + 1) * group; c++) any_dead |= dead[c] != 0;
+        for (size_t c = u * group; c < (u + 1) * group; c++) ok[c] = (unit_ok[u] && !any_dead) ? 1 : 0;
     }
-    C.tm.t.host_ms += now_ms() - th;
     if (h_status & 4u) {
         // some proof point failed to decompress: upstream returns VerificationError for that proof.
         // Re-check per chunk on the host to attribute the failure.

@@ -1693,19 +1693,20 @@ __global__ void __launch_bounds__(TPB) k_add_points(u32 count, const uint8_t *a,
 }
 #endif
 // bulletproofs verify_multiple: g_k = -z - a s_k ; h_k = z + y^-k (zz z^j 2^i - b s_k^-1)  -> canonical [g | h]
-// One array of 2N scalars per batch of `group` consecutive proofs: sum_c rho_c * (g_c | h_c) -- the proofs of a batch
-// share the generators, so their G/H terms collapse into one MSM (rho_c is folded into rz, ra, rb, rzz by the host).
+// One array of 2N scalars per group of consecutive proofs (grp[g] = first proof, proof count): sum_c rho_c * (g_c | h_c) -- the proofs of
+// a group share the generators, so their G/H terms collapse into one MSM (rho_c is folded into rz, ra, rb, rzz by the host).
 #if ROFL_KG(4)
-__global__ void __launch_bounds__(TPB) k_verify_scalars(u32 n, u32 m, u32 lgN, u32 group, const ChunkParams *cp, const PowTabs *pt, const sc *two_pow, sc *out) {
+__global__ void __launch_bounds__(TPB) k_verify_scalars(u32 n, u32 m, u32 lgN, const uint2 *grp, const ChunkParams *cp, const PowTabs *pt, const sc *two_pow, sc *out) {
     u32 gidx = blockIdx.y;
+    const u32 first = grp[gidx].x, group = grp[gidx].y;
     size_t N = (size_t)n * m;
     u32 k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= N) return;
     u32 j = k / n, i = k % n;
     sc gacc = sc_zero(), hacc = sc_zero();
     for (u32 cc = 0; cc < group; cc++) {
-        const ChunkParams &P = cp[gidx * group + cc];
-        const PowTabs &T = pt[gidx * group + cc];
+        const ChunkParams &P = cp[first + cc];
+        const PowTabs &T = pt[first + cc];
         // s = prod_q (bit_{lgN-1-q}(k) ? u_q : u_q^-1) (challenge q in creation order), 1/s = the same product at ~k
         u32 kc = ~k;
         sc s = sc_montmul(sc_montmul(load_sc(&T.s[0][k & (PT_E - 1)]), load_sc(&T.s[1][(k >> PT_W) & (PT_E - 1)])), load_sc(&T.s[2][(k >> (2 * PT_W)) & (PT_E - 1)]));

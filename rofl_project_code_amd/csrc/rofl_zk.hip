@@ -124,7 +124,9 @@ template <class F> int guarded(F f) {
 // the others are proved.  Returns non-zero only for errors that concern the whole call.
 int create_impl(Ctx &C, size_t nc, const float *const *values, size_t d, const uint8_t *const *blind, size_t prove_range, size_t n_partition,
                 unsigned fp_bits, unsigned fp_frac, const rofl_nonce_t *nonces, uint8_t *const *proofs_out, size_t *plen_out, size_t *np_out,
-                uint8_t *const *commits_out, int *rcs) {
+                uint8_t *const *commits_out, int *rcs, bool single) {
+    // `single`: the call is rofl_create_rangeproof (one client: its errors are the call's errors); batch calls -- also their one-client
+    // shards when a batch is spread over several devices -- report per client in rcs
     for (size_t i = 0; i < nc; i++) rcs[i] = ROFL_OK;
     if (!valid_fp(fp_bits, fp_frac) || d == 0 || n_partition == 0 || prove_range == 0 || prove_range > fp_bits || !nonces || nc == 0)
         return fail(ROFL_BAD_PARAM, "bad parameter (the reference panics here)");
@@ -156,14 +158,14 @@ int create_impl(Ctx &C, size_t nc, const float *const *values, size_t d, const u
         else if (h_status[i] & 2) rcs[i] = ROFL_NON_FINITE;
         any |= rcs[i] == ROFL_OK;
     }
-    if (nc == 1 && rcs[0] == ROFL_VALUE_OUT_OF_RANGE) return fail(ROFL_VALUE_OUT_OF_RANGE, "ValueOutOfRangeError");
-    if (nc == 1 && rcs[0] == ROFL_NON_FINITE) return fail(ROFL_NON_FINITE, "non-finite value (the reference panics in fixed::saturating_from_float)");
+    if (single && rcs[0] == ROFL_VALUE_OUT_OF_RANGE) return fail(ROFL_VALUE_OUT_OF_RANGE, "ValueOutOfRangeError");
+    if (single && rcs[0] == ROFL_NON_FINITE) return fail(ROFL_NON_FINITE, "non-finite value (the reference panics in fixed::saturating_from_float)");
     if (!is_pow2(chunk) || dp % chunk) return fail(ROFL_INVALID_AGGREGATION, "InvalidAggregation (the reference panics)");
     if (!(prove_range == 8 || prove_range == 16 || prove_range == 32 || prove_range == 64)) return fail(ROFL_INVALID_BITSIZE, "InvalidBitsize");
     for (size_t i = 0; i < nc; i++)
         if (rcs[i] == ROFL_OK && nonces[i].mode == 0 && nonces[i].stream_scalars < P * chunk * (2 * prove_range + 4)) {
             rcs[i] = ROFL_NONCE_SHORT;
-            if (nc == 1) return fail(ROFL_NONCE_SHORT, "nonce stream too short");
+            if (single) return fail(ROFL_NONCE_SHORT, "nonce stream too short");
         }
     size_t plen = 32 * (9 + 2 * (size_t)lg2u(prove_range * chunk));
     *plen_out = plen; *np_out = P;
@@ -185,7 +187,7 @@ int create_impl(Ctx &C, size_t nc, const float *const *values, size_t d, const u
           const rofl_nonce_t &nn = nonces[act[k]];
           ChunkNonce base{}; base.mode = nn.mode;
           if (nn.mode == 1) memcpy(base.seed.w, nn.seed, 32);
-          else { HIPCHK(hipMemcpyAsync(sb + off, nn.stream, nn.stream_scalars * 64, hipMemcpyHostToDevice, C.stream)); base.d_stream = sb + off; base.stream_scalars = nn.stream_scalars; off += nn.stream_scalars * 64; }
+          else { C.up(sb + off, nn.stream, nn.stream_scalars * 64, C.stream); base.d_stream = sb + off; base.stream_scalars = nn.stream_scalars; off += nn.stream_scalars * 64; }
           for (size_t c = 0; c < P; c++) { cn[k * P + c] = base; cn[k * P + c].base = c * per; }
       } }
     // V_j and un-shifted commitments C_j = V_j - 2^(range-1) B   (range_proof_vec/mod.rs:96-99)
@@ -222,8 +224,12 @@ int create_impl(Ctx &C, size_t nc, const float *const *values, size_t d, const u
 // 8 commitments check 6 of them; dp/2 + 1 proofs check half).  The proof count comes off the wire, so that is a soundness hole, not
 // a format quirk: here a set whose proofs do not cover every chunk exactly is reported as "does not verify" (ok = 0, return code 0).
 // rofl_set_option("verify_zip_truncate", 1) restores the reference's behaviour bit for bit (byte-level comparisons).
+// `single`: the call is rofl_verify_rangeproof (a malformed set is the call's FormatError); batch calls -- also their one-client shards
+// when a batch is spread over several devices -- give every client its own verdict.  gid[i] (nullptr: i) = client i's index in the
+// caller's batch: it keys the client's random weights, so that a shard draws what the whole batch would have drawn for it.
 int verify_impl(Ctx &C, size_t n_clients, const uint8_t *const *proofs, size_t proof_len, size_t n_proofs, const uint8_t *const *commits,
-                size_t d, size_t prove_range, unsigned fp_bits, unsigned fp_frac, const uint8_t seed[32], int *ok_out) {
+                size_t d, size_t prove_range, unsigned fp_bits, unsigned fp_frac, const uint8_t seed[32], int *ok_out, bool single,
+                const size_t *gid = nullptr) {
     for (size_t i = 0; i < n_clients; i++) ok_out[i] = 0;
     if (!valid_fp(fp_bits, fp_frac) || d == 0 || n_proofs == 0 || prove_range == 0 || prove_range > fp_bits || n_clients == 0)
         return fail(ROFL_BAD_PARAM, "bad parameter (the reference panics here)");
@@ -232,8 +238,7 @@ int verify_impl(Ctx &C, size_t n_clients, const uint8_t *const *proofs, size_t p
     if (chunk == 0) return fail(ROFL_BAD_PARAM, "more proofs than padded commitments (the reference panics in chunks(0))");
     size_t n_chunks = (dp + chunk - 1) / chunk;
     size_t nv = std::min(n_proofs, n_chunks);            // zip truncates (range_proof_vec/mod.rs:173-176)
-    const Ctx &P0 = C.parent ? *C.parent : C;
-    const bool zip_truncate = P0.opt_zip_truncate != 0;      // rofl_set_option("verify_zip_truncate")
+    const bool zip_truncate = opts().zip_truncate.load() != 0;      // rofl_set_option("verify_zip_truncate")
     if (n_proofs * chunk != dp) {
         if (!zip_truncate) { g_err = "proof count does not cover the padded commitment vector: not verified"; return ROFL_OK; }
         if (dp % chunk) return fail(ROFL_BAD_PARAM, "ragged chunks are not supported");
@@ -246,8 +251,10 @@ int verify_impl(Ctx &C, size_t n_clients, const uint8_t *const *proofs, size_t p
     size_t lg = (ne - 2) / 2;
     size_t P = n_clients * nv;
     std::vector<uint8_t> pf(P * proof_len);
-    for (size_t i = 0; i < n_clients; i++)
-        HIPCHK(hipMemcpy(&pf[i * nv * proof_len], proofs[i], nv * proof_len, hipMemcpyDefault));   // host or device memory
+    for (size_t i = 0; i < n_clients; i++) {      // host or device memory; caller memory is not handed to the HIP runtime
+        if (is_device_ptr(proofs[i])) HIPCHK(hipMemcpy(&pf[i * nv * proof_len], proofs[i], nv * proof_len, hipMemcpyDeviceToHost));
+        else memcpy(&pf[i * nv * proof_len], proofs[i], nv * proof_len);
+    }
     // RangeProof::from_bytes rejects non-canonical scalars.  A single set: FormatError, as the reference (the caller cannot even build
     // its Vec<RangeProof>).  In a batch every client has its own verdict (server.rs:656-687 verifies each client on its own): the
     // offender gets ok = 0 and the others are still verified -- its scalars are zeroed in the local copy so that the shared launch
@@ -258,7 +265,7 @@ int verify_impl(Ctx &C, size_t n_clients, const uint8_t *const *proofs, size_t p
         const size_t offs[5] = {128, 160, 192, 7 * 32 + 64 * lg, 7 * 32 + 64 * lg + 32};
         for (size_t o : offs)
             if (!sc_is_canonical_bytes(pb + o)) {
-                if (n_clients == 1) return fail(ROFL_FORMAT_ERROR, "proof rejected before verification (format / bitsize)");
+                if (single) return fail(ROFL_FORMAT_ERROR, "proof rejected before verification (format / bitsize)");
                 bad_format[q / nv] = 1; memset(pb + o, 0, 32);
             }
     }
@@ -290,7 +297,7 @@ int verify_impl(Ctx &C, size_t n_clients, const uint8_t *const *proofs, size_t p
     for (size_t i = 0; i < n_clients; i++) bad_commit[i] = (h_st[i] & 4u) != 0;
     // a single set with an invalid encoding: the reference cannot even build its Vec<RistrettoPoint> (decompress fails) -> FormatError;
     // in a batch the other clients are still verified and the offender gets ok = 0
-    if (n_clients == 1 && bad_commit[0]) return fail(ROFL_FORMAT_ERROR, "commitment is not a valid Ristretto encoding");
+    if (single && bad_commit[0]) return fail(ROFL_FORMAT_ERROR, "commitment is not a valid Ristretto encoding");
     // flatten (client, chunk) -> problem list
     std::vector<uint8_t> Vh(P * chunk * 32);
     std::vector<u64> cidx(P);
@@ -306,25 +313,71 @@ int verify_impl(Ctx &C, size_t n_clients, const uint8_t *const *proofs, size_t p
     std::vector<int> okc(P);
     GensPin gens_pin = get_gens(C, prove_range, chunk);
     C.sync();
-    const bool vbatch = P0.opt_verify_batch != 0;             // rofl_set_option("verify_batch")
+    const int vbatch = opts().verify_batch.load();            // rofl_set_option("verify_batch")
     size_t grp = vbatch ? nv : 1;
+    // verify_batch = 2: one check for the whole batch, a closer look only when it fails (verify_chunks); clients already known to be
+    // malformed are kept out of the shared checks
+    const bool hier = vbatch == 2 && n_clients > 1;
+    std::vector<u64> ridx(P); std::vector<char> skip(P, 0);
+    for (size_t q = 0; q < P; q++) { size_t i = q / nv; ridx[q] = ((u64)(gid ? gid[i] : i) << 24) | cidx[q]; skip[q] = hier && (bad_commit[i] || bad_format[i]); }
     // all (client, chunk) pairs in one pass; a client's chunks form one batch of the random-weighted check
     sc v_shift = sc_from_u64(1ULL << (prove_range - 1));
     std::vector<u64> v_real(P);
     for (size_t q = 0; q < P; q++) { size_t lo = cidx[q] * chunk; v_real[q] = lo >= d ? 0 : std::min(chunk, d - lo); }
-    int rc = verify_chunks(C, "RangeProof", prove_range, P, prove_range, chunk, pf.data(), proof_len, Vh.data(), d_vn2, seed, cidx.data(), okc.data(), grp, &v_shift, v_real.data());
+    int rc = verify_chunks(C, "RangeProof", prove_range, P, prove_range, chunk, pf.data(), proof_len, Vh.data(), d_vn2, seed, cidx.data(), okc.data(), grp, &v_shift, v_real.data(),
+                           n_clients > 1 ? ridx.data() : nullptr, hier, skip.data());
     timing_end(C);
     if (rc) return fail(rc, "proof rejected before verification (format / bitsize)");
     for (size_t i = 0; i < n_clients; i++) { int r = (bad_commit[i] || bad_format[i]) ? 0 : 1; for (size_t c = 0; c < nv; c++) r &= okc[i * nv + c]; ok_out[i] = r; }
     return ROFL_OK;
 }
 
+// The devices a batch entry point spreads its clients over: rofl_set_option("devices", mask).  Empty = the calling thread's device.
+std::vector<int> batch_devices() {
+    std::vector<int> v; long m = opts().devices.load();
+    for (int i = 0; i < kMaxDevices && m; i++, m >>= 1) if (m & 1) v.push_back(i);
+    return v;
+}
+// Clients round-robin over the listed devices, one internal thread per device (bound to it for the duration), each running the ordinary
+// single-device path on its share; verdicts / return codes land in the caller's arrays, in host memory -- in one process there is no
+// collective to run.  run(share, device_slot) is the per-device body; it returns the call-level return code of its share.
+template <class F> int shard_over_devices(size_t n_clients, const std::vector<int> &devs, F run) {
+    const size_t nd = std::min(devs.size(), n_clients);
+    std::vector<std::vector<size_t>> share(nd);
+    for (size_t i = 0; i < n_clients; i++) share[i % nd].push_back(i);
+    std::vector<int> rcs(nd, ROFL_OK); std::vector<std::string> errs(nd);
+    std::vector<std::thread> th;
+    auto body = [&](size_t k) { DeviceBinding bind(devs[k]); rcs[k] = guarded([&]() -> int { return run(share[k]); }); if (rcs[k]) errs[k] = g_err; };
+    for (size_t k = 1; k < nd; k++) th.emplace_back(body, k);
+    body(0);
+    for (auto &t : th) t.join();
+    for (size_t k = 0; k < nd; k++) if (rcs[k]) return fail(rcs[k], errs[k]);
+    return ROFL_OK;
+}
 }  // namespace
 
 // ================================================================ C ABI
 extern "C" {
 
-int rofl_set_device(int device) { g_device = device; return guarded([&]() -> int { LaneLock lane_lock = acquire_lane(); Ctx &C = *lane_lock.c; C.init(); return ROFL_OK; }); }
+// rofl_set_device binds the calling thread to `device` (and makes it the default of threads that have no binding of their own), then
+// brings that device's context up so that a missing device shows here and not in the first proof.
+int rofl_set_device(int device) {
+    if (device < 0 || device >= kMaxDevices) return fail(ROFL_BAD_PARAM, "bad device index");
+    const int prev = t_device, prev_default = g_default_device.load();
+    t_device = device; g_default_device.store(device);
+    int rc = guarded([&]() -> int { LaneLock lane_lock = acquire_lane(); Ctx &C = *lane_lock.c; C.init(); return ROFL_OK; });
+    if (rc) { t_device = prev; g_default_device.store(prev_default); }      // a device that cannot be used is not selected
+    return rc;
+}
+int rofl_get_device(int *device_out) { if (!device_out) return fail(ROFL_BAD_PARAM, "bad parameter"); *device_out = current_device(); return ROFL_OK; }
+int rofl_dbg_bind_device(int device) { if (device < -1 || device >= kMaxDevices) return ROFL_BAD_PARAM; t_device = device; return ROFL_OK; }
+int rofl_dbg_map_device(int logical, int physical) {
+    if (logical < 0 || logical >= kMaxDevices || physical < 0) return ROFL_BAD_PARAM;
+    devmap_init();
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    if (g_ctxs.count(logical)) return fail(ROFL_BAD_PARAM, "the device is already in use");
+    g_devmap[logical] = physical; return ROFL_OK;
+}
 int rofl_last_error(char *buf, size_t len) { if (!buf || !len) return ROFL_BAD_PARAM; snprintf(buf, len, "%s", g_err.c_str()); return ROFL_OK; }
 size_t rofl_next_pow2(size_t v) { return v ? next_pow2(v) : 0; }
 size_t rofl_rangeproof_chunks(size_t d, size_t n_partition) {
@@ -369,25 +422,54 @@ int rofl_create_rangeproof(const float *values, size_t d, const uint8_t *blindin
     return guarded([&]() -> int { LaneLock lane_lock = acquire_lane(); Ctx &C = *lane_lock.c;
         if (d != d_blindings) return fail(ROFL_WRONG_NUM_BLINDING, "WrongNumBlindingFactors");
         int rc1 = ROFL_OK;
-        int rc = create_impl(C, 1, &values, d, &blindings32, prove_range, n_partition, fp_bits, fp_frac, nonce, &proofs_out, proof_len_out, n_proofs_out, &commits_out, &rc1);
+        int rc = create_impl(C, 1, &values, d, &blindings32, prove_range, n_partition, fp_bits, fp_frac, nonce, &proofs_out, proof_len_out, n_proofs_out, &commits_out, &rc1, true);
         return rc ? rc : rc1; });
 }
 int rofl_create_rangeproof_batch(size_t n_clients, const float *const *values, size_t d, const uint8_t *const *blindings32, size_t prove_range,
                                  size_t n_partition, unsigned fp_bits, unsigned fp_frac, const rofl_nonce_t *nonces, uint8_t *const *proofs_out,
                                  size_t *proof_len_out, size_t *n_proofs_out, uint8_t *const *commits_out, int *rc_out) {
-    return guarded([&]() -> int { LaneLock lane_lock = acquire_lane(); Ctx &C = *lane_lock.c;
-        if (!values || !blindings32 || !proofs_out || !commits_out || !rc_out || !proof_len_out || !n_proofs_out) return fail(ROFL_BAD_PARAM, "bad parameter");
-        return create_impl(C, n_clients, values, d, blindings32, prove_range, n_partition, fp_bits, fp_frac, nonces, proofs_out, proof_len_out, n_proofs_out, commits_out, rc_out); });
+    if (!values || !blindings32 || !proofs_out || !commits_out || !rc_out || !proof_len_out || !n_proofs_out || !nonces) return fail(ROFL_BAD_PARAM, "bad parameter");
+    const bool single = n_clients == 1;
+    std::vector<int> devs = batch_devices();
+    if (devs.empty() || n_clients < 2)
+        return guarded([&]() -> int { std::unique_ptr<DeviceBinding> bind; if (!devs.empty()) bind.reset(new DeviceBinding(devs[0]));
+            LaneLock lane_lock = acquire_lane(); Ctx &C = *lane_lock.c;
+            return create_impl(C, n_clients, values, d, blindings32, prove_range, n_partition, fp_bits, fp_frac, nonces, proofs_out, proof_len_out, n_proofs_out, commits_out, rc_out, single); });
+    std::mutex out_mu;
+    return guarded([&]() -> int { return shard_over_devices(n_clients, devs, [&](const std::vector<size_t> &idx) -> int {
+        const size_t k = idx.size();
+        std::vector<const float *> v(k); std::vector<const uint8_t *> b(k); std::vector<rofl_nonce_t> nn(k); std::vector<uint8_t *> po(k), co(k); std::vector<int> rc(k, ROFL_OK);
+        for (size_t j = 0; j < k; j++) { v[j] = values[idx[j]]; b[j] = blindings32[idx[j]]; nn[j] = nonces[idx[j]]; po[j] = proofs_out[idx[j]]; co[j] = commits_out[idx[j]]; }
+        size_t plen = 0, np = 0;
+        LaneLock lane_lock = acquire_lane(); Ctx &C = *lane_lock.c;
+        int r = create_impl(C, k, v.data(), d, b.data(), prove_range, n_partition, fp_bits, fp_frac, nn.data(), po.data(), &plen, &np, co.data(), rc.data(), false);
+        for (size_t j = 0; j < k; j++) rc_out[idx[j]] = rc[j];
+        if (!r) { std::lock_guard<std::mutex> lk(out_mu); *proof_len_out = plen; *n_proofs_out = np; }
+        return r; }); });
 }
 int rofl_verify_rangeproof(const uint8_t *proofs, size_t proof_len, size_t n_proofs, const uint8_t *commits32, size_t d, size_t prove_range,
                            unsigned fp_bits, unsigned fp_frac, const uint8_t verifier_seed[32], int *ok_out) {
     return guarded([&]() -> int { LaneLock lane_lock = acquire_lane(); Ctx &C = *lane_lock.c;
-        return verify_impl(C, 1, &proofs, proof_len, n_proofs, &commits32, d, prove_range, fp_bits, fp_frac, verifier_seed, ok_out); });
+        return verify_impl(C, 1, &proofs, proof_len, n_proofs, &commits32, d, prove_range, fp_bits, fp_frac, verifier_seed, ok_out, true); });
 }
 int rofl_verify_rangeproof_batch(size_t n_clients, const uint8_t *const *proofs, size_t proof_len, size_t n_proofs, const uint8_t *const *commits32,
                                  size_t d, size_t prove_range, unsigned fp_bits, unsigned fp_frac, const uint8_t verifier_seed[32], int *ok_out) {
-    return guarded([&]() -> int { LaneLock lane_lock = acquire_lane(); Ctx &C = *lane_lock.c;
-        return verify_impl(C, n_clients, proofs, proof_len, n_proofs, commits32, d, prove_range, fp_bits, fp_frac, verifier_seed, ok_out); });
+    if (!proofs || !commits32 || !ok_out || !verifier_seed) return fail(ROFL_BAD_PARAM, "bad parameter");
+    const bool single = n_clients == 1;
+    std::vector<int> devs = batch_devices();
+    if (devs.empty() || n_clients < 2)
+        return guarded([&]() -> int { std::unique_ptr<DeviceBinding> bind; if (!devs.empty()) bind.reset(new DeviceBinding(devs[0]));
+            LaneLock lane_lock = acquire_lane(); Ctx &C = *lane_lock.c;
+            return verify_impl(C, n_clients, proofs, proof_len, n_proofs, commits32, d, prove_range, fp_bits, fp_frac, verifier_seed, ok_out, single); });
+    for (size_t i = 0; i < n_clients; i++) ok_out[i] = 0;
+    return guarded([&]() -> int { return shard_over_devices(n_clients, devs, [&](const std::vector<size_t> &idx) -> int {
+        const size_t k = idx.size();
+        std::vector<const uint8_t *> p(k), c(k); std::vector<int> ok(k, 0);
+        for (size_t j = 0; j < k; j++) { p[j] = proofs[idx[j]]; c[j] = commits32[idx[j]]; }
+        LaneLock lane_lock = acquire_lane(); Ctx &C = *lane_lock.c;
+        int r = verify_impl(C, k, p.data(), proof_len, n_proofs, c.data(), d, prove_range, fp_bits, fp_frac, verifier_seed, ok.data(), false, idx.data());
+        for (size_t j = 0; j < k; j++) ok_out[idx[j]] = ok[j];
+        return r; }); });
 }
 int rofl_clip_f32(const float *in, size_t d, size_t prove_range, unsigned fp_bits, unsigned fp_frac, float *out) {
     if (!valid_fp(fp_bits, fp_frac) || prove_range == 0) return fail(ROFL_BAD_PARAM, "bad parameter");
@@ -437,7 +519,7 @@ int rofl_create_rangeproof_l2(const float *values, size_t d, const uint8_t *blin
         // prove_range generators of party 0 are the same chain prefix.
         ChunkNonce cn{}; cn.mode = nonce->mode;
         if (nonce->mode == 1) memcpy(cn.seed.w, nonce->seed, 32);
-        else { uint8_t *sb = C.stream_buf.as<uint8_t>(nonce->stream_scalars * 64 + 64); HIPCHK(hipMemcpyAsync(sb, nonce->stream, nonce->stream_scalars * 64, hipMemcpyHostToDevice, C.stream)); cn.d_stream = sb; cn.stream_scalars = nonce->stream_scalars; }
+        else { uint8_t *sb = C.stream_buf.as<uint8_t>(nonce->stream_scalars * 64 + 64); C.up(sb, nonce->stream, nonce->stream_scalars * 64, C.stream); cn.d_stream = sb; cn.stream_scalars = nonce->stream_scalars; }
         uint8_t *pout = proof_out;
         prove_chunks(C, "L2RangeProof", 1, prove_range, 1, vshift, d_bl, std::vector<ChunkNonce>(1, cn), hV, &pout);
         timing_end(C);
@@ -506,7 +588,7 @@ int sigma_create(int kind, const float *values, size_t d, const uint8_t *r1, siz
     if (dex) C.up(dex, existing, 32 * d, C.stream);
     NonceSeed seed{}; const uint8_t *d_stream = nullptr; u64 ss = 0;
     if (nonce->mode == 1) memcpy(seed.w, nonce->seed, 32);
-    else { ss = nonce->stream_scalars; uint8_t *sb = C.stream_buf.as<uint8_t>(ss * 64 + 64); HIPCHK(hipMemcpyAsync(sb, nonce->stream, ss * 64, hipMemcpyHostToDevice, C.stream)); d_stream = sb; }
+    else { ss = nonce->stream_scalars; uint8_t *sb = C.stream_buf.as<uint8_t>(ss * 64 + 64); C.up(sb, nonce->stream, ss * 64, C.stream); d_stream = sb; }
     hipLaunchKernelGGL(k_sigma_prove, dim3((unsigned)((d + 63) / 64)), dim3(64), 0, C.stream, kind, (u32)d, dv, fp_bits, fp_frac, dr1, dr2, dex,
                        nonce->mode, seed, d_stream, ss, sigma_init_state(kind), C.d_tabB, C.d_tabBb, dp, dc, status);
     u32 st = 0;
@@ -531,7 +613,7 @@ int sigma_verify(int kind, const uint8_t *proofs, const uint8_t *commits, size_t
     HIPCHK(hipMemsetAsync(status, 0, 16, C.stream));
     C.up(dp, proofs, d * plen, C.stream);
     C.up(dc, commits, d * clen, C.stream);
-    const bool sg_batch = (C.parent ? C.parent : &C)->opt_sigma_batch != 0;      // rofl_set_option("sigma_batch")
+    const bool sg_batch = opts().sigma_batch.load() != 0;      // rofl_set_option("sigma_batch")
     if (sg_batch) {
         // one random linear combination of all elements' equations: decode + transcripts per element on the device, then ONE Pippenger MSM
         // over the 4-6 d points and two fixed-base terms (k_sigma_vprep); the weights come from fresh OS randomness
@@ -931,29 +1013,32 @@ int rofl_wire_decode(int kind, const uint8_t *data, size_t len, rofl_wire_msg_t 
     return rc ? fail(rc, rc == ROFL_FORMAT_ERROR ? "malformed message (prost's decode_length_delimited would return Err; the reference unwraps it)" : "bad parameter") : ROFL_OK;
 }
 namespace {
-int *option_slot(Ctx &P, const char *key, long *lo, long *hi) {
-    struct { const char *k; int Ctx::*f; long lo, hi; } tab[] = {
-        {"verify_zip_truncate", &Ctx::opt_zip_truncate, 0, 1}, {"verify_batch", &Ctx::opt_verify_batch, 0, 1},
-        {"sigma_batch", &Ctx::opt_sigma_batch, 0, 1}, {"blocking_sync", &Ctx::blocking_sync, -1, 1}};
-    for (auto &t : tab) if (key && !strcmp(key, t.k)) { *lo = t.lo; *hi = t.hi; return &(P.*(t.f)); }
-    return nullptr;
+struct OptSlot { std::atomic<int> *i; std::atomic<long> *l; long lo, hi; };
+bool option_slot(const char *key, OptSlot *o) {
+    Options &O = opts();
+    const struct { const char *k; OptSlot s; } tab[] = {
+        {"verify_zip_truncate", {&O.zip_truncate, nullptr, 0, 1}}, {"verify_batch", {&O.verify_batch, nullptr, 0, 2}},
+        {"sigma_batch", {&O.sigma_batch, nullptr, 0, 1}}, {"blocking_sync", {&O.blocking_sync, nullptr, -1, 1}},
+        {"devices", {nullptr, &O.devices, 0, (long)(~0UL >> 1)}}};
+    for (auto &t : tab) if (key && !strcmp(key, t.k)) { *o = t.s; return true; }
+    return false;
 }
 }  // namespace
 int rofl_set_option(const char *key, long value) {
-    return guarded([&]() -> int {
-        Ctx &P = ctx(); { std::lock_guard<std::mutex> g(P.init_mu); P.init(); }
-        long lo, hi; int *slot = option_slot(P, key, &lo, &hi);
-        if (!slot || value < lo || value > hi) return fail(ROFL_BAD_PARAM, "unknown option or value out of range");
-        *slot = (int)value; return ROFL_OK;
-    });
+    OptSlot o;
+    if (!option_slot(key, &o) || value < o.lo || value > o.hi) return fail(ROFL_BAD_PARAM, "unknown option or value out of range");
+    if (o.i) o.i->store((int)value); else o.l->store(value);
+    return ROFL_OK;
 }
 int rofl_get_option(const char *key, long *value_out) {
-    return guarded([&]() -> int {
-        Ctx &P = ctx(); { std::lock_guard<std::mutex> g(P.init_mu); P.init(); }
-        long lo, hi; int *slot = option_slot(P, key, &lo, &hi);
-        if (!slot || !value_out) return fail(ROFL_BAD_PARAM, "unknown option");
-        *value_out = *slot; return ROFL_OK;
-    });
+    if (!value_out) return fail(ROFL_BAD_PARAM, "bad parameter");
+    if (key && !strcmp(key, "lanes")) {      // read-only: the lanes of the calling thread's device (ROFL_LANES after clamping)
+        return guarded([&]() -> int { Ctx &P = ctx(); { std::lock_guard<std::mutex> g(P.init_mu); P.init(); } *value_out = P.nlanes; return ROFL_OK; });
+    }
+    OptSlot o;
+    if (!option_slot(key, &o)) return fail(ROFL_BAD_PARAM, "unknown option");
+    *value_out = o.i ? (long)o.i->load() : o.l->load();
+    return ROFL_OK;
 }
 int rofl_set_timing(int enabled) {
     return guarded([&]() -> int {

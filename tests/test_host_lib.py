@@ -213,3 +213,63 @@ def test_host_encode8_matches_scalar_encoder(hiplib):
         pytest.skip("no AVX-512 IFMA on this CPU")
     assert rc == 0
 
+
+
+def test_device_binding_is_per_thread(hiplib):
+    """One process drives several GPUs (rofl_service's server is one process with a verification pool, server.rs:379-384, 656-687): the
+    device is a property of the calling thread.  Two threads keep different devices while they interleave, a thread without a binding of
+    its own follows the process default, and nothing here needs a GPU (rofl_dbg_bind_device is the binding half of rofl_set_device)."""
+    import threading
+    L = hiplib
+    out = {}
+    barrier = threading.Barrier(2)
+
+    def worker(dev, key):
+        assert L.rofl_dbg_bind_device(dev) == 0
+        seen = []
+        for _ in range(200):
+            barrier.wait()
+            g = ctypes.c_int(-7); assert L.rofl_get_device(ctypes.byref(g)) == 0
+            seen.append(g.value)
+        out[key] = set(seen)
+
+    ts = [threading.Thread(target=worker, args=(d, d)) for d in (3, 5)]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    assert out == {3: {3}, 5: {5}}
+    g = ctypes.c_int(-7)
+    assert L.rofl_get_device(ctypes.byref(g)) == 0
+    default = g.value                                   # this thread has no binding: the process default (0 unless something set it)
+    seen = []
+    t = threading.Thread(target=lambda: (L.rofl_get_device(ctypes.byref(g)), seen.append(g.value)))
+    t.start(); t.join()
+    assert seen == [default]
+    assert L.rofl_dbg_bind_device(64) != 0 and L.rofl_set_device(-1) == 11 and L.rofl_set_device(64) == 11
+    # a device that cannot be brought up (no GPU here, or no such GPU) is reported and NOT selected
+    import torch
+    if not torch.cuda.is_available():
+        assert L.rofl_set_device(2) >= 100
+        assert L.rofl_get_device(ctypes.byref(g)) == 0 and g.value == default
+
+
+def test_options_are_process_wide_and_checked(hiplib):
+    """rofl_set_option / rofl_get_option work without a device (a server sets them once, before any GPU call)."""
+    L = hiplib
+    L.rofl_set_option.argtypes = [ctypes.c_char_p, ctypes.c_long]
+    L.rofl_get_option.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_long)]
+    v = ctypes.c_long()
+    for key, dflt, good, bad in ((b"verify_batch", 1, (0, 2, 1), (3, -1)), (b"verify_zip_truncate", 0, (1, 0), (2,)), (b"sigma_batch", 1, (0, 1), (2,)),
+                                 (b"blocking_sync", -1, (0, 1, -1), (2, -2)), (b"devices", 0, (0b11, 1 << 40, 0), (-1,))):
+        assert L.rofl_get_option(key, ctypes.byref(v)) == 0 and v.value == dflt, key
+        for g in good:
+            assert L.rofl_set_option(key, g) == 0 and L.rofl_get_option(key, ctypes.byref(v)) == 0 and v.value == g
+        for b in bad:
+            assert L.rofl_set_option(key, b) == 11
+        assert L.rofl_get_option(key, ctypes.byref(v)) == 0 and v.value == dflt
+    assert L.rofl_set_option(b"nonsense", 1) == 11 and L.rofl_get_option(b"nonsense", ctypes.byref(v)) == 11
+    seen = []
+    import threading
+    t = threading.Thread(target=lambda: (L.rofl_set_option(b"verify_batch", 2), None))
+    t.start(); t.join()
+    assert L.rofl_get_option(b"verify_batch", ctypes.byref(v)) == 0 and v.value == 2      # set on another thread, seen here
+    assert L.rofl_set_option(b"verify_batch", 1) == 0

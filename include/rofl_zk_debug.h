@@ -27,7 +27,11 @@ int rofl_last_timing(rofl_timing_t *out);
  * those launches -- field multiplications (7 per mixed point addition, 8 per doubling, 9 per extended addition) and the bytes
  * a launch has to move at least once (32 B per scalar or point, 4 B per bucket-list entry). */
 enum { ROFL_TK_MSM_ACCUMULATE_FB = 0, ROFL_TK_MSM_ACCUMULATE_GEN = 1, ROFL_TK_MSM_SCATTER = 2, ROFL_TK_MSM_REDUCE = 3,
-       ROFL_TK_MSM_SMALL = 4, ROFL_TK_FOLD_TAB = 5, ROFL_TK_FOLD = 6, ROFL_TK_OTHER = 7, ROFL_TK_COUNT = 8 };
+       ROFL_TK_MSM_SMALL = 4, ROFL_TK_FOLD_TAB = 5, ROFL_TK_FOLD = 6, ROFL_TK_OTHER = 7,
+       ROFL_TK_SIGMA = 8,            /* k_sigma_prove / k_sigma_vprep / k_sigma_verify: the per-element Sigma-proofs (the L2 composite of cfg 3 / 5) */
+       ROFL_TK_VERIFY_SCALARS = 9,   /* k_verify_scalars: the verifier's 2N generator scalars, summed over the proofs of a group (scalar field: no fe_muls) */
+       ROFL_TK_CODEC = 10,           /* k_decode / k_commit: Ristretto decoding / commitment + encoding of d points */
+       ROFL_TK_COUNT = 11 };
 typedef struct { double ms; uint64_t launches, fe_muls, bytes; } rofl_kernel_time_t;
 int rofl_last_kernel_times(rofl_kernel_time_t out[ROFL_TK_COUNT]);
 /* 0 = off; 1 = HIP events around every instrumented launch (~150 event records per proof: ~0.7 ms of a 25 ms proof); 2 = only around the

@@ -17,12 +17,16 @@ pub struct RoflNonce {
 }
 
 extern "C" {
+    /// Binds the CALLING THREAD to `device` (like hipSetDevice) and makes it the default of threads that never call this.
+    /// A server that drives N GPUs from its rayon pool either binds each pool thread once (`rayon::ThreadPoolBuilder::start_handler`)
+    /// or calls `rofl_set_option(b"devices\0".., (1 << N) - 1)` and hands all clients of a round to the `_batch` entry points.
     pub fn rofl_set_device(device: c_int) -> c_int;
+    pub fn rofl_get_device(device_out: *mut c_int) -> c_int;
     pub fn rofl_last_error(buf: *mut c_char, len: usize) -> c_int;
     pub fn rofl_bp_gens_prepare(n_bits: usize, m: usize) -> c_int;
     pub fn rofl_bp_gens_table_bytes(n_bits: usize, m: usize, bytes_out: *mut usize) -> c_int;
-    /// behaviour options ("verify_zip_truncate", "verify_batch", "sigma_batch", "blocking_sync"); the ROFL_* environment variables
-    /// only provide defaults.  A server that wants the reference's zip-truncating verify bit for bit calls
+    /// process-wide behaviour options ("verify_zip_truncate", "verify_batch" 0 / 1 / 2, "sigma_batch", "blocking_sync", "devices" = bit
+    /// mask of the devices the `_batch` entry points spread their clients over); the ROFL_* environment variables only provide defaults.  A server that wants the reference's zip-truncating verify bit for bit calls
     /// `rofl_set_option(b"verify_zip_truncate\0".as_ptr() as *const c_char, 1)` once after `rofl_set_device`.
     pub fn rofl_set_option(key: *const c_char, value: std::os::raw::c_long) -> c_int;
     pub fn rofl_get_option(key: *const c_char, value_out: *mut std::os::raw::c_long) -> c_int;

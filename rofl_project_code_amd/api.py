@@ -192,7 +192,7 @@ class _KernelTime(ctypes.Structure):
 
 
 KERNEL_KINDS = ("k_msm_accumulate_fb", "k_msm_accumulate_gen", "k_msm_bin_l1+l2 / k_msm_scatter_lds", "k_msm_reduce_level+fused", "k_msm_small",
-                "k_fold_gens_tab", "k_fold_gens", "other")
+                "k_fold_gens_tab", "k_fold_gens", "other", "k_sigma_prove / k_sigma_vprep / k_sigma_verify", "k_verify_scalars", "k_decode / k_commit")
 
 
 def last_kernel_times():

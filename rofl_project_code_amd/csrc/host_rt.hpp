@@ -18,6 +18,7 @@ static const Knob KNOBS[] = {
     {"ROFL_VERIFY_ZIP_TRUNCATE", "0", "option verify_zip_truncate: 1 = the reference's zip-truncating verify_rangeproof"},
     {"ROFL_VERIFY_BATCH", "1", "option verify_batch: 0 = one check per proof, 1 = one per client, 2 = one per batch of clients (bisecting down to per-client checks on failure)"},
     {"ROFL_SIGMA_BATCH", "1", "option sigma_batch: 0 = one check per element in the Sigma-proof verifiers"},
+    {"ROFL_STAGE_KEEP_MB", "256", "pinned staging memory a lane keeps between calls (a call that needed more frees it when it ends)"},
     {"ROFL_GENS_BUDGET_MB", "98304", "HBM budget of the generator-table cache (LRU eviction of unpinned entries beyond it)"},
     {"ROFL_FOLD_T1", "3", "IPP rounds before the first generator fold (1..6)"},
     {"ROFL_FOLD_T", "2", "IPP rounds between later folds (1..6)"},
@@ -183,15 +184,19 @@ class HostPool {
     // An index is claimed only after it has been checked against `count` (compare-and-swap, not fetch-add): a worker that wakes
     // late and arrives while run() is resetting the job (count == 0 in that window) must not consume an index of the next job --
     // with a blind fetch-add it could take index 0 between `next = 0` and `count = n` and drop it, and run() would wait forever.
+    // A task that throws (the tasks allocate) must not take the process down from a worker thread, nor leave run() waiting for a `done`
+    // that never comes: the first exception is kept, the index still counts as done, and run() rethrows on the caller's thread, where
+    // guarded() turns it into an error code.
+    std::exception_ptr first_error; std::mutex err_mu;
     void work() {
-        active.fetch_add(1);
+        struct Active { std::atomic<int> &a; explicit Active(std::atomic<int> &x) : a(x) { a.fetch_add(1); } ~Active() { a.fetch_sub(1); } } guard(active);
         for (;;) {
             size_t i = next.load();
             if (i >= count.load()) break;
             if (!next.compare_exchange_weak(i, i + 1)) continue;
-            fn(i); done.fetch_add(1);
+            try { fn(i); } catch (...) { std::lock_guard<std::mutex> lk(err_mu); if (!first_error) first_error = std::current_exception(); }
+            done.fetch_add(1);
         }
-        active.fetch_sub(1);
     }
     // A worker that has just finished a job polls for the next one for a short while before it sleeps: the hops of a proof follow each
     // other at 0.1-0.3 ms, and a sleeping thread has to be put back on a CPU by the scheduler first -- on a busy host (the GPU boxes run
@@ -222,9 +227,11 @@ class HostPool {
                 }
                 // a job seen while polling is taken without the mutex (fifteen pollers queueing for it cost the hop tens of microseconds): run()
                 // publishes fn / count / next before it bumps gen, and the acquire load above orders this thread's reads after that
-                if (g != seen) { seen = g; work(); continue; }
+                // (a hint is for the wait it was announced before: one that arrived while this thread was busy or asleep is over by now)
+                if (g != seen) { seen = g; my_hint = hint_seq.load(std::memory_order_acquire); work(); continue; }
             }
             { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return stop || gen.load() != seen; }); if (stop) return; seen = gen.load(); }
+            my_hint = hint_seq.load(std::memory_order_acquire);
             work();
         }
     }
@@ -249,10 +256,11 @@ public:
     void run(size_t n, std::function<void(size_t)> f) {
         if (n <= 1 || workers.empty()) { for (size_t i = 0; i < n; i++) f(i); return; }
         spin_until([&] { return active.load() == 0; });     // no straggler of the previous job may still look at fn
-        { std::lock_guard<std::mutex> lk(mu); count = 0; fn = std::move(f); done = 0; next = 0; count = n; gen++; }
+        { std::lock_guard<std::mutex> lk(mu); count = 0; fn = std::move(f); done = 0; next = 0; first_error = nullptr; count = n; gen++; }
         cv.notify_all();
         work();
         spin_until([&] { return done.load() >= n; });
+        if (first_error) { std::exception_ptr e; { std::lock_guard<std::mutex> lk(err_mu); e = first_error; first_error = nullptr; } std::rethrow_exception(e); }
         // workers that woke late see next >= count and go back to sleep; make sure none is still inside work()
         // with a stale fn before the next run() replaces it: done == n implies every claimed index finished.
     }
@@ -308,13 +316,17 @@ struct Stage {
         c.used = n; chunks.push_back(c); return c.p;
     }
     // after the call's last synchronisation: hand the results over, recycle the arena (several chunks -> one of their total size next time)
+    // The arena is trimmed to ROFL_STAGE_KEEP_MB afterwards: one large batched call (dozens of clients' commitments) must not leave
+    // gigabytes of pinned host memory allocated for the life of the process, on every lane.
     void finish(bool deliver) {
         if (deliver) for (auto &q : pend) memcpy(q.user, q.stage, q.n);
         pend.clear();
-        if (chunks.size() > 1) {
-            size_t tot = 0; for (auto &c : chunks) { tot += c.cap; (void)hipHostFree(c.p); }
+        static const size_t keep = (knob("ROFL_STAGE_KEEP_MB") ? (size_t)std::max(1L, atol(knob("ROFL_STAGE_KEEP_MB"))) : (size_t)256) << 20;
+        size_t tot = 0; for (auto &c : chunks) tot += c.cap;
+        if (tot > keep || chunks.size() > 1) {
+            for (auto &c : chunks) (void)hipHostFree(c.p);
             chunks.clear();
-            Chunk c; c.cap = tot; if (hipHostMalloc(&c.p, c.cap, hipHostMallocDefault) == hipSuccess) chunks.push_back(c);
+            if (tot <= keep) { Chunk c; c.cap = tot; if (hipHostMalloc(&c.p, c.cap, hipHostMallocDefault) == hipSuccess) chunks.push_back(c); }
         }
         for (auto &c : chunks) c.used = 0;
         dirty = false;
@@ -409,6 +421,11 @@ struct Ctx {
         HIPCHK(hipMemcpyAsync(s, src_dev, n, hipMemcpyDeviceToHost, st));
         stg.pend.push_back({dst_user, s, n});
         return s;
+    }
+    std::vector<hipEvent_t> ev_pool;      // numbered events of the current call (pipelined input groups)
+    hipEvent_t pool_event(size_t k) {
+        while (ev_pool.size() <= k) { hipEvent_t e; HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ev_pool.push_back(e); }
+        return ev_pool[k];
     }
     Ctx *parent = nullptr;
     std::vector<Ctx *> sibs;      // additional lanes

@@ -17,6 +17,12 @@ sc verifier_c(const uint8_t seed[32], u64 idx) {
 // d_Vniels holds the UNSHIFTED commitments C_j (k_decode); h_V the encodings of V_j = C_j + v_shift * B for the first v_real[c] values of
 // chunk c (identity padding after them): the check needs sum_j s_j V_j, which is the MSM over the C_j plus (sum_{j < v_real} s_j) * v_shift on B.
 //
+// Inputs that arrive while the transcripts are being hashed (a batch of clients whose commitments are decoded group by group):
+// ready[k] = (end proof, event): the V encodings and status words of the proofs below `end` are complete once `ev` has fired.
+// h_status[i] & 4: client i (proofs_per_client proofs each) has a commitment that does not decode -- its proofs leave the shared checks.
+struct VerifyReady { size_t end; hipEvent_t ev; };
+struct VerifyInputs { const std::vector<VerifyReady> *ready; const u32 *h_status; size_t proofs_per_client; };
+//
 // `group` consecutive proofs form a UNIT (a client's chunks: the reference returns one bool per client) that is checked as one batch:
 // sum_c rho_c * (check_c) == 0 with random weights rho_c, so the generator terms of its proofs share one MSM.  Every proof of a unit gets
 // the unit's verdict.  `hier` (rofl_set_option("verify_batch", 2), the server role: server.rs:474-484 fails the whole round on one bad
@@ -28,7 +34,7 @@ sc verifier_c(const uint8_t seed[32], u64 idx) {
 int verify_chunks(Ctx &C, const char *label, size_t gens_capacity, size_t P, size_t n, size_t m, const uint8_t *proofs, size_t plen,
                   const uint8_t *h_V, const niels *d_Vniels, const uint8_t seed[32], const u64 *c_index, int *ok, size_t group = 1,
                   const sc *v_shift = nullptr, const u64 *v_real = nullptr, const u64 *rho_index = nullptr, bool hier = false,
-                  const char *skip = nullptr) {
+                  const char *skip = nullptr, const VerifyInputs *vin = nullptr) {
     for (size_t c = 0; c < P; c++) ok[c] = 0;
     static const bool vtrace = knob("ROFL_TRACE") && atoi(knob("ROFL_TRACE")) >= 2;
     double vt0 = now_ms(), vtl = vt0;
@@ -78,7 +84,7 @@ int verify_chunks(Ctx &C, const char *label, size_t gens_capacity, size_t P, siz
     HIPCHK(hipMemcpyAsync(d_auxc, h_auxc, P * (4 + 2 * lg) * 32, hipMemcpyHostToDevice, C.stream));
     hipLaunchKernelGGL(k_decode, grid1(P * (4 + 2 * lg)), dim3(TPB), 0, C.stream, (u32)(P * (4 + 2 * lg)), (u32)(P * (4 + 2 * lg)), d_auxc, (const niels *)nullptr, d_auxn, (uint8_t *)nullptr, status);
     double th = now_ms();
-    C.pool->run(P, [&](size_t c) {
+    auto transcript = [&](size_t c) {
         const uint8_t *p = proofs + c * plen; const uint8_t *ipp = p + 7 * 32;
         Merlin t(label, strlen(label));
         t.append("dom-sep", (const uint8_t *)"rangeproof v1", 13);
@@ -88,7 +94,7 @@ int verify_chunks(Ctx &C, const char *label, size_t gens_capacity, size_t P, siz
         bool bad = false;
         for (int i = 0; i < 4; i++) if (!memcmp(p + 32 * i, zero32, 32)) bad = true;
         for (size_t k = 0; k < 2 * lg; k++) if (!memcmp(ipp + 32 * k, zero32, 32)) bad = true;
-        if (bad || (skip && skip[c])) { dead[c] = 1; }
+        if (bad || (skip && skip[c]) || (hier && vin && (vin->h_status[c / vin->proofs_per_client] & 4u))) { dead[c] = 1; }
         t.append("A", p, 32); t.append("S", p + 32, 32);
         sc y = t.challenge_scalar("y"), z = t.challenge_scalar("z");
         t.append("T_1", p + 64, 32); t.append("T_2", p + 96, 32);
@@ -150,7 +156,16 @@ int verify_chunks(Ctx &C, const char *label, size_t gens_capacity, size_t P, siz
             (void)zm;
             sB[c] = sc_add(sB[c], h_mul(h_mul(h_mul(rho, h_mul(cc, zz)), geo_z), *v_shift));
         }
-    });
+    };
+    if (vin && vin->ready && !vin->ready->empty()) {      // group by group, as the encodings arrive (the device is still decoding the later groups)
+        size_t c0 = 0;
+        for (const VerifyReady &r : *vin->ready) {
+            HIPCHK(hipEventSynchronize(r.ev));
+            const size_t c1 = std::min(r.end, P);
+            if (c1 > c0) C.pool->run(c1 - c0, [&](size_t k) { transcript(c0 + k); });
+            c0 = c1;
+        }
+    } else C.pool->run(P, transcript);
     C.tm.t.host_ms += now_ms() - th;
     vmark("transcripts");
     HIPCHK(hipMemcpyAsync(d_cp, h_cp, sizeof(ChunkParams) * P, hipMemcpyHostToDevice, C.stream));
@@ -183,7 +198,9 @@ int verify_chunks(Ctx &C, const char *label, size_t gens_capacity, size_t P, siz
         Grp *h_grp = C.h_vgrp.as<Grp>(ng);
         memcpy(h_grp, groups.data(), sizeof(Grp) * ng);
         HIPCHK(hipMemcpyAsync(d_grp, h_grp, sizeof(Grp) * ng, hipMemcpyHostToDevice, C.stream));
-        hipLaunchKernelGGL(k_verify_scalars, grid1(N, (u32)ng), dim3(TPB), 0, C.stream, (u32)n, (u32)m, (u32)lg, reinterpret_cast<const uint2 *>(d_grp), d_cp, (const PowTabs *)d_pt, C.d_two_pow, gh);
+        uint64_t vs_proofs = 0; for (auto &g : groups) vs_proofs += g.count;
+        { KSpan ks_vs(C.tm, C.stream, ROFL_TK_VERIFY_SCALARS, 0, (uint64_t)ng * 2 * N * 32 + vs_proofs * sizeof(PowTabs));
+          hipLaunchKernelGGL(k_verify_scalars, grid1(N, (u32)ng), dim3(TPB), 0, C.stream, (u32)n, (u32)m, (u32)lg, reinterpret_cast<const uint2 *>(d_grp), d_cp, (const PowTabs *)d_pt, C.d_two_pow, gh); }
         std::vector<MsmProb> pr(ng), prB(ng); std::vector<ge5> resA, resB;
         for (size_t g = 0; g < ng; g++) pr[g] = MsmProb{tbl, gh + g * 2 * N};
         for (size_t g = 0; g < ng; g++) prB[g] = MsmProb{aux_pts + (size_t)groups[g].start * naux, aux_scal + (size_t)groups[g].start * naux};

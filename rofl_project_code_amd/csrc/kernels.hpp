@@ -1664,6 +1664,12 @@ __global__ void __launch_bounds__(TPB) k_decode(u32 count, u32 valid_count, cons
                          uint8_t *out_enc, u32 *status) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
+    {   // blockIdx.y = vector (a batch of clients): `count` entries each, one status word each
+        const size_t y = blockIdx.y;
+        in += y * count * 32; status += y;
+        if (out_niels) out_niels += y * count;
+        if (out_enc) out_enc += y * count * 32;
+    }
     if (i >= valid_count) {   // padding: identity
         if (out_niels) store_niels(&out_niels[i], niels_identity());
         if (out_enc) { uint4 z = make_uint4(0, 0, 0, 0); reinterpret_cast<uint4 *>(out_enc + (size_t)i * 32)[0] = z; reinterpret_cast<uint4 *>(out_enc + (size_t)i * 32)[1] = z; }

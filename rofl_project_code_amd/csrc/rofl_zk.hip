@@ -206,7 +206,8 @@ int create_impl(Ctx &C, size_t nc, const float *const *values, size_t d, const u
     HIPCHK(hipEventRecord(C.ev_fork, C.stream));                  // inputs quantised (and compacted)
     HIPCHK(hipStreamWaitEvent(C.stream2, C.ev_fork, 0));
     HIPCHK(hipMemcpyAsync(d_shift, &h_shift, sizeof(niels), hipMemcpyHostToDevice, C.stream2));
-    hipLaunchKernelGGL(k_commit, grid1(na * dp), dim3(TPB), 0, C.stream2, (u32)(na * dp), vshift, (const sc *)nullptr, d_blind_buf, C.d_tabB, C.d_tabBb, d_shift, Vb, Cb, (u32)d, (u32)dp);
+    { KSpan ks(C.tm, C.stream2, ROFL_TK_CODEC, (uint64_t)na * dp * (2 * 64 * 7 + 2 * 265), (uint64_t)na * dp * (8 + 32 + 64));
+    hipLaunchKernelGGL(k_commit, grid1(na * dp), dim3(TPB), 0, C.stream2, (u32)(na * dp), vshift, (const sc *)nullptr, d_blind_buf, C.d_tabB, C.d_tabBb, d_shift, Vb, Cb, (u32)d, (u32)dp); }
     uint8_t *hV = C.h_V.as<uint8_t>(na * dp * 32);
     HIPCHK(hipMemcpyAsync(hV, Vb, na * dp * 32, hipMemcpyDeviceToHost, C.stream2));
     HIPCHK(hipEventRecord(C.ev_v, C.stream2));
@@ -284,48 +285,69 @@ int verify_impl(Ctx &C, size_t n_clients, const uint8_t *const *proofs, size_t p
     niels *d_vn = C.gbuf[0].as<niels>(tot);
     u32 *status = C.status.as<u32>(n_clients + 4);       // one status word per client: an undecodable commitment fails that client only
     HIPCHK(hipMemsetAsync(status, 0, 4 * (n_clients + 4), C.stream));
-    std::vector<uint8_t> hV(tot * 32);
-    for (size_t i = 0; i < n_clients; i++) {
-        C.up(d_in + i * dp * 32, commits[i], d * 32, C.stream);
-        hipLaunchKernelGGL(k_decode, grid1(dp), dim3(TPB), 0, C.stream, (u32)dp, (u32)d, d_in + i * dp * 32, d_shift, d_vn + i * dp, d_enc + i * dp * 32, status + i);
-    }
-    HIPCHK(hipMemcpyAsync(hV.data(), d_enc, tot * 32, hipMemcpyDeviceToHost, C.stream));
+    uint8_t *hV = C.h_V.as<uint8_t>(tot * 32);            // pinned: the encodings of the shifted commitments, for the transcripts
     u32 *h_st = C.h_misc.as<u32>(n_clients + 4);
-    HIPCHK(hipMemcpyAsync(h_st, status, 4 * n_clients, hipMemcpyDeviceToHost, C.stream));
-    C.sync();
-    std::vector<char> bad_commit(n_clients, 0);
-    for (size_t i = 0; i < n_clients; i++) bad_commit[i] = (h_st[i] & 4u) != 0;
-    // a single set with an invalid encoding: the reference cannot even build its Vec<RistrettoPoint> (decompress fails) -> FormatError;
-    // in a batch the other clients are still verified and the offender gets ok = 0
-    if (single && bad_commit[0]) return fail(ROFL_FORMAT_ERROR, "commitment is not a valid Ristretto encoding");
-    // flatten (client, chunk) -> problem list
-    std::vector<uint8_t> Vh(P * chunk * 32);
+    // Commitments in, decoded, shifted encodings out -- in groups of a few clients: the host hashes the encodings of group g into the
+    // transcripts (verify_chunks) while the device decodes group g + 1.  Host memory is staged (one parallel copy per group on the pool);
+    // device pointers go straight in.
+    const size_t GC = std::max<size_t>(1, std::min<size_t>(n_clients, ((size_t)1 << 19) / dp));      // ~2^19 commitments per group
+    std::vector<VerifyReady> ready;
+    bool all_host = true; for (size_t i = 0; i < n_clients; i++) all_host &= !is_device_ptr(commits[i]);
+    for (size_t i0 = 0; i0 < n_clients; i0 += GC) {
+        const size_t gc = std::min(GC, n_clients - i0);
+        if (all_host && d * 32 >= Stage::kMin) {
+            uint8_t *st = (uint8_t *)C.stg.alloc(gc * d * 32);
+            const size_t slices = std::max<size_t>(1, (d * 32) >> 18);      // ~256 KB per task
+            C.pool->run(gc * slices, [&](size_t t) { size_t i = t / slices, k = t % slices, lo = d * 32 * k / slices, hi = d * 32 * (k + 1) / slices;
+                                                     memcpy(st + i * d * 32 + lo, commits[i0 + i] + lo, hi - lo); });
+            HIPCHK(hipMemcpy2DAsync(d_in + i0 * dp * 32, dp * 32, st, d * 32, d * 32, gc, hipMemcpyHostToDevice, C.stream));
+        } else
+            for (size_t i = i0; i < i0 + gc; i++) C.up(d_in + i * dp * 32, commits[i], d * 32, C.stream);
+        { KSpan ks(C.tm, C.stream, ROFL_TK_CODEC, (uint64_t)gc * d * (2 * 265 + 7), (uint64_t)gc * d * 64);
+          hipLaunchKernelGGL(k_decode, grid1(dp, (u32)gc), dim3(TPB), 0, C.stream, (u32)dp, (u32)d, d_in + i0 * dp * 32, d_shift, d_vn + i0 * dp, d_enc + i0 * dp * 32, status + i0); }
+        HIPCHK(hipMemcpyAsync(hV + i0 * dp * 32, d_enc + i0 * dp * 32, gc * dp * 32, hipMemcpyDeviceToHost, C.stream));
+        HIPCHK(hipMemcpyAsync(h_st + i0, status + i0, 4 * gc, hipMemcpyDeviceToHost, C.stream));
+        ready.push_back(VerifyReady{(i0 + gc) * nv, C.pool_event(ready.size())});
+        HIPCHK(hipEventRecord(ready.back().ev, C.stream));
+    }
+    // flatten (client, chunk) -> problem list.  A client's verified chunks are a prefix of its dp commitments: when the proofs cover
+    // everything (the normal case) the per-client arrays ARE the per-proof arrays; otherwise one strided copy each
     std::vector<u64> cidx(P);
-    niels *d_vn2 = C.gbuf[1].as<niels>(P * chunk);
-    for (size_t i = 0; i < n_clients; i++)
-        for (size_t c = 0; c < nv; c++) {
-            size_t q = i * nv + c;
-            memcpy(&Vh[q * chunk * 32], &hV[(i * dp + c * chunk) * 32], chunk * 32);
-            cidx[q] = c;
-        }
-    // a client's verified chunks are a prefix of its dp commitments: one strided copy (a plain one when the proofs cover everything)
-    HIPCHK(hipMemcpy2DAsync(d_vn2, nv * chunk * sizeof(niels), d_vn, dp * sizeof(niels), nv * chunk * sizeof(niels), n_clients, hipMemcpyDeviceToDevice, C.stream));
+    for (size_t i = 0; i < n_clients; i++) for (size_t c = 0; c < nv; c++) cidx[i * nv + c] = c;
+    const uint8_t *Vh = hV; const niels *d_vn2 = d_vn;
+    std::vector<uint8_t> Vh_own;
+    if (nv * chunk != dp) {
+        HIPCHK(hipStreamSynchronize(C.stream));
+        Vh_own.resize(P * chunk * 32);
+        for (size_t i = 0; i < n_clients; i++) memcpy(&Vh_own[i * nv * chunk * 32], hV + i * dp * 32, nv * chunk * 32);
+        Vh = Vh_own.data();
+        niels *cp2 = C.gbuf[1].as<niels>(P * chunk);
+        HIPCHK(hipMemcpy2DAsync(cp2, nv * chunk * sizeof(niels), d_vn, dp * sizeof(niels), nv * chunk * sizeof(niels), n_clients, hipMemcpyDeviceToDevice, C.stream));
+        d_vn2 = cp2;
+    }
     std::vector<int> okc(P);
     GensPin gens_pin = get_gens(C, prove_range, chunk);
-    C.sync();
     const int vbatch = opts().verify_batch.load();            // rofl_set_option("verify_batch")
     size_t grp = vbatch ? nv : 1;
     // verify_batch = 2: one check for the whole batch, a closer look only when it fails (verify_chunks); clients already known to be
     // malformed are kept out of the shared checks
     const bool hier = vbatch == 2 && n_clients > 1;
     std::vector<u64> ridx(P); std::vector<char> skip(P, 0);
-    for (size_t q = 0; q < P; q++) { size_t i = q / nv; ridx[q] = ((u64)(gid ? gid[i] : i) << 24) | cidx[q]; skip[q] = hier && (bad_commit[i] || bad_format[i]); }
+    for (size_t q = 0; q < P; q++) { size_t i = q / nv; ridx[q] = ((u64)(gid ? gid[i] : i) << 24) | cidx[q]; skip[q] = hier && bad_format[i]; }
     // all (client, chunk) pairs in one pass; a client's chunks form one batch of the random-weighted check
     sc v_shift = sc_from_u64(1ULL << (prove_range - 1));
     std::vector<u64> v_real(P);
     for (size_t q = 0; q < P; q++) { size_t lo = cidx[q] * chunk; v_real[q] = lo >= d ? 0 : std::min(chunk, d - lo); }
-    int rc = verify_chunks(C, "RangeProof", prove_range, P, prove_range, chunk, pf.data(), proof_len, Vh.data(), d_vn2, seed, cidx.data(), okc.data(), grp, &v_shift, v_real.data(),
-                           n_clients > 1 ? ridx.data() : nullptr, hier, skip.data());
+    // (an undecodable commitment is known only when its group has been decoded: verify_chunks asks for the client's status word then)
+    VerifyInputs vin{&ready, h_st, nv};
+    int rc = verify_chunks(C, "RangeProof", prove_range, P, prove_range, chunk, pf.data(), proof_len, Vh, d_vn2, seed, cidx.data(), okc.data(), grp, &v_shift, v_real.data(),
+                           n_clients > 1 ? ridx.data() : nullptr, hier, skip.data(), &vin);
+    HIPCHK(hipStreamSynchronize(C.stream));      // (a no-op after the checks; verify_chunks may have left before its first wait)
+    std::vector<char> bad_commit(n_clients, 0);
+    for (size_t i = 0; i < n_clients; i++) bad_commit[i] = (h_st[i] & 4u) != 0;
+    // a single set with an invalid encoding: the reference cannot even build its Vec<RistrettoPoint> (decompress fails) -> FormatError;
+    // in a batch the other clients are still verified and the offender gets ok = 0
+    if (single && bad_commit[0]) { timing_end(C); return fail(ROFL_FORMAT_ERROR, "commitment is not a valid Ristretto encoding"); }
     timing_end(C);
     if (rc) return fail(rc, "proof rejected before verification (format / bitsize)");
     for (size_t i = 0; i < n_clients; i++) { int r = (bad_commit[i] || bad_format[i]) ? 0 : 1; for (size_t c = 0; c < nv; c++) r &= okc[i * nv + c]; ok_out[i] = r; }
@@ -589,8 +611,11 @@ int sigma_create(int kind, const float *values, size_t d, const uint8_t *r1, siz
     NonceSeed seed{}; const uint8_t *d_stream = nullptr; u64 ss = 0;
     if (nonce->mode == 1) memcpy(seed.w, nonce->seed, 32);
     else { ss = nonce->stream_scalars; uint8_t *sb = C.stream_buf.as<uint8_t>(ss * 64 + 64); C.up(sb, nonce->stream, ss * 64, C.stream); d_stream = sb; }
-    hipLaunchKernelGGL(k_sigma_prove, dim3((unsigned)((d + 63) / 64)), dim3(64), 0, C.stream, kind, (u32)d, dv, fp_bits, fp_frac, dr1, dr2, dex,
-                       nonce->mode, seed, d_stream, ss, sigma_init_state(kind), C.d_tabB, C.d_tabBb, dp, dc, status);
+    // algorithmic work per element: 7 fixed-base multiplications (64 mixed additions each), one variable-base one (~325 point operations),
+    // 2 * npts encodings; bytes as SURVEY 8(d): value + randomness in, commitments + proof out
+    { KSpan ks_sigma(C.tm, C.stream, ROFL_TK_SIGMA, (uint64_t)d * (7 * 64 * 7 + 325 * 8 + 2 * npts * 265), (uint64_t)d * (4 + 32 * (has_sq ? 2 : 1) + clen + plen));
+      hipLaunchKernelGGL(k_sigma_prove, dim3((unsigned)((d + 63) / 64)), dim3(64), 0, C.stream, kind, (u32)d, dv, fp_bits, fp_frac, dr1, dr2, dex,
+                         nonce->mode, seed, d_stream, ss, sigma_init_state(kind), C.d_tabB, C.d_tabBb, dp, dc, status); }
     u32 st = 0;
     C.down(proofs_out, dp, d * plen, C.stream);
     C.down(commits_out, dc, d * clen, C.stream);
@@ -624,7 +649,8 @@ int sigma_verify(int kind, const uint8_t *proofs, const uint8_t *commits, size_t
         niels *pts = C.gbuf[0].as<niels>(nslots * d);
         sc *scal = C.SL.as<sc>(nslots * d);
         sc *d_fixed = C.tmp_out.as<sc>(nblk * 2);
-        hipLaunchKernelGGL(k_sigma_vprep, dim3((unsigned)nblk), dim3(TPB), 0, C.stream, kind, (u32)d, dp, dc, sigma_init_state(kind), ws, pts, scal, d_fixed, status);
+        { KSpan ks_sigma(C.tm, C.stream, ROFL_TK_SIGMA, (uint64_t)d * (2 * npts * 265), (uint64_t)d * (clen + plen));      // decoding of 2 npts points per element
+          hipLaunchKernelGGL(k_sigma_vprep, dim3((unsigned)nblk), dim3(TPB), 0, C.stream, kind, (u32)d, dp, dc, sigma_init_state(kind), ws, pts, scal, d_fixed, status); }
         std::vector<sc> h_fixed(nblk * 2);
         u32 st0 = 0;
         HIPCHK(hipMemcpyAsync(h_fixed.data(), d_fixed, sizeof(sc) * nblk * 2, hipMemcpyDeviceToHost, C.stream));
@@ -639,7 +665,8 @@ int sigma_verify(int kind, const uint8_t *proofs, const uint8_t *commits, size_t
         *ok_out = h51::is_identity_ristretto(tot) ? 1 : 0;
         return ROFL_OK;
     }
-    hipLaunchKernelGGL(k_sigma_verify, dim3((unsigned)((d + 63) / 64)), dim3(64), 0, C.stream, kind, (u32)d, dp, dc, sigma_init_state(kind), C.d_tabB, C.d_tabBb, status + 1, status);
+    { KSpan ks_sigma(C.tm, C.stream, ROFL_TK_SIGMA, (uint64_t)d * (2 * npts * 265 + (kind ? 3 : 2) * 2 * 325 * 8), (uint64_t)d * (clen + plen));
+      hipLaunchKernelGGL(k_sigma_verify, dim3((unsigned)((d + 63) / 64)), dim3(64), 0, C.stream, kind, (u32)d, dp, dc, sigma_init_state(kind), C.d_tabB, C.d_tabBb, status + 1, status); }
     u32 st[2] = {0, 0};
     HIPCHK(hipMemcpyAsync(st, status, 8, hipMemcpyDeviceToHost, C.stream));
     C.sync();

@@ -80,6 +80,10 @@ int rofl_dbg_host_bench(int what, unsigned iters, double *ns_out);
 int rofl_dbg_host_horner8_selftest(unsigned W, unsigned c, int lanes, double *us_simd, double *us_scalar);
 /* h8::encode8 (eight Ristretto encodings per AVX-512 IFMA stream) against the scalar host encoder: 0 = all equal, 1 = mismatch, -1 = no IFMA */
 int rofl_dbg_host_encode8_selftest(unsigned batches, double *us_simd, double *us_scalar);
+/* csrc/keccak_x8.hpp (eight Merlin transcripts per AVX-512 stream: the verifier's transcript prefixes) against the scalar transcript:
+ * `lanes` transcripts, `count` commitments each, `skew` extra prefix bytes (moves the records across the rate block): 0 = states and the
+ * next challenge agree, 1 = mismatch, -1 = no AVX-512 on this CPU */
+int rofl_dbg_host_merlin8_selftest(int lanes, unsigned count, unsigned skew, double *us_simd, double *us_scalar);
 /* host share of the hops of the calling thread's last create / verify: out[0] hops, [1] enqueue ms, [2] wait ms, [3] window-combination wall ms,
  * [4] sum of each hop's slowest pool task ms, [5..8] the maxima over the hops of enqueue, wait, combination wall, slowest task */
 int rofl_dbg_last_hops(double out[10]);

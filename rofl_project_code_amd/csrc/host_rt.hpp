@@ -46,6 +46,7 @@ static const Knob KNOBS[] = {
     {"ROFL_MSM_LDS_MIN", "8192", "MSMs with fewer terms use the per-item slot sort"},
     {"ROFL_MSM_LDS_TILE", "131072", "items one block of the LDS slot sort ranks"},
     {"ROFL_MSM_SMALL_MAX", "8192", "terms per side up to which a generic MSM runs as one fused launch (0 = off)"},
+    {"ROFL_MERLIN_X8", "1", "0 = the verifier hashes every chunk's transcript prefix on its own even when the host has AVX-512 (eight chunks per instruction stream otherwise, from 32 chunks on)"},
     {"ROFL_MSM_HOST8", "1", "0 = launches with many problems combine their windows on the device (k_msm_horner) even when the host has AVX-512 IFMA"},
     {"ROFL_MSM_DEV_HORNER_MIN", "32", "launches with at least this many problems combine their windows on the device"},
     {"ROFL_MSM_T13", "8192", "generic MSMs from this many terms on use 13-bit windows"},
@@ -490,7 +491,7 @@ struct Ctx {
     // workspace
     DevBuf cp, sL, sR, party, Scanon, vshift, blind, Vbytes, Cbytes, status, partial, partial2, scpart, a, b, a2, b2, ptab[2], yinv,
         SL, SR, powtabs, foldprobs, naf,
-        gbuf[2], aux_pts, aux_scal, vscal, tmp_in, tmp_in2, tmp_out, vals, uni, stream_buf, vgroups;
+        gbuf[2], aux_pts, aux_scal, vscal, tmp_in, tmp_in2, tmp_out, vals, uni, stream_buf, vgroups, vtabs;
     PinBuf h_cp, h_part, h_misc, h_misc2, h_auxc, h_auxs, h_V, h_ip, h_round, h_fdig, h_fprob, h_abfin, h_vgrp;
     MsmWs mws[2];
     std::map<uint64_t, double> wait_ms;      // how long the wait of a tagged hop took the last times (hint for the pool workers' naps)

@@ -84,12 +84,21 @@ int verify_chunks(Ctx &C, const char *label, size_t gens_capacity, size_t P, siz
     HIPCHK(hipMemcpyAsync(d_auxc, h_auxc, P * (4 + 2 * lg) * 32, hipMemcpyHostToDevice, C.stream));
     hipLaunchKernelGGL(k_decode, grid1(P * (4 + 2 * lg)), dim3(TPB), 0, C.stream, (u32)(P * (4 + 2 * lg)), (u32)(P * (4 + 2 * lg)), d_auxc, (const niels *)nullptr, d_auxn, (uint8_t *)nullptr, status);
     double th = now_ms();
-    auto transcript = [&](size_t c) {
+    // the transcript prefix (the m commitments of a chunk; sequential sponge): with enough proofs eight chunks share one AVX-512
+    // instruction stream (keccak_x8.hpp), otherwise one chunk per task
+    static const bool x8_on = k8::available() && !(knob("ROFL_MERLIN_X8") && atoi(knob("ROFL_MERLIN_X8")) == 0);
+    auto prefix = [&](Merlin *const t[8], const size_t c[8], int cnt) {
+        const uint8_t *msg[8];
+        for (int l = 0; l < cnt; l++) {
+            t[l]->append("dom-sep", (const uint8_t *)"rangeproof v1", 13);
+            t[l]->append_u64("n", n); t[l]->append_u64("m", m);
+            msg[l] = h_V + c[l] * m * 32;
+        }
+        if (x8_on && cnt >= 5) k8::append32_run_x8(t, cnt, 'V', msg, m);
+        else for (int l = 0; l < cnt; l++) t[l]->append32_run('V', msg[l], m);
+    };
+    auto transcript = [&](size_t c, Merlin &t) {
         const uint8_t *p = proofs + c * plen; const uint8_t *ipp = p + 7 * 32;
-        Merlin t(label, strlen(label));
-        t.append("dom-sep", (const uint8_t *)"rangeproof v1", 13);
-        t.append_u64("n", n); t.append_u64("m", m);
-        t.append32_run('V', h_V + c * m * 32, m);
         // validate_and_append_point rejects the identity encoding
         bool bad = false;
         for (int i = 0; i < 4; i++) if (!memcmp(p + 32 * i, zero32, 32)) bad = true;
@@ -157,20 +166,40 @@ int verify_chunks(Ctx &C, const char *label, size_t gens_capacity, size_t P, siz
             sB[c] = sc_add(sB[c], h_mul(h_mul(h_mul(rho, h_mul(cc, zz)), geo_z), *v_shift));
         }
     };
+    // proofs [c0, c1): eight per task when the lanes of the SIMD sponge can be filled and the pool still gets a task per thread
+    auto hash_range = [&](size_t c0, size_t c1) {
+        if (c1 <= c0) return;
+        const size_t cnt = c1 - c0, per = (x8_on && cnt >= 32) ? 8 : 1;
+        C.pool->run((cnt + per - 1) / per, [&](size_t b) {
+            Merlin tr[8] = {Merlin(label, strlen(label)), Merlin(label, strlen(label)), Merlin(label, strlen(label)), Merlin(label, strlen(label)),
+                            Merlin(label, strlen(label)), Merlin(label, strlen(label)), Merlin(label, strlen(label)), Merlin(label, strlen(label))};
+            Merlin *t[8]; size_t cs[8]; int k = 0;
+            for (size_t c = c0 + b * per; c < std::min(c1, c0 + (b + 1) * per); c++, k++) { t[k] = &tr[k]; cs[k] = c; }
+            prefix(t, cs, k);
+            for (int l = 0; l < k; l++) transcript(cs[l], tr[l]);
+        });
+    };
     if (vin && vin->ready && !vin->ready->empty()) {      // group by group, as the encodings arrive (the device is still decoding the later groups)
         size_t c0 = 0;
         for (const VerifyReady &r : *vin->ready) {
             HIPCHK(hipEventSynchronize(r.ev));
             const size_t c1 = std::min(r.end, P);
-            if (c1 > c0) C.pool->run(c1 - c0, [&](size_t k) { transcript(c0 + k); });
+            hash_range(c0, c1);
             c0 = c1;
         }
-    } else C.pool->run(P, transcript);
+    } else hash_range(0, P);
     C.tm.t.host_ms += now_ms() - th;
     vmark("transcripts");
     HIPCHK(hipMemcpyAsync(d_cp, h_cp, sizeof(ChunkParams) * P, hipMemcpyHostToDevice, C.stream));
     PowTabs *d_pt = C.powtabs.as<PowTabs>(P);
     hipLaunchKernelGGL(k_pow_tables, dim3((4 * PT_L * PT_E + TPB - 1) / TPB, (u32)P), dim3(TPB), 0, C.stream, d_cp, d_pt, (u32)lg, 1);
+    // the block-structured form of the generator scalars (k_verify_scalars2) takes whole blocks of 512 indices, all of them inside the tables
+    const bool vs2 = N >= 512 && lg <= 3 * PT_W && n <= 64;
+    VTabs *d_vt = nullptr;
+    if (vs2) {
+        d_vt = C.vtabs.as<VTabs>(P);
+        hipLaunchKernelGGL(k_vtabs, dim3((9 * PT_E + 64 + 255) / 256, (u32)P), dim3(256), 0, C.stream, d_cp, (const PowTabs *)d_pt, C.d_two_pow, d_vt, (u32)n, lg2u(n));
+    }
     // aux arrays: per proof [m commitments | 4 + 2 lg proof points] and their scalars.  The closer look of `hier` checks runs of units whose
     // last one may be shorter: the arrays end in one group's worth of zero scalars, so every MSM problem of a launch can take the same length.
     const size_t gB = hier ? (size_t)std::ceil(std::sqrt((double)units)) : 1;      // units per group of the middle level
@@ -200,7 +229,8 @@ int verify_chunks(Ctx &C, const char *label, size_t gens_capacity, size_t P, siz
         HIPCHK(hipMemcpyAsync(d_grp, h_grp, sizeof(Grp) * ng, hipMemcpyHostToDevice, C.stream));
         uint64_t vs_proofs = 0; for (auto &g : groups) vs_proofs += g.count;
         { KSpan ks_vs(C.tm, C.stream, ROFL_TK_VERIFY_SCALARS, 0, (uint64_t)ng * 2 * N * 32 + vs_proofs * sizeof(PowTabs));
-          hipLaunchKernelGGL(k_verify_scalars, grid1(N, (u32)ng), dim3(TPB), 0, C.stream, (u32)n, (u32)m, (u32)lg, reinterpret_cast<const uint2 *>(d_grp), d_cp, (const PowTabs *)d_pt, C.d_two_pow, gh); }
+          if (vs2) hipLaunchKernelGGL(k_verify_scalars2, dim3((unsigned)(N / 512), (u32)ng), dim3(256), 0, C.stream, (u32)n, lg2u(n), (u32)m, reinterpret_cast<const uint2 *>(d_grp), d_cp, (const VTabs *)d_vt, gh);
+          else hipLaunchKernelGGL(k_verify_scalars, grid1(N, (u32)ng), dim3(TPB), 0, C.stream, (u32)n, (u32)m, (u32)lg, reinterpret_cast<const uint2 *>(d_grp), d_cp, (const PowTabs *)d_pt, C.d_two_pow, gh); }
         std::vector<MsmProb> pr(ng), prB(ng); std::vector<ge5> resA, resB;
         for (size_t g = 0; g < ng; g++) pr[g] = MsmProb{tbl, gh + g * 2 * N};
         for (size_t g = 0; g < ng; g++) prB[g] = MsmProb{aux_pts + (size_t)groups[g].start * naux, aux_scal + (size_t)groups[g].start * naux};

@@ -1732,6 +1732,76 @@ __global__ void __launch_bounds__(TPB) k_verify_scalars(u32 n, u32 m, u32 lgN, c
     store_sc(&o[N + k], sc_from_mont(hacc));
 }
 #endif
+// The same sums with the index structure taken out of the inner loop (batches of clients: 192 proofs per group at cfg 4 made the loop above
+// the verifier's largest kernel, ~13 scalar multiplications per (proof, index) at the VALU's multiply rate).  Everything that depends on
+// k only through its high digits is shared by a block:
+//   s_c(k)                  = [s1(d1) s2'(d2)] * s0(lo)                       k = 128 d + lo, d = 128 d2 + d1;  s2' carries ra
+//   -rb s_c^-1(k) y^-k      = [q1(d1) q2'(d2)] * q0(lo)                       q_l(e) = s_l(~e) yinv^(e 128^l);  q2' carries -rb
+//   rzz z^j 2^i y^-k        = [w0 w1 w2'](j) * zi(i),  k = n j + i            w = yinv^n z, zi(i) = (2 yinv)^i;  w2' carries rzz
+// A block of 256 threads covers 512 consecutive k (four values of d, 512 / n values of j); per tile of VS_TP proofs it first computes the
+// bracketed factors into LDS, then every thread does three multiplications per (proof, index) for its two indices, which share lo and i.
+struct VTabs { sc s0[PT_E], s1[PT_E], s2[PT_E], q0[PT_E], q1[PT_E], q2[PT_E], w0[PT_E], w1[PT_E], w2[PT_E], zi[64]; };     // Montgomery form
+#define VS_TP 8
+#if ROFL_KG(4)
+__global__ void __launch_bounds__(256) k_vtabs(const ChunkParams *cp, const PowTabs *pt, const sc *two_pow, VTabs *vt, u32 n, u32 lgn) {
+    const u32 c = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 9 * PT_E + 64) return;
+    const ChunkParams &P = cp[c]; const PowTabs &T = pt[c]; VTabs &V = vt[c];
+    if (t >= 9 * PT_E) { u32 i = t - 9 * PT_E; store_sc(&V.zi[i], i < n ? sc_montmul(load_sc(&two_pow[i]), load_sc(&T.yinv[0][i])) : sc_zero()); return; }
+    const u32 tab = t / PT_E, e = t % PT_E, lvl = tab % 3;
+    sc r;
+    if (tab < 3) { r = load_sc(&T.s[lvl][e]); if (lvl == 2) r = sc_montmul(r, load_sc(&P.ra)); }
+    else if (tab < 6) {
+        r = sc_montmul(load_sc(&T.s[lvl][~e & (PT_E - 1)]), load_sc(&T.yinv[lvl][e]));
+        if (lvl == 2) r = sc_montmul(r, sc_neg(load_sc(&P.rb)));
+    } else {      // w^(e 128^lvl), w = yinv^n z
+        r = sc_montmul(pt_pow(T.yinv, P.yinvpow2, e << (lgn + PT_W * lvl)), load_sc(&T.z[lvl][e]));
+        if (lvl == 2) r = sc_montmul(r, load_sc(&P.rzz));
+    }
+    sc *dst = tab == 0 ? V.s0 : tab == 1 ? V.s1 : tab == 2 ? V.s2 : tab == 3 ? V.q0 : tab == 4 ? V.q1 : tab == 5 ? V.q2 : tab == 6 ? V.w0 : tab == 7 ? V.w1 : V.w2;
+    store_sc(&dst[e], r);
+}
+__global__ void __launch_bounds__(256) k_verify_scalars2(u32 n, u32 lgn, u32 m, const uint2 *grp, const ChunkParams *cp, const VTabs *vt, sc *out) {
+    __shared__ sc sh[VS_TP][8 + 64];
+    const u32 first = grp[blockIdx.y].x, count = grp[blockIdx.y].y;
+    const size_t N = (size_t)n * m;
+    const u32 base = blockIdx.x * 512, t = threadIdx.x, lo = t & 127, half = t >> 7;
+    const u32 nj = 512 >> lgn, i = lo & (n - 1), j0 = base >> lgn;
+    u32 kk[2], js[2];
+#pragma unroll
+    for (int r = 0; r < 2; r++) { kk[r] = base + (half + 2 * r) * 128 + lo; js[r] = (kk[r] >> lgn) - j0; }
+    sc gacc[2] = {sc_zero(), sc_zero()}, hacc[2] = {sc_zero(), sc_zero()}, rzsum = sc_zero();
+    for (u32 c0 = 0; c0 < count; c0 += VS_TP) {
+        const u32 tp = min((u32)VS_TP, count - c0);
+        for (u32 task = t; task < tp * (8 + nj); task += 256) {
+            const u32 pi = task / (8 + nj), v = task % (8 + nj);
+            const VTabs &V = vt[first + c0 + pi];
+            sc r;
+            if (v < 8) { const u32 d = (base >> 7) + (v & 3); r = v < 4 ? sc_montmul(load_sc(&V.s1[d & 127]), load_sc(&V.s2[d >> 7])) : sc_montmul(load_sc(&V.q1[d & 127]), load_sc(&V.q2[d >> 7])); }
+            else { const u32 j = j0 + v - 8; r = sc_montmul(sc_montmul(load_sc(&V.w0[j & 127]), load_sc(&V.w1[(j >> 7) & 127])), load_sc(&V.w2[j >> 14])); }
+            sh[pi][v] = r;
+        }
+        __syncthreads();
+        for (u32 pi = 0; pi < tp; pi++) {
+            const VTabs &V = vt[first + c0 + pi];
+            const sc s0 = load_sc(&V.s0[lo]), q0 = load_sc(&V.q0[lo]), zi = load_sc(&V.zi[i]);
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                gacc[r] = sc_add(gacc[r], sc_montmul(sh[pi][half + 2 * r], s0));
+                hacc[r] = sc_add(hacc[r], sc_add(sc_montmul(sh[pi][4 + half + 2 * r], q0), sc_montmul(sh[pi][8 + js[r]], zi)));
+            }
+            rzsum = sc_add(rzsum, load_sc(&cp[first + c0 + pi].rz));
+        }
+        __syncthreads();
+    }
+    sc *o = out + (size_t)blockIdx.y * 2 * N;
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        store_sc(&o[kk[r]], sc_from_mont(sc_neg(sc_add(rzsum, gacc[r]))));
+        store_sc(&o[N + kk[r]], sc_from_mont(sc_add(rzsum, hacc[r])));
+    }
+}
+#endif
 #if ROFL_KG(4)
 __global__ void __launch_bounds__(TPB) k_vscalars(u32 m, const ChunkParams *cp, const PowTabs *pt, sc *out, size_t stride) {
     u32 c = blockIdx.y;

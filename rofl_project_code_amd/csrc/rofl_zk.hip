@@ -32,6 +32,7 @@
 #include "wire.hpp"
 #include "host51.hpp"
 #include "host51x8.hpp"
+#include "keccak_x8.hpp"
 
 using namespace rofl;
 
@@ -1244,6 +1245,34 @@ int rofl_dbg_host_encode8_selftest(unsigned batches, double *us_simd, double *us
     }
     if (us_simd) *us_simd = tv * 1e3 / (batches ? batches : 1);
     if (us_scalar) *us_scalar = ts * 1e3 / (batches ? batches : 1);
+    return bad;
+}
+// k8::append32_run_x8 against Merlin::append32_run: `lanes` transcripts that have absorbed the same prefix, `count` commitments each, from every
+// starting position of the rate block (`skew` extra prefix bytes shift it); the challenge drawn afterwards must agree.  0 = equal, 1 = mismatch,
+// -1 = no AVX-512.  Timings: microseconds for all lanes together.
+int rofl_dbg_host_merlin8_selftest(int lanes, unsigned count, unsigned skew, double *us_simd, double *us_scalar) {
+    if (!k8::available()) return -1;
+    if (lanes < 1 || lanes > 8 || skew > 400) return ROFL_BAD_PARAM;
+    std::vector<uint8_t> data((size_t)8 * count * 32);
+    for (size_t i = 0; i < data.size(); i++) data[i] = (uint8_t)((i * 2654435761u) >> 13);
+    std::vector<uint8_t> pre(skew, 0x5a);
+    std::vector<Merlin> a, b;
+    for (int l = 0; l < lanes; l++) { a.emplace_back("RangeProof", 10); b.emplace_back("RangeProof", 10); }
+    for (int l = 0; l < lanes; l++) { uint8_t id = (uint8_t)l; a[l].append("id", &id, 1); b[l].append("id", &id, 1); if (skew) { a[l].append("skew", pre.data(), skew); b[l].append("skew", pre.data(), skew); } }
+    double t0 = now_ms();
+    for (int l = 0; l < lanes; l++) a[l].append32_run('V', data.data() + (size_t)l * count * 32, count);
+    double t1 = now_ms();
+    Merlin *t[8]; const uint8_t *msg[8];
+    for (int l = 0; l < lanes; l++) { t[l] = &b[l]; msg[l] = data.data() + (size_t)l * count * 32; }
+    k8::append32_run_x8(t, lanes, 'V', msg, count);
+    double t2 = now_ms();
+    int bad = 0;
+    for (int l = 0; l < lanes; l++) {
+        bad |= a[l].pos != b[l].pos || a[l].pos_begin != b[l].pos_begin || a[l].cur_flags != b[l].cur_flags || memcmp(a[l].stw, b[l].stw, 200) != 0;
+        uint8_t ca[64], cb[64]; a[l].challenge_bytes("y", ca, 64); b[l].challenge_bytes("y", cb, 64); bad |= memcmp(ca, cb, 64) != 0;
+    }
+    if (us_simd) *us_simd = (t2 - t1) * 1e3;
+    if (us_scalar) *us_scalar = (t1 - t0) * 1e3;
     return bad;
 }
 // the host hops of the calling thread's last create / verify call: out[0..8] = number of MSM hops, enqueue ms, wait ms, window-combination

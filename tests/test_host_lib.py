@@ -273,3 +273,17 @@ def test_options_are_process_wide_and_checked(hiplib):
     t.start(); t.join()
     assert L.rofl_get_option(b"verify_batch", ctypes.byref(v)) == 0 and v.value == 2      # set on another thread, seen here
     assert L.rofl_set_option(b"verify_batch", 1) == 0
+
+
+def test_simd_transcripts_match_the_scalar_ones(hiplib):
+    """csrc/keccak_x8.hpp: eight Merlin transcripts per AVX-512 stream (the verifier's transcript prefixes when a batch of clients is
+    checked) against Merlin::append32_run -- every lane count, records crossing the rate block at every offset, state bytes, positions and
+    the next challenge compared.  Skipped on a CPU without AVX-512, where the library keeps the scalar sponge."""
+    L = hiplib
+    if L.rofl_dbg_host_merlin8_selftest(8, 10, 0, None, None) == -1:
+        pytest.skip("no AVX-512 on this CPU")
+    for lanes in range(1, 9):
+        assert L.rofl_dbg_host_merlin8_selftest(lanes, 257, lanes, None, None) == 0, lanes
+    assert [s for s in range(0, 170) if L.rofl_dbg_host_merlin8_selftest(8, 37, s, None, None)] == []
+    assert L.rofl_dbg_host_merlin8_selftest(8, 8192, 0, None, None) == 0
+    assert L.rofl_dbg_host_merlin8_selftest(0, 8, 0, None, None) == 11

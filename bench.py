@@ -50,7 +50,9 @@ def parse_args():
     ap.add_argument("--config", type=int, default=2, choices=(2, 4, 5),
                     help="BASELINE.json config: 2 = the headline (1 client, L-inf 32-bit, d = 25 000); 4 = 48 clients, L-inf 32-bit, d = 55 000, sharded over the ranks, "
                          "batch create -> all-gather -> every rank batch-verifies another rank's share; 5 = the same with the L2 composite (EncParamsL2)")
-    ap.add_argument("--n-partition", type=int, default=NPART, help="n_partition of configs 4 / 5 (reference bench: 4; its e2e experiments: 64)")
+    ap.add_argument("--n-partition", type=int, default=NPART, help="n_partition (reference bench: 4 -- the headline; its e2e experiments: 64)")
+    ap.add_argument("--host-cores", type=int, default=0, help="pin this rank to its first K usable cores before any GPU call (the host budget of one of 8 ranks on a node: 2, 4, 8, 16)")
+    ap.add_argument("--verify-batch", type=int, default=-1, choices=(-1, 1, 2), help="--config 4: rofl_set_option(\"verify_batch\"): 2 (default) = the rank's whole share in ONE call with one random-weighted check, 1 = one check per client, six clients per call")
     ap.add_argument("--clients", type=int, default=48, help="clients of configs 4 / 5 (cifar_large.yml: 48)")
     return ap.parse_args()
 
@@ -119,7 +121,8 @@ def cpu_baseline(sample_d, R=None):
     import orc
     vals, bl = synth_client(0)
     vals, bl = vals[:sample_d].copy(), bl[:sample_d].copy()
-    os.environ.setdefault("OMP_NUM_THREADS", str(NPART))
+    threads = max(1, min(NPART, avail_cores()))
+    os.environ.setdefault("OMP_NUM_THREADS", str(threads))
     t = time.time()
     rc, pr, cm = orc.create_rangeproof(vals, bl, NBITS, NPART, FP_BITS, FP_FRAC, seed=b"\x01" * 32)
     t1 = time.time()
@@ -132,11 +135,11 @@ def cpu_baseline(sample_d, R=None):
         parity = bool(gpr.shape == pr.shape and (gpr == pr).all() and (gcm == cm).all())
         assert parity, "HIP proofs / commitments differ from the oracle on the benchmark workload"
         assert R.range_proof_vec.verify_rangeproof(pr, cm, NBITS, verifier_seed=b"\x07" * 32, fp=FP)      # the oracle's proof through the HIP verifier
-    return {"value": sample_d / dt, "unit": "elements/s", "cores": NPART, "kind": "port", "parity_checked": parity,
+    return {"value": sample_d / dt, "unit": "elements/s", "cores": threads, "kind": "port", "parity_checked": parity,
             "parity_note": "HIP create_rangeproof on the same (values, blindings, nonce seed): all %d proofs (%d bytes each) and %d commitments bit-identical to the oracle's; "
                            "the oracle's proofs accepted by the HIP verifier" % (pr.shape[0], pr.shape[1], cm.shape[0]) if parity else None,
             "sample": f"oracle (plain-C restatement) create+verify of d={sample_d} of the workload's {D} elements, 32-bit, P={NPART}: "
-                      f"create {t1 - t:.1f} s + verify {dt - (t1 - t):.1f} s on {NPART} host threads (one per chunk, as the reference's rayon par_iter)",
+                      f"create {t1 - t:.1f} s + verify {dt - (t1 - t):.1f} s on {threads} host threads (one per chunk up to the cores of the box, as the reference's rayon par_iter)",
             "reference_probe": probe}
 
 
@@ -200,31 +203,132 @@ def synth_multi(cfg, client, step):
     return vals, r1, r2
 
 
+def roofline_of(ktot, peak_mul, n_units, elapsed_per_unit):
+    """The bench line's `kernels` / `roofline` / `valu_roofline` blocks from an accumulated rofl_last_kernel_times table (HIP events on the
+    library's streams): the dominant kernel = the kind with the largest accumulated device time; achieved = its algorithmic bytes (32 B per
+    scalar or point touched) / its average launch duration; traffic from the newest committed PMC pass when it names that kernel."""
+    import glob
+    table = []
+    for name, e in sorted(ktot.items(), key=lambda kv: -kv[1]["ms"]):
+        if not e["launches"]:
+            continue
+        sec = e["ms"] * 1e-3
+        table.append({"kernel": name, "ms_per_unit": e["ms"] / n_units, "launches_per_unit": e["launches"] / n_units, "avg_launch_ms": e["ms"] / e["launches"],
+                      "algorithmic_GBps": e["bytes"] / sec / 1e9, "hbm_frac": e["bytes"] / sec / 1e9 / HBM_PEAK_GBPS,
+                      "achieved_fe_mul_per_s": e["fe_muls"] / sec if e["fe_muls"] else None,
+                      "fe_mul_frac_of_peak": (e["fe_muls"] / sec / peak_mul) if (e["fe_muls"] and peak_mul) else None})
+    if not table:
+        return {}, None, None
+    dom = table[0]
+    traffic, pmc_src = None, None
+    try:
+        pj = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))[-1]
+        pmc_src = os.path.basename(pj)
+        key = dom["kernel"].split("+")[0].split(" ")[0].replace("k_msm_reduce_level", "k_msm_reduce")
+        ents = [v for k, v in json.load(open(pj)).items() if ("rofl::" + key) in k]
+        nl = sum(e["launches"] for e in ents)
+        if nl:
+            traffic = sum(e["launches"] * (2.0 * e["fetch_kb_per_launch"] + e["write_kb_per_launch"]) for e in ents) * 1024.0 / nl
+    except Exception:      # noqa: BLE001
+        traffic = None
+    e = ktot[dom["kernel"]]
+    launch_s = dom["avg_launch_ms"] * 1e-3
+    roof = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["algorithmic_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": dom["hbm_frac"],
+            "traffic": traffic, "avg_launch_ms": dom["avg_launch_ms"], "algorithmic_bytes_per_launch": e["bytes"] / e["launches"],
+            "traffic_frac": (traffic / launch_s / 1e9 / HBM_PEAK_GBPS) if traffic else None, "pmc_source": pmc_src,
+            "launch_time_source": "HIP events on the library's streams around every launch of this kernel, in one fully instrumented round after the timed steps (one call after the other)",
+            "note": "255-bit modular arithmetic on the VALU: `frac` prices the algorithmic bytes against HBM as north_star asks; valu_roofline is the binding figure"}
+    all_muls = sum(v["fe_muls"] for v in ktot.values())
+    valu = {"fe_mul_per_s_peak_measured": peak_mul, "kernel": dom["kernel"], "achieved_fe_mul_per_s": dom["achieved_fe_mul_per_s"], "frac": dom["fe_mul_frac_of_peak"],
+            "end_to_end_fe_muls_per_unit": all_muls / n_units,
+            "end_to_end_frac": (all_muls / n_units / elapsed_per_unit / peak_mul) if (peak_mul and elapsed_per_unit) else None}
+    return {"fe_mul_per_s_peak_measured": peak_mul, "top": table[:8]}, roof, valu
+
+
+def cpu_baseline_multi(cfg, R, P):
+    """CPU baseline beside the cfg 4 / cfg 5 lines: the oracle on a bounded sample of ONE client of the workload, then the HIP path on the same
+    inputs, byte for byte (parity_checked).  cfg 4: create + verify of d_s = 16 384 of the client's 55 000 values; cfg 5: the L2 composite
+    (8-bit range proof + sum proof + square proofs, params.rs:608-646) of d_s = 4 096 values."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc
+    from rofl_project_code_amd import params
+    threads = max(1, min(P, avail_cores()))
+    os.environ.setdefault("OMP_NUM_THREADS", str(threads))
+    vals, r1, r2 = synth_multi(cfg, 0, 0)
+    if cfg == 4:
+        ds = 16384
+        v, b = vals[:ds].copy(), r1[:ds].copy()
+        t0 = time.time(); rc, pr, cm = orc.create_rangeproof(v, b, NBITS, P, FP_BITS, FP_FRAC, seed=b"\x01" * 32); t1 = time.time()
+        rc2, ok = orc.verify_rangeproof(pr, cm, NBITS, FP_BITS, FP_FRAC); t2 = time.time()
+        assert rc == 0 and rc2 == 0 and ok
+        gpr, gcm = R.range_proof_vec.create_rangeproof(v, b, NBITS, P, nonce=R.Nonce.seeded(b"\x01" * 32), fp=FP)
+        parity = bool((gpr == pr).all() and (gcm == cm).all()) and R.range_proof_vec.verify_rangeproof(pr, cm, NBITS, verifier_seed=b"\x07" * 32, fp=FP)
+        what = "oracle create+verify of d=%d of one client's %d values, 32-bit, P=%d: create %.1f s + verify %.1f s" % (ds, D_MULTI, P, t1 - t0, t2 - t1)
+    else:
+        ds = 4096
+        v, b, b2 = vals[:ds].copy(), r1[:ds].copy(), r2[:ds].copy()
+        seed = b"\x01" * 32
+        wd = params.witness_digest(v, b, b2)
+        sub = lambda tag: params._sub_nonce(seed, tag, wd).seed
+        t0 = time.time()
+        rc, opr, ocm = orc.create_rangeproof(v, b, 8, P, FP_BITS, FP_FRAC, seed=sub(b"range"))
+        rc1, ol2, ol2c = orc.create_rangeproof_l2(v, b2, 32, P, FP_BITS, FP_FRAC, seed=sub(b"l2"))
+        rc2, osq, osqc = orc.sigma_create(1, v, b, b2, FP_BITS, FP_FRAC, seed=sub(b"sq"), existing=ocm)
+        t1 = time.time()
+        assert rc == 0 and rc1 == 0 and rc2 == 0
+        okv = orc.sigma_verify(1, osq, osqc) == (0, True) and orc.verify_rangeproof(opr, ocm, 8, FP_BITS, FP_FRAC) == (0, True) and orc.verify_rangeproof_l2(ol2, ol2c, 32, FP_BITS, FP_FRAC) == (0, True)
+        t2 = time.time()
+        assert okv
+        upd = params.EncParamsL2.encrypt(v, b, 8, P, 32, nonce_seed=seed, rand_scalars=b2, fp=FP)
+        parity = bool((upd.range_proofs == opr).all() and (upd.square_range_proof == ol2).all() and (upd.square_proofs == osq).all() and (upd.enc_values == osqc).all()) and upd.verify(verifier_seed=b"\x07" * 32, fp=FP)
+        what = "oracle L2 composite (8-bit range proof + L2 sum proof + square proofs) of d=%d of one client's %d values, P=%d: create %.1f s + verify %.1f s" % (ds, D_MULTI, P, t1 - t0, t2 - t1)
+    assert parity, "HIP output differs from the oracle on the benchmark workload"
+    return {"value": ds / (t2 - t0), "unit": "elements/s", "cores": threads, "kind": "port", "parity_checked": parity, "sample": what + " on %d host threads" % threads}
+
+
 def run_multi_client(args, R, rd, dist, cdev, world, rank, backend):
     """BASELINE configs 4 / 5: `--clients` (48) seeded clients of d = 55 000 sharded round-robin over the ranks (dist.shard_clients;
     the server hands one client per pool task, server.rs:656-687).  One step = one round of the protocol:
       every rank creates the proofs of ITS clients (cfg 4: rofl_create_rangeproof_batch in groups of 6, --multi-inflight (3) such calls in
       flight on host threads; cfg 5: EncParamsL2.encrypt + serialize, params.rs:608-663, --multi-inflight (4) clients in flight) -> ONE all-gather of [proof bytes | commitments] (cfg 5: the wire messages) -> every rank verifies
-      the share of ANOTHER rank (rank + 1; cfg 4: rofl_verify_rangeproof_batch, cfg 5: deserialize + verify) -> MIN all-reduce of the
+      the share of ANOTHER rank (rank + 1; cfg 4: ONE rofl_verify_rangeproof_batch call with verify_batch = 2 -- one random-weighted check for
+      the whole share, BASELINE cfg 4 as worded; cfg 5: deserialize + verify) -> MIN all-reduce of the
       verdicts (one failing client fails the round, server.rs:474-484).
     value = clients * d * K / wall time: the total work is fixed, so N > 1 is STRONG scaling."""
+    import resource
+    import threading
     import numpy as np
     import torch
-    from rofl_project_code_amd import params
+    from rofl_project_code_amd import api, params
     cfg, NC, P = args.config, args.clients, args.n_partition
     assert NC % world == 0, "--clients must be a multiple of the number of ranks (equal payloads per rank)"
     rpv = R.range_proof_vec
     mine = rd.shard_clients(NC, rank, world)
     src = (rank + 1) % world
     group = 6
+    vbatch = (2 if args.verify_batch < 0 else args.verify_batch) if cfg == 4 else 1
+    R.set_option("verify_batch", vbatch)
     total_steps = args.warmup + args.steps
     phase = {"create": 0.0, "exchange": 0.0, "verify": 0.0, "payload": 0}
+    ktot = {k: {"ms": 0.0, "launches": 0, "fe_muls": 0, "bytes": 0} for k in api.KERNEL_KINDS}
+    klock = threading.Lock()
+    collect = {"on": False}
+
+    def grab():      # the calling thread's last instrumented call (rofl_last_kernel_times is per thread)
+        if not collect["on"]:
+            return
+        kt = R.last_kernel_times()
+        with klock:
+            for name, e in kt.items():
+                for f in e:
+                    ktot[name][f] += e[f]
     cpool = None
     if args.multi_inflight > 1:
         from concurrent.futures import ThreadPoolExecutor
         cpool = ThreadPoolExecutor(max_workers=args.multi_inflight, thread_name_prefix="bench-client")
 
-    def step(s, record):
+    def step(s, record, cpool=cpool):      # cpool=None: one call after the other (the instrumented round: event intervals without queueing)
         t0 = time.perf_counter()
         ins = [synth_multi(cfg, c, s) for c in mine]
         t_in = time.perf_counter()
@@ -233,6 +337,7 @@ def run_multi_client(args, R, rd, dist, cdev, world, rank, backend):
                 g = list(range(g0, min(g0 + group, len(mine))))
                 res = rpv.create_rangeproof_batch([ins[k][0] for k in g], [ins[k][1] for k in g], NBITS, P,
                                                   nonces=[R.Nonce.seeded(bytes([(mine[k] + 1) % 256]) * 32) for k in g], fp=FP)
+                grab()
                 for r_ in res:
                     assert not isinstance(r_, Exception), r_
                 return res
@@ -255,10 +360,14 @@ def run_multi_client(args, R, rd, dist, cdev, world, rank, backend):
         n_their = len(rd.shard_clients(NC, src, world))
         if cfg == 4:
             pp = theirs[0].reshape((n_their,) + payloads[0].shape[1:]); cc = theirs[1].reshape((n_their,) + payloads[1].shape[1:])
-            check_group = lambda g0: rpv.verify_rangeproof_batch([pp[k] for k in range(g0, min(g0 + group, n_their))], [cc[k] for k in range(g0, min(g0 + group, n_their))],
-                                                                 NBITS, verifier_seed=bytes([s % 256]) * 32, fp=FP)
-            vstarts = list(range(0, n_their, group))
-            oks = [o for res in (cpool.map(check_group, vstarts) if cpool else map(check_group, vstarts)) for o in res]
+            vgroup = n_their if vbatch == 2 else group      # verify_batch = 2: the whole share in one call, one check
+            def check_group(g0):
+                r_ = rpv.verify_rangeproof_batch([pp[k] for k in range(g0, min(g0 + vgroup, n_their))], [cc[k] for k in range(g0, min(g0 + vgroup, n_their))],
+                                                 NBITS, verifier_seed=bytes([s % 256]) * 32, fp=FP)
+                grab()
+                return r_
+            vstarts = list(range(0, n_their, vgroup))
+            oks = [o for res in (cpool.map(check_group, vstarts) if (cpool and len(vstarts) > 1) else map(check_group, vstarts)) for o in res]
             ok = all(oks)
         else:
             bb = theirs[0].reshape(n_their, -1)
@@ -277,7 +386,6 @@ def run_multi_client(args, R, rd, dist, cdev, world, rank, backend):
             dist.barrier(); torch.cuda.synchronize()
 
     # cold figures: tables of this config's (n, m) built once per process, then the first round
-    from rofl_project_code_amd import api
     m_chunk = rpv.next_pow2(D_MULTI) // P
     cold_sets = [(NBITS, m_chunk)] if cfg == 4 else [(8, m_chunk), (32, 1)]
     t_c0 = time.perf_counter()
@@ -289,11 +397,14 @@ def run_multi_client(args, R, rd, dist, cdev, world, rank, backend):
         step(s, False)
     sync()
     gen_s = 0.0
+    ru0 = resource.getrusage(resource.RUSAGE_SELF)
     t0 = time.perf_counter()
     for s in range(args.warmup, total_steps):
         gen_s += step(s, True)
     sync()
-    elapsed = time.perf_counter() - t0 - gen_s      # drawing the synthetic inputs (numpy RNG on the host) is not part of the path
+    wall = time.perf_counter() - t0
+    ru1 = resource.getrusage(resource.RUSAGE_SELF)
+    elapsed = wall - gen_s      # drawing the synthetic inputs (numpy RNG on the host) is not part of the path
     rccl_world = 1
     if world > 1:
         te = torch.tensor([elapsed], dtype=torch.float64, device=cdev); dist.all_reduce(te, op=dist.ReduceOp.MAX); elapsed = float(te.item())
@@ -302,6 +413,9 @@ def run_multi_client(args, R, rd, dist, cdev, world, rank, backend):
     if rank == 0:
         K = args.steps
         kind = "L-inf 32-bit range proofs" if cfg == 4 else "L2 composite (EncParamsL2: 8-bit range proof + L2 sum proof + square proofs)"
+        # the numpy RNG of the synthetic inputs runs on this process's cores too: its CPU time is taken out like its wall time (single thread)
+        cpu_busy = ((ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime) - gen_s) / max(elapsed, 1e-9)
+        cd = phase["create"] / K; vd = phase["verify"] / K
         out = {"metric": "range-proof elements/sec (create+verify), %d clients d=55k" % NC, "value": NC * D_MULTI * K / elapsed, "unit": "elements/s",
                "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "strong",
                "vs_baseline": None, "dtype": "u32x8 (255-bit integer field)", "data": "synthetic", "rccl_world_size": rccl_world,
@@ -309,13 +423,31 @@ def run_multi_client(args, R, rd, dist, cdev, world, rank, backend):
                "config": {"workload": "BASELINE cfg %d: %s, d=55000 (resnet18_intrinsic_55k), %d clients sharded over %d rank(s): batch create -> one all-gather of "
                                       "proof bytes + commitments -> every rank batch-verifies the share of rank+1 -> MIN all-reduce of the verdicts" % (cfg, kind, NC, world),
                           "d": D_MULTI, "clients": NC, "clients_per_rank": len(mine), "prove_range": NBITS if cfg == 4 else 8, "l2_range": None if cfg == 4 else 32,
-                          "n_partition": P, "fp_bits": FP_BITS, "fp_frac": FP_FRAC, "host_cores": avail_cores(),
-                          "clients_in_flight_per_rank": (args.multi_inflight if cfg == 5 else ("%d batched calls of 6 clients" % args.multi_inflight if cpool else "one batched call of 6 clients at a time"))},
+                          "n_partition": P, "fp_bits": FP_BITS, "fp_frac": FP_FRAC, "host_cores": avail_cores(), "host_cores_pinned": args.host_cores or None,
+                          "host_cores_busy": round(cpu_busy, 2), "lanes": R.get_option("lanes"), "verify_batch": vbatch if cfg == 4 else None,
+                          "clients_in_flight_per_rank": (args.multi_inflight if cfg == 5 else ("create: %d batched calls of 6 clients in flight; verify: %s" % (args.multi_inflight if cpool else 1, "ONE call for the rank's whole share, one random-weighted check (verify_batch = 2)" if vbatch == 2 else "batched calls of 6 clients, one check per client")))},
                "breakdown_ms_per_step_rank0": {k: phase[k] / K * 1e3 for k in ("create", "exchange", "verify")},
+               "create_only_elements_per_s": len(mine) * D_MULTI / cd if cd else None,
+               "verify_only_elements_per_s": len(mine) * D_MULTI / vd if vd else None,
                "all_gather_bytes_per_rank": int(phase["payload"]),
                "cold": {"gens_tables_build_ms": gens_build_ms, "first_round_ms": first_round_ms,
                         "tables_bytes": {"%dx%d" % (nb_, m_): int(api.bp_gens_table_bytes(nb_, m_)) for nb_, m_ in cold_sets},
                         "note": "rank 0, once per process: generator + window + fold tables of this config's (n_bits, m), then the first round (sigma-proof tables, workspaces)"}}
+        if world == 1 and not args.no_extras:
+            # one fully instrumented round after the timed steps: the per-kernel table of THIS workload, its dominant kernel against the rooflines
+            try:
+                peak_mul = R.bench_femul(400)
+            except Exception:      # noqa: BLE001
+                peak_mul = None
+            R.set_timing(1); collect["on"] = True
+            step(total_steps, False, cpool=None)
+            collect["on"] = False; R.set_timing(0)
+            kern, roof, valu = roofline_of(ktot, peak_mul, len(mine), elapsed / K / len(mine))
+            if roof:
+                out["kernels"] = dict(kern, note="per client, from one fully instrumented round after the timed steps%s" % ("" if cfg == 4 else " (range-proof and Sigma-proof kernels; the composite's three proofs run on three lanes)"))
+                out["roofline"] = roof; out["valu_roofline"] = valu
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline_multi(cfg, R, P)
         print(json.dumps(out)); sys.stdout.flush()
     if world > 1:
         dist.barrier(); dist.destroy_process_group()
@@ -357,6 +489,10 @@ def run_rank(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.host_cores > 0 and hasattr(os, "sched_setaffinity"):      # before torch / HIP / the library start any thread
+        cores = sorted(os.sched_getaffinity(0)); k = args.host_cores
+        mine_ = cores[local_rank * k:(local_rank + 1) * k]              # ranks of one node take disjoint slices while they last
+        os.sched_setaffinity(0, set(mine_ if len(mine_) == k else cores[:k]))
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     extras = rank == 0 and world == 1 and not args.no_extras
     CIF = args.clients_in_flight if args.clients_in_flight > 0 else max(1, min(6, int(avail_cores() / (2.5 * local_world))))
@@ -371,13 +507,13 @@ def run_rank(args):
     if args.config == 4:
         # cfg 4: the clients of a rank go through rofl_create_rangeproof_batch / rofl_verify_rangeproof_batch six at a time, `multi_inflight` such
         # calls in flight on separate lanes (host threads): the latency-bound tail of one call overlaps the throughput-bound phases of another
-        os.environ.setdefault("ROFL_LANES", str(max(3, args.multi_inflight)))
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(4, args.multi_inflight + 2)))
+        os.environ.setdefault("ROFL_LANES", str(min(16, max(3, args.multi_inflight))))
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(4, min(16, args.multi_inflight) + 2)))
     if args.config == 5:
         # cfg 5: a client's L2 update is three proofs on three lanes; `multi_inflight` clients are in flight at a time (the reference's server
         # verifies its clients from a rayon pool, server.rs:656-687; its clients prove on their own machines)
-        os.environ.setdefault("ROFL_LANES", str(3 * max(1, args.multi_inflight)))
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(4, 3 * max(1, args.multi_inflight) + 2)))
+        os.environ.setdefault("ROFL_LANES", str(min(16, 3 * max(1, args.multi_inflight))))      # the library takes 1..16 (and clamps beyond)
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(4, min(16, 3 * max(1, args.multi_inflight)) + 2)))
     if extras:
         os.environ.setdefault("ROFL_LANES", str(max(3, CIF)))
         # one hardware queue per lane: the HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES (default 4) queues, read
@@ -517,13 +653,13 @@ def run_rank(args):
     step_sorted = sorted(step_ms)
     median_ms = step_sorted[len(step_sorted) // 2] if len(step_sorted) % 2 else 0.5 * (step_sorted[len(step_sorted) // 2 - 1] + step_sorted[len(step_sorted) // 2])
     out = {
-        "metric": "range-proof elements/sec (create+verify), d=25k 32-bit", "value": value, "unit": "elements/s",
+        "metric": "range-proof elements/sec (create+verify), d=25k 32-bit" + ("" if NPART == 4 else ", n_partition=%d" % NPART), "value": value, "unit": "elements/s",
         "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": elapsed / K * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32x8 (255-bit integer field)", "data": "synthetic",
         "rccl_world_size": rccl_world, "collective_backend": backend if world > 1 else None,
         "config": {"workload": "BASELINE cfg 2: L-inf 32-bit range proof, d=25000 (resnet18_intrinsic_25k), 1 client create+verify per step per GPU, inputs handed over as host buffers (H2D inside the timed region)",
                    "d": D, "prove_range": NBITS, "n_partition": NPART, "fp_bits": FP_BITS, "fp_frac": FP_FRAC, "clients_per_step_per_gpu": 1,
-                   "host_cores": avail_cores(), "host_cores_busy": round(cpu_busy, 2), "wait_policy": "sleep" if os.environ.get("ROFL_BLOCKING_SYNC") == "1" else "spin",
+                   "host_cores": avail_cores(), "host_cores_pinned": args.host_cores or None, "host_cores_busy": round(cpu_busy, 2), "lanes": R.get_option("lanes"), "wait_policy": "sleep" if os.environ.get("ROFL_BLOCKING_SYNC") == "1" else "spin",
                    "protocol": "warm-up steps, then K timed steps back to back; value = N*K*d / wall time of the K steps (max over ranks); median_ms_per_step = the reference bench's statistic (benches/rangeproof_bench.rs:53-85)"},
         "median_ms_per_step": median_ms, "min_ms_per_step": step_sorted[0], "max_ms_per_step": step_sorted[-1], "step_ms": [round(x, 2) for x in step_ms],
         "elements_per_s_at_median": D / (median_ms * 1e-3),
@@ -674,7 +810,9 @@ def run_rank(args):
 
 
 def main():
+    global NPART
     args = parse_args()
+    NPART = args.n_partition
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch_ranks(args)
         return

@@ -42,6 +42,13 @@ for mode in MODES:
         t = time.perf_counter(); round_(r + 2); ts.append((time.perf_counter() - t) * 1e3)
     ts.sort()
     out["verify_batch=%d" % vb] = {"ms_per_round_median": ts[len(ts) // 2], "ms_min": ts[0], "verify_only_elements_per_s": NC * D / (ts[len(ts) // 2] * 1e-3), "calls_per_round": (NC + grp - 1) // grp}
+    if os.environ.get("KTIMES", "1") == "1":      # one fully instrumented round: HIP events around every instrumented launch
+        R.set_timing(1)
+        oks = rpv.verify_rangeproof_batch(proofs[:grp], commits[:grp], NB, verifier_seed=b"\x55" * 32, fp=FP)
+        kt = R.last_kernel_times(); tm = R.last_timing()
+        R.set_timing(0)
+        out["verify_batch=%d" % vb]["kernels_ms_one_call_of_%d_clients" % grp] = {k: round(v["ms"], 3) for k, v in kt.items() if v["launches"]}
+        out["verify_batch=%d" % vb]["device_span_ms"] = round(tm["total_ms"], 3); out["verify_batch=%d" % vb]["host_ms"] = round(tm["host_ms"], 3)
     if vb == 2 and os.environ.get("TAMPER", "1") == "1":      # the closer look: one bad client among NC
         bad = [p.copy() for p in proofs]; bad[NC // 3][1, 70] ^= 1
         t = time.perf_counter()

@@ -727,7 +727,7 @@ def run_rank(args):
                            "layout_min_frac": (layout_min / launch_s / 1e9 / HBM_PEAK_GBPS) if layout_min else None,
                            "pmc_source": pmc_src, "launch_time_source": "HIP events on the library's stream around every launch of this kernel in the K timed steps" if live else "instrumented steps",
                            "counter_correction": "FETCH_SIZE and WRITE_SIZE in KiB from separate rocprofv3 --pmc passes; traffic = 2 x FETCH_SIZE + WRITE_SIZE "
-                                                 "(the gfx950 read counter reports half of the fetched bytes, MI355X_MICROARCH.md), per launch, averaged over the launches of the command",
+                                                 "(the gfx950 read counter reports half of the fetched bytes, MI355X_MICROARCH.md; confirmed for THIS kernel's access pattern -- one 128-byte record per lane, random -- by profiles/r04_pmc_calibration.json: 2.00 bytes gathered per counted byte from a 1 GB table), per launch, averaged over the launches of the command",
                            "note": "Two memory figures: `frac` prices the ALGORITHMIC bytes (32 B per scalar or point touched, SURVEY 8(d)); `traffic_frac` is what the "
                                    "kernel really pulls from HBM per the PMC passes and `layout_min_frac` the least this table layout can move (one 128-byte window-table "
                                    "record per (term, window) pair).  The accumulation is co-bound: random 128-byte gathers at traffic_frac of the HBM peak and the "

@@ -79,6 +79,9 @@ __device__ __forceinline__ nd gload_nd(const niels *p) { return nd_unpack(gload_
 // Window-table entry of the fixed-base MSM: the affine niels triple already in the register radix (3 x 10 limbs + 2 words
 // of padding = 128 B, one cache line per gather; the 96-byte packed form straddles two 64-byte sectors just the same and
 // costs 66 VALU instructions per addition to unpack).
+#ifndef ROFL_ACC_LIST_CHUNK
+#define ROFL_ACC_LIST_CHUNK 0
+#endif
 struct ndm { u32 v[32]; };
 __device__ __forceinline__ nd gload_ndm(const ndm *p) {
     v4u w[8];
@@ -1267,6 +1270,39 @@ template <bool FB> __device__ __forceinline__ void msm_accumulate_body(u32 n, u3
     //  forcing 5 waves/SIMD -- 96 VGPRs, 136 B/lane of scratch -- takes 1.65x as long)
     // the list entry of the NEXT addition is fetched one iteration ahead (one register): the entry -> point gather chain is two
     // dependent memory latencies per addition otherwise
+#if ROFL_ACC_LIST_CHUNK
+    // The 64 lanes of a wave stream 64 different lists; with 16 waves per CU that is 128 KB of live list lines against a 32 KB L1 and this
+    // CU's share of L2, and a 128-byte line read four bytes at a time is evicted between two of its 32 reads about every other time
+    // (PMC, profiles/r04_experiments.txt: 5.8 GB per launch against the 3.8 GB that the table records and list entries amount to; the gather
+    // micro-benchmark, which has no lists, fetches exactly its 128 bytes per record).  This variant takes the entries two (ROFL_ACC_LIST_CHUNK
+    // = 2) or four (= 4) at a time from the aligned chunk that holds them (a chunk may start before the list and end after it: both lie inside
+    // the sort's own arrays) and requests the next chunk when the last entry of the current one has been taken, one addition ahead.
+    // MEASURED: four at a time 5.79 -> 4.99 GB per launch and 1.225 -> 1.312 ms (the selects and the branch cost more than the re-fetches);
+    // not the default.
+    const uintptr_t la = reinterpret_cast<uintptr_t>(lst);
+#if ROFL_ACC_LIST_CHUNK == 2
+    const uint2 *ch = reinterpret_cast<const uint2 *>(la & ~(uintptr_t)7);
+    u32 k = (u32)(la >> 2) & 1u;
+    uint2 cur = num ? *ch : make_uint2(0, 0);
+    for (u32 e = 0; e < num; e++) {
+        const u32 v = k ? cur.y : cur.x;
+        if (k) { if (e + 1 < num) cur = *++ch; }
+        k ^= 1u;
+        u32 idx = v & idx_mask;
+        acc = gd_madd(acc, FB ? gload_ndm(reinterpret_cast<const ndm *>(pts) + idx) : gload_nd(&pts[idx]), (v >> 31) != 0);
+    }
+#else
+    const uint4 *ch = reinterpret_cast<const uint4 *>(la & ~(uintptr_t)15);
+    u32 k = (u32)(la >> 2) & 3u;
+    uint4 cur = num ? *ch : make_uint4(0, 0, 0, 0);
+    for (u32 e = 0; e < num; e++) {
+        const u32 v = k == 0 ? cur.x : k == 1 ? cur.y : k == 2 ? cur.z : cur.w;
+        if (k == 3) { if (e + 1 < num) cur = *++ch; k = 0; } else k++;
+        u32 idx = v & idx_mask;
+        acc = gd_madd(acc, FB ? gload_ndm(reinterpret_cast<const ndm *>(pts) + idx) : gload_nd(&pts[idx]), (v >> 31) != 0);
+    }
+#endif
+#else
     u32 vnext = num ? lst[0] : 0u;
     for (u32 e = 0; e < num; e++) {
         u32 v = vnext;
@@ -1274,6 +1310,7 @@ template <bool FB> __device__ __forceinline__ void msm_accumulate_body(u32 n, u3
         u32 idx = v & idx_mask;
         acc = gd_madd(acc, FB ? gload_ndm(reinterpret_cast<const ndm *>(pts) + idx) : gload_nd(&pts[idx]), (v >> 31) != 0);
     }
+#endif
     store_gd(&buckets[bi], acc);
 }
 #if ROFL_KG(1)

@@ -136,8 +136,16 @@ MsmJob msm_enqueue(Ctx &C, MsmWs &W, const std::vector<MsmProb> &probs, size_t n
     MsmWin mw{P.c, P.W, P.wide};
     // results and flags go from the kernels straight into mapped host memory (no D2H copies on the hop); with many problems the
     // Horner chains run on the device and only one point per problem comes back
-    J.dev_horner = !fb && np >= C.msm_dev_horner_min && P.W <= 64;
+    // The window chains of a launch (253 doublings per problem) run (a) on the host pool, two half chains per problem -- 16 tasks of ~31 us for
+    // the eight L / R problems of a four-chunk client, as fast as it gets with sixteen idle cores, 4x as long with four; (b) with AVX-512 IFMA,
+    // eight problems per instruction stream on ONE thread after the device has added up each window's bit-sums (k_msm_wsum): ~50 us for the
+    // hop's whole host part (chains, eight encodings, four transcripts, one batched inversion), no pool hand-off, the other cores stay asleep;
+    // (c) on the device (k_msm_horner) when there are many problems and no IFMA.  (b) from eight problems on (ROFL_MSM_HOST8_MIN): on a rank
+    // with 4 cores -- one of eight ranks of a node -- 24.2 against 25.0 ms per client and 2.5 against 2.8 busy cores; on a loaded 16-core host
+    // as fast as (a) at 2.5 against 6.6 busy cores (profiles/r04_experiments.txt item 4).
     static const bool host8_on = h8::available() && !(knob("ROFL_MSM_HOST8") && atoi(knob("ROFL_MSM_HOST8")) == 0);
+    static const size_t host8_min = knob("ROFL_MSM_HOST8_MIN") ? (size_t)std::max(1L, atol(knob("ROFL_MSM_HOST8_MIN"))) : 8;
+    J.dev_horner = !fb && P.W <= 64 && (np >= C.msm_dev_horner_min || (host8_on && np >= host8_min));
     J.host8 = J.dev_horner && host8_on;
     ge *hres_dev = W.h_res.dev<ge>(PW * (size_t)P.c + np);
     u32 *h_flag = W.h_ovf.as<u32>(4), *d_flag = W.h_ovf.dev<u32>(4);

@@ -48,6 +48,7 @@ static const Knob KNOBS[] = {
     {"ROFL_MSM_SMALL_MAX", "8192", "terms per side up to which a generic MSM runs as one fused launch (0 = off)"},
     {"ROFL_MERLIN_X8", "1", "0 = the verifier hashes every chunk's transcript prefix on its own even when the host has AVX-512 (eight chunks per instruction stream otherwise, from 32 chunks on)"},
     {"ROFL_MSM_HOST8", "1", "0 = launches with many problems combine their windows on the device (k_msm_horner) even when the host has AVX-512 IFMA"},
+    {"ROFL_MSM_HOST8_MIN", "8", "launches with at least this many problems run their window chains eight per AVX-512 IFMA stream on the host (when the CPU has it)"},
     {"ROFL_MSM_DEV_HORNER_MIN", "32", "launches with at least this many problems combine their windows on the device"},
     {"ROFL_MSM_T13", "8192", "generic MSMs from this many terms on use 13-bit windows"},
     {"ROFL_MSM_T10", "512 / 2048", "generic MSMs from this many terms on use 10-bit windows (7-bit below, 4-bit below 64); default 2048 for launches with >= 32 problems"},
@@ -177,11 +178,17 @@ int usable_cores() {
 // ---------------------------------------------------------------- small host thread pool
 // The per-round host tails (one Horner chain + transcript per chunk) are independent across chunks.
 class HostPool {
-    std::vector<std::thread> workers; std::mutex mu; std::condition_variable cv;
-    std::function<void(size_t)> fn; std::atomic<size_t> count{0}, next{0}, done{0}; std::atomic<int> active{0}; std::atomic<uint64_t> gen{0}; bool stop = false;
+    std::vector<std::thread> workers; std::mutex mu;
+    std::function<void(size_t)> fn; std::atomic<size_t> count{0}, next{0}, done{0}; std::atomic<int> active{0}; std::atomic<uint64_t> gen{0}; std::atomic<bool> stop{false};
+    std::unique_ptr<std::atomic<uint32_t>[]> asleep;      // asleep[w] == 1: worker w waits on this word (futex)
+    void wake(int w) { if (asleep[w].exchange(0, std::memory_order_seq_cst) == 1) syscall(SYS_futex, reinterpret_cast<uint32_t *>(&asleep[w]), FUTEX_WAKE_PRIVATE, 1, nullptr, nullptr, 0); }
     double spin_us = 400.0;      // ROFL_POOL_SPIN_US: how long an idle worker polls for the next job before it sleeps
     std::atomic<uint64_t> hint_seq{0}; std::atomic<double> gap_us{0.0};      // expect_gap(): the caller's estimate of its coming wait for the device
     const std::atomic<int> *calls_in_flight = nullptr;      // polling is for a call that is alone on the device: with several in flight the pools of the lanes would fight over the cores
+    // Only as many workers poll as recent jobs had tasks for (the "hot" set: worker w polls while w < hot); the others sleep on their own
+    // futex words and are woken one by one when a job has a task for them.  A four-chunk client never has more than eight tasks in a job -- sixteen pollers burnt
+    // 6.5 cores for a proof that keeps three busy.
+    std::atomic<int> hot{0}; int recent_max = 0, recent_runs = 0;
     // An index is claimed only after it has been checked against `count` (compare-and-swap, not fetch-add): a worker that wakes
     // late and arrives while run() is resetting the job (count == 0 in that window) must not consume an index of the next job --
     // with a blind fetch-add it could take index 0 between `next = 0` and `count = n` and drop it, and run() would wait forever.
@@ -202,10 +209,10 @@ class HostPool {
     // A worker that has just finished a job polls for the next one for a short while before it sleeps: the hops of a proof follow each
     // other at 0.1-0.3 ms, and a sleeping thread has to be put back on a CPU by the scheduler first -- on a busy host (the GPU boxes run
     // at a load average above 20) that wake-up is where multi-millisecond outliers of a 25 ms proof came from.
-    void loop() {
+    void loop(int my_index) {
         uint64_t seen = 0, my_hint = 0;
         for (;;) {
-            if (spin_us > 0 && (!calls_in_flight || calls_in_flight->load(std::memory_order_relaxed) <= 1)) {
+            if (spin_us > 0 && my_index < hot.load(std::memory_order_relaxed) && (!calls_in_flight || calls_in_flight->load(std::memory_order_relaxed) <= 1)) {
                 auto t0 = std::chrono::steady_clock::now();
                 uint64_t g;
                 while ((g = gen.load(std::memory_order_acquire)) == seen) {
@@ -231,7 +238,15 @@ class HostPool {
                 // (a hint is for the wait it was announced before: one that arrived while this thread was busy or asleep is over by now)
                 if (g != seen) { seen = g; my_hint = hint_seq.load(std::memory_order_acquire); work(); continue; }
             }
-            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return stop || gen.load() != seen; }); if (stop) return; seen = gen.load(); }
+            // sleep on this worker's own futex word: run() wakes exactly the workers its job has tasks for (w < n), nobody else
+            for (;;) {
+                asleep[my_index].store(1, std::memory_order_seq_cst);
+                if (stop.load(std::memory_order_seq_cst) || gen.load(std::memory_order_seq_cst) != seen) { asleep[my_index].store(0, std::memory_order_relaxed); break; }
+                syscall(SYS_futex, reinterpret_cast<uint32_t *>(&asleep[my_index]), FUTEX_WAIT_PRIVATE, 1u, nullptr, nullptr, 0);
+                if (asleep[my_index].load(std::memory_order_acquire) == 0) break;      // woken for a job (or for stop); spurious wake-ups go round again
+            }
+            if (stop.load()) return;
+            seen = gen.load(std::memory_order_acquire);
             my_hint = hint_seq.load(std::memory_order_acquire);
             work();
         }
@@ -248,17 +263,25 @@ public:
     explicit HostPool(int nthreads, const std::atomic<int> *in_flight = nullptr) : calls_in_flight(in_flight) {
         if (const char *e = knob("ROFL_POOL_SPIN_US")) spin_us = atof(e);
         if (const char *e = knob("ROFL_POOL_NAP")) nap = atoi(e) != 0;
-        for (int i = 1; i < nthreads; i++) workers.emplace_back([this] { loop(); });
+        asleep.reset(new std::atomic<uint32_t>[nthreads > 0 ? nthreads : 1]);
+        for (int i = 0; i < nthreads; i++) asleep[i].store(0);
+        for (int i = 1; i < nthreads; i++) workers.emplace_back([this, i] { loop(i); });
     }
-    ~HostPool() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); for (auto &t : workers) t.join(); }
+    ~HostPool() { stop.store(true, std::memory_order_seq_cst); for (size_t w = 1; w <= workers.size(); w++) wake((int)w); for (auto &t : workers) t.join(); }
     // called right before the caller starts a wait it expects to last `us` microseconds (0 = unknown): polling workers nap through it
     void expect_gap(double us) { if (!nap) return; gap_us.store(us, std::memory_order_relaxed); hint_seq.fetch_add(1, std::memory_order_release); }
     bool nap = true;      // ROFL_POOL_NAP=0: workers only poll / sleep on the condition variable, as before
     void run(size_t n, std::function<void(size_t)> f) {
         if (n <= 1 || workers.empty()) { for (size_t i = 0; i < n; i++) f(i); return; }
         spin_until([&] { return active.load() == 0; });     // no straggler of the previous job may still look at fn
-        { std::lock_guard<std::mutex> lk(mu); count = 0; fn = std::move(f); done = 0; next = 0; first_error = nullptr; count = n; gen++; }
-        cv.notify_all();
+        {   // the hot set follows the largest job of the last 64 (the caller is executor 0: a job of n tasks wants n - 1 workers)
+            int want = (int)std::min<size_t>(n, workers.size() + 1);
+            recent_max = std::max(recent_max, want);
+            if (want > hot.load(std::memory_order_relaxed)) hot.store(want, std::memory_order_relaxed);
+            if (++recent_runs >= 64) { hot.store(recent_max, std::memory_order_relaxed); recent_max = 0; recent_runs = 0; }
+        }
+        { std::lock_guard<std::mutex> lk(mu); count = 0; fn = std::move(f); done = 0; next = 0; first_error = nullptr; count = n; gen.fetch_add(1, std::memory_order_seq_cst); }
+        for (size_t w = 1; w < n && w <= workers.size(); w++) wake((int)w);      // (polling and napping workers have asleep == 0: one atomic exchange each)
         work();
         spin_until([&] { return done.load() >= n; });
         if (first_error) { std::exception_ptr e; { std::lock_guard<std::mutex> lk(err_mu); e = first_error; first_error = nullptr; } std::rethrow_exception(e); }

@@ -9,6 +9,9 @@
 #include <chrono>
 #include <time.h>
 #include <sched.h>
+#include <unistd.h>
+#include <sys/syscall.h>
+#include <linux/futex.h>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>

@@ -1,9 +1,16 @@
-"""Golden vectors for the wire codec, produced by the protobuf runtime (google.protobuf) from a descriptor
-built to match rofl_service/proto/roflservice/flservice.proto:75-100 field for field.  prost's encode_length_delimited =
-varint(len) + the canonical proto3 encoding, which is what SerializeToString emits (fields in number order, defaults
-omitted).  Run here: python tests/golden/gen_wire_fixtures.py  ->  tests/golden/wire.json"""
-import json, os, random
+"""Golden vectors for the wire codec, produced by the protobuf runtime (google.protobuf) from THE REFERENCE'S OWN
+schema object: the message classes of /root/reference/rofl_train_client/trainservice/flservice_pb2.py (protoc output of
+rofl_service/proto/roflservice/flservice.proto, :75-100 for these three messages), imported in the build container -- the
+reference does not travel, only the vectors do.  (Its generated code predates protobuf 3.20, so it is imported under the
+pure-Python implementation.)  The descriptor typed out below is kept as a cross-check: it must equal the reference's field for
+field, and it is the fallback when the reference checkout is not there (the GPU boxes).
+prost's encode_length_delimited = varint(len) + the canonical proto3 encoding, which is what SerializeToString emits (fields in
+number order, defaults omitted).  Run here: python tests/golden/gen_wire_fixtures.py  ->  tests/golden/wire.json"""
+import json, os, random, sys
+os.environ.setdefault("PROTOCOL_BUFFERS_PYTHON_IMPLEMENTATION", "python")
 from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+
+REF_PB2_DIR = "/root/reference/rofl_train_client/trainservice"
 
 T = descriptor_pb2.FieldDescriptorProto
 SCHEMA = {      # message -> [(name, number, type, repeated)]
@@ -17,14 +24,52 @@ SCHEMA = {      # message -> [(name, number, type, repeated)]
 }
 
 
+REF_PROTO = "/root/reference/rofl_service/proto/roflservice/flservice.proto"
+
+
+def check_schema_against_proto():
+    """SCHEMA against the text of the reference's .proto (when the checkout is there): every field's name, number, type, repeated."""
+    if not os.path.isfile(REF_PROTO):
+        return False
+    import re
+    txt = open(REF_PROTO).read()
+    types = {"bytes": T.TYPE_BYTES, "int32": T.TYPE_INT32, "float": T.TYPE_FLOAT}
+    for mname, fields in SCHEMA.items():
+        body = re.search(r"message\s+%s\s*\{(.*?)\}" % mname, txt, re.S).group(1)
+        got = [(m.group(3), int(m.group(4)), types[m.group(2)], bool(m.group(1))) for m in re.finditer(r"(repeated\s+)?(\w+)\s+(\w+)\s*=\s*(\d+)\s*;", body)]
+        assert got == [tuple(x) for x in fields], (mname, got)
+    return True
+
+
+def reference_classes():
+    """The reference's generated classes for the messages its Python client knows (its flservice_pb2.py predates EncNormDataCompressed),
+    {} when the checkout is absent.  Their descriptors must match SCHEMA."""
+    if not os.path.isfile(os.path.join(REF_PB2_DIR, "flservice_pb2.py")):
+        return {}
+    sys.path.insert(0, REF_PB2_DIR)
+    import flservice_pb2 as pb
+    out = {}
+    for mname, fields in SCHEMA.items():
+        cls_ = getattr(pb, mname, None)
+        if cls_ is None:
+            continue
+        got = [(f.name, f.number, f.type, bool(f.is_repeated) if hasattr(f, "is_repeated") else f.label == 3) for f in cls_.DESCRIPTOR.fields]
+        assert got == [tuple(x) for x in fields], (mname, got)
+        out[mname] = cls_
+    return out
+
+
 def classes():
+    ref = reference_classes()
+    check_schema_against_proto()
     fd = descriptor_pb2.FileDescriptorProto(name="flservice_wire.proto", package="roflservice", syntax="proto3")
     for mname, fields in SCHEMA.items():
         m = fd.message_type.add(name=mname)
         for name, num, typ, rep in fields:
             m.field.add(name=name, number=num, type=typ, label=T.LABEL_REPEATED if rep else T.LABEL_OPTIONAL)
     pool = descriptor_pool.DescriptorPool(); pool.Add(fd)
-    return {n: message_factory.GetMessageClass(pool.FindMessageTypeByName("roflservice." + n)) for n in SCHEMA}
+    own = {n: message_factory.GetMessageClass(pool.FindMessageTypeByName("roflservice." + n)) for n in SCHEMA}
+    return {n: ref.get(n, own[n]) for n in SCHEMA}
 
 
 def varint(n):
@@ -60,7 +105,8 @@ def main():
         vec.append({"message": name, "fields": {k: ([x.hex() for x in v] if isinstance(v, list) else (v.hex() if isinstance(v, bytes) else v)) for k, v in kw.items()},
                     "encoded": length_delimited(m).hex()})
     json.dump(vec, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "wire.json"), "w"), indent=0)
-    print("wrote", len(vec), "vectors")
+    print("wrote", len(vec), "vectors; message classes from the reference's flservice_pb2:", sorted(reference_classes()) or "none (typed-out descriptor)",
+          "; SCHEMA checked against flservice.proto:", check_schema_against_proto())
 
 
 if __name__ == "__main__":

@@ -25,7 +25,10 @@ MsmPlan msm_plan(size_t n, size_t np = 1) {
 // overlap: host work to run while the kernels execute; post(p): runs on the pool thread that finished problem p's window combination,
 // right after results[p] is final (the caller's per-problem tail -- encoding, transcript -- without a second pool hand-off on the hop)
 struct MsmOpt { u32 lr_nh = 0, lr_ng = 0; const niels *fb_wtab = nullptr; size_t fb_stride = 0; u32 fb_c = 16; std::function<void()> overlap; std::function<void(size_t)> post; u32 tag = 0;      /* tag: which hop of its caller this is (0 = unknown): keys the wait-time estimate */
-                std::function<void(size_t, int)> post8; };      // post8(p0, count): the finisher of problems p0 .. p0 + count - 1 (p0 a multiple of 8) of a host8 task, instead of `count` calls of post
+                std::function<void(size_t, int)> post8;
+                // inner-product rounds: the launch may add c_side * Q to problem 2c + side itself (the fused small-MSM launch does): partial inner
+                // products [chunk][ip_nblk][2] in device memory, Q per chunk; *ip_included tells the caller's finisher whether it happened
+                const sc *ip_dev = nullptr; u32 ip_nblk = 0; const niels *qpts = nullptr; bool *ip_included = nullptr; };      // post8(p0, count): the finisher of problems p0 .. p0 + count - 1 (p0 a multiple of 8) of a host8 task, instead of `count` calls of post
 
 // An MSM goes through four stages: PLAN (which variant, window layout, bucket sets, capacities) -> SORT (digits into per-bucket lists)
 // -> ACCUMULATE (one thread per bucket) -> REDUCE (bit-sum tree; the window combination is left to the host, or to k_msm_horner when a
@@ -154,6 +157,7 @@ MsmJob msm_enqueue(Ctx &C, MsmWs &W, const std::vector<MsmProb> &probs, size_t n
     const u32 nb_final = P.c - 1;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     *h_flag = 0;
+    if (opt.ip_included) *opt.ip_included = J.kind == MsmKind::Small && opt.ip_dev && opt.qpts && lr;
     if (J.kind == MsmKind::Small) {
         ge *S_fin_s = J.dev_horner ? W.S[0].as<ge>(PW) : hres_dev;
         ge *C_fin_s = J.dev_horner ? W.Cacc[0].as<ge>(PW * (size_t)nb_final) : hres_dev + PW;
@@ -165,7 +169,8 @@ MsmJob msm_enqueue(Ctx &C, MsmWs &W, const std::vector<MsmProb> &probs, size_t n
         unsigned long long *tl_dev = nullptr;
         if (small_tl) { HIPCHK(hipMalloc(&tl_dev, PW * 32)); HIPCHK(hipMemsetAsync(tl_dev, 0, PW * 32, st)); }
         hipLaunchKernelGGL(k_msm_small, dim3((unsigned)PW), dim3(P.B < 64 ? 64 : P.B), std::max(lds_lists, lds_red), st, n_side, mw, mm, d_probs, buckets,
-                           S_fin_s, C_fin_s, nb_final, d_flag, small_cap, tl_dev);
+                           S_fin_s, C_fin_s, nb_final, d_flag, small_cap, tl_dev, J.host8 ? hres_dev : (ge *)nullptr,
+                           lr ? opt.ip_dev : (const sc *)nullptr, opt.ip_nblk, lr ? opt.qpts : (const niels *)nullptr);
         if (small_tl) {      // mean phase durations over the blocks of this launch (100 MHz clock)
             std::vector<unsigned long long> hts(PW * 4);
             HIPCHK(hipMemcpyAsync(hts.data(), tl_dev, PW * 32, hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st)); HIPCHK(hipFree(tl_dev));
@@ -174,7 +179,7 @@ MsmJob msm_enqueue(Ctx &C, MsmWs &W, const std::vector<MsmProb> &probs, size_t n
             fprintf(stderr, "[rofl] k_msm_small PW=%zu n_side=%u c=%u: rank %.1f us, bucket sums %.1f us, reduce %.1f us (block means); first start -> last end %.1f us\n",
                     PW, n_side, P.c, ph[0] / PW * 0.01, ph[1] / PW * 0.01, ph[2] / PW * 0.01, (double)(t_hi - t_lo) * 0.01);
         }
-        if (J.host8) hipLaunchKernelGGL(k_msm_wsum, grid1(PW * 4), dim3(TPB), 0, st, (u32)PW, (const ge *)S_fin_s, (const ge *)C_fin_s, nb_final, hres_dev);
+        if (J.host8) {}      // (the launch added up each window's bit-sums itself)
         else if (J.dev_horner) hipLaunchKernelGGL(k_msm_horner, dim3((unsigned)np), dim3(256), 0, st, mw, (const ge *)S_fin_s, (const ge *)C_fin_s, nb_final, hres_dev);
         return J;
     }

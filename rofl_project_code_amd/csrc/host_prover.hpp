@@ -173,6 +173,16 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
     bool just_materialised = false, ab_on_host = false;
     sc *ptab[2] = {C.ptab[0].as<sc>(P * 2 * N), C.ptab[1].as<sc>(P * 2 * N)}; int psel = 0;      // pending-challenge product tables (ping-pong)
     std::unique_ptr<std::atomic<int>[]> lr_done(new std::atomic<int>[P]);
+    // Q = w B per chunk (upstream's InnerProductProof takes Q): the fused small-MSM launches of the later rounds add <a_L, b_R> Q and
+    // <a_R, b_L> Q on the device; the other launches leave that term to the host finisher (a fixed-base multiplication per problem)
+    sc *ip_dev = C.ipdev.as<sc>(P * 256 * 2);
+    niels *d_q = C.qpts.as<niels>(P);
+    {
+        niels *h_q = C.h_q.as<niels>(P);
+        C.pool->run(P, [&](size_t c) { h_q[c] = h51::to_niels32(h_fixed_mul(C.ht.B5, w[c])); });
+        HIPCHK(hipMemcpyAsync(d_q, h_q, sizeof(niels) * P, hipMemcpyHostToDevice, C.stream));
+    }
+    bool ip_included = false;
     for (unsigned round = 0; round < lgN; round++) {
         size_t n_k = n_g >> r, nh = n_k / 2;
         sc *SL = C.SL.as<sc>(P * 2 * n_g), *SR = C.SR.as<sc>(P * 2 * n_g);
@@ -185,7 +195,7 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
             int use_new = just_materialised ? 0 : 1;
             hipLaunchKernelGGL(k_ipp_round, dim3(nblkI, (u32)P), dim3(TPB), 0, C.stream, (u32)n_g, (u32)n_k, use_new ? r - 1 : 0u, use_new, d_cp,
                                (const sc *)C.h_round.dev<sc>(2 * P), (const sc *)a, (const sc *)b, a2, b2, N, yinvpow, N, SL, C.h_ip.dev<sc>(P * 256 * 2),
-                               (const sc *)ptab[psel], ptab[psel ^ 1], N, n_k == 2 ? C.h_abfin.dev<sc>(4 * P) : (sc *)nullptr);
+                               (const sc *)ptab[psel], ptab[psel ^ 1], N, n_k == 2 ? C.h_abfin.dev<sc>(4 * P) : (sc *)nullptr, ip_dev);
             if (n_k == 2) ab_on_host = true;
             std::swap(a, a2); std::swap(b, b2); psel ^= 1;
         } else {
@@ -200,6 +210,7 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
         MsmOpt mo;
         if (merged) { mo.lr_nh = (u32)nh; mo.lr_ng = (u32)n_g; }
         mo.tag = 100 + round;
+        if (fused) { mo.ip_dev = ip_dev; mo.ip_nblk = nblkI; mo.qpts = d_q; mo.ip_included = &ip_included; }
         if (first_level && wtab) { gens.fb_for(2 * P, &mo.fb_wtab, &mo.fb_c); mo.fb_stride = 2 * N; }
         // The host tail of the round runs inside the MSM's own pool tasks: the thread that finishes problem 2c (+1) adds c_L w B (c_R w B)
         // and encodes L (R); the second of a chunk's two to get there hashes both into the transcript, draws u and inverts it.  L and R
@@ -208,8 +219,11 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
         mo.post = [&](size_t p) {
             size_t c = p >> 1; int side = (int)(p & 1);
             uint8_t *o = proofs_out[c] + 7 * 32 + 64 * round;
-            sc cx = h_canon(sum_partials(h_ip + c * nblkI * 2, nblkI, 2, (size_t)side));
-            h51::encode(o + 32 * side, h51::gadd(res[p], h_fixed_mul(C.ht.B5, h_mul(cx, w[c]))));
+            if (ip_included) h51::encode(o + 32 * side, res[p]);
+            else {
+                sc cx = h_canon(sum_partials(h_ip + c * nblkI * 2, nblkI, 2, (size_t)side));
+                h51::encode(o + 32 * side, h51::gadd(res[p], h_fixed_mul(C.ht.B5, h_mul(cx, w[c]))));
+            }
             if (lr_done[c].fetch_add(1) != 1) return;          // the chunk's other point is still on its way
             tr[c].append("L", o, 32); tr[c].append("R", o + 32, 32);
             sc u = tr[c].challenge_scalar("u");
@@ -226,6 +240,7 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
             for (int l = 0; l < 8; l++) {
                 if (l >= cnt) { pts[l] = h51::identity(); continue; }
                 size_t p = p0 + (size_t)l, c = p >> 1;
+                if (ip_included) { pts[l] = res[p]; continue; }
                 sc cx = h_canon(sum_partials(h_ip + c * nblkI * 2, nblkI, 2, p & 1));
                 pts[l] = h51::gadd(res[p], h_fixed_mul(C.ht.B5, h_mul(cx, w[c])));
             }

@@ -632,7 +632,7 @@ __global__ void __launch_bounds__(TPB) k_ipp_fold_ab(u32 nh, ChunkParams *cp, co
 #if ROFL_KG(4)
 __global__ void __launch_bounds__(TPB) k_ipp_round(u32 n_g, u32 n_k, u32 r_prev, int use_new, ChunkParams *cp, const sc *round_ch, const sc *a_in, const sc *b_in,
                                                    sc *a_out, sc *b_out, size_t ab_stride, const sc *yinvpow, size_t y_stride, sc *SL, sc *ip_out,
-                                                   const sc *ptab_in, sc *ptab_out, size_t ptab_stride, sc *ab_host) {
+                                                   const sc *ptab_in, sc *ptab_out, size_t ptab_stride, sc *ab_host, sc *ip_dev) {
     __shared__ sc lds[TPB * 2];
     __shared__ sc s_u[2];
     u32 c = blockIdx.y;
@@ -680,6 +680,10 @@ __global__ void __launch_bounds__(TPB) k_ipp_round(u32 n_g, u32 n_k, u32 r_prev,
     if (threadIdx.x == 0) {
         store_sc(&ip_out[((size_t)c * gridDim.x + blockIdx.x) * 2 + 0], v[0]);
         store_sc(&ip_out[((size_t)c * gridDim.x + blockIdx.x) * 2 + 1], v[1]);
+        if (ip_dev) {      // the same partial sums where the round's MSM launch can read them without crossing PCIe (k_msm_small adds c_L w B itself)
+            store_sc(&ip_dev[((size_t)c * gridDim.x + blockIdx.x) * 2 + 0], v[0]);
+            store_sc(&ip_dev[((size_t)c * gridDim.x + blockIdx.x) * 2 + 1], v[1]);
+        }
     }
 }
 #endif
@@ -1546,7 +1550,8 @@ __device__ __forceinline__ void msm_reduce_binary_body(u32 E, const ge *si_g, ge
 #define MSM_SMALL_CAP_MAX 80  /* upper bound of the run-time `cap` (72 at n_side <= 16 B: mean load <= 32, P(overflow) ~ 1e-12) */
 #if ROFL_KG(1)
 __global__ void __launch_bounds__(512) k_msm_small(u32 n_side, MsmWin mw, MsmMap mm, const MsmProb *probs, ge *buckets, ge *S_fin, ge *C_fin,
-                                                   u32 nb_final, u32 *overflow, u32 cap, unsigned long long *dbg) {
+                                                   u32 nb_final, u32 *overflow, u32 cap, unsigned long long *dbg, ge *wsum_out,
+                                                   const sc *ip_dev, u32 ip_nblk, const niels *qpts) {
     extern __shared__ __align__(16) unsigned char smem[];
     // debugging aid (ROFL_DBG_SMALL_TIMELINE): 100 MHz wall-clock stamps of the block's phases -- start, ranked, buckets summed, reduced
     auto stamp = [&](int k) { if (dbg && threadIdx.x == 0) dbg[(size_t)blockIdx.x * 4 + k] = wall_clock64(); };
@@ -1572,9 +1577,29 @@ __global__ void __launch_bounds__(512) k_msm_small(u32 n_side, MsmWin mw, MsmMap
             else *(volatile u32 *)overflow = 1u;          // mapped host memory: a plain store (idempotent)
         }
     }
+    // One more term for the L / R problems of an inner-product round: c_side * Q with Q = w B (upstream's <a_L, b_R> Q) -- c_side is the sum of
+    // the partial inner products the round's k_ipp_round launch left in device memory, Q the chunk's point.  The host added this term with a
+    // fixed-base multiplication per problem on every hop (6 us each; eight of them in a row where one thread finishes eight problems).
+    const u32 QIDX = 0x7fffffffu;
+    if (ip_dev && threadIdx.x == 0) {
+        sc acc = sc_zero();
+        for (u32 b = 0; b < ip_nblk; b++) acc = sc_add(acc, load_sc(&ip_dev[((size_t)(p >> 1) * ip_nblk + b) * 2 + (p & 1u)]));
+        sc cs = sc_from_mont(acc);
+        int d = msm_digit_mem(reinterpret_cast<const u32 *>(&cs), wpos, wwid);
+        u32 ad = (u32)(d < 0 ? -d : d), entry = QIDX | (d < 0 ? 0x80000000u : 0u);
+        for (int rep = 0; rep < 2; rep++) {
+            u32 a1 = rep == 0 ? (ad > B ? B : 0u) : (ad > B ? ad - B : ad);
+            if (!a1) continue;
+            u32 pos = atomicAdd(&lcnt[a1 - 1], 1u);
+            if (pos < cap) lst[(a1 - 1) * cap + pos] = entry;
+            else *(volatile u32 *)overflow = 1u;
+        }
+    }
     __syncthreads();
     stamp(1);
     const niels *pts = probs[p].pts;
+    const niels *qpt = qpts ? qpts + (p >> 1) : pts;
+    auto fetch = [&](u32 v) { const u32 i = v & 0x7fffffffu; return gload_nd(i == QIDX ? qpt : &pts[i]); };
     // Balance the bucket sums over the block's waves (blockDim == B = 512: 8 waves, two per SIMD).  A wave runs as long as its fullest
     // bucket (mean 4 entries, ~10 in every wave of 64 unsorted buckets); with the buckets sorted by load, wave w < 4 takes the w-th
     // heaviest group of 64 and its SIMD partner w + 4 the (7 - w)-th: every SIMD sees ~11 additions' worth of issue instead of ~20.
@@ -1601,10 +1626,10 @@ __global__ void __launch_bounds__(512) k_msm_small(u32 n_side, MsmWin mw, MsmMap
         // the next point is in flight while the current one is added (the block runs at 2 waves/SIMD: registers are not the limit here,
         // the gather latency in front of every addition was)
         u32 v = num ? lst[b * cap] : 0u;
-        nd nxt = gload_nd(&pts[v & 0x7fffffffu]);
+        nd nxt = fetch(v);
         for (u32 e = 0; e < num; e++) {
             nd q = nxt; bool ng = (v >> 31) != 0;
-            if (e + 1 < num) { v = lst[b * cap + e + 1]; nxt = gload_nd(&pts[v & 0x7fffffffu]); }
+            if (e + 1 < num) { v = lst[b * cap + e + 1]; nxt = fetch(v); }
             acc = gd_madd(acc, q, ng);
         }
         store_gd(&buckets[(size_t)pw * B + b], acc);
@@ -1615,6 +1640,22 @@ __global__ void __launch_bounds__(512) k_msm_small(u32 n_side, MsmWin mw, MsmMap
     if (B >= 16) msm_reduce_binary_body(B, buckets + (size_t)pw * B, S_fin + pw, C_fin + (size_t)pw * nb_final, smem);
     else msm_reduce_fused_body(B, 0, buckets + (size_t)pw * B, nullptr, S_fin + pw, C_fin + (size_t)pw * nb_final, smem);
     stamp(3);
+    // launches whose window chains go to the host eight per SIMD stream (k_msm_wsum's job, without a launch of its own): one quad adds up
+    // this window's bit-sums, W = S + sum_l 2^l D_l, and hands the host ONE point per (problem, window)
+    if (wsum_out) {
+        __threadfence_block();
+        __syncthreads();
+        if (threadIdx.x < 4) {
+            const u32 q = threadIdx.x;
+            auto coord = [&](const ge *pt) { gq r; r.v = fd_unpack(reinterpret_cast<const fe *>(pt)[q]); return r; };
+            const ge *cf = C_fin + (size_t)pw * nb_final;
+            gq acc = coord(&cf[nb_final - 1]);
+#pragma unroll 1
+            for (int l = (int)nb_final - 2; l >= 0; l--) acc = gq_add(gq_double(acc, q), coord(&cf[l]), q);
+            acc = gq_add(acc, coord(&S_fin[pw]), q);
+            reinterpret_cast<fe *>(&wsum_out[pw])[q] = fd_pack(acc.v);
+        }
+    }
 }
 #endif
 

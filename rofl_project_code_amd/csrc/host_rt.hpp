@@ -514,7 +514,7 @@ struct Ctx {
     // workspace
     DevBuf cp, sL, sR, party, Scanon, vshift, blind, Vbytes, Cbytes, status, partial, partial2, scpart, a, b, a2, b2, ptab[2], yinv,
         SL, SR, powtabs, foldprobs, naf,
-        gbuf[2], aux_pts, aux_scal, vscal, tmp_in, tmp_in2, tmp_out, vals, uni, stream_buf, vgroups, vtabs, ipdev, qpts;
+        gbuf[2], aux_pts, aux_scal, vscal, tmp_in, tmp_in2, tmp_out, vals, uni, stream_buf, vgroups, vtabs, ipdev, qpts, vspart;
     PinBuf h_cp, h_part, h_misc, h_misc2, h_auxc, h_auxs, h_V, h_ip, h_round, h_fdig, h_fprob, h_abfin, h_vgrp, h_q;
     MsmWs mws[2];
     std::map<uint64_t, double> wait_ms;      // how long the wait of a tagged hop took the last times (hint for the pool workers' naps)

@@ -229,7 +229,14 @@ int verify_chunks(Ctx &C, const char *label, size_t gens_capacity, size_t P, siz
         HIPCHK(hipMemcpyAsync(d_grp, h_grp, sizeof(Grp) * ng, hipMemcpyHostToDevice, C.stream));
         uint64_t vs_proofs = 0; for (auto &g : groups) vs_proofs += g.count;
         { KSpan ks_vs(C.tm, C.stream, ROFL_TK_VERIFY_SCALARS, 0, (uint64_t)ng * 2 * N * 32 + vs_proofs * sizeof(PowTabs));
-          if (vs2) hipLaunchKernelGGL(k_verify_scalars2, dim3((unsigned)(N / 512), (u32)ng), dim3(256), 0, C.stream, (u32)n, lg2u(n), (u32)m, reinterpret_cast<const uint2 *>(d_grp), d_cp, (const VTabs *)d_vt, gh);
+          if (vs2) {
+              // enough blocks for the chip: a group's proofs are split into slices when N / 512 x groups is small
+              size_t nsl = std::min<size_t>(maxc, std::max<size_t>(1, 1024 / ((N / 512) * ng)));
+              const u32 per = (u32)((maxc + nsl - 1) / nsl); nsl = (maxc + per - 1) / per;
+              sc *dst = nsl > 1 ? C.vspart.as<sc>(ng * nsl * 2 * N) : gh;
+              hipLaunchKernelGGL(k_verify_scalars2, dim3((unsigned)(N / 512), (u32)ng, (u32)nsl), dim3(256), 0, C.stream, (u32)n, lg2u(n), (u32)m, reinterpret_cast<const uint2 *>(d_grp), d_cp, (const VTabs *)d_vt, dst, per);
+              if (nsl > 1) hipLaunchKernelGGL(k_vs_sum, grid1(2 * N, (u32)ng), dim3(TPB), 0, C.stream, (u32)(2 * N), (u32)nsl, (const sc *)dst, gh);
+          }
           else hipLaunchKernelGGL(k_verify_scalars, grid1(N, (u32)ng), dim3(TPB), 0, C.stream, (u32)n, (u32)m, (u32)lg, reinterpret_cast<const uint2 *>(d_grp), d_cp, (const PowTabs *)d_pt, C.d_two_pow, gh); }
         std::vector<MsmProb> pr(ng), prB(ng); std::vector<ge5> resA, resB;
         for (size_t g = 0; g < ng; g++) pr[g] = MsmProb{tbl, gh + g * 2 * N};

@@ -1839,9 +1839,12 @@ __global__ void __launch_bounds__(256) k_vtabs(const ChunkParams *cp, const PowT
     sc *dst = tab == 0 ? V.s0 : tab == 1 ? V.s1 : tab == 2 ? V.s2 : tab == 3 ? V.q0 : tab == 4 ? V.q1 : tab == 5 ? V.q2 : tab == 6 ? V.w0 : tab == 7 ? V.w1 : V.w2;
     store_sc(&dst[e], r);
 }
-__global__ void __launch_bounds__(256) k_verify_scalars2(u32 n, u32 lgn, u32 m, const uint2 *grp, const ChunkParams *cp, const VTabs *vt, sc *out) {
+// blockIdx.z = slice of the group's proofs (few blocks otherwise: one client with n_partition = 64 has N / 512 = 32): slice z takes `per`
+// consecutive proofs and writes its partial sums to out + (group * gridDim.z + z) * 2N; k_vs_sum adds the slices up.
+__global__ void __launch_bounds__(256) k_verify_scalars2(u32 n, u32 lgn, u32 m, const uint2 *grp, const ChunkParams *cp, const VTabs *vt, sc *out, u32 per) {
     __shared__ sc sh[VS_TP][8 + 64];
-    const u32 first = grp[blockIdx.y].x, count = grp[blockIdx.y].y;
+    u32 first = grp[blockIdx.y].x, count = grp[blockIdx.y].y;
+    { const u32 lo = min(count, blockIdx.z * per), hi = min(count, lo + per); first += lo; count = hi - lo; }
     const size_t N = (size_t)n * m;
     const u32 base = blockIdx.x * 512, t = threadIdx.x, lo = t & 127, half = t >> 7;
     const u32 nj = 512 >> lgn, i = lo & (n - 1), j0 = base >> lgn;
@@ -1872,12 +1875,20 @@ __global__ void __launch_bounds__(256) k_verify_scalars2(u32 n, u32 lgn, u32 m, 
         }
         __syncthreads();
     }
-    sc *o = out + (size_t)blockIdx.y * 2 * N;
+    sc *o = out + ((size_t)blockIdx.y * gridDim.z + blockIdx.z) * 2 * N;
 #pragma unroll
     for (int r = 0; r < 2; r++) {
         store_sc(&o[kk[r]], sc_from_mont(sc_neg(sc_add(rzsum, gacc[r]))));
         store_sc(&o[N + kk[r]], sc_from_mont(sc_add(rzsum, hacc[r])));
     }
+}
+// out[g][k] = sum_z part[g][z][k] (canonical scalars), k < len
+__global__ void __launch_bounds__(TPB) k_vs_sum(u32 len, u32 nsl, const sc *part, sc *out) {
+    const u32 k = blockIdx.x * blockDim.x + threadIdx.x, g = blockIdx.y;
+    if (k >= len) return;
+    sc acc = load_sc(&part[(size_t)g * nsl * len + k]);
+    for (u32 z = 1; z < nsl; z++) acc = sc_add(acc, load_sc(&part[((size_t)g * nsl + z) * len + k]));
+    store_sc(&out[(size_t)g * len + k], acc);
 }
 #endif
 #if ROFL_KG(4)

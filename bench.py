@@ -51,6 +51,7 @@ def parse_args():
                     help="BASELINE.json config: 2 = the headline (1 client, L-inf 32-bit, d = 25 000); 4 = 48 clients, L-inf 32-bit, d = 55 000, sharded over the ranks, "
                          "batch create -> all-gather -> every rank batch-verifies another rank's share; 5 = the same with the L2 composite (EncParamsL2)")
     ap.add_argument("--n-partition", type=int, default=NPART, help="n_partition (reference bench: 4 -- the headline; its e2e experiments: 64)")
+    ap.add_argument("--one-process", action="store_true", help="--config 4 with --gpus N: ONE process drives the N devices through the C ABI (rofl_set_option(\"devices\", mask): the batch entry points deal the clients to the devices from internal threads; no torch.distributed, no collective) -- the shape of the reference's server (server.rs:379-384, 656-687).  With fewer physical GPUs than N the logical devices wrap around (ROFL_DEVICE_MAP)")
     ap.add_argument("--host-cores", type=int, default=0, help="pin this rank to its first K usable cores before any GPU call (the host budget of one of 8 ranks on a node: 2, 4, 8, 16)")
     ap.add_argument("--verify-batch", type=int, default=-1, choices=(-1, 1, 2), help="--config 4: rofl_set_option(\"verify_batch\"): 2 (default) = the rank's whole share in ONE call with one random-weighted check, 1 = one check per client, six clients per call")
     ap.add_argument("--clients", type=int, default=48, help="clients of configs 4 / 5 (cifar_large.yml: 48)")
@@ -809,10 +810,83 @@ def run_rank(args):
         dist.destroy_process_group()
 
 
+def run_one_process(args):
+    """BASELINE cfg 4 as ONE host process: all `--clients` clients go through ONE rofl_create_rangeproof_batch and ONE
+    rofl_verify_rangeproof_batch call per step; the library deals them round-robin to `--gpus` devices (option "devices") and runs each
+    device's share from an internal thread (create: the share as one launch sequence per device; verify: one random-weighted check per
+    device's share, verify_batch = 2).  Results are gathered in host memory: inside one process there is no collective to run."""
+    import resource
+    import numpy as np
+    ndev = args.gpus
+    import torch
+    nphys = max(1, torch.cuda.device_count())      # (counting devices does not initialise the GPU)
+    if nphys < ndev:
+        os.environ.setdefault("ROFL_DEVICE_MAP", ",".join(str(i % nphys) for i in range(ndev)))
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    import rofl_project_code_amd as R
+    from rofl_project_code_amd import api, build
+    build.build()
+    rpv = R.range_proof_vec
+    NC, P = args.clients, args.n_partition
+    for dv in range(ndev):
+        R.set_device(dv)
+        api.bp_gens_prepare(NBITS, rpv.next_pow2(D_MULTI) // P)
+    R.set_device(0)
+    R.set_option("devices", (1 << ndev) - 1); R.set_option("verify_batch", 2)
+    phase = {"create": 0.0, "verify": 0.0}
+
+    def step(s, record):
+        t0 = time.perf_counter()
+        ins = [synth_multi(4, c, s) for c in range(NC)]
+        t_in = time.perf_counter()
+        res = []
+        grp = 6 * ndev      # six clients per device and call (the workspace of a batched create grows with its clients)
+        for g0 in range(0, NC, grp):
+            g = range(g0, min(g0 + grp, NC))
+            res += rpv.create_rangeproof_batch([ins[c][0] for c in g], [ins[c][1] for c in g], NBITS, P, nonces=[R.Nonce.seeded(bytes([(c + 1) % 256]) * 32) for c in g], fp=FP)
+        for r_ in res:
+            assert not isinstance(r_, Exception), r_
+        t1 = time.perf_counter()
+        oks = rpv.verify_rangeproof_batch([r_[0] for r_ in res], [r_[1] for r_ in res], NBITS, verifier_seed=bytes([s % 256]) * 32, fp=FP)
+        t2 = time.perf_counter()
+        assert all(oks), "a client's proofs failed to verify"
+        if record:
+            phase["create"] += t1 - t_in; phase["verify"] += t2 - t1
+        return t_in - t0
+
+    step(0, False)
+    for s in range(args.warmup):
+        step(s, False)
+    gen_s = 0.0
+    ru0 = resource.getrusage(resource.RUSAGE_SELF)
+    t0 = time.perf_counter()
+    for s in range(args.warmup, args.warmup + args.steps):
+        gen_s += step(s, True)
+    wall = time.perf_counter() - t0
+    ru1 = resource.getrusage(resource.RUSAGE_SELF)
+    elapsed = wall - gen_s
+    K = args.steps
+    print(json.dumps({"metric": "range-proof elements/sec (create+verify), %d clients d=55k, one host process" % NC, "value": NC * D_MULTI * K / elapsed, "unit": "elements/s",
+                      "n_gpus": ndev, "steps": K, "warmup": args.warmup, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                      "dtype": "u32x8 (255-bit integer field)", "data": "synthetic", "rccl_world_size": None, "collective_backend": None,
+                      "config": {"workload": "BASELINE cfg 4: L-inf 32-bit range proofs, d=55000, %d clients, ONE host process driving %d logical device(s) on %d physical GPU(s) through the C ABI "
+                                             "(rofl_set_option(\"devices\")): batched create calls of six clients per device and ONE batched verify call per step, dealt to the devices inside the library" % (NC, ndev, min(ndev, nphys)),
+                                 "d": D_MULTI, "clients": NC, "n_partition": P, "prove_range": NBITS, "fp_bits": FP_BITS, "fp_frac": FP_FRAC, "devices_mask": (1 << ndev) - 1,
+                                 "physical_gpus": min(ndev, nphys), "verify_batch": 2, "host_cores": avail_cores(),
+                                 "host_cores_busy": round(((ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime) - gen_s) / max(elapsed, 1e-9), 2)},
+                      "breakdown_ms_per_step": {k: phase[k] / K * 1e3 for k in ("create", "verify")},
+                      "create_only_elements_per_s": NC * D_MULTI * K / phase["create"], "verify_only_elements_per_s": NC * D_MULTI * K / phase["verify"]}))
+    sys.stdout.flush()
+
+
 def main():
     global NPART
     args = parse_args()
     NPART = args.n_partition
+    if args.one_process:
+        if args.config != 4:
+            sys.stderr.write("bench.py: --one-process is a mode of --config 4\n"); sys.exit(2)
+        return run_one_process(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch_ranks(args)
         return

@@ -2,7 +2,7 @@
 bench_constants.rs:10: one warm-up, 4 timed samples, median), one client at a time through the C ABI.  The first call of a shape
 is reported separately as `cold_*` (it builds the generator tables the reference recomputes on every call,
 range_proof_vec/mod.rs:126,201).  Configs 4 and 5 are 48-client jobs over 8 GPUs: one GPU's share (6 clients) is run here.
-Writes one JSON object per config to stdout / gpurun_out/r03_configs.json."""
+Writes one JSON object per config to stdout / gpurun_out/r04_configs.json."""
 import json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
@@ -34,7 +34,7 @@ def linf(name, d, nb, P, fp_bits, fp_frac, clients=1, batch_verify=False):
     cold_c = (time.perf_counter() - t) * 1e3
     t = time.perf_counter(); ok = R.range_proof_vec.verify_rangeproof(pr, cm, nb, verifier_seed=b"\x08" * 32); cold_v = (time.perf_counter() - t) * 1e3
     assert ok
-    tc, tv, tb, tcb = [], [], [], []
+    tc, tv, tb, tcb, tb2 = [], [], [], [], []
     for s in range(SAMPLES):
         prs, cms = [], []
         t0 = time.perf_counter()
@@ -49,6 +49,10 @@ def linf(name, d, nb, P, fp_bits, fp_frac, clients=1, batch_verify=False):
         if batch_verify:
             t3 = time.perf_counter(); okb = R.range_proof_vec.verify_rangeproof_batch(prs, cms, nb, verifier_seed=bytes([s]) * 32); tb.append((time.perf_counter() - t3) * 1e3 / clients)
             assert all(okb)
+            R.set_option("verify_batch", 2)      # one random-weighted check for the six clients (the server role)
+            t3 = time.perf_counter(); okb = R.range_proof_vec.verify_rangeproof_batch(prs, cms, nb, verifier_seed=bytes([s]) * 32); tb2.append((time.perf_counter() - t3) * 1e3 / clients)
+            R.set_option("verify_batch", 1)
+            assert all(okb)
             t4 = time.perf_counter()
             res = R.range_proof_vec.create_rangeproof_batch([i[0] for i in ins], [i[1] for i in ins], nb, P, nonces=[R.Nonce.seeded(bytes([s + 1, c]) * 16) for c in range(clients)])
             tcb.append((time.perf_counter() - t4) * 1e3 / clients)
@@ -60,6 +64,7 @@ def linf(name, d, nb, P, fp_bits, fp_frac, clients=1, batch_verify=False):
            "cold_create_ms": cold_c, "cold_verify_ms": cold_v, "protocol": "1 warm-up (the cold call), 4 samples, median; sequential clients"}
     if tb:
         out["batch_verify_ms_per_client"] = med(tb); out["batch_verify_elements_per_s"] = d / med(tb) * 1e3
+        out["batch_verify_one_check_ms_per_client"] = med(tb2); out["batch_verify_one_check_elements_per_s"] = d / med(tb2) * 1e3
         out["batch_create_ms_per_client"] = med(tcb); out["batch_create_plus_batch_verify_elements_per_s"] = d / (med(tcb) + med(tb)) * 1e3
     return out
 
@@ -106,7 +111,7 @@ res = [
     l2("cfg5: L2 composite, d=55000, 6 of 48 clients (one GPU's share of 8), P=4", 55000, 4, clients=6),
 ]
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-with open(os.path.join(ROOT, "gpurun_out", "r03_configs.json"), "w") as f:
+with open(os.path.join(ROOT, "gpurun_out", "r04_configs.json"), "w") as f:
     json.dump(res, f, indent=1)
 for r in res:
     print(json.dumps(r))

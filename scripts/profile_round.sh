@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run on the GPU box (via gpurun): bench line, rocprofv3 kernel stats and the two PMC passes of the same command.
 # Outputs under gpurun_out/prof_<tag>/ ; copy the summaries into profiles/.
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

@@ -109,12 +109,13 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
     });
     C.tm.t.host_ms += now_ms() - th;
     HIPCHK(hipMemcpyAsync(d_cp, h_cp, sizeof(ChunkParams) * P, hipMemcpyHostToDevice, C.stream));
-    u32 nblkT = (u32)std::min<size_t>(64, (N + TPB - 1) / TPB);
-    sc *tpart = C.tmp_out.as<sc>(P * 64 * 3);
+    // (enough blocks for four waves per SIMD when the chunks are few: 64 per chunk ran a four-chunk client's 1 M slots on 65 536 threads)
+    u32 nblkT = (u32)std::min<size_t>(std::max<size_t>(64, std::min<size_t>(256, 2048 / P)), (N + TPB - 1) / TPB);
+    sc *tpart = C.tmp_out.as<sc>(P * 256 * 3);
     hipLaunchKernelGGL(k_pow_tables, dim3((4 * PT_L * PT_E + TPB - 1) / TPB, (u32)P), dim3(TPB), 0, C.stream, d_cp, d_pt, lgN, 0);
     hipLaunchKernelGGL(k_poly_t, dim3(nblkT, (u32)P), dim3(TPB), 0, C.stream, (u32)n, (u32)m, d_cp, (const PowTabs *)d_pt, d_vshift, sL, sR, C.d_two_pow, tpart);
     hipLaunchKernelGGL(k_party_sums, dim3(nblkS, (u32)P), dim3(TPB), 0, C.stream, (u32)m, 1, d_cp, (const PowTabs *)d_pt, party, d_blind, scpart);
-    sc *h_t = C.h_part.as<sc>(P * 64 * 3);
+    sc *h_t = C.h_part.as<sc>(P * 256 * 3);
     HIPCHK(hipMemcpyAsync(h_t, tpart, sizeof(sc) * P * nblkT * 3, hipMemcpyDeviceToHost, C.stream));
     HIPCHK(hipMemcpyAsync(h_sc, scpart, sizeof(sc) * P * nblkS * 3, hipMemcpyDeviceToHost, C.stream));
     C.sync();

@@ -55,7 +55,7 @@ static const Knob KNOBS[] = {
     {"ROFL_MSM_C", "0", "window width of every generic MSM (4, 7, 10, 13, 16; 0 = by size)"},
     {"ROFL_MSM_GROUP_REDUCE", "0", "1 = two-launch bucket reduction by groups of 512 (measured slower)"},
     {"ROFL_RED_SPLIT", "0", "1 = four threads per 8-group in k_msm_reduce_level (measured slower)"},
-    {"ROFL_RED_FUSED_T", "512", "largest block of k_msm_reduce_fused"},
+    {"ROFL_RED_FUSED_T", "768", "largest block of k_msm_reduce_fused"},
     {"ROFL_ACC_BALANCE", "1", "0 = accumulate blocks in plain descending-load order instead of equal-work blocks"},
     {"ROFL_TRACE", "0", "1 = one line per MSM on stderr, 2 = per-phase host timeline of every proof / verification"},
     {"ROFL_DBG_IDX_MASK", "0x7fffffff", "timing experiments only (WRONG results): confines the table gathers to a prefix"},

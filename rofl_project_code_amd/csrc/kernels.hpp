@@ -1483,7 +1483,7 @@ __device__ __forceinline__ void msm_reduce_fused_body(u32 E, u32 nb, const ge *s
     }
 }
 #if ROFL_KG(1)
-__global__ void __launch_bounds__(512) k_msm_reduce_fused(u32 E, u32 nb, const ge *S_in, const ge *C_in, ge *S_fin, ge *C_fin, u32 nb_final) {
+__global__ void __launch_bounds__(768) k_msm_reduce_fused(u32 E, u32 nb, const ge *S_in, const ge *C_in, ge *S_fin, ge *C_fin, u32 nb_final) {
     extern __shared__ __align__(16) unsigned char smem[];
     u32 pw = blockIdx.x;
     msm_reduce_fused_body(E, nb, S_in + (size_t)pw * E, C_in + (size_t)pw * nb * E, S_fin + pw, C_fin + (size_t)pw * nb_final, smem);

@@ -150,3 +150,18 @@ def test_rccl_world_size_one_exchange():
     p.start(); p.join(600)
     assert p.exitcode == 0
     assert q.get(timeout=5) == "ok"
+
+
+def test_bench_config4_one_process_two_devices():
+    """BASELINE cfg 4 in the shape of the reference's server: ONE host process, the clients of a round dealt to two logical devices inside
+    the library (rofl_set_option("devices", 0b11); both logical devices are GPU 0 on the one-GPU box), one batched verify call with
+    verify_batch = 2.  bench.py asserts every verdict.  Four clients of d = 55 000 here; 48 in a real run."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "4", "--one-process", "--gpus", "2", "--clients", "4", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["config"]["devices_mask"] == 3 and line["config"]["clients"] == 4 and line["config"]["verify_batch"] == 2
+    assert line["value"] > 0 and line["verify_only_elements_per_s"] > 0 and "one host process" in line["metric"]

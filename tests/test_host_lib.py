@@ -287,3 +287,25 @@ def test_simd_transcripts_match_the_scalar_ones(hiplib):
     assert [s for s in range(0, 170) if L.rofl_dbg_host_merlin8_selftest(8, 37, s, None, None)] == []
     assert L.rofl_dbg_host_merlin8_selftest(8, 8192, 0, None, None) == 0
     assert L.rofl_dbg_host_merlin8_selftest(0, 8, 0, None, None) == 11
+
+
+def test_sharded_batch_reports_a_device_that_cannot_be_used(hiplib):
+    """rofl_set_option("devices", mask) with devices that do not exist (logical 9 and 10; no GPU at all in the build container): the batch
+    entry points come back with the HIP error of the failing share -- no crash, no hang, the message on the CALLER's thread -- and the
+    option can be cleared again."""
+    L = hiplib
+    L.rofl_set_option.argtypes = [ctypes.c_char_p, ctypes.c_long]
+    assert L.rofl_set_option(b"devices", (1 << 9) | (1 << 10)) == 0
+    try:
+        n, d = 3, 8
+        proofs = [ctypes.create_string_buffer(4 * 480) for _ in range(n)]
+        commits = [ctypes.create_string_buffer(d * 32) for _ in range(n)]
+        pp = (ctypes.c_void_p * n)(*[ctypes.addressof(p) for p in proofs]); cp = (ctypes.c_void_p * n)(*[ctypes.addressof(c) for c in commits])
+        ok = (ctypes.c_int * n)(7, 7, 7)
+        rc = L.rofl_verify_rangeproof_batch(sz(n), pp, sz(480), sz(4), cp, sz(d), sz(8), 16, 7, bytes(32), ok)
+        assert rc >= 100, rc
+        assert list(ok) == [0, 0, 0]
+        msg = ctypes.create_string_buffer(256); L.rofl_last_error(msg, sz(256))
+        assert b"HIP" in msg.value or b"hip" in msg.value, msg.value
+    finally:
+        assert L.rofl_set_option(b"devices", 0) == 0

@@ -343,8 +343,7 @@ void msm_finish(Ctx &C, const MsmJob &J, std::vector<ge5> &results, const MsmOpt
         else for (size_t p = 0; p < np; p++) results[p] = h51::from_ge_loose(h[p]);
     } else if (J.fb()) {
         // sets of a problem carry equal weight: add them up, then one Horner over the c - 1 bit-sums
-        C.pool->run(np, [&](size_t p) {
-            double tc0 = now_ms();
+        auto fb_one = [&](size_t p) {
             size_t base = p * sets;                         // lr: problem 2q+side owns sets [(2q+side)*sets, ...)
             ge5 acc = h51::identity(); bool started = false;
             for (int l = (int)nb - 1; l >= 0; l--) {
@@ -352,7 +351,22 @@ void msm_finish(Ctx &C, const MsmJob &J, std::vector<ge5> &results, const MsmOpt
                 for (u32 s = 0; s < sets; s++) { acc = h51::gadd(acc, h51::from_ge_loose(h[PW + (base + s) * nb + l])); started = true; }
                 if (l == 0) for (u32 s = 0; s < sets; s++) acc = h51::gadd(acc, h51::from_ge_loose(h[base + s]));
             }
-            results[p] = acc; if (opt.post) opt.post(p); cpu_each[p] = now_ms() - tc0;
+            results[p] = acc;
+        };
+        if (opt.post8 && np >= 32 && h8::available()) {
+            // many problems (n_partition = 64: 128 per round): eight per task, finished together -- eight encodings per AVX-512 stream and the
+            // four challenge inversions of the task's chunks behind one inversion, as the generic launches do
+            C.pool->run((np + 7) / 8, [&](size_t b) {
+                double tc0 = now_ms();
+                size_t p0 = b * 8; int cnt = (int)std::min<size_t>(8, np - p0);
+                for (int l = 0; l < cnt; l++) fb_one(p0 + (size_t)l);
+                opt.post8(p0, cnt);
+                cpu_each[p0] = now_ms() - tc0;
+            });
+        } else
+        C.pool->run(np, [&](size_t p) {
+            double tc0 = now_ms();
+            fb_one(p); if (opt.post) opt.post(p); cpu_each[p] = now_ms() - tc0;
         });
     } else {
         // One 253-step chain per problem: sum_w 2^(pos_w) (S_w + sum_l 2^l D_(w,l)).  With few problems (the IPP rounds of a client with four

@@ -28,7 +28,8 @@ struct MsmOpt { u32 lr_nh = 0, lr_ng = 0; const niels *fb_wtab = nullptr; size_t
                 std::function<void(size_t, int)> post8;
                 // inner-product rounds: the launch may add c_side * Q to problem 2c + side itself (the fused small-MSM launch does): partial inner
                 // products [chunk][ip_nblk][2] in device memory, Q per chunk; *ip_included tells the caller's finisher whether it happened
-                const sc *ip_dev = nullptr; u32 ip_nblk = 0; const niels *qpts = nullptr; bool *ip_included = nullptr; };      // post8(p0, count): the finisher of problems p0 .. p0 + count - 1 (p0 a multiple of 8) of a host8 task, instead of `count` calls of post
+                const sc *ip_dev = nullptr; u32 ip_nblk = 0; const niels *qpts = nullptr; bool *ip_included = nullptr;
+                hipEvent_t pts_ready = nullptr; };      // the points are still being written on another stream: the first kernel that reads them waits for this      // post8(p0, count): the finisher of problems p0 .. p0 + count - 1 (p0 a multiple of 8) of a host8 task, instead of `count` calls of post
 
 // An MSM goes through four stages: PLAN (which variant, window layout, bucket sets, capacities) -> SORT (digits into per-bucket lists)
 // -> ACCUMULATE (one thread per bucket) -> REDUCE (bit-sum tree; the window combination is left to the host, or to k_msm_horner when a
@@ -168,6 +169,7 @@ MsmJob msm_enqueue(Ctx &C, MsmWs &W, const std::vector<MsmProb> &probs, size_t n
         static const bool small_tl = knob("ROFL_DBG_SMALL_TIMELINE") != nullptr;
         unsigned long long *tl_dev = nullptr;
         if (small_tl) { HIPCHK(hipMalloc(&tl_dev, PW * 32)); HIPCHK(hipMemsetAsync(tl_dev, 0, PW * 32, st)); }
+        if (opt.pts_ready) HIPCHK(hipStreamWaitEvent(st, opt.pts_ready, 0));
         hipLaunchKernelGGL(k_msm_small, dim3((unsigned)PW), dim3(P.B < 64 ? 64 : P.B), std::max(lds_lists, lds_red), st, n_side, mw, mm, d_probs, buckets,
                            S_fin_s, C_fin_s, nb_final, d_flag, small_cap, tl_dev, J.host8 ? hres_dev : (ge *)nullptr,
                            lr ? opt.ip_dev : (const sc *)nullptr, opt.ip_nblk, lr ? opt.qpts : (const niels *)nullptr);
@@ -234,6 +236,7 @@ MsmJob msm_enqueue(Ctx &C, MsmWs &W, const std::vector<MsmProb> &probs, size_t n
         } else
             hipLaunchKernelGGL(k_msm_scatter_slots, grid1(n, (u32)(nq * P.W)), dim3(TPB), 0, st, (u32)n, mw, mm, d_probs, cnt, slots, cap, ovf_count, ovf, MSM_OVF_MAX);
         hipLaunchKernelGGL(k_msm_scan, dim3((unsigned)PW), dim3(P.B >= 1024 ? 1024 : 256), 0, st, P.B, cnt, off, (u32 *)nullptr, perm);
+        if (opt.pts_ready) HIPCHK(hipStreamWaitEvent(st, opt.pts_ready, 0));      // (the sort above only read the scalars)
         if (C.tm.enabled) { e0 = C.tm.get(); e1 = C.tm.get(); HIPCHK(hipEventRecord(e0, st)); }
         {
             uint64_t acc_adds = terms * P.W;
@@ -250,6 +253,7 @@ MsmJob msm_enqueue(Ctx &C, MsmWs &W, const std::vector<MsmProb> &probs, size_t n
         hipLaunchKernelGGL(k_msm_count, grid1(n, (u32)(nq * P.W)), dim3(TPB), 0, st, (u32)n, mw, mm, d_probs, cnt);
         hipLaunchKernelGGL(k_msm_scan, dim3((unsigned)PW), dim3(P.B >= 1024 ? 1024 : 256), 0, st, P.B, cnt, off, cur, perm);
         hipLaunchKernelGGL(k_msm_scatter, grid1(n, (u32)(nq * P.W)), dim3(TPB), 0, st, (u32)n, mw, mm, d_probs, cur, sorted);
+        if (opt.pts_ready) HIPCHK(hipStreamWaitEvent(st, opt.pts_ready, 0));
         if (C.tm.enabled) { e0 = C.tm.get(); e1 = C.tm.get(); HIPCHK(hipEventRecord(e0, st)); }
         hipLaunchKernelGGL(k_msm_accumulate_gen, grid1((size_t)Wb * P.B, (u32)nq), dim3(TPB), 0, st, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, sorted, perm, buckets, 0u, dbg_mask, acc_balance);
         if (C.tm.enabled) HIPCHK(hipEventRecord(e1, st));

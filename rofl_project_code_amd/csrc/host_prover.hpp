@@ -183,7 +183,7 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
         C.pool->run(P, [&](size_t c) { h_q[c] = h51::to_niels32(h_fixed_mul(C.ht.B5, w[c])); });
         HIPCHK(hipMemcpyAsync(d_q, h_q, sizeof(niels) * P, hipMemcpyHostToDevice, C.stream));
     }
-    bool ip_included = false;
+    bool ip_included = false, pts_pending = false;
     for (unsigned round = 0; round < lgN; round++) {
         size_t n_k = n_g >> r, nh = n_k / 2;
         sc *SL = C.SL.as<sc>(P * 2 * n_g), *SR = C.SR.as<sc>(P * 2 * n_g);
@@ -211,6 +211,7 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
         MsmOpt mo;
         if (merged) { mo.lr_nh = (u32)nh; mo.lr_ng = (u32)n_g; }
         mo.tag = 100 + round;
+        if (pts_pending) { mo.pts_ready = C.ev_norm; pts_pending = false; }
         if (fused) { mo.ip_dev = ip_dev; mo.ip_nblk = nblkI; mo.qpts = d_q; mo.ip_included = &ip_included; }
         if (first_level && wtab) { gens.fb_for(2 * P, &mo.fb_wtab, &mo.fb_c); mo.fb_stride = 2 * N; }
         // The host tail of the round runs inside the MSM's own pool tasks: the thread that finishes problem 2c (+1) adds c_L w B (c_R w B)
@@ -377,9 +378,24 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
                 // (the K-1 redundant chains of a segmented launch buy latency, they are not work)
                 uint64_t fold_muls = (nz * 7 / (2 * P) + (uint64_t)(top + 1) * 8 + 7) * (uint64_t)(2 * P * n_new);
                 KSpan ks_fold(C.tm, C.stream, use_tab ? ROFL_TK_FOLD_TAB : ROFL_TK_FOLD, fold_muls, (uint64_t)2 * P * n_g * 32 + (uint64_t)2 * P * n_new * 32);
-                if (use_tab)
+                // A big first fold leaves its outputs in extended coordinates and k_niels_batch converts them, eight per inversion, on the side
+                // stream while the next round's k_ipp_round and sort kernels run; that round's first point-reading kernel waits (pts_ready).
+                static const bool defer_on = !(knob("ROFL_FOLD_DEFER") && atoi(knob("ROFL_FOLD_DEFER")) == 0);
+                const bool defer = use_tab && defer_on && 2 * P * n_new >= ((size_t)1 << 17);
+                ge *ext = defer ? C.foldext.as<ge>(2 * P * n_new) : nullptr;
+                if (use_tab) {
                     hipLaunchKernelGGL(k_fold_gens_tab, grid, block, (K - 1) * 64 * sizeof(ge), C.stream, (u32)n_new, nsrc, seg, fc, tbl, (size_t)(2 * N),
-                                       (const FoldTabProb *)d_fpv, d_dig, unit);
+                                       (const FoldTabProb *)d_fpv, d_dig, unit, ext);
+                  if (defer) {
+                    if (!C.ev_norm) { HIPCHK(hipEventCreateWithFlags(&C.ev_norm, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&C.ev_norm0, hipEventDisableTiming)); }
+                    HIPCHK(hipEventRecord(C.ev_norm0, C.stream));
+                    HIPCHK(hipStreamWaitEvent(C.stream2, C.ev_norm0, 0));
+                    const size_t tot = 2 * P * n_new;
+                    hipLaunchKernelGGL(k_niels_batch, grid1((tot + NB_BATCH - 1) / NB_BATCH), dim3(TPB), 0, C.stream2, (u32)tot, (const ge *)ext, gnew);
+                    HIPCHK(hipEventRecord(C.ev_norm, C.stream2));
+                    pts_pending = true;
+                  }
+                }
                 else if (nsrc == 4 && unit && fold_regs)      // three scalar-carrying sources, kept in registers
                     hipLaunchKernelGGL(k_fold_gens4, grid, block, (K - 1) * 64 * sizeof(ge), C.stream, (u32)n_new, seg, (const FoldProb *)d_fpv, d_dig);
                 else

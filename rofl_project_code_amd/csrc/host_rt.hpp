@@ -33,6 +33,7 @@ static const Knob KNOBS[] = {
     {"ROFL_FOLD_UNIT", "1", "0 = do not keep the common factor s_0 of a fold in gscale / hscale"},
     {"ROFL_FOLD_K", "0", "digit-position segments per fold output (1, 2, 4; 0 = by launch size)"},
     {"ROFL_FOLD_THREADS", "131072", "fold launches with fewer threads split their chains into segments"},
+    {"ROFL_FOLD_DEFER", "1", "0 = the first fold converts every output to affine form itself (one inversion per output) instead of leaving that to k_niels_batch on the side stream"},
     {"ROFL_FOLD_REGS", "1", "0 = the generic fold kernel instead of the three-sources-in-registers one"},
     {"ROFL_IPP_FUSED", "1", "0 = k_ipp_fold_ab + k_ipp_scalars + k_ipp_inner instead of one k_ipp_round per round"},
     {"ROFL_MSM_LR", "1", "0 = separate L and R scalar arrays (with zeros) instead of the merged layout"},
@@ -473,7 +474,7 @@ struct Ctx {
     // Waiting for the lane's stream.  hipStreamSynchronize spins (lowest latency: right for a call that is alone on the device); with
     // more than three calls in flight -- or when the host asked for it (ROFL_BLOCKING_SYNC=1) -- the thread sleeps between queries instead, so
     // a server that keeps several clients in flight does not burn one host core per client on busy-waiting (ROFL_BLOCKING_SYNC=0: always spin).
-    hipEvent_t ev_block = nullptr, ev_v = nullptr, ev_fork = nullptr, ev_a = nullptr, ev_a0 = nullptr, ev_m2 = nullptr, ev_m2j = nullptr; bool batch_mode = false;
+    hipEvent_t ev_block = nullptr, ev_v = nullptr, ev_fork = nullptr, ev_a = nullptr, ev_a0 = nullptr, ev_m2 = nullptr, ev_m2j = nullptr, ev_norm = nullptr, ev_norm0 = nullptr; bool batch_mode = false;
     void sync() {
         const Ctx *P = parent ? parent : this;
         // (up to three calls in flight still spin: the three proofs of ONE client's L2 update run side by side -- EncParamsL2::encrypt --
@@ -514,7 +515,7 @@ struct Ctx {
     // workspace
     DevBuf cp, sL, sR, party, Scanon, vshift, blind, Vbytes, Cbytes, status, partial, partial2, scpart, a, b, a2, b2, ptab[2], yinv,
         SL, SR, powtabs, foldprobs, naf,
-        gbuf[2], aux_pts, aux_scal, vscal, tmp_in, tmp_in2, tmp_out, vals, uni, stream_buf, vgroups, vtabs, ipdev, qpts, vspart;
+        gbuf[2], aux_pts, aux_scal, vscal, tmp_in, tmp_in2, tmp_out, vals, uni, stream_buf, vgroups, vtabs, ipdev, qpts, vspart, foldext;
     PinBuf h_cp, h_part, h_misc, h_misc2, h_auxc, h_auxs, h_V, h_ip, h_round, h_fdig, h_fprob, h_abfin, h_vgrp, h_q;
     MsmWs mws[2];
     std::map<uint64_t, double> wait_ms;      // how long the wait of a tagged hop took the last times (hint for the pool workers' naps)

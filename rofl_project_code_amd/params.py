@@ -86,11 +86,25 @@ class wire:
 _pool = None
 
 
+kernel_time_sink = None      # measurement hook (bench.py): called with api.last_kernel_times() on the thread of every proof call of a container
+
+
+def _timed(thunk):
+    def run():
+        r = thunk()
+        if kernel_time_sink is not None:
+            kernel_time_sink(api.last_kernel_times())      # rofl_last_kernel_times is per calling thread
+        return r
+    return run
+
+
 def _concurrently(*thunks):
     """Run independent proof calls on separate library lanes (each call takes a free lane: HIP stream + workspace).  The
     reference runs them one after the other, each spread over the rayon pool; on the GPU the latency-bound tails of one proof
     (a 5-round sum proof, the per-element Sigma-proof kernels) overlap the throughput-bound phases of another."""
     global _pool
+    if kernel_time_sink is not None:
+        thunks = [_timed(t) for t in thunks]
     if len(thunks) == 1:
         return [thunks[0]()]
     if _pool is None:

@@ -501,10 +501,11 @@ def run_rank(args):
         os.sched_setaffinity(0, set(mine_ if len(mine_) == k else cores[:k]))
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     extras = rank == 0 and world == 1 and not args.no_extras
-    CIF = args.clients_in_flight if args.clients_in_flight > 0 else max(1, min(6, int(avail_cores() / (2.5 * local_world))))
-    if avail_cores() / max(local_world, 1) < 2.5:
-        # a lone call spins while it waits for the GPU (lowest latency, ~2 host cores per rank with its pool threads); when the ranks of a
-        # node share fewer cores than that, wait by sleeping instead (+1 ms per client, ~0.9 cores per rank)
+    CIF = args.clients_in_flight if args.clients_in_flight > 0 else max(1, min(6, int(avail_cores() / (2.0 * local_world))))
+    if avail_cores() / max(local_world, 1) < 2.0:
+        # a lone call spins while it waits for the GPU (lowest latency; since round 4 the hop's host part runs on the calling thread, so a rank
+        # on TWO cores is as fast spinning as on sixteen: 23.9 ms at 1.9 busy cores against 25.8 ms sleeping, profiles/r04_experiments.txt item 8);
+        # only with less than two cores per rank wait by sleeping instead (~0.7 cores per rank)
         os.environ.setdefault("ROFL_BLOCKING_SYNC", "1")
     if local_world > 1:      # the library sizes its host pool from the cores of the process; ranks of one node share them
         os.environ.setdefault("ROFL_HOST_THREADS", str(max(2, min(14, int(avail_cores() / local_world) - 1))))

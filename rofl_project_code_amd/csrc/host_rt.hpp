@@ -423,6 +423,10 @@ Options &opts() {
     return o;
 }
 
+// Calls in flight in the whole process.  The pools' polling is for a call that is alone: with several in flight -- on one device or, in a
+// server that drives N devices, on several -- the pools of the lanes would fight over the host's cores.
+std::atomic<int> g_calls_in_flight{0};
+
 // One Ctx = one "lane": a HIP stream with its own workspace, staging buffers, timing and host pool.  The primary
 // lane of a device owns the shared read-only state (fixed-base tables, generator cache).  An API call runs on one
 // lane; concurrent calls from different host threads (the reference's server verifies clients from a thread pool,
@@ -567,7 +571,7 @@ struct Ctx {
             int nt = std::min(16, std::max(2, usable_cores()));
             if (const char *e = knob("ROFL_HOST_THREADS")) nt = atoi(e);
             if (nt < 1) nt = 1; if (nt > 64) nt = 64;
-            pool.reset(new HostPool(nt, &active_calls)); }
+            pool.reset(new HostPool(nt, &g_calls_in_flight)); }
         if (const char *e = knob("ROFL_FOLD_T1")) { int v = atoi(e); if (v >= 1 && v <= 6) fold_t1 = v; }
         if (const char *e = knob("ROFL_FOLD_TAB")) fold_tab = atoi(e) != 0;
         if (const char *e = knob("ROFL_GENS_BUDGET_MB")) { long v = atol(e); if (v >= 1) gens_budget = (size_t)v << 20; }
@@ -594,7 +598,7 @@ struct Ctx {
         msm_fb = p.msm_fb; msm_fb_min = p.msm_fb_min; msm_lr = p.msm_lr;
         fold_min = p.fold_min; msm_dev_horner_min = p.msm_dev_horner_min; msm_small_max = p.msm_small_max; msm_slots = p.msm_slots; fold_t = p.fold_t; fold_t1 = p.fold_t1; fold_k = p.fold_k; fold_tab = p.fold_tab;
         fold_unit = p.fold_unit; fold_threads = p.fold_threads; nlanes = 1;
-        { int nt = 6; if (const char *e = knob("ROFL_HOST_THREADS")) nt = atoi(e); if (nt < 1) nt = 1; pool.reset(new HostPool(nt, &p.active_calls)); }
+        { int nt = 6; if (const char *e = knob("ROFL_HOST_THREADS")) nt = atoi(e); if (nt < 1) nt = 1; pool.reset(new HostPool(nt, &g_calls_in_flight)); }
         inited = true;
     }
 };
@@ -648,7 +652,7 @@ struct LaneLock {
             if (c->stream2) (void)hipStreamSynchronize(c->stream2);
             c->stg.finish(std::uncaught_exceptions() == 0);
         }
-        if (primary) primary->active_calls.fetch_sub(1);
+        if (primary) { primary->active_calls.fetch_sub(1); g_calls_in_flight.fetch_sub(1); }
     }
 };
 // `side`: a call that hardly uses the host pool (one-value sum proofs, the per-element Sigma-proof kernels) looks for a free sibling lane
@@ -659,7 +663,7 @@ LaneLock acquire_lane(bool primary_only = false, bool side = false) {
     Ctx &P = ctx();
     { std::lock_guard<std::mutex> g(P.init_mu); P.init(); }
     HIPCHK(hipSetDevice(P.phys));                      // the calling thread may be new to HIP, or last used another device
-    LaneLock ll; ll.primary = &P; P.active_calls.fetch_add(1);
+    LaneLock ll; ll.primary = &P; P.active_calls.fetch_add(1); g_calls_in_flight.fetch_add(1);
     size_t L = primary_only ? 1 : 1 + P.sibs.size();
     for (size_t k = 0; k < L; k++) {
         size_t i = side && L > 1 ? (k + 1) % L : k;      // side calls: siblings first, the primary lane last

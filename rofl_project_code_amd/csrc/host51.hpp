@@ -201,7 +201,7 @@ inline s4 s4_montmul(const s4 &a, const s4 &b) {
     return r;
 }
 // a^(l-2), Montgomery in / out; fixed 4-bit windows over the public exponent (variable time in the exponent only)
-inline sc sc_invert_mont_fast(const sc &a_mont) {
+inline sc sc_invert_mont_ladder(const sc &a_mont) {
     static const u64 E[4] = {0x5812631a5cf5d3edULL - 2, 0x14def9dea2f79cd6ULL, 0ULL, 0x1000000000000000ULL};
     s4 tab[16]; tab[1] = s4_from(a_mont); tab[0] = s4_from(sc_one_mont());
     for (int i = 2; i < 16; i++) tab[i] = s4_montmul(tab[i - 1], tab[1]);
@@ -212,6 +212,105 @@ inline sc sc_invert_mont_fast(const sc &a_mont) {
         if (d) acc = s4_montmul(acc, tab[d]);
     }
     return s4_to(acc);
+}
+
+// ---- x^-1 mod l by Bernstein-Yang division steps ("safegcd", variable time: the inputs are public challenges).
+// The IPP hop inverts one challenge (or one product of four) per round: 252 squarings + ~60 multiplications took 10 us of an 0.2 ms hop.
+// Here: batches of 62 division steps on the low 64 bits of (f, g) give a 2 x 2 transition matrix t with [f', g'] = t [f, g] / 2^62; the
+// same matrix is applied to (d, e) modulo l (a multiple of l makes the sums divisible by 2^62), keeping d x = f, e x = g (mod l) up to
+// the accumulated power of two.  When g = 0, f = +-1 and d = +-x^-1.  Numbers are signed, five limbs of 62 bits.
+namespace gcd62 {
+typedef __int128 i128;
+struct s62 { int64_t v[5]; };
+static const int64_t M62 = (int64_t)((1ULL << 62) - 1);
+// l = 2^252 + 27742317777372353535851937790883648493 in 62-bit limbs, and l^-1 mod 2^62
+inline s62 mod_l() {
+    const unsigned __int128 lo = ((unsigned __int128)0x14def9dea2f79cd6ULL << 64) | 0x5812631a5cf5d3edULL;      // low 128 bits of l
+    s62 r; r.v[0] = (int64_t)((u64)lo & (u64)M62); r.v[1] = (int64_t)((u64)(lo >> 62) & (u64)M62); r.v[2] = (int64_t)((u64)(lo >> 124));
+    r.v[3] = 0; r.v[4] = (int64_t)1 << (252 - 248);      // 2^252 = 2^(4 * 62 + 4)
+    return r;
+}
+inline u64 inv62(u64 a) { u64 x = a; for (int i = 0; i < 6; i++) x *= 2 - a * x; return x & (u64)M62; }      // a odd: a x = 1 (mod 2^62)
+struct trans { int64_t u, v, q, r; };
+// up to 62 division steps on (f0, g0) = the low bits of f (odd) and g; eta = -delta.  Returns the new eta.
+inline int64_t divsteps62(int64_t eta, u64 f0, u64 g0, trans &t) {
+    u64 u = 1, v = 0, q = 0, r = 1, f = f0, g = g0;
+    int i = 62;
+    for (;;) {
+        int zeros = __builtin_ctzll(g | (~0ULL << i));      // trailing zeros of g, at most i
+        g >>= zeros; u <<= zeros; v <<= zeros; eta -= zeros; i -= zeros;
+        if (i == 0) break;
+        if (eta < 0) { u64 tmp; eta = -eta; tmp = f; f = g; g = 0 - tmp; tmp = u; u = q; q = 0 - tmp; tmp = v; v = r; r = 0 - tmp; }
+        g += f; q += u; r += v;                               // f, g odd: g + f is even
+    }
+    t.u = (int64_t)u; t.v = (int64_t)v; t.q = (int64_t)q; t.r = (int64_t)r;
+    return eta;
+}
+// (a, b) <- t (a, b) / 2^62, exact (f, g)
+inline void update_fg(s62 &f, s62 &g, const trans &t) {
+    i128 cf = (i128)t.u * f.v[0] + (i128)t.v * g.v[0], cg = (i128)t.q * f.v[0] + (i128)t.r * g.v[0];
+    cf >>= 62; cg >>= 62;                                      // the low 62 bits are zero by construction
+    for (int i = 1; i < 5; i++) {
+        cf += (i128)t.u * f.v[i] + (i128)t.v * g.v[i]; cg += (i128)t.q * f.v[i] + (i128)t.r * g.v[i];
+        f.v[i - 1] = (int64_t)cf & M62; cf >>= 62; g.v[i - 1] = (int64_t)cg & M62; cg >>= 62;
+    }
+    f.v[4] = (int64_t)cf; g.v[4] = (int64_t)cg;
+}
+// (d, e) <- t (d, e) / 2^62 mod l: md, me multiples of l make the sums divisible by 2^62
+inline void update_de(s62 &d, s62 &e, const trans &t, const s62 &L, u64 linv) {
+    i128 cd = (i128)t.u * d.v[0] + (i128)t.v * e.v[0], ce = (i128)t.q * d.v[0] + (i128)t.r * e.v[0];
+    const int64_t md = (int64_t)((0 - (u64)cd * linv) & (u64)M62), me = (int64_t)((0 - (u64)ce * linv) & (u64)M62);
+    cd += (i128)md * L.v[0]; ce += (i128)me * L.v[0];
+    cd >>= 62; ce >>= 62;
+    for (int i = 1; i < 5; i++) {
+        cd += (i128)t.u * d.v[i] + (i128)t.v * e.v[i] + (i128)md * L.v[i]; ce += (i128)t.q * d.v[i] + (i128)t.r * e.v[i] + (i128)me * L.v[i];
+        d.v[i - 1] = (int64_t)cd & M62; cd >>= 62; e.v[i - 1] = (int64_t)ce & M62; ce >>= 62;
+    }
+    d.v[4] = (int64_t)cd; e.v[4] = (int64_t)ce;
+}
+inline bool is_zero(const s62 &a) { return (a.v[0] | a.v[1] | a.v[2] | a.v[3] | a.v[4]) == 0; }
+// x (canonical, 0 < x < l) -> x^-1 mod l (canonical); 0 -> 0
+inline void invert(u64 out[4], const u64 x[4]) {
+    static const s62 L = mod_l();
+    static const u64 linv = inv62((u64)L.v[0]);
+    s62 f = L, g, d = {{0, 0, 0, 0, 0}}, e = {{1, 0, 0, 0, 0}};
+    g.v[0] = (int64_t)(x[0] & (u64)M62); g.v[1] = (int64_t)(((x[0] >> 62) | (x[1] << 2)) & (u64)M62); g.v[2] = (int64_t)(((x[1] >> 60) | (x[2] << 4)) & (u64)M62);
+    g.v[3] = (int64_t)(((x[2] >> 58) | (x[3] << 6)) & (u64)M62); g.v[4] = (int64_t)(x[3] >> 56);
+    int64_t eta = -1;
+    for (int it = 0; it < 16 && !is_zero(g); it++) {          // 12 batches cover the 735 steps the analysis allows for 256-bit inputs
+        trans t;
+        eta = divsteps62(eta, (u64)f.v[0] | ((u64)f.v[1] << 62), (u64)g.v[0] | ((u64)g.v[1] << 62), t);
+        update_de(d, e, t, L, linv);
+        update_fg(f, g, t);
+    }
+    // f = +-1; d = +-x^-1 + k l with a small k: bring it into [0, l)
+    const bool neg = f.v[4] < 0 || (f.v[4] == 0 && f.v[3] == 0 && f.v[2] == 0 && f.v[1] == 0 && f.v[0] == 0);      // (f is -1 when its top limb is negative)
+    if (f.v[4] < 0) for (int i = 0; i < 5; i++) d.v[i] = -d.v[i];
+    (void)neg;
+    // normalise the limbs (they may be negative after the negation), then add / subtract l until 0 <= d < l
+    for (int pass = 0; pass < 2; pass++) {
+        int64_t c = 0;
+        for (int i = 0; i < 4; i++) { int64_t w = d.v[i] + c; d.v[i] = w & M62; c = w >> 62; }
+        d.v[4] += c;
+    }
+    auto add_l = [&](int sign) { int64_t c = 0; for (int i = 0; i < 5; i++) { int64_t w = d.v[i] + sign * L.v[i] + c; if (i < 4) { d.v[i] = w & M62; c = w >> 62; } else d.v[i] = w; } };
+    auto geq_l = [&]() { for (int i = 4; i >= 0; i--) { if (d.v[i] != L.v[i]) return d.v[i] > L.v[i]; } return true; };
+    for (int k = 0; k < 64 && d.v[4] < 0; k++) add_l(+1);
+    for (int k = 0; k < 64 && geq_l(); k++) add_l(-1);
+    const unsigned __int128 lo = (unsigned __int128)(u64)d.v[0] | ((unsigned __int128)(u64)d.v[1] << 62) | ((unsigned __int128)(u64)d.v[2] << 124);
+    out[0] = (u64)lo; out[1] = (u64)(lo >> 64);
+    const unsigned __int128 hi = ((unsigned __int128)(u64)d.v[2] >> 4) | ((unsigned __int128)(u64)d.v[3] << 58) | ((unsigned __int128)(u64)d.v[4] << 120);
+    out[2] = (u64)hi; out[3] = (u64)(hi >> 64);
+}
+}  // namespace gcd62
+
+// Montgomery in / out: (a R)^-1 = a^-1 R^-1, times R^2 twice (sc_to_mont multiplies by R)
+inline sc sc_invert_mont_fast(const sc &a_mont) {
+    u64 x[4], y[4];
+    for (int i = 0; i < 4; i++) x[i] = (u64)a_mont.v[2 * i] | ((u64)a_mont.v[2 * i + 1] << 32);
+    gcd62::invert(y, x);
+    sc r; for (int i = 0; i < 4; i++) { r.v[2 * i] = (u32)y[i]; r.v[2 * i + 1] = (u32)(y[i] >> 32); }
+    return sc_to_mont(sc_to_mont(r));
 }
 
 }  // namespace h51

@@ -54,6 +54,10 @@ def parse_args():
     ap.add_argument("--one-process", action="store_true", help="--config 4 with --gpus N: ONE process drives the N devices through the C ABI (rofl_set_option(\"devices\", mask): the batch entry points deal the clients to the devices from internal threads; no torch.distributed, no collective) -- the shape of the reference's server (server.rs:379-384, 656-687).  With fewer physical GPUs than N the logical devices wrap around (ROFL_DEVICE_MAP)")
     ap.add_argument("--host-cores", type=int, default=0, help="pin this rank to its first K usable cores before any GPU call (the host budget of one of 8 ranks on a node: 2, 4, 8, 16)")
     ap.add_argument("--verify-batch", type=int, default=-1, choices=(-1, 1, 2), help="--config 4: rofl_set_option(\"verify_batch\"): 2 (default) = the rank's whole share in ONE call with one random-weighted check, 1 = one check per client, six clients per call")
+    ap.add_argument("--hip-runtime", choices=("process", "system"), default="process",
+                    help="process (default): whatever HIP runtime the process ends up with -- importing torch first maps torch's BUNDLED libamdhip64 (ROCm 7.0) and "
+                         "librofl_zk.so binds to it by soname; system: map /opt/rocm's libamdhip64.so.7 (the runtime a Rust host links) before torch is imported, so the "
+                         "library runs on it while torch keeps its own copy (two runtimes in one process: a measurement mode for N = 1, not for RCCL runs)")
     ap.add_argument("--clients", type=int, default=48, help="clients of configs 4 / 5 (cifar_large.yml: 48)")
     return ap.parse_args()
 
@@ -667,6 +671,7 @@ def run_rank(args):
         "config": {"workload": "BASELINE cfg 2: L-inf 32-bit range proof, d=25000 (resnet18_intrinsic_25k), 1 client create+verify per step per GPU, inputs handed over as host buffers (H2D inside the timed region)",
                    "d": D, "prove_range": NBITS, "n_partition": NPART, "fp_bits": FP_BITS, "fp_frac": FP_FRAC, "clients_per_step_per_gpu": 1,
                    "host_cores": avail_cores(), "host_cores_pinned": args.host_cores or None, "host_cores_busy": round(cpu_busy, 2), "lanes": R.get_option("lanes"), "wait_policy": "sleep" if os.environ.get("ROFL_BLOCKING_SYNC") == "1" else "spin",
+                   "hip_runtime": mapped_hip_runtime(),
                    "protocol": "warm-up steps, then K timed steps back to back; value = N*K*d / wall time of the K steps (max over ranks); median_ms_per_step = the reference bench's statistic (benches/rangeproof_bench.rs:53-85)"},
         "median_ms_per_step": median_ms, "min_ms_per_step": step_sorted[0], "max_ms_per_step": step_sorted[-1], "step_ms": [round(x, 2) for x in step_ms],
         "elements_per_s_at_median": D / (median_ms * 1e-3),
@@ -806,9 +811,23 @@ def run_rank(args):
                                               "rofl_verify_rangeproof_batch call from a single host thread"}
         if not args.no_l2:
             out["l2_composite"] = l2_composite(R)
+        if args.hip_runtime == "process" and any("/torch/" in x for x in mapped_hip_runtime()) and os.path.exists("/opt/rocm/lib/libamdhip64.so.7"):
+            # The same K steps in a child process whose library binds to the SYSTEM HIP runtime (what a Rust host links) instead of the one
+            # torch bundles: reported beside the headline, never as `value`.
+            try:
+                cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--steps", str(K), "--warmup", str(args.warmup), "--n-partition", str(NPART),
+                                     "--hip-runtime", "system", "--no-extras", "--no-cpu-baseline"], capture_output=True, text=True, timeout=300)
+                cj = json.loads(cp.stdout.strip().splitlines()[-1])
+                out["system_hip_runtime"] = {"ms_per_step": cj["ms_per_step"], "median_ms_per_step": cj["median_ms_per_step"], "elements_per_s": cj["value"],
+                                             "hip_runtime": cj["config"]["hip_runtime"],
+                                             "note": "NOT the headline: the same K timed steps in a child process with /opt/rocm's libamdhip64.so.7 mapped before torch, so "
+                                                     "librofl_zk.so runs on the system runtime (profiles/r04_experiments.txt item 13: torch's bundled ROCm 7.0 runtime costs ~0.5 ms "
+                                                     "per step and one ~8 ms stall per process)"}
+            except Exception as e:      # a measurement extra: never fails the bench
+                out["system_hip_runtime"] = {"error": repr(e)[:200]}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, R)
-    out["other_configs"] = "bench.py --config 4 | 5 (48 clients sharded over the ranks); profiles/r03_configs.json (scripts/gpu_configs.py): all five BASELINE configs and the e2e partition count P=64, reference bench protocol"
+    out["other_configs"] = "bench.py --config 4 | 5 (48 clients sharded over the ranks); profiles/r04_configs.json (scripts/gpu_configs.py): all five BASELINE configs and the e2e partition count P=64, reference bench protocol"
     print(json.dumps(out))
     sys.stdout.flush()
     if world > 1:
@@ -885,10 +904,24 @@ def run_one_process(args):
     sys.stdout.flush()
 
 
+def mapped_hip_runtime():
+    """The libamdhip64 file(s) mapped into this process (config.hip_runtime)."""
+    try:
+        with open("/proc/self/maps") as f:
+            return sorted({ln.split()[-1] for ln in f if "libamdhip64" in ln})
+    except OSError:
+        return []
+
+
 def main():
     global NPART
     args = parse_args()
     NPART = args.n_partition
+    if args.hip_runtime == "system":
+        if args.gpus > 1:
+            sys.stderr.write("bench.py: --hip-runtime system is an N = 1 measurement mode\n"); sys.exit(2)
+        import ctypes
+        ctypes.CDLL("/opt/rocm/lib/libamdhip64.so.7", mode=ctypes.RTLD_GLOBAL)      # before anything imports torch
     if args.one_process:
         if args.config != 4:
             sys.stderr.write("bench.py: --one-process is a mode of --config 4\n"); sys.exit(2)

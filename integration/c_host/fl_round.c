@@ -1,0 +1,190 @@
+/*
+ * One federated round against librofl_zk.so from a plain C99 host -- no Python, no torch: the shape of the reference's processes
+ * (rofl_service/src/flserver/client.rs:265-266 clients as tasks of one process; server.rs:379-384, 513-521, 656-687 one server process
+ * that hands every client to a verification pool), written against include/rofl_zk.h only.  It is the compiled-host stand-in for the
+ * Rust binding of INTEGRATION.md (no Rust toolchain in this image): tests/test_c_host.py builds it with gcc -std=c99 -pedantic -Werror,
+ * runs it on the GPU box and compares every byte it wrote with the ctypes path and the oracle.
+ *
+ *   fl_round sizes
+ *       no GPU: prints the size helpers for a few shapes (the library loads and links from C)
+ *   fl_round run <d> <prove_range> <n_partition> <n_clients> <n_devices> <out-file>
+ *       client role : one pthread per device, bound with rofl_set_device; client i is proved on device i % n_devices
+ *       server role : rofl_set_option("devices", mask) + ("verify_batch", 2), ONE rofl_verify_rangeproof_batch call for the round;
+ *                     then the same call with one byte of client 1's first proof flipped (only that client may fail)
+ *       out-file    : header (8 x u64: d, prove_range, n_partition, n_clients, n_proofs, proof_len, fp_bits, fp_frac), then per client
+ *                     values (d f32), blindings (d x 32), nonce seed (32), proofs (n_proofs x proof_len), commitments (d x 32);
+ *                     then verdicts of the clean round and of the tampered round (n_clients x i32 each)
+ */
+#include <pthread.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "rofl_zk.h"
+
+#define FP_BITS 32u
+#define FP_FRAC 7u
+
+static uint64_t lcg_state;
+static uint32_t lcg(void) {
+    lcg_state = lcg_state * 6364136223846793005ull + 1442695040888963407ull;
+    return (uint32_t)(lcg_state >> 32);
+}
+
+static void die(const char *what, int rc) {
+    char msg[512];
+    msg[0] = 0;
+    rofl_last_error(msg, sizeof msg);
+    fprintf(stderr, "fl_round: %s failed with %d: %s\n", what, rc, msg);
+    exit(1);
+}
+
+typedef struct {
+    size_t d, prove_range, n_partition, n_clients, n_devices, n_proofs, proof_len;
+    float **values;
+    uint8_t **blindings, **proofs, **commits;
+    rofl_nonce_t *nonces;
+    int device;
+    int rc;
+} round_t;
+
+static void *client_thread(void *arg) {
+    round_t *r = (round_t *)arg;
+    int bound = -1;
+    size_t i;
+    r->rc = rofl_set_device(r->device);
+    if (r->rc) return NULL;
+    rofl_get_device(&bound);
+    if (bound != r->device) { r->rc = -2; return NULL; }
+    for (i = (size_t)r->device; i < r->n_clients; i += r->n_devices) {
+        size_t plen = 0, np = 0;
+        r->rc = rofl_create_rangeproof(r->values[i], r->d, r->blindings[i], r->d, r->prove_range, r->n_partition, FP_BITS, FP_FRAC,
+                                       &r->nonces[i], r->proofs[i], &plen, &np, r->commits[i]);
+        if (r->rc) return NULL;
+        if (plen != r->proof_len || np != r->n_proofs) { r->rc = -3; return NULL; }
+    }
+    return NULL;
+}
+
+static int sizes(void) {
+    static const size_t shapes[][3] = {{5000, 8, 4}, {25000, 32, 4}, {25000, 32, 64}, {55000, 32, 4}, {3, 8, 1}};
+    size_t k;
+    for (k = 0; k < sizeof shapes / sizeof shapes[0]; k++) {
+        size_t d = shapes[k][0], n = shapes[k][1], p = shapes[k][2];
+        printf("%zu %zu %zu %zu %zu %zu\n", d, n, p, rofl_next_pow2(d), rofl_rangeproof_chunks(d, p), rofl_rangeproof_size(n, d, p));
+    }
+    return 0;
+}
+
+int main(int argc, char **argv) {
+    round_t R;
+    round_t *per_dev;
+    pthread_t *th;
+    FILE *f;
+    size_t i, j;
+    int rc, *ok_clean, *ok_tampered;
+    long mask = 0, got = 0;
+    uint8_t seed[32];
+    uint64_t head[8];
+    float lo = 0, hi = 0;
+
+    if (argc >= 2 && strcmp(argv[1], "sizes") == 0) return sizes();
+    if (argc != 8 || strcmp(argv[1], "run") != 0) {
+        fprintf(stderr, "usage: fl_round sizes | fl_round run <d> <prove_range> <n_partition> <n_clients> <n_devices> <out-file>\n");
+        return 2;
+    }
+    memset(&R, 0, sizeof R);
+    R.d = (size_t)strtoul(argv[2], NULL, 10);
+    R.prove_range = (size_t)strtoul(argv[3], NULL, 10);
+    R.n_partition = (size_t)strtoul(argv[4], NULL, 10);
+    R.n_clients = (size_t)strtoul(argv[5], NULL, 10);
+    R.n_devices = (size_t)strtoul(argv[6], NULL, 10);
+    if (!R.d || !R.n_clients || !R.n_devices || R.n_devices > 16) return 2;
+    R.n_proofs = rofl_rangeproof_chunks(R.d, R.n_partition);
+    R.proof_len = rofl_rangeproof_size(R.prove_range, R.d, R.n_partition);
+    if (!R.n_proofs || !R.proof_len) { fprintf(stderr, "fl_round: the size helpers reject this shape\n"); return 2; }
+
+    /* inputs: values inside the clip interval of (prove_range, fp), canonical blinding scalars, one nonce seed per client */
+    rc = rofl_get_clip_bounds(R.prove_range, FP_BITS, FP_FRAC, &lo, &hi);
+    if (rc) die("rofl_get_clip_bounds", rc);
+    R.values = (float **)calloc(R.n_clients, sizeof *R.values);
+    R.blindings = (uint8_t **)calloc(R.n_clients, sizeof *R.blindings);
+    R.proofs = (uint8_t **)calloc(R.n_clients, sizeof *R.proofs);
+    R.commits = (uint8_t **)calloc(R.n_clients, sizeof *R.commits);
+    R.nonces = (rofl_nonce_t *)calloc(R.n_clients, sizeof *R.nonces);
+    lcg_state = 0x726f666c5f7a6bull + R.d;
+    for (i = 0; i < R.n_clients; i++) {
+        R.values[i] = (float *)malloc(R.d * sizeof(float));
+        R.blindings[i] = (uint8_t *)malloc(R.d * 32);
+        R.proofs[i] = (uint8_t *)malloc(R.n_proofs * R.proof_len);
+        R.commits[i] = (uint8_t *)malloc(R.d * 32);
+        for (j = 0; j < R.d; j++) {
+            double u = (double)lcg() / 4294967296.0;
+            R.values[i][j] = (float)((double)lo + u * 0.999 * ((double)hi - (double)lo));
+        }
+        for (j = 0; j < R.d * 32; j++) R.blindings[i][j] = (uint8_t)(lcg() >> 24);
+        for (j = 0; j < R.d; j++) R.blindings[i][j * 32 + 31] &= 0x0f;      /* < 2^252: canonical */
+        R.nonces[i].mode = 1;
+        for (j = 0; j < 32; j++) R.nonces[i].seed[j] = (uint8_t)(lcg() >> 24);
+    }
+
+    /* client role: one thread per device */
+    per_dev = (round_t *)calloc(R.n_devices, sizeof *per_dev);
+    th = (pthread_t *)calloc(R.n_devices, sizeof *th);
+    for (i = 0; i < R.n_devices; i++) {
+        per_dev[i] = R;
+        per_dev[i].device = (int)i;
+        if (pthread_create(&th[i], NULL, client_thread, &per_dev[i])) return 1;
+    }
+    for (i = 0; i < R.n_devices; i++) {
+        pthread_join(th[i], NULL);
+        if (per_dev[i].rc) die("client thread (rofl_set_device / rofl_create_rangeproof)", per_dev[i].rc);
+    }
+
+    /* server role: one call for the round, its clients spread over the devices by the library */
+    for (i = 0; i < R.n_devices; i++) mask |= 1L << i;
+    rc = rofl_set_device(0);
+    if (rc) die("rofl_set_device(0)", rc);
+    rc = rofl_set_option("devices", mask);
+    if (rc) die("rofl_set_option(devices)", rc);
+    rc = rofl_set_option("verify_batch", 2);
+    if (rc) die("rofl_set_option(verify_batch)", rc);
+    if (rofl_get_option("devices", &got) || got != mask) die("rofl_get_option(devices)", -1);
+    memset(seed, 0x5a, sizeof seed);
+    ok_clean = (int *)calloc(R.n_clients, sizeof(int));
+    ok_tampered = (int *)calloc(R.n_clients, sizeof(int));
+    rc = rofl_verify_rangeproof_batch(R.n_clients, (const uint8_t *const *)R.proofs, R.proof_len, R.n_proofs,
+                                      (const uint8_t *const *)R.commits, R.d, R.prove_range, FP_BITS, FP_FRAC, seed, ok_clean);
+    if (rc) die("rofl_verify_rangeproof_batch", rc);
+    if (R.n_clients > 1) {
+        uint8_t *bad = (uint8_t *)malloc(R.n_proofs * R.proof_len);
+        const uint8_t **set = (const uint8_t **)malloc(R.n_clients * sizeof *set);
+        memcpy(bad, R.proofs[1], R.n_proofs * R.proof_len);
+        bad[4 * 32 + 5] ^= 0x01;                                            /* t_x of chunk 0 */
+        for (i = 0; i < R.n_clients; i++) set[i] = i == 1 ? bad : R.proofs[i];
+        rc = rofl_verify_rangeproof_batch(R.n_clients, set, R.proof_len, R.n_proofs, (const uint8_t *const *)R.commits, R.d, R.prove_range,
+                                          FP_BITS, FP_FRAC, seed, ok_tampered);
+        if (rc) die("rofl_verify_rangeproof_batch (tampered)", rc);
+        free(bad);
+        free(set);
+    }
+
+    f = fopen(argv[7], "wb");
+    if (!f) { perror(argv[7]); return 1; }
+    head[0] = R.d; head[1] = R.prove_range; head[2] = R.n_partition; head[3] = R.n_clients;
+    head[4] = R.n_proofs; head[5] = R.proof_len; head[6] = FP_BITS; head[7] = FP_FRAC;
+    fwrite(head, sizeof head, 1, f);
+    for (i = 0; i < R.n_clients; i++) {
+        fwrite(R.values[i], sizeof(float), R.d, f);
+        fwrite(R.blindings[i], 32, R.d, f);
+        fwrite(R.nonces[i].seed, 1, 32, f);
+        fwrite(R.proofs[i], R.proof_len, R.n_proofs, f);
+        fwrite(R.commits[i], 32, R.d, f);
+    }
+    fwrite(ok_clean, sizeof(int), R.n_clients, f);
+    fwrite(ok_tampered, sizeof(int), R.n_clients, f);
+    fclose(f);
+    for (i = 0; i < R.n_clients; i++) printf("client %zu: clean %d tampered %d\n", i, ok_clean[i], ok_tampered[i]);
+    return 0;
+}

@@ -1,0 +1,90 @@
+"""The C ABI from a compiled host: integration/c_host/fl_round.c is plain C99 against include/rofl_zk.h (no Python, no torch in the process)
+and plays one federated round the way the reference's processes do -- client threads bound to their devices, then ONE batched verification
+call for the round spread over the devices (rofl_service/src/flserver/server.rs:379-384, 513-521, 656-687).  It stands in for the Rust
+binding of INTEGRATION.md, which cannot be compiled in this image.  CPU: the header is valid pedantic C99, the program links against the
+shipped library and the size helpers agree with the Python mirror.  GPU: every byte the C host produced is what the ctypes path and the
+oracle produce from the same inputs, and the verdicts are per client."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "integration", "c_host", "fl_round.c")
+OUT = os.path.join(ROOT, "integration", "c_host", "build")
+
+
+@pytest.fixture(scope="module")
+def fl_round(hiplib):
+    pkg = os.path.join(ROOT, "rofl_project_code_amd")
+    os.makedirs(OUT, exist_ok=True)
+    exe = os.path.join(OUT, "fl_round")
+    cmd = ["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-O1", "-D_POSIX_C_SOURCE=200809L", "-I", os.path.join(ROOT, "include"), SRC, "-o", exe,
+           "-L", pkg, "-l:librofl_zk.so", "-Wl,-rpath," + pkg, "-pthread"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def test_c_host_builds_as_c99_and_the_size_helpers_agree(fl_round):
+    import rofl_project_code_amd as R
+    r = subprocess.run([fl_round, "sizes"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    rows = [tuple(int(x) for x in ln.split()) for ln in r.stdout.strip().splitlines()]
+    assert len(rows) == 5
+    rpv = R.range_proof_vec
+    for d, nb, P, p2, chunks, plen in rows:
+        assert p2 == rpv.next_pow2(d)
+        m = max(p2 // P, 1)                        # values per chunk: the vector is padded to p2 and cut into n_partition chunks (range_proof_vec/mod.rs:24-40)
+        assert chunks == min(P, p2)
+        lg = (nb * m).bit_length() - 1
+        assert plen == 32 * (9 + 2 * lg)          # A S T1 T2 t_x t_x_blinding e_blinding, lg(n m) x (L, R), a, b
+    # the headline shape: 4 proofs of 1 440 bytes
+    assert rows[1][4:] == (4, 1440)
+
+
+def _parse(path):
+    buf = open(path, "rb").read()
+    d, nb, P, nc, npf, plen, fpb, fpf = struct.unpack_from("<8Q", buf, 0)
+    off = 64
+    clients = []
+    for _ in range(nc):
+        vals = np.frombuffer(buf, np.float32, d, off); off += 4 * d
+        bl = np.frombuffer(buf, np.uint8, 32 * d, off).reshape(d, 32); off += 32 * d
+        seed = bytes(buf[off:off + 32]); off += 32
+        pr = np.frombuffer(buf, np.uint8, npf * plen, off).reshape(npf, plen); off += npf * plen
+        cm = np.frombuffer(buf, np.uint8, 32 * d, off).reshape(d, 32); off += 32 * d
+        clients.append((vals, bl, seed, pr, cm))
+    clean = np.frombuffer(buf, np.int32, nc, off); off += 4 * nc
+    tampered = np.frombuffer(buf, np.int32, nc, off); off += 4 * nc
+    assert off == len(buf)
+    return (d, nb, P, nc, npf, plen, (fpb, fpf)), clients, clean, tampered
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1000, 32, 4, 5, 2), (300, 8, 1, 3, 1), (25000, 32, 4, 3, 2)], ids=["d1000-2dev", "d300-1dev", "cfg2-2dev"])
+def test_c_host_round_matches_ctypes_and_oracle(fl_round, tmp_path, shape):
+    import orc
+    import rofl_project_code_amd as R
+    d, nb, P, nc, ndev = shape
+    out = str(tmp_path / "round.bin")
+    env = dict(os.environ, ROFL_DEVICE_MAP=",".join("0" for _ in range(ndev)))      # the box has one GPU: logical devices share it
+    r = subprocess.run([fl_round, "run", str(d), str(nb), str(P), str(nc), str(ndev), out], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    head, clients, clean, tampered = _parse(out)
+    assert head[:4] == (d, nb, P, nc)
+    fp = head[6]
+    assert clean.tolist() == [1] * nc
+    assert tampered.tolist() == ([1, 0] + [1] * (nc - 2) if nc > 1 else [0] * nc)
+    R.set_device(0)
+    for i, (vals, bl, seed, pr, cm) in enumerate(clients):
+        hpr, hcm = R.range_proof_vec.create_rangeproof(vals, bl, nb, P, nonce=R.Nonce.seeded(seed), fp=fp)
+        assert (np.asarray(hpr) == pr).all() and (np.asarray(hcm) == cm).all(), "client %d: C host and ctypes path differ" % i
+        if d <= 1000 or i == 0:
+            rc, ok = orc.verify_rangeproof(pr, cm, nb, fp[0], fp[1])
+            assert rc == 0 and ok, "the oracle rejects client %d's proof from the C host" % i
+        if d <= 1000:
+            rc, opr, ocm = orc.create_rangeproof(vals, bl, nb, P, fp[0], fp[1], seed=seed)
+            assert rc == 0 and (opr == pr).all() and (ocm == cm).all(), "client %d: C host and oracle differ" % i

@@ -7,6 +7,9 @@
  *
  *   fl_round sizes
  *       no GPU: prints the size helpers for a few shapes (the library loads and links from C)
+ *   fl_round bench <d> <prove_range> <n_partition> <iterations>
+ *       one client, create + verify back to back from host buffers (BASELINE cfg 2 when called with 25000 32 4): the library's latency
+ *       as a compiled host sees it, on the system HIP runtime, with no interpreter in the loop; prints the median and the extremes
  *   fl_round run <d> <prove_range> <n_partition> <n_clients> <n_devices> <out-file>
  *       client role : one pthread per device, bound with rofl_set_device; client i is proved on device i % n_devices
  *       server role : rofl_set_option("devices", mask) + ("verify_batch", 2), ONE rofl_verify_rangeproof_batch call for the round;
@@ -20,6 +23,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "rofl_zk.h"
 
@@ -77,6 +81,64 @@ static int sizes(void) {
     return 0;
 }
 
+static double now_ms(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec * 1e3 + (double)ts.tv_nsec * 1e-6;
+}
+
+static int cmp_double(const void *a, const void *b) {
+    double x = *(const double *)a, y = *(const double *)b;
+    return (x > y) - (x < y);
+}
+
+static int bench(size_t d, size_t prove_range, size_t n_partition, size_t iters) {
+    size_t n_proofs = rofl_rangeproof_chunks(d, n_partition), proof_len = rofl_rangeproof_size(prove_range, d, n_partition), j, it;
+    float *values = (float *)malloc(d * sizeof(float)), lo = 0, hi = 0;
+    uint8_t *blindings = (uint8_t *)malloc(d * 32), *proofs = (uint8_t *)malloc(n_proofs * proof_len), *commits = (uint8_t *)malloc(d * 32);
+    double *tc = (double *)malloc(iters * sizeof(double)), *tv = (double *)malloc(iters * sizeof(double)), *ts = (double *)malloc(iters * sizeof(double));
+    uint8_t seed[32];
+    rofl_nonce_t nonce;
+    int rc, ok = 0;
+    if (!n_proofs || !proof_len || iters < 3) return 2;
+    rc = rofl_get_clip_bounds(prove_range, FP_BITS, FP_FRAC, &lo, &hi);
+    if (rc) die("rofl_get_clip_bounds", rc);
+    lcg_state = 12345;
+    for (j = 0; j < d; j++) values[j] = (float)((double)lo + (double)lcg() / 4294967296.0 * 0.999 * ((double)hi - (double)lo));
+    for (j = 0; j < d * 32; j++) blindings[j] = (uint8_t)(lcg() >> 24);
+    for (j = 0; j < d; j++) blindings[j * 32 + 31] &= 0x0f;
+    memset(seed, 0x5a, sizeof seed);
+    memset(&nonce, 0, sizeof nonce);
+    nonce.mode = 1;
+    rc = rofl_set_device(0);
+    if (rc) die("rofl_set_device", rc);
+    rc = rofl_bp_gens_prepare(prove_range, rofl_next_pow2(d) / n_partition);
+    if (rc) die("rofl_bp_gens_prepare", rc);
+    for (it = 0; it < iters + 3; it++) {                                    /* three warm-ups */
+        size_t plen = 0, np = 0;
+        double t0, t1, t2;
+        nonce.seed[0] = (uint8_t)it;
+        t0 = now_ms();
+        rc = rofl_create_rangeproof(values, d, blindings, d, prove_range, n_partition, FP_BITS, FP_FRAC, &nonce, proofs, &plen, &np, commits);
+        if (rc) die("rofl_create_rangeproof", rc);
+        t1 = now_ms();
+        rc = rofl_verify_rangeproof(proofs, plen, np, commits, d, prove_range, FP_BITS, FP_FRAC, seed, &ok);
+        if (rc || !ok) die("rofl_verify_rangeproof", rc ? rc : -1);
+        t2 = now_ms();
+        if (it >= 3) { tc[it - 3] = t1 - t0; tv[it - 3] = t2 - t1; ts[it - 3] = t2 - t0; }
+        if (getenv("FL_ROUND_EACH")) fprintf(stderr, "iteration %zu: create %.3f verify %.3f ms\n", it, t1 - t0, t2 - t1);
+    }
+    qsort(tc, iters, sizeof(double), cmp_double);
+    qsort(tv, iters, sizeof(double), cmp_double);
+    qsort(ts, iters, sizeof(double), cmp_double);
+    printf("{\"host\": \"C99, no interpreter\", \"d\": %zu, \"prove_range\": %zu, \"n_partition\": %zu, \"iterations\": %zu, "
+           "\"create_ms\": {\"median\": %.3f, \"min\": %.3f, \"max\": %.3f}, \"verify_ms\": {\"median\": %.3f, \"min\": %.3f, \"max\": %.3f}, "
+           "\"create_plus_verify_ms\": {\"median\": %.3f, \"min\": %.3f, \"max\": %.3f}, \"elements_per_s_at_median\": %.0f}\n",
+           d, prove_range, n_partition, iters, tc[iters / 2], tc[0], tc[iters - 1], tv[iters / 2], tv[0], tv[iters - 1],
+           ts[iters / 2], ts[0], ts[iters - 1], (double)d / (ts[iters / 2] * 1e-3));
+    return 0;
+}
+
 int main(int argc, char **argv) {
     round_t R;
     round_t *per_dev;
@@ -90,8 +152,10 @@ int main(int argc, char **argv) {
     float lo = 0, hi = 0;
 
     if (argc >= 2 && strcmp(argv[1], "sizes") == 0) return sizes();
+    if (argc == 6 && strcmp(argv[1], "bench") == 0)
+        return bench((size_t)strtoul(argv[2], NULL, 10), (size_t)strtoul(argv[3], NULL, 10), (size_t)strtoul(argv[4], NULL, 10), (size_t)strtoul(argv[5], NULL, 10));
     if (argc != 8 || strcmp(argv[1], "run") != 0) {
-        fprintf(stderr, "usage: fl_round sizes | fl_round run <d> <prove_range> <n_partition> <n_clients> <n_devices> <out-file>\n");
+        fprintf(stderr, "usage: fl_round sizes | fl_round bench <d> <prove_range> <n_partition> <iterations> | fl_round run <d> <prove_range> <n_partition> <n_clients> <n_devices> <out-file>\n");
         return 2;
     }
     memset(&R, 0, sizeof R);

@@ -48,6 +48,18 @@ struct MsmJob {
 static const u32 MSM_OVF_MAX = 4096;
 
 // ---- plan
+// Entries a coarse bin of the two-level sort has room for, given the mean load `avg` of a bin.  The (c-1)-bit windows of the layout reach only
+// half of the buckets, so the bins of that half carry 2 x avg; on top of that eight standard deviations of a Poisson load (a fixed margin of
+// 256 was 2.8 sigma at avg = 4 096 -- the verifier's 2^20-term generator MSM of a d = 55 000 client overflowed a bin in six calls of ten and
+// was repeated on the slot path, 3.0 -> 4.5 ms per verification).
+static inline u32 msm_bin_cap(size_t avg) {
+    static const int sigmas = knob("ROFL_MSM_BIN_SIGMA") ? atoi(knob("ROFL_MSM_BIN_SIGMA")) : 8;
+    size_t hot = 2 * avg, dev = 1;
+    if (sigmas <= 0) return (u32)((hot + 256 + 63) / 64 * 64);
+    while (dev * dev < hot) dev++;                      // ceil(sqrt(hot))
+    return (u32)((hot + (size_t)sigmas * dev + 64 + 63) / 64 * 64);
+}
+
 bool msm_plan_job(Ctx &C, MsmJob &J, const MsmOpt &opt, const MsmAllow &al, MsmMap &mm, u32 &small_cap, Msm2L &tl) {
     const size_t np = J.np, n = J.n; const bool lr = J.lr; const size_t nq = J.nq;
     const size_t per_side = lr ? n / 2 : n;
@@ -70,7 +82,7 @@ bool msm_plan_job(Ctx &C, MsmJob &J, const MsmOpt &opt, const MsmAllow &al, MsmM
         // sort (a 6.4 GB slot array, 3x the sort time).  More sets per problem until the bins fit (ROFL_MSM_FB_FITSETS=0: as before).
         static const bool fitsets = !(knob("ROFL_MSM_FB_FITSETS") && atoi(knob("ROFL_MSM_FB_FITSETS")) == 0);
         if (fitsets && al.two && C.msm_two_level && (J.P.B == 32768 || J.P.B == 16384) && per_side >= 8192)
-            while (sets < J.P.W && ((2 * (per_side * (J.P.W / sets) / 512) + 256 + 63) / 64 * 64) * 4 + 1024 > 96 * 1024) {
+            while (sets < J.P.W && (size_t)msm_bin_cap(per_side * (J.P.W / sets) / 512) * 4 + 1024 > 96 * 1024) {
                 u32 nx = sets + 1; while (nx < J.P.W && J.P.W % nx) nx++;
                 sets = nx;
             }
@@ -88,7 +100,7 @@ bool msm_plan_job(Ctx &C, MsmJob &J, const MsmOpt &opt, const MsmAllow &al, MsmM
         if (two) {
             // a coarse bin has to fit one block's LDS in level 2: 256 bins of 128 buckets while that holds (<= 4 windows per array at
             // 2^19 terms), 512 bins of 64 buckets with half the staging row for arrays that take 8 windows (two sets per problem)
-            auto size_bins = [&]() { size_t avg = per_side * mm.fb_wps / tl.nbins; tl.cap_bin = (u32)((2 * avg + 256 + 63) / 64 * 64); return (size_t)tl.cap_bin * 4 + 1024 <= 96 * 1024; };
+            auto size_bins = [&]() { tl.cap_bin = msm_bin_cap(per_side * mm.fb_wps / tl.nbins); return (size_t)tl.cap_bin * 4 + 1024 <= 96 * 1024; };
             bool fits = size_bins();
             if (!fits) { tl = Msm2L{512, fb0 - 1, 24, 0, 72}; fits = size_bins(); }
             if (!fits || per_side < 8192) two = false;

@@ -25,6 +25,7 @@ static const Knob KNOBS[] = {
     {"ROFL_FOLD_T", "2", "IPP rounds between later folds (1..6)"},
     {"ROFL_FOLD_MIN", "1024", "no fold once fewer generators per chunk would remain (launches with many chunks fold down to 64)"},
     {"ROFL_MSM_FB_FITSETS", "1", "0 = do not add bucket sets to a fixed-base launch whose coarse bins would not fit the two-level sort"},
+    {"ROFL_MSM_BIN_SIGMA", "8", "room of a coarse bin of the two-level sort above twice its mean load, in standard deviations of that load (0 = the fixed 256 entries of rounds 2-3)"},
     {"ROFL_POOL_NAP", "1", "0 = pool workers do not nap through a wait whose length the caller announced (they poll for ROFL_POOL_SPIN_US, then sleep until woken)"},
     {"ROFL_SYNC_POLL", "0", "1 = wait for the lane's stream with hipStreamQuery in a pause loop instead of hipStreamSynchronize"},
     {"ROFL_FOLD_TAB", "1", "0 = first fold without the precomputed odd-multiple slices"},

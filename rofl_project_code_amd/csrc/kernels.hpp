@@ -1887,6 +1887,8 @@ __global__ void __launch_bounds__(256) k_verify_scalars2(u32 n, u32 lgn, u32 m, 
 #pragma unroll
     for (int r = 0; r < 2; r++) { kk[r] = base + (half + 2 * r) * 128 + lo; js[r] = (kk[r] >> lgn) - j0; }
     sc gacc[2] = {sc_zero(), sc_zero()}, hacc[2] = {sc_zero(), sc_zero()}, rzsum = sc_zero();
+    // the products of a tile of VS_TP proofs are summed unreduced (sc_mac_wide) and reduced once: 2 x VS_TP = 16 products per accumulator at most
+    static_assert(VS_TP <= 8, "sc_redc_wide takes the sum of at most sixteen products");
     for (u32 c0 = 0; c0 < count; c0 += VS_TP) {
         const u32 tp = min((u32)VS_TP, count - c0);
         for (u32 task = t; task < tp * (8 + nj); task += 256) {
@@ -1898,16 +1900,24 @@ __global__ void __launch_bounds__(256) k_verify_scalars2(u32 n, u32 lgn, u32 m, 
             sh[pi][v] = r;
         }
         __syncthreads();
+        u32 gw[2][17], hw[2][17];
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int q = 0; q < 17; q++) { gw[r][q] = 0; hw[r][q] = 0; }
         for (u32 pi = 0; pi < tp; pi++) {
             const VTabs &V = vt[first + c0 + pi];
             const sc s0 = load_sc(&V.s0[lo]), q0 = load_sc(&V.q0[lo]), zi = load_sc(&V.zi[i]);
 #pragma unroll
             for (int r = 0; r < 2; r++) {
-                gacc[r] = sc_add(gacc[r], sc_montmul(sh[pi][half + 2 * r], s0));
-                hacc[r] = sc_add(hacc[r], sc_add(sc_montmul(sh[pi][4 + half + 2 * r], q0), sc_montmul(sh[pi][8 + js[r]], zi)));
+                sc_mac_wide(gw[r], sh[pi][half + 2 * r], s0);
+                sc_mac_wide(hw[r], sh[pi][4 + half + 2 * r], q0);
+                sc_mac_wide(hw[r], sh[pi][8 + js[r]], zi);
             }
             rzsum = sc_add(rzsum, load_sc(&cp[first + c0 + pi].rz));
         }
+#pragma unroll
+        for (int r = 0; r < 2; r++) { gacc[r] = sc_add(gacc[r], sc_redc_wide(gw[r])); hacc[r] = sc_add(hacc[r], sc_redc_wide(hw[r])); }
         __syncthreads();
     }
     sc *o = out + ((size_t)blockIdx.y * gridDim.z + blockIdx.z) * 2 * N;

@@ -1301,6 +1301,18 @@ int rofl_dbg_host_sc_invert(const uint8_t a[32], uint8_t out_ref[32], uint8_t ou
     return 0;
 }
 int rofl_dbg_host_sc_mul(const uint8_t a[32], const uint8_t b[32], uint8_t out[32]) { sc_tobytes(out, h_mul(sc_frombytes(a), sc_frombytes(b))); return 0; }
+int rofl_dbg_host_sc_lazy(const uint8_t *a32, const uint8_t *b32, size_t count, uint8_t out_lazy[32], uint8_t out_ref[32]) {
+    if (count > 16) return ROFL_BAD_PARAM;      // sc_redc_wide's bound: sixteen products of operands < l
+    u32 acc[17]; for (int i = 0; i < 17; i++) acc[i] = 0;
+    sc ref = sc_zero();
+    for (size_t k = 0; k < count; k++) {
+        const sc a = sc_frombytes(a32 + 32 * k), b = sc_frombytes(b32 + 32 * k);
+        sc_mac_wide(acc, a, b);
+        ref = sc_add(ref, sc_montmul(a, b));
+    }
+    sc_tobytes(out_lazy, sc_redc_wide(acc)); sc_tobytes(out_ref, ref);
+    return 0;
+}
 int rofl_dbg_host_sc_wide(const uint8_t in[64], uint8_t out[32]) { sc_tobytes(out, sc_from_wide(sc_frombytes(in), sc_frombytes(in + 32))); return 0; }
 int rofl_dbg_host_from_uniform(const uint8_t in[64], uint8_t out[32]) { ristretto_encode(out, ristretto_from_uniform(in)); return 0; }
 int rofl_dbg_host_scalarmult_base(const uint8_t k[32], int use_bb, uint8_t out[32]) {

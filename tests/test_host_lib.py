@@ -172,6 +172,28 @@ def test_fast_scalar_inversion_matches_reference_and_python(hiplib):
         assert o1.raw == want and o2.raw == want
 
 
+def test_lazily_reduced_scalar_sums_match_montgomery_products(hiplib):
+    """sc_mac_wide / sc_redc_wide (k_verify_scalars2 sums the products of eight proofs unreduced and reduces once) against the sum of
+    sc_montmul results and against Python: sum a_k b_k / 2^256 mod l, for random operands and for sixteen products of (l - 1)^2 -- the bound"""
+    import ctypes
+    import numpy as np
+    L = 2 ** 252 + 27742317777372353535851937790883648493
+    Rinv = pow(1 << 256, -1, L)
+    rng = np.random.default_rng(12)
+    rnd = lambda: int.from_bytes(rng.integers(0, 256, 32, dtype=np.uint8).tobytes(), "little") % L
+    cases = [([L - 1] * 16, [L - 1] * 16), ([L - 1] * 16, [1] * 16), ([0] * 3, [5] * 3), ([1], [1]), ([], [])]
+    for count in (1, 2, 7, 8, 15, 16):
+        for _ in range(40):
+            cases.append(([rnd() for _ in range(count)], [rnd() for _ in range(count)]))
+    for a, b in cases:
+        ab = b"".join(x.to_bytes(32, "little") for x in a); bb = b"".join(x.to_bytes(32, "little") for x in b)
+        o1 = ctypes.create_string_buffer(32); o2 = ctypes.create_string_buffer(32)
+        assert hiplib.rofl_dbg_host_sc_lazy(ab, bb, ctypes.c_size_t(len(a)), o1, o2) == 0
+        want = (sum(x * y for x, y in zip(a, b)) * Rinv % L).to_bytes(32, "little")
+        assert o1.raw == want and o2.raw == want
+    assert hiplib.rofl_dbg_host_sc_lazy(b"\0" * 32 * 17, b"\0" * 32 * 17, ctypes.c_size_t(17), ctypes.create_string_buffer(32), ctypes.create_string_buffer(32)) == 11
+
+
 def test_knob_registry_is_complete_and_documented():
     """Every ROFL_* variable the library reads is registered in ONE table (csrc/host_rt.hpp: KNOBS), nothing else is read from the
     environment, and the table of DESIGN.md is the one scripts/gen_knob_table.py generates from it."""

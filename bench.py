@@ -13,6 +13,13 @@ parent never touches the GPU); under torchrun the ranks come from the environmen
 verifies its own client per step (clients are independent, server.rs:656-687), then proof bytes + commitments are all-gathered
 over RCCL and the verify bits MIN-all-reduced.
 
+The library's consumer is a compiled host that links the image's HIP runtime (/opt/rocm); importing torch first would bind librofl_zk.so to the
+older runtime torch bundles instead (soname match), which costs ~0.5 ms per step and one ~8 ms stall per process.  So the N = 1 headline runs in a
+child process that maps /opt/rocm's libamdhip64.so.7 before torch (--hip-runtime auto -> system; torch keeps its own copy for the
+torch.cuda.synchronize() brackets, and every library call is synchronous), falls back to the process's runtime if that child fails, names the
+mapped runtime(s) in config.hip_runtime and reports the same K steps on the other runtime beside the headline.  N > 1 ranks use the process's
+runtime.
+
 Extra figures (rank 0, N = 1, outside the timed region, separate keys): the same steps with HBM-resident inputs, C clients in
 flight on C lanes, the per-kernel table, the L2 composite and the CPU baseline.
 """
@@ -30,6 +37,7 @@ sys.path.insert(0, ROOT)
 
 D, NBITS, NPART, FP_BITS, FP_FRAC = 25000, 32, 4, 32, 7
 FP = (FP_BITS, FP_FRAC)
+SYSTEM_HIP = "/opt/rocm/lib/libamdhip64.so.7"      # the image's ROCm 7.2 runtime: what a compiled host links
 HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # algorithmic bytes per element, generators counted in compressed form (32 B per point)
 ALG_BYTES_CREATE = 4 + 32 + 32 + 64 * NBITS
@@ -54,10 +62,12 @@ def parse_args():
     ap.add_argument("--one-process", action="store_true", help="--config 4 with --gpus N: ONE process drives the N devices through the C ABI (rofl_set_option(\"devices\", mask): the batch entry points deal the clients to the devices from internal threads; no torch.distributed, no collective) -- the shape of the reference's server (server.rs:379-384, 656-687).  With fewer physical GPUs than N the logical devices wrap around (ROFL_DEVICE_MAP)")
     ap.add_argument("--host-cores", type=int, default=0, help="pin this rank to its first K usable cores before any GPU call (the host budget of one of 8 ranks on a node: 2, 4, 8, 16)")
     ap.add_argument("--verify-batch", type=int, default=-1, choices=(-1, 1, 2), help="--config 4: rofl_set_option(\"verify_batch\"): 2 (default) = the rank's whole share in ONE call with one random-weighted check, 1 = one check per client, six clients per call")
-    ap.add_argument("--hip-runtime", choices=("process", "system"), default="process",
-                    help="process (default): whatever HIP runtime the process ends up with -- importing torch first maps torch's BUNDLED libamdhip64 (ROCm 7.0) and "
-                         "librofl_zk.so binds to it by soname; system: map /opt/rocm's libamdhip64.so.7 (the runtime a Rust host links) before torch is imported, so the "
-                         "library runs on it while torch keeps its own copy (two runtimes in one process: a measurement mode for N = 1, not for RCCL runs)")
+    ap.add_argument("--hip-runtime", choices=("auto", "process", "system"), default="auto",
+                    help="which HIP runtime librofl_zk.so runs on.  process: whatever the process ends up with -- importing torch first maps torch's BUNDLED "
+                         "libamdhip64 (ROCm 7.0) and the library binds to it by soname; system: /opt/rocm's libamdhip64.so.7 -- the runtime a Rust host links -- "
+                         "is mapped before torch is imported, so the library runs on it while torch keeps its own copy for the contract's torch.cuda.synchronize() "
+                         "(N = 1 only); auto (default): the headline (--config 2, N = 1) runs as a child process in `system` mode and falls back to `process` if that "
+                         "child fails; every other mode is `process`.  profiles/r04_experiments.txt item 13")
     ap.add_argument("--clients", type=int, default=48, help="clients of configs 4 / 5 (cifar_large.yml: 48)")
     return ap.parse_args()
 
@@ -811,20 +821,23 @@ def run_rank(args):
                                               "rofl_verify_rangeproof_batch call from a single host thread"}
         if not args.no_l2:
             out["l2_composite"] = l2_composite(R)
-        if args.hip_runtime == "process" and any("/torch/" in x for x in mapped_hip_runtime()) and os.path.exists("/opt/rocm/lib/libamdhip64.so.7"):
-            # The same K steps in a child process whose library binds to the SYSTEM HIP runtime (what a Rust host links) instead of the one
-            # torch bundles: reported beside the headline, never as `value`.
+        if os.path.exists(SYSTEM_HIP):
+            # The same K steps in a child process on the OTHER HIP runtime (this process: the system runtime a Rust host links, or the one torch
+            # bundles), reported beside the headline, never as `value`.
+            other = "process" if args.hip_runtime == "system" else "system"
+            key = "torch_bundled_hip_runtime" if other == "process" else "system_hip_runtime"
             try:
                 cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--steps", str(K), "--warmup", str(args.warmup), "--n-partition", str(NPART),
-                                     "--hip-runtime", "system", "--no-extras", "--no-cpu-baseline"], capture_output=True, text=True, timeout=300)
+                                     "--hip-runtime", other, "--no-extras", "--no-cpu-baseline"], capture_output=True, text=True, timeout=300)
                 cj = json.loads(cp.stdout.strip().splitlines()[-1])
-                out["system_hip_runtime"] = {"ms_per_step": cj["ms_per_step"], "median_ms_per_step": cj["median_ms_per_step"], "elements_per_s": cj["value"],
-                                             "hip_runtime": cj["config"]["hip_runtime"],
-                                             "note": "NOT the headline: the same K timed steps in a child process with /opt/rocm's libamdhip64.so.7 mapped before torch, so "
-                                                     "librofl_zk.so runs on the system runtime (profiles/r04_experiments.txt item 13: torch's bundled ROCm 7.0 runtime costs ~0.5 ms "
-                                                     "per step and one ~8 ms stall per process)"}
+                out[key] = {"ms_per_step": cj["ms_per_step"], "median_ms_per_step": cj["median_ms_per_step"], "max_ms_per_step": cj["max_ms_per_step"],
+                            "elements_per_s": cj["value"], "hip_runtime": cj["config"]["hip_runtime"],
+                            "note": "NOT the headline: the same K timed steps in a child process whose librofl_zk.so runs on " +
+                                    ("the HIP runtime torch bundles (torch imported first; ROCm 7.0: ~0.5 ms more per step and one ~8 ms stall per process, "
+                                     "profiles/r04_experiments.txt item 13)" if other == "process" else
+                                     "/opt/rocm's libamdhip64.so.7, mapped before torch (profiles/r04_experiments.txt item 13)")}
             except Exception as e:      # a measurement extra: never fails the bench
-                out["system_hip_runtime"] = {"error": repr(e)[:200]}
+                out[key] = {"error": repr(e)[:200]}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, R)
     out["other_configs"] = "bench.py --config 4 | 5 (48 clients sharded over the ranks); profiles/r04_configs.json (scripts/gpu_configs.py): all five BASELINE configs and the e2e partition count P=64, reference bench protocol"
@@ -917,11 +930,28 @@ def main():
     global NPART
     args = parse_args()
     NPART = args.n_partition
+    if args.hip_runtime == "auto":
+        # The headline runs on the runtime the library is deployed on: as a child process (this one never touches the GPU) so that a failure
+        # of the two-runtime arrangement costs a retry, not the bench line.
+        single = args.gpus == 1 and "WORLD_SIZE" not in os.environ and args.config == 2 and not args.one_process
+        if single and os.path.exists(SYSTEM_HIP):
+            try:
+                cp = subprocess.run([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--hip-runtime", "system"], stdout=subprocess.PIPE, text=True, timeout=1500)
+                line = cp.stdout.strip().splitlines()[-1] if cp.stdout.strip() else ""
+                if cp.returncode == 0 and "value" in json.loads(line):
+                    print(line); sys.stdout.flush()
+                    return
+                sys.stderr.write("bench.py: the run on the system HIP runtime ended with %d; repeating on the process's runtime\n" % cp.returncode)
+            except Exception as e:
+                sys.stderr.write("bench.py: the run on the system HIP runtime failed (%r); repeating on the process's runtime\n" % (e,))
+        args.hip_runtime = "process"
     if args.hip_runtime == "system":
-        if args.gpus > 1:
-            sys.stderr.write("bench.py: --hip-runtime system is an N = 1 measurement mode\n"); sys.exit(2)
+        if args.gpus > 1 or "WORLD_SIZE" in os.environ:
+            sys.stderr.write("bench.py: --hip-runtime system is an N = 1 mode\n"); sys.exit(2)
+        if os.environ.get("BENCH_TEST_FAIL_SYSTEM_RUNTIME"):      # tests/test_gpu_dist.py: the fallback of `auto`
+            sys.exit(3)
         import ctypes
-        ctypes.CDLL("/opt/rocm/lib/libamdhip64.so.7", mode=ctypes.RTLD_GLOBAL)      # before anything imports torch
+        ctypes.CDLL(SYSTEM_HIP, mode=ctypes.RTLD_GLOBAL)      # before anything imports torch
     if args.one_process:
         if args.config != 4:
             sys.stderr.write("bench.py: --one-process is a mode of --config 4\n"); sys.exit(2)

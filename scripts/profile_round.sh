@@ -6,7 +6,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-CMD="bench.py --steps 8 --warmup 3 --no-extras"      # the headline only: one client per step (BASELINE cfg 2)
+CMD="bench.py --steps 8 --warmup 3 --no-extras --hip-runtime process"      # the headline only: one client per step (BASELINE cfg 2)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $CMD > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $CMD > /dev/null 2> $OUT/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $CMD > /dev/null 2> $OUT/pmc_write.err

@@ -165,3 +165,20 @@ def test_bench_config4_one_process_two_devices():
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["config"]["devices_mask"] == 3 and line["config"]["clients"] == 4 and line["config"]["verify_batch"] == 2
     assert line["value"] > 0 and line["verify_only_elements_per_s"] > 0 and "one host process" in line["metric"]
+
+
+def test_headline_runs_on_the_system_hip_runtime_and_falls_back():
+    """bench.py (N = 1, --config 2) runs its steps in a child whose librofl_zk.so is bound to /opt/rocm's HIP runtime -- what a compiled host links --
+    with torch's bundled copy beside it for the contract's torch.cuda.synchronize(); if that child fails the bench repeats on the process's runtime."""
+    import json
+    argv = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-extras", "--no-cpu-baseline"]
+    r = subprocess.run(argv, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    libs = j["config"]["hip_runtime"]
+    assert any(x.startswith("/opt/rocm") for x in libs) and j["value"] > 0, libs
+    r = subprocess.run(argv, capture_output=True, text=True, timeout=600, env=dict(os.environ, BENCH_TEST_FAIL_SYSTEM_RUNTIME="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "repeating on the process's runtime" in r.stderr
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    assert not any(x.startswith("/opt/rocm") for x in j["config"]["hip_runtime"]) and j["value"] > 0

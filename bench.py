@@ -66,8 +66,8 @@ def parse_args():
                     help="which HIP runtime librofl_zk.so runs on.  process: whatever the process ends up with -- importing torch first maps torch's BUNDLED "
                          "libamdhip64 (ROCm 7.0) and the library binds to it by soname; system: /opt/rocm's libamdhip64.so.7 -- the runtime a Rust host links -- "
                          "is mapped before torch is imported, so the library runs on it while torch keeps its own copy for the contract's torch.cuda.synchronize() "
-                         "(N = 1 only); auto (default): the headline (--config 2, N = 1) runs as a child process in `system` mode and falls back to `process` if that "
-                         "child fails; every other mode is `process`.  profiles/r04_experiments.txt item 13")
+                         "(N = 1 only); auto (default): an N = 1 run (no process group) happens in a child process in `system` mode and falls back to `process` if that "
+                         "child fails; N > 1 and --one-process are `process`.  profiles/r04_experiments.txt item 13")
     ap.add_argument("--clients", type=int, default=48, help="clients of configs 4 / 5 (cifar_large.yml: 48)")
     return ap.parse_args()
 
@@ -439,7 +439,7 @@ def run_multi_client(args, R, rd, dist, cdev, world, rank, backend):
                                       "proof bytes + commitments -> every rank batch-verifies the share of rank+1 -> MIN all-reduce of the verdicts" % (cfg, kind, NC, world),
                           "d": D_MULTI, "clients": NC, "clients_per_rank": len(mine), "prove_range": NBITS if cfg == 4 else 8, "l2_range": None if cfg == 4 else 32,
                           "n_partition": P, "fp_bits": FP_BITS, "fp_frac": FP_FRAC, "host_cores": avail_cores(), "host_cores_pinned": args.host_cores or None,
-                          "host_cores_busy": round(cpu_busy, 2), "lanes": R.get_option("lanes"), "verify_batch": vbatch if cfg == 4 else None,
+                          "host_cores_busy": round(cpu_busy, 2), "lanes": R.get_option("lanes"), "verify_batch": vbatch if cfg == 4 else None, "hip_runtime": mapped_hip_runtime(),
                           "clients_in_flight_per_rank": (args.multi_inflight if cfg == 5 else ("create: %d batched calls of 6 clients in flight; verify: %s" % (args.multi_inflight if cpool else 1, "ONE call for the rank's whole share, one random-weighted check (verify_batch = 2)" if vbatch == 2 else "batched calls of 6 clients, one check per client")))},
                "breakdown_ms_per_step_rank0": {k: phase[k] / K * 1e3 for k in ("create", "exchange", "verify")},
                "create_only_elements_per_s": len(mine) * D_MULTI / cd if cd else None,
@@ -933,7 +933,7 @@ def main():
     if args.hip_runtime == "auto":
         # The headline runs on the runtime the library is deployed on: as a child process (this one never touches the GPU) so that a failure
         # of the two-runtime arrangement costs a retry, not the bench line.
-        single = args.gpus == 1 and "WORLD_SIZE" not in os.environ and args.config == 2 and not args.one_process
+        single = args.gpus == 1 and "WORLD_SIZE" not in os.environ and not args.one_process      # no process group, no RCCL in such a run
         if single and os.path.exists(SYSTEM_HIP):
             try:
                 cp = subprocess.run([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--hip-runtime", "system"], stdout=subprocess.PIPE, text=True, timeout=1500)

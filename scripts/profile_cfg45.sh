@@ -7,7 +7,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 for c in 4 5; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats$c -- python3 bench.py --config $c --steps 2 --warmup 1 --no-extras > $OUT/bench_cfg${c}_under_rocprof.json 2> $OUT/stats$c.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats$c -- python3 bench.py --config $c --steps 2 --warmup 1 --no-extras --hip-runtime process > $OUT/bench_cfg${c}_under_rocprof.json 2> $OUT/stats$c.err
   cp $(find $OUT/stats$c -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_cfg${c}_kernel_stats.csv
   rm -rf $OUT/stats$c
 done

@@ -108,6 +108,7 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
         fill_pow2(cp.ypow2, cp.y, MAX_LG); fill_pow2(cp.yinvpow2, cp.yinv, MAX_LG); fill_pow2(cp.zpow2, cp.z, MAX_LG);
     });
     C.tm.t.host_ms += now_ms() - th;
+    mark("y z host");
     HIPCHK(hipMemcpyAsync(d_cp, h_cp, sizeof(ChunkParams) * P, hipMemcpyHostToDevice, C.stream));
     // (enough blocks for four waves per SIMD when the chunks are few: 64 per chunk ran a four-chunk client's 1 M slots on 65 536 threads)
     u32 nblkT = (u32)std::min<size_t>(std::max<size_t>(64, std::min<size_t>(256, 2048 / P)), (N + TPB - 1) / TPB);
@@ -119,6 +120,7 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
     HIPCHK(hipMemcpyAsync(h_t, tpart, sizeof(sc) * P * nblkT * 3, hipMemcpyDeviceToHost, C.stream));
     HIPCHK(hipMemcpyAsync(h_sc, scpart, sizeof(sc) * P * nblkS * 3, hipMemcpyDeviceToHost, C.stream));
     C.sync();
+    mark("t kernels");
     th = now_ms();
     C.pool->run(P, [&](size_t c) {
         uint8_t *o = proofs_out[c];
@@ -147,6 +149,7 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
         t.append_u64("n", N);
     });
     C.tm.t.host_ms += now_ms() - th;
+    mark("T x host");
     HIPCHK(hipMemcpyAsync(d_cp, h_cp, sizeof(ChunkParams) * P, hipMemcpyHostToDevice, C.stream));
     sc *a = C.a.as<sc>(P * N), *b = C.b.as<sc>(P * N), *yinvpow = C.yinv.as<sc>(P * N);
     hipLaunchKernelGGL(k_lr_vec, grid1(N, (u32)P), dim3(TPB), 0, C.stream, (u32)n, (u32)m, d_cp, (const PowTabs *)d_pt, d_vshift, sL, sR, C.d_two_pow, a, b, yinvpow);

@@ -20,6 +20,8 @@ static const Knob KNOBS[] = {
     {"ROFL_SIGMA_BATCH", "1", "option sigma_batch: 0 = one check per element in the Sigma-proof verifiers"},
     {"ROFL_STAGE_KEEP_MB", "256", "pinned staging memory a lane keeps between calls (a call that needed more frees it when it ends)"},
     {"ROFL_GENS_LAZY", "1", "0 = the first call of a shape waits for its full fold table (otherwise it is served from the compact table while a background thread builds the full one)"},
+    {"ROFL_GENS_LAZY_IDLE_MS", "20", "the background build of a full fold table starts when no call has been in flight for this long (its allocation stalls every HIP call of the process)"},
+    {"ROFL_GENS_LAZY_MAX_WAIT_MS", "3000", "... or after this long, whichever comes first (a host that never pauses still gets its full table)"},
     {"ROFL_GENS_BUDGET_MB", "98304", "HBM budget of the generator-table cache (LRU eviction of unpinned entries beyond it)"},
     {"ROFL_FOLD_T1", "3", "IPP rounds before the first generator fold (1..6)"},
     {"ROFL_FOLD_T", "2", "IPP rounds between later folds (1..6)"},
@@ -429,6 +431,7 @@ Options &opts() {
 // Calls in flight in the whole process.  The pools' polling is for a call that is alone: with several in flight -- on one device or, in a
 // server that drives N devices, on several -- the pools of the lanes would fight over the host's cores.
 std::atomic<int> g_calls_in_flight{0};
+std::atomic<bool> g_gens_shutdown{false};      // process exit: background table builders that are still waiting for a quiet moment give up
 
 // One Ctx = one "lane": a HIP stream with its own workspace, staging buffers, timing and host pool.  The primary
 // lane of a device owns the shared read-only state (fixed-base tables, generator cache).  An API call runs on one
@@ -837,14 +840,38 @@ GensPin get_gens(Ctx &C, size_t n, size_t m) {
         P0.gens_pending[key] = 1;
         P0.gens_upgrades.emplace_back([&P0, raw, key, fc_full, N] {
             auto unpin = [&] { std::lock_guard<std::mutex> lk(P0.gens_mu); raw->users--; P0.gens_pending.erase(key); };
+            // Wait for a quiet moment: allocating tens of GB holds the runtime's lock for 0.05-0.7 s (every HIP call of the process waits) and the
+            // table kernel then fills the device for ~70 ms -- inside the first call that is the whole gain of the compact table gone again.
+            // A client proves once per training round and a server verifies once per round: pauses are plentiful.  rofl_bp_gens_prepare hurries it.
+            {
+                static const double idle_ms = knob("ROFL_GENS_LAZY_IDLE_MS") ? atof(knob("ROFL_GENS_LAZY_IDLE_MS")) : 20.0;
+                static const double max_ms = knob("ROFL_GENS_LAZY_MAX_WAIT_MS") ? atof(knob("ROFL_GENS_LAZY_MAX_WAIT_MS")) : 3000.0;
+                const double w0 = now_ms(); double quiet_since = -1;
+                for (;;) {
+                    if (g_gens_shutdown.load()) { unpin(); return; }
+                    { std::lock_guard<std::mutex> lk(P0.gens_mu); auto it = P0.gens_pending.find(key); if (it != P0.gens_pending.end() && it->second == 2) break; }      // hurried
+                    const double t = now_ms();
+                    if (t - w0 >= max_ms) break;
+                    if (g_calls_in_flight.load() == 0) { if (quiet_since < 0) quiet_since = t; if (t - quiet_since >= idle_ms) break; } else quiet_since = -1;
+                    struct timespec ts = {0, 1000000}; nanosleep(&ts, nullptr);
+                }
+            }
             if (hipSetDevice(P0.phys) != hipSuccess) { unpin(); return; }
             const size_t bytes = sizeof(niels) * 2 * N * fc_full.np * fc_full.e;
             void *tv = nullptr; hipStream_t bs = nullptr;
+            const bool btrace = knob("ROFL_TRACE") && atoi(knob("ROFL_TRACE")) >= 2; const double bt0 = now_ms();
             if (hipMalloc(&tv, bytes) != hipSuccess) { (void)hipGetLastError(); unpin(); return; }      // HBM is short: the compact table stays
-            bool ok = hipStreamCreateWithFlags(&bs, hipStreamNonBlocking) == hipSuccess;
+            if (btrace) fprintf(stderr, "[rofl-trace gens-upgrade] hipMalloc of %.1f GB +%.3f ms\n", bytes / 1e9, now_ms() - bt0);
+            // the builder's one large launch runs at the LOWEST stream priority: the proofs that are served from the compact table meanwhile keep
+            // getting their workgroups dispatched (at equal priority the first create of a fresh process waited ~65 ms behind it)
+            int prio_least = 0, prio_greatest = 0;
+            (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+            bool ok = hipStreamCreateWithPriority(&bs, hipStreamNonBlocking, prio_least) == hipSuccess;
+            if (!ok) { (void)hipGetLastError(); bs = nullptr; ok = hipStreamCreateWithFlags(&bs, hipStreamNonBlocking) == hipSuccess; }
             ok = ok && hipMemcpyAsync(tv, raw->tbl, sizeof(niels) * 2 * N, hipMemcpyDeviceToDevice, bs) == hipSuccess;
             if (ok) { hipLaunchKernelGGL(k_gens_tables, grid1(2 * N * fc_full.np), dim3(TPB), 0, bs, (u32)(2 * N), fc_full, reinterpret_cast<niels *>(tv), (size_t)(2 * N)); ok = hipStreamSynchronize(bs) == hipSuccess; }
             if (bs) (void)hipStreamDestroy(bs);
+            if (btrace) fprintf(stderr, "[rofl-trace gens-upgrade] table built at +%.3f ms\n", now_ms() - bt0);
             std::lock_guard<std::mutex> lk(P0.gens_mu);
             raw->users--; P0.gens_pending.erase(key);
             auto it = P0.gens.find(key);
@@ -864,10 +891,10 @@ GensPin get_gens(Ctx &C, size_t n, size_t m) {
 void gens_wait_full(Ctx &C, size_t n, size_t m) {
     Ctx &P0 = C.parent ? *C.parent : C;
     for (;;) {
-        { std::lock_guard<std::mutex> lk(P0.gens_mu); if (!P0.gens_pending.count(std::make_pair(n, m))) return; }
+        { std::lock_guard<std::mutex> lk(P0.gens_mu); auto it = P0.gens_pending.find(std::make_pair(n, m)); if (it == P0.gens_pending.end()) return; it->second = 2; }      // 2 = somebody is waiting: build now
         struct timespec ts = {0, 500000}; nanosleep(&ts, nullptr);
     }
 }
 // the background builders are joined before the process tears the HIP runtime down
-struct GensUpgradeJoiner { ~GensUpgradeJoiner() { std::vector<std::thread> ts; { std::lock_guard<std::mutex> lk(g_ctx_mu); for (auto &kv : g_ctxs) for (auto &t : kv.second->gens_upgrades) ts.push_back(std::move(t)); }
+struct GensUpgradeJoiner { ~GensUpgradeJoiner() { g_gens_shutdown.store(true); std::vector<std::thread> ts; { std::lock_guard<std::mutex> lk(g_ctx_mu); for (auto &kv : g_ctxs) for (auto &t : kv.second->gens_upgrades) ts.push_back(std::move(t)); }
                                                   for (auto &t : ts) if (t.joinable()) t.join(); } } g_gens_upgrade_joiner;

@@ -67,8 +67,8 @@ int rofl_last_error(char *buf, size_t len);            /* human-readable text of
 /* BulletproofGens::new(n_bits, m) (generators.rs; re-run by the reference on every helper call,
  * range_proof_vec/mod.rs:126,201) -- built once on the device and cached per (n_bits, m).  When this call returns the shape's tables are
  * complete: a server calls it at start-up.  A create / verify call that meets a new shape does not wait for the large fold table (tens of
- * GB at the paper's sizes: its allocation alone can take most of a second): it is served from a compact table at once while a background
- * thread builds the full one and swaps it in. */
+ * GB at the paper's sizes: its allocation alone can take most of a second): it is served from a compact table at once, and a background
+ * thread builds the full one in the first quiet moment (no call in flight for 20 ms; after 3 s at the latest) and swaps it in. */
 int rofl_bp_gens_prepare(size_t n_bits, size_t m);
 /* HBM held by the cached tables of (n_bits, m): generators + fold slices + window slices; 0 if they have not been built */
 int rofl_bp_gens_table_bytes(size_t n_bits, size_t m, size_t *bytes_out);

@@ -43,6 +43,7 @@ struct MsmJob {
     MsmWs *ws = nullptr; size_t np = 0, nq = 0, n = 0, PW = 0; MsmPlan P{}; MsmKind kind = MsmKind::CountSort; bool lr = false, two = false, dev_horner = false;
     bool host8 = false;      // dev_horner launches whose chains come back to the host, eight per SIMD stream (k_msm_wsum + h8::horner8)
     u32 sets = 0, cap = 0;
+    u32 small_group = 1;     // fused small launch: windows of a problem per block (4 at c = 7 with thousands of bucket arrays: n_partition = 64)
     bool fb() const { return kind == MsmKind::FixedBase; }
 };
 static const u32 MSM_OVF_MAX = 4096;
@@ -122,6 +123,16 @@ bool msm_plan_job(Ctx &C, MsmJob &J, const MsmOpt &opt, const MsmAllow &al, MsmM
     size_t small_lds = std::max((size_t)J.P.B * 4 * (1 + small_cap), std::max(((size_t)(J.P.B / 8) * 4 + (size_t)(J.P.B / 16) * 5 + 1) * sizeof(ge), ((size_t)J.P.B + (size_t)J.P.B * 3 / 4 + 1) * sizeof(ge)));
     bool small = slots_mode && al.small && C.msm_small_max && per_side <= C.msm_small_max && J.P.c <= 10 && per_side <= 16 * J.P.B && (J.PW <= 512 || small_lds <= 24 * 1024);
     J.kind = small ? MsmKind::Small : slots_mode ? MsmKind::Slots : MsmKind::CountSort;
+    // Thousands of one-wave blocks (c = 7: 64 buckets, one (problem, window) each -- n_partition = 64 runs 128 problems x 37 windows per round)
+    // are bound by instruction issue, and a wave works as long as its FULLEST bucket (mean load 2-4, maximum ~14): four windows of a problem
+    // share a block of four waves, their 256 buckets are sorted by load so that every wave gets buckets of similar depth (14 + 5 + 3 + 2
+    // additions instead of 4 x 14), and the four bit-sum trees run side by side in the same lanes (ROFL_MSM_SMALL_GROUP=1: one window per block).
+    J.small_group = 1;
+    if (small && J.P.B == 64 && J.PW > 512) {
+        static const u32 grp = knob("ROFL_MSM_SMALL_GROUP") ? (u32)std::max(1, std::min(4, atoi(knob("ROFL_MSM_SMALL_GROUP")))) : 4u;
+        J.small_group = grp == 3 ? 2 : grp;
+        if (J.small_group > 1 && per_side <= 2 * J.P.B) small_cap = 28;      // mean load <= 4 in the half-filled windows: P(> 28) ~ 1e-15 per bucket; 4 x 64 lists of 28 = 29 KB of LDS
+    }
     if (J.kind == MsmKind::Slots && (size_t)J.PW * J.P.B * J.cap * 4 > ((size_t)8 << 30)) return false;
     return true;
 }
@@ -174,24 +185,33 @@ MsmJob msm_enqueue(Ctx &C, MsmWs &W, const std::vector<MsmProb> &probs, size_t n
     if (J.kind == MsmKind::Small) {
         ge *S_fin_s = J.dev_horner ? W.S[0].as<ge>(PW) : hres_dev;
         ge *C_fin_s = J.dev_horner ? W.Cacc[0].as<ge>(PW * (size_t)nb_final) : hres_dev + PW;
-        size_t lds_lists = (size_t)P.B * 4 * (1 + small_cap);
-        size_t lds_red = std::max(((size_t)(P.B / 8) * 4 + (size_t)(P.B / 16) * 5 + 1) * sizeof(ge), ((size_t)P.B + (size_t)P.B * 3 / 4 + 1) * sizeof(ge));      // fused / binary reduction trees
+        const u32 G = J.small_group;
+        size_t lds_lists = (size_t)G * P.B * 4 * (1 + small_cap);
+        size_t lds_red = G > 1 ? ((size_t)G * P.B * 3 / 4 + 1) * sizeof(ge)      // in-place trees over G windows
+                               : std::max(((size_t)(P.B / 8) * 4 + (size_t)(P.B / 16) * 5 + 1) * sizeof(ge), ((size_t)P.B + (size_t)P.B * 3 / 4 + 1) * sizeof(ge));      // fused / binary reduction trees
         uint64_t items = (uint64_t)np * n_side * P.W;
         KSpan ks(C.tm, st, ROFL_TK_MSM_SMALL, items * 7 + (uint64_t)PW * P.B * 10, (uint64_t)np * n_side * (32 + 96));
         static const bool small_tl = knob("ROFL_DBG_SMALL_TIMELINE") != nullptr;
         unsigned long long *tl_dev = nullptr;
         if (small_tl) { HIPCHK(hipMalloc(&tl_dev, PW * 32)); HIPCHK(hipMemsetAsync(tl_dev, 0, PW * 32, st)); }
         if (opt.pts_ready) HIPCHK(hipStreamWaitEvent(st, opt.pts_ready, 0));
-        hipLaunchKernelGGL(k_msm_small, dim3((unsigned)PW), dim3(P.B < 64 ? 64 : P.B), std::max(lds_lists, lds_red), st, n_side, mw, mm, d_probs, buckets,
-                           S_fin_s, C_fin_s, nb_final, d_flag, small_cap, tl_dev, J.host8 ? hres_dev : (ge *)nullptr,
-                           lr ? opt.ip_dev : (const sc *)nullptr, opt.ip_nblk, lr ? opt.qpts : (const niels *)nullptr);
+        const u32 Wg = (P.W + G - 1) / G;      // blocks per problem
+        if (G > 1)
+            hipLaunchKernelGGL(k_msm_small_g, dim3((unsigned)(np * Wg)), dim3(G * P.B), std::max(lds_lists, lds_red), st, n_side, mw, mm, d_probs, buckets,
+                               S_fin_s, C_fin_s, nb_final, d_flag, small_cap, G, tl_dev, J.host8 ? hres_dev : (ge *)nullptr,
+                               lr ? opt.ip_dev : (const sc *)nullptr, opt.ip_nblk, lr ? opt.qpts : (const niels *)nullptr);
+        else
+            hipLaunchKernelGGL(k_msm_small, dim3((unsigned)PW), dim3(P.B < 64 ? 64 : P.B), std::max(lds_lists, lds_red), st, n_side, mw, mm, d_probs, buckets,
+                               S_fin_s, C_fin_s, nb_final, d_flag, small_cap, G, tl_dev, J.host8 ? hres_dev : (ge *)nullptr,
+                               lr ? opt.ip_dev : (const sc *)nullptr, opt.ip_nblk, lr ? opt.qpts : (const niels *)nullptr);
         if (small_tl) {      // mean phase durations over the blocks of this launch (100 MHz clock)
             std::vector<unsigned long long> hts(PW * 4);
             HIPCHK(hipMemcpyAsync(hts.data(), tl_dev, PW * 32, hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st)); HIPCHK(hipFree(tl_dev));
             double ph[3] = {0, 0, 0}; unsigned long long t_lo = ~0ull, t_hi = 0;
-            for (size_t b = 0; b < PW; b++) { for (int k = 0; k < 3; k++) ph[k] += (double)(hts[b * 4 + k + 1] - hts[b * 4 + k]); t_lo = std::min(t_lo, hts[b * 4]); t_hi = std::max(t_hi, hts[b * 4 + 3]); }
-            fprintf(stderr, "[rofl] k_msm_small PW=%zu n_side=%u c=%u: rank %.1f us, bucket sums %.1f us, reduce %.1f us (block means); first start -> last end %.1f us\n",
-                    PW, n_side, P.c, ph[0] / PW * 0.01, ph[1] / PW * 0.01, ph[2] / PW * 0.01, (double)(t_hi - t_lo) * 0.01);
+            const size_t nblocks = G > 1 ? np * Wg : PW;
+            for (size_t b = 0; b < nblocks; b++) { for (int k = 0; k < 3; k++) ph[k] += (double)(hts[b * 4 + k + 1] - hts[b * 4 + k]); t_lo = std::min(t_lo, hts[b * 4]); t_hi = std::max(t_hi, hts[b * 4 + 3]); }
+            fprintf(stderr, "[rofl] k_msm_small PW=%zu blocks=%zu n_side=%u c=%u: rank %.1f us, bucket sums %.1f us, reduce %.1f us (block means); first start -> last end %.1f us\n",
+                    PW, nblocks, n_side, P.c, ph[0] / nblocks * 0.01, ph[1] / nblocks * 0.01, ph[2] / nblocks * 0.01, (double)(t_hi - t_lo) * 0.01);
         }
         if (J.host8) {}      // (the launch added up each window's bit-sums itself)
         else if (J.dev_horner) hipLaunchKernelGGL(k_msm_horner, dim3((unsigned)np), dim3(256), 0, st, mw, (const ge *)S_fin_s, (const ge *)C_fin_s, nb_final, hres_dev);

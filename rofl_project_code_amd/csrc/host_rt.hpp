@@ -51,6 +51,7 @@ static const Knob KNOBS[] = {
     {"ROFL_MSM_LDS_MIN", "8192", "MSMs with fewer terms use the per-item slot sort"},
     {"ROFL_MSM_LDS_TILE", "131072", "items one block of the LDS slot sort ranks"},
     {"ROFL_MSM_SMALL_MAX", "8192", "terms per side up to which a generic MSM runs as one fused launch (0 = off)"},
+    {"ROFL_MSM_SMALL_GROUP", "4", "windows of a problem per block of the fused launch at c = 7 with more than 512 bucket arrays (1 = one window per one-wave block, 2, 4)"},
     {"ROFL_MERLIN_X8", "1", "0 = the verifier hashes every chunk's transcript prefix on its own even when the host has AVX-512 (eight chunks per instruction stream otherwise, from 32 chunks on)"},
     {"ROFL_MSM_HOST8", "1", "0 = launches with many problems combine their windows on the device (k_msm_horner) even when the host has AVX-512 IFMA"},
     {"ROFL_MSM_HOST8_MIN", "8", "launches with at least this many problems run their window chains eight per AVX-512 IFMA stream on the host (when the CPU has it)"},

@@ -1576,6 +1576,91 @@ __device__ __forceinline__ void msm_reduce_binary_body(u32 E, const ge *si_g, ge
         si = so; ci = co; E = E2; nb += 1; sel ^= 1;
     }
 }
+// msm_reduce_binary_body for G bucket arrays of E buckets side by side (G * E threads): the arrays are treated as ONE array of G * E entries --
+// a pair (2g, 2g + 1) never straddles two trees because E is a power of two -- so the lanes that a single 64-bucket tree leaves idle from its
+// second level on carry the other trees (four windows: ~6 + 9 wave-level additions instead of 4 x (3 + 3)).  LDS is what limits the blocks per CU
+// here, so (a) the first two levels are taken straight from the bucket arrays in global memory (S2[g] = b[4g] + .. + b[4g+3], bit-sum 0 =
+// b[4g+1] + b[4g+3], bit-sum 1 = b[4g+2] + b[4g+3]: the level-1 state is never stored) and (b) every later level works IN PLACE (read, barrier,
+// write): 3/4 G E entries instead of 7/4 G E.  The last level (one entry per tree, bit-sum-major) is stored window-major, and only for the
+// `gv` <= G arrays that exist (the spare ones read the last real array again: defined values, discarded).
+__device__ __forceinline__ void msm_binary_level_inplace(u32 E, u32 nb, ge *buf) {      // S[E] | C[nb][E]  ->  S[E/2] | C[nb + 1][E/2], same buffer
+    const u32 E2 = E / 2, items = E2 * (1 + nb);
+    const ge *si = buf, *ci = buf + E;
+    if (items * 4 <= blockDim.x) {
+        const u32 item = threadIdx.x >> 2, q = threadIdx.x & 3;
+        const bool on = item < items;
+        const u32 role = on ? item / E2 : 0, g = on ? item % E2 : 0;
+        fe res, hi;
+        if (on) {
+            const ge *pa, *pb;
+            if (role == 0) { pa = &si[2 * g]; pb = &si[2 * g + 1]; }
+            else { const ge *cc = ci + (size_t)(role - 1) * E; pa = &cc[2 * g]; pb = &cc[2 * g + 1]; }
+            const fe fa = reinterpret_cast<const fe *>(pa)[q]; hi = reinterpret_cast<const fe *>(pb)[q];
+            gq a, b; a.v = fd_unpack(fa); b.v = fd_unpack(hi);
+            res = fd_pack(gq_add(a, b, q).v);
+        }
+        __syncthreads();
+        if (on) {
+            ge *so = buf, *co = buf + E2;
+            ge *dst = role == 0 ? &so[g] : &co[(size_t)(role - 1) * E2 + g];
+            reinterpret_cast<fe *>(dst)[q] = res;
+            if (role == 0) reinterpret_cast<fe *>(&co[(size_t)nb * E2 + g])[q] = hi;
+        }
+        __syncthreads();
+        return;
+    }
+    // one item per thread (items <= blockDim for the callers of this function: E <= blockDim / 2 ... checked by the caller's geometry)
+    const u32 item = threadIdx.x;
+    const bool on = item < items;
+    const u32 role = on ? item / E2 : 0, g = on ? item % E2 : 0;
+    ge res, hi;
+    if (on) {
+        const ge *cc = role == 0 ? si : ci + (size_t)(role - 1) * E;
+        const ge lo = cc[2 * g]; hi = cc[2 * g + 1];
+        res = gd_pack(gd_add(gd_unpack(lo), gd_unpack(hi)));
+    }
+    __syncthreads();
+    if (on) {
+        ge *so = buf, *co = buf + E2;
+        if (role == 0) { so[g] = res; co[(size_t)nb * E2 + g] = hi; }
+        else co[(size_t)(role - 1) * E2 + g] = res;
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void msm_reduce_binary_multi(u32 E, u32 G, u32 gv, const ge *si_g, ge *fin_s, ge *fin_c, u32 nb_final, unsigned char *smem) {
+    ge *buf = reinterpret_cast<ge *>(smem);
+    const u32 Et = G * E, E4 = Et / 4;                             // (blockDim == Et; E >= 8)
+    // levels 1 + 2 from global memory, one addition deep each: A[g] = b[4g] + b[4g+1] (-> S slot), bit-sum 0, bit-sum 1; then S2[g] = A[g] + bit-sum 1
+    {
+        const u32 item = threadIdx.x;
+        if (item < 3 * E4) {
+            const u32 role = item / E4, g = item % E4;
+            const u32 tree = (4 * g) / E, in_tree = (4 * g) % E, src_tree = tree < gv ? tree : gv - 1;
+            const ge *b = si_g + (size_t)src_tree * E + in_tree;
+            const ge x = load_ge(&b[role == 0 ? 0 : role == 1 ? 1 : 2]), y = load_ge(&b[role == 0 ? 1 : 3]);
+            buf[(size_t)role * E4 + g] = gd_pack(gd_add(gd_unpack(x), gd_unpack(y)));      // [0] A | [1] bit-sum 0 | [2] bit-sum 1
+        }
+        __syncthreads();
+        if (4 * E4 <= blockDim.x) {                                 // S2 = A + bit-sum 1, four lanes per entry
+            const u32 g = threadIdx.x >> 2, q = threadIdx.x & 3;
+            if (g < E4) {
+                gq a, c; a.v = fd_unpack(reinterpret_cast<const fe *>(&buf[g])[q]); c.v = fd_unpack(reinterpret_cast<const fe *>(&buf[(size_t)2 * E4 + g])[q]);
+                reinterpret_cast<fe *>(&buf[g])[q] = fd_pack(gq_add(a, c, q).v);      // (entry g is read and written by its own quad only)
+            }
+        } else {
+            for (u32 g = threadIdx.x; g < E4; g += blockDim.x) buf[g] = gd_pack(gd_add(gd_unpack(buf[g]), gd_unpack(buf[(size_t)2 * E4 + g])));
+        }
+        __syncthreads();
+    }
+    u32 nb = 2, Ecur = E4;                                         // entries of the concatenated array; Ecur / G per tree
+    while (Ecur > G) { msm_binary_level_inplace(Ecur, nb, buf); Ecur /= 2; nb += 1; }
+    // buf: S[G] | C[nb][G]  (nb == nb_final == log2 E)
+    for (u32 item = threadIdx.x; item < gv * (1 + nb); item += blockDim.x) {
+        const u32 g = item / (1 + nb), l = item % (1 + nb);
+        if (l == 0) store_ge(&fin_s[g], buf[g]);
+        else if (l - 1 < nb_final) store_ge(&fin_c[(size_t)g * nb_final + (l - 1)], buf[(size_t)G + (size_t)(l - 1) * G + g]);
+    }
+}
 // A small MSM (the IPP tail: a few thousand terms per problem) in ONE launch instead of memset / scatter / scan / accumulate /
 // overflow / reduce: block = one (problem, window) bucket array (generic window layout, c <= 10).  The window's digits are
 // ranked into per-bucket lists in LDS (SMALL_CAP entries each), thread b sums bucket b's points in a uniform loop, the buckets
@@ -1584,33 +1669,44 @@ __device__ __forceinline__ void msm_reduce_binary_body(u32 E, const ge *si_g, ge
 #define MSM_SMALL_CAP 64      /* list entries per bucket at a mean load <= 16 (n_side <= 8 B, narrow windows fill half of the buckets): P(overflow) ~ 1e-18 per bucket */
 #define MSM_SMALL_CAP_MAX 80  /* upper bound of the run-time `cap` (72 at n_side <= 16 B: mean load <= 32, P(overflow) ~ 1e-12) */
 #if ROFL_KG(1)
-__global__ void __launch_bounds__(512) k_msm_small(u32 n_side, MsmWin mw, MsmMap mm, const MsmProb *probs, ge *buckets, ge *S_fin, ge *C_fin,
-                                                   u32 nb_final, u32 *overflow, u32 cap, unsigned long long *dbg, ge *wsum_out,
-                                                   const sc *ip_dev, u32 ip_nblk, const niels *qpts) {
-    extern __shared__ __align__(16) unsigned char smem[];
+__device__ __forceinline__ void msm_small_body(unsigned char *smem, u32 n_side, MsmWin mw, MsmMap mm, const MsmProb *probs, ge *buckets, ge *S_fin, ge *C_fin,
+                                               u32 nb_final, u32 *overflow, u32 cap, u32 G, unsigned long long *dbg, ge *wsum_out,
+                                               const sc *ip_dev, u32 ip_nblk, const niels *qpts) {
     // debugging aid (ROFL_DBG_SMALL_TIMELINE): 100 MHz wall-clock stamps of the block's phases -- start, ranked, buckets summed, reduced
     auto stamp = [&](int k) { if (dbg && threadIdx.x == 0) dbg[(size_t)blockIdx.x * 4 + k] = wall_clock64(); };
     stamp(0);
     const u32 B = 1u << (mw.c - 1);
-    u32 pw = blockIdx.x, p = pw / mw.W, w = pw % mw.W;
+    // G = 1: block = one (problem, window).  G > 1 (c = 7, thousands of arrays): block = G consecutive windows of a problem, G * B threads;
+    // "virtual bucket" vb = g * B + b is bucket b of window w0 + g.  The last block of a problem may hold fewer than G windows: its spare
+    // virtual buckets stay empty and nothing of them is stored.
+    const u32 Wg = (mw.W + G - 1) / G;
+    const u32 p = G > 1 ? blockIdx.x / Wg : blockIdx.x / mw.W, w0 = G > 1 ? (blockIdx.x % Wg) * G : blockIdx.x % mw.W;
+    const u32 gv = min(G, mw.W - w0);                                // windows this block really holds
+    const u32 pw = p * mw.W + w0;                                    // bucket array of the block's first window
+    const u32 VB = G * B;
     u32 side = mm.lr_nh ? (p & 1u) : 0u;
-    u32 *lcnt = reinterpret_cast<u32 *>(smem);                       // [B]
-    u32 *lst = lcnt + B;                                             // [B][cap]: term index | sign
-    for (u32 b = threadIdx.x; b < B; b += blockDim.x) lcnt[b] = 0;
+    u32 *lcnt = reinterpret_cast<u32 *>(smem);                       // [VB]
+    u32 *lst = lcnt + VB;                                            // [VB][cap]: term index | sign
+    for (u32 b = threadIdx.x; b < VB; b += blockDim.x) lcnt[b] = 0;
     __syncthreads();
-    u32 wpos, wwid; msm_window(mw, w, wpos, wwid);
     const sc *scal = probs[p].scal;
-    for (u32 k = threadIdx.x; k < n_side; k += blockDim.x) {
-        u32 i = mm.lr_nh ? msm_side_term(mm, side, k) : k;
-        int d = msm_digit_mem(reinterpret_cast<const u32 *>(&scal[i]), wpos, wwid);
-        u32 ad = (u32)(d < 0 ? -d : d), entry = i | (d < 0 ? 0x80000000u : 0u);
+    auto put = [&](const u32 *kw, u32 g, u32 entry_idx) {            // the digit of window w0 + g of the scalar at kw -> that window's bucket list
+        u32 wpos, wwid; msm_window(mw, w0 + g, wpos, wwid);
+        int d = msm_digit_mem(kw, wpos, wwid);
+        u32 ad = (u32)(d < 0 ? -d : d), entry = entry_idx | (d < 0 ? 0x80000000u : 0u);
         for (int rep = 0; rep < 2; rep++) {
             u32 a1 = rep == 0 ? (ad > B ? B : 0u) : (ad > B ? ad - B : ad);
             if (!a1) continue;
-            u32 pos = atomicAdd(&lcnt[a1 - 1], 1u);
-            if (pos < cap) lst[(a1 - 1) * cap + pos] = entry;
+            u32 vb = g * B + a1 - 1;
+            u32 pos = atomicAdd(&lcnt[vb], 1u);
+            if (pos < cap) lst[vb * cap + pos] = entry;
             else *(volatile u32 *)overflow = 1u;          // mapped host memory: a plain store (idempotent)
         }
+    };
+    for (u32 k = threadIdx.x; k < n_side; k += blockDim.x) {
+        u32 i = mm.lr_nh ? msm_side_term(mm, side, k) : k;
+        const u32 *kw = reinterpret_cast<const u32 *>(&scal[i]);
+        for (u32 g = 0; g < gv; g++) put(kw, g, i);
     }
     // One more term for the L / R problems of an inner-product round: c_side * Q with Q = w B (upstream's <a_L, b_R> Q) -- c_side is the sum of
     // the partial inner products the round's k_ipp_round launch left in device memory, Q the chunk's point.  The host added this term with a
@@ -1620,31 +1716,25 @@ __global__ void __launch_bounds__(512) k_msm_small(u32 n_side, MsmWin mw, MsmMap
         sc acc = sc_zero();
         for (u32 b = 0; b < ip_nblk; b++) acc = sc_add(acc, load_sc(&ip_dev[((size_t)(p >> 1) * ip_nblk + b) * 2 + (p & 1u)]));
         sc cs = sc_from_mont(acc);
-        int d = msm_digit_mem(reinterpret_cast<const u32 *>(&cs), wpos, wwid);
-        u32 ad = (u32)(d < 0 ? -d : d), entry = QIDX | (d < 0 ? 0x80000000u : 0u);
-        for (int rep = 0; rep < 2; rep++) {
-            u32 a1 = rep == 0 ? (ad > B ? B : 0u) : (ad > B ? ad - B : ad);
-            if (!a1) continue;
-            u32 pos = atomicAdd(&lcnt[a1 - 1], 1u);
-            if (pos < cap) lst[(a1 - 1) * cap + pos] = entry;
-            else *(volatile u32 *)overflow = 1u;
-        }
+        for (u32 g = 0; g < gv; g++) put(reinterpret_cast<const u32 *>(&cs), g, QIDX);
     }
     __syncthreads();
     stamp(1);
     const niels *pts = probs[p].pts;
     const niels *qpt = qpts ? qpts + (p >> 1) : pts;
     auto fetch = [&](u32 v) { const u32 i = v & 0x7fffffffu; return gload_nd(i == QIDX ? qpt : &pts[i]); };
-    // Balance the bucket sums over the block's waves (blockDim == B = 512: 8 waves, two per SIMD).  A wave runs as long as its fullest
-    // bucket (mean 4 entries, ~10 in every wave of 64 unsorted buckets); with the buckets sorted by load, wave w < 4 takes the w-th
-    // heaviest group of 64 and its SIMD partner w + 4 the (7 - w)-th: every SIMD sees ~11 additions' worth of issue instead of ~20.
+    // Balance the bucket sums over the block's waves.  A wave runs as long as its fullest bucket (mean 4 entries, ~10 in every wave of 64
+    // unsorted buckets); with the buckets sorted by load every wave gets buckets of similar depth.  blockDim == B = 512 (8 waves, two per
+    // SIMD): wave w < 4 takes the w-th heaviest group of 64 and its SIMD partner w + 4 the (7 - w)-th -- every SIMD sees ~11 additions' worth
+    // of issue instead of ~20.  G windows of 64 buckets (G waves, one per SIMD): each wave takes one of the G groups of 64 of the load order.
     u32 my_b = threadIdx.x;
-    if (blockDim.x == 512 && B == 512) {
+    const bool sorted = (blockDim.x == 512 && B == 512) || G > 1;
+    if (sorted) {
         __shared__ u32 chist[MSM_SMALL_CAP_MAX + 2], cbase[MSM_SMALL_CAP_MAX + 2];
         __shared__ unsigned short order[512];
         if (threadIdx.x < MSM_SMALL_CAP_MAX + 2) chist[threadIdx.x] = 0;
         __syncthreads();
-        u32 mycnt = lcnt[threadIdx.x]; if (mycnt > cap) mycnt = cap;
+        u32 mycnt = lcnt[threadIdx.x]; if (mycnt > cap) mycnt = cap;      // (blockDim == VB: one virtual bucket per thread)
         u32 rank_in = atomicAdd(&chist[mycnt], 1u);
         __syncthreads();
         if (threadIdx.x == 0) { u32 run = 0; for (int cval = (int)cap; cval >= 0; cval--) { cbase[cval] = run; run += chist[cval]; } }      // descending load
@@ -1652,45 +1742,62 @@ __global__ void __launch_bounds__(512) k_msm_small(u32 n_side, MsmWin mw, MsmMap
         order[cbase[mycnt] + rank_in] = (unsigned short)threadIdx.x;
         __syncthreads();
         u32 wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
-        u32 grp = wv < 4 ? wv : 11 - wv;
+        // (G waves, one per SIMD: the blocks that share a CU rotate the assignment, otherwise wave 0 of every block -- the deepest buckets -- would
+        //  land on the same SIMD)
+        u32 grp = G > 1 ? (wv + blockIdx.x) % G : (wv < 4 ? wv : 11 - wv);
         my_b = order[grp * 64 + ln];
     }
-    for (u32 b = my_b; b < B; b += blockDim.x) {
-        u32 num = lcnt[b]; if (num > cap) num = cap;
+    for (u32 vb = my_b; vb < VB; vb += blockDim.x) {
+        u32 num = lcnt[vb]; if (num > cap) num = cap;
         gd acc = gd_identity();
         // the next point is in flight while the current one is added (the block runs at 2 waves/SIMD: registers are not the limit here,
         // the gather latency in front of every addition was)
-        u32 v = num ? lst[b * cap] : 0u;
+        u32 v = num ? lst[vb * cap] : 0u;
         nd nxt = fetch(v);
         for (u32 e = 0; e < num; e++) {
             nd q = nxt; bool ng = (v >> 31) != 0;
-            if (e + 1 < num) { v = lst[b * cap + e + 1]; nxt = fetch(v); }
+            if (e + 1 < num) { v = lst[vb * cap + e + 1]; nxt = fetch(v); }
             acc = gd_madd(acc, q, ng);
         }
-        store_gd(&buckets[(size_t)pw * B + b], acc);
+        if (vb < gv * B) store_gd(&buckets[(size_t)pw * B + vb], acc);      // (consecutive windows of a problem are consecutive bucket arrays)
     }
     __threadfence_block();
     __syncthreads();
     stamp(2);
-    if (B >= 16) msm_reduce_binary_body(B, buckets + (size_t)pw * B, S_fin + pw, C_fin + (size_t)pw * nb_final, smem);
+    if (G > 1) msm_reduce_binary_multi(B, G, gv, buckets + (size_t)pw * B, S_fin + pw, C_fin + (size_t)pw * nb_final, nb_final, smem);
+    else if (B >= 16) msm_reduce_binary_body(B, buckets + (size_t)pw * B, S_fin + pw, C_fin + (size_t)pw * nb_final, smem);
     else msm_reduce_fused_body(B, 0, buckets + (size_t)pw * B, nullptr, S_fin + pw, C_fin + (size_t)pw * nb_final, smem);
     stamp(3);
-    // launches whose window chains go to the host eight per SIMD stream (k_msm_wsum's job, without a launch of its own): one quad adds up
-    // this window's bit-sums, W = S + sum_l 2^l D_l, and hands the host ONE point per (problem, window)
+    // launches whose window chains go to the host eight per SIMD stream (k_msm_wsum's job, without a launch of its own): one quad per window adds
+    // up the window's bit-sums, W = S + sum_l 2^l D_l, and hands the host ONE point per (problem, window)
     if (wsum_out) {
         __threadfence_block();
         __syncthreads();
-        if (threadIdx.x < 4) {
-            const u32 q = threadIdx.x;
+        if (threadIdx.x < 4 * gv) {
+            const u32 q = threadIdx.x & 3, g = threadIdx.x >> 2;
             auto coord = [&](const ge *pt) { gq r; r.v = fd_unpack(reinterpret_cast<const fe *>(pt)[q]); return r; };
-            const ge *cf = C_fin + (size_t)pw * nb_final;
+            const ge *cf = C_fin + (size_t)(pw + g) * nb_final;
             gq acc = coord(&cf[nb_final - 1]);
 #pragma unroll 1
             for (int l = (int)nb_final - 2; l >= 0; l--) acc = gq_add(gq_double(acc, q), coord(&cf[l]), q);
-            acc = gq_add(acc, coord(&S_fin[pw]), q);
-            reinterpret_cast<fe *>(&wsum_out[pw])[q] = fd_pack(acc.v);
+            acc = gq_add(acc, coord(&S_fin[pw + g]), q);
+            reinterpret_cast<fe *>(&wsum_out[pw + g])[q] = fd_pack(acc.v);
         }
     }
+}
+__global__ void __launch_bounds__(512) k_msm_small(u32 n_side, MsmWin mw, MsmMap mm, const MsmProb *probs, ge *buckets, ge *S_fin, ge *C_fin,
+                                                   u32 nb_final, u32 *overflow, u32 cap, u32 G, unsigned long long *dbg, ge *wsum_out,
+                                                   const sc *ip_dev, u32 ip_nblk, const niels *qpts) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    msm_small_body(smem, n_side, mw, mm, probs, buckets, S_fin, C_fin, nb_final, overflow, cap, G, dbg, wsum_out, ip_dev, ip_nblk, qpts);
+}
+// the same body for blocks of G windows x 64 buckets (256 threads): compiled for four waves per SIMD, so that four of these blocks share a CU
+// (the 512-thread form above is compiled for two; thousands of small blocks want the occupancy, not the registers)
+__global__ void __launch_bounds__(256, 4) k_msm_small_g(u32 n_side, MsmWin mw, MsmMap mm, const MsmProb *probs, ge *buckets, ge *S_fin, ge *C_fin,
+                                                        u32 nb_final, u32 *overflow, u32 cap, u32 G, unsigned long long *dbg, ge *wsum_out,
+                                                        const sc *ip_dev, u32 ip_nblk, const niels *qpts) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    msm_small_body(smem, n_side, mw, mm, probs, buckets, S_fin, C_fin, nb_final, overflow, cap, G, dbg, wsum_out, ip_dev, ip_nblk, qpts);
 }
 #endif
 

@@ -168,6 +168,8 @@ def l2_composite(R, reps=5, warm=3):
     vals = (rng.integers(-3, 4, size=D) / 128.0).astype(np.float32)       # on the quantisation grid, small L2 norm
     r1 = rng.integers(0, 256, size=(D, 32), dtype=np.uint8); r1[:, 31] &= 0x0F
     r2 = rng.integers(0, 256, size=(D, 32), dtype=np.uint8); r2[:, 31] &= 0x0F
+    from rofl_project_code_amd import api
+    api.bp_gens_prepare(8, R.range_proof_vec.next_pow2(D) // NPART); api.bp_gens_prepare(32, 1)      # complete tables of the composite's two shapes (steady state)
     ts = []
     for rep in range(reps + warm):      # the three proofs of a composite land on different lanes from call to call: every lane's workspace grows once
         t0 = time.perf_counter()

@@ -131,7 +131,6 @@ bool msm_plan_job(Ctx &C, MsmJob &J, const MsmOpt &opt, const MsmAllow &al, MsmM
     if (small && J.P.B == 64 && J.PW > 512) {
         static const u32 grp = knob("ROFL_MSM_SMALL_GROUP") ? (u32)std::max(1, std::min(4, atoi(knob("ROFL_MSM_SMALL_GROUP")))) : 4u;
         J.small_group = grp == 3 ? 2 : grp;
-        if (J.small_group > 1 && per_side <= 2 * J.P.B) small_cap = 28;      // mean load <= 4 in the half-filled windows: P(> 28) ~ 1e-15 per bucket; 4 x 64 lists of 28 = 29 KB of LDS
     }
     if (J.kind == MsmKind::Slots && (size_t)J.PW * J.P.B * J.cap * 4 > ((size_t)8 << 30)) return false;
     return true;
@@ -186,7 +185,8 @@ MsmJob msm_enqueue(Ctx &C, MsmWs &W, const std::vector<MsmProb> &probs, size_t n
         ge *S_fin_s = J.dev_horner ? W.S[0].as<ge>(PW) : hres_dev;
         ge *C_fin_s = J.dev_horner ? W.Cacc[0].as<ge>(PW * (size_t)nb_final) : hres_dev + PW;
         const u32 G = J.small_group;
-        size_t lds_lists = (size_t)G * P.B * 4 * (1 + small_cap);
+        size_t lds_lists = G > 1 ? (size_t)G * P.B * (4 + 2 * (size_t)small_cap)      // 16-bit list entries (k_msm_small_g)
+                                 : (size_t)P.B * 4 * (1 + small_cap);
         size_t lds_red = G > 1 ? ((size_t)G * P.B * 3 / 4 + 1) * sizeof(ge)      // in-place trees over G windows
                                : std::max(((size_t)(P.B / 8) * 4 + (size_t)(P.B / 16) * 5 + 1) * sizeof(ge), ((size_t)P.B + (size_t)P.B * 3 / 4 + 1) * sizeof(ge));      // fused / binary reduction trees
         uint64_t items = (uint64_t)np * n_side * P.W;

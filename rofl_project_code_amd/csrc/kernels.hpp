@@ -3,6 +3,7 @@
 // Conventions: blockIdx.y = "problem" (one Bulletproof chunk, or one MSM problem).
 // Scalars in device arrays are in Montgomery form unless a name ends with _canon.
 #pragma once
+#include <type_traits>
 #include "fe32.hpp"
 #include "fe26.hpp"
 #include "quad26.hpp"
@@ -1669,6 +1670,9 @@ __device__ __forceinline__ void msm_reduce_binary_multi(u32 E, u32 G, u32 gv, co
 #define MSM_SMALL_CAP 64      /* list entries per bucket at a mean load <= 16 (n_side <= 8 B, narrow windows fill half of the buckets): P(overflow) ~ 1e-18 per bucket */
 #define MSM_SMALL_CAP_MAX 80  /* upper bound of the run-time `cap` (72 at n_side <= 16 B: mean load <= 32, P(overflow) ~ 1e-12) */
 #if ROFL_KG(1)
+// L16: the bucket lists hold 16-bit entries (term index < 0x7fff | sign in bit 15) -- half the LDS of the lists; the grouped launch (at most
+// 16 x 64 terms a side) uses it to fit four blocks per CU at every list capacity.
+template <bool L16>
 __device__ __forceinline__ void msm_small_body(unsigned char *smem, u32 n_side, MsmWin mw, MsmMap mm, const MsmProb *probs, ge *buckets, ge *S_fin, ge *C_fin,
                                                u32 nb_final, u32 *overflow, u32 cap, u32 G, unsigned long long *dbg, ge *wsum_out,
                                                const sc *ip_dev, u32 ip_nblk, const niels *qpts) {
@@ -1685,21 +1689,23 @@ __device__ __forceinline__ void msm_small_body(unsigned char *smem, u32 n_side, 
     const u32 pw = p * mw.W + w0;                                    // bucket array of the block's first window
     const u32 VB = G * B;
     u32 side = mm.lr_nh ? (p & 1u) : 0u;
+    typedef typename std::conditional<L16, unsigned short, u32>::type lst_t;
+    const u32 SIGN = L16 ? 0x8000u : 0x80000000u, IDXM = SIGN - 1;
     u32 *lcnt = reinterpret_cast<u32 *>(smem);                       // [VB]
-    u32 *lst = lcnt + VB;                                            // [VB][cap]: term index | sign
+    lst_t *lst = reinterpret_cast<lst_t *>(lcnt + VB);               // [VB][cap]: term index | sign
     for (u32 b = threadIdx.x; b < VB; b += blockDim.x) lcnt[b] = 0;
     __syncthreads();
     const sc *scal = probs[p].scal;
     auto put = [&](const u32 *kw, u32 g, u32 entry_idx) {            // the digit of window w0 + g of the scalar at kw -> that window's bucket list
         u32 wpos, wwid; msm_window(mw, w0 + g, wpos, wwid);
         int d = msm_digit_mem(kw, wpos, wwid);
-        u32 ad = (u32)(d < 0 ? -d : d), entry = entry_idx | (d < 0 ? 0x80000000u : 0u);
+        u32 ad = (u32)(d < 0 ? -d : d), entry = entry_idx | (d < 0 ? SIGN : 0u);
         for (int rep = 0; rep < 2; rep++) {
             u32 a1 = rep == 0 ? (ad > B ? B : 0u) : (ad > B ? ad - B : ad);
             if (!a1) continue;
             u32 vb = g * B + a1 - 1;
             u32 pos = atomicAdd(&lcnt[vb], 1u);
-            if (pos < cap) lst[vb * cap + pos] = entry;
+            if (pos < cap) lst[vb * cap + pos] = (lst_t)entry;
             else *(volatile u32 *)overflow = 1u;          // mapped host memory: a plain store (idempotent)
         }
     };
@@ -1711,7 +1717,7 @@ __device__ __forceinline__ void msm_small_body(unsigned char *smem, u32 n_side, 
     // One more term for the L / R problems of an inner-product round: c_side * Q with Q = w B (upstream's <a_L, b_R> Q) -- c_side is the sum of
     // the partial inner products the round's k_ipp_round launch left in device memory, Q the chunk's point.  The host added this term with a
     // fixed-base multiplication per problem on every hop (6 us each; eight of them in a row where one thread finishes eight problems).
-    const u32 QIDX = 0x7fffffffu;
+    const u32 QIDX = IDXM;
     if (ip_dev && threadIdx.x == 0) {
         sc acc = sc_zero();
         for (u32 b = 0; b < ip_nblk; b++) acc = sc_add(acc, load_sc(&ip_dev[((size_t)(p >> 1) * ip_nblk + b) * 2 + (p & 1u)]));
@@ -1722,7 +1728,7 @@ __device__ __forceinline__ void msm_small_body(unsigned char *smem, u32 n_side, 
     stamp(1);
     const niels *pts = probs[p].pts;
     const niels *qpt = qpts ? qpts + (p >> 1) : pts;
-    auto fetch = [&](u32 v) { const u32 i = v & 0x7fffffffu; return gload_nd(i == QIDX ? qpt : &pts[i]); };
+    auto fetch = [&](u32 v) { const u32 i = v & IDXM; return gload_nd(i == QIDX ? qpt : &pts[i]); };
     // Balance the bucket sums over the block's waves.  A wave runs as long as its fullest bucket (mean 4 entries, ~10 in every wave of 64
     // unsorted buckets); with the buckets sorted by load every wave gets buckets of similar depth.  blockDim == B = 512 (8 waves, two per
     // SIMD): wave w < 4 takes the w-th heaviest group of 64 and its SIMD partner w + 4 the (7 - w)-th -- every SIMD sees ~11 additions' worth
@@ -1755,7 +1761,7 @@ __device__ __forceinline__ void msm_small_body(unsigned char *smem, u32 n_side, 
         u32 v = num ? lst[vb * cap] : 0u;
         nd nxt = fetch(v);
         for (u32 e = 0; e < num; e++) {
-            nd q = nxt; bool ng = (v >> 31) != 0;
+            nd q = nxt; bool ng = (v & SIGN) != 0;
             if (e + 1 < num) { v = lst[vb * cap + e + 1]; nxt = fetch(v); }
             acc = gd_madd(acc, q, ng);
         }
@@ -1789,7 +1795,7 @@ __global__ void __launch_bounds__(512) k_msm_small(u32 n_side, MsmWin mw, MsmMap
                                                    u32 nb_final, u32 *overflow, u32 cap, u32 G, unsigned long long *dbg, ge *wsum_out,
                                                    const sc *ip_dev, u32 ip_nblk, const niels *qpts) {
     extern __shared__ __align__(16) unsigned char smem[];
-    msm_small_body(smem, n_side, mw, mm, probs, buckets, S_fin, C_fin, nb_final, overflow, cap, G, dbg, wsum_out, ip_dev, ip_nblk, qpts);
+    msm_small_body<false>(smem, n_side, mw, mm, probs, buckets, S_fin, C_fin, nb_final, overflow, cap, G, dbg, wsum_out, ip_dev, ip_nblk, qpts);
 }
 // the same body for blocks of G windows x 64 buckets (256 threads): compiled for four waves per SIMD, so that four of these blocks share a CU
 // (the 512-thread form above is compiled for two; thousands of small blocks want the occupancy, not the registers)
@@ -1797,7 +1803,7 @@ __global__ void __launch_bounds__(256, 4) k_msm_small_g(u32 n_side, MsmWin mw, M
                                                         u32 nb_final, u32 *overflow, u32 cap, u32 G, unsigned long long *dbg, ge *wsum_out,
                                                         const sc *ip_dev, u32 ip_nblk, const niels *qpts) {
     extern __shared__ __align__(16) unsigned char smem[];
-    msm_small_body(smem, n_side, mw, mm, probs, buckets, S_fin, C_fin, nb_final, overflow, cap, G, dbg, wsum_out, ip_dev, ip_nblk, qpts);
+    msm_small_body<true>(smem, n_side, mw, mm, probs, buckets, S_fin, C_fin, nb_final, overflow, cap, G, dbg, wsum_out, ip_dev, ip_nblk, qpts);
 }
 #endif
 

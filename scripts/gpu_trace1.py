@@ -10,6 +10,7 @@ import bench
 R.set_device(0); api.set_fp(32, 7)
 vals, bl = bench.synth_client(1)
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+api.bp_gens_prepare(32, max(R.range_proof_vec.next_pow2(bench.D) // P, 1))      # the full fold table (a warm client: not the compact table of a first call)
 for i in range(3):
     sys.stderr.write("=== create %d\n" % i)
     t = time.perf_counter()

@@ -644,14 +644,24 @@ __global__ void __launch_bounds__(TPB) k_ipp_round(u32 n_g, u32 n_k, u32 r_prev,
     const sc *ai = a_in + c * ab_stride, *bi = b_in + c * ab_stride;
     sc *ao = a_out + c * ab_stride, *bo = b_out + c * ab_stride;
     const u32 nh = n_k / 2;
-    const sc gs = load_sc(&cp[c].gscale), hs = load_sc(&cp[c].hscale);
+    // the chunk's scales OUT of Montgomery form: a product with them then leaves the Montgomery domain by itself, and the MSM scalars
+    // a' s_G, b' s_H come out canonical without a conversion of their own (two multiplications per element less)
+    const sc gs = sc_from_mont(load_sc(&cp[c].gscale)), hs = sc_from_mont(load_sc(&cp[c].hscale));
     sc *sl = SL + (size_t)c * 2 * n_g;
     sc v[2] = {sc_zero(), sc_zero()};
+    // x u + y u' as ONE reduction over the sum of the two plain products (fe32.hpp: sc_mac_wide / sc_redc_wide)
+    auto fold2 = [](const sc &x, const sc &cu, const sc &y, const sc &cv) {
+        u32 w[17];
+#pragma unroll
+        for (int q = 0; q < 17; q++) w[q] = 0;
+        sc_mac_wide(w, x, cu); sc_mac_wide(w, y, cv);
+        return sc_redc_wide(w);
+    };
     for (u32 j = blockIdx.x * blockDim.x + threadIdx.x; j < n_g; j += gridDim.x * blockDim.x) {
         u32 h = j / n_k, i = j % n_k;
         bool lo = i < nh; u32 ii = lo ? nh + i : i - nh;
-        sc af = sc_add(sc_montmul(load_sc(&ai[ii]), u), sc_montmul(load_sc(&ai[n_k + ii]), ui));
-        sc bf = sc_add(sc_montmul(load_sc(&bi[ii]), ui), sc_montmul(load_sc(&bi[n_k + ii]), u));
+        sc af = fold2(load_sc(&ai[ii]), u, load_sc(&ai[n_k + ii]), ui);
+        sc bf = fold2(load_sc(&bi[ii]), ui, load_sc(&bi[n_k + ii]), u);
         // product of the pending challenges selected by the bits of h (challenge q <-> bit r-1-q): the table of the previous round
         // (2^r_prev entries per chunk and side, written by that round's launch) extended by the newest challenge -- one multiplication
         // per element instead of r of them (r reaches 11 in the tail)
@@ -660,18 +670,18 @@ __global__ void __launch_bounds__(TPB) k_ipp_round(u32 n_g, u32 n_k, u32 r_prev,
         sc tH = r_prev ? load_sc(&ptab_in[(size_t)c * 2 * ptab_stride + ptab_stride + hp]) : sc_one_mont();
         if (use_new) { bool bit = h & 1; tG = sc_montmul(tG, bit ? u : ui); tH = sc_montmul(tH, bit ? ui : u); }
         if (i == 0) { store_sc(&ptab_out[(size_t)c * 2 * ptab_stride + h], tG); store_sc(&ptab_out[(size_t)c * 2 * ptab_stride + ptab_stride + h], tH); }
-        sc sG = sc_montmul(gs, tG), sH = sc_montmul(hs, tH);
+        sc sG = sc_montmul(gs, tG), sH = sc_montmul(hs, tH);                  // plain values (gs, hs are)
         sH = sc_montmul(sH, load_sc(&yinvpow[c * y_stride + j]));
-        store_sc(&sl[j], sc_from_mont(sc_montmul(af, sG)));
-        store_sc(&sl[n_g + j], sc_from_mont(sc_montmul(bf, sH)));
+        store_sc(&sl[j], sc_montmul(af, sG));                                  // Montgomery x plain -> canonical
+        store_sc(&sl[n_g + j], sc_montmul(bf, sH));
         if (h == 0) {
             store_sc(&ao[ii], af); store_sc(&bo[ii], bf);
             // last round (n_k == 2): the two entries of a and b also go to mapped host memory -- the host applies the final challenge
             // itself (a = a_0 u + a_1 u^-1, b = b_0 u^-1 + b_1 u) instead of one more launch, two copies and a wait at the end of every proof
             if (ab_host && n_k == 2) { store_sc(&ab_host[c * 4 + ii], af); store_sc(&ab_host[c * 4 + 2 + ii], bf); }
             if (lo) {      // this thread holds a'[nh+i], b'[nh+i]; with a'[i], b'[i] it owns one term of each inner product
-                sc al = sc_add(sc_montmul(load_sc(&ai[i]), u), sc_montmul(load_sc(&ai[n_k + i]), ui));
-                sc bl = sc_add(sc_montmul(load_sc(&bi[i]), ui), sc_montmul(load_sc(&bi[n_k + i]), u));
+                sc al = fold2(load_sc(&ai[i]), u, load_sc(&ai[n_k + i]), ui);
+                sc bl = fold2(load_sc(&bi[i]), ui, load_sc(&bi[n_k + i]), u);
                 v[0] = sc_add(v[0], sc_montmul(al, bf));
                 v[1] = sc_add(v[1], sc_montmul(af, bl));
             }

@@ -666,12 +666,13 @@ __global__ void __launch_bounds__(TPB) k_ipp_round(u32 n_g, u32 n_k, u32 r_prev,
         // (2^r_prev entries per chunk and side, written by that round's launch) extended by the newest challenge -- one multiplication
         // per element instead of r of them (r reaches 11 in the tail)
         u32 hp = use_new ? h >> 1 : h;
-        sc tG = r_prev ? load_sc(&ptab_in[(size_t)c * 2 * ptab_stride + hp]) : sc_one_mont();
-        sc tH = r_prev ? load_sc(&ptab_in[(size_t)c * 2 * ptab_stride + ptab_stride + hp]) : sc_one_mont();
+        // (the table carries the chunk's scale along, in plain form: gscale / hscale are constant while challenges are pending -- a fold
+        //  changes them and empties the table -- so s_G and s_H need no multiplication of their own)
+        sc tG = r_prev ? load_sc(&ptab_in[(size_t)c * 2 * ptab_stride + hp]) : gs;
+        sc tH = r_prev ? load_sc(&ptab_in[(size_t)c * 2 * ptab_stride + ptab_stride + hp]) : hs;
         if (use_new) { bool bit = h & 1; tG = sc_montmul(tG, bit ? u : ui); tH = sc_montmul(tH, bit ? ui : u); }
         if (i == 0) { store_sc(&ptab_out[(size_t)c * 2 * ptab_stride + h], tG); store_sc(&ptab_out[(size_t)c * 2 * ptab_stride + ptab_stride + h], tH); }
-        sc sG = sc_montmul(gs, tG), sH = sc_montmul(hs, tH);                  // plain values (gs, hs are)
-        sH = sc_montmul(sH, load_sc(&yinvpow[c * y_stride + j]));
+        const sc sG = tG, sH = sc_montmul(tH, load_sc(&yinvpow[c * y_stride + j]));      // plain values (the table's are)
         store_sc(&sl[j], sc_montmul(af, sG));                                  // Montgomery x plain -> canonical
         store_sc(&sl[n_g + j], sc_montmul(bf, sH));
         if (h == 0) {

@@ -57,10 +57,12 @@ typedef struct {
 /* ---- context / device ----
  * One process drives any number of GPUs (the reference's server is ONE process that hands its clients to a verification pool,
  * rofl_service/src/flserver/server.rs:379-384, 513-521, 656-687).  The device a call runs on is a property of the CALLING THREAD, as with
- * hipSetDevice: rofl_set_device(d) binds the calling thread to device d, brings that device's context up (an unusable device is reported
- * here and leaves the binding unchanged) and makes d the default of threads that never called it -- a one-GPU host sets it once and calls
- * from any thread; a multi-GPU server binds each pool thread to its device, or lists the devices in rofl_set_option("devices", mask) and
- * lets rofl_create_rangeproof_batch / rofl_verify_rangeproof_batch spread their clients.  Generator tables are cached per device. */
+ * hipSetDevice: rofl_set_device(d) binds the calling thread to device d and brings that device's context up (an unusable device is reported
+ * here and leaves the binding unchanged).  The FIRST successful call of the process also makes d the default of threads that never call it
+ * -- a one-GPU host sets it once and calls from any thread; later calls bind their own thread only (rofl_set_option("default_device", d)
+ * moves the default explicitly).  A multi-GPU server binds each pool thread to its device, or lists the devices in
+ * rofl_set_option("devices", mask) and lets rofl_create_rangeproof_batch / rofl_verify_rangeproof_batch spread their clients.
+ * Generator tables are cached per device. */
 int rofl_set_device(int device);
 int rofl_get_device(int *device_out);                  /* the device the calling thread's next call runs on */
 int rofl_last_error(char *buf, size_t len);            /* human-readable text of the calling thread's last failure */
@@ -68,7 +70,10 @@ int rofl_last_error(char *buf, size_t len);            /* human-readable text of
  * range_proof_vec/mod.rs:126,201) -- built once on the device and cached per (n_bits, m).  When this call returns the shape's tables are
  * complete: a server calls it at start-up.  A create / verify call that meets a new shape does not wait for the large fold table (tens of
  * GB at the paper's sizes: its allocation alone can take most of a second): it is served from a compact table at once, and a background
- * thread builds the full one in the first quiet moment (no call in flight for 20 ms; after 3 s at the latest) and swaps it in. */
+ * thread builds the full one in the first quiet moment (no call in flight for 20 ms; after 3 s at the latest) and swaps it in.
+ * If HBM is too short for the full table even after every table nobody reads has been evicted, the shape keeps its compact table (same
+ * results; the first generator fold of a proof is ~2.5 ms slower): the call still returns 0, rofl_last_error carries a note,
+ * rofl_bp_gens_table_bytes reports the compact size, and a later rofl_bp_gens_prepare tries again. */
 int rofl_bp_gens_prepare(size_t n_bits, size_t m);
 /* HBM held by the cached tables of (n_bits, m): generators + fold slices + window slices; 0 if they have not been built */
 int rofl_bp_gens_table_bytes(size_t n_bits, size_t m, size_t *bytes_out);
@@ -231,6 +236,7 @@ int rofl_wire_decode(int kind, const uint8_t *data, size_t len, rofl_wire_msg_t 
  *                          listed devices
  *   "sigma_batch"          1 (default): the per-element Sigma-proofs of a vector are verified as one random linear combination; 0: one
  *                          check per element (rand_proof_vec/mod.rs:93-118)
+ *   "default_device"       the device of threads that never called rofl_set_device (default: the first device that was set, else 0)
  *   "blocking_sync"        -1 (default): spin while at most three calls are in flight, sleep between polls beyond that; 0: always spin;
  *                          1: always sleep (one host core per waiting call is not burned; ~50 us more latency per wait)
  * rofl_get_option also answers the read-only key "lanes": the calls that can be in flight on the calling thread's device (ROFL_LANES).

@@ -407,8 +407,14 @@ struct MsmWs {
 };
 
 // One cached BulletproofGens::new(n, m): [G(N) | H(N)] + fold slices (tbl), the 16 window slices of the fixed-base MSM (wtab)
-struct GensEntry { niels *tbl = nullptr; ndm *wtab = nullptr, *wtab_many = nullptr; u32 wc = 16, wc_many = 0; FoldTabCfg fc{}; size_t bytes = 0, n = 0, m = 0; u64 tick = 0; int users = 0;
-                   bool shares_wtab = false; };      // a retired fast-start entry: its window tables now belong to the entry that replaced it
+// The window tables are owned by reference count: the fast-start swap hands the SAME tables to the entry that replaces the compact one, and
+// calls that still read the retired entry keep them alive -- whoever drops the last reference frees them (an eviction of the new entry while
+// a retired reader was in mid-proof used to free them under it).
+struct WTabs { ndm *wtab = nullptr, *wtab_many = nullptr; size_t bytes = 0;
+               ~WTabs() { if (wtab) (void)hipFree(wtab); if (wtab_many) (void)hipFree(wtab_many); } };
+struct GensEntry { niels *tbl = nullptr; std::shared_ptr<WTabs> wt; ndm *wtab = nullptr, *wtab_many = nullptr; u32 wc = 16, wc_many = 0; FoldTabCfg fc{}; size_t bytes = 0, n = 0, m = 0; u64 tick = 0; int users = 0;
+                   bool retired = false;      // a replaced fast-start entry: still read by the calls that pinned it, no longer in the cache map
+                   int full_state = 0; };     // 0 = this is the shape's final table; 1 = the full fold table is still to come; -1 = its build failed (HBM short): compact for good unless prepare retries
 
 // Behaviour options (rofl_set_option): process-wide, so that a server that drives several devices sets them once.  The environment
 // only provides the defaults, read when the first option is touched.
@@ -512,6 +518,19 @@ struct Ctx {
         for (;;) {
             hipError_t q = hipEventQuery(ev_block);
             if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) throw HipErr{q, "hipEventQuery"};
+            struct timespec ts = {0, 20000}; nanosleep(&ts, nullptr);
+        }
+    }
+    // the same policy for an event of this call (the pipelined input groups of the batch verifier): a server that verifies many batches side by
+    // side must not spin one host core per waiting call here either
+    void wait_event(hipEvent_t ev) {
+        const Ctx *P = parent ? parent : this;
+        const int bs = opts().blocking_sync.load(std::memory_order_relaxed);
+        if (!(bs == 1 || (bs < 0 && (P->active_calls.load() > 3 || batch_mode)))) { HIPCHK(hipEventSynchronize(ev)); return; }
+        for (;;) {
+            hipError_t q = hipEventQuery(ev);
+            if (q == hipSuccess) return;
             if (q != hipErrorNotReady) throw HipErr{q, "hipEventQuery"};
             struct timespec ts = {0, 20000}; nanosleep(&ts, nullptr);
         }
@@ -627,6 +646,7 @@ constexpr int kMaxDevices = 64;
 std::mutex g_ctx_mu;
 std::map<int, Ctx *> g_ctxs;
 std::atomic<int> g_default_device{0};
+std::atomic<bool> g_default_set{false};      // the first successful rofl_set_device (or option default_device) has chosen the default
 thread_local int t_device = -1;
 int g_devmap[kMaxDevices];
 std::once_flag g_devmap_once;
@@ -714,8 +734,7 @@ u32 fb_window_c(size_t gens) {
 // format against (n, m) BEFORE asking for tables, and an allocation failure degrades (evict, then the compact table layout, then
 // no window table) instead of leaving the device full.
 void gens_free_entry(GensEntry *e) {
-    if (e->wtab && !e->shares_wtab) (void)hipFree(e->wtab);
-    if (e->wtab_many && !e->shares_wtab) (void)hipFree(e->wtab_many);
+    e->wt.reset();                                // the window tables go with their last owner (WTabs)
     e->wtab_many = nullptr;
     if (e->tbl) (void)hipFree(e->tbl);
     e->wtab = nullptr; e->tbl = nullptr;
@@ -724,6 +743,7 @@ void gens_free_entry(GensEntry *e) {
 void gens_evict(Ctx &P0, size_t keep_bytes, const GensEntry *spare) {
     for (;;) {
         size_t total = 0; for (auto &kv : P0.gens) total += kv.second->bytes;
+        for (auto &r : P0.gens_retired) total += r->bytes;      // (held until their readers return: they count, they cannot be chosen)
         if (total <= keep_bytes) return;
         auto victim = P0.gens.end();
         for (auto it = P0.gens.begin(); it != P0.gens.end(); ++it)
@@ -769,6 +789,70 @@ struct GensPin {
     }
     const FoldTabCfg &fc() const { return e->fc; }
 };
+// The full fold table of a shape that was started on the compact one (fast start).  Runs on a background thread (wait_quiet: after the
+// first quiet moment) or, when an earlier build failed for want of HBM, synchronously from rofl_bp_gens_prepare.  The caller has pinned
+// `raw` (users) and registered `key` in gens_pending; both are released here.  Returns whether the shape now has its full table.
+bool gens_upgrade(Ctx &P0, GensEntry *raw, std::pair<size_t, size_t> key, FoldTabCfg fc_full, size_t N, bool wait_quiet) {
+    auto give_up = [&](int state) { std::lock_guard<std::mutex> lk(P0.gens_mu); raw->users--; raw->full_state = state; P0.gens_pending.erase(key);
+                                    for (size_t k = 0; k < P0.gens_retired.size();)
+                                        if (P0.gens_retired[k]->users == 0) { gens_free_entry(P0.gens_retired[k].get()); P0.gens_retired.erase(P0.gens_retired.begin() + (long)k); } else k++; };
+    // Wait for a quiet moment: allocating tens of GB holds the runtime's lock for 0.05-0.7 s (every HIP call of the process waits) and the
+    // table kernel then fills the device for ~70 ms -- inside the first call that is the whole gain of the compact table gone again.
+    // A client proves once per training round and a server verifies once per round: pauses are plentiful.  rofl_bp_gens_prepare hurries it.
+    if (wait_quiet) {
+        static const double idle_ms = knob("ROFL_GENS_LAZY_IDLE_MS") ? atof(knob("ROFL_GENS_LAZY_IDLE_MS")) : 20.0;
+        static const double max_ms = knob("ROFL_GENS_LAZY_MAX_WAIT_MS") ? atof(knob("ROFL_GENS_LAZY_MAX_WAIT_MS")) : 3000.0;
+        const double w0 = now_ms(); double quiet_since = -1;
+        for (;;) {
+            if (g_gens_shutdown.load()) { give_up(1); return false; }
+            { std::lock_guard<std::mutex> lk(P0.gens_mu); auto it = P0.gens_pending.find(key); if (it != P0.gens_pending.end() && it->second == 2) break; }      // hurried
+            const double t = now_ms();
+            if (t - w0 >= max_ms) break;
+            if (g_calls_in_flight.load() == 0) { if (quiet_since < 0) quiet_since = t; if (t - quiet_since >= idle_ms) break; } else quiet_since = -1;
+            struct timespec ts = {0, 1000000}; nanosleep(&ts, nullptr);
+        }
+    }
+    if (hipSetDevice(P0.phys) != hipSuccess) { (void)hipGetLastError(); give_up(-1); return false; }
+    const size_t bytes = sizeof(niels) * 2 * N * fc_full.np * fc_full.e;
+    void *tv = nullptr; hipStream_t bs = nullptr;
+    const bool btrace = knob("ROFL_TRACE") && atoi(knob("ROFL_TRACE")) >= 2; const double bt0 = now_ms();
+    {   // the allocation goes through the cache's own allocator: room is made within the budget first (unpinned entries, least recently used),
+        // and a failed hipMalloc evicts everything unpinned before it gives up -- the same rules as every other table
+        std::lock_guard<std::mutex> lk(P0.gens_mu);
+        gens_evict(P0, P0.gens_budget > bytes ? P0.gens_budget - bytes : 0, raw);
+        if (gens_malloc(P0, &tv, bytes, raw) != hipSuccess) tv = nullptr;
+    }
+    if (!tv) { give_up(-1); return false; }      // HBM is short: the compact table stays; rofl_bp_gens_prepare reports it / tries again
+    if (btrace) fprintf(stderr, "[rofl-trace gens-upgrade] hipMalloc of %.1f GB +%.3f ms\n", bytes / 1e9, now_ms() - bt0);
+    // the builder's one large launch runs at the LOWEST stream priority: the proofs that are served from the compact table meanwhile keep
+    // getting their workgroups dispatched (at equal priority the first create of a fresh process waited ~65 ms behind it)
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    bool ok = hipStreamCreateWithPriority(&bs, hipStreamNonBlocking, prio_least) == hipSuccess;
+    if (!ok) { (void)hipGetLastError(); bs = nullptr; ok = hipStreamCreateWithFlags(&bs, hipStreamNonBlocking) == hipSuccess; }
+    ok = ok && hipMemcpyAsync(tv, raw->tbl, sizeof(niels) * 2 * N, hipMemcpyDeviceToDevice, bs) == hipSuccess;
+    if (ok) { hipLaunchKernelGGL(k_gens_tables, grid1(2 * N * fc_full.np), dim3(TPB), 0, bs, (u32)(2 * N), fc_full, reinterpret_cast<niels *>(tv), (size_t)(2 * N)); ok = hipStreamSynchronize(bs) == hipSuccess; }
+    if (bs) (void)hipStreamDestroy(bs);
+    if (btrace) fprintf(stderr, "[rofl-trace gens-upgrade] table built at +%.3f ms\n", now_ms() - bt0);
+    std::lock_guard<std::mutex> lk(P0.gens_mu);
+    raw->users--; P0.gens_pending.erase(key);
+    auto it = P0.gens.find(key);
+    if (!ok || it == P0.gens.end() || it->second.get() != raw) {      // (evicted meanwhile, or the build failed)
+        (void)hipFree(tv); raw->full_state = ok ? raw->full_state : -1;
+        for (size_t k = 0; k < P0.gens_retired.size();)
+            if (P0.gens_retired[k]->users == 0) { gens_free_entry(P0.gens_retired[k].get()); P0.gens_retired.erase(P0.gens_retired.begin() + (long)k); } else k++;
+        return false;
+    }
+    std::unique_ptr<GensEntry> full(new GensEntry(*raw));      // shares the window tables (WTabs) with the entry it replaces
+    full->tbl = reinterpret_cast<niels *>(tv); full->fc = fc_full; full->users = 0; full->tick = ++P0.gens_tick; full->full_state = 0;
+    full->bytes = raw->bytes - sizeof(niels) * 2 * N * raw->fc.np * raw->fc.e + bytes;
+    std::unique_ptr<GensEntry> old = std::move(it->second);
+    it->second = std::move(full);
+    old->retired = true; old->bytes = sizeof(niels) * 2 * N * old->fc.np * old->fc.e;      // what it still holds alone: its compact fold table
+    if (old->users == 0) gens_free_entry(old.get()); else P0.gens_retired.push_back(std::move(old));
+    gens_evict(P0, P0.gens_budget, it->second.get());
+    return true;
+}
 GensPin get_gens(Ctx &C, size_t n, size_t m) {
     Ctx &P0 = C.parent ? *C.parent : C;
     std::lock_guard<std::mutex> gens_lock(P0.gens_mu);
@@ -813,6 +897,7 @@ GensPin get_gens(Ctx &C, size_t n, size_t m) {
             void *wtv = nullptr;
             if (gens_malloc(P0, &wtv, sizeof(ndm) * 2 * N * fp.W, ent.get()) == hipSuccess) {      // without it the MSMs over these generators run in generic mode
                 ndm *wt = reinterpret_cast<ndm *>(wtv);
+                ent->wt = std::make_shared<WTabs>(); ent->wt->wtab = wt; ent->wt->bytes = sizeof(ndm) * 2 * N * fp.W;
                 hipLaunchKernelGGL(k_gens_wtab, grid1(2 * N), dim3(TPB), 0, C.stream, (u32)(2 * N), MsmWin{fp.c, fp.W, fp.wide}, tbl, wt, (size_t)(2 * N));
                 ent->wtab = wt; ent->wc = fp.c; ent->bytes += sizeof(ndm) * 2 * N * fp.W;
                 // Small generator sets also get a 15-bit layout (17 slices; 71 MB at 2N = 32 768).  Many small chunks (n_partition = 64: 128 L / R
@@ -825,6 +910,7 @@ GensPin get_gens(Ctx &C, size_t n, size_t m) {
                     void *w2 = nullptr;
                     if (gens_malloc(P0, &w2, sizeof(ndm) * 2 * N * f2.W, ent.get()) == hipSuccess) {
                         hipLaunchKernelGGL(k_gens_wtab, grid1(2 * N), dim3(TPB), 0, C.stream, (u32)(2 * N), MsmWin{f2.c, f2.W, f2.wide}, tbl, reinterpret_cast<ndm *>(w2), (size_t)(2 * N));
+                        ent->wt->wtab_many = reinterpret_cast<ndm *>(w2); ent->wt->bytes += sizeof(ndm) * 2 * N * f2.W;
                         ent->wtab_many = reinterpret_cast<ndm *>(w2); ent->wc_many = f2.c; ent->bytes += sizeof(ndm) * 2 * N * f2.W;
                     }
                 }
@@ -838,61 +924,34 @@ GensPin get_gens(Ctx &C, size_t n, size_t m) {
     gens_evict(P0, P0.gens_budget, raw);            // keep the cache inside its HBM budget (unpinned entries only)
     if (lazy) {
         raw->users++;                                // the builder reads this entry's generators: pinned until it has swapped (or given up)
+        raw->full_state = 1;
         P0.gens_pending[key] = 1;
-        P0.gens_upgrades.emplace_back([&P0, raw, key, fc_full, N] {
-            auto unpin = [&] { std::lock_guard<std::mutex> lk(P0.gens_mu); raw->users--; P0.gens_pending.erase(key); };
-            // Wait for a quiet moment: allocating tens of GB holds the runtime's lock for 0.05-0.7 s (every HIP call of the process waits) and the
-            // table kernel then fills the device for ~70 ms -- inside the first call that is the whole gain of the compact table gone again.
-            // A client proves once per training round and a server verifies once per round: pauses are plentiful.  rofl_bp_gens_prepare hurries it.
-            {
-                static const double idle_ms = knob("ROFL_GENS_LAZY_IDLE_MS") ? atof(knob("ROFL_GENS_LAZY_IDLE_MS")) : 20.0;
-                static const double max_ms = knob("ROFL_GENS_LAZY_MAX_WAIT_MS") ? atof(knob("ROFL_GENS_LAZY_MAX_WAIT_MS")) : 3000.0;
-                const double w0 = now_ms(); double quiet_since = -1;
-                for (;;) {
-                    if (g_gens_shutdown.load()) { unpin(); return; }
-                    { std::lock_guard<std::mutex> lk(P0.gens_mu); auto it = P0.gens_pending.find(key); if (it != P0.gens_pending.end() && it->second == 2) break; }      // hurried
-                    const double t = now_ms();
-                    if (t - w0 >= max_ms) break;
-                    if (g_calls_in_flight.load() == 0) { if (quiet_since < 0) quiet_since = t; if (t - quiet_since >= idle_ms) break; } else quiet_since = -1;
-                    struct timespec ts = {0, 1000000}; nanosleep(&ts, nullptr);
-                }
-            }
-            if (hipSetDevice(P0.phys) != hipSuccess) { unpin(); return; }
-            const size_t bytes = sizeof(niels) * 2 * N * fc_full.np * fc_full.e;
-            void *tv = nullptr; hipStream_t bs = nullptr;
-            const bool btrace = knob("ROFL_TRACE") && atoi(knob("ROFL_TRACE")) >= 2; const double bt0 = now_ms();
-            if (hipMalloc(&tv, bytes) != hipSuccess) { (void)hipGetLastError(); unpin(); return; }      // HBM is short: the compact table stays
-            if (btrace) fprintf(stderr, "[rofl-trace gens-upgrade] hipMalloc of %.1f GB +%.3f ms\n", bytes / 1e9, now_ms() - bt0);
-            // the builder's one large launch runs at the LOWEST stream priority: the proofs that are served from the compact table meanwhile keep
-            // getting their workgroups dispatched (at equal priority the first create of a fresh process waited ~65 ms behind it)
-            int prio_least = 0, prio_greatest = 0;
-            (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-            bool ok = hipStreamCreateWithPriority(&bs, hipStreamNonBlocking, prio_least) == hipSuccess;
-            if (!ok) { (void)hipGetLastError(); bs = nullptr; ok = hipStreamCreateWithFlags(&bs, hipStreamNonBlocking) == hipSuccess; }
-            ok = ok && hipMemcpyAsync(tv, raw->tbl, sizeof(niels) * 2 * N, hipMemcpyDeviceToDevice, bs) == hipSuccess;
-            if (ok) { hipLaunchKernelGGL(k_gens_tables, grid1(2 * N * fc_full.np), dim3(TPB), 0, bs, (u32)(2 * N), fc_full, reinterpret_cast<niels *>(tv), (size_t)(2 * N)); ok = hipStreamSynchronize(bs) == hipSuccess; }
-            if (bs) (void)hipStreamDestroy(bs);
-            if (btrace) fprintf(stderr, "[rofl-trace gens-upgrade] table built at +%.3f ms\n", now_ms() - bt0);
-            std::lock_guard<std::mutex> lk(P0.gens_mu);
-            raw->users--; P0.gens_pending.erase(key);
-            auto it = P0.gens.find(key);
-            if (!ok || it == P0.gens.end() || it->second.get() != raw) { (void)hipFree(tv); return; }      // (evicted meanwhile, or the build failed)
-            std::unique_ptr<GensEntry> full(new GensEntry(*raw));
-            full->tbl = reinterpret_cast<niels *>(tv); full->fc = fc_full; full->users = 0; full->tick = ++P0.gens_tick; full->shares_wtab = false;
-            full->bytes = raw->bytes - sizeof(niels) * 2 * N * raw->fc.np * raw->fc.e + bytes;
-            std::unique_ptr<GensEntry> old = std::move(it->second);
-            it->second = std::move(full);
-            old->shares_wtab = true; old->bytes = sizeof(niels) * 2 * N * old->fc.np * old->fc.e;
-            if (old->users == 0) gens_free_entry(old.get()); else P0.gens_retired.push_back(std::move(old));
-        });
+        P0.gens_upgrades.emplace_back([&P0, raw, key, fc_full, N] { gens_upgrade(P0, raw, key, fc_full, N, /*wait_quiet=*/true); });
     }
     return GensPin(&P0, raw);
 }
-// rofl_bp_gens_prepare: the shape's tables are COMPLETE when it returns (a server calls it at start-up and pays the whole build there)
-void gens_wait_full(Ctx &C, size_t n, size_t m) {
+// rofl_bp_gens_prepare: the shape's tables are COMPLETE when it returns (a server calls it at start-up and pays the whole build there).
+// A full table whose background build failed for want of HBM is tried once more here, synchronously; false = the shape stays on the
+// compact fold table (slower first fold, same results) and the caller is told.
+bool gens_wait_full(Ctx &C, size_t n, size_t m) {
     Ctx &P0 = C.parent ? *C.parent : C;
+    const auto key = std::make_pair(n, m);
     for (;;) {
-        { std::lock_guard<std::mutex> lk(P0.gens_mu); auto it = P0.gens_pending.find(std::make_pair(n, m)); if (it == P0.gens_pending.end()) return; it->second = 2; }      // 2 = somebody is waiting: build now
+        GensEntry *retry = nullptr; FoldTabCfg fc_full{};
+        {   std::lock_guard<std::mutex> lk(P0.gens_mu);
+            auto pit = P0.gens_pending.find(key);
+            if (pit != P0.gens_pending.end()) pit->second = 2;      // 2 = somebody is waiting: build now
+            else {
+                auto it = P0.gens.find(key);
+                if (it == P0.gens.end() || it->second->full_state == 0) return true;
+                if (it->second->full_state < 0) {      // the build failed earlier: once more, on this thread
+                    retry = it->second.get(); retry->users++; retry->full_state = 1; P0.gens_pending[key] = 2;
+                    fc_full = FoldTabCfg{P0.fold_pb, P0.fold_w, 256 / P0.fold_pb, 1u << (P0.fold_w - 2)};
+                    while (fc_full.w > 6 && sizeof(niels) * 2 * n * m * fc_full.np * fc_full.e > P0.fold_tab_budget) { fc_full.w--; fc_full.e = 1u << (fc_full.w - 2); }
+                }
+            }
+        }
+        if (retry) return gens_upgrade(P0, retry, key, fc_full, n * m, /*wait_quiet=*/false);
         struct timespec ts = {0, 500000}; nanosleep(&ts, nullptr);
     }
 }

@@ -182,7 +182,7 @@ int verify_chunks(Ctx &C, const char *label, size_t gens_capacity, size_t P, siz
     if (vin && vin->ready && !vin->ready->empty()) {      // group by group, as the encodings arrive (the device is still decoding the later groups)
         size_t c0 = 0;
         for (const VerifyReady &r : *vin->ready) {
-            HIPCHK(hipEventSynchronize(r.ev));
+            C.wait_event(r.ev);
             const size_t c1 = std::min(r.end, P);
             hash_range(c0, c1);
             c0 = c1;

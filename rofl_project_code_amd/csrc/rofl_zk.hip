@@ -19,6 +19,7 @@
 #include <memory>
 #include <atomic>
 #include <condition_variable>
+#include <deque>
 #include <exception>
 #include <functional>
 #include <mutex>
@@ -321,7 +322,7 @@ int verify_impl(Ctx &C, size_t n_clients, const uint8_t *const *proofs, size_t p
     const uint8_t *Vh = hV; const niels *d_vn2 = d_vn;
     std::vector<uint8_t> Vh_own;
     if (nv * chunk != dp) {
-        HIPCHK(hipStreamSynchronize(C.stream));
+        C.sync();
         Vh_own.resize(P * chunk * 32);
         for (size_t i = 0; i < n_clients; i++) memcpy(&Vh_own[i * nv * chunk * 32], hV + i * dp * 32, nv * chunk * 32);
         Vh = Vh_own.data();
@@ -346,7 +347,7 @@ int verify_impl(Ctx &C, size_t n_clients, const uint8_t *const *proofs, size_t p
     VerifyInputs vin{&ready, h_st, nv};
     int rc = verify_chunks(C, "RangeProof", prove_range, P, prove_range, chunk, pf.data(), proof_len, Vh, d_vn2, seed, cidx.data(), okc.data(), grp, &v_shift, v_real.data(),
                            n_clients > 1 ? ridx.data() : nullptr, hier, skip.data(), &vin);
-    HIPCHK(hipStreamSynchronize(C.stream));      // (a no-op after the checks; verify_chunks may have left before its first wait)
+    C.sync();      // (a no-op after the checks; verify_chunks may have left before its first wait)
     std::vector<char> bad_commit(n_clients, 0);
     for (size_t i = 0; i < n_clients; i++) bad_commit[i] = (h_st[i] & 4u) != 0;
     // a single set with an invalid encoding: the reference cannot even build its Vec<RistrettoPoint> (decompress fails) -> FormatError;
@@ -357,6 +358,48 @@ int verify_impl(Ctx &C, size_t n_clients, const uint8_t *const *proofs, size_t p
     for (size_t i = 0; i < n_clients; i++) { int r = (bad_commit[i] || bad_format[i]) ? 0 : 1; for (size_t c = 0; c < nv; c++) r &= okc[i * nv + c]; ok_out[i] = r; }
     return ROFL_OK;
 }
+
+// One persistent worker thread per logical device for the sharded batch calls.  A worker serves one job at a time (concurrent sharded calls
+// queue on the device's worker: the device is the shared resource anyway); jobs never throw (their body is guarded()).
+class ShardWorkers {
+    struct W { std::thread th; std::mutex mu; std::condition_variable cv; std::deque<std::pair<uint64_t, std::function<void()>>> q; uint64_t next_id = 1, done_id = 0; bool stop = false; };
+    std::mutex mu; std::map<int, std::unique_ptr<W>> ws;
+public:
+    struct Ticket { bool ok = false; int dev = 0; uint64_t id = 0; };
+    Ticket submit(int dev, std::function<void()> job) {
+        W *w = nullptr;
+        {   std::lock_guard<std::mutex> lk(mu);
+            auto it = ws.find(dev);
+            if (it == ws.end()) {
+                std::unique_ptr<W> nw(new W());
+                W *raw = nw.get();
+                try {
+                    raw->th = std::thread([raw] {
+                        for (;;) {
+                            std::pair<uint64_t, std::function<void()>> j;
+                            { std::unique_lock<std::mutex> lk(raw->mu); raw->cv.wait(lk, [&] { return raw->stop || !raw->q.empty(); }); if (raw->q.empty()) return; j = std::move(raw->q.front()); raw->q.pop_front(); }
+                            j.second();
+                            { std::lock_guard<std::mutex> lk(raw->mu); raw->done_id = j.first; }
+                            raw->cv.notify_all();
+                        }
+                    });
+                } catch (...) { return Ticket{}; }      // EAGAIN / bad_alloc: reported by the caller as an error code
+                it = ws.emplace(dev, std::move(nw)).first;
+            }
+            w = it->second.get();
+        }
+        Ticket t; t.ok = true; t.dev = dev;
+        { std::lock_guard<std::mutex> lk(w->mu); t.id = w->next_id++; w->q.emplace_back(t.id, std::move(job)); }
+        w->cv.notify_all();
+        return t;
+    }
+    void wait(const Ticket &t) {
+        W *w; { std::lock_guard<std::mutex> lk(mu); w = ws[t.dev].get(); }
+        std::unique_lock<std::mutex> lk(w->mu); w->cv.wait(lk, [&] { return w->done_id >= t.id; });
+    }
+    ~ShardWorkers() { for (auto &kv : ws) { { std::lock_guard<std::mutex> lk(kv.second->mu); kv.second->stop = true; } kv.second->cv.notify_all(); if (kv.second->th.joinable()) kv.second->th.join(); } }
+};
+ShardWorkers &shard_workers() { static ShardWorkers s; return s; }
 
 // The devices a batch entry point spreads its clients over: rofl_set_option("devices", mask).  Empty = the calling thread's device.
 std::vector<int> batch_devices() {
@@ -372,11 +415,18 @@ template <class F> int shard_over_devices(size_t n_clients, const std::vector<in
     std::vector<std::vector<size_t>> share(nd);
     for (size_t i = 0; i < n_clients; i++) share[i % nd].push_back(i);
     std::vector<int> rcs(nd, ROFL_OK); std::vector<std::string> errs(nd);
-    std::vector<std::thread> th;
     auto body = [&](size_t k) { DeviceBinding bind(devs[k]); rcs[k] = guarded([&]() -> int { return run(share[k]); }); if (rcs[k]) errs[k] = g_err; };
-    for (size_t k = 1; k < nd; k++) th.emplace_back(body, k);
+    // one persistent worker per device (ShardWorkers): no thread is created on the call path, and a thread that cannot be created at
+    // start-up is an error code, not std::terminate from a vector of joinable threads
+    ShardWorkers &sw = shard_workers();
+    std::vector<ShardWorkers::Ticket> tickets;
+    for (size_t k = 1; k < nd; k++) {
+        ShardWorkers::Ticket t = sw.submit(devs[k], [&body, k] { body(k); });
+        if (!t.ok) { for (auto &q : tickets) sw.wait(q); return fail(ROFL_HIP_ERROR, "could not start the worker thread of a device"); }
+        tickets.push_back(t);
+    }
     body(0);
-    for (auto &t : th) t.join();
+    for (auto &t : tickets) sw.wait(t);
     for (size_t k = 0; k < nd; k++) if (rcs[k]) return fail(rcs[k], errs[k]);
     return ROFL_OK;
 }
@@ -389,10 +439,21 @@ extern "C" {
 // brings that device's context up so that a missing device shows here and not in the first proof.
 int rofl_set_device(int device) {
     if (device < 0 || device >= kMaxDevices) return fail(ROFL_BAD_PARAM, "bad device index");
-    const int prev = t_device, prev_default = g_default_device.load();
-    t_device = device; g_default_device.store(device);
+    const int prev = t_device;
+    t_device = device;
     int rc = guarded([&]() -> int { LaneLock lane_lock = acquire_lane(); Ctx &C = *lane_lock.c; C.init(); return ROFL_OK; });
-    if (rc) { t_device = prev; g_default_device.store(prev_default); }      // a device that cannot be used is not selected
+    if (rc) {      // a device that cannot be used is not selected -- and leaves no half-built context behind (rofl_dbg_map_device would see it "in use")
+        t_device = prev;
+        std::lock_guard<std::mutex> lk(g_ctx_mu);
+        auto it = g_ctxs.find(device);
+        if (it != g_ctxs.end() && !it->second->inited && it->second->active_calls.load() == 0) { delete it->second; g_ctxs.erase(it); }
+        return rc;
+    }
+    // The process default -- what threads without a binding of their own follow -- is set by the FIRST successful call only: in a server whose
+    // pool threads each bind their own device, the default of unbound threads must not become whichever thread called last.
+    // rofl_set_option("default_device", d) moves it explicitly.
+    bool expected = false;
+    if (g_default_set.compare_exchange_strong(expected, true)) g_default_device.store(device);
     return rc;
 }
 int rofl_get_device(int *device_out) { if (!device_out) return fail(ROFL_BAD_PARAM, "bad parameter"); *device_out = current_device(); return ROFL_OK; }
@@ -417,7 +478,9 @@ size_t rofl_rangeproof_size(size_t n_bits, size_t d, size_t n_partition) {
 size_t rofl_nonces_per_chunk(size_t n_bits, size_t m) { return m * (2 * n_bits + 4); }
 
 int rofl_bp_gens_prepare(size_t n_bits, size_t m) {
-    return guarded([&]() -> int { LaneLock lane_lock = acquire_lane(); Ctx &C = *lane_lock.c; C.init(); if (!n_bits || !m) return fail(ROFL_BAD_PARAM, "bad parameter"); { GensPin pin = get_gens(C, n_bits, m); } gens_wait_full(C, n_bits, m); return ROFL_OK; });
+    return guarded([&]() -> int { LaneLock lane_lock = acquire_lane(); Ctx &C = *lane_lock.c; C.init(); if (!n_bits || !m) return fail(ROFL_BAD_PARAM, "bad parameter"); { GensPin pin = get_gens(C, n_bits, m); }
+        if (!gens_wait_full(C, n_bits, m)) g_err = "HBM is short: the shape keeps its compact fold table (same results, slower first fold)";      // not an error: see rofl_zk.h
+        return ROFL_OK; });
 }
 int rofl_bp_gens_table_bytes(size_t n_bits, size_t m, size_t *bytes_out) {
     return guarded([&]() -> int {
@@ -1056,6 +1119,10 @@ bool option_slot(const char *key, OptSlot *o) {
 }
 }  // namespace
 int rofl_set_option(const char *key, long value) {
+    if (key && !strcmp(key, "default_device")) {      // the device of threads that never called rofl_set_device (otherwise: the first device that was set)
+        if (value < 0 || value >= kMaxDevices) return fail(ROFL_BAD_PARAM, "unknown option or value out of range");
+        g_default_device.store((int)value); g_default_set.store(true); return ROFL_OK;
+    }
     OptSlot o;
     if (!option_slot(key, &o) || value < o.lo || value > o.hi) return fail(ROFL_BAD_PARAM, "unknown option or value out of range");
     if (o.i) o.i->store((int)value); else o.l->store(value);
@@ -1066,6 +1133,7 @@ int rofl_get_option(const char *key, long *value_out) {
     if (key && !strcmp(key, "lanes")) {      // read-only: the lanes of the calling thread's device (ROFL_LANES after clamping)
         return guarded([&]() -> int { Ctx &P = ctx(); { std::lock_guard<std::mutex> g(P.init_mu); P.init(); } *value_out = P.nlanes; return ROFL_OK; });
     }
+    if (key && !strcmp(key, "default_device")) { *value_out = g_default_device.load(); return ROFL_OK; }
     OptSlot o;
     if (!option_slot(key, &o)) return fail(ROFL_BAD_PARAM, "unknown option");
     *value_out = o.i ? (long)o.i->load() : o.l->load();

@@ -272,6 +272,19 @@ def test_device_binding_is_per_thread(hiplib):
     if not torch.cuda.is_available():
         assert L.rofl_set_device(2) >= 100
         assert L.rofl_get_device(ctypes.byref(g)) == 0 and g.value == default
+        # ... and leaves no half-built context behind: the logical device can still be re-mapped (it would be "already in use" otherwise)
+        assert L.rofl_dbg_map_device(2, 0) == 0
+    # the default of unbound threads moves only through the explicit option (or the first successful rofl_set_device)
+    L.rofl_set_option.argtypes = [ctypes.c_char_p, ctypes.c_long]
+    L.rofl_get_option.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_long)]
+    v = ctypes.c_long()
+    assert L.rofl_set_option(b"default_device", 7) == 0 and L.rofl_get_option(b"default_device", ctypes.byref(v)) == 0 and v.value == 7
+    seen = []
+    t = threading.Thread(target=lambda: (L.rofl_get_device(ctypes.byref(g)), seen.append(g.value)))
+    t.start(); t.join()
+    assert seen == [7]
+    assert L.rofl_set_option(b"default_device", 64) == 11
+    assert L.rofl_set_option(b"default_device", default) == 0
 
 
 def test_options_are_process_wide_and_checked(hiplib):

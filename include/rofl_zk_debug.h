@@ -48,6 +48,10 @@ int rofl_dbg_bind_device(int device);
 /* GPU multi-scalar multiplication sum_i k_i * P_i through the production Pippenger pipeline (dalek
  * vartime_multiscalar_mul as used by upstream verify_multiple); test hook for skewed / extreme scalars. */
 int rofl_dbg_msm(const uint8_t *scalars32, const uint8_t *points32, size_t n, uint8_t out32[32]);
+/* process-wide counters of the MSM driver: out[0] MSMs that finished on their first attempt's variant, out[1] repeats after a bucket-list
+ * overflow of the fused small launch, out[2] repeats on the slot path after a coarse bin of the two-level sort overflowed (scalars built to
+ * collide), out[3] repeats after the slot path's overflow list ran out.  The server-path tests use them to show which path a scenario took. */
+int rofl_dbg_msm_retries(uint64_t out[4]);
 /* field-multiply micro-benchmark: returns GF(2^255-19) multiplications per second on the device */
 int rofl_bench_femul(unsigned iters, double *fe_mul_per_sec_out);
 /* self-test of the quad-parallel point arithmetic (csrc/quad26.hpp): pair i = (P, Q) -> 2^doublings P + Q, one thread per pair and one quad of lanes per pair */

@@ -17,6 +17,13 @@
  *       out-file    : header (8 x u64: d, prove_range, n_partition, n_clients, n_proofs, proof_len, fp_bits, fp_frac), then per client
  *                     values (d f32), blindings (d x 32), nonce seed (32), proofs (n_proofs x proof_len), commitments (d x 32);
  *                     then verdicts of the clean round and of the tampered round (n_clients x i32 each)
+ *   fl_round reject <d> <prove_range> <n_partition> <n_clients> <n_devices> <out-file>
+ *       the same round, then what a batch verifier is defined by -- what it rejects (server.rs:474-484 fails the round on any bad client):
+ *       five scenarios (clean | one late R flipped | a late L, two swapped commitments and a non-canonical scalar in three clients |
+ *       a = 0 in every chunk of one client: scalars that collide in the sort | clean again), each verified twice: the server path
+ *       (verify_batch = 2, devices = all) and the per-client path (verify_batch = 1, one device)
+ *       out-file    : header as above, then 5 x 2 x n_clients verdicts (i32) and, per scenario, the index of the chunk that was touched
+ *                     in each client (n_clients x i32, -1 = untouched), then per client proofs and commitments of scenarios 1..3 as verified
  */
 #include <pthread.h>
 #include <stdint.h>
@@ -139,72 +146,159 @@ static int bench(size_t d, size_t prove_range, size_t n_partition, size_t iters)
     return 0;
 }
 
+static void setup_round(round_t *R, char **argv) {
+    size_t i, j;
+    float lo = 0, hi = 0;
+    int rc;
+    memset(R, 0, sizeof *R);
+    R->d = (size_t)strtoul(argv[2], NULL, 10);
+    R->prove_range = (size_t)strtoul(argv[3], NULL, 10);
+    R->n_partition = (size_t)strtoul(argv[4], NULL, 10);
+    R->n_clients = (size_t)strtoul(argv[5], NULL, 10);
+    R->n_devices = (size_t)strtoul(argv[6], NULL, 10);
+    if (!R->d || !R->n_clients || !R->n_devices || R->n_devices > 16) exit(2);
+    R->n_proofs = rofl_rangeproof_chunks(R->d, R->n_partition);
+    R->proof_len = rofl_rangeproof_size(R->prove_range, R->d, R->n_partition);
+    if (!R->n_proofs || !R->proof_len) { fprintf(stderr, "fl_round: the size helpers reject this shape\n"); exit(2); }
+
+    /* inputs: values inside the clip interval of (prove_range, fp), canonical blinding scalars, one nonce seed per client */
+    rc = rofl_get_clip_bounds(R->prove_range, FP_BITS, FP_FRAC, &lo, &hi);
+    if (rc) die("rofl_get_clip_bounds", rc);
+    R->values = (float **)calloc(R->n_clients, sizeof *R->values);
+    R->blindings = (uint8_t **)calloc(R->n_clients, sizeof *R->blindings);
+    R->proofs = (uint8_t **)calloc(R->n_clients, sizeof *R->proofs);
+    R->commits = (uint8_t **)calloc(R->n_clients, sizeof *R->commits);
+    R->nonces = (rofl_nonce_t *)calloc(R->n_clients, sizeof *R->nonces);
+    lcg_state = 0x726f666c5f7a6bull + R->d;
+    for (i = 0; i < R->n_clients; i++) {
+        R->values[i] = (float *)malloc(R->d * sizeof(float));
+        R->blindings[i] = (uint8_t *)malloc(R->d * 32);
+        R->proofs[i] = (uint8_t *)malloc(R->n_proofs * R->proof_len);
+        R->commits[i] = (uint8_t *)malloc(R->d * 32);
+        for (j = 0; j < R->d; j++) {
+            double u = (double)lcg() / 4294967296.0;
+            R->values[i][j] = (float)((double)lo + u * 0.999 * ((double)hi - (double)lo));
+        }
+        for (j = 0; j < R->d * 32; j++) R->blindings[i][j] = (uint8_t)(lcg() >> 24);
+        for (j = 0; j < R->d; j++) R->blindings[i][j * 32 + 31] &= 0x0f;      /* < 2^252: canonical */
+        R->nonces[i].mode = 1;
+        for (j = 0; j < 32; j++) R->nonces[i].seed[j] = (uint8_t)(lcg() >> 24);
+    }
+}
+
+/* client role: one thread per device */
+static void prove_round(round_t *R) {
+    round_t *per_dev = (round_t *)calloc(R->n_devices, sizeof *per_dev);
+    pthread_t *th = (pthread_t *)calloc(R->n_devices, sizeof *th);
+    size_t i;
+    for (i = 0; i < R->n_devices; i++) {
+        per_dev[i] = *R;
+        per_dev[i].device = (int)i;
+        if (pthread_create(&th[i], NULL, client_thread, &per_dev[i])) exit(1);
+    }
+    for (i = 0; i < R->n_devices; i++) {
+        pthread_join(th[i], NULL);
+        if (per_dev[i].rc) die("client thread (rofl_set_device / rofl_create_rangeproof)", per_dev[i].rc);
+    }
+    free(per_dev);
+    free(th);
+}
+
+static void write_head(FILE *f, const round_t *R) {
+    uint64_t head[8];
+    head[0] = R->d; head[1] = R->prove_range; head[2] = R->n_partition; head[3] = R->n_clients;
+    head[4] = R->n_proofs; head[5] = R->proof_len; head[6] = FP_BITS; head[7] = FP_FRAC;
+    fwrite(head, sizeof head, 1, f);
+}
+
+/* the server role under attack: see the header comment */
+#define N_SCEN 5
+static int reject(char **argv) {
+    round_t R;
+    size_t i, s, lg = 0, chunk, plen, psz;
+    long mask = 0;
+    int rc, *verdict, *touched;
+    uint8_t seed[32], **p, **c;
+    FILE *f;
+    setup_round(&R, argv);
+    if (R.n_clients < 6 || R.d < 64) { fprintf(stderr, "fl_round reject: at least six clients of 64 values\n"); return 2; }
+    prove_round(&R);
+    plen = R.proof_len; psz = R.n_proofs * plen;
+    lg = (plen / 32 - 9) / 2;
+    chunk = rofl_next_pow2(R.d) / R.n_proofs;
+    for (i = 0; i < R.n_devices; i++) mask |= 1L << i;
+    rc = rofl_set_device(0);
+    if (rc) die("rofl_set_device(0)", rc);
+    memset(seed, 0x5a, sizeof seed);
+    verdict = (int *)calloc(N_SCEN * 2 * R.n_clients, sizeof(int));
+    touched = (int *)malloc(N_SCEN * R.n_clients * sizeof(int));
+    for (i = 0; i < N_SCEN * R.n_clients; i++) touched[i] = -1;
+    p = (uint8_t **)calloc(R.n_clients, sizeof *p);
+    c = (uint8_t **)calloc(R.n_clients, sizeof *c);
+    for (i = 0; i < R.n_clients; i++) { p[i] = (uint8_t *)malloc(psz); c[i] = (uint8_t *)malloc(R.d * 32); }
+    f = fopen(argv[7], "wb");
+    if (!f) { perror(argv[7]); return 1; }
+    write_head(f, &R);
+    fseek(f, (long)(64 + (N_SCEN * 2 + N_SCEN) * R.n_clients * sizeof(int)), SEEK_SET);
+    for (s = 0; s < N_SCEN; s++) {
+        int path;
+        size_t n = R.n_clients, last = R.n_proofs - 1;
+        for (i = 0; i < n; i++) { memcpy(p[i], R.proofs[i], psz); memcpy(c[i], R.commits[i], R.d * 32); }
+        if (s == 1) {                                  /* the last round's R of the last full chunk of the last client */
+            size_t k = n - 1, ch = R.n_proofs > 1 ? last - 1 : 0;
+            p[k][ch * plen + 7 * 32 + 64 * (lg - 1) + 32 + 5] ^= 0x10; touched[s * n + k] = (int)ch;
+        } else if (s == 2) {
+            uint8_t tmp[32];
+            size_t a = 1, b = n / 2, e = n - 2, chb = R.n_proofs > 2 ? 1 : 0;
+            p[a][7 * 32 + 64 * (lg - 2) + 9] ^= 0x01; touched[s * n + a] = 0;                               /* a late L of chunk 0 */
+            memcpy(tmp, c[b] + (chb * chunk + 3) * 32, 32);                                                   /* two commitments swapped */
+            memcpy(c[b] + (chb * chunk + 3) * 32, c[b] + (chb * chunk + 4) * 32, 32);
+            memcpy(c[b] + (chb * chunk + 4) * 32, tmp, 32); touched[s * n + b] = (int)chb;
+            memset(p[e] + 128, 0xff, 32); touched[s * n + e] = 0;                                             /* t_x >= l: not canonical */
+        } else if (s == 3) {                           /* a = 0 in every chunk: one scalar for all G terms of the client's own check */
+            size_t k = 2, ch;
+            for (ch = 0; ch < R.n_proofs; ch++) memset(p[k] + ch * plen + plen - 64, 0, 32);
+            touched[s * n + k] = 0;
+        }
+        for (path = 0; path < 2; path++) {
+            rc = rofl_set_option("verify_batch", path == 0 ? 2 : 1);
+            if (rc) die("rofl_set_option(verify_batch)", rc);
+            rc = rofl_set_option("devices", path == 0 ? mask : 0);
+            if (rc) die("rofl_set_option(devices)", rc);
+            rc = rofl_verify_rangeproof_batch(n, (const uint8_t *const *)p, plen, R.n_proofs, (const uint8_t *const *)c, R.d, R.prove_range,
+                                              FP_BITS, FP_FRAC, seed, verdict + (s * 2 + (size_t)path) * n);
+            if (rc) die("rofl_verify_rangeproof_batch", rc);
+        }
+        if (s >= 1 && s <= 3) for (i = 0; i < n; i++) { fwrite(p[i], 1, psz, f); fwrite(c[i], 32, R.d, f); }
+        printf("scenario %zu:", s);
+        for (i = 0; i < n; i++) printf(" %d%d", verdict[(s * 2) * n + i], verdict[(s * 2 + 1) * n + i]);
+        printf("\n");
+    }
+    fseek(f, 64, SEEK_SET);
+    fwrite(verdict, sizeof(int), N_SCEN * 2 * R.n_clients, f);
+    fwrite(touched, sizeof(int), N_SCEN * R.n_clients, f);
+    fclose(f);
+    return 0;
+}
+
 int main(int argc, char **argv) {
     round_t R;
-    round_t *per_dev;
-    pthread_t *th;
     FILE *f;
-    size_t i, j;
+    size_t i;
     int rc, *ok_clean, *ok_tampered;
     long mask = 0, got = 0;
     uint8_t seed[32];
-    uint64_t head[8];
-    float lo = 0, hi = 0;
 
     if (argc >= 2 && strcmp(argv[1], "sizes") == 0) return sizes();
     if (argc == 6 && strcmp(argv[1], "bench") == 0)
         return bench((size_t)strtoul(argv[2], NULL, 10), (size_t)strtoul(argv[3], NULL, 10), (size_t)strtoul(argv[4], NULL, 10), (size_t)strtoul(argv[5], NULL, 10));
+    if (argc == 8 && strcmp(argv[1], "reject") == 0) return reject(argv);
     if (argc != 8 || strcmp(argv[1], "run") != 0) {
-        fprintf(stderr, "usage: fl_round sizes | fl_round bench <d> <prove_range> <n_partition> <iterations> | fl_round run <d> <prove_range> <n_partition> <n_clients> <n_devices> <out-file>\n");
+        fprintf(stderr, "usage: fl_round sizes | fl_round bench <d> <prove_range> <n_partition> <iterations> | fl_round run|reject <d> <prove_range> <n_partition> <n_clients> <n_devices> <out-file>\n");
         return 2;
     }
-    memset(&R, 0, sizeof R);
-    R.d = (size_t)strtoul(argv[2], NULL, 10);
-    R.prove_range = (size_t)strtoul(argv[3], NULL, 10);
-    R.n_partition = (size_t)strtoul(argv[4], NULL, 10);
-    R.n_clients = (size_t)strtoul(argv[5], NULL, 10);
-    R.n_devices = (size_t)strtoul(argv[6], NULL, 10);
-    if (!R.d || !R.n_clients || !R.n_devices || R.n_devices > 16) return 2;
-    R.n_proofs = rofl_rangeproof_chunks(R.d, R.n_partition);
-    R.proof_len = rofl_rangeproof_size(R.prove_range, R.d, R.n_partition);
-    if (!R.n_proofs || !R.proof_len) { fprintf(stderr, "fl_round: the size helpers reject this shape\n"); return 2; }
-
-    /* inputs: values inside the clip interval of (prove_range, fp), canonical blinding scalars, one nonce seed per client */
-    rc = rofl_get_clip_bounds(R.prove_range, FP_BITS, FP_FRAC, &lo, &hi);
-    if (rc) die("rofl_get_clip_bounds", rc);
-    R.values = (float **)calloc(R.n_clients, sizeof *R.values);
-    R.blindings = (uint8_t **)calloc(R.n_clients, sizeof *R.blindings);
-    R.proofs = (uint8_t **)calloc(R.n_clients, sizeof *R.proofs);
-    R.commits = (uint8_t **)calloc(R.n_clients, sizeof *R.commits);
-    R.nonces = (rofl_nonce_t *)calloc(R.n_clients, sizeof *R.nonces);
-    lcg_state = 0x726f666c5f7a6bull + R.d;
-    for (i = 0; i < R.n_clients; i++) {
-        R.values[i] = (float *)malloc(R.d * sizeof(float));
-        R.blindings[i] = (uint8_t *)malloc(R.d * 32);
-        R.proofs[i] = (uint8_t *)malloc(R.n_proofs * R.proof_len);
-        R.commits[i] = (uint8_t *)malloc(R.d * 32);
-        for (j = 0; j < R.d; j++) {
-            double u = (double)lcg() / 4294967296.0;
-            R.values[i][j] = (float)((double)lo + u * 0.999 * ((double)hi - (double)lo));
-        }
-        for (j = 0; j < R.d * 32; j++) R.blindings[i][j] = (uint8_t)(lcg() >> 24);
-        for (j = 0; j < R.d; j++) R.blindings[i][j * 32 + 31] &= 0x0f;      /* < 2^252: canonical */
-        R.nonces[i].mode = 1;
-        for (j = 0; j < 32; j++) R.nonces[i].seed[j] = (uint8_t)(lcg() >> 24);
-    }
-
-    /* client role: one thread per device */
-    per_dev = (round_t *)calloc(R.n_devices, sizeof *per_dev);
-    th = (pthread_t *)calloc(R.n_devices, sizeof *th);
-    for (i = 0; i < R.n_devices; i++) {
-        per_dev[i] = R;
-        per_dev[i].device = (int)i;
-        if (pthread_create(&th[i], NULL, client_thread, &per_dev[i])) return 1;
-    }
-    for (i = 0; i < R.n_devices; i++) {
-        pthread_join(th[i], NULL);
-        if (per_dev[i].rc) die("client thread (rofl_set_device / rofl_create_rangeproof)", per_dev[i].rc);
-    }
+    setup_round(&R, argv);
+    prove_round(&R);
 
     /* server role: one call for the round, its clients spread over the devices by the library */
     for (i = 0; i < R.n_devices; i++) mask |= 1L << i;
@@ -236,9 +330,7 @@ int main(int argc, char **argv) {
 
     f = fopen(argv[7], "wb");
     if (!f) { perror(argv[7]); return 1; }
-    head[0] = R.d; head[1] = R.prove_range; head[2] = R.n_partition; head[3] = R.n_clients;
-    head[4] = R.n_proofs; head[5] = R.proof_len; head[6] = FP_BITS; head[7] = FP_FRAC;
-    fwrite(head, sizeof head, 1, f);
+    write_head(f, &R);
     for (i = 0; i < R.n_clients; i++) {
         fwrite(R.values[i], sizeof(float), R.d, f);
         fwrite(R.blindings[i], 32, R.d, f);

@@ -176,6 +176,14 @@ def get_option(key):
     return out.value
 
 
+def msm_retries():
+    """test hook (include/rofl_zk_debug.h): process-wide counters of the MSM driver --
+    {"done", "small_overflow", "bin_overflow_to_slots", "slot_overflow"}"""
+    out = (ctypes.c_uint64 * 4)()
+    _check(lib().rofl_dbg_msm_retries(out))
+    return dict(zip(("done", "small_overflow", "bin_overflow_to_slots", "slot_overflow"), (int(x) for x in out)))
+
+
 def set_timing(on):
     """0 / False = off, 1 / True = every instrumented launch, 2 = only the fixed-base accumulation (cheap enough for timed steps)"""
     _check(lib().rofl_set_timing(int(on)))

@@ -342,7 +342,18 @@ MsmJob msm_enqueue(Ctx &C, MsmWs &W, const std::vector<MsmProb> &probs, size_t n
 }
 
 // after the stream has been synchronised: did the attempt overflow one of its fixed-size structures?  (then `al` has lost that variant)
+// rofl_dbg_msm_retries: MSMs finished / repeated after a list overflow of the fused small launch / after a coarse-bin overflow of the two-level
+// sort (-> slot path) / after an overflow of the slot path's overflow list (-> the next slower variant).  Process-wide; the tests of the server
+// path use them to show that a scenario really took the path it was built for.
+std::atomic<uint64_t> g_msm_stat[4];
+bool msm_retry_inner(const MsmJob &J, MsmAllow &al);
 bool msm_retry(const MsmJob &J, MsmAllow &al) {
+    const bool small = J.kind == MsmKind::Small, two = J.two;
+    const bool again = msm_retry_inner(J, al);
+    g_msm_stat[again ? (small ? 1 : two ? 2 : 3) : 0].fetch_add(1, std::memory_order_relaxed);
+    return again;
+}
+bool msm_retry_inner(const MsmJob &J, MsmAllow &al) {
     u32 flag = *J.ws->h_ovf.as<u32>(4);
     if (knob("ROFL_TRACE") && J.kind != MsmKind::CountSort) fprintf(stderr, "[rofl] msm np=%zu n=%zu c=%u cap=%u fb=%u lr=%d overflow=%u\n", J.np, J.n, J.P.c, J.cap, J.fb() ? J.sets : 0u, (int)J.lr, flag);
     if (J.kind == MsmKind::Small) { if (flag) { al.small = false; return true; } return false; }      // a bucket list overflowed: repeat through the general pipeline

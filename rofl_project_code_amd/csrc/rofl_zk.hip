@@ -1039,6 +1039,7 @@ int rofl_dbg_msm(const uint8_t *scalars32, const uint8_t *points32, size_t n, ui
         return ROFL_OK;
     });
 }
+int rofl_dbg_msm_retries(uint64_t out[4]) { if (!out) return ROFL_BAD_PARAM; for (int i = 0; i < 4; i++) out[i] = g_msm_stat[i].load(); return ROFL_OK; }
 int rofl_dbg_quad_ops(const uint8_t *pairs64, size_t pairs, unsigned doublings, uint8_t *out_serial32, uint8_t *out_quad32) {
     return guarded([&]() -> int {
         LaneLock lane_lock = acquire_lane(); Ctx &C = *lane_lock.c;

@@ -88,3 +88,48 @@ def test_c_host_round_matches_ctypes_and_oracle(fl_round, tmp_path, shape):
         if d <= 1000:
             rc, opr, ocm = orc.create_rangeproof(vals, bl, nb, P, fp[0], fp[1], seed=seed)
             assert rc == 0 and (opr == pr).all() and (ocm == cm).all(), "client %d: C host and oracle differ" % i
+
+
+def _parse_reject(path):
+    buf = open(path, "rb").read()
+    d, nb, P, nc, npf, plen, fpb, fpf = struct.unpack_from("<8Q", buf, 0)
+    off = 64
+    verdict = np.frombuffer(buf, np.int32, 5 * 2 * nc, off).reshape(5, 2, nc); off += 4 * 5 * 2 * nc
+    touched = np.frombuffer(buf, np.int32, 5 * nc, off).reshape(5, nc); off += 4 * 5 * nc
+    scen = {}
+    for s in (1, 2, 3):
+        cl = []
+        for _ in range(nc):
+            pr = np.frombuffer(buf, np.uint8, npf * plen, off).reshape(npf, plen); off += npf * plen
+            cm = np.frombuffer(buf, np.uint8, 32 * d, off).reshape(d, 32); off += 32 * d
+            cl.append((pr, cm))
+        scen[s] = cl
+    assert off == len(buf)
+    return (d, nb, P, nc, npf, plen, (fpb, fpf)), verdict, touched, scen
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1000, 32, 4, 6, 2), (55000, 32, 4, 12, 2)], ids=["d1000", "cfg4-12-clients"])
+def test_c_host_server_role_rejects_per_client(fl_round, tmp_path, shape):
+    """`fl_round reject`: the compiled host plays the server under attack (server.rs:474-484, 656-687) -- one / three bad members, a
+    member whose scalars collide in the sort -- through verify_batch = 2 + devices and through the per-client path: the two verdict lists
+    agree in every scenario, only the touched clients fail, and the oracle rejects the touched chunk of each of them."""
+    import orc
+    d, nb, P, nc, ndev = shape
+    out = str(tmp_path / "reject.bin")
+    env = dict(os.environ, ROFL_DEVICE_MAP=",".join("0" for _ in range(ndev)))
+    r = subprocess.run([fl_round, "reject", str(d), str(nb), str(P), str(nc), str(ndev), out], capture_output=True, text=True, timeout=1200, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    head, verdict, touched, scen = _parse_reject(out)
+    assert head[:4] == (d, nb, P, nc)
+    fp = head[6]; chunk = (1 << (d - 1).bit_length()) // head[4]
+    for s in range(5):
+        assert (verdict[s, 0] == verdict[s, 1]).all(), (s, verdict[s])                 # server path == per-client path
+        assert (verdict[s, 0] == (touched[s] < 0)).all(), (s, verdict[s], touched[s])   # exactly the touched clients fail
+    assert [int((touched[s] >= 0).sum()) for s in range(5)] == [0, 1, 3, 1, 0]
+    for s in (1, 2, 3):
+        for i in np.nonzero(touched[s] >= 0)[0]:
+            c = int(touched[s][i]); pr, cm = scen[s][i]
+            assert (c + 1) * chunk <= d
+            rc, ok = orc.verify_rangeproof(pr[c:c + 1].copy(), cm[c * chunk:(c + 1) * chunk].copy(), nb, fp[0], fp[1])
+            assert rc != 0 or ok is False, (s, i, c)

@@ -17,8 +17,9 @@ The library's consumer is a compiled host that links the image's HIP runtime (/o
 older runtime torch bundles instead (soname match), which costs ~0.5 ms per step and one ~8 ms stall per process.  So the N = 1 headline runs in a
 child process that maps /opt/rocm's libamdhip64.so.7 before torch (--hip-runtime auto -> system; torch keeps its own copy for the
 torch.cuda.synchronize() brackets, and every library call is synchronous), falls back to the process's runtime if that child fails, names the
-mapped runtime(s) in config.hip_runtime and reports the same K steps on the other runtime beside the headline.  N > 1 ranks use the process's
-runtime.
+mapped runtime(s) in config.hip_runtime and reports the same K steps on the other runtime beside the headline.  The ranks of an N > 1 run map the
+same runtime and exchange through the library's own RCCL communicator (rofl_comm_*, /opt/rocm's librccl): one runtime for every rank count;
+hip_runtime_per_rank lists what every rank mapped.
 
 Extra figures (rank 0, N = 1, outside the timed region, separate keys): the same steps with HBM-resident inputs, C clients in
 flight on C lanes, the per-kernel table, the L2 composite and the CPU baseline.
@@ -70,6 +71,25 @@ def parse_args():
                          "child fails; N > 1 and --one-process are `process`.  profiles/r04_experiments.txt item 13")
     ap.add_argument("--clients", type=int, default=48, help="clients of configs 4 / 5 (cifar_large.yml: 48)")
     return ap.parse_args()
+
+
+# The contract is ONE JSON line on stdout.  Libraries in a rank's process write to fd 1 as they please (/opt/rocm's RCCL prints
+# "Librccl path : ..." when its communicator goes): a process that does GPU work keeps a private copy of stdout for the line and points
+# fd 1 at stderr for everything else.
+_OUT = None
+
+
+def claim_stdout():
+    global _OUT
+    if _OUT is None:
+        sys.stdout.flush()
+        _OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
+def emit(line):
+    o = _OUT or sys.stdout
+    o.write(line + "\n"); o.flush()
 
 
 # ---------------------------------------------------------------------------------------------------------------- launcher
@@ -304,7 +324,7 @@ def cpu_baseline_multi(cfg, R, P):
     return {"value": ds / (t2 - t0), "unit": "elements/s", "cores": threads, "kind": "port", "parity_checked": parity, "sample": what + " on %d host threads" % threads}
 
 
-def run_multi_client(args, R, rd, dist, cdev, world, rank, backend):
+def run_multi_client(args, R, rd, dist, cdev, world, rank, backend, comm):
     """BASELINE configs 4 / 5: `--clients` (48) seeded clients of d = 55 000 sharded round-robin over the ranks (dist.shard_clients;
     the server hands one client per pool task, server.rs:656-687).  One step = one round of the protocol:
       every rank creates the proofs of ITS clients (cfg 4: rofl_create_rangeproof_batch in groups of 6, --multi-inflight (3) such calls in
@@ -371,7 +391,7 @@ def run_multi_client(args, R, rd, dist, cdev, world, rank, backend):
             payloads = [np.stack(blobs)]
         t1 = time.perf_counter()
         phase["payload"] = sum(int(x.size) for x in payloads)
-        _, per_rank = rd.exchange_round(payloads, True, cdev)      # every rank's proofs and commitments (wire messages) to every rank
+        _, per_rank = comm.exchange_round(payloads, True)      # every rank's proofs and commitments (wire messages) to every rank
         t2 = time.perf_counter()
         theirs = per_rank[src]
         n_their = len(rd.shard_clients(NC, src, world))
@@ -390,7 +410,7 @@ def run_multi_client(args, R, rd, dist, cdev, world, rank, backend):
             bb = theirs[0].reshape(n_their, -1)
             check = lambda k: params.EncParamsL2.deserialize(bytes(bb[k])).verify(verifier_seed=bytes([s % 256]) * 32, fp=FP)
             ok = all(cpool.map(check, range(n_their))) if cpool else all(check(k) for k in range(n_their))
-        ok = rd.all_verified(ok, cdev)
+        ok = comm.all_verified(ok)
         t3 = time.perf_counter()
         assert ok, "a client's proofs failed to verify"
         if record:
@@ -399,8 +419,8 @@ def run_multi_client(args, R, rd, dist, cdev, world, rank, backend):
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier(); torch.cuda.synchronize()
+        if args.exchange:
+            comm.barrier(); torch.cuda.synchronize()
 
     # cold figures: tables of this config's (n, m) built once per process, then the first round
     m_chunk = rpv.next_pow2(D_MULTI) // P
@@ -422,11 +442,12 @@ def run_multi_client(args, R, rd, dist, cdev, world, rank, backend):
     wall = time.perf_counter() - t0
     ru1 = resource.getrusage(resource.RUSAGE_SELF)
     elapsed = wall - gen_s      # drawing the synthetic inputs (numpy RNG on the host) is not part of the path
-    rccl_world = 1
-    if world > 1:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=cdev); dist.all_reduce(te, op=dist.ReduceOp.MAX); elapsed = float(te.item())
-        ones = torch.ones(1, dtype=torch.int32, device=cdev); dist.all_reduce(ones); rccl_world = int(ones.item())
+    rccl_world = 1; runtimes = None
+    if args.exchange:
+        elapsed = float(comm.reduce([elapsed], "max")[0])
+        rccl_world = int(round(comm.reduce([1.0], "sum")[0]))
         assert rccl_world == world
+        runtimes = gather_runtimes(comm)
     if rank == 0:
         K = args.steps
         kind = "L-inf 32-bit range proofs" if cfg == 4 else "L2 composite (EncParamsL2: 8-bit range proof + L2 sum proof + square proofs)"
@@ -436,7 +457,7 @@ def run_multi_client(args, R, rd, dist, cdev, world, rank, backend):
         out = {"metric": "range-proof elements/sec (create+verify), %d clients d=55k" % NC, "value": NC * D_MULTI * K / elapsed, "unit": "elements/s",
                "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "strong",
                "vs_baseline": None, "dtype": "u32x8 (255-bit integer field)", "data": "synthetic", "rccl_world_size": rccl_world,
-               "collective_backend": backend if world > 1 else None,
+               "collective_backend": comm.backend if args.exchange else None, "hip_runtime_per_rank": runtimes,
                "config": {"workload": "BASELINE cfg %d: %s, d=55000 (resnet18_intrinsic_55k), %d clients sharded over %d rank(s): batch create -> one all-gather of "
                                       "proof bytes + commitments -> every rank batch-verifies the share of rank+1 -> MIN all-reduce of the verdicts" % (cfg, kind, NC, world),
                           "d": D_MULTI, "clients": NC, "clients_per_rank": len(mine), "prove_range": NBITS if cfg == 4 else 8, "l2_range": None if cfg == 4 else 32,
@@ -470,9 +491,11 @@ def run_multi_client(args, R, rd, dist, cdev, world, rank, backend):
                 out["roofline"] = roof; out["valu_roofline"] = valu
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline_multi(cfg, R, P)
-        print(json.dumps(out)); sys.stdout.flush()
+        emit(json.dumps(out))
+    if args.exchange:
+        comm.barrier(); comm.close()
     if world > 1:
-        dist.barrier(); dist.destroy_process_group()
+        dist.destroy_process_group()
 
 
 # ---------------------------------------------------------------------------------------------------------------- one rank
@@ -498,14 +521,14 @@ def dry_run(args, world, rank):
         te = torch.tensor([elapsed], dtype=torch.float64); dist.all_reduce(te, op=dist.ReduceOp.MAX); elapsed = float(te.item())
         ones = torch.ones(1, dtype=torch.int32); dist.all_reduce(ones); rccl_world = int(ones.item())
     if rank == 0:
-        print(json.dumps({"metric": "dry run (no GPU work)", "value": world * args.steps * D / max(elapsed, 1e-9), "n_gpus": world, "steps": args.steps,
-                          "warmup": args.warmup, "rccl_world_size": rccl_world, "collective_backend": "gloo"}))
-        sys.stdout.flush()
+        emit(json.dumps({"metric": "dry run (no GPU work)", "value": world * args.steps * D / max(elapsed, 1e-9), "n_gpus": world, "steps": args.steps,
+                         "warmup": args.warmup, "rccl_world_size": rccl_world, "collective_backend": "gloo"}))
     if world > 1:
         dist.barrier(); dist.destroy_process_group()
 
 
 def run_rank(args):
+    claim_stdout()
     import faulthandler
     faulthandler.dump_traceback_later(1500, exit=True)      # never sit on a GPU box forever: dump the stacks and leave after 25 min
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -556,11 +579,10 @@ def run_rank(args):
     cdev = dev if backend == "nccl" else torch.device("cpu")      # device of the collective payloads
     dist = None
     if world > 1:
+        # control plane: a gloo group (rendezvous through MASTER_ADDR / MASTER_PORT, the RCCL unique id, agreeing on the communicator);
+        # the DATA plane of the timed steps is `comm` below
         import torch.distributed as dist
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+        dist.init_process_group("gloo")
 
     import rofl_project_code_amd as R
     from rofl_project_code_amd import api, build, dist as rd
@@ -569,13 +591,20 @@ def run_rank(args):
     if world > 1:
         dist.barrier()
     R.set_device(local_rank)
+    # The communicator of the exchange steps: the library's own RCCL communicator (rofl_comm_*: RCCL loaded next to the HIP runtime the
+    # proofs run on -- ONE runtime for every rank count, no torch in the data path); ROFL_BENCH_COMM=torch or a failure to form it falls
+    # back to torch.distributed (`backend`).  Several ranks on one GPU (the 1-GPU test hook) cannot use RCCL at all: gloo.
+    comm = rd.make_comm(rank, world, cdev, prefer_lib=(backend == "nccl" and os.environ.get("ROFL_BENCH_SAME_DEVICE") != "1" and os.environ.get("ROFL_BENCH_COMM", "lib") == "lib"),
+                        torch_backend=backend, log=lambda m: sys.stderr.write("bench.py[rank %d]: %s\n" % (rank, m)),
+                        force_lib=os.environ.get("ROFL_BENCH_FORCE_COMM") == "1")      # (a launcher-started world of ONE still exchanges through RCCL: the 1-GPU rehearsal)
+    args.exchange = world > 1 or isinstance(comm, rd.LibComm)
     # HIP events on the library's stream.  Timed steps: only around the launches of the kernel the roofline block prices (the fixed-base
     # accumulation, ten event records per step).  The per-kernel table of all instrumented kinds (~150 records, ~0.7 ms per step) comes
     # from separate instrumented steps after the timed region.
     R.set_timing(0 if os.environ.get("ROFL_BENCH_NOTIMING") == "1" else 2)
     rpv = R.range_proof_vec
     if args.config != 2:
-        return run_multi_client(args, R, rd, dist, cdev, world, rank, backend)
+        return run_multi_client(args, R, rd, dist, cdev, world, rank, backend, comm)
 
     total_steps = args.warmup + args.steps
     clients = [synth_client(1000 * (s * world + rank)) for s in range(total_steps)]
@@ -584,8 +613,8 @@ def run_rank(args):
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        if args.exchange:
+            comm.barrier()
             torch.cuda.synchronize()
 
     def one_client(vals, bl, idx, s, record):
@@ -611,8 +640,8 @@ def run_rank(args):
     def step(s, record, inputs=None):
         vals, bl = (inputs or clients)[s]
         pr, cm, ok = one_client(vals, bl, s, s, record)
-        if world > 1:       # the exchange step: server-side collection of proof bytes + commitments, verify bits
-            ok, _ = rd.exchange_round([pr, cm], ok, cdev)      # one all-gather: [verify bit | proof bytes | commitments] of every rank
+        if args.exchange:   # the exchange step: server-side collection of proof bytes + commitments, verify bits
+            ok, _ = comm.exchange_round([pr, cm], ok)      # one all-gather: [verify bit | proof bytes | commitments] of every rank
         assert ok, "proof failed to verify"
 
     # cold figures: the reference rebuilds BulletproofGens in every call; here the tables are built once per (n, m)
@@ -636,19 +665,15 @@ def run_rank(args):
     gc.enable()
     ru1 = resource.getrusage(resource.RUSAGE_SELF)
     cpu_busy = ((ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)) / elapsed
-    rccl_world = 1
-    if world > 1:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
-        ones = torch.ones(1, dtype=torch.int32, device=cdev)
-        dist.all_reduce(ones)                               # every rank that really joined the communicator counts once
-        rccl_world = int(ones.item())
-        assert rccl_world == dist.get_world_size() == world
+    rccl_world = 1; runtimes = None
+    if args.exchange:
+        elapsed = float(comm.reduce([elapsed], "max")[0])
+        rccl_world = int(round(comm.reduce([1.0], "sum")[0]))      # every rank that really joined the communicator counts once
+        assert rccl_world == world and (dist is None or dist.get_world_size() == world)
+        runtimes = gather_runtimes(comm)
 
     if rank != 0:
-        if world > 1:
-            dist.barrier(); dist.destroy_process_group()
+        comm.barrier(); comm.close(); dist.destroy_process_group()
         return
 
     K = args.steps
@@ -660,7 +685,7 @@ def run_rank(args):
     for name in ktot:
         ktot[name] = {"ms": 0.0, "launches": 0, "fe_muls": 0, "bytes": 0}
     KI = min(K, 6)
-    if world > 1:      # (rank 0 alone past this point: no more collectives, hence no more steps -- the table then holds the timed steps' kernel only)
+    if args.exchange:  # (rank 0 alone past this point: no more collectives, hence no more steps -- the table then holds the timed steps' kernel only)
         ktot["k_msm_accumulate_fb"] = dict(dom_timed); agg.update(agg_timed); KI = K; instr_elapsed = None
     elif os.environ.get("ROFL_BENCH_NOTIMING") != "1":
         R.set_timing(1)
@@ -679,7 +704,7 @@ def run_rank(args):
         "metric": "range-proof elements/sec (create+verify), d=25k 32-bit" + ("" if NPART == 4 else ", n_partition=%d" % NPART), "value": value, "unit": "elements/s",
         "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": elapsed / K * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32x8 (255-bit integer field)", "data": "synthetic",
-        "rccl_world_size": rccl_world, "collective_backend": backend if world > 1 else None,
+        "rccl_world_size": rccl_world, "collective_backend": comm.backend if args.exchange else None, "hip_runtime_per_rank": runtimes,
         "config": {"workload": "BASELINE cfg 2: L-inf 32-bit range proof, d=25000 (resnet18_intrinsic_25k), 1 client create+verify per step per GPU, inputs handed over as host buffers (H2D inside the timed region)",
                    "d": D, "prove_range": NBITS, "n_partition": NPART, "fp_bits": FP_BITS, "fp_frac": FP_FRAC, "clients_per_step_per_gpu": 1,
                    "host_cores": avail_cores(), "host_cores_pinned": args.host_cores or None, "host_cores_busy": round(cpu_busy, 2), "lanes": R.get_option("lanes"), "wait_policy": "sleep" if os.environ.get("ROFL_BLOCKING_SYNC") == "1" else "spin",
@@ -843,10 +868,10 @@ def run_rank(args):
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, R)
     out["other_configs"] = "bench.py --config 4 | 5 (48 clients sharded over the ranks); profiles/r04_configs.json (scripts/gpu_configs.py): all five BASELINE configs and the e2e partition count P=64, reference bench protocol"
-    print(json.dumps(out))
-    sys.stdout.flush()
+    emit(json.dumps(out))
+    if args.exchange:
+        comm.barrier(); comm.close()
     if world > 1:
-        dist.barrier()
         dist.destroy_process_group()
 
 
@@ -855,6 +880,7 @@ def run_one_process(args):
     rofl_verify_rangeproof_batch call per step; the library deals them round-robin to `--gpus` devices (option "devices") and runs each
     device's share from an internal thread (create: the share as one launch sequence per device; verify: one random-weighted check per
     device's share, verify_batch = 2).  Results are gathered in host memory: inside one process there is no collective to run."""
+    claim_stdout()
     import resource
     import numpy as np
     ndev = args.gpus
@@ -906,7 +932,7 @@ def run_one_process(args):
     ru1 = resource.getrusage(resource.RUSAGE_SELF)
     elapsed = wall - gen_s
     K = args.steps
-    print(json.dumps({"metric": "range-proof elements/sec (create+verify), %d clients d=55k, one host process" % NC, "value": NC * D_MULTI * K / elapsed, "unit": "elements/s",
+    emit(json.dumps({"metric": "range-proof elements/sec (create+verify), %d clients d=55k, one host process" % NC, "value": NC * D_MULTI * K / elapsed, "unit": "elements/s",
                       "n_gpus": ndev, "steps": K, "warmup": args.warmup, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                       "dtype": "u32x8 (255-bit integer field)", "data": "synthetic", "rccl_world_size": None, "collective_backend": None,
                       "config": {"workload": "BASELINE cfg 4: L-inf 32-bit range proofs, d=55000, %d clients, ONE host process driving %d logical device(s) on %d physical GPU(s) through the C ABI "
@@ -916,7 +942,14 @@ def run_one_process(args):
                                  "host_cores_busy": round(((ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime) - gen_s) / max(elapsed, 1e-9), 2)},
                       "breakdown_ms_per_step": {k: phase[k] / K * 1e3 for k in ("create", "verify")},
                       "create_only_elements_per_s": NC * D_MULTI * K / phase["create"], "verify_only_elements_per_s": NC * D_MULTI * K / phase["verify"]}))
-    sys.stdout.flush()
+
+
+def gather_runtimes(comm):
+    """config.hip_runtime of every rank (one 512-byte record each through the communicator): the ranks of a node must agree"""
+    import numpy as np
+    rec = (";".join(mapped_hip_runtime()).encode()[:511]).ljust(512, b"\0")
+    _, per = comm.exchange_round([np.frombuffer(rec, dtype=np.uint8)], True)
+    return [bytes(p[0]).rstrip(b"\0").decode(errors="replace").split(";") for p in per]
 
 
 def mapped_hip_runtime():
@@ -946,14 +979,22 @@ def main():
                 sys.stderr.write("bench.py: the run on the system HIP runtime ended with %d; repeating on the process's runtime\n" % cp.returncode)
             except Exception as e:
                 sys.stderr.write("bench.py: the run on the system HIP runtime failed (%r); repeating on the process's runtime\n" % (e,))
-        args.hip_runtime = "process"
+        # A rank of a multi-process run (and the one-process mode) maps the same runtime itself: every rank count then runs the library --
+        # and, through rofl_comm_*, its RCCL collectives -- on ONE runtime, the one the N = 1 headline uses.  (No child-process retry here:
+        # a rank cannot respawn itself under a launcher; a runtime that cannot be mapped leaves the rank on the process's runtime.)
+        is_rank = "WORLD_SIZE" in os.environ or args.one_process
+        args.hip_runtime = "system" if (is_rank and os.path.exists(SYSTEM_HIP) and not os.environ.get("ROFL_BENCH_DRYRUN") and not (args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.one_process)) else "process"
     if args.hip_runtime == "system":
-        if args.gpus > 1 or "WORLD_SIZE" in os.environ:
-            sys.stderr.write("bench.py: --hip-runtime system is an N = 1 mode\n"); sys.exit(2)
         if os.environ.get("BENCH_TEST_FAIL_SYSTEM_RUNTIME"):      # tests/test_gpu_dist.py: the fallback of `auto`
             sys.exit(3)
         import ctypes
-        ctypes.CDLL(SYSTEM_HIP, mode=ctypes.RTLD_GLOBAL)      # before anything imports torch
+        try:
+            ctypes.CDLL(SYSTEM_HIP, mode=ctypes.RTLD_GLOBAL)      # before anything imports torch
+            os.environ.setdefault("ROFL_RCCL_LIB", os.path.join(os.path.dirname(SYSTEM_HIP), "librccl.so.1"))      # not the copy torch bundles
+        except OSError as e:
+            if "WORLD_SIZE" not in os.environ and not args.one_process:
+                raise
+            sys.stderr.write("bench.py: %s could not be mapped (%r): this rank stays on the process's HIP runtime\n" % (SYSTEM_HIP, e))
     if args.one_process:
         if args.config != 4:
             sys.stderr.write("bench.py: --one-process is a mode of --config 4\n"); sys.exit(2)

@@ -21,7 +21,7 @@
  * Return codes: 0 ok; 1 WrongNumBlindingFactors; 2 ValueOutOfRangeError; 3 InvalidBitsize;
  * 4 InvalidAggregation; 5 FormatError; 6 InvalidGeneratorsLength; 7 NormOutOfRangeError;
  * 8 OverflowError; 9 SumError; 10 non-finite input (reference panics); 11 bad parameter
- * (reference panics); 12 nonce stream too short; >= 100 HIP runtime error (100 + hipError_t).
+ * (reference panics); 12 nonce stream too short; 99 RCCL error (rofl_comm_*); >= 100 HIP runtime error (100 + hipError_t).
  * A failed verification is NOT an error: it is reported through *ok_out = 0 with return code 0
  * (range_proof_vec/mod.rs:210-215 maps VerificationError to Ok(false)).
  */
@@ -37,7 +37,7 @@ enum {
     ROFL_OK = 0, ROFL_WRONG_NUM_BLINDING = 1, ROFL_VALUE_OUT_OF_RANGE = 2, ROFL_INVALID_BITSIZE = 3,
     ROFL_INVALID_AGGREGATION = 4, ROFL_FORMAT_ERROR = 5, ROFL_INVALID_GENS_LENGTH = 6,
     ROFL_NORM_OUT_OF_RANGE = 7, ROFL_OVERFLOW = 8, ROFL_SUM_ERROR = 9, ROFL_NON_FINITE = 10,
-    ROFL_BAD_PARAM = 11, ROFL_NONCE_SHORT = 12, ROFL_HIP_ERROR = 100
+    ROFL_BAD_PARAM = 11, ROFL_NONCE_SHORT = 12, ROFL_COMM_ERROR = 99, ROFL_HIP_ERROR = 100
 };
 
 /* Prover randomness.  The reference draws every nonce from rand::thread_rng() inside
@@ -211,6 +211,29 @@ int rofl_wire_encode(const rofl_wire_msg_t *m, uint8_t *out, size_t cap, size_t 
 /* Decode: spans point into `data`; the repeated range_proof entries are gathered into range_proofs_out (capacity in
  * bytes; pass NULL first to learn n_range_proofs / range_proof_len).  Returns 5 (FormatError) on malformed input. */
 int rofl_wire_decode(int kind, const uint8_t *data, size_t len, rofl_wire_msg_t *m, uint8_t *range_proofs_out, size_t range_proofs_cap);
+
+/* ---- multi-process exchange: one process per GPU, RCCL over xGMI ----
+ * The proof path has no collective inside it (clients and chunks are independent, server.rs:656-687); what a round exchanges is its RESULTS:
+ * every rank's [verdict | proof bytes | commitments] to every rank (the server's collection of the client updates, server.rs:379-384), and
+ * a MIN over the verdicts (server.rs:474-484: one failing client fails the round).  These entry points give a host that is not Python that
+ * exchange, on the same HIP runtime as the proofs: librccl (ROFL_RCCL_LIB, default "librccl.so.1") is loaded with dlopen on first use, the
+ * library has no link-time dependency on it, and every call fails with 99 when it cannot be loaded.  One communicator per process, bound
+ * to the device of the thread that calls rofl_comm_init.  Payloads are host memory (that is where the ABI returns proofs and commitments);
+ * they are staged through pinned buffers of the communicator and all-gathered device to device.
+ *   rofl_comm_unique_id : rank 0 draws the 128-byte id (ncclGetUniqueId) and hands it to the other ranks out of band (a file, a socket, the
+ *                         launcher's store)
+ *   rofl_comm_init      : ncclCommInitRank; collective over all `world` ranks
+ *   rofl_comm_allgather : all_out[r * n .. (r + 1) * n) = rank r's `local`; n equal on every rank
+ *   rofl_comm_allreduce_f64 : op 0 sum, 1 min, 2 max over `count` <= 4096 doubles, in place (verdict bits, timings, counts)
+ *   rofl_comm_barrier   : every rank has arrived
+ *   rofl_comm_info      : rank / world of the communicator (-1 / 0 without one), the RCCL version and the path of the loaded library */
+int rofl_comm_unique_id(uint8_t id_out[128]);
+int rofl_comm_init(const uint8_t id[128], int rank, int world);
+int rofl_comm_allgather(const uint8_t *local, size_t n, uint8_t *all_out /* world * n */);
+int rofl_comm_allreduce_f64(double *inout, size_t count, int op);
+int rofl_comm_barrier(void);
+int rofl_comm_info(int *rank_out, int *world_out, int *rccl_version_out, char *lib_path_out, size_t len);
+int rofl_comm_destroy(void);
 
 /* Memory spaces.  The per-element INPUT arrays of rofl_create_rangeproof (values, blindings), rofl_verify_rangeproof(_batch)
  * (proofs, commitments) and of the per-element Sigma-proof entry points (values, randomness, existing commitments, proofs,

@@ -24,6 +24,11 @@
  *       (verify_batch = 2, devices = all) and the per-client path (verify_batch = 1, one device)
  *       out-file    : header as above, then 5 x 2 x n_clients verdicts (i32) and, per scenario, the index of the chunk that was touched
  *                     in each client (n_clients x i32, -1 = untouched), then per client proofs and commitments of scenarios 1..3 as verified
+ *   fl_round comm <id-file> <rank> <world>
+ *       one process per GPU, no Python: rank 0 draws the RCCL unique id (rofl_comm_unique_id) and publishes it in <id-file>, the other ranks
+ *       wait for the file; rofl_set_device(rank), rofl_comm_init, then one round's exchange -- each rank proves one small client, the ranks
+ *       all-gather [verdict | proofs | commitments], every rank verifies the proofs of rank + 1, MIN of the verdicts -- and a barrier.
+ *       (A world of one runs on the one-GPU test box; RCCL refuses two ranks on one GPU.)
  */
 #include <pthread.h>
 #include <stdint.h>
@@ -281,6 +286,79 @@ static int reject(char **argv) {
     return 0;
 }
 
+/* one process per GPU: the exchange of a round through the library's RCCL communicator */
+static int comm_mode(const char *id_file, int rank, int world) {
+    enum { D = 600, NB = 32, PART = 4 };
+    uint8_t id[128], seed[32], *mine, *all, blind[D * 32];
+    float values[D];
+    size_t n_proofs = rofl_rangeproof_chunks(D, PART), plen = rofl_rangeproof_size(NB, D, PART), rec, i, got_len = 0, got_np = 0;
+    rofl_nonce_t nonce;
+    int rc, ok = 0, r = -1, w = 0, ver = 0, src;
+    double v[2];
+    char lib[512];
+    FILE *f;
+    if (world < 1 || rank < 0 || rank >= world) return 2;
+    rc = rofl_set_device(rank);
+    if (rc) die("rofl_set_device", rc);
+    if (rank == 0) {
+        char tmp[1024];
+        rc = rofl_comm_unique_id(id);
+        if (rc) die("rofl_comm_unique_id", rc);
+        snprintf(tmp, sizeof tmp, "%s.tmp", id_file);
+        f = fopen(tmp, "wb");
+        if (!f || fwrite(id, 1, 128, f) != 128) { perror(tmp); return 1; }
+        fclose(f);
+        if (rename(tmp, id_file)) { perror(id_file); return 1; }      /* atomic: a reader never sees half an id */
+    } else {
+        for (i = 0; i < 6000; i++) {                                  /* up to a minute */
+            struct timespec ts;
+            f = fopen(id_file, "rb");
+            if (f) { size_t k = fread(id, 1, 128, f); fclose(f); if (k == 128) break; }
+            ts.tv_sec = 0; ts.tv_nsec = 10000000;
+            nanosleep(&ts, NULL);
+        }
+        if (i == 6000) { fprintf(stderr, "fl_round comm: no unique id in %s\n", id_file); return 1; }
+    }
+    rc = rofl_comm_init(id, rank, world);
+    if (rc) die("rofl_comm_init", rc);
+    rc = rofl_comm_info(&r, &w, &ver, lib, sizeof lib);
+    if (rc || r != rank || w != world) die("rofl_comm_info", rc ? rc : -1);
+    /* this rank's client */
+    lcg_state = 777u + (uint64_t)rank;
+    for (i = 0; i < D; i++) values[i] = (float)((double)lcg() / 4294967296.0 * 200.0 - 100.0);
+    for (i = 0; i < D * 32; i++) blind[i] = (uint8_t)(lcg() >> 24);
+    for (i = 0; i < D; i++) blind[i * 32 + 31] &= 0x0f;
+    memset(&nonce, 0, sizeof nonce);
+    nonce.mode = 1;
+    memset(nonce.seed, 0x30 + rank, 32);
+    rec = 1 + n_proofs * plen + (size_t)D * 32;
+    mine = (uint8_t *)malloc(rec);
+    all = (uint8_t *)malloc(rec * (size_t)world);
+    rc = rofl_create_rangeproof(values, D, blind, D, NB, PART, FP_BITS, FP_FRAC, &nonce, mine + 1, &got_len, &got_np, mine + 1 + n_proofs * plen);
+    if (rc || got_len != plen || got_np != n_proofs) die("rofl_create_rangeproof", rc ? rc : -1);
+    mine[0] = 1;
+    rc = rofl_comm_allgather(mine, rec, all);
+    if (rc) die("rofl_comm_allgather", rc);
+    if (memcmp(all + (size_t)rank * rec, mine, rec) != 0) { fprintf(stderr, "fl_round comm: my own record came back changed\n"); return 1; }
+    src = (rank + 1) % world;
+    memset(seed, 0x5a, sizeof seed);
+    rc = rofl_verify_rangeproof(all + (size_t)src * rec + 1, plen, n_proofs, all + (size_t)src * rec + 1 + n_proofs * plen, D, NB, FP_BITS, FP_FRAC, seed, &ok);
+    if (rc) die("rofl_verify_rangeproof", rc);
+    v[0] = ok ? 1.0 : 0.0; v[1] = 1.0;
+    rc = rofl_comm_allreduce_f64(v, 1, 1);                             /* MIN of the verdicts */
+    if (rc) die("rofl_comm_allreduce_f64(min)", rc);
+    rc = rofl_comm_allreduce_f64(v + 1, 1, 0);                         /* how many ranks joined */
+    if (rc) die("rofl_comm_allreduce_f64(sum)", rc);
+    rc = rofl_comm_barrier();
+    if (rc) die("rofl_comm_barrier", rc);
+    rc = rofl_comm_destroy();
+    if (rc) die("rofl_comm_destroy", rc);
+    printf("rank %d of %d: round verified %d, ranks joined %.0f, rccl %d from %s\n", rank, world, (int)v[0], v[1], ver, lib);
+    free(mine);
+    free(all);
+    return v[0] == 1.0 && (int)v[1] == world ? 0 : 1;
+}
+
 int main(int argc, char **argv) {
     round_t R;
     FILE *f;
@@ -293,8 +371,9 @@ int main(int argc, char **argv) {
     if (argc == 6 && strcmp(argv[1], "bench") == 0)
         return bench((size_t)strtoul(argv[2], NULL, 10), (size_t)strtoul(argv[3], NULL, 10), (size_t)strtoul(argv[4], NULL, 10), (size_t)strtoul(argv[5], NULL, 10));
     if (argc == 8 && strcmp(argv[1], "reject") == 0) return reject(argv);
+    if (argc == 5 && strcmp(argv[1], "comm") == 0) return comm_mode(argv[2], atoi(argv[3]), atoi(argv[4]));
     if (argc != 8 || strcmp(argv[1], "run") != 0) {
-        fprintf(stderr, "usage: fl_round sizes | fl_round bench <d> <prove_range> <n_partition> <iterations> | fl_round run|reject <d> <prove_range> <n_partition> <n_clients> <n_devices> <out-file>\n");
+        fprintf(stderr, "usage: fl_round sizes | fl_round bench <d> <prove_range> <n_partition> <iterations> | fl_round run|reject <d> <prove_range> <n_partition> <n_clients> <n_devices> <out-file> | fl_round comm <id-file> <rank> <world>\n");
         return 2;
     }
     setup_round(&R, argv);

@@ -176,6 +176,51 @@ def get_option(key):
     return out.value
 
 
+class comm:
+    """rofl_comm_*: the exchange steps of a round between the ranks of a node (one process per GPU) through the library's own RCCL
+    communicator -- on the HIP runtime the library is bound to, no torch in the data path.  Payloads are host memory."""
+
+    @staticmethod
+    def unique_id():
+        out = (ctypes.c_uint8 * 128)()
+        _check(lib().rofl_comm_unique_id(out))
+        return bytes(out)
+
+    @staticmethod
+    def init(uid, rank, world):
+        uid = bytes(uid)
+        assert len(uid) == 128
+        _check(lib().rofl_comm_init((ctypes.c_uint8 * 128).from_buffer_copy(uid), int(rank), int(world)))
+
+    @staticmethod
+    def info():
+        r, w, v = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        buf = ctypes.create_string_buffer(1024)
+        _check(lib().rofl_comm_info(ctypes.byref(r), ctypes.byref(w), ctypes.byref(v), buf, _sz(1024)))
+        return {"rank": r.value, "world": w.value, "rccl_version": v.value, "library": buf.value.decode(errors="replace")}
+
+    @staticmethod
+    def allgather(local_u8, world):
+        a = np.ascontiguousarray(local_u8, dtype=np.uint8).reshape(-1)
+        out = np.empty((int(world), a.size), dtype=np.uint8)
+        _check(lib().rofl_comm_allgather(_ptr(a), _sz(a.size), _ptr(out)))
+        return out
+
+    @staticmethod
+    def allreduce(values, op="sum"):
+        a = np.ascontiguousarray(values, dtype=np.float64).reshape(-1).copy()
+        _check(lib().rofl_comm_allreduce_f64(_ptr(a), _sz(a.size), {"sum": 0, "min": 1, "max": 2}[op]))
+        return a
+
+    @staticmethod
+    def barrier():
+        _check(lib().rofl_comm_barrier())
+
+    @staticmethod
+    def destroy():
+        _check(lib().rofl_comm_destroy())
+
+
 def msm_retries():
     """test hook (include/rofl_zk_debug.h): process-wide counters of the MSM driver --
     {"done", "small_overflow", "bin_overflow_to_slots", "slot_overflow"}"""

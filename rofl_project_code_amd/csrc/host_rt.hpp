@@ -12,6 +12,7 @@ static const Knob KNOBS[] = {
     {"ROFL_LANES", "3", "calls that can be in flight on a device (HIP stream + workspace each); 1..16, larger values are clamped (with a note on stderr)"},
     {"ROFL_DEVICES", "0", "option devices: bit mask of the logical devices the batch entry points shard their clients over (0 = the calling thread's device only)"},
     {"ROFL_DEVICE_MAP", "", "logical -> physical HIP device, comma separated (0,0 = two logical devices on GPU 0: how the multi-device paths are tested on a one-GPU box); default: identity"},
+    {"ROFL_RCCL_LIB", "librccl.so.1", "the RCCL library rofl_comm_* loads with dlopen (a host that has torch in the process names /opt/rocm/lib/librccl.so.1: the bare soname would resolve to torch's bundled copy)"},
     {"ROFL_HOST_THREADS", "usable cores, in [2, 16]", "threads of the primary lane's host pool (window combination, encodings, transcripts of a round); other lanes: 6"},
     {"ROFL_POOL_SPIN_US", "400", "how long an idle pool worker polls for the next job before it sleeps (0 = sleep at once)"},
     {"ROFL_BLOCKING_SYNC", "-1", "option blocking_sync: -1 spin while <= 3 calls are in flight, 0 always spin, 1 sleep between polls"},

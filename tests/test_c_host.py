@@ -133,3 +133,14 @@ def test_c_host_server_role_rejects_per_client(fl_round, tmp_path, shape):
             assert (c + 1) * chunk <= d
             rc, ok = orc.verify_rangeproof(pr[c:c + 1].copy(), cm[c * chunk:(c + 1) * chunk].copy(), nb, fp[0], fp[1])
             assert rc != 0 or ok is False, (s, i, c)
+
+
+@pytest.mark.gpu
+def test_c_host_exchanges_a_round_through_the_library_rccl(fl_round, tmp_path):
+    """`fl_round comm`: a compiled host with no interpreter and no torch forms the library's RCCL communicator (unique id through a file), proves a
+    client, all-gathers [verdict | proofs | commitments], verifies the next rank's proofs and reduces the verdicts -- the exchange of
+    SURVEY 8(e) for a C / Rust rofl_service.  A world of one on the one-GPU box (RCCL refuses two ranks on one GPU)."""
+    env = dict(os.environ, ROFL_RCCL_LIB="/opt/rocm/lib/librccl.so.1")
+    r = subprocess.run([fl_round, "comm", str(tmp_path / "rccl.id"), "0", "1"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "rank 0 of 1: round verified 1, ranks joined 1" in r.stdout and "/opt/rocm" in r.stdout, r.stdout

@@ -4,6 +4,7 @@ proof bytes + commitments are all-gathered and each rank verifies -- on the GPU 
 Also: bench.py --gpus 2 starts its own two ranks and reports n_gpus = 2."""
 import json
 import os
+import socket
 import subprocess
 import sys
 
@@ -182,3 +183,75 @@ def test_headline_runs_on_the_system_hip_runtime_and_falls_back():
     assert "repeating on the process's runtime" in r.stderr
     j = json.loads(r.stdout.strip().splitlines()[-1])
     assert not any(x.startswith("/opt/rocm") for x in j["config"]["hip_runtime"]) and j["value"] > 0
+
+
+_LIB_RCCL_WORLD1 = r"""
+import ctypes, os, sys
+ctypes.CDLL("/opt/rocm/lib/libamdhip64.so.7", mode=ctypes.RTLD_GLOBAL)      # what a compiled host links; no torch in this process
+os.environ["ROFL_RCCL_LIB"] = "/opt/rocm/lib/librccl.so.1"
+sys.path.insert(0, %r)
+import numpy as np
+import rofl_project_code_amd as R
+from rofl_project_code_amd import api
+assert "torch" not in sys.modules
+R.set_device(0)
+uid = api.comm.unique_id()
+api.comm.init(uid, 0, 1)
+info = api.comm.info()
+assert info["rank"] == 0 and info["world"] == 1 and info["rccl_version"] > 20000 and info["library"].startswith("/opt/rocm"), info
+rng = np.random.default_rng(3)
+pr = rng.integers(0, 256, size=(4, 1440), dtype=np.uint8); cm = rng.integers(0, 256, size=(25000, 32), dtype=np.uint8)
+buf = np.concatenate([[1], pr.reshape(-1), cm.reshape(-1)]).astype(np.uint8)
+got = api.comm.allgather(buf, 1)
+assert got.shape == (1, buf.size) and (got[0] == buf).all()
+big = rng.integers(0, 256, size=6 * 55000 * 32 + 17, dtype=np.uint8)       # a rank's share of a cfg-4 round (six clients' commitments)
+assert (api.comm.allgather(big, 1)[0] == big).all()
+assert api.comm.allreduce([1.0, 0.0, 2.5], "min").tolist() == [1.0, 0.0, 2.5] and api.comm.allreduce([3.0], "sum")[0] == 3.0 and api.comm.allreduce([7.25], "max")[0] == 7.25
+api.comm.barrier()
+# a proof made and verified in the same process, on the same runtime, with the communicator alive
+vals = rng.uniform(-100, 100, 600).astype(np.float32); bl = rng.integers(0, 256, size=(600, 32), dtype=np.uint8); bl[:, 31] &= 0x0F
+p2, c2 = R.range_proof_vec.create_rangeproof(vals, bl, 32, 4, nonce=R.Nonce.seeded(b"\x07" * 32), fp=(32, 7))
+assert R.range_proof_vec.verify_rangeproof(p2, c2, 32, fp=(32, 7))
+try:
+    api.comm.init(uid, 0, 1); raise SystemExit("a second communicator was accepted")
+except R.RoflError as e:
+    assert e.code == 11
+api.comm.destroy(); api.comm.destroy()
+try:
+    api.comm.barrier(); raise SystemExit("a collective without a communicator was accepted")
+except R.RoflError as e:
+    assert e.code == 11
+maps = sorted({ln.split()[-1] for ln in open("/proc/self/maps") if "libamdhip64" in ln})
+assert len(maps) == 1 and maps[0].startswith("/opt/rocm"), maps
+print("lib rccl ok", info["rccl_version"], maps[0])
+"""
+
+
+def test_library_rccl_communicator_world_of_one():
+    """rofl_comm_* (include/rofl_zk.h): the library's own RCCL communicator on the real GPU in a group of one -- librccl from /opt/rocm loaded
+    by the library next to the HIP runtime it is bound to, no torch in the process: unique id, init, all-gather of a round's payload, the
+    reductions, a proof beside the live communicator, the error paths.  The first multi-GPU run is then not RCCL's first run on this path."""
+    r = subprocess.run([sys.executable, "-c", _LIB_RCCL_WORLD1 % ROOT], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "lib rccl ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+def test_rank_path_runs_on_the_system_runtime_and_exchanges_through_the_library():
+    """What the driver's multi-GPU launch runs per rank, on the one GPU of the box: a launcher-style environment (WORLD_SIZE = 1) makes bench.py
+    take the rank path -- /opt/rocm's HIP runtime mapped before torch, the exchange step of every timed step through rofl_comm_* (RCCL) -- and
+    the line names the runtime every rank mapped.  The step time must be the headline child's (same runtime, same box): within 3 %."""
+    import json
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", LOCAL_WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ROFL_BENCH_FORCE_COMM="1")
+    argv = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "10", "--warmup", "3", "--no-extras", "--no-cpu-baseline"]
+    r = subprocess.run(argv, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len(r.stdout.strip().splitlines()) == 1, r.stdout      # ONE line on stdout: what RCCL and friends print to fd 1 goes to stderr
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    assert j["rccl_world_size"] == 1 and j["collective_backend"].startswith("rccl ") and "/opt/rocm" in j["collective_backend"], j["collective_backend"]
+    assert any(x.startswith("/opt/rocm") for x in j["config"]["hip_runtime"]) and j["hip_runtime_per_rank"] == [j["config"]["hip_runtime"]]
+    env2 = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r2 = subprocess.run(argv, capture_output=True, text=True, timeout=900, env=env2)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    h = json.loads(r2.stdout.strip().splitlines()[-1])
+    # the exchange (one all-gather of 0.8 MB through RCCL in a group of one) is inside the rank path's step and not in the headline's
+    assert j["median_ms_per_step"] <= 1.03 * h["median_ms_per_step"] + 0.4, (j["median_ms_per_step"], h["median_ms_per_step"])

@@ -344,3 +344,33 @@ def test_sharded_batch_reports_a_device_that_cannot_be_used(hiplib):
         assert b"HIP" in msg.value or b"hip" in msg.value, msg.value
     finally:
         assert L.rofl_set_option(b"devices", 0) == 0
+
+
+def test_comm_entry_points_fail_cleanly_without_a_gpu_or_a_communicator(hiplib):
+    """rofl_comm_* (the library's RCCL exchange): librccl is loaded on first use (dlopen; no link-time dependency -- the library must load on
+    hosts without RCCL), collectives without a communicator are bad-parameter errors, and without a GPU the unique id is an RCCL error code,
+    not a crash."""
+    import subprocess, sys
+    code = r"""
+import ctypes, os, sys
+L = ctypes.CDLL(%r)
+r, w, v = ctypes.c_int(5), ctypes.c_int(5), ctypes.c_int(0)
+buf = ctypes.create_string_buffer(512)
+rc = L.rofl_comm_info(ctypes.byref(r), ctypes.byref(w), ctypes.byref(v), buf, ctypes.c_size_t(512))
+assert r.value == -1 and w.value == 0
+one = (ctypes.c_double * 1)(1.0)
+if rc == 0:
+    assert v.value > 20000 and b"rccl" in buf.value
+    assert L.rofl_comm_barrier() == 11 and L.rofl_comm_allreduce_f64(one, ctypes.c_size_t(1), 0) == 11
+    assert L.rofl_comm_allgather(buf, ctypes.c_size_t(8), buf) == 11
+else:
+    assert rc == 99 and L.rofl_comm_barrier() == 99
+assert L.rofl_comm_destroy() == 0
+print("comm ok", rc)
+""" % hiplib._name
+    for libname in ("/opt/rocm/lib/librccl.so.1", "/nonexistent/librccl.so.1"):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, ROFL_RCCL_LIB=libname))
+        assert r.returncode == 0 and "comm ok" in r.stdout, r.stdout + r.stderr[-2000:]
+        if libname.startswith("/nonexistent"):
+            assert "comm ok 99" in r.stdout
+    assert b"librccl" not in subprocess.run(["readelf", "-d", hiplib._name], capture_output=True).stdout      # no link-time dependency

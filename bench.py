@@ -70,6 +70,7 @@ def parse_args():
                          "(N = 1 only); auto (default): an N = 1 run (no process group) happens in a child process in `system` mode and falls back to `process` if that "
                          "child fails; N > 1 and --one-process are `process`.  profiles/r04_experiments.txt item 13")
     ap.add_argument("--clients", type=int, default=48, help="clients of configs 4 / 5 (cifar_large.yml: 48)")
+    ap.add_argument("--l2-create-batch", type=int, default=-1, help="--config 5: clients per EncParamsL2.encrypt_batch call (their 8-bit legs as one rofl_create_rangeproof_batch); 0 / 1 = one encrypt() per client; default 4")
     return ap.parse_args()
 
 
@@ -344,7 +345,7 @@ def run_multi_client(args, R, rd, dist, cdev, world, rank, backend, comm):
     mine = rd.shard_clients(NC, rank, world)
     src = (rank + 1) % world
     group = 6
-    vbatch = (2 if args.verify_batch < 0 else args.verify_batch) if cfg == 4 else 1
+    vbatch = 2 if args.verify_batch < 0 else args.verify_batch      # the server role: one check per batch (cfg 4: of range proofs; cfg 5: of L2 updates)
     R.set_option("verify_batch", vbatch)
     total_steps = args.warmup + args.steps
     phase = {"create": 0.0, "exchange": 0.0, "verify": 0.0, "payload": 0}
@@ -381,14 +382,25 @@ def run_multi_client(args, R, rd, dist, cdev, world, rank, backend, comm):
             starts = list(range(0, len(mine), group))
             groups = list(cpool.map(make_group, starts)) if cpool else [make_group(g0) for g0 in starts]
             prs = [r_[0] for res in groups for r_ in res]; cms = [r_[1] for res in groups for r_ in res]
-            payloads = [np.stack(prs), np.stack(cms)]
+            payloads = prs + cms      # (one payload part per client and kind: the communicator packs them once; no np.stack copy on top)
+        elif args.l2_create_batch > 1:
+            # the rank's clients in groups: the 8-bit L-inf legs of a group are ONE rofl_create_rangeproof_batch call, the square proofs and sum proofs
+            # of its clients run beside it (EncParamsL2.encrypt_batch); `multi_inflight` groups in flight
+            gsz = args.l2_create_batch
+            def make_group(g0):
+                g = list(range(g0, min(g0 + gsz, len(mine))))
+                ups_ = params.EncParamsL2.encrypt_batch([(ins[k][0], ins[k][1], ins[k][2]) for k in g], 8, P, 32, nonce_seeds=[bytes([(mine[k] + 1) % 256]) * 32 for k in g], fp=FP)
+                return [u.serialize(as_array=True) for u in ups_]
+            starts = list(range(0, len(mine), gsz))
+            blobs = [b for grp_ in (cpool.map(make_group, starts) if cpool else map(make_group, starts)) for b in grp_]
         else:
             def make(k):
                 upd = params.EncParamsL2.encrypt(ins[k][0], ins[k][1], 8, P, 32, nonce_seed=bytes([(mine[k] + 1) % 256]) * 32, rand_scalars=ins[k][2], fp=FP)
-                return np.frombuffer(upd.serialize(), dtype=np.uint8)
+                return upd.serialize(as_array=True)
             blobs = list(cpool.map(make, range(len(mine)))) if cpool else [make(k) for k in range(len(mine))]
+        if cfg != 4:
             assert len({b.size for b in blobs}) == 1
-            payloads = [np.stack(blobs)]
+            payloads = blobs
         t1 = time.perf_counter()
         phase["payload"] = sum(int(x.size) for x in payloads)
         _, per_rank = comm.exchange_round(payloads, True)      # every rank's proofs and commitments (wire messages) to every rank
@@ -396,7 +408,7 @@ def run_multi_client(args, R, rd, dist, cdev, world, rank, backend, comm):
         theirs = per_rank[src]
         n_their = len(rd.shard_clients(NC, src, world))
         if cfg == 4:
-            pp = theirs[0].reshape((n_their,) + payloads[0].shape[1:]); cc = theirs[1].reshape((n_their,) + payloads[1].shape[1:])
+            pp = [theirs[k].reshape(payloads[0].shape) for k in range(n_their)]; cc = [theirs[n_their + k].reshape(payloads[-1].shape) for k in range(n_their)]
             vgroup = n_their if vbatch == 2 else group      # verify_batch = 2: the whole share in one call, one check
             def check_group(g0):
                 r_ = rpv.verify_rangeproof_batch([pp[k] for k in range(g0, min(g0 + vgroup, n_their))], [cc[k] for k in range(g0, min(g0 + vgroup, n_their))],
@@ -406,9 +418,13 @@ def run_multi_client(args, R, rd, dist, cdev, world, rank, backend, comm):
             vstarts = list(range(0, n_their, vgroup))
             oks = [o for res in (cpool.map(check_group, vstarts) if (cpool and len(vstarts) > 1) else map(check_group, vstarts)) for o in res]
             ok = all(oks)
+        elif vbatch == 2:
+            # the server's side of the round: the messages are parsed in place (views of the gathered bytes) and verified as ONE batch --
+            # square proofs, L-inf legs and sum proofs of all clients in three batched calls side by side (EncParamsL2.verify_batch)
+            ups = [params.EncParamsL2.deserialize(theirs[k], copy=False) for k in range(n_their)]
+            ok = all(params.EncParamsL2.verify_batch(ups, verifier_seed=bytes([s % 256]) * 32, fp=FP))
         else:
-            bb = theirs[0].reshape(n_their, -1)
-            check = lambda k: params.EncParamsL2.deserialize(bytes(bb[k])).verify(verifier_seed=bytes([s % 256]) * 32, fp=FP)
+            check = lambda k: params.EncParamsL2.deserialize(theirs[k], copy=False).verify(verifier_seed=bytes([s % 256]) * 32, fp=FP)
             ok = all(cpool.map(check, range(n_their))) if cpool else all(check(k) for k in range(n_their))
         ok = comm.all_verified(ok)
         t3 = time.perf_counter()
@@ -462,7 +478,7 @@ def run_multi_client(args, R, rd, dist, cdev, world, rank, backend, comm):
                                       "proof bytes + commitments -> every rank batch-verifies the share of rank+1 -> MIN all-reduce of the verdicts" % (cfg, kind, NC, world),
                           "d": D_MULTI, "clients": NC, "clients_per_rank": len(mine), "prove_range": NBITS if cfg == 4 else 8, "l2_range": None if cfg == 4 else 32,
                           "n_partition": P, "fp_bits": FP_BITS, "fp_frac": FP_FRAC, "host_cores": avail_cores(), "host_cores_pinned": args.host_cores or None,
-                          "host_cores_busy": round(cpu_busy, 2), "lanes": R.get_option("lanes"), "verify_batch": vbatch if cfg == 4 else None, "hip_runtime": mapped_hip_runtime(),
+                          "host_cores_busy": round(cpu_busy, 2), "lanes": R.get_option("lanes"), "verify_batch": vbatch, "hip_runtime": mapped_hip_runtime(),
                           "clients_in_flight_per_rank": (args.multi_inflight if cfg == 5 else ("create: %d batched calls of 6 clients in flight; verify: %s" % (args.multi_inflight if cpool else 1, "ONE call for the rank's whole share, one random-weighted check (verify_batch = 2)" if vbatch == 2 else "batched calls of 6 clients, one check per client")))},
                "breakdown_ms_per_step_rank0": {k: phase[k] / K * 1e3 for k in ("create", "exchange", "verify")},
                "create_only_elements_per_s": len(mine) * D_MULTI / cd if cd else None,
@@ -550,6 +566,8 @@ def run_rank(args):
         os.environ.setdefault("ROFL_HOST_THREADS", str(max(2, min(14, int(avail_cores() / local_world) - 1))))
     if args.multi_inflight <= 0:
         args.multi_inflight = 3 if args.config == 4 else 4
+    if args.config == 5 and args.l2_create_batch < 0:
+        args.l2_create_batch = 4      # the rank's clients in groups of four: their 8-bit legs as one batched call (profiles/r05_experiments.txt)
     if args.config == 4:
         # cfg 4: the clients of a rank go through rofl_create_rangeproof_batch / rofl_verify_rangeproof_batch six at a time, `multi_inflight` such
         # calls in flight on separate lanes (host threads): the latency-bound tail of one call overlaps the throughput-bound phases of another

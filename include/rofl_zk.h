@@ -120,6 +120,13 @@ int rofl_verify_rangeproof_batch(size_t n_clients, const uint8_t *const *proofs,
                                  size_t n_proofs, const uint8_t *const *commits32, size_t d,
                                  size_t prove_range, unsigned fp_bits, unsigned fp_frac,
                                  const uint8_t verifier_seed[32], int *ok_out);
+/* The same with the commitments of client i read every `commit_stride` >= 32 bytes from commits32[i]: the L components of ElGamal pairs
+ * (stride 64) or SquareRandProofCommitments (stride 96) exactly as they arrive on the wire -- what the server's verify does with
+ * `enc_values.iter().map(|x| x.c.L)` (rofl_service/src/flserver/params.rs:197, 215) without a packing pass on the host. */
+int rofl_verify_rangeproof_batch_strided(size_t n_clients, const uint8_t *const *proofs, size_t proof_len,
+                                         size_t n_proofs, const uint8_t *const *commits32, size_t commit_stride, size_t d,
+                                         size_t prove_range, unsigned fp_bits, unsigned fp_frac,
+                                         const uint8_t verifier_seed[32], int *ok_out);
 /* clip_f32_to_range_vec :104-111 */
 int rofl_clip_f32(const float *in, size_t d, size_t prove_range, unsigned fp_bits, unsigned fp_frac, float *out);
 
@@ -133,6 +140,12 @@ int rofl_create_rangeproof_l2(const float *values, size_t d, const uint8_t *blin
 int rofl_verify_rangeproof_l2(const uint8_t *proof, size_t proof_len, const uint8_t commit[32],
                               size_t prove_range, unsigned fp_bits, unsigned fp_frac,
                               const uint8_t verifier_seed[32], int *ok_out);
+
+/* server side (params.rs:220-231 for every client of a round, server.rs:656-687): n_clients one-value L2 sum proofs of one length, commitment i
+ * = sum of client i's c_sq (commits32: n_clients * 32 bytes).  ok_out[i] = client i's verdict (a malformed member fails alone);
+ * rofl_set_option("verify_batch", 2) checks them with one random-weighted equation and looks closer only when that fails. */
+int rofl_verify_rangeproof_l2_batch(size_t n_clients, const uint8_t *const *proofs, size_t proof_len, const uint8_t *commits32,
+                                    size_t prove_range, unsigned fp_bits, unsigned fp_frac, const uint8_t verifier_seed[32], int *ok_out);
 
 /* ---- per-element Sigma-proofs ----
  * rand_proof_vec/mod.rs:14-118 (create_randproof_vec, create_randproof_vec_existing, verify_randproof_vec):
@@ -149,12 +162,23 @@ int rofl_create_squarerandproof_vec(const float *values, size_t d, const uint8_t
                                     const uint8_t *existing32, unsigned fp_bits, unsigned fp_frac, const rofl_nonce_t *nonce,
                                     uint8_t *proofs_out /* d*192 */, uint8_t *commits_out /* d*96 */);
 int rofl_verify_squarerandproof_vec(const uint8_t *proofs, const uint8_t *commits, size_t d, int *ok_out);
+/* server side: the vectors of n_clients clients (d elements each) in ONE launch sequence -- 55 000 elements alone leave most of the chip idle,
+ * a round of clients fills it.  Every client is its own random linear combination (one problem of a multi-problem Pippenger launch), so
+ * ok_out[i] is client i's verdict exactly as the per-client call gives it; a member with a non-canonical scalar or an undecodable point
+ * gets ok = 0 and the others are still verified.  csq_sum_out32 (may be NULL; n_clients * 32 bytes): sum_i c_sq_i of every client,
+ * compressed -- the commitment of the client's L2 sum proof (params.rs:220, 277), a by-product of decoding (zero bytes = the identity for
+ * a malformed member). */
+int rofl_verify_randproof_vec_batch(size_t n_clients, const uint8_t *const *proofs, const uint8_t *const *commits, size_t d, int *ok_out);
+int rofl_verify_squarerandproof_vec_batch(size_t n_clients, const uint8_t *const *proofs, const uint8_t *const *commits, size_t d,
+                                          int *ok_out, uint8_t *csq_sum_out32);
 /* square_proof_vec/mod.rs:18-159 (create_l2rangeproof_vec(_existing), verify_l2rangeproof_vec over Pedersen commitments only):
  *   commitments 64 B = c_l|c_sq, proof 160 B = c_l'|c_sq'|Z_m|Z_r1|Z_r2; nonces m', r1', r2' at 3i.. */
 int rofl_create_squareproof_vec(const float *values, size_t d, const uint8_t *r1_32, size_t d_r1, const uint8_t *r2_32,
                                 const uint8_t *existing32, unsigned fp_bits, unsigned fp_frac, const rofl_nonce_t *nonce,
                                 uint8_t *proofs_out /* d*160 */, uint8_t *commits_out /* d*64 */);
 int rofl_verify_squareproof_vec(const uint8_t *proofs, const uint8_t *commits, size_t d, int *ok_out);
+int rofl_verify_squareproof_vec_batch(size_t n_clients, const uint8_t *const *proofs, const uint8_t *const *commits, size_t d,
+                                      int *ok_out, uint8_t *csq_sum_out32);
 /* compressed_rand_proof/mod.rs:43-102, 134-160 (helper_prove, helper_prove_existing, helper_verify): ONE 128-byte proof
  * C'.L|C'.R|Z_m|Z_r for all d ElGamal pairs (d*64 B), z = nonce + sum_i x_i c^(i+1); nonces m', r' at index 0, 1.
  * d < 900 000 (size of the reference's label table UNIQUE_U8_TRIPLETS). */

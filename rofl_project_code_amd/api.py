@@ -379,20 +379,22 @@ class range_proof_vec:
         return bool(ok.value)
 
     @staticmethod
-    def verify_rangeproof_batch(proofs_list, commits_list, prove_range, verifier_seed=None, fp=None):
+    def verify_rangeproof_batch(proofs_list, commits_list, prove_range, verifier_seed=None, fp=None, commit_stride=32):
         """One verdict per client (server.rs:656-687 verifies one client per pool task).  The C entry point takes ONE
         (n_proofs, proof_len, d) for the whole batch and reads that many bytes from every client's pointers, and all three are
         attacker-chosen on the wire: clients whose shapes differ from the majority shape are verified on their own (a malformed
-        set counts as not verified), never handed to the batch call with somebody else's lengths."""
+        set counts as not verified), never handed to the batch call with somebody else's lengths.
+        commit_stride = 64 / 96: commits_list[i] is the client's (d, stride) array of ElGamal pairs / SquareRandProofCommitments as it came
+        off the wire and the commitments are its first 32 bytes per row (params.rs:197, 215) -- no packing pass on the host."""
         if len(proofs_list) != len(commits_list):
             raise ValueError("one commitment vector per proof set")
         ps = [np.ascontiguousarray(p, dtype=np.uint8) for p in proofs_list]
-        cs = [_u8(c) for c in commits_list]
+        cs = [_u8(c, last=commit_stride) for c in commits_list]
         n = len(ps)
         if n == 0:
             return []
         seed = bytes(verifier_seed) if verifier_seed is not None else os.urandom(32)
-        shapes = [(p.shape if p.ndim == 2 else None, c.shape if c.ndim == 2 and c.shape[1:] == (32,) else None) for p, c in zip(ps, cs)]
+        shapes = [(p.shape if p.ndim == 2 else None, c.shape if c.ndim == 2 and c.shape[1:] == (commit_stride,) else None) for p, c in zip(ps, cs)]
         valid = [sh for sh in shapes if sh[0] is not None and sh[1] is not None and sh[0][0] > 0 and sh[1][0] > 0]
         res = [False] * n
         if not valid:
@@ -402,14 +404,14 @@ class range_proof_vec:
         for i, sh in enumerate(shapes):
             if sh != major and sh in valid:          # a different but well-formed shape: its own call
                 try:
-                    res[i] = range_proof_vec.verify_rangeproof(ps[i], cs[i], prove_range, verifier_seed=seed, fp=fp)
+                    res[i] = range_proof_vec.verify_rangeproof(ps[i], cs[i][:, :32], prove_range, verifier_seed=seed, fp=fp)
                 except RoflError:
                     res[i] = False
         pp = (ctypes.c_void_p * len(idx))(*[ps[i].ctypes.data for i in idx])
         cp = (ctypes.c_void_p * len(idx))(*[cs[i].ctypes.data for i in idx])
         ok = (ctypes.c_int * len(idx))()
-        _check(lib().rofl_verify_rangeproof_batch(_sz(len(idx)), pp, _sz(major[0][1]), _sz(major[0][0]), cp, _sz(major[1][0]),
-                                                  _sz(prove_range), *_fp(fp), seed, ok))
+        _check(lib().rofl_verify_rangeproof_batch_strided(_sz(len(idx)), pp, _sz(major[0][1]), _sz(major[0][0]), cp, _sz(commit_stride), _sz(major[1][0]),
+                                                          _sz(prove_range), *_fp(fp), seed, ok))
         for k, i in enumerate(idx):
             res[i] = bool(ok[k])
         return res
@@ -440,8 +442,54 @@ class l2_range_proof_vec:
         return bool(ok.value)
 
 
+    @staticmethod
+    def verify_rangeproof_l2_batch(proofs, commits, prove_range, verifier_seed=None, fp=None):
+        """rofl_verify_rangeproof_l2_batch: the L2 sum proofs of a round's clients (one length), commits[i] = client i's sum of c_sq.
+        One verdict per client."""
+        ps = [np.ascontiguousarray(p, dtype=np.uint8).reshape(-1) for p in proofs]
+        n = len(ps)
+        if n == 0:
+            return []
+        c = np.ascontiguousarray(commits, dtype=np.uint8).reshape(n, 32)
+        if len({p.size for p in ps}) != 1:
+            raise RoflError(5, "FormatError: the proofs of a batch have one length")
+        seed = bytes(verifier_seed) if verifier_seed is not None else os.urandom(32)
+        pp = (ctypes.c_void_p * n)(*[p.ctypes.data for p in ps])
+        ok = (ctypes.c_int * n)()
+        _check(lib().rofl_verify_rangeproof_l2_batch(_sz(n), pp, _sz(ps[0].size), _ptr(c), _sz(prove_range), *_fp(fp), seed, ok))
+        return [bool(x) for x in ok]
+
+
+def _sigma_verify_batch(fn, plen, clen, proofs_list, commits_list, want_csq):
+    """shared body of the three rofl_verify_*_vec_batch bindings: vectors of one length d; returns (verdicts, csq sums or None)"""
+    ps = [np.ascontiguousarray(p, dtype=np.uint8).reshape(-1, plen) for p in proofs_list]
+    cs = [np.ascontiguousarray(c, dtype=np.uint8).reshape(-1, clen) for c in commits_list]
+    n = len(ps)
+    if n != len(cs):
+        raise ValueError("one commitment vector per proof vector")
+    if n == 0:
+        return [], (np.zeros((0, 32), np.uint8) if want_csq else None)
+    d = ps[0].shape[0]
+    if any(p.shape[0] != d for p in ps) or any(c.shape[0] != d for c in cs):
+        raise RoflError(1, "WrongNumberOfElGamalPairs: the vectors of a batch have one length")
+    pp = (ctypes.c_void_p * n)(*[p.ctypes.data for p in ps])
+    cp = (ctypes.c_void_p * n)(*[c.ctypes.data for c in cs])
+    ok = (ctypes.c_int * n)()
+    if want_csq is None:
+        _check(fn(_sz(n), pp, cp, _sz(d), ok))
+        return [bool(x) for x in ok], None
+    sums = np.zeros((n, 32), dtype=np.uint8)
+    _check(fn(_sz(n), pp, cp, _sz(d), ok, _ptr(sums) if want_csq else None))
+    return [bool(x) for x in ok], (sums if want_csq else None)
+
+
 class rand_proof_vec:
     """rand_proof_vec/mod.rs:14-118.  proofs uint8[d,128], ElGamal pairs uint8[d,64]."""
+
+    @staticmethod
+    def verify_randproof_vec_batch(proofs_list, pairs_list):
+        """rofl_verify_randproof_vec_batch: the vectors of a round's clients in one launch sequence; one verdict per client"""
+        return _sigma_verify_batch(lib().rofl_verify_randproof_vec_batch, 128, 64, proofs_list, pairs_list, None)[0]
 
     @staticmethod
     def create_randproof_vec(values, random_vec, nonce=None, existing=None, fp=None):
@@ -505,8 +553,20 @@ class square_rand_proof_vec:
         return bool(ok.value)
 
 
+    @staticmethod
+    def verify_l2rangeproof_vec_batch(proofs_list, commits_list, with_csq_sums=False):
+        """rofl_verify_squarerandproof_vec_batch: one verdict per client; with_csq_sums: also every client's sum of c_sq (params.rs:220)"""
+        ok, sums = _sigma_verify_batch(lib().rofl_verify_squarerandproof_vec_batch, 192, 96, proofs_list, commits_list, bool(with_csq_sums))
+        return (ok, sums) if with_csq_sums else ok
+
+
 class square_proof_vec:
     """square_proof_vec/mod.rs:18-159.  proofs uint8[d,160], commitments uint8[d,64] (c_l | c_sq)."""
+
+    @staticmethod
+    def verify_l2rangeproof_vec_batch(proofs_list, commits_list, with_csq_sums=False):
+        ok, sums = _sigma_verify_batch(lib().rofl_verify_squareproof_vec_batch, 160, 64, proofs_list, commits_list, bool(with_csq_sums))
+        return (ok, sums) if with_csq_sums else ok
 
     @staticmethod
     def create_l2rangeproof_vec(values, random_vec, random_vec_2, nonce=None, existing=None, fp=None):

@@ -13,7 +13,7 @@ static const Knob KNOBS[] = {
     {"ROFL_DEVICES", "0", "option devices: bit mask of the logical devices the batch entry points shard their clients over (0 = the calling thread's device only)"},
     {"ROFL_DEVICE_MAP", "", "logical -> physical HIP device, comma separated (0,0 = two logical devices on GPU 0: how the multi-device paths are tested on a one-GPU box); default: identity"},
     {"ROFL_RCCL_LIB", "librccl.so.1", "the RCCL library rofl_comm_* loads with dlopen (a host that has torch in the process names /opt/rocm/lib/librccl.so.1: the bare soname would resolve to torch's bundled copy)"},
-    {"ROFL_HOST_THREADS", "usable cores, in [2, 16]", "threads of the primary lane's host pool (window combination, encodings, transcripts of a round); other lanes: 6"},
+    {"ROFL_HOST_THREADS", "usable cores, in [2, 16]", "threads of the primary lane's host pool (window combination, encodings, transcripts of a round); other lanes: usable cores, in [6, 12]"},
     {"ROFL_POOL_SPIN_US", "400", "how long an idle pool worker polls for the next job before it sleeps (0 = sleep at once)"},
     {"ROFL_BLOCKING_SYNC", "-1", "option blocking_sync: -1 spin while <= 3 calls are in flight, 0 always spin, 1 sleep between polls"},
     {"ROFL_VERIFY_ZIP_TRUNCATE", "0", "option verify_zip_truncate: 1 = the reference's zip-truncating verify_rangeproof"},
@@ -363,6 +363,26 @@ struct Stage {
         dirty = false;
     }
 };
+// The staging copy of a large input: caller memory -> pinned staging, read once by the DMA engine afterwards.  Ordinary stores would first
+// fetch every destination line (read-for-ownership): three units of memory traffic per byte copied instead of two, and the copy of a
+// round's 760 MB of Sigma-proofs is bound by exactly that.  Non-temporal stores from 64 KB on (AVX2, checked at run time).
+__attribute__((target("avx2"))) inline void stream_copy_avx2(uint8_t *dst, const uint8_t *src, size_t n) {
+    size_t head = (32 - ((uintptr_t)dst & 31)) & 31; if (head > n) head = n;
+    memcpy(dst, src, head); dst += head; src += head; n -= head;
+    size_t i = 0;
+    for (; i + 128 <= n; i += 128) {
+        __m256i a = _mm256_loadu_si256((const __m256i *)(src + i)), b = _mm256_loadu_si256((const __m256i *)(src + i + 32));
+        __m256i c = _mm256_loadu_si256((const __m256i *)(src + i + 64)), e = _mm256_loadu_si256((const __m256i *)(src + i + 96));
+        _mm256_stream_si256((__m256i *)(dst + i), a); _mm256_stream_si256((__m256i *)(dst + i + 32), b);
+        _mm256_stream_si256((__m256i *)(dst + i + 64), c); _mm256_stream_si256((__m256i *)(dst + i + 96), e);
+    }
+    _mm_sfence();
+    memcpy(dst + i, src + i, n - i);
+}
+inline void stage_copy(void *dst, const void *src, size_t n) {
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2 && n >= ((size_t)64 << 10)) stream_copy_avx2((uint8_t *)dst, (const uint8_t *)src, n); else memcpy(dst, src, n);
+}
 inline bool is_device_ptr(const void *p) {
     hipPointerAttribute_t a;
     if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }      // unregistered host memory
@@ -628,7 +648,9 @@ struct Ctx {
         msm_fb = p.msm_fb; msm_fb_min = p.msm_fb_min; msm_lr = p.msm_lr;
         fold_min = p.fold_min; msm_dev_horner_min = p.msm_dev_horner_min; msm_small_max = p.msm_small_max; msm_slots = p.msm_slots; fold_t = p.fold_t; fold_t1 = p.fold_t1; fold_k = p.fold_k; fold_tab = p.fold_tab;
         fold_unit = p.fold_unit; fold_threads = p.fold_threads; nlanes = 1;
-        { int nt = 6; if (const char *e = knob("ROFL_HOST_THREADS")) nt = atoi(e); if (nt < 1) nt = 1; pool.reset(new HostPool(nt, &g_calls_in_flight)); }
+        // (the other lanes: up to twelve -- a batched server call that lands on a sibling lane stages hundreds of MB through its pool, and which of two
+        //  concurrent batch calls finds the primary lane free is a race; idle workers sleep on their futex words and cost nothing)
+        { int nt = std::min(12, std::max(6, usable_cores())); if (const char *e = knob("ROFL_HOST_THREADS")) nt = atoi(e); if (nt < 1) nt = 1; pool.reset(new HostPool(nt, &g_calls_in_flight)); }
         inited = true;
     }
 };

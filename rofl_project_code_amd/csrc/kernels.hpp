@@ -437,6 +437,26 @@ __global__ void __launch_bounds__(TPB) k_point_sum(const ge *in, u32 n, ge *out)
 }
 #endif
 
+// sums of decoded points held as affine niels triples: vector y = in[y * stride .. + n) -> out[y][gridDim.x] block partials.  The batched
+// Sigma-proof verifier has every c_sq decoded already (k_sigma_vprep); `sum c_sq` per client (params.rs:220) costs one mixed addition each.
+#if ROFL_KG(4)
+__global__ void __launch_bounds__(TPB) k_niels_sum(const niels *in, u32 n, size_t stride, ge *out) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    ge *lds = reinterpret_cast<ge *>(smem);
+    u32 t = threadIdx.x;
+    const niels *src = in + (size_t)blockIdx.y * stride;
+    gd acc = gd_identity();
+    for (u32 i = blockIdx.x * blockDim.x + t; i < n; i += gridDim.x * blockDim.x) acc = gd_madd(acc, load_nd(&src[i]), false);
+    lds[t] = gd_pack(acc);
+    __syncthreads();
+    for (u32 s = blockDim.x / 2; s > 0; s >>= 1) {
+        if (t < s) lds[t] = ge_add(lds[t], lds[t + s]);
+        __syncthreads();
+    }
+    if (t == 0) store_ge(&out[(size_t)blockIdx.y * gridDim.x + blockIdx.x], lds[0]);
+}
+#endif
+
 // sum of compressed points (params.rs:220, 277: `enc_values.iter().map(|x| x.c_sq).sum()`): decode + grid-stride sum + LDS tree
 #if ROFL_KG(4)
 __global__ void __launch_bounds__(TPB) k_decode_sum(const uint8_t *in, u32 n, u32 stride, ge *out, u32 *status) {
@@ -2241,18 +2261,25 @@ __global__ void __launch_bounds__(64) k_sigma_verify(int kind, u32 d, const uint
 // 2-4 variable-base scalar multiplications (~325 point operations each).  Here the 2-3 group equations of all d elements are folded
 // into a single random linear combination  sum_i (w1_i e1_i + w2_i e2_i + w3_i e3_i) == 0  -- one Pippenger MSM over the 4-6 d decoded
 // points (~16 mixed additions per point) plus two fixed-base terms -- exactly the trick upstream's verify_multiple uses for range
-// proofs.  A forged element passes with probability 2^-252 (the weights come from fresh OS randomness).  This kernel does the
+// proofs.  A forged element passes with probability 2^-126 at most (127- or 126-bit weights from fresh OS randomness).  This kernel does the
 // per-element part: decode + validity (FormatError), the element's Merlin transcript -> c_i, the weights, the MSM scalars, and the
 // block partial sums of the B / B_blinding coefficients.
-//   e1: Z_m B + Z_r1 Bb - c L - L' = 0        e2 (kinds 0, 1): Z_r1 B - c R - R' = 0        e3 (kinds 1, 2): Z_m L + Z_r2 Bb - c Csq - Csq' = 0
+//   e1: c L + L' - Z_m B - Z_r1 Bb = 0        e2 (kinds 0, 1): c R + R' - Z_r1 B = 0        e3 (kinds 1, 2): c Csq + Csq' - Z_m L - Z_r2 Bb = 0
 // point / scalar slot k of element i at index k * d + i;  slots: L, L', [R, R'], [Csq, Csq'].
 #if ROFL_KG(3)
-__global__ void __launch_bounds__(TPB) k_sigma_vprep(int kind, u32 d, const uint8_t *proofs, const uint8_t *commits, DMerlin init, NonceSeed wseed,
-                                                      niels *pts, sc *scal_canon, sc *fixed_part /* [gridDim.x][2] Montgomery */, u32 *status) {
+// blockIdx.y = vector (the clients of a server-side batch: `d` elements each, laid out one after the other in every array; its own
+// status word; weight index widx0 + y * d + i so that no two elements of a batch share a weight).
+__global__ void __launch_bounds__(TPB) k_sigma_vprep(int kind, u32 d, const uint8_t *proofs, const uint8_t *commits, DMerlin init, NonceSeed wseed, u64 widx0, u32 wbits,
+                                                      niels *pts, sc *scal_canon, sc *fixed_part /* [gridDim.y][gridDim.x][2] Montgomery */, u32 *status /* [gridDim.y] */) {
     __shared__ sc lds[TPB * 2];
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     bool has_R = kind != 2, has_sq = kind != 0;
     u32 npts = 1 + (has_R ? 1 : 0) + (has_sq ? 1 : 0), nn = has_sq ? 3 : 2, clen = 32 * npts, plen = 32 * (npts + nn), sq_off = has_R ? 64 : 32;
+    {
+        const size_t y = blockIdx.y;
+        proofs += y * d * plen; commits += y * d * clen; pts += y * 2 * npts * d; scal_canon += y * 2 * npts * d;
+        fixed_part += y * gridDim.x * 2; status += y; widx0 += y * d;
+    }
     sc v[2] = {sc_zero(), sc_zero()};
     if (i < d) {
         const uint8_t *pf = proofs + (size_t)plen * i, *cm = commits + (size_t)clen * i, *z = pf + clen;
@@ -2260,38 +2287,44 @@ __global__ void __launch_bounds__(TPB) k_sigma_vprep(int kind, u32 d, const uint
         bool okf = !sc_geq_l(zm.v) && !sc_geq_l(zr1.v) && !sc_geq_l(zr2.v);
         sc c;
         { DMerlin t = init; sg_transcript(kind, t, cm, pf, has_R); c = dm_challenge_scalar(t, "c", 1); }      // needs the bytes only
-        // weights: SHAKE256("rofl-zk/sgbatch" || seed || 3 i + k), wide-reduced
+        // weights: the low `wbits` (127 or 126) bits of SHAKE256("rofl-zk/sgbatch" || seed || 3 i + k).  Weights of that size are what batch
+        // verification needs (a forged element passes with probability 2^-wbits) and the three primed points then carry short scalars: their
+        // upper windows are empty, a quarter of the MSM's additions gone.  The host picks wbits so that the top bit of a weight is NOT the top
+        // bit of a window of the MSM's layout: the signed-digit recoding would carry it into the next window as the digit +1 for half of all
+        // terms -- one bucket with tens of thousands of entries, summed by one thread.  The combination is taken with the sign that leaves +w on the primed points:
+        //   sum_i  w1 (c L + L' - Z_m B - Z_r1 Bb) + w2 (c R + R' - Z_r1 B) + w3 (c Csq + Csq' - Z_m L - Z_r2 Bb) == 0
         sc w[3];
         const u64 dom[2] = {0x2f6b7a2d6c666f72ULL, 0x686374616267732fULL};      // "rofl-zk/" "/sgbatch"
         for (int k = 0; k < 3; k++) {
-            u64 st[25]; shake256_seeded_block(st, dom, wseed.w, 3ull * i + k);
-            sc lo, hi;
+            u64 st[25]; shake256_seeded_block(st, dom, wseed.w, 3ull * (widx0 + i) + k);
 #pragma unroll
-            for (int q = 0; q < 4; q++) { lo.v[2 * q] = (u32)st[q]; lo.v[2 * q + 1] = (u32)(st[q] >> 32); hi.v[2 * q] = (u32)st[4 + q]; hi.v[2 * q + 1] = (u32)(st[4 + q] >> 32); }
-            w[k] = sc_from_wide(lo, hi);
+            for (int q = 0; q < 2; q++) { w[k].v[2 * q] = (u32)st[q]; w[k].v[2 * q + 1] = (u32)(st[q] >> 32); }
+#pragma unroll
+            for (int q = 4; q < 8; q++) w[k].v[q] = 0;
+            w[k].v[3] &= 0xffffffffu >> (128 - wbits);
         }
         if (!has_R) w[1] = sc_zero();
         if (!has_sq) w[2] = sc_zero();
-        // B: w1 Z_m + w2 Z_r1 ; Bb: w1 Z_r1 + w3 Z_r2
-        v[0] = sc_to_mont(sc_add(sc_mul_plain(w[0], zm), sc_mul_plain(w[1], zr1)));
-        v[1] = sc_to_mont(sc_add(sc_mul_plain(w[0], zr1), sc_mul_plain(w[2], zr2)));
+        // B: -(w1 Z_m + w2 Z_r1) ; Bb: -(w1 Z_r1 + w3 Z_r2)
+        v[0] = sc_to_mont(sc_neg(sc_add(sc_mul_plain(w[0], zm), sc_mul_plain(w[1], zr1))));
+        v[1] = sc_to_mont(sc_neg(sc_add(sc_mul_plain(w[0], zr1), sc_mul_plain(w[2], zr2))));
         // one point at a time (six live points would not fit the register file): decode, store its niels form and its scalar
         u32 slot = 0; gd p;
-        okf &= sg_decode(p, cm);                   // L: -w1 c + w3 Z_m
-        store_niels(&pts[(size_t)slot * d + i], sg_affine_niels(p)); store_sc(&scal_canon[(size_t)slot * d + i], sc_sub(sc_mul_plain(w[2], zm), sc_mul_plain(w[0], c))); slot++;
-        okf &= sg_decode(p, pf);                   // L': -w1
-        store_niels(&pts[(size_t)slot * d + i], sg_affine_niels(p)); store_sc(&scal_canon[(size_t)slot * d + i], sc_neg(w[0])); slot++;
+        okf &= sg_decode(p, cm);                   // L: w1 c - w3 Z_m
+        store_niels(&pts[(size_t)slot * d + i], sg_affine_niels(p)); store_sc(&scal_canon[(size_t)slot * d + i], sc_sub(sc_mul_plain(w[0], c), sc_mul_plain(w[2], zm))); slot++;
+        okf &= sg_decode(p, pf);                   // L': w1
+        store_niels(&pts[(size_t)slot * d + i], sg_affine_niels(p)); store_sc(&scal_canon[(size_t)slot * d + i], w[0]); slot++;
         if (has_R) {
-            okf &= sg_decode(p, cm + 32);          // R: -w2 c
-            store_niels(&pts[(size_t)slot * d + i], sg_affine_niels(p)); store_sc(&scal_canon[(size_t)slot * d + i], sc_neg(sc_mul_plain(w[1], c))); slot++;
-            okf &= sg_decode(p, pf + 32);          // R': -w2
-            store_niels(&pts[(size_t)slot * d + i], sg_affine_niels(p)); store_sc(&scal_canon[(size_t)slot * d + i], sc_neg(w[1])); slot++;
+            okf &= sg_decode(p, cm + 32);          // R: w2 c
+            store_niels(&pts[(size_t)slot * d + i], sg_affine_niels(p)); store_sc(&scal_canon[(size_t)slot * d + i], sc_mul_plain(w[1], c)); slot++;
+            okf &= sg_decode(p, pf + 32);          // R': w2
+            store_niels(&pts[(size_t)slot * d + i], sg_affine_niels(p)); store_sc(&scal_canon[(size_t)slot * d + i], w[1]); slot++;
         }
         if (has_sq) {
-            okf &= sg_decode(p, cm + sq_off);      // Csq: -w3 c
-            store_niels(&pts[(size_t)slot * d + i], sg_affine_niels(p)); store_sc(&scal_canon[(size_t)slot * d + i], sc_neg(sc_mul_plain(w[2], c))); slot++;
-            okf &= sg_decode(p, pf + sq_off);      // Csq': -w3
-            store_niels(&pts[(size_t)slot * d + i], sg_affine_niels(p)); store_sc(&scal_canon[(size_t)slot * d + i], sc_neg(w[2])); slot++;
+            okf &= sg_decode(p, cm + sq_off);      // Csq: w3 c
+            store_niels(&pts[(size_t)slot * d + i], sg_affine_niels(p)); store_sc(&scal_canon[(size_t)slot * d + i], sc_mul_plain(w[2], c)); slot++;
+            okf &= sg_decode(p, pf + sq_off);      // Csq': w3
+            store_niels(&pts[(size_t)slot * d + i], sg_affine_niels(p)); store_sc(&scal_canon[(size_t)slot * d + i], w[2]); slot++;
         }
         if (!okf) atomicOr(status, 4u);            // FormatError: the host ignores the sum
     }

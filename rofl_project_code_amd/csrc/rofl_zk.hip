@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>      // types only: the library is loaded with dlopen when rofl_comm_* is first used (no link-time dependency)
 #include <dlfcn.h>
+#include <immintrin.h>
 #include <chrono>
 #include <time.h>
 #include <sched.h>
@@ -235,11 +236,13 @@ int create_impl(Ctx &C, size_t nc, const float *const *values, size_t d, const u
 // `single`: the call is rofl_verify_rangeproof (a malformed set is the call's FormatError); batch calls -- also their one-client shards
 // when a batch is spread over several devices -- give every client its own verdict.  gid[i] (nullptr: i) = client i's index in the
 // caller's batch: it keys the client's random weights, so that a shard draws what the whole batch would have drawn for it.
+// cstride: distance in bytes between two commitments of a client's array (32 = packed; 64 / 96 = the L component of ElGamal pairs /
+// SquareRandProofCommitments as they arrive on the wire, params.rs:197, 215: `enc_values.iter().map(|x| x.c.L)`).
 int verify_impl(Ctx &C, size_t n_clients, const uint8_t *const *proofs, size_t proof_len, size_t n_proofs, const uint8_t *const *commits,
                 size_t d, size_t prove_range, unsigned fp_bits, unsigned fp_frac, const uint8_t seed[32], int *ok_out, bool single,
-                const size_t *gid = nullptr) {
+                const size_t *gid = nullptr, size_t cstride = 32) {
     for (size_t i = 0; i < n_clients; i++) ok_out[i] = 0;
-    if (!valid_fp(fp_bits, fp_frac) || d == 0 || n_proofs == 0 || prove_range == 0 || prove_range > fp_bits || n_clients == 0)
+    if (!valid_fp(fp_bits, fp_frac) || d == 0 || n_proofs == 0 || prove_range == 0 || prove_range > fp_bits || n_clients == 0 || cstride < 32)
         return fail(ROFL_BAD_PARAM, "bad parameter (the reference panics here)");
     size_t dp = next_pow2(d);
     size_t chunk = dp / n_proofs;
@@ -302,14 +305,21 @@ int verify_impl(Ctx &C, size_t n_clients, const uint8_t *const *proofs, size_t p
     bool all_host = true; for (size_t i = 0; i < n_clients; i++) all_host &= !is_device_ptr(commits[i]);
     for (size_t i0 = 0; i0 < n_clients; i0 += GC) {
         const size_t gc = std::min(GC, n_clients - i0);
-        if (all_host && d * 32 >= Stage::kMin) {
+        if (all_host && (d * 32 >= Stage::kMin || cstride != 32)) {
             uint8_t *st = (uint8_t *)C.stg.alloc(gc * d * 32);
             const size_t slices = std::max<size_t>(1, (d * 32) >> 18);      // ~256 KB per task
-            C.pool->run(gc * slices, [&](size_t t) { size_t i = t / slices, k = t % slices, lo = d * 32 * k / slices, hi = d * 32 * (k + 1) / slices;
-                                                     memcpy(st + i * d * 32 + lo, commits[i0 + i] + lo, hi - lo); });
+            C.pool->run(gc * slices, [&](size_t t) { size_t i = t / slices, k = t % slices;
+                                                     if (cstride == 32) { size_t lo = d * 32 * k / slices, hi = d * 32 * (k + 1) / slices; stage_copy(st + i * d * 32 + lo, commits[i0 + i] + lo, hi - lo); }
+                                                     else { const uint8_t *src = commits[i0 + i]; uint8_t *dst = st + i * d * 32;      // gather: the staging copy is also the packing
+                                                            for (size_t e = d * k / slices, e1 = d * (k + 1) / slices; e < e1; e++) memcpy(dst + e * 32, src + e * cstride, 32); } });
             HIPCHK(hipMemcpy2DAsync(d_in + i0 * dp * 32, dp * 32, st, d * 32, d * 32, gc, hipMemcpyHostToDevice, C.stream));
         } else
-            for (size_t i = i0; i < i0 + gc; i++) C.up(d_in + i * dp * 32, commits[i], d * 32, C.stream);
+            for (size_t i = i0; i < i0 + gc; i++) {
+                if (cstride == 32) C.up(d_in + i * dp * 32, commits[i], d * 32, C.stream);
+                else if (is_device_ptr(commits[i])) HIPCHK(hipMemcpy2DAsync(d_in + i * dp * 32, 32, commits[i], cstride, 32, d, hipMemcpyDeviceToDevice, C.stream));
+                else { uint8_t *st = (uint8_t *)C.stg.alloc(d * 32); for (size_t e = 0; e < d; e++) memcpy(st + e * 32, commits[i] + e * cstride, 32);
+                       HIPCHK(hipMemcpyAsync(d_in + i * dp * 32, st, d * 32, hipMemcpyHostToDevice, C.stream)); }
+            }
         { KSpan ks(C.tm, C.stream, ROFL_TK_CODEC, (uint64_t)gc * d * (2 * 265 + 7), (uint64_t)gc * d * 64);
           hipLaunchKernelGGL(k_decode, grid1(dp, (u32)gc), dim3(TPB), 0, C.stream, (u32)dp, (u32)d, d_in + i0 * dp * 32, d_shift, d_vn + i0 * dp, d_enc + i0 * dp * 32, status + i0); }
         HIPCHK(hipMemcpyAsync(hV + i0 * dp * 32, d_enc + i0 * dp * 32, gc * dp * 32, hipMemcpyDeviceToHost, C.stream));
@@ -545,20 +555,24 @@ int rofl_verify_rangeproof(const uint8_t *proofs, size_t proof_len, size_t n_pro
 }
 int rofl_verify_rangeproof_batch(size_t n_clients, const uint8_t *const *proofs, size_t proof_len, size_t n_proofs, const uint8_t *const *commits32,
                                  size_t d, size_t prove_range, unsigned fp_bits, unsigned fp_frac, const uint8_t verifier_seed[32], int *ok_out) {
-    if (!proofs || !commits32 || !ok_out || !verifier_seed) return fail(ROFL_BAD_PARAM, "bad parameter");
+    return rofl_verify_rangeproof_batch_strided(n_clients, proofs, proof_len, n_proofs, commits32, 32, d, prove_range, fp_bits, fp_frac, verifier_seed, ok_out);
+}
+int rofl_verify_rangeproof_batch_strided(size_t n_clients, const uint8_t *const *proofs, size_t proof_len, size_t n_proofs, const uint8_t *const *commits32, size_t commit_stride,
+                                         size_t d, size_t prove_range, unsigned fp_bits, unsigned fp_frac, const uint8_t verifier_seed[32], int *ok_out) {
+    if (!proofs || !commits32 || !ok_out || !verifier_seed || commit_stride < 32) return fail(ROFL_BAD_PARAM, "bad parameter");
     const bool single = n_clients == 1;
     std::vector<int> devs = batch_devices();
     if (devs.empty() || n_clients < 2)
         return guarded([&]() -> int { std::unique_ptr<DeviceBinding> bind; if (!devs.empty()) bind.reset(new DeviceBinding(devs[0]));
             LaneLock lane_lock = acquire_lane(); Ctx &C = *lane_lock.c;
-            return verify_impl(C, n_clients, proofs, proof_len, n_proofs, commits32, d, prove_range, fp_bits, fp_frac, verifier_seed, ok_out, single); });
+            return verify_impl(C, n_clients, proofs, proof_len, n_proofs, commits32, d, prove_range, fp_bits, fp_frac, verifier_seed, ok_out, single, nullptr, commit_stride); });
     for (size_t i = 0; i < n_clients; i++) ok_out[i] = 0;
     return guarded([&]() -> int { return shard_over_devices(n_clients, devs, [&](const std::vector<size_t> &idx) -> int {
         const size_t k = idx.size();
         std::vector<const uint8_t *> p(k), c(k); std::vector<int> ok(k, 0);
         for (size_t j = 0; j < k; j++) { p[j] = proofs[idx[j]]; c[j] = commits32[idx[j]]; }
         LaneLock lane_lock = acquire_lane(); Ctx &C = *lane_lock.c;
-        int r = verify_impl(C, k, p.data(), proof_len, n_proofs, c.data(), d, prove_range, fp_bits, fp_frac, verifier_seed, ok.data(), false, idx.data());
+        int r = verify_impl(C, k, p.data(), proof_len, n_proofs, c.data(), d, prove_range, fp_bits, fp_frac, verifier_seed, ok.data(), false, idx.data(), commit_stride);
         for (size_t j = 0; j < k; j++) ok_out[idx[j]] = ok[j];
         return r; }); });
 }
@@ -647,6 +661,58 @@ int rofl_verify_rangeproof_l2(const uint8_t *proof, size_t proof_len, const uint
     });
 }
 
+// verify_rangeproof_l2 for the clients of a round (params.rs:220-231, server.rs:656-687): n_clients one-value proofs over the (64, 1)
+// generators, commitments = each client's sum of c_sq.  The proofs share the generators, so with verify_batch = 2 they are ONE
+// random-weighted equation (a closer look only when it fails); with 1 one check per client, all in one launch sequence.  Per-client
+// verdicts either way; a malformed member (length is per call; non-canonical scalar, undecodable commitment, identity point) fails alone.
+int rofl_verify_rangeproof_l2_batch(size_t n_clients, const uint8_t *const *proofs, size_t proof_len, const uint8_t *commits32, size_t prove_range,
+                                    unsigned fp_bits, unsigned fp_frac, const uint8_t verifier_seed[32], int *ok_out) {
+    if (!ok_out || !verifier_seed || (n_clients && (!proofs || !commits32))) return fail(ROFL_BAD_PARAM, "bad parameter");
+    return guarded([&]() -> int {
+        LaneLock lane_lock = acquire_lane(false, true); Ctx &C = *lane_lock.c;
+        for (size_t i = 0; i < n_clients; i++) ok_out[i] = 0;
+        if (!valid_fp(fp_bits, fp_frac) || prove_range == 0) return fail(ROFL_BAD_PARAM, "bad parameter");
+        if (n_clients == 0) return ROFL_OK;
+        if (proof_len % 32 != 0 || proof_len < 7 * 32) return fail(ROFL_FORMAT_ERROR, "FormatError: proof length");
+        const size_t ne = (proof_len - 7 * 32) / 32;
+        if (ne < 2 || (ne - 2) % 2 != 0 || (ne - 2) / 2 >= 32) return fail(ROFL_FORMAT_ERROR, "FormatError: proof length");
+        const size_t lg = (ne - 2) / 2, nc = n_clients;
+        std::vector<uint8_t> pf(nc * proof_len);
+        std::vector<char> skip(nc, 0);
+        for (size_t i = 0; i < nc; i++) {
+            if (is_device_ptr(proofs[i])) HIPCHK(hipMemcpy(&pf[i * proof_len], proofs[i], proof_len, hipMemcpyDeviceToHost)); else memcpy(&pf[i * proof_len], proofs[i], proof_len);
+            uint8_t *pb = &pf[i * proof_len];
+            const size_t offs[5] = {128, 160, 192, 7 * 32 + 64 * lg, 7 * 32 + 64 * lg + 32};
+            for (size_t o : offs) if (!sc_is_canonical_bytes(pb + o)) { skip[i] = 1; memset(pb + o, 0, 32); }      // its own verdict: false; the others go on
+        }
+        if (!(prove_range == 8 || prove_range == 16 || prove_range == 32 || prove_range == 64)) return fail(ROFL_INVALID_BITSIZE, "proof rejected before verification (format / bitsize)");
+        if (prove_range != ((size_t)1 << lg)) return ROFL_OK;      // VerificationError for every client -> false
+        C.init();
+        C.batch_mode = nc > 1;
+        timing_begin(C);
+        uint8_t *d_in = C.Cbytes.as<uint8_t>(nc * 32), *d_enc = C.Vbytes.as<uint8_t>(nc * 32);
+        niels *d_vn = C.gbuf[0].as<niels>(nc);
+        u32 *status = C.status.as<u32>(nc + 4);
+        HIPCHK(hipMemsetAsync(status, 0, 4 * (nc + 4), C.stream));
+        C.up(d_in, commits32, nc * 32, C.stream);
+        hipLaunchKernelGGL(k_decode, grid1(1, (u32)nc), dim3(TPB), 0, C.stream, 1u, 1u, d_in, (const niels *)nullptr, d_vn, d_enc, status);
+        uint8_t *hV = C.h_V.as<uint8_t>(nc * 32); u32 *h_st = C.h_misc.as<u32>(nc + 4);
+        HIPCHK(hipMemcpyAsync(hV, d_enc, nc * 32, hipMemcpyDeviceToHost, C.stream));
+        HIPCHK(hipMemcpyAsync(h_st, status, 4 * nc, hipMemcpyDeviceToHost, C.stream));
+        C.sync();
+        for (size_t i = 0; i < nc; i++) if (h_st[i] & 4u) skip[i] = 1;
+        std::vector<u64> cidx(nc, 0), ridx(nc); std::vector<int> okc(nc, 0);
+        for (size_t i = 0; i < nc; i++) ridx[i] = (u64)i << 24;
+        const bool hier = opts().verify_batch.load() == 2 && nc > 1;
+        int rc = verify_chunks(C, "L2RangeProof", 64, nc, prove_range, 1, pf.data(), proof_len, hV, d_vn, verifier_seed, cidx.data(), okc.data(), 1, nullptr, nullptr,
+                               ridx.data(), hier, skip.data());
+        timing_end(C);
+        if (rc) return fail(rc, "proof rejected before verification (format / bitsize)");
+        for (size_t i = 0; i < nc; i++) ok_out[i] = skip[i] ? 0 : okc[i];
+        return ROFL_OK;
+    });
+}
+
 namespace {
 DMerlin sigma_init_state(int kind) {
     const char *lbl = kind == 0 ? "RandProof" : (kind == 1 ? "SquareRandProof" : "SquareProof");
@@ -695,54 +761,145 @@ int sigma_create(int kind, const float *values, size_t d, const uint8_t *r1, siz
     if (st & 4u) return fail(ROFL_FORMAT_ERROR, "invalid Ristretto encoding");
     return ROFL_OK;
 }
-int sigma_verify(int kind, const uint8_t *proofs, const uint8_t *commits, size_t d, int *ok_out) {
-    LaneLock lane_lock = acquire_lane(false, true); Ctx &C = *lane_lock.c;
-    *ok_out = 0;
-    if (d == 0) { *ok_out = 1; return ROFL_OK; }
-    size_t npts = 1 + (kind != 2) + (kind != 0 ? 1 : 0), clen = 32 * npts, plen = 32 * (npts + (kind != 0 ? 3 : 2));
+// Verification of the per-element Sigma-proofs of `nc` vectors of d elements (the clients of a round: the reference's server verifies every
+// client's update, server.rs:656-687, each with verify_randproof_vec / verify_l2rangeproof_vec, params.rs:188-189, 208, 262).  One launch
+// sequence for all of them: the clients' bytes are staged and uploaded group by group (the pool copies group g + 1 while group g is on its
+// way and being decoded), k_sigma_vprep runs over (element, client), and every client is ONE problem of a multi-problem Pippenger launch --
+// its own random linear combination, hence its own verdict, with no closer look needed (clients share nothing here, unlike the range
+// proofs' generator MSM).  55 000 elements alone are less than one wave per SIMD; 48 clients fill the chip.
+// csq_sum_out (kinds 1, 2; may be null): sum_i c_sq_i of every client, compressed (params.rs:220, 277) -- the points are decoded here anyway.
+// `single`: the call is one of the rofl_verify_*_vec entry points (a malformed vector is the call's FormatError); batch calls give the
+// offender ok = 0 and go on.
+int sigma_verify_batch(int kind, size_t nc, const uint8_t *const *proofs, const uint8_t *const *commits, size_t d, int *ok_out, uint8_t *csq_sum_out, bool single) {
+    LaneLock lane_lock = acquire_lane(false, nc == 1); Ctx &C = *lane_lock.c;
+    for (size_t i = 0; i < nc; i++) ok_out[i] = 0;
+    const bool has_R = kind != 2, has_sq = kind != 0;
+    if (csq_sum_out) memset(csq_sum_out, 0, 32 * nc);      // the identity (also the sum of an empty vector)
+    if (nc == 0) return ROFL_OK;
+    if (d == 0) { for (size_t i = 0; i < nc; i++) ok_out[i] = 1; return ROFL_OK; }
+    const size_t npts = 1 + (has_R ? 1 : 0) + (has_sq ? 1 : 0), clen = 32 * npts, plen = 32 * (npts + (has_sq ? 3 : 2));
+    const size_t nslots = 2 * npts, nblk = (d + TPB - 1) / TPB;
+    if (nc * nslots * d >= ((size_t)1 << 31) || nc * nblk > ((size_t)1 << 22)) return fail(ROFL_BAD_PARAM, "batch too large (split it)");
     C.init();
+    C.batch_mode = nc > 1;
     timing_begin(C);
-    uint8_t *dp = C.aux_pts.as<uint8_t>(d * plen), *dc = C.aux_scal.as<uint8_t>(d * clen);
-    u32 *status = C.status.as<u32>(4);
-    HIPCHK(hipMemsetAsync(status, 0, 16, C.stream));
-    C.up(dp, proofs, d * plen, C.stream);
-    C.up(dc, commits, d * clen, C.stream);
-    const bool sg_batch = opts().sigma_batch.load() != 0;      // rofl_set_option("sigma_batch")
-    if (sg_batch) {
-        // one random linear combination of all elements' equations: decode + transcripts per element on the device, then ONE Pippenger MSM
-        // over the 4-6 d points and two fixed-base terms (k_sigma_vprep); the weights come from fresh OS randomness
-        size_t nslots = 2 * npts, nblk = (d + TPB - 1) / TPB;
-        NonceSeed ws{};
-        { FILE *f = fopen("/dev/urandom", "rb"); bool got = f && fread(ws.w, 1, 32, f) == 32; if (f) fclose(f);
-          if (!got) return fail(ROFL_HIP_ERROR, "no randomness for the batched Sigma-proof check"); }
-        niels *pts = C.gbuf[0].as<niels>(nslots * d);
-        sc *scal = C.SL.as<sc>(nslots * d);
-        sc *d_fixed = C.tmp_out.as<sc>(nblk * 2);
-        { KSpan ks_sigma(C.tm, C.stream, ROFL_TK_SIGMA, (uint64_t)d * (2 * npts * 265), (uint64_t)d * (clen + plen));      // decoding of 2 npts points per element
-          hipLaunchKernelGGL(k_sigma_vprep, dim3((unsigned)nblk), dim3(TPB), 0, C.stream, kind, (u32)d, dp, dc, sigma_init_state(kind), ws, pts, scal, d_fixed, status); }
-        std::vector<sc> h_fixed(nblk * 2);
-        u32 st0 = 0;
-        HIPCHK(hipMemcpyAsync(h_fixed.data(), d_fixed, sizeof(sc) * nblk * 2, hipMemcpyDeviceToHost, C.stream));
-        HIPCHK(hipMemcpyAsync(&st0, status, 4, hipMemcpyDeviceToHost, C.stream));
-        C.sync();
-        if (st0 & 4u) { timing_end(C); return fail(ROFL_FORMAT_ERROR, "FormatError: non-canonical scalar or invalid point"); }
-        std::vector<MsmProb> pr(1, MsmProb{pts, scal}); std::vector<ge5> res;
-        msm_run(C, pr, nslots * d, res);
-        sc sB = h_canon(sum_partials(h_fixed.data(), nblk, 2, 0)), sBb = h_canon(sum_partials(h_fixed.data(), nblk, 2, 1));
-        ge5 tot = h51::gadd(res[0], h51::gadd(h_fixed_mul(C.ht.B5, sB), h_fixed_mul(C.ht.Bb5, sBb)));
+    if (!opts().sigma_batch.load()) {      // rofl_set_option("sigma_batch", 0): one check per element (the reference's form), client by client
+        int rc_all = ROFL_OK;
+        for (size_t i = 0; i < nc; i++) {
+            uint8_t *dp = C.aux_pts.as<uint8_t>(d * plen), *dc = C.aux_scal.as<uint8_t>(d * clen);
+            u32 *status = C.status.as<u32>(4);
+            HIPCHK(hipMemsetAsync(status, 0, 16, C.stream));
+            C.up(dp, proofs[i], d * plen, C.stream); C.up(dc, commits[i], d * clen, C.stream);
+            { KSpan ks_sigma(C.tm, C.stream, ROFL_TK_SIGMA, (uint64_t)d * (2 * npts * 265 + (kind ? 3 : 2) * 2 * 325 * 8), (uint64_t)d * (clen + plen));
+              hipLaunchKernelGGL(k_sigma_verify, dim3((unsigned)((d + 63) / 64)), dim3(64), 0, C.stream, kind, (u32)d, dp, dc, sigma_init_state(kind), C.d_tabB, C.d_tabBb, status + 1, status); }
+            u32 *st = C.h_misc.as<u32>(4);
+            HIPCHK(hipMemcpyAsync(st, status, 8, hipMemcpyDeviceToHost, C.stream));
+            if (csq_sum_out && has_sq) {
+                u32 nb2 = (u32)std::min<size_t>(64, nblk); ge *part = C.partial2.as<ge>(nb2);
+                hipLaunchKernelGGL(k_decode_sum, dim3(nb2), dim3(TPB), TPB * sizeof(ge), C.stream, dc + (has_R ? 64 : 32), (u32)d, (u32)clen, part, status + 2);
+                ge *hp = C.h_part.as<ge>(nb2);
+                HIPCHK(hipMemcpyAsync(hp, part, sizeof(ge) * nb2, hipMemcpyDeviceToHost, C.stream));
+                C.sync();
+                ge5 acc = h51::identity(); for (u32 k = 0; k < nb2; k++) acc = h51::gadd(acc, h51::from_ge(hp[k]));
+                h51::encode(csq_sum_out + 32 * i, acc);
+            } else C.sync();
+            if (st[0] & 4u) { if (single) { timing_end(C); return fail(ROFL_FORMAT_ERROR, "FormatError: non-canonical scalar or invalid point"); } if (csq_sum_out) memset(csq_sum_out + 32 * i, 0, 32); continue; }
+            ok_out[i] = st[1] == 0;
+        }
         timing_end(C);
-        *ok_out = h51::is_identity_ristretto(tot) ? 1 : 0;
-        return ROFL_OK;
+        return rc_all;
     }
-    { KSpan ks_sigma(C.tm, C.stream, ROFL_TK_SIGMA, (uint64_t)d * (2 * npts * 265 + (kind ? 3 : 2) * 2 * 325 * 8), (uint64_t)d * (clen + plen));
-      hipLaunchKernelGGL(k_sigma_verify, dim3((unsigned)((d + 63) / 64)), dim3(64), 0, C.stream, kind, (u32)d, dp, dc, sigma_init_state(kind), C.d_tabB, C.d_tabBb, status + 1, status); }
-    u32 st[2] = {0, 0};
-    HIPCHK(hipMemcpyAsync(st, status, 8, hipMemcpyDeviceToHost, C.stream));
+    static const bool strace = knob("ROFL_TRACE") && atoi(knob("ROFL_TRACE")) >= 2;
+    double st0 = now_ms(), stl = st0;
+    auto smark = [&](const char *what) { if (!strace) return; double t = now_ms(); fprintf(stderr, "[rofl-trace sigma-verify] %-18s +%.3f ms  (t=%.3f)\n", what, t - stl, t - st0); stl = t; };
+    uint8_t *dp = C.aux_pts.as<uint8_t>(nc * d * plen), *dc = C.aux_scal.as<uint8_t>(nc * d * clen);
+    u32 *status = C.status.as<u32>(nc + 4);
+    HIPCHK(hipMemsetAsync(status, 0, 4 * (nc + 4), C.stream));
+    NonceSeed ws{};
+    { FILE *f = fopen("/dev/urandom", "rb"); bool got = f && fread(ws.w, 1, 32, f) == 32; if (f) fclose(f);
+      if (!got) return fail(ROFL_HIP_ERROR, "no randomness for the batched Sigma-proof check"); }
+    niels *pts = C.gbuf[0].as<niels>(nc * nslots * d);
+    sc *scal = C.SL.as<sc>(nc * nslots * d);
+    sc *d_fixed = C.tmp_out.as<sc>(nc * nblk * 2);
+    const DMerlin init = sigma_init_state(kind);
+    // the weights' size: their top bit must not be the top bit of a window of the layout the MSM will use (see k_sigma_vprep)
+    static const u32 wbits = [] {      // (whichever of the generic layouts the MSM driver ends up with, retries included)
+        for (u32 cand = 127; cand > 96; cand--) {
+            bool hit = false;
+            for (u32 c : {4u, 7u, 10u, 13u, 16u}) { MsmPlan mp = msm_plan_c(c); for (u32 w = 0, end = 0; w < mp.W; w++) { end += w + 1 == mp.W ? mp.c + 1 : (w < mp.wide ? mp.c : mp.c - 1); hit |= end == cand; } }
+            if (!hit) return cand;
+        }
+        return 96u; }();
+    // groups of clients: ~64 MB of caller bytes each, through two staging buffers
+    const size_t per = d * (plen + clen);
+    const size_t G = std::max<size_t>(1, std::min<size_t>(nc, ((size_t)64 << 20) / per));
+    bool all_host = true; for (size_t i = 0; i < nc; i++) all_host &= !is_device_ptr(proofs[i]) && !is_device_ptr(commits[i]);
+    uint8_t *stage[2] = {nullptr, nullptr}; bool used[2] = {false, false};
+    if (all_host && per >= Stage::kMin) { stage[0] = (uint8_t *)C.stg.alloc(G * per); if (nc > G) stage[1] = (uint8_t *)C.stg.alloc(G * per); }
+    for (size_t g0 = 0, gi = 0; g0 < nc; g0 += G, gi++) {
+        const size_t gc = std::min(G, nc - g0), b = gi & 1;
+        if (stage[0]) {
+            if (used[b]) C.wait_event(C.pool_event(b));      // the copy that read this buffer two groups ago
+            uint8_t *sp = stage[b], *sq = stage[b] + gc * d * plen;
+            const size_t sl_p = std::max<size_t>(1, (d * plen) >> 18), sl_c = std::max<size_t>(1, (d * clen) >> 18);      // ~256 KB per task
+            C.pool->run(gc * (sl_p + sl_c), [&](size_t t) {
+                size_t i = t / (sl_p + sl_c), k = t % (sl_p + sl_c);
+                if (k < sl_p) { size_t lo = d * plen * k / sl_p, hi = d * plen * (k + 1) / sl_p; stage_copy(sp + i * d * plen + lo, proofs[g0 + i] + lo, hi - lo); }
+                else { k -= sl_p; size_t lo = d * clen * k / sl_c, hi = d * clen * (k + 1) / sl_c; stage_copy(sq + i * d * clen + lo, commits[g0 + i] + lo, hi - lo); }
+            });
+            HIPCHK(hipMemcpyAsync(dp + g0 * d * plen, sp, gc * d * plen, hipMemcpyHostToDevice, C.stream));
+            HIPCHK(hipMemcpyAsync(dc + g0 * d * clen, sq, gc * d * clen, hipMemcpyHostToDevice, C.stream));
+            HIPCHK(hipEventRecord(C.pool_event(b), C.stream)); used[b] = true;
+        } else
+            for (size_t i = g0; i < g0 + gc; i++) { C.up(dp + i * d * plen, proofs[i], d * plen, C.stream); C.up(dc + i * d * clen, commits[i], d * clen, C.stream); }
+        KSpan ks_sigma(C.tm, C.stream, ROFL_TK_SIGMA, (uint64_t)gc * d * (2 * npts * 265), (uint64_t)gc * d * (clen + plen));      // decoding of 2 npts points per element
+        hipLaunchKernelGGL(k_sigma_vprep, dim3((unsigned)nblk, (unsigned)gc), dim3(TPB), 0, C.stream, kind, (u32)d, dp + g0 * d * plen, dc + g0 * d * clen, init, ws, (u64)(g0 * d), wbits,
+                           pts + g0 * nslots * d, scal + g0 * nslots * d, d_fixed + g0 * nblk * 2, status + g0);
+    }
+    smark("staged + enqueued");
+    sc *h_fixed = C.h_part.as<sc>(nc * nblk * 2);
+    u32 *h_st = C.h_misc.as<u32>(nc + 4);
+    HIPCHK(hipMemcpyAsync(h_fixed, d_fixed, sizeof(sc) * nc * nblk * 2, hipMemcpyDeviceToHost, C.stream));
+    HIPCHK(hipMemcpyAsync(h_st, status, 4 * nc, hipMemcpyDeviceToHost, C.stream));
+    const u32 nb2 = (u32)std::min<size_t>(64, nblk);
+    ge *h_csq = nullptr;
+    if (csq_sum_out && has_sq) {
+        ge *part = C.partial2.as<ge>(nc * nb2);
+        hipLaunchKernelGGL(k_niels_sum, dim3(nb2, (unsigned)nc), dim3(TPB), TPB * sizeof(ge), C.stream, (const niels *)(pts + (nslots - 2) * d), (u32)d, nslots * d, part);
+        h_csq = C.h_misc2.as<ge>(nc * nb2);
+        HIPCHK(hipMemcpyAsync(h_csq, part, sizeof(ge) * nc * nb2, hipMemcpyDeviceToHost, C.stream));
+    }
     C.sync();
+    smark("decoded");
+    std::vector<size_t> good;
+    for (size_t i = 0; i < nc; i++) {
+        if (h_st[i] & 4u) { if (single) { timing_end(C); return fail(ROFL_FORMAT_ERROR, "FormatError: non-canonical scalar or invalid point"); } }
+        else good.push_back(i);
+    }
+    // every client one problem; launches of up to sixteen (the slot array of a launch grows with its problems)
+    for (size_t k0 = 0; k0 < good.size(); k0 += 16) {
+        const size_t kc = std::min<size_t>(16, good.size() - k0);
+        std::vector<MsmProb> pr(kc); std::vector<ge5> res;
+        for (size_t k = 0; k < kc; k++) pr[k] = MsmProb{pts + good[k0 + k] * nslots * d, scal + good[k0 + k] * nslots * d};
+        C.tm.t.msm_terms += kc * nslots * d;
+        msm_run(C, pr, nslots * d, res);
+        for (size_t k = 0; k < kc; k++) {
+            const size_t i = good[k0 + k];
+            sc sB = h_canon(sum_partials(h_fixed + i * nblk * 2, nblk, 2, 0)), sBb = h_canon(sum_partials(h_fixed + i * nblk * 2, nblk, 2, 1));
+            ge5 tot = h51::gadd(res[k], h51::gadd(h_fixed_mul(C.ht.B5, sB), h_fixed_mul(C.ht.Bb5, sBb)));
+            ok_out[i] = h51::is_identity_ristretto(tot) ? 1 : 0;
+        }
+    }
+    smark("msm + verdicts");
+    if (h_csq) for (size_t i : good) {
+        ge5 acc = h51::identity(); for (u32 k = 0; k < nb2; k++) acc = h51::gadd(acc, h51::from_ge(h_csq[i * nb2 + k]));
+        h51::encode(csq_sum_out + 32 * i, acc);
+    }
     timing_end(C);
-    if (st[0] & 4u) return fail(ROFL_FORMAT_ERROR, "FormatError: non-canonical scalar or invalid point");
-    *ok_out = st[1] == 0;
     return ROFL_OK;
+}
+int sigma_verify(int kind, const uint8_t *proofs, const uint8_t *commits, size_t d, int *ok_out) {
+    return sigma_verify_batch(kind, 1, &proofs, &commits, d, ok_out, nullptr, true);
 }
 // ---- compressed_rand_proof
 sc compressed_challenge(const uint8_t *pairs, size_t d, const uint8_t cprime[64]) {
@@ -873,6 +1030,21 @@ int rofl_create_squarerandproof_vec(const float *values, size_t d, const uint8_t
 }
 int rofl_verify_squarerandproof_vec(const uint8_t *proofs, const uint8_t *commits, size_t d, int *ok_out) {
     return guarded([&]() -> int { return sigma_verify(1, proofs, commits, d, ok_out); });
+}
+namespace {
+int sigma_batch_entry(int kind, size_t n_clients, const uint8_t *const *proofs, const uint8_t *const *commits, size_t d, int *ok_out, uint8_t *csq_sum_out32) {
+    if (!ok_out || (n_clients && (!proofs || !commits))) return fail(ROFL_BAD_PARAM, "bad parameter");
+    return guarded([&]() -> int { return sigma_verify_batch(kind, n_clients, proofs, commits, d, ok_out, csq_sum_out32, false); });
+}
+}  // namespace
+int rofl_verify_randproof_vec_batch(size_t n_clients, const uint8_t *const *proofs, const uint8_t *const *commits, size_t d, int *ok_out) {
+    return sigma_batch_entry(0, n_clients, proofs, commits, d, ok_out, nullptr);
+}
+int rofl_verify_squarerandproof_vec_batch(size_t n_clients, const uint8_t *const *proofs, const uint8_t *const *commits, size_t d, int *ok_out, uint8_t *csq_sum_out32) {
+    return sigma_batch_entry(1, n_clients, proofs, commits, d, ok_out, csq_sum_out32);
+}
+int rofl_verify_squareproof_vec_batch(size_t n_clients, const uint8_t *const *proofs, const uint8_t *const *commits, size_t d, int *ok_out, uint8_t *csq_sum_out32) {
+    return sigma_batch_entry(2, n_clients, proofs, commits, d, ok_out, csq_sum_out32);
 }
 
 int rofl_commit_vec(const uint8_t *values32, const uint8_t *blindings32, size_t d, uint8_t *out32) {

@@ -41,7 +41,7 @@ class wire:
 
     @staticmethod
     def encode(kind, enc_values=None, rand_proof=None, square_proof=None, range_proofs=None, square_range_proof=None,
-               range_bits=0, l2_range_bits=0, check_percentage=0.0):
+               range_bits=0, l2_range_bits=0, check_percentage=0.0, as_array=False):
         keep = []
         m = _WireMsg(); m.kind = kind
 
@@ -61,13 +61,18 @@ class wire:
             m.range_proofs = rp.ctypes.data if rp.size else None; m.range_proof_len = rp.shape[1]; m.n_range_proofs = rp.shape[0]
         m.range_bits, m.l2_range_bits, m.check_percentage = int(range_bits), int(l2_range_bits), float(check_percentage)
         n = lib().rofl_wire_encoded_size(ctypes.byref(m))
-        out = np.zeros(max(n, 1), dtype=np.uint8); ln = ctypes.c_size_t()
+        out = np.empty(max(n, 1), dtype=np.uint8); ln = ctypes.c_size_t()
         _check(lib().rofl_wire_encode(ctypes.byref(m), _ptr(out), _sz(out.size), ctypes.byref(ln)))
-        return out[:ln.value].tobytes()
+        return out[:ln.value] if as_array else out[:ln.value].tobytes()      # as_array: no second copy of a 16 MB message
 
     @staticmethod
-    def decode(kind, data):
-        buf = np.frombuffer(bytes(data), dtype=np.uint8)
+    def decode(kind, data, copy=True):
+        """copy=False: `data` is a contiguous uint8 array that outlives the result; the payload fields are VIEWS into it (a server that
+        verifies a round of 16 MB messages does not copy each of them twice on the way in)."""
+        if not copy and isinstance(data, np.ndarray) and data.dtype == np.uint8 and data.flags["C_CONTIGUOUS"]:
+            buf = data.reshape(-1)
+        else:
+            buf = np.frombuffer(bytes(data), dtype=np.uint8); copy = True
         m = _WireMsg()
         _check(lib().rofl_wire_decode(kind, _ptr(buf), _sz(buf.size), ctypes.byref(m), None, _sz(0)))
         rp = np.zeros((m.n_range_proofs, m.range_proof_len), dtype=np.uint8)
@@ -77,7 +82,9 @@ class wire:
 
         def span(name):
             p, n = getattr(m, name), getattr(m, name + "_len")
-            return buf[p - base:p - base + n].copy() if p and n else np.zeros(0, dtype=np.uint8)
+            if not (p and n):
+                return np.zeros(0, dtype=np.uint8)
+            return buf[p - base:p - base + n].copy() if copy else buf[p - base:p - base + n]
         return {"enc_values": span("enc_values"), "rand_proof": span("rand_proof"), "square_proof": span("square_proof"),
                 "square_range_proof": span("square_range_proof"), "range_proofs": rp, "range_bits": m.range_bits,
                 "l2_range_bits": m.l2_range_bits, "check_percentage": m.check_percentage}
@@ -109,7 +116,7 @@ def _concurrently(*thunks):
         return [thunks[0]()]
     if _pool is None:
         from concurrent.futures import ThreadPoolExecutor
-        _pool = ThreadPoolExecutor(max_workers=12, thread_name_prefix="rofl-params")      # three proofs per container, up to four containers in flight (threads start on demand)
+        _pool = ThreadPoolExecutor(max_workers=32, thread_name_prefix="rofl-params")      # three proofs per container, several containers in flight (threads start on demand)
     futs = [_pool.submit(t) for t in thunks]
     return [f.result() for f in futs]
 
@@ -297,6 +304,46 @@ class EncParamsL2:
         assert (rp_com == enc_com).all()
         return cls(commits, proofs, rp, sum_proof, prove_range, l2_range)
 
+    @classmethod
+    def encrypt_batch(cls, clients, prove_range, n_partition, l2_range, nonce_seeds=None, fp=None):
+        """encrypt() for several clients of one process (rofl_service's client binary hosts its clients as tasks of one process,
+        client.rs:265-266): clients = [(plaintext_vec, blinding_vec, rand_scalars or None), ...] of one length.  The L-inf legs of all of
+        them are ONE rofl_create_rangeproof_batch call (one launch sequence, one set of host hops); their square proofs and sum proofs run
+        beside it on other lanes.  Every container is byte-identical to what encrypt() returns for that client with the same nonce seed."""
+        fp = api._fp(fp)
+        n = len(clients)
+        if n == 0:
+            return []
+        seeds = list(nonce_seeds) if nonce_seeds is not None else [None] * n
+        xs, bls, r2s, wds, clipped = [], [], [], [], []
+        for (x, bl, r2) in clients:
+            x = np.ascontiguousarray(x, dtype=np.float32); bl = api._u8(bl)
+            r2 = pedersen_ops.rnd_scalar_vec(x.size) if r2 is None else api._u8(r2)
+            xs.append(x); bls.append(bl); r2s.append(r2)
+            clipped.append(range_proof_vec.clip_f32_to_range_vec(x, prove_range, fp=fp))
+        d = xs[0].size
+        if any(x.size != d for x in xs):
+            raise ValueError("the clients of a batch have one vector length")
+        wds = [witness_digest(x, bl, r2) if sd is not None else b"" for x, bl, r2, sd in zip(xs, bls, r2s, seeds)]
+        # the range proofs' commitments, computed first (one call for all clients) so that the square proofs can complete them while the range proofs run
+        enc_all = pedersen_ops.commit_vec(np.concatenate([conversion32.f32_to_scalar_vec(c, fp=fp) for c in clipped]), np.concatenate(bls))
+        enc_com = [enc_all[i * d:(i + 1) * d] for i in range(n)]
+        thunks = [lambda: range_proof_vec.create_rangeproof_batch(clipped, bls, prove_range, n_partition, nonces=[_sub_nonce(sd, b"range", wd) for sd, wd in zip(seeds, wds)], fp=fp)]
+        for i in range(n):
+            thunks.append(lambda i=i: l2_range_proof_vec.create_rangeproof_l2(clipped[i], r2s[i], l2_range, n_partition, nonce=_sub_nonce(seeds[i], b"l2", wds[i]), fp=fp))
+            thunks.append(lambda i=i: square_rand_proof_vec.create_l2rangeproof_vec_existing(clipped[i], enc_com[i], bls[i], r2s[i], nonce=_sub_nonce(seeds[i], b"sq", wds[i]), fp=fp))
+        res = _concurrently(*thunks)
+        out = []
+        for i in range(n):
+            r = res[0][i]
+            if isinstance(r, Exception):
+                raise r
+            rp, rp_com = r
+            assert (rp_com == enc_com[i]).all()
+            (sum_proof, _), (proofs, commits) = res[1 + 2 * i], res[2 + 2 * i]
+            out.append(cls(commits, proofs, rp, sum_proof, prove_range, l2_range))
+        return out
+
     def _sum_c_sq(self):
         return pedersen_ops.sum_rp_vec(self.enc_values[:, 64:96])
 
@@ -312,13 +359,63 @@ class EncParamsL2:
             return False
         return bool(ok and ok_range and ok_sum)
 
-    def serialize(self):
-        return wire.encode(self.kind, enc_values=self.enc_values, square_proof=self.square_proofs, range_proofs=self.range_proofs,
-                           square_range_proof=self.square_range_proof, range_bits=self.prove_range, l2_range_bits=self.l2_prove_range)
+    @staticmethod
+    def _square_batch(us):
+        return square_rand_proof_vec.verify_l2rangeproof_vec_batch([u.square_proofs for u in us], [u.enc_values for u in us], with_csq_sums=True)
 
     @classmethod
-    def deserialize(cls, data):
-        m = wire.decode(cls.kind, data)
+    def verify_batch(cls, updates, verifier_seed=None, fp=None):
+        """The server's side of a round (server.rs:656-687 hands every client's update to the verification pool; :474-484 rejects the round
+        when one fails): EncModelParams::verify, EncL2 arm (params.rs:204-232), for ALL clients of the round as three batched calls that run
+        side by side -- the square proofs of every client in one launch sequence (rofl_verify_squarerandproof_vec_batch, which also hands
+        back every client's sum of c_sq), the L-inf legs through rofl_verify_rangeproof_batch_strided (commitments read in place from the
+        96-byte SquareRandProofCommitments; one random-weighted equation per batch with verify_batch = 2) and, once the sums are there, the
+        L2 sum proofs through rofl_verify_rangeproof_l2_batch.  One verdict per client, the same as update.verify() gives each of them;
+        clients whose shapes differ from the majority's are verified on their own."""
+        fp = api._fp(fp)
+        n = len(updates)
+        res = [False] * n
+        if n == 0:
+            return res
+        def shape(u):
+            try:
+                return (u.enc_values.shape[0], u.square_proofs.shape[0], u.range_proofs.shape if u.range_proofs.ndim == 2 else None, u.square_range_proof.size, u.prove_range, u.l2_prove_range)
+            except AttributeError:
+                return None
+        shapes = [shape(u) for u in updates]
+        ok_shape = [sh for sh in shapes if sh is not None and sh[0] == sh[1] and sh[0] > 0 and sh[2] is not None and sh[2][0] > 0]
+        if not ok_shape:
+            return [u.verify(verifier_seed=verifier_seed, fp=fp) if sh is not None else False for u, sh in zip(updates, shapes)]
+        major = max(set(ok_shape), key=ok_shape.count)
+        idx = [i for i, sh in enumerate(shapes) if sh == major]
+        for i, sh in enumerate(shapes):
+            if sh != major:
+                res[i] = bool(sh is not None and updates[i].verify(verifier_seed=verifier_seed, fp=fp))
+        us = [updates[i] for i in idx]
+        def sigma_then_sum():
+            ok_sq, sums = cls._square_batch(us)
+            if kernel_time_sink is not None:
+                kernel_time_sink(api.last_kernel_times())      # (this thread makes two calls; _timed reports the second)
+            ok_sum = l2_range_proof_vec.verify_rangeproof_l2_batch([u.square_range_proof for u in us], sums, major[5], verifier_seed=_sub_seed(verifier_seed, b"s"), fp=fp)
+            return ok_sq, ok_sum
+        try:
+            (ok_sq, ok_sum), ok_range = _concurrently(
+                sigma_then_sum,
+                lambda: range_proof_vec.verify_rangeproof_batch([u.range_proofs for u in us], [u.enc_values for u in us], major[4], verifier_seed=_sub_seed(verifier_seed, b"v"), fp=fp, commit_stride=96))
+        except (RoflError, ValueError, OverflowError, IndexError):
+            # (a call-level error -- a proof length no proof can have, a bit size outside 8 / 16 / 32 / 64: every member of this shape is malformed the same way)
+            return [bool(r) for r in res]
+        for k, i in enumerate(idx):
+            res[i] = bool(ok_sq[k] and ok_range[k] and ok_sum[k])
+        return res
+
+    def serialize(self, as_array=False):
+        return wire.encode(self.kind, enc_values=self.enc_values, square_proof=self.square_proofs, range_proofs=self.range_proofs,
+                           square_range_proof=self.square_range_proof, range_bits=self.prove_range, l2_range_bits=self.l2_prove_range, as_array=as_array)
+
+    @classmethod
+    def deserialize(cls, data, copy=True):
+        m = wire.decode(cls.kind, data, copy=copy)
         if m["enc_values"].size % 96 or m["square_proof"].size % 192:
             raise RoflError(5, "FormatError")
         return cls(m["enc_values"], m["square_proof"], m["range_proofs"], m["square_range_proof"], m["range_bits"], m["l2_range_bits"])
@@ -356,6 +453,10 @@ class EncParamsL2Compressed(EncParamsL2):
         sq_proofs, sq_commits = square_proof_vec.create_l2rangeproof_vec_existing(clipped, enc_com, bl, r2, nonce=_sub_nonce(nonce_seed, b"sq", wd), fp=fp)
         merged = np.concatenate([pairs, sq_commits[:, 32:64]], axis=1)        # merge(): c = ElGamal pair, c_sq from the square proof (params.rs:777-787)
         return cls(merged, sq_proofs, rand_proof, rp, sum_proof, prove_range, l2_range)
+
+    @staticmethod
+    def _square_batch(us):      # SquareProofCommitments { c_l: c.L, c_sq } (params.rs:262-266); as in verify(), the compressed randomness proof is not re-checked
+        return square_proof_vec.verify_l2rangeproof_vec_batch([u.square_proofs for u in us], [np.concatenate([u.enc_values[:, :32], u.enc_values[:, 64:96]], axis=1) for u in us], with_csq_sums=True)
 
     def verify(self, verifier_seed=None, fp=None):
         """EncModelParams::verify, EncL2Compressed arm (params.rs:255-289).  NB: as in the reference, the compressed

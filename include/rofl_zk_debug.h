@@ -48,6 +48,13 @@ int rofl_dbg_bind_device(int device);
 /* GPU multi-scalar multiplication sum_i k_i * P_i through the production Pippenger pipeline (dalek
  * vartime_multiscalar_mul as used by upstream verify_multiple); test hook for skewed / extreme scalars. */
 int rofl_dbg_msm(const uint8_t *scalars32, const uint8_t *points32, size_t n, uint8_t out32[32]);
+/* RangeProof::verify_multiple(&BulletproofGens::new(gens_capacity, m), &PedersenGens::default(), &mut Transcript::new(label), commits, n_bits)
+ * on one aggregated proof, called the way upstream's own tests call it: any transcript label, the m (a power of two) commitments as they
+ * are -- no shift by 2^(n-1) B, no padding.  The operator API fixes the labels ("RangeProof", "L2RangeProof") and the shift as the reference
+ * does; upstream's serialized-proof test vectors use another label (b"Deserialize-And-Verify Test", 64 x 8 generators), so this is the entry
+ * through which a byte vector of bulletproofs 4.0.0 would reach the HIP verifier.  5 = malformed proof or commitment, 6 = gens_capacity < n_bits. */
+int rofl_dbg_verify_labelled(const uint8_t *label, size_t label_len, size_t gens_capacity, const uint8_t *proof, size_t proof_len,
+                             const uint8_t *commits32, size_t m, size_t n_bits, const uint8_t verifier_seed[32], int *ok_out);
 /* process-wide counters of the MSM driver: out[0] MSMs that finished on their first attempt's variant, out[1] repeats after a bucket-list
  * overflow of the fused small launch, out[2] repeats on the slot path after a coarse bin of the two-level sort overflowed (scalars built to
  * collide), out[3] repeats after the slot path's overflow list ran out.  The server-path tests use them to show which path a scenario took. */

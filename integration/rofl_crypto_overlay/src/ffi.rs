@@ -60,6 +60,65 @@ extern "C" {
     pub fn rofl_add_points_vec(a32: *const u8, b32: *const u8, d: usize, out32: *mut u8) -> c_int;
     pub fn rofl_shift_points(a32: *const u8, d: usize, offset32: *const u8, out32: *mut u8) -> c_int;
     pub fn rofl_discrete_log_vec(points32: *const u8, d: usize, table_size: usize, bsgs_bits: c_uint, scalars_out32: *mut u8) -> c_int;
+
+    // ---- the rest of include/rofl_zk.h (scripts/check_ffi.py keeps this block and the header in step: names and arity)
+    pub fn rofl_bp_gens_export(n_bits: usize, m: usize, g_out: *mut u8, h_out: *mut u8) -> c_int;
+    pub fn rofl_next_pow2(v: usize) -> usize;
+    pub fn rofl_nonces_per_chunk(n_bits: usize, m: usize) -> usize;
+    /// commitments of client i read every `commit_stride` bytes from commits32[i] (64: ElGamal pairs, 96: SquareRandProofCommitments as they
+    /// arrive on the wire) -- what params.rs:197, 215 do with `enc_values.iter().map(|x| x.c.L)`
+    pub fn rofl_verify_rangeproof_batch_strided(n_clients: usize, proofs: *const *const u8, proof_len: usize, n_proofs: usize,
+        commits32: *const *const u8, commit_stride: usize, d: usize, prove_range: usize, fp_bits: c_uint, fp_frac: c_uint,
+        verifier_seed: *const u8, ok_out: *mut c_int) -> c_int;
+    pub fn rofl_clip_f32(input: *const c_float, d: usize, prove_range: usize, fp_bits: c_uint, fp_frac: c_uint, out: *mut c_float) -> c_int;
+    pub fn rofl_verify_rangeproof_l2_batch(n_clients: usize, proofs: *const *const u8, proof_len: usize, commits32: *const u8,
+        prove_range: usize, fp_bits: c_uint, fp_frac: c_uint, verifier_seed: *const u8, ok_out: *mut c_int) -> c_int;
+    pub fn rofl_verify_randproof_vec_batch(n_clients: usize, proofs: *const *const u8, commits: *const *const u8, d: usize, ok_out: *mut c_int) -> c_int;
+    pub fn rofl_verify_squarerandproof_vec_batch(n_clients: usize, proofs: *const *const u8, commits: *const *const u8, d: usize,
+        ok_out: *mut c_int, csq_sum_out32: *mut u8) -> c_int;
+    pub fn rofl_create_squareproof_vec(values: *const c_float, d: usize, r1_32: *const u8, d_r1: usize, r2_32: *const u8,
+        existing32: *const u8, fp_bits: c_uint, fp_frac: c_uint, nonce: *const RoflNonce, proofs_out: *mut u8,
+        commits_out: *mut u8) -> c_int;
+    pub fn rofl_verify_squareproof_vec(proofs: *const u8, commits: *const u8, d: usize, ok_out: *mut c_int) -> c_int;
+    pub fn rofl_verify_squareproof_vec_batch(n_clients: usize, proofs: *const *const u8, commits: *const *const u8, d: usize,
+        ok_out: *mut c_int, csq_sum_out32: *mut u8) -> c_int;
+    pub fn rofl_create_compressed_randproof(values: *const c_float, d: usize, r32: *const u8, d_r: usize, existing32: *const u8,
+        fp_bits: c_uint, fp_frac: c_uint, nonce: *const RoflNonce, proof_out: *mut u8, pairs_out: *mut u8) -> c_int;
+    pub fn rofl_verify_compressed_randproof(proof: *const u8, pairs: *const u8, d: usize, ok_out: *mut c_int) -> c_int;
+    pub fn rofl_sum_points(points: *const u8, d: usize, stride: usize, out32: *mut u8) -> c_int;
+    pub fn rofl_f32_to_scalar_vec(input: *const c_float, d: usize, fp_bits: c_uint, fp_frac: c_uint, out32: *mut u8) -> c_int;
+    pub fn rofl_scalar_to_f32_vec(in32: *const u8, d: usize, fp_bits: c_uint, fp_frac: c_uint, out: *mut c_float) -> c_int;
+    pub fn rofl_get_clip_bounds(range: usize, fp_bits: c_uint, fp_frac: c_uint, min_out: *mut c_float, max_out: *mut c_float) -> c_int;
+    pub fn rofl_fp_square_vec(in32: *const u8, d: usize, fp_bits: c_uint, fp_frac: c_uint, out32: *mut u8) -> c_int;
+    pub fn rofl_scalar_powers(value32: *const u8, count: usize, out32: *mut u8) -> c_int;
+    pub fn rofl_scalar_add_vec(a32: *const u8, b32: *const u8, d: usize, subtract: c_int, out32: *mut u8) -> c_int;
+    pub fn rofl_f32_to_fp_vec(input: *const c_float, d: usize, fp_bits: c_uint, fp_frac: c_uint, out: *mut u64) -> c_int;
+    pub fn rofl_uint_to_f32_vec(input: *const u64, d: usize, fp_bits: c_uint, fp_frac: c_uint, out: *mut c_float) -> c_int;
+    pub fn rofl_get_l2_clip_bounds(range: usize, fp_bits: c_uint, fp_frac: c_uint, out: *mut c_float) -> c_int;
+    pub fn rofl_wire_encoded_size(m: *const RoflWireMsg) -> usize;
+    pub fn rofl_wire_encode(m: *const RoflWireMsg, out: *mut u8, cap: usize, len_out: *mut usize) -> c_int;
+    pub fn rofl_wire_decode(kind: c_int, data: *const u8, len: usize, m: *mut RoflWireMsg, range_proofs_out: *mut u8, range_proofs_cap: usize) -> c_int;
+    // one process per GPU: the exchange of a round over the library's own RCCL communicator
+    pub fn rofl_comm_unique_id(id_out: *mut u8) -> c_int;
+    pub fn rofl_comm_init(id: *const u8, rank: c_int, world: c_int) -> c_int;
+    pub fn rofl_comm_allgather(local: *const u8, n: usize, all_out: *mut u8) -> c_int;
+    pub fn rofl_comm_allreduce_f64(inout: *mut f64, count: usize, op: c_int) -> c_int;
+    pub fn rofl_comm_barrier() -> c_int;
+    pub fn rofl_comm_info(rank_out: *mut c_int, world_out: *mut c_int, rccl_version_out: *mut c_int, lib_path_out: *mut c_char, len: usize) -> c_int;
+    pub fn rofl_comm_destroy() -> c_int;
+}
+
+/// rofl_wire_msg_t (include/rofl_zk.h): the proto3 messages of flservice.proto:75-100 as spans over `to_bytes` concatenations
+#[repr(C)]
+pub struct RoflWireMsg {
+    pub kind: c_int,                       // 0 EncRangeData, 1 EncNormData, 2 EncNormDataCompressed
+    pub enc_values: *const u8, pub enc_values_len: usize,
+    pub rand_proof: *const u8, pub rand_proof_len: usize,
+    pub square_proof: *const u8, pub square_proof_len: usize,
+    pub range_proofs: *const u8, pub range_proof_len: usize, pub n_range_proofs: usize,
+    pub square_range_proof: *const u8, pub square_range_proof_len: usize,
+    pub range_bits: i32, pub l2_range_bits: i32,
+    pub check_percentage: c_float,
 }
 
 // return codes of include/rofl_zk.h
@@ -73,6 +132,11 @@ pub const ROFL_INVALID_GENERATORS_LENGTH: c_int = 6;
 pub const ROFL_NORM_OUT_OF_RANGE: c_int = 7;
 pub const ROFL_OVERFLOW: c_int = 8;
 pub const ROFL_SUM_ERROR: c_int = 9;
+pub const ROFL_NON_FINITE: c_int = 10;
+pub const ROFL_BAD_PARAM: c_int = 11;
+pub const ROFL_NONCE_SHORT: c_int = 12;
+pub const ROFL_COMM_ERROR: c_int = 99;
+pub const ROFL_HIP_ERROR: c_int = 100;
 
 pub fn fp_bits() -> c_uint { N_BITS as c_uint }
 pub fn fp_frac() -> c_uint { <Frac as Unsigned>::U32 }

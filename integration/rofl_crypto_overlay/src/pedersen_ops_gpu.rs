@@ -43,3 +43,14 @@ pub fn discrete_log_vec(rp_vec: &Vec<RistrettoPoint>, table_size: usize) -> Vec<
     assert!(rc == ROFL_OK, "rofl_zk: {}", last_error());
     bytes_to_scalars(&out)
 }
+
+/// `enc_values.iter().map(|x| x.c_sq).sum()` of rofl_service/src/flserver/params.rs:220, 277 on the device: the sum of d compressed points
+/// read every `stride` bytes (96 over serialized SquareRandProofCommitments, 32 over a packed vector); an empty input gives the identity.
+pub fn sum_points_strided(bytes: &[u8], d: usize, stride: usize) -> RistrettoPoint {
+    assert!(stride >= 32 && bytes.len() >= d.saturating_sub(1) * stride + if d > 0 { 32 } else { 0 });
+    let mut out = [0u8; 32];
+    let rc = unsafe { rofl_sum_points(bytes.as_ptr(), d, stride, out.as_mut_ptr()) };
+    assert!(rc == ROFL_OK, "rofl_zk: {}", last_error());
+    bytes_to_points(&out)[0]
+}
+pub fn sum_rp_vec(rp_vec: &Vec<RistrettoPoint>) -> RistrettoPoint { sum_points_strided(&points_to_bytes(rp_vec), rp_vec.len(), 32) }

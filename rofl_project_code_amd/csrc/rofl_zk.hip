@@ -1213,6 +1213,40 @@ int rofl_dbg_msm(const uint8_t *scalars32, const uint8_t *points32, size_t n, ui
         return ROFL_OK;
     });
 }
+// bulletproofs' RangeProof::verify_multiple(&bp_gens, &pc_gens, &mut Transcript::new(label), &value_commitments, n) on ONE aggregated proof
+// exactly as upstream's own tests call it: any transcript label (upstream's serialized-proof vectors use b"Deserialize-And-Verify Test"),
+// the commitments as they are (no shift, no padding: m must be a power of two), generators of capacity >= n.  If byte vectors of
+// bulletproofs 4.0.0 ever become reachable, they go straight through the HIP verifier here (the crate-level pin the oracle lacks).
+int rofl_dbg_verify_labelled(const uint8_t *label, size_t label_len, size_t gens_capacity, const uint8_t *proof, size_t proof_len,
+                             const uint8_t *commits32, size_t m, size_t n_bits, const uint8_t verifier_seed[32], int *ok_out) {
+    return guarded([&]() -> int {
+        LaneLock lane_lock = acquire_lane(false, true); Ctx &C = *lane_lock.c;
+        if (!label || !label_len || label_len > 255 || !proof || !commits32 || !m || !is_pow2(m) || !verifier_seed || !ok_out) return fail(ROFL_BAD_PARAM, "bad parameter");
+        *ok_out = 0;
+        std::string lbl((const char *)label, label_len);
+        if (lbl.find('\0') != std::string::npos) return fail(ROFL_BAD_PARAM, "the label holds a NUL byte");
+        C.init();
+        timing_begin(C);
+        uint8_t *d_in = C.Cbytes.as<uint8_t>(m * 32), *d_enc = C.Vbytes.as<uint8_t>(m * 32);
+        niels *d_vn = C.gbuf[0].as<niels>(m);
+        u32 *status = C.status.as<u32>(4);
+        HIPCHK(hipMemsetAsync(status, 0, 16, C.stream));
+        C.up(d_in, commits32, m * 32, C.stream);
+        hipLaunchKernelGGL(k_decode, grid1(m), dim3(TPB), 0, C.stream, (u32)m, (u32)m, d_in, (const niels *)nullptr, d_vn, d_enc, status);
+        std::vector<uint8_t> hV(m * 32); u32 *h_st = C.h_misc.as<u32>(4);
+        uint8_t *hp = C.h_V.as<uint8_t>(m * 32);
+        HIPCHK(hipMemcpyAsync(hp, d_enc, m * 32, hipMemcpyDeviceToHost, C.stream));
+        HIPCHK(hipMemcpyAsync(h_st, status, 4, hipMemcpyDeviceToHost, C.stream));
+        C.sync();
+        if (h_st[0] & 4u) { timing_end(C); return fail(ROFL_FORMAT_ERROR, "commitment is not a valid Ristretto encoding"); }
+        u64 cidx = 0; int ok = 0;
+        int rc = verify_chunks(C, lbl.c_str(), gens_capacity, 1, n_bits, m, proof, proof_len, hp, d_vn, verifier_seed, &cidx, &ok);
+        timing_end(C);
+        if (rc) return fail(rc, "proof rejected before verification (format / bitsize / generator capacity)");
+        *ok_out = ok;
+        return ROFL_OK;
+    });
+}
 int rofl_dbg_msm_retries(uint64_t out[4]) { if (!out) return ROFL_BAD_PARAM; for (int i = 0; i < 4; i++) out[i] = g_msm_stat[i].load(); return ROFL_OK; }
 int rofl_dbg_quad_ops(const uint8_t *pairs64, size_t pairs, unsigned doublings, uint8_t *out_serial32, uint8_t *out_quad32) {
     return guarded([&]() -> int {

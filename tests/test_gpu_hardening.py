@@ -262,3 +262,38 @@ def test_caller_memory_is_staged_for_any_size(R):
         s = R.pedersen_ops.add_rp_vec(got, got)          # two staged inputs, one staged output
         assert (s[pick] == orc.add_points_vec(want, want)[1]).all(), d
         del got, s
+
+
+def test_verify_with_a_free_transcript_label(R):
+    """rofl_dbg_verify_labelled (debug header): verify_multiple as upstream's own tests call it -- any label, unshifted commitments, generator
+    capacity >= n.  The L2 sum proof (label "L2RangeProof", no shift) and one chunk of an L-inf proof (label "RangeProof", commitments shifted
+    by 2^(n-1) B as range_proof_vec/mod.rs:155-167 does) are accepted under their labels and rejected under any other."""
+    import ctypes
+    L = R.lib()
+    fp = (32, 7)
+    rng = np.random.default_rng(31)
+
+    def labelled(label, cap, proof, commits, m, n):
+        ok = ctypes.c_int(-1)
+        p = np.ascontiguousarray(proof, np.uint8).reshape(-1); c = np.ascontiguousarray(commits, np.uint8).reshape(-1, 32)
+        rc = L.rofl_dbg_verify_labelled(label, ctypes.c_size_t(len(label)), ctypes.c_size_t(cap), p.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(p.size),
+                                        c.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(m), ctypes.c_size_t(n), b"\x09" * 32, ctypes.byref(ok))
+        return rc, ok.value
+    d = 40
+    x = (rng.integers(-3, 4, size=d) / 128.0).astype(np.float32); r2 = orc.rand_scalars(rng, d)
+    proof, commit = R.l2_range_proof_vec.create_rangeproof_l2(x, r2, 32, 4, nonce=R.Nonce.seeded(b"\x11" * 32), fp=fp)
+    assert labelled(b"L2RangeProof", 64, proof, commit, 1, 32) == (0, 1)
+    assert labelled(b"L2RangeProof", 32, proof, commit, 1, 32) == (0, 1)
+    assert labelled(b"RangeProof", 64, proof, commit, 1, 32) == (0, 0)
+    assert labelled(b"Deserialize-And-Verify Test", 64, proof, commit, 1, 32) == (0, 0)
+    assert labelled(b"L2RangeProof", 16, proof, commit, 1, 32)[0] == 6          # InvalidGeneratorsLength
+    bad = proof.copy(); bad[3] ^= 1
+    assert labelled(b"L2RangeProof", 64, bad, commit, 1, 32) in ((0, 0), (5, 0))
+    vals = rng.uniform(-100, 100, 64).astype(np.float32); bl = orc.rand_scalars(rng, 64)
+    pr, cm = R.range_proof_vec.create_rangeproof(vals, bl, 8, 4, nonce=R.Nonce.seeded(b"\x12" * 32), fp=(16, 7))
+    shift = R.pedersen_ops.commit_no_blinding_vec(np.frombuffer((128).to_bytes(32, "little"), np.uint8).reshape(1, 32))[0]
+    V = R.pedersen_ops.compute_shifted_values_rp(cm, shift)
+    assert labelled(b"RangeProof", 8, pr[1], V[16:32], 16, 8) == (0, 1)
+    assert labelled(b"RangeProof", 8, pr[1], cm[16:32], 16, 8) == (0, 0)       # the unshifted commitments are not what was proved
+    assert labelled(b"rangeproof", 8, pr[1], V[16:32], 16, 8) == (0, 0)
+    assert labelled(b"RangeProof", 8, pr[1], V[16:28], 12, 8)[0] == 11          # m must be a power of two

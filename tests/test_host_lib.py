@@ -374,3 +374,19 @@ print("comm ok", rc)
         if libname.startswith("/nonexistent"):
             assert "comm ok 99" in r.stdout
     assert b"librccl" not in subprocess.run(["readelf", "-d", hiplib._name], capture_output=True).stdout      # no link-time dependency
+
+
+def test_rust_ffi_block_matches_the_header():
+    """integration/rofl_crypto_overlay/src/ffi.rs declares every export of include/rofl_zk.h with the same arity and parameter shapes
+    (scripts/check_ffi.py: nothing in this image compiles the two against each other) -- and the checker does notice a drift."""
+    import importlib.util, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "check_ffi.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout
+    spec = importlib.util.spec_from_file_location("check_ffi", os.path.join(root, "scripts", "check_ffi.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    c = m.c_functions(os.path.join(root, "include", "rofl_zk.h"))
+    assert c["rofl_comm_init"] == ("int", [("ptr", "int"), ("val", "int"), ("val", "int")])
+    assert c["rofl_clip_f32"][1][0] == ("ptr", "float") and c["rofl_next_pow2"][0] == "size_t"
+    assert m.rust_shape("proofs: *const *const u8") == ("ptrptr", "int") and m.rust_shape("nonce: *const RoflNonce") == ("ptr", "struct")
+    assert len(c) >= 56

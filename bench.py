@@ -69,6 +69,7 @@ def parse_args():
                          "is mapped before torch is imported, so the library runs on it while torch keeps its own copy for the contract's torch.cuda.synchronize() "
                          "(N = 1 only); auto (default): an N = 1 run (no process group) happens in a child process in `system` mode and falls back to `process` if that "
                          "child fails; N > 1 and --one-process are `process`.  profiles/r04_experiments.txt item 13")
+    ap.add_argument("--compact-tables", action="store_true", help="the 16-slice fold table (ROFL_FOLD_PB=64, ROFL_FOLD_W=4: 0.8-1.9 GB per shape instead of 26 GB; the first fold of a proof is ~2.5 ms slower) -- for rehearsals that put eight device contexts on ONE GPU")
     ap.add_argument("--clients", type=int, default=48, help="clients of configs 4 / 5 (cifar_large.yml: 48)")
     ap.add_argument("--l2-create-batch", type=int, default=-1, help="--config 5: clients per EncParamsL2.encrypt_batch call (their 8-bit legs as one rofl_create_rangeproof_batch); 0 / 1 = one encrypt() per client; default 4")
     return ap.parse_args()
@@ -458,12 +459,13 @@ def run_multi_client(args, R, rd, dist, cdev, world, rank, backend, comm):
     wall = time.perf_counter() - t0
     ru1 = resource.getrusage(resource.RUSAGE_SELF)
     elapsed = wall - gen_s      # drawing the synthetic inputs (numpy RNG on the host) is not part of the path
-    rccl_world = 1; runtimes = None
+    rccl_world = 1; runtimes = None; per_rank_info = None
     if args.exchange:
         elapsed = float(comm.reduce([elapsed], "max")[0])
         rccl_world = int(round(comm.reduce([1.0], "sum")[0]))
         assert rccl_world == world
-        runtimes = gather_runtimes(comm)
+        per_rank_info = gather_rank_info(comm, host_cores_busy=round(((ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime) - gen_s) / max(wall - gen_s, 1e-9), 2), host_cores=avail_cores())
+        runtimes = [r_.get("hip_runtime") for r_ in per_rank_info]
     if rank == 0:
         K = args.steps
         kind = "L-inf 32-bit range proofs" if cfg == 4 else "L2 composite (EncParamsL2: 8-bit range proof + L2 sum proof + square proofs)"
@@ -473,7 +475,7 @@ def run_multi_client(args, R, rd, dist, cdev, world, rank, backend, comm):
         out = {"metric": "range-proof elements/sec (create+verify), %d clients d=55k" % NC, "value": NC * D_MULTI * K / elapsed, "unit": "elements/s",
                "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "strong",
                "vs_baseline": None, "dtype": "u32x8 (255-bit integer field)", "data": "synthetic", "rccl_world_size": rccl_world,
-               "collective_backend": comm.backend if args.exchange else None, "hip_runtime_per_rank": runtimes,
+               "collective_backend": comm.backend if args.exchange else None, "hip_runtime_per_rank": runtimes, "per_rank": per_rank_info,
                "config": {"workload": "BASELINE cfg %d: %s, d=55000 (resnet18_intrinsic_55k), %d clients sharded over %d rank(s): batch create -> one all-gather of "
                                       "proof bytes + commitments -> every rank batch-verifies the share of rank+1 -> MIN all-reduce of the verdicts" % (cfg, kind, NC, world),
                           "d": D_MULTI, "clients": NC, "clients_per_rank": len(mine), "prove_range": NBITS if cfg == 4 else 8, "l2_range": None if cfg == 4 else 32,
@@ -683,12 +685,14 @@ def run_rank(args):
     gc.enable()
     ru1 = resource.getrusage(resource.RUSAGE_SELF)
     cpu_busy = ((ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)) / elapsed
-    rccl_world = 1; runtimes = None
+    rccl_world = 1; runtimes = None; per_rank_info = None
     if args.exchange:
+        own_elapsed = elapsed
         elapsed = float(comm.reduce([elapsed], "max")[0])
         rccl_world = int(round(comm.reduce([1.0], "sum")[0]))      # every rank that really joined the communicator counts once
         assert rccl_world == world and (dist is None or dist.get_world_size() == world)
-        runtimes = gather_runtimes(comm)
+        per_rank_info = gather_rank_info(comm, host_cores_busy=round(cpu_busy, 2), ms_per_step=round(own_elapsed / args.steps * 1e3, 3), host_cores=avail_cores())
+        runtimes = [r_.get("hip_runtime") for r_ in per_rank_info]
 
     if rank != 0:
         comm.barrier(); comm.close(); dist.destroy_process_group()
@@ -722,11 +726,12 @@ def run_rank(args):
         "metric": "range-proof elements/sec (create+verify), d=25k 32-bit" + ("" if NPART == 4 else ", n_partition=%d" % NPART), "value": value, "unit": "elements/s",
         "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": elapsed / K * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32x8 (255-bit integer field)", "data": "synthetic",
-        "rccl_world_size": rccl_world, "collective_backend": comm.backend if args.exchange else None, "hip_runtime_per_rank": runtimes,
+        "rccl_world_size": rccl_world, "collective_backend": comm.backend if args.exchange else None, "hip_runtime_per_rank": runtimes, "per_rank": per_rank_info,
         "config": {"workload": "BASELINE cfg 2: L-inf 32-bit range proof, d=25000 (resnet18_intrinsic_25k), 1 client create+verify per step per GPU, inputs handed over as host buffers (H2D inside the timed region)",
                    "d": D, "prove_range": NBITS, "n_partition": NPART, "fp_bits": FP_BITS, "fp_frac": FP_FRAC, "clients_per_step_per_gpu": 1,
                    "host_cores": avail_cores(), "host_cores_pinned": args.host_cores or None, "host_cores_busy": round(cpu_busy, 2), "lanes": R.get_option("lanes"), "wait_policy": "sleep" if os.environ.get("ROFL_BLOCKING_SYNC") == "1" else "spin",
-                   "hip_runtime": mapped_hip_runtime(),
+                   "hip_runtime": mapped_hip_runtime(), "tables": "compact (16 fold slices)" if args.compact_tables else "full",
+                   "rehearsal": ("%d ranks share ONE GPU (ROFL_BENCH_SAME_DEVICE; collectives over gloo, RCCL refuses duplicate devices): a dress rehearsal of the N-rank path, NOT a scaling number" % world) if (world > 1 and os.environ.get("ROFL_BENCH_SAME_DEVICE") == "1") else None,
                    "protocol": "warm-up steps, then K timed steps back to back; value = N*K*d / wall time of the K steps (max over ranks); median_ms_per_step = the reference bench's statistic (benches/rangeproof_bench.rs:53-85)"},
         "median_ms_per_step": median_ms, "min_ms_per_step": step_sorted[0], "max_ms_per_step": step_sorted[-1], "step_ms": [round(x, 2) for x in step_ms],
         "elements_per_s_at_median": D / (median_ms * 1e-3),
@@ -912,9 +917,19 @@ def run_one_process(args):
     build.build()
     rpv = R.range_proof_vec
     NC, P = args.clients, args.n_partition
-    for dv in range(ndev):
-        R.set_device(dv)
-        api.bp_gens_prepare(NBITS, rpv.next_pow2(D_MULTI) // P)
+    # the devices' tables are built side by side, one thread per device (0.6 s each on a fresh process; eight in a row was 5 s of start-up)
+    import threading
+    t_prep = time.perf_counter(); prep_err = []
+    def prep(dv):
+        try:
+            R.set_device(dv); api.bp_gens_prepare(NBITS, rpv.next_pow2(D_MULTI) // P)
+        except Exception as e:      # noqa: BLE001
+            prep_err.append((dv, repr(e)))
+    ths = [threading.Thread(target=prep, args=(dv,)) for dv in range(ndev)]
+    for t_ in ths: t_.start()
+    for t_ in ths: t_.join()
+    assert not prep_err, prep_err
+    prepare_ms = (time.perf_counter() - t_prep) * 1e3
     R.set_device(0)
     R.set_option("devices", (1 << ndev) - 1); R.set_option("verify_batch", 2)
     phase = {"create": 0.0, "verify": 0.0}
@@ -956,18 +971,27 @@ def run_one_process(args):
                       "config": {"workload": "BASELINE cfg 4: L-inf 32-bit range proofs, d=55000, %d clients, ONE host process driving %d logical device(s) on %d physical GPU(s) through the C ABI "
                                              "(rofl_set_option(\"devices\")): batched create calls of six clients per device and ONE batched verify call per step, dealt to the devices inside the library" % (NC, ndev, min(ndev, nphys)),
                                  "d": D_MULTI, "clients": NC, "n_partition": P, "prove_range": NBITS, "fp_bits": FP_BITS, "fp_frac": FP_FRAC, "devices_mask": (1 << ndev) - 1,
-                                 "physical_gpus": min(ndev, nphys), "verify_batch": 2, "host_cores": avail_cores(),
+                                 "physical_gpus": min(ndev, nphys), "verify_batch": 2, "host_cores": avail_cores(), "tables": "compact (16 fold slices)" if args.compact_tables else "full",
+                                 "tables_prepare_ms_all_devices_in_parallel": round(prepare_ms, 1), "hip_runtime": mapped_hip_runtime(),
+                                 "rehearsal": ("%d logical devices share %d physical GPU(s): this run checks that the N-device path completes (contexts, tables, sharding, verdicts); it is NOT a scaling number" % (ndev, nphys)) if nphys < ndev else None,
                                  "host_cores_busy": round(((ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime) - gen_s) / max(elapsed, 1e-9), 2)},
                       "breakdown_ms_per_step": {k: phase[k] / K * 1e3 for k in ("create", "verify")},
                       "create_only_elements_per_s": NC * D_MULTI * K / phase["create"], "verify_only_elements_per_s": NC * D_MULTI * K / phase["verify"]}))
 
 
-def gather_runtimes(comm):
-    """config.hip_runtime of every rank (one 512-byte record each through the communicator): the ranks of a node must agree"""
+def gather_rank_info(comm, **extra):
+    """One small JSON record per rank through the communicator: the HIP runtime(s) it mapped (the ranks of a node must agree), its busy host
+    cores and whatever else the caller adds -- rank 0 prints them as hip_runtime_per_rank / per_rank."""
     import numpy as np
-    rec = (";".join(mapped_hip_runtime()).encode()[:511]).ljust(512, b"\0")
+    rec = json.dumps(dict(hip_runtime=mapped_hip_runtime(), **extra)).encode()[:1023].ljust(1024, b" ")
     _, per = comm.exchange_round([np.frombuffer(rec, dtype=np.uint8)], True)
-    return [bytes(p[0]).rstrip(b"\0").decode(errors="replace").split(";") for p in per]
+    out = []
+    for p_ in per:
+        try:
+            out.append(json.loads(bytes(p_[0]).decode(errors="replace")))
+        except ValueError:
+            out.append({"hip_runtime": None})
+    return out
 
 
 def mapped_hip_runtime():
@@ -983,6 +1007,8 @@ def main():
     global NPART
     args = parse_args()
     NPART = args.n_partition
+    if args.compact_tables:
+        os.environ["ROFL_FOLD_PB"] = "64"; os.environ["ROFL_FOLD_W"] = "4"
     if args.hip_runtime == "auto":
         # The headline runs on the runtime the library is deployed on: as a child process (this one never touches the GPU) so that a failure
         # of the two-runtime arrangement costs a retry, not the bench line.

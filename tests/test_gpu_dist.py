@@ -255,3 +255,17 @@ def test_rank_path_runs_on_the_system_runtime_and_exchanges_through_the_library(
     h = json.loads(r2.stdout.strip().splitlines()[-1])
     # the exchange (one all-gather of 0.8 MB through RCCL in a group of one) is inside the rank path's step and not in the headline's
     assert j["median_ms_per_step"] <= 1.03 * h["median_ms_per_step"] + 0.4, (j["median_ms_per_step"], h["median_ms_per_step"])
+
+
+def test_eight_logical_devices_one_process_rehearsal():
+    """The first real 8-GPU run must not be the first time eight device contexts exist: `bench.py --config 4 --one-process --gpus 8` with eight
+    logical devices on the one GPU (compact fold tables so that eight contexts fit), tables prepared in parallel, one client per device."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "4", "--one-process", "--gpus", "8", "--clients", "8", "--steps", "1", "--warmup", "0", "--compact-tables"],
+                       env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 8 and line["config"]["devices_mask"] == 255 and line["config"]["tables"].startswith("compact") and "NOT a scaling number" in line["config"]["rehearsal"]
+    assert line["value"] > 0 and any(x.startswith("/opt/rocm") for x in line["config"]["hip_runtime"])

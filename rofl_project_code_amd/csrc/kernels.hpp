@@ -2270,14 +2270,14 @@ __global__ void __launch_bounds__(64) k_sigma_verify(int kind, u32 d, const uint
 // blockIdx.y = vector (the clients of a server-side batch: `d` elements each, laid out one after the other in every array; its own
 // status word; weight index widx0 + y * d + i so that no two elements of a batch share a weight).
 __global__ void __launch_bounds__(TPB) k_sigma_vprep(int kind, u32 d, const uint8_t *proofs, const uint8_t *commits, DMerlin init, NonceSeed wseed, u64 widx0, u32 wbits,
-                                                      niels *pts, sc *scal_canon, sc *fixed_part /* [gridDim.y][gridDim.x][2] Montgomery */, u32 *status /* [gridDim.y] */) {
+                                                      sc *scal_canon, sc *fixed_part /* [gridDim.y][gridDim.x][2] Montgomery */, u32 *status /* [gridDim.y] */) {
     __shared__ sc lds[TPB * 2];
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     bool has_R = kind != 2, has_sq = kind != 0;
     u32 npts = 1 + (has_R ? 1 : 0) + (has_sq ? 1 : 0), nn = has_sq ? 3 : 2, clen = 32 * npts, plen = 32 * (npts + nn), sq_off = has_R ? 64 : 32;
     {
         const size_t y = blockIdx.y;
-        proofs += y * d * plen; commits += y * d * clen; pts += y * 2 * npts * d; scal_canon += y * 2 * npts * d;
+        proofs += y * d * plen; commits += y * d * clen; scal_canon += y * 2 * npts * d;
         fixed_part += y * gridDim.x * 2; status += y; widx0 += y * d;
     }
     sc v[2] = {sc_zero(), sc_zero()};
@@ -2308,28 +2308,42 @@ __global__ void __launch_bounds__(TPB) k_sigma_vprep(int kind, u32 d, const uint
         // B: -(w1 Z_m + w2 Z_r1) ; Bb: -(w1 Z_r1 + w3 Z_r2)
         v[0] = sc_to_mont(sc_neg(sc_add(sc_mul_plain(w[0], zm), sc_mul_plain(w[1], zr1))));
         v[1] = sc_to_mont(sc_neg(sc_add(sc_mul_plain(w[0], zr1), sc_mul_plain(w[2], zr2))));
-        // one point at a time (six live points would not fit the register file): decode, store its niels form and its scalar
-        u32 slot = 0; gd p;
-        okf &= sg_decode(p, cm);                   // L: w1 c - w3 Z_m
-        store_niels(&pts[(size_t)slot * d + i], sg_affine_niels(p)); store_sc(&scal_canon[(size_t)slot * d + i], sc_sub(sc_mul_plain(w[0], c), sc_mul_plain(w[2], zm))); slot++;
-        okf &= sg_decode(p, pf);                   // L': w1
-        store_niels(&pts[(size_t)slot * d + i], sg_affine_niels(p)); store_sc(&scal_canon[(size_t)slot * d + i], w[0]); slot++;
+        // the scalars of the element's points (the points themselves are decoded by k_sigma_vdecode, one thread per point): slot k of element i at k * d + i
+        u32 slot = 0;
+        store_sc(&scal_canon[(size_t)slot * d + i], sc_sub(sc_mul_plain(w[0], c), sc_mul_plain(w[2], zm))); slot++;      // L: w1 c - w3 Z_m
+        store_sc(&scal_canon[(size_t)slot * d + i], w[0]); slot++;                                                          // L': w1
         if (has_R) {
-            okf &= sg_decode(p, cm + 32);          // R: w2 c
-            store_niels(&pts[(size_t)slot * d + i], sg_affine_niels(p)); store_sc(&scal_canon[(size_t)slot * d + i], sc_mul_plain(w[1], c)); slot++;
-            okf &= sg_decode(p, pf + 32);          // R': w2
-            store_niels(&pts[(size_t)slot * d + i], sg_affine_niels(p)); store_sc(&scal_canon[(size_t)slot * d + i], w[1]); slot++;
+            store_sc(&scal_canon[(size_t)slot * d + i], sc_mul_plain(w[1], c)); slot++;                                     // R: w2 c
+            store_sc(&scal_canon[(size_t)slot * d + i], w[1]); slot++;                                                      // R': w2
         }
         if (has_sq) {
-            okf &= sg_decode(p, cm + sq_off);      // Csq: w3 c
-            store_niels(&pts[(size_t)slot * d + i], sg_affine_niels(p)); store_sc(&scal_canon[(size_t)slot * d + i], sc_mul_plain(w[2], c)); slot++;
-            okf &= sg_decode(p, pf + sq_off);      // Csq': w3
-            store_niels(&pts[(size_t)slot * d + i], sg_affine_niels(p)); store_sc(&scal_canon[(size_t)slot * d + i], w[2]); slot++;
+            store_sc(&scal_canon[(size_t)slot * d + i], sc_mul_plain(w[2], c)); slot++;                                     // Csq: w3 c
+            store_sc(&scal_canon[(size_t)slot * d + i], w[2]); slot++;                                                      // Csq': w3
         }
         if (!okf) atomicOr(status, 4u);            // FormatError: the host ignores the sum
     }
     block_sum_sc<2>(v, lds);
     if (threadIdx.x == 0) { store_sc(&fixed_part[blockIdx.x * 2], v[0]); store_sc(&fixed_part[blockIdx.x * 2 + 1], v[1]); }
+}
+#endif
+// The points of the batched Sigma-proof check: ONE THREAD PER POINT (slot k of element i of vector y at pts[(y * nslots + k) * d + i]; the
+// commitments' points in the even slots, the proof's primed points in the odd ones), decoded into affine niels form.  Kept apart from
+// k_sigma_vprep -- whose transcript and weight sponges hold 256 VGPRs + 75 AGPRs at one wave per SIMD -- this is the plain inverse-square-root
+// chain at the occupancy and rate of k_decode: the fused kernel took 34.7 ms for a round of 48 clients of d = 55 000, the two together 2x ms.
+#if ROFL_KG(3)
+__global__ void __launch_bounds__(TPB) k_sigma_vdecode(int kind, u32 d, const uint8_t *proofs, const uint8_t *commits, niels *pts, u32 *status /* [gridDim.y] */) {
+    bool has_R = kind != 2, has_sq = kind != 0;
+    u32 npts = 1 + (has_R ? 1 : 0) + (has_sq ? 1 : 0), nn = has_sq ? 3 : 2, clen = 32 * npts, plen = 32 * (npts + nn), nslots = 2 * npts;
+    const size_t y = blockIdx.y;
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)nslots * d) return;
+    u32 slot = (u32)(t / d), i = (u32)(t % d);
+    const uint8_t *src = (slot & 1) ? proofs + (y * d + i) * plen + 32 * (slot >> 1) : commits + (y * d + i) * clen + 32 * (slot >> 1);
+    __align__(16) uint8_t b[32];
+    reinterpret_cast<uint4 *>(b)[0] = reinterpret_cast<const uint4 *>(src)[0]; reinterpret_cast<uint4 *>(b)[1] = reinterpret_cast<const uint4 *>(src)[1];
+    gd p;
+    if (!gd_ristretto_decode(p, b)) { atomicOr(status + y, 4u); p = gd_identity(); }
+    store_niels(&pts[(y * nslots + slot) * d + i], sg_affine_niels(p));
 }
 #endif
 // ---- compressed_rand_proof: the d ElGamal pairs, the challenge-power dot products, the verification scalars

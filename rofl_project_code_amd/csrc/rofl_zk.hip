@@ -834,12 +834,46 @@ int sigma_verify_batch(int kind, size_t nc, const uint8_t *const *proofs, const 
     const size_t per = d * (plen + clen);
     const size_t G = std::max<size_t>(1, std::min<size_t>(nc, ((size_t)64 << 20) / per));
     bool all_host = true; for (size_t i = 0; i < nc; i++) all_host &= !is_device_ptr(proofs[i]) && !is_device_ptr(commits[i]);
-    uint8_t *stage[2] = {nullptr, nullptr}; bool used[2] = {false, false};
-    if (all_host && per >= Stage::kMin) { stage[0] = (uint8_t *)C.stg.alloc(G * per); if (nc > G) stage[1] = (uint8_t *)C.stg.alloc(G * per); }
+    // three staging buffers; the uploads run on a stream of their own (the copy of group g + 1 beside the kernels of group g: on one stream they
+    // alternated, and the "staging" time of the first version was the host waiting for that stream)
+    constexpr size_t NST = 3;
+    uint8_t *stage[NST] = {nullptr, nullptr, nullptr}; bool used[NST] = {false, false, false};
+    if (all_host && per >= Stage::kMin) for (size_t b = 0; b < NST && b * G < nc; b++) stage[b] = (uint8_t *)C.stg.alloc(G * per);
+    if (stage[0] && !C.stream_up) HIPCHK(hipStreamCreateWithFlags(&C.stream_up, hipStreamNonBlocking));
+    struct JoinUp { hipStream_t s; ~JoinUp() { if (s) (void)hipStreamSynchronize(s); } } join_up{stage[0] ? C.stream_up : nullptr};
+    // events of the call: 0..2 upload of staging buffer b done, 3 / 4 a launch's clients decoded, 5 / 6 a launch finished
+    if (stage[0]) { HIPCHK(hipEventRecord(C.pool_event(7), C.stream)); HIPCHK(hipStreamWaitEvent(C.stream_up, C.pool_event(7), 0)); }      // (after the status memset)
+    // Every client is one problem of a multi-problem Pippenger launch; launches of up to sixteen clients (the slot array of a launch grows with
+    // its problems) go to the SIDE stream as soon as their clients are decoded, so that they run while the host is still staging and the main
+    // stream still uploading and decoding the later clients.  Two MSM workspaces alternate: launch k + 2 waits for launch k's results.
+    if (!C.stream2) HIPCHK(hipStreamCreateWithFlags(&C.stream2, hipStreamNonBlocking));
+    struct Join { hipStream_t s; ~Join() { (void)hipStreamSynchronize(s); } } join{C.stream2};      // nothing of the side stream outlives the call, error paths included
+    struct Job { size_t c0, cnt; MsmJob J; MsmAllow al; std::vector<MsmProb> pr; std::vector<ge5> res; bool done = false, redo = false; };
+    std::vector<std::unique_ptr<Job>> jobs;
+    const size_t SGC = 16;
+    auto finish_job = [&](Job &jb, size_t k) {
+        C.wait_event(C.pool_event(5 + (k & 1)));
+        if (msm_retry(jb.J, jb.al)) jb.redo = true;      // a fixed-size structure overflowed (scalars built to collide): repeated on its own after the pipeline
+        else msm_finish(C, jb.J, jb.res, MsmOpt());
+        jb.done = true;
+    };
+    auto launch_job = [&](size_t c0, size_t cnt) {
+        const size_t k = jobs.size();
+        if (k >= 2 && !jobs[k - 2]->done) finish_job(*jobs[k - 2], k - 2);      // its workspace is taken over
+        std::unique_ptr<Job> jb(new Job()); jb->c0 = c0; jb->cnt = cnt; jb->pr.resize(cnt);
+        for (size_t q = 0; q < cnt; q++) jb->pr[q] = MsmProb{pts + (c0 + q) * nslots * d, scal + (c0 + q) * nslots * d};
+        C.tm.t.msm_terms += cnt * nslots * d;
+        HIPCHK(hipEventRecord(C.pool_event(3 + (k & 1)), C.stream));                 // the clients of this launch are decoded, their scalars written
+        HIPCHK(hipStreamWaitEvent(C.stream2, C.pool_event(3 + (k & 1)), 0));
+        jb->J = msm_enqueue(C, C.mws[k & 1], jb->pr, nslots * d, MsmOpt(), jb->al, C.stream2);
+        HIPCHK(hipEventRecord(C.pool_event(5 + (k & 1)), C.stream2));
+        jobs.push_back(std::move(jb));
+    };
+    size_t sg_start = 0;
     for (size_t g0 = 0, gi = 0; g0 < nc; g0 += G, gi++) {
-        const size_t gc = std::min(G, nc - g0), b = gi & 1;
+        const size_t gc = std::min(G, nc - g0), b = gi % NST;
         if (stage[0]) {
-            if (used[b]) C.wait_event(C.pool_event(b));      // the copy that read this buffer two groups ago
+            if (used[b]) C.wait_event(C.pool_event(b));      // the upload that read this buffer three groups ago
             uint8_t *sp = stage[b], *sq = stage[b] + gc * d * plen;
             const size_t sl_p = std::max<size_t>(1, (d * plen) >> 18), sl_c = std::max<size_t>(1, (d * clen) >> 18);      // ~256 KB per task
             C.pool->run(gc * (sl_p + sl_c), [&](size_t t) {
@@ -847,14 +881,18 @@ int sigma_verify_batch(int kind, size_t nc, const uint8_t *const *proofs, const 
                 if (k < sl_p) { size_t lo = d * plen * k / sl_p, hi = d * plen * (k + 1) / sl_p; stage_copy(sp + i * d * plen + lo, proofs[g0 + i] + lo, hi - lo); }
                 else { k -= sl_p; size_t lo = d * clen * k / sl_c, hi = d * clen * (k + 1) / sl_c; stage_copy(sq + i * d * clen + lo, commits[g0 + i] + lo, hi - lo); }
             });
-            HIPCHK(hipMemcpyAsync(dp + g0 * d * plen, sp, gc * d * plen, hipMemcpyHostToDevice, C.stream));
-            HIPCHK(hipMemcpyAsync(dc + g0 * d * clen, sq, gc * d * clen, hipMemcpyHostToDevice, C.stream));
-            HIPCHK(hipEventRecord(C.pool_event(b), C.stream)); used[b] = true;
+            HIPCHK(hipMemcpyAsync(dp + g0 * d * plen, sp, gc * d * plen, hipMemcpyHostToDevice, C.stream_up));
+            HIPCHK(hipMemcpyAsync(dc + g0 * d * clen, sq, gc * d * clen, hipMemcpyHostToDevice, C.stream_up));
+            HIPCHK(hipEventRecord(C.pool_event(b), C.stream_up)); used[b] = true;
+            HIPCHK(hipStreamWaitEvent(C.stream, C.pool_event(b), 0));      // this group's kernels wait for its bytes
         } else
             for (size_t i = g0; i < g0 + gc; i++) { C.up(dp + i * d * plen, proofs[i], d * plen, C.stream); C.up(dc + i * d * clen, commits[i], d * clen, C.stream); }
-        KSpan ks_sigma(C.tm, C.stream, ROFL_TK_SIGMA, (uint64_t)gc * d * (2 * npts * 265), (uint64_t)gc * d * (clen + plen));      // decoding of 2 npts points per element
-        hipLaunchKernelGGL(k_sigma_vprep, dim3((unsigned)nblk, (unsigned)gc), dim3(TPB), 0, C.stream, kind, (u32)d, dp + g0 * d * plen, dc + g0 * d * clen, init, ws, (u64)(g0 * d), wbits,
-                           pts + g0 * nslots * d, scal + g0 * nslots * d, d_fixed + g0 * nblk * 2, status + g0);
+        {   KSpan ks_sigma(C.tm, C.stream, ROFL_TK_SIGMA, (uint64_t)gc * d * (2 * npts * 265), (uint64_t)gc * d * (clen + plen));      // decoding of 2 npts points per element
+            hipLaunchKernelGGL(k_sigma_vdecode, dim3((unsigned)((nslots * d + TPB - 1) / TPB), (unsigned)gc), dim3(TPB), 0, C.stream, kind, (u32)d, dp + g0 * d * plen, dc + g0 * d * clen,
+                               pts + g0 * nslots * d, status + g0);
+            hipLaunchKernelGGL(k_sigma_vprep, dim3((unsigned)nblk, (unsigned)gc), dim3(TPB), 0, C.stream, kind, (u32)d, dp + g0 * d * plen, dc + g0 * d * clen, init, ws, (u64)(g0 * d), wbits,
+                               scal + g0 * nslots * d, d_fixed + g0 * nblk * 2, status + g0); }
+        if (g0 + gc - sg_start >= SGC || g0 + gc == nc) { launch_job(sg_start, g0 + gc - sg_start); sg_start = g0 + gc; }
     }
     smark("staged + enqueued");
     sc *h_fixed = C.h_part.as<sc>(nc * nblk * 2);
@@ -871,25 +909,23 @@ int sigma_verify_batch(int kind, size_t nc, const uint8_t *const *proofs, const 
     }
     C.sync();
     smark("decoded");
+    for (size_t k = 0; k < jobs.size(); k++) if (!jobs[k]->done) finish_job(*jobs[k], k);
+    HIPCHK(hipStreamSynchronize(C.stream2));
+    for (auto &jb : jobs) if (jb->redo) { jb->res.clear(); msm_run(C, jb->pr, nslots * d, jb->res); }
     std::vector<size_t> good;
+    std::vector<char> is_bad(nc, 0);
     for (size_t i = 0; i < nc; i++) {
-        if (h_st[i] & 4u) { if (single) { timing_end(C); return fail(ROFL_FORMAT_ERROR, "FormatError: non-canonical scalar or invalid point"); } }
+        if (h_st[i] & 4u) { is_bad[i] = 1; if (single) { timing_end(C); return fail(ROFL_FORMAT_ERROR, "FormatError: non-canonical scalar or invalid point"); } }
         else good.push_back(i);
     }
-    // every client one problem; launches of up to sixteen (the slot array of a launch grows with its problems)
-    for (size_t k0 = 0; k0 < good.size(); k0 += 16) {
-        const size_t kc = std::min<size_t>(16, good.size() - k0);
-        std::vector<MsmProb> pr(kc); std::vector<ge5> res;
-        for (size_t k = 0; k < kc; k++) pr[k] = MsmProb{pts + good[k0 + k] * nslots * d, scal + good[k0 + k] * nslots * d};
-        C.tm.t.msm_terms += kc * nslots * d;
-        msm_run(C, pr, nslots * d, res);
-        for (size_t k = 0; k < kc; k++) {
-            const size_t i = good[k0 + k];
+    for (auto &jb : jobs)
+        for (size_t q = 0; q < jb->cnt; q++) {
+            const size_t i = jb->c0 + q;
+            if (is_bad[i]) continue;      // (its problem ran with the others -- the scalars of a malformed member are still well-formed numbers -- and its result is ignored)
             sc sB = h_canon(sum_partials(h_fixed + i * nblk * 2, nblk, 2, 0)), sBb = h_canon(sum_partials(h_fixed + i * nblk * 2, nblk, 2, 1));
-            ge5 tot = h51::gadd(res[k], h51::gadd(h_fixed_mul(C.ht.B5, sB), h_fixed_mul(C.ht.Bb5, sBb)));
+            ge5 tot = h51::gadd(jb->res[q], h51::gadd(h_fixed_mul(C.ht.B5, sB), h_fixed_mul(C.ht.Bb5, sBb)));
             ok_out[i] = h51::is_identity_ristretto(tot) ? 1 : 0;
         }
-    }
     smark("msm + verdicts");
     if (h_csq) for (size_t i : good) {
         ge5 acc = h51::identity(); for (u32 k = 0; k < nb2; k++) acc = h51::gadd(acc, h51::from_ge(h_csq[i * nb2 + k]));

@@ -289,7 +289,7 @@ def test_verify_with_a_free_transcript_label(R):
     assert labelled(b"L2RangeProof", 16, proof, commit, 1, 32)[0] == 6          # InvalidGeneratorsLength
     bad = proof.copy(); bad[3] ^= 1
     assert labelled(b"L2RangeProof", 64, bad, commit, 1, 32) in ((0, 0), (5, 0))
-    vals = rng.uniform(-100, 100, 64).astype(np.float32); bl = orc.rand_scalars(rng, 64)
+    vals = rng.uniform(-0.9, 0.9, 64).astype(np.float32); bl = orc.rand_scalars(rng, 64)
     pr, cm = R.range_proof_vec.create_rangeproof(vals, bl, 8, 4, nonce=R.Nonce.seeded(b"\x12" * 32), fp=(16, 7))
     shift = R.pedersen_ops.commit_no_blinding_vec(np.frombuffer((128).to_bytes(32, "little"), np.uint8).reshape(1, 32))[0]
     V = R.pedersen_ops.compute_shifted_values_rp(cm, shift)

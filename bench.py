@@ -156,6 +156,7 @@ def cpu_baseline(sample_d, R=None):
     probe = {"cargo": shutil.which("cargo") or "absent", "reference_checkout": os.path.isdir("/root/reference/rofl_crypto"),
              "crate_registry": os.path.isdir(os.path.expanduser("~/.cargo/registry"))}
     import orc
+    build_flags = orc.use_native()      # the baseline is timed on a build made for THIS host (-O3 -march=native)
     vals, bl = synth_client(0)
     vals, bl = vals[:sample_d].copy(), bl[:sample_d].copy()
     threads = max(1, min(NPART, avail_cores()))
@@ -172,7 +173,7 @@ def cpu_baseline(sample_d, R=None):
         parity = bool(gpr.shape == pr.shape and (gpr == pr).all() and (gcm == cm).all())
         assert parity, "HIP proofs / commitments differ from the oracle on the benchmark workload"
         assert R.range_proof_vec.verify_rangeproof(pr, cm, NBITS, verifier_seed=b"\x07" * 32, fp=FP)      # the oracle's proof through the HIP verifier
-    return {"value": sample_d / dt, "unit": "elements/s", "cores": threads, "kind": "port", "parity_checked": parity,
+    return {"value": sample_d / dt, "unit": "elements/s", "cores": threads, "kind": "port", "build": "gcc " + build_flags, "parity_checked": parity,
             "parity_note": "HIP create_rangeproof on the same (values, blindings, nonce seed): all %d proofs (%d bytes each) and %d commitments bit-identical to the oracle's; "
                            "the oracle's proofs accepted by the HIP verifier" % (pr.shape[0], pr.shape[1], cm.shape[0]) if parity else None,
             "sample": f"oracle (plain-C restatement) create+verify of d={sample_d} of the workload's {D} elements, 32-bit, P={NPART}: "
@@ -291,6 +292,7 @@ def cpu_baseline_multi(cfg, R, P):
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orc
+    build_flags = orc.use_native()
     from rofl_project_code_amd import params
     threads = max(1, min(P, avail_cores()))
     os.environ.setdefault("OMP_NUM_THREADS", str(threads))
@@ -323,7 +325,7 @@ def cpu_baseline_multi(cfg, R, P):
         parity = bool((upd.range_proofs == opr).all() and (upd.square_range_proof == ol2).all() and (upd.square_proofs == osq).all() and (upd.enc_values == osqc).all()) and upd.verify(verifier_seed=b"\x07" * 32, fp=FP)
         what = "oracle L2 composite (8-bit range proof + L2 sum proof + square proofs) of d=%d of one client's %d values, P=%d: create %.1f s + verify %.1f s" % (ds, D_MULTI, P, t1 - t0, t2 - t1)
     assert parity, "HIP output differs from the oracle on the benchmark workload"
-    return {"value": ds / (t2 - t0), "unit": "elements/s", "cores": threads, "kind": "port", "parity_checked": parity, "sample": what + " on %d host threads" % threads}
+    return {"value": ds / (t2 - t0), "unit": "elements/s", "cores": threads, "kind": "port", "build": "gcc " + build_flags, "parity_checked": parity, "sample": what + " on %d host threads" % threads}
 
 
 def run_multi_client(args, R, rd, dist, cdev, world, rank, backend, comm):

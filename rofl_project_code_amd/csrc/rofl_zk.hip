@@ -474,7 +474,7 @@ int rofl_dbg_map_device(int logical, int physical) {
     if (logical < 0 || logical >= kMaxDevices || physical < 0) return ROFL_BAD_PARAM;
     devmap_init();
     std::lock_guard<std::mutex> lk(g_ctx_mu);
-    if (g_ctxs.count(logical)) return fail(ROFL_BAD_PARAM, "the device is already in use");
+    if (g_ctxs.count(logical)) return g_devmap[logical] == physical ? ROFL_OK : fail(ROFL_BAD_PARAM, "the device is already in use");      // (asking for the mapping it already has is fine)
     g_devmap[logical] = physical; return ROFL_OK;
 }
 int rofl_last_error(char *buf, size_t len) { if (!buf || !len) return ROFL_BAD_PARAM; snprintf(buf, len, "%s", g_err.c_str()); return ROFL_OK; }

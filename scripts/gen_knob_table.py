@@ -1,6 +1,6 @@
-"""The tuning-knob table of DESIGN.md, generated from the KNOBS registry in csrc/host_rt.hpp.
+"""The tuning-knob table of KNOBS.md, generated from the KNOBS registry in csrc/host_rt.hpp.
     python scripts/gen_knob_table.py          -> prints the markdown table
-    python scripts/gen_knob_table.py --write  -> rewrites the block between <!-- knobs:begin --> and <!-- knobs:end --> in DESIGN.md"""
+    python scripts/gen_knob_table.py --write  -> rewrites the block between <!-- knobs:begin --> and <!-- knobs:end --> in KNOBS.md"""
 import os
 import re
 import sys
@@ -34,7 +34,7 @@ def table():
 if __name__ == "__main__":
     t = table()
     if "--write" in sys.argv:
-        p = os.path.join(ROOT, "DESIGN.md")
+        p = os.path.join(ROOT, "KNOBS.md")
         d = open(p).read()
         a, b = d.index("<!-- knobs:begin -->") + len("<!-- knobs:begin -->"), d.index("<!-- knobs:end -->")
         open(p, "w").write(d[:a] + "\n" + t + "\n" + d[b:])

@@ -17,6 +17,21 @@ class _Nonce(ctypes.Structure):
 _lib = None
 
 
+def use_native():
+    """bench.py's cpu_baseline leg: time the -O3 -march=native build of the oracle, compiled on THIS machine (oracle/Makefile `native`).
+    Returns the flags that are in effect; falls back to the portable build (and says so) when the native one cannot be built or loaded here."""
+    global _lib, _PATH
+    native = os.path.join(_ROOT, "oracle", "liborc_native.so")
+    try:
+        subprocess.check_call(["make", "-C", os.path.join(_ROOT, "oracle"), "-B", "native"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        ctypes.CDLL(native)
+    except (subprocess.CalledProcessError, OSError):
+        return "-O2 (portable build: the native one could not be built here)"
+    if _lib is None or _PATH != native:
+        _PATH, _lib = native, None
+    return "-O3 -march=native (built on this host)"
+
+
 def lib():
     global _lib
     if _lib is None:

@@ -196,7 +196,7 @@ def test_lazily_reduced_scalar_sums_match_montgomery_products(hiplib):
 
 def test_knob_registry_is_complete_and_documented():
     """Every ROFL_* variable the library reads is registered in ONE table (csrc/host_rt.hpp: KNOBS), nothing else is read from the
-    environment, and the table of DESIGN.md is the one scripts/gen_knob_table.py generates from it."""
+    environment, and the table of KNOBS.md is the one scripts/gen_knob_table.py generates from it."""
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
     import gen_knob_table as g
     names = [k[0] for k in g.knobs()]
@@ -207,7 +207,7 @@ def test_knob_registry_is_complete_and_documented():
         src = open(os.path.join(ROOT, "rofl_project_code_amd", "csrc", f)).read()
         assert len(re.findall(r"\bgetenv\(", src)) == (1 if f == "host_rt.hpp" else 0), f      # the one inside knob()
         assert "setenv(" not in src and "putenv(" not in src
-    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    design = open(os.path.join(ROOT, "KNOBS.md")).read()
     a, b = design.index("<!-- knobs:begin -->") + len("<!-- knobs:begin -->"), design.index("<!-- knobs:end -->")
     assert design[a:b].strip() == g.table().strip(), "run: python scripts/gen_knob_table.py --write"
 

@@ -302,6 +302,8 @@ int verify_impl(Ctx &C, size_t n_clients, const uint8_t *const *proofs, size_t p
     // device pointers go straight in.
     const size_t GC = std::max<size_t>(1, std::min<size_t>(n_clients, ((size_t)1 << 19) / dp));      // ~2^19 commitments per group
     std::vector<VerifyReady> ready;
+    bool used_up = false;
+    struct JoinUp { Ctx &c; bool &used; ~JoinUp() { if (used && c.stream_up) (void)hipStreamSynchronize(c.stream_up); } } join_up{C, used_up};      // nothing of the upload stream outlives the call
     bool all_host = true; for (size_t i = 0; i < n_clients; i++) all_host &= !is_device_ptr(commits[i]);
     for (size_t i0 = 0; i0 < n_clients; i0 += GC) {
         const size_t gc = std::min(GC, n_clients - i0);
@@ -312,7 +314,13 @@ int verify_impl(Ctx &C, size_t n_clients, const uint8_t *const *proofs, size_t p
                                                      if (cstride == 32) { size_t lo = d * 32 * k / slices, hi = d * 32 * (k + 1) / slices; stage_copy(st + i * d * 32 + lo, commits[i0 + i] + lo, hi - lo); }
                                                      else { const uint8_t *src = commits[i0 + i]; uint8_t *dst = st + i * d * 32;      // gather: the staging copy is also the packing
                                                             for (size_t e = d * k / slices, e1 = d * (k + 1) / slices; e < e1; e++) memcpy(dst + e * 32, src + e * cstride, 32); } });
-            HIPCHK(hipMemcpy2DAsync(d_in + i0 * dp * 32, dp * 32, st, d * 32, d * 32, gc, hipMemcpyHostToDevice, C.stream));
+            // the upload of group g + 1 runs beside the decoding of group g (a stream of its own; the decode kernel waits for its group's bytes)
+            if (!C.stream_up) HIPCHK(hipStreamCreateWithFlags(&C.stream_up, hipStreamNonBlocking));
+            if (i0 == 0) { HIPCHK(hipEventRecord(C.pool_event(0), C.stream)); HIPCHK(hipStreamWaitEvent(C.stream_up, C.pool_event(0), 0)); }      // (after the shift upload and the status memset)
+            HIPCHK(hipMemcpy2DAsync(d_in + i0 * dp * 32, dp * 32, st, d * 32, d * 32, gc, hipMemcpyHostToDevice, C.stream_up));
+            HIPCHK(hipEventRecord(C.pool_event(1 + (ready.size() & 1)), C.stream_up));
+            HIPCHK(hipStreamWaitEvent(C.stream, C.pool_event(1 + (ready.size() & 1)), 0));
+            used_up = true;
         } else
             for (size_t i = i0; i < i0 + gc; i++) {
                 if (cstride == 32) C.up(d_in + i * dp * 32, commits[i], d * 32, C.stream);
@@ -324,7 +332,7 @@ int verify_impl(Ctx &C, size_t n_clients, const uint8_t *const *proofs, size_t p
           hipLaunchKernelGGL(k_decode, grid1(dp, (u32)gc), dim3(TPB), 0, C.stream, (u32)dp, (u32)d, d_in + i0 * dp * 32, d_shift, d_vn + i0 * dp, d_enc + i0 * dp * 32, status + i0); }
         HIPCHK(hipMemcpyAsync(hV + i0 * dp * 32, d_enc + i0 * dp * 32, gc * dp * 32, hipMemcpyDeviceToHost, C.stream));
         HIPCHK(hipMemcpyAsync(h_st + i0, status + i0, 4 * gc, hipMemcpyDeviceToHost, C.stream));
-        ready.push_back(VerifyReady{(i0 + gc) * nv, C.pool_event(ready.size())});
+        ready.push_back(VerifyReady{(i0 + gc) * nv, C.pool_event(3 + ready.size())});      // (events 0..2 of the call: the upload stream's)
         HIPCHK(hipEventRecord(ready.back().ev, C.stream));
     }
     // flatten (client, chunk) -> problem list.  A client's verified chunks are a prefix of its dp commitments: when the proofs cover

@@ -588,6 +588,8 @@ def run_rank(args):
         # once when the runtime initialises.  Set here, by the host program -- the library itself leaves the environment alone.
         os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(4, CIF + 2)))
 
+    if world > 1 and os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost", "::1"):
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")      # one node: RCCL's bootstrap over loopback (the container hostname may not resolve)
     if os.environ.get("ROFL_BENCH_DRYRUN"):
         return dry_run(args, world, rank)
     import numpy as np

@@ -287,7 +287,7 @@ int rofl_comm_destroy(void);
  *   "blocking_sync"        -1 (default): spin while at most three calls are in flight, sleep between polls beyond that; 0: always spin;
  *                          1: always sleep (one host core per waiting call is not burned; ~50 us more latency per wait)
  * rofl_get_option also answers the read-only key "lanes": the calls that can be in flight on the calling thread's device (ROFL_LANES).
- * The remaining ROFL_* environment variables are tuning knobs that never change results ("Tuning knobs"). */
+ * The remaining ROFL_* environment variables are tuning knobs that never change results (KNOBS.md). */
 int rofl_set_option(const char *key, long value);
 int rofl_get_option(const char *key, long *value_out);
 

@@ -7,7 +7,7 @@
 // Limb bounds ("tight": even limbs < 2^26 + 2^19, odd limbs < 2^25 + 2^19):
 //   fd_mul / fd_sq / fd_carry / fd_unpack outputs are tight;
 //   fd_add: no carry;  fd_sub(a, b) = a + 2p - b needs b tight;
-//   fd_mul(f, g) needs f < 2^28 and g < 2^27.75 limb-wise (accumulators stay below 2^64: see DESIGN.md section 5).
+//   fd_mul(f, g) needs f < 2^28 and g < 2^27.75 limb-wise (accumulators stay below 2^64: see DESIGN.md section 3, item 8).
 #pragma once
 #include "fe32.hpp"
 #if defined(ROFL_FD_CHECK_HOST) && !defined(__HIP_DEVICE_COMPILE__)

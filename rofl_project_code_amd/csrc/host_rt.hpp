@@ -3,10 +3,10 @@
 #pragma once
 
 // ---------------------------------------------------------------- tuning knobs
-// Every ROFL_* environment variable the library reads, in ONE table (scripts/gen_knob_table.py turns it into the table of DESIGN.md and
+// Every ROFL_* environment variable the library reads, in ONE table (scripts/gen_knob_table.py turns it into the table of KNOBS.md and
 // tests/test_host_lib.py checks that no other name is read).  Knobs never change results -- proofs, commitments and verdicts are the same
 // for every setting (the behaviour switches of rofl_set_option are the exception and are marked "option") -- they move work between
-// variants, and most of them exist because an experiment in DESIGN.md needed them.  Read once per process (or per device context).
+// variants, and most of them exist because an experiment in profiles/r0*_experiments.txt needed them.  Read once per process (or per device context).
 struct Knob { const char *name, *dflt, *what; };
 static const Knob KNOBS[] = {
     {"ROFL_LANES", "3", "calls that can be in flight on a device (HIP stream + workspace each); 1..16, larger values are clamped (with a note on stderr)"},
@@ -19,6 +19,7 @@ static const Knob KNOBS[] = {
     {"ROFL_VERIFY_ZIP_TRUNCATE", "0", "option verify_zip_truncate: 1 = the reference's zip-truncating verify_rangeproof"},
     {"ROFL_VERIFY_BATCH", "1", "option verify_batch: 0 = one check per proof, 1 = one per client, 2 = one per batch of clients (bisecting down to per-client checks on failure)"},
     {"ROFL_SIGMA_BATCH", "1", "option sigma_batch: 0 = one check per element in the Sigma-proof verifiers"},
+    {"ROFL_STAGE_COHERENT", "0", "1 = the staging arenas are coherent (hipHostMallocDefault) pinned memory as in rounds 3-4 instead of non-coherent (the DMA engine reads 32 instead of 57 GB/s out of it)"},
     {"ROFL_STAGE_KEEP_MB", "256", "pinned staging memory a lane keeps between calls (a call that needed more frees it when it ends)"},
     {"ROFL_GENS_LAZY", "1", "0 = the first call of a shape waits for its full fold table (otherwise it is served from the compact table while a background thread builds the full one)"},
     {"ROFL_GENS_LAZY_IDLE_MS", "20", "the background build of a full fold table starts when no call has been in flight for this long (its allocation stalls every HIP call of the process)"},
@@ -341,12 +342,12 @@ struct Stage {
     static constexpr size_t kMin = 32 << 10;      // below this the runtime's own bounce buffers do the same job
     // The arena is only ever the source or destination of copies (no kernel reads it): non-coherent pinned memory.  The DMA engine moves
     // 57 GB/s out of it against 32 GB/s out of the default (coherent, fine-grained) flavour on this platform (scripts/stage_bw.hip).
-    static constexpr unsigned kFlags = hipHostMallocNonCoherent;
+    static unsigned flags() { static const unsigned f = (knob("ROFL_STAGE_COHERENT") && atoi(knob("ROFL_STAGE_COHERENT")) != 0) ? hipHostMallocDefault : hipHostMallocNonCoherent; return f; }
     void *alloc(size_t n) {
         n = (n + 255) & ~(size_t)255; dirty = true;
         for (auto &c : chunks) if (c.cap - c.used >= n) { void *r = (char *)c.p + c.used; c.used += n; return r; }
         Chunk c; c.cap = std::max<size_t>(n, (size_t)4 << 20);      // never moves or frees a chunk that copies in flight may still use
-        HIPCHK(hipHostMalloc(&c.p, c.cap, kFlags));
+        HIPCHK(hipHostMalloc(&c.p, c.cap, flags()));
         c.used = n; chunks.push_back(c); return c.p;
     }
     // after the call's last synchronisation: hand the results over, recycle the arena (several chunks -> one of their total size next time)
@@ -360,7 +361,7 @@ struct Stage {
         if (tot > keep || chunks.size() > 1) {
             for (auto &c : chunks) (void)hipHostFree(c.p);
             chunks.clear();
-            if (tot <= keep) { Chunk c; c.cap = tot; if (hipHostMalloc(&c.p, c.cap, kFlags) == hipSuccess) chunks.push_back(c); }
+            if (tot <= keep) { Chunk c; c.cap = tot; if (hipHostMalloc(&c.p, c.cap, flags()) == hipSuccess) chunks.push_back(c); }
         }
         for (auto &c : chunks) c.used = 0;
         dirty = false;

@@ -314,13 +314,16 @@ int verify_impl(Ctx &C, size_t n_clients, const uint8_t *const *proofs, size_t p
                                                      if (cstride == 32) { size_t lo = d * 32 * k / slices, hi = d * 32 * (k + 1) / slices; stage_copy(st + i * d * 32 + lo, commits[i0 + i] + lo, hi - lo); }
                                                      else { const uint8_t *src = commits[i0 + i]; uint8_t *dst = st + i * d * 32;      // gather: the staging copy is also the packing
                                                             for (size_t e = d * k / slices, e1 = d * (k + 1) / slices; e < e1; e++) memcpy(dst + e * 32, src + e * cstride, 32); } });
-            // the upload of group g + 1 runs beside the decoding of group g (a stream of its own; the decode kernel waits for its group's bytes)
-            if (!C.stream_up) HIPCHK(hipStreamCreateWithFlags(&C.stream_up, hipStreamNonBlocking));
-            if (i0 == 0) { HIPCHK(hipEventRecord(C.pool_event(0), C.stream)); HIPCHK(hipStreamWaitEvent(C.stream_up, C.pool_event(0), 0)); }      // (after the shift upload and the status memset)
-            HIPCHK(hipMemcpy2DAsync(d_in + i0 * dp * 32, dp * 32, st, d * 32, d * 32, gc, hipMemcpyHostToDevice, C.stream_up));
-            HIPCHK(hipEventRecord(C.pool_event(1 + (ready.size() & 1)), C.stream_up));
-            HIPCHK(hipStreamWaitEvent(C.stream, C.pool_event(1 + (ready.size() & 1)), 0));
-            used_up = true;
+            if (n_clients > GC) {
+                // several groups: the upload of group g + 1 runs beside the decoding of group g (a stream of its own; the decode kernel waits for its group's bytes)
+                if (!C.stream_up) HIPCHK(hipStreamCreateWithFlags(&C.stream_up, hipStreamNonBlocking));
+                if (i0 == 0) { HIPCHK(hipEventRecord(C.pool_event(0), C.stream)); HIPCHK(hipStreamWaitEvent(C.stream_up, C.pool_event(0), 0)); }      // (after the shift upload and the status memset)
+                HIPCHK(hipMemcpy2DAsync(d_in + i0 * dp * 32, dp * 32, st, d * 32, d * 32, gc, hipMemcpyHostToDevice, C.stream_up));
+                HIPCHK(hipEventRecord(C.pool_event(1 + (ready.size() & 1)), C.stream_up));
+                HIPCHK(hipStreamWaitEvent(C.stream, C.pool_event(1 + (ready.size() & 1)), 0));
+                used_up = true;
+            } else      // one group (a single client: the latency case): no second stream, no events
+                HIPCHK(hipMemcpy2DAsync(d_in + i0 * dp * 32, dp * 32, st, d * 32, d * 32, gc, hipMemcpyHostToDevice, C.stream));
         } else
             for (size_t i = i0; i < i0 + gc; i++) {
                 if (cstride == 32) C.up(d_in + i * dp * 32, commits[i], d * 32, C.stream);

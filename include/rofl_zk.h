@@ -167,7 +167,7 @@ int rofl_verify_squarerandproof_vec(const uint8_t *proofs, const uint8_t *commit
  * ok_out[i] is client i's verdict exactly as the per-client call gives it; a member with a non-canonical scalar or an undecodable point
  * gets ok = 0 and the others are still verified.  csq_sum_out32 (may be NULL; n_clients * 32 bytes): sum_i c_sq_i of every client,
  * compressed -- the commitment of the client's L2 sum proof (params.rs:220, 277), a by-product of decoding (zero bytes = the identity for
- * a malformed member). */
+ * a malformed member).  With rofl_set_option("devices", mask) the clients are dealt round-robin to the listed devices. */
 int rofl_verify_randproof_vec_batch(size_t n_clients, const uint8_t *const *proofs, const uint8_t *const *commits, size_t d, int *ok_out);
 int rofl_verify_squarerandproof_vec_batch(size_t n_clients, const uint8_t *const *proofs, const uint8_t *const *commits, size_t d,
                                           int *ok_out, uint8_t *csq_sum_out32);

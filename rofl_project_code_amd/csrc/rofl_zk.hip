@@ -1081,7 +1081,18 @@ int rofl_verify_squarerandproof_vec(const uint8_t *proofs, const uint8_t *commit
 namespace {
 int sigma_batch_entry(int kind, size_t n_clients, const uint8_t *const *proofs, const uint8_t *const *commits, size_t d, int *ok_out, uint8_t *csq_sum_out32) {
     if (!ok_out || (n_clients && (!proofs || !commits))) return fail(ROFL_BAD_PARAM, "bad parameter");
-    return guarded([&]() -> int { return sigma_verify_batch(kind, n_clients, proofs, commits, d, ok_out, csq_sum_out32, false); });
+    std::vector<int> devs = batch_devices();      // rofl_set_option("devices", mask): the clients are dealt round-robin to the listed devices, as in the range-proof batch calls
+    if (devs.empty() || n_clients < 2)
+        return guarded([&]() -> int { std::unique_ptr<DeviceBinding> bind; if (!devs.empty()) bind.reset(new DeviceBinding(devs[0]));
+            return sigma_verify_batch(kind, n_clients, proofs, commits, d, ok_out, csq_sum_out32, false); });
+    for (size_t i = 0; i < n_clients; i++) ok_out[i] = 0;
+    return guarded([&]() -> int { return shard_over_devices(n_clients, devs, [&](const std::vector<size_t> &idx) -> int {
+        const size_t k = idx.size();
+        std::vector<const uint8_t *> p(k), c(k); std::vector<int> ok(k, 0); std::vector<uint8_t> sums(csq_sum_out32 ? 32 * k : 0);
+        for (size_t j = 0; j < k; j++) { p[j] = proofs[idx[j]]; c[j] = commits[idx[j]]; }
+        int r = sigma_verify_batch(kind, k, p.data(), c.data(), d, ok.data(), csq_sum_out32 ? sums.data() : nullptr, false);
+        for (size_t j = 0; j < k; j++) { ok_out[idx[j]] = ok[j]; if (csq_sum_out32) memcpy(csq_sum_out32 + 32 * idx[j], &sums[32 * j], 32); }
+        return r; }); });
 }
 }  // namespace
 int rofl_verify_randproof_vec_batch(size_t n_clients, const uint8_t *const *proofs, const uint8_t *const *commits, size_t d, int *ok_out) {

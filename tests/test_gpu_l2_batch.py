@@ -175,3 +175,26 @@ def test_encrypt_batch_is_byte_identical_to_single_encrypts(R):
         one = R.EncParamsL2.encrypt(cl[i][0], cl[i][1], nb, P, l2n, nonce_seed=seeds[i], rand_scalars=cl[i][2], fp=FP)
         assert got[i].serialize() == one.serialize(), i
     assert R.EncParamsL2.verify_batch(got, verifier_seed=b"\x02" * 32, fp=FP) == [True] * n
+
+
+def test_l2_round_over_two_logical_devices(R):
+    """One server process, two devices (rofl_set_option("devices", 0b11); both logical devices are GPU 0 on the test box): the square-proof batch and
+    the range legs of a round are dealt to the devices inside the library; verdicts and the sums of c_sq are those of the one-device call."""
+    from rofl_project_code_amd import api
+    api.map_device(1, 0)
+    d, nb, P, l2n, n = 900, 8, 4, 32, 6
+    ups = [_client(R, 800 + i, d, nb, P, l2n) for i in range(n)]
+    t = [_copy(R, u) for u in ups]
+    t[1].square_proofs[17, 5] ^= 1; t[4].range_proofs[0, 40] ^= 1
+    seed = b"\x44" * 32
+    try:
+        R.set_option("verify_batch", 2)
+        one = R.EncParamsL2.verify_batch(t, verifier_seed=seed, fp=FP)
+        ok1, s1 = R.square_rand_proof_vec.verify_l2rangeproof_vec_batch([u.square_proofs for u in ups], [u.enc_values for u in ups], with_csq_sums=True)
+        R.set_option("devices", 0b11)
+        two = R.EncParamsL2.verify_batch(t, verifier_seed=seed, fp=FP)
+        ok2, s2 = R.square_rand_proof_vec.verify_l2rangeproof_vec_batch([u.square_proofs for u in ups], [u.enc_values for u in ups], with_csq_sums=True)
+        assert one == two == [True, False, True, True, False, True]
+        assert ok1 == ok2 == [True] * n and (s1 == s2).all()
+    finally:
+        R.set_option("devices", 0); R.set_option("verify_batch", 1)

@@ -52,6 +52,21 @@ while time.time() < t_end:
         upd = params.EncParamsL2.encrypt(v2, b2, 8, 4, 32, nonce_seed=bytes([it % 250 + 1]) * 32, rand_scalars=rs, fp=(32, 7))
         assert params.EncParamsL2.deserialize(upd.serialize()).verify(fp=(32, 7))
         calls += 2
+    if it % 13 == 0:     # round 5: a round of L2 updates through encrypt_batch / verify_batch (three streams, two MSM workspaces, staging ring), one member tampered
+        cl = []
+        for k in range(5):
+            v2, b2 = inputs(9000 + it + k, 2000, 8, (32, 7)); v2 = (np.round(v2 * 128) / 128 / 64).astype(np.float32)
+            rs = np.random.default_rng(it + k).integers(0, 256, size=(2000, 32), dtype=np.uint8); rs[:, 31] &= 0x0F
+            cl.append((v2, b2, rs))
+        ups = params.EncParamsL2.encrypt_batch(cl, 8, 4, 32, nonce_seeds=[bytes([k + 1]) * 32 for k in range(5)], fp=(32, 7))
+        blobs = [u.serialize(as_array=True) for u in ups]
+        U = [params.EncParamsL2.deserialize(b, copy=False) for b in blobs]
+        U[3] = params.EncParamsL2.deserialize(blobs[3]); U[3].square_proofs[7, 70] ^= 1
+        for vb in (2, 1):
+            R.set_option("verify_batch", vb)
+            assert params.EncParamsL2.verify_batch(U, fp=(32, 7)) == [True, True, True, False, True]
+        R.set_option("verify_batch", 1)
+        calls += 8
     if it % 50 == 0:
         samples.append({"iteration": it, "calls": calls, "rss_mb": round(proc.memory_info().rss / 2 ** 20, 1), "device_free_mb": round(dev_free_mb(), 1)})
     it += 1

@@ -167,7 +167,8 @@ def make_comm(rank, world, device, control_group=None, prefer_lib=True, torch_ba
     cpu = torch.device("cpu")
     if prefer_lib:      # every rank must be able to load librccl before anyone enters ncclCommInitRank (a rank that never arrives would hang the rest)
         try:
-            LibComm_info = __import__("rofl_project_code_amd.api", fromlist=["comm"]).comm.info(); can = 1
+            from . import api
+            api.comm.info(); can = 1      # loads librccl (ROFL_RCCL_LIB); raises when it cannot be loaded
         except Exception as e:      # noqa: BLE001
             can = 0
             if log: log("librccl not usable on rank %d: %r" % (rank, e))

@@ -63,3 +63,42 @@ def test_two_rank_gloo():
         p.join(180)
         assert p.exitcode == 0
     assert sorted(q.get() for _ in range(2)) == [0, 1]
+
+
+def _comm_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    from rofl_project_code_amd import dist as rd
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    notes = []
+    # no GPU here: the ranks AGREE (over the gloo control group) that the library's RCCL communicator cannot be formed -- rank 0 cannot draw a
+    # unique id -- and every rank ends up on the same fallback; nobody is left waiting inside ncclCommInitRank
+    comm = rd.make_comm(rank, world, torch.device("cpu"), prefer_lib=True, torch_backend="gloo", log=notes.append)
+    assert isinstance(comm, rd.TorchComm) and comm.backend == "gloo" and comm.world == world and comm.rank == rank
+    ok, per = comm.exchange_round([np.full(40, rank, np.uint8), np.arange(5, dtype=np.uint8) + rank], rank == 0)
+    assert ok is False and [int(p[0][0]) for p in per] == list(range(world)) and [int(p[1][4]) for p in per] == [4 + r for r in range(world)]
+    assert comm.all_verified(True) is True and comm.all_verified(rank != 1) is False
+    assert comm.reduce([float(rank + 1), 10.0], "sum").tolist() == [3.0, 20.0] and comm.reduce([float(rank)], "max")[0] == 1.0 and comm.reduce([float(rank)], "min")[0] == 0.0
+    comm.barrier(); comm.close()
+    one = rd.make_comm(0, 1, torch.device("cpu"))
+    assert isinstance(one, rd.LocalComm) and one.exchange_round([np.zeros(3, np.uint8)], True)[0] is True and one.reduce([2.0], "max")[0] == 2.0
+    dist.barrier(); dist.destroy_process_group()
+    q.put((rank, bool(notes) if rank == 0 else True))
+
+
+def test_communicator_choice_is_agreed_across_ranks():
+    """rofl_project_code_amd.dist.make_comm: LibComm (the library's RCCL) when every rank can form it, otherwise ONE fallback for all ranks.
+    On the CPU rank 0 cannot draw the unique id; both ranks must land on TorchComm(gloo) and run the round's collectives there."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_comm_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    got = sorted(q.get() for _ in range(2))
+    assert got == [(0, True), (1, True)]      # (rank 0 logged why the library's communicator was not used)

@@ -400,13 +400,28 @@ void msm_finish(Ctx &C, const MsmJob &J, std::vector<ge5> &results, const MsmOpt
             }
             results[p] = acc;
         };
-        if (opt.post8 && np >= 32 && h8::available()) {
-            // many problems (n_partition = 64: 128 per round): eight per task, finished together -- eight encodings per AVX-512 stream and the
-            // four challenge inversions of the task's chunks behind one inversion, as the generic launches do
+        static const size_t fb8_min = knob("ROFL_MSM_FB_HOST8_MIN") ? (size_t)std::max(1L, atol(knob("ROFL_MSM_FB_HOST8_MIN"))) : 8;
+        if (opt.post8 && np >= fb8_min && h8::available() && sets * (nb + 1) <= 64) {
+            // From eight problems on (the L / R problems of a four-chunk client: ONE task, on the calling thread, no pool hand-off; n_partition = 64:
+            // sixteen tasks): eight problems per AVX-512 IFMA stream, finished together -- the bit-sum chains (the sets' sums and bit-sums as
+            // "windows" that share positions: sum_l 2^l sum_s D[s][l] + sum_s S[s]), eight encodings per stream and the four challenge inversions
+            // of the task's chunks behind one inversion, as the generic launches do.  (Rounds 3-4 ran eight scalar chains on eight pool threads
+            // here below 32 problems: ~0.1 ms per hop against ~0.05.)
+            const int Wn = (int)(sets * (nb + 1));
+            u32 pos[64];
+            for (u32 s = 0; s < sets; s++) pos[s] = 0;
+            for (u32 l = 0; l < nb; l++) for (u32 s = 0; s < sets; s++) pos[sets + l * sets + s] = l;
             C.pool->run((np + 7) / 8, [&](size_t b) {
                 double tc0 = now_ms();
                 size_t p0 = b * 8; int cnt = (int)std::min<size_t>(8, np - p0);
-                for (int l = 0; l < cnt; l++) fb_one(p0 + (size_t)l);
+                ge5 out[8];
+                h8::horner8(out, cnt, Wn, pos, [&](int l, int w) {
+                    const size_t base = (p0 + (size_t)l) * sets;
+                    if ((u32)w < sets) return (const ge *)&h[base + (size_t)w];
+                    const u32 lv = ((u32)w - sets) / sets, s = ((u32)w - sets) % sets;
+                    return (const ge *)&h[PW + (base + s) * nb + lv];
+                });
+                for (int l = 0; l < cnt; l++) results[p0 + (size_t)l] = out[l];
                 opt.post8(p0, cnt);
                 cpu_each[p0] = now_ms() - tc0;
             });

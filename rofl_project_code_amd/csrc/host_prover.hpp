@@ -187,6 +187,7 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
         HIPCHK(hipMemcpyAsync(d_q, h_q, sizeof(niels) * P, hipMemcpyHostToDevice, C.stream));
     }
     bool ip_included = false, pts_pending = false;
+    std::vector<ge5> cq;      // per round: c_L w B, c_R w B of every chunk, computed while the round's MSM runs
     for (unsigned round = 0; round < lgN; round++) {
         size_t n_k = n_g >> r, nh = n_k / 2;
         sc *SL = C.SL.as<sc>(P * 2 * n_g), *SR = C.SR.as<sc>(P * 2 * n_g);
@@ -208,6 +209,12 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
             hipLaunchKernelGGL(k_ipp_inner, dim3(nblkI, (u32)P), dim3(TPB), 0, C.stream, (u32)nh, a, b, N, C.h_ip.dev<sc>(P * 256 * 2));
         }
         just_materialised = false;
+        // <a_L, b_R> w B and <a_R, b_L> w B of the launches that do not add them on the device (everything but the fused small launch): the partial
+        // inner products are in mapped host memory as soon as the round's first kernel has run, long before its MSM has -- the host computes the
+        // 2P fixed-base multiples while the device works (they were 6 us each on the hop: eight in a row where one task finishes eight problems)
+        if (!C.ev_ip) HIPCHK(hipEventCreateWithFlags(&C.ev_ip, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(C.ev_ip, C.stream));
+        bool cq_ready = false;
         std::vector<MsmProb> pr(2 * P);
         for (size_t c = 0; c < P; c++) { pr[2 * c] = MsmProb{cur[c], SL + c * 2 * n_g}; pr[2 * c + 1] = MsmProb{cur[c], (merged ? SL : SR) + c * 2 * n_g}; }
         C.tm.t.msm_terms += P * 2 * n_g;
@@ -221,10 +228,19 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
         // and encodes L (R); the second of a chunk's two to get there hashes both into the transcript, draws u and inverts it.  L and R
         // of a chunk are encoded side by side and the hop has one pool hand-off instead of two.
         for (size_t c = 0; c < P; c++) lr_done[c].store(0);
+        mo.overlap = [&]() {      // (after the launches are queued, before the wait: ip_included is known)
+            static const bool cq_on = !(knob("ROFL_HOP_CQ") && atoi(knob("ROFL_HOP_CQ")) == 0);
+            if (ip_included || !cq_on) return;
+            C.wait_event(C.ev_ip);
+            cq.resize(2 * P);
+            C.pool->run(2 * P, [&](size_t p) { sc cx = h_canon(sum_partials(h_ip + (p >> 1) * nblkI * 2, nblkI, 2, p & 1)); cq[p] = h_fixed_mul(C.ht.B5, h_mul(cx, w[p >> 1])); });
+            cq_ready = true;
+        };
         mo.post = [&](size_t p) {
             size_t c = p >> 1; int side = (int)(p & 1);
             uint8_t *o = proofs_out[c] + 7 * 32 + 64 * round;
             if (ip_included) h51::encode(o + 32 * side, res[p]);
+            else if (cq_ready) h51::encode(o + 32 * side, h51::gadd(res[p], cq[p]));
             else {
                 sc cx = h_canon(sum_partials(h_ip + c * nblkI * 2, nblkI, 2, (size_t)side));
                 h51::encode(o + 32 * side, h51::gadd(res[p], h_fixed_mul(C.ht.B5, h_mul(cx, w[c]))));
@@ -246,6 +262,7 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
                 if (l >= cnt) { pts[l] = h51::identity(); continue; }
                 size_t p = p0 + (size_t)l, c = p >> 1;
                 if (ip_included) { pts[l] = res[p]; continue; }
+                if (cq_ready) { pts[l] = h51::gadd(res[p], cq[p]); continue; }
                 sc cx = h_canon(sum_partials(h_ip + c * nblkI * 2, nblkI, 2, p & 1));
                 pts[l] = h51::gadd(res[p], h_fixed_mul(C.ht.B5, h_mul(cx, w[c])));
             }

@@ -57,6 +57,8 @@ static const Knob KNOBS[] = {
     {"ROFL_MERLIN_X8", "1", "0 = the verifier hashes every chunk's transcript prefix on its own even when the host has AVX-512 (eight chunks per instruction stream otherwise, from 32 chunks on)"},
     {"ROFL_MSM_HOST8", "1", "0 = launches with many problems combine their windows on the device (k_msm_horner) even when the host has AVX-512 IFMA"},
     {"ROFL_MSM_HOST8_MIN", "8", "launches with at least this many problems run their window chains eight per AVX-512 IFMA stream on the host (when the CPU has it)"},
+    {"ROFL_MSM_FB_HOST8_MIN", "8", "fixed-base launches with at least this many problems finish eight problems per AVX-512 IFMA task (32 = as in rounds 3-4: one scalar chain per pool task below 32 problems)"},
+    {"ROFL_HOP_CQ", "1", "0 = the <a,b> w B terms of a round are computed on the hop (after the wait) instead of on the pool while the round's MSM runs"},
     {"ROFL_MSM_DEV_HORNER_MIN", "32", "launches with at least this many problems combine their windows on the device"},
     {"ROFL_MSM_T13", "8192", "generic MSMs from this many terms on use 13-bit windows"},
     {"ROFL_MSM_T10", "512 / 2048", "generic MSMs from this many terms on use 10-bit windows (7-bit below, 4-bit below 64); default 2048 for launches with >= 32 problems"},
@@ -520,7 +522,7 @@ struct Ctx {
     // Waiting for the lane's stream.  hipStreamSynchronize spins (lowest latency: right for a call that is alone on the device); with
     // more than three calls in flight -- or when the host asked for it (ROFL_BLOCKING_SYNC=1) -- the thread sleeps between queries instead, so
     // a server that keeps several clients in flight does not burn one host core per client on busy-waiting (ROFL_BLOCKING_SYNC=0: always spin).
-    hipEvent_t ev_block = nullptr, ev_v = nullptr, ev_fork = nullptr, ev_a = nullptr, ev_a0 = nullptr, ev_m2 = nullptr, ev_m2j = nullptr, ev_norm = nullptr, ev_norm0 = nullptr; bool batch_mode = false;
+    hipEvent_t ev_block = nullptr, ev_v = nullptr, ev_fork = nullptr, ev_a = nullptr, ev_a0 = nullptr, ev_m2 = nullptr, ev_m2j = nullptr, ev_norm = nullptr, ev_norm0 = nullptr, ev_ip = nullptr; bool batch_mode = false;
     void sync() {
         const Ctx *P = parent ? parent : this;
         // (up to three calls in flight still spin: the three proofs of ONE client's L2 update run side by side -- EncParamsL2::encrypt --

@@ -98,6 +98,10 @@ int rofl_dbg_host_encode8_selftest(unsigned batches, double *us_simd, double *us
  * `lanes` transcripts, `count` commitments each, `skew` extra prefix bytes (moves the records across the rate block): 0 = states and the
  * next challenge agree, 1 = mismatch, -1 = no AVX-512 on this CPU */
 int rofl_dbg_host_merlin8_selftest(int lanes, unsigned count, unsigned skew, double *us_simd, double *us_scalar);
+/* csrc/keccak.hpp keccak_f1600_zmm (ONE Keccak-f[1600] state across five AVX-512 registers: what every host transcript runs where the CPU has
+ * it) against the scalar permutation: `states` pseudo-random states permuted `chain` times each, and the known answer of the zero state.
+ * 0 = all equal, 1 = mismatch, -1 = no AVX-512 on this CPU; ns per permutation of both on request */
+int rofl_dbg_host_keccak_zmm_selftest(unsigned states, unsigned chain, double *ns_zmm, double *ns_scalar);
 /* host share of the hops of the calling thread's last create / verify: out[0] hops, [1] enqueue ms, [2] wait ms, [3] window-combination wall ms,
  * [4] sum of each hop's slowest pool task ms, [5..8] the maxima over the hops of enqueue, wait, combination wall, slowest task */
 int rofl_dbg_last_hops(double out[10]);

@@ -1742,6 +1742,30 @@ int rofl_dbg_host_encode8_selftest(unsigned batches, double *us_simd, double *us
 // k8::append32_run_x8 against Merlin::append32_run: `lanes` transcripts that have absorbed the same prefix, `count` commitments each, from every
 // starting position of the rate block (`skew` extra prefix bytes shift it); the challenge drawn afterwards must agree.  0 = equal, 1 = mismatch,
 // -1 = no AVX-512.  Timings: microseconds for all lanes together.
+// keccak_f1600_zmm (one state across AVX-512 registers) against the scalar permutation on `states` pseudo-random states, chained `chain` deep,
+// plus the known answer of the all-zero state.  0 = all equal, 1 = mismatch, -1 = no AVX-512 on this CPU.
+int rofl_dbg_host_keccak_zmm_selftest(unsigned states, unsigned chain, double *ns_zmm, double *ns_scalar) {
+    if (!__builtin_cpu_supports("avx512f")) return -1;
+    if (!states || !chain) return ROFL_BAD_PARAM;
+    int bad = 0;
+    { u64 z[25] = {0}; keccak_f1600_zmm(z); bad |= z[0] != 0xF1258F7940E1DDE7ULL || z[24] != 0xEAF1FF7B5CECA249ULL; }
+    u64 x = 0x9e3779b97f4a7c15ULL;
+    double tz = 0, ts = 0;
+    for (unsigned i = 0; i < states; i++) {
+        u64 a[25], b[25];
+        for (int k = 0; k < 25; k++) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; a[k] = b[k] = (i % 5 == 4 && k % 3 == 0) ? 0 : x; }
+        double t0 = now_ms();
+        for (unsigned c = 0; c < chain; c++) keccak_f1600_zmm(a);
+        double t1 = now_ms();
+        for (unsigned c = 0; c < chain; c++) keccak_f1600_host(b);
+        double t2 = now_ms();
+        tz += t1 - t0; ts += t2 - t1;
+        bad |= memcmp(a, b, sizeof a) != 0;
+    }
+    if (ns_zmm) *ns_zmm = tz * 1e6 / ((double)states * chain);
+    if (ns_scalar) *ns_scalar = ts * 1e6 / ((double)states * chain);
+    return bad;
+}
 int rofl_dbg_host_merlin8_selftest(int lanes, unsigned count, unsigned skew, double *us_simd, double *us_scalar) {
     if (!k8::available()) return -1;
     if (lanes < 1 || lanes > 8 || skew > 400) return ROFL_BAD_PARAM;

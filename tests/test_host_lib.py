@@ -324,6 +324,21 @@ def test_simd_transcripts_match_the_scalar_ones(hiplib):
     assert L.rofl_dbg_host_merlin8_selftest(0, 8, 0, None, None) == 11
 
 
+def test_keccak_across_avx512_registers_matches_the_scalar_rounds(hiplib):
+    """csrc/keccak.hpp keccak_f1600_zmm -- one Keccak-f[1600] state in five AVX-512 registers, what host transcripts run on hosts where a
+    start-up measurement finds it faster -- against the scalar rounds: the zero state's known answer, pseudo-random and sparse states,
+    chains of permutations.  Skipped on a CPU without AVX-512."""
+    L = hiplib
+    L.rofl_dbg_host_keccak_zmm_selftest.argtypes = [ctypes.c_uint, ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p]
+    rc = L.rofl_dbg_host_keccak_zmm_selftest(1, 1, None, None)
+    if rc == -1:
+        pytest.skip("no AVX-512 on this CPU")
+    assert rc == 0
+    assert L.rofl_dbg_host_keccak_zmm_selftest(500, 1, None, None) == 0
+    assert L.rofl_dbg_host_keccak_zmm_selftest(20, 300, None, None) == 0
+    assert L.rofl_dbg_host_keccak_zmm_selftest(0, 1, None, None) == 11
+
+
 def test_sharded_batch_reports_a_device_that_cannot_be_used(hiplib):
     """rofl_set_option("devices", mask) with devices that do not exist (logical 9 and 10; no GPU at all in the build container): the batch
     entry points come back with the HIP error of the failing share -- no crash, no hang, the message on the CALLER's thread -- and the

@@ -98,6 +98,9 @@ int rofl_dbg_host_encode8_selftest(unsigned batches, double *us_simd, double *us
  * `lanes` transcripts, `count` commitments each, `skew` extra prefix bytes (moves the records across the rate block): 0 = states and the
  * next challenge agree, 1 = mismatch, -1 = no AVX-512 on this CPU */
 int rofl_dbg_host_merlin8_selftest(int lanes, unsigned count, unsigned skew, double *us_simd, double *us_scalar);
+/* Merlin::append32_run (the run of m commitment appends of a chunk, records assembled in registers and split at the end of the rate block)
+ * against `count` plain appends after `skew` (<= 400) extra prefix bytes: 0 = state, positions and next challenge equal, 1 = mismatch */
+int rofl_dbg_host_merlin_run_selftest(unsigned count, unsigned skew);
 /* csrc/keccak.hpp keccak_f1600_zmm (ONE Keccak-f[1600] state across five AVX-512 registers: what every host transcript runs where the CPU has
  * it) against the scalar permutation: `states` pseudo-random states permuted `chain` times each, and the known answer of the zero state.
  * 0 = all equal, 1 = mismatch, -1 = no AVX-512 on this CPU; ns per permutation of both on request */

@@ -60,6 +60,7 @@ int verify_chunks(Ctx &C, const char *label, size_t gens_capacity, size_t P, siz
     std::vector<char> dead(P, 0);
     if (N != ((size_t)1 << lg)) return ROFL_OK;    // VerificationError for every chunk
     GensPin gens = get_gens(C, n, m);
+    vmark("gens");
     niels *tbl = gens.tbl();
     const niels *wtab = gens.wtab();
     ChunkParams *h_cp = C.h_cp.as<ChunkParams>(P);
@@ -83,7 +84,9 @@ int verify_chunks(Ctx &C, const char *label, size_t gens_capacity, size_t P, siz
     HIPCHK(hipMemsetAsync(status, 0, 16, C.stream));
     HIPCHK(hipMemcpyAsync(d_auxc, h_auxc, P * (4 + 2 * lg) * 32, hipMemcpyHostToDevice, C.stream));
     hipLaunchKernelGGL(k_decode, grid1(P * (4 + 2 * lg)), dim3(TPB), 0, C.stream, (u32)(P * (4 + 2 * lg)), (u32)(P * (4 + 2 * lg)), d_auxc, (const niels *)nullptr, d_auxn, (uint8_t *)nullptr, status);
+    vmark("decode launch");
     double th = now_ms();
+    std::atomic<u64> tr_prefix_ns{0}, tr_rest_ns{0};      // slowest task's share (ROFL_TRACE=2)
     // the transcript prefix (the m commitments of a chunk; sequential sponge): with enough proofs eight chunks share one AVX-512
     // instruction stream (keccak_x8.hpp), otherwise one chunk per task
     static const bool x8_on = k8::available() && !(knob("ROFL_MERLIN_X8") && atoi(knob("ROFL_MERLIN_X8")) == 0);
@@ -175,8 +178,16 @@ int verify_chunks(Ctx &C, const char *label, size_t gens_capacity, size_t P, siz
                             Merlin(label, strlen(label)), Merlin(label, strlen(label)), Merlin(label, strlen(label)), Merlin(label, strlen(label))};
             Merlin *t[8]; size_t cs[8]; int k = 0;
             for (size_t c = c0 + b * per; c < std::min(c1, c0 + (b + 1) * per); c++, k++) { t[k] = &tr[k]; cs[k] = c; }
+            const double ta = vtrace ? now_ms() : 0;
             prefix(t, cs, k);
+            const double tb = vtrace ? now_ms() : 0;
             for (int l = 0; l < k; l++) transcript(cs[l], tr[l]);
+            if (vtrace) {
+                const double tc = now_ms();
+                u64 a = (u64)((tb - ta) * 1e6), r = (u64)((tc - tb) * 1e6), o;
+                o = tr_prefix_ns.load(); while (a > o && !tr_prefix_ns.compare_exchange_weak(o, a)) {}
+                o = tr_rest_ns.load(); while (r > o && !tr_rest_ns.compare_exchange_weak(o, r)) {}
+            }
         });
     };
     if (vin && vin->ready && !vin->ready->empty()) {      // group by group, as the encodings arrive (the device is still decoding the later groups)
@@ -190,6 +201,7 @@ int verify_chunks(Ctx &C, const char *label, size_t gens_capacity, size_t P, siz
     } else hash_range(0, P);
     C.tm.t.host_ms += now_ms() - th;
     vmark("transcripts");
+    if (vtrace) fprintf(stderr, "[rofl-trace verify] slowest task: prefix %.3f ms, challenges and scalars %.3f ms\n", tr_prefix_ns.load() * 1e-6, tr_rest_ns.load() * 1e-6);
     HIPCHK(hipMemcpyAsync(d_cp, h_cp, sizeof(ChunkParams) * P, hipMemcpyHostToDevice, C.stream));
     PowTabs *d_pt = C.powtabs.as<PowTabs>(P);
     hipLaunchKernelGGL(k_pow_tables, dim3((4 * PT_L * PT_E + TPB - 1) / TPB, (u32)P), dim3(TPB), 0, C.stream, d_cp, d_pt, (u32)lg, 1);

@@ -262,22 +262,45 @@ struct Merlin {
         meta_ad(label, ll, false); meta_ad(le, 4, true); ad(msg, len, false);
     }
     // == count x append("<label>", msg + 32 j, 32) for a one-character label (the m commitments V_j of a chunk: 8 192 appends of 41
-    // transcript bytes each).  While the 2 + 1 + 4 + 2 + 32 bytes of an operation stay inside the rate block they are XORed in as one
-    // record with the two STROBE headers computed directly; an operation that reaches the end of the block takes the general path.
+    // transcript bytes each: {pos_begin, META_AD} label len {pos_begin', AD} msg).  The record is put together in registers with both STROBE
+    // headers computed directly and XORed into the rate block eight bytes at a time.  A record that reaches the end of the block (one in
+    // four) is split there: what begin_op / run_f would have done to pos_begin on the way is a function of k, the bytes left in the block --
+    // the second header starts at record byte 7, so a block that ends within the first seven bytes (k <= 7) permutes with pos_begin =
+    // start + 1 and the second operation begins in the new block with pos_begin 0; otherwise the permutation sees start + 8.
+    static void xor_bytes(uint8_t *dst, const uint8_t *src, size_t n) {
+        size_t i = 0;
+        for (; i + 8 <= n; i += 8) { u64 x, y; memcpy(&x, dst + i, 8); memcpy(&y, src + i, 8); x ^= y; memcpy(dst + i, &x, 8); }
+        for (; i < n; i++) dst[i] ^= src[i];
+    }
     void append32_run(char label, const uint8_t *msg, size_t count) {
         for (size_t j = 0; j < count; j++, msg += 32) {
-            if ((unsigned)pos + 41 < (unsigned)R) {
-                uint8_t rec[48] = {pos_begin, 16 | 2, (uint8_t)label, 32, 0, 0, 0, (uint8_t)(pos + 1), 2};
-                memcpy(rec + 9, msg, 32);
-                uint8_t *st = b() + pos;
-                for (int i = 0; i < 40; i += 8) { u64 x, y; memcpy(&x, st + i, 8); memcpy(&y, rec + i, 8); x ^= y; memcpy(st + i, &x, 8); }
-                st[40] ^= rec[40];
-                pos_begin = (uint8_t)(pos + 8); cur_flags = 2; pos = (uint8_t)(pos + 41);
+            const unsigned k = (unsigned)R - pos;                 // bytes left in the rate block, 1..166
+            u64 m0, m1, m2, m3; memcpy(&m0, msg, 8); memcpy(&m1, msg + 8, 8); memcpy(&m2, msg + 16, 8); memcpy(&m3, msg + 24, 8);
+            const u64 w0 = (u64)pos_begin | (u64)(16 | 2) << 8 | (u64)(uint8_t)label << 16 | (u64)32 << 24 | (u64)(k <= 7 ? 0 : (uint8_t)(pos + 1)) << 56;
+            const u64 w1 = 2 | m0 << 8, w2 = m0 >> 56 | m1 << 8, w3 = m1 >> 56 | m2 << 8, w4 = m2 >> 56 | m3 << 8;
+            const uint8_t b40 = (uint8_t)(m3 >> 56);
+            uint8_t *st = b() + pos;
+            if (k > 41) {
+                u64 x;
+                memcpy(&x, st, 8); x ^= w0; memcpy(st, &x, 8);
+                memcpy(&x, st + 8, 8); x ^= w1; memcpy(st + 8, &x, 8);
+                memcpy(&x, st + 16, 8); x ^= w2; memcpy(st + 16, &x, 8);
+                memcpy(&x, st + 24, 8); x ^= w3; memcpy(st + 24, &x, 8);
+                memcpy(&x, st + 32, 8); x ^= w4; memcpy(st + 32, &x, 8);
+                st[40] ^= b40;
+                pos_begin = (uint8_t)(pos + 8); pos = (uint8_t)(pos + 41);
             } else {
-                const char lb[2] = {label, 0};
-                append(lb, msg, 32);
+                uint8_t rec[48];
+                memcpy(rec, &w0, 8); memcpy(rec + 8, &w1, 8); memcpy(rec + 16, &w2, 8); memcpy(rec + 24, &w3, 8); memcpy(rec + 32, &w4, 8); rec[40] = b40;
+                xor_bytes(st, rec, k);
+                uint8_t *s0 = b();
+                s0[R] ^= (uint8_t)(pos + (k <= 7 ? 1 : 8)); s0[R + 1] ^= 0x04 ^ 0x80;
+                perm();
+                xor_bytes(s0, rec + k, 41 - k);
+                pos = (uint8_t)(41 - k); pos_begin = (uint8_t)(k <= 7 ? 8 - k : 0);
             }
         }
+        if (count) cur_flags = 2;
     }
     void append_u64(const char *label, u64 x) { uint8_t b[8]; memcpy(b, &x, 8); append(label, b, 8); }
     void append_scalar(const char *label, const sc &s) { uint8_t b[32]; sc_tobytes(b, s); append(label, b, 32); }

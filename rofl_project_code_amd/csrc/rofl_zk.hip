@@ -1742,6 +1742,21 @@ int rofl_dbg_host_encode8_selftest(unsigned batches, double *us_simd, double *us
 // k8::append32_run_x8 against Merlin::append32_run: `lanes` transcripts that have absorbed the same prefix, `count` commitments each, from every
 // starting position of the rate block (`skew` extra prefix bytes shift it); the challenge drawn afterwards must agree.  0 = equal, 1 = mismatch,
 // -1 = no AVX-512.  Timings: microseconds for all lanes together.
+// Merlin::append32_run (records put together in registers, split at the end of the rate block) against `count` plain append("V", msg, 32)
+// calls after `skew` extra prefix bytes: state, positions and the next challenge.  0 = equal, 1 = mismatch.
+int rofl_dbg_host_merlin_run_selftest(unsigned count, unsigned skew) {
+    if (skew > 400) return ROFL_BAD_PARAM;
+    std::vector<uint8_t> data((size_t)count * 32 + 1);
+    for (size_t i = 0; i < data.size(); i++) data[i] = (uint8_t)((i * 2246822519u) >> 11);
+    std::vector<uint8_t> pre(skew, 0xa5);
+    Merlin a("RangeProof", 10), b("RangeProof", 10);
+    if (skew) { a.append("skew", pre.data(), skew); b.append("skew", pre.data(), skew); }
+    a.append32_run('V', data.data(), count);
+    for (unsigned j = 0; j < count; j++) b.append("V", data.data() + (size_t)j * 32, 32);
+    int bad = a.pos != b.pos || a.pos_begin != b.pos_begin || a.cur_flags != b.cur_flags || memcmp(a.stw, b.stw, 200) != 0;
+    uint8_t ca[64], cb[64]; a.challenge_bytes("y", ca, 64); b.challenge_bytes("y", cb, 64); bad |= memcmp(ca, cb, 64) != 0;
+    return bad;
+}
 // keccak_f1600_zmm (one state across AVX-512 registers) against the scalar permutation on `states` pseudo-random states, chained `chain` deep,
 // plus the known answer of the all-zero state.  0 = all equal, 1 = mismatch, -1 = no AVX-512 on this CPU.
 int rofl_dbg_host_keccak_zmm_selftest(unsigned states, unsigned chain, double *ns_zmm, double *ns_scalar) {

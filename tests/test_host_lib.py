@@ -324,6 +324,17 @@ def test_simd_transcripts_match_the_scalar_ones(hiplib):
     assert L.rofl_dbg_host_merlin8_selftest(0, 8, 0, None, None) == 11
 
 
+def test_commitment_run_of_a_transcript_matches_plain_appends(hiplib):
+    """Merlin::append32_run -- the m commitment appends of a chunk with both STROBE headers computed directly, a record that reaches the end
+    of the rate block split there -- against plain append() calls: every start offset in the block (skew), run lengths around the block
+    period, a full chunk.  Positions, state bytes and the next challenge compared."""
+    L = hiplib
+    bad = [(c, s) for c in (0, 1, 2, 3, 4, 5, 9, 37, 257) for s in range(0, 340) if L.rofl_dbg_host_merlin_run_selftest(c, s)]
+    assert bad == []
+    assert L.rofl_dbg_host_merlin_run_selftest(8192, 0) == 0
+    assert L.rofl_dbg_host_merlin_run_selftest(1, 401) == 11
+
+
 def test_keccak_across_avx512_registers_matches_the_scalar_rounds(hiplib):
     """csrc/keccak.hpp keccak_f1600_zmm -- one Keccak-f[1600] state in five AVX-512 registers, what host transcripts run on hosts where a
     start-up measurement finds it faster -- against the scalar rounds: the zero state's known answer, pseudo-random and sparse states,

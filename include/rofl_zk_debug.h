@@ -71,6 +71,8 @@ int rofl_dbg_host_fe_ops(const uint8_t a[32], const uint8_t b[32], uint8_t out_a
 int rofl_dbg_host_sc_invert(const uint8_t a[32], uint8_t out_ref[32], uint8_t out_fast[32], double *ns_ref, double *ns_fast);
 int rofl_dbg_host_sc_mul(const uint8_t a[32], const uint8_t b[32], uint8_t out[32]);
 int rofl_dbg_host_sc_wide(const uint8_t in[64], uint8_t out[32]);
+/* the same through the Montgomery-form reduction the nonce kernel uses ((lo R^2 + hi R^3) R^-1, then out of Montgomery form) */
+int rofl_dbg_host_sc_wide_mont(const uint8_t in[64], uint8_t out[32]);
 /* sum of `count` <= 16 products a_k * b_k (operands < l) through the lazily reduced accumulator of k_verify_scalars2 (sc_mac_wide + ONE
  * sc_redc_wide) and as a sum of Montgomery products: both are sum a_k b_k / 2^256 mod l, canonical */
 int rofl_dbg_host_sc_lazy(const uint8_t *a32, const uint8_t *b32, size_t count, uint8_t out_lazy[32], uint8_t out_ref[32]);

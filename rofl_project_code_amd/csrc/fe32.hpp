@@ -245,6 +245,7 @@ HD u32 sc_l_limb(int i) {
 HD sc sc_zero() { sc r = {{0, 0, 0, 0, 0, 0, 0, 0}}; return r; }
 HD sc sc_one_plain() { sc r = {{1, 0, 0, 0, 0, 0, 0, 0}}; return r; }
 HD sc sc_R2() { sc r = {{0x449c0f01u, 0xa40611e3u, 0x68859347u, 0xd00e1ba7u, 0x17f5be65u, 0xceec73d2u, 0x7c309a3du, 0x0399411bu}}; return r; }
+HD sc sc_R3() { sc r = {{0x7b83a2dbu, 0x2a9e4968u, 0xaef7f3ecu, 0x278324e6u, 0x04ec5b65u, 0x8065dc6cu, 0x3599cec7u, 0x0e530b77u}}; return r; }      // 2^768 mod l
 HD sc sc_one_mont() { sc r = {{0x8d98951du, 0xd6ec3174u, 0x737dcf70u, 0xc6ef5bf4u, 0xfffffffeu, 0xffffffffu, 0xffffffffu, 0x0fffffffu}}; return r; }
 
 HD bool sc_geq_l(const u32 a[8]) {
@@ -377,10 +378,23 @@ HD void sc_tobytes(uint8_t *s, const sc &a) {
     for (int i = 0; i < 8; i++) { s[4 * i] = (uint8_t)a.v[i]; s[4 * i + 1] = (uint8_t)(a.v[i] >> 8); s[4 * i + 2] = (uint8_t)(a.v[i] >> 16); s[4 * i + 3] = (uint8_t)(a.v[i] >> 24); }
 }
 // 64 bytes -> canonical scalar (Scalar::from_bytes_mod_order_wide)
+// (lo R + hi R^2) R^-1 = lo + hi 2^256: two plain products under ONE Montgomery reduction (T < 2 * 2^256 * l: the reduction leaves < 3 l)
 HD sc sc_from_wide(const sc &lo, const sc &hi) {
-    sc lo_r = sc_from_mont(sc_to_mont(lo));
-    sc hi_r = sc_montmul(hi, sc_R2());      // hi * 2^256 mod l
-    return sc_add(lo_r, hi_r);
+    u32 acc[17];
+#pragma unroll
+    for (int i = 0; i < 17; i++) acc[i] = 0;
+    sc_mac_wide(acc, lo, sc_one_mont());
+    sc_mac_wide(acc, hi, sc_R2());
+    return sc_redc_wide(acc);
+}
+// the same value in Montgomery form, (lo R^2 + hi R^3) R^-1 = (lo + hi 2^256) R  (for callers that want both: from_mont of this is the canonical one)
+HD sc sc_from_wide_mont(const sc &lo, const sc &hi) {
+    u32 acc[17];
+#pragma unroll
+    for (int i = 0; i < 17; i++) acc[i] = 0;
+    sc_mac_wide(acc, lo, sc_R2());
+    sc_mac_wide(acc, hi, sc_R3());
+    return sc_redc_wide(acc);
 }
 HD sc sc_from_u64(u64 x) { sc r = sc_zero(); r.v[0] = (u32)x; r.v[1] = (u32)(x >> 32); return r; }
 HDN inline sc sc_invert_mont(const sc &a) {   // Montgomery in/out: a^(l-2)

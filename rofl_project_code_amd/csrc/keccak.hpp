@@ -11,7 +11,18 @@
 
 namespace rofl {
 
-HD u64 rotl64(u64 x, int n) { return (x << n) | (x >> (64 - n)); }
+// (device: a 64-bit rotation as two 32-bit funnel shifts -- v_alignbit_b32 -- instead of two 64-bit shifts and an OR pair; n is a literal everywhere)
+HD u64 rotl64(u64 x, int n) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    u32 lo = (u32)x, hi = (u32)(x >> 32);
+    if (n >= 32) { u32 t = lo; lo = hi; hi = t; n -= 32; }
+    if (n == 0) return ((u64)hi << 32) | lo;
+    const u32 nh = __builtin_amdgcn_alignbit(hi, lo, 32 - n), nl = __builtin_amdgcn_alignbit(lo, hi, 32 - n);
+    return ((u64)nh << 32) | nl;
+#else
+    return (x << n) | (x >> (64 - n));
+#endif
+}
 
 HDN inline void keccak_f1600(u64 s[25]) {
     const u64 RC[24] = {
@@ -29,6 +40,10 @@ HDN inline void keccak_f1600(u64 s[25]) {
         u64 c4 = s[4] ^ s[9] ^ s[14] ^ s[19] ^ s[24];
         u64 d0 = c4 ^ rotl64(c1, 1), d1 = c0 ^ rotl64(c2, 1), d2 = c1 ^ rotl64(c3, 1);
         u64 d3 = c2 ^ rotl64(c4, 1), d4 = c3 ^ rotl64(c0, 1);
+#if defined(__HIP_DEVICE_COMPILE__)
+        // keep the five D words as values: left alone, the compiler XORs c and rol(c) into the 25 lanes separately (100 XORs for 60)
+        asm volatile("" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4));
+#endif
 #pragma unroll
         for (int j = 0; j < 25; j += 5) { s[j] ^= d0; s[j + 1] ^= d1; s[j + 2] ^= d2; s[j + 3] ^= d3; s[j + 4] ^= d4; }
         // rho + pi

@@ -312,8 +312,8 @@ __global__ void __launch_bounds__(TPB) k_nonce_expand(u32 n, u32 m, const ChunkP
             for (int i = 0; i < 8; i++) { lo.v[i] = s[i]; hi.v[i] = s[8 + i]; }
         } else { lo = sc_zero(); hi = sc_zero(); }
     }
-    sc vc = sc_from_wide(lo, hi);
-    sc v = sc_to_mont(vc);
+    sc v = sc_from_wide_mont(lo, hi);       // Montgomery form for the polynomial kernels, canonical for the MSM: one wide reduction + one conversion
+    sc vc = sc_from_mont(v);
     u64 first = (u64)m * (2 * n + 2);
     size_t N = (size_t)n * m;
     if (k < first) {

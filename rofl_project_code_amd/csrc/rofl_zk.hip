@@ -1841,6 +1841,7 @@ int rofl_dbg_host_sc_lazy(const uint8_t *a32, const uint8_t *b32, size_t count, 
     sc_tobytes(out_lazy, sc_redc_wide(acc)); sc_tobytes(out_ref, ref);
     return 0;
 }
+int rofl_dbg_host_sc_wide_mont(const uint8_t in[64], uint8_t out[32]) { sc_tobytes(out, sc_from_mont(sc_from_wide_mont(sc_frombytes(in), sc_frombytes(in + 32)))); return 0; }
 int rofl_dbg_host_sc_wide(const uint8_t in[64], uint8_t out[32]) { sc_tobytes(out, sc_from_wide(sc_frombytes(in), sc_frombytes(in + 32))); return 0; }
 int rofl_dbg_host_from_uniform(const uint8_t in[64], uint8_t out[32]) { ristretto_encode(out, ristretto_from_uniform(in)); return 0; }
 int rofl_dbg_host_scalarmult_base(const uint8_t k[32], int use_bb, uint8_t out[32]) {

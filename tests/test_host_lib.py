@@ -324,6 +324,24 @@ def test_simd_transcripts_match_the_scalar_ones(hiplib):
     assert L.rofl_dbg_host_merlin8_selftest(0, 8, 0, None, None) == 11
 
 
+def test_wide_scalar_reduction_against_big_integers(hiplib):
+    """Scalar::from_bytes_mod_order_wide as built here -- two plain products under ONE Montgomery reduction, canonical and Montgomery-form
+    variants (fe32.hpp sc_from_wide / sc_from_wide_mont: what k_nonce_expand runs per nonce) -- against Python integers: the extremes of the
+    512-bit range, values around multiples of the group order, 300 pseudo-random inputs."""
+    L = hiplib
+    ell = 2 ** 252 + 27742317777372353535851937790883648493
+    rng = np.random.default_rng(5)
+    cases = [0, 1, ell - 1, ell, ell + 1, 2 ** 256 - 1, 2 ** 256, 2 ** 512 - 1, (2 ** 256 - 1) << 256, ell * ell, ell * (2 ** 259) - 1, 16 * ell * ell + 5]
+    cases += [int.from_bytes(rng.bytes(64), "little") for _ in range(300)]
+    for x in cases:
+        x %= 2 ** 512
+        want = (x % ell).to_bytes(32, "little")
+        for fn in (L.rofl_dbg_host_sc_wide, L.rofl_dbg_host_sc_wide_mont):
+            out = ctypes.create_string_buffer(32)
+            assert fn(x.to_bytes(64, "little"), out) == 0
+            assert out.raw == want, hex(x)
+
+
 def test_commitment_run_of_a_transcript_matches_plain_appends(hiplib):
     """Merlin::append32_run -- the m commitment appends of a chunk with both STROBE headers computed directly, a record that reaches the end
     of the rate block split there -- against plain append() calls: every start offset in the block (skew), run lengths around the block

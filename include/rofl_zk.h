@@ -46,7 +46,8 @@ enum {
  *   mode 0: `stream` holds 64-byte wide scalars in the reference draw order
  *           (per chunk c, offset c*m*(2n+4): per party a_blinding, s_blinding, s_L[0..n), s_R[0..n);
  *            then per party t_1_blinding, t_2_blinding), each reduced like Scalar::from_bytes_mod_order_wide.
- *   mode 1: scalar k = wide-reduce(SHAKE256("rofl-zk/nonce/v1" || seed[32] || u64le(k))[0..64]). */
+ *   mode 1: scalar k = wide-reduce(SHAKE256("rofl-zk/nonce/v2" || seed[32] || u64le(k >> 1))[64 (k & 1) .. 64 (k & 1) + 64]):
+ *           two wide scalars per block of the XOF (its rate is 136 bytes). */
 typedef struct {
     int mode;
     const uint8_t *stream;

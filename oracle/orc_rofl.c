@@ -25,12 +25,16 @@ static void nonce_get(const orc_nonce_t *ns, uint64_t idx, sc *out) {
         if (idx >= ns->stream_scalars) { memset(b, 0, 64); }
         else memcpy(b, ns->stream + 64 * idx, 64);
     } else {
+        /* two scalars per SHAKE256 block: scalar idx is bytes 64 (idx & 1) .. + 64 of SHAKE256("rofl-zk/nonce/v2" || seed || u64le(idx >> 1)) */
+        uint8_t blk[128];
+        const uint64_t bi = idx >> 1;
         shake256_ctx c; shake256_init(&c);
-        shake256_absorb(&c, (const uint8_t *)"rofl-zk/nonce/v1", 16);
+        shake256_absorb(&c, (const uint8_t *)"rofl-zk/nonce/v2", 16);
         shake256_absorb(&c, ns->seed, 32);
-        uint8_t le[8]; for (int i = 0; i < 8; i++) le[i] = (uint8_t)(idx >> (8 * i));
+        uint8_t le[8]; for (int i = 0; i < 8; i++) le[i] = (uint8_t)(bi >> (8 * i));
         shake256_absorb(&c, le, 8);
-        shake256_squeeze(&c, b, 64);
+        shake256_squeeze(&c, blk, 128);
+        memcpy(b, blk + 64 * (idx & 1), 64);
     }
     sc_frombytes_wide(out, b);
 }

@@ -40,7 +40,7 @@ enum {
 };
 
 /* nonce source: mode 0 = explicit stream of 64-byte wide scalars in reference draw order,
- *               mode 1 = 32-byte seed expanded with SHAKE256("rofl-zk/nonce/v1"||seed||u64le(index)) */
+ *               mode 1 = 32-byte seed: scalar k = wide-reduce of bytes 64 (k & 1) .. + 64 of SHAKE256("rofl-zk/nonce/v2"||seed||u64le(k >> 1)) */
 typedef struct {
     int mode;
     const uint8_t *stream;

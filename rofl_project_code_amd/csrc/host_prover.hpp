@@ -44,7 +44,7 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
     }
     HIPCHK(hipMemcpyAsync(d_cp, h_cp, sizeof(ChunkParams) * P, hipMemcpyHostToDevice, C.stream));
     sc *sL = C.sL.as<sc>(P * N), *sR = C.sR.as<sc>(P * N), *party = C.party.as<sc>(P * 4 * m), *Scanon = C.Scanon.as<sc>(P * 2 * N);
-    hipLaunchKernelGGL(k_nonce_expand, grid1(per, (u32)P), dim3(TPB), 0, C.stream, (u32)n, (u32)m, d_cp, sL, sR, party, Scanon);
+    hipLaunchKernelGGL(k_nonce_expand, grid1(per / 2 + 1, (u32)P), dim3(TPB), 0, C.stream, (u32)n, (u32)m, d_cp, sL, sR, party, Scanon);
     // A partials: they depend on the values only and the host reads them after the S MSM -- side stream, beside the nonce expansion
     if (!C.stream2) HIPCHK(hipStreamCreateWithFlags(&C.stream2, hipStreamNonBlocking));
     if (!C.ev_a) { HIPCHK(hipEventCreateWithFlags(&C.ev_a, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&C.ev_a0, hipEventDisableTiming)); }
@@ -152,7 +152,15 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
     mark("T x host");
     HIPCHK(hipMemcpyAsync(d_cp, h_cp, sizeof(ChunkParams) * P, hipMemcpyHostToDevice, C.stream));
     sc *a = C.a.as<sc>(P * N), *b = C.b.as<sc>(P * N), *yinvpow = C.yinv.as<sc>(P * N);
-    hipLaunchKernelGGL(k_lr_vec, grid1(N, (u32)P), dim3(TPB), 0, C.stream, (u32)n, (u32)m, d_cp, (const PowTabs *)d_pt, d_vshift, sL, sR, C.d_two_pow, a, b, yinvpow);
+    // l(x), r(x) -- and with them, in the same pass, the first round's MSM scalars and inner products (k_lr_first; ROFL_LR_FIRST=0: three launches)
+    static const bool lr_first_on = !(knob("ROFL_LR_FIRST") && atoi(knob("ROFL_LR_FIRST")) == 0);
+    const bool lr_first = lr_first_on && C.msm_lr != 0 && N >= 2;
+    const u32 lr_first_blocks = (u32)std::min<size_t>(256, (N / 2 + TPB - 1) / TPB);
+    if (lr_first)
+        hipLaunchKernelGGL(k_lr_first, dim3(lr_first_blocks, (u32)P), dim3(TPB), 0, C.stream, (u32)n, (u32)m, d_cp, (const PowTabs *)d_pt, d_vshift, sL, sR, C.d_two_pow, a, b, yinvpow,
+                           C.SL.as<sc>(P * 2 * N), C.h_ip.dev<sc>(P * 256 * 2));
+    else
+        hipLaunchKernelGGL(k_lr_vec, grid1(N, (u32)P), dim3(TPB), 0, C.stream, (u32)n, (u32)m, d_cp, (const PowTabs *)d_pt, d_vshift, sL, sR, C.d_two_pow, a, b, yinvpow);
     mark("poly/T/x");
 
     // ---- IPP rounds with lazily folded generators
@@ -203,6 +211,8 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
                                (const sc *)ptab[psel], ptab[psel ^ 1], N, n_k == 2 ? C.h_abfin.dev<sc>(4 * P) : (sc *)nullptr, ip_dev);
             if (n_k == 2) ab_on_host = true;
             std::swap(a, a2); std::swap(b, b2); psel ^= 1;
+        } else if (round == 0 && lr_first) {
+            nblkI = lr_first_blocks;      // scalars and partial inner products were written with l(x), r(x)
         } else {
             hipLaunchKernelGGL(k_ipp_scalars, grid1(n_g, (u32)P), dim3(TPB), 0, C.stream, (u32)n_g, (u32)n_k, r, d_cp, a, b, N, yinvpow, N, SL, SR, merged ? 1 : 0);
             nblkI = (u32)std::min<size_t>(32, (nh + TPB - 1) / TPB);

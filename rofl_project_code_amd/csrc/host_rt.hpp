@@ -59,6 +59,7 @@ static const Knob KNOBS[] = {
     {"ROFL_MSM_HOST8_MIN", "8", "launches with at least this many problems run their window chains eight per AVX-512 IFMA stream on the host (when the CPU has it)"},
     {"ROFL_MSM_FB_HOST8_MIN", "8", "fixed-base launches with at least this many problems finish eight problems per AVX-512 IFMA task (32 = as in rounds 3-4: one scalar chain per pool task below 32 problems)"},
     {"ROFL_KECCAK_ZMM", "", "host transcripts: 1 = Keccak-f[1600] with one state across five AVX-512 registers, 0 = the scalar rounds; unset = whichever a 50 us measurement at first use finds faster (Intel: the registers, 1.27x; Zen 5: scalar)"},
+    {"ROFL_LR_FIRST", "1", "0 = l(x), r(x), the first round's MSM scalars and its inner products in three launches (k_lr_vec, k_ipp_scalars, k_ipp_inner) instead of one (k_lr_first)"},
     {"ROFL_HOP_CQ", "1", "0 = the <a,b> w B terms of a round are computed on the hop (after the wait) instead of on the pool while the round's MSM runs"},
     {"ROFL_MSM_DEV_HORNER_MIN", "32", "launches with at least this many problems combine their windows on the device"},
     {"ROFL_MSM_T13", "8192", "generic MSMs from this many terms on use 13-bit windows"},

@@ -86,6 +86,7 @@ HDN inline void keccak_f1600(u64 s[25]) {
 // SHAKE256 of a short (< 136 byte) message given as whole little-endian u64 words plus tail bytes,
 // squeezing exactly one block.  Used for the nonce / verifier-challenge DRBG:
 //   SHAKE256(domain16 || seed32 || u64le(index))   (56 bytes = 7 words)
+#define ROFL_NONCE_DOM {0x2f6b7a2d6c666f72ULL, 0x32762f65636e6f6eULL}      /* "rofl-zk/" "nonce/v2" */
 HD void shake256_seeded_block(u64 st[25], const u64 dom[2], const u64 seed[4], u64 index) {
 #pragma unroll
     for (int i = 0; i < 25; i++) st[i] = 0;

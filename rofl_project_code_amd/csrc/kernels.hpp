@@ -284,47 +284,54 @@ __global__ void __launch_bounds__(TPB) k_gens_tables(u32 total, FoldTabCfg cfg, 
 #endif
 
 // ================================================================ nonces
-// mode 1: SHAKE256("rofl-zk/nonce/v1" || seed || u64le(idx)) ; mode 0: explicit 64-byte stream.
+// mode 1: scalar idx = bytes 64 (idx & 1) .. + 64 of SHAKE256("rofl-zk/nonce/v2" || seed || u64le(idx >> 1)) -- two wide scalars per block of
+// the XOF, one Keccak-f per thread ; mode 0: explicit 64-byte stream.
 // Reference draw order (bulletproofs party.rs): per party j: a_bl, s_bl, s_L[0..n), s_R[0..n);
 // then per party: t1_bl, t2_bl.
 #if ROFL_KG(4)
 __global__ void __launch_bounds__(TPB) k_nonce_expand(u32 n, u32 m, const ChunkParams *cp, sc *sL, sc *sR, sc *party /* [chunk][4][m] */, sc *S_canon /* [chunk][2N] */) {
     u32 c = blockIdx.y;
-    u64 per = (u64)m * (2 * n + 4);
-    u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= per) return;
+    const u64 per = (u64)m * (2 * n + 4);
     // every chunk names its own nonce source: the chunks of a launch may belong to different clients (batched create)
-    u64 idx = cp[c].nonce_base + k;
+    const u64 base = cp[c].nonce_base;
+    const u64 blk = (base >> 1) + (u64)blockIdx.x * blockDim.x + threadIdx.x;      // thread = one XOF block = scalars 2 blk, 2 blk + 1
+    if (2 * blk >= base + per) return;
     const int mode = cp[c].nonce_mode;
     const uint8_t *stream = cp[c].nonce_stream; const u64 stream_scalars = cp[c].nonce_stream_scalars;
-    sc lo, hi;
+    u64 st[25];
     if (mode == 1) {
-        const u64 dom[2] = {0x2f6b7a2d6c666f72ULL, 0x31762f65636e6f6eULL};  // "rofl-zk/" "nonce/v1"
-        u64 st[25];
+        const u64 dom[2] = ROFL_NONCE_DOM;
         u64 sw[4] = {cp[c].nonce_seed.w[0], cp[c].nonce_seed.w[1], cp[c].nonce_seed.w[2], cp[c].nonce_seed.w[3]};
-        shake256_seeded_block(st, dom, sw, idx);
+        shake256_seeded_block(st, dom, sw, blk);
+    }
+    const u64 first = (u64)m * (2 * n + 2);
+    const size_t N = (size_t)n * m;
 #pragma unroll
-        for (int i = 0; i < 4; i++) { lo.v[2 * i] = (u32)st[i]; lo.v[2 * i + 1] = (u32)(st[i] >> 32); hi.v[2 * i] = (u32)st[4 + i]; hi.v[2 * i + 1] = (u32)(st[4 + i] >> 32); }
-    } else {
-        if (idx < stream_scalars) {
+    for (int h = 0; h < 2; h++) {
+        const u64 idx = 2 * blk + h;
+        if (idx < base || idx >= base + per) continue;
+        const u64 k = idx - base;
+        sc lo, hi;
+        if (mode == 1) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) { lo.v[2 * i] = (u32)st[8 * h + i]; lo.v[2 * i + 1] = (u32)(st[8 * h + i] >> 32); hi.v[2 * i] = (u32)st[8 * h + 4 + i]; hi.v[2 * i + 1] = (u32)(st[8 * h + 4 + i] >> 32); }
+        } else if (idx < stream_scalars) {
             const u32 *s = reinterpret_cast<const u32 *>(stream + idx * 64);
 #pragma unroll
             for (int i = 0; i < 8; i++) { lo.v[i] = s[i]; hi.v[i] = s[8 + i]; }
         } else { lo = sc_zero(); hi = sc_zero(); }
-    }
-    sc v = sc_from_wide_mont(lo, hi);       // Montgomery form for the polynomial kernels, canonical for the MSM: one wide reduction + one conversion
-    sc vc = sc_from_mont(v);
-    u64 first = (u64)m * (2 * n + 2);
-    size_t N = (size_t)n * m;
-    if (k < first) {
-        u32 j = (u32)(k / (2 * n + 2)), r = (u32)(k % (2 * n + 2));
-        if (r == 0) store_sc(&party[((size_t)c * 4 + 0) * m + j], v);
-        else if (r == 1) store_sc(&party[((size_t)c * 4 + 1) * m + j], v);
-        else if (r < 2 + n) { store_sc(&sL[c * N + (size_t)j * n + (r - 2)], v); store_sc(&S_canon[c * 2 * N + (size_t)j * n + (r - 2)], vc); }
-        else { store_sc(&sR[c * N + (size_t)j * n + (r - 2 - n)], v); store_sc(&S_canon[c * 2 * N + N + (size_t)j * n + (r - 2 - n)], vc); }
-    } else {
-        u64 q = k - first; u32 j = (u32)(q / 2);
-        store_sc(&party[((size_t)c * 4 + 2 + (q & 1)) * m + j], v);
+        sc v = sc_from_wide_mont(lo, hi);       // Montgomery form for the polynomial kernels, canonical for the MSM: one wide reduction + one conversion
+        sc vc = sc_from_mont(v);
+        if (k < first) {
+            u32 j = (u32)(k / (2 * n + 2)), r = (u32)(k % (2 * n + 2));
+            if (r == 0) store_sc(&party[((size_t)c * 4 + 0) * m + j], v);
+            else if (r == 1) store_sc(&party[((size_t)c * 4 + 1) * m + j], v);
+            else if (r < 2 + n) { store_sc(&sL[c * N + (size_t)j * n + (r - 2)], v); store_sc(&S_canon[c * 2 * N + (size_t)j * n + (r - 2)], vc); }
+            else { store_sc(&sR[c * N + (size_t)j * n + (r - 2 - n)], v); store_sc(&S_canon[c * 2 * N + N + (size_t)j * n + (r - 2 - n)], vc); }
+        } else {
+            u64 q = k - first; u32 j = (u32)(q / 2);
+            store_sc(&party[((size_t)c * 4 + 2 + (q & 1)) * m + j], v);
+        }
     }
 }
 #endif
@@ -562,6 +569,47 @@ __global__ void __launch_bounds__(TPB) k_lr_vec(u32 n, u32 m, const ChunkParams 
     store_sc(&a[c * N + k], sc_add(l0, sc_montmul(l1, cp[c].x)));
     store_sc(&b[c * N + k], sc_add(r0, sc_montmul(r1, cp[c].x)));
     store_sc(&yinvpow[c * N + k], pt_pow(pt[c].yinv, cp[c].yinvpow2, k));
+}
+#endif
+
+// k_lr_vec + the first round's k_ipp_scalars (merged form) + k_ipp_inner in one pass: a thread owns the pairs (i, N/2 + i) of its chunk and
+// writes a, b, y^-j, the round's MSM scalars (no pending challenges yet: s_G = gscale, s_H = hscale y^-j; generator j of the low half takes
+// the vectors' high half and vice versa) and the partial inner products <a_L, b_R>, <a_R, b_L> of its block -> ip_out[chunk][block][2].
+#if ROFL_KG(4)
+__global__ void __launch_bounds__(TPB) k_lr_first(u32 n, u32 m, const ChunkParams *cp, const PowTabs *pt, const u64 *vshift, const sc *sL, const sc *sR,
+                           const sc *two_pow, sc *a, sc *b, sc *yinvpow, sc *SL, sc *ip_out) {
+    __shared__ sc lds[TPB * 2];
+    const u32 c = blockIdx.y;
+    const size_t N = (size_t)n * m;
+    const u32 nh = (u32)(N / 2);
+    const sc sG = load_sc(&cp[c].gscale), sH0 = load_sc(&cp[c].hscale), x = cp[c].x;
+    sc *sl = SL + (size_t)c * 2 * N;
+    sc v[2] = {sc_zero(), sc_zero()};
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < nh; i += gridDim.x * blockDim.x) {
+        sc av[2], bv[2], yv[2];
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            const u32 k = s ? nh + i : i;
+            sc l0, r0, r1;
+            sc l1 = load_sc(&sL[c * N + k]);
+            slot_vectors(cp[c], pt[c], n, k, vshift[(size_t)c * m + k / n], load_sc(&sR[c * N + k]), l0, r0, r1, two_pow);
+            av[s] = sc_add(l0, sc_montmul(l1, x));
+            bv[s] = sc_add(r0, sc_montmul(r1, x));
+            yv[s] = pt_pow(pt[c].yinv, cp[c].yinvpow2, k);
+            store_sc(&a[c * N + k], av[s]); store_sc(&b[c * N + k], bv[s]); store_sc(&yinvpow[c * N + k], yv[s]);
+        }
+        store_sc(&sl[i], sc_from_mont(sc_montmul(av[1], sG)));
+        store_sc(&sl[N + i], sc_from_mont(sc_montmul(bv[1], sc_montmul(sH0, yv[0]))));
+        store_sc(&sl[nh + i], sc_from_mont(sc_montmul(av[0], sG)));
+        store_sc(&sl[N + nh + i], sc_from_mont(sc_montmul(bv[0], sc_montmul(sH0, yv[1]))));
+        v[0] = sc_add(v[0], sc_montmul(av[0], bv[1]));
+        v[1] = sc_add(v[1], sc_montmul(av[1], bv[0]));
+    }
+    block_sum_sc<2>(v, lds);
+    if (threadIdx.x == 0) {
+        store_sc(&ip_out[((size_t)c * gridDim.x + blockIdx.x) * 2 + 0], v[0]);
+        store_sc(&ip_out[((size_t)c * gridDim.x + blockIdx.x) * 2 + 1], v[1]);
+    }
 }
 #endif
 
@@ -2179,13 +2227,22 @@ __device__ inline sc sg_f32_to_sc(float v, u32 fp_bits, u32 fp_frac) {     // co
     sc m = sc_from_u64(kq); if (v < 0.0f) m = sc_neg(m);
     return m;
 }
-__device__ inline sc sg_nonce(int mode, const NonceSeed &seed, const uint8_t *stream, u64 stream_scalars, u64 idx) {
+// nonce idx of a Sigma-proof call (same sources as k_nonce_expand).  `cache` keeps the last XOF block: consecutive indices share one Keccak-f.
+struct SgNonceCache { u64 blk; u64 w[16]; };
+__device__ inline sc sg_nonce(int mode, const NonceSeed &seed, const uint8_t *stream, u64 stream_scalars, u64 idx, SgNonceCache &cache) {
     sc lo, hi;
     if (mode == 1) {
-        const u64 dom[2] = {0x2f6b7a2d6c666f72ULL, 0x31762f65636e6f6eULL};
-        u64 st[25]; shake256_seeded_block(st, dom, seed.w, idx);
+        if (cache.blk != (idx >> 1)) {
+            const u64 dom[2] = ROFL_NONCE_DOM;
+            u64 st[25]; shake256_seeded_block(st, dom, seed.w, idx >> 1);
 #pragma unroll
-        for (int q = 0; q < 4; q++) { lo.v[2 * q] = (u32)st[q]; lo.v[2 * q + 1] = (u32)(st[q] >> 32); hi.v[2 * q] = (u32)st[4 + q]; hi.v[2 * q + 1] = (u32)(st[4 + q] >> 32); }
+            for (int q = 0; q < 16; q++) cache.w[q] = st[q];
+            cache.blk = idx >> 1;
+        }
+        const bool h = idx & 1;
+#pragma unroll
+        for (int q = 0; q < 4; q++) { u64 a = h ? cache.w[8 + q] : cache.w[q], b = h ? cache.w[12 + q] : cache.w[4 + q];
+                                      lo.v[2 * q] = (u32)a; lo.v[2 * q + 1] = (u32)(a >> 32); hi.v[2 * q] = (u32)b; hi.v[2 * q + 1] = (u32)(b >> 32); }
     } else if (idx < stream_scalars) {
         const u32 *s = reinterpret_cast<const u32 *>(stream + idx * 64);
 #pragma unroll
@@ -2206,7 +2263,8 @@ __global__ void __launch_bounds__(64) k_sigma_prove(int kind, u32 d, const float
     sc m = sg_f32_to_sc(v, fp_bits, fp_frac);
     sc r1 = load_sc_reduced(&r1c[i]), r2 = has_sq ? load_sc_reduced(&r2c[i]) : sc_zero();
     sc nc[3];
-    for (u32 j = 0; j < nn; j++) nc[j] = sg_nonce(mode, seed, stream, stream_scalars, (u64)nn * i + j);   // m', r1' (, r2')
+    SgNonceCache ncache; ncache.blk = ~0ULL;
+    for (u32 j = 0; j < nn; j++) nc[j] = sg_nonce(mode, seed, stream, stream_scalars, (u64)nn * i + j, ncache);   // m', r1' (, r2')
     uint8_t *cm = commits + (size_t)clen * i, *pf = proofs + (size_t)plen * i;
     gd L;
     if (existing) { if (!sg_decode(L, existing + (size_t)32 * i)) { atomicOr(status, 4u); return; } for (int q = 0; q < 32; q++) cm[q] = existing[(size_t)32 * i + q]; }

@@ -1889,9 +1889,10 @@ int rofl_dbg_host_merlin(const uint8_t *label, size_t label_len, const uint8_t *
     Merlin t((const char *)label, label_len); t.append("msg", msg, msg_len); t.challenge_bytes("chal", out, 64); return 0;
 }
 int rofl_dbg_host_nonce(const uint8_t seed[32], uint64_t idx, uint8_t out[32]) {
-    const u64 dom[2] = {0x2f6b7a2d6c666f72ULL, 0x31762f65636e6f6eULL};
-    u64 sd[4]; memcpy(sd, seed, 32); u64 st[25]; shake256_seeded_block(st, dom, sd, idx);
-    sc lo, hi; for (int i = 0; i < 4; i++) { lo.v[2 * i] = (u32)st[i]; lo.v[2 * i + 1] = (u32)(st[i] >> 32); hi.v[2 * i] = (u32)st[4 + i]; hi.v[2 * i + 1] = (u32)(st[4 + i] >> 32); }
+    const u64 dom[2] = ROFL_NONCE_DOM;
+    u64 sd[4]; memcpy(sd, seed, 32); u64 st[25]; shake256_seeded_block(st, dom, sd, idx >> 1);
+    const int h = (int)(idx & 1);
+    sc lo, hi; for (int i = 0; i < 4; i++) { lo.v[2 * i] = (u32)st[8 * h + i]; lo.v[2 * i + 1] = (u32)(st[8 * h + i] >> 32); hi.v[2 * i] = (u32)st[8 * h + 4 + i]; hi.v[2 * i + 1] = (u32)(st[8 * h + 4 + i] >> 32); }
     sc_tobytes(out, sc_from_wide(lo, hi)); return 0;
 }
 

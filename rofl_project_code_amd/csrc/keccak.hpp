@@ -40,9 +40,13 @@ HDN inline void keccak_f1600(u64 s[25]) {
         u64 c4 = s[4] ^ s[9] ^ s[14] ^ s[19] ^ s[24];
         u64 d0 = c4 ^ rotl64(c1, 1), d1 = c0 ^ rotl64(c2, 1), d2 = c1 ^ rotl64(c3, 1);
         u64 d3 = c2 ^ rotl64(c4, 1), d4 = c3 ^ rotl64(c0, 1);
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(ROFL_KGROUP) && ROFL_KGROUP == 4
+        // (kernel group 4 only -- k_nonce_expand, one permutation per thread and registers to spare; in the Sigma-proof transcript kernels of
+        // group 3 the pinned words cost 18 VGPRs and a wave of occupancy)
         // keep the five D words as values: left alone, the compiler XORs c and rol(c) into the 25 lanes separately (100 XORs for 60)
-        asm volatile("" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4));
+        {   u32 l0 = (u32)d0, h0 = (u32)(d0 >> 32), l1 = (u32)d1, h1 = (u32)(d1 >> 32), l2 = (u32)d2, h2 = (u32)(d2 >> 32), l3 = (u32)d3, h3 = (u32)(d3 >> 32), l4 = (u32)d4, h4 = (u32)(d4 >> 32);
+            asm volatile("" : "+v"(l0), "+v"(h0), "+v"(l1), "+v"(h1), "+v"(l2), "+v"(h2), "+v"(l3), "+v"(h3), "+v"(l4), "+v"(h4));
+            d0 = ((u64)h0 << 32) | l0; d1 = ((u64)h1 << 32) | l1; d2 = ((u64)h2 << 32) | l2; d3 = ((u64)h3 << 32) | l3; d4 = ((u64)h4 << 32) | l4; }
 #endif
 #pragma unroll
         for (int j = 0; j < 25; j += 5) { s[j] ^= d0; s[j + 1] ^= d1; s[j + 2] ^= d2; s[j + 3] ^= d3; s[j + 4] ^= d4; }

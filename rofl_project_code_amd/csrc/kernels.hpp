@@ -576,7 +576,7 @@ __global__ void __launch_bounds__(TPB) k_lr_vec(u32 n, u32 m, const ChunkParams 
 // writes a, b, y^-j, the round's MSM scalars (no pending challenges yet: s_G = gscale, s_H = hscale y^-j; generator j of the low half takes
 // the vectors' high half and vice versa) and the partial inner products <a_L, b_R>, <a_R, b_L> of its block -> ip_out[chunk][block][2].
 #if ROFL_KG(4)
-__global__ void __launch_bounds__(TPB) k_lr_first(u32 n, u32 m, const ChunkParams *cp, const PowTabs *pt, const u64 *vshift, const sc *sL, const sc *sR,
+__global__ void __launch_bounds__(TPB, 3) k_lr_first(u32 n, u32 m, const ChunkParams *cp, const PowTabs *pt, const u64 *vshift, const sc *sL, const sc *sR,
                            const sc *two_pow, sc *a, sc *b, sc *yinvpow, sc *SL, sc *ip_out) {
     __shared__ sc lds[TPB * 2];
     const u32 c = blockIdx.y;
@@ -586,24 +586,27 @@ __global__ void __launch_bounds__(TPB) k_lr_first(u32 n, u32 m, const ChunkParam
     sc *sl = SL + (size_t)c * 2 * N;
     sc v[2] = {sc_zero(), sc_zero()};
     for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < nh; i += gridDim.x * blockDim.x) {
-        sc av[2], bv[2], yv[2];
-#pragma unroll
+        // the two elements one after the other in a ROLLED loop (unrolled, the compiler interleaves them: 230 VGPRs and spills), results in named
+        // registers (an indexed pair would live in scratch)
+        sc a0 = sc_zero(), b0 = a0, y0 = a0, a1 = a0, b1 = a0, y1 = a0;
+#pragma unroll 1
         for (int s = 0; s < 2; s++) {
             const u32 k = s ? nh + i : i;
             sc l0, r0, r1;
             sc l1 = load_sc(&sL[c * N + k]);
             slot_vectors(cp[c], pt[c], n, k, vshift[(size_t)c * m + k / n], load_sc(&sR[c * N + k]), l0, r0, r1, two_pow);
-            av[s] = sc_add(l0, sc_montmul(l1, x));
-            bv[s] = sc_add(r0, sc_montmul(r1, x));
-            yv[s] = pt_pow(pt[c].yinv, cp[c].yinvpow2, k);
-            store_sc(&a[c * N + k], av[s]); store_sc(&b[c * N + k], bv[s]); store_sc(&yinvpow[c * N + k], yv[s]);
+            sc ao = sc_add(l0, sc_montmul(l1, x));
+            sc bo = sc_add(r0, sc_montmul(r1, x));
+            sc yo = pt_pow(pt[c].yinv, cp[c].yinvpow2, k);
+            store_sc(&a[c * N + k], ao); store_sc(&b[c * N + k], bo); store_sc(&yinvpow[c * N + k], yo);
+            if (s == 0) { a0 = ao; b0 = bo; y0 = yo; } else { a1 = ao; b1 = bo; y1 = yo; }
         }
-        store_sc(&sl[i], sc_from_mont(sc_montmul(av[1], sG)));
-        store_sc(&sl[N + i], sc_from_mont(sc_montmul(bv[1], sc_montmul(sH0, yv[0]))));
-        store_sc(&sl[nh + i], sc_from_mont(sc_montmul(av[0], sG)));
-        store_sc(&sl[N + nh + i], sc_from_mont(sc_montmul(bv[0], sc_montmul(sH0, yv[1]))));
-        v[0] = sc_add(v[0], sc_montmul(av[0], bv[1]));
-        v[1] = sc_add(v[1], sc_montmul(av[1], bv[0]));
+        store_sc(&sl[i], sc_from_mont(sc_montmul(a1, sG)));
+        store_sc(&sl[N + i], sc_from_mont(sc_montmul(b1, sc_montmul(sH0, y0))));
+        store_sc(&sl[nh + i], sc_from_mont(sc_montmul(a0, sG)));
+        store_sc(&sl[N + nh + i], sc_from_mont(sc_montmul(b0, sc_montmul(sH0, y1))));
+        v[0] = sc_add(v[0], sc_montmul(a0, b1));
+        v[1] = sc_add(v[1], sc_montmul(a1, b0));
     }
     block_sum_sc<2>(v, lds);
     if (threadIdx.x == 0) {

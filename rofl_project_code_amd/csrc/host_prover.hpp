@@ -324,8 +324,10 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
             FoldTabCfg fc = gens.fc();
             size_t dstride = use_tab ? (size_t)fc.np * FOLD_TAB_DIGITS : 256;
             th = now_ms();
-            int8_t *h_dig = C.h_fdig.as<int8_t>(2 * P * nsrc * dstride);      // the fold's own pinned staging: nothing else writes them while its copies are queued
-            memset(h_dig, 0, 2 * P * nsrc * dstride);
+            const size_t dbytes = use_tab ? 2 : 1;      // table folds: width-9 NAF digits reach +-255 (int16_t); plain NAF: int8_t
+            int8_t *h_dig = C.h_fdig.as<int8_t>(2 * P * nsrc * dstride * dbytes);      // the fold's own pinned staging: nothing else writes them while its copies are queued
+            int16_t *h_dig16 = reinterpret_cast<int16_t *>(h_dig);
+            memset(h_dig, 0, 2 * P * nsrc * dstride * dbytes);
             FoldProb *h_fp = C.h_fprob.as<FoldProb>(2 * P + 2 * P);
             FoldTabProb *h_ftp = reinterpret_cast<FoldTabProb *>(h_fp + 2 * P);
             niels *gnew = C.gbuf[gsel].as<niels>(P * 2 * n_new);
@@ -355,8 +357,8 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
                                 lo >>= (bit0 % 32);
                                 return fc.pb == 64 ? lo : (lo & (((u64)1 << fc.pb) - 1));
                             };
-                            int t1 = wnaf_u64(h_dig + (((2 * c) * nsrc + h) * fc.np + pc) * FOLD_TAB_DIGITS, piece(gc), fc.w);
-                            int t2 = wnaf_u64(h_dig + (((2 * c + 1) * nsrc + h) * fc.np + pc) * FOLD_TAB_DIGITS, piece(hc), fc.w);
+                            int t1 = wnaf_u64(h_dig16 + (((2 * c) * nsrc + h) * fc.np + pc) * FOLD_TAB_DIGITS, piece(gc), fc.w);
+                            int t2 = wnaf_u64(h_dig16 + (((2 * c + 1) * nsrc + h) * fc.np + pc) * FOLD_TAB_DIGITS, piece(hc), fc.w);
                             top = std::max(top, std::max(t1, t2));
                         }
                     } else {
@@ -374,8 +376,8 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
             });
             int top = 0; for (int t : topc) top = std::max(top, t);
             C.tm.t.host_ms += now_ms() - th;
-            int8_t *d_dig = C.naf.as<int8_t>(2 * P * nsrc * dstride);
-            HIPCHK(hipMemcpyAsync(d_dig, h_dig, 2 * P * nsrc * dstride, hipMemcpyHostToDevice, C.stream));
+            int8_t *d_dig = C.naf.as<int8_t>(2 * P * nsrc * dstride * dbytes);
+            HIPCHK(hipMemcpyAsync(d_dig, h_dig, 2 * P * nsrc * dstride * dbytes, hipMemcpyHostToDevice, C.stream));
             void *d_fpv = C.foldprobs.ensure(2 * P * 16);
             if (use_tab) HIPCHK(hipMemcpyAsync(d_fpv, h_ftp, sizeof(FoldTabProb) * 2 * P, hipMemcpyHostToDevice, C.stream));
             else HIPCHK(hipMemcpyAsync(d_fpv, h_fp, sizeof(FoldProb) * 2 * P, hipMemcpyHostToDevice, C.stream));
@@ -403,7 +405,7 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
                 for (u32 k = 0; k <= FOLD_MAXSEG; k++) seg.lo[k] = bounds[k <= K ? k : K];
                 dim3 grid((unsigned)((n_new + 63) / 64), (u32)(2 * P)), block(64, K);
                 uint64_t nz = 0;
-                if (C.tm.enabled) { size_t tot_d = 2 * P * nsrc * dstride; for (size_t q = 0; q < tot_d; q++) nz += h_dig[q] != 0; }
+                if (C.tm.enabled) { size_t tot_d = 2 * P * nsrc * dstride; for (size_t q = 0; q < tot_d; q++) nz += use_tab ? h_dig16[q] != 0 : h_dig[q] != 0; }
                 // algorithmic work per output: the non-zero digits of its problem (mixed additions) and ONE chain of top+1 doublings
                 // (the K-1 redundant chains of a segmented launch buy latency, they are not work)
                 uint64_t fold_muls = (nz * 7 / (2 * P) + (uint64_t)(top + 1) * 8 + 7) * (uint64_t)(2 * P * n_new);
@@ -415,7 +417,7 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
                 ge *ext = defer ? C.foldext.as<ge>(2 * P * n_new) : nullptr;
                 if (use_tab) {
                     hipLaunchKernelGGL(k_fold_gens_tab, grid, block, (K - 1) * 64 * sizeof(ge), C.stream, (u32)n_new, nsrc, seg, fc, tbl, (size_t)(2 * N),
-                                       (const FoldTabProb *)d_fpv, d_dig, unit, ext);
+                                       (const FoldTabProb *)d_fpv, reinterpret_cast<const int16_t *>(d_dig), unit, ext);
                   if (defer) {
                     if (!C.ev_norm) { HIPCHK(hipEventCreateWithFlags(&C.ev_norm, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&C.ev_norm0, hipEventDisableTiming)); }
                     HIPCHK(hipEventRecord(C.ev_norm0, C.stream));

@@ -34,8 +34,8 @@ static const Knob KNOBS[] = {
     {"ROFL_SYNC_POLL", "0", "1 = wait for the lane's stream with hipStreamQuery in a pause loop instead of hipStreamSynchronize"},
     {"ROFL_FOLD_TAB", "1", "0 = first fold without the precomputed odd-multiple slices"},
     {"ROFL_FOLD_PB", "32", "piece width of the fold table in bits (16, 32, 64)"},
-    {"ROFL_FOLD_W", "8", "NAF width of the fold table (3..8; narrowed until the table fits ROFL_FOLD_TAB_MB)"},
-    {"ROFL_FOLD_TAB_MB", "32768", "HBM budget of one (n, m) fold table"},
+    {"ROFL_FOLD_W", "9", "NAF width of the fold table (3..9: 2^(w-2) odd multiples per 32-bit piece, 1/(w+1) of the digits non-zero; narrowed until the table fits ROFL_FOLD_TAB_MB)"},
+    {"ROFL_FOLD_TAB_MB", "57344", "HBM budget of one (n, m) fold table (cfg 2 at width 9 and cfg 4 at width 8: 51.2 GB)"},
     {"ROFL_FOLD_UNIT", "1", "0 = do not keep the common factor s_0 of a fold in gscale / hscale"},
     {"ROFL_FOLD_K", "0", "digit-position segments per fold output (1, 2, 4; 0 = by launch size)"},
     {"ROFL_FOLD_THREADS", "131072", "fold launches with fewer threads split their chains into segments"},
@@ -124,13 +124,13 @@ int sc_naf(int8_t out[256], const sc &k) {
 
 // width-4 NAF (digits in +-{1,3,5,7}) of a 64-bit piece; returns the highest non-zero position (-1 if zero)
 // width-w NAF of a piece of at most 64 bits: odd digits |d| < 2^(w-1), at most one non-zero among w consecutive positions
-int wnaf_u64(int8_t out[FOLD_TAB_DIGITS], u64 piece, unsigned w) {
+int wnaf_u64(int16_t out[FOLD_TAB_DIGITS], u64 piece, unsigned w) {
     unsigned __int128 k = piece; int top = -1;
     const int full = 1 << w, half = 1 << (w - 1);
     for (int pos = 0; pos < FOLD_TAB_DIGITS; pos++) {
         int d = 0;
         if (k & 1) { d = (int)(k & (unsigned)(full - 1)); if (d >= half) d -= full; if (d >= 0) k -= (unsigned)d; else k += (unsigned)(-d); top = pos; }
-        out[pos] = (int8_t)d; k >>= 1;
+        out[pos] = (int16_t)d; k >>= 1;
     }
     return top;
 }
@@ -517,7 +517,7 @@ struct Ctx {
     std::vector<std::thread> gens_upgrades;                                // background builders of the full fold tables (joined at exit)
     std::map<std::pair<size_t, size_t>, int> gens_pending;                 // shapes whose full table is still being built (rofl_bp_gens_prepare waits for them)
     u64 gens_tick = 0; size_t gens_budget = (size_t)96 << 30;   // ROFL_GENS_BUDGET_MB: evict least recently used (unpinned) tables beyond this
-    u32 fold_pb = 32, fold_w = 8; size_t fold_tab_budget = (size_t)32 << 30;   // widest NAF whose table fits the per-(n, m) budget (ROFL_FOLD_W, ROFL_FOLD_TAB_MB)
+    u32 fold_pb = 32, fold_w = 9; size_t fold_tab_budget = (size_t)56 << 30;   // widest NAF whose table fits the per-(n, m) budget (ROFL_FOLD_W, ROFL_FOLD_TAB_MB)
     int msm_lds = 1, msm_two_level = 1, msm_group_reduce = 0; size_t msm_lds_min = 8192, msm_lds_tile = 131072;
     size_t msm_fb_threads = (size_t)1 << 19;
     int msm_fb = 1; size_t msm_fb_min = (size_t)1 << 12; int msm_lr = 1;   // window tables for every (n, m) with 2N >= 4096: many small chunks (n_partition = 64) share them
@@ -636,7 +636,7 @@ struct Ctx {
         if (const char *e = knob("ROFL_FOLD_TAB")) fold_tab = atoi(e) != 0;
         if (const char *e = knob("ROFL_GENS_BUDGET_MB")) { long v = atol(e); if (v >= 1) gens_budget = (size_t)v << 20; }
         if (const char *e = knob("ROFL_FOLD_PB")) { int v = atoi(e); if (v == 16 || v == 32 || v == 64) fold_pb = (u32)v; }
-        if (const char *e = knob("ROFL_FOLD_W")) { int v = atoi(e); if (v >= 3 && v <= 8) fold_w = (u32)v; }
+        if (const char *e = knob("ROFL_FOLD_W")) { int v = atoi(e); if (v >= 3 && v <= 9) fold_w = (u32)v; }
         if (const char *e = knob("ROFL_FOLD_TAB_MB")) { long v = atol(e); if (v >= 1) fold_tab_budget = (size_t)v << 20; }
         if (const char *e = knob("ROFL_FOLD_UNIT")) fold_unit = atoi(e) != 0;
         if (const char *e = knob("ROFL_FOLD_K")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) fold_k = v; }
@@ -897,7 +897,7 @@ GensPin get_gens(Ctx &C, size_t n, size_t m) {
     FoldTabCfg fc{P0.fold_pb, P0.fold_w, 256 / P0.fold_pb, 1u << (P0.fold_w - 2)};
     // HBM capacity for VALU work: a width-w NAF needs 2^(w-2) odd multiples per piece and leaves 1/(w+1) of the digits non-zero
     while (fc.w > 6 && sizeof(niels) * 2 * N * fc.np * fc.e > P0.fold_tab_budget) { fc.w--; fc.e = 1u << (fc.w - 2); }
-    if (sizeof(niels) * 2 * N * fc.np * fc.e > ((size_t)40 << 30)) fc = FoldTabCfg{64, 4, 4, 4};     // very large tables: the compact layout
+    if (sizeof(niels) * 2 * N * fc.np * fc.e > std::max(P0.fold_tab_budget, (size_t)40 << 30)) fc = FoldTabCfg{64, 4, 4, 4};     // very large tables: the compact layout
     // Fast start: allocating a 25 GB table takes 0 - 0.7 s depending on the state of the box, and the first call of a process waited for it.
     // The first calls are served from the compact 16-slice fold table (0.8 GB at cfg 2; the first fold is ~2.5 ms slower) while a background
     // thread allocates and builds the full table, then swaps it in; calls that still read the compact entry keep it alive until they return.

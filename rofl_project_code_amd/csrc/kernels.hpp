@@ -863,7 +863,7 @@ __global__ void __launch_bounds__(256, 2) k_fold_gens4(u32 n_new, FoldSeg seg, c
 struct FoldTabProb { u32 src_off; niels *dst; };
 #if ROFL_KG(2)
 __global__ void __launch_bounds__(256, 4) k_fold_gens_tab(u32 n_new, u32 nsrc, FoldSeg seg, FoldTabCfg cfg, const niels *tbl16, size_t stride,
-                                                       const FoldTabProb *probs, const int8_t *dig /* [prob][nsrc][np][72] */, int unit_first, ge *ext_out) {
+                                                       const FoldTabProb *probs, const int16_t *dig /* [prob][nsrc][np][72] */, int unit_first, ge *ext_out) {
     extern __shared__ __align__(16) unsigned char smem[];
     ge *lds = reinterpret_cast<ge *>(smem);
     u32 q = blockIdx.y;
@@ -871,7 +871,7 @@ __global__ void __launch_bounds__(256, 4) k_fold_gens_tab(u32 n_new, u32 nsrc, F
     u32 k = threadIdx.y, K = blockDim.y;
     bool active = i < n_new;
     const niels *src = tbl16 + probs[q].src_off;
-    const int8_t *dg = dig + (size_t)q * nsrc * cfg.np * FOLD_TAB_DIGITS;
+    const int16_t *dg = dig + (size_t)q * nsrc * cfg.np * FOLD_TAB_DIGITS;
     gd acc = gd_identity();
     if (active) {
         int lo = seg.lo[k], hi = seg.lo[k + 1] - 1;

@@ -69,7 +69,7 @@ def parse_args():
                          "is mapped before torch is imported, so the library runs on it while torch keeps its own copy for the contract's torch.cuda.synchronize() "
                          "(N = 1 only); auto (default): an N = 1 run (no process group) happens in a child process in `system` mode and falls back to `process` if that "
                          "child fails; N > 1 and --one-process are `process`.  profiles/r04_experiments.txt item 13")
-    ap.add_argument("--compact-tables", action="store_true", help="the 16-slice fold table (ROFL_FOLD_PB=64, ROFL_FOLD_W=4: 0.8-1.9 GB per shape instead of 52 GB; the first fold of a proof is ~2.5 ms slower) -- for rehearsals that put eight device contexts on ONE GPU")
+    ap.add_argument("--compact-tables", action="store_true", help="the 16-slice fold table (ROFL_FOLD_PB=64, ROFL_FOLD_W=4: 0.8-1.9 GB per shape instead of 104 GB; the first fold of a proof is ~2.5 ms slower) -- for rehearsals that put eight device contexts on ONE GPU")
     ap.add_argument("--clients", type=int, default=48, help="clients of configs 4 / 5 (cifar_large.yml: 48)")
     ap.add_argument("--l2-create-batch", type=int, default=-1, help="--config 5: clients per EncParamsL2.encrypt_batch call (their 8-bit legs as one rofl_create_rangeproof_batch); 0 / 1 = one encrypt() per client; default 4")
     return ap.parse_args()

@@ -24,7 +24,8 @@ static const Knob KNOBS[] = {
     {"ROFL_GENS_LAZY", "1", "0 = the first call of a shape waits for its full fold table (otherwise it is served from the compact table while a background thread builds the full one)"},
     {"ROFL_GENS_LAZY_IDLE_MS", "20", "the background build of a full fold table starts when no call has been in flight for this long (its allocation stalls every HIP call of the process)"},
     {"ROFL_GENS_LAZY_MAX_WAIT_MS", "3000", "... or after this long, whichever comes first (a host that never pauses still gets its full table)"},
-    {"ROFL_GENS_BUDGET_MB", "98304", "HBM budget of the generator-table cache (LRU eviction of unpinned entries beyond it)"},
+    {"ROFL_GENS_RESERVE_MB", "40960", "HBM a table allocation of 4 GB or more leaves free on the device (other contexts / processes / workspaces; the runtime aborts when HBM runs out): the table is narrowed instead"},
+    {"ROFL_GENS_BUDGET_MB", "131072", "HBM budget of the generator-table cache (LRU eviction of unpinned entries beyond it)"},
     {"ROFL_FOLD_T1", "3", "IPP rounds before the first generator fold (1..6)"},
     {"ROFL_FOLD_T", "2", "IPP rounds between later folds (1..6)"},
     {"ROFL_FOLD_MIN", "1024", "no fold once fewer generators per chunk would remain (launches with many chunks fold down to 64)"},
@@ -34,8 +35,8 @@ static const Knob KNOBS[] = {
     {"ROFL_SYNC_POLL", "0", "1 = wait for the lane's stream with hipStreamQuery in a pause loop instead of hipStreamSynchronize"},
     {"ROFL_FOLD_TAB", "1", "0 = first fold without the precomputed odd-multiple slices"},
     {"ROFL_FOLD_PB", "32", "piece width of the fold table in bits (16, 32, 64)"},
-    {"ROFL_FOLD_W", "9", "NAF width of the fold table (3..9: 2^(w-2) odd multiples per 32-bit piece, 1/(w+1) of the digits non-zero; narrowed until the table fits ROFL_FOLD_TAB_MB)"},
-    {"ROFL_FOLD_TAB_MB", "57344", "HBM budget of one (n, m) fold table (cfg 2 at width 9 and cfg 4 at width 8: 51.2 GB)"},
+    {"ROFL_FOLD_W", "10", "NAF width of the fold table (3..10: 2^(w-2) odd multiples per 32-bit piece, 1/(w+1) of the digits non-zero; narrowed until the table fits ROFL_FOLD_TAB_MB)"},
+    {"ROFL_FOLD_TAB_MB", "106496", "HBM budget of one (n, m) fold table (cfg 2 at width 10 and cfg 4 at width 9: 102.4 GB of the 288; 57344 = one width less, half the memory, +0.25 ms per cfg-2 proof)"},
     {"ROFL_FOLD_UNIT", "1", "0 = do not keep the common factor s_0 of a fold in gscale / hscale"},
     {"ROFL_FOLD_K", "0", "digit-position segments per fold output (1, 2, 4; 0 = by launch size)"},
     {"ROFL_FOLD_THREADS", "131072", "fold launches with fewer threads split their chains into segments"},
@@ -516,8 +517,8 @@ struct Ctx {
     std::vector<std::unique_ptr<GensEntry>> gens_retired;                  // fast-start entries that were replaced while calls still read them (freed when unpinned)
     std::vector<std::thread> gens_upgrades;                                // background builders of the full fold tables (joined at exit)
     std::map<std::pair<size_t, size_t>, int> gens_pending;                 // shapes whose full table is still being built (rofl_bp_gens_prepare waits for them)
-    u64 gens_tick = 0; size_t gens_budget = (size_t)96 << 30;   // ROFL_GENS_BUDGET_MB: evict least recently used (unpinned) tables beyond this
-    u32 fold_pb = 32, fold_w = 9; size_t fold_tab_budget = (size_t)56 << 30;   // widest NAF whose table fits the per-(n, m) budget (ROFL_FOLD_W, ROFL_FOLD_TAB_MB)
+    u64 gens_tick = 0; size_t gens_budget = (size_t)128 << 30;   // ROFL_GENS_BUDGET_MB: evict least recently used (unpinned) tables beyond this
+    u32 fold_pb = 32, fold_w = 10; size_t fold_tab_budget = (size_t)104 << 30;   // widest NAF whose table fits the per-(n, m) budget (ROFL_FOLD_W, ROFL_FOLD_TAB_MB)
     int msm_lds = 1, msm_two_level = 1, msm_group_reduce = 0; size_t msm_lds_min = 8192, msm_lds_tile = 131072;
     size_t msm_fb_threads = (size_t)1 << 19;
     int msm_fb = 1; size_t msm_fb_min = (size_t)1 << 12; int msm_lr = 1;   // window tables for every (n, m) with 2N >= 4096: many small chunks (n_partition = 64) share them
@@ -636,7 +637,7 @@ struct Ctx {
         if (const char *e = knob("ROFL_FOLD_TAB")) fold_tab = atoi(e) != 0;
         if (const char *e = knob("ROFL_GENS_BUDGET_MB")) { long v = atol(e); if (v >= 1) gens_budget = (size_t)v << 20; }
         if (const char *e = knob("ROFL_FOLD_PB")) { int v = atoi(e); if (v == 16 || v == 32 || v == 64) fold_pb = (u32)v; }
-        if (const char *e = knob("ROFL_FOLD_W")) { int v = atoi(e); if (v >= 3 && v <= 9) fold_w = (u32)v; }
+        if (const char *e = knob("ROFL_FOLD_W")) { int v = atoi(e); if (v >= 3 && v <= 10) fold_w = (u32)v; }
         if (const char *e = knob("ROFL_FOLD_TAB_MB")) { long v = atol(e); if (v >= 1) fold_tab_budget = (size_t)v << 20; }
         if (const char *e = knob("ROFL_FOLD_UNIT")) fold_unit = atoi(e) != 0;
         if (const char *e = knob("ROFL_FOLD_K")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) fold_k = v; }
@@ -786,7 +787,16 @@ void gens_evict(Ctx &P0, size_t keep_bytes, const GensEntry *spare) {
         P0.gens.erase(victim);
     }
 }
+// Big tables never take the device below a reserve (ROFL_GENS_RESERVE_MB): other contexts and processes on the same GPU, the lanes' workspaces
+// and the runtime's own queues and scratch allocate later, and the runtime does not fail when HBM is gone -- it ABORTS the process
+// (HSA_STATUS_ERROR_OUT_OF_RESOURCES: seen with two contexts holding 100 GB fold tables each and a third process starting).  The caller
+// narrows the table and tries again.
 hipError_t gens_malloc(Ctx &P0, void **p, size_t bytes, const GensEntry *spare) {
+    if (bytes >= ((size_t)4 << 30)) {
+        static const size_t reserve = (size_t)(knob("ROFL_GENS_RESERVE_MB") ? atol(knob("ROFL_GENS_RESERVE_MB")) : 40960) << 20;
+        auto fits = [&] { size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return true; } return fr >= bytes + reserve; };
+        if (!fits()) { gens_evict(P0, 0, spare); if (!fits()) return hipErrorOutOfMemory; }
+    }
     hipError_t e = hipMalloc(p, bytes);
     if (e == hipSuccess) return e;
     (void)hipGetLastError();
@@ -846,7 +856,7 @@ bool gens_upgrade(Ctx &P0, GensEntry *raw, std::pair<size_t, size_t> key, FoldTa
         }
     }
     if (hipSetDevice(P0.phys) != hipSuccess) { (void)hipGetLastError(); give_up(-1); return false; }
-    const size_t bytes = sizeof(niels) * 2 * N * fc_full.np * fc_full.e;
+    size_t bytes = sizeof(niels) * 2 * N * fc_full.np * fc_full.e;
     void *tv = nullptr; hipStream_t bs = nullptr;
     const bool btrace = knob("ROFL_TRACE") && atoi(knob("ROFL_TRACE")) >= 2; const double bt0 = now_ms();
     {   // the allocation goes through the cache's own allocator: room is made within the budget first (unpinned entries, least recently used),
@@ -854,6 +864,11 @@ bool gens_upgrade(Ctx &P0, GensEntry *raw, std::pair<size_t, size_t> key, FoldTa
         std::lock_guard<std::mutex> lk(P0.gens_mu);
         gens_evict(P0, P0.gens_budget > bytes ? P0.gens_budget - bytes : 0, raw);
         if (gens_malloc(P0, &tv, bytes, raw) != hipSuccess) tv = nullptr;
+        while (!tv && fc_full.pb != 64 && fc_full.w > 7) {      // HBM is short: one NAF width less = half the table
+            fc_full.w--; fc_full.e = 1u << (fc_full.w - 2);
+            bytes = sizeof(niels) * 2 * N * fc_full.np * fc_full.e;
+            if (gens_malloc(P0, &tv, bytes, raw) != hipSuccess) tv = nullptr;
+        }
     }
     if (!tv) { give_up(-1); return false; }      // HBM is short: the compact table stays; rofl_bp_gens_prepare reports it / tries again
     if (btrace) fprintf(stderr, "[rofl-trace gens-upgrade] hipMalloc of %.1f GB +%.3f ms\n", bytes / 1e9, now_ms() - bt0);
@@ -907,7 +922,11 @@ GensPin get_gens(Ctx &C, size_t n, size_t m) {
     if (lazy) fc = FoldTabCfg{64, 4, 4, 4};
     void *tblv = nullptr;
     hipError_t me = gens_malloc(P0, &tblv, sizeof(niels) * 2 * N * fc.np * fc.e, nullptr);      // slice 0 = generators, the rest = fold tables
-    if (me != hipSuccess && !(fc.pb == 64 && fc.w == 4)) {      // HBM is short even after eviction: the compact fold-table layout (16 slices)
+    while (me != hipSuccess && !(fc.pb == 64 && fc.w == 4) && fc.w > 7) {      // HBM is short: one NAF width less = half the table
+        fc.w--; fc.e = 1u << (fc.w - 2);
+        me = gens_malloc(P0, &tblv, sizeof(niels) * 2 * N * fc.np * fc.e, nullptr);
+    }
+    if (me != hipSuccess && !(fc.pb == 64 && fc.w == 4)) {      // still short even after eviction: the compact fold-table layout (16 slices)
         fc = FoldTabCfg{64, 4, 4, 4};
         me = gens_malloc(P0, &tblv, sizeof(niels) * 2 * N * fc.np * fc.e, nullptr);
     }

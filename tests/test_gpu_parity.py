@@ -588,6 +588,7 @@ def test_bsgs_discrete_log(R):
     {"ROFL_VERIFY_BATCH": "0", "ROFL_FOLD_PB": "64", "ROFL_FOLD_W": "4", "ROFL_LANES": "1"},
     {"ROFL_FOLD_PB": "16", "ROFL_FOLD_W": "5", "ROFL_FOLD_T1": "2", "ROFL_FOLD_MIN": "16"},
     {"ROFL_GENS_BUDGET_MB": "1", "ROFL_LANES": "2"},                      # every new (n, m) evicts the previous tables
+    {"ROFL_GENS_RESERVE_MB": "400000"},                                   # no big table may be allocated (reserve > HBM): fold tables of 4 GB and more are narrowed until they fit
     {"ROFL_MSM_DEV_HORNER_MIN": "1", "ROFL_MSM_FB": "0"},                 # every MSM finishes its Horner chains on the device
     {"ROFL_MSM_DEV_HORNER_MIN": "1", "ROFL_MSM_FB_MIN": "64"},
     {"ROFL_MSM_SMALL_MAX": "0"},                                          # the general pipeline at the sizes the fused small-MSM launch normally takes

@@ -195,6 +195,11 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
         HIPCHK(hipMemcpyAsync(d_q, h_q, sizeof(niels) * P, hipMemcpyHostToDevice, C.stream));
     }
     bool ip_included = false, pts_pending = false;
+    // odd multiples of the materialised generators for the next (non-table) fold, built on a stream of their own while the rounds before it run
+    const int fold_wnaf = C.fold_unit ? C.fold_wnaf : 0;
+    const u32 mult_E = fold_wnaf ? 1u << (fold_wnaf - 2) : 0;
+    bool mult_ready = false, mult_used = false; const niels *mult_base = nullptr; size_t mult_count = 0;
+    struct JoinMult { Ctx &c; bool &used; ~JoinMult() { if (used && c.stream3) (void)hipStreamSynchronize(c.stream3); } } join_mult{C, mult_used};      // nothing of that stream outlives the call
     std::vector<ge5> cq;      // per round: c_L w B, c_R w B of every chunk, computed while the round's MSM runs
     for (unsigned round = 0; round < lgN; round++) {
         size_t n_k = n_g >> r, nh = n_k / 2;
@@ -321,6 +326,9 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
             size_t n_new = n_g >> r; u32 nsrc = 1u << r;
             bool use_tab = first_level && C.fold_tab;
             int unit = C.fold_unit;
+            // width-w NAF over the odd multiples that were built since the previous fold (all chunks' sources are one contiguous array)
+            const bool use_w = !use_tab && mult_ready && unit && nsrc <= 64 && mult_base == cur[0] && mult_count == 2 * P * n_g;
+            std::vector<std::vector<u32>> evs(use_w ? 2 * P : 0);
             FoldTabCfg fc = gens.fc();
             size_t dstride = use_tab ? (size_t)fc.np * FOLD_TAB_DIGITS : 256;
             th = now_ms();
@@ -361,6 +369,13 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
                             int t2 = wnaf_u64(h_dig16 + (((2 * c + 1) * nsrc + h) * fc.np + pc) * FOLD_TAB_DIGITS, piece(hc), fc.w);
                             top = std::max(top, std::max(t1, t2));
                         }
+                    } else if (use_w) {
+                        int8_t dg[2][256];
+                        int t1 = sc_wnaf(dg[0], gc, (unsigned)fold_wnaf), t2 = sc_wnaf(dg[1], hc, (unsigned)fold_wnaf);
+                        for (int sd = 0; sd < 2; sd++)
+                            for (int b = 0; b <= (sd ? t2 : t1); b++)
+                                if (int d = dg[sd][b]) evs[2 * c + sd].push_back(FOLD_EV(b, h, (u32)((d < 0 ? -d : d) - 1) >> 1, d < 0));
+                        top = std::max(top, std::max(t1, t2));
                     } else {
                         int t1 = sc_naf(h_dig + ((2 * c) * nsrc + h) * 256, gc);
                         int t2 = sc_naf(h_dig + ((2 * c + 1) * nsrc + h) * 256, hc);
@@ -392,7 +407,7 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
                 if (C.fold_k > 0) K = (u32)C.fold_k;
                 FoldSeg seg{};
                 double eff = (double)(nsrc - (unit ? 1 : 0));
-                double cst = 1.0 + (use_tab ? eff * fc.np / (fc.w + 1.0) : eff / 3.0), lo_t = 0, hi_t = (top + 1) * cst + top + 1;
+                double cst = 1.0 + (use_tab ? eff * fc.np / (fc.w + 1.0) : use_w ? eff / (fold_wnaf + 1.0) : eff / 3.0), lo_t = 0, hi_t = (top + 1) * cst + top + 1;
                 int bounds[FOLD_MAXSEG + 1];
                 for (int it = 0; it < 60; it++) {
                     double T = 0.5 * (lo_t + hi_t), pos = 0;
@@ -405,7 +420,7 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
                 for (u32 k = 0; k <= FOLD_MAXSEG; k++) seg.lo[k] = bounds[k <= K ? k : K];
                 dim3 grid((unsigned)((n_new + 63) / 64), (u32)(2 * P)), block(64, K);
                 uint64_t nz = 0;
-                if (C.tm.enabled) { size_t tot_d = 2 * P * nsrc * dstride; for (size_t q = 0; q < tot_d; q++) nz += use_tab ? h_dig16[q] != 0 : h_dig[q] != 0; }
+                if (C.tm.enabled) { size_t tot_d = 2 * P * nsrc * dstride; if (use_w) { for (auto &e : evs) nz += e.size(); } else for (size_t q = 0; q < tot_d; q++) nz += use_tab ? h_dig16[q] != 0 : h_dig[q] != 0; }
                 // algorithmic work per output: the non-zero digits of its problem (mixed additions) and ONE chain of top+1 doublings
                 // (the K-1 redundant chains of a segmented launch buy latency, they are not work)
                 uint64_t fold_muls = (nz * 7 / (2 * P) + (uint64_t)(top + 1) * 8 + 7) * (uint64_t)(2 * P * n_new);
@@ -428,6 +443,31 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
                     pts_pending = true;
                   }
                 }
+                else if (use_w) {
+                    // events of every problem, highest bit first; a segment starts at its first event at or below its top bit
+                    size_t tot_ev = 0; for (auto &e : evs) tot_ev += e.size();
+                    u32 *h_ev = C.h_fev.as<u32>(tot_ev + 4 + (2 * P * sizeof(FoldWProb) + 3) / 4);
+                    FoldWProb *h_wp = reinterpret_cast<FoldWProb *>(h_ev + ((tot_ev + 2) & ~(size_t)1));
+                    size_t off = 0;
+                    for (size_t q = 0; q < 2 * P; q++) {
+                        std::vector<u32> &e = evs[q];
+                        std::stable_sort(e.begin(), e.end(), [](u32 x, u32 y) { return (x & 511u) > (y & 511u); });
+                        FoldWProb &w = h_wp[q];
+                        w.src = h_fp[q].src; w.dst = h_fp[q].dst; w.tab_off = (u32)(h_fp[q].src - mult_base); w.ev_off = (u32)off; w.n_ev = (u32)e.size();
+                        for (u32 k = 0; k < FOLD_MAXSEG; k++) {
+                            const int hi = seg.lo[std::min<u32>(k + 1, FOLD_MAXSEG)] - 1;
+                            u32 j = 0; while (j < e.size() && (int)(e[j] & 511u) > hi) j++;
+                            w.seg_start[k] = j;
+                        }
+                        memcpy(h_ev + off, e.data(), e.size() * sizeof(u32)); off += e.size();
+                    }
+                    u32 *d_ev = C.fold_ev.as<u32>(tot_ev + 4 + (2 * P * sizeof(FoldWProb) + 3) / 4);
+                    const size_t wp_off = (tot_ev + 2) & ~(size_t)1;
+                    HIPCHK(hipMemcpyAsync(d_ev, h_ev, (wp_off) * sizeof(u32) + 2 * P * sizeof(FoldWProb), hipMemcpyHostToDevice, C.stream));
+                    HIPCHK(hipStreamWaitEvent(C.stream, C.ev_mult, 0));      // the table was built beside the last rounds
+                    hipLaunchKernelGGL(k_fold_gens_w, grid, block, (K - 1) * 64 * sizeof(ge), C.stream, (u32)n_new, seg, reinterpret_cast<const FoldWProb *>(d_ev + wp_off),
+                                       (const u32 *)d_ev, (const niels *)C.fmul_tab.p, mult_count);
+                }
                 else if (nsrc == 4 && unit && fold_regs)      // three scalar-carrying sources, kept in registers
                     hipLaunchKernelGGL(k_fold_gens4, grid, block, (K - 1) * 64 * sizeof(ge), C.stream, (u32)n_new, seg, (const FoldProb *)d_fpv, d_dig);
                 else
@@ -440,6 +480,26 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
             if (ptrace) C.sync();      // the phase trace wants the fold's own wall time
             mark("fold", (long)n_new);
             for (size_t c = 0; c < P; c++) { cur[c] = gnew + c * 2 * n_new; pu[c].clear(); pui[c].clear(); }
+            mult_ready = false;
+            {   // will there be another fold, fold_t rounds from here?  Then its sources' odd multiples are built now, off the critical path.
+                const size_t n_next = n_new >> C.fold_t;
+                const bool next_pays = n_next >= C.fold_min || (n_next >= 64 && 2 * P * n_next >= 8 * C.fold_min);
+                const size_t cnt = 2 * P * n_new;
+                if (mult_E > 1 && (size_t)round + C.fold_t + 1 < lgN && next_pays && ((size_t)1 << C.fold_t) <= 64 && cnt <= ((size_t)1 << 22)) {
+                    if (!C.stream3) HIPCHK(hipStreamCreateWithFlags(&C.stream3, hipStreamNonBlocking));
+                    if (!C.ev_mult) { HIPCHK(hipEventCreateWithFlags(&C.ev_mult, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&C.ev_mult0, hipEventDisableTiming)); }
+                    ge *mext = C.fmul_ext.as<ge>((mult_E - 1) * cnt);
+                    niels *mtab = C.fmul_tab.as<niels>((mult_E - 1) * cnt);
+                    // the points must be there in affine form: after the side-stream conversion of a deferred first fold, or after the fold kernel itself
+                    if (pts_pending) HIPCHK(hipStreamWaitEvent(C.stream3, C.ev_norm, 0));
+                    else { HIPCHK(hipEventRecord(C.ev_mult0, C.stream)); HIPCHK(hipStreamWaitEvent(C.stream3, C.ev_mult0, 0)); }
+                    hipLaunchKernelGGL(k_odd_multiples, grid1(cnt), dim3(TPB), 0, C.stream3, (u32)cnt, mult_E, (const niels *)gnew, mext);
+                    const size_t tot = (mult_E - 1) * cnt;
+                    hipLaunchKernelGGL(k_niels_batch, grid1((tot + NB_BATCH - 1) / NB_BATCH), dim3(TPB), 0, C.stream3, (u32)tot, (const ge *)mext, mtab);
+                    HIPCHK(hipEventRecord(C.ev_mult, C.stream3));
+                    mult_ready = true; mult_used = true; mult_base = gnew; mult_count = cnt;
+                }
+            }
             n_g = n_new; r = 0; gsel ^= 1; first_level = false; just_materialised = true;
         }
     }

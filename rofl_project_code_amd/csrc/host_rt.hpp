@@ -37,6 +37,7 @@ static const Knob KNOBS[] = {
     {"ROFL_FOLD_PB", "32", "piece width of the fold table in bits (16, 32, 64)"},
     {"ROFL_FOLD_W", "10", "NAF width of the fold table (3..10: 2^(w-2) odd multiples per 32-bit piece, 1/(w+1) of the digits non-zero; narrowed until the table fits ROFL_FOLD_TAB_MB)"},
     {"ROFL_FOLD_TAB_MB", "106496", "HBM budget of one (n, m) fold table (cfg 2 at width 10 and cfg 4 at width 9: 102.4 GB of the 288; 57344 = one width less, half the memory, +0.25 ms per cfg-2 proof)"},
+    {"ROFL_FOLD_WNAF", "0", "later folds: NAF width over odd multiples of the sources built on a side stream during the preceding rounds (3..6; 0 = plain NAF over the sources alone: the build disturbs the rounds it runs beside by what the shorter fold chains save -- measured neutral, off by default)"},
     {"ROFL_FOLD_UNIT", "1", "0 = do not keep the common factor s_0 of a fold in gscale / hscale"},
     {"ROFL_FOLD_K", "0", "digit-position segments per fold output (1, 2, 4; 0 = by launch size)"},
     {"ROFL_FOLD_THREADS", "131072", "fold launches with fewer threads split their chains into segments"},
@@ -104,6 +105,26 @@ sc h_mul(const sc &a, const sc &b) { return sc_mul_plain(a, b); }          // ca
 sc h_inv(const sc &canon) { return h_canon(h51::sc_invert_mont_fast(h_mont(canon))); }
 bool sc_is_canonical_bytes(const uint8_t *b) { sc s = sc_frombytes(b); return !sc_geq_l(s.v); }
 
+// width-w NAF (3 <= w <= 8) of a canonical scalar: odd digits |d| < 2^(w-1), at most one non-zero among w consecutive positions, density
+// 1 / (w + 1); returns the index of the highest non-zero digit (-1 if zero)
+int sc_wnaf(int8_t out[256], const sc &k, unsigned w) {
+    u32 x[9]; for (int i = 0; i < 8; i++) x[i] = k.v[i]; x[8] = 0;
+    const int full = 1 << w, half = 1 << (w - 1);
+    int top = -1;
+    for (int pos = 0; pos < 256; pos++) {
+        int d = 0;
+        if (x[0] & 1) {
+            d = (int)(x[0] & (u32)(full - 1)); if (d >= half) d -= full;
+            if (d > 0) { x[0] -= (u32)d; }        // (the low w bits are d: no borrow)
+            else { u64 c = (u64)(-d); for (int i = 0; i < 9 && c; i++) { c += x[i]; x[i] = (u32)c; c >>= 32; } }
+            top = pos;
+        }
+        out[pos] = (int8_t)d;
+        for (int i = 0; i < 8; i++) x[i] = (x[i] >> 1) | (x[i + 1] << 31);
+        x[8] >>= 1;
+    }
+    return top;
+}
 // width-2 NAF (digits -1,0,1) of a canonical scalar; returns index of the highest non-zero digit (-1 if zero)
 int sc_naf(int8_t out[256], const sc &k) {
     u32 x[9]; for (int i = 0; i < 8; i++) x[i] = k.v[i]; x[8] = 0;
@@ -508,6 +529,7 @@ struct Ctx {
     std::atomic<int> active_calls{0};  // primary lane only: calls currently holding a lane
     std::atomic<unsigned> rr{0};
     hipStream_t stream = nullptr, stream2 = nullptr;      // stream2: side stream for work that may run beside the main one (created on first use)
+    hipStream_t stream3 = nullptr;                        // the odd-multiple tables of the later folds are built here, beside the rounds that precede the fold
     hipStream_t stream_up = nullptr;                      // uploads of a pipelined batch call: the copy of group g + 1 runs beside the kernels of group g (created on first use)
     std::mutex mu;
     HostTables ht;
@@ -526,7 +548,7 @@ struct Ctx {
     // Waiting for the lane's stream.  hipStreamSynchronize spins (lowest latency: right for a call that is alone on the device); with
     // more than three calls in flight -- or when the host asked for it (ROFL_BLOCKING_SYNC=1) -- the thread sleeps between queries instead, so
     // a server that keeps several clients in flight does not burn one host core per client on busy-waiting (ROFL_BLOCKING_SYNC=0: always spin).
-    hipEvent_t ev_block = nullptr, ev_v = nullptr, ev_fork = nullptr, ev_a = nullptr, ev_a0 = nullptr, ev_m2 = nullptr, ev_m2j = nullptr, ev_norm = nullptr, ev_norm0 = nullptr, ev_ip = nullptr; bool batch_mode = false;
+    hipEvent_t ev_block = nullptr, ev_v = nullptr, ev_fork = nullptr, ev_a = nullptr, ev_a0 = nullptr, ev_m2 = nullptr, ev_m2j = nullptr, ev_norm = nullptr, ev_norm0 = nullptr, ev_ip = nullptr, ev_mult = nullptr, ev_mult0 = nullptr; bool batch_mode = false;
     void sync() {
         const Ctx *P = parent ? parent : this;
         // (up to three calls in flight still spin: the three proofs of ONE client's L2 update run side by side -- EncParamsL2::encrypt --
@@ -574,14 +596,14 @@ struct Ctx {
     size_t msm_small_max = 8192;      // ROFL_MSM_SMALL_MAX: generic MSMs with at most this many terms per problem side run as one fused launch (0 = off)
     size_t msm_dev_horner_min = 32;   // ROFL_MSM_DEV_HORNER_MIN: launches with at least this many problems finish their Horner chains on the device
     bool msm_slots = true;
-    int fold_t = 2, fold_t1 = 3, fold_k = 0, fold_tab = 1, fold_unit = 1; long fold_threads = 131072;
+    int fold_t = 2, fold_t1 = 3, fold_k = 0, fold_tab = 1, fold_unit = 1, fold_wnaf = 0; long fold_threads = 131072;
     Timing tm;
     struct HopStats { double enqueue = 0, sync = 0, horner_wall = 0, horner_cpu = 0, host_wall = 0, host_cpu = 0, max_enqueue = 0, max_sync = 0, max_horner = 0, max_task = 0; int n = 0; } hs;      // where the host hops of the current call go (ROFL_TRACE, rofl_dbg_last_hops)
     // workspace
     DevBuf cp, sL, sR, party, Scanon, vshift, blind, Vbytes, Cbytes, status, partial, partial2, scpart, a, b, a2, b2, ptab[2], yinv,
         SL, SR, powtabs, foldprobs, naf,
-        gbuf[2], aux_pts, aux_scal, vscal, tmp_in, tmp_in2, tmp_out, vals, uni, stream_buf, vgroups, vtabs, ipdev, qpts, vspart, foldext;
-    PinBuf h_cp, h_part, h_misc, h_misc2, h_auxc, h_auxs, h_V, h_ip, h_round, h_fdig, h_fprob, h_abfin, h_vgrp, h_q;
+        gbuf[2], aux_pts, aux_scal, vscal, tmp_in, tmp_in2, tmp_out, vals, uni, stream_buf, vgroups, vtabs, ipdev, qpts, vspart, foldext, fmul_ext, fmul_tab, fold_ev;
+    PinBuf h_cp, h_part, h_misc, h_misc2, h_auxc, h_auxs, h_V, h_ip, h_round, h_fdig, h_fprob, h_abfin, h_vgrp, h_q, h_fev;
     MsmWs mws[2];
     std::map<uint64_t, double> wait_ms;      // how long the wait of a tagged hop took the last times (hint for the pool workers' naps)
 
@@ -640,6 +662,7 @@ struct Ctx {
         if (const char *e = knob("ROFL_FOLD_W")) { int v = atoi(e); if (v >= 3 && v <= 10) fold_w = (u32)v; }
         if (const char *e = knob("ROFL_FOLD_TAB_MB")) { long v = atol(e); if (v >= 1) fold_tab_budget = (size_t)v << 20; }
         if (const char *e = knob("ROFL_FOLD_UNIT")) fold_unit = atoi(e) != 0;
+        if (const char *e = knob("ROFL_FOLD_WNAF")) { int v = atoi(e); if (v == 0 || (v >= 3 && v <= 6)) fold_wnaf = v; }
         if (const char *e = knob("ROFL_FOLD_K")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) fold_k = v; }
         if (const char *e = knob("ROFL_FOLD_THREADS")) { long v = atol(e); if (v > 0) fold_threads = v; }
         if (const char *e = knob("ROFL_LANES")) {      // out-of-range values are clamped, not ignored: the caller sized its thread pool by them
@@ -658,7 +681,7 @@ struct Ctx {
         msm_fb_threads = p.msm_fb_threads;
         msm_fb = p.msm_fb; msm_fb_min = p.msm_fb_min; msm_lr = p.msm_lr;
         fold_min = p.fold_min; msm_dev_horner_min = p.msm_dev_horner_min; msm_small_max = p.msm_small_max; msm_slots = p.msm_slots; fold_t = p.fold_t; fold_t1 = p.fold_t1; fold_k = p.fold_k; fold_tab = p.fold_tab;
-        fold_unit = p.fold_unit; fold_threads = p.fold_threads; nlanes = 1;
+        fold_unit = p.fold_unit; fold_wnaf = p.fold_wnaf; fold_threads = p.fold_threads; nlanes = 1;
         // (the other lanes: up to twelve -- a batched server call that lands on a sibling lane stages hundreds of MB through its pool, and which of two
         //  concurrent batch calls finds the primary lane free is a race; idle workers sleep on their futex words and cost nothing)
         { int nt = std::min(12, std::max(6, usable_cores())); if (const char *e = knob("ROFL_HOST_THREADS")) nt = atoi(e); if (nt < 1) nt = 1; pool.reset(new HostPool(nt, &g_calls_in_flight)); }

@@ -855,6 +855,74 @@ __global__ void __launch_bounds__(256, 2) k_fold_gens4(u32 n_new, FoldSeg seg, c
 }
 #endif
 
+// Later folds with odd multiples of their sources.  The sources of a later fold are the previous fold's outputs -- proof-specific, so nothing
+// can be precomputed across proofs; but they exist two rounds before the fold needs them.  k_odd_multiples builds (2e+1) P for e = 1 .. E-1 of
+// every materialised point on the SIDE stream while those rounds run (extended coordinates; k_niels_batch turns them into affine niels, eight
+// per inversion), and the fold walks width-w NAF digits (one non-zero in w + 1 positions instead of one in three): its chain -- the critical
+// path of the phase, at two waves per SIMD -- loses a third of its additions for work that was done off the path.
+#if ROFL_KG(2)
+__global__ void __launch_bounds__(TPB) k_odd_multiples(u32 count, u32 E, const niels *src, ge *ext /* [E-1][count] */) {
+    const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    const gd p = gd_unpack(ge_from_niels(load_niels(&src[j])));
+    const gd p2 = gd_double(p);
+    gd cur = p;
+    for (u32 e = 1; e < E; e++) { cur = gd_add(cur, p2); store_gd(&ext[(size_t)(e - 1) * count + j], cur); }
+}
+#endif
+// The fold itself: an EVENT list per problem instead of digit arrays -- (bit, source, multiple, sign), highest bit first, wave-uniform -- so
+// that the operand of the next addition is fetched while the doublings in front of it run (the table is in HBM: gathered inside the chain,
+// as the generic kernel does with its sources, every addition waited ~1.7 us for its operand).  Segments as in k_fold_gens.
+struct FoldWProb { const niels *src; niels *dst; u32 tab_off, ev_off, n_ev, seg_start[FOLD_MAXSEG]; };
+#define FOLD_EV(bit, h, e, neg) ((u32)(bit) | ((u32)(h) << 9) | ((u32)(e) << 15) | ((u32)(neg) << 23))
+#if ROFL_KG(2)
+__global__ void __launch_bounds__(256, 2) k_fold_gens_w(u32 n_new, FoldSeg seg, const FoldWProb *probs, const u32 *events, const niels *tab, size_t tstride) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    ge *lds = reinterpret_cast<ge *>(smem);
+    const u32 q = blockIdx.y;
+    const u32 i = blockIdx.x * 64 + threadIdx.x;
+    const u32 k = threadIdx.y, K = blockDim.y;
+    const bool active = i < n_new;
+    const niels *src = probs[q].src;
+    const u32 *ev = events + probs[q].ev_off;
+    gd acc = gd_identity();
+    if (active) {
+        const niels *tb = tab + probs[q].tab_off;
+        auto operand = [&](u32 w) { const u32 h = (w >> 9) & 63u, e = (w >> 15) & 255u;
+                                    const niels *p = e ? tb + (size_t)(e - 1) * tstride : src;
+                                    return gload_nd(&p[(size_t)h * n_new + i]); };
+        const int lo = seg.lo[k];
+        int pos = seg.lo[k + 1];                              // the accumulator's scale: `pos - b` doublings go in front of an addition at bit b
+        u32 j = probs[q].seg_start[k];
+        const u32 jend = k == 0 ? probs[q].n_ev : probs[q].seg_start[k - 1];      // (segments run from the top down: k - 1 covers the bits below k's)
+        if (j < jend) {
+            u32 w = ev[j];
+            nd nxt = operand(w);
+            while (j < jend) {
+                const nd cur = nxt; const u32 wc = w;
+                j++;
+                if (j < jend) { w = ev[j]; nxt = operand(w); }
+                const int b = (int)(wc & 511u);
+                for (; pos > b; pos--) acc = gd_double(acc);
+                acc = gd_madd(acc, cur, (wc >> 23) & 1u);
+            }
+        }
+        for (; pos > lo; pos--) acc = gd_double(acc);
+        for (int t = 0; t < lo; t++) acc = gd_double(acc);
+    }
+    if (K > 1) {
+        if (k > 0) lds[(k - 1) * 64 + threadIdx.x] = gd_pack(acc);
+        __syncthreads();
+        if (k == 0)
+            for (u32 s2 = 1; s2 < K; s2++) acc = gd_add(acc, gd_unpack(lds[(s2 - 1) * 64 + threadIdx.x]));
+    }
+    if (active && k == 0) {
+        acc = gd_madd(acc, gload_nd(&src[i]), false);   // source 0 has scalar 1 (scale kept aside)
+        gstore_niels(&probs[q].dst[i], gd_to_niels(acc));
+    }
+}
+#endif
+
 // First materialisation: the sources are the FIXED generators, for which get_gens precomputed
 //   tbl16[(q*4+e)*stride + g] = (2e+1) * 2^(64q) * G_g      (q < 4, e < 4; affine niels)
 // so a 253-bit scalar becomes four 64-bit pieces in width-4 NAF: 64 doublings per output instead of 253 and

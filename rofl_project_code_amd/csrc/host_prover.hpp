@@ -430,9 +430,46 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
                 static const bool defer_on = !(knob("ROFL_FOLD_DEFER") && atoi(knob("ROFL_FOLD_DEFER")) == 0);
                 const bool defer = use_tab && defer_on && 2 * P * n_new >= ((size_t)1 << 17);
                 ge *ext = defer ? C.foldext.as<ge>(2 * P * n_new) : nullptr;
-                if (use_tab) {
+                static const bool tab_ev = !(knob("ROFL_FOLD_TAB_EV") && atoi(knob("ROFL_FOLD_TAB_EV")) == 0);
+                if (use_tab && tab_ev && unit && nsrc <= 64 && (size_t)fc.np * fc.e <= 4095) {
+                    // the table fold as an event list (bit, source, slice, sign), highest bit first: no scan over the ~1 800 mostly-zero digit
+                    // slots of a chain, and the operand of the next addition is in flight while the current one runs
+                    std::vector<std::vector<u32>> tev(2 * P);
+                    C.pool->run(2 * P, [&](size_t q) {
+                        std::vector<u32> &e = tev[q];
+                        for (u32 h = 1; h < nsrc; h++)
+                            for (u32 pc = 0; pc < fc.np; pc++) {
+                                const int16_t *dd = h_dig16 + ((q * nsrc + h) * fc.np + pc) * FOLD_TAB_DIGITS;
+                                for (int b = 0; b < FOLD_TAB_DIGITS; b++) if (int d = dd[b]) e.push_back(FOLD_EV(b, h, pc * fc.e + ((u32)((d < 0 ? -d : d) - 1) >> 1), d < 0));
+                            }
+                        std::stable_sort(e.begin(), e.end(), [](u32 x, u32 y) { return (x & 511u) > (y & 511u); });
+                    });
+                    size_t tot_ev = 0; for (auto &e : tev) tot_ev += e.size();
+                    u32 *h_ev = C.h_fev.as<u32>(tot_ev + 4 + (2 * P * sizeof(FoldWProb) + 3) / 4);
+                    const size_t wp_off = (tot_ev + 2) & ~(size_t)1;
+                    FoldWProb *h_wp = reinterpret_cast<FoldWProb *>(h_ev + wp_off);
+                    size_t off = 0;
+                    for (size_t q = 0; q < 2 * P; q++) {
+                        std::vector<u32> &e = tev[q];
+                        FoldWProb &w = h_wp[q];
+                        w.src = tbl + h_ftp[q].src_off; w.dst = h_ftp[q].dst; w.tab_off = h_ftp[q].src_off; w.ev_off = (u32)off; w.n_ev = (u32)e.size();
+                        for (u32 k = 0; k < FOLD_MAXSEG; k++) {
+                            const int hi = seg.lo[std::min<u32>(k + 1, FOLD_MAXSEG)] - 1;
+                            u32 j = 0; while (j < e.size() && (int)(e[j] & 511u) > hi) j++;
+                            w.seg_start[k] = j;
+                        }
+                        memcpy(h_ev + off, e.data(), e.size() * sizeof(u32)); off += e.size();
+                    }
+                    u32 *d_ev = C.fold_ev.as<u32>(tot_ev + 4 + (2 * P * sizeof(FoldWProb) + 3) / 4);
+                    HIPCHK(hipMemcpyAsync(d_ev, h_ev, wp_off * sizeof(u32) + 2 * P * sizeof(FoldWProb), hipMemcpyHostToDevice, C.stream));
+                    // slice s of the table = tbl + s * stride; slice 0 = the generators themselves (the kernel reads table slices as tab + (s - 1) * stride)
+                    hipLaunchKernelGGL(k_fold_gens_w, grid, block, (K - 1) * 64 * sizeof(ge), C.stream, (u32)n_new, seg, reinterpret_cast<const FoldWProb *>(d_ev + wp_off),
+                                       (const u32 *)d_ev, (const niels *)(tbl + (size_t)(2 * N)), (size_t)(2 * N), ext);
+                } else if (use_tab) {
                     hipLaunchKernelGGL(k_fold_gens_tab, grid, block, (K - 1) * 64 * sizeof(ge), C.stream, (u32)n_new, nsrc, seg, fc, tbl, (size_t)(2 * N),
                                        (const FoldTabProb *)d_fpv, reinterpret_cast<const int16_t *>(d_dig), unit, ext);
+                }
+                if (use_tab) {
                   if (defer) {
                     if (!C.ev_norm) { HIPCHK(hipEventCreateWithFlags(&C.ev_norm, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&C.ev_norm0, hipEventDisableTiming)); }
                     HIPCHK(hipEventRecord(C.ev_norm0, C.stream));
@@ -466,7 +503,7 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
                     HIPCHK(hipMemcpyAsync(d_ev, h_ev, (wp_off) * sizeof(u32) + 2 * P * sizeof(FoldWProb), hipMemcpyHostToDevice, C.stream));
                     HIPCHK(hipStreamWaitEvent(C.stream, C.ev_mult, 0));      // the table was built beside the last rounds
                     hipLaunchKernelGGL(k_fold_gens_w, grid, block, (K - 1) * 64 * sizeof(ge), C.stream, (u32)n_new, seg, reinterpret_cast<const FoldWProb *>(d_ev + wp_off),
-                                       (const u32 *)d_ev, (const niels *)C.fmul_tab.p, mult_count);
+                                       (const u32 *)d_ev, (const niels *)C.fmul_tab.p, mult_count, (ge *)nullptr);
                 }
                 else if (nsrc == 4 && unit && fold_regs)      // three scalar-carrying sources, kept in registers
                     hipLaunchKernelGGL(k_fold_gens4, grid, block, (K - 1) * 64 * sizeof(ge), C.stream, (u32)n_new, seg, (const FoldProb *)d_fpv, d_dig);

@@ -38,6 +38,7 @@ static const Knob KNOBS[] = {
     {"ROFL_FOLD_W", "10", "NAF width of the fold table (3..10: 2^(w-2) odd multiples per 32-bit piece, 1/(w+1) of the digits non-zero; narrowed until the table fits ROFL_FOLD_TAB_MB)"},
     {"ROFL_FOLD_TAB_MB", "106496", "HBM budget of one (n, m) fold table (cfg 2 at width 10 and cfg 4 at width 9: 102.4 GB of the 288; 57344 = one width less, half the memory, +0.25 ms per cfg-2 proof)"},
     {"ROFL_FOLD_WNAF", "0", "later folds: NAF width over odd multiples of the sources built on a side stream during the preceding rounds (3..6; 0 = plain NAF over the sources alone: the build disturbs the rounds it runs beside by what the shorter fold chains save -- measured neutral, off by default)"},
+    {"ROFL_FOLD_TAB_EV", "1", "0 = the first (table) fold scans digit arrays (k_fold_gens_tab) instead of walking an event list with operand prefetch (k_fold_gens_w)"},
     {"ROFL_FOLD_UNIT", "1", "0 = do not keep the common factor s_0 of a fold in gscale / hscale"},
     {"ROFL_FOLD_K", "0", "digit-position segments per fold output (1, 2, 4; 0 = by launch size)"},
     {"ROFL_FOLD_THREADS", "131072", "fold launches with fewer threads split their chains into segments"},

@@ -874,9 +874,9 @@ __global__ void __launch_bounds__(TPB) k_odd_multiples(u32 count, u32 E, const n
 // that the operand of the next addition is fetched while the doublings in front of it run (the table is in HBM: gathered inside the chain,
 // as the generic kernel does with its sources, every addition waited ~1.7 us for its operand).  Segments as in k_fold_gens.
 struct FoldWProb { const niels *src; niels *dst; u32 tab_off, ev_off, n_ev, seg_start[FOLD_MAXSEG]; };
-#define FOLD_EV(bit, h, e, neg) ((u32)(bit) | ((u32)(h) << 9) | ((u32)(e) << 15) | ((u32)(neg) << 23))
+#define FOLD_EV(bit, h, e, neg) ((u32)(bit) | ((u32)(h) << 9) | ((u32)(e) << 15) | ((u32)(neg) << 27))      /* e: table slice, 0 = the source itself (12 bits) */
 #if ROFL_KG(2)
-__global__ void __launch_bounds__(256, 2) k_fold_gens_w(u32 n_new, FoldSeg seg, const FoldWProb *probs, const u32 *events, const niels *tab, size_t tstride) {
+__device__ __forceinline__ void fold_w_body(u32 n_new, const FoldSeg &seg, const FoldWProb *probs, const u32 *events, const niels *tab, size_t tstride, ge *ext_out) {
     extern __shared__ __align__(16) unsigned char smem[];
     ge *lds = reinterpret_cast<ge *>(smem);
     const u32 q = blockIdx.y;
@@ -888,7 +888,7 @@ __global__ void __launch_bounds__(256, 2) k_fold_gens_w(u32 n_new, FoldSeg seg, 
     gd acc = gd_identity();
     if (active) {
         const niels *tb = tab + probs[q].tab_off;
-        auto operand = [&](u32 w) { const u32 h = (w >> 9) & 63u, e = (w >> 15) & 255u;
+        auto operand = [&](u32 w) { const u32 h = (w >> 9) & 63u, e = (w >> 15) & 4095u;
                                     const niels *p = e ? tb + (size_t)(e - 1) * tstride : src;
                                     return gload_nd(&p[(size_t)h * n_new + i]); };
         const int lo = seg.lo[k];
@@ -904,7 +904,7 @@ __global__ void __launch_bounds__(256, 2) k_fold_gens_w(u32 n_new, FoldSeg seg, 
                 if (j < jend) { w = ev[j]; nxt = operand(w); }
                 const int b = (int)(wc & 511u);
                 for (; pos > b; pos--) acc = gd_double(acc);
-                acc = gd_madd(acc, cur, (wc >> 23) & 1u);
+                acc = gd_madd(acc, cur, (wc >> 27) & 1u);
             }
         }
         for (; pos > lo; pos--) acc = gd_double(acc);
@@ -918,8 +918,14 @@ __global__ void __launch_bounds__(256, 2) k_fold_gens_w(u32 n_new, FoldSeg seg, 
     }
     if (active && k == 0) {
         acc = gd_madd(acc, gload_nd(&src[i]), false);   // source 0 has scalar 1 (scale kept aside)
-        gstore_niels(&probs[q].dst[i], gd_to_niels(acc));
+        if (ext_out) store_gd(&ext_out[(size_t)q * n_new + i], acc);      // (the first fold: k_niels_batch converts on the side stream)
+        else gstore_niels(&probs[q].dst[i], gd_to_niels(acc));
     }
+}
+// (167 VGPRs: three waves per SIMD.  Compiled for four -- 128 VGPRs, 260 bytes of scratch -- the table fold is 0.5 ms slower; held at two by LDS
+// padding 1.0 ms slower: the operand gathers want waves to hide behind, but not at the price of spills.)
+__global__ void __launch_bounds__(256, 2) k_fold_gens_w(u32 n_new, FoldSeg seg, const FoldWProb *probs, const u32 *events, const niels *tab, size_t tstride, ge *ext_out) {
+    fold_w_body(n_new, seg, probs, events, tab, tstride, ext_out);
 }
 #endif
 

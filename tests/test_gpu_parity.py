@@ -590,6 +590,7 @@ def test_bsgs_discrete_log(R):
     {"ROFL_GENS_BUDGET_MB": "1", "ROFL_LANES": "2"},                      # every new (n, m) evicts the previous tables
     {"ROFL_FOLD_WNAF": "4", "ROFL_FOLD_MIN": "16"},                        # later folds over odd multiples of their sources (event-list kernel, side-stream table build)
     {"ROFL_FOLD_WNAF": "5", "ROFL_FOLD_T": "1", "ROFL_FOLD_MIN": "16"},
+    {"ROFL_FOLD_TAB_EV": "0"},                                            # the first fold through the digit-scanning kernel (k_fold_gens_tab) instead of the event list
     {"ROFL_GENS_RESERVE_MB": "400000"},                                   # no big table may be allocated (reserve > HBM): fold tables of 4 GB and more are narrowed until they fit
     {"ROFL_MSM_DEV_HORNER_MIN": "1", "ROFL_MSM_FB": "0"},                 # every MSM finishes its Horner chains on the device
     {"ROFL_MSM_DEV_HORNER_MIN": "1", "ROFL_MSM_FB_MIN": "64"},

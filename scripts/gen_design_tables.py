@@ -6,7 +6,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BOUND = {"k_msm_accumulate_fb": "VALU issue (7-multiplication mixed addition x 16 windows) co-bound with random 128-byte gathers",
-         "k_fold_gens_tab": "VALU (~160 mixed additions + 33 doublings per output)", "k_fold_gens": "VALU at 2 waves/SIMD (segmented chains)",
+         "k_fold_gens_tab": "VALU (~160 mixed additions + 33 doublings per output; the kind's kernel is k_fold_gens_w, the event-list fold, on the fixed generators' table)", "k_fold_gens": "VALU at 2 waves/SIMD (segmented chains)",
          "k_msm_bin_l1+l2 / k_msm_scatter_lds": "LDS atomics + HBM writes (no field arithmetic)", "k_msm_reduce_level+fused": "latency: three dependent launches, the last on few blocks",
          "k_msm_small": "latency: one block per (problem, window)", "k_msm_accumulate_gen": "VALU / latency", "other": "mixed (k_ipp_round, k_poly_t, k_lr_vec, k_nonce_expand, ...)",
          "k_decode / k_commit": "VALU (inverse-square-root chains)", "k_verify_scalars": "scalar-field arithmetic", "k_sigma_prove / k_sigma_vprep / k_sigma_verify": "VALU"}

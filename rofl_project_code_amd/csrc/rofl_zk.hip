@@ -571,7 +571,7 @@ int rofl_verify_rangeproof_batch(size_t n_clients, const uint8_t *const *proofs,
 int rofl_verify_rangeproof_batch_strided(size_t n_clients, const uint8_t *const *proofs, size_t proof_len, size_t n_proofs, const uint8_t *const *commits32, size_t commit_stride,
                                          size_t d, size_t prove_range, unsigned fp_bits, unsigned fp_frac, const uint8_t verifier_seed[32], int *ok_out) {
     if (!proofs || !commits32 || !ok_out || !verifier_seed || commit_stride < 32) return fail(ROFL_BAD_PARAM, "bad parameter");
-    const bool single = n_clients == 1;
+    const bool single = false;      // a batch has per-member verdicts, also a batch of ONE: a malformed member gets ok = 0, not the FormatError of rofl_verify_rangeproof (found by the long batch fuzz)
     std::vector<int> devs = batch_devices();
     if (devs.empty() || n_clients < 2)
         return guarded([&]() -> int { std::unique_ptr<DeviceBinding> bind; if (!devs.empty()) bind.reset(new DeviceBinding(devs[0]));

@@ -122,6 +122,27 @@ def test_round_of_twelve_at_the_e2e_partition_count(R):
         R.set_option("devices", 0); R.set_option("verify_batch", 1)
 
 
+def test_a_batch_of_one_gives_a_verdict_not_an_error(R):
+    """A malformed member of a batch fails ALONE (include/rofl_zk.h) -- also when it is the only member: a non-canonical scalar in the proof of a
+    one-client batch is ok = 0, not the FormatError that rofl_verify_rangeproof raises for a single set (found by tests/gpu_fuzz_batch.py at
+    seed 424242, 300 s: the batch entry treated n_clients == 1 as the single call).  Both verify_batch modes, devices on and off."""
+    rng = np.random.default_rng(77)
+    d, nb, P, fp = 300, 16, 2, (16, 7)
+    mn, mx = R.conversion32.get_clip_bounds(nb, fp=fp)
+    ins = [(np.clip(rng.uniform(mn, mx, size=d).astype(np.float32), mn, np.nextafter(np.float32(mx), np.float32(0))), orc.rand_scalars(rng, d)) for _ in range(2)]
+    res = [R.range_proof_vec.create_rangeproof(v, b, nb, P, nonce=R.Nonce.seeded(bytes([k + 1]) * 32), fp=fp) for k, (v, b) in enumerate(ins)]
+    bad = res[0][0].copy(); bad[1, 128 + 31] |= 0xF0          # t_x of the second chunk: not a canonical scalar any more
+    with pytest.raises(R.RoflError):
+        R.range_proof_vec.verify_rangeproof(bad, res[0][1], nb, fp=fp)
+    for vb in (1, 2):
+        for devs in (0, 0b11):
+            R.set_option("verify_batch", vb); R.set_option("devices", devs)
+            assert R.range_proof_vec.verify_rangeproof_batch([bad], [res[0][1]], nb, verifier_seed=b"\x09" * 32, fp=fp) == [False]
+            assert R.range_proof_vec.verify_rangeproof_batch([res[0][0]], [res[0][1]], nb, verifier_seed=b"\x09" * 32, fp=fp) == [True]
+            assert R.range_proof_vec.verify_rangeproof_batch([bad, res[1][0]], [res[0][1], res[1][1]], nb, verifier_seed=b"\x09" * 32, fp=fp) == [False, True]
+    R.set_option("verify_batch", 1); R.set_option("devices", 0)
+
+
 def test_batch_paths_fuzz():
     """tests/gpu_fuzz_batch.py, 60 s, fixed seed: three host threads over two logical devices, random shapes (8 / 16 / 32 bits, 1-8 chunks,
     1-11 clients), random members tampered; batched creates against single creates, verify_batch 1 / 2 x devices on / off against per-client

@@ -541,7 +541,7 @@ int rofl_create_rangeproof_batch(size_t n_clients, const float *const *values, s
                                  size_t n_partition, unsigned fp_bits, unsigned fp_frac, const rofl_nonce_t *nonces, uint8_t *const *proofs_out,
                                  size_t *proof_len_out, size_t *n_proofs_out, uint8_t *const *commits_out, int *rc_out) {
     if (!values || !blindings32 || !proofs_out || !commits_out || !rc_out || !proof_len_out || !n_proofs_out || !nonces) return fail(ROFL_BAD_PARAM, "bad parameter");
-    const bool single = n_clients == 1;
+    const bool single = false;      // per-client outcomes in rc_out, also for a batch of ONE (the return value is for errors of the whole call)
     std::vector<int> devs = batch_devices();
     if (devs.empty() || n_clients < 2)
         return guarded([&]() -> int { std::unique_ptr<DeviceBinding> bind; if (!devs.empty()) bind.reset(new DeviceBinding(devs[0]));

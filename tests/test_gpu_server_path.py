@@ -141,6 +141,14 @@ def test_a_batch_of_one_gives_a_verdict_not_an_error(R):
             assert R.range_proof_vec.verify_rangeproof_batch([res[0][0]], [res[0][1]], nb, verifier_seed=b"\x09" * 32, fp=fp) == [True]
             assert R.range_proof_vec.verify_rangeproof_batch([bad, res[1][0]], [res[0][1], res[1][1]], nb, verifier_seed=b"\x09" * 32, fp=fp) == [False, True]
     R.set_option("verify_batch", 1); R.set_option("devices", 0)
+    # the create side: a client whose value is out of range is ITS outcome (rc_out), also when it is the only client of the batch
+    vbad = ins[0][0].copy(); vbad[5] = np.float32(1e9)
+    out = R.range_proof_vec.create_rangeproof_batch([vbad], [ins[0][1]], nb, P, nonces=[R.Nonce.seeded(b"\x01" * 32)], fp=fp)
+    assert isinstance(out[0], R.RoflError) and out[0].code == 2
+    out = R.range_proof_vec.create_rangeproof_batch([vbad, ins[1][0]], [ins[0][1], ins[1][1]], nb, P, nonces=[R.Nonce.seeded(b"\x01" * 32), R.Nonce.seeded(b"\x02" * 32)], fp=fp)
+    assert isinstance(out[0], R.RoflError) and out[0].code == 2 and (out[1][0] == res[1][0]).all()
+    with pytest.raises(R.RoflError):
+        R.range_proof_vec.create_rangeproof(vbad, ins[0][1], nb, P, nonce=R.Nonce.seeded(b"\x01" * 32), fp=fp)
 
 
 def test_batch_paths_fuzz():

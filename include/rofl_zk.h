@@ -93,6 +93,26 @@ int rofl_create_rangeproof(const float *values, size_t d, const uint8_t *blindin
                            size_t prove_range, size_t n_partition, unsigned fp_bits, unsigned fp_frac,
                            const rofl_nonce_t *nonce, uint8_t *proofs_out, size_t *proof_len_out,
                            size_t *n_proofs_out, uint8_t *commits_out /* d*32 */);
+/* ONE client split by chunks (a single client's update over several GPUs).  The reference proves the chunks of a client
+ * independently of each other -- par_iter over the chunks, a transcript and a generator set per chunk (range_proof_vec/mod.rs:54-78,
+ * create_rangeproof_helper :118-142) -- so a rank or a device can take any run [chunk_first, chunk_first + chunk_count) of them; there is no
+ * collective inside.  `values` / `blindings32` are the client's WHOLE vectors (d fixes the chunk length m = next_pow2(d) / chunks); the range
+ * check of :27-29 covers the elements the run reads.  proofs_out receives chunk_count proofs, commits_out the commitments of the run's own
+ * elements [chunk_first * m, min(d, (chunk_first + chunk_count) * m)) -- *n_commits_out of them, possibly 0 for a run of padding chunks.
+ * The nonce index space stays the client's (chunk c draws from c * m * (2n + 4)): the runs' outputs, concatenated in chunk order, are
+ * byte for byte what rofl_create_rangeproof returns.
+ * In ONE process the split needs no extra call: with rofl_set_option("devices", mask) naming several devices, rofl_create_rangeproof and
+ * rofl_verify_rangeproof deal the client's chunks to them in contiguous runs (one internal thread per device; same bytes, same verdict). */
+int rofl_create_rangeproof_chunks(const float *values, size_t d, const uint8_t *blindings32, size_t d_blindings,
+                                  size_t prove_range, size_t n_partition, unsigned fp_bits, unsigned fp_frac,
+                                  const rofl_nonce_t *nonce, size_t chunk_first, size_t chunk_count,
+                                  uint8_t *proofs_out, size_t *proof_len_out, uint8_t *commits_out, size_t *n_commits_out);
+/* The verdict of one run of a client's proofs (verify_rangeproof_helper per chunk, :178-181, 193-216); the AND over the runs is
+ * rofl_verify_rangeproof's bit.  n_proofs and d are the client's (n_proofs must cover the padded vector exactly); `proofs` holds the run's
+ * chunk_count proofs, commits32 the run's own commitments (as rofl_create_rangeproof_chunks returned them; not read when the run has none). */
+int rofl_verify_rangeproof_chunks(const uint8_t *proofs, size_t proof_len, size_t n_proofs, size_t chunk_first, size_t chunk_count,
+                                  const uint8_t *commits32, size_t d, size_t prove_range, unsigned fp_bits, unsigned fp_frac,
+                                  const uint8_t verifier_seed[32], int *ok_out);
 /* Client-side batch: n_clients independent updates of one shape (d, prove_range, n_partition) proved as ONE launch sequence -- the
  * counterpart of rofl_verify_rangeproof_batch for hosts that run many clients per process (rofl_service's client binary hosts its
  * clients as tasks of one process, client.rs:265-266; the server hands one client per pool thread, server.rs:513-521, 656-687).
@@ -281,7 +301,8 @@ int rofl_comm_destroy(void);
  *                          case is one generator MSM per batch)
  *   "devices"              bit mask of logical devices (bit d = device d); 0 (default): batch calls run on the calling thread's device;
  *                          otherwise rofl_create_rangeproof_batch / rofl_verify_rangeproof_batch deal their clients round-robin to the
- *                          listed devices
+ *                          listed devices, and the single-client calls rofl_create_rangeproof / rofl_verify_rangeproof deal the client's
+ *                          CHUNKS to them in contiguous runs (same bytes, same verdict)
  *   "sigma_batch"          1 (default): the per-element Sigma-proofs of a vector are verified as one random linear combination; 0: one
  *                          check per element (rand_proof_vec/mod.rs:93-118)
  *   "default_device"       the device of threads that never called rofl_set_device (default: the first device that was set, else 0)

@@ -35,6 +35,13 @@ extern "C" {
     pub fn rofl_create_rangeproof(values: *const c_float, d: usize, blindings32: *const u8, d_blindings: usize,
         prove_range: usize, n_partition: usize, fp_bits: c_uint, fp_frac: c_uint, nonce: *const RoflNonce,
         proofs_out: *mut u8, proof_len_out: *mut usize, n_proofs_out: *mut usize, commits_out: *mut u8) -> c_int;
+    pub fn rofl_create_rangeproof_chunks(values: *const c_float, d: usize, blindings32: *const u8, d_blindings: usize,
+        prove_range: usize, n_partition: usize, fp_bits: c_uint, fp_frac: c_uint, nonce: *const RoflNonce,
+        chunk_first: usize, chunk_count: usize, proofs_out: *mut u8, proof_len_out: *mut usize, commits_out: *mut u8,
+        n_commits_out: *mut usize) -> c_int;
+    pub fn rofl_verify_rangeproof_chunks(proofs: *const u8, proof_len: usize, n_proofs: usize, chunk_first: usize,
+        chunk_count: usize, commits32: *const u8, d: usize, prove_range: usize, fp_bits: c_uint, fp_frac: c_uint,
+        verifier_seed: *const u8, ok_out: *mut c_int) -> c_int;
     pub fn rofl_create_rangeproof_batch(n_clients: usize, values: *const *const c_float, d: usize, blindings32: *const *const u8,
         prove_range: usize, n_partition: usize, fp_bits: c_uint, fp_frac: c_uint, nonces: *const RoflNonce,
         proofs_out: *const *mut u8, proof_len_out: *mut usize, n_proofs_out: *mut usize, commits_out: *const *mut u8,
@@ -137,6 +144,20 @@ pub const ROFL_BAD_PARAM: c_int = 11;
 pub const ROFL_NONCE_SHORT: c_int = 12;
 pub const ROFL_COMM_ERROR: c_int = 99;
 pub const ROFL_HIP_ERROR: c_int = 100;
+
+/// The ONE verdict on which the library's default differs from the reference: a proof set that covers fewer chunks than the padded
+/// commitment vector (range_proof_vec/mod.rs:169-176 zips and silently drops the tail -> `Ok(true)`; the library's default says
+/// `Ok(false)`).  Built with `--features reference_semantics` the overlay asks for the reference's behaviour bit for bit, once per
+/// process, before its first verification; without the feature the hardened default stays.
+pub fn ensure_options() {
+    static ONCE: std::sync::Once = std::sync::Once::new();
+    ONCE.call_once(|| {
+        if cfg!(feature = "reference_semantics") {
+            let rc = unsafe { rofl_set_option(b"verify_zip_truncate\0".as_ptr() as *const c_char, 1) };
+            assert_eq!(rc, ROFL_OK, "rofl_set_option(verify_zip_truncate): {}", last_error());
+        }
+    });
+}
 
 pub fn fp_bits() -> c_uint { N_BITS as c_uint }
 pub fn fp_frac() -> c_uint { <Frac as Unsigned>::U32 }

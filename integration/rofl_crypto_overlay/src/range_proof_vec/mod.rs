@@ -43,6 +43,7 @@ pub fn verify_rangeproof(
     commit_vec: &Vec<RistrettoPoint>,
     prove_range: usize,
 ) -> Result<bool, ProofError> {
+    ensure_options();
     let pb: Vec<u8> = range_proof_vec.iter().flat_map(|p| p.to_bytes()).collect();
     let cb = points_to_bytes(commit_vec);
     let seed = fresh_seed();

@@ -324,6 +324,49 @@ class range_proof_vec:
         return proofs, commits[:d]
 
     @staticmethod
+    def chunk_geometry(d, n_partition):
+        """(n_chunks, m): the proofs create_rangeproof produces for d values and the values per chunk (range_proof_vec/mod.rs:54-70)."""
+        P = lib().rofl_rangeproof_chunks(_sz(d), _sz(n_partition))
+        return P, (lib().rofl_next_pow2(_sz(d)) // P if P else 0)
+
+    @staticmethod
+    def create_rangeproof_chunks(values, blindings, prove_range, n_partition, chunk_first, chunk_count, nonce=None, fp=None):
+        """rofl_create_rangeproof_chunks: the proofs of chunks [chunk_first, chunk_first + chunk_count) of ONE client -- the unit a rank
+        (or a device) takes when a single client's update is split (the reference proves the chunks independently on its rayon pool,
+        range_proof_vec/mod.rs:54-78).  `values` / `blindings` are the client's whole vectors.  -> (proofs u8[chunk_count, proof_len],
+        commitments u8[k, 32] of the run's own k elements).  Concatenated over the runs in chunk order = create_rangeproof's result."""
+        v = np.ascontiguousarray(values, dtype=np.float32)
+        b = _u8(blindings)
+        d = v.size
+        nonce = nonce or Nonce.random()
+        ns = nonce._struct()
+        P, m = range_proof_vec.chunk_geometry(max(d, 1), max(n_partition, 1))
+        plen = lib().rofl_rangeproof_size(_sz(max(prove_range, 1)), _sz(max(d, 1)), _sz(max(n_partition, 1)))
+        proofs = np.zeros((max(chunk_count, 1), max(plen, 32)), dtype=np.uint8)
+        commits = np.zeros((max(chunk_count * m, 1), 32), dtype=np.uint8)
+        plen_o, nc_o = _sz(), _sz()
+        _check(lib().rofl_create_rangeproof_chunks(_ptr(v), _sz(d), _ptr(b), _sz(b.shape[0] if b.size else 0), _sz(prove_range), _sz(n_partition), *_fp(fp),
+                                                   ctypes.byref(ns), _sz(chunk_first), _sz(chunk_count), _ptr(proofs), ctypes.byref(plen_o), _ptr(commits),
+                                                   ctypes.byref(nc_o)))
+        assert plen_o.value == plen
+        return proofs, commits[:nc_o.value]
+
+    @staticmethod
+    def verify_rangeproof_chunks(proofs_run, n_proofs, chunk_first, commits_run, d, prove_range, verifier_seed=None, fp=None):
+        """rofl_verify_rangeproof_chunks: the verdict of a run of ONE client's proofs (the AND over the runs is verify_rangeproof's
+        bit, range_proof_vec/mod.rs:168-181).  proofs_run u8[count, proof_len] and commits_run (the run's own commitments) are what
+        create_rangeproof_chunks returned for the run; n_proofs and d are the client's."""
+        p = np.ascontiguousarray(proofs_run, dtype=np.uint8)
+        c = _u8(commits_run)
+        if c.size == 0:
+            c = np.zeros((1, 32), dtype=np.uint8)      # a run of padding chunks has no commitments of its own (nothing is read)
+        seed = bytes(verifier_seed) if verifier_seed is not None else os.urandom(32)
+        ok = ctypes.c_int()
+        _check(lib().rofl_verify_rangeproof_chunks(_ptr(p), _sz(p.shape[1]), _sz(n_proofs), _sz(chunk_first), _sz(p.shape[0]), _ptr(c), _sz(d),
+                                                   _sz(prove_range), *_fp(fp), seed, ctypes.byref(ok)))
+        return bool(ok.value)
+
+    @staticmethod
     def create_rangeproof_batch(values_list, blindings_list, prove_range, n_partition, nonces=None, fp=None):
         """rofl_create_rangeproof_batch: the updates of several clients (same d) proved as one launch sequence.
         -> list of (proofs, commitments) per client; a client whose own inputs are rejected (out of range, NaN, short nonce

@@ -132,26 +132,38 @@ template <class F> int guarded(F f) {
 // the others are proved.  Returns non-zero only for errors that concern the whole call.
 int create_impl(Ctx &C, size_t nc, const float *const *values, size_t d, const uint8_t *const *blind, size_t prove_range, size_t n_partition,
                 unsigned fp_bits, unsigned fp_frac, const rofl_nonce_t *nonces, uint8_t *const *proofs_out, size_t *plen_out, size_t *np_out,
-                uint8_t *const *commits_out, int *rcs, bool single) {
+                uint8_t *const *commits_out, int *rcs, bool single, size_t chunk_first = 0, size_t chunk_count = 0) {
     // `single`: the call is rofl_create_rangeproof (one client: its errors are the call's errors); batch calls -- also their one-client
-    // shards when a batch is spread over several devices -- report per client in rcs
+    // shards when a batch is spread over several devices -- report per client in rcs.
+    // [chunk_first, chunk_first + chunk_count) (count 0: all): the chunks of every client that THIS call proves -- the reference proves a
+    // client's chunks independently of each other (range_proof_vec/mod.rs:54-78: par_iter over the chunks, a transcript and a generator set
+    // per chunk), so a device or a rank can take any run of them.  values / blindings are still the client's whole vectors (the range check
+    // of :27-29 is over the slice this call reads; the caller of a split combines the outcomes); proofs_out[i] receives chunk_count proofs,
+    // commits_out[i] the commitments of the run's own elements, i.e. it points at element chunk_first * m of the client's array; the nonce
+    // index space stays the client's (chunk c draws from c * m * (2n + 4)), so the bytes are those of the unsplit call.
     for (size_t i = 0; i < nc; i++) rcs[i] = ROFL_OK;
     if (!valid_fp(fp_bits, fp_frac) || d == 0 || n_partition == 0 || prove_range == 0 || prove_range > fp_bits || !nonces || nc == 0)
         return fail(ROFL_BAD_PARAM, "bad parameter (the reference panics here)");
-    size_t dp = next_pow2(d);
-    size_t n_chunks = std::min(dp, n_partition), chunk = dp / n_chunks;
-    size_t P = (dp + chunk - 1) / chunk;
+    const size_t d_all = d, dp_all = next_pow2(d);
+    size_t n_chunks = std::min(dp_all, n_partition), chunk = dp_all / n_chunks;
+    const size_t P_all = (dp_all + chunk - 1) / chunk;
+    if (chunk_count == 0) { chunk_first = 0; chunk_count = P_all; }
+    if (chunk_first >= P_all || chunk_count > P_all - chunk_first) return fail(ROFL_BAD_PARAM, "chunk range outside the client's chunks");
+    // from here on d, dp, P describe the run: `d` real elements (possibly none: a run of padding chunks) at the front of dp = P * chunk
+    const size_t el0 = chunk_first * chunk;
+    const size_t P = chunk_count, dp = P * chunk;
+    d = el0 >= d_all ? 0 : std::min(d_all - el0, dp);
     float mn, mx; clip_bounds(prove_range, fp_bits, fp_frac, &mn, &mx);
     C.init();
     C.batch_mode = nc > 1;
     timing_begin(C);
-    float *d_vals = C.vals.as<float>(nc * d);
+    float *d_vals = C.vals.as<float>(nc * d + 1);
     u64 *vshift = C.vshift.as<u64>(nc * dp);
     sc *d_blind_buf = C.blind.as<sc>(nc * dp);
     HIPCHK(hipMemsetAsync(d_blind_buf, 0, sizeof(sc) * nc * dp, C.stream));
-    for (size_t i = 0; i < nc; i++) {      // the callers' arrays: host or device memory
-        C.up(d_vals + i * d, values[i], sizeof(float) * d, C.stream);
-        C.up(d_blind_buf + i * dp, blind[i], 32 * d, C.stream);
+    for (size_t i = 0; i < nc && d; i++) {      // the callers' arrays: host or device memory
+        C.up(d_vals + i * d, values[i] + el0, sizeof(float) * d, C.stream);
+        C.up(d_blind_buf + i * dp, blind[i] + el0 * 32, 32 * d, C.stream);
     }
     u32 *status = C.status.as<u32>(nc + 4);
     HIPCHK(hipMemsetAsync(status, 0, 4 * (nc + 4), C.stream));
@@ -171,7 +183,7 @@ int create_impl(Ctx &C, size_t nc, const float *const *values, size_t d, const u
     if (!is_pow2(chunk) || dp % chunk) return fail(ROFL_INVALID_AGGREGATION, "InvalidAggregation (the reference panics)");
     if (!(prove_range == 8 || prove_range == 16 || prove_range == 32 || prove_range == 64)) return fail(ROFL_INVALID_BITSIZE, "InvalidBitsize");
     for (size_t i = 0; i < nc; i++)
-        if (rcs[i] == ROFL_OK && nonces[i].mode == 0 && nonces[i].stream_scalars < P * chunk * (2 * prove_range + 4)) {
+        if (rcs[i] == ROFL_OK && nonces[i].mode == 0 && nonces[i].stream_scalars < P_all * chunk * (2 * prove_range + 4)) {
             rcs[i] = ROFL_NONCE_SHORT;
             if (single) return fail(ROFL_NONCE_SHORT, "nonce stream too short");
         }
@@ -188,15 +200,18 @@ int create_impl(Ctx &C, size_t nc, const float *const *values, size_t d, const u
         }
     // explicit nonce streams go to the device once
     std::vector<ChunkNonce> cn(na * P);
-    { size_t tot = 0; for (size_t k = 0; k < na; k++) if (nonces[act[k]].mode == 0) tot += nonces[act[k]].stream_scalars * 64;
+    { const u64 per = (u64)chunk * (2 * prove_range + 4);      // nonces of one chunk; a run reads scalars [chunk_first * per, (chunk_first + P) * per) of the client's stream
+      const size_t run_bytes = (size_t)(P * per) * 64, run_off = (size_t)(chunk_first * per) * 64;
+      size_t tot = 0; for (size_t k = 0; k < na; k++) if (nonces[act[k]].mode == 0) tot += run_bytes;
       uint8_t *sb = tot ? C.stream_buf.as<uint8_t>(tot + 64) : nullptr; size_t off = 0;
-      u64 per = (u64)chunk * (2 * prove_range + 4);
       for (size_t k = 0; k < na; k++) {
           const rofl_nonce_t &nn = nonces[act[k]];
           ChunkNonce base{}; base.mode = nn.mode;
           if (nn.mode == 1) memcpy(base.seed.w, nn.seed, 32);
-          else { C.up(sb + off, nn.stream, nn.stream_scalars * 64, C.stream); base.d_stream = sb + off; base.stream_scalars = nn.stream_scalars; off += nn.stream_scalars * 64; }
-          for (size_t c = 0; c < P; c++) { cn[k * P + c] = base; cn[k * P + c].base = c * per; }
+          else {      // only the run's part of the stream goes up; the kernel indexes the stream by the client's nonce index, so the base address is moved back by the part that stayed behind (never dereferenced there)
+              C.up(sb + off, nn.stream + run_off, run_bytes, C.stream);
+              base.d_stream = reinterpret_cast<const uint8_t *>(reinterpret_cast<uintptr_t>(sb + off) - run_off); base.stream_scalars = (chunk_first + P) * per; off += run_bytes; }
+          for (size_t c = 0; c < P; c++) { cn[k * P + c] = base; cn[k * P + c].base = (chunk_first + c) * per; }
       } }
     // V_j and un-shifted commitments C_j = V_j - 2^(range-1) B   (range_proof_vec/mod.rs:96-99)
     sc negoff = sc_neg(sc_from_u64(1ULL << (prove_range - 1)));
@@ -219,7 +234,7 @@ int create_impl(Ctx &C, size_t nc, const float *const *values, size_t d, const u
     uint8_t *hV = C.h_V.as<uint8_t>(na * dp * 32);
     HIPCHK(hipMemcpyAsync(hV, Vb, na * dp * 32, hipMemcpyDeviceToHost, C.stream2));
     HIPCHK(hipEventRecord(C.ev_v, C.stream2));
-    for (size_t k = 0; k < na; k++) C.down(commits_out[act[k]], Cb + k * dp * 32, d * 32, C.stream2);
+    for (size_t k = 0; k < na && d; k++) C.down(commits_out[act[k]], Cb + k * dp * 32, d * 32, C.stream2);
     std::vector<uint8_t *> pout(na * P);
     for (size_t k = 0; k < na; k++) for (size_t c = 0; c < P; c++) pout[k * P + c] = proofs_out[act[k]] + c * plen;
     prove_chunks(C, "RangeProof", na * P, prove_range, chunk, vshift, d_blind_buf, cn, hV, pout.data(), C.ev_v);
@@ -240,10 +255,15 @@ int create_impl(Ctx &C, size_t nc, const float *const *values, size_t d, const u
 // SquareRandProofCommitments as they arrive on the wire, params.rs:197, 215: `enc_values.iter().map(|x| x.c.L)`).
 int verify_impl(Ctx &C, size_t n_clients, const uint8_t *const *proofs, size_t proof_len, size_t n_proofs, const uint8_t *const *commits,
                 size_t d, size_t prove_range, unsigned fp_bits, unsigned fp_frac, const uint8_t seed[32], int *ok_out, bool single,
-                const size_t *gid = nullptr, size_t cstride = 32) {
+                const size_t *gid = nullptr, size_t cstride = 32, size_t chunk_first = 0, size_t chunk_count = 0) {
+    // [chunk_first, chunk_first + chunk_count) (count 0: all): the proofs of every client that THIS call checks -- the reference verifies a
+    // client's proofs independently of each other and ANDs the bits (range_proof_vec/mod.rs:168-181), so a device or a rank can take any run
+    // of them.  n_proofs and d stay the client's (they fix the chunk length); proofs[i] points at the run's first proof, commits[i] at the
+    // run's first commitment (element chunk_first * m of the client's array).
     for (size_t i = 0; i < n_clients; i++) ok_out[i] = 0;
     if (!valid_fp(fp_bits, fp_frac) || d == 0 || n_proofs == 0 || prove_range == 0 || prove_range > fp_bits || n_clients == 0 || cstride < 32)
         return fail(ROFL_BAD_PARAM, "bad parameter (the reference panics here)");
+    const size_t d_all = d;
     size_t dp = next_pow2(d);
     size_t chunk = dp / n_proofs;
     if (chunk == 0) return fail(ROFL_BAD_PARAM, "more proofs than padded commitments (the reference panics in chunks(0))");
@@ -254,6 +274,12 @@ int verify_impl(Ctx &C, size_t n_clients, const uint8_t *const *proofs, size_t p
         if (!zip_truncate) { g_err = "proof count does not cover the padded commitment vector: not verified"; return ROFL_OK; }
         if (dp % chunk) return fail(ROFL_BAD_PARAM, "ragged chunks are not supported");
     }
+    if (chunk_count) {      // a run of the client's verified chunks: from here on d, dp, nv describe the run
+        if (chunk_first >= nv || chunk_count > nv - chunk_first) return fail(ROFL_BAD_PARAM, "chunk range outside the client's proofs");
+        const size_t el0 = chunk_first * chunk;
+        nv = chunk_count; dp = nv * chunk;
+        d = el0 >= d_all ? 0 : std::min(d_all - el0, dp);
+    } else chunk_first = 0;
     // Everything below allocates per (prove_range, chunk): check the proofs' own shape against it first (RangeProof::from_bytes,
     // then the N == 2^lg test of verify_multiple), so that a forged proof count cannot make the device build tables.
     if (proof_len % 32 != 0 || proof_len < 7 * 32) return fail(ROFL_FORMAT_ERROR, "FormatError: proof length");
@@ -307,7 +333,8 @@ int verify_impl(Ctx &C, size_t n_clients, const uint8_t *const *proofs, size_t p
     bool all_host = true; for (size_t i = 0; i < n_clients; i++) all_host &= !is_device_ptr(commits[i]);
     for (size_t i0 = 0; i0 < n_clients; i0 += GC) {
         const size_t gc = std::min(GC, n_clients - i0);
-        if (all_host && (d * 32 >= Stage::kMin || cstride != 32)) {
+        if (d == 0) {      // a run of padding chunks: nothing to bring in, the decode kernel writes identities
+        } else if (all_host && (d * 32 >= Stage::kMin || cstride != 32)) {
             uint8_t *st = (uint8_t *)C.stg.alloc(gc * d * 32);
             const size_t slices = std::max<size_t>(1, (d * 32) >> 18);      // ~256 KB per task
             C.pool->run(gc * slices, [&](size_t t) { size_t i = t / slices, k = t % slices;
@@ -341,7 +368,7 @@ int verify_impl(Ctx &C, size_t n_clients, const uint8_t *const *proofs, size_t p
     // flatten (client, chunk) -> problem list.  A client's verified chunks are a prefix of its dp commitments: when the proofs cover
     // everything (the normal case) the per-client arrays ARE the per-proof arrays; otherwise one strided copy each
     std::vector<u64> cidx(P);
-    for (size_t i = 0; i < n_clients; i++) for (size_t c = 0; c < nv; c++) cidx[i * nv + c] = c;
+    for (size_t i = 0; i < n_clients; i++) for (size_t c = 0; c < nv; c++) cidx[i * nv + c] = chunk_first + c;      // the chunk's index in its client: keys its random weights
     const uint8_t *Vh = hV; const niels *d_vn2 = d_vn;
     std::vector<uint8_t> Vh_own;
     if (nv * chunk != dp) {
@@ -365,7 +392,7 @@ int verify_impl(Ctx &C, size_t n_clients, const uint8_t *const *proofs, size_t p
     // all (client, chunk) pairs in one pass; a client's chunks form one batch of the random-weighted check
     sc v_shift = sc_from_u64(1ULL << (prove_range - 1));
     std::vector<u64> v_real(P);
-    for (size_t q = 0; q < P; q++) { size_t lo = cidx[q] * chunk; v_real[q] = lo >= d ? 0 : std::min(chunk, d - lo); }
+    for (size_t q = 0; q < P; q++) { size_t lo = cidx[q] * chunk; v_real[q] = lo >= d_all ? 0 : std::min(chunk, d_all - lo); }
     // (an undecodable commitment is known only when its group has been decoded: verify_chunks asks for the client's status word then)
     VerifyInputs vin{&ready, h_st, nv};
     int rc = verify_chunks(C, "RangeProof", prove_range, P, prove_range, chunk, pf.data(), proof_len, Vh, d_vn2, seed, cidx.data(), okc.data(), grp, &v_shift, v_real.data(),
@@ -433,12 +460,11 @@ std::vector<int> batch_devices() {
 // Clients round-robin over the listed devices, one internal thread per device (bound to it for the duration), each running the ordinary
 // single-device path on its share; verdicts / return codes land in the caller's arrays, in host memory -- in one process there is no
 // collective to run.  run(share, device_slot) is the per-device body; it returns the call-level return code of its share.
-template <class F> int shard_over_devices(size_t n_clients, const std::vector<int> &devs, F run) {
-    const size_t nd = std::min(devs.size(), n_clients);
-    std::vector<std::vector<size_t>> share(nd);
-    for (size_t i = 0; i < n_clients; i++) share[i % nd].push_back(i);
-    std::vector<int> rcs(nd, ROFL_OK); std::vector<std::string> errs(nd);
-    auto body = [&](size_t k) { DeviceBinding bind(devs[k]); rcs[k] = guarded([&]() -> int { return run(share[k]); }); if (rcs[k]) errs[k] = g_err; };
+// run(k) for k < nd, each on the worker of devs[k] (k = 0 on the calling thread), bound to its device; rcs[k] / errs[k] = what it returned.
+// The return value is non-zero only when a worker thread could not be started.
+template <class F> int run_on_devices(const std::vector<int> &devs, size_t nd, std::vector<int> &rcs, std::vector<std::string> &errs, F run) {
+    rcs.assign(nd, ROFL_OK); errs.assign(nd, std::string());
+    auto body = [&](size_t k) { DeviceBinding bind(devs[k]); rcs[k] = guarded([&]() -> int { return run(k); }); if (rcs[k]) errs[k] = g_err; };
     // one persistent worker per device (ShardWorkers): no thread is created on the call path, and a thread that cannot be created at
     // start-up is an error code, not std::terminate from a vector of joinable threads
     ShardWorkers &sw = shard_workers();
@@ -450,9 +476,72 @@ template <class F> int shard_over_devices(size_t n_clients, const std::vector<in
     }
     body(0);
     for (auto &t : tickets) sw.wait(t);
+    return ROFL_OK;
+}
+template <class F> int shard_over_devices(size_t n_clients, const std::vector<int> &devs, F run) {
+    const size_t nd = std::min(devs.size(), n_clients);
+    std::vector<std::vector<size_t>> share(nd);
+    for (size_t i = 0; i < n_clients; i++) share[i % nd].push_back(i);
+    std::vector<int> rcs; std::vector<std::string> errs;
+    if (int rc = run_on_devices(devs, nd, rcs, errs, [&](size_t k) -> int { return run(share[k]); })) return rc;
     for (size_t k = 0; k < nd; k++) if (rcs[k]) return fail(rcs[k], errs[k]);
     return ROFL_OK;
 }
+
+// ONE client over several devices ("cfg 2/3 at > 1 GPU -> chunks over ranks").  The reference proves and verifies a client's
+// chunks in parallel on its rayon pool (range_proof_vec/mod.rs:54-78, 168-181: every chunk is its own Bulletproof with its own transcript);
+// here device k takes the k-th contiguous run of the P chunks -- a run's commitments are one span of the caller's array, the cost of a
+// chunk does not depend on its data (padding chunks are proved like any other), so contiguous runs balance exactly like a round-robin deal.
+// No collective: proofs and commitments land in the caller's host arrays.  The bytes are those of the unsplit call (the nonce index space is
+// the client's).  Returns the geometry in *chunk_out / *P_out; 0 runs = the call is not splittable (one chunk, or one device).
+std::vector<std::pair<size_t, size_t>> chunk_runs(size_t P, size_t nd) {
+    std::vector<std::pair<size_t, size_t>> r;
+    nd = std::min(nd, P);
+    for (size_t k = 0; k < nd; k++) { size_t a = k * P / nd, b = (k + 1) * P / nd; if (b > a) r.emplace_back(a, b - a); }
+    return r;
+}
+int create_split(const std::vector<int> &devs, const float *values, size_t d, const uint8_t *blind, size_t prove_range, size_t n_partition, unsigned fp_bits,
+                 unsigned fp_frac, const rofl_nonce_t *nonce, uint8_t *proofs_out, size_t *plen_out, size_t *np_out, uint8_t *commits_out) {
+    const size_t dp = next_pow2(d), nch = std::min(dp, n_partition), chunk = dp / nch, P = (dp + chunk - 1) / chunk;
+    const size_t plen = 32 * (9 + 2 * (size_t)lg2u(prove_range * chunk));      // (every run reports the same; needed here to place the runs' proofs)
+    auto runs = chunk_runs(P, devs.size());
+    std::vector<int> rcs, rc1(runs.size(), ROFL_OK); std::vector<std::string> errs;
+    if (int rc = run_on_devices(devs, runs.size(), rcs, errs, [&](size_t k) -> int {
+            LaneLock lane_lock = acquire_lane(); Ctx &C = *lane_lock.c;
+            uint8_t *po = proofs_out + runs[k].first * plen, *co = commits_out + std::min(runs[k].first * chunk, d) * 32;
+            size_t pl = 0, np = 0;
+            return create_impl(C, 1, &values, d, &blind, prove_range, n_partition, fp_bits, fp_frac, nonce, &po, &pl, &np, &co, &rc1[k], false, runs[k].first, runs[k].second); }))
+        return rc;
+    // the outcome of the unsplit call, in the reference's order of checks: parameters, the range check over ALL values (:27-29), the
+    // conversion's panic, then the upstream errors
+    auto any = [&](const std::vector<int> &v, int code) { return std::find(v.begin(), v.end(), code) != v.end(); };
+    if (any(rcs, ROFL_BAD_PARAM)) return fail(ROFL_BAD_PARAM, "bad parameter (the reference panics here)");
+    for (size_t k = 0; k < rcs.size(); k++) if (rcs[k] >= ROFL_HIP_ERROR || rcs[k] == ROFL_COMM_ERROR) return fail(rcs[k], errs[k]);
+    if (any(rc1, ROFL_VALUE_OUT_OF_RANGE)) return fail(ROFL_VALUE_OUT_OF_RANGE, "ValueOutOfRangeError");
+    if (any(rc1, ROFL_NON_FINITE)) return fail(ROFL_NON_FINITE, "non-finite value (the reference panics in fixed::saturating_from_float)");
+    for (size_t k = 0; k < rcs.size(); k++) if (rcs[k]) return fail(rcs[k], errs[k]);
+    if (any(rc1, ROFL_NONCE_SHORT)) return fail(ROFL_NONCE_SHORT, "nonce stream too short");
+    *plen_out = plen; *np_out = P;
+    return ROFL_OK;
+}
+int verify_split(const std::vector<int> &devs, const uint8_t *proofs, size_t proof_len, size_t n_proofs, const uint8_t *commits, size_t d, size_t prove_range,
+                 unsigned fp_bits, unsigned fp_frac, const uint8_t seed[32], int *ok_out) {
+    const size_t chunk = next_pow2(d) / n_proofs;
+    auto runs = chunk_runs(n_proofs, devs.size());
+    std::vector<int> rcs, oks(runs.size(), 0); std::vector<std::string> errs;
+    if (int rc = run_on_devices(devs, runs.size(), rcs, errs, [&](size_t k) -> int {
+            LaneLock lane_lock = acquire_lane(); Ctx &C = *lane_lock.c;
+            const uint8_t *pp = proofs + runs[k].first * proof_len, *cc = commits + std::min(runs[k].first * chunk, d) * 32;
+            return verify_impl(C, 1, &pp, proof_len, n_proofs, &cc, d, prove_range, fp_bits, fp_frac, seed, &oks[k], true, nullptr, 32, runs[k].first, runs[k].second); }))
+        return rc;
+    *ok_out = 0;
+    for (size_t k = 0; k < rcs.size(); k++) if (rcs[k]) return fail(rcs[k], errs[k]);      // a malformed set is the call's FormatError, whichever run met it
+    int ok = 1; for (int o : oks) ok &= o;
+    *ok_out = ok;
+    return ROFL_OK;
+}
+// can this (d, n_proofs) set be split?  Only the regular case: the proofs cover the padded vector exactly
+bool verify_splittable(size_t d, size_t n_proofs) { if (!d || n_proofs < 2) return false; size_t dp = next_pow2(d); return n_proofs <= dp && (dp / n_proofs) * n_proofs == dp; }
 }  // namespace
 
 // ================================================================ C ABI
@@ -531,11 +620,32 @@ int rofl_bp_gens_export(size_t n_bits, size_t m, uint8_t *G_out, uint8_t *H_out)
 int rofl_create_rangeproof(const float *values, size_t d, const uint8_t *blindings32, size_t d_blindings, size_t prove_range, size_t n_partition,
                            unsigned fp_bits, unsigned fp_frac, const rofl_nonce_t *nonce, uint8_t *proofs_out, size_t *proof_len_out,
                            size_t *n_proofs_out, uint8_t *commits_out) {
-    return guarded([&]() -> int { LaneLock lane_lock = acquire_lane(); Ctx &C = *lane_lock.c;
+    return guarded([&]() -> int {
         if (d != d_blindings) return fail(ROFL_WRONG_NUM_BLINDING, "WrongNumBlindingFactors");
+        // rofl_set_option("devices", mask) with several devices: the client's chunks are dealt to them (create_split); malformed parameters take the ordinary path and get its diagnostics
+        std::vector<int> devs = batch_devices();
+        if (devs.size() > 1 && values && blindings32 && nonce && proofs_out && commits_out && proof_len_out && n_proofs_out && d && n_partition && valid_fp(fp_bits, fp_frac) &&
+            prove_range && prove_range <= fp_bits && rofl_rangeproof_chunks(d, n_partition) > 1)
+            return create_split(devs, values, d, blindings32, prove_range, n_partition, fp_bits, fp_frac, nonce, proofs_out, proof_len_out, n_proofs_out, commits_out);
+        std::unique_ptr<DeviceBinding> bind; if (devs.size() == 1) bind.reset(new DeviceBinding(devs[0]));
+        LaneLock lane_lock = acquire_lane(); Ctx &C = *lane_lock.c;
         int rc1 = ROFL_OK;
         int rc = create_impl(C, 1, &values, d, &blindings32, prove_range, n_partition, fp_bits, fp_frac, nonce, &proofs_out, proof_len_out, n_proofs_out, &commits_out, &rc1, true);
         return rc ? rc : rc1; });
+}
+int rofl_create_rangeproof_chunks(const float *values, size_t d, const uint8_t *blindings32, size_t d_blindings, size_t prove_range, size_t n_partition,
+                                  unsigned fp_bits, unsigned fp_frac, const rofl_nonce_t *nonce, size_t chunk_first, size_t chunk_count,
+                                  uint8_t *proofs_out, size_t *proof_len_out, uint8_t *commits_out, size_t *n_commits_out) {
+    return guarded([&]() -> int {
+        if (!values || !blindings32 || !nonce || !proofs_out || !proof_len_out || !commits_out || !n_commits_out || chunk_count == 0) return fail(ROFL_BAD_PARAM, "bad parameter");
+        if (d != d_blindings) return fail(ROFL_WRONG_NUM_BLINDING, "WrongNumBlindingFactors");
+        LaneLock lane_lock = acquire_lane(); Ctx &C = *lane_lock.c;
+        int rc1 = ROFL_OK; size_t np = 0;
+        int rc = create_impl(C, 1, &values, d, &blindings32, prove_range, n_partition, fp_bits, fp_frac, nonce, &proofs_out, proof_len_out, &np, &commits_out, &rc1, true, chunk_first, chunk_count);
+        if (rc || rc1) return rc ? rc : rc1;
+        const size_t dp = next_pow2(d), chunk = dp / std::min(dp, n_partition), el0 = chunk_first * chunk;
+        *n_commits_out = el0 >= d ? 0 : std::min(d - el0, chunk_count * chunk);
+        return ROFL_OK; });
 }
 int rofl_create_rangeproof_batch(size_t n_clients, const float *const *values, size_t d, const uint8_t *const *blindings32, size_t prove_range,
                                  size_t n_partition, unsigned fp_bits, unsigned fp_frac, const rofl_nonce_t *nonces, uint8_t *const *proofs_out,
@@ -561,8 +671,22 @@ int rofl_create_rangeproof_batch(size_t n_clients, const float *const *values, s
 }
 int rofl_verify_rangeproof(const uint8_t *proofs, size_t proof_len, size_t n_proofs, const uint8_t *commits32, size_t d, size_t prove_range,
                            unsigned fp_bits, unsigned fp_frac, const uint8_t verifier_seed[32], int *ok_out) {
-    return guarded([&]() -> int { LaneLock lane_lock = acquire_lane(); Ctx &C = *lane_lock.c;
+    return guarded([&]() -> int {
+        std::vector<int> devs = batch_devices();
+        if (devs.size() > 1 && proofs && commits32 && ok_out && verifier_seed && verify_splittable(d, n_proofs))      // the client's proofs over the listed devices (verify_split)
+            return verify_split(devs, proofs, proof_len, n_proofs, commits32, d, prove_range, fp_bits, fp_frac, verifier_seed, ok_out);
+        std::unique_ptr<DeviceBinding> bind; if (devs.size() == 1) bind.reset(new DeviceBinding(devs[0]));
+        LaneLock lane_lock = acquire_lane(); Ctx &C = *lane_lock.c;
         return verify_impl(C, 1, &proofs, proof_len, n_proofs, &commits32, d, prove_range, fp_bits, fp_frac, verifier_seed, ok_out, true); });
+}
+int rofl_verify_rangeproof_chunks(const uint8_t *proofs, size_t proof_len, size_t n_proofs, size_t chunk_first, size_t chunk_count, const uint8_t *commits32,
+                                  size_t d, size_t prove_range, unsigned fp_bits, unsigned fp_frac, const uint8_t verifier_seed[32], int *ok_out) {
+    return guarded([&]() -> int {
+        if (!proofs || !commits32 || !ok_out || !verifier_seed || chunk_count == 0) return fail(ROFL_BAD_PARAM, "bad parameter");
+        { const size_t dp = d ? next_pow2(d) : 0;
+          if (!d || !n_proofs || n_proofs > dp || (dp / n_proofs) * n_proofs != dp) return fail(ROFL_BAD_PARAM, "a run of chunks needs a proof count that covers the padded vector exactly"); }
+        LaneLock lane_lock = acquire_lane(); Ctx &C = *lane_lock.c;
+        return verify_impl(C, 1, &proofs, proof_len, n_proofs, &commits32, d, prove_range, fp_bits, fp_frac, verifier_seed, ok_out, true, nullptr, 32, chunk_first, chunk_count); });
 }
 int rofl_verify_rangeproof_batch(size_t n_clients, const uint8_t *const *proofs, size_t proof_len, size_t n_proofs, const uint8_t *const *commits32,
                                  size_t d, size_t prove_range, unsigned fp_bits, unsigned fp_frac, const uint8_t verifier_seed[32], int *ok_out) {

@@ -76,7 +76,13 @@ int rofl_last_error(char *buf, size_t len);            /* human-readable text of
  * results; the first generator fold of a proof is ~2.5 ms slower): the call still returns 0, rofl_last_error carries a note,
  * rofl_bp_gens_table_bytes reports the compact size, and a later rofl_bp_gens_prepare tries again. */
 int rofl_bp_gens_prepare(size_t n_bits, size_t m);
-/* HBM held by the cached tables of (n_bits, m): generators + fold slices + window slices; 0 if they have not been built */
+/* The same for a process that only VERIFIES the shape -- the reference's server (rofl_service/src/flserver/server.rs:656-687): the generators
+ * and the window slices of the fixed-base MSM, without the prover's fold table (2.2 GB instead of 104 GB at BASELINE cfg 4).  The verify
+ * entry points build exactly this on first use of a shape, so the call is only there to pay it at start-up.  Tables are role-aware either
+ * way: nothing on a verify path ever builds, holds or evicts for a fold table; a create call (or rofl_bp_gens_prepare) that later meets the
+ * shape adds it. */
+int rofl_bp_gens_prepare_verify(size_t n_bits, size_t m);
+/* HBM held by the cached tables of (n_bits, m): generators + fold slices (prover role only) + window slices; 0 if they have not been built */
 int rofl_bp_gens_table_bytes(size_t n_bits, size_t m, size_t *bytes_out);
 /* copy the cached generators back, compressed, party-major: G_out/H_out n_bits*m*32 bytes each */
 int rofl_bp_gens_export(size_t n_bits, size_t m, uint8_t *G_out, uint8_t *H_out);

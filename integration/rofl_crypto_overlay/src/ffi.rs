@@ -24,6 +24,7 @@ extern "C" {
     pub fn rofl_get_device(device_out: *mut c_int) -> c_int;
     pub fn rofl_last_error(buf: *mut c_char, len: usize) -> c_int;
     pub fn rofl_bp_gens_prepare(n_bits: usize, m: usize) -> c_int;
+    pub fn rofl_bp_gens_prepare_verify(n_bits: usize, m: usize) -> c_int;
     pub fn rofl_bp_gens_table_bytes(n_bits: usize, m: usize, bytes_out: *mut usize) -> c_int;
     /// process-wide behaviour options ("verify_zip_truncate", "verify_batch" 0 / 1 / 2, "sigma_batch", "blocking_sync", "devices" = bit
     /// mask of the devices the `_batch` entry points spread their clients over); the ROFL_* environment variables only provide defaults.  A server that wants the reference's zip-truncating verify bit for bit calls

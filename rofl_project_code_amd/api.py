@@ -162,6 +162,12 @@ def bp_gens_prepare(n_bits, m):
     _check(lib().rofl_bp_gens_prepare(_sz(n_bits), _sz(m)))
 
 
+def bp_gens_prepare_verify(n_bits, m):
+    """rofl_bp_gens_prepare_verify: the tables a VERIFIER of (n_bits, m) reads -- generators and window slices, no fold table (a server's
+    start-up call; the verify entry points build the same on first use)."""
+    _check(lib().rofl_bp_gens_prepare_verify(_sz(n_bits), _sz(m)))
+
+
 def set_option(key, value):
     """rofl_set_option: process-wide behaviour switches of the library (include/rofl_zk.h): "verify_zip_truncate", "verify_batch"
     (0 per proof, 1 per client, 2 per batch with a closer look on failure), "sigma_batch", "blocking_sync", "devices" (bit mask of the

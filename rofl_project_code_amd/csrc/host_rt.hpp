@@ -467,7 +467,13 @@ struct WTabs { ndm *wtab = nullptr, *wtab_many = nullptr; size_t bytes = 0;
                ~WTabs() { if (wtab) (void)hipFree(wtab); if (wtab_many) (void)hipFree(wtab_many); } };
 struct GensEntry { niels *tbl = nullptr; std::shared_ptr<WTabs> wt; ndm *wtab = nullptr, *wtab_many = nullptr; u32 wc = 16, wc_many = 0; FoldTabCfg fc{}; size_t bytes = 0, n = 0, m = 0; u64 tick = 0; int users = 0;
                    bool retired = false;      // a replaced fast-start entry: still read by the calls that pinned it, no longer in the cache map
-                   int full_state = 0; };     // 0 = this is the shape's final table; 1 = the full fold table is still to come; -1 = its build failed (HBM short): compact for good unless prepare retries
+                   int full_state = 0;        // 0 = this is the shape's final table; 1 = the full fold table is still to come; -1 = its build failed (HBM short): compact for good unless prepare retries
+                   bool has_fold = true;      // false: built for a VERIFIER -- generators + window slices only (the verifier never folds); a prover that meets it builds the fold table first
+                   bool fold_building = false; };      // a prover is adding the fold table to a verifier's entry right now (others wait for the swap)
+// Who asks for a shape's tables.  The prover reads everything; the verifier reads the generators (slice 0 of `tbl`) and the window slices of the
+// fixed-base MSM, never the fold slices -- 102 GB of the 104 at BASELINE cfg 2 / cfg 4.  The reference's server (rofl_service/src/flserver/server.rs:656-687)
+// only ever verifies: its process must not build, hold or evict for a table it never reads.
+enum GensRole { GENS_PROVE = 0, GENS_VERIFY = 1 };
 
 // Behaviour options (rofl_set_option): process-wide, so that a server that drives several devices sets them once.  The environment
 // only provides the defaults, read when the first option is touched.
@@ -859,7 +865,9 @@ struct GensPin {
 // The full fold table of a shape that was started on the compact one (fast start).  Runs on a background thread (wait_quiet: after the
 // first quiet moment) or, when an earlier build failed for want of HBM, synchronously from rofl_bp_gens_prepare.  The caller has pinned
 // `raw` (users) and registered `key` in gens_pending; both are released here.  Returns whether the shape now has its full table.
-bool gens_upgrade(Ctx &P0, GensEntry *raw, std::pair<size_t, size_t> key, FoldTabCfg fc_full, size_t N, bool wait_quiet) {
+bool gens_upgrade(Ctx &P0, GensEntry *raw, std::pair<size_t, size_t> key, FoldTabCfg fc_full, size_t N, bool wait_quiet, const FoldTabCfg *then_full = nullptr) {
+    // then_full: `fc_full` is only the compact layout (a prover met a verifier's entry and wants to start at once); the entry that is swapped in
+    // is registered for a background build of *then_full, exactly like a fresh fast-start entry
     auto give_up = [&](int state) { std::lock_guard<std::mutex> lk(P0.gens_mu); raw->users--; raw->full_state = state; P0.gens_pending.erase(key);
                                     for (size_t k = 0; k < P0.gens_retired.size();)
                                         if (P0.gens_retired[k]->users == 0) { gens_free_entry(P0.gens_retired[k].get()); P0.gens_retired.erase(P0.gens_retired.begin() + (long)k); } else k++; };
@@ -917,33 +925,70 @@ bool gens_upgrade(Ctx &P0, GensEntry *raw, std::pair<size_t, size_t> key, FoldTa
     }
     std::unique_ptr<GensEntry> full(new GensEntry(*raw));      // shares the window tables (WTabs) with the entry it replaces
     full->tbl = reinterpret_cast<niels *>(tv); full->fc = fc_full; full->users = 0; full->tick = ++P0.gens_tick; full->full_state = 0;
+    full->has_fold = true; full->fold_building = false;
     full->bytes = raw->bytes - sizeof(niels) * 2 * N * raw->fc.np * raw->fc.e + bytes;
     std::unique_ptr<GensEntry> old = std::move(it->second);
     it->second = std::move(full);
     old->retired = true; old->bytes = sizeof(niels) * 2 * N * old->fc.np * old->fc.e;      // what it still holds alone: its compact fold table
     if (old->users == 0) gens_free_entry(old.get()); else P0.gens_retired.push_back(std::move(old));
     gens_evict(P0, P0.gens_budget, it->second.get());
+    if (then_full) {
+        GensEntry *nraw = it->second.get();
+        const FoldTabCfg fcf = *then_full;
+        nraw->users++; nraw->full_state = 1; P0.gens_pending[key] = 1;
+        Ctx *pp = &P0;
+        P0.gens_upgrades.emplace_back([pp, nraw, key, fcf, N] { gens_upgrade(*pp, nraw, key, fcf, N, /*wait_quiet=*/true); });
+    }
     return true;
 }
-GensPin get_gens(Ctx &C, size_t n, size_t m) {
-    Ctx &P0 = C.parent ? *C.parent : C;
-    std::lock_guard<std::mutex> gens_lock(P0.gens_mu);
-    auto key = std::make_pair(n, m);
-    auto it = P0.gens.find(key);
-    if (it != P0.gens.end()) { it->second->tick = ++P0.gens_tick; it->second->users++; return GensPin(&P0, it->second.get()); }
-    size_t N = n * m;
-    std::unique_ptr<GensEntry> ent(new GensEntry());
+// the fold-table layout a prover wants for N = n * m generators per side: the widest NAF whose table fits the per-shape budget
+FoldTabCfg gens_full_cfg(const Ctx &P0, size_t N) {
     FoldTabCfg fc{P0.fold_pb, P0.fold_w, 256 / P0.fold_pb, 1u << (P0.fold_w - 2)};
     // HBM capacity for VALU work: a width-w NAF needs 2^(w-2) odd multiples per piece and leaves 1/(w+1) of the digits non-zero
     while (fc.w > 6 && sizeof(niels) * 2 * N * fc.np * fc.e > P0.fold_tab_budget) { fc.w--; fc.e = 1u << (fc.w - 2); }
     if (sizeof(niels) * 2 * N * fc.np * fc.e > std::max(P0.fold_tab_budget, (size_t)40 << 30)) fc = FoldTabCfg{64, 4, 4, 4};     // very large tables: the compact layout
+    return fc;
+}
+bool gens_lazy_for(const FoldTabCfg &fc, size_t N) {
+    static const bool lazy_on = !(knob("ROFL_GENS_LAZY") && atoi(knob("ROFL_GENS_LAZY")) == 0);
+    return lazy_on && !(fc.pb == 64 && fc.w == 4) && sizeof(niels) * 2 * N * fc.np * fc.e >= ((size_t)4 << 30);
+}
+GensPin get_gens(Ctx &C, size_t n, size_t m, GensRole role = GENS_PROVE) {
+    Ctx &P0 = C.parent ? *C.parent : C;
+    auto key = std::make_pair(n, m);
+    size_t N = n * m;
+    for (;;) {      // (a prover that meets a verifier's entry adds the fold table and looks again)
+        std::unique_lock<std::mutex> find_lock(P0.gens_mu);
+        auto it = P0.gens.find(key);
+        if (it == P0.gens.end()) break;      // (the lock is released here; the builder below takes it again -- see there)
+        GensEntry *e = it->second.get();
+        if (role == GENS_VERIFY || e->has_fold) { e->tick = ++P0.gens_tick; e->users++; return GensPin(&P0, e); }
+        if (e->fold_building) { find_lock.unlock(); struct timespec ts = {0, 200000}; nanosleep(&ts, nullptr); continue; }      // another prover is at it
+        e->fold_building = true; e->users++; P0.gens_pending[key] = 2;
+        find_lock.unlock();
+        const FoldTabCfg fc_full = gens_full_cfg(P0, N);
+        const bool lazy = gens_lazy_for(fc_full, N);
+        const FoldTabCfg fc_first = lazy ? FoldTabCfg{64, 4, 4, 4} : fc_full;
+        if (!gens_upgrade(P0, e, key, fc_first, N, /*wait_quiet=*/false, lazy ? &fc_full : nullptr)) {
+            { std::lock_guard<std::mutex> lk(P0.gens_mu); auto it2 = P0.gens.find(key); if (it2 != P0.gens.end() && it2->second.get() == e) e->fold_building = false; }
+            throw HipErr{hipErrorOutOfMemory, "hipMalloc(fold table of a shape first used by a verifier)"};
+        }
+    }
+    std::lock_guard<std::mutex> gens_lock(P0.gens_mu);
+    {   // (between the two locks another thread may have built the shape)
+        auto it = P0.gens.find(key);
+        if (it != P0.gens.end() && (role == GENS_VERIFY || it->second->has_fold)) { it->second->tick = ++P0.gens_tick; it->second->users++; return GensPin(&P0, it->second.get()); }
+        if (it != P0.gens.end()) throw HipErr{hipErrorNotReady, "generator tables changed hands while they were being looked up"};      // (a verifier's entry appeared in the gap: the caller retries the call; never seen)
+    }
+    std::unique_ptr<GensEntry> ent(new GensEntry());
+    FoldTabCfg fc = gens_full_cfg(P0, N);
     // Fast start: allocating a 25 GB table takes 0 - 0.7 s depending on the state of the box, and the first call of a process waited for it.
     // The first calls are served from the compact 16-slice fold table (0.8 GB at cfg 2; the first fold is ~2.5 ms slower) while a background
     // thread allocates and builds the full table, then swaps it in; calls that still read the compact entry keep it alive until they return.
-    static const bool lazy_on = !(knob("ROFL_GENS_LAZY") && atoi(knob("ROFL_GENS_LAZY")) == 0);
     const FoldTabCfg fc_full = fc;
-    const bool lazy = lazy_on && !(fc.pb == 64 && fc.w == 4) && sizeof(niels) * 2 * N * fc.np * fc.e >= ((size_t)4 << 30);
+    const bool lazy = role == GENS_PROVE && gens_lazy_for(fc, N);
     if (lazy) fc = FoldTabCfg{64, 4, 4, 4};
+    if (role == GENS_VERIFY) fc = FoldTabCfg{64, 4, 1, 1};      // one "slice": the generators themselves
     void *tblv = nullptr;
     hipError_t me = gens_malloc(P0, &tblv, sizeof(niels) * 2 * N * fc.np * fc.e, nullptr);      // slice 0 = generators, the rest = fold tables
     while (me != hipSuccess && !(fc.pb == 64 && fc.w == 4) && fc.w > 7) {      // HBM is short: one NAF width less = half the table
@@ -956,13 +1001,13 @@ GensPin get_gens(Ctx &C, size_t n, size_t m) {
     }
     if (me != hipSuccess) throw HipErr{me, "hipMalloc(generator tables)"};
     niels *tbl = reinterpret_cast<niels *>(tblv);
-    ent->tbl = tbl; ent->fc = fc; ent->n = n; ent->m = m;
+    ent->tbl = tbl; ent->fc = fc; ent->n = n; ent->m = m; ent->has_fold = role != GENS_VERIFY;
     ent->bytes = sizeof(niels) * 2 * N * fc.np * fc.e;
     try {
         uint8_t *uni = C.uni.as<uint8_t>(2 * N * 64);
         hipLaunchKernelGGL(k_gens_xof, grid1(2 * m), dim3(TPB), 0, C.stream, (u32)n, (u32)m, uni);
         hipLaunchKernelGGL(k_gens_map, grid1(2 * N), dim3(TPB), 0, C.stream, (u32)(2 * N), uni, tbl);
-        hipLaunchKernelGGL(k_gens_tables, grid1(2 * N * fc.np), dim3(TPB), 0, C.stream, (u32)(2 * N), fc, tbl, (size_t)(2 * N));
+        if (ent->has_fold) hipLaunchKernelGGL(k_gens_tables, grid1(2 * N * fc.np), dim3(TPB), 0, C.stream, (u32)(2 * N), fc, tbl, (size_t)(2 * N));
         // Window table of the fixed-base MSM.  Its window width follows the size of the generator set: 16-bit windows (16 slices, 32 768
         // buckets per set) from 2^17 generators on; 13-bit windows (20 slices, 4 096 buckets) below -- many small chunks (n_partition = 64:
         // 128 L / R problems of 16 384 terms per round) would otherwise spread 8 entries per bucket over 4 M buckets, and the bucket

@@ -59,7 +59,7 @@ int verify_chunks(Ctx &C, const char *label, size_t gens_capacity, size_t P, siz
     size_t N = n * m;
     std::vector<char> dead(P, 0);
     if (N != ((size_t)1 << lg)) return ROFL_OK;    // VerificationError for every chunk
-    GensPin gens = get_gens(C, n, m);
+    GensPin gens = get_gens(C, n, m, GENS_VERIFY);
     vmark("gens");
     niels *tbl = gens.tbl();
     const niels *wtab = gens.wtab();

@@ -381,7 +381,7 @@ int verify_impl(Ctx &C, size_t n_clients, const uint8_t *const *proofs, size_t p
         d_vn2 = cp2;
     }
     std::vector<int> okc(P);
-    GensPin gens_pin = get_gens(C, prove_range, chunk);
+    GensPin gens_pin = get_gens(C, prove_range, chunk, GENS_VERIFY);      // generators + window slices; a verifier never builds the prover's fold table
     const int vbatch = opts().verify_batch.load();            // rofl_set_option("verify_batch")
     size_t grp = vbatch ? nv : 1;
     // verify_batch = 2: one check for the whole batch, a closer look only when it fails (verify_chunks); clients already known to be
@@ -594,6 +594,11 @@ int rofl_bp_gens_prepare(size_t n_bits, size_t m) {
         if (!gens_wait_full(C, n_bits, m)) g_err = "HBM is short: the shape keeps its compact fold table (same results, slower first fold)";      // not an error: see rofl_zk.h
         return ROFL_OK; });
 }
+int rofl_bp_gens_prepare_verify(size_t n_bits, size_t m) {
+    return guarded([&]() -> int { LaneLock lane_lock = acquire_lane(); Ctx &C = *lane_lock.c; C.init(); if (!n_bits || !m) return fail(ROFL_BAD_PARAM, "bad parameter");
+        { GensPin pin = get_gens(C, n_bits, m, GENS_VERIFY); }
+        return ROFL_OK; });
+}
 int rofl_bp_gens_table_bytes(size_t n_bits, size_t m, size_t *bytes_out) {
     return guarded([&]() -> int {
         if (!bytes_out) return fail(ROFL_BAD_PARAM, "bad parameter");
@@ -608,7 +613,7 @@ int rofl_bp_gens_export(size_t n_bits, size_t m, uint8_t *G_out, uint8_t *H_out)
     return guarded([&]() -> int {
         LaneLock lane_lock = acquire_lane(); Ctx &C = *lane_lock.c; C.init();
         if (!n_bits || !m) return fail(ROFL_BAD_PARAM, "bad parameter");
-        GensPin gens = get_gens(C, n_bits, m); niels *tbl = gens.tbl(); size_t N = n_bits * m;
+        GensPin gens = get_gens(C, n_bits, m, GENS_VERIFY); niels *tbl = gens.tbl(); size_t N = n_bits * m;
         // encode through the commit path: decode-free -- use k_msm-free helper: copy niels back and encode on host
         std::vector<niels> h(2 * N);
         HIPCHK(hipMemcpy(h.data(), tbl, sizeof(niels) * 2 * N, hipMemcpyDeviceToHost));

@@ -1,0 +1,60 @@
+"""Worker of tests/test_gpu_roles.py: generator tables are role-aware.
+
+  gpu_role_worker.py prove  <case.npz> <out.npz>      a client process: proves the case at n_partition = 64, saves proofs + commitments
+  gpu_role_worker.py verify <case.npz> <p64.npz>      a SERVER process (rofl_service/src/flserver/server.rs:656-687 only ever verifies):
+      verifies the oracle's P = 4 proof set and the client's P = 64 set of d = 55 000, tampered copies too, and checks that it holds
+      < 3 GB per shape, both shapes at once, no fold table -- then proves the same case in this process: the create call meets the
+      verifier's entry, adds the fold table, and returns the oracle's bytes."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    mode, case = sys.argv[1], np.load(sys.argv[2])
+    import rofl_project_code_amd as R
+    from rofl_project_code_amd import api
+    R.set_device(0)
+    vals, bl, seed, nb = case["vals"], case["bl"], bytes(case["seed"]), int(case["nb"])
+    fp = (int(case["fp"][0]), int(case["fp"][1]))
+    d = vals.size; dp = 1 << (d - 1).bit_length()
+    if mode == "prove":
+        pr, cm = R.range_proof_vec.create_rangeproof(vals, bl, nb, 64, nonce=R.Nonce.seeded(seed), fp=fp)
+        np.savez(sys.argv[3], pr=pr, cm=cm)
+        print("role ok: proved", pr.shape)
+        return
+    p64 = np.load(sys.argv[3])
+    m4, m64 = dp // 4, dp // 64
+    t0 = time.time(); api.bp_gens_prepare_verify(nb, m4); t_prep = time.time() - t0
+    b4 = api.bp_gens_table_bytes(nb, m4)
+    assert 0 < b4 < 3e9, b4
+    assert R.range_proof_vec.verify_rangeproof(case["opr"], case["ocm"], nb, verifier_seed=b"\x01" * 32, fp=fp) is True
+    assert R.range_proof_vec.verify_rangeproof(p64["pr"], p64["cm"], nb, verifier_seed=b"\x01" * 32, fp=fp) is True
+    bad = case["opr"].copy(); bad[2, 77] ^= 8
+    assert R.range_proof_vec.verify_rangeproof(bad, case["ocm"], nb, verifier_seed=b"\x01" * 32, fp=fp) is False
+    bad = p64["pr"].copy(); bad[40, 300] ^= 1
+    assert R.range_proof_vec.verify_rangeproof(bad, p64["cm"], nb, verifier_seed=b"\x01" * 32, fp=fp) is False
+    assert R.range_proof_vec.verify_rangeproof_batch([case["opr"]] * 3, [case["ocm"]] * 3, nb, verifier_seed=b"\x02" * 32, fp=fp) == [True] * 3
+    time.sleep(0.2)      # (a background builder, if a verify path had started one, would be at work by now)
+    b4b, b64 = api.bp_gens_table_bytes(nb, m4), api.bp_gens_table_bytes(nb, m64)
+    assert b4b == b4 and 0 < b64 < 3e9, (b4, b4b, b64)      # both shapes resident at once, nothing evicted, nothing grown
+    free0 = __import__("torch").cuda.mem_get_info()[0] if False else None      # (no torch in this process: the byte counts above are the library's own accounting)
+    # the same process now proves: the create call meets the verifier's entry of (nb, m4) and adds the fold table
+    pr, cm = R.range_proof_vec.create_rangeproof(vals, bl, nb, 4, nonce=R.Nonce.seeded(seed), fp=fp)
+    assert (pr == case["opr"]).all() and (cm == case["ocm"]).all(), "create after verify differs from the oracle"
+    assert api.bp_gens_table_bytes(nb, m4) > b4
+    api.bp_gens_prepare(nb, m4)      # and the full table on request
+    b_full = api.bp_gens_table_bytes(nb, m4)
+    pr2, _ = R.range_proof_vec.create_rangeproof(vals, bl, nb, 4, nonce=R.Nonce.seeded(seed), fp=fp)
+    assert (pr2 == case["opr"]).all()
+    assert R.range_proof_vec.verify_rangeproof(pr2, cm, nb, verifier_seed=b"\x03" * 32, fp=fp) is True
+    print("role ok: verify-only %.2f GB (P=4 shape, built in %.2f s) + %.2f GB (P=64 shape); after create %.1f GB" % (b4 / 1e9, t_prep, b64 / 1e9, b_full / 1e9))
+
+
+if __name__ == "__main__":
+    main()

@@ -66,41 +66,28 @@ def test_cfg4_chunk0_vs_oracle(R):
     assert R.range_proof_vec.verify_rangeproof(opr, ocm, nb, verifier_seed=b"\x02" * 32, fp=fp)
 
 
-def test_cfg2_whole_proof_full_size_vs_oracle(R):
+def test_cfg2_whole_proof_full_size_vs_oracle(R, full_oracle):
     """BASELINE cfg 2 (the headline): d = 25 000, 32-bit, P = 4 -- ALL four chunks and all commitments against the oracle, bit for
-    bit (chunks 1-3 used to be covered by round trip / tamper only).  The oracle proves the chunks on four threads."""
-    import os
-    os.environ.setdefault("OMP_NUM_THREADS", "4")
-    fp = (32, 7)
-    rng = np.random.default_rng(250004)
-    d, nb, P = 25000, 32, 4
-    vals = _uniform(R, rng, d, nb, fp)
-    bl = rng.integers(0, 256, size=(d, 32), dtype=np.uint8); bl[:, 31] &= 0x0F
-    seed = b"\x51" * 32
-    pr, cm = R.range_proof_vec.create_rangeproof(vals, bl, nb, P, nonce=R.Nonce.seeded(seed), fp=fp)
-    rc, opr, ocm = orc.create_rangeproof(vals, bl, nb, P, 32, 7, seed=seed)
-    assert rc == 0 and opr.shape == pr.shape == (4, 1440)
-    for c in range(4):
-        assert (opr[c] == pr[c]).all(), "chunk %d differs from the oracle" % c
+    bit (chunks 1-3 used to be covered by round trip / tamper only).  The oracle proves the chunks on four threads
+    (once per session: conftest.full_oracle)."""
+    c = full_oracle.case("cfg2")
+    pr, cm = R.range_proof_vec.create_rangeproof(c["vals"], c["bl"], c["nb"], c["P"], nonce=R.Nonce.seeded(c["seed"]), fp=c["fp"])
+    opr, ocm = c["opr"], c["ocm"]
+    assert opr.shape == pr.shape == (4, 1440)
+    for k in range(4):
+        assert (opr[k] == pr[k]).all(), "chunk %d differs from the oracle" % k
     assert (ocm == cm).all()
-    assert orc.verify_rangeproof(pr, cm, nb, 32, 7) == (0, True)
+    assert orc.verify_rangeproof(pr, cm, c["nb"], 32, 7) == (0, True)
 
 
-def test_cfg4_whole_proof_full_size_vs_oracle(R):
+def test_cfg4_whole_proof_full_size_vs_oracle(R, full_oracle):
     """BASELINE cfg 4 shape, one client: d = 55 000 (m = 16 384 per chunk, N = 2^19), 32-bit, P = 4 -- all four chunks bit for bit."""
-    import os
-    os.environ.setdefault("OMP_NUM_THREADS", "4")
-    fp = (32, 7)
-    rng = np.random.default_rng(550004)
-    d, nb, P = 55000, 32, 4
-    vals = _uniform(R, rng, d, nb, fp)
-    bl = rng.integers(0, 256, size=(d, 32), dtype=np.uint8); bl[:, 31] &= 0x0F
-    seed = b"\x52" * 32
-    pr, cm = R.range_proof_vec.create_rangeproof(vals, bl, nb, P, nonce=R.Nonce.seeded(seed), fp=fp)
-    rc, opr, ocm = orc.create_rangeproof(vals, bl, nb, P, 32, 7, seed=seed)
-    assert rc == 0 and opr.shape == pr.shape == (4, 1504)
-    for c in range(4):
-        assert (opr[c] == pr[c]).all(), "chunk %d differs from the oracle" % c
+    c = full_oracle.case("cfg4")
+    pr, cm = R.range_proof_vec.create_rangeproof(c["vals"], c["bl"], c["nb"], c["P"], nonce=R.Nonce.seeded(c["seed"]), fp=c["fp"])
+    opr, ocm = c["opr"], c["ocm"]
+    assert opr.shape == pr.shape == (4, 1504)
+    for k in range(4):
+        assert (opr[k] == pr[k]).all(), "chunk %d differs from the oracle" % k
     assert (ocm == cm).all()
 
 

@@ -197,11 +197,11 @@ MsmJob msm_enqueue(Ctx &C, MsmWs &W, const std::vector<MsmProb> &probs, size_t n
         if (opt.pts_ready) HIPCHK(hipStreamWaitEvent(st, opt.pts_ready, 0));
         const u32 Wg = (P.W + G - 1) / G;      // blocks per problem
         if (G > 1)
-            hipLaunchKernelGGL(k_msm_small_g, dim3((unsigned)(np * Wg)), dim3(G * P.B), std::max(lds_lists, lds_red), st, n_side, mw, mm, d_probs, buckets,
+            ROFL_LAUNCH(k_msm_small_g, dim3((unsigned)(np * Wg)), dim3(G * P.B), std::max(lds_lists, lds_red), st, n_side, mw, mm, d_probs, buckets,
                                S_fin_s, C_fin_s, nb_final, d_flag, small_cap, G, tl_dev, J.host8 ? hres_dev : (ge *)nullptr,
                                lr ? opt.ip_dev : (const sc *)nullptr, opt.ip_nblk, lr ? opt.qpts : (const niels *)nullptr);
         else
-            hipLaunchKernelGGL(k_msm_small, dim3((unsigned)PW), dim3(P.B < 64 ? 64 : P.B), std::max(lds_lists, lds_red), st, n_side, mw, mm, d_probs, buckets,
+            ROFL_LAUNCH(k_msm_small, dim3((unsigned)PW), dim3(P.B < 64 ? 64 : P.B), std::max(lds_lists, lds_red), st, n_side, mw, mm, d_probs, buckets,
                                S_fin_s, C_fin_s, nb_final, d_flag, small_cap, G, tl_dev, J.host8 ? hres_dev : (ge *)nullptr,
                                lr ? opt.ip_dev : (const sc *)nullptr, opt.ip_nblk, lr ? opt.qpts : (const niels *)nullptr);
         if (small_tl) {      // mean phase durations over the blocks of this launch (100 MHz clock)
@@ -214,7 +214,7 @@ MsmJob msm_enqueue(Ctx &C, MsmWs &W, const std::vector<MsmProb> &probs, size_t n
                     PW, nblocks, n_side, P.c, ph[0] / nblocks * 0.01, ph[1] / nblocks * 0.01, ph[2] / nblocks * 0.01, (double)(t_hi - t_lo) * 0.01);
         }
         if (J.host8) {}      // (the launch added up each window's bit-sums itself)
-        else if (J.dev_horner) hipLaunchKernelGGL(k_msm_horner, dim3((unsigned)np), dim3(256), 0, st, mw, (const ge *)S_fin_s, (const ge *)C_fin_s, nb_final, hres_dev);
+        else if (J.dev_horner) ROFL_LAUNCH(k_msm_horner, dim3((unsigned)np), dim3(256), 0, st, mw, (const ge *)S_fin_s, (const ge *)C_fin_s, nb_final, hres_dev);
         return J;
     }
     // ---- SORT (+ ACCUMULATE: its list format depends on the sort)
@@ -229,9 +229,9 @@ MsmJob msm_enqueue(Ctx &C, MsmWs &W, const std::vector<MsmProb> &probs, size_t n
         while (((size_t)((n_side + tile - 1) / tile) * PW > 512 || (n_side + tile - 1) / tile > 48) && tile < n_side) tile *= 2;      // <= 48 tiles per array: their left-overs (< 32 each) fit the bin tails with room for row spills
         dim3 grid((n_side + tile - 1) / tile, (u32)PW);
         { KSpan ks(C.tm, st, ROFL_TK_MSM_SCATTER, 0, terms * 32 + terms * P.W * 4);
-          hipLaunchKernelGGL(k_msm_bin_l1, grid, dim3(1024), (size_t)(tl.nbins + tl.nbins * tl.stage) * 4, st, n_side, tile, iter_pts, mw, mm, d_probs, bcur, bins, btail, tl, d_flag);
-          hipLaunchKernelGGL(k_msm_bin_l2, dim3(tl.nbins, (u32)PW), dim3(512), (size_t)(2 * 128 + tl.cap_bin) * 4, st, tl, P.B, bcur, bins, (const u32 *)btail, cnt, off, d_flag); }
-        hipLaunchKernelGGL(k_msm_scan, dim3((unsigned)PW), dim3(P.B >= 1024 ? 1024 : 256), 0, st, P.B, cnt, off, (u32 *)nullptr, perm);
+          ROFL_LAUNCH(k_msm_bin_l1, grid, dim3(1024), (size_t)(tl.nbins + tl.nbins * tl.stage) * 4, st, n_side, tile, iter_pts, mw, mm, d_probs, bcur, bins, btail, tl, d_flag);
+          ROFL_LAUNCH(k_msm_bin_l2, dim3(tl.nbins, (u32)PW), dim3(512), (size_t)(2 * 128 + tl.cap_bin) * 4, st, tl, P.B, bcur, bins, (const u32 *)btail, cnt, off, d_flag); }
+        ROFL_LAUNCH(k_msm_scan, dim3((unsigned)PW), dim3(P.B >= 1024 ? 1024 : 256), 0, st, P.B, cnt, off, (u32 *)nullptr, perm);
         if (C.tm.enabled) { e0 = C.tm.get(); e1 = C.tm.get(); HIPCHK(hipEventRecord(e0, st)); }
         {
             KSpan ks_acc(C.tm, st, ROFL_TK_MSM_ACCUMULATE_FB, terms * P.W * 7, terms * 32);
@@ -240,13 +240,13 @@ MsmJob msm_enqueue(Ctx &C, MsmWs &W, const std::vector<MsmProb> &probs, size_t n
                 dim3 g = grid1((size_t)Wb * P.B, (u32)nq);
                 size_t waves = (size_t)g.x * g.y * (TPB / 64);
                 unsigned long long *rec; HIPCHK(hipMalloc(&rec, waves * 32)); HIPCHK(hipMemsetAsync(rec, 0, waves * 32, st));
-                hipLaunchKernelGGL(k_msm_accumulate_fb_dbg, g, dim3(TPB), 0, st, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, bins, perm, buckets, MSM_LIST_ABS, dbg_mask, acc_balance, rec);
+                ROFL_LAUNCH(k_msm_accumulate_fb_dbg, g, dim3(TPB), 0, st, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, bins, perm, buckets, MSM_LIST_ABS, dbg_mask, acc_balance, rec);
                 std::vector<unsigned long long> h(waves * 4);
                 HIPCHK(hipMemcpyAsync(h.data(), rec, waves * 32, hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st));
                 if (FILE *f = fopen(timeline, "ab")) { unsigned long long hdr[4] = {0x54494d45ull, waves, g.x, g.y}; fwrite(hdr, 8, 4, f); fwrite(h.data(), 8, h.size(), f); fclose(f); }
                 HIPCHK(hipFree(rec));
             } else
-            hipLaunchKernelGGL(k_msm_accumulate_fb, grid1((size_t)Wb * P.B, (u32)nq), dim3(TPB), 0, st, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, bins, perm, buckets, MSM_LIST_ABS, dbg_mask, acc_balance);
+            ROFL_LAUNCH(k_msm_accumulate_fb, grid1((size_t)Wb * P.B, (u32)nq), dim3(TPB), 0, st, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, bins, perm, buckets, MSM_LIST_ABS, dbg_mask, acc_balance);
         }
         if (C.tm.enabled) HIPCHK(hipEventRecord(e1, st));
     } else if (J.kind != MsmKind::CountSort) {      // slot sort (fixed-base or generic)
@@ -264,30 +264,30 @@ MsmJob msm_enqueue(Ctx &C, MsmWs &W, const std::vector<MsmProb> &probs, size_t n
             dim3 grid((n_side + tile - 1) / tile, (u32)(nq * (lr ? 2 : 1) * per_q));
             uint64_t items = terms * P.W;
             KSpan ks(C.tm, st, ROFL_TK_MSM_SCATTER, 0, terms * 32 + items * 4);
-            hipLaunchKernelGGL(k_msm_scatter_lds, grid, dim3(1024), (size_t)P.B * 4, st, n_side, tile, mw, mm, d_probs, cnt, slots, cap, ovf_count, ovf, MSM_OVF_MAX, dbg_scatter);
+            ROFL_LAUNCH(k_msm_scatter_lds, grid, dim3(1024), (size_t)P.B * 4, st, n_side, tile, mw, mm, d_probs, cnt, slots, cap, ovf_count, ovf, MSM_OVF_MAX, dbg_scatter);
         } else
-            hipLaunchKernelGGL(k_msm_scatter_slots, grid1(n, (u32)(nq * P.W)), dim3(TPB), 0, st, (u32)n, mw, mm, d_probs, cnt, slots, cap, ovf_count, ovf, MSM_OVF_MAX);
-        hipLaunchKernelGGL(k_msm_scan, dim3((unsigned)PW), dim3(P.B >= 1024 ? 1024 : 256), 0, st, P.B, cnt, off, (u32 *)nullptr, perm);
+            ROFL_LAUNCH(k_msm_scatter_slots, grid1(n, (u32)(nq * P.W)), dim3(TPB), 0, st, (u32)n, mw, mm, d_probs, cnt, slots, cap, ovf_count, ovf, MSM_OVF_MAX);
+        ROFL_LAUNCH(k_msm_scan, dim3((unsigned)PW), dim3(P.B >= 1024 ? 1024 : 256), 0, st, P.B, cnt, off, (u32 *)nullptr, perm);
         if (opt.pts_ready) HIPCHK(hipStreamWaitEvent(st, opt.pts_ready, 0));      // (the sort above only read the scalars)
         if (C.tm.enabled) { e0 = C.tm.get(); e1 = C.tm.get(); HIPCHK(hipEventRecord(e0, st)); }
         {
             uint64_t acc_adds = terms * P.W;
             KSpan ks_acc(C.tm, st, fb ? ROFL_TK_MSM_ACCUMULATE_FB : ROFL_TK_MSM_ACCUMULATE_GEN, acc_adds * 7, terms * 32);
-            if (fb) hipLaunchKernelGGL(k_msm_accumulate_fb, grid1((size_t)Wb * P.B, (u32)nq), dim3(TPB), 0, st, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, slots, perm, buckets, cap, dbg_mask, acc_balance);
-            else hipLaunchKernelGGL(k_msm_accumulate_gen, grid1((size_t)Wb * P.B, (u32)nq), dim3(TPB), 0, st, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, slots, perm, buckets, cap, dbg_mask, acc_balance);
+            if (fb) ROFL_LAUNCH(k_msm_accumulate_fb, grid1((size_t)Wb * P.B, (u32)nq), dim3(TPB), 0, st, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, slots, perm, buckets, cap, dbg_mask, acc_balance);
+            else ROFL_LAUNCH(k_msm_accumulate_gen, grid1((size_t)Wb * P.B, (u32)nq), dim3(TPB), 0, st, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, slots, perm, buckets, cap, dbg_mask, acc_balance);
         }
         if (C.tm.enabled) HIPCHK(hipEventRecord(e1, st));
-        hipLaunchKernelGGL(k_msm_overflow, dim3(1), dim3(64), 0, st, Wb, P.B, (u32)(np / nq), d_probs, ovf_count, ovf, MSM_OVF_MAX, buckets, fb ? 1 : 0);
+        ROFL_LAUNCH(k_msm_overflow, dim3(1), dim3(64), 0, st, Wb, P.B, (u32)(np / nq), d_probs, ovf_count, ovf, MSM_OVF_MAX, buckets, fb ? 1 : 0);
         HIPCHK(hipMemcpyAsync(h_flag, ovf_count, 4, hipMemcpyDeviceToHost, st));
     } else {      // count / scan / scatter: no fixed-size structure, always sufficient
         HIPCHK(hipMemsetAsync(cnt, 0, sizeof(u32) * (PW * P.B + 4), st));
         u32 *sorted = W.sorted.as<u32>(PW * n * 2);
-        hipLaunchKernelGGL(k_msm_count, grid1(n, (u32)(nq * P.W)), dim3(TPB), 0, st, (u32)n, mw, mm, d_probs, cnt);
-        hipLaunchKernelGGL(k_msm_scan, dim3((unsigned)PW), dim3(P.B >= 1024 ? 1024 : 256), 0, st, P.B, cnt, off, cur, perm);
-        hipLaunchKernelGGL(k_msm_scatter, grid1(n, (u32)(nq * P.W)), dim3(TPB), 0, st, (u32)n, mw, mm, d_probs, cur, sorted);
+        ROFL_LAUNCH(k_msm_count, grid1(n, (u32)(nq * P.W)), dim3(TPB), 0, st, (u32)n, mw, mm, d_probs, cnt);
+        ROFL_LAUNCH(k_msm_scan, dim3((unsigned)PW), dim3(P.B >= 1024 ? 1024 : 256), 0, st, P.B, cnt, off, cur, perm);
+        ROFL_LAUNCH(k_msm_scatter, grid1(n, (u32)(nq * P.W)), dim3(TPB), 0, st, (u32)n, mw, mm, d_probs, cur, sorted);
         if (opt.pts_ready) HIPCHK(hipStreamWaitEvent(st, opt.pts_ready, 0));
         if (C.tm.enabled) { e0 = C.tm.get(); e1 = C.tm.get(); HIPCHK(hipEventRecord(e0, st)); }
-        hipLaunchKernelGGL(k_msm_accumulate_gen, grid1((size_t)Wb * P.B, (u32)nq), dim3(TPB), 0, st, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, sorted, perm, buckets, 0u, dbg_mask, acc_balance);
+        ROFL_LAUNCH(k_msm_accumulate_gen, grid1((size_t)Wb * P.B, (u32)nq), dim3(TPB), 0, st, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, sorted, perm, buckets, 0u, dbg_mask, acc_balance);
         if (C.tm.enabled) HIPCHK(hipEventRecord(e1, st));
     }
     if (C.tm.enabled) {
@@ -311,16 +311,16 @@ MsmJob msm_enqueue(Ctx &C, MsmWs &W, const std::vector<MsmProb> &probs, size_t n
             ge *GS = W.S[0].as<ge>(PW * G);
             ge *GC = W.Cacc[0].as<ge>(PW * (size_t)G * 9);
             size_t lds_a = ((size_t)64 * 4 + (size_t)32 * 5 + 1) * sizeof(ge);
-            hipLaunchKernelGGL(k_msm_reduce_fused, dim3((unsigned)(PW * G)), dim3(256), lds_a, st, 512u, 0u, (const ge *)buckets, (const ge *)nullptr, GS, GC, 9u);
+            ROFL_LAUNCH(k_msm_reduce_fused, dim3((unsigned)(PW * G)), dim3(256), lds_a, st, 512u, 0u, (const ge *)buckets, (const ge *)nullptr, GS, GC, 9u);
             u32 half = G / 2 ? G / 2 : 1, nout = 10 + gbits;
-            hipLaunchKernelGGL(k_msm_reduce_groups, dim3((unsigned)PW), dim3(half, nout), (size_t)nout * half * sizeof(ge), st, G, gbits, (const ge *)GS, (const ge *)GC, S_fin, C_fin, nb_final);
+            ROFL_LAUNCH(k_msm_reduce_groups, dim3((unsigned)PW), dim3(half, nout), (size_t)nout * half * sizeof(ge), st, G, gbits, (const ge *)GS, (const ge *)GC, S_fin, C_fin, nb_final);
         } else {
             while (E > 512) {
                 u32 E8 = E / 8;
                 ge *S_out = W.S[lv & 1].as<ge>(PW * E8);
                 ge *C_out = W.Cacc[lv & 1].as<ge>(PW * (size_t)(nb + 3) * E8);
                 static const int red_split = knob("ROFL_RED_SPLIT") ? atoi(knob("ROFL_RED_SPLIT")) : 0;
-                hipLaunchKernelGGL(k_msm_reduce_level, grid1((size_t)E8 * ((red_split ? 4 : 1) + nb), (u32)PW), dim3(TPB), 0, st, E, nb, S_in, C_in, S_out, C_out, red_split);
+                ROFL_LAUNCH(k_msm_reduce_level, grid1((size_t)E8 * ((red_split ? 4 : 1) + nb), (u32)PW), dim3(TPB), 0, st, E, nb, S_in, C_in, S_out, C_out, red_split);
                 S_in = S_out; C_in = C_out; E = E8; nb += 3; lv++;
             }
             if (J.dev_horner) { S_fin = W.S[lv & 1].as<ge>(PW); C_fin = W.Cacc[lv & 1].as<ge>(PW * (size_t)nb_final); }
@@ -331,13 +331,13 @@ MsmJob msm_enqueue(Ctx &C, MsmWs &W, const std::vector<MsmProb> &probs, size_t n
             u32 fused_items = (E / 8) * (4 + nb), fused_threads = fused_items > 512 ? (fused_items > 640 ? 768 : 640) : fused_items > 256 ? 512 : fused_items > 128 ? 256 : fused_items > 64 ? 128 : 64;
             if (fused_threads > red_fused_max) fused_threads = red_fused_max;
             size_t lds = ((size_t)(E / 8) * (1 + nb + 3) + (size_t)(E / 16) * (1 + nb + 4) + 1) * sizeof(ge);
-            hipLaunchKernelGGL(k_msm_reduce_fused, dim3((unsigned)PW), dim3(fused_threads), lds, st, E, nb, S_in, C_in, S_fin, C_fin, nb_final);
+            ROFL_LAUNCH(k_msm_reduce_fused, dim3((unsigned)PW), dim3(fused_threads), lds, st, E, nb, S_in, C_in, S_fin, C_fin, nb_final);
         }
     }
     if (J.host8)           // many problems, AVX-512 IFMA host: the device adds up each window's bit-sums, the chains across the windows go to the host
-        hipLaunchKernelGGL(k_msm_wsum, grid1(PW * 4), dim3(TPB), 0, st, (u32)PW, (const ge *)S_fin, (const ge *)C_fin, nb_final, hres_dev);
+        ROFL_LAUNCH(k_msm_wsum, grid1(PW * 4), dim3(TPB), 0, st, (u32)PW, (const ge *)S_fin, (const ge *)C_fin, nb_final, hres_dev);
     else if (J.dev_horner)      // many problems: their Horner chains run side by side on the device, one point per problem comes back
-        hipLaunchKernelGGL(k_msm_horner, dim3((unsigned)np), dim3(256), 0, st, mw, (const ge *)S_fin, (const ge *)C_fin, nb_final, hres_dev);
+        ROFL_LAUNCH(k_msm_horner, dim3((unsigned)np), dim3(256), 0, st, mw, (const ge *)S_fin, (const ge *)C_fin, nb_final, hres_dev);
     return J;
 }
 

@@ -44,24 +44,24 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
     }
     HIPCHK(hipMemcpyAsync(d_cp, h_cp, sizeof(ChunkParams) * P, hipMemcpyHostToDevice, C.stream));
     sc *sL = C.sL.as<sc>(P * N), *sR = C.sR.as<sc>(P * N), *party = C.party.as<sc>(P * 4 * m), *Scanon = C.Scanon.as<sc>(P * 2 * N);
-    hipLaunchKernelGGL(k_nonce_expand, grid1(per / 2 + 1, (u32)P), dim3(TPB), 0, C.stream, (u32)n, (u32)m, d_cp, sL, sR, party, Scanon);
+    ROFL_LAUNCH(k_nonce_expand, grid1(per / 2 + 1, (u32)P), dim3(TPB), 0, C.stream, (u32)n, (u32)m, d_cp, sL, sR, party, Scanon);
     // A partials: they depend on the values only and the host reads them after the S MSM -- side stream, beside the nonce expansion
     if (!C.stream2) HIPCHK(hipStreamCreateWithFlags(&C.stream2, hipStreamNonBlocking));
     if (!C.ev_a) { HIPCHK(hipEventCreateWithFlags(&C.ev_a, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&C.ev_a0, hipEventDisableTiming)); }
     HIPCHK(hipEventRecord(C.ev_a0, C.stream));                    // d_vshift is ready (and the previous call's reads of `partial` are done)
     HIPCHK(hipStreamWaitEvent(C.stream2, C.ev_a0, 0));
     ge *partial = C.partial.as<ge>(P * m);
-    hipLaunchKernelGGL(k_bitcommit, grid1(m, (u32)P), dim3(TPB), 0, C.stream2, (u32)n, (u32)m, d_vshift, tbl, partial);
+    ROFL_LAUNCH(k_bitcommit, grid1(m, (u32)P), dim3(TPB), 0, C.stream2, (u32)n, (u32)m, d_vshift, tbl, partial);
     u32 nblkA = (u32)std::min<size_t>(16, (m + TPB - 1) / TPB);
     ge *partial2 = C.partial2.as<ge>(P * nblkA);
-    hipLaunchKernelGGL(k_point_sum, dim3(nblkA, (u32)P), dim3(TPB), TPB * sizeof(ge), C.stream2, partial, (u32)m, partial2);
+    ROFL_LAUNCH(k_point_sum, dim3(nblkA, (u32)P), dim3(TPB), TPB * sizeof(ge), C.stream2, partial, (u32)m, partial2);
     ge *h_A = C.h_part.as<ge>(P * nblkA);
     HIPCHK(hipMemcpyAsync(h_A, partial2, sizeof(ge) * P * nblkA, hipMemcpyDeviceToHost, C.stream2));
     HIPCHK(hipEventRecord(C.ev_a, C.stream2));
     u32 nblkS = (u32)std::min<size_t>(16, (m + TPB - 1) / TPB);
     sc *scpart = C.scpart.as<sc>(P * 64 * 3);
     PowTabs *d_pt = C.powtabs.as<PowTabs>(P);
-    hipLaunchKernelGGL(k_party_sums, dim3(nblkS, (u32)P), dim3(TPB), 0, C.stream, (u32)m, 0, d_cp, (const PowTabs *)d_pt, party, d_blind, scpart);
+    ROFL_LAUNCH(k_party_sums, dim3(nblkS, (u32)P), dim3(TPB), 0, C.stream, (u32)m, 0, d_cp, (const PowTabs *)d_pt, party, d_blind, scpart);
     sc *h_sc = C.h_misc2.as<sc>(P * 64 * 3);
     HIPCHK(hipMemcpyAsync(h_sc, scpart, sizeof(sc) * P * nblkS * 3, hipMemcpyDeviceToHost, C.stream));
     // S = <sL,G> + <sR,H> + s_bl * Bb
@@ -113,9 +113,9 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
     // (enough blocks for four waves per SIMD when the chunks are few: 64 per chunk ran a four-chunk client's 1 M slots on 65 536 threads)
     u32 nblkT = (u32)std::min<size_t>(std::max<size_t>(64, std::min<size_t>(256, 2048 / P)), (N + TPB - 1) / TPB);
     sc *tpart = C.tmp_out.as<sc>(P * 256 * 3);
-    hipLaunchKernelGGL(k_pow_tables, dim3((4 * PT_L * PT_E + TPB - 1) / TPB, (u32)P), dim3(TPB), 0, C.stream, d_cp, d_pt, lgN, 0);
-    hipLaunchKernelGGL(k_poly_t, dim3(nblkT, (u32)P), dim3(TPB), 0, C.stream, (u32)n, (u32)m, d_cp, (const PowTabs *)d_pt, d_vshift, sL, sR, C.d_two_pow, tpart);
-    hipLaunchKernelGGL(k_party_sums, dim3(nblkS, (u32)P), dim3(TPB), 0, C.stream, (u32)m, 1, d_cp, (const PowTabs *)d_pt, party, d_blind, scpart);
+    ROFL_LAUNCH(k_pow_tables, dim3((4 * PT_L * PT_E + TPB - 1) / TPB, (u32)P), dim3(TPB), 0, C.stream, d_cp, d_pt, lgN, 0);
+    ROFL_LAUNCH(k_poly_t, dim3(nblkT, (u32)P), dim3(TPB), 0, C.stream, (u32)n, (u32)m, d_cp, (const PowTabs *)d_pt, d_vshift, sL, sR, C.d_two_pow, tpart);
+    ROFL_LAUNCH(k_party_sums, dim3(nblkS, (u32)P), dim3(TPB), 0, C.stream, (u32)m, 1, d_cp, (const PowTabs *)d_pt, party, d_blind, scpart);
     sc *h_t = C.h_part.as<sc>(P * 256 * 3);
     HIPCHK(hipMemcpyAsync(h_t, tpart, sizeof(sc) * P * nblkT * 3, hipMemcpyDeviceToHost, C.stream));
     HIPCHK(hipMemcpyAsync(h_sc, scpart, sizeof(sc) * P * nblkS * 3, hipMemcpyDeviceToHost, C.stream));
@@ -157,10 +157,10 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
     const bool lr_first = lr_first_on && C.msm_lr != 0 && N >= 2;
     const u32 lr_first_blocks = (u32)std::min<size_t>(256, (N / 2 + TPB - 1) / TPB);
     if (lr_first)
-        hipLaunchKernelGGL(k_lr_first, dim3(lr_first_blocks, (u32)P), dim3(TPB), 0, C.stream, (u32)n, (u32)m, d_cp, (const PowTabs *)d_pt, d_vshift, sL, sR, C.d_two_pow, a, b, yinvpow,
+        ROFL_LAUNCH(k_lr_first, dim3(lr_first_blocks, (u32)P), dim3(TPB), 0, C.stream, (u32)n, (u32)m, d_cp, (const PowTabs *)d_pt, d_vshift, sL, sR, C.d_two_pow, a, b, yinvpow,
                            C.SL.as<sc>(P * 2 * N), C.h_ip.dev<sc>(P * 256 * 2));
     else
-        hipLaunchKernelGGL(k_lr_vec, grid1(N, (u32)P), dim3(TPB), 0, C.stream, (u32)n, (u32)m, d_cp, (const PowTabs *)d_pt, d_vshift, sL, sR, C.d_two_pow, a, b, yinvpow);
+        ROFL_LAUNCH(k_lr_vec, grid1(N, (u32)P), dim3(TPB), 0, C.stream, (u32)n, (u32)m, d_cp, (const PowTabs *)d_pt, d_vshift, sL, sR, C.d_two_pow, a, b, yinvpow);
     mark("poly/T/x");
 
     // ---- IPP rounds with lazily folded generators
@@ -211,7 +211,7 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
         if (fused) {
             nblkI = (u32)std::min<size_t>(256, std::max<size_t>(1, (n_g + TPB - 1) / TPB));      // one slot per thread while the 256 partial-sum rows last (the tail rounds are one 13-multiplication chain deep)
             int use_new = just_materialised ? 0 : 1;
-            hipLaunchKernelGGL(k_ipp_round, dim3(nblkI, (u32)P), dim3(TPB), 0, C.stream, (u32)n_g, (u32)n_k, use_new ? r - 1 : 0u, use_new, d_cp,
+            ROFL_LAUNCH(k_ipp_round, dim3(nblkI, (u32)P), dim3(TPB), 0, C.stream, (u32)n_g, (u32)n_k, use_new ? r - 1 : 0u, use_new, d_cp,
                                (const sc *)C.h_round.dev<sc>(2 * P), (const sc *)a, (const sc *)b, a2, b2, N, yinvpow, N, SL, C.h_ip.dev<sc>(P * 256 * 2),
                                (const sc *)ptab[psel], ptab[psel ^ 1], N, n_k == 2 ? C.h_abfin.dev<sc>(4 * P) : (sc *)nullptr, ip_dev);
             if (n_k == 2) ab_on_host = true;
@@ -219,9 +219,9 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
         } else if (round == 0 && lr_first) {
             nblkI = lr_first_blocks;      // scalars and partial inner products were written with l(x), r(x)
         } else {
-            hipLaunchKernelGGL(k_ipp_scalars, grid1(n_g, (u32)P), dim3(TPB), 0, C.stream, (u32)n_g, (u32)n_k, r, d_cp, a, b, N, yinvpow, N, SL, SR, merged ? 1 : 0);
+            ROFL_LAUNCH(k_ipp_scalars, grid1(n_g, (u32)P), dim3(TPB), 0, C.stream, (u32)n_g, (u32)n_k, r, d_cp, a, b, N, yinvpow, N, SL, SR, merged ? 1 : 0);
             nblkI = (u32)std::min<size_t>(32, (nh + TPB - 1) / TPB);
-            hipLaunchKernelGGL(k_ipp_inner, dim3(nblkI, (u32)P), dim3(TPB), 0, C.stream, (u32)nh, a, b, N, C.h_ip.dev<sc>(P * 256 * 2));
+            ROFL_LAUNCH(k_ipp_inner, dim3(nblkI, (u32)P), dim3(TPB), 0, C.stream, (u32)nh, a, b, N, C.h_ip.dev<sc>(P * 256 * 2));
         }
         just_materialised = false;
         // <a_L, b_R> w B and <a_R, b_L> w B of the launches that do not add them on the device (everything but the fused small launch): the partial
@@ -313,7 +313,7 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
         // the fold of a, b by this challenge happens inside the next round's k_ipp_round; only the old three-kernel path and the
         // last round (whose result is the proof's final a, b) fold here
         if ((last && !ab_on_host) || !(merged && ipp_fused))
-            hipLaunchKernelGGL(k_ipp_fold_ab, grid1(nh, (u32)P), dim3(TPB), 0, C.stream, (u32)nh, d_cp, (const sc *)C.h_round.dev<sc>(2 * P), r, a, b, N);
+            ROFL_LAUNCH(k_ipp_fold_ab, grid1(nh, (u32)P), dim3(TPB), 0, C.stream, (u32)nh, d_cp, (const sc *)C.h_round.dev<sc>(2 * P), r, a, b, N);
         r++;
         unsigned t_now = first_level ? (unsigned)C.fold_t1 : (unsigned)C.fold_t;
         // fold_min is a per-chunk size chosen for P = 4 (below it the fold kernel is latency-bound); what matters is the number of
@@ -463,10 +463,10 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
                     u32 *d_ev = C.fold_ev.as<u32>(tot_ev + 4 + (2 * P * sizeof(FoldWProb) + 3) / 4);
                     HIPCHK(hipMemcpyAsync(d_ev, h_ev, wp_off * sizeof(u32) + 2 * P * sizeof(FoldWProb), hipMemcpyHostToDevice, C.stream));
                     // slice s of the table = tbl + s * stride; slice 0 = the generators themselves (the kernel reads table slices as tab + (s - 1) * stride)
-                    hipLaunchKernelGGL(k_fold_gens_w, grid, block, (K - 1) * 64 * sizeof(ge), C.stream, (u32)n_new, seg, reinterpret_cast<const FoldWProb *>(d_ev + wp_off),
+                    ROFL_LAUNCH(k_fold_gens_w, grid, block, (K - 1) * 64 * sizeof(ge), C.stream, (u32)n_new, seg, reinterpret_cast<const FoldWProb *>(d_ev + wp_off),
                                        (const u32 *)d_ev, (const niels *)(tbl + (size_t)(2 * N)), (size_t)(2 * N), ext);
                 } else if (use_tab) {
-                    hipLaunchKernelGGL(k_fold_gens_tab, grid, block, (K - 1) * 64 * sizeof(ge), C.stream, (u32)n_new, nsrc, seg, fc, tbl, (size_t)(2 * N),
+                    ROFL_LAUNCH(k_fold_gens_tab, grid, block, (K - 1) * 64 * sizeof(ge), C.stream, (u32)n_new, nsrc, seg, fc, tbl, (size_t)(2 * N),
                                        (const FoldTabProb *)d_fpv, reinterpret_cast<const int16_t *>(d_dig), unit, ext);
                 }
                 if (use_tab) {
@@ -475,7 +475,7 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
                     HIPCHK(hipEventRecord(C.ev_norm0, C.stream));
                     HIPCHK(hipStreamWaitEvent(C.stream2, C.ev_norm0, 0));
                     const size_t tot = 2 * P * n_new;
-                    hipLaunchKernelGGL(k_niels_batch, grid1((tot + NB_BATCH - 1) / NB_BATCH), dim3(TPB), 0, C.stream2, (u32)tot, (const ge *)ext, gnew);
+                    ROFL_LAUNCH(k_niels_batch, grid1((tot + NB_BATCH - 1) / NB_BATCH), dim3(TPB), 0, C.stream2, (u32)tot, (const ge *)ext, gnew);
                     HIPCHK(hipEventRecord(C.ev_norm, C.stream2));
                     pts_pending = true;
                   }
@@ -502,13 +502,13 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
                     const size_t wp_off = (tot_ev + 2) & ~(size_t)1;
                     HIPCHK(hipMemcpyAsync(d_ev, h_ev, (wp_off) * sizeof(u32) + 2 * P * sizeof(FoldWProb), hipMemcpyHostToDevice, C.stream));
                     HIPCHK(hipStreamWaitEvent(C.stream, C.ev_mult, 0));      // the table was built beside the last rounds
-                    hipLaunchKernelGGL(k_fold_gens_w, grid, block, (K - 1) * 64 * sizeof(ge), C.stream, (u32)n_new, seg, reinterpret_cast<const FoldWProb *>(d_ev + wp_off),
+                    ROFL_LAUNCH(k_fold_gens_w, grid, block, (K - 1) * 64 * sizeof(ge), C.stream, (u32)n_new, seg, reinterpret_cast<const FoldWProb *>(d_ev + wp_off),
                                        (const u32 *)d_ev, (const niels *)C.fmul_tab.p, mult_count, (ge *)nullptr);
                 }
                 else if (nsrc == 4 && unit && fold_regs)      // three scalar-carrying sources, kept in registers
-                    hipLaunchKernelGGL(k_fold_gens4, grid, block, (K - 1) * 64 * sizeof(ge), C.stream, (u32)n_new, seg, (const FoldProb *)d_fpv, d_dig);
+                    ROFL_LAUNCH(k_fold_gens4, grid, block, (K - 1) * 64 * sizeof(ge), C.stream, (u32)n_new, seg, (const FoldProb *)d_fpv, d_dig);
                 else
-                    hipLaunchKernelGGL(k_fold_gens, grid, block, (K - 1) * 64 * sizeof(ge), C.stream, (u32)n_new, nsrc, seg, (const FoldProb *)d_fpv, d_dig, unit);
+                    ROFL_LAUNCH(k_fold_gens, grid, block, (K - 1) * 64 * sizeof(ge), C.stream, (u32)n_new, nsrc, seg, (const FoldProb *)d_fpv, d_dig, unit);
             }
             if (C.tm.enabled) { HIPCHK(hipEventRecord(e1, C.stream)); C.tm.fold_ev.push_back({e0, e1}); C.tm.t.fold_launches++; { char tg[96]; snprintf(tg, sizeof tg, "fold n_g=%zu nsrc=%u tab=%d", n_g, nsrc, (int)use_tab); C.tm.fold_tag.push_back(tg); } C.tm.t.fold_point_reads += (uint64_t)2 * P * n_g; }
             HIPCHK(hipMemcpyAsync(d_cp, h_cp, sizeof(ChunkParams) * P, hipMemcpyHostToDevice, C.stream));   // gscale / hscale
@@ -530,9 +530,9 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
                     // the points must be there in affine form: after the side-stream conversion of a deferred first fold, or after the fold kernel itself
                     if (pts_pending) HIPCHK(hipStreamWaitEvent(C.stream3, C.ev_norm, 0));
                     else { HIPCHK(hipEventRecord(C.ev_mult0, C.stream)); HIPCHK(hipStreamWaitEvent(C.stream3, C.ev_mult0, 0)); }
-                    hipLaunchKernelGGL(k_odd_multiples, grid1(cnt), dim3(TPB), 0, C.stream3, (u32)cnt, mult_E, (const niels *)gnew, mext);
+                    ROFL_LAUNCH(k_odd_multiples, grid1(cnt), dim3(TPB), 0, C.stream3, (u32)cnt, mult_E, (const niels *)gnew, mext);
                     const size_t tot = (mult_E - 1) * cnt;
-                    hipLaunchKernelGGL(k_niels_batch, grid1((tot + NB_BATCH - 1) / NB_BATCH), dim3(TPB), 0, C.stream3, (u32)tot, (const ge *)mext, mtab);
+                    ROFL_LAUNCH(k_niels_batch, grid1((tot + NB_BATCH - 1) / NB_BATCH), dim3(TPB), 0, C.stream3, (u32)tot, (const ge *)mext, mtab);
                     HIPCHK(hipEventRecord(C.ev_mult, C.stream3));
                     mult_ready = true; mult_used = true; mult_base = gnew; mult_count = cnt;
                 }

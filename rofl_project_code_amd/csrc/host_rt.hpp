@@ -96,6 +96,13 @@ thread_local std::string g_err;
 int fail(int code, const std::string &msg) { g_err = msg; return code; }
 struct HipErr { hipError_t e; const char *what; };
 #define HIPCHK(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) throw HipErr{e__, #x}; } while (0)
+// Every kernel launch is checked where it is made: a launch the runtime refuses (a grid dimension past 65 535, too much LDS) would otherwise
+// leave its outputs as the previous call left them, and a verifier would read a verdict out of stale data.  hipGetLastError is a thread-local
+// read; whether the runtime's last-error slot is sticky or overwritten by the next successful call, the launch is the last call made here.
+// (The slot is emptied first: every other runtime call of the library is checked where it is made, so what an earlier one left there --
+// a hipErrorNotReady from a query, where the runtime records those -- is not this launch's.)
+#define ROFL_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); hipError_t e__ = hipGetLastError(); \
+                              if (e__ != hipSuccess && e__ != hipErrorNotReady) throw HipErr{e__, "kernel launch"}; } while (0)
 
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -911,7 +918,7 @@ bool gens_upgrade(Ctx &P0, GensEntry *raw, std::pair<size_t, size_t> key, FoldTa
     bool ok = hipStreamCreateWithPriority(&bs, hipStreamNonBlocking, prio_least) == hipSuccess;
     if (!ok) { (void)hipGetLastError(); bs = nullptr; ok = hipStreamCreateWithFlags(&bs, hipStreamNonBlocking) == hipSuccess; }
     ok = ok && hipMemcpyAsync(tv, raw->tbl, sizeof(niels) * 2 * N, hipMemcpyDeviceToDevice, bs) == hipSuccess;
-    if (ok) { hipLaunchKernelGGL(k_gens_tables, grid1(2 * N * fc_full.np), dim3(TPB), 0, bs, (u32)(2 * N), fc_full, reinterpret_cast<niels *>(tv), (size_t)(2 * N)); ok = hipStreamSynchronize(bs) == hipSuccess; }
+    if (ok) { hipLaunchKernelGGL(k_gens_tables, grid1(2 * N * fc_full.np), dim3(TPB), 0, bs, (u32)(2 * N), fc_full, reinterpret_cast<niels *>(tv), (size_t)(2 * N)); ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(bs) == hipSuccess; }
     if (bs) (void)hipStreamDestroy(bs);
     if (btrace) fprintf(stderr, "[rofl-trace gens-upgrade] table built at +%.3f ms\n", now_ms() - bt0);
     std::lock_guard<std::mutex> lk(P0.gens_mu);
@@ -1005,9 +1012,9 @@ GensPin get_gens(Ctx &C, size_t n, size_t m, GensRole role = GENS_PROVE) {
     ent->bytes = sizeof(niels) * 2 * N * fc.np * fc.e;
     try {
         uint8_t *uni = C.uni.as<uint8_t>(2 * N * 64);
-        hipLaunchKernelGGL(k_gens_xof, grid1(2 * m), dim3(TPB), 0, C.stream, (u32)n, (u32)m, uni);
-        hipLaunchKernelGGL(k_gens_map, grid1(2 * N), dim3(TPB), 0, C.stream, (u32)(2 * N), uni, tbl);
-        if (ent->has_fold) hipLaunchKernelGGL(k_gens_tables, grid1(2 * N * fc.np), dim3(TPB), 0, C.stream, (u32)(2 * N), fc, tbl, (size_t)(2 * N));
+        ROFL_LAUNCH(k_gens_xof, grid1(2 * m), dim3(TPB), 0, C.stream, (u32)n, (u32)m, uni);
+        ROFL_LAUNCH(k_gens_map, grid1(2 * N), dim3(TPB), 0, C.stream, (u32)(2 * N), uni, tbl);
+        if (ent->has_fold) ROFL_LAUNCH(k_gens_tables, grid1(2 * N * fc.np), dim3(TPB), 0, C.stream, (u32)(2 * N), fc, tbl, (size_t)(2 * N));
         // Window table of the fixed-base MSM.  Its window width follows the size of the generator set: 16-bit windows (16 slices, 32 768
         // buckets per set) from 2^17 generators on; 13-bit windows (20 slices, 4 096 buckets) below -- many small chunks (n_partition = 64:
         // 128 L / R problems of 16 384 terms per round) would otherwise spread 8 entries per bucket over 4 M buckets, and the bucket
@@ -1019,7 +1026,7 @@ GensPin get_gens(Ctx &C, size_t n, size_t m, GensRole role = GENS_PROVE) {
             if (gens_malloc(P0, &wtv, sizeof(ndm) * 2 * N * fp.W, ent.get()) == hipSuccess) {      // without it the MSMs over these generators run in generic mode
                 ndm *wt = reinterpret_cast<ndm *>(wtv);
                 ent->wt = std::make_shared<WTabs>(); ent->wt->wtab = wt; ent->wt->bytes = sizeof(ndm) * 2 * N * fp.W;
-                hipLaunchKernelGGL(k_gens_wtab, grid1(2 * N), dim3(TPB), 0, C.stream, (u32)(2 * N), MsmWin{fp.c, fp.W, fp.wide}, tbl, wt, (size_t)(2 * N));
+                ROFL_LAUNCH(k_gens_wtab, grid1(2 * N), dim3(TPB), 0, C.stream, (u32)(2 * N), MsmWin{fp.c, fp.W, fp.wide}, tbl, wt, (size_t)(2 * N));
                 ent->wtab = wt; ent->wc = fp.c; ent->bytes += sizeof(ndm) * 2 * N * fp.W;
                 // Small generator sets also get a 15-bit layout (17 slices; 71 MB at 2N = 32 768).  Many small chunks (n_partition = 64: 128 L / R
                 // problems of 16 384 terms per round) spread 8 entries per bucket over 4 M buckets at c = 16 and the bucket REDUCTION (0.85 ms
@@ -1030,7 +1037,7 @@ GensPin get_gens(Ctx &C, size_t n, size_t m, GensRole role = GENS_PROVE) {
                     MsmPlan f2 = msm_plan_c(15);
                     void *w2 = nullptr;
                     if (gens_malloc(P0, &w2, sizeof(ndm) * 2 * N * f2.W, ent.get()) == hipSuccess) {
-                        hipLaunchKernelGGL(k_gens_wtab, grid1(2 * N), dim3(TPB), 0, C.stream, (u32)(2 * N), MsmWin{f2.c, f2.W, f2.wide}, tbl, reinterpret_cast<ndm *>(w2), (size_t)(2 * N));
+                        ROFL_LAUNCH(k_gens_wtab, grid1(2 * N), dim3(TPB), 0, C.stream, (u32)(2 * N), MsmWin{f2.c, f2.W, f2.wide}, tbl, reinterpret_cast<ndm *>(w2), (size_t)(2 * N));
                         ent->wt->wtab_many = reinterpret_cast<ndm *>(w2); ent->wt->bytes += sizeof(ndm) * 2 * N * f2.W;
                         ent->wtab_many = reinterpret_cast<ndm *>(w2); ent->wc_many = f2.c; ent->bytes += sizeof(ndm) * 2 * N * f2.W;
                     }

@@ -83,7 +83,7 @@ int verify_chunks(Ctx &C, const char *label, size_t gens_capacity, size_t P, siz
     u32 *status = C.status.as<u32>(4);
     HIPCHK(hipMemsetAsync(status, 0, 16, C.stream));
     HIPCHK(hipMemcpyAsync(d_auxc, h_auxc, P * (4 + 2 * lg) * 32, hipMemcpyHostToDevice, C.stream));
-    hipLaunchKernelGGL(k_decode, grid1(P * (4 + 2 * lg)), dim3(TPB), 0, C.stream, (u32)(P * (4 + 2 * lg)), (u32)(P * (4 + 2 * lg)), d_auxc, (const niels *)nullptr, d_auxn, (uint8_t *)nullptr, status);
+    ROFL_LAUNCH(k_decode, grid1(P * (4 + 2 * lg)), dim3(TPB), 0, C.stream, (u32)(P * (4 + 2 * lg)), (u32)(P * (4 + 2 * lg)), d_auxc, (const niels *)nullptr, d_auxn, (uint8_t *)nullptr, status);
     vmark("decode launch");
     double th = now_ms();
     std::atomic<u64> tr_prefix_ns{0}, tr_rest_ns{0};      // slowest task's share (ROFL_TRACE=2)
@@ -204,13 +204,13 @@ int verify_chunks(Ctx &C, const char *label, size_t gens_capacity, size_t P, siz
     if (vtrace) fprintf(stderr, "[rofl-trace verify] slowest task: prefix %.3f ms, challenges and scalars %.3f ms\n", tr_prefix_ns.load() * 1e-6, tr_rest_ns.load() * 1e-6);
     HIPCHK(hipMemcpyAsync(d_cp, h_cp, sizeof(ChunkParams) * P, hipMemcpyHostToDevice, C.stream));
     PowTabs *d_pt = C.powtabs.as<PowTabs>(P);
-    hipLaunchKernelGGL(k_pow_tables, dim3((4 * PT_L * PT_E + TPB - 1) / TPB, (u32)P), dim3(TPB), 0, C.stream, d_cp, d_pt, (u32)lg, 1);
+    ROFL_LAUNCH(k_pow_tables, dim3((4 * PT_L * PT_E + TPB - 1) / TPB, (u32)P), dim3(TPB), 0, C.stream, d_cp, d_pt, (u32)lg, 1);
     // the block-structured form of the generator scalars (k_verify_scalars2) takes whole blocks of 512 indices, all of them inside the tables
     const bool vs2 = N >= 512 && lg <= 3 * PT_W && n <= 64;
     VTabs *d_vt = nullptr;
     if (vs2) {
         d_vt = C.vtabs.as<VTabs>(P);
-        hipLaunchKernelGGL(k_vtabs, dim3((9 * PT_E + 64 + 255) / 256, (u32)P), dim3(256), 0, C.stream, d_cp, (const PowTabs *)d_pt, C.d_two_pow, d_vt, (u32)n, lg2u(n));
+        ROFL_LAUNCH(k_vtabs, dim3((9 * PT_E + 64 + 255) / 256, (u32)P), dim3(256), 0, C.stream, d_cp, (const PowTabs *)d_pt, C.d_two_pow, d_vt, (u32)n, lg2u(n));
     }
     // aux arrays: per proof [m commitments | 4 + 2 lg proof points] and their scalars.  The closer look of `hier` checks runs of units whose
     // last one may be shorter: the arrays end in one group's worth of zero scalars, so every MSM problem of a launch can take the same length.
@@ -219,7 +219,7 @@ int verify_chunks(Ctx &C, const char *label, size_t gens_capacity, size_t P, siz
     niels *aux_pts = C.aux_pts.as<niels>((P + pad) * naux);
     sc *aux_scal = C.aux_scal.as<sc>((P + pad) * naux);
     if (pad) HIPCHK(hipMemsetAsync(aux_scal + P * naux, 0, sizeof(sc) * pad * naux, C.stream));
-    hipLaunchKernelGGL(k_vscalars, grid1(m, (u32)P), dim3(TPB), 0, C.stream, (u32)m, d_cp, (const PowTabs *)d_pt, aux_scal, naux);
+    ROFL_LAUNCH(k_vscalars, grid1(m, (u32)P), dim3(TPB), 0, C.stream, (u32)m, d_cp, (const PowTabs *)d_pt, aux_scal, naux);
     {   // three strided copies for all proofs
         const size_t na2 = 4 + 2 * lg;
         HIPCHK(hipMemcpy2DAsync(aux_pts, naux * sizeof(niels), d_Vniels, m * sizeof(niels), m * sizeof(niels), P, hipMemcpyDeviceToDevice, C.stream));
@@ -246,10 +246,10 @@ int verify_chunks(Ctx &C, const char *label, size_t gens_capacity, size_t P, siz
               size_t nsl = std::min<size_t>(maxc, std::max<size_t>(1, 1024 / ((N / 512) * ng)));
               const u32 per = (u32)((maxc + nsl - 1) / nsl); nsl = (maxc + per - 1) / per;
               sc *dst = nsl > 1 ? C.vspart.as<sc>(ng * nsl * 2 * N) : gh;
-              hipLaunchKernelGGL(k_verify_scalars2, dim3((unsigned)(N / 512), (u32)ng, (u32)nsl), dim3(256), 0, C.stream, (u32)n, lg2u(n), (u32)m, reinterpret_cast<const uint2 *>(d_grp), d_cp, (const VTabs *)d_vt, dst, per);
-              if (nsl > 1) hipLaunchKernelGGL(k_vs_sum, grid1(2 * N, (u32)ng), dim3(TPB), 0, C.stream, (u32)(2 * N), (u32)nsl, (const sc *)dst, gh);
+              ROFL_LAUNCH(k_verify_scalars2, dim3((unsigned)(N / 512), (u32)ng, (u32)nsl), dim3(256), 0, C.stream, (u32)n, lg2u(n), (u32)m, reinterpret_cast<const uint2 *>(d_grp), d_cp, (const VTabs *)d_vt, dst, per);
+              if (nsl > 1) ROFL_LAUNCH(k_vs_sum, grid1(2 * N, (u32)ng), dim3(TPB), 0, C.stream, (u32)(2 * N), (u32)nsl, (const sc *)dst, gh);
           }
-          else hipLaunchKernelGGL(k_verify_scalars, grid1(N, (u32)ng), dim3(TPB), 0, C.stream, (u32)n, (u32)m, (u32)lg, reinterpret_cast<const uint2 *>(d_grp), d_cp, (const PowTabs *)d_pt, C.d_two_pow, gh); }
+          else ROFL_LAUNCH(k_verify_scalars, grid1(N, (u32)ng), dim3(TPB), 0, C.stream, (u32)n, (u32)m, (u32)lg, reinterpret_cast<const uint2 *>(d_grp), d_cp, (const PowTabs *)d_pt, C.d_two_pow, gh); }
         std::vector<MsmProb> pr(ng), prB(ng); std::vector<ge5> resA, resB;
         for (size_t g = 0; g < ng; g++) pr[g] = MsmProb{tbl, gh + g * 2 * N};
         for (size_t g = 0; g < ng; g++) prB[g] = MsmProb{aux_pts + (size_t)groups[g].start * naux, aux_scal + (size_t)groups[g].start * naux};

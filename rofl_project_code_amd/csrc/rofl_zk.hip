@@ -116,6 +116,8 @@ void timing_end(Ctx &C) {
 }
 
 
+constexpr size_t kMaxBatchMembers = 65535;      // gridDim.y: what a batch entry point accepts in one call (the launches themselves are checked too, ROFL_LAUNCH)
+
 template <class F> int guarded(F f) {
     try { return f(); }
     catch (const HipErr &e) {
@@ -167,7 +169,7 @@ int create_impl(Ctx &C, size_t nc, const float *const *values, size_t d, const u
     }
     u32 *status = C.status.as<u32>(nc + 4);
     HIPCHK(hipMemsetAsync(status, 0, 4 * (nc + 4), C.stream));
-    hipLaunchKernelGGL(k_quantize_shift, grid1(dp, (u32)nc), dim3(TPB), 0, C.stream, d_vals, (u32)d, (u32)dp, (u32)prove_range, fp_bits, fp_frac, mn, mx, vshift, status);
+    ROFL_LAUNCH(k_quantize_shift, grid1(dp, (u32)nc), dim3(TPB), 0, C.stream, d_vals, (u32)d, (u32)dp, (u32)prove_range, fp_bits, fp_frac, mn, mx, vshift, status);
     u32 *h_status = C.h_misc.as<u32>(nc + 4);
     HIPCHK(hipMemcpyAsync(h_status, status, 4 * nc, hipMemcpyDeviceToHost, C.stream));
     C.sync();
@@ -189,6 +191,7 @@ int create_impl(Ctx &C, size_t nc, const float *const *values, size_t d, const u
         }
     size_t plen = 32 * (9 + 2 * (size_t)lg2u(prove_range * chunk));
     *plen_out = plen; *np_out = P;
+    if (2 * nc * P > kMaxBatchMembers) return fail(ROFL_BAD_PARAM, "batch too large (split it)");      // the L / R problems of all chunks index gridDim.y
     std::vector<size_t> act;
     for (size_t i = 0; i < nc; i++) if (rcs[i] == ROFL_OK) act.push_back(i);
     if (act.empty()) { timing_end(C); return ROFL_OK; }
@@ -230,7 +233,7 @@ int create_impl(Ctx &C, size_t nc, const float *const *values, size_t d, const u
     HIPCHK(hipStreamWaitEvent(C.stream2, C.ev_fork, 0));
     HIPCHK(hipMemcpyAsync(d_shift, &h_shift, sizeof(niels), hipMemcpyHostToDevice, C.stream2));
     { KSpan ks(C.tm, C.stream2, ROFL_TK_CODEC, (uint64_t)na * dp * (2 * 64 * 7 + 2 * 265), (uint64_t)na * dp * (8 + 32 + 64));
-    hipLaunchKernelGGL(k_commit, grid1(na * dp), dim3(TPB), 0, C.stream2, (u32)(na * dp), vshift, (const sc *)nullptr, d_blind_buf, C.d_tabB, C.d_tabBb, d_shift, Vb, Cb, (u32)d, (u32)dp); }
+    ROFL_LAUNCH(k_commit, grid1(na * dp), dim3(TPB), 0, C.stream2, (u32)(na * dp), vshift, (const sc *)nullptr, d_blind_buf, C.d_tabB, C.d_tabBb, d_shift, Vb, Cb, (u32)d, (u32)dp); }
     uint8_t *hV = C.h_V.as<uint8_t>(na * dp * 32);
     HIPCHK(hipMemcpyAsync(hV, Vb, na * dp * 32, hipMemcpyDeviceToHost, C.stream2));
     HIPCHK(hipEventRecord(C.ev_v, C.stream2));
@@ -287,6 +290,8 @@ int verify_impl(Ctx &C, size_t n_clients, const uint8_t *const *proofs, size_t p
     if (ne < 2 || (ne - 2) % 2 != 0 || (ne - 2) / 2 >= 32) return fail(ROFL_FORMAT_ERROR, "FormatError: proof length");
     size_t lg = (ne - 2) / 2;
     size_t P = n_clients * nv;
+    // every (client, chunk) pair is a row of gridDim.y in the verifier's kernels (and, with the closer look of verify_batch = 2, a few padding rows more)
+    if (P + 2 * nv * (size_t)std::ceil(std::sqrt((double)n_clients)) > kMaxBatchMembers) return fail(ROFL_BAD_PARAM, "batch too large (split it)");
     std::vector<uint8_t> pf(P * proof_len);
     for (size_t i = 0; i < n_clients; i++) {      // host or device memory; caller memory is not handed to the HIP runtime
         if (is_device_ptr(proofs[i])) HIPCHK(hipMemcpy(&pf[i * nv * proof_len], proofs[i], nv * proof_len, hipMemcpyDeviceToHost));
@@ -359,7 +364,7 @@ int verify_impl(Ctx &C, size_t n_clients, const uint8_t *const *proofs, size_t p
                        HIPCHK(hipMemcpyAsync(d_in + i * dp * 32, st, d * 32, hipMemcpyHostToDevice, C.stream)); }
             }
         { KSpan ks(C.tm, C.stream, ROFL_TK_CODEC, (uint64_t)gc * d * (2 * 265 + 7), (uint64_t)gc * d * 64);
-          hipLaunchKernelGGL(k_decode, grid1(dp, (u32)gc), dim3(TPB), 0, C.stream, (u32)dp, (u32)d, d_in + i0 * dp * 32, d_shift, d_vn + i0 * dp, d_enc + i0 * dp * 32, status + i0); }
+          ROFL_LAUNCH(k_decode, grid1(dp, (u32)gc), dim3(TPB), 0, C.stream, (u32)dp, (u32)d, d_in + i0 * dp * 32, d_shift, d_vn + i0 * dp, d_enc + i0 * dp * 32, status + i0); }
         HIPCHK(hipMemcpyAsync(hV + i0 * dp * 32, d_enc + i0 * dp * 32, gc * dp * 32, hipMemcpyDeviceToHost, C.stream));
         HIPCHK(hipMemcpyAsync(h_st + i0, status + i0, 4 * gc, hipMemcpyDeviceToHost, C.stream));
         ready.push_back(VerifyReady{(i0 + gc) * nv, C.pool_event(3 + ready.size())});      // (events 0..2 of the call: the upload stream's)
@@ -756,7 +761,7 @@ int rofl_create_rangeproof_l2(const float *values, size_t d, const uint8_t *blin
         HIPCHK(hipMemcpyAsync(vshift, &v, 8, hipMemcpyHostToDevice, C.stream));
         HIPCHK(hipMemcpyAsync(d_bl, &bsum, 32, hipMemcpyHostToDevice, C.stream));
         uint8_t *Vb = C.Vbytes.as<uint8_t>(32);
-        hipLaunchKernelGGL(k_commit, grid1(1), dim3(TPB), 0, C.stream, 1u, vshift, (const sc *)nullptr, d_bl, C.d_tabB, C.d_tabBb, (const niels *)nullptr, Vb, (uint8_t *)nullptr, 0u, 1u);
+        ROFL_LAUNCH(k_commit, grid1(1), dim3(TPB), 0, C.stream, 1u, vshift, (const sc *)nullptr, d_bl, C.d_tabB, C.d_tabBb, (const niels *)nullptr, Vb, (uint8_t *)nullptr, 0u, 1u);
         uint8_t hV[32];
         HIPCHK(hipMemcpyAsync(hV, Vb, 32, hipMemcpyDeviceToHost, C.stream));
         C.sync();
@@ -786,7 +791,7 @@ int rofl_verify_rangeproof_l2(const uint8_t *proof, size_t proof_len, const uint
         u32 *status = C.status.as<u32>(4);
         HIPCHK(hipMemsetAsync(status, 0, 16, C.stream));
         HIPCHK(hipMemcpyAsync(d_in, commit, 32, hipMemcpyHostToDevice, C.stream));
-        hipLaunchKernelGGL(k_decode, grid1(1), dim3(TPB), 0, C.stream, 1u, 1u, d_in, (const niels *)nullptr, d_vn, d_enc, status);
+        ROFL_LAUNCH(k_decode, grid1(1), dim3(TPB), 0, C.stream, 1u, 1u, d_in, (const niels *)nullptr, d_vn, d_enc, status);
         uint8_t hV[32]; u32 st = 0;
         HIPCHK(hipMemcpyAsync(hV, d_enc, 32, hipMemcpyDeviceToHost, C.stream));
         HIPCHK(hipMemcpyAsync(&st, status, 4, hipMemcpyDeviceToHost, C.stream));
@@ -817,6 +822,7 @@ int rofl_verify_rangeproof_l2_batch(size_t n_clients, const uint8_t *const *proo
         const size_t ne = (proof_len - 7 * 32) / 32;
         if (ne < 2 || (ne - 2) % 2 != 0 || (ne - 2) / 2 >= 32) return fail(ROFL_FORMAT_ERROR, "FormatError: proof length");
         const size_t lg = (ne - 2) / 2, nc = n_clients;
+        if (nc > kMaxBatchMembers / 2) return fail(ROFL_BAD_PARAM, "batch too large (split it)");      // a member = a row of gridDim.y
         std::vector<uint8_t> pf(nc * proof_len);
         std::vector<char> skip(nc, 0);
         for (size_t i = 0; i < nc; i++) {
@@ -835,7 +841,7 @@ int rofl_verify_rangeproof_l2_batch(size_t n_clients, const uint8_t *const *proo
         u32 *status = C.status.as<u32>(nc + 4);
         HIPCHK(hipMemsetAsync(status, 0, 4 * (nc + 4), C.stream));
         C.up(d_in, commits32, nc * 32, C.stream);
-        hipLaunchKernelGGL(k_decode, grid1(1, (u32)nc), dim3(TPB), 0, C.stream, 1u, 1u, d_in, (const niels *)nullptr, d_vn, d_enc, status);
+        ROFL_LAUNCH(k_decode, grid1(1, (u32)nc), dim3(TPB), 0, C.stream, 1u, 1u, d_in, (const niels *)nullptr, d_vn, d_enc, status);
         uint8_t *hV = C.h_V.as<uint8_t>(nc * 32); u32 *h_st = C.h_misc.as<u32>(nc + 4);
         HIPCHK(hipMemcpyAsync(hV, d_enc, nc * 32, hipMemcpyDeviceToHost, C.stream));
         HIPCHK(hipMemcpyAsync(h_st, status, 4 * nc, hipMemcpyDeviceToHost, C.stream));
@@ -889,7 +895,7 @@ int sigma_create(int kind, const float *values, size_t d, const uint8_t *r1, siz
     // algorithmic work per element: 7 fixed-base multiplications (64 mixed additions each), one variable-base one (~325 point operations),
     // 2 * npts encodings; bytes as SURVEY 8(d): value + randomness in, commitments + proof out
     { KSpan ks_sigma(C.tm, C.stream, ROFL_TK_SIGMA, (uint64_t)d * (7 * 64 * 7 + 325 * 8 + 2 * npts * 265), (uint64_t)d * (4 + 32 * (has_sq ? 2 : 1) + clen + plen));
-      hipLaunchKernelGGL(k_sigma_prove, dim3((unsigned)((d + 63) / 64)), dim3(64), 0, C.stream, kind, (u32)d, dv, fp_bits, fp_frac, dr1, dr2, dex,
+      ROFL_LAUNCH(k_sigma_prove, dim3((unsigned)((d + 63) / 64)), dim3(64), 0, C.stream, kind, (u32)d, dv, fp_bits, fp_frac, dr1, dr2, dex,
                          nonce->mode, seed, d_stream, ss, sigma_init_state(kind), C.d_tabB, C.d_tabBb, dp, dc, status); }
     u32 st = 0;
     C.down(proofs_out, dp, d * plen, C.stream);
@@ -919,7 +925,8 @@ int sigma_verify_batch(int kind, size_t nc, const uint8_t *const *proofs, const 
     if (d == 0) { for (size_t i = 0; i < nc; i++) ok_out[i] = 1; return ROFL_OK; }
     const size_t npts = 1 + (has_R ? 1 : 0) + (has_sq ? 1 : 0), clen = 32 * npts, plen = 32 * (npts + (has_sq ? 3 : 2));
     const size_t nslots = 2 * npts, nblk = (d + TPB - 1) / TPB;
-    if (nc * nslots * d >= ((size_t)1 << 31) || nc * nblk > ((size_t)1 << 22)) return fail(ROFL_BAD_PARAM, "batch too large (split it)");
+    // (the members of a batch index gridDim.y of the decode / transcript / sum kernels and the problems of the Pippenger launches: 65 535 at most)
+    if (nc > kMaxBatchMembers || nc * nslots * d >= ((size_t)1 << 31) || nc * nblk > ((size_t)1 << 22)) return fail(ROFL_BAD_PARAM, "batch too large (split it)");
     C.init();
     C.batch_mode = nc > 1;
     timing_begin(C);
@@ -931,12 +938,12 @@ int sigma_verify_batch(int kind, size_t nc, const uint8_t *const *proofs, const 
             HIPCHK(hipMemsetAsync(status, 0, 16, C.stream));
             C.up(dp, proofs[i], d * plen, C.stream); C.up(dc, commits[i], d * clen, C.stream);
             { KSpan ks_sigma(C.tm, C.stream, ROFL_TK_SIGMA, (uint64_t)d * (2 * npts * 265 + (kind ? 3 : 2) * 2 * 325 * 8), (uint64_t)d * (clen + plen));
-              hipLaunchKernelGGL(k_sigma_verify, dim3((unsigned)((d + 63) / 64)), dim3(64), 0, C.stream, kind, (u32)d, dp, dc, sigma_init_state(kind), C.d_tabB, C.d_tabBb, status + 1, status); }
+              ROFL_LAUNCH(k_sigma_verify, dim3((unsigned)((d + 63) / 64)), dim3(64), 0, C.stream, kind, (u32)d, dp, dc, sigma_init_state(kind), C.d_tabB, C.d_tabBb, status + 1, status); }
             u32 *st = C.h_misc.as<u32>(4);
             HIPCHK(hipMemcpyAsync(st, status, 8, hipMemcpyDeviceToHost, C.stream));
             if (csq_sum_out && has_sq) {
                 u32 nb2 = (u32)std::min<size_t>(64, nblk); ge *part = C.partial2.as<ge>(nb2);
-                hipLaunchKernelGGL(k_decode_sum, dim3(nb2), dim3(TPB), TPB * sizeof(ge), C.stream, dc + (has_R ? 64 : 32), (u32)d, (u32)clen, part, status + 2);
+                ROFL_LAUNCH(k_decode_sum, dim3(nb2), dim3(TPB), TPB * sizeof(ge), C.stream, dc + (has_R ? 64 : 32), (u32)d, (u32)clen, part, status + 2);
                 ge *hp = C.h_part.as<ge>(nb2);
                 HIPCHK(hipMemcpyAsync(hp, part, sizeof(ge) * nb2, hipMemcpyDeviceToHost, C.stream));
                 C.sync();
@@ -972,7 +979,7 @@ int sigma_verify_batch(int kind, size_t nc, const uint8_t *const *proofs, const 
         return 96u; }();
     // groups of clients: ~64 MB of caller bytes each, through two staging buffers
     const size_t per = d * (plen + clen);
-    const size_t G = std::max<size_t>(1, std::min<size_t>(nc, ((size_t)64 << 20) / per));
+    const size_t G = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(nc, 16), ((size_t)64 << 20) / per));      // (at most sixteen: a group is also a row count of gridDim.y and part of one Pippenger launch)
     bool all_host = true; for (size_t i = 0; i < nc; i++) all_host &= !is_device_ptr(proofs[i]) && !is_device_ptr(commits[i]);
     // three staging buffers; the uploads run on a stream of their own (the copy of group g + 1 beside the kernels of group g: on one stream they
     // alternated, and the "staging" time of the first version was the host waiting for that stream)
@@ -983,7 +990,7 @@ int sigma_verify_batch(int kind, size_t nc, const uint8_t *const *proofs, const 
     struct JoinUp { hipStream_t s; ~JoinUp() { if (s) (void)hipStreamSynchronize(s); } } join_up{stage[0] ? C.stream_up : nullptr};
     // events of the call: 0..2 upload of staging buffer b done, 3 / 4 a launch's clients decoded, 5 / 6 a launch finished
     if (stage[0]) { HIPCHK(hipEventRecord(C.pool_event(7), C.stream)); HIPCHK(hipStreamWaitEvent(C.stream_up, C.pool_event(7), 0)); }      // (after the status memset)
-    // Every client is one problem of a multi-problem Pippenger launch; launches of up to sixteen clients (the slot array of a launch grows with
+    // Every client is one problem of a multi-problem Pippenger launch; launches of 16 to 31 clients (whole decode groups; the slot array of a launch grows with
     // its problems) go to the SIDE stream as soon as their clients are decoded, so that they run while the host is still staging and the main
     // stream still uploading and decoding the later clients.  Two MSM workspaces alternate: launch k + 2 waits for launch k's results.
     if (!C.stream2) HIPCHK(hipStreamCreateWithFlags(&C.stream2, hipStreamNonBlocking));
@@ -1028,9 +1035,9 @@ int sigma_verify_batch(int kind, size_t nc, const uint8_t *const *proofs, const 
         } else
             for (size_t i = g0; i < g0 + gc; i++) { C.up(dp + i * d * plen, proofs[i], d * plen, C.stream); C.up(dc + i * d * clen, commits[i], d * clen, C.stream); }
         {   KSpan ks_sigma(C.tm, C.stream, ROFL_TK_SIGMA, (uint64_t)gc * d * (2 * npts * 265), (uint64_t)gc * d * (clen + plen));      // decoding of 2 npts points per element
-            hipLaunchKernelGGL(k_sigma_vdecode, dim3((unsigned)((nslots * d + TPB - 1) / TPB), (unsigned)gc), dim3(TPB), 0, C.stream, kind, (u32)d, dp + g0 * d * plen, dc + g0 * d * clen,
+            ROFL_LAUNCH(k_sigma_vdecode, dim3((unsigned)((nslots * d + TPB - 1) / TPB), (unsigned)gc), dim3(TPB), 0, C.stream, kind, (u32)d, dp + g0 * d * plen, dc + g0 * d * clen,
                                pts + g0 * nslots * d, status + g0);
-            hipLaunchKernelGGL(k_sigma_vprep, dim3((unsigned)nblk, (unsigned)gc), dim3(TPB), 0, C.stream, kind, (u32)d, dp + g0 * d * plen, dc + g0 * d * clen, init, ws, (u64)(g0 * d), wbits,
+            ROFL_LAUNCH(k_sigma_vprep, dim3((unsigned)nblk, (unsigned)gc), dim3(TPB), 0, C.stream, kind, (u32)d, dp + g0 * d * plen, dc + g0 * d * clen, init, ws, (u64)(g0 * d), wbits,
                                scal + g0 * nslots * d, d_fixed + g0 * nblk * 2, status + g0); }
         if (g0 + gc - sg_start >= SGC || g0 + gc == nc) { launch_job(sg_start, g0 + gc - sg_start); sg_start = g0 + gc; }
     }
@@ -1043,7 +1050,7 @@ int sigma_verify_batch(int kind, size_t nc, const uint8_t *const *proofs, const 
     ge *h_csq = nullptr;
     if (csq_sum_out && has_sq) {
         ge *part = C.partial2.as<ge>(nc * nb2);
-        hipLaunchKernelGGL(k_niels_sum, dim3(nb2, (unsigned)nc), dim3(TPB), TPB * sizeof(ge), C.stream, (const niels *)(pts + (nslots - 2) * d), (u32)d, nslots * d, part);
+        ROFL_LAUNCH(k_niels_sum, dim3(nb2, (unsigned)nc), dim3(TPB), TPB * sizeof(ge), C.stream, (const niels *)(pts + (nslots - 2) * d), (u32)d, nslots * d, part);
         h_csq = C.h_misc2.as<ge>(nc * nb2);
         HIPCHK(hipMemcpyAsync(h_csq, part, sizeof(ge) * nc * nb2, hipMemcpyDeviceToHost, C.stream));
     }
@@ -1107,7 +1114,7 @@ int compressed_create(const float *values, size_t d, const uint8_t *r32, size_t 
         C.up(dv, values, 4 * d, C.stream);
         C.up(dr, r32, 32 * d, C.stream);
         if (dex) C.up(dex, existing, 32 * d, C.stream);
-        hipLaunchKernelGGL(k_eg_pairs, dim3((unsigned)((d + 63) / 64)), dim3(64), 0, C.stream, (u32)d, dv, fp_bits, fp_frac, dr, dex, C.d_tabB, C.d_tabBb, dpairs, status);
+        ROFL_LAUNCH(k_eg_pairs, dim3((unsigned)((d + 63) / 64)), dim3(64), 0, C.stream, (u32)d, dv, fp_bits, fp_frac, dr, dex, C.d_tabB, C.d_tabBb, dpairs, status);
         pairs_host = (const uint8_t *)C.down(pairs_out, dpairs, 64 * d, C.stream);
     }
     u32 st = 0;
@@ -1131,7 +1138,7 @@ int compressed_create(const float *values, size_t d, const uint8_t *r32, size_t 
         CPow cp; fill_pow2(cp.sq, h_mont(c), MAX_LG);
         u32 nblk = (u32)std::min<size_t>(64, (d + TPB - 1) / TPB);
         sc *part = C.tmp_out.as<sc>(64 * 2);
-        hipLaunchKernelGGL(k_cpow_dot, dim3(nblk), dim3(TPB), 0, C.stream, (u32)d, dv, fp_bits, fp_frac, dr, cp, part);
+        ROFL_LAUNCH(k_cpow_dot, dim3(nblk), dim3(TPB), 0, C.stream, (u32)d, dv, fp_bits, fp_frac, dr, cp, part);
         sc hp[128];
         HIPCHK(hipMemcpyAsync(hp, part, sizeof(sc) * nblk * 2, hipMemcpyDeviceToHost, C.stream));
         C.sync();
@@ -1158,9 +1165,9 @@ int compressed_verify(const uint8_t *proof, const uint8_t *pairs, size_t d, int 
         u32 *status = C.status.as<u32>(4);
         HIPCHK(hipMemsetAsync(status, 0, 16, C.stream));
         C.up(dpairs, pairs, 64 * d, C.stream);
-        hipLaunchKernelGGL(k_decode_pairs, grid1(2 * d), dim3(TPB), 0, C.stream, (u32)d, dpairs, pts, pts + d, status);
+        ROFL_LAUNCH(k_decode_pairs, grid1(2 * d), dim3(TPB), 0, C.stream, (u32)d, dpairs, pts, pts + d, status);
         CPow cp; fill_pow2(cp.sq, h_mont(c), MAX_LG);
-        hipLaunchKernelGGL(k_cpow_scalars, grid1(d), dim3(TPB), 0, C.stream, (u32)d, cp, scal);
+        ROFL_LAUNCH(k_cpow_scalars, grid1(d), dim3(TPB), 0, C.stream, (u32)d, cp, scal);
         u32 st = 0;
         HIPCHK(hipMemcpyAsync(&st, status, 4, hipMemcpyDeviceToHost, C.stream));
         C.sync();
@@ -1243,7 +1250,7 @@ int rofl_commit_vec(const uint8_t *values32, const uint8_t *blindings32, size_t 
         uint8_t *o = C.Cbytes.as<uint8_t>(d * 32);
         C.up(dv, values32, 32 * d, C.stream);
         if (db) C.up(db, blindings32, 32 * d, C.stream);
-        hipLaunchKernelGGL(k_commit, grid1(d), dim3(TPB), 0, C.stream, (u32)d, (const u64 *)nullptr, dv, db, C.d_tabB, C.d_tabBb, (const niels *)nullptr, (uint8_t *)nullptr, o, (u32)d, (u32)d);
+        ROFL_LAUNCH(k_commit, grid1(d), dim3(TPB), 0, C.stream, (u32)d, (const u64 *)nullptr, dv, db, C.d_tabB, C.d_tabBb, (const niels *)nullptr, (uint8_t *)nullptr, o, (u32)d, (u32)d);
         C.down(out32, o, 32 * d, C.stream);
         C.sync();
         return ROFL_OK;
@@ -1259,7 +1266,7 @@ int rofl_add_points_vec(const uint8_t *a32, const uint8_t *b32, size_t d, uint8_
         HIPCHK(hipMemsetAsync(status, 0, 16, C.stream));
         C.up(da, a32, 32 * d, C.stream);
         C.up(db, b32, 32 * d, C.stream);
-        hipLaunchKernelGGL(k_add_points, grid1(d), dim3(TPB), 0, C.stream, (u32)d, da, db, o, status);
+        ROFL_LAUNCH(k_add_points, grid1(d), dim3(TPB), 0, C.stream, (u32)d, da, db, o, status);
         u32 st = 0;
         C.down(out32, o, 32 * d, C.stream);
         HIPCHK(hipMemcpyAsync(&st, status, 4, hipMemcpyDeviceToHost, C.stream));
@@ -1280,7 +1287,7 @@ int rofl_sum_points(const uint8_t *points, size_t d, size_t stride, uint8_t out3
         u32 *status = C.status.as<u32>(4);
         HIPCHK(hipMemsetAsync(status, 0, 16, C.stream));
         C.up(da, points, stride * d, C.stream);
-        hipLaunchKernelGGL(k_decode_sum, dim3(nblk), dim3(TPB), TPB * sizeof(ge), C.stream, da, (u32)d, (u32)stride, part, status);
+        ROFL_LAUNCH(k_decode_sum, dim3(nblk), dim3(TPB), TPB * sizeof(ge), C.stream, da, (u32)d, (u32)stride, part, status);
         std::vector<ge> hp(nblk); u32 st = 0;
         HIPCHK(hipMemcpyAsync(hp.data(), part, sizeof(ge) * nblk, hipMemcpyDeviceToHost, C.stream));
         HIPCHK(hipMemcpyAsync(&st, status, 4, hipMemcpyDeviceToHost, C.stream));
@@ -1305,7 +1312,7 @@ int rofl_shift_points(const uint8_t *a32, size_t d, const uint8_t offset32[32], 
         HIPCHK(hipMemsetAsync(status, 0, 16, C.stream));
         HIPCHK(hipMemcpyAsync(ds, &hs, sizeof hs, hipMemcpyHostToDevice, C.stream));
         C.up(da, a32, 32 * d, C.stream);
-        hipLaunchKernelGGL(k_decode, grid1(d), dim3(TPB), 0, C.stream, (u32)d, (u32)d, da, ds, (niels *)nullptr, o, status);
+        ROFL_LAUNCH(k_decode, grid1(d), dim3(TPB), 0, C.stream, (u32)d, (u32)d, da, ds, (niels *)nullptr, o, status);
         u32 st = 0;
         C.down(out32, o, 32 * d, C.stream);
         HIPCHK(hipMemcpyAsync(&st, status, 4, hipMemcpyDeviceToHost, C.stream));
@@ -1389,7 +1396,7 @@ int rofl_dbg_msm(const uint8_t *scalars32, const uint8_t *points32, size_t n, ui
         HIPCHK(hipMemsetAsync(status, 0, 16, C.stream));
         C.up(dp, points32, n * 32, C.stream);
         C.up(ds, hs.data(), n * 32, C.stream);
-        hipLaunchKernelGGL(k_decode, grid1(n), dim3(TPB), 0, C.stream, (u32)n, (u32)n, dp, (const niels *)nullptr, dn, (uint8_t *)nullptr, status);
+        ROFL_LAUNCH(k_decode, grid1(n), dim3(TPB), 0, C.stream, (u32)n, (u32)n, dp, (const niels *)nullptr, dn, (uint8_t *)nullptr, status);
         u32 st = 0;
         HIPCHK(hipMemcpyAsync(&st, status, 4, hipMemcpyDeviceToHost, C.stream));
         C.sync();
@@ -1419,7 +1426,7 @@ int rofl_dbg_verify_labelled(const uint8_t *label, size_t label_len, size_t gens
         u32 *status = C.status.as<u32>(4);
         HIPCHK(hipMemsetAsync(status, 0, 16, C.stream));
         C.up(d_in, commits32, m * 32, C.stream);
-        hipLaunchKernelGGL(k_decode, grid1(m), dim3(TPB), 0, C.stream, (u32)m, (u32)m, d_in, (const niels *)nullptr, d_vn, d_enc, status);
+        ROFL_LAUNCH(k_decode, grid1(m), dim3(TPB), 0, C.stream, (u32)m, (u32)m, d_in, (const niels *)nullptr, d_vn, d_enc, status);
         std::vector<uint8_t> hV(m * 32); u32 *h_st = C.h_misc.as<u32>(4);
         uint8_t *hp = C.h_V.as<uint8_t>(m * 32);
         HIPCHK(hipMemcpyAsync(hp, d_enc, m * 32, hipMemcpyDeviceToHost, C.stream));
@@ -1445,7 +1452,7 @@ int rofl_dbg_quad_ops(const uint8_t *pairs64, size_t pairs, unsigned doublings, 
         HIPCHK(hipMemsetAsync(status, 0, 16, C.stream));
         HIPCHK(hipMemsetAsync(dout, 0, pairs * 64, C.stream));
         C.up(din, pairs64, pairs * 64, C.stream);
-        hipLaunchKernelGGL(k_dbg_quad, grid1(pairs * 4), dim3(TPB), 0, C.stream, (u32)pairs, doublings, (const uint8_t *)din, dout, dout + pairs * 32, status);
+        ROFL_LAUNCH(k_dbg_quad, grid1(pairs * 4), dim3(TPB), 0, C.stream, (u32)pairs, doublings, (const uint8_t *)din, dout, dout + pairs * 32, status);
         u32 st = 0;
         HIPCHK(hipMemcpyAsync(&st, status, 4, hipMemcpyDeviceToHost, C.stream));
         C.down(out_serial32, dout, pairs * 32, C.stream);
@@ -1468,7 +1475,7 @@ int rofl_discrete_log_vec(const uint8_t *points32, size_t d, size_t table_size, 
             b.mask = nslots - 1;
             HIPCHK(hipMalloc(&b.keys, 32 * (table_size + 1))); HIPCHK(hipMalloc(&b.slots, sizeof(u32) * nslots));
             HIPCHK(hipMemsetAsync(b.slots, 0, sizeof(u32) * nslots, C.stream));
-            hipLaunchKernelGGL(k_bsgs_build, dim3((unsigned)((table_size + 1 + 63) / 64)), dim3(64), 0, C.stream, (u32)table_size, C.d_tabB, b.keys, b.slots, b.mask);
+            ROFL_LAUNCH(k_bsgs_build, dim3((unsigned)((table_size + 1 + 63) / 64)), dim3(64), 0, C.stream, (u32)table_size, C.d_tabB, b.keys, b.slots, b.mask);
             it = C.bsgs.emplace(table_size, b).first;
         }
         const Ctx::Bsgs &B = it->second;
@@ -1480,7 +1487,7 @@ int rofl_discrete_log_vec(const uint8_t *points32, size_t d, size_t table_size, 
         u32 *status = C.status.as<u32>(4);
         HIPCHK(hipMemsetAsync(status, 0, 16, C.stream));
         C.up(dp, points32, 32 * d, C.stream);
-        hipLaunchKernelGGL(k_bsgs_solve, dim3((unsigned)((d + 63) / 64)), dim3(64), 0, C.stream, (u32)d, dp, (u32)table_size, bsgs_bits, max_it, neg_mG, B.keys, B.slots, B.mask, dout, status);
+        ROFL_LAUNCH(k_bsgs_solve, dim3((unsigned)((d + 63) / 64)), dim3(64), 0, C.stream, (u32)d, dp, (u32)table_size, bsgs_bits, max_it, neg_mG, B.keys, B.slots, B.mask, dout, status);
         u32 st = 0;
         C.down(scalars_out32, dout, 32 * d, C.stream);
         HIPCHK(hipMemcpyAsync(&st, status, 4, hipMemcpyDeviceToHost, C.stream));
@@ -1723,9 +1730,9 @@ int rofl_bench_femul(unsigned iters, double *out) {
             std::vector<ndm> ht(256); for (int i = 0; i < 256; i++) for (int k = 0; k < 32; k++) ht[i].v[k] = (0x9e3779b9u * (i * 32 + k + 1)) >> 8;
             HIPCHK(hipMemcpy(dt, ht.data(), sizeof(ndm) * 256, hipMemcpyHostToDevice));
             auto launch = [&](u32 it) {
-                if (mode == 3) hipLaunchKernelGGL(k_bench_madd_gather, dim3(blocks), dim3(TPB), fl, C.stream, it, (u32)entries, dt, dg);
-                else if (mode == 2) hipLaunchKernelGGL(k_bench_madd_l1, dim3(blocks), dim3(TPB), fl, C.stream, it, (u32)entries, dt, dg);
-                else hipLaunchKernelGGL(k_bench_madd_regs, dim3(blocks), dim3(TPB), fl, C.stream, it, (u32)entries, dt, dg);
+                if (mode == 3) ROFL_LAUNCH(k_bench_madd_gather, dim3(blocks), dim3(TPB), fl, C.stream, it, (u32)entries, dt, dg);
+                else if (mode == 2) ROFL_LAUNCH(k_bench_madd_l1, dim3(blocks), dim3(TPB), fl, C.stream, it, (u32)entries, dt, dg);
+                else ROFL_LAUNCH(k_bench_madd_regs, dim3(blocks), dim3(TPB), fl, C.stream, it, (u32)entries, dt, dg);
             };
             launch(8u);
             HIPCHK(hipEventRecord(e0, C.stream));
@@ -1737,9 +1744,9 @@ int rofl_bench_femul(unsigned iters, double *out) {
             HIPCHK(hipFree(dt)); HIPCHK(hipFree(dg)); HIPCHK(hipFree(din)); HIPCHK(hipFree(dout)); HIPCHK(hipEventDestroy(e0)); HIPCHK(hipEventDestroy(e1));
             return ROFL_OK;
         }
-        hipLaunchKernelGGL(k_bench_femul, dim3(blocks), dim3(TPB), fl, C.stream, 8u, din, dout);
+        ROFL_LAUNCH(k_bench_femul, dim3(blocks), dim3(TPB), fl, C.stream, 8u, din, dout);
         HIPCHK(hipEventRecord(e0, C.stream));
-        hipLaunchKernelGGL(k_bench_femul, dim3(blocks), dim3(TPB), fl, C.stream, iters, din, dout);
+        ROFL_LAUNCH(k_bench_femul, dim3(blocks), dim3(TPB), fl, C.stream, iters, din, dout);
         HIPCHK(hipEventRecord(e1, C.stream));
         HIPCHK(hipEventSynchronize(e1));
         float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));

@@ -43,7 +43,6 @@ def main():
     time.sleep(0.2)      # (a background builder, if a verify path had started one, would be at work by now)
     b4b, b64 = api.bp_gens_table_bytes(nb, m4), api.bp_gens_table_bytes(nb, m64)
     assert b4b == b4 and 0 < b64 < 3e9, (b4, b4b, b64)      # both shapes resident at once, nothing evicted, nothing grown
-    free0 = __import__("torch").cuda.mem_get_info()[0] if False else None      # (no torch in this process: the byte counts above are the library's own accounting)
     # the same process now proves: the create call meets the verifier's entry of (nb, m4) and adds the fold table
     pr, cm = R.range_proof_vec.create_rangeproof(vals, bl, nb, 4, nonce=R.Nonce.seeded(seed), fp=fp)
     assert (pr == case["opr"]).all() and (cm == case["ocm"]).all(), "create after verify differs from the oracle"

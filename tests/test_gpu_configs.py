@@ -47,23 +47,17 @@ def test_cfg1_full_size_whole_proof_vs_oracle(R):
     assert orc.verify_rangeproof(bad, cm, nb, 16, 7) == (0, False)
 
 
-def test_cfg4_chunk0_vs_oracle(R):
+def test_cfg4_chunk0_vs_oracle(R, full_oracle):
     """BASELINE cfg 4 shape: d = 55 000 (d_pad 65 536, m = 16 384, N = 524 288, 19 rounds), 32-bit, P = 4.  Chunk 0's nonces
-    start at index 0, so it equals the oracle's single-chunk proof over the first 16 384 values; the oracle also accepts the
-    GPU's chunk and the GPU accepts the oracle's."""
-    fp = (32, 7)
-    rng = np.random.default_rng(55000)
-    d, nb, P, m = 55000, 32, 4, 16384
-    vals = _uniform(R, rng, d, nb, fp)
-    bl = rng.integers(0, 256, size=(d, 32), dtype=np.uint8); bl[:, 31] &= 0x0F
-    seed = b"\x41" * 32
-    pr, cm = R.range_proof_vec.create_rangeproof(vals, bl, nb, P, nonce=R.Nonce.seeded(seed), fp=fp)
-    assert pr.shape == (4, 1504)
-    rc, opr, ocm = orc.create_rangeproof(vals[:m], bl[:m], nb, 1, 32, 7, seed=seed)
-    assert rc == 0 and (ocm == cm[:m]).all() and (opr[0] == pr[0]).all()
-    assert R.range_proof_vec.verify_rangeproof(pr, cm, nb, verifier_seed=b"\x01" * 32, fp=fp)
-    assert orc.verify_rangeproof(pr[:1], cm[:m], nb, 32, 7) == (0, True)
-    assert R.range_proof_vec.verify_rangeproof(opr, ocm, nb, verifier_seed=b"\x02" * 32, fp=fp)
+    start at index 0, so the oracle's chunk 0 of the four-chunk proof equals the single-chunk proof (P = 1) over the first 16 384 values:
+    the HIP path proves exactly that and must return the same bytes; the oracle accepts the GPU's chunk and the GPU the oracle's."""
+    c = full_oracle.case("cfg4")
+    fp, nb, m = c["fp"], c["nb"], 16384
+    pr, cm = R.range_proof_vec.create_rangeproof(c["vals"][:m], c["bl"][:m], nb, 1, nonce=R.Nonce.seeded(c["seed"]), fp=fp)
+    assert pr.shape == (1, 1504)
+    assert (c["ocm"][:m] == cm).all() and (c["opr"][0] == pr[0]).all()
+    assert orc.verify_rangeproof(pr, cm, nb, 32, 7) == (0, True)
+    assert R.range_proof_vec.verify_rangeproof(c["opr"][:1], c["ocm"][:m], nb, verifier_seed=b"\x02" * 32, fp=fp)
 
 
 def test_cfg2_whole_proof_full_size_vs_oracle(R, full_oracle):
@@ -168,8 +162,8 @@ def test_cfg3_cfg5_l2_composite_vs_oracle(R, d):
 def test_many_chunk_shapes_fuzz(R):
     """Random shapes with 16 .. 128 chunks of 2^11 .. 2^15 generators (the regime of the reference's e2e runs: 15-bit window tables for
     launches with many problems, device-side Horner, folds down to 64 generators per chunk): three chunks per case against the oracle's
-    single-chunk prover, round trip and tamper (tests/gpu_fuzz_many_chunks.py, 45 s here; 75 cases in 300 s when run on its own)."""
+    single-chunk prover, round trip and tamper (tests/gpu_fuzz_many_chunks.py, 30 s here; 75 cases in 300 s when run on its own)."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tests", "gpu_fuzz_many_chunks.py"), "45", "2026"], capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "gpu_fuzz_many_chunks.py"), "30", "2026"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "fuzz ok:" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]

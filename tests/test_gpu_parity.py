@@ -603,19 +603,23 @@ def test_msm_variants_small_sizes(R, env):
     assert r.returncode == 0 and "FB_SMALL PASS" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-def test_two_level_sort_bin_shapes(R):
+def test_two_level_sort_bin_shapes(R, full_oracle, tmp_path):
     """The two-level bucket sort of the fixed-base launches at its three shapes -- 4 windows per bucket array (256 coarse bins, the
     single-client default), 8 and 16 windows per array (512 bins; what calls in flight next to others and single-set plans take) --
-    and the one-level LDS scatter: all bit-identical to the oracle on one chunk of 2^19 terms."""
-    import subprocess, sys
+    and the one-level LDS scatter: all bit-identical to the oracle on one chunk of 2^19 terms (chunk 0 of the session's full-size cfg-4
+    oracle proof = the single-chunk proof over its first 16 384 values: its nonces start at index 0)."""
+    import hashlib, subprocess, sys
     helper = os.path.join(os.path.dirname(__file__), "gpu_two_level_check.py")
-    def run(env, *args):
+    c = full_oracle.case("cfg4"); m = 16384
+    npz = str(tmp_path / "chunk0.npz")
+    np.savez(npz, vals=c["vals"][:m], bl=c["bl"][:m], seed=np.frombuffer(c["seed"], np.uint8))
+    want = hashlib.sha256(c["opr"][:1].tobytes() + c["ocm"][:m].tobytes()).hexdigest()
+    def run(env):
         e = dict(os.environ); e.update(env)
-        r = subprocess.run([sys.executable, helper, *args], env=e, capture_output=True, text=True, timeout=900)
+        r = subprocess.run([sys.executable, helper, npz], env=e, capture_output=True, text=True, timeout=900)
         lines = [l for l in r.stdout.splitlines() if l.startswith("DIGEST")]
         assert r.returncode == 0 and lines, r.stdout[-2000:] + r.stderr[-2000:]
         return lines[0].split()[1:]
-    want = run({}, "oracle")[0]
     for env in ({}, {"ROFL_MSM_FB_THREADS": "65536"}, {"ROFL_MSM_FB_THREADS": "32768"},      # two sets / one set per problem: 8 and 16 windows per bucket array
                 {"ROFL_MSM_TWO_LEVEL": "0"}, {"ROFL_ACC_BALANCE": "0"}):
         got = run(env)

@@ -152,9 +152,9 @@ def test_a_batch_of_one_gives_a_verdict_not_an_error(R):
 
 
 def test_batch_paths_fuzz():
-    """tests/gpu_fuzz_batch.py, 60 s, fixed seed: three host threads over two logical devices, random shapes (8 / 16 / 32 bits, 1-8 chunks,
+    """tests/gpu_fuzz_batch.py, 30 s here (the long form is the script itself), fixed seed: three host threads over two logical devices, random shapes (8 / 16 / 32 bits, 1-8 chunks,
     1-11 clients), random members tampered; batched creates against single creates, verify_batch 1 / 2 x devices on / off against per-client
     verification, sampled members against the oracle."""
     env = dict(os.environ); env.pop("ROFL_DEVICE_MAP", None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "gpu_fuzz_batch.py"), "60", "20261003"], capture_output=True, text=True, timeout=900, env=env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "gpu_fuzz_batch.py"), "30", "20261003"], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0 and "batch fuzz ok:" in r.stdout, r.stdout[-1500:] + r.stderr[-2500:]

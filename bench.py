@@ -54,12 +54,14 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=25000, help="elements of the workload the CPU baseline proves and verifies (25 000 = all of it, ~25 s on 4 threads)")
     ap.add_argument("--no-l2", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short cfg 1 / cfg 4 / cfg 5 measurements that the default N = 1 run reports beside the headline")
     ap.add_argument("--no-extras", action="store_true", help="headline only (profiling runs)")
     ap.add_argument("--clients-in-flight", type=int, default=0, help="C of the separate concurrent-clients figure (0 = 6, fewer when host cores are scarce)")
     ap.add_argument("--config", type=int, default=2, choices=(2, 4, 5),
                     help="BASELINE.json config: 2 = the headline (1 client, L-inf 32-bit, d = 25 000); 4 = 48 clients, L-inf 32-bit, d = 55 000, sharded over the ranks, "
                          "batch create -> all-gather -> every rank batch-verifies another rank's share; 5 = the same with the L2 composite (EncParamsL2)")
     ap.add_argument("--n-partition", type=int, default=NPART, help="n_partition (reference bench: 4 -- the headline; its e2e experiments: 64)")
+    ap.add_argument("--split-chunks", action="store_true", help="--config 2 with --gpus N: ONE client per step for the whole job -- rank r proves and verifies the r-th contiguous run of the client's chunks (rofl_create_rangeproof_chunks / rofl_verify_rangeproof_chunks), one all-gather assembles proofs and commitments (SURVEY 8(e): 'cfg 2/3 at > 1 GPU -> chunks over ranks'; range_proof_vec/mod.rs:54-78, 168-181).  Strong scaling: value = K * d / time, useful up to n_partition ranks")
     ap.add_argument("--one-process", action="store_true", help="--config 4 with --gpus N: ONE process drives the N devices through the C ABI (rofl_set_option(\"devices\", mask): the batch entry points deal the clients to the devices from internal threads; no torch.distributed, no collective) -- the shape of the reference's server (server.rs:379-384, 656-687).  With fewer physical GPUs than N the logical devices wrap around (ROFL_DEVICE_MAP)")
     ap.add_argument("--host-cores", type=int, default=0, help="pin this rank to its first K usable cores before any GPU call (the host budget of one of 8 ranks on a node: 2, 4, 8, 16)")
     ap.add_argument("--verify-batch", type=int, default=-1, choices=(-1, 1, 2), help="--config 4: rofl_set_option(\"verify_batch\"): 2 (default) = the rank's whole share in ONE call with one random-weighted check, 1 = one check per client, six clients per call")
@@ -207,6 +209,63 @@ def l2_composite(R, reps=5, warm=3):
     med = ts[len(ts) // 2]
     return {"workload": "L2 composite d=25000 (EncParamsL2::encrypt / verify): 8-bit range proof + L2 sum proof + square proofs, the three proofs on separate lanes",
             "elements_per_s": D / med[0], "create_ms": med[1] * 1e3, "verify_ms": med[2] * 1e3}
+
+
+def other_configs(args, R):
+    """The other BASELINE configs beside the headline, measured in the same default run (never `value`): cfg 1 and cfg 3 per client in this
+    process, cfg 4 and cfg 5 as short rounds of 48 clients in child processes (`bench.py --config 4 | 5 --steps 2 --warmup 1`: their own lanes,
+    tables and CPU sample), each with the parity flag of its oracle sample."""
+    import numpy as np
+    res = {"note": "NOT the headline metric: BASELINE.json configs[0], [2], [3], [4] measured beside it so that every config has a driver-visible figure; "
+                   "cfg 4 / cfg 5 = one MI355X doing all 48 clients of a round (create -> exchange -> verify), 2 timed rounds after 1 warm-up"}
+    # ---- cfg 1: L-inf 8-bit, d = 5 000, fp16 / frac7, P = 4 (the reference's own CPU-runnable bench shape)
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import orc
+        fp1, d1, nb1 = (16, 7), 5000, 8
+        rng = np.random.default_rng(11)
+        mx = np.float32(((1 << (nb1 - 1)) - 1) / 128.0)
+        vals = np.clip(rng.uniform(-mx, mx, size=d1).astype(np.float32), -mx, np.nextafter(mx, np.float32(0)))
+        bl = rng.integers(0, 256, size=(d1, 32), dtype=np.uint8); bl[:, 31] &= 0x0F
+        ts = []
+        for rep in range(8):
+            t0 = time.perf_counter()
+            pr, cm = R.range_proof_vec.create_rangeproof(vals, bl, nb1, NPART, nonce=R.Nonce.seeded(b"\x01" * 32), fp=fp1)
+            t1 = time.perf_counter()
+            ok = R.range_proof_vec.verify_rangeproof(pr, cm, nb1, verifier_seed=b"\x02" * 32, fp=fp1)
+            t2 = time.perf_counter()
+            assert ok
+            if rep >= 3:
+                ts.append((t2 - t0, t1 - t0, t2 - t1))
+        ts.sort(); med = ts[len(ts) // 2]
+        t0 = time.time(); rc, opr, ocm = orc.create_rangeproof(vals, bl, nb1, NPART, 16, 7, seed=b"\x01" * 32); rc2, ook = orc.verify_rangeproof(opr, ocm, nb1, 16, 7); tcpu = time.time() - t0
+        parity = bool(rc == 0 and rc2 == 0 and ook and (opr == pr).all() and (ocm == cm).all())
+        assert parity, "cfg 1: HIP bytes differ from the oracle"
+        res["cfg1"] = {"workload": "BASELINE cfg 1: L-inf 8-bit range proof, d=5000 (mnist_dev_intrinsic_5k), fp16/frac7, P=%d, 1 client create+verify, median of 5" % NPART,
+                       "elements_per_s": d1 / med[0], "create_ms": med[1] * 1e3, "verify_ms": med[2] * 1e3,
+                       "cpu_baseline": {"value": d1 / tcpu, "unit": "elements/s", "kind": "port", "cores": max(1, min(NPART, avail_cores())), "parity_checked": parity,
+                                        "sample": "oracle create+verify of the whole workload (d=5000) in %.1f s" % tcpu}}
+    except Exception as e:      # noqa: BLE001 -- a measurement extra never fails the bench line
+        res["cfg1"] = {"error": repr(e)[:300]}
+    if "l2_composite" not in res:
+        res["cfg3"] = "see l2_composite (EncParamsL2::encrypt / verify at d = 25 000) in this line"
+    # ---- cfg 4 / cfg 5: rounds of 48 clients, child processes
+    for cfg in (4, 5):
+        try:
+            t0 = time.time()
+            cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", str(cfg), "--steps", "2", "--warmup", "1", "--n-partition", str(NPART),
+                                 "--hip-runtime", args.hip_runtime if args.hip_runtime in ("system", "process") else "process"], capture_output=True, text=True, timeout=400)
+            cj = json.loads(cp.stdout.strip().splitlines()[-1])
+            cb = cj.get("cpu_baseline") or {}
+            res["cfg%d" % cfg] = {"workload": cj["config"]["workload"], "elements_per_s": cj["value"], "ms_per_round": cj["ms_per_step"], "steps": cj["steps"], "warmup": cj["warmup"],
+                                  "breakdown_ms_per_round": cj.get("breakdown_ms_per_step_rank0"),
+                                  "create_only_elements_per_s": cj.get("create_only_elements_per_s"), "verify_only_elements_per_s": cj.get("verify_only_elements_per_s"),
+                                  "end_to_end_frac": (cj.get("valu_roofline") or {}).get("end_to_end_frac"),
+                                  "cpu_baseline": {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "parity_checked", "sample")},
+                                  "child_wall_s": round(time.time() - t0, 1)}
+        except Exception as e:      # noqa: BLE001
+            res["cfg%d" % cfg] = {"error": repr(e)[:300]}
+    return res
 
 
 def avail_cores():
@@ -559,7 +618,7 @@ def run_rank(args):
         mine_ = cores[local_rank * k:(local_rank + 1) * k]              # ranks of one node take disjoint slices while they last
         os.sched_setaffinity(0, set(mine_ if len(mine_) == k else cores[:k]))
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-    extras = rank == 0 and world == 1 and not args.no_extras
+    extras = rank == 0 and world == 1 and not args.no_extras and not args.split_chunks
     CIF = args.clients_in_flight if args.clients_in_flight > 0 else max(1, min(6, int(avail_cores() / (2.0 * local_world))))
     if avail_cores() / max(local_world, 1) < 2.0:
         # a lone call spins while it waits for the GPU (lowest latency; since round 4 the hop's host part runs on the calling thread, so a rank
@@ -631,7 +690,11 @@ def run_rank(args):
         return run_multi_client(args, R, rd, dist, cdev, world, rank, backend, comm)
 
     total_steps = args.warmup + args.steps
-    clients = [synth_client(1000 * (s * world + rank)) for s in range(total_steps)]
+    split = bool(args.split_chunks)
+    # split: the SAME client on every rank (the job proves ONE client per step); otherwise a client of its own per rank and step (weak scaling)
+    clients = [synth_client(1000 * (s if split else s * world + rank)) for s in range(total_steps)]
+    n_chunks = int(api.lib().rofl_rangeproof_chunks(D, NPART)); m_chunk = rpv.next_pow2(D) // n_chunks
+    plen_chunk = int(api.lib().rofl_rangeproof_size(NBITS, D, NPART))
     ktot = {k: {"ms": 0.0, "launches": 0, "fe_muls": 0, "bytes": 0} for k in api.KERNEL_KINDS}
     agg = {"create_ms": 0.0, "verify_ms": 0.0, "device_ms": 0.0, "host_ms": 0.0, "msm_terms": 0}
 
@@ -661,7 +724,32 @@ def run_rank(args):
             agg["msm_terms"] += tc["msm_terms"] + tv["msm_terms"]
         return pr, cm, ok
 
+    def grab(record):
+        if record:
+            t_, k_ = R.last_timing(), R.last_kernel_times()
+            for name, e in k_.items():
+                for f in e:
+                    ktot[name][f] += e[f]
+            agg["device_ms"] += t_["total_ms"]; agg["host_ms"] += t_["host_ms"]; agg["msm_terms"] += t_["msm_terms"]
+
+    def step_split(s, record):
+        """ONE client for the whole job: this rank's run of chunks -> all-gather -> the next rank's run verified here -> MIN of the verdicts"""
+        vals, bl = clients[s]
+        nonce = R.Nonce.seeded(bytes([s % 256]) * 32)
+        t0 = time.perf_counter()
+        pr, cm = rd.split_create(comm, rank, world, n_chunks, m_chunk, D, plen_chunk,
+                                 lambda f, c: (lambda out: (grab(record), out)[1])(rpv.create_rangeproof_chunks(vals, bl, NBITS, NPART, f, c, nonce=nonce, fp=FP)))
+        t1 = time.perf_counter()
+        ok = rd.split_verify(comm, rank, world, pr, cm, m_chunk,
+                             lambda f, p_, c_: (lambda out: (grab(record), out)[1])(rpv.verify_rangeproof_chunks(p_, n_chunks, f, c_, D, NBITS, verifier_seed=bytes([s % 256]) * 32, fp=FP)))
+        t2 = time.perf_counter()
+        if record:
+            agg["create_ms"] += (t1 - t0) * 1e3; agg["verify_ms"] += (t2 - t1) * 1e3
+        assert ok, "proof failed to verify"
+
     def step(s, record, inputs=None):
+        if split:
+            return step_split(s, record)
         vals, bl = (inputs or clients)[s]
         pr, cm, ok = one_client(vals, bl, s, s, record)
         if args.exchange:   # the exchange step: server-side collection of proof bytes + commitments, verify bits
@@ -723,15 +811,18 @@ def run_rank(args):
         R.set_timing(0)
     else:
         instr_elapsed = None
-    value = world * K * D / elapsed
+    value = (1 if split else world) * K * D / elapsed
     step_sorted = sorted(step_ms)
     median_ms = step_sorted[len(step_sorted) // 2] if len(step_sorted) % 2 else 0.5 * (step_sorted[len(step_sorted) // 2 - 1] + step_sorted[len(step_sorted) // 2])
     out = {
         "metric": "range-proof elements/sec (create+verify), d=25k 32-bit" + ("" if NPART == 4 else ", n_partition=%d" % NPART), "value": value, "unit": "elements/s",
         "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": elapsed / K * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32x8 (255-bit integer field)", "data": "synthetic",
+        "higher_is_better": True, "scaling": "strong" if split else "weak", "vs_baseline": None, "dtype": "u32x8 (255-bit integer field)", "data": "synthetic",
+        "split_chunks": ({"runs": rd.chunk_runs(n_chunks, world), "n_chunks": n_chunks, "values_per_chunk": m_chunk,
+                          "note": "ONE client per step for the whole job: rank r proves the r-th contiguous run of the client's chunks (rofl_create_rangeproof_chunks), one all-gather of [proofs | commitments] assembles the client's proof set on every rank, rank r verifies the run of rank r + 1 (rofl_verify_rangeproof_chunks), MIN over the verdicts; ranks beyond the chunk count only join the collectives"} if split else None),
         "rccl_world_size": rccl_world, "collective_backend": comm.backend if args.exchange else None, "hip_runtime_per_rank": runtimes, "per_rank": per_rank_info,
-        "config": {"workload": "BASELINE cfg 2: L-inf 32-bit range proof, d=25000 (resnet18_intrinsic_25k), 1 client create+verify per step per GPU, inputs handed over as host buffers (H2D inside the timed region)",
+        "config": {"workload": ("BASELINE cfg 2: L-inf 32-bit range proof, d=25000 (resnet18_intrinsic_25k), ONE client create+verify per step for the whole job, its chunks split over the ranks (--split-chunks), inputs handed over as host buffers" if split else
+                                "BASELINE cfg 2: L-inf 32-bit range proof, d=25000 (resnet18_intrinsic_25k), 1 client create+verify per step per GPU, inputs handed over as host buffers (H2D inside the timed region)"),
                    "d": D, "prove_range": NBITS, "n_partition": NPART, "fp_bits": FP_BITS, "fp_frac": FP_FRAC, "clients_per_step_per_gpu": 1,
                    "host_cores": avail_cores(), "host_cores_pinned": args.host_cores or None, "host_cores_busy": round(cpu_busy, 2), "lanes": R.get_option("lanes"), "wait_policy": "sleep" if os.environ.get("ROFL_BLOCKING_SYNC") == "1" else "spin",
                    "hip_runtime": mapped_hip_runtime(), "tables": "compact (16 fold slices)" if args.compact_tables else "full",
@@ -894,6 +985,8 @@ def run_rank(args):
                 out[key] = {"error": repr(e)[:200]}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, R)
+        if not args.no_other_configs:
+            out["baseline_configs"] = other_configs(args, R)
     out["other_configs"] = "bench.py --config 4 | 5 (48 clients sharded over the ranks); profiles/r04_configs.json (scripts/gpu_configs.py): all five BASELINE configs and the e2e partition count P=64, reference bench protocol"
     emit(json.dumps(out))
     if args.exchange:
@@ -983,6 +1076,84 @@ def run_one_process(args):
                       "create_only_elements_per_s": NC * D_MULTI * K / phase["create"], "verify_only_elements_per_s": NC * D_MULTI * K / phase["verify"]}))
 
 
+def run_one_process_split(args):
+    """BASELINE cfg 2 as ONE host process on `--gpus` devices: the unchanged single-client calls (rofl_create_rangeproof / rofl_verify_rangeproof)
+    with rofl_set_option("devices", mask) -- the library deals the client's chunks to the devices in contiguous runs (what the reference does
+    on its rayon pool, range_proof_vec/mod.rs:54-78, 168-181).  No collective: proofs and commitments land in the caller's arrays."""
+    claim_stdout()
+    import resource
+    ndev = args.gpus
+    import torch
+    nphys = max(1, torch.cuda.device_count())
+    if nphys < ndev:
+        os.environ.setdefault("ROFL_DEVICE_MAP", ",".join(str(i % nphys) for i in range(ndev)))
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    import rofl_project_code_amd as R
+    from rofl_project_code_amd import api, build
+    build.build()
+    rpv = R.range_proof_vec
+    P = args.n_partition
+    n_chunks = int(api.lib().rofl_rangeproof_chunks(D, P)); m = rpv.next_pow2(D) // n_chunks
+    import threading
+    t_prep = time.perf_counter(); prep_err = []
+    def prep(dv):
+        try:
+            R.set_device(dv); api.bp_gens_prepare(NBITS, m)
+        except Exception as e:      # noqa: BLE001
+            prep_err.append((dv, repr(e)))
+    ths = [threading.Thread(target=prep, args=(dv,)) for dv in range(min(ndev, n_chunks))]
+    for t_ in ths: t_.start()
+    for t_ in ths: t_.join()
+    assert not prep_err, prep_err
+    prepare_ms = (time.perf_counter() - t_prep) * 1e3
+    R.set_device(0)
+    R.set_option("devices", (1 << ndev) - 1)
+    total = args.warmup + args.steps
+    clients = [synth_client(1000 * s) for s in range(total)]
+    phase = {"create": 0.0, "verify": 0.0}
+
+    def step(s, record):
+        vals, bl = clients[s]
+        t0 = time.perf_counter()
+        pr, cm = rpv.create_rangeproof(vals, bl, NBITS, P, nonce=R.Nonce.seeded(bytes([s % 256]) * 32), fp=FP)
+        t1 = time.perf_counter()
+        ok = rpv.verify_rangeproof(pr, cm, NBITS, verifier_seed=bytes([s % 256]) * 32, fp=FP)
+        t2 = time.perf_counter()
+        assert ok, "proof failed to verify"
+        if record:
+            phase["create"] += t1 - t0; phase["verify"] += t2 - t1
+        return pr, cm
+
+    # parity of the split against the one-device call on the first client (bytes must not depend on the deal)
+    pr_s, cm_s = step(0, False)
+    R.set_option("devices", 0); pr_1, cm_1 = step(0, False); R.set_option("devices", (1 << ndev) - 1)
+    same = bool((pr_s == pr_1).all() and (cm_s == cm_1).all())
+    assert same, "the split call's bytes differ from the one-device call's"
+    for s in range(args.warmup):
+        step(s, False)
+    ru0 = resource.getrusage(resource.RUSAGE_SELF)
+    step_ms = []
+    t0 = time.perf_counter()
+    for s in range(args.warmup, total):
+        ts = time.perf_counter(); step(s, True); step_ms.append((time.perf_counter() - ts) * 1e3)
+    elapsed = time.perf_counter() - t0
+    ru1 = resource.getrusage(resource.RUSAGE_SELF)
+    K = args.steps
+    emit(json.dumps({"metric": "range-proof elements/sec (create+verify), d=25k 32-bit" + ("" if P == 4 else ", n_partition=%d" % P) + ", one client split over the devices of one host process",
+                      "value": K * D / elapsed, "unit": "elements/s", "n_gpus": ndev, "steps": K, "warmup": args.warmup, "ms_per_step": elapsed / K * 1e3,
+                      "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32x8 (255-bit integer field)", "data": "synthetic",
+                      "rccl_world_size": None, "collective_backend": None,
+                      "config": {"workload": "BASELINE cfg 2: L-inf 32-bit range proof, d=25000, ONE client create+verify per step, its %d chunks dealt to %d logical device(s) on %d physical GPU(s) in contiguous runs by "
+                                             "rofl_create_rangeproof / rofl_verify_rangeproof under rofl_set_option(\"devices\")" % (n_chunks, ndev, min(ndev, nphys)),
+                                 "d": D, "n_partition": P, "prove_range": NBITS, "fp_bits": FP_BITS, "fp_frac": FP_FRAC, "devices_mask": (1 << ndev) - 1, "physical_gpus": min(ndev, nphys),
+                                 "host_cores": avail_cores(), "tables": "compact (16 fold slices)" if args.compact_tables else "full", "tables_prepare_ms_all_devices_in_parallel": round(prepare_ms, 1),
+                                 "hip_runtime": mapped_hip_runtime(), "split_bytes_equal_one_device_call": same,
+                                 "rehearsal": ("%d logical devices share %d physical GPU(s): this run checks that the split path completes and returns the one-device bytes; it is NOT a scaling number" % (ndev, nphys)) if nphys < ndev else None,
+                                 "host_cores_busy": round(((ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)) / max(elapsed, 1e-9), 2)},
+                      "step_ms": [round(x, 2) for x in step_ms],
+                      "breakdown_ms_per_client": {k: phase[k] / K * 1e3 for k in ("create", "verify")}}))
+
+
 def gather_rank_info(comm, **extra):
     """One small JSON record per rank through the communicator: the HIP runtime(s) it mapped (the ranks of a node must agree), its busy host
     cores and whatever else the caller adds -- rank 0 prints them as hip_runtime_per_rank / per_rank."""
@@ -1044,8 +1215,10 @@ def main():
                 raise
             sys.stderr.write("bench.py: %s could not be mapped (%r): this rank stays on the process's HIP runtime\n" % (SYSTEM_HIP, e))
     if args.one_process:
+        if args.config == 2:
+            return run_one_process_split(args)      # ONE client's chunks over the devices
         if args.config != 4:
-            sys.stderr.write("bench.py: --one-process is a mode of --config 4\n"); sys.exit(2)
+            sys.stderr.write("bench.py: --one-process is a mode of --config 2 (one client split by chunks) and --config 4 (clients dealt to the devices)\n"); sys.exit(2)
         return run_one_process(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch_ranks(args)

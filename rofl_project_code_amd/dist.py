@@ -33,6 +33,53 @@ def all_verified(ok_local, device, group=None, force_collective=False):
     return bool(t.item())
 
 
+# ---------------------------------------------------------------------------------------------------------------- ONE client over the ranks
+# SURVEY 8(e): "cfg 2/3 at > 1 GPU -> chunks over ranks".  The reference proves / verifies a client's chunks independently on its rayon pool
+# (range_proof_vec/mod.rs:54-78, 168-181); here rank r takes the r-th contiguous run of the chunks (the same deal as the library's one-process
+# split, rofl_set_option("devices")), one all-gather assembles the client's proof set and commitment vector on every rank, and the verdict is
+# the MIN over the ranks' runs.  No collective inside a proof.
+def chunk_runs(n_chunks, world):
+    """[(first, count)] per rank: contiguous runs, as even as they come; ranks beyond the chunk count get (0, 0) and only join the collectives."""
+    nd = min(world, n_chunks)
+    runs = [(k * n_chunks // nd, (k + 1) * n_chunks // nd - k * n_chunks // nd) for k in range(nd)]
+    return runs + [(0, 0)] * (world - nd)
+
+
+def split_create(comm, rank, world, n_chunks, m, d, proof_len, create_run):
+    """create_run(first, count) -> (proofs u8[count, proof_len], commitments u8[k, 32] of the run's own elements) -- e.g.
+    range_proof_vec.create_rangeproof_chunks.  Returns (proofs u8[n_chunks, proof_len], commitments u8[d, 32]) assembled from ONE
+    all-gather, identical on every rank and byte for byte what the unsplit create returns."""
+    runs = chunk_runs(n_chunks, world)
+    cmax = max(c for _, c in runs)
+    first, count = runs[rank]
+    buf_p = np.zeros((cmax, proof_len), np.uint8); buf_c = np.zeros((cmax * m, 32), np.uint8)
+    if count:
+        pr, cm = create_run(first, count)
+        buf_p[:count] = pr; buf_c[:cm.shape[0]] = cm
+    _, per_rank = comm.exchange_round([buf_p, buf_c], True)
+    proofs = np.zeros((n_chunks, proof_len), np.uint8); commits = np.zeros((d, 32), np.uint8)
+    for r, (f, c) in enumerate(runs):
+        if not c:
+            continue
+        proofs[f:f + c] = per_rank[r][0].reshape(cmax, proof_len)[:c]
+        lo, hi = min(d, f * m), min(d, (f + c) * m)
+        commits[lo:hi] = per_rank[r][1].reshape(cmax * m, 32)[:hi - lo]
+    return proofs, commits
+
+
+def split_verify(comm, rank, world, proofs, commits, m, verify_run, shift=1):
+    """verify_run(first, proofs_run, commits_run) -> bool for a run of the client's proofs -- e.g. range_proof_vec.verify_rangeproof_chunks.
+    Rank r checks the run that rank (r + shift) created (so the bytes it reads really crossed the collective); the verdict is the MIN over
+    the ranks (range_proof_vec/mod.rs:182-190 ANDs the chunks' bits)."""
+    n_chunks, d = proofs.shape[0], commits.shape[0]
+    first, count = chunk_runs(n_chunks, world)[(rank + shift) % world]
+    ok = True
+    if count:
+        lo, hi = min(d, first * m), min(d, (first + count) * m)
+        ok = bool(verify_run(first, proofs[first:first + count], commits[lo:hi]))
+    return comm.all_verified(ok)
+
+
 _round_bufs = {}
 
 

@@ -1,0 +1,57 @@
+"""rocprofv3 --kernel-trace csv of a batched round -> who ran beside whom.
+For every kernel name: launches, mean / p50 / max duration, and -- the question of VERDICT r5 'weak 4' -- how much of its launches' time another
+queue's k_msm_accumulate_fb / k_fold_gens* launch was running (starvation beside a foreign VALU-saturating launch) against how long its
+launches take when nothing else runs.  usage: kt_overlap.py <trace_dir> [skip_fraction]   (skip the first part of the trace: warm-up)"""
+import bisect
+import collections
+import csv
+import glob
+import sys
+
+f = sorted(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True))[-1]
+skip = float(sys.argv[2]) if len(sys.argv) > 2 else 0.5
+rows = list(csv.DictReader(open(f)))
+name = lambda r: r["Kernel_Name"].split("(")[0].replace("rofl::", "")
+ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name(r), r.get("Queue_Id", "?"), int(r.get("Grid_Size_X") or 0) * int(r.get("Grid_Size_Y") or 1)) for r in rows), key=lambda e: e[0])
+t_lo = ev[0][0] + skip * (ev[-1][1] - ev[0][0])
+ev = [e for e in ev if e[0] >= t_lo]
+heavy = [e for e in ev if e[2] in ("k_msm_accumulate_fb", "k_fold_gens_w", "k_fold_gens4", "k_fold_gens", "k_msm_accumulate_gen", "k_fold_gens_tab")]
+hs = [e[0] for e in heavy]
+
+
+def overlap_with_heavy(e):
+    s, t, _, q, _ = e
+    tot = 0
+    i = bisect.bisect_left(hs, s) - 64
+    for h in heavy[max(0, i):]:
+        if h[0] >= t:
+            break
+        if h[3] == q or h[1] <= s:
+            continue
+        tot += min(t, h[1]) - max(s, h[0])
+    return min(tot, t - s)
+
+
+stat = collections.defaultdict(list)
+for e in ev:
+    stat[e[2]].append(e)
+span = (ev[-1][1] - ev[0][0]) / 1e6
+print("trace window %.1f ms, %d launches on %d queues" % (span, len(ev), len({e[3] for e in ev})))
+print("%-26s %6s %9s %9s %9s %9s  %s" % ("kernel", "n", "total ms", "mean ms", "alone ms", "beside ms", "share of its time beside a foreign heavy launch"))
+for k, es in sorted(stat.items(), key=lambda kv: -sum(e[1] - e[0] for e in kv[1]))[:18]:
+    d = [(e[1] - e[0]) / 1e6 for e in es]
+    ov = [overlap_with_heavy(e) / max(e[1] - e[0], 1) for e in es]
+    alone = [x for x, o in zip(d, ov) if o < 0.1]
+    beside = [x for x, o in zip(d, ov) if o > 0.5]
+    print("%-26s %6d %9.1f %9.3f %9s %9s  %.2f" % (k, len(es), sum(d), sum(d) / len(d), ("%.3f" % (sum(alone) / len(alone))) if alone else "-",
+                                                  ("%.3f" % (sum(beside) / len(beside))) if beside else "-", sum(o * x for o, x in zip(ov, d)) / max(sum(d), 1e-9)))
+# size classes of the sort kernels: duration against grid size (is a big launch slow because it is big, or because it shares the chip?)
+for k in ("k_msm_bin_l2", "k_msm_bin_l1", "k_msm_reduce_level"):
+    es = stat.get(k, [])
+    by = collections.defaultdict(list)
+    for e in es:
+        by[e[4]].append(((e[1] - e[0]) / 1e6, overlap_with_heavy(e) / max(e[1] - e[0], 1)))
+    print("---- %s by grid size (threads): n, mean ms alone / beside" % k)
+    for g, v in sorted(by.items()):
+        a = [x for x, o in v if o < 0.1]; b = [x for x, o in v if o > 0.5]
+        print("   %10d  n=%4d  alone %s  beside %s" % (g, len(v), ("%.3f" % (sum(a) / len(a))) if a else "-", ("%.3f" % (sum(b) / len(b))) if b else "-"))

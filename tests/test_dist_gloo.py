@@ -102,3 +102,73 @@ def test_communicator_choice_is_agreed_across_ranks():
         assert p.exitcode == 0
     got = sorted(q.get() for _ in range(2))
     assert got == [(0, True), (1, True)]      # (rank 0 logged why the library's communicator was not used)
+
+
+def _split_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    import orc
+    from rofl_project_code_amd import dist as rd
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    comm = rd.TorchComm(torch.device("cpu"))
+    assert rd.chunk_runs(4, 2) == [(0, 2), (2, 2)] and rd.chunk_runs(8, 3) == [(0, 2), (2, 3), (5, 3)] and rd.chunk_runs(2, 4) == [(0, 1), (1, 1), (0, 0), (0, 0)]
+    # ONE client (same seeded inputs on every rank), d = 11 of d_pad = 16 in 8 chunks of m = 2: chunk 5 is half padding, chunks 6 and 7 padding only
+    d, nb, P, fb, ff = 11, 8, 8, 16, 7
+    rng = np.random.default_rng(77)
+    vals = rng.uniform(-0.4, 0.4, d).astype(np.float32); bl = orc.rand_scalars(rng, d)
+    seed = b"\x2b" * 32
+    rc, want_p, want_c = orc.create_rangeproof(vals, bl, nb, P, fb, ff, seed=seed)      # the unsplit answer
+    assert rc == 0
+    n_chunks, plen = want_p.shape; m = 16 // n_chunks
+    vp = np.zeros(16, np.float32); vp[:d] = vals
+    bp = np.zeros((16, 32), np.uint8); bp[:d] = bl
+    calls = []
+
+    def create_run(first, count):      # the rank's run, chunk by chunk, from each chunk's own place in the client's nonce space
+        calls.append((first, count))
+        ps = []
+        for c in range(first, first + count):
+            lo, hi = c * m, min((c + 1) * m, d)
+            rc, pr, _ = orc.prove_chunk(vp[c * m:(c + 1) * m], bp[c * m:(c + 1) * m], nb, c, ff, seed, n_real=max(hi - lo, 0))
+            assert rc == 0
+            ps.append(pr)
+        lo, hi = min(d, first * m), min(d, (first + count) * m)
+        return np.stack(ps), want_c[lo:hi]      # (commitments: C_j = f32_to_scalar(x_j) B + r_j B~, independent of the split)
+
+    proofs, commits = rd.split_create(comm, rank, world, n_chunks, m, d, plen, create_run)
+    assert calls == [rd.chunk_runs(n_chunks, world)[rank]]
+    assert (proofs == want_p).all() and (commits == want_c).all()
+
+    # The oracle on a run: the run's chunks as a proof set of their own.  verify_rangeproof shifts every commitment it is given up by 2^(n-1) B
+    # and pads with the identity AFTERWARDS (range_proof_vec/mod.rs:155-167), so the padding elements of a run are handed over as
+    # C_pad = -2^(n-1) B, whose shifted form is the identity the prover committed to.
+    L = (1 << 252) + 27742317777372353535851937790883648493
+    c_pad = orc.commit_vec(np.frombuffer((L - (1 << (nb - 1))).to_bytes(32, "little"), np.uint8).reshape(1, 32), np.zeros((1, 32), np.uint8))[0]
+
+    def verify_run(first, pr, cm):
+        cnt = pr.shape[0]
+        full = np.tile(c_pad, (cnt * m, 1)); full[:cm.shape[0]] = cm
+        return orc.verify_rangeproof(pr, full, nb, fb, ff) == (0, True)
+
+    assert rd.split_verify(comm, rank, world, proofs, commits, m, verify_run) is True
+    bad = proofs.copy(); bad[n_chunks - 1, 40] ^= 1      # a bad proof in the LAST run: whichever rank checks that run fails the client
+    assert rd.split_verify(comm, rank, world, bad, commits, m, verify_run) is False
+    dist.barrier(); dist.destroy_process_group()
+    q.put(rank)
+
+
+def test_one_client_split_over_two_ranks_gloo():
+    """SURVEY 8(e) "cfg 2/3 at > 1 GPU -> chunks over ranks" on CPU: two ranks prove contiguous runs of ONE client's chunks (the oracle
+    as the prover), one all-gather assembles proofs and commitments, every rank holds the unsplit bytes; the verdict is the MIN over runs."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_split_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    assert sorted(q.get() for _ in range(2)) == [0, 1]

@@ -54,6 +54,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=25000, help="elements of the workload the CPU baseline proves and verifies (25 000 = all of it, ~25 s on 4 threads)")
     ap.add_argument("--no-l2", action="store_true")
+    ap.add_argument("--children-by-parent", action="store_true", help=argparse.SUPPRESS)      # set by the top-level process, which runs the cfg 4 / cfg 5 rounds itself after this one has exited
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short cfg 1 / cfg 4 / cfg 5 measurements that the default N = 1 run reports beside the headline")
     ap.add_argument("--no-extras", action="store_true", help="headline only (profiling runs)")
     ap.add_argument("--clients-in-flight", type=int, default=0, help="C of the separate concurrent-clients figure (0 = 6, fewer when host cores are scarce)")
@@ -249,12 +250,22 @@ def other_configs(args, R):
         res["cfg1"] = {"error": repr(e)[:300]}
     if "l2_composite" not in res:
         res["cfg3"] = "see l2_composite (EncParamsL2::encrypt / verify at d = 25 000) in this line"
-    # ---- cfg 4 / cfg 5: rounds of 48 clients, child processes
+    if not args.children_by_parent:      # (run directly with an explicit --hip-runtime: the rounds are measured from here, beside this process's tables)
+        res.update(other_configs_children(args.hip_runtime if args.hip_runtime in ("system", "process") else "process"))
+    return res
+
+
+def other_configs_children(hip_runtime):
+    """BASELINE cfg 4 and cfg 5 as short rounds of 48 clients on one MI355X, each in a process of its own (`bench.py --config N --steps 2 --warmup 1`:
+    its own lanes, tables and CPU sample).  Called by the top-level process AFTER the headline process has exited, so that the rounds do not
+    share HBM with the headline's 104 GB of tables."""
+    res = {}
     for cfg in (4, 5):
+        cp = None
         try:
             t0 = time.time()
             cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", str(cfg), "--steps", "2", "--warmup", "1", "--n-partition", str(NPART),
-                                 "--hip-runtime", args.hip_runtime if args.hip_runtime in ("system", "process") else "process"], capture_output=True, text=True, timeout=400)
+                                 "--hip-runtime", hip_runtime], capture_output=True, text=True, timeout=400)
             cj = json.loads(cp.stdout.strip().splitlines()[-1])
             cb = cj.get("cpu_baseline") or {}
             res["cfg%d" % cfg] = {"workload": cj["config"]["workload"], "elements_per_s": cj["value"], "ms_per_round": cj["ms_per_step"], "steps": cj["steps"], "warmup": cj["warmup"],
@@ -263,9 +274,44 @@ def other_configs(args, R):
                                   "end_to_end_frac": (cj.get("valu_roofline") or {}).get("end_to_end_frac"),
                                   "cpu_baseline": {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "parity_checked", "sample")},
                                   "child_wall_s": round(time.time() - t0, 1)}
-        except Exception as e:      # noqa: BLE001
-            res["cfg%d" % cfg] = {"error": repr(e)[:300]}
+        except Exception as e:      # noqa: BLE001 -- a measurement extra never fails the bench line
+            res["cfg%d" % cfg] = {"error": repr(e)[:300], "stderr_tail": cp.stderr[-600:] if cp is not None else None}
     return res
+
+
+def valu_issue_block(kernel_kind):
+    """VALU instruction-issue figures of `kernel_kind` from the newest committed rocprofv3 PMC pass (profiles/*_pmc_valu.json, scripts/profile_valu.sh:
+    SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU, GRBM_GUI_ACTIVE per launch of the same bench command) -- the instruction-level companion of
+    valu_roofline.frac, which counts only field multiplications: a mixed addition's 1 227 instructions are 7 multiplications AND the additions,
+    subtractions, selects and carries of eight field operations.
+      insts_per_simd_cycle = SQ_INSTS_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)       (wave-instructions issued per SIMD and shader cycle)
+      issue_frac           = that / the same quotient of k_bench_femul in the same pass      (the multiplication-only ceiling kernel, 160
+                             instructions per multiplication: the issue rate the chip sustains on this instruction mix)
+      valu_active_frac     = 4 x SQ_ACTIVE_INST_VALU / SIMD-cycles                           (share of SIMD-cycles with a VALU instruction in
+                             flight; SQ_ACTIVE_INST_* count quad-cycles, MI355X_MICROARCH.md)"""
+    import glob
+    try:
+        pj = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_valu.json")))[-1]
+        data = json.load(open(pj))
+        key = "rofl::" + kernel_kind.split("+")[0].split(" ")[0]
+        k = next((v for n, v in data.items() if n == key), None)
+        c = data.get("rofl::k_bench_femul")
+        if not k or not k.get("GRBM_GUI_ACTIVE"):
+            return None
+        simd_cyc = lambda e: 1024.0 * e["GRBM_GUI_ACTIVE"] / 8.0
+        ipc = k["SQ_INSTS_VALU"] / simd_cyc(k)
+        out = {"source": os.path.basename(pj), "kernel": key, "launches_profiled": k["launches"], "valu_insts_per_launch": k["SQ_INSTS_VALU"],
+               "shader_cycles_per_launch": k["GRBM_GUI_ACTIVE"] / 8.0, "insts_per_simd_cycle": ipc, "cycles_per_wave_instruction": 1.0 / ipc,
+               "valu_active_frac": 4.0 * k["SQ_ACTIVE_INST_VALU"] / simd_cyc(k),
+               "wait_inst_share_of_wave_cycles": k.get("SQ_WAIT_INST_ANY", 0.0) / max(k.get("SQ_WAVE_CYCLES", 1.0), 1.0),
+               "waves_per_launch": k.get("SQ_WAVES")}
+        if c and c.get("GRBM_GUI_ACTIVE"):
+            cipc = c["SQ_INSTS_VALU"] / simd_cyc(c)
+            out.update({"ceiling_kernel": "rofl::k_bench_femul (multiplications only)", "ceiling_insts_per_simd_cycle": cipc, "issue_frac": ipc / cipc,
+                        "headroom_note": "issue_frac is what is left to gain by keeping the SIMDs issuing (occupancy, gather latency); 1 - valu_roofline.frac / issue_frac is what the non-multiplication instructions of the addition formula cost"})
+        return out
+    except Exception:      # noqa: BLE001
+        return None
 
 
 def avail_cores():
@@ -888,6 +934,10 @@ def run_rank(args):
         out["roofline"] = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["algorithmic_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                            "frac": dom["hbm_frac"], "traffic": traffic, "avg_launch_ms": dom["avg_launch_ms"],
                            "algorithmic_bytes_per_launch": e["bytes"] / e["launches"],
+                           # SURVEY 8(d) prices the generators too (64 n B per element = 32 B per point): a term of this kernel is a (scalar, point) pair.
+                           # `achieved` / `frac` above count the 32-byte scalar only (the point is a table record, accounted in layout_min); the pair is:
+                           "algorithmic_bytes_per_launch_scalar_and_point": (2 * e["bytes"] / e["launches"]) if dom["kernel"].startswith("k_msm_accumulate") else None,
+                           "frac_scalar_and_point": (2 * dom["hbm_frac"]) if dom["kernel"].startswith("k_msm_accumulate") else None,
                            "traffic_GBps": (traffic / launch_s / 1e9) if traffic else None,
                            "traffic_frac": (traffic / launch_s / 1e9 / HBM_PEAK_GBPS) if traffic else None,
                            "layout_min_bytes_per_launch": layout_min,
@@ -907,7 +957,8 @@ def run_rank(args):
                                 "frac": dom["fe_mul_frac_of_peak"],
                                 "end_to_end_fe_muls_per_step": all_muls / KI,
                                 "end_to_end_frac": (all_muls / KI / (elapsed / K) / peak_mul) if peak_mul else None,
-                                "note": "frac: the dominant kernel against the multiplication-only micro-benchmark run in this process; end_to_end_frac: algorithmic "
+                                "issue": valu_issue_block(dom["kernel"]),
+                                "note": "frac: the dominant kernel against the multiplication-only micro-benchmark run in this process; issue: instruction-level figures of the same kernel from the committed PMC pass (issue.issue_frac = VALU instructions issued per SIMD-cycle against the ceiling kernel's); end_to_end_frac: algorithmic "
                                         "field multiplications of all instrumented kernels per step / (ceiling x wall time of a timed step)"}
 
     if extras:
@@ -1190,9 +1241,13 @@ def main():
         single = args.gpus == 1 and "WORLD_SIZE" not in os.environ and not args.one_process      # no process group, no RCCL in such a run
         if single and os.path.exists(SYSTEM_HIP):
             try:
-                cp = subprocess.run([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--hip-runtime", "system"], stdout=subprocess.PIPE, text=True, timeout=1500)
+                cp = subprocess.run([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--hip-runtime", "system", "--children-by-parent"], stdout=subprocess.PIPE, text=True, timeout=1500)
                 line = cp.stdout.strip().splitlines()[-1] if cp.stdout.strip() else ""
                 if cp.returncode == 0 and "value" in json.loads(line):
+                    hj = json.loads(line)
+                    if args.config == 2 and "baseline_configs" in hj:      # the headline process has exited: the rounds of 48 clients get the whole device
+                        hj["baseline_configs"].update(other_configs_children("system"))
+                        line = json.dumps(hj)
                     print(line); sys.stdout.flush()
                     return
                 sys.stderr.write("bench.py: the run on the system HIP runtime ended with %d; repeating on the process's runtime\n" % cp.returncode)

@@ -234,7 +234,8 @@ MsmJob msm_enqueue(Ctx &C, MsmWs &W, const std::vector<MsmProb> &probs, size_t n
         ROFL_LAUNCH(k_msm_scan, dim3((unsigned)PW), dim3(P.B >= 1024 ? 1024 : 256), 0, st, P.B, cnt, off, (u32 *)nullptr, perm);
         if (C.tm.enabled) { e0 = C.tm.get(); e1 = C.tm.get(); HIPCHK(hipEventRecord(e0, st)); }
         {
-            KSpan ks_acc(C.tm, st, ROFL_TK_MSM_ACCUMULATE_FB, terms * P.W * 7, terms * 32);
+            HeavyScope heavy(C, st); hipStream_t hst = heavy.run;      // (the debug timeline variant below stays on st)
+            KSpan ks_acc(C.tm, hst, ROFL_TK_MSM_ACCUMULATE_FB, terms * P.W * 7, terms * 32);
             static const char *timeline = knob("ROFL_DBG_ACC_TIMELINE");      // debugging: per-wave start / end / placement of every launch, appended to this file
             if (timeline) {
                 dim3 g = grid1((size_t)Wb * P.B, (u32)nq);
@@ -246,7 +247,7 @@ MsmJob msm_enqueue(Ctx &C, MsmWs &W, const std::vector<MsmProb> &probs, size_t n
                 if (FILE *f = fopen(timeline, "ab")) { unsigned long long hdr[4] = {0x54494d45ull, waves, g.x, g.y}; fwrite(hdr, 8, 4, f); fwrite(h.data(), 8, h.size(), f); fclose(f); }
                 HIPCHK(hipFree(rec));
             } else
-            ROFL_LAUNCH(k_msm_accumulate_fb, grid1((size_t)Wb * P.B, (u32)nq), dim3(TPB), 0, st, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, bins, perm, buckets, MSM_LIST_ABS, dbg_mask, acc_balance);
+            ROFL_LAUNCH(k_msm_accumulate_fb, grid1((size_t)Wb * P.B, (u32)nq), dim3(TPB), 0, hst, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, bins, perm, buckets, MSM_LIST_ABS, dbg_mask, acc_balance);
         }
         if (C.tm.enabled) HIPCHK(hipEventRecord(e1, st));
     } else if (J.kind != MsmKind::CountSort) {      // slot sort (fixed-base or generic)
@@ -272,9 +273,11 @@ MsmJob msm_enqueue(Ctx &C, MsmWs &W, const std::vector<MsmProb> &probs, size_t n
         if (C.tm.enabled) { e0 = C.tm.get(); e1 = C.tm.get(); HIPCHK(hipEventRecord(e0, st)); }
         {
             uint64_t acc_adds = terms * P.W;
-            KSpan ks_acc(C.tm, st, fb ? ROFL_TK_MSM_ACCUMULATE_FB : ROFL_TK_MSM_ACCUMULATE_GEN, acc_adds * 7, terms * 32);
-            if (fb) ROFL_LAUNCH(k_msm_accumulate_fb, grid1((size_t)Wb * P.B, (u32)nq), dim3(TPB), 0, st, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, slots, perm, buckets, cap, dbg_mask, acc_balance);
-            else ROFL_LAUNCH(k_msm_accumulate_gen, grid1((size_t)Wb * P.B, (u32)nq), dim3(TPB), 0, st, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, slots, perm, buckets, cap, dbg_mask, acc_balance);
+            const bool big = acc_adds >= ((uint64_t)1 << 22);      // (a launch of a few hundred microseconds is not worth two events)
+            HeavyScope heavy(C, st, big); hipStream_t hst = heavy.run;
+            KSpan ks_acc(C.tm, hst, fb ? ROFL_TK_MSM_ACCUMULATE_FB : ROFL_TK_MSM_ACCUMULATE_GEN, acc_adds * 7, terms * 32);
+            if (fb) ROFL_LAUNCH(k_msm_accumulate_fb, grid1((size_t)Wb * P.B, (u32)nq), dim3(TPB), 0, hst, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, slots, perm, buckets, cap, dbg_mask, acc_balance);
+            else ROFL_LAUNCH(k_msm_accumulate_gen, grid1((size_t)Wb * P.B, (u32)nq), dim3(TPB), 0, hst, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, slots, perm, buckets, cap, dbg_mask, acc_balance);
         }
         if (C.tm.enabled) HIPCHK(hipEventRecord(e1, st));
         ROFL_LAUNCH(k_msm_overflow, dim3(1), dim3(64), 0, st, Wb, P.B, (u32)(np / nq), d_probs, ovf_count, ovf, MSM_OVF_MAX, buckets, fb ? 1 : 0);

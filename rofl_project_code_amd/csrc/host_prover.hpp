@@ -424,7 +424,8 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
                 // algorithmic work per output: the non-zero digits of its problem (mixed additions) and ONE chain of top+1 doublings
                 // (the K-1 redundant chains of a segmented launch buy latency, they are not work)
                 uint64_t fold_muls = (nz * 7 / (2 * P) + (uint64_t)(top + 1) * 8 + 7) * (uint64_t)(2 * P * n_new);
-                KSpan ks_fold(C.tm, C.stream, use_tab ? ROFL_TK_FOLD_TAB : ROFL_TK_FOLD, fold_muls, (uint64_t)2 * P * n_g * 32 + (uint64_t)2 * P * n_new * 32);
+                HeavyScope heavy(C, C.stream, 2 * P * n_new >= ((size_t)1 << 15)); hipStream_t fst = heavy.run;      // big folds at the lowest priority while calls share the device (host_rt.hpp)
+                KSpan ks_fold(C.tm, fst, use_tab ? ROFL_TK_FOLD_TAB : ROFL_TK_FOLD, fold_muls, (uint64_t)2 * P * n_g * 32 + (uint64_t)2 * P * n_new * 32);
                 // A big first fold leaves its outputs in extended coordinates and k_niels_batch converts them, eight per inversion, on the side
                 // stream while the next round's k_ipp_round and sort kernels run; that round's first point-reading kernel waits (pts_ready).
                 static const bool defer_on = !(knob("ROFL_FOLD_DEFER") && atoi(knob("ROFL_FOLD_DEFER")) == 0);
@@ -461,15 +462,16 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
                         memcpy(h_ev + off, e.data(), e.size() * sizeof(u32)); off += e.size();
                     }
                     u32 *d_ev = C.fold_ev.as<u32>(tot_ev + 4 + (2 * P * sizeof(FoldWProb) + 3) / 4);
-                    HIPCHK(hipMemcpyAsync(d_ev, h_ev, wp_off * sizeof(u32) + 2 * P * sizeof(FoldWProb), hipMemcpyHostToDevice, C.stream));
+                    HIPCHK(hipMemcpyAsync(d_ev, h_ev, wp_off * sizeof(u32) + 2 * P * sizeof(FoldWProb), hipMemcpyHostToDevice, fst));
                     // slice s of the table = tbl + s * stride; slice 0 = the generators themselves (the kernel reads table slices as tab + (s - 1) * stride)
-                    ROFL_LAUNCH(k_fold_gens_w, grid, block, (K - 1) * 64 * sizeof(ge), C.stream, (u32)n_new, seg, reinterpret_cast<const FoldWProb *>(d_ev + wp_off),
+                    ROFL_LAUNCH(k_fold_gens_w, grid, block, (K - 1) * 64 * sizeof(ge), fst, (u32)n_new, seg, reinterpret_cast<const FoldWProb *>(d_ev + wp_off),
                                        (const u32 *)d_ev, (const niels *)(tbl + (size_t)(2 * N)), (size_t)(2 * N), ext);
                 } else if (use_tab) {
-                    ROFL_LAUNCH(k_fold_gens_tab, grid, block, (K - 1) * 64 * sizeof(ge), C.stream, (u32)n_new, nsrc, seg, fc, tbl, (size_t)(2 * N),
+                    ROFL_LAUNCH(k_fold_gens_tab, grid, block, (K - 1) * 64 * sizeof(ge), fst, (u32)n_new, nsrc, seg, fc, tbl, (size_t)(2 * N),
                                        (const FoldTabProb *)d_fpv, reinterpret_cast<const int16_t *>(d_dig), unit, ext);
                 }
                 if (use_tab) {
+                  heavy.end();      // (C.stream continues behind the fold)
                   if (defer) {
                     if (!C.ev_norm) { HIPCHK(hipEventCreateWithFlags(&C.ev_norm, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&C.ev_norm0, hipEventDisableTiming)); }
                     HIPCHK(hipEventRecord(C.ev_norm0, C.stream));
@@ -500,15 +502,15 @@ void prove_chunks(Ctx &C, const char *label, size_t P, size_t n, size_t m, const
                     }
                     u32 *d_ev = C.fold_ev.as<u32>(tot_ev + 4 + (2 * P * sizeof(FoldWProb) + 3) / 4);
                     const size_t wp_off = (tot_ev + 2) & ~(size_t)1;
-                    HIPCHK(hipMemcpyAsync(d_ev, h_ev, (wp_off) * sizeof(u32) + 2 * P * sizeof(FoldWProb), hipMemcpyHostToDevice, C.stream));
-                    HIPCHK(hipStreamWaitEvent(C.stream, C.ev_mult, 0));      // the table was built beside the last rounds
-                    ROFL_LAUNCH(k_fold_gens_w, grid, block, (K - 1) * 64 * sizeof(ge), C.stream, (u32)n_new, seg, reinterpret_cast<const FoldWProb *>(d_ev + wp_off),
+                    HIPCHK(hipMemcpyAsync(d_ev, h_ev, (wp_off) * sizeof(u32) + 2 * P * sizeof(FoldWProb), hipMemcpyHostToDevice, fst));
+                    HIPCHK(hipStreamWaitEvent(fst, C.ev_mult, 0));      // the table was built beside the last rounds
+                    ROFL_LAUNCH(k_fold_gens_w, grid, block, (K - 1) * 64 * sizeof(ge), fst, (u32)n_new, seg, reinterpret_cast<const FoldWProb *>(d_ev + wp_off),
                                        (const u32 *)d_ev, (const niels *)C.fmul_tab.p, mult_count, (ge *)nullptr);
                 }
                 else if (nsrc == 4 && unit && fold_regs)      // three scalar-carrying sources, kept in registers
-                    ROFL_LAUNCH(k_fold_gens4, grid, block, (K - 1) * 64 * sizeof(ge), C.stream, (u32)n_new, seg, (const FoldProb *)d_fpv, d_dig);
+                    ROFL_LAUNCH(k_fold_gens4, grid, block, (K - 1) * 64 * sizeof(ge), fst, (u32)n_new, seg, (const FoldProb *)d_fpv, d_dig);
                 else
-                    ROFL_LAUNCH(k_fold_gens, grid, block, (K - 1) * 64 * sizeof(ge), C.stream, (u32)n_new, nsrc, seg, (const FoldProb *)d_fpv, d_dig, unit);
+                    ROFL_LAUNCH(k_fold_gens, grid, block, (K - 1) * 64 * sizeof(ge), fst, (u32)n_new, nsrc, seg, (const FoldProb *)d_fpv, d_dig, unit);
             }
             if (C.tm.enabled) { HIPCHK(hipEventRecord(e1, C.stream)); C.tm.fold_ev.push_back({e0, e1}); C.tm.t.fold_launches++; { char tg[96]; snprintf(tg, sizeof tg, "fold n_g=%zu nsrc=%u tab=%d", n_g, nsrc, (int)use_tab); C.tm.fold_tag.push_back(tg); } C.tm.t.fold_point_reads += (uint64_t)2 * P * n_g; }
             HIPCHK(hipMemcpyAsync(d_cp, h_cp, sizeof(ChunkParams) * P, hipMemcpyHostToDevice, C.stream));   // gscale / hscale

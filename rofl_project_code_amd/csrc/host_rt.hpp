@@ -545,6 +545,8 @@ struct Ctx {
     hipStream_t stream = nullptr, stream2 = nullptr;      // stream2: side stream for work that may run beside the main one (created on first use)
     hipStream_t stream3 = nullptr;                        // the odd-multiple tables of the later folds are built here, beside the rounds that precede the fold
     hipStream_t stream_up = nullptr;                      // uploads of a pipelined batch call: the copy of group g + 1 runs beside the kernels of group g (created on first use)
+    hipStream_t stream_lo = nullptr;                      // LOWEST priority: the VALU-saturating launches (bucket accumulation, generator folds) of calls that share the device (HeavyScope)
+    std::vector<hipEvent_t> heavy_ev; size_t heavy_k = 0;  // ring of fork / join events of the heavy launches
     std::mutex mu;
     HostTables ht;
     niels *d_tabB = nullptr, *d_tabBb = nullptr;
@@ -737,6 +739,38 @@ Ctx &ctx_of(int dev) {
 }
 Ctx &ctx() { return ctx_of(current_device()); }
 // binds the calling thread for the lifetime of the object (the worker threads of a sharded batch call)
+// The launches that fill the chip for milliseconds -- k_msm_accumulate_*, k_fold_gens* -- at the LOWEST stream priority while several calls
+// share the device (batched rounds, calls in flight on other lanes).  Why: at equal priority a foreign lane's sort / reduce / scalar kernels
+// (no field arithmetic, a few hundred blocks) get their workgroups dispatched only as the heavy launch's drain -- profiles/r06_cfg4_timeline_*.txt:
+// k_msm_bin_l2 1.6 ms alone, 23 ms beside another lane's accumulation; k_msm_reduce_level 0.7 -> 11.5 ms -- so every call's dependency chain
+// stalls behind the other calls' heavy launches and the device runs out of heavy work to overlap.  With the heavy launches below everything
+// else the short kernels cut in as blocks retire, the chains advance, and there is always another heavy launch queued.
+// A lone call keeps everything on its one stream (two extra events per launch are latency there).
+struct HeavyScope {
+    Ctx &C; hipStream_t st, run; bool forked = false;
+    static bool enabled() { static const bool on = !(knob("ROFL_HEAVY_LO") && atoi(knob("ROFL_HEAVY_LO")) == 0); return on; }
+    HeavyScope(Ctx &c, hipStream_t s, bool want = true) : C(c), st(s), run(s) {      // want = false: a launch too short to be worth two events
+        if (!want || !enabled() || !(C.batch_mode || C.crowded())) return;
+        if (!C.stream_lo) {
+            int least = 0, greatest = 0;
+            if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); return; }
+            if (hipStreamCreateWithPriority(&C.stream_lo, hipStreamNonBlocking, least) != hipSuccess) { (void)hipGetLastError(); C.stream_lo = nullptr; return; }
+        }
+        while (C.heavy_ev.size() < 16) { hipEvent_t e; HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); C.heavy_ev.push_back(e); }
+        hipEvent_t e0 = C.heavy_ev[(C.heavy_k++) & 15];
+        HIPCHK(hipEventRecord(e0, st)); HIPCHK(hipStreamWaitEvent(C.stream_lo, e0, 0));
+        run = C.stream_lo; forked = true;
+    }
+    void end() {
+        if (!forked) return;
+        forked = false;
+        hipEvent_t e1 = C.heavy_ev[(C.heavy_k++) & 15];
+        HIPCHK(hipEventRecord(e1, run)); HIPCHK(hipStreamWaitEvent(st, e1, 0));
+    }
+    ~HeavyScope() { if (forked) { hipEvent_t e1 = C.heavy_ev[(C.heavy_k++) & 15]; (void)hipEventRecord(e1, run); (void)hipStreamWaitEvent(st, e1, 0); } }
+    HeavyScope(const HeavyScope &) = delete; HeavyScope &operator=(const HeavyScope &) = delete;
+};
+
 struct DeviceBinding { int saved; explicit DeviceBinding(int dev) : saved(t_device) { t_device = dev; } ~DeviceBinding() { t_device = saved; } };
 
 // A lane held for the duration of one API call.

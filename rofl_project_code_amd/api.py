@@ -129,7 +129,9 @@ def _dev_arg(x, elem_bytes, row=1):
 
 
 def set_device(dev):
-    """rofl_set_device: bind the CALLING THREAD to logical device `dev` (and make it the default of threads without a binding)."""
+    """rofl_set_device: bind the CALLING THREAD to logical device `dev` and bring that device up.  Only the FIRST successful call of the
+    process also makes `dev` the default of threads that never bind (set_option("default_device", d) moves it later); the containers of
+    params.py run their legs on pool threads bound to the device of the thread that called them."""
     _check(lib().rofl_set_device(int(dev)))
 
 

@@ -21,6 +21,7 @@ static const Knob KNOBS[] = {
     {"ROFL_SIGMA_BATCH", "1", "option sigma_batch: 0 = one check per element in the Sigma-proof verifiers"},
     {"ROFL_STAGE_COHERENT", "0", "1 = the staging arenas are coherent (hipHostMallocDefault) pinned memory as in rounds 3-4 instead of non-coherent (the DMA engine reads 32 instead of 57 GB/s out of it)"},
     {"ROFL_STAGE_KEEP_MB", "256", "pinned staging memory a lane keeps between calls (a call that needed more frees it when it ends)"},
+    {"ROFL_HEAVY_LO", "1", "0 = the chip-filling launches (bucket accumulation, generator folds) stay on the call's own stream also while several calls share the device (default: they go to a lowest-priority stream of the lane then, so that the other calls' short kernels are dispatched between their blocks)"},
     {"ROFL_GENS_LAZY", "1", "0 = the first call of a shape waits for its full fold table (otherwise it is served from the compact table while a background thread builds the full one)"},
     {"ROFL_GENS_LAZY_IDLE_MS", "20", "the background build of a full fold table starts when no call has been in flight for this long (its allocation stalls every HIP call of the process)"},
     {"ROFL_GENS_LAZY_MAX_WAIT_MS", "3000", "... or after this long, whichever comes first (a host that never pauses still gets its full table)"},

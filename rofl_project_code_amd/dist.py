@@ -215,7 +215,11 @@ def make_comm(rank, world, device, control_group=None, prefer_lib=True, torch_ba
     if prefer_lib:      # every rank must be able to load librccl before anyone enters ncclCommInitRank (a rank that never arrives would hang the rest)
         try:
             from . import api
-            api.comm.info(); can = 1      # loads librccl (ROFL_RCCL_LIB); raises when it cannot be loaded
+            info = api.comm.info()      # loads librccl (ROFL_RCCL_LIB); raises when it cannot be loaded
+            if info["world"] != 0:
+                raise RuntimeError("this process already holds a communicator")
+            api.set_device(api.get_device())      # the device context rofl_comm_init binds to comes up HERE (a rank whose GPU cannot be initialised must say so before anybody enters ncclCommInitRank)
+            can = 1
         except Exception as e:      # noqa: BLE001
             can = 0
             if log: log("librccl not usable on rank %d: %r" % (rank, e))
@@ -234,10 +238,21 @@ def make_comm(rank, world, device, control_group=None, prefer_lib=True, torch_ba
         if int(flag.item()) == 1:
             dist.broadcast(uid, src=0, group=control_group)
             c = None
+            # ncclCommInitRank is collective and has no timeout of its own: a rank that dies between the agreement above and its own call would
+            # leave the others inside it forever.  A watchdog ends this process (non-zero) when the call has not returned in time; the launcher
+            # then stops the remaining ranks (bench.py launch_ranks, torchrun).
+            import os, threading
+            limit = float(os.environ.get("ROFL_COMM_INIT_TIMEOUT_S", "180"))
+            def _give_up():
+                if log: log("rofl_comm_init did not return within %.0f s on rank %d: leaving" % (limit, rank))
+                os._exit(17)
+            dog = threading.Timer(limit, _give_up); dog.daemon = True; dog.start()
             try:
                 c = LibComm(uid.numpy().tobytes(), rank, world)
             except Exception as e:      # noqa: BLE001
                 if log: log("rofl_comm_init failed on rank %d: %r" % (rank, e))
+            finally:
+                dog.cancel()
             good = torch.tensor([1 if c else 0], dtype=torch.int32); dist.all_reduce(good, op=dist.ReduceOp.MIN, group=control_group)
             if int(good.item()) == 1:
                 return c

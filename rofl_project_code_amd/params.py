@@ -117,8 +117,30 @@ def _concurrently(*thunks):
     if _pool is None:
         from concurrent.futures import ThreadPoolExecutor
         _pool = ThreadPoolExecutor(max_workers=32, thread_name_prefix="rofl-params")      # three proofs per container, several containers in flight (threads start on demand)
-    futs = [_pool.submit(t) for t in thunks]
+    # The device is a property of the calling THREAD (rofl_set_device): the pool's workers run every leg of a container on the device of the
+    # thread that asked for it, not on the process default (which only the first rofl_set_device of the process moves).
+    dev = api.get_device()
+
+    def bound(t):
+        def run():
+            api.bind_device(dev)
+            return t()
+        return run
+    futs = [_pool.submit(bound(t)) for t in thunks]
     return [f.result() for f in futs]
+
+
+# What a container's verify() may turn into "does not verify": errors that a crafted MESSAGE can provoke (FormatError, a bit size or an
+# aggregation no proof can have, lengths that do not match).  Everything else -- HIP / RCCL runtime errors (>= 99), a bad parameter of the
+# call itself, a batch that has to be split, a missing /dev/urandom -- is a fault of the SERVER and is raised: rejecting a round of honest
+# clients (server.rs:474-484) because the verifier broke would look the same as a round of cheaters.
+# Code 11 (bad parameter; the reference panics) is both: range_bits = 0 or more proofs than commitments come off the wire, "batch too large
+# (split it)" does not.  A single update's verify() counts it as the message's fault; verify_batch falls back to per-client verification.
+_MESSAGE_ERRORS = (1, 3, 4, 5, 6, 11)
+
+
+def _is_message_error(e):
+    return isinstance(e, (ValueError, OverflowError, IndexError)) or (isinstance(e, RoflError) and e.code in _MESSAGE_ERRORS)
 
 
 try:
@@ -202,17 +224,19 @@ class EncParamsRange:
             ok, ok_range = _concurrently(
                 lambda: rand_proof_vec.verify_randproof_vec(self.rand_proofs, self.enc_values),
                 lambda: range_proof_vec.verify_rangeproof(self.range_proofs, self.enc_values[:k, :32], self.prove_range, verifier_seed=_sub_seed(verifier_seed, b"v"), fp=fp))
-        except (RoflError, ValueError, OverflowError, IndexError):
+        except (RoflError, ValueError, OverflowError, IndexError) as e:
+            if not _is_message_error(e):
+                raise      # a fault of the verifier, not a verdict (see _MESSAGE_ERRORS)
             return False
         return bool(ok and ok_range)
 
-    def serialize(self):
+    def serialize(self, as_array=False):
         return wire.encode(self.kind, enc_values=self.enc_values, rand_proof=self.rand_proofs, range_proofs=self.range_proofs,
-                           range_bits=self.prove_range, check_percentage=self.check_percentage)
+                           range_bits=self.prove_range, check_percentage=self.check_percentage, as_array=as_array)
 
     @classmethod
-    def deserialize(cls, data):
-        m = wire.decode(cls.kind, data)
+    def deserialize(cls, data, copy=True):
+        m = wire.decode(cls.kind, data, copy=copy)
         if m["enc_values"].size % 64 or m["rand_proof"].size % 128:
             raise RoflError(5, "FormatError")
         return cls(m["enc_values"], m["rand_proof"], m["range_proofs"], m["range_bits"], m["check_percentage"])
@@ -259,17 +283,19 @@ class EncParamsRangeCompressed(EncParamsRange):
             ok, ok_range = _concurrently(
                 lambda: compressed_rand_proof.helper_verify(self.rand_proof, self.enc_values),
                 lambda: range_proof_vec.verify_rangeproof(self.range_proofs, self.enc_values[:k, :32], self.prove_range, verifier_seed=_sub_seed(verifier_seed, b"v"), fp=fp))
-        except (RoflError, ValueError, OverflowError, IndexError):
+        except (RoflError, ValueError, OverflowError, IndexError) as e:
+            if not _is_message_error(e):
+                raise      # a fault of the verifier, not a verdict (see _MESSAGE_ERRORS)
             return False
         return bool(ok and ok_range)
 
-    def serialize(self):
+    def serialize(self, as_array=False):
         return wire.encode(self.kind, enc_values=self.enc_values, rand_proof=self.rand_proof, range_proofs=self.range_proofs,
-                           range_bits=self.prove_range, check_percentage=self.check_percentage)
+                           range_bits=self.prove_range, check_percentage=self.check_percentage, as_array=as_array)
 
     @classmethod
-    def deserialize(cls, data):
-        m = wire.decode(cls.kind, data)
+    def deserialize(cls, data, copy=True):
+        m = wire.decode(cls.kind, data, copy=copy)
         if m["enc_values"].size % 64 or m["rand_proof"].size != 128:
             raise RoflError(5, "FormatError")
         return cls(m["enc_values"], m["rand_proof"], m["range_proofs"], m["range_bits"], m["check_percentage"])
@@ -355,7 +381,9 @@ class EncParamsL2:
                 lambda: square_rand_proof_vec.verify_l2rangeproof_vec(self.square_proofs, self.enc_values),
                 lambda: range_proof_vec.verify_rangeproof(self.range_proofs, self.enc_values[:, :32], self.prove_range, verifier_seed=_sub_seed(verifier_seed, b"v"), fp=fp),
                 lambda: l2_range_proof_vec.verify_rangeproof_l2(self.square_range_proof, self._sum_c_sq(), self.l2_prove_range, verifier_seed=_sub_seed(verifier_seed, b"s"), fp=fp))
-        except (RoflError, ValueError, OverflowError, IndexError):
+        except (RoflError, ValueError, OverflowError, IndexError) as e:
+            if not _is_message_error(e):
+                raise      # a fault of the verifier, not a verdict (see _MESSAGE_ERRORS)
             return False
         return bool(ok and ok_range and ok_sum)
 
@@ -402,7 +430,13 @@ class EncParamsL2:
             (ok_sq, ok_sum), ok_range = _concurrently(
                 sigma_then_sum,
                 lambda: range_proof_vec.verify_rangeproof_batch([u.range_proofs for u in us], [u.enc_values for u in us], major[4], verifier_seed=_sub_seed(verifier_seed, b"v"), fp=fp, commit_stride=96))
-        except (RoflError, ValueError, OverflowError, IndexError):
+        except (RoflError, ValueError, OverflowError, IndexError) as e:
+            if not _is_message_error(e):
+                raise      # the verifier itself failed (HIP / RCCL runtime error): not a verdict about any client
+            if isinstance(e, RoflError) and e.code == 11:      # a parameter of the batched call (a batch that has to be split, or a field of the majority shape): client by client
+                for i in idx:
+                    res[i] = bool(updates[i].verify(verifier_seed=verifier_seed, fp=fp))
+                return [bool(r) for r in res]
             # (a call-level error -- a proof length no proof can have, a bit size outside 8 / 16 / 32 / 64: every member of this shape is malformed the same way)
             return [bool(r) for r in res]
         for k, i in enumerate(idx):
@@ -468,18 +502,20 @@ class EncParamsL2Compressed(EncParamsL2):
                 lambda: square_proof_vec.verify_l2rangeproof_vec(self.square_proofs, sqc),
                 lambda: range_proof_vec.verify_rangeproof(self.range_proofs, self.enc_values[:, :32], self.prove_range, verifier_seed=_sub_seed(verifier_seed, b"v"), fp=fp),
                 lambda: l2_range_proof_vec.verify_rangeproof_l2(self.square_range_proof, self._sum_c_sq(), self.l2_prove_range, verifier_seed=_sub_seed(verifier_seed, b"s"), fp=fp))
-        except (RoflError, ValueError, OverflowError, IndexError):
+        except (RoflError, ValueError, OverflowError, IndexError) as e:
+            if not _is_message_error(e):
+                raise      # a fault of the verifier, not a verdict (see _MESSAGE_ERRORS)
             return False
         return bool(ok and ok_range and ok_sum)
 
-    def serialize(self):
+    def serialize(self, as_array=False):
         return wire.encode(self.kind, enc_values=self.enc_values, square_proof=self.square_proofs, rand_proof=self.rand_proof,
                            range_proofs=self.range_proofs, square_range_proof=self.square_range_proof, range_bits=self.prove_range,
-                           l2_range_bits=self.l2_prove_range)
+                           l2_range_bits=self.l2_prove_range, as_array=as_array)
 
     @classmethod
-    def deserialize(cls, data):
-        m = wire.decode(cls.kind, data)
+    def deserialize(cls, data, copy=True):
+        m = wire.decode(cls.kind, data, copy=copy)
         if m["enc_values"].size % 96 or m["square_proof"].size % 160 or m["rand_proof"].size != 128:
             raise RoflError(5, "FormatError")
         return cls(m["enc_values"], m["square_proof"], m["rand_proof"], m["range_proofs"], m["square_range_proof"], m["range_bits"], m["l2_range_bits"])

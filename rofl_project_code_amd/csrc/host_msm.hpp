@@ -227,6 +227,24 @@ MsmJob msm_enqueue(Ctx &C, MsmWs &W, const std::vector<MsmProb> &probs, size_t n
         u32 iter_pts = (tl.stage >= 144 ? 16384u : 12288u) / mm.fb_wps; if (iter_pts < 1024) iter_pts = 1024;      // ~ 64 (48) new items per bin and iteration against a row of 144 (72)
         u32 tile = iter_pts;
         while (((size_t)((n_side + tile - 1) / tile) * PW > 512 || (n_side + tile - 1) / tile > 48) && tile < n_side) tile *= 2;      // <= 48 tiles per array: their left-overs (< 32 each) fit the bin tails with room for row spills
+        {   // A block holds a CU (its staging rows are ~148 KB of LDS), so the launch runs in ceil(blocks / 256) passes of one tile each.  With many bucket
+            // arrays (a batch of clients: PW = 96) the doubling above lands on e.g. 3 tiles x 96 arrays = 288 blocks -- a full pass and a second one for 32
+            // blocks: 5.1 ms where 2.6 were due (profiles/r06_cfg4_timeline_inflight1.txt).  Look for a tile (any multiple of an iteration) whose passes
+            // x tile length is shorter; the power-of-two choice stays unless another is clearly better (a lone client's 512 blocks are two exact passes).
+            static const bool tile_search = !(knob("ROFL_MSM_BIN_TILE_SEARCH") && atoi(knob("ROFL_MSM_BIN_TILE_SEARCH")) == 0);
+            const size_t kCU = 256;
+            auto cost = [&](u32 t) { const size_t tiles = (n_side + t - 1) / t; return (double)((tiles * PW + kCU - 1) / kCU) * ((double)std::min<u32>(t, n_side) + 0.25 * iter_pts); };      // (+ a block's fixed part: counters, the flush of its rows)
+            if (tile_search) {
+                u32 best = tile; double best_cost = cost(tile);
+                for (u32 t = iter_pts; t < n_side + iter_pts; t += iter_pts) {
+                    const size_t tiles = (n_side + t - 1) / t;
+                    if (tiles > 48 || tiles * PW > 4096) continue;
+                    const double c = cost(t);
+                    if (c < best_cost * 0.999) { best = t; best_cost = c; }
+                }
+                if (best_cost < 0.85 * cost(tile)) tile = best;
+            }
+        }
         dim3 grid((n_side + tile - 1) / tile, (u32)PW);
         { KSpan ks(C.tm, st, ROFL_TK_MSM_SCATTER, 0, terms * 32 + terms * P.W * 4);
           ROFL_LAUNCH(k_msm_bin_l1, grid, dim3(1024), (size_t)(tl.nbins + tl.nbins * tl.stage) * 4, st, n_side, tile, iter_pts, mw, mm, d_probs, bcur, bins, btail, tl, d_flag);

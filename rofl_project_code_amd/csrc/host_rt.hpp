@@ -21,7 +21,8 @@ static const Knob KNOBS[] = {
     {"ROFL_SIGMA_BATCH", "1", "option sigma_batch: 0 = one check per element in the Sigma-proof verifiers"},
     {"ROFL_STAGE_COHERENT", "0", "1 = the staging arenas are coherent (hipHostMallocDefault) pinned memory as in rounds 3-4 instead of non-coherent (the DMA engine reads 32 instead of 57 GB/s out of it)"},
     {"ROFL_STAGE_KEEP_MB", "256", "pinned staging memory a lane keeps between calls (a call that needed more frees it when it ends)"},
-    {"ROFL_HEAVY_LO", "1", "0 = the chip-filling launches (bucket accumulation, generator folds) stay on the call's own stream also while several calls share the device (default: they go to a lowest-priority stream of the lane then, so that the other calls' short kernels are dispatched between their blocks)"},
+    {"ROFL_MSM_BIN_TILE_SEARCH", "1", "0 = the coarse-bin pass of the two-level bucket sort keeps its power-of-two tile also when another tile length fills the CUs in fewer, shorter passes (batched rounds)"},
+    {"ROFL_HEAVY_LO", "0", "1 = while several calls share the device, the chip-filling launches (bucket accumulation, generator folds) go to a lowest-priority stream of their lane so that other calls' short kernels are dispatched between their blocks (measured: neutral for rounds of range proofs, slower for rounds of L2 updates -- profiles/r06_experiments.txt item 2; off)"},
     {"ROFL_GENS_LAZY", "1", "0 = the first call of a shape waits for its full fold table (otherwise it is served from the compact table while a background thread builds the full one)"},
     {"ROFL_GENS_LAZY_IDLE_MS", "20", "the background build of a full fold table starts when no call has been in flight for this long (its allocation stalls every HIP call of the process)"},
     {"ROFL_GENS_LAZY_MAX_WAIT_MS", "3000", "... or after this long, whichever comes first (a host that never pauses still gets its full table)"},
@@ -740,16 +741,16 @@ Ctx &ctx_of(int dev) {
 }
 Ctx &ctx() { return ctx_of(current_device()); }
 // binds the calling thread for the lifetime of the object (the worker threads of a sharded batch call)
-// The launches that fill the chip for milliseconds -- k_msm_accumulate_*, k_fold_gens* -- at the LOWEST stream priority while several calls
-// share the device (batched rounds, calls in flight on other lanes).  Why: at equal priority a foreign lane's sort / reduce / scalar kernels
-// (no field arithmetic, a few hundred blocks) get their workgroups dispatched only as the heavy launch's drain -- profiles/r06_cfg4_timeline_*.txt:
-// k_msm_bin_l2 1.6 ms alone, 23 ms beside another lane's accumulation; k_msm_reduce_level 0.7 -> 11.5 ms -- so every call's dependency chain
-// stalls behind the other calls' heavy launches and the device runs out of heavy work to overlap.  With the heavy launches below everything
-// else the short kernels cut in as blocks retire, the chains advance, and there is always another heavy launch queued.
-// A lone call keeps everything on its one stream (two extra events per launch are latency there).
+// EXPERIMENT (ROFL_HEAVY_LO=1; off): the launches that fill the chip for milliseconds -- k_msm_accumulate_*, k_fold_gens* -- at the LOWEST
+// stream priority while several calls share the device (batched rounds, calls in flight on other lanes).  The idea: at equal priority a foreign
+// lane's sort / reduce / scalar kernels (no field arithmetic, a few hundred blocks) get their workgroups dispatched only as the heavy launch
+// drains -- profiles/r06_cfg4_timeline_inflight3.txt: k_msm_bin_l2 1.6 ms alone, 23 ms beside another lane's accumulation; k_msm_reduce_level
+// 0.7 -> 11.5 ms -- so the short kernels should cut in as blocks retire.  Measured (profiles/r06_experiments.txt item 2): a cfg-4 round 1 368 /
+// 1 364 ms against 1 370 / 1 360 (neutral: with three calls in flight the device is saturated either way -- the stretched kernels wait, the
+// chip does not), a cfg-5 round 810 + 153 ms against 540 + 64 (the Sigma-proof legs' Pippenger launches wait behind everything).  Kept as a knob.
 struct HeavyScope {
     Ctx &C; hipStream_t st, run; bool forked = false;
-    static bool enabled() { static const bool on = !(knob("ROFL_HEAVY_LO") && atoi(knob("ROFL_HEAVY_LO")) == 0); return on; }
+    static bool enabled() { static const bool on = knob("ROFL_HEAVY_LO") && atoi(knob("ROFL_HEAVY_LO")) != 0; return on; }
     HeavyScope(Ctx &c, hipStream_t s, bool want = true) : C(c), st(s), run(s) {      // want = false: a launch too short to be worth two events
         if (!want || !enabled() || !(C.batch_mode || C.crowded())) return;
         if (!C.stream_lo) {

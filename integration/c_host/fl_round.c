@@ -24,6 +24,14 @@
  *       (verify_batch = 2, devices = all) and the per-client path (verify_batch = 1, one device)
  *       out-file    : header as above, then 5 x 2 x n_clients verdicts (i32) and, per scenario, the index of the chunk that was touched
  *                     in each client (n_clients x i32, -1 = untouched), then per client proofs and commitments of scenarios 1..3 as verified
+ *   fl_round split <d> <prove_range> <n_partition> <n_devices> <out-file>
+ *       ONE client over several devices ("cfg 2/3 at > 1 GPU -> chunks over ranks"; the reference proves a client's chunks in
+ *       parallel on its rayon pool, range_proof_vec/mod.rs:54-78, 168-181), three ways that must give the same bytes:
+ *       (a) rofl_create_rangeproof on one device; (b) the same call with rofl_set_option("devices", mask): the library deals the chunks;
+ *       (c) what a rank of a one-process-per-GPU host does: rofl_create_rangeproof_chunks per contiguous run, each run on its own thread
+ *       and device, results placed by the caller -- then rofl_verify_rangeproof_chunks per run (clean, and with a byte of the LAST run's
+ *       proof flipped: only that run may fail) and rofl_verify_rangeproof over the assembled set with the devices option.
+ *       out-file    : header as above (n_clients = 1), values, blindings, nonce seed, proofs and commitments of (a); exit code 1 on any difference
  *   fl_round comm <id-file> <rank> <world>
  *       one process per GPU, no Python: rank 0 draws the RCCL unique id (rofl_comm_unique_id) and publishes it in <id-file>, the other ranks
  *       wait for the file; rofl_set_device(rank), rofl_comm_init, then one round's exchange -- each rank proves one small client, the ranks
@@ -287,6 +295,116 @@ static int reject(char **argv) {
 }
 
 /* one process per GPU: the exchange of a round through the library's RCCL communicator */
+/* ---- one client split by chunks ---- */
+typedef struct {
+    const float *values; const uint8_t *blindings; const rofl_nonce_t *nonce;
+    size_t d, prove_range, n_partition, first, count, proof_len, m;
+    uint8_t *proofs, *commits;      /* the CLIENT's arrays: the run writes its own part */
+    int device, rc, ok, ok_bad;
+    const uint8_t *seed;
+} run_t;
+
+static void *run_thread(void *arg) {
+    run_t *r = (run_t *)arg;
+    size_t plen = 0, nc = 0, lo = r->first * r->m, want;
+    if (lo > r->d) lo = r->d;
+    want = (r->first + r->count) * r->m;
+    if (want > r->d) want = r->d;
+    want -= lo;
+    r->rc = rofl_set_device(r->device);
+    if (r->rc) return NULL;
+    r->rc = rofl_create_rangeproof_chunks(r->values, r->d, r->blindings, r->d, r->prove_range, r->n_partition, FP_BITS, FP_FRAC, r->nonce, r->first, r->count,
+                                          r->proofs + r->first * r->proof_len, &plen, r->commits + lo * 32, &nc);
+    if (r->rc) return NULL;
+    if (plen != r->proof_len || nc != want) { r->rc = -3; return NULL; }
+    r->rc = rofl_verify_rangeproof_chunks(r->proofs + r->first * r->proof_len, r->proof_len, rofl_rangeproof_chunks(r->d, r->n_partition), r->first, r->count,
+                                          r->commits + lo * 32, r->d, r->prove_range, FP_BITS, FP_FRAC, r->seed, &r->ok);
+    return NULL;
+}
+
+static int split_mode(char **argv) {
+    size_t d = (size_t)strtoul(argv[2], NULL, 10), prove_range = (size_t)strtoul(argv[3], NULL, 10), n_partition = (size_t)strtoul(argv[4], NULL, 10);
+    size_t n_devices = (size_t)strtoul(argv[5], NULL, 10), n_proofs = rofl_rangeproof_chunks(d, n_partition), proof_len = rofl_rangeproof_size(prove_range, d, n_partition);
+    size_t m = rofl_next_pow2(d) / n_proofs, nruns = n_devices < n_proofs ? n_devices : n_proofs, j, k, plen = 0, np = 0;
+    float *values = (float *)malloc(d * sizeof(float)), lim;
+    uint8_t *blindings = (uint8_t *)malloc(d * 32), *pa = (uint8_t *)calloc(n_proofs, proof_len), *ca = (uint8_t *)calloc(d, 32);
+    uint8_t *pb = (uint8_t *)calloc(n_proofs, proof_len), *cb = (uint8_t *)calloc(d, 32), *pc = (uint8_t *)calloc(n_proofs, proof_len), *cc = (uint8_t *)calloc(d, 32);
+    run_t *runs = (run_t *)calloc(nruns, sizeof *runs);
+    pthread_t *th = (pthread_t *)calloc(nruns, sizeof *th);
+    rofl_nonce_t nonce;
+    uint8_t seed[32];
+    long mask = 0;
+    int rc, ok = 0, bad = 0;
+    FILE *f;
+    round_t H;
+    lcg_state = 0x5eed0000ull + d;
+    lim = (float)((double)((1ull << (prove_range - 1)) - 1) / (double)(1u << FP_FRAC)) * 0.999f;
+    for (j = 0; j < d; j++) values[j] = ((float)(lcg() >> 8) / 8388608.0f - 1.0f) * lim;
+    for (j = 0; j < d * 32; j++) blindings[j] = (uint8_t)(lcg() >> 24);
+    for (j = 0; j < d; j++) blindings[j * 32 + 31] &= 0x0f;
+    memset(&nonce, 0, sizeof nonce);
+    nonce.mode = 1;
+    memset(nonce.seed, 0x42, 32);
+    memset(seed, 0x5a, sizeof seed);
+    /* (a) one device */
+    rc = rofl_set_device(0);
+    if (rc) die("rofl_set_device(0)", rc);
+    rc = rofl_create_rangeproof(values, d, blindings, d, prove_range, n_partition, FP_BITS, FP_FRAC, &nonce, pa, &plen, &np, ca);
+    if (rc) die("rofl_create_rangeproof", rc);
+    if (plen != proof_len || np != n_proofs) { fprintf(stderr, "fl_round: unexpected proof geometry\n"); return 1; }
+    /* (b) the library deals the chunks */
+    for (j = 0; j < n_devices; j++) mask |= 1L << j;
+    rc = rofl_set_option("devices", mask);
+    if (rc) die("rofl_set_option(devices)", rc);
+    rc = rofl_create_rangeproof(values, d, blindings, d, prove_range, n_partition, FP_BITS, FP_FRAC, &nonce, pb, &plen, &np, cb);
+    if (rc) die("rofl_create_rangeproof (devices)", rc);
+    rc = rofl_verify_rangeproof(pb, proof_len, n_proofs, cb, d, prove_range, FP_BITS, FP_FRAC, seed, &ok);
+    if (rc) die("rofl_verify_rangeproof (devices)", rc);
+    pb[(n_proofs - 1) * proof_len + 70] ^= 0x10;
+    rc = rofl_verify_rangeproof(pb, proof_len, n_proofs, cb, d, prove_range, FP_BITS, FP_FRAC, seed, &bad);
+    if (rc) die("rofl_verify_rangeproof (devices, tampered)", rc);
+    pb[(n_proofs - 1) * proof_len + 70] ^= 0x10;
+    rc = rofl_set_option("devices", 0);
+    if (rc) die("rofl_set_option(devices, 0)", rc);
+    if (memcmp(pa, pb, n_proofs * proof_len) || memcmp(ca, cb, d * 32) || !ok || bad) { fprintf(stderr, "fl_round: the devices split differs (ok %d, tampered %d)\n", ok, bad); return 1; }
+    /* (c) the caller deals contiguous runs, one thread and device per run */
+    for (k = 0; k < nruns; k++) {
+        run_t *r = &runs[k];
+        r->values = values; r->blindings = blindings; r->nonce = &nonce; r->d = d; r->prove_range = prove_range; r->n_partition = n_partition;
+        r->first = k * n_proofs / nruns; r->count = (k + 1) * n_proofs / nruns - r->first; r->proof_len = proof_len; r->m = m;
+        r->proofs = pc; r->commits = cc; r->device = (int)k; r->seed = seed;
+        if (pthread_create(&th[k], NULL, run_thread, r)) { perror("pthread_create"); return 1; }
+    }
+    for (k = 0; k < nruns; k++) pthread_join(th[k], NULL);
+    for (k = 0; k < nruns; k++) {
+        if (runs[k].rc) die("a run of chunks", runs[k].rc);
+        if (!runs[k].ok) { fprintf(stderr, "fl_round: run %zu did not verify\n", k); return 1; }
+    }
+    if (memcmp(pa, pc, n_proofs * proof_len) || memcmp(ca, cc, d * 32)) { fprintf(stderr, "fl_round: the runs' bytes differ from the whole call's\n"); return 1; }
+    /* a flipped byte in the last run: that run fails, the first still verifies */
+    pc[(n_proofs - 1) * proof_len + 70] ^= 0x10;
+    for (k = 0; k < nruns; k += (nruns > 1 ? nruns - 1 : 1)) {
+        run_t *r = &runs[k];
+        size_t lo = r->first * m > d ? d : r->first * m;
+        rc = rofl_verify_rangeproof_chunks(pc + r->first * proof_len, proof_len, n_proofs, r->first, r->count, cc + lo * 32, d, prove_range, FP_BITS, FP_FRAC, seed, &r->ok_bad);
+        if (rc) die("rofl_verify_rangeproof_chunks (tampered)", rc);
+    }
+    if (runs[nruns - 1].ok_bad != 0 || (nruns > 1 && runs[0].ok_bad != 1)) { fprintf(stderr, "fl_round: tampered runs: first %d last %d\n", runs[0].ok_bad, runs[nruns - 1].ok_bad); return 1; }
+    f = fopen(argv[6], "wb");
+    if (!f) { perror(argv[6]); return 1; }
+    memset(&H, 0, sizeof H);
+    H.d = d; H.prove_range = prove_range; H.n_partition = n_partition; H.n_clients = 1; H.n_proofs = n_proofs; H.proof_len = proof_len;
+    write_head(f, &H);
+    fwrite(values, sizeof(float), d, f);
+    fwrite(blindings, 32, d, f);
+    fwrite(nonce.seed, 1, 32, f);
+    fwrite(pa, proof_len, n_proofs, f);
+    fwrite(ca, 32, d, f);
+    fclose(f);
+    printf("split ok: d=%zu chunks=%zu runs=%zu\n", d, n_proofs, nruns);
+    return 0;
+}
+
 static int comm_mode(const char *id_file, int rank, int world) {
     enum { D = 600, NB = 32, PART = 4 };
     uint8_t id[128], seed[32], *mine, *all, blind[D * 32];
@@ -372,8 +490,9 @@ int main(int argc, char **argv) {
         return bench((size_t)strtoul(argv[2], NULL, 10), (size_t)strtoul(argv[3], NULL, 10), (size_t)strtoul(argv[4], NULL, 10), (size_t)strtoul(argv[5], NULL, 10));
     if (argc == 8 && strcmp(argv[1], "reject") == 0) return reject(argv);
     if (argc == 5 && strcmp(argv[1], "comm") == 0) return comm_mode(argv[2], atoi(argv[3]), atoi(argv[4]));
+    if (argc == 7 && strcmp(argv[1], "split") == 0) return split_mode(argv);
     if (argc != 8 || strcmp(argv[1], "run") != 0) {
-        fprintf(stderr, "usage: fl_round sizes | fl_round bench <d> <prove_range> <n_partition> <iterations> | fl_round run|reject <d> <prove_range> <n_partition> <n_clients> <n_devices> <out-file> | fl_round comm <id-file> <rank> <world>\n");
+        fprintf(stderr, "usage: fl_round sizes | fl_round bench <d> <prove_range> <n_partition> <iterations> | fl_round run|reject <d> <prove_range> <n_partition> <n_clients> <n_devices> <out-file> | fl_round split <d> <prove_range> <n_partition> <n_devices> <out-file> | fl_round comm <id-file> <rank> <world>\n");
         return 2;
     }
     setup_round(&R, argv);

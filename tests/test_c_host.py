@@ -90,6 +90,46 @@ def test_c_host_round_matches_ctypes_and_oracle(fl_round, tmp_path, shape):
             assert rc == 0 and (opr == pr).all() and (ocm == cm).all(), "client %d: C host and oracle differ" % i
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1000, 32, 8, 2), (200, 8, 4, 4), (25000, 32, 4, 2), (25000, 32, 64, 4)], ids=["d1000-P8-2dev", "d200-P4-4dev", "cfg2-2dev", "cfg2-P64-4dev"])
+def test_c_host_splits_one_client_over_devices(fl_round, tmp_path, shape):
+    """SURVEY 8(e) "cfg 2/3 at > 1 GPU -> chunks over ranks" from a compiled C99 host: rofl_create_rangeproof under the devices option, and
+    rofl_create_rangeproof_chunks / rofl_verify_rangeproof_chunks per run on one thread and device each, both byte for byte the one-device
+    call (checked inside the program); here: those bytes equal the ctypes path's and the oracle accepts them (small shapes: the oracle's own
+    bytes too).  Logical devices share the box's one GPU; small fold tables so that four contexts fit comfortably."""
+    import orc
+    import rofl_project_code_amd as R
+    d, nb, P, ndev = shape
+    out = str(tmp_path / "split.bin")
+    env = dict(os.environ, ROFL_DEVICE_MAP=",".join("0" for _ in range(ndev)), ROFL_FOLD_TAB_MB="2048", ROFL_LANES="2")
+    r = subprocess.run([fl_round, "split", str(d), str(nb), str(P), str(ndev), out], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "split ok:" in r.stdout, r.stdout + r.stderr
+    head, clients, _, _ = _parse_split(out)
+    fp = head[6]
+    vals, bl, seed, pr, cm = clients[0]
+    R.set_device(0)
+    hpr, hcm = R.range_proof_vec.create_rangeproof(vals, bl, nb, P, nonce=R.Nonce.seeded(seed), fp=fp)
+    assert (np.asarray(hpr) == pr).all() and (np.asarray(hcm) == cm).all(), "C host and ctypes path differ"
+    if d <= 1000:
+        rc, opr, ocm = orc.create_rangeproof(vals, bl, nb, P, fp[0], fp[1], seed=seed)
+        assert rc == 0 and (opr == pr).all() and (ocm == cm).all(), "C host and oracle differ"
+    else:
+        assert R.range_proof_vec.verify_rangeproof(pr, cm, nb, verifier_seed=b"\x09" * 32, fp=fp)
+
+
+def _parse_split(path):
+    buf = open(path, "rb").read()
+    d, nb, P, nc, npf, plen, fpb, fpf = struct.unpack_from("<8Q", buf, 0)
+    off = 64
+    vals = np.frombuffer(buf, np.float32, d, off); off += 4 * d
+    bl = np.frombuffer(buf, np.uint8, 32 * d, off).reshape(d, 32); off += 32 * d
+    seed = bytes(buf[off:off + 32]); off += 32
+    pr = np.frombuffer(buf, np.uint8, npf * plen, off).reshape(npf, plen); off += npf * plen
+    cm = np.frombuffer(buf, np.uint8, 32 * d, off).reshape(d, 32); off += 32 * d
+    assert off == len(buf)
+    return (d, nb, P, nc, npf, plen, (fpb, fpf)), [(vals, bl, seed, pr, cm)], None, None
+
+
 def _parse_reject(path):
     buf = open(path, "rb").read()
     d, nb, P, nc, npf, plen, fpb, fpf = struct.unpack_from("<8Q", buf, 0)

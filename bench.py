@@ -778,9 +778,9 @@ def run_rank(args):
                     ktot[name][f] += e[f]
             agg["device_ms"] += t_["total_ms"]; agg["host_ms"] += t_["host_ms"]; agg["msm_terms"] += t_["msm_terms"]
 
-    def step_split(s, record):
+    def step_split(s, record, inputs=None):
         """ONE client for the whole job: this rank's run of chunks -> all-gather -> the next rank's run verified here -> MIN of the verdicts"""
-        vals, bl = clients[s]
+        vals, bl = (inputs or clients)[s]
         nonce = R.Nonce.seeded(bytes([s % 256]) * 32)
         t0 = time.perf_counter()
         pr, cm = rd.split_create(comm, rank, world, n_chunks, m_chunk, D, plen_chunk,
@@ -832,6 +832,22 @@ def run_rank(args):
         per_rank_info = gather_rank_info(comm, host_cores_busy=round(cpu_busy, 2), ms_per_step=round(own_elapsed / args.steps * 1e3, 3), host_cores=avail_cores())
         runtimes = [r_.get("hip_runtime") for r_ in per_rank_info]
 
+    # N > 1, weak-scaling line: the SAME job's strong-scaling figure beside it -- ONE client per step for all ranks, its chunks split over them
+    # (SURVEY 8(e) "cfg 2/3 at > 1 GPU -> chunks over ranks"): what several GPUs do for one client's latency.  Every rank takes part; never `value`.
+    split_extra = None
+    if args.exchange and world > 1 and not split and not args.no_extras:
+        KS = max(2, min(args.steps, 6))
+        same = [synth_client(1000 * s + 7) for s in range(KS + 1)]      # the same seeded client on every rank
+        step_split(0, False, same)
+        sync()
+        ts0 = time.perf_counter()
+        for s_ in range(1, KS + 1):
+            step_split(s_, False, same)
+        sync()
+        el_s = float(comm.reduce([time.perf_counter() - ts0], "max")[0])
+        split_extra = {"ms_per_client": el_s / KS * 1e3, "elements_per_s": KS * D / el_s, "steps": KS, "scaling": "strong", "runs": rd.chunk_runs(n_chunks, world),
+                       "note": "NOT `value`: ONE client per step for the whole job -- rank r proves the r-th contiguous run of its %d chunks (rofl_create_rangeproof_chunks), one all-gather of [proofs | commitments], rank r verifies the run of rank r + 1, MIN of the verdicts; compare with ms_per_step of the N = 1 line (useful up to n_partition ranks)" % n_chunks}
+
     if rank != 0:
         comm.barrier(); comm.close(); dist.destroy_process_group()
         return
@@ -866,6 +882,7 @@ def run_rank(args):
         "higher_is_better": True, "scaling": "strong" if split else "weak", "vs_baseline": None, "dtype": "u32x8 (255-bit integer field)", "data": "synthetic",
         "split_chunks": ({"runs": rd.chunk_runs(n_chunks, world), "n_chunks": n_chunks, "values_per_chunk": m_chunk,
                           "note": "ONE client per step for the whole job: rank r proves the r-th contiguous run of the client's chunks (rofl_create_rangeproof_chunks), one all-gather of [proofs | commitments] assembles the client's proof set on every rank, rank r verifies the run of rank r + 1 (rofl_verify_rangeproof_chunks), MIN over the verdicts; ranks beyond the chunk count only join the collectives"} if split else None),
+        "one_client_split_over_ranks": split_extra,
         "rccl_world_size": rccl_world, "collective_backend": comm.backend if args.exchange else None, "hip_runtime_per_rank": runtimes, "per_rank": per_rank_info,
         "config": {"workload": ("BASELINE cfg 2: L-inf 32-bit range proof, d=25000 (resnet18_intrinsic_25k), ONE client create+verify per step for the whole job, its chunks split over the ranks (--split-chunks), inputs handed over as host buffers" if split else
                                 "BASELINE cfg 2: L-inf 32-bit range proof, d=25000 (resnet18_intrinsic_25k), 1 client create+verify per step per GPU, inputs handed over as host buffers (H2D inside the timed region)"),

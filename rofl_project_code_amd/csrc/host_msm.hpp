@@ -242,6 +242,8 @@ MsmJob msm_enqueue(Ctx &C, MsmWs &W, const std::vector<MsmProb> &probs, size_t n
                     const double c = cost(t);
                     if (c < best_cost * 0.999) { best = t; best_cost = c; }
                 }
+                if (knob("ROFL_TRACE")) fprintf(stderr, "[rofl] bin_l1 tiling: n_side=%u PW=%zu iter=%u: tile %u (%zu blocks, cost %.0f) -> best %u (%zu blocks, cost %.0f)\n", n_side, PW, iter_pts, tile,
+                                                (size_t)((n_side + tile - 1) / tile) * PW, cost(tile), best, (size_t)((n_side + best - 1) / best) * PW, best_cost);
                 if (best_cost < 0.85 * cost(tile)) tile = best;
             }
         }

@@ -2,7 +2,7 @@
 bench_constants.rs:10: one warm-up, 4 timed samples, median), one client at a time through the C ABI.  The first call of a shape
 is reported separately as `cold_*` (it builds the generator tables the reference recomputes on every call,
 range_proof_vec/mod.rs:126,201).  Configs 4 and 5 are 48-client jobs over 8 GPUs: one GPU's share (6 clients) is run here.
-Writes one JSON object per config to stdout / gpurun_out/r05_configs.json."""
+Writes one JSON object per config to stdout / gpurun_out/<TAG>_configs.json (TAG from the environment, default r06)."""
 import json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
@@ -115,7 +115,7 @@ res = [
     l2("cfg5: L2 composite, d=55000, 6 of 48 clients (one GPU's share of 8), P=4", 55000, 4, clients=6),
 ]
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-with open(os.path.join(ROOT, "gpurun_out", "r05_configs.json"), "w") as f:
+with open(os.path.join(ROOT, "gpurun_out", os.environ.get("TAG", "r06") + "_configs.json"), "w") as f:
     json.dump(res, f, indent=1)
 for r in res:
     print(json.dumps(r))

@@ -34,6 +34,19 @@ while time.time()-t0<budget:
         except R.RoflError as e: res=None; gerr=e.code
         orc_rc,orc_ok=orc.verify_rangeproof(bad,cm,nb,fb,ff)
         assert gerr==orc_rc and (res is None or res==orc_ok),(nb,fb,ff,P,d,gerr,orc_rc,res,orc_ok)
+        # the client split into runs of chunks at random cut points: the runs' bytes are the whole call's, run by run, and so are the verdicts
+        npr,m=R.range_proof_vec.chunk_geometry(d,P)
+        if npr>1:
+            cuts=sorted(set([0,npr]+[int(x) for x in rng.integers(1,npr,size=int(rng.integers(1,4)))]))
+            for a,b in zip(cuts[:-1],cuts[1:]):
+                p_,c_=R.range_proof_vec.create_rangeproof_chunks(vals,bl,nb,P,a,b-a,nonce=R.Nonce.seeded(seed))
+                lo,hi=min(d,a*m),min(d,b*m)
+                assert (p_==pr[a:b]).all() and (c_==cm[lo:hi]).all(),("chunks",nb,fb,ff,P,d,a,b)
+                assert R.range_proof_vec.verify_rangeproof_chunks(p_,npr,a,c_,d,nb,verifier_seed=seed) is True
+                try: rb=R.range_proof_vec.verify_rangeproof_chunks(bad[a:b],npr,a,c_,d,nb,verifier_seed=seed)
+                except R.RoflError as e: rb=None; assert e.code==5
+                if rb is not None and (bad[a:b]==pr[a:b]).all(): assert rb is True      # the flipped bit is in another run
+                if rb is not None and not (bad[a:b]==pr[a:b]).all() and orc_rc==0: assert rb is False or orc_ok
     # sigma
     kind=int(rng.integers(0,2)); ds=int(rng.integers(1,200))
     v2=rng.uniform(-4,4,size=ds).astype(np.float32); r1=orc.rand_scalars(rng,ds); r2=orc.rand_scalars(rng,ds)

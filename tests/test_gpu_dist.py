@@ -92,6 +92,17 @@ def test_bench_gpus2_starts_two_ranks():
     assert line["value"] > 0 and "cfg 2" in line["config"]["workload"]
 
 
+def test_bench_two_ranks_report_the_one_client_split():
+    """Every N > 1 line of the headline config carries, beside its weak-scaling value, ONE client split by chunks over the ranks,
+    and `--split-chunks` makes that the timed workload (strong scaling).  Two ranks on GPU 0 over gloo here."""
+    line = _bench_two_ranks("--steps", "2", "--warmup", "1", "--no-cpu-baseline")
+    sp = line["one_client_split_over_ranks"]
+    assert line["scaling"] == "weak" and sp and sp["runs"] == [[0, 2], [2, 2]] and sp["ms_per_client"] > 0 and sp["scaling"] == "strong"
+    line = _bench_two_ranks("--split-chunks", "--steps", "2", "--warmup", "1", "--n-partition", "64")
+    assert line["scaling"] == "strong" and line["n_gpus"] == 2 and line["split_chunks"]["runs"] == [[0, 32], [32, 32]] and line["split_chunks"]["n_chunks"] == 64
+    assert abs(line["value"] - 2 * 25000 / (line["ms_per_step"] * 2e-3)) < 1e-6 * line["value"]      # K * d / time: one client per step for the whole job
+
+
 def _bench_two_ranks(*argv):
     env = dict(os.environ)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):

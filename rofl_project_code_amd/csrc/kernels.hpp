@@ -2361,6 +2361,90 @@ __global__ void __launch_bounds__(64) k_sigma_prove(int kind, u32 d, const float
 }
 #endif
 
+// The same prover with ONE THREAD PER POINT instead of one per element (ROFL_SIGMA_SPLIT, the default): an element's 4-6 output points --
+// R, c_sq, L', R', c_sq' (and L when no commitment is handed in) -- are independent of each other; each costs one or two fixed-base
+// multiplications and one encoding (a 254-step square-root chain), c_sq' a variable-base multiplication on top.  One thread doing all of them
+// is a chain of ~7 300 field multiplications in 256 VGPRs + 60 AGPRs + 1.8 KB of scratch at one wave per SIMD (3.3 ms for a vector of
+// 55 000 alone on the chip); blockIdx.y = the slot, so a block's threads run the same formula, a vector is 4-6x as many threads of a
+// fifth of the length, and the transcript + responses (scalar arithmetic, k_sigma_finish) read the encoded bytes back.  Same formulas,
+// same nonce indices, same bytes.
+enum { SG_L = 0, SG_LCHK = 1, SG_R = 2, SG_CSQ = 3, SG_LP = 4, SG_RP = 5, SG_CSQP = 6 };
+struct SgSlots { int n; int id[6]; };
+// (two kernels: the slots that are fixed-base multiplications + one encoding, and c_sq' with its variable-base multiplication and its 1 KB
+//  table in scratch -- in one kernel every slot would be given the registers and the scratch of the largest)
+template <bool VAR> __device__ __forceinline__ void sigma_point_body(int kind, int slot, u32 d, const float *vals, u32 fp_bits, u32 fp_frac, const sc *r1c, const sc *r2c,
+                                                                    const uint8_t *existing, int mode, const NonceSeed &seed, const uint8_t *stream, u64 stream_scalars,
+                                                                    const niels *tabB, const niels *tabBb, uint8_t *proofs, uint8_t *commits, u32 *status) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d) return;
+    bool has_R = kind != 2, has_sq = kind != 0;
+    u32 npts = 1 + (has_R ? 1 : 0) + (has_sq ? 1 : 0), nn = has_sq ? 3 : 2, clen = 32 * npts, plen = 32 * (npts + nn), sq_off = has_R ? 64 : 32;
+    float v = vals[i];
+    if (v != v) return;                                // (k_sigma_finish reports it)
+    uint8_t *cm = commits + (size_t)clen * i, *pf = proofs + (size_t)plen * i;
+    SgNonceCache ncache; ncache.blk = ~0ULL;
+    auto nonce = [&](u32 j) { return sg_nonce(mode, seed, stream, stream_scalars, (u64)nn * i + j, ncache); };      // m', r1' (, r2')
+    if (VAR) {      // SG_CSQP: m' L + r2' Bb
+        gd L;
+        if (existing) { if (!sg_decode(L, existing + (size_t)32 * i)) { atomicOr(status, 4u); return; } }
+        else { sc m = sg_f32_to_sc(v, fp_bits, fp_frac), r1 = load_sc_reduced(&r1c[i]); L = gd_add(sg_fixed_mul(tabB, m), sg_fixed_mul(tabBb, r1)); }
+        sc n0 = nonce(0), n2 = nonce(2);
+        sg_encode(pf + sq_off, gd_add(sg_var_mul(n0, L), sg_fixed_mul(tabBb, n2)));
+        return;
+    }
+    if (slot == SG_LCHK) { gd L; if (!sg_decode(L, existing + (size_t)32 * i)) atomicOr(status, 4u); return; }
+    // every other slot: a B + b Bb (b may be absent), encoded
+    sc a, b; bool two = true; uint8_t *out;
+    if (slot == SG_L) { a = sg_f32_to_sc(v, fp_bits, fp_frac); b = load_sc_reduced(&r1c[i]); out = cm; }
+    else if (slot == SG_R) { a = load_sc_reduced(&r1c[i]); b = sc_zero(); two = false; out = cm + 32; }
+    else if (slot == SG_CSQ) { sc m = sg_f32_to_sc(v, fp_bits, fp_frac); a = sc_mul_plain(m, m); b = load_sc_reduced(&r2c[i]); out = cm + sq_off; }
+    else if (slot == SG_LP) { a = nonce(0); b = nonce(1); out = pf; }
+    else { a = nonce(1); b = sc_zero(); two = false; out = pf + 32; }      // SG_RP
+    gd P = sg_fixed_mul(tabB, a);
+    if (two) P = gd_add(P, sg_fixed_mul(tabBb, b));
+    sg_encode(out, P);
+}
+#if ROFL_KG(2)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) k_sigma_points(int kind, SgSlots slots, u32 d, const float *vals, u32 fp_bits, u32 fp_frac, const sc *r1c, const sc *r2c,
+                                                     const uint8_t *existing, int mode, NonceSeed seed, const uint8_t *stream, u64 stream_scalars,
+                                                     const niels *tabB, const niels *tabBb, uint8_t *proofs, uint8_t *commits, u32 *status) {
+    sigma_point_body<false>(kind, slots.id[blockIdx.y], d, vals, fp_bits, fp_frac, r1c, r2c, existing, mode, seed, stream, stream_scalars, tabB, tabBb, proofs, commits, status);
+}
+#endif
+#if ROFL_KG(3)
+__global__ void __launch_bounds__(64) k_sigma_point_var(int kind, u32 d, const float *vals, u32 fp_bits, u32 fp_frac, const sc *r1c, const sc *r2c,
+                                                        const uint8_t *existing, int mode, NonceSeed seed, const uint8_t *stream, u64 stream_scalars,
+                                                        const niels *tabB, const niels *tabBb, uint8_t *proofs, uint8_t *commits, u32 *status) {
+    sigma_point_body<true>(kind, SG_CSQP, d, vals, fp_bits, fp_frac, r1c, r2c, existing, mode, seed, stream, stream_scalars, tabB, tabBb, proofs, commits, status);
+}
+#endif
+#if ROFL_KG(4)
+__global__ void __launch_bounds__(TPB) k_sigma_finish(int kind, u32 d, const float *vals, u32 fp_bits, u32 fp_frac, const sc *r1c, const sc *r2c,
+                                                      const uint8_t *existing, int mode, NonceSeed seed, const uint8_t *stream, u64 stream_scalars,
+                                                      DMerlin init, uint8_t *proofs, uint8_t *commits, u32 *status) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d) return;
+    bool has_R = kind != 2, has_sq = kind != 0;
+    u32 npts = 1 + (has_R ? 1 : 0) + (has_sq ? 1 : 0), nn = has_sq ? 3 : 2, clen = 32 * npts, plen = 32 * (npts + nn);
+    float v = vals[i];
+    if (v != v) { atomicOr(status, 2u); return; }
+    sc m = sg_f32_to_sc(v, fp_bits, fp_frac);
+    sc r1 = load_sc_reduced(&r1c[i]), r2 = has_sq ? load_sc_reduced(&r2c[i]) : sc_zero();
+    sc nc[3];
+    SgNonceCache ncache; ncache.blk = ~0ULL;
+    for (u32 j = 0; j < nn; j++) nc[j] = sg_nonce(mode, seed, stream, stream_scalars, (u64)nn * i + j, ncache);
+    uint8_t *cm = commits + (size_t)clen * i, *pf = proofs + (size_t)plen * i;
+    if (existing) for (int q = 0; q < 32; q++) cm[q] = existing[(size_t)32 * i + q];
+    DMerlin t = init;
+    sg_transcript(kind, t, cm, pf, has_R);
+    sc c = dm_challenge_scalar(t, "c", 1);
+    uint8_t *z = pf + clen;
+    sc_tobytes(z, sc_add(nc[0], sc_mul_plain(m, c)));
+    sc_tobytes(z + 32, sc_add(nc[1], sc_mul_plain(r1, c)));
+    if (has_sq) sc_tobytes(z + 64, sc_add(nc[2], sc_mul_plain(sc_sub(r2, sc_mul_plain(m, r1)), c)));
+}
+#endif
+
 #if ROFL_KG(3)
 __global__ void __launch_bounds__(64) k_sigma_verify(int kind, u32 d, const uint8_t *proofs, const uint8_t *commits, DMerlin init,
                                                      const niels *tabB, const niels *tabBb, u32 *fail_count, u32 *status) {

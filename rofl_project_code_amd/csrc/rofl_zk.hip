@@ -895,6 +895,26 @@ int sigma_create(int kind, const float *values, size_t d, const uint8_t *r1, siz
     // algorithmic work per element: 7 fixed-base multiplications (64 mixed additions each), one variable-base one (~325 point operations),
     // 2 * npts encodings; bytes as SURVEY 8(d): value + randomness in, commitments + proof out
     { KSpan ks_sigma(C.tm, C.stream, ROFL_TK_SIGMA, (uint64_t)d * (7 * 64 * 7 + 325 * 8 + 2 * npts * 265), (uint64_t)d * (4 + 32 * (has_sq ? 2 : 1) + clen + plen));
+      static const bool split = !(knob("ROFL_SIGMA_SPLIT") && atoi(knob("ROFL_SIGMA_SPLIT")) == 0);
+      if (split) {      // one thread per point (blockIdx.y = slot; c_sq' -- the variable-base one -- as a launch of its own on the side stream), then transcripts + responses per element
+          SgSlots sl{}; auto add = [&](int id) { sl.id[sl.n++] = id; };
+          if (!dex) add(SG_L); else if (!has_sq) add(SG_LCHK);             // (with c_sq' in the list the commitment handed in is decoded -- and checked -- there)
+          if (has_sq) add(SG_CSQ);
+          add(SG_LP);
+          if (kind != 2) { add(SG_R); add(SG_RP); }
+          if (has_sq) {
+              if (!C.stream2) HIPCHK(hipStreamCreateWithFlags(&C.stream2, hipStreamNonBlocking));
+              HIPCHK(hipEventRecord(C.pool_event(0), C.stream)); HIPCHK(hipStreamWaitEvent(C.stream2, C.pool_event(0), 0));      // inputs uploaded
+              ROFL_LAUNCH(k_sigma_point_var, dim3((unsigned)((d + 63) / 64)), dim3(64), 0, C.stream2, kind, (u32)d, dv, fp_bits, fp_frac, dr1, dr2, dex,
+                          nonce->mode, seed, d_stream, ss, C.d_tabB, C.d_tabBb, dp, dc, status);
+              HIPCHK(hipEventRecord(C.pool_event(1), C.stream2));
+          }
+          ROFL_LAUNCH(k_sigma_points, dim3((unsigned)((d + 63) / 64), (unsigned)sl.n), dim3(64), 0, C.stream, kind, sl, (u32)d, dv, fp_bits, fp_frac, dr1, dr2, dex,
+                      nonce->mode, seed, d_stream, ss, C.d_tabB, C.d_tabBb, dp, dc, status);
+          if (has_sq) HIPCHK(hipStreamWaitEvent(C.stream, C.pool_event(1), 0));
+          ROFL_LAUNCH(k_sigma_finish, grid1(d), dim3(TPB), 0, C.stream, kind, (u32)d, dv, fp_bits, fp_frac, dr1, dr2, dex, nonce->mode, seed, d_stream, ss,
+                      sigma_init_state(kind), dp, dc, status);
+      } else
       ROFL_LAUNCH(k_sigma_prove, dim3((unsigned)((d + 63) / 64)), dim3(64), 0, C.stream, kind, (u32)d, dv, fp_bits, fp_frac, dr1, dr2, dex,
                          nonce->mode, seed, d_stream, ss, sigma_init_state(kind), C.d_tabB, C.d_tabBb, dp, dc, status); }
     u32 st = 0;

@@ -1,4 +1,4 @@
-"""The kernel table of DESIGN.md section 5, generated from a bench line (profiles/r05_bench.json by default):
+"""The kernel table of DESIGN.md section 5, generated from a bench line (profiles/r06_bench.json by default):
     python scripts/gen_design_tables.py [bench.json] [--write]     (--write replaces the block between the kernel-table markers)"""
 import json
 import os
@@ -24,15 +24,16 @@ def table(path):
     head = ("`%s` (BASELINE cfg 2, one client per step; HIP events of %s instrumented steps; ceiling %.3g field multiplications/s measured in the same process):\n\n"
             % (os.path.basename(path), k.get("instrumented_steps", "the"), peak))
     tail = ("\n\n`roofline` block of that line: kernel `%s`, algorithmic %.1f MB per launch in %.3f ms = **%.1f GB/s = frac %.4f of 8 TB/s**; PMC traffic %.2f GB per launch "
-            "(`traffic_frac` %.2f; layout minimum %.2f); `valu_roofline.frac` **%.2f**; `end_to_end_frac` %.2f."
+            "(`traffic_frac` %.2f; layout minimum %.2f); scalar + point accounting %.1f MB = frac %.4f; `valu_roofline.frac` **%.2f**, `issue.issue_frac` %s, `end_to_end_frac` %.2f."
             % (r["kernel"], r["algorithmic_bytes_per_launch"] / 1e6, r["avg_launch_ms"], r["achieved"], r["frac"], (r["traffic"] or 0) / 1e9, r["traffic_frac"] or 0,
-               r.get("layout_min_frac") or 0, v["frac"], v["end_to_end_frac"]))
+               r.get("layout_min_frac") or 0, (r.get("algorithmic_bytes_per_launch_scalar_and_point") or 0) / 1e6, r.get("frac_scalar_and_point") or 0, v["frac"],
+               ("%.2f" % v["issue"]["issue_frac"]) if (v.get("issue") or {}).get("issue_frac") else "—", v["end_to_end_frac"]))
     return head + "\n".join(rows) + tail
 
 
 if __name__ == "__main__":
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
-    path = args[0] if args else os.path.join(ROOT, "profiles", "r05_bench.json")
+    path = args[0] if args else os.path.join(ROOT, "profiles", "r06_bench.json")
     t = table(path)
     if "--write" in sys.argv:
         p = os.path.join(ROOT, "DESIGN.md"); d = open(p).read()

@@ -1096,6 +1096,7 @@ def run_one_process(args):
     assert not prep_err, prep_err
     prepare_ms = (time.perf_counter() - t_prep) * 1e3
     R.set_device(0)
+    R.set_option("default_device", 0)      # (the preparation threads raced for the process default: the first rofl_set_device of a process sets it)
     R.set_option("devices", (1 << ndev) - 1); R.set_option("verify_batch", 2)
     phase = {"create": 0.0, "verify": 0.0}
 
@@ -1175,6 +1176,7 @@ def run_one_process_split(args):
     assert not prep_err, prep_err
     prepare_ms = (time.perf_counter() - t_prep) * 1e3
     R.set_device(0)
+    R.set_option("default_device", 0)      # (the preparation threads raced for the process default: the first rofl_set_device of a process sets it)
     R.set_option("devices", (1 << ndev) - 1)
     total = args.warmup + args.steps
     clients = [synth_client(1000 * s) for s in range(total)]

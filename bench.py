@@ -218,7 +218,7 @@ def other_configs(args, R):
     tables and CPU sample), each with the parity flag of its oracle sample."""
     import numpy as np
     res = {"note": "NOT the headline metric: BASELINE.json configs[0], [2], [3], [4] measured beside it so that every config has a driver-visible figure; "
-                   "cfg 4 / cfg 5 = one MI355X doing all 48 clients of a round (create -> exchange -> verify), 2 timed rounds after 1 warm-up"}
+                   "cfg 4 / cfg 5 = one MI355X doing all 48 clients of a round (create -> exchange -> verify), 2 timed rounds after 1 (cfg 5: 2) warm-up round(s)"}
     # ---- cfg 1: L-inf 8-bit, d = 5 000, fp16 / frac7, P = 4 (the reference's own CPU-runnable bench shape)
     try:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -264,7 +264,7 @@ def other_configs_children(hip_runtime):
         cp = None
         try:
             t0 = time.time()
-            cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", str(cfg), "--steps", "2", "--warmup", "1", "--n-partition", str(NPART),
+            cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", str(cfg), "--steps", "2", "--warmup", "1" if cfg == 4 else "2", "--n-partition", str(NPART),      # (cfg 5: twelve lanes' workspaces grow on first use)
                                  "--hip-runtime", hip_runtime], capture_output=True, text=True, timeout=400)
             cj = json.loads(cp.stdout.strip().splitlines()[-1])
             cb = cj.get("cpu_baseline") or {}
@@ -1055,7 +1055,7 @@ def run_rank(args):
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, R)
         if not args.no_other_configs:
             out["baseline_configs"] = other_configs(args, R)
-    out["other_configs"] = "bench.py --config 4 | 5 (48 clients sharded over the ranks); profiles/r04_configs.json (scripts/gpu_configs.py): all five BASELINE configs and the e2e partition count P=64, reference bench protocol"
+    out["other_configs"] = "bench.py --config 4 | 5 (48 clients sharded over the ranks); profiles/r06_configs.json (scripts/gpu_configs.py): all five BASELINE configs and the e2e partition count P=64, reference bench protocol"
     emit(json.dumps(out))
     if args.exchange:
         comm.barrier(); comm.close()

@@ -52,7 +52,48 @@ def main():
     pr2, _ = R.range_proof_vec.create_rangeproof(vals, bl, nb, 4, nonce=R.Nonce.seeded(seed), fp=fp)
     assert (pr2 == case["opr"]).all()
     assert R.range_proof_vec.verify_rangeproof(pr2, cm, nb, verifier_seed=b"\x03" * 32, fp=fp) is True
-    print("role ok: verify-only %.2f GB (P=4 shape, built in %.2f s) + %.2f GB (P=64 shape); after create %.1f GB" % (b4 / 1e9, t_prep, b64 / 1e9, b_full / 1e9))
+    # provers and verifiers meet a FRESH shape at the same time (d = 12 000 at P = 4: m = 4 096): the verifier's entry, the prover's synchronous
+    # fold-table upgrade, a second prover waiting for the swap, readers of the replaced entry -- every result must be the reference answer
+    import threading
+    d2 = 12000
+    v2, bl2 = vals[:d2].copy(), bl[:d2].copy()
+    want_p, want_c = None, None
+    R.set_option("default_device", 0)
+    api.bp_gens_prepare_verify(nb, 4096)      # a verifier's entry exists: both provers meet it at once -- one adds the fold table, the other waits for the swap
+    assert api.bp_gens_table_bytes(nb, 4096) < 1e9
+    res, errs = {}, []
+    go = threading.Barrier(4)
+
+    def prover(k):
+        try:
+            go.wait()
+            for it in range(3):
+                res[("p", k, it)] = R.range_proof_vec.create_rangeproof(v2, bl2, nb, 4, nonce=R.Nonce.seeded(b"\x77" * 32), fp=fp)
+        except BaseException as e:      # noqa: BLE001
+            errs.append(e)
+
+    def verifier(k):
+        try:
+            go.wait()
+            for it in range(6):      # the oracle's cfg-4 proof is of another shape (m = 16 384): keeps the OTHER table busy while (nb, 4096) changes hands
+                assert R.range_proof_vec.verify_rangeproof(case["opr"], case["ocm"], nb, verifier_seed=bytes([k + 1]) * 32, fp=fp) is True
+                if ("p", 0, 0) in res:
+                    pr_, cm_ = res[("p", 0, 0)]
+                    assert R.range_proof_vec.verify_rangeproof(pr_, cm_, nb, verifier_seed=bytes([k + 9]) * 32, fp=fp) is True
+        except BaseException as e:      # noqa: BLE001
+            errs.append(e)
+
+    ths = [threading.Thread(target=prover, args=(0,)), threading.Thread(target=prover, args=(1,)), threading.Thread(target=verifier, args=(0,)), threading.Thread(target=verifier, args=(1,))]
+    for t in ths: t.start()
+    for t in ths: t.join()
+    assert not errs, errs
+    first = res[("p", 0, 0)]
+    for key, (pr_, cm_) in res.items():
+        assert (pr_ == first[0]).all() and (cm_ == first[1]).all(), key
+    import orc
+    assert orc.verify_rangeproof(first[0], first[1], nb, fp[0], fp[1]) == (0, True)
+    assert R.range_proof_vec.verify_rangeproof(first[0], first[1], nb, verifier_seed=b"\x05" * 32, fp=fp) is True
+    print("role ok: verify-only %.2f GB (P=4 shape, built in %.2f s) + %.2f GB (P=64 shape); after create %.1f GB; concurrent provers / verifiers on a fresh shape agree" % (b4 / 1e9, t_prep, b64 / 1e9, b_full / 1e9))
 
 
 if __name__ == "__main__":

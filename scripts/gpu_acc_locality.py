@@ -6,11 +6,11 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import rofl_project_code_amd as R
 R.set_device(0); R.api.set_fp(32, 7)
-rng = np.random.default_rng(3); d = 25000
+rng = np.random.default_rng(3); d = int(os.environ.get("D", "25000"))
 mx = np.float32(16777216.0)
 vals = np.clip(rng.uniform(-mx, mx, d).astype(np.float32), -mx, np.nextafter(mx, np.float32(0)))
 bl = rng.integers(0, 256, size=(d, 32), dtype=np.uint8); bl[:, 31] &= 15
-R.api.bp_gens_prepare(32, 8192)
+R.api.bp_gens_prepare(32, (1 << (d - 1).bit_length()) // 4)
 R.set_timing(1)
 acc = []
 for it in range(6):
@@ -18,4 +18,4 @@ for it in range(6):
     k = R.last_kernel_times()["k_msm_accumulate_fb"]
     if it >= 2: acc.append(k["ms"] / max(k["launches"], 1))
 mask = os.environ.get("ROFL_DBG_IDX_MASK", "none")
-print("idx mask %s (%s MB of table): k_msm_accumulate_fb %.3f ms per launch" % (mask, (int(mask, 0) + 1) * 128 >> 20 if mask != "none" else "1024", sum(acc) / len(acc)))
+print("idx mask %s (%s MB of table): k_msm_accumulate_fb %.3f ms per launch" % (mask, (int(mask, 0) + 1) * 128 >> 20 if mask != "none" else "whole", sum(acc) / len(acc)))

@@ -224,6 +224,12 @@ MsmJob msm_enqueue(Ctx &C, MsmWs &W, const std::vector<MsmProb> &probs, size_t n
         u32 *bcur = W.cur.as<u32>(PW * tl.nbins * 2);
         u32 *btail = W.tail.as<u32>(PW * tl.nbins * (size_t)MSM_BIN_TAIL);
         HIPCHK(hipMemsetAsync(bcur, 0, sizeof(u32) * PW * tl.nbins * 2, st));
+        // window-ordered bucket lists + set-major block order of the accumulation (ROFL_MSM_WINDOW_ORDER; r06_experiments.txt item 14): when the index of
+        // an entry says which window slot it belongs to by a shift (stride and sets powers of two) and there is more than one slot per array
+        static const bool worder_on = !(knob("ROFL_MSM_WINDOW_ORDER") && atoi(knob("ROFL_MSM_WINDOW_ORDER")) == 0);
+        const u64 wdiv = (u64)mm.fb_stride * mm.fb_sets;
+        const bool worder = worder_on && mm.fb_wps > 1 && mm.fb_wps <= 16 && wdiv && (wdiv & (wdiv - 1)) == 0 && wdiv < ((u64)1 << tl.ebits);
+        const u32 worder_wps = worder ? mm.fb_wps : 1u, worder_shift = worder ? (u32)lg2u((size_t)wdiv) : 0u;
         u32 iter_pts = (tl.stage >= 144 ? 16384u : 12288u) / mm.fb_wps; if (iter_pts < 1024) iter_pts = 1024;      // ~ 64 (48) new items per bin and iteration against a row of 144 (72)
         u32 tile = iter_pts;
         while (((size_t)((n_side + tile - 1) / tile) * PW > 512 || (n_side + tile - 1) / tile > 48) && tile < n_side) tile *= 2;      // <= 48 tiles per array: their left-overs (< 32 each) fit the bin tails with room for row spills
@@ -250,7 +256,8 @@ MsmJob msm_enqueue(Ctx &C, MsmWs &W, const std::vector<MsmProb> &probs, size_t n
         dim3 grid((n_side + tile - 1) / tile, (u32)PW);
         { KSpan ks(C.tm, st, ROFL_TK_MSM_SCATTER, 0, terms * 32 + terms * P.W * 4);
           ROFL_LAUNCH(k_msm_bin_l1, grid, dim3(1024), (size_t)(tl.nbins + tl.nbins * tl.stage) * 4, st, n_side, tile, iter_pts, mw, mm, d_probs, bcur, bins, btail, tl, d_flag);
-          ROFL_LAUNCH(k_msm_bin_l2, dim3(tl.nbins, (u32)PW), dim3(512), (size_t)(2 * 128 + tl.cap_bin) * 4, st, tl, P.B, bcur, bins, (const u32 *)btail, cnt, off, d_flag); }
+          ROFL_LAUNCH(k_msm_bin_l2, dim3(tl.nbins, (u32)PW), dim3(512), (size_t)(2 * 128 * worder_wps + tl.cap_bin) * 4, st, tl, P.B, bcur, bins, (const u32 *)btail, cnt, off, d_flag,
+                      worder_wps, worder_shift); }
         ROFL_LAUNCH(k_msm_scan, dim3((unsigned)PW), dim3(P.B >= 1024 ? 1024 : 256), 0, st, P.B, cnt, off, (u32 *)nullptr, perm);
         if (C.tm.enabled) { e0 = C.tm.get(); e1 = C.tm.get(); HIPCHK(hipEventRecord(e0, st)); }
         {
@@ -267,7 +274,8 @@ MsmJob msm_enqueue(Ctx &C, MsmWs &W, const std::vector<MsmProb> &probs, size_t n
                 if (FILE *f = fopen(timeline, "ab")) { unsigned long long hdr[4] = {0x54494d45ull, waves, g.x, g.y}; fwrite(hdr, 8, 4, f); fwrite(h.data(), 8, h.size(), f); fclose(f); }
                 HIPCHK(hipFree(rec));
             } else
-            ROFL_LAUNCH(k_msm_accumulate_fb, grid1((size_t)Wb * P.B, (u32)nq), dim3(TPB), 0, hst, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, bins, perm, buckets, MSM_LIST_ABS, dbg_mask, acc_balance);
+            ROFL_LAUNCH(k_msm_accumulate_fb, grid1((size_t)Wb * P.B, (u32)nq), dim3(TPB), 0, hst, (u32)n, P.c, Wb, (u32)(np / nq), d_probs, cnt, off, bins, perm, buckets, MSM_LIST_ABS, dbg_mask,
+                        acc_balance | ((worder && nq > 1 && Wb > 1) ? 2u : 0u));
         }
         if (C.tm.enabled) HIPCHK(hipEventRecord(e1, st));
     } else if (J.kind != MsmKind::CountSort) {      // slot sort (fixed-base or generic)

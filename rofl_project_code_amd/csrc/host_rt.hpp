@@ -21,6 +21,7 @@ static const Knob KNOBS[] = {
     {"ROFL_SIGMA_BATCH", "1", "option sigma_batch: 0 = one check per element in the Sigma-proof verifiers"},
     {"ROFL_STAGE_COHERENT", "0", "1 = the staging arenas are coherent (hipHostMallocDefault) pinned memory as in rounds 3-4 instead of non-coherent (the DMA engine reads 32 instead of 57 GB/s out of it)"},
     {"ROFL_STAGE_KEEP_MB", "256", "pinned staging memory a lane keeps between calls (a call that needed more frees it when it ends)"},
+    {"ROFL_MSM_WINDOW_ORDER", "1", "0 = the bucket lists of the fixed-base two-level sort stay in arrival order and the accumulation's blocks in (problem, array) order (default: lists ordered by window slot, blocks array-major, so that the gathers of a launch stay within a few window slices of the table at a time)"},
     {"ROFL_SIGMA_SPLIT", "1", "0 = the per-element Sigma-proof prover runs as one thread per element (k_sigma_prove) instead of one thread per output point + a finishing kernel (k_sigma_points, k_sigma_finish); same bytes"},
     {"ROFL_MSM_BIN_TILE_SEARCH", "1", "0 = the coarse-bin pass of the two-level bucket sort keeps its power-of-two tile also when another tile length fills the CUs in fewer, shorter passes (batched rounds)"},
     {"ROFL_HEAVY_LO", "0", "1 = while several calls share the device, the chip-filling launches (bucket accumulation, generator folds) go to a lowest-priority stream of their lane so that other calls' short kernels are dispatched between their blocks (measured: neutral for rounds of range proofs, slower for rounds of L2 updates -- profiles/r06_experiments.txt item 2; off)"},

@@ -1369,9 +1369,14 @@ __global__ void __launch_bounds__(1024) k_msm_bin_l1(u32 n_side, u32 tile_pts, u
 }
 #endif
 #if ROFL_KG(1)
-__global__ void __launch_bounds__(512) k_msm_bin_l2(Msm2L L, u32 B, const u32 *bin_cursor, u32 *bins, const u32 *tails, u32 *cnt /* [PW][B] */, u32 *off /* [PW][B] */, u32 *overflow) {
+// wps > 1: a bucket's list comes out ordered by WINDOW SLOT (entry >> wshift = which of the wps windows of its bucket array the entry belongs
+// to): the accumulation walks the lists in order, so the threads of a launch gather from one or two window slices of the table at a time
+// instead of all of them (profiles/r06_experiments.txt item 14) -- the ranking key is (bucket, slot) instead of the bucket, nothing else changes.
+__global__ void __launch_bounds__(512) k_msm_bin_l2(Msm2L L, u32 B, const u32 *bin_cursor, u32 *bins, const u32 *tails, u32 *cnt /* [PW][B] */, u32 *off /* [PW][B] */, u32 *overflow,
+                                                    u32 wps, u32 wshift) {
     extern __shared__ u32 sm2[];
-    const u32 FB = 1u << L.fbits;
+    const u32 FBK = 1u << L.fbits;                                  // buckets of a coarse bin
+    const u32 FB = FBK * wps;                                       // ranking keys: (bucket, window slot)
     u32 *hist = sm2, *ofs = sm2 + FB, *out = sm2 + 2 * FB;          // [FB], [FB], [cap_bin]
     u32 bin = blockIdx.x, pw = blockIdx.y;
     u32 n = bin_cursor[((size_t)pw * L.nbins + bin) * 2], n2 = bin_cursor[((size_t)pw * L.nbins + bin) * 2 + 1];
@@ -1391,10 +1396,11 @@ __global__ void __launch_bounds__(512) k_msm_bin_l2(Msm2L L, u32 B, const u32 *b
     }
     u32 *reg = bins + rbase;
     const u32 *tl = tails + ((size_t)pw * L.nbins + bin) * MSM_BIN_TAIL;
-    const u32 fmask = FB - 1, keep = ~(fmask << L.ebits);
+    const u32 fmask = FBK - 1, keep = ~(fmask << L.ebits), emask = (1u << L.ebits) - 1;
+    auto key = [&](u32 v) { u32 f = (v >> L.ebits) & fmask; if (wps <= 1) return f; u32 ws = (v & emask) >> wshift; return f * wps + (ws < wps ? ws : wps - 1); };
     for (u32 f = threadIdx.x; f < FB; f += blockDim.x) hist[f] = 0;
     __syncthreads();
-    for (u32 j = threadIdx.x; j < n + n2; j += blockDim.x) atomicAdd(&hist[((j < n ? reg[j] : tl[j - n]) >> L.ebits) & fmask], 1u);
+    for (u32 j = threadIdx.x; j < n + n2; j += blockDim.x) atomicAdd(&hist[key(j < n ? reg[j] : tl[j - n])], 1u);
     __syncthreads();
     if (threadIdx.x < 64) {                                          // exclusive scan of FB <= 128 counters by one wave
         u32 per = (FB + 63) / 64, lo = threadIdx.x * per, sum = 0;
@@ -1405,15 +1411,16 @@ __global__ void __launch_bounds__(512) k_msm_bin_l2(Msm2L L, u32 B, const u32 *b
         for (u32 f = lo; f < lo + per && f < FB; f++) { ofs[f] = run; run += hist[f]; }
     }
     __syncthreads();
-    for (u32 f = threadIdx.x; f < FB; f += blockDim.x) {
-        size_t bi = (size_t)pw * B + (size_t)bin * FB + f;
-        cnt[bi] = hist[f];
-        off[bi] = (u32)(rbase + ofs[f]);
+    for (u32 f = threadIdx.x; f < FBK; f += blockDim.x) {
+        size_t bi = (size_t)pw * B + (size_t)bin * FBK + f;
+        u32 tot = 0; for (u32 q = 0; q < wps; q++) tot += hist[f * wps + q];
+        cnt[bi] = tot;
+        off[bi] = (u32)(rbase + ofs[f * wps]);
     }
     __syncthreads();
     for (u32 j = threadIdx.x; j < n + n2; j += blockDim.x) {
         u32 v = j < n ? reg[j] : tl[j - n];
-        u32 pos = atomicAdd(&ofs[(v >> L.ebits) & fmask], 1u);
+        u32 pos = atomicAdd(&ofs[key(v)], 1u);
         out[pos] = v & keep;
     }
     __syncthreads();
@@ -1441,9 +1448,18 @@ template <bool FB> __device__ __forceinline__ void msm_accumulate_body(u32 n, u3
                                  const u32 *sorted, const u32 *perm, ge *buckets, u32 cap, u32 idx_mask, u32 balance) {
     u32 p = blockIdx.y, B = 1u << (c - 1);
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if ((balance & 2u) && B >= TPB) {
+        // set-major dispatch: the launch's blocks in the order (bucket array of a problem, problem, block) instead of (problem, array, block), so that
+        // the blocks resident at one time belong to one or two arrays of every problem -- with window-ordered lists (k_msm_bin_l2) they gather
+        // from a few window slices of the table at a time (the problems of a launch share the table).  gridDim.x = W * B / TPB exactly.
+        const u32 nbs = B / TPB, lin = blockIdx.y * gridDim.x + blockIdx.x, per_set = nbs * gridDim.y;
+        const u32 ws = lin / per_set, rem = lin - ws * per_set;
+        p = rem / nbs;
+        t = ws * B + (rem - p * nbs) * TPB + threadIdx.x;
+    }
     if (t >= W * B) return;
     u32 w = t / B;
-    if (balance && B >= 1024) {
+    if ((balance & 1u) && B >= 1024) {
         // perm lists an array's buckets by descending count, so consecutive waves -- and blocks -- get lighter and lighter and the launch
         // ends on a long tail of half-empty CUs.  Give every block the same work instead: block j of an array takes the waves ranked
         // j, nw-1-j, nw/2-1-j and nw/2+j of its nw (two symmetric pairs around the median).  No rotation of the classes over a block's

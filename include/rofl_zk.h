@@ -66,6 +66,11 @@ typedef struct {
  * Generator tables are cached per device. */
 int rofl_set_device(int device);
 int rofl_get_device(int *device_out);                  /* the device the calling thread's next call runs on */
+/* The binding half of rofl_set_device alone: the calling thread's calls go to `device` from now on (-1: back to the process default), no HIP
+ * call, no lane taken -- for the worker threads of a host-side pool that run calls on behalf of a thread that has already brought the device
+ * up (rofl_project_code_amd/params.py binds its pool workers to the submitting thread's device this way; a rayon pool would do it in its
+ * start handler after one rofl_set_device per device). */
+int rofl_bind_device(int device);
 int rofl_last_error(char *buf, size_t len);            /* human-readable text of the calling thread's last failure */
 /* BulletproofGens::new(n_bits, m) (generators.rs; re-run by the reference on every helper call,
  * range_proof_vec/mod.rs:126,201) -- built once on the device and cached per (n_bits, m).  When this call returns the shape's tables are

@@ -22,6 +22,7 @@ extern "C" {
     /// or calls `rofl_set_option(b"devices\0".., (1 << N) - 1)` and hands all clients of a round to the `_batch` entry points.
     pub fn rofl_set_device(device: c_int) -> c_int;
     pub fn rofl_get_device(device_out: *mut c_int) -> c_int;
+    pub fn rofl_bind_device(device: c_int) -> c_int;
     pub fn rofl_last_error(buf: *mut c_char, len: usize) -> c_int;
     pub fn rofl_bp_gens_prepare(n_bits: usize, m: usize) -> c_int;
     pub fn rofl_bp_gens_prepare_verify(n_bits: usize, m: usize) -> c_int;

@@ -147,8 +147,9 @@ def map_device(logical, physical):
 
 
 def bind_device(dev):
-    """test hook: the thread-binding half of set_device without touching HIP (-1 = unbind)"""
-    _check(lib().rofl_dbg_bind_device(int(dev)))
+    """rofl_bind_device: the thread-binding half of set_device without touching HIP (-1 = back to the process default) -- for pool workers
+    that run calls on behalf of a thread whose device is already up"""
+    _check(lib().rofl_bind_device(int(dev)))
 
 
 def bp_gens_table_bytes(n_bits, m):

@@ -574,6 +574,7 @@ int rofl_set_device(int device) {
     return rc;
 }
 int rofl_get_device(int *device_out) { if (!device_out) return fail(ROFL_BAD_PARAM, "bad parameter"); *device_out = current_device(); return ROFL_OK; }
+int rofl_bind_device(int device) { if (device < -1 || device >= kMaxDevices) return fail(ROFL_BAD_PARAM, "bad device index"); t_device = device; return ROFL_OK; }
 int rofl_dbg_bind_device(int device) { if (device < -1 || device >= kMaxDevices) return ROFL_BAD_PARAM; t_device = device; return ROFL_OK; }
 int rofl_dbg_map_device(int logical, int physical) {
     if (logical < 0 || logical >= kMaxDevices || physical < 0) return ROFL_BAD_PARAM;

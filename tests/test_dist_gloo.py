@@ -172,3 +172,67 @@ def test_one_client_split_over_two_ranks_gloo():
         p.join(240)
         assert p.exitcode == 0
     assert sorted(q.get() for _ in range(2)) == [0, 1]
+
+
+def test_split_helpers_with_more_ranks_than_chunks():
+    """dist.split_create / split_verify in a world of EIGHT with four chunks (BASELINE cfg 2 at P = 4 on an 8-GPU node) and with 64: ranks without
+    a run only join the collectives, every run is created once, checked once (by the rank before its owner), and the assembled arrays are the
+    whole client's.  Threads and an in-process communicator stand in for the ranks: no GPU, no process group."""
+    import threading
+    sys.path.insert(0, ROOT)
+    from rofl_project_code_amd import dist as rd
+
+    class ThreadComm:
+        def __init__(self, shared, rank, world): self.s, self.rank, self.world = shared, rank, world
+
+        def _all(self, item):
+            self.s["slots"][self.rank] = item
+            self.s["bar"].wait()
+            got = list(self.s["slots"])
+            self.s["bar"].wait()
+            return got
+
+        def exchange_round(self, payloads, ok_local):
+            got = self._all((bool(ok_local), [np.ascontiguousarray(p, dtype=np.uint8).reshape(-1).copy() for p in payloads]))
+            return all(g[0] for g in got), [g[1] for g in got]
+
+        def all_verified(self, ok_local): return all(self._all(bool(ok_local)))
+
+    for n_chunks, d, m, plen in ((4, 25000, 8192, 1440), (64, 25000, 512, 1184), (4, 9000, 8192, 1440)):      # (the last: chunks 2 and 3 hold no real element)
+        world = 8
+        rng = np.random.default_rng(n_chunks + d)
+        want_p = rng.integers(0, 256, size=(n_chunks, plen), dtype=np.uint8)
+        want_c = rng.integers(0, 256, size=(d, 32), dtype=np.uint8)
+        shared = {"slots": [None] * world, "bar": threading.Barrier(world)}
+        created, checked, out, errs = [], [], {}, []
+
+        def rank_main(r):
+            try:
+                comm = ThreadComm(shared, r, world)
+
+                def create_run(first, count):
+                    created.append((r, first, count))
+                    return want_p[first:first + count], want_c[min(d, first * m):min(d, (first + count) * m)]
+
+                def verify_run(first, pr, cm):
+                    checked.append((r, first, pr.shape[0]))
+                    return bool((pr == want_p[first:first + pr.shape[0]]).all() and (cm == want_c[min(d, first * m):min(d, (first + pr.shape[0]) * m)]).all())
+
+                p, c = rd.split_create(comm, r, world, n_chunks, m, d, plen, create_run)
+                ok = rd.split_verify(comm, r, world, p, c, m, verify_run)
+                bad = p.copy(); bad[n_chunks - 1, 5] ^= 1
+                ok_bad = rd.split_verify(comm, r, world, bad, c, m, verify_run)
+                out[r] = (p, c, ok, ok_bad)
+            except BaseException as e:      # noqa: BLE001
+                errs.append(e); shared["bar"].abort()
+
+        ths = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+        for t in ths: t.start()
+        for t in ths: t.join()
+        assert not errs, errs
+        runs = rd.chunk_runs(n_chunks, world)
+        assert sum(c for _, c in runs) == n_chunks and sorted(created) == sorted((r, f, c) for r, (f, c) in enumerate(runs) if c)
+        assert len([x for x in checked]) == 2 * len([1 for _, c in runs if c])      # every run checked once per split_verify call
+        for r in range(world):
+            p, c, ok, ok_bad = out[r]
+            assert (p == want_p).all() and (c == want_c).all() and ok is True and ok_bad is False

@@ -633,9 +633,10 @@ struct Ctx {
         HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         // The side stream is created WITH the main stream, not on first use: the runtime deals streams to its hardware queues in creation order
         // (GPU_MAX_HW_QUEUES, 4 by default), and a side stream created after the other lanes' main streams landed on its own lane's queue for some
-        // lane counts -- the commitment kernel then ran behind the nonce expansion instead of beside it: ROFL_LANES = 2 or 6 cost a lone client
-        // 0.6-0.9 ms per step against 1, 3, 4 or 12 (profiles/r06_experiments.txt item 17).
+        // lane counts -- the commitment kernel then ran behind the nonce expansion instead of beside it: 0.3-0.6 ms per step of a lone client at every
+        // lane count on one box, 0.6-0.9 ms at 2 and 6 lanes on another (profiles/r06_experiments.txt item 17).
         HIPCHK(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&stream_up, hipStreamNonBlocking));      // (the upload stream of the pipelined batch verifiers: same reason)
         // PedersenGens::default(): B = Ristretto basepoint, B_blinding = hash_from_bytes::<Sha3_512>(B)
         static const uint8_t Bc[32] = {0xe2, 0xf2, 0xae, 0x0a, 0x6a, 0xbc, 0x4e, 0x71, 0xa8, 0x84, 0xa9, 0x61, 0xc5, 0x00, 0x51, 0x5f,
                                        0x58, 0xe3, 0x0b, 0x6a, 0xa5, 0x82, 0xdd, 0x8d, 0xb6, 0xa6, 0x59, 0x45, 0xe0, 0x8d, 0x2d, 0x76};
@@ -702,6 +703,7 @@ struct Ctx {
         parent = &p; device = p.device; phys = p.phys;
         HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));      // (with the main stream: see init)
+        HIPCHK(hipStreamCreateWithFlags(&stream_up, hipStreamNonBlocking));
         ht = p.ht; d_tabB = p.d_tabB; d_tabBb = p.d_tabBb; d_two_pow = p.d_two_pow;
         msm_lds = p.msm_lds; msm_two_level = p.msm_two_level; msm_group_reduce = p.msm_group_reduce; msm_lds_min = p.msm_lds_min; msm_lds_tile = p.msm_lds_tile;
         msm_fb_threads = p.msm_fb_threads;

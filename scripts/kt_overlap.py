@@ -35,6 +35,19 @@ def overlap_with_heavy(e):
 stat = collections.defaultdict(list)
 for e in ev:
     stat[e[2]].append(e)
+# how much of the window had at least one kernel running (union of the launch intervals), and how long the longest idle gaps were
+_cov, _end, _gaps, _last, _big = 0, ev[0][0], [], ev[0][2], []
+for e in ev:
+    if e[0] > _end:
+        _gaps.append((e[0] - _end) / 1e6)
+        if e[0] - _end > 2e6: _big.append(((_end - ev[0][0]) / 1e6, (e[0] - _end) / 1e6, _last, e[2]))
+        _cov += e[1] - e[0]; _end = e[1]; _last = e[2]
+    elif e[1] > _end: _cov += e[1] - _end; _end = e[1]; _last = e[2]
+if len(sys.argv) > 3 and sys.argv[3] == "gaps":
+    print("idle gaps > 2 ms (start in window ms, length ms, last kernel before -> first kernel after):")
+    for g in _big: print("   %9.1f  %7.2f   %s -> %s" % g)
+print("device busy (some kernel running) %.1f %% of the window; idle gaps > 0.2 ms: %d, their sum %.1f ms, the longest %.2f ms"
+      % (100.0 * _cov / max(ev[-1][1] - ev[0][0], 1), len([g for g in _gaps if g > 0.2]), sum(g for g in _gaps if g > 0.2), max(_gaps) if _gaps else 0.0))
 span = (ev[-1][1] - ev[0][0]) / 1e6
 print("trace window %.1f ms, %d launches on %d queues" % (span, len(ev), len({e[3] for e in ev})))
 print("%-26s %6s %9s %9s %9s %9s  %s" % ("kernel", "n", "total ms", "mean ms", "alone ms", "beside ms", "share of its time beside a foreign heavy launch"))

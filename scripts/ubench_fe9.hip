@@ -6,6 +6,7 @@
 // shift): h_k += 19 * lo32, h_{k+1} += 19 * 2^(32 - s_k) * hi32.  97 multiply-adds + 6 doublings + a 9-column carry chain.
 // What the narrower slack costs: a 64-bit column holds 9 products of (limb_f * limb_g * 2) only while limb_f * limb_g < 2^59.8, so of the
 // six sums / differences a mixed addition feeds into multiplications, three need a carry pass first (the 25.5-bit radix needs none).
+//   build: cd scripts && hipcc --offload-arch=gfx950 -O3 -std=c++17 -o ubench_fe9 ubench_fe9.hip
 //   ubench_fe9 selftest          host only: f9_mul / g9_madd against fd_mul / gd_madd on random inputs (no GPU call)
 //   ubench_fe9                   GPU: multiplications / s and mixed additions / s of both forms at 4 and 8 waves per SIMD
 #include <hip/hip_runtime.h>

@@ -186,6 +186,16 @@ int rofl_verify_rangeproof_l2_batch(size_t n_clients, const uint8_t *const *proo
  *   adds c_sq = m^2 B + r2 Bb; proof 192 B = C'.L|C'.R|c_sq'|Z_m|Z_r1|Z_r2, commitments 96 B = L|R|c_sq.
  * `existing32` (may be NULL) are value commitments to complete (prove_existing: L = m_com).
  * Nonce draw order per element i: m', r' (index 2i..) resp. m', r1', r2' (index 3i..), rofl_nonce_t as above. */
+/* One vector over several devices / ranks: the elements of a vector are independent of each other (one proof per element on the
+ * reference's rayon pool, rand_proof_vec/mod.rs:45-58, square_rand_proof_vec/mod.rs:45-58).  In ONE process, with rofl_set_option("devices", mask)
+ * naming several devices, the create_*_vec / verify_*_vec calls below deal contiguous runs of elements to them (same bytes, same verdict).  A rank of
+ * a one-process-per-GPU host proves its run [elem_first, elem_first + elem_count) with rofl_create_sigmaproof_vec_range -- kind 0 RandProof, 1
+ * SquareRandProof, 2 SquareProof; the arrays are the WHOLE vector's (d elements; r2_32 NULL for kind 0, existing32 may be NULL), the outputs receive the
+ * run's elem_count proofs and commitments; element i keeps its place in the vector's nonce index space, so the runs concatenate to the bytes of the
+ * unsplit call -- and verifies a run with the verify_*_vec call on the run's own sub-arrays (the vector's verdict is the AND over the runs). */
+int rofl_create_sigmaproof_vec_range(int kind, const float *values, size_t d, const uint8_t *r1_32, const uint8_t *r2_32, const uint8_t *existing32,
+                                     unsigned fp_bits, unsigned fp_frac, const rofl_nonce_t *nonce, size_t elem_first, size_t elem_count,
+                                     uint8_t *proofs_out, uint8_t *commits_out);
 int rofl_create_randproof_vec(const float *values, size_t d, const uint8_t *r32, size_t d_r, const uint8_t *existing32,
                               unsigned fp_bits, unsigned fp_frac, const rofl_nonce_t *nonce, uint8_t *proofs_out /* d*128 */,
                               uint8_t *commits_out /* d*64 */);
@@ -313,7 +323,8 @@ int rofl_comm_destroy(void);
  *   "devices"              bit mask of logical devices (bit d = device d); 0 (default): batch calls run on the calling thread's device;
  *                          otherwise rofl_create_rangeproof_batch / rofl_verify_rangeproof_batch deal their clients round-robin to the
  *                          listed devices, and the single-client calls rofl_create_rangeproof / rofl_verify_rangeproof deal the client's
- *                          CHUNKS to them in contiguous runs (same bytes, same verdict)
+ *                          CHUNKS to them in contiguous runs (same bytes, same verdict), as do the per-element Sigma-proof vector calls
+ *                          with runs of ELEMENTS
  *   "sigma_batch"          1 (default): the per-element Sigma-proofs of a vector are verified as one random linear combination; 0: one
  *                          check per element (rand_proof_vec/mod.rs:93-118)
  *   "default_device"       the device of threads that never called rofl_set_device (default: the first device that was set, else 0)

@@ -58,6 +58,9 @@ extern "C" {
         proof_out: *mut u8, proof_len_out: *mut usize, commit_out: *mut u8) -> c_int;
     pub fn rofl_verify_rangeproof_l2(proof: *const u8, proof_len: usize, commit: *const u8, prove_range: usize,
         fp_bits: c_uint, fp_frac: c_uint, verifier_seed: *const u8, ok_out: *mut c_int) -> c_int;
+    pub fn rofl_create_sigmaproof_vec_range(kind: c_int, values: *const c_float, d: usize, r1_32: *const u8, r2_32: *const u8,
+        existing32: *const u8, fp_bits: c_uint, fp_frac: c_uint, nonce: *const RoflNonce, elem_first: usize, elem_count: usize,
+        proofs_out: *mut u8, commits_out: *mut u8) -> c_int;
     pub fn rofl_create_randproof_vec(values: *const c_float, d: usize, r32: *const u8, d_r: usize, existing32: *const u8,
         fp_bits: c_uint, fp_frac: c_uint, nonce: *const RoflNonce, proofs_out: *mut u8, pairs_out: *mut u8) -> c_int;
     pub fn rofl_verify_randproof_vec(proofs: *const u8, pairs: *const u8, d: usize, ok_out: *mut c_int) -> c_int;

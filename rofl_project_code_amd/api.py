@@ -535,6 +535,30 @@ def _sigma_verify_batch(fn, plen, clen, proofs_list, commits_list, want_csq):
     return [bool(x) for x in ok], (sums if want_csq else None)
 
 
+SIGMA_KINDS = {0: (128, 64), 1: (192, 96), 2: (160, 64)}      # kind -> (proof bytes, commitment bytes) per element: RandProof, SquareRandProof, SquareProof
+
+
+def create_sigmaproof_vec_range(kind, values, random_vec, random_vec_2, elem_first, elem_count, nonce=None, existing=None, fp=None):
+    """rofl_create_sigmaproof_vec_range: the proofs of elements [elem_first, elem_first + elem_count) of ONE vector -- the unit a rank takes when a
+    client's per-element Sigma-proofs are split over GPUs (the reference proves the elements independently on its rayon pool,
+    rand_proof_vec/mod.rs:45-58, square_rand_proof_vec/mod.rs:45-58).  The arrays are the whole vector's; the runs, concatenated in element
+    order, are byte for byte what the unsplit create_*_vec call returns.  -> (proofs u8[count, P], commitments u8[count, C])"""
+    plen, clen = SIGMA_KINDS[int(kind)]
+    v = np.ascontiguousarray(values, dtype=np.float32)
+    r1 = _u8(random_vec)
+    r2 = None if random_vec_2 is None else _u8(random_vec_2)
+    ex = None if existing is None else _u8(existing)
+    if r1.shape[0] != v.size or (r2 is not None and r2.shape[0] != v.size) or (ex is not None and ex.shape[0] != v.size):
+        raise RoflError(1, "WrongNumBlindingFactors")
+    nonce = nonce or Nonce.random()
+    ns = nonce._struct()
+    proofs = np.zeros((max(elem_count, 1), plen), dtype=np.uint8)
+    commits = np.zeros((max(elem_count, 1), clen), dtype=np.uint8)
+    _check(lib().rofl_create_sigmaproof_vec_range(int(kind), _ptr(v), _sz(v.size), _ptr(r1), None if r2 is None else _ptr(r2), None if ex is None else _ptr(ex), *_fp(fp),
+                                                  ctypes.byref(ns), _sz(elem_first), _sz(elem_count), _ptr(proofs), _ptr(commits)))
+    return proofs[:elem_count], commits[:elem_count]
+
+
 class rand_proof_vec:
     """rand_proof_vec/mod.rs:14-118.  proofs uint8[d,128], ElGamal pairs uint8[d,64]."""
 

@@ -2345,7 +2345,7 @@ __device__ inline sc sg_nonce(int mode, const NonceSeed &seed, const uint8_t *st
 }
 #if ROFL_KG(3)
 __global__ void __launch_bounds__(64) k_sigma_prove(int kind, u32 d, const float *vals, u32 fp_bits, u32 fp_frac, const sc *r1c, const sc *r2c,
-                                                    const uint8_t *existing, int mode, NonceSeed seed, const uint8_t *stream, u64 stream_scalars,
+                                                    const uint8_t *existing, int mode, NonceSeed seed, const uint8_t *stream, u64 stream_scalars, u64 nonce_base,
                                                     DMerlin init, const niels *tabB, const niels *tabBb, uint8_t *proofs, uint8_t *commits, u32 *status) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= d) return;
@@ -2357,7 +2357,7 @@ __global__ void __launch_bounds__(64) k_sigma_prove(int kind, u32 d, const float
     sc r1 = load_sc_reduced(&r1c[i]), r2 = has_sq ? load_sc_reduced(&r2c[i]) : sc_zero();
     sc nc[3];
     SgNonceCache ncache; ncache.blk = ~0ULL;
-    for (u32 j = 0; j < nn; j++) nc[j] = sg_nonce(mode, seed, stream, stream_scalars, (u64)nn * i + j, ncache);   // m', r1' (, r2')
+    for (u32 j = 0; j < nn; j++) nc[j] = sg_nonce(mode, seed, stream, stream_scalars, nonce_base + (u64)nn * i + j, ncache);   // m', r1' (, r2')
     uint8_t *cm = commits + (size_t)clen * i, *pf = proofs + (size_t)plen * i;
     gd L;
     if (existing) { if (!sg_decode(L, existing + (size_t)32 * i)) { atomicOr(status, 4u); return; } for (int q = 0; q < 32; q++) cm[q] = existing[(size_t)32 * i + q]; }
@@ -2389,7 +2389,7 @@ struct SgSlots { int n; int id[6]; };
 // (two kernels: the slots that are fixed-base multiplications + one encoding, and c_sq' with its variable-base multiplication and its 1 KB
 //  table in scratch -- in one kernel every slot would be given the registers and the scratch of the largest)
 template <bool VAR> __device__ __forceinline__ void sigma_point_body(int kind, int slot, u32 d, const float *vals, u32 fp_bits, u32 fp_frac, const sc *r1c, const sc *r2c,
-                                                                    const uint8_t *existing, int mode, const NonceSeed &seed, const uint8_t *stream, u64 stream_scalars,
+                                                                    const uint8_t *existing, int mode, const NonceSeed &seed, const uint8_t *stream, u64 stream_scalars, u64 nonce_base,
                                                                     const niels *tabB, const niels *tabBb, uint8_t *proofs, uint8_t *commits, u32 *status) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= d) return;
@@ -2399,7 +2399,7 @@ template <bool VAR> __device__ __forceinline__ void sigma_point_body(int kind, i
     if (v != v) return;                                // (k_sigma_finish reports it)
     uint8_t *cm = commits + (size_t)clen * i, *pf = proofs + (size_t)plen * i;
     SgNonceCache ncache; ncache.blk = ~0ULL;
-    auto nonce = [&](u32 j) { return sg_nonce(mode, seed, stream, stream_scalars, (u64)nn * i + j, ncache); };      // m', r1' (, r2')
+    auto nonce = [&](u32 j) { return sg_nonce(mode, seed, stream, stream_scalars, nonce_base + (u64)nn * i + j, ncache); };      // m', r1' (, r2')
     if (VAR) {      // SG_CSQP: m' L + r2' Bb
         gd L;
         if (existing) { if (!sg_decode(L, existing + (size_t)32 * i)) { atomicOr(status, 4u); return; } }
@@ -2422,21 +2422,21 @@ template <bool VAR> __device__ __forceinline__ void sigma_point_body(int kind, i
 }
 #if ROFL_KG(2)
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) k_sigma_points(int kind, SgSlots slots, u32 d, const float *vals, u32 fp_bits, u32 fp_frac, const sc *r1c, const sc *r2c,
-                                                     const uint8_t *existing, int mode, NonceSeed seed, const uint8_t *stream, u64 stream_scalars,
+                                                     const uint8_t *existing, int mode, NonceSeed seed, const uint8_t *stream, u64 stream_scalars, u64 nonce_base,
                                                      const niels *tabB, const niels *tabBb, uint8_t *proofs, uint8_t *commits, u32 *status) {
-    sigma_point_body<false>(kind, slots.id[blockIdx.y], d, vals, fp_bits, fp_frac, r1c, r2c, existing, mode, seed, stream, stream_scalars, tabB, tabBb, proofs, commits, status);
+    sigma_point_body<false>(kind, slots.id[blockIdx.y], d, vals, fp_bits, fp_frac, r1c, r2c, existing, mode, seed, stream, stream_scalars, nonce_base, tabB, tabBb, proofs, commits, status);
 }
 #endif
 #if ROFL_KG(3)
 __global__ void __launch_bounds__(64) k_sigma_point_var(int kind, u32 d, const float *vals, u32 fp_bits, u32 fp_frac, const sc *r1c, const sc *r2c,
-                                                        const uint8_t *existing, int mode, NonceSeed seed, const uint8_t *stream, u64 stream_scalars,
+                                                        const uint8_t *existing, int mode, NonceSeed seed, const uint8_t *stream, u64 stream_scalars, u64 nonce_base,
                                                         const niels *tabB, const niels *tabBb, uint8_t *proofs, uint8_t *commits, u32 *status) {
-    sigma_point_body<true>(kind, SG_CSQP, d, vals, fp_bits, fp_frac, r1c, r2c, existing, mode, seed, stream, stream_scalars, tabB, tabBb, proofs, commits, status);
+    sigma_point_body<true>(kind, SG_CSQP, d, vals, fp_bits, fp_frac, r1c, r2c, existing, mode, seed, stream, stream_scalars, nonce_base, tabB, tabBb, proofs, commits, status);
 }
 #endif
 #if ROFL_KG(4)
 __global__ void __launch_bounds__(TPB) k_sigma_finish(int kind, u32 d, const float *vals, u32 fp_bits, u32 fp_frac, const sc *r1c, const sc *r2c,
-                                                      const uint8_t *existing, int mode, NonceSeed seed, const uint8_t *stream, u64 stream_scalars,
+                                                      const uint8_t *existing, int mode, NonceSeed seed, const uint8_t *stream, u64 stream_scalars, u64 nonce_base,
                                                       DMerlin init, uint8_t *proofs, uint8_t *commits, u32 *status) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= d) return;
@@ -2448,7 +2448,7 @@ __global__ void __launch_bounds__(TPB) k_sigma_finish(int kind, u32 d, const flo
     sc r1 = load_sc_reduced(&r1c[i]), r2 = has_sq ? load_sc_reduced(&r2c[i]) : sc_zero();
     sc nc[3];
     SgNonceCache ncache; ncache.blk = ~0ULL;
-    for (u32 j = 0; j < nn; j++) nc[j] = sg_nonce(mode, seed, stream, stream_scalars, (u64)nn * i + j, ncache);
+    for (u32 j = 0; j < nn; j++) nc[j] = sg_nonce(mode, seed, stream, stream_scalars, nonce_base + (u64)nn * i + j, ncache);
     uint8_t *cm = commits + (size_t)clen * i, *pf = proofs + (size_t)plen * i;
     if (existing) for (int q = 0; q < 32; q++) cm[q] = existing[(size_t)32 * i + q];
     DMerlin t = init;

@@ -870,15 +870,22 @@ DMerlin sigma_init_state(int kind) {
     DMerlin d; memcpy(d.st, t.b(), 200); d.pos = t.pos; d.pos_begin = t.pos_begin;
     return d;
 }
+// [elem_first, elem_first + d) of a vector of d_all elements (d_all = 0: the whole vector): the elements of a Sigma-proof vector are independent
+// of each other (rand_proof_vec/mod.rs:45-58, square_rand_proof_vec/mod.rs:45-58: one proof per element on the rayon pool), so a device or a
+// rank can take any run of them -- SURVEY 8(e), the third unit of independence.  The arrays passed in are the RUN's (values, r1, r2, existing
+// and both outputs start at the run's first element); the nonce index space stays the vector's (element i draws from nn * i), so the bytes
+// are those of the unsplit call.
 int sigma_create(int kind, const float *values, size_t d, const uint8_t *r1, size_t d_r1, const uint8_t *r2, const uint8_t *existing,
-                 unsigned fp_bits, unsigned fp_frac, const rofl_nonce_t *nonce, uint8_t *proofs_out, uint8_t *commits_out) {
+                 unsigned fp_bits, unsigned fp_frac, const rofl_nonce_t *nonce, uint8_t *proofs_out, uint8_t *commits_out, size_t elem_first = 0, size_t d_all = 0) {
     LaneLock lane_lock = acquire_lane(false, true); Ctx &C = *lane_lock.c;
     if (d != d_r1) return fail(ROFL_WRONG_NUM_BLINDING, "WrongNumBlindingFactors");
     if (!valid_fp(fp_bits, fp_frac) || !nonce) return fail(ROFL_BAD_PARAM, "bad parameter");
-    if (d == 0) return ROFL_OK;
+    if (d_all == 0) { d_all = d; elem_first = 0; }
+    if (elem_first > d_all || d > d_all - elem_first) return fail(ROFL_BAD_PARAM, "element range outside the vector");
     bool has_sq = kind != 0;
     size_t npts = 1 + (kind != 2) + (has_sq ? 1 : 0), nn = has_sq ? 3 : 2, clen = 32 * npts, plen = 32 * (npts + nn);
-    if (nonce->mode == 0 && nonce->stream_scalars < nn * d) return fail(ROFL_NONCE_SHORT, "nonce stream too short");
+    if (nonce->mode == 0 && nonce->stream_scalars < nn * d_all) return fail(ROFL_NONCE_SHORT, "nonce stream too short");
+    if (d == 0) return ROFL_OK;
     C.init();
     timing_begin(C);
     float *dv = C.vals.as<float>(d); sc *dr1 = C.tmp_in.as<sc>(d); sc *dr2 = has_sq ? C.tmp_in2.as<sc>(d) : nullptr;
@@ -891,8 +898,12 @@ int sigma_create(int kind, const float *values, size_t d, const uint8_t *r1, siz
     if (has_sq) C.up(dr2, r2, 32 * d, C.stream);
     if (dex) C.up(dex, existing, 32 * d, C.stream);
     NonceSeed seed{}; const uint8_t *d_stream = nullptr; u64 ss = 0;
+    const u64 nonce_base = (u64)nn * elem_first;
     if (nonce->mode == 1) memcpy(seed.w, nonce->seed, 32);
-    else { ss = nonce->stream_scalars; uint8_t *sb = C.stream_buf.as<uint8_t>(ss * 64 + 64); C.up(sb, nonce->stream, ss * 64, C.stream); d_stream = sb; }
+    else {      // only the run's part of the stream goes up; the kernels index it by the vector's nonce index, so the base address is moved back by what stayed behind
+        const size_t run_bytes = nn * d * 64, run_off = (size_t)nonce_base * 64;
+        uint8_t *sb = C.stream_buf.as<uint8_t>(run_bytes + 64); C.up(sb, nonce->stream + run_off, run_bytes, C.stream);
+        d_stream = reinterpret_cast<const uint8_t *>(reinterpret_cast<uintptr_t>(sb) - run_off); ss = nonce_base + nn * d; }
     // algorithmic work per element: 7 fixed-base multiplications (64 mixed additions each), one variable-base one (~325 point operations),
     // 2 * npts encodings; bytes as SURVEY 8(d): value + randomness in, commitments + proof out
     { KSpan ks_sigma(C.tm, C.stream, ROFL_TK_SIGMA, (uint64_t)d * (7 * 64 * 7 + 325 * 8 + 2 * npts * 265), (uint64_t)d * (4 + 32 * (has_sq ? 2 : 1) + clen + plen));
@@ -907,17 +918,17 @@ int sigma_create(int kind, const float *values, size_t d, const uint8_t *r1, siz
               if (!C.stream2) HIPCHK(hipStreamCreateWithFlags(&C.stream2, hipStreamNonBlocking));
               HIPCHK(hipEventRecord(C.pool_event(0), C.stream)); HIPCHK(hipStreamWaitEvent(C.stream2, C.pool_event(0), 0));      // inputs uploaded
               ROFL_LAUNCH(k_sigma_point_var, dim3((unsigned)((d + 63) / 64)), dim3(64), 0, C.stream2, kind, (u32)d, dv, fp_bits, fp_frac, dr1, dr2, dex,
-                          nonce->mode, seed, d_stream, ss, C.d_tabB, C.d_tabBb, dp, dc, status);
+                          nonce->mode, seed, d_stream, ss, nonce_base, C.d_tabB, C.d_tabBb, dp, dc, status);
               HIPCHK(hipEventRecord(C.pool_event(1), C.stream2));
           }
           ROFL_LAUNCH(k_sigma_points, dim3((unsigned)((d + 63) / 64), (unsigned)sl.n), dim3(64), 0, C.stream, kind, sl, (u32)d, dv, fp_bits, fp_frac, dr1, dr2, dex,
-                      nonce->mode, seed, d_stream, ss, C.d_tabB, C.d_tabBb, dp, dc, status);
+                      nonce->mode, seed, d_stream, ss, nonce_base, C.d_tabB, C.d_tabBb, dp, dc, status);
           if (has_sq) HIPCHK(hipStreamWaitEvent(C.stream, C.pool_event(1), 0));
-          ROFL_LAUNCH(k_sigma_finish, grid1(d), dim3(TPB), 0, C.stream, kind, (u32)d, dv, fp_bits, fp_frac, dr1, dr2, dex, nonce->mode, seed, d_stream, ss,
+          ROFL_LAUNCH(k_sigma_finish, grid1(d), dim3(TPB), 0, C.stream, kind, (u32)d, dv, fp_bits, fp_frac, dr1, dr2, dex, nonce->mode, seed, d_stream, ss, nonce_base,
                       sigma_init_state(kind), dp, dc, status);
       } else
       ROFL_LAUNCH(k_sigma_prove, dim3((unsigned)((d + 63) / 64)), dim3(64), 0, C.stream, kind, (u32)d, dv, fp_bits, fp_frac, dr1, dr2, dex,
-                         nonce->mode, seed, d_stream, ss, sigma_init_state(kind), C.d_tabB, C.d_tabBb, dp, dc, status); }
+                         nonce->mode, seed, d_stream, ss, nonce_base, sigma_init_state(kind), C.d_tabB, C.d_tabBb, dp, dc, status); }
     u32 st = 0;
     C.down(proofs_out, dp, d * plen, C.stream);
     C.down(commits_out, dc, d * clen, C.stream);
@@ -1207,12 +1218,73 @@ int compressed_verify(const uint8_t *proof, const uint8_t *pairs, size_t d, int 
 }
 }  // namespace
 
+namespace {
+// ONE vector of per-element Sigma-proofs over several devices: contiguous runs of elements (rofl_set_option("devices", mask)), as the single-client
+// range-proof calls deal chunks.  Runs shorter than a few thousand elements are not worth a device.
+std::vector<std::pair<size_t, size_t>> elem_runs(size_t d, size_t nd) {
+    std::vector<std::pair<size_t, size_t>> r;
+    nd = std::max<size_t>(1, std::min(nd, d / 2048));
+    for (size_t k = 0; k < nd; k++) { size_t a = k * d / nd, b = (k + 1) * d / nd; if (b > a) r.emplace_back(a, b - a); }
+    return r;
+}
+int sigma_create_any(int kind, const float *values, size_t d, const uint8_t *r1, size_t d_r1, const uint8_t *r2, const uint8_t *existing, unsigned fp_bits, unsigned fp_frac,
+                     const rofl_nonce_t *nonce, uint8_t *proofs_out, uint8_t *commits_out) {
+    std::vector<int> devs = batch_devices();
+    auto runs = elem_runs(d, devs.size());
+    if (devs.size() < 2 || runs.size() < 2 || d != d_r1 || !values || !r1 || !nonce || !proofs_out || !commits_out || (kind != 0 && !r2)) {
+        std::unique_ptr<DeviceBinding> bind; if (devs.size() == 1) bind.reset(new DeviceBinding(devs[0]));
+        return sigma_create(kind, values, d, r1, d_r1, r2, existing, fp_bits, fp_frac, nonce, proofs_out, commits_out);
+    }
+    const bool has_sq = kind != 0;
+    const size_t npts = 1 + (kind != 2) + (has_sq ? 1 : 0), nn = has_sq ? 3 : 2, clen = 32 * npts, plen = 32 * (npts + nn);
+    std::vector<int> rcs; std::vector<std::string> errs;
+    if (int rc = run_on_devices(devs, runs.size(), rcs, errs, [&](size_t k) -> int {
+            const size_t e0 = runs[k].first, cnt = runs[k].second;
+            return sigma_create(kind, values + e0, cnt, r1 + 32 * e0, cnt, r2 ? r2 + 32 * e0 : nullptr, existing ? existing + 32 * e0 : nullptr, fp_bits, fp_frac, nonce,
+                                proofs_out + e0 * plen, commits_out + e0 * clen, e0, d); }))
+        return rc;
+    // the unsplit call's outcome: the NaN check comes before anything is decoded (k_sigma_finish / k_sigma_prove report 2 before 4 per element; across
+    // elements the call reports NON_FINITE first, sigma_create)
+    for (size_t k = 0; k < rcs.size(); k++) if (rcs[k] >= ROFL_HIP_ERROR || rcs[k] == ROFL_BAD_PARAM || rcs[k] == ROFL_NONCE_SHORT) return fail(rcs[k], errs[k]);
+    for (size_t k = 0; k < rcs.size(); k++) if (rcs[k] == ROFL_NON_FINITE) return fail(rcs[k], errs[k]);
+    for (size_t k = 0; k < rcs.size(); k++) if (rcs[k]) return fail(rcs[k], errs[k]);
+    return ROFL_OK;
+}
+int sigma_verify_any(int kind, const uint8_t *proofs, const uint8_t *commits, size_t d, int *ok_out) {
+    std::vector<int> devs = batch_devices();
+    auto runs = elem_runs(d, devs.size());
+    if (devs.size() < 2 || runs.size() < 2 || !proofs || !commits || !ok_out) {
+        std::unique_ptr<DeviceBinding> bind; if (devs.size() == 1) bind.reset(new DeviceBinding(devs[0]));
+        return sigma_verify_batch(kind, 1, &proofs, &commits, d, ok_out, nullptr, true);
+    }
+    const bool has_sq = kind != 0;
+    const size_t npts = 1 + (kind != 2) + (has_sq ? 1 : 0), nn = has_sq ? 3 : 2, clen = 32 * npts, plen = 32 * (npts + nn);
+    std::vector<int> rcs, oks(runs.size(), 0); std::vector<std::string> errs;
+    if (int rc = run_on_devices(devs, runs.size(), rcs, errs, [&](size_t k) -> int {
+            const uint8_t *pp = proofs + runs[k].first * plen, *cc = commits + runs[k].first * clen;
+            return sigma_verify_batch(kind, 1, &pp, &cc, runs[k].second, &oks[k], nullptr, true); }))      // every run is its own random linear combination
+        return rc;
+    *ok_out = 0;
+    for (size_t k = 0; k < rcs.size(); k++) if (rcs[k]) return fail(rcs[k], errs[k]);      // a malformed vector is the call's FormatError, whichever run met it
+    int ok = 1; for (int o : oks) ok &= o;
+    *ok_out = ok;
+    return ROFL_OK;
+}
+}  // namespace
+int rofl_create_sigmaproof_vec_range(int kind, const float *values, size_t d, const uint8_t *r1_32, const uint8_t *r2_32, const uint8_t *existing32, unsigned fp_bits, unsigned fp_frac,
+                                     const rofl_nonce_t *nonce, size_t elem_first, size_t elem_count, uint8_t *proofs_out, uint8_t *commits_out) {
+    return guarded([&]() -> int {
+        if (kind < 0 || kind > 2 || !values || !r1_32 || !nonce || !proofs_out || !commits_out || (kind != 0 && !r2_32) || elem_first > d || elem_count > d - elem_first)
+            return fail(ROFL_BAD_PARAM, "bad parameter");
+        return sigma_create(kind, values + elem_first, elem_count, r1_32 + 32 * elem_first, elem_count, r2_32 ? r2_32 + 32 * elem_first : nullptr,
+                            existing32 ? existing32 + 32 * elem_first : nullptr, fp_bits, fp_frac, nonce, proofs_out, commits_out, elem_first, d); });
+}
 int rofl_create_squareproof_vec(const float *values, size_t d, const uint8_t *r1_32, size_t d_r1, const uint8_t *r2_32, const uint8_t *existing32,
                                 unsigned fp_bits, unsigned fp_frac, const rofl_nonce_t *nonce, uint8_t *proofs_out, uint8_t *commits_out) {
-    return guarded([&]() -> int { return sigma_create(2, values, d, r1_32, d_r1, r2_32, existing32, fp_bits, fp_frac, nonce, proofs_out, commits_out); });
+    return guarded([&]() -> int { return sigma_create_any(2, values, d, r1_32, d_r1, r2_32, existing32, fp_bits, fp_frac, nonce, proofs_out, commits_out); });
 }
 int rofl_verify_squareproof_vec(const uint8_t *proofs, const uint8_t *commits, size_t d, int *ok_out) {
-    return guarded([&]() -> int { return sigma_verify(2, proofs, commits, d, ok_out); });
+    return guarded([&]() -> int { return sigma_verify_any(2, proofs, commits, d, ok_out); });
 }
 int rofl_create_compressed_randproof(const float *values, size_t d, const uint8_t *r32, size_t d_r, const uint8_t *existing32, unsigned fp_bits, unsigned fp_frac,
                                      const rofl_nonce_t *nonce, uint8_t proof_out[128], uint8_t *pairs_out) {
@@ -1223,17 +1295,17 @@ int rofl_verify_compressed_randproof(const uint8_t proof[128], const uint8_t *pa
 }
 int rofl_create_randproof_vec(const float *values, size_t d, const uint8_t *r32, size_t d_r, const uint8_t *existing32, unsigned fp_bits, unsigned fp_frac,
                               const rofl_nonce_t *nonce, uint8_t *proofs_out, uint8_t *commits_out) {
-    return guarded([&]() -> int { return sigma_create(0, values, d, r32, d_r, nullptr, existing32, fp_bits, fp_frac, nonce, proofs_out, commits_out); });
+    return guarded([&]() -> int { return sigma_create_any(0, values, d, r32, d_r, nullptr, existing32, fp_bits, fp_frac, nonce, proofs_out, commits_out); });
 }
 int rofl_verify_randproof_vec(const uint8_t *proofs, const uint8_t *commits, size_t d, int *ok_out) {
-    return guarded([&]() -> int { return sigma_verify(0, proofs, commits, d, ok_out); });
+    return guarded([&]() -> int { return sigma_verify_any(0, proofs, commits, d, ok_out); });
 }
 int rofl_create_squarerandproof_vec(const float *values, size_t d, const uint8_t *r1_32, size_t d_r1, const uint8_t *r2_32, const uint8_t *existing32,
                                     unsigned fp_bits, unsigned fp_frac, const rofl_nonce_t *nonce, uint8_t *proofs_out, uint8_t *commits_out) {
-    return guarded([&]() -> int { return sigma_create(1, values, d, r1_32, d_r1, r2_32, existing32, fp_bits, fp_frac, nonce, proofs_out, commits_out); });
+    return guarded([&]() -> int { return sigma_create_any(1, values, d, r1_32, d_r1, r2_32, existing32, fp_bits, fp_frac, nonce, proofs_out, commits_out); });
 }
 int rofl_verify_squarerandproof_vec(const uint8_t *proofs, const uint8_t *commits, size_t d, int *ok_out) {
-    return guarded([&]() -> int { return sigma_verify(1, proofs, commits, d, ok_out); });
+    return guarded([&]() -> int { return sigma_verify_any(1, proofs, commits, d, ok_out); });
 }
 namespace {
 int sigma_batch_entry(int kind, size_t n_clients, const uint8_t *const *proofs, const uint8_t *const *commits, size_t d, int *ok_out, uint8_t *csq_sum_out32) {

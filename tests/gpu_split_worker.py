@@ -17,7 +17,41 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+def l2_main(nd):
+    """gpu_split_worker.py l2 <n_devices>: one L2 update (cfg 3: d = 25 000, 8-bit range leg at P = 4, square proofs, sum proof) on one device and
+    with its legs dealt to 2 .. n_devices logical devices: same bytes; verdicts; tamper."""
+    import rofl_project_code_amd as R
+    from rofl_project_code_amd import api, params
+    for k in range(1, nd):
+        api.map_device(k, 0)
+    R.set_device(0)
+    fp = (32, 7); d = 25000
+    rng = np.random.default_rng(31)
+    vals = (rng.integers(-3, 4, size=d) / 128.0).astype(np.float32)
+    r1 = rng.integers(0, 256, size=(d, 32), dtype=np.uint8); r1[:, 31] &= 0x0F
+    r2 = rng.integers(0, 256, size=(d, 32), dtype=np.uint8); r2[:, 31] &= 0x0F
+    one = params.EncParamsL2.encrypt(vals, r1, 8, 4, 32, nonce_seed=b"\x61" * 32, rand_scalars=r2, fp=fp)
+    assert one.verify(verifier_seed=b"\x02" * 32, fp=fp) is True
+    for k in sorted({2, nd}):
+        R.set_option("devices", (1 << k) - 1)
+        upd = params.EncParamsL2.encrypt(vals, r1, 8, 4, 32, nonce_seed=b"\x61" * 32, rand_scalars=r2, fp=fp)
+        for name in ("enc_values", "square_proofs", "range_proofs", "square_range_proof"):
+            assert (getattr(upd, name) == getattr(one, name)).all(), "%s differs on %d devices" % (name, k)
+        assert upd.verify(verifier_seed=b"\x03" * 32, fp=fp) is True
+        bad = params.EncParamsL2(upd.enc_values, upd.square_proofs.copy(), upd.range_proofs, upd.square_range_proof, upd.prove_range, upd.l2_prove_range)
+        bad.square_proofs[d - 3, 100] ^= 1      # an element of the LAST run
+        assert bad.verify(verifier_seed=b"\x03" * 32, fp=fp) is False
+        pr, cm = R.square_rand_proof_vec.create_l2rangeproof_vec(vals, r1, r2, nonce=R.Nonce.seeded(b"\x62" * 32), fp=fp)      # the vector call itself, split
+        R.set_option("devices", 0)
+        pr1, cm1 = R.square_rand_proof_vec.create_l2rangeproof_vec(vals, r1, r2, nonce=R.Nonce.seeded(b"\x62" * 32), fp=fp)
+        assert (pr == pr1).all() and (cm == cm1).all()
+        assert R.square_rand_proof_vec.verify_l2rangeproof_vec(pr, cm) is True
+    print("split ok: L2 update of d=%d on 1, 2 and %d devices: same bytes" % (d, nd))
+
+
 def main():
+    if sys.argv[1] == "l2":
+        return l2_main(int(sys.argv[2]))
     case, nd, P = np.load(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
     import rofl_project_code_amd as R
     from rofl_project_code_amd import api

@@ -132,3 +132,54 @@ def test_cfg2_e2e_partition_chunks_over_logical_devices(full_oracle, tmp_path, n
     npz = str(tmp_path / "cfg2_p64.npz")
     np.savez(npz, vals=c["vals"], bl=c["bl"], seed=np.frombuffer(c["seed"], np.uint8), nb=nb, fp=np.array(c["fp"]), ochunk_idx=np.array(idx), ochunk_proofs=np.stack(proofs))
     _run_worker(npz, nd, 64)
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_sigma_vector_runs_of_elements_reproduce_the_unsplit_call(R, kind):
+    """The per-element Sigma-proofs of a vector are independent (rand_proof_vec/mod.rs:45-58, square_rand_proof_vec/mod.rs:45-58): runs of
+    elements proved by rofl_create_sigmaproof_vec_range concatenate to the bytes of the unsplit call -- and of the oracle --, seeded and with an
+    explicit nonce stream, with and without existing commitments; every run verifies on its own sub-arrays."""
+    from rofl_project_code_amd import api
+    fp = (32, 7); d = 333
+    rng = np.random.default_rng(900 + kind)
+    vals = (rng.integers(-400, 400, size=d) / 128.0).astype(np.float32)
+    r1, r2 = orc.rand_scalars(rng, d), orc.rand_scalars(rng, d)
+    nn = 2 if kind == 0 else 3
+    mods = {0: R.rand_proof_vec, 1: R.square_rand_proof_vec, 2: R.square_proof_vec}
+    def whole(nonce, existing):
+        if kind == 0:
+            return R.rand_proof_vec.create_randproof_vec(vals, r1, nonce=nonce, existing=existing, fp=fp)
+        return mods[kind].create_l2rangeproof_vec(vals, r1, r2, nonce=nonce, existing=existing, fp=fp)
+    verify = {0: R.rand_proof_vec.verify_randproof_vec, 1: R.square_rand_proof_vec.verify_l2rangeproof_vec, 2: R.square_proof_vec.verify_l2rangeproof_vec}[kind]
+    stream = rng.integers(0, 256, size=(nn * d, 64), dtype=np.uint8)
+    for nonce_of, okw in ((lambda: R.Nonce.seeded(b"\x33" * 32), dict(seed=b"\x33" * 32)), (lambda: R.Nonce.stream(stream), dict(stream=stream))):
+        pr, cm = whole(nonce_of(), None)
+        rc, opr, ocm = orc.sigma_create(kind, vals, r1, r2 if kind else None, fp[0], fp[1], **okw)
+        assert rc == 0 and (opr == pr).all() and (ocm == cm).all()
+        for existing in (None, cm[:, :32].copy()):
+            want_p, want_c = whole(nonce_of(), existing)
+            for cuts in ([0, d], [0, 1, d], [0, 100, 101, 250, d]):
+                ps, cs = [], []
+                for a, b in zip(cuts[:-1], cuts[1:]):
+                    p, c = api.create_sigmaproof_vec_range(kind, vals, r1, r2 if kind else None, a, b - a, nonce=nonce_of(), existing=existing, fp=fp)
+                    assert verify(p, c) is True
+                    ps.append(p); cs.append(c)
+                assert (np.concatenate(ps) == want_p).all() and (np.concatenate(cs) == want_c).all(), (kind, cuts, existing is not None)
+    bad = pr[100:250].copy(); bad[7, 70] ^= 1
+    assert verify(bad, cm[100:250]) is False
+    with pytest.raises(R.RoflError) as e:
+        api.create_sigmaproof_vec_range(kind, vals, r1, r2 if kind else None, 300, 40, nonce=R.Nonce.seeded(b"\x01" * 32), fp=fp)
+    assert e.value.code == 11
+    with pytest.raises(R.RoflError) as e:      # a stream too short for the VECTOR is refused whichever run is asked for
+        api.create_sigmaproof_vec_range(kind, vals, r1, r2 if kind else None, 0, 10, nonce=R.Nonce.stream(stream[:-1]), fp=fp)
+    assert e.value.code == 12
+
+
+def test_l2_update_over_logical_devices(tmp_path):
+    """BASELINE cfg 3 with ONE client over 2 and 4 devices: EncParamsL2.encrypt / verify (rofl_service/src/flserver/params.rs:608-646, 204-232) under
+    rofl_set_option("devices") -- the 8-bit range leg split by chunks, the square proofs by runs of elements -- returns the bytes of the one-device
+    update, which verify on one device and split; a tampered square proof fails."""
+    env = dict(os.environ); env.pop("ROFL_DEVICE_MAP", None)
+    env.update({"ROFL_FOLD_TAB_MB": "2048", "ROFL_LANES": "3"})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "gpu_split_worker.py"), "l2", "4"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "split ok:" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]

@@ -39,7 +39,7 @@ def l2_main(nd):
             assert (getattr(upd, name) == getattr(one, name)).all(), "%s differs on %d devices" % (name, k)
         assert upd.verify(verifier_seed=b"\x03" * 32, fp=fp) is True
         bad = params.EncParamsL2(upd.enc_values, upd.square_proofs.copy(), upd.range_proofs, upd.square_range_proof, upd.prove_range, upd.l2_prove_range)
-        bad.square_proofs[d - 3, 100] ^= 1      # an element of the LAST run
+        bad.square_proofs[d - 3, 130] ^= 1      # a response scalar of an element of the LAST run
         assert bad.verify(verifier_seed=b"\x03" * 32, fp=fp) is False
         pr, cm = R.square_rand_proof_vec.create_l2rangeproof_vec(vals, r1, r2, nonce=R.Nonce.seeded(b"\x62" * 32), fp=fp)      # the vector call itself, split
         R.set_option("devices", 0)

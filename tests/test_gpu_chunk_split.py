@@ -165,7 +165,7 @@ def test_sigma_vector_runs_of_elements_reproduce_the_unsplit_call(R, kind):
                     assert verify(p, c) is True
                     ps.append(p); cs.append(c)
                 assert (np.concatenate(ps) == want_p).all() and (np.concatenate(cs) == want_c).all(), (kind, cuts, existing is not None)
-    bad = pr[100:250].copy(); bad[7, 70] ^= 1
+    bad = pr[100:250].copy(); bad[7, bad.shape[1] - 60] ^= 1      # a response scalar (a flipped point byte would be the vector's FormatError)
     assert verify(bad, cm[100:250]) is False
     with pytest.raises(R.RoflError) as e:
         api.create_sigmaproof_vec_range(kind, vals, r1, r2 if kind else None, 300, 40, nonce=R.Nonce.seeded(b"\x01" * 32), fp=fp)

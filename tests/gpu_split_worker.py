@@ -38,6 +38,9 @@ def l2_main(nd):
         for name in ("enc_values", "square_proofs", "range_proofs", "square_range_proof"):
             assert (getattr(upd, name) == getattr(one, name)).all(), "%s differs on %d devices" % (name, k)
         assert upd.verify(verifier_seed=b"\x03" * 32, fp=fp) is True
+        used = [j for j in range(k) if (R.set_device(j), api.bp_gens_table_bytes(8, 32768 // 4))[1] > 0]      # the 8-bit leg's four chunks went to min(k, 4) devices
+        R.set_device(0)
+        assert len(used) == min(k, 4), used
         bad = params.EncParamsL2(upd.enc_values, upd.square_proofs.copy(), upd.range_proofs, upd.square_range_proof, upd.prove_range, upd.l2_prove_range)
         bad.square_proofs[d - 3, 130] ^= 1      # a response scalar of an element of the LAST run
         assert bad.verify(verifier_seed=b"\x03" * 32, fp=fp) is False

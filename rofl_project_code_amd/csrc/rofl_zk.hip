@@ -421,10 +421,22 @@ class ShardWorkers {
     std::mutex mu; std::map<int, std::unique_ptr<W>> ws;
 public:
     struct Ticket { bool ok = false; int dev = 0; uint64_t id = 0; };
+    // Up to kPerDevice workers per device: the three legs of ONE L2 update (range proof by chunks, square proofs by elements, their verifiers)
+    // split over the devices at the same time, and a leg's share of a device must not wait behind another leg's.  A job goes to an idle
+    // worker of its device when there is one (created on demand), otherwise to the one with the shortest queue.
+    static constexpr int kPerDevice = 3;
     Ticket submit(int dev, std::function<void()> job) {
-        W *w = nullptr;
+        W *w = nullptr; int key = dev * kPerDevice;
         {   std::lock_guard<std::mutex> lk(mu);
-            auto it = ws.find(dev);
+            size_t best_load = ~(size_t)0;
+            for (int sl = 0; sl < kPerDevice; sl++) {
+                auto f = ws.find(dev * kPerDevice + sl);
+                if (f == ws.end()) { if (best_load) { key = dev * kPerDevice + sl; best_load = 0; } break; }      // a worker that does not exist yet is idle
+                size_t load; { std::lock_guard<std::mutex> lk2(f->second->mu); load = (size_t)(f->second->next_id - 1 - f->second->done_id); }
+                if (load < best_load) { best_load = load; key = dev * kPerDevice + sl; }
+                if (load == 0) break;
+            }
+            auto it = ws.find(key);
             if (it == ws.end()) {
                 std::unique_ptr<W> nw(new W());
                 W *raw = nw.get();
@@ -439,11 +451,11 @@ public:
                         }
                     });
                 } catch (...) { return Ticket{}; }      // EAGAIN / bad_alloc: reported by the caller as an error code
-                it = ws.emplace(dev, std::move(nw)).first;
+                it = ws.emplace(key, std::move(nw)).first;
             }
             w = it->second.get();
         }
-        Ticket t; t.ok = true; t.dev = dev;
+        Ticket t; t.ok = true; t.dev = key;
         { std::lock_guard<std::mutex> lk(w->mu); t.id = w->next_id++; w->q.emplace_back(t.id, std::move(job)); }
         w->cv.notify_all();
         return t;

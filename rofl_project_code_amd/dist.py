@@ -80,6 +80,42 @@ def split_verify(comm, rank, world, proofs, commits, m, verify_run, shift=1):
     return comm.all_verified(ok)
 
 
+def elem_runs(d, world, min_run=2048):
+    """[(first, count)] per rank for the ELEMENTS of a Sigma-proof vector (one proof per element, independent of the others:
+    rand_proof_vec/mod.rs:45-58): contiguous runs of at least min_run elements -- the deal of the library's one-process split; ranks
+    beyond d // min_run get (0, 0)."""
+    nd = max(1, min(world, d // min_run))
+    return [(k * d // nd, (k + 1) * d // nd - k * d // nd) for k in range(nd)] + [(0, 0)] * (world - nd)
+
+
+def split_create_elems(comm, rank, world, d, proof_len, commit_len, create_run, min_run=2048):
+    """create_run(first, count) -> (proofs u8[count, proof_len], commitments u8[count, commit_len]) -- e.g. api.create_sigmaproof_vec_range.
+    One all-gather; returns the whole vector's (proofs u8[d, proof_len], commitments u8[d, commit_len]) on every rank, byte for byte the
+    unsplit create_*_vec result."""
+    runs = elem_runs(d, world, min_run)
+    cmax = max(c for _, c in runs)
+    first, count = runs[rank]
+    buf_p = np.zeros((cmax, proof_len), np.uint8); buf_c = np.zeros((cmax, commit_len), np.uint8)
+    if count:
+        pr, cm = create_run(first, count)
+        buf_p[:count] = pr; buf_c[:count] = cm
+    _, per_rank = comm.exchange_round([buf_p, buf_c], True)
+    proofs = np.zeros((d, proof_len), np.uint8); commits = np.zeros((d, commit_len), np.uint8)
+    for r, (f, c) in enumerate(runs):
+        if c:
+            proofs[f:f + c] = per_rank[r][0].reshape(cmax, proof_len)[:c]
+            commits[f:f + c] = per_rank[r][1].reshape(cmax, commit_len)[:c]
+    return proofs, commits
+
+
+def split_verify_elems(comm, rank, world, proofs, commits, verify_run, shift=1, min_run=2048):
+    """verify_run(proofs_run, commits_run) -> bool -- the ordinary verify_*_vec call on a run's sub-arrays.  Rank r checks the run of rank
+    r + shift; the vector's verdict is the MIN over the ranks."""
+    first, count = elem_runs(proofs.shape[0], world, min_run)[(rank + shift) % world]
+    ok = bool(verify_run(proofs[first:first + count], commits[first:first + count])) if count else True
+    return comm.all_verified(ok)
+
+
 _round_bufs = {}
 
 

@@ -230,6 +230,28 @@ def test_split_helpers_with_more_ranks_than_chunks():
         for t in ths: t.start()
         for t in ths: t.join()
         assert not errs, errs
+        if n_chunks == 4 and d == 25000:      # the same for the ELEMENTS of a Sigma-proof vector (192-byte proofs, 96-byte commitments): runs of >= 2 048
+            ep = rng.integers(0, 256, size=(d, 192), dtype=np.uint8); ec = rng.integers(0, 256, size=(d, 96), dtype=np.uint8)
+            assert rd.elem_runs(5000, 8) == [(0, 2500), (2500, 2500)] + [(0, 0)] * 6 and rd.elem_runs(100, 4) == [(0, 100)] + [(0, 0)] * 3
+            eout, eerrs = {}, []
+
+            def elem_main(r):
+                try:
+                    comm = ThreadComm(shared, r, world)
+                    p, c = rd.split_create_elems(comm, r, world, d, 192, 96, lambda f, n: (ep[f:f + n], ec[f:f + n]))
+                    chk = lambda pr, cm: bool(any((pr == ep[f:f + pr.shape[0]]).all() and (cm == ec[f:f + pr.shape[0]]).all() for f, _ in rd.elem_runs(d, world)))
+                    ok = rd.split_verify_elems(comm, r, world, p, c, chk)
+                    bad = p.copy(); bad[d - 1, 3] ^= 1
+                    eout[r] = (p, c, ok, rd.split_verify_elems(comm, r, world, bad, c, chk))
+                except BaseException as e:      # noqa: BLE001
+                    eerrs.append(e); shared["bar"].abort()
+
+            ths = [threading.Thread(target=elem_main, args=(r,)) for r in range(world)]
+            for t in ths: t.start()
+            for t in ths: t.join()
+            assert not eerrs, eerrs
+            for r in range(world):
+                assert (eout[r][0] == ep).all() and (eout[r][1] == ec).all() and eout[r][2] is True and eout[r][3] is False
         runs = rd.chunk_runs(n_chunks, world)
         assert sum(c for _, c in runs) == n_chunks and sorted(created) == sorted((r, f, c) for r, (f, c) in enumerate(runs) if c)
         assert len([x for x in checked]) == 2 * len([1 for _, c in runs if c])      # every run checked once per split_verify call

@@ -2384,15 +2384,16 @@ __global__ void __launch_bounds__(64) k_sigma_prove(int kind, u32 d, const float
 // 55 000 alone on the chip); blockIdx.y = the slot, so a block's threads run the same formula, a vector is 4-6x as many threads of a
 // fifth of the length, and the transcript + responses (scalar arithmetic, k_sigma_finish) read the encoded bytes back.  Same formulas,
 // same nonce indices, same bytes.
-enum { SG_L = 0, SG_LCHK = 1, SG_R = 2, SG_CSQ = 3, SG_LP = 4, SG_RP = 5, SG_CSQP = 6 };
+enum { SG_L = 0, SG_LCHK = 1, SG_R = 2, SG_CSQ = 3, SG_LP = 4, SG_RP = 5, SG_CSQP = 6, SG_CSQP_F = 7, SG_LCMP = 8 };
 struct SgSlots { int n; int id[6]; };
 // (two kernels: the slots that are fixed-base multiplications + one encoding, and c_sq' with its variable-base multiplication and its 1 KB
 //  table in scratch -- in one kernel every slot would be given the registers and the scratch of the largest)
 template <bool VAR> __device__ __forceinline__ void sigma_point_body(int kind, int slot, u32 d, const float *vals, u32 fp_bits, u32 fp_frac, const sc *r1c, const sc *r2c,
                                                                     const uint8_t *existing, int mode, const NonceSeed &seed, const uint8_t *stream, u64 stream_scalars, u64 nonce_base,
-                                                                    const niels *tabB, const niels *tabBb, uint8_t *proofs, uint8_t *commits, u32 *status) {
+                                                                    const niels *tabB, const niels *tabBb, uint8_t *proofs, uint8_t *commits, u32 *status, uint8_t *slow_mark) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= d) return;
+    if (VAR && slow_mark && !slow_mark[i]) return;      // (the fixed-base form of c_sq' stands: see SG_CSQP_F)
     bool has_R = kind != 2, has_sq = kind != 0;
     u32 npts = 1 + (has_R ? 1 : 0) + (has_sq ? 1 : 0), nn = has_sq ? 3 : 2, clen = 32 * npts, plen = 32 * (npts + nn), sq_off = has_R ? 64 : 32;
     float v = vals[i];
@@ -2410,28 +2411,40 @@ template <bool VAR> __device__ __forceinline__ void sigma_point_body(int kind, i
     }
     if (slot == SG_LCHK) { gd L; if (!sg_decode(L, existing + (size_t)32 * i)) atomicOr(status, 4u); return; }
     // every other slot: a B + b Bb (b may be absent), encoded
-    sc a, b; bool two = true; uint8_t *out;
-    if (slot == SG_L) { a = sg_f32_to_sc(v, fp_bits, fp_frac); b = load_sc_reduced(&r1c[i]); out = cm; }
+    // SG_CSQP_F: c_sq' = m' L + r2' Bb WITHOUT the variable-base multiplication -- the prover knows the opening of L = m B + r1 Bb (they are its own
+    // inputs), so m' L = (m' m) B + (m' r1) Bb and c_sq' = (m' m) B + (m' r1 + r2') Bb: two fixed-base multiplications (128 mixed additions) instead of
+    // a decoding, ~320 point operations on a table in scratch and one fixed-base multiplication.  A commitment that is HANDED IN (prove_existing) is
+    // what the reference multiplies (square_rand_proof/party.rs: c_sq' = m' * c.L + ...): SG_LCMP recomputes m B + r1 Bb, compares its encoding with
+    // the bytes handed in, and marks the element when they differ -- k_sigma_point_var then redoes exactly those elements the reference's way
+    // (an inconsistent commitment gives a proof that does not verify either way, but its BYTES stay the reference's).
+    sc a, b; bool two = true; uint8_t *out = nullptr;
+    if (slot == SG_CSQP_F) { sc m = sg_f32_to_sc(v, fp_bits, fp_frac), n0 = nonce(0); a = sc_mul_plain(n0, m); b = sc_add(sc_mul_plain(n0, load_sc_reduced(&r1c[i])), nonce(2)); out = pf + sq_off; }
+    else if (slot == SG_LCMP) { a = sg_f32_to_sc(v, fp_bits, fp_frac); b = load_sc_reduced(&r1c[i]); }
+    else if (slot == SG_L) { a = sg_f32_to_sc(v, fp_bits, fp_frac); b = load_sc_reduced(&r1c[i]); out = cm; }
     else if (slot == SG_R) { a = load_sc_reduced(&r1c[i]); b = sc_zero(); two = false; out = cm + 32; }
     else if (slot == SG_CSQ) { sc m = sg_f32_to_sc(v, fp_bits, fp_frac); a = sc_mul_plain(m, m); b = load_sc_reduced(&r2c[i]); out = cm + sq_off; }
     else if (slot == SG_LP) { a = nonce(0); b = nonce(1); out = pf; }
     else { a = nonce(1); b = sc_zero(); two = false; out = pf + 32; }      // SG_RP
     gd P = sg_fixed_mul(tabB, a);
     if (two) P = gd_add(P, sg_fixed_mul(tabBb, b));
-    sg_encode(out, P);
+    if (slot == SG_LCMP) {
+        uint8_t tmp[32]; sg_encode(tmp, P);
+        bool same = true; for (int q = 0; q < 32; q++) same &= tmp[q] == existing[(size_t)32 * i + q];
+        if (!same) slow_mark[i] = 1;
+    } else sg_encode(out, P);
 }
 #if ROFL_KG(2)
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) k_sigma_points(int kind, SgSlots slots, u32 d, const float *vals, u32 fp_bits, u32 fp_frac, const sc *r1c, const sc *r2c,
                                                      const uint8_t *existing, int mode, NonceSeed seed, const uint8_t *stream, u64 stream_scalars, u64 nonce_base,
-                                                     const niels *tabB, const niels *tabBb, uint8_t *proofs, uint8_t *commits, u32 *status) {
-    sigma_point_body<false>(kind, slots.id[blockIdx.y], d, vals, fp_bits, fp_frac, r1c, r2c, existing, mode, seed, stream, stream_scalars, nonce_base, tabB, tabBb, proofs, commits, status);
+                                                     const niels *tabB, const niels *tabBb, uint8_t *proofs, uint8_t *commits, u32 *status, uint8_t *slow_mark) {
+    sigma_point_body<false>(kind, slots.id[blockIdx.y], d, vals, fp_bits, fp_frac, r1c, r2c, existing, mode, seed, stream, stream_scalars, nonce_base, tabB, tabBb, proofs, commits, status, slow_mark);
 }
 #endif
 #if ROFL_KG(3)
 __global__ void __launch_bounds__(64) k_sigma_point_var(int kind, u32 d, const float *vals, u32 fp_bits, u32 fp_frac, const sc *r1c, const sc *r2c,
                                                         const uint8_t *existing, int mode, NonceSeed seed, const uint8_t *stream, u64 stream_scalars, u64 nonce_base,
-                                                        const niels *tabB, const niels *tabBb, uint8_t *proofs, uint8_t *commits, u32 *status) {
-    sigma_point_body<true>(kind, SG_CSQP, d, vals, fp_bits, fp_frac, r1c, r2c, existing, mode, seed, stream, stream_scalars, nonce_base, tabB, tabBb, proofs, commits, status);
+                                                        const niels *tabB, const niels *tabBb, uint8_t *proofs, uint8_t *commits, u32 *status, uint8_t *slow_mark) {
+    sigma_point_body<true>(kind, SG_CSQP, d, vals, fp_bits, fp_frac, r1c, r2c, existing, mode, seed, stream, stream_scalars, nonce_base, tabB, tabBb, proofs, commits, status, slow_mark);
 }
 #endif
 #if ROFL_KG(4)

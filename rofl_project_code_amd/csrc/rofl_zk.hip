@@ -922,20 +922,20 @@ int sigma_create(int kind, const float *values, size_t d, const uint8_t *r1, siz
       static const bool split = !(knob("ROFL_SIGMA_SPLIT") && atoi(knob("ROFL_SIGMA_SPLIT")) == 0);
       if (split) {      // one thread per point (blockIdx.y = slot; c_sq' -- the variable-base one -- as a launch of its own on the side stream), then transcripts + responses per element
           SgSlots sl{}; auto add = [&](int id) { sl.id[sl.n++] = id; };
-          if (!dex) add(SG_L); else if (!has_sq) add(SG_LCHK);             // (with c_sq' in the list the commitment handed in is decoded -- and checked -- there)
-          if (has_sq) add(SG_CSQ);
+          // c_sq' in its fixed-base form (SG_CSQP_F: the prover knows the opening of L); a commitment handed in is compared with m B + r1 Bb first
+          // (SG_LCMP) and the elements where it differs -- none, unless the caller's commitments are not the values' -- are redone by
+          // k_sigma_point_var exactly as the reference computes them
+          uint8_t *marks = nullptr;
+          if (has_sq && dex) { marks = C.vspart.as<uint8_t>(d); HIPCHK(hipMemsetAsync(marks, 0, d, C.stream)); }
+          if (!dex) add(SG_L); else add(has_sq ? SG_LCMP : SG_LCHK);
+          if (has_sq) { add(SG_CSQP_F); add(SG_CSQ); }
           add(SG_LP);
           if (kind != 2) { add(SG_R); add(SG_RP); }
-          if (has_sq) {
-              if (!C.stream2) HIPCHK(hipStreamCreateWithFlags(&C.stream2, hipStreamNonBlocking));
-              HIPCHK(hipEventRecord(C.pool_event(0), C.stream)); HIPCHK(hipStreamWaitEvent(C.stream2, C.pool_event(0), 0));      // inputs uploaded
-              ROFL_LAUNCH(k_sigma_point_var, dim3((unsigned)((d + 63) / 64)), dim3(64), 0, C.stream2, kind, (u32)d, dv, fp_bits, fp_frac, dr1, dr2, dex,
-                          nonce->mode, seed, d_stream, ss, nonce_base, C.d_tabB, C.d_tabBb, dp, dc, status);
-              HIPCHK(hipEventRecord(C.pool_event(1), C.stream2));
-          }
           ROFL_LAUNCH(k_sigma_points, dim3((unsigned)((d + 63) / 64), (unsigned)sl.n), dim3(64), 0, C.stream, kind, sl, (u32)d, dv, fp_bits, fp_frac, dr1, dr2, dex,
-                      nonce->mode, seed, d_stream, ss, nonce_base, C.d_tabB, C.d_tabBb, dp, dc, status);
-          if (has_sq) HIPCHK(hipStreamWaitEvent(C.stream, C.pool_event(1), 0));
+                      nonce->mode, seed, d_stream, ss, nonce_base, C.d_tabB, C.d_tabBb, dp, dc, status, marks);
+          if (marks)
+              ROFL_LAUNCH(k_sigma_point_var, dim3((unsigned)((d + 63) / 64)), dim3(64), 0, C.stream, kind, (u32)d, dv, fp_bits, fp_frac, dr1, dr2, dex,
+                          nonce->mode, seed, d_stream, ss, nonce_base, C.d_tabB, C.d_tabBb, dp, dc, status, marks);
           ROFL_LAUNCH(k_sigma_finish, grid1(d), dim3(TPB), 0, C.stream, kind, (u32)d, dv, fp_bits, fp_frac, dr1, dr2, dex, nonce->mode, seed, d_stream, ss, nonce_base,
                       sigma_init_state(kind), dp, dc, status);
       } else

@@ -423,6 +423,45 @@ def test_sigma_proofs_bit_exact(R, kind, d, fb, ff):
     R.api.set_fp(16, 7)
 
 
+@pytest.mark.parametrize("kind", [1, 2])
+def test_square_proofs_with_commitments_that_are_not_the_values(R, kind):
+    """square_rand_proof/party.rs (prove_existing): c_sq' = m' * L of the commitment HANDED IN.  The HIP path computes c_sq' from the opening it knows
+    when the handed-in bytes ARE m B + r1 Bb, and the reference's way (decode, variable-base multiplication) for every element where they are not:
+    the proof bytes equal the oracle's for consistent, inconsistent (another value's, another blinding's, the identity) and mixed inputs, and an
+    invalid encoding is the reference's FormatError."""
+    R.api.set_fp(16, 7)
+    rng = np.random.default_rng(4242 + kind)
+    d = 300
+    vals = rng.uniform(-3, 3, size=d).astype(np.float32)
+    r1, r2 = orc.rand_scalars(rng, d), orc.rand_scalars(rng, d)
+    seed = bytes(rng.integers(0, 256, 32, dtype=np.uint8))
+    M = R.square_rand_proof_vec if kind == 1 else R.square_proof_vec
+    good = R.pedersen_ops.commit_vec(R.conversion32.f32_to_scalar_vec(vals), r1)
+    ex = good.copy()
+    ex[3] = good[4]                                                                   # another element's commitment
+    ex[70] = R.pedersen_ops.commit_vec(R.conversion32.f32_to_scalar_vec(vals[70:71]), r2[70:71])[0]   # the value under another blinding
+    ex[64] = 0                                                                        # the identity
+    ex[255:270] = good[100:115]                                                       # a run of them across a 64-thread block boundary
+    ex[d - 1] = R.pedersen_ops.commit_no_blinding_vec(r1[:1])[0]
+    for name, e_ in (("consistent", good), ("mixed", ex), ("all wrong", np.roll(good, 1, axis=0))):
+        rc, opr, ocm = orc.sigma_create(kind, vals, r1, r2, 16, 7, seed=seed, existing=e_)
+        pr, cm = M.create_l2rangeproof_vec_existing(vals, e_, r1, r2, nonce=R.Nonce.seeded(seed))
+        assert rc == 0 and (pr == opr).all() and (cm == ocm).all(), name
+        assert M.verify_l2rangeproof_vec(pr, cm) is (name == "consistent") and orc.sigma_verify(kind, pr, cm) == (0, name == "consistent")
+    # the runs of elements of a split client see the same marks (ranges that start and end inside the run of wrong commitments)
+    if kind == 1:
+        rc, opr, ocm = orc.sigma_create(kind, vals, r1, r2, 16, 7, seed=seed, existing=ex)
+        for a, b in ((0, 66), (66, 260), (260, d)):
+            p_, c_ = R.api.create_sigmaproof_vec_range(kind, vals, r1, r2, a, b - a, nonce=R.Nonce.seeded(seed), existing=ex)
+            assert (p_ == opr[a:b]).all() and (c_ == ocm[a:b]).all(), (a, b)
+    bad = good.copy(); bad[17] = 0xFF                                                  # not a canonical field element
+    rc, _, _ = orc.sigma_create(kind, vals, r1, r2, 16, 7, seed=seed, existing=bad)
+    with pytest.raises(R.RoflError) as e:
+        M.create_l2rangeproof_vec_existing(vals, bad, r1, r2, nonce=R.Nonce.seeded(seed))
+    assert rc == e.value.code == 5
+    R.api.set_fp(16, 7)
+
+
 def test_sigma_reference_semantics(R):
     """l2_range_proof_vec/mod.rs:539-561: sum of the c_sq of the square proofs == the L2 range-proof commitment;
     square_rand_proof_vec/mod.rs:195-208: existing round trip; wrong lengths -> WrongNumBlindingFactors."""

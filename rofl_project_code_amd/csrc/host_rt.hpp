@@ -553,7 +553,7 @@ struct Ctx {
     std::vector<hipEvent_t> heavy_ev; size_t heavy_k = 0;  // ring of fork / join events of the heavy launches
     std::mutex mu;
     HostTables ht;
-    niels *d_tabB = nullptr, *d_tabBb = nullptr;
+    niels *d_tabB = nullptr, *d_tabBb = nullptr, *d_tabB8 = nullptr, *d_tabBb8 = nullptr;      // radix-16 (64 x 8) and radix-256 (32 x 128) fixed-base tables of B and B~
     sc *d_two_pow = nullptr;
     std::map<std::pair<size_t, size_t>, std::unique_ptr<GensEntry>> gens;   // (n, m) -> tables; primary lane only, under gens_mu
     std::vector<std::unique_ptr<GensEntry>> gens_retired;                  // fast-start entries that were replaced while calls still read them (freed when unpinned)
@@ -656,6 +656,11 @@ struct Ctx {
         HIPCHK(hipMalloc(&d_tabBb, sizeof(niels) * 512));
         HIPCHK(hipMemcpy(d_tabB, ht.B.data(), sizeof(niels) * 512, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(d_tabBb, ht.Bb.data(), sizeof(niels) * 512, hipMemcpyHostToDevice));
+        HIPCHK(hipMalloc(&d_tabB8, sizeof(niels) * 4096));
+        HIPCHK(hipMalloc(&d_tabBb8, sizeof(niels) * 4096));
+        ROFL_LAUNCH(k_fixed_tab8, dim3(64), dim3(64), 0, 0, (const niels *)d_tabB, d_tabB8);
+        ROFL_LAUNCH(k_fixed_tab8, dim3(64), dim3(64), 0, 0, (const niels *)d_tabBb, d_tabBb8);
+        HIPCHK(hipDeviceSynchronize());
         sc tp[64]; sc two = h_mont(sc_from_u64(2)); tp[0] = sc_one_mont();
         for (int i = 1; i < 64; i++) tp[i] = sc_montmul(tp[i - 1], two);
         HIPCHK(hipMalloc(&d_two_pow, sizeof(tp)));
@@ -704,7 +709,7 @@ struct Ctx {
         HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));      // (with the main stream: see init)
         HIPCHK(hipStreamCreateWithFlags(&stream_up, hipStreamNonBlocking));
-        ht = p.ht; d_tabB = p.d_tabB; d_tabBb = p.d_tabBb; d_two_pow = p.d_two_pow;
+        ht = p.ht; d_tabB = p.d_tabB; d_tabBb = p.d_tabBb; d_tabB8 = p.d_tabB8; d_tabBb8 = p.d_tabBb8; d_two_pow = p.d_two_pow;
         msm_lds = p.msm_lds; msm_two_level = p.msm_two_level; msm_group_reduce = p.msm_group_reduce; msm_lds_min = p.msm_lds_min; msm_lds_tile = p.msm_lds_tile;
         msm_fb_threads = p.msm_fb_threads;
         msm_fb = p.msm_fb; msm_fb_min = p.msm_fb_min; msm_lr = p.msm_lr;

@@ -371,18 +371,19 @@ __global__ void __launch_bounds__(TPB) k_quantize_shift(const float *vals, u32 d
 #endif
 
 // ================================================================ K3: Pedersen commit (fixed-base)
-// tables: radix-16 signed digits, tab[w][e] = (e+1) * 16^w * P, w < 64, e < 8  (affine niels)
+// tables: radix-256 signed digits, tab[w][e] = (e+1) * 256^w * P, w < 32, e < 128  (affine niels; built by k_fixed_tab8 from the radix-16
+// table the per-element chains started with: half the mixed additions, the 393 KB of a base stay in L2)
 __device__ __forceinline__ gd fixed_base_mul_acc(gd acc, const niels *tab, const sc &k, int nwin) {
-    // k canonical (< 2^253 when nwin == 64 so the carry digit is zero)
+    // k canonical (< 2^253 when nwin == 32 so the carry digit is zero)
     int carry = 0;
     for (int i = 0; i < nwin; i++) {
-        int v = (int)((k.v[i >> 3] >> ((i & 7) * 4)) & 15) + carry;
-        carry = (v + 8) >> 4;
-        int dgt = v - (carry << 4);
+        int v = (int)((k.v[i >> 2] >> ((i & 3) * 8)) & 255) + carry;
+        carry = (v + 128) >> 8;
+        int dgt = v - (carry << 8);
         int ad = dgt < 0 ? -dgt : dgt;
-        if (ad) acc = gd_madd(acc, load_nd(&tab[i * 8 + ad - 1]), dgt < 0);
+        if (ad) acc = gd_madd(acc, load_nd(&tab[i * 128 + ad - 1]), dgt < 0);
     }
-    if (carry && nwin < 64) acc = gd_madd(acc, load_nd(&tab[nwin * 8 + 0]), false);
+    if (carry && nwin < 32) acc = gd_madd(acc, load_nd(&tab[nwin * 128 + 0]), false);
     return acc;
 }
 // V_j = v_j*B + r_j*Bb (compressed), and optionally C_j = V_j + shift (compressed)
@@ -396,9 +397,9 @@ __global__ void __launch_bounds__(TPB) k_commit(u32 count, const u64 *v64, const
     gd acc = gd_identity();
     // scalars arrive from the C ABI as 32 raw bytes: anything >= l is reduced (a dalek Scalar is always < l; the windows below
     // assume < 2^253)
-    if (v64) { sc v = sc_from_u64(v64[j]); acc = fixed_base_mul_acc(acc, tabB, v, 16); }
-    else { sc v = load_sc_reduced(&v256_canon[j]); acc = fixed_base_mul_acc(acc, tabB, v, 64); }
-    if (blind_canon) { sc r = load_sc_reduced(&blind_canon[j]); acc = fixed_base_mul_acc(acc, tabBb, r, 64); }
+    if (v64) { sc v = sc_from_u64(v64[j]); acc = fixed_base_mul_acc(acc, tabB, v, 8); }
+    else { sc v = load_sc_reduced(&v256_canon[j]); acc = fixed_base_mul_acc(acc, tabB, v, 32); }
+    if (blind_canon) { sc r = load_sc_reduced(&blind_canon[j]); acc = fixed_base_mul_acc(acc, tabBb, r, 32); }
     if (V_out) gd_ristretto_encode(V_out + (size_t)j * 32, acc);
     if (C_out && (j % c_period) < c_count) {
         gd cpt = shift ? gd_madd(acc, load_nd(shift), false) : acc;
@@ -2284,6 +2285,27 @@ __device__ inline gd sg_fixed_mul(const niels *tab, const sc &k) {     // k cano
     }
     return acc;
 }
+// the same with radix-256 signed digits: tab8[w][e] = (e+1) * 256^w * P, w < 32, e < 128 (393 KB per base, built once by k_fixed_tab8: gathers
+// from L2) -- 32 mixed additions instead of 64.  k canonical (< 2^253: the top digit takes the carry without overflowing)
+__device__ inline gd sg_fixed_mul8(const niels *tab8, const sc &k) {
+    gd acc = gd_identity(); int carry = 0;
+    for (int i = 0; i < 32; i++) {
+        int v = (int)((k.v[i >> 2] >> ((i & 3) * 8)) & 255) + carry;
+        carry = (v + 128) >> 8;
+        int dgt = v - (carry << 8), ad = dgt < 0 ? -dgt : dgt;
+        if (ad) acc = gd_madd(acc, load_nd(&tab8[i * 128 + ad - 1]), dgt < 0);
+    }
+    return acc;
+}
+#if ROFL_KG(2)
+__global__ void __launch_bounds__(64) k_fixed_tab8(const niels *tab4, niels *tab8) {
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x, w = t >> 7, e = t & 127;
+    if (w >= 32) return;
+    if (w == 31 && e >= 32) { store_niels(&tab8[t], load_niels(&tab4[0])); return; }      // (never read: the top digit of a canonical scalar is <= 32)
+    sc k = sc_zero(); k.v[w >> 2] = (e + 1) << ((w & 3) * 8);
+    store_niels(&tab8[t], gd_to_niels(sg_fixed_mul(tab4, k)));
+}
+#endif
 __device__ inline gd gd_neg(const gd &p) { gd r; r.X = fd_neg(p.X); r.Y = p.Y; r.Z = p.Z; r.T = fd_neg(p.T); return r; }
 // k * P, signed radix-16 windows, k canonical (< 2^253)
 __device__ inline gd sg_var_mul(const sc &k, const gd &P) {
@@ -2425,8 +2447,8 @@ template <bool VAR> __device__ __forceinline__ void sigma_point_body(int kind, i
     else if (slot == SG_CSQ) { sc m = sg_f32_to_sc(v, fp_bits, fp_frac); a = sc_mul_plain(m, m); b = load_sc_reduced(&r2c[i]); out = cm + sq_off; }
     else if (slot == SG_LP) { a = nonce(0); b = nonce(1); out = pf; }
     else { a = nonce(1); b = sc_zero(); two = false; out = pf + 32; }      // SG_RP
-    gd P = sg_fixed_mul(tabB, a);
-    if (two) P = gd_add(P, sg_fixed_mul(tabBb, b));
+    gd P = sg_fixed_mul8(tabB, a);                      // (k_sigma_points is handed the radix-256 tables, k_sigma_point_var the radix-16 ones)
+    if (two) P = gd_add(P, sg_fixed_mul8(tabBb, b));
     if (slot == SG_LCMP) {
         uint8_t tmp[32]; sg_encode(tmp, P);
         bool same = true; for (int q = 0; q < 32; q++) same &= tmp[q] == existing[(size_t)32 * i + q];
@@ -2605,8 +2627,8 @@ __global__ void __launch_bounds__(64) k_eg_pairs(u32 d, const float *vals, u32 f
     sc m = sg_f32_to_sc(v, fp_bits, fp_frac), r = load_sc_reduced(&rc[i]);
     uint8_t *o = pairs + (size_t)64 * i;
     if (existing) { gd L; if (!sg_decode(L, existing + (size_t)32 * i)) { atomicOr(status, 4u); return; } for (int q = 0; q < 32; q++) o[q] = existing[(size_t)32 * i + q]; }
-    else sg_encode(o, gd_add(sg_fixed_mul(tabB, m), sg_fixed_mul(tabBb, r)));
-    sg_encode(o + 32, sg_fixed_mul(tabB, r));
+    else sg_encode(o, gd_add(sg_fixed_mul8(tabB, m), sg_fixed_mul8(tabBb, r)));      // (radix-256 tables)
+    sg_encode(o + 32, sg_fixed_mul8(tabB, r));
 }
 #endif
 // partial sums of m_i c^(i+1) and r_i c^(i+1)  -> out[blk][2] (Montgomery);  cpow2[b] = c^(2^b) (Montgomery)

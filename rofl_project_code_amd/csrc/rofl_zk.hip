@@ -232,8 +232,8 @@ int create_impl(Ctx &C, size_t nc, const float *const *values, size_t d, const u
     HIPCHK(hipEventRecord(C.ev_fork, C.stream));                  // inputs quantised (and compacted)
     HIPCHK(hipStreamWaitEvent(C.stream2, C.ev_fork, 0));
     HIPCHK(hipMemcpyAsync(d_shift, &h_shift, sizeof(niels), hipMemcpyHostToDevice, C.stream2));
-    { KSpan ks(C.tm, C.stream2, ROFL_TK_CODEC, (uint64_t)na * dp * (2 * 64 * 7 + 2 * 265), (uint64_t)na * dp * (8 + 32 + 64));
-    ROFL_LAUNCH(k_commit, grid1(na * dp), dim3(TPB), 0, C.stream2, (u32)(na * dp), vshift, (const sc *)nullptr, d_blind_buf, C.d_tabB, C.d_tabBb, d_shift, Vb, Cb, (u32)d, (u32)dp); }
+    { KSpan ks(C.tm, C.stream2, ROFL_TK_CODEC, (uint64_t)na * dp * ((8 + 1 + 32) * 7 + 2 * 265), (uint64_t)na * dp * (8 + 32 + 64));      // 8 + carry + 32 radix-256 windows, two encodings
+    ROFL_LAUNCH(k_commit, grid1(na * dp), dim3(TPB), 0, C.stream2, (u32)(na * dp), vshift, (const sc *)nullptr, d_blind_buf, C.d_tabB8, C.d_tabBb8, d_shift, Vb, Cb, (u32)d, (u32)dp); }
     uint8_t *hV = C.h_V.as<uint8_t>(na * dp * 32);
     HIPCHK(hipMemcpyAsync(hV, Vb, na * dp * 32, hipMemcpyDeviceToHost, C.stream2));
     HIPCHK(hipEventRecord(C.ev_v, C.stream2));
@@ -774,7 +774,7 @@ int rofl_create_rangeproof_l2(const float *values, size_t d, const uint8_t *blin
         HIPCHK(hipMemcpyAsync(vshift, &v, 8, hipMemcpyHostToDevice, C.stream));
         HIPCHK(hipMemcpyAsync(d_bl, &bsum, 32, hipMemcpyHostToDevice, C.stream));
         uint8_t *Vb = C.Vbytes.as<uint8_t>(32);
-        ROFL_LAUNCH(k_commit, grid1(1), dim3(TPB), 0, C.stream, 1u, vshift, (const sc *)nullptr, d_bl, C.d_tabB, C.d_tabBb, (const niels *)nullptr, Vb, (uint8_t *)nullptr, 0u, 1u);
+        ROFL_LAUNCH(k_commit, grid1(1), dim3(TPB), 0, C.stream, 1u, vshift, (const sc *)nullptr, d_bl, C.d_tabB8, C.d_tabBb8, (const niels *)nullptr, Vb, (uint8_t *)nullptr, 0u, 1u);
         uint8_t hV[32];
         HIPCHK(hipMemcpyAsync(hV, Vb, 32, hipMemcpyDeviceToHost, C.stream));
         C.sync();
@@ -916,11 +916,13 @@ int sigma_create(int kind, const float *values, size_t d, const uint8_t *r1, siz
         const size_t run_bytes = nn * d * 64, run_off = (size_t)nonce_base * 64;
         uint8_t *sb = C.stream_buf.as<uint8_t>(run_bytes + 64); C.up(sb, nonce->stream + run_off, run_bytes, C.stream);
         d_stream = reinterpret_cast<const uint8_t *>(reinterpret_cast<uintptr_t>(sb) - run_off); ss = nonce_base + nn * d; }
-    // algorithmic work per element: 7 fixed-base multiplications (64 mixed additions each), one variable-base one (~325 point operations),
-    // 2 * npts encodings; bytes as SURVEY 8(d): value + randomness in, commitments + proof out
-    { KSpan ks_sigma(C.tm, C.stream, ROFL_TK_SIGMA, (uint64_t)d * (7 * 64 * 7 + 325 * 8 + 2 * npts * 265), (uint64_t)d * (4 + 32 * (has_sq ? 2 : 1) + clen + plen));
-      static const bool split = !(knob("ROFL_SIGMA_SPLIT") && atoi(knob("ROFL_SIGMA_SPLIT")) == 0);
-      if (split) {      // one thread per point (blockIdx.y = slot; c_sq' -- the variable-base one -- as a launch of its own on the side stream), then transcripts + responses per element
+    // algorithmic work per element AS BUILT: fixed-base multiplications of 32 mixed additions (radix-256 tables) -- L, L' and c_sq, c_sq' two each,
+    // R, R' one each -- and 2 * npts encodings (the one-thread-per-element form: 7 multiplications of 64 additions + a variable-base one of
+    // ~325 point operations); bytes as SURVEY 8(d): value + randomness in, commitments + proof out
+    static const bool split = !(knob("ROFL_SIGMA_SPLIT") && atoi(knob("ROFL_SIGMA_SPLIT")) == 0);
+    const uint64_t sg_muls = split ? (uint64_t)(4 + (kind != 2 ? 2 : 0) + (has_sq ? 4 : 0)) * 32 * 7 + 2 * npts * 265 : (uint64_t)7 * 64 * 7 + 325 * 8 + 2 * npts * 265;
+    { KSpan ks_sigma(C.tm, C.stream, ROFL_TK_SIGMA, (uint64_t)d * sg_muls, (uint64_t)d * (4 + 32 * (has_sq ? 2 : 1) + clen + plen));
+      if (split) {      // one thread per point (blockIdx.y = slot), then transcripts + responses per element
           SgSlots sl{}; auto add = [&](int id) { sl.id[sl.n++] = id; };
           // c_sq' in its fixed-base form (SG_CSQP_F: the prover knows the opening of L); a commitment handed in is compared with m B + r1 Bb first
           // (SG_LCMP) and the elements where it differs -- none, unless the caller's commitments are not the values' -- are redone by
@@ -932,7 +934,7 @@ int sigma_create(int kind, const float *values, size_t d, const uint8_t *r1, siz
           add(SG_LP);
           if (kind != 2) { add(SG_R); add(SG_RP); }
           ROFL_LAUNCH(k_sigma_points, dim3((unsigned)((d + 63) / 64), (unsigned)sl.n), dim3(64), 0, C.stream, kind, sl, (u32)d, dv, fp_bits, fp_frac, dr1, dr2, dex,
-                      nonce->mode, seed, d_stream, ss, nonce_base, C.d_tabB, C.d_tabBb, dp, dc, status, marks);
+                      nonce->mode, seed, d_stream, ss, nonce_base, C.d_tabB8, C.d_tabBb8, dp, dc, status, marks);
           if (marks)
               ROFL_LAUNCH(k_sigma_point_var, dim3((unsigned)((d + 63) / 64)), dim3(64), 0, C.stream, kind, (u32)d, dv, fp_bits, fp_frac, dr1, dr2, dex,
                           nonce->mode, seed, d_stream, ss, nonce_base, C.d_tabB, C.d_tabBb, dp, dc, status, marks);
@@ -1158,7 +1160,7 @@ int compressed_create(const float *values, size_t d, const uint8_t *r32, size_t 
         C.up(dv, values, 4 * d, C.stream);
         C.up(dr, r32, 32 * d, C.stream);
         if (dex) C.up(dex, existing, 32 * d, C.stream);
-        ROFL_LAUNCH(k_eg_pairs, dim3((unsigned)((d + 63) / 64)), dim3(64), 0, C.stream, (u32)d, dv, fp_bits, fp_frac, dr, dex, C.d_tabB, C.d_tabBb, dpairs, status);
+        ROFL_LAUNCH(k_eg_pairs, dim3((unsigned)((d + 63) / 64)), dim3(64), 0, C.stream, (u32)d, dv, fp_bits, fp_frac, dr, dex, C.d_tabB8, C.d_tabBb8, dpairs, status);
         pairs_host = (const uint8_t *)C.down(pairs_out, dpairs, 64 * d, C.stream);
     }
     u32 st = 0;
@@ -1355,7 +1357,7 @@ int rofl_commit_vec(const uint8_t *values32, const uint8_t *blindings32, size_t 
         uint8_t *o = C.Cbytes.as<uint8_t>(d * 32);
         C.up(dv, values32, 32 * d, C.stream);
         if (db) C.up(db, blindings32, 32 * d, C.stream);
-        ROFL_LAUNCH(k_commit, grid1(d), dim3(TPB), 0, C.stream, (u32)d, (const u64 *)nullptr, dv, db, C.d_tabB, C.d_tabBb, (const niels *)nullptr, (uint8_t *)nullptr, o, (u32)d, (u32)d);
+        ROFL_LAUNCH(k_commit, grid1(d), dim3(TPB), 0, C.stream, (u32)d, (const u64 *)nullptr, dv, db, C.d_tabB8, C.d_tabBb8, (const niels *)nullptr, (uint8_t *)nullptr, o, (u32)d, (u32)d);
         C.down(out32, o, 32 * d, C.stream);
         C.sync();
         return ROFL_OK;

@@ -38,6 +38,30 @@ class _FullSizeOracle:
 
     def __init__(self):
         self._cache = {}
+        self._threads = {}
+
+    def prefetch(self, names=("cfg4", "cfg2")):
+        """Start the oracle's proofs on background threads (the C oracle releases the GIL and runs its chunks on OpenMP threads) so that they
+        are computed beside the first minutes of the GPU suite instead of in front of the tests that read them."""
+        import threading
+        import orc
+        os.environ.setdefault("OMP_NUM_THREADS", "4")
+        orc.lib()      # (tables of the oracle: initialised once, on this thread, before any other thread enters it -- oracle/orc_curve.c orc_init)
+        import numpy as np
+        orc.create_rangeproof(np.zeros(2, np.float32), np.zeros((2, 32), np.uint8), 8, 1, 16, 7, seed=b"\0" * 32)
+        for n in names:
+            if n not in self._cache and n not in self._threads:
+                t = threading.Thread(target=self._compute, args=(n,), daemon=True, name="oracle-" + n)
+                self._threads[n] = t
+                t.start()
+
+    def _compute(self, name):
+        import orc
+        os.environ.setdefault("OMP_NUM_THREADS", "4")
+        c = self.inputs(name)
+        rc, opr, ocm = orc.create_rangeproof(c["vals"], c["bl"], c["nb"], c["P"], c["fp"][0], c["fp"][1], seed=c["seed"])
+        c["rc"], c["opr"], c["ocm"] = rc, opr, ocm
+        self._cache[name] = c
 
     @staticmethod
     def inputs(name):
@@ -50,17 +74,25 @@ class _FullSizeOracle:
         return dict(vals=vals, bl=bl, seed=seed, nb=nb, P=P, fp=fp, d=d)
 
     def case(self, name):
+        t = self._threads.pop(name, None)
+        if t is not None:
+            t.join()
         if name not in self._cache:
-            import orc
-            os.environ.setdefault("OMP_NUM_THREADS", "4")
-            c = self.inputs(name)
-            rc, opr, ocm = orc.create_rangeproof(c["vals"], c["bl"], c["nb"], c["P"], c["fp"][0], c["fp"][1], seed=c["seed"])
-            assert rc == 0
-            c["opr"], c["ocm"] = opr, ocm
-            self._cache[name] = c
+            self._compute(name)
+        assert self._cache[name]["rc"] == 0
         return self._cache[name]
+
+
+_FULL_ORACLE = _FullSizeOracle()
+
+
+def pytest_collection_finish(session):
+    # a run that holds several of the full-size comparisons (the GPU suite) starts the oracle's proofs now, beside the first tests
+    users = [it for it in session.items if "full_oracle" in getattr(it, "fixturenames", ())]
+    if len(users) >= 3 and not session.config.option.collectonly:
+        _FULL_ORACLE.prefetch()
 
 
 @pytest.fixture(scope="session")
 def full_oracle():
-    return _FullSizeOracle()
+    return _FULL_ORACLE

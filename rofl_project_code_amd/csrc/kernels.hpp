@@ -2410,12 +2410,9 @@ enum { SG_L = 0, SG_LCHK = 1, SG_R = 2, SG_CSQ = 3, SG_LP = 4, SG_RP = 5, SG_CSQ
 struct SgSlots { int n; int id[6]; };
 // (two kernels: the slots that are fixed-base multiplications + one encoding, and c_sq' with its variable-base multiplication and its 1 KB
 //  table in scratch -- in one kernel every slot would be given the registers and the scratch of the largest)
-template <bool VAR> __device__ __forceinline__ void sigma_point_body(int kind, int slot, u32 d, const float *vals, u32 fp_bits, u32 fp_frac, const sc *r1c, const sc *r2c,
+template <bool VAR> __device__ __forceinline__ void sigma_point_elem(u32 i, int kind, int slot, u32 d, const float *vals, u32 fp_bits, u32 fp_frac, const sc *r1c, const sc *r2c,
                                                                     const uint8_t *existing, int mode, const NonceSeed &seed, const uint8_t *stream, u64 stream_scalars, u64 nonce_base,
                                                                     const niels *tabB, const niels *tabBb, uint8_t *proofs, uint8_t *commits, u32 *status, uint8_t *slow_mark) {
-    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= d) return;
-    if (VAR && slow_mark && !slow_mark[i]) return;      // (the fixed-base form of c_sq' stands: see SG_CSQP_F)
     bool has_R = kind != 2, has_sq = kind != 0;
     u32 npts = 1 + (has_R ? 1 : 0) + (has_sq ? 1 : 0), nn = has_sq ? 3 : 2, clen = 32 * npts, plen = 32 * (npts + nn), sq_off = has_R ? 64 : 32;
     float v = vals[i];
@@ -2452,8 +2449,21 @@ template <bool VAR> __device__ __forceinline__ void sigma_point_body(int kind, i
     if (slot == SG_LCMP) {
         uint8_t tmp[32]; sg_encode(tmp, P);
         bool same = true; for (int q = 0; q < 32; q++) same &= tmp[q] == existing[(size_t)32 * i + q];
-        if (!same) slow_mark[i] = 1;
-    } else sg_encode(out, P);
+        slow_mark[i] = same ? 0 : 1;                    // (every element's mark is written here: the buffer needs no clearing -- a NaN element, which
+    } else sg_encode(out, P);                           //  returns above, is skipped by k_sigma_point_var the same way whatever its mark holds)
+}
+// k_sigma_points: one thread per (element, slot).  k_sigma_point_var: a SMALL grid that walks the marks (an honest caller has none set: the launch
+// is a scan of d bytes that finds a place beside other calls' heavy launches at once, not d / 64 blocks queueing for workgroup slots)
+template <bool VAR> __device__ __forceinline__ void sigma_point_body(int kind, int slot, u32 d, const float *vals, u32 fp_bits, u32 fp_frac, const sc *r1c, const sc *r2c,
+                                                                    const uint8_t *existing, int mode, const NonceSeed &seed, const uint8_t *stream, u64 stream_scalars, u64 nonce_base,
+                                                                    const niels *tabB, const niels *tabBb, uint8_t *proofs, uint8_t *commits, u32 *status, uint8_t *slow_mark) {
+    if (!VAR) {
+        u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+        if (i < d) sigma_point_elem<false>(i, kind, slot, d, vals, fp_bits, fp_frac, r1c, r2c, existing, mode, seed, stream, stream_scalars, nonce_base, tabB, tabBb, proofs, commits, status, slow_mark);
+        return;
+    }
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < d; i += gridDim.x * blockDim.x)
+        if (!slow_mark || slow_mark[i]) sigma_point_elem<true>(i, kind, slot, d, vals, fp_bits, fp_frac, r1c, r2c, existing, mode, seed, stream, stream_scalars, nonce_base, tabB, tabBb, proofs, commits, status, slow_mark);
 }
 #if ROFL_KG(2)
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) k_sigma_points(int kind, SgSlots slots, u32 d, const float *vals, u32 fp_bits, u32 fp_frac, const sc *r1c, const sc *r2c,

@@ -928,7 +928,7 @@ int sigma_create(int kind, const float *values, size_t d, const uint8_t *r1, siz
           // (SG_LCMP) and the elements where it differs -- none, unless the caller's commitments are not the values' -- are redone by
           // k_sigma_point_var exactly as the reference computes them
           uint8_t *marks = nullptr;
-          if (has_sq && dex) { marks = C.vspart.as<uint8_t>(d); HIPCHK(hipMemsetAsync(marks, 0, d, C.stream)); }
+          if (has_sq && dex) marks = C.vspart.as<uint8_t>(d);      // (written for every element by the SG_LCMP slot: no clearing)
           if (!dex) add(SG_L); else add(has_sq ? SG_LCMP : SG_LCHK);
           if (has_sq) { add(SG_CSQP_F); add(SG_CSQ); }
           add(SG_LP);
@@ -936,7 +936,7 @@ int sigma_create(int kind, const float *values, size_t d, const uint8_t *r1, siz
           ROFL_LAUNCH(k_sigma_points, dim3((unsigned)((d + 63) / 64), (unsigned)sl.n), dim3(64), 0, C.stream, kind, sl, (u32)d, dv, fp_bits, fp_frac, dr1, dr2, dex,
                       nonce->mode, seed, d_stream, ss, nonce_base, C.d_tabB8, C.d_tabBb8, dp, dc, status, marks);
           if (marks)
-              ROFL_LAUNCH(k_sigma_point_var, dim3((unsigned)((d + 63) / 64)), dim3(64), 0, C.stream, kind, (u32)d, dv, fp_bits, fp_frac, dr1, dr2, dex,
+              ROFL_LAUNCH(k_sigma_point_var, dim3((unsigned)std::min<size_t>((d + 63) / 64, 256)), dim3(64), 0, C.stream, kind, (u32)d, dv, fp_bits, fp_frac, dr1, dr2, dex,      // (walks the marks: one block per CU at most)
                           nonce->mode, seed, d_stream, ss, nonce_base, C.d_tabB, C.d_tabBb, dp, dc, status, marks);
           ROFL_LAUNCH(k_sigma_finish, grid1(d), dim3(TPB), 0, C.stream, kind, (u32)d, dv, fp_bits, fp_frac, dr1, dr2, dex, nonce->mode, seed, d_stream, ss, nonce_base,
                       sigma_init_state(kind), dp, dc, status);

@@ -660,7 +660,7 @@ struct Ctx {
         HIPCHK(hipMalloc(&d_tabBb8, sizeof(niels) * 4096));
         ROFL_LAUNCH(k_fixed_tab8, dim3(64), dim3(64), 0, 0, (const niels *)d_tabB, d_tabB8);
         ROFL_LAUNCH(k_fixed_tab8, dim3(64), dim3(64), 0, 0, (const niels *)d_tabBb, d_tabBb8);
-        HIPCHK(hipDeviceSynchronize());
+        HIPCHK(hipStreamSynchronize(nullptr));      // (the null stream only: another context's lanes on this device -- non-blocking streams -- are not waited for)
         sc tp[64]; sc two = h_mont(sc_from_u64(2)); tp[0] = sc_one_mont();
         for (int i = 1; i < 64; i++) tp[i] = sc_montmul(tp[i - 1], two);
         HIPCHK(hipMalloc(&d_two_pow, sizeof(tp)));
